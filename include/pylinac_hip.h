@@ -1,0 +1,147 @@
+/*
+ * pylinac_hip.h -- C ABI of libpylinac_hip.so, the MI355X (gfx950) image-QA compute core.
+ *
+ * The reference (jrkerns/pylinac v3.46.0) has NO native/FFI boundary: its hot path is numpy glue
+ * over scipy.ndimage / scipy.signal / skimage calls.  This header therefore
+ * declares the entry points a binding for that path would need, one per third-party call the
+ * reference makes; each cites the reference call site it replaces.
+ *
+ * Conventions
+ *   - Batched, stateless, stream-ordered.  All pointers are DEVICE pointers unless the name says
+ *     "host".  Frames are [n][h][w] row-major and densely packed.  Nothing is allocated inside;
+ *     the caller owns every buffer (PyTorch tensors in the Python host layer).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - Return value: pl_status (0 = PL_OK).  pl_last_error() gives a thread-local message.
+ *   - Floating-point device code is compiled with -ffp-contract=off: every kernel reproduces the
+ *     reference's float64 operation ORDER, so integer outputs are bit-exact and float outputs are
+ *     bit-exact wherever the reference's own order is defined.
+ */
+#ifndef PYLINAC_HIP_H
+#define PYLINAC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PL_ABI_VERSION 1
+
+typedef enum pl_status {
+  PL_OK = 0,
+  PL_ERR_INVALID_ARG = 1,
+  PL_ERR_UNSUPPORTED = 2,
+  PL_ERR_HIP = 3
+} pl_status;
+
+typedef enum pl_dtype {
+  PL_U16 = 0,
+  PL_I16 = 1,
+  PL_F32 = 2,
+  PL_F64 = 3,
+  PL_U8 = 4
+} pl_dtype;
+
+typedef enum pl_reduce_op { PL_SUM = 0, PL_MEAN = 1, PL_MAX = 2, PL_MIN = 3 } pl_reduce_op;
+
+/* peak_props keys pylinac sorts by: pylinac/core/profile.py:2616-2618 */
+typedef enum pl_peak_sort { PL_SORT_PROMINENCES = 0, PL_SORT_PEAK_HEIGHTS = 1, PL_SORT_WIDTHS = 2 } pl_peak_sort;
+
+int pl_abi_version(void);
+const char* pl_status_string(int status);
+const char* pl_last_error(void);
+/* 1 when a HIP device is usable from this process */
+int pl_device_available(void);
+
+/* ---- a2: ndimage.gaussian_filter (pylinac/core/array_utils.py:133) ------------------------------
+ * One correlate1d pass along `axis` (0 = rows/vertical, 1 = columns/horizontal) of every frame,
+ * mode='reflect', scipy's symmetric summation order in float64, result cast into `dtype`
+ * (truncation toward zero for integer dtypes).  d_weights = 2*radius+1 float64 taps on the device
+ * (scipy's _gaussian_kernel1d; the host layer computes them).  in != out. */
+int pl_gaussian1d(const void* in, void* out, int dtype, int64_t n, int h, int w, int axis,
+                  const double* d_weights, int radius, void* stream);
+/* axis 0 into tmp, then axis 1 into out: ndimage.gaussian_filter on a 2-D frame. */
+int pl_gaussian2d(const void* in, void* out, void* tmp, int dtype, int64_t n, int h, int w,
+                  const double* d_weights, int radius, void* stream);
+
+/* ---- a1: ndimage.median_filter(size=s) (pylinac/core/array_utils.py:131) ------------------------
+ * s x s window (h > 1) or length-s window (h == 1), mode='reflect', origin 0, rank (s*s)/2. */
+int pl_median2d(const void* in, void* out, int dtype, int64_t n, int h, int w, int size,
+                void* stream);
+
+/* ---- a5: min/max reductions + ground/normalize/invert (pylinac/core/array_utils.py:63-102) ----- */
+int pl_minmax(const void* in, int dtype, int64_t n, int64_t count, double* d_min, double* d_max,
+              void* stream);
+/* out = a - d_min[i] + value           (same dtype)   array_utils.py:102 */
+int pl_ground(const void* in, void* out, int dtype, int64_t n, int64_t count, const double* d_min,
+              double value, void* stream);
+/* out(f64) = a / d_val[i]                              array_utils.py:70 */
+int pl_normalize(const void* in, double* out, int dtype, int64_t n, int64_t count,
+                 const double* d_val, void* stream);
+/* out = -a + d_max[i] + d_min[i]       (same dtype)   array_utils.py:77 */
+int pl_invert(const void* in, void* out, int dtype, int64_t n, int64_t count, const double* d_min,
+              const double* d_max, void* stream);
+
+/* ---- a3: BaseImage.threshold / as_binary (pylinac/core/image.py:785-815) ------------------------
+ * kind 0 ('high'): out = a >= t ? a : 0 ; kind 1 ('low'): out = a <= t ? a : 0.
+ * d_thr holds one float64 threshold per frame (thr_stride 1) or one for all (thr_stride 0). */
+int pl_threshold(const void* in, void* out, int dtype, int64_t n, int64_t count,
+                 const double* d_thr, int thr_stride, int kind, void* stream);
+/* out(u8) = a >= t */
+int pl_as_binary(const void* in, uint8_t* out, int dtype, int64_t n, int64_t count,
+                 const double* d_thr, int thr_stride, void* stream);
+
+/* ---- a4/a6: per-frame integer histogram, Otsu, order statistics ---------------------------------
+ * hist: uint32 [n][65536]; bin b counts value b (PL_U16) or value b-32768 (PL_I16).  Every bin
+ * is written (no zero-fill needed). */
+int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, void* stream);
+/* skimage.filters.threshold_otsu on an integer image (pylinac/ct.py:3323,3338; acr.py:1409):
+ * one bin per integer in [min,max], float64 class statistics, first argmax.  Outputs int32[n]. */
+int pl_otsu_from_hist(const uint32_t* d_hist, int dtype, int64_t n, int32_t* d_thr,
+                      int32_t* d_min, int32_t* d_max, void* stream);
+/* exact order statistics: out[i][k] = value with 0-based rank d_ranks[k] in frame i
+ * (np.percentile call sites: pylinac/core/image.py:899-926, picketfence.py:229-238). */
+int pl_order_stats_from_hist(const uint32_t* d_hist, int dtype, int64_t n, const int64_t* d_ranks,
+                             int nranks, int32_t* d_out, void* stream);
+
+/* ---- a7: profile extraction, np.mean/np.sum/np.max/np.min(image, axis) --------------------------
+ * (pylinac/picketfence.py:747-750, 1513-1514; starshot.py:216-217).  axis 0 -> out[n][w],
+ * axis 1 -> out[n][h]; float64 output; integer inputs are summed exactly. */
+int pl_reduce_axis(const void* in, int dtype, int64_t n, int h, int w, int axis, int op,
+                   double* d_out, void* stream);
+
+/* threshold + axis-0 integer column sums in one pass over a u16 frame (pipeline fusion of
+ * image.py:797-800 and picketfence.py:747-750).  d_colsum: uint64 [n][w], zeroed inside. */
+int pl_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_t n, int h, int w,
+                            const int32_t* d_thr, unsigned long long* d_colsum, void* stream);
+
+/* ---- a8-a10: pylinac.core.profile.find_peaks over scipy.signal.find_peaks -----------------------
+ * (pylinac/core/profile.py:2545-2649).  One 1-D float64 profile per batch item. */
+typedef struct pl_peak_params {
+  double threshold;       /* `threshold` argument                                             */
+  int threshold_is_ratio; /* 1: height = min + threshold*(max-min) over the FULL profile       */
+  int distance;           /* scipy `distance` (>= 1), already ceil'ed                          */
+  int has_prominence;     /* `required_prominence is not None`                                 */
+  double prominence_min;
+  double width_min;       /* `min_width` (pylinac passes 0)                                    */
+  double rel_height;      /* 1 - fwxm_height                                                   */
+  int region_lo;          /* search region [lo, hi) in samples; idx are reported un-trimmed     */
+  int region_hi;
+  int max_number;         /* <= 0: keep all                                                    */
+  int sort_key;           /* pl_peak_sort                                                      */
+} pl_peak_params;
+
+/* d_x: float64 [n][len] (row stride = stride elements).  Outputs (capacity `cap` per profile):
+ *   d_count int32[n]; d_idx,d_left_base,d_right_base int32[n][cap];
+ *   d_props float64[n][6][cap] = heights, prominences, widths, width_heights, left_ips, right_ips
+ *   d_status int32[n]: 0 ok, 1 = more than `cap` peaks (truncated).
+ * left_ips/right_ips are relative to the trimmed region, exactly like the reference
+ * (pylinac/core/profile.py:2613 shifts only the indices). */
+int pl_find_peaks(const double* d_x, int64_t n, int len, int64_t stride, const pl_peak_params* params,
+                  int cap, int32_t* d_count, int32_t* d_idx, int32_t* d_left_base,
+                  int32_t* d_right_base, double* d_props, int32_t* d_status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYLINAC_HIP_H */

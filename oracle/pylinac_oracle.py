@@ -1,0 +1,523 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the pylinac image-QA hot path.
+
+This file is *not* part of the product.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it, and only as the checker.
+
+It restates, in numpy, the glue that pylinac wraps around scipy / scikit-image for the hot
+path of SURVEY.md section 8, each function citing the reference file:line it follows.
+The arithmetic itself lives in third-party native code that is not under /root/reference:
+
+  * scipy  (pin in the reference: ``scipy>=1.11.0``, pyproject.toml:30-47; container 1.15.3)
+    ``ndimage.gaussian_filter / median_filter`` and ``signal.find_peaks``,
+  * scikit-image (``>=0.18``; container: 0.18.3 under /opt/conda/bin/python3.9 only)
+    ``filters.threshold_otsu``.
+
+For those two levels this file holds
+
+  (1) the *glue* functions (``filter``, ``threshold``, ``find_peaks`` ...) that call the real
+      scipy exactly as the reference does (scipy is present on the GPU box), and
+  (2) independent restatements of the published third-party algorithms
+      (``gaussian_filter_restated``, ``median_filter_restated``, ``scipy_find_peaks_restated``,
+      ``threshold_otsu``) that spell out the exact summation order / tie rules the HIP kernels
+      implement.  (2) is pinned against (1) and against golden vectors produced by the
+      reference's own code (tests/golden/make_golden.py, tests/test_oracle_golden.py).
+
+Parity status: pinned (reference KATs of SURVEY.md section 8c + golden vectors generated
+by importing the reference through oracle/ref_loader.py).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+from scipy import ndimage, signal
+
+# --------------------------------------------------------------------------------------
+# a1/a2  filtering  (pylinac/core/array_utils.py:105-138, pylinac/core/image.py:695-712)
+# --------------------------------------------------------------------------------------
+
+
+def resolve_filter_size(array: np.ndarray, size):
+    """Float size in (0,1) -> int(round(len(array)*size)) clamped to >= 1.
+    ``len(array)`` is the ROW count for a 2-D array.  pylinac/core/array_utils.py:124-129."""
+    if isinstance(size, float):
+        if 0 < size < 1:
+            size = int(round(len(array) * size))
+            size = max(size, 1)
+        else:
+            raise ValueError("Float was passed but was not between 0 and 1")
+    return size
+
+
+def filter(array: np.ndarray, size=0.05, kind: str = "median") -> np.ndarray:
+    """pylinac/core/array_utils.py:105-138 (the body behind ``BaseImage.filter``)."""
+    if not array.size:
+        raise ValueError("Array must not be empty")  # array_utils.py:23-26
+    size = resolve_filter_size(array, size)
+    if kind == "median":
+        return ndimage.median_filter(array, size=size)  # array_utils.py:131
+    elif kind == "gaussian":
+        return ndimage.gaussian_filter(array, sigma=size)  # array_utils.py:133
+    raise ValueError(f"Filter type {kind} unsupported. Use one of 'median', 'gaussian'")
+
+
+def gaussian_kernel1d(sigma: float, truncate: float = 4.0):
+    """scipy/ndimage/_filters.py ``_gaussian_kernel1d`` + ``gaussian_filter1d`` (order 0):
+    radius ``int(truncate*sigma+0.5)``, ``exp(-0.5/sigma^2 * x^2)`` normalised by its sum.
+    Returns (weights[2*radius+1], radius).  The kernel is exactly symmetric."""
+    sd = float(sigma)
+    lw = int(truncate * sd + 0.5)
+    sigma2 = sd * sd
+    x = np.arange(-lw, lw + 1)
+    phi = np.exp(-0.5 / sigma2 * x**2)
+    phi = phi / phi.sum()
+    return phi[::-1].copy(), lw
+
+
+def reflect_index(i, n: int):
+    """scipy 'reflect' (half-sample symmetric, ``d c b a | a b c d | d c b a``), any distance."""
+    i = np.asarray(i)
+    p = 2 * n
+    m = np.mod(i, p)
+    return np.where(m >= n, p - 1 - m, m)
+
+
+def _correlate1d_symmetric(a: np.ndarray, w: np.ndarray, lw: int, axis: int) -> np.ndarray:
+    """scipy ``NI_Correlate1D`` symmetric branch (ni_filters.c), float64 accumulator:
+         acc  = x[0]*w[0]
+         acc += (x[-j] + x[+j]) * w[-j]     for j = radius .. 1   (outermost tap first)
+    no FMA contraction.  Returns float64 (caller casts into the output dtype)."""
+    n = a.shape[axis]
+    x = np.moveaxis(a.astype(np.float64), axis, -1)
+    idx = reflect_index(np.arange(-lw, n + lw), n)
+    x = x[..., idx]
+    c = lw
+    acc = x[..., c : c + n] * w[lw]
+    for j in range(lw, 0, -1):
+        acc = acc + (x[..., c - j : c - j + n] + x[..., c + j : c + j + n]) * w[lw - j]
+    return np.moveaxis(acc, -1, axis)
+
+
+def cast_like_scipy(acc: np.ndarray, dtype) -> np.ndarray:
+    """scipy copies the double line buffer into the output array with a C cast
+    (ni_support.c CASE_COPY_LINE_TO_DATA): truncation toward zero for integer dtypes,
+    round-to-nearest for float32."""
+    dtype = np.dtype(dtype)
+    if dtype.kind in "ui":
+        return np.trunc(acc).astype(dtype)
+    return acc.astype(dtype)
+
+
+def gaussian_filter_restated(a: np.ndarray, sigma: float) -> np.ndarray:
+    """``ndimage.gaussian_filter(a, sigma)`` as pylinac calls it (array_utils.py:133):
+    axis 0 first, then axis 1 ...; the *output of each pass has the input dtype* and feeds the
+    next pass."""
+    w, lw = gaussian_kernel1d(sigma)
+    out = a
+    for axis in range(a.ndim):
+        out = cast_like_scipy(_correlate1d_symmetric(out, w, lw, axis), a.dtype)
+    return out
+
+
+def median_filter_restated(a: np.ndarray, size: int) -> np.ndarray:
+    """``ndimage.median_filter(a, size=s)``: s^ndim window, mode='reflect', origin 0 (window
+    starts at ``i - s//2``), rank ``s^ndim // 2``."""
+    s = int(size)
+    lo = s // 2
+    if a.ndim == 1:
+        n = a.shape[0]
+        idx = reflect_index(np.arange(n)[:, None] - lo + np.arange(s)[None, :], n)
+        win = a[idx]
+        return np.sort(win, axis=-1)[..., (s) // 2]
+    h, w = a.shape
+    ri = reflect_index(np.arange(h)[:, None] - lo + np.arange(s)[None, :], h)  # [h, s]
+    ci = reflect_index(np.arange(w)[:, None] - lo + np.arange(s)[None, :], w)  # [w, s]
+    win = a[ri[:, None, :, None], ci[None, :, None, :]].reshape(h, w, s * s)
+    return np.sort(win, axis=-1)[..., (s * s) // 2]
+
+
+# --------------------------------------------------------------------------------------
+# a3  threshold / as_binary   (pylinac/core/image.py:785-815)
+# --------------------------------------------------------------------------------------
+
+
+def threshold(array: np.ndarray, threshold, kind: str = "high") -> np.ndarray:
+    """``np.where(a >= t, a, 0)`` ('high') / ``np.where(a <= t, a, 0)``; image.py:797-800."""
+    if kind == "high":
+        return np.where(array >= threshold, array, 0)
+    return np.where(array <= threshold, array, 0)
+
+
+def as_binary(array: np.ndarray, threshold) -> np.ndarray:
+    """image.py:802-815 -> int64 0/1 array."""
+    return np.where(array >= threshold, 1, 0)
+
+
+# --------------------------------------------------------------------------------------
+# a5  ground / normalize / invert / stretch  (pylinac/core/array_utils.py:63-102, 141-168)
+# --------------------------------------------------------------------------------------
+
+
+def ground(array, value=0):
+    return array - array.min() + value  # array_utils.py:102
+
+
+def normalize(array, value=None):
+    val = array.max() if value is None else value  # array_utils.py:66-71
+    return array / val
+
+
+def invert(array):
+    return -array + array.max() + array.min()  # array_utils.py:77
+
+
+def stretch(array, min=0, max=1):
+    if max <= min:
+        raise ValueError(f"Max must be larger than min. Passed max of {max} was <= {min}")
+    return ground(normalize(ground(array)) * (max - min), value=min)  # array_utils.py:168
+
+
+# --------------------------------------------------------------------------------------
+# a4  Otsu  (skimage 0.18.3 filters/thresholding.py threshold_otsu + exposure.histogram;
+#            call sites pylinac/ct.py:3323,3338-3340, pylinac/acr.py:1409)
+# --------------------------------------------------------------------------------------
+
+
+def histogram_like_skimage(image: np.ndarray, nbins: int = 256):
+    """skimage.exposure.histogram(source_range='image'): integer image -> one bin per integer
+    value in [min, max] (``_bincount_histogram``); float image -> ``np.histogram(bins=nbins)``
+    with bin centres."""
+    flat = image.ravel()
+    if np.issubdtype(flat.dtype, np.integer):
+        imin = int(flat.min())
+        imax = int(flat.max())
+        counts = np.bincount((flat.astype(np.int64) - imin), minlength=imax - imin + 1)
+        centers = np.arange(imin, imax + 1)
+        return counts, centers
+    counts, edges = np.histogram(flat, bins=nbins, range=None)
+    return counts, (edges[:-1] + edges[1:]) / 2.0
+
+
+def threshold_otsu(image: np.ndarray, nbins: int = 256):
+    """skimage 0.18.3 ``threshold_otsu``: constant image -> that value; otherwise argmax (first)
+    of ``w1[:-1]*w2[1:]*(m1[:-1]-m2[1:])**2`` with float64 cumulative sums; returns the bin
+    centre."""
+    first = image.ravel()[0]
+    if np.all(image == first):
+        return first
+    counts, centers = histogram_like_skimage(image, nbins)
+    counts = counts.astype(float)
+    weight1 = np.cumsum(counts)
+    weight2 = np.cumsum(counts[::-1])[::-1]
+    mean1 = np.cumsum(counts * centers) / weight1
+    mean2 = (np.cumsum((counts * centers)[::-1]) / weight2[::-1])[::-1]
+    variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:]) ** 2
+    idx = np.argmax(variance12)
+    return centers[idx]
+
+
+# --------------------------------------------------------------------------------------
+# a6  percentiles  (np.percentile default 'linear'; call sites pylinac/core/image.py:899-926,
+#                   pylinac/picketfence.py:229-238, pylinac/winston_lutz.py:775,1109-1133)
+# --------------------------------------------------------------------------------------
+
+
+def percentile(array: np.ndarray, q):
+    return np.percentile(array, q)
+
+
+def percentile_from_order_stats(lo_val, hi_val, frac):
+    """numpy ``_lerp`` (lib/_function_base_impl.py): a + (b-a)*t, and b - (b-a)*(1-t) for
+    t >= 0.5; used to rebuild np.percentile from two exact order statistics."""
+    a = np.float64(lo_val)
+    b = np.float64(hi_val)
+    t = np.float64(frac)
+    d = b - a
+    r = a + d * t
+    if t >= 0.5:
+        r = b - d * (1 - t)
+    if d == 0:
+        r = a
+    return r
+
+
+# --------------------------------------------------------------------------------------
+# a7  profile extraction  (no Image.profile() in the reference; pylinac/picketfence.py:747-750)
+# --------------------------------------------------------------------------------------
+
+
+def profile(array: np.ndarray, axis: int = 0, kind: str = "mean") -> np.ndarray:
+    """``np.mean(image, axis)`` (picketfence.py:747-750), ``np.max(central, axis)``
+    (starshot.py:216-217), ``np.sum(array, axis)`` (picketfence.py:1513-1514)."""
+    if kind == "mean":
+        return np.mean(array, axis=axis)
+    if kind == "max":
+        return np.max(array, axis=axis)
+    if kind == "sum":
+        return np.sum(array, axis=axis)
+    if kind == "median":
+        return np.median(array, axis=axis)
+    raise ValueError(kind)
+
+
+# --------------------------------------------------------------------------------------
+# a8  find_peaks  (pylinac/core/profile.py:2545-2649 over scipy.signal.find_peaks)
+# --------------------------------------------------------------------------------------
+
+
+def parse_peak_args(peak_separation, search_region, threshold, values):
+    """pylinac/core/profile.py:2626-2649 (note: int 0/1 also count as ratios)."""
+    val_range = values.max() - values.min()
+    if 0 <= threshold <= 1:
+        threshold = values.min() + threshold * val_range
+    if 0 <= peak_separation <= 1:
+        peak_separation = max(int(peak_separation * len(values)), 1)
+    if max(search_region) <= 1:
+        shift_amount = int(search_region[0] * len(values))
+        values = values[
+            int(search_region[0] * len(values)) : int(search_region[1] * len(values))
+        ]
+    else:
+        values = values[search_region[0] : search_region[1]]
+        shift_amount = search_region[0]
+    return peak_separation, shift_amount, threshold, values
+
+
+def find_peaks(
+    values,
+    threshold=-np.inf,
+    peak_separation=0,
+    max_number=None,
+    fwxm_height: float = 0.5,
+    min_width: int = 0,
+    search_region=(0.0, 1.0),
+    peak_sort: str = "prominences",
+    required_prominence=None,
+    impl: str = "scipy",
+):
+    """pylinac/core/profile.py:2545-2623.  Only ``peak_idxs`` are shifted by the search-region
+    offset (``left_ips``/``right_ips`` are not, profile.py:2613).  ``impl='restated'`` swaps
+    scipy.signal.find_peaks for the pure-python restatement below."""
+    values = np.asarray(values)
+    peak_separation, shift_amount, threshold, trimmed = parse_peak_args(
+        peak_separation, search_region, threshold, values
+    )
+    fp = signal.find_peaks if impl == "scipy" else scipy_find_peaks_restated
+    peak_idxs, peak_props = fp(
+        trimmed,
+        rel_height=(1 - fwxm_height),
+        width=min_width,
+        height=threshold,
+        distance=peak_separation,
+        prominence=required_prominence,
+    )
+    peak_idxs = peak_idxs + shift_amount
+    # Tie order of np.argsort(default quicksort) is implementation-defined;
+    # the build pins it to 'stable' (== numpy's insertion sort for <=16 elements).
+    order = list(np.argsort(peak_props[peak_sort], kind="stable"))[::-1][:max_number]
+    largest = sorted(order)
+    for key, vals in list(peak_props.items()):
+        peak_props[key] = vals[largest]
+    return peak_idxs[largest], peak_props
+
+
+def scipy_find_peaks_restated(
+    x, height=None, distance=None, prominence=None, width=None, rel_height=0.5
+):
+    """Pure-python restatement of scipy.signal.find_peaks (scipy/signal/_peak_finding.py and
+    _peak_finding_utils.pyx) for the argument set pylinac uses.
+    ``height``/``prominence``/``width`` are scalar minima (or None)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    # -- _local_maxima_1d: strict rise, plateau -> midpoint, strict fall; ends never peaks
+    peaks = []
+    i = 1
+    i_max = n - 1
+    while i < i_max:
+        if x[i - 1] < x[i]:
+            i_ahead = i + 1
+            while i_ahead < i_max and x[i_ahead] == x[i]:
+                i_ahead += 1
+            if x[i_ahead] < x[i]:
+                peaks.append((i + i_ahead - 1) // 2)
+                i = i_ahead
+        i += 1
+    peaks = np.array(peaks, dtype=np.intp)
+    props = {}
+    if height is not None:
+        ph = x[peaks]
+        keep = ph >= height
+        peaks = peaks[keep]
+        props["peak_heights"] = ph[keep]
+    if distance is not None:
+        # _select_by_peak_distance: highest first; ties -> stable argsort order
+        d = math.ceil(distance)
+        keep = np.ones(peaks.size, dtype=bool)
+        order = np.argsort(x[peaks], kind="stable")
+        for i in range(peaks.size - 1, -1, -1):
+            j = order[i]
+            if not keep[j]:
+                continue
+            k = j - 1
+            while k >= 0 and peaks[j] - peaks[k] < d:
+                keep[k] = False
+                k -= 1
+            k = j + 1
+            while k < peaks.size and peaks[k] - peaks[j] < d:
+                keep[k] = False
+                k += 1
+        peaks = peaks[keep]
+        props = {k_: v[keep] for k_, v in props.items()}
+    if prominence is not None or width is not None:
+        prom = np.empty(peaks.size)
+        lb = np.empty(peaks.size, dtype=np.intp)
+        rb = np.empty(peaks.size, dtype=np.intp)
+        for p, pk in enumerate(peaks):
+            i = lb[p] = pk
+            left_min = x[pk]
+            while 0 <= i and x[i] <= x[pk]:
+                if x[i] < left_min:
+                    left_min = x[i]
+                    lb[p] = i
+                i -= 1
+            i = rb[p] = pk
+            right_min = x[pk]
+            while i <= n - 1 and x[i] <= x[pk]:
+                if x[i] < right_min:
+                    right_min = x[i]
+                    rb[p] = i
+                i += 1
+            prom[p] = x[pk] - max(left_min, right_min)
+        props.update(prominences=prom, left_bases=lb, right_bases=rb)
+    if prominence is not None:
+        keep = props["prominences"] >= prominence
+        peaks = peaks[keep]
+        props = {k_: v[keep] for k_, v in props.items()}
+    if width is not None:
+        widths = np.empty(peaks.size)
+        wh = np.empty(peaks.size)
+        lips = np.empty(peaks.size)
+        rips = np.empty(peaks.size)
+        for p, pk in enumerate(peaks):
+            i_min = props["left_bases"][p]
+            i_max2 = props["right_bases"][p]
+            h = wh[p] = x[pk] - props["prominences"][p] * rel_height
+            i = pk
+            while i_min < i and h < x[i]:
+                i -= 1
+            lip = float(i)
+            if x[i] < h:
+                lip += (h - x[i]) / (x[i + 1] - x[i])
+            i = pk
+            while i < i_max2 and h < x[i]:
+                i += 1
+            rip = float(i)
+            if x[i] < h:
+                rip -= (h - x[i]) / (x[i - 1] - x[i])
+            widths[p] = rip - lip
+            lips[p] = lip
+            rips[p] = rip
+        keep = widths >= width
+        props.update(widths=widths, width_heights=wh, left_ips=lips, right_ips=rips)
+        peaks = peaks[keep]
+        props = {k_: v[keep] for k_, v in props.items()}
+    return peaks, props
+
+
+# --------------------------------------------------------------------------------------
+# a9/a10  MultiProfile / FWXMProfile  (pylinac/core/profile.py:2050-2176, 578-611, 322-344)
+# --------------------------------------------------------------------------------------
+
+
+def multiprofile_find_peaks(values, threshold=0.3, min_distance=0.05, max_number=None,
+                            search_region=(0.0, 1.0), peak_sort="prominences", impl="scipy"):
+    """MultiProfile.find_peaks, profile.py:2050-2103 -> (idx, heights)."""
+    idx, props = find_peaks(values, threshold=threshold, peak_separation=min_distance,
+                            max_number=max_number, search_region=search_region,
+                            peak_sort=peak_sort, impl=impl)
+    return idx, props["peak_heights"]
+
+
+def multiprofile_find_valleys(values, threshold=0.3, min_distance=0.05, max_number=None,
+                              search_region=(0.0, 1.0), impl="scipy"):
+    """MultiProfile.find_valleys, profile.py:2105-2133: peaks of ``-values``."""
+    values = np.asarray(values)
+    idx, _ = find_peaks(-values, threshold=threshold, peak_separation=min_distance,
+                        max_number=max_number, search_region=search_region, impl=impl)
+    return idx, values[idx]
+
+
+def multiprofile_find_fwxm_peaks(values, threshold=0.3, min_distance=0.05, max_number=None,
+                                 search_region=(0.0, 1.0), peak_sort="prominences",
+                                 required_prominence=None, impl="scipy"):
+    """MultiProfile.find_fwxm_peaks, profile.py:2135-2176: ``int(round(lt + (rt-lt)/2))``
+    (python banker's rounding) and the value at that index."""
+    values = np.asarray(values)
+    _, props = find_peaks(values, threshold=threshold, peak_separation=min_distance,
+                          max_number=max_number, search_region=search_region,
+                          peak_sort=peak_sort, required_prominence=required_prominence,
+                          impl=impl)
+    idxs = [int(round(lt + (rt - lt) / 2)) for lt, rt in zip(props["left_ips"], props["right_ips"])]
+    return np.array(idxs), np.array([values[i] for i in idxs])
+
+
+def fwxm_edges(values, fwxm_height: float = 50, impl="scipy"):
+    """FWXMProfile.field_edge_idx / center_idx / field_width_px with default x-values
+    (profile.py:602-611, 322-327, 339-344).  ``x_at_x_idx`` over ``arange(len)`` with a k=1,s=0
+    spline is the identity.  Raises IndexError when no peak exists,
+    like the reference (profile.py:608)."""
+    _, props = find_peaks(values, fwxm_height=fwxm_height / 100, max_number=1, impl=impl)
+    left = float(props["left_ips"][0])
+    right = float(props["right_ips"][0])
+    center = abs(right - left) / 2 + left
+    width = max(right, left) - min(right, left)
+    return left, right, center, width
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE config #2 + profile/peak: the pipeline bench.py measures
+# --------------------------------------------------------------------------------------
+
+EPID_RECORD_FIELDS = (
+    "otsu_threshold", "n_peaks", "peak_idx", "peak_height", "prominence",
+    "left_edge", "right_edge", "center", "width",
+)
+
+
+def epid_pipeline_frame(frame: np.ndarray, sigma=5, median_size=3, fwxm_height=50):
+    """filter(5,'gaussian') -> filter(3,'median') -> Otsu -> threshold(t,'high') ->
+    np.mean(axis=0) profile -> FWXM peak (SURVEY.md section 8d config #2 + a7/a8/a10).
+    Returns (thresholded u16 frame, profile f64[W], record f64[9])."""
+    g = filter(frame, sigma, "gaussian")
+    m = filter(g, median_size, "median")
+    t = threshold_otsu(m)
+    th = threshold(m, t, "high").astype(frame.dtype)
+    prof = np.mean(th, axis=0)
+    rec = np.full(len(EPID_RECORD_FIELDS), np.nan)
+    rec[0] = float(t)
+    try:
+        idx, props = find_peaks(prof, fwxm_height=fwxm_height / 100, max_number=1)
+    except (IndexError, ValueError):
+        idx, props = np.array([], dtype=int), None
+    rec[1] = float(len(idx))
+    if len(idx):
+        left = float(props["left_ips"][0])
+        right = float(props["right_ips"][0])
+        rec[2] = float(idx[0])
+        rec[3] = float(props["peak_heights"][0])
+        rec[4] = float(props["prominences"][0])
+        rec[5] = left
+        rec[6] = right
+        rec[7] = abs(right - left) / 2 + left
+        rec[8] = max(right, left) - min(right, left)
+    return th, prof, rec
+
+
+def epid_pipeline(frames: np.ndarray, **kw):
+    outs, profs, recs = [], [], []
+    for f in frames:
+        th, prof, rec = epid_pipeline_frame(f, **kw)
+        outs.append(th)
+        profs.append(prof)
+        recs.append(rec)
+    return np.stack(outs), np.stack(profs), np.stack(recs)

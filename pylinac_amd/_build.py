@@ -1,0 +1,83 @@
+"""Builds libpylinac_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+``python -m pylinac_amd._build`` or ``__graft_entry__.build()``.  One object per .hip file,
+compiled in parallel, linked into ``pylinac_amd/libpylinac_hip.so`` (git-ignored, but shipped to
+the GPU box by gpurun).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+BUILD = PKG.parent / "build" / "hip"
+LIB = PKG / "libpylinac_hip.so"
+
+# -ffp-contract=off is part of the CONTRACT, not a tuning flag: the kernels reproduce scipy's
+# float64 operation order, an FMA contraction changes results ("exactness").
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-ffp-contract=off",
+    "-fno-fast-math",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC=...)")
+
+
+def sources() -> list[Path]:
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _stale(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    cc = hipcc()
+    BUILD.mkdir(parents=True, exist_ok=True)
+    headers = list(CSRC.glob("*.h")) + [PKG.parent / "include" / "pylinac_hip.h", Path(__file__)]
+    jobs = []
+    objs = []
+    for src in sources():
+        obj = BUILD / (src.stem + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append([cc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        return r
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)])
+    return LIB
+
+
+if __name__ == "__main__":
+    lib = build(force="--force" in sys.argv, verbose=True)
+    print(lib)

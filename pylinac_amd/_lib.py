@@ -1,0 +1,105 @@
+"""ctypes binding of libpylinac_hip.so (the C ABI declared in include/pylinac_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, the product
+raises.  A CPU path would silently void every parity/performance claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "libpylinac_hip.so"
+_lib = None
+
+
+class PylinacHipError(RuntimeError):
+    pass
+
+
+class PeakParams(C.Structure):
+    """struct pl_peak_params (include/pylinac_hip.h)."""
+
+    _fields_ = [
+        ("threshold", C.c_double),
+        ("threshold_is_ratio", C.c_int),
+        ("distance", C.c_int),
+        ("has_prominence", C.c_int),
+        ("prominence_min", C.c_double),
+        ("width_min", C.c_double),
+        ("rel_height", C.c_double),
+        ("region_lo", C.c_int),
+        ("region_hi", C.c_int),
+        ("max_number", C.c_int),
+        ("sort_key", C.c_int),
+    ]
+
+
+# dtype / enum values of the header
+PL_U16, PL_I16, PL_F32, PL_F64, PL_U8 = 0, 1, 2, 3, 4
+PL_SUM, PL_MEAN, PL_MAX, PL_MIN = 0, 1, 2, 3
+PL_SORT = {"prominences": 0, "peak_heights": 1, "widths": 2}
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_d = C.c_double
+
+# name -> argtypes ; every symbol declared in include/pylinac_hip.h must be listed here
+SIGNATURES = {
+    "pl_abi_version": ([], C.c_int),
+    "pl_status_string": ([_i], C.c_char_p),
+    "pl_last_error": ([], C.c_char_p),
+    "pl_device_available": ([], C.c_int),
+    "pl_gaussian1d": ([_p, _p, _i, _l, _i, _i, _i, _p, _i, _p], C.c_int),
+    "pl_gaussian2d": ([_p, _p, _p, _i, _l, _i, _i, _p, _i, _p], C.c_int),
+    "pl_median2d": ([_p, _p, _i, _l, _i, _i, _i, _p], C.c_int),
+    "pl_minmax": ([_p, _i, _l, _l, _p, _p, _p], C.c_int),
+    "pl_ground": ([_p, _p, _i, _l, _l, _p, _d, _p], C.c_int),
+    "pl_normalize": ([_p, _p, _i, _l, _l, _p, _p], C.c_int),
+    "pl_invert": ([_p, _p, _i, _l, _l, _p, _p, _p], C.c_int),
+    "pl_threshold": ([_p, _p, _i, _l, _l, _p, _i, _i, _p], C.c_int),
+    "pl_as_binary": ([_p, _p, _i, _l, _l, _p, _i, _p], C.c_int),
+    "pl_hist16": ([_p, _i, _l, _l, _p, _p], C.c_int),
+    "pl_otsu_from_hist": ([_p, _i, _l, _p, _p, _p, _p], C.c_int),
+    "pl_order_stats_from_hist": ([_p, _i, _l, _p, _i, _p, _p], C.c_int),
+    "pl_reduce_axis": ([_p, _i, _l, _i, _i, _i, _i, _p, _p], C.c_int),
+    "pl_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
+    "pl_find_peaks": (
+        [_p, _l, _i, _l, C.POINTER(PeakParams), _i, _p, _p, _p, _p, _p, _p, _p],
+        C.c_int,
+    ),
+}
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("PYLINAC_HIP_LIB", _LIB_PATH))
+
+
+def load():
+    """Load the shared library (once).  Raises PylinacHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise PylinacHipError(
+            f"{path} not found: build it with `python -m pylinac_amd._build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback by design."
+        )
+    lib = C.CDLL(str(path))
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.pl_abi_version() != 1:
+        raise PylinacHipError(f"ABI version mismatch: library reports {lib.pl_abi_version()}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.pl_last_error().decode() or lib.pl_status_string(rc).decode()
+        raise PylinacHipError(f"{what or 'libpylinac_hip'} failed (status {rc}): {msg}")

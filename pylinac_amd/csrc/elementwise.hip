@@ -1,0 +1,274 @@
+// Per-frame min/max and the elementwise mutators of BaseImage.
+//
+// Replaces (numpy expressions in the reference):
+//   pl_minmax      array.min()/array.max()                  pylinac/core/array_utils.py:66,77,102
+//   pl_ground      array - array.min() + value              pylinac/core/array_utils.py:92-102
+//   pl_normalize   array / val   (-> float64)               pylinac/core/array_utils.py:63-71
+//   pl_invert      -array + array.max() + array.min()       pylinac/core/array_utils.py:74-77
+//   pl_threshold   np.where(a >= t, a, 0) / (a <= t)        pylinac/core/image.py:785-800
+//   pl_as_binary   np.where(a >= t, 1, 0)                   pylinac/core/image.py:802-815
+//
+// All are HBM-bound streaming kernels: 16-byte loads/stores per lane, one contiguous chunk of one
+// frame per block (so the per-frame scalar is block-uniform and read through the scalar cache).
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunkBytes = 64 * 1024;  // bytes of input one block streams
+
+template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };
+
+struct Plan { int64_t chunk; int bpf; };  // elements per block, blocks per frame
+
+template <typename T>
+static Plan make_plan(int64_t count) {
+  Plan p;
+  p.chunk = kChunkBytes / (int64_t)sizeof(T);
+  p.bpf = (int)pl_cdiv(count, p.chunk);
+  return p;
+}
+
+// Apply f(elem, frame) over one block's chunk with 16-byte vector access when aligned.
+template <typename TI, typename TO, typename F>
+__device__ __forceinline__ void stream_chunk(const TI* __restrict__ in, TO* __restrict__ out,
+                                             int64_t count, int64_t chunk, int bpf, F f) {
+  const int64_t frame = blockIdx.x / bpf;
+  const int64_t off = (int64_t)(blockIdx.x % bpf) * chunk;
+  const int64_t len = (count - off) < chunk ? (count - off) : chunk;
+  const TI* src = in + frame * count + off;
+  TO* dst = out + frame * count + off;
+  constexpr int N = Vec16<TI>::N;
+  constexpr int OB = N * (int)sizeof(TO);          // output bytes per lane-iteration
+  constexpr int OA = OB >= 16 ? 16 : OB;           // widest naturally aligned store we can use
+  struct alignas(OA) OutPack { TO e[N]; };
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(dst) & (OA - 1)) == 0);
+  if (aligned) {
+    const int64_t nvec = len / N;
+    for (int64_t v = threadIdx.x; v < nvec; v += kThreads) {
+      union { uint4 q; TI e[N]; } u;
+      u.q = reinterpret_cast<const uint4*>(src)[v];
+      OutPack r;
+#pragma unroll
+      for (int k = 0; k < N; ++k) r.e[k] = f(u.e[k], frame);
+      reinterpret_cast<OutPack*>(dst)[v] = r;
+    }
+    for (int64_t i = nvec * N + threadIdx.x; i < len; i += kThreads) dst[i] = f(src[i], frame);
+  } else {
+    for (int64_t i = threadIdx.x; i < len; i += kThreads) dst[i] = f(src[i], frame);
+  }
+}
+
+// ------------------------------------------------------------------------------------ min / max
+__device__ __forceinline__ void atomic_min_f64(double* addr, double v) {
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+  unsigned long long old = *a;
+  while (v < __longlong_as_double((long long)old)) {
+    unsigned long long assumed = old;
+    old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+    if (old == assumed) break;
+  }
+}
+__device__ __forceinline__ void atomic_max_f64(double* addr, double v) {
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+  unsigned long long old = *a;
+  while (v > __longlong_as_double((long long)old)) {
+    unsigned long long assumed = old;
+    old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+    if (old == assumed) break;
+  }
+}
+
+__global__ void minmax_init(double* mn, double* mx, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) { mn[i] = __longlong_as_double(0x7ff0000000000000LL); mx[i] = __longlong_as_double((long long)0xfff0000000000000ULL); }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+minmax_kernel(const T* __restrict__ in, int64_t count, int64_t chunk, int bpf, double* mn, double* mx) {
+  const int64_t frame = blockIdx.x / bpf;
+  const int64_t off = (int64_t)(blockIdx.x % bpf) * chunk;
+  const int64_t len = (count - off) < chunk ? (count - off) : chunk;
+  const T* src = in + frame * count + off;
+  constexpr int N = Vec16<T>::N;
+  T lo = src[0], hi = src[0];
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const int64_t nvec = len / N;
+    for (int64_t v = threadIdx.x; v < nvec; v += kThreads) {
+      union { uint4 q; T e[N]; } u;
+      u.q = reinterpret_cast<const uint4*>(src)[v];
+#pragma unroll
+      for (int k = 0; k < N; ++k) { lo = u.e[k] < lo ? u.e[k] : lo; hi = u.e[k] > hi ? u.e[k] : hi; }
+    }
+    for (int64_t i = nvec * N + threadIdx.x; i < len; i += kThreads) { T e = src[i]; lo = e < lo ? e : lo; hi = e > hi ? e : hi; }
+  } else {
+    for (int64_t i = threadIdx.x; i < len; i += kThreads) { T e = src[i]; lo = e < lo ? e : lo; hi = e > hi ? e : hi; }
+  }
+  double dlo = (double)lo, dhi = (double)hi;
+  dlo = pl_wave_reduce(dlo, [](double a, double b) { return a < b ? a : b; });
+  dhi = pl_wave_reduce(dhi, [](double a, double b) { return a > b ? a : b; });
+  __shared__ double slo[kThreads / PL_WAVE], shi[kThreads / PL_WAVE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { slo[wv] = dlo; shi[wv] = dhi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kThreads / PL_WAVE; ++k) { dlo = slo[k] < dlo ? slo[k] : dlo; dhi = shi[k] > dhi ? shi[k] : dhi; }
+    atomic_min_f64(mn + frame, dlo);
+    atomic_max_f64(mx + frame, dhi);
+  }
+}
+
+// ----------------------------------------------------------------------------- elementwise ops
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+ground_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int64_t chunk, int bpf,
+              const double* __restrict__ mn, double value) {
+  stream_chunk<T, T>(in, out, count, chunk, bpf, [=](T a, int64_t fr) -> T {
+    if constexpr (sizeof(T) == 2) {
+      // numpy: uint16/int16 array - same-dtype scalar (+ python int 0): modular arithmetic
+      int v = (int)a - (int)mn[fr] + (int)value;
+      return (T)v;
+    } else {
+      return (T)(a - (T)mn[fr] + (T)value);
+    }
+  });
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+normalize_kernel(const T* __restrict__ in, double* __restrict__ out, int64_t count, int64_t chunk,
+                 int bpf, const double* __restrict__ val) {
+  stream_chunk<T, double>(in, out, count, chunk, bpf,
+                          [=](T a, int64_t fr) -> double { return (double)a / val[fr]; });
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+invert_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int64_t chunk, int bpf,
+              const double* __restrict__ mn, const double* __restrict__ mx) {
+  stream_chunk<T, T>(in, out, count, chunk, bpf, [=](T a, int64_t fr) -> T {
+    if constexpr (sizeof(T) == 2) {
+      int v = -(int)a + (int)mx[fr] + (int)mn[fr];  // modular in the 16-bit dtype, like numpy
+      return (T)v;
+    } else {
+      return (T)((-a + (T)mx[fr]) + (T)mn[fr]);
+    }
+  });
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+threshold_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int64_t chunk, int bpf,
+                 const double* __restrict__ thr, int thr_stride, int kind) {
+  stream_chunk<T, T>(in, out, count, chunk, bpf, [=](T a, int64_t fr) -> T {
+    const double t = thr[fr * thr_stride];
+    const bool keep = kind == 0 ? ((double)a >= t) : ((double)a <= t);
+    return keep ? a : (T)0;
+  });
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+binary_kernel(const T* __restrict__ in, unsigned char* __restrict__ out, int64_t count, int64_t chunk,
+              int bpf, const double* __restrict__ thr, int thr_stride) {
+  stream_chunk<T, unsigned char>(in, out, count, chunk, bpf, [=](T a, int64_t fr) -> unsigned char {
+    return ((double)a >= thr[fr * thr_stride]) ? 1 : 0;
+  });
+}
+
+static int check_grid(int64_t n, int bpf, const char* who) {
+  if (n * bpf > 0x7fffffffLL) { pl_set_error("%s: batch too large for one launch", who); return PL_ERR_INVALID_ARG; }
+  return PL_OK;
+}
+
+}  // namespace
+
+#define PL_EW_PROLOGUE(who)                                        \
+  PL_REQUIRE(in && out, "null pointer");                           \
+  PL_REQUIRE(n >= 0 && count > 0, "bad shape");                    \
+  if (n == 0) return PL_OK;                                        \
+  hipStream_t st = (hipStream_t)stream;
+
+extern "C" int pl_minmax(const void* in, int dtype, int64_t n, int64_t count, double* d_min,
+                         double* d_max, void* stream) {
+  PL_REQUIRE(in && d_min && d_max, "null pointer");
+  PL_REQUIRE(n >= 0 && count > 0, "bad shape");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(minmax_init, dim3((unsigned)pl_cdiv(n, kThreads)), dim3(kThreads), 0, st, d_min, d_max, n);
+  PL_DISPATCH_DTYPE(dtype, T, {
+    Plan p = make_plan<T>(count);
+    if (int rc = check_grid(n, p.bpf, "pl_minmax")) return rc;
+    hipLaunchKernelGGL(minmax_kernel<T>, dim3((unsigned)(n * p.bpf)), dim3(kThreads), 0, st, (const T*)in,
+                       count, p.chunk, p.bpf, d_min, d_max);
+  });
+  return pl_check_launch("pl_minmax");
+}
+
+extern "C" int pl_ground(const void* in, void* out, int dtype, int64_t n, int64_t count,
+                         const double* d_min, double value, void* stream) {
+  PL_EW_PROLOGUE("pl_ground");
+  PL_REQUIRE(d_min, "null d_min");
+  PL_DISPATCH_DTYPE(dtype, T, {
+    Plan p = make_plan<T>(count);
+    if (int rc = check_grid(n, p.bpf, "pl_ground")) return rc;
+    hipLaunchKernelGGL(ground_kernel<T>, dim3((unsigned)(n * p.bpf)), dim3(kThreads), 0, st, (const T*)in,
+                       (T*)out, count, p.chunk, p.bpf, d_min, value);
+  });
+  return pl_check_launch("pl_ground");
+}
+
+extern "C" int pl_normalize(const void* in, double* out, int dtype, int64_t n, int64_t count,
+                            const double* d_val, void* stream) {
+  PL_EW_PROLOGUE("pl_normalize");
+  PL_REQUIRE(d_val, "null d_val");
+  PL_DISPATCH_DTYPE(dtype, T, {
+    Plan p = make_plan<T>(count);
+    if (int rc = check_grid(n, p.bpf, "pl_normalize")) return rc;
+    hipLaunchKernelGGL(normalize_kernel<T>, dim3((unsigned)(n * p.bpf)), dim3(kThreads), 0, st,
+                       (const T*)in, out, count, p.chunk, p.bpf, d_val);
+  });
+  return pl_check_launch("pl_normalize");
+}
+
+extern "C" int pl_invert(const void* in, void* out, int dtype, int64_t n, int64_t count,
+                         const double* d_min, const double* d_max, void* stream) {
+  PL_EW_PROLOGUE("pl_invert");
+  PL_REQUIRE(d_min && d_max, "null min/max");
+  PL_DISPATCH_DTYPE(dtype, T, {
+    Plan p = make_plan<T>(count);
+    if (int rc = check_grid(n, p.bpf, "pl_invert")) return rc;
+    hipLaunchKernelGGL(invert_kernel<T>, dim3((unsigned)(n * p.bpf)), dim3(kThreads), 0, st, (const T*)in,
+                       (T*)out, count, p.chunk, p.bpf, d_min, d_max);
+  });
+  return pl_check_launch("pl_invert");
+}
+
+extern "C" int pl_threshold(const void* in, void* out, int dtype, int64_t n, int64_t count,
+                            const double* d_thr, int thr_stride, int kind, void* stream) {
+  PL_EW_PROLOGUE("pl_threshold");
+  PL_REQUIRE(d_thr && (thr_stride == 0 || thr_stride == 1), "bad threshold array");
+  PL_REQUIRE(kind == 0 || kind == 1, "kind must be 0 (high) or 1 (low)");
+  PL_DISPATCH_DTYPE(dtype, T, {
+    Plan p = make_plan<T>(count);
+    if (int rc = check_grid(n, p.bpf, "pl_threshold")) return rc;
+    hipLaunchKernelGGL(threshold_kernel<T>, dim3((unsigned)(n * p.bpf)), dim3(kThreads), 0, st,
+                       (const T*)in, (T*)out, count, p.chunk, p.bpf, d_thr, thr_stride, kind);
+  });
+  return pl_check_launch("pl_threshold");
+}
+
+extern "C" int pl_as_binary(const void* in, uint8_t* out, int dtype, int64_t n, int64_t count,
+                            const double* d_thr, int thr_stride, void* stream) {
+  PL_EW_PROLOGUE("pl_as_binary");
+  PL_REQUIRE(d_thr && (thr_stride == 0 || thr_stride == 1), "bad threshold array");
+  PL_DISPATCH_DTYPE(dtype, T, {
+    Plan p = make_plan<T>(count);
+    if (int rc = check_grid(n, p.bpf, "pl_as_binary")) return rc;
+    hipLaunchKernelGGL(binary_kernel<T>, dim3((unsigned)(n * p.bpf)), dim3(kThreads), 0, st, (const T*)in,
+                       out, count, p.chunk, p.bpf, d_thr, thr_stride);
+  });
+  return pl_check_launch("pl_as_binary");
+}

@@ -1,0 +1,239 @@
+// Per-frame exact 16-bit histogram, Otsu threshold and order statistics
+// (SURVEY.md section 8 rows a4 and a6).
+//
+// Replaces:
+//   skimage.filters.threshold_otsu on integer images  (pylinac/ct.py:3323,3338-3340, acr.py:1409;
+//       skimage 0.18.3 filters/thresholding.py + exposure.histogram: one bin per integer value in
+//       [min,max], float64 cumulative class statistics, FIRST argmax of
+//       w1[:-1]*w2[1:]*(m1[:-1]-m2[1:])**2, returns the bin centre),
+//   np.percentile order statistics  (pylinac/core/image.py:899-926, picketfence.py:229-238,
+//       winston_lutz.py:775,1109-1133): exact k-th smallest values, the linear interpolation
+//       between the two neighbours is two flops done by the host layer.
+//
+// Histogram: a 65536-bin uint32 table is 256 KiB -- larger than LDS (160 KiB) -- and global
+// atomics would serialise on L2.  Each frame is therefore histogrammed by PARTS=4 workgroups,
+// workgroup p owning bins [16384p, 16384p+16384) in 64 KiB of LDS and streaming the whole frame
+// (16-byte loads; the 4 readers of a frame are placed on one XCD so three of the four reads are
+// L2 hits).  LDS atomics are issued per run of equal values.  Every bin is written exactly once
+// with a plain coalesced store, so the table needs no zero-fill and no global atomics.
+//
+// Otsu / order statistics: one 1024-lane workgroup per frame; lane t owns bins [64t, 64t+64);
+// exact integer prefix sums (uint64 counts, int64 value sums -- identical to numpy's float64
+// cumsum because every partial sum is an integer < 2^53), then the float64 variance expression in
+// skimage's operation order and a (value, first-index) arg-max reduction.
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kHistThreads = 1024;
+constexpr int kParts = 4;
+constexpr int kBinsPerPart = 65536 / kParts;  // 16384 -> 64 KiB LDS
+
+__global__ void __launch_bounds__(kHistThreads)
+hist16_kernel(const unsigned short* __restrict__ in, int64_t n, int64_t count, unsigned flip,
+              uint32_t* __restrict__ hist) {
+  __shared__ unsigned bins[kBinsPerPart];
+  // 8 frames x kParts parts per group; the parts of one frame share blockIdx % 8 (same XCD)
+  const unsigned within = blockIdx.x % (8 * kParts);
+  const int64_t frame = (int64_t)(blockIdx.x / (8 * kParts)) * 8 + (within & 7);
+  const unsigned part = within >> 3;
+  if (frame >= n) return;
+  for (int i = threadIdx.x; i < kBinsPerPart; i += kHistThreads) bins[i] = 0;
+  __syncthreads();
+
+  const unsigned short* src = in + frame * count;
+  auto tally = [&](unsigned key, unsigned& prev, unsigned& run) {
+    key ^= flip;
+    unsigned b = ((key >> 14) == part) ? (key & (kBinsPerPart - 1)) : 0xffffffffu;
+    if (b == prev) {
+      ++run;
+    } else {
+      if (prev != 0xffffffffu) atomicAdd(&bins[prev], run);
+      prev = b;
+      run = 1;
+    }
+  };
+  unsigned prev = 0xffffffffu, run = 0;
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const int64_t nvec = count / 8;
+    for (int64_t v = threadIdx.x; v < nvec; v += kHistThreads) {
+      uint4 q = reinterpret_cast<const uint4*>(src)[v];
+      unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        tally(wds[k] & 0xffffu, prev, run);
+        tally(wds[k] >> 16, prev, run);
+      }
+    }
+    for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally(src[i], prev, run);
+  } else {
+    for (int64_t i = threadIdx.x; i < count; i += kHistThreads) tally(src[i], prev, run);
+  }
+  if (prev != 0xffffffffu) atomicAdd(&bins[prev], run);
+  __syncthreads();
+  uint32_t* dst = hist + frame * 65536 + (size_t)part * kBinsPerPart;
+  for (int i = threadIdx.x; i < kBinsPerPart; i += kHistThreads) dst[i] = bins[i];
+}
+
+// ---- block-wide exclusive scan over 1024 lanes (16 waves) for a pair of 64-bit integers --------
+struct Pair { unsigned long long c; long long s; };
+
+__device__ __forceinline__ Pair block_exclusive_scan(Pair v, Pair* total, Pair* wave_tot /*[16]*/) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  Pair inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned long long c = __shfl_up(inc.c, o, 64);
+    long long s = __shfl_up(inc.s, o, 64);
+    if (lane >= o) { inc.c += c; inc.s += s; }
+  }
+  if (lane == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  Pair base = {0, 0};
+  Pair tot = {0, 0};
+  for (int k = 0; k < kHistThreads / 64; ++k) {
+    if (k < wv) { base.c += wave_tot[k].c; base.s += wave_tot[k].s; }
+    tot.c += wave_tot[k].c; tot.s += wave_tot[k].s;
+  }
+  __syncthreads();
+  *total = tot;
+  Pair ex = {base.c + inc.c - v.c, base.s + inc.s - v.s};
+  return ex;
+}
+
+__global__ void __launch_bounds__(kHistThreads)
+otsu_kernel(const uint32_t* __restrict__ hist, int bias, int32_t* __restrict__ thr,
+            int32_t* __restrict__ vmin, int32_t* __restrict__ vmax) {
+  __shared__ Pair wave_tot[kHistThreads / 64];
+  __shared__ int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64];
+  __shared__ double s_var[kHistThreads / 64];
+  __shared__ int s_idx[kHistThreads / 64];
+  const int64_t frame = blockIdx.x;
+  const uint32_t* hh = hist + frame * 65536;
+  const int b0 = threadIdx.x * 64;
+  const uint4* p = reinterpret_cast<const uint4*>(hh + b0);
+  Pair mine = {0, 0};
+  int lo = 1 << 30, hi = -1;
+  for (int k4 = 0; k4 < 16; ++k4) {
+    const uint4 q = p[k4];
+    const uint32_t c[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int b = b0 + 4 * k4 + j;
+      mine.c += c[j];
+      mine.s += (long long)c[j] * (long long)(b - bias);
+      if (c[j]) { if (lo == (1 << 30)) lo = b; hi = b; }
+    }
+  }
+  // first / last occupied bin of the frame
+  lo = pl_wave_reduce(lo, [](int a, int b) { return a < b ? a : b; });
+  hi = pl_wave_reduce(hi, [](int a, int b) { return a > b ? a : b; });
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
+  Pair total;
+  Pair ex = block_exclusive_scan(mine, &total, wave_tot);  // contains __syncthreads
+  for (int k = 0; k < kHistThreads / 64; ++k) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; }
+
+  double best = -1.0;
+  int best_k = 1 << 30;
+  unsigned long long w1 = ex.c;
+  long long s1 = ex.s;
+  for (int k4 = 0; k4 < 16; ++k4) {   // second sweep re-reads the 256 B from L2 (no spills)
+    const uint4 q = p[k4];
+    const uint32_t c[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int b = b0 + 4 * k4 + j;
+      w1 += c[j];
+      s1 += (long long)c[j] * (long long)(b - bias);
+      if (b >= lo && b < hi) {
+        const double dw1 = (double)w1, dw2 = (double)(total.c - w1);
+        const double m1 = (double)s1 / dw1;
+        const double m2 = (double)(total.s - s1) / dw2;
+        const double d = m1 - m2;
+        const double var = (dw1 * dw2) * (d * d);
+        if (var > best) { best = var; best_k = b; }
+      }
+    }
+  }
+  // arg-max with first-index tie rule
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(best, o, 64);
+    int ok = __shfl_xor(best_k, o, 64);
+    if (ov > best || (ov == best && ok < best_k)) { best = ov; best_k = ok; }
+  }
+  if (lane == 0) { s_var[wv] = best; s_idx[wv] = best_k; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kHistThreads / 64; ++k)
+      if (s_var[k] > best || (s_var[k] == best && s_idx[k] < best_k)) { best = s_var[k]; best_k = s_idx[k]; }
+    // constant image: skimage returns that value (thresholding.py: np.all(image == first_pixel))
+    thr[frame] = (lo == hi) ? (lo - bias) : (best_k - bias);
+    if (vmin) vmin[frame] = lo - bias;
+    if (vmax) vmax[frame] = hi - bias;
+  }
+}
+
+__global__ void __launch_bounds__(kHistThreads)
+order_stats_kernel(const uint32_t* __restrict__ hist, int bias, const int64_t* __restrict__ ranks,
+                   int nranks, int32_t* __restrict__ out) {
+  __shared__ Pair wave_tot[kHistThreads / 64];
+  const int64_t frame = blockIdx.x;
+  const uint32_t* hh = hist + frame * 65536;
+  const int b0 = threadIdx.x * 64;
+  Pair mine = {0, 0};
+  for (int k = 0; k < 64; ++k) mine.c += hh[b0 + k];
+  Pair total;
+  Pair ex = block_exclusive_scan(mine, &total, wave_tot);
+  for (int q = 0; q < nranks; ++q) {
+    long long r = ranks[q];
+    if (r < 0) r = 0;
+    if ((unsigned long long)r >= total.c) r = (long long)total.c - 1;
+    if ((unsigned long long)r >= ex.c && (unsigned long long)r < ex.c + mine.c) {
+      unsigned long long acc = ex.c;
+      for (int k = 0; k < 64; ++k) {
+        acc += hh[b0 + k];
+        if ((unsigned long long)r < acc) { out[frame * nranks + q] = b0 + k - bias; break; }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist,
+                         void* stream) {
+  PL_REQUIRE(in && d_hist, "null pointer");
+  PL_REQUIRE(n >= 0 && count > 0, "bad shape");
+  PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
+  if (n == 0) return PL_OK;
+  int64_t blocks = pl_cdiv(n, 8) * 8 * kParts;
+  PL_REQUIRE(blocks <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(hist16_kernel, dim3((unsigned)blocks), dim3(kHistThreads), 0, (hipStream_t)stream,
+                     (const unsigned short*)in, n, count, dtype == PL_I16 ? 0x8000u : 0u, d_hist);
+  return pl_check_launch("pl_hist16");
+}
+
+extern "C" int pl_otsu_from_hist(const uint32_t* d_hist, int dtype, int64_t n, int32_t* d_thr,
+                                 int32_t* d_min, int32_t* d_max, void* stream) {
+  PL_REQUIRE(d_hist && d_thr, "null pointer");
+  PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL, "bad batch");
+  if (n == 0) return PL_OK;
+  hipLaunchKernelGGL(otsu_kernel, dim3((unsigned)n), dim3(kHistThreads), 0, (hipStream_t)stream, d_hist,
+                     dtype == PL_I16 ? 32768 : 0, d_thr, d_min, d_max);
+  return pl_check_launch("pl_otsu_from_hist");
+}
+
+extern "C" int pl_order_stats_from_hist(const uint32_t* d_hist, int dtype, int64_t n,
+                                        const int64_t* d_ranks, int nranks, int32_t* d_out,
+                                        void* stream) {
+  PL_REQUIRE(d_hist && d_ranks && d_out, "null pointer");
+  PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && nranks > 0, "bad batch");
+  if (n == 0) return PL_OK;
+  hipLaunchKernelGGL(order_stats_kernel, dim3((unsigned)n), dim3(kHistThreads), 0, (hipStream_t)stream,
+                     d_hist, dtype == PL_I16 ? 32768 : 0, d_ranks, nranks, d_out);
+  return pl_check_launch("pl_order_stats_from_hist");
+}

@@ -1,0 +1,189 @@
+// 2-D / 1-D median filter with scipy semantics.
+//
+// Replaces: scipy.ndimage.median_filter(array, size=s) as called at
+// pylinac/core/array_utils.py:131 (BaseImage.filter(kind="median"), pylinac/core/image.py:695-712;
+// the PF noise filter pylinac/picketfence.py:226 uses size 3).
+//
+// Semantics: s x s window (length-s for a 1-D profile), mode='reflect', origin 0 (window starts
+// at i - s/2), rank (s*s)/2, dtype preserved, exact.
+//
+// 3x3: each lane owns one column and slides down its rows; each new row contributes a SORTED
+// horizontal triple (min3/med3/max3 on the VALU), triples are kept in registers for three rows,
+// and the median of nine is med3(max3(lows), med3(mids), min3(highs)) -- 7 three-operand VALU ops
+// per pixel, no LDS, no cross-lane traffic; the three loads per row are adjacent lanes' bytes and
+// coalesce into the same 128-byte lines.
+// General s: rank selection by bisection on an order-preserving integer key over an LDS tile.
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// order-preserving key types --------------------------------------------------------------------
+template <typename T> struct Key;
+template <> struct Key<unsigned short> {
+  using K = unsigned int; static constexpr int bits = 16;
+  __device__ static K enc(unsigned short v) { return v; }
+  __device__ static unsigned short dec(K k) { return (unsigned short)k; }
+};
+template <> struct Key<short> {
+  using K = unsigned int; static constexpr int bits = 16;
+  __device__ static K enc(short v) { return (unsigned int)((int)v + 32768); }
+  __device__ static short dec(K k) { return (short)((int)k - 32768); }
+};
+template <> struct Key<float> {
+  using K = unsigned int; static constexpr int bits = 32;
+  __device__ static K enc(float v) {
+    unsigned int u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  }
+  __device__ static float dec(K k) {
+    unsigned int u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+  }
+};
+template <> struct Key<double> {
+  using K = unsigned long long; static constexpr int bits = 64;
+  __device__ static K enc(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+  }
+  __device__ static double dec(K k) {
+    unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+  }
+};
+
+template <typename K> __device__ __forceinline__ K kmin(K a, K b) { return a < b ? a : b; }
+template <typename K> __device__ __forceinline__ K kmax(K a, K b) { return a > b ? a : b; }
+template <typename K> __device__ __forceinline__ K kmed3(K a, K b, K c) {
+  return kmax(kmin(a, b), kmin(kmax(a, b), c));
+}
+
+// ------------------------------------------------------------------------------------ 3x3 fast
+template <typename T, int ROWS>
+__global__ void __launch_bounds__(kThreads)
+median3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_tiles,
+               int row_groups) {
+  using K = typename Key<T>::K;
+  unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = id % col_tiles;
+  id /= col_tiles;
+  const int rg = id % row_groups;
+  const size_t frame = id / row_groups;
+  const int c = ct * kThreads + threadIdx.x;
+  if (c >= w) return;
+  const int r0 = rg * ROWS;
+  const T* f = in + frame * (size_t)h * w;
+  T* o = out + frame * (size_t)h * w;
+  const int cl = pl_reflect(c - 1, w), cr = pl_reflect(c + 1, w);
+
+  K lo[3], mi[3], hi[3];
+  auto load_row = [&](int r, int slot) {
+    const T* p = f + (size_t)pl_reflect(r, h) * w;
+    K a = Key<T>::enc(p[cl]), b = Key<T>::enc(p[c]), d = Key<T>::enc(p[cr]);
+    lo[slot] = kmin(kmin(a, b), d);
+    hi[slot] = kmax(kmax(a, b), d);
+    mi[slot] = kmed3(a, b, d);
+  };
+  load_row(r0 - 1, 0);
+  load_row(r0, 1);
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int r = r0 + i;
+    if (r >= h) break;
+    load_row(r + 1, (i + 2) % 3);
+    K a = kmax(kmax(lo[0], lo[1]), lo[2]);
+    K b = kmed3(mi[0], mi[1], mi[2]);
+    K d = kmin(kmin(hi[0], hi[1]), hi[2]);
+    o[(size_t)r * w + c] = Key<T>::dec(kmed3(a, b, d));
+  }
+}
+
+// --------------------------------------------------------------------- general size (LDS tile)
+// 16x16 outputs per block; tile (16+sh-1) x (16+sw-1) keys staged in LDS; each lane bisects the
+// key space: smallest key v with  #{window <= v} >= rank+1.
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+median_general_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w, int sh, int sw,
+                      int tiles_x, int tiles_y, int rank) {
+  using KT = Key<T>;
+  using K = typename KT::K;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  K* tile = reinterpret_cast<K*>(smem_raw);
+  constexpr int TS = 16;
+  unsigned id = blockIdx.x;
+  const int tx = id % tiles_x;
+  id /= tiles_x;
+  const int ty = id % tiles_y;
+  const size_t frame = id / tiles_y;
+  const T* f = in + frame * (size_t)h * w;
+  T* o = out + frame * (size_t)h * w;
+  const int th = TS + sh - 1, tw = TS + sw - 1;
+  const int r_base = ty * TS - sh / 2, c_base = tx * TS - sw / 2;
+  for (int e = threadIdx.x; e < th * tw; e += kThreads) {
+    int rr = pl_reflect(r_base + e / tw, h), cc = pl_reflect(c_base + e % tw, w);
+    tile[e] = KT::enc(f[(size_t)rr * w + cc]);
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+  const int r = ty * TS + ly, c = tx * TS + lx;
+  if (r >= h || c >= w) return;
+  const K* win = tile + ly * tw + lx;
+  K lo = 0, hi = (KT::bits == 64) ? ~(K)0 : (K)(((unsigned long long)1 << KT::bits) - 1);
+  const int need = rank + 1;
+  while (lo < hi) {
+    K mid = lo + (hi - lo) / 2;
+    int cnt = 0;
+    for (int y = 0; y < sh; ++y)
+      for (int x = 0; x < sw; ++x) cnt += (win[y * tw + x] <= mid) ? 1 : 0;
+    if (cnt >= need) hi = mid; else lo = mid + 1;
+  }
+  o[(size_t)r * w + c] = KT::dec(lo);
+}
+
+template <typename T>
+int median_t(const T* in, T* out, int64_t n, int h, int w, int size, hipStream_t st) {
+  if (size == 1) {
+    hipError_t e = hipMemcpyAsync(out, in, (size_t)n * h * w * sizeof(T), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { pl_set_error("pl_median2d: copy failed: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+    return PL_OK;
+  }
+  if (size == 3 && h > 1) {
+    constexpr int ROWS = 16;
+    int col_tiles = (int)pl_cdiv(w, kThreads), row_groups = (int)pl_cdiv(h, ROWS);
+    int64_t blocks = n * col_tiles * row_groups;
+    if (blocks > 0x7fffffffLL) { pl_set_error("pl_median2d: batch too large"); return PL_ERR_INVALID_ARG; }
+    hipLaunchKernelGGL((median3_kernel<T, ROWS>), dim3((unsigned)blocks), dim3(kThreads), 0, st, in,
+                       out, h, w, col_tiles, row_groups);
+    return pl_check_launch("pl_median2d");
+  }
+  const int sh = (h > 1) ? size : 1, sw = size;
+  const int rank = (sh * sw) / 2;
+  const size_t lds = (size_t)(16 + sh - 1) * (16 + sw - 1) * sizeof(typename Key<T>::K);
+  if (lds > 160 * 1024) { pl_set_error("pl_median2d: window %d too large", size); return PL_ERR_UNSUPPORTED; }
+  int tiles_x = (int)pl_cdiv(w, 16), tiles_y = (int)pl_cdiv(h, 16);
+  int64_t blocks = n * tiles_x * tiles_y;
+  if (blocks > 0x7fffffffLL) { pl_set_error("pl_median2d: batch too large"); return PL_ERR_INVALID_ARG; }
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)median_general_kernel<T>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { pl_set_error("pl_median2d: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+  }
+  hipLaunchKernelGGL(median_general_kernel<T>, dim3((unsigned)blocks), dim3(kThreads), lds, st, in, out,
+                     h, w, sh, sw, tiles_x, tiles_y, rank);
+  return pl_check_launch("pl_median2d");
+}
+
+}  // namespace
+
+extern "C" int pl_median2d(const void* in, void* out, int dtype, int64_t n, int h, int w, int size,
+                           void* stream) {
+  PL_REQUIRE(in && out && in != out, "null or aliased pointers");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");
+  PL_REQUIRE(size >= 1, "size must be >= 1");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  PL_DISPATCH_DTYPE(dtype, T, return median_t<T>((const T*)in, (T*)out, n, h, w, size, st));
+  return PL_OK;
+}

@@ -1,0 +1,316 @@
+// Batched 1-D peak finding with scipy.signal.find_peaks semantics, plus pylinac's own pre/post
+// steps.
+//
+// Replaces: pylinac.core.profile.find_peaks (pylinac/core/profile.py:2545-2623) and
+// _parse_peak_args (:2626-2649), i.e. the call
+//     scipy.signal.find_peaks(trimmed, rel_height=1-fwxm_height, width=min_width,
+//                             height=threshold, distance=peak_separation, prominence=required)
+// followed by "keep the max_number largest by peak_props[peak_sort], re-sorted left to right".
+//
+// One 256-lane workgroup per profile.  Stages (the order of scipy's filters is preserved):
+//   A  min/max of the FULL profile (ratio threshold: height = min + thr*(max-min))
+//   B  local maxima (strict rise, plateau -> midpoint (l+r)/2, strict fall; ends never peaks)
+//      + height filter, compacted IN ORDER with ballot/popcount scans
+//   C  distance filter: priority = height, highest first, processed sequentially by one lane
+//      exactly like _select_by_peak_distance (ties: stable order -- scipy's own tie order comes
+//      from np.argsort's default introsort and is implementation-defined)
+//   D  prominences + bases: one lane per peak walks outwards in LDS
+//   E  prominence filter   F  widths at rel_height (+ width filter)
+//   G  top-max_number by key (stable, reversed)   H  ordered output compaction
+// Float64 throughout, operations in scipy's order, so the float results are bit-identical.
+#include <math.h>
+
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kStageMax = 4096;   // profiles up to this length are staged in LDS
+constexpr int kMaxCand = 4096;    // candidate peaks kept per profile
+
+struct Scan { int wave[kThreads / PL_WAVE]; };
+
+__device__ __forceinline__ int block_flag_scan(int flag, int* total, Scan* s) {
+  const unsigned long long b = __ballot(flag);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int pre = __popcll(b & ((1ull << lane) - 1ull));
+  if (lane == 0) s->wave[wv] = __popcll(b);
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kThreads / PL_WAVE; ++k) {
+    if (k < wv) base += s->wave[k];
+    tot += s->wave[k];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + pre;
+}
+
+struct Widths { double width, height, lip, rip; };
+
+__device__ __forceinline__ Widths peak_width(const double* xs, int pk, int lb, int rb, double prom,
+                                             double rel_height) {
+  Widths r;
+  const double h = xs[pk] - prom * rel_height;
+  r.height = h;
+  int i = pk;
+  while (lb < i && h < xs[i]) --i;
+  double lip = (double)i;
+  if (xs[i] < h) lip += (h - xs[i]) / (xs[i + 1] - xs[i]);
+  i = pk;
+  while (i < rb && h < xs[i]) ++i;
+  double rip = (double)i;
+  if (xs[i] < h) rip -= (h - xs[i]) / (xs[i - 1] - xs[i]);
+  r.lip = lip;
+  r.rip = rip;
+  r.width = rip - lip;
+  return r;
+}
+
+__global__ void __launch_bounds__(kThreads)
+find_peaks_kernel(const double* __restrict__ x, int len, int64_t stride, pl_peak_params prm, int cap,
+                  int maxc, int stage_x, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
+                  int32_t* __restrict__ d_lb, int32_t* __restrict__ d_rb, double* __restrict__ d_props,
+                  int32_t* __restrict__ d_status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ Scan scan;
+  __shared__ double s_red[2 * (kThreads / PL_WAVE)];
+  __shared__ int s_cnt;
+
+  const int64_t prof = blockIdx.x;
+  const double* xfull = x + prof * stride;
+  int lo = prm.region_lo < 0 ? 0 : prm.region_lo;
+  int hi = prm.region_hi > len ? len : prm.region_hi;
+  if (hi < lo) hi = lo;
+  const int m = hi - lo;
+
+  // LDS carve-up: [prom f64][width f64][idx][lb][rb][keep] x maxc, then optional staged profile
+  double* s_prom = reinterpret_cast<double*>(smem);
+  double* s_width = s_prom + maxc;
+  int* s_idx = reinterpret_cast<int*>(s_width + maxc);
+  int* s_lb = s_idx + maxc;
+  int* s_rb = s_lb + maxc;
+  int* s_keep = s_rb + maxc;
+  double* s_x = reinterpret_cast<double*>(s_keep + maxc + (maxc & 1));
+
+  // ---- A: height threshold -------------------------------------------------------------------
+  double height = prm.threshold;
+  if (prm.threshold_is_ratio) {
+    double mn = xfull[0], mx = xfull[0];
+    for (int i = threadIdx.x; i < len; i += kThreads) {
+      double v = xfull[i];
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+    }
+    mn = pl_wave_reduce(mn, [](double a, double b) { return a < b ? a : b; });
+    mx = pl_wave_reduce(mx, [](double a, double b) { return a > b ? a : b; });
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = mn; s_red[4 + (threadIdx.x >> 6)] = mx; }
+    __syncthreads();
+    for (int k = 0; k < kThreads / PL_WAVE; ++k) {
+      mn = s_red[k] < mn ? s_red[k] : mn;
+      mx = s_red[4 + k] > mx ? s_red[4 + k] : mx;
+    }
+    height = mn + prm.threshold * (mx - mn);  // pylinac/core/profile.py:2633-2635
+  }
+
+  const double* xs = xfull + lo;
+  if (stage_x) {
+    for (int i = threadIdx.x; i < m; i += kThreads) s_x[i] = xs[i];
+    xs = s_x;
+  }
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+
+  // ---- B: local maxima + height filter, ordered compaction -----------------------------------
+  int overflow = 0;
+  for (int base = 0; base < m; base += kThreads) {
+    const int i = base + threadIdx.x;
+    int flag = 0, mid = 0;
+    if (i >= 1 && i < m - 1 && xs[i - 1] < xs[i]) {
+      int a = i + 1;
+      while (a < m - 1 && xs[a] == xs[i]) ++a;
+      if (xs[a] < xs[i]) {
+        mid = (i + a - 1) / 2;
+        flag = (xs[mid] >= height) ? 1 : 0;
+      }
+    }
+    int tot;
+    const int off = block_flag_scan(flag, &tot, &scan);
+    const int cur = s_cnt;
+    if (flag) {
+      if (cur + off < maxc) s_idx[cur + off] = mid; else overflow = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt = cur + tot;
+    __syncthreads();
+  }
+  int P = s_cnt;
+  if (P > maxc) { P = maxc; overflow = 1; }
+  overflow = __syncthreads_or(overflow);
+
+  // ---- C: distance filter --------------------------------------------------------------------
+  if (prm.distance > 1 && P > 1) {
+    int* s_order = s_lb;  // scratch: bases are not computed yet
+    for (int j = threadIdx.x; j < P; j += kThreads) {
+      const double hj = xs[s_idx[j]];
+      int r = 0;
+      for (int k = 0; k < P; ++k) {
+        const double hk = xs[s_idx[k]];
+        r += (hk < hj || (hk == hj && k < j)) ? 1 : 0;
+      }
+      s_order[r] = j;
+      s_keep[j] = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int d = prm.distance;
+      for (int i = P - 1; i >= 0; --i) {
+        const int j = s_order[i];
+        if (!s_keep[j]) continue;
+        int k = j - 1;
+        while (k >= 0 && s_idx[j] - s_idx[k] < d) { s_keep[k] = 0; --k; }
+        k = j + 1;
+        while (k < P && s_idx[k] - s_idx[j] < d) { s_keep[k] = 0; ++k; }
+      }
+    }
+    __syncthreads();
+    int* s_tmp = s_rb;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (int base = 0; base < P; base += kThreads) {
+      const int j = base + threadIdx.x;
+      const int flag = (j < P) ? s_keep[j] : 0;
+      int tot;
+      const int off = block_flag_scan(flag, &tot, &scan);
+      const int cur = s_cnt;
+      if (flag) s_tmp[cur + off] = s_idx[j];
+      __syncthreads();
+      if (threadIdx.x == 0) s_cnt = cur + tot;
+      __syncthreads();
+    }
+    P = s_cnt;
+    for (int j = threadIdx.x; j < P; j += kThreads) s_idx[j] = s_tmp[j];
+    __syncthreads();
+  }
+
+  // ---- D/E/F: prominences, bases, widths, filters ---------------------------------------------
+  for (int p = threadIdx.x; p < P; p += kThreads) {
+    const int pk = s_idx[p];
+    const double xp = xs[pk];
+    int i = pk, lb = pk;
+    double left_min = xp;
+    while (0 <= i && xs[i] <= xp) {
+      if (xs[i] < left_min) { left_min = xs[i]; lb = i; }
+      --i;
+    }
+    i = pk;
+    int rb = pk;
+    double right_min = xp;
+    while (i <= m - 1 && xs[i] <= xp) {
+      if (xs[i] < right_min) { right_min = xs[i]; rb = i; }
+      ++i;
+    }
+    const double prom = xp - (left_min > right_min ? left_min : right_min);
+    int keep = (!prm.has_prominence || prom >= prm.prominence_min) ? 1 : 0;
+    const Widths wd = peak_width(xs, pk, lb, rb, prom, prm.rel_height);
+    keep = keep && (wd.width >= prm.width_min);
+    s_prom[p] = prom;
+    s_width[p] = wd.width;
+    s_lb[p] = lb;
+    s_rb[p] = rb;
+    s_keep[p] = keep;
+  }
+  __syncthreads();
+
+  // ---- G: keep the max_number largest by key (np.argsort(kind=stable)[::-1][:max_number]) ------
+  if (prm.max_number > 0) {
+    // s_keep is read-only during the ranking; a peak to drop is tagged by complementing its
+    // (non-negative) right base, then untagged after the barrier.
+    for (int p = threadIdx.x; p < P; p += kThreads) {
+      if (!s_keep[p]) continue;
+      const double kp = prm.sort_key == PL_SORT_PROMINENCES ? s_prom[p]
+                        : prm.sort_key == PL_SORT_PEAK_HEIGHTS ? xs[s_idx[p]] : s_width[p];
+      int ahead = 0;
+      for (int k = 0; k < P; ++k) {
+        if (!s_keep[k]) continue;
+        const double kk = prm.sort_key == PL_SORT_PROMINENCES ? s_prom[k]
+                          : prm.sort_key == PL_SORT_PEAK_HEIGHTS ? xs[s_idx[k]] : s_width[k];
+        ahead += (kk > kp || (kk == kp && k > p)) ? 1 : 0;
+      }
+      if (ahead >= prm.max_number) s_rb[p] = ~s_rb[p];
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += kThreads)
+      if (s_rb[p] < 0) { s_rb[p] = ~s_rb[p]; s_keep[p] = 0; }
+    __syncthreads();
+  }
+
+  // ---- H: ordered output ----------------------------------------------------------------------
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  int32_t* o_idx = d_idx + prof * cap;
+  int32_t* o_lb = d_lb + prof * cap;
+  int32_t* o_rb = d_rb + prof * cap;
+  double* o_p = d_props + prof * 6 * (int64_t)cap;
+  for (int base = 0; base < P; base += kThreads) {
+    const int p = base + threadIdx.x;
+    const int flag = (p < P) ? s_keep[p] : 0;
+    int tot;
+    const int off = block_flag_scan(flag, &tot, &scan);
+    const int cur = s_cnt;
+    const int dst = cur + off;
+    if (flag && dst < cap) {
+      const int pk = s_idx[p];
+      const Widths wd = peak_width(xs, pk, s_lb[p], s_rb[p], s_prom[p], prm.rel_height);
+      o_idx[dst] = pk + lo;  // only the indices are shifted (pylinac/core/profile.py:2613)
+      o_lb[dst] = s_lb[p];
+      o_rb[dst] = s_rb[p];
+      o_p[0 * cap + dst] = xs[pk];
+      o_p[1 * cap + dst] = s_prom[p];
+      o_p[2 * cap + dst] = wd.width;
+      o_p[3 * cap + dst] = wd.height;
+      o_p[4 * cap + dst] = wd.lip;
+      o_p[5 * cap + dst] = wd.rip;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt = cur + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int total = s_cnt;
+    d_count[prof] = total < cap ? total : cap;
+    d_status[prof] = overflow ? 2 : (total > cap ? 1 : 0);
+  }
+}
+
+}  // namespace
+
+extern "C" int pl_find_peaks(const double* d_x, int64_t n, int len, int64_t stride,
+                             const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,
+                             int32_t* d_left_base, int32_t* d_right_base, double* d_props,
+                             int32_t* d_status, void* stream) {
+  PL_REQUIRE(d_x && params && d_count && d_idx && d_left_base && d_right_base && d_props && d_status,
+             "null pointer");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && len > 0 && stride >= len && cap > 0, "bad shape");
+  PL_REQUIRE(params->distance >= 1, "distance must be >= 1");
+  if (n == 0) return PL_OK;
+  int lo = params->region_lo < 0 ? 0 : params->region_lo;
+  int hi = params->region_hi > len ? len : params->region_hi;
+  int m = hi > lo ? hi - lo : 0;
+  int maxc = m / 2 + 1;
+  if (maxc > kMaxCand) maxc = kMaxCand;
+  const int stage_x = (m <= kStageMax) ? 1 : 0;
+  size_t lds = (size_t)maxc * (8 + 8 + 4 * 4) + 8 + (stage_x ? (size_t)m * 8 : 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)find_peaks_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) { pl_set_error("pl_find_peaks: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(find_peaks_kernel, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
+                     len, stride, *params, cap, maxc, stage_x, d_count, d_idx, d_left_base, d_right_base,
+                     d_props, d_status);
+  return pl_check_launch("pl_find_peaks");
+}

@@ -1,0 +1,86 @@
+// Shared device/host helpers for libpylinac_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pylinac_hip.h"
+
+#define PL_WAVE 64
+
+// ---- host side -------------------------------------------------------------------------------
+void pl_set_error(const char* fmt, ...);
+int pl_check_launch(const char* what);
+
+#define PL_REQUIRE(cond, msg)                    \
+  do {                                           \
+    if (!(cond)) {                               \
+      pl_set_error("%s: %s", __func__, msg);     \
+      return PL_ERR_INVALID_ARG;                 \
+    }                                            \
+  } while (0)
+
+static inline int64_t pl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device side -----------------------------------------------------------------------------
+// scipy 'reflect' (half-sample symmetric:  d c b a | a b c d | d c b a), valid for any distance.
+__device__ __forceinline__ int pl_reflect(int i, int n) {
+  if ((unsigned)i < (unsigned)n) return i;
+  int p = 2 * n;
+  int m = i % p;
+  if (m < 0) m += p;
+  return m >= n ? p - 1 - m : m;
+}
+
+// Blocks b and b+8 share an XCD (observed dispatch, speed only).  Map the hardware block id onto
+// a logical id such that CONSECUTIVE logical ids run on the SAME XCD, so that neighbouring tiles
+// of one frame (which share halo rows) hit the same 4 MiB L2.  Bijective for any grid size
+// (cdna_hip_programming.md, "XCD swizzle must be bijective").
+__device__ __forceinline__ unsigned pl_xcd_remap(unsigned b, unsigned nwg) {
+  unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (b >> 3);
+}
+
+template <typename T>
+__device__ __forceinline__ T pl_from_double(double v);
+// C cast double -> integer == truncation toward zero (scipy ni_support.c CASE_COPY_LINE_TO_DATA)
+template <>
+__device__ __forceinline__ unsigned short pl_from_double<unsigned short>(double v) {
+  return (unsigned short)(unsigned int)v;
+}
+template <>
+__device__ __forceinline__ short pl_from_double<short>(double v) {
+  return (short)(int)v;
+}
+template <>
+__device__ __forceinline__ float pl_from_double<float>(double v) {
+  return (float)v;
+}
+template <>
+__device__ __forceinline__ double pl_from_double<double>(double v) {
+  return v;
+}
+template <>
+__device__ __forceinline__ unsigned char pl_from_double<unsigned char>(double v) {
+  return (unsigned char)(unsigned int)v;
+}
+
+// wave-level reductions (64 lanes, xor butterflies -> every lane holds the result)
+template <typename T, typename F>
+__device__ __forceinline__ T pl_wave_reduce(T v, F f) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = f(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// dispatch a dtype enum onto a template parameter
+#define PL_DISPATCH_DTYPE(dtype, T, ...)                         \
+  switch (dtype) {                                               \
+    case PL_U16: { using T = unsigned short; __VA_ARGS__; break; } \
+    case PL_I16: { using T = short; __VA_ARGS__; break; }        \
+    case PL_F32: { using T = float; __VA_ARGS__; break; }        \
+    case PL_F64: { using T = double; __VA_ARGS__; break; }       \
+    default:                                                     \
+      pl_set_error("%s: unsupported dtype %d", __func__, (int)(dtype)); \
+      return PL_ERR_UNSUPPORTED;                                 \
+  }

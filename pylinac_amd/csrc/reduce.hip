@@ -1,0 +1,175 @@
+// Profile extraction: axis reductions of a frame.
+//
+// Replaces the ad-hoc numpy reductions the analyzers use in place of an Image.profile():
+//   np.mean(image, axis)   pylinac/picketfence.py:747-750, pylinac/field_analysis.py:1094-1117
+//   np.sum(array, axis)    pylinac/picketfence.py:1513-1514, pylinac/field_analysis.py:488-506
+//   np.max(central, axis)  pylinac/starshot.py:216-217
+// Integer frames are summed in int64 (exact; numpy's float64/uint64 accumulation of integers is
+// exact as well, so any order agrees), float frames are accumulated in the frame's own precision,
+// sequentially along axis 0 (numpy's order for a C-contiguous frame) and by a wave tree along
+// axis 1 (numpy uses pairwise summation there: equal to ~1 ulp, not bitwise).
+//
+// pl_threshold_colsum_u16 fuses BaseImage.threshold (pylinac/core/image.py:797-800) with the
+// axis-0 column sums of the thresholded frame: one read and one write of the frame, 16-byte
+// accesses, per-lane uint32 partial sums over a 32-row band, one uint64 atomic per column/band.
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <typename T> struct Acc { using type = long long; };
+template <> struct Acc<float> { using type = float; };
+template <> struct Acc<double> { using type = double; };
+
+template <typename T>
+__device__ __forceinline__ double finish(typename Acc<T>::type acc, int op, int count) {
+  using A = typename Acc<T>::type;
+  if (op == PL_MEAN) {
+    if constexpr (sizeof(T) == 2) return (double)acc / (double)count;  // float64 mean of integers
+    else return (double)(A)(acc / (A)count);                            // mean in the frame's precision
+  }
+  return (double)acc;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+reduce_axis0_kernel(const T* __restrict__ in, int h, int w, int col_tiles, int op,
+                    double* __restrict__ out) {
+  using A = typename Acc<T>::type;
+  const int ct = blockIdx.x % col_tiles;
+  const size_t frame = blockIdx.x / col_tiles;
+  const int c = ct * kThreads + threadIdx.x;
+  if (c >= w) return;
+  const T* p = in + frame * (size_t)h * w + c;
+  if (op == PL_SUM || op == PL_MEAN) {
+    A acc = 0;
+    for (int r = 0; r < h; ++r) acc += (A)p[(size_t)r * w];
+    out[frame * w + c] = finish<T>(acc, op, h);
+  } else {
+    T best = p[0];
+    for (int r = 1; r < h; ++r) {
+      T v = p[(size_t)r * w];
+      best = (op == PL_MAX) ? (v > best ? v : best) : (v < best ? v : best);
+    }
+    out[frame * w + c] = (double)best;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+reduce_axis1_kernel(const T* __restrict__ in, int64_t rows_total, int w, int op,
+                    double* __restrict__ out) {
+  using A = typename Acc<T>::type;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kThreads / PL_WAVE) + (threadIdx.x >> 6);
+  if (row >= rows_total) return;
+  const T* p = in + row * (size_t)w;
+  if (op == PL_SUM || op == PL_MEAN) {
+    A acc = 0;
+    for (int c = lane; c < w; c += PL_WAVE) acc += (A)p[c];
+    acc = pl_wave_reduce(acc, [](A a, A b) { return a + b; });
+    if (lane == 0) out[row] = finish<T>(acc, op, w);
+  } else {
+    T best = p[lane < w ? lane : 0];
+    for (int c = lane; c < w; c += PL_WAVE) {
+      T v = p[c];
+      best = (op == PL_MAX) ? (v > best ? v : best) : (v < best ? v : best);
+    }
+    best = pl_wave_reduce(best, [op](T a, T b) { return (op == PL_MAX) ? (a > b ? a : b) : (a < b ? a : b); });
+    if (lane == 0) out[row] = (double)best;
+  }
+}
+
+// ------------------------------------------------------------- fused threshold + column sums
+constexpr int kBandRows = 32;
+constexpr int kTcThreads = 128;  // 128 lanes x 8 columns = 1024 columns per sweep
+
+__global__ void __launch_bounds__(kTcThreads)
+threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, int h,
+                        int w, int bands, const int32_t* __restrict__ thr,
+                        unsigned long long* __restrict__ colsum) {
+  const unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
+  const int band = id % bands;
+  const size_t frame = id / bands;
+  const int t = thr[frame];
+  const int r0 = band * kBandRows;
+  const int r1 = (r0 + kBandRows < h) ? r0 + kBandRows : h;
+  const unsigned short* f = in + frame * (size_t)h * w;
+  unsigned short* o = out + frame * (size_t)h * w;
+  unsigned long long* cs = colsum + frame * (size_t)w;
+  const bool vec = ((w & 7) == 0) && ((reinterpret_cast<uintptr_t>(f) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(o) & 15) == 0);
+  if (vec) {
+    for (int c = threadIdx.x * 8; c < w; c += kTcThreads * 8) {
+      unsigned s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = r0; r < r1; ++r) {
+        union { uint4 q; unsigned short e[8]; } u;
+        u.q = *reinterpret_cast<const uint4*>(f + (size_t)r * w + c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          unsigned short v = ((int)u.e[k] >= t) ? u.e[k] : (unsigned short)0;
+          u.e[k] = v;
+          s[k] += v;
+        }
+        *reinterpret_cast<uint4*>(o + (size_t)r * w + c) = u.q;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(cs + c + k, (unsigned long long)s[k]);
+    }
+  } else {
+    for (int c = threadIdx.x; c < w; c += kTcThreads) {
+      unsigned s = 0;
+      for (int r = r0; r < r1; ++r) {
+        unsigned short v = f[(size_t)r * w + c];
+        v = ((int)v >= t) ? v : (unsigned short)0;
+        o[(size_t)r * w + c] = v;
+        s += v;
+      }
+      atomicAdd(cs + c, (unsigned long long)s);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pl_reduce_axis(const void* in, int dtype, int64_t n, int h, int w, int axis, int op,
+                              double* d_out, void* stream) {
+  PL_REQUIRE(in && d_out, "null pointer");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");
+  PL_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
+  PL_REQUIRE(op >= PL_SUM && op <= PL_MIN, "bad op");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (axis == 0) {
+    int col_tiles = (int)pl_cdiv(w, kThreads);
+    PL_REQUIRE(n * col_tiles <= 0x7fffffffLL, "batch too large");
+    PL_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL(reduce_axis0_kernel<T>, dim3((unsigned)(n * col_tiles)),
+                                         dim3(kThreads), 0, st, (const T*)in, h, w, col_tiles, op, d_out));
+  } else {
+    int64_t rows = n * h;
+    int64_t blocks = pl_cdiv(rows, kThreads / PL_WAVE);
+    PL_REQUIRE(blocks <= 0x7fffffffLL, "batch too large");
+    PL_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL(reduce_axis1_kernel<T>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                                         st, (const T*)in, rows, w, op, d_out));
+  }
+  return pl_check_launch("pl_reduce_axis");
+}
+
+extern "C" int pl_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_t n, int h, int w,
+                                       const int32_t* d_thr, unsigned long long* d_colsum,
+                                       void* stream) {
+  PL_REQUIRE(in && out && d_thr && d_colsum, "null pointer");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_colsum, 0, (size_t)n * w * sizeof(unsigned long long), st);
+  if (e != hipSuccess) { pl_set_error("pl_threshold_colsum_u16: memset: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+  int bands = (int)pl_cdiv(h, kBandRows);
+  PL_REQUIRE(n * bands <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(threshold_colsum_kernel, dim3((unsigned)(n * bands)), dim3(kTcThreads), 0, st, in, out,
+                     h, w, bands, d_thr, d_colsum);
+  return pl_check_launch("pl_threshold_colsum_u16");
+}

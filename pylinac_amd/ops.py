@@ -1,0 +1,394 @@
+"""Batched device operators: thin, validating wrappers over the C ABI.
+
+Everything here takes and returns ``torch`` tensors resident on the GPU, laid out ``[N, H, W]``
+(frames) or ``[N, L]`` (profiles).  PyTorch is used for device memory and streams only; all
+arithmetic is in libpylinac_hip.so.  The numpy-facing mirror of the reference API
+(``pylinac_amd.array_utils`` / ``.image`` / ``.profile``) is built on these functions.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PL_F32, PL_F64, PL_I16, PL_U16, PeakParams, check
+
+_DTYPES = {torch.uint16: PL_U16, torch.int16: PL_I16, torch.float32: PL_F32, torch.float64: PL_F64}
+_REDUCE = {"sum": _lib.PL_SUM, "mean": _lib.PL_MEAN, "max": _lib.PL_MAX, "min": _lib.PL_MIN}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError(
+            f"unsupported dtype {t.dtype}; supported: uint16, int16, float32, float64"
+        ) from None
+
+
+def _frames(t: torch.Tensor) -> torch.Tensor:
+    """Validate a device batch [N,H,W] (a single [H,W] frame is viewed as N=1)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch.Tensor on a HIP device")
+    if not t.is_cuda:
+        raise ValueError("tensor must live on the GPU (no CPU fallback exists)")
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() != 3:
+        raise ValueError(f"expected [N,H,W] or [H,W]; got shape {tuple(t.shape)}")
+    if t.numel() == 0:
+        raise ValueError("Array must not be empty")
+    return t.contiguous()
+
+
+def _per_frame(v, n: int, device) -> tuple[torch.Tensor, int]:
+    """Scalar or per-frame values -> float64 device tensor + stride (0 broadcast / 1 per frame)."""
+    if isinstance(v, torch.Tensor):
+        v = v.to(device=device, dtype=torch.float64).reshape(-1).contiguous()
+        if v.numel() == 1:
+            return v, 0
+        if v.numel() != n:
+            raise ValueError(f"expected 1 or {n} per-frame values; got {v.numel()}")
+        return v, 1
+    return torch.tensor([float(v)], dtype=torch.float64, device=device), 0
+
+
+# ------------------------------------------------------------------------------------ filtering
+def gaussian_weights(sigma: float, truncate: float = 4.0) -> tuple[np.ndarray, int]:
+    """scipy's ``_gaussian_kernel1d`` (order 0) as used by ``ndimage.gaussian_filter``:
+    radius ``int(truncate*sigma + 0.5)``; host float64, formula and evaluation order identical
+    (scipy/ndimage/_filters.py)."""
+    sd = float(sigma)
+    lw = int(truncate * sd + 0.5)
+    x = np.arange(-lw, lw + 1)
+    phi = np.exp(-0.5 / (sd * sd) * x**2)
+    phi = phi / phi.sum()
+    return phi[::-1].copy(), lw
+
+
+_weights_cache: dict = {}
+
+
+def _device_weights(sigma: float, device) -> tuple[torch.Tensor, int]:
+    key = (float(sigma), str(device))
+    hit = _weights_cache.get(key)
+    if hit is None:
+        w, lw = gaussian_weights(sigma)
+        hit = (torch.from_numpy(w).to(device), lw)
+        _weights_cache[key] = hit
+    return hit
+
+
+def gaussian_filter(frames: torch.Tensor, sigma: float, out=None, tmp=None) -> torch.Tensor:
+    """``ndimage.gaussian_filter(frame, sigma)`` per frame (pylinac/core/array_utils.py:133)."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    wts, lw = _device_weights(sigma, x.device)
+    out = torch.empty_like(x) if out is None else out
+    tmp = torch.empty_like(x) if tmp is None else tmp
+    check(
+        _lib.load().pl_gaussian2d(x.data_ptr(), out.data_ptr(), tmp.data_ptr(), _dt(x), n, h, w,
+                                  wts.data_ptr(), lw, _stream()),
+        "pl_gaussian2d",
+    )
+    return out
+
+
+def gaussian_filter1d(x: torch.Tensor, sigma: float, axis: int = -1) -> torch.Tensor:
+    """One correlate1d pass.  ``x``: [N,L] profiles (axis=-1) or [N,H,W] frames (axis 0 / 1)."""
+    if x.dim() == 2 and axis in (-1, 1):
+        f = _frames(x.unsqueeze(1))  # [N,1,L]
+        ax = 1
+    else:
+        f = _frames(x)
+        ax = axis
+    n, h, w = f.shape
+    wts, lw = _device_weights(sigma, f.device)
+    out = torch.empty_like(f)
+    check(
+        _lib.load().pl_gaussian1d(f.data_ptr(), out.data_ptr(), _dt(f), n, h, w, ax, wts.data_ptr(), lw,
+                                  _stream()),
+        "pl_gaussian1d",
+    )
+    return out.reshape(x.shape)
+
+
+def median_filter(frames: torch.Tensor, size: int, out=None) -> torch.Tensor:
+    """``ndimage.median_filter(frame, size=size)`` per frame (pylinac/core/array_utils.py:131).
+    [N,L] input is filtered as N 1-D profiles."""
+    if frames.dim() == 2 and False:
+        pass
+    x = _frames(frames)
+    n, h, w = x.shape
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().pl_median2d(x.data_ptr(), out.data_ptr(), _dt(x), n, h, w, int(size), _stream()),
+          "pl_median2d")
+    return out
+
+
+def median_filter1d(profiles: torch.Tensor, size: int) -> torch.Tensor:
+    x = profiles if profiles.dim() == 2 else profiles.unsqueeze(0)
+    return median_filter(x.unsqueeze(1), size).reshape(profiles.shape)
+
+
+# -------------------------------------------------------------------------- min/max + mutators
+def minmax(frames: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    x = _frames(frames)
+    n = x.shape[0]
+    mn = torch.empty(n, dtype=torch.float64, device=x.device)
+    mx = torch.empty(n, dtype=torch.float64, device=x.device)
+    check(_lib.load().pl_minmax(x.data_ptr(), _dt(x), n, x[0].numel(), mn.data_ptr(), mx.data_ptr(), _stream()),
+          "pl_minmax")
+    return mn, mx
+
+
+def ground(frames: torch.Tensor, value: float = 0.0, mn=None) -> torch.Tensor:
+    x = _frames(frames)
+    n = x.shape[0]
+    if mn is None:
+        mn, _ = minmax(x)
+    out = torch.empty_like(x)
+    check(_lib.load().pl_ground(x.data_ptr(), out.data_ptr(), _dt(x), n, x[0].numel(), mn.data_ptr(),
+                                float(value), _stream()), "pl_ground")
+    return out
+
+
+def normalize(frames: torch.Tensor, value=None) -> torch.Tensor:
+    """``array / val`` -> float64 (float32 frames stay float32, like numpy)."""
+    x = _frames(frames)
+    n = x.shape[0]
+    if value is None:
+        _, val = minmax(x)
+    else:
+        val, stride = _per_frame(value, n, x.device)
+        if x.dtype == torch.float32:  # numpy rounds a python scalar to the array dtype (NEP 50)
+            val = val.to(torch.float32).to(torch.float64)
+        if stride == 0:
+            val = val.expand(n).contiguous()
+    out = torch.empty(x.shape, dtype=torch.float64, device=x.device)
+    check(_lib.load().pl_normalize(x.data_ptr(), out.data_ptr(), _dt(x), n, x[0].numel(), val.data_ptr(),
+                                   _stream()), "pl_normalize")
+    # float32 / float32 is float32 in numpy; rounding the float64 quotient once more is exact
+    return out.to(torch.float32) if x.dtype == torch.float32 else out
+
+
+def invert(frames: torch.Tensor) -> torch.Tensor:
+    x = _frames(frames)
+    n = x.shape[0]
+    mn, mx = minmax(x)
+    out = torch.empty_like(x)
+    check(_lib.load().pl_invert(x.data_ptr(), out.data_ptr(), _dt(x), n, x[0].numel(), mn.data_ptr(),
+                                mx.data_ptr(), _stream()), "pl_invert")
+    return out
+
+
+def threshold(frames: torch.Tensor, thr, kind: str = "high", out=None) -> torch.Tensor:
+    """``np.where(a >= t, a, 0)`` ('high') / ``np.where(a <= t, a, 0)`` (pylinac/core/image.py:797-800)."""
+    x = _frames(frames)
+    n = x.shape[0]
+    t, stride = _per_frame(thr, n, x.device)
+    if x.dtype == torch.float32 and not isinstance(thr, (torch.Tensor, np.generic)):
+        t = t.to(torch.float32).to(torch.float64)  # NEP 50: python scalar adopts the array dtype
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().pl_threshold(x.data_ptr(), out.data_ptr(), _dt(x), n, x[0].numel(), t.data_ptr(),
+                                   stride, 0 if kind == "high" else 1, _stream()), "pl_threshold")
+    return out
+
+
+def as_binary(frames: torch.Tensor, thr) -> torch.Tensor:
+    """``a >= t`` as uint8 0/1 (pylinac/core/image.py:802-815; the host mirror widens to int64)."""
+    x = _frames(frames)
+    n = x.shape[0]
+    t, stride = _per_frame(thr, n, x.device)
+    if x.dtype == torch.float32 and not isinstance(thr, (torch.Tensor, np.generic)):
+        t = t.to(torch.float32).to(torch.float64)
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(_lib.load().pl_as_binary(x.data_ptr(), out.data_ptr(), _dt(x), n, x[0].numel(), t.data_ptr(),
+                                   stride, _stream()), "pl_as_binary")
+    return out
+
+
+# ----------------------------------------------------------------- histogram / Otsu / percentile
+def histogram16(frames: torch.Tensor, out=None) -> torch.Tensor:
+    """Exact per-frame histogram of a 16-bit integer batch: uint32 [N, 65536] (stored in an int32
+    tensor; bin b = value b for uint16, value b-32768 for int16)."""
+    x = _frames(frames)
+    if x.dtype not in (torch.uint16, torch.int16):
+        raise TypeError("histogram16 needs uint16 or int16 frames")
+    n = x.shape[0]
+    out = torch.empty((n, 65536), dtype=torch.int32, device=x.device) if out is None else out
+    check(_lib.load().pl_hist16(x.data_ptr(), _dt(x), n, x[0].numel(), out.data_ptr(), _stream()), "pl_hist16")
+    return out
+
+
+def otsu_from_hist(hist: torch.Tensor, dtype: torch.dtype):
+    n = hist.shape[0]
+    thr = torch.empty(n, dtype=torch.int32, device=hist.device)
+    mn = torch.empty_like(thr)
+    mx = torch.empty_like(thr)
+    check(_lib.load().pl_otsu_from_hist(hist.data_ptr(), _DTYPES[dtype], n, thr.data_ptr(), mn.data_ptr(),
+                                        mx.data_ptr(), _stream()), "pl_otsu_from_hist")
+    return thr, mn, mx
+
+
+def threshold_otsu(frames: torch.Tensor) -> torch.Tensor:
+    """``skimage.filters.threshold_otsu`` per integer frame -> int32 [N]."""
+    x = _frames(frames)
+    return otsu_from_hist(histogram16(x), x.dtype)[0]
+
+
+def percentile(frames: torch.Tensor, q) -> torch.Tensor:
+    """``np.percentile(frame, q)`` (default linear method) per 16-bit frame -> float64 [N, len(q)].
+    The two neighbouring order statistics come from the exact device histogram; the final
+    interpolation is numpy's ``_lerp`` formula evaluated in float64 on the host."""
+    x = _frames(frames)
+    n = x.shape[0]
+    cnt = x[0].numel()
+    qs = np.atleast_1d(np.asarray(q, dtype=np.float64))
+    if np.any(qs < 0) or np.any(qs > 100):
+        raise ValueError("Percentiles must be in the range [0, 100]")
+    virt = (qs / 100.0) * (cnt - 1)  # numpy: quantile * (n - 1)
+    lo = np.floor(virt).astype(np.int64)
+    hi = np.minimum(lo + 1, cnt - 1)
+    frac = virt - lo
+    ranks = torch.from_numpy(np.concatenate([lo, hi])).to(x.device)
+    out = torch.empty((n, ranks.numel()), dtype=torch.int32, device=x.device)
+    hist = histogram16(x)
+    check(_lib.load().pl_order_stats_from_hist(hist.data_ptr(), _dt(x), n, ranks.data_ptr(), ranks.numel(),
+                                               out.data_ptr(), _stream()), "pl_order_stats_from_hist")
+    st = out.cpu().numpy().astype(np.float64)
+    a, b = st[:, : len(qs)], st[:, len(qs):]
+    d = b - a
+    res = a + d * frac
+    hi_t = frac >= 0.5
+    res = np.where(hi_t[None, :], b - d * (1 - frac), res)
+    res = np.where(d == 0, a, res)
+    return torch.from_numpy(res)
+
+
+# ------------------------------------------------------------------------------------- profiles
+def reduce_axis(frames: torch.Tensor, axis: int, op: str = "mean") -> torch.Tensor:
+    """``np.<op>(frame, axis)`` per frame -> float64 [N, W] (axis 0) or [N, H] (axis 1)."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    out = torch.empty((n, w if axis == 0 else h), dtype=torch.float64, device=x.device)
+    check(_lib.load().pl_reduce_axis(x.data_ptr(), _dt(x), n, h, w, int(axis), _REDUCE[op], out.data_ptr(),
+                                     _stream()), "pl_reduce_axis")
+    return out
+
+
+def threshold_colsum_u16(frames: torch.Tensor, thr_i32: torch.Tensor, out=None, colsum=None):
+    x = _frames(frames)
+    if x.dtype != torch.uint16:
+        raise TypeError("threshold_colsum_u16 needs uint16 frames")
+    n, h, w = x.shape
+    out = torch.empty_like(x) if out is None else out
+    colsum = torch.empty((n, w), dtype=torch.int64, device=x.device) if colsum is None else colsum
+    check(_lib.load().pl_threshold_colsum_u16(x.data_ptr(), out.data_ptr(), n, h, w, thr_i32.data_ptr(),
+                                              colsum.data_ptr(), _stream()), "pl_threshold_colsum_u16")
+    return out, colsum
+
+
+# ---------------------------------------------------------------------------------------- peaks
+PEAK_PROP_KEYS = ("peak_heights", "prominences", "widths", "width_heights", "left_ips", "right_ips")
+
+
+@dataclass
+class PeakBatch:
+    """Device-resident result of :func:`find_peaks_batch` (capacity ``cap`` per profile)."""
+
+    count: torch.Tensor       # int32 [N]
+    idx: torch.Tensor         # int32 [N, cap]
+    left_bases: torch.Tensor  # int32 [N, cap]
+    right_bases: torch.Tensor # int32 [N, cap]
+    props: torch.Tensor       # float64 [N, 6, cap] in PEAK_PROP_KEYS order
+    status: torch.Tensor      # int32 [N]: 0 ok, 1 truncated to cap, 2 too many candidate maxima
+
+    def to_host(self, i: int = 0):
+        """(peak_idxs, peak_props) for profile ``i`` in the reference's return format."""
+        st = int(self.status[i])
+        if st != 0:
+            raise _lib.PylinacHipError(
+                f"find_peaks: profile {i} overflowed the peak capacity (status {st}); raise `cap`")
+        c = int(self.count[i])
+        idx = self.idx[i, :c].cpu().numpy().astype(np.intp)
+        p = self.props[i, :, :c].cpu().numpy()
+        props = {k: p[j].copy() for j, k in enumerate(PEAK_PROP_KEYS)}
+        props["left_bases"] = self.left_bases[i, :c].cpu().numpy().astype(np.intp)
+        props["right_bases"] = self.right_bases[i, :c].cpu().numpy().astype(np.intp)
+        return idx, props
+
+
+def make_peak_params(length: int, threshold=-np.inf, peak_separation=0, max_number=None,
+                     fwxm_height: float = 0.5, min_width=0, search_region=(0.0, 1.0),
+                     peak_sort: str = "prominences", required_prominence=None) -> PeakParams:
+    """``_parse_peak_args`` (pylinac/core/profile.py:2626-2649) minus the data-dependent part
+    (the ratio threshold needs the profile's min/max and is resolved on the device)."""
+    p = PeakParams()
+    if 0 <= threshold <= 1:
+        p.threshold_is_ratio = 1
+    p.threshold = float(threshold)
+    if 0 <= peak_separation <= 1:
+        peak_separation = max(int(peak_separation * length), 1)
+    p.distance = max(int(math.ceil(peak_separation)), 1)
+    if max(search_region) <= 1:
+        lo = int(search_region[0] * length)
+        hi = int(search_region[1] * length)
+    else:
+        lo, hi = search_region[0], search_region[1]
+    sl = range(length)[lo:hi]  # python slice semantics of values[lo:hi]
+    p.region_lo = sl.start
+    p.region_hi = sl.stop if len(sl) else sl.start
+    p.has_prominence = 0 if required_prominence is None else 1
+    p.prominence_min = 0.0 if required_prominence is None else float(required_prominence)
+    p.width_min = float(min_width)
+    p.rel_height = 1 - fwxm_height
+    p.max_number = -1 if max_number is None else int(max_number)
+    if peak_sort not in _lib.PL_SORT:
+        raise KeyError(peak_sort)
+    p.sort_key = _lib.PL_SORT[peak_sort]
+    return p
+
+
+def find_peaks_batch(profiles: torch.Tensor, cap: int | None = None, **kwargs) -> PeakBatch:
+    """``pylinac.core.profile.find_peaks`` for every row of ``profiles`` [N, L] (float64)."""
+    x = profiles
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    if not x.is_cuda:
+        raise ValueError("profiles must live on the GPU")
+    if x.dtype != torch.float64:
+        x = x.to(torch.float64)
+    x = x.contiguous()
+    n, length = x.shape
+    if length == 0:
+        raise ValueError("Array must not be empty")
+    prm = make_peak_params(length, **kwargs)
+    if cap is None:
+        cap = prm.max_number if prm.max_number > 0 else max((prm.region_hi - prm.region_lo) // 2 + 1, 1)
+        cap = max(cap, 1)
+    dev = x.device
+    res = PeakBatch(
+        count=torch.empty(n, dtype=torch.int32, device=dev),
+        idx=torch.empty((n, cap), dtype=torch.int32, device=dev),
+        left_bases=torch.empty((n, cap), dtype=torch.int32, device=dev),
+        right_bases=torch.empty((n, cap), dtype=torch.int32, device=dev),
+        props=torch.empty((n, 6, cap), dtype=torch.float64, device=dev),
+        status=torch.empty(n, dtype=torch.int32, device=dev),
+    )
+    check(
+        _lib.load().pl_find_peaks(x.data_ptr(), n, length, x.stride(0), C.byref(prm), cap,
+                                  res.count.data_ptr(), res.idx.data_ptr(), res.left_bases.data_ptr(),
+                                  res.right_bases.data_ptr(), res.props.data_ptr(), res.status.data_ptr(),
+                                  _stream()),
+        "pl_find_peaks",
+    )
+    return res
