@@ -39,7 +39,9 @@ typedef enum pl_dtype {
   PL_I16 = 1,
   PL_F32 = 2,
   PL_F64 = 3,
-  PL_U8 = 4
+  PL_U8 = 4,
+  PL_I32 = 5,
+  PL_I64 = 6
 } pl_dtype;
 
 typedef enum pl_reduce_op { PL_SUM = 0, PL_MEAN = 1, PL_MAX = 2, PL_MIN = 3 } pl_reduce_op;
@@ -82,6 +84,10 @@ int pl_normalize(const void* in, double* out, int dtype, int64_t n, int64_t coun
 int pl_invert(const void* in, void* out, int dtype, int64_t n, int64_t count, const double* d_min,
               const double* d_max, void* stream);
 
+/* out = a * factor   (same dtype; the multiply inside stretch(), array_utils.py:168) */
+int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,
+             void* stream);
+
 /* ---- a3: BaseImage.threshold / as_binary (pylinac/core/image.py:785-815) ------------------------
  * kind 0 ('high'): out = a >= t ? a : 0 ; kind 1 ('low'): out = a <= t ? a : 0.
  * d_thr holds one float64 threshold per frame (thr_stride 1) or one for all (thr_stride 0). */
@@ -115,6 +121,10 @@ int pl_reduce_axis(const void* in, int dtype, int64_t n, int h, int w, int axis,
 int pl_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_t n, int h, int w,
                             const int32_t* d_thr, unsigned long long* d_colsum, void* stream);
 
+/* d_out[n][w] = d_colsum[n][w] / h in float64: the np.mean(axis=0) profile of an integer frame. */
+int pl_colsum_to_mean(const unsigned long long* d_colsum, int64_t n, int w, int h, double* d_out,
+                      void* stream);
+
 /* ---- a8-a10: pylinac.core.profile.find_peaks over scipy.signal.find_peaks -----------------------
  * (pylinac/core/profile.py:2545-2649).  One 1-D float64 profile per batch item. */
 typedef struct pl_peak_params {
@@ -140,6 +150,13 @@ typedef struct pl_peak_params {
 int pl_find_peaks(const double* d_x, int64_t n, int len, int64_t stride, const pl_peak_params* params,
                   int cap, int32_t* d_count, int32_t* d_idx, int32_t* d_left_base,
                   int32_t* d_right_base, double* d_props, int32_t* d_status, void* stream);
+
+/* FWXMProfile.field_edge_idx/center_idx/field_width_px (pylinac/core/profile.py:602-611, 322-344)
+ * from a pl_find_peaks result obtained with max_number = 1:
+ * d_out float64 [n][8] = n_peaks, peak_idx, height, prominence, left, right, centre, width
+ * (NaN-filled when a profile has no peak; the reference raises IndexError there). */
+int pl_fwxm_record(const int32_t* d_count, const int32_t* d_idx, const double* d_props, int cap,
+                   int64_t n, double* d_out, void* stream);
 
 #ifdef __cplusplus
 }

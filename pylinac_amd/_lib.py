@@ -36,7 +36,7 @@ class PeakParams(C.Structure):
 
 
 # dtype / enum values of the header
-PL_U16, PL_I16, PL_F32, PL_F64, PL_U8 = 0, 1, 2, 3, 4
+PL_U16, PL_I16, PL_F32, PL_F64, PL_U8, PL_I32, PL_I64 = 0, 1, 2, 3, 4, 5, 6
 PL_SUM, PL_MEAN, PL_MAX, PL_MIN = 0, 1, 2, 3
 PL_SORT = {"prominences": 0, "peak_heights": 1, "widths": 2}
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     "pl_ground": ([_p, _p, _i, _l, _l, _p, _d, _p], C.c_int),
     "pl_normalize": ([_p, _p, _i, _l, _l, _p, _p], C.c_int),
     "pl_invert": ([_p, _p, _i, _l, _l, _p, _p, _p], C.c_int),
+    "pl_scale": ([_p, _p, _i, _l, _l, _d, _p], C.c_int),
     "pl_threshold": ([_p, _p, _i, _l, _l, _p, _i, _i, _p], C.c_int),
     "pl_as_binary": ([_p, _p, _i, _l, _l, _p, _i, _p], C.c_int),
     "pl_hist16": ([_p, _i, _l, _l, _p, _p], C.c_int),
@@ -65,6 +66,8 @@ SIGNATURES = {
     "pl_order_stats_from_hist": ([_p, _i, _l, _p, _i, _p, _p], C.c_int),
     "pl_reduce_axis": ([_p, _i, _l, _i, _i, _i, _i, _p, _p], C.c_int),
     "pl_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
+    "pl_colsum_to_mean": ([_p, _l, _i, _i, _p, _p], C.c_int),
+    "pl_fwxm_record": ([_p, _p, _p, _i, _l, _p, _p], C.c_int),
     "pl_find_peaks": (
         [_p, _l, _i, _l, C.POINTER(PeakParams), _i, _p, _p, _p, _p, _p, _p, _p],
         C.c_int,

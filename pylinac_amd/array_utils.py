@@ -1,0 +1,151 @@
+"""Drop-in mirror of ``pylinac.core.array_utils`` for the hot-path functions
+(pylinac/core/array_utils.py:63-168): same names, argument meaning and error behaviour, with the
+arithmetic done by libpylinac_hip.so on the GPU.
+
+Inputs may be numpy arrays (1-D profiles or 2-D frames; the result is a numpy array, as in the
+reference) or ``torch`` tensors already on the GPU (``[H,W]`` / ``[N,H,W]``; the result stays on
+the device -- the batched fast path).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+_NP_OK = (np.uint8, np.uint16, np.int16, np.int32, np.int64, np.float32, np.float64)
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "pylinac_amd needs a HIP device (torch.cuda.is_available() is False); "
+            "there is no CPU fallback by design"
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def array_not_empty(array) -> None:
+    """pylinac/core/array_utils.py:23-26."""
+    size = array.numel() if isinstance(array, torch.Tensor) else np.asarray(array).size
+    if not size:
+        raise ValueError("Array must not be empty")
+
+
+class _Staged:
+    """numpy <-> device staging: 1-D -> [1,1,L], 2-D -> [1,H,W]; tensors pass through."""
+
+    def __init__(self, array):
+        array_not_empty(array)
+        self.is_tensor = isinstance(array, torch.Tensor)
+        if self.is_tensor:
+            self.ndim = array.dim()
+            self.t = array
+            return
+        a = np.asarray(array)
+        if a.dtype.type not in _NP_OK:
+            if a.dtype == np.bool_:
+                a = a.astype(np.uint8)
+            elif a.dtype.kind in "iu":
+                a = a.astype(np.int64)
+            else:
+                raise TypeError(f"unsupported dtype {a.dtype}")
+        if a.ndim not in (1, 2):
+            raise ValueError(f"expected a 1-D profile or 2-D frame; got {a.ndim}-D")
+        self.ndim = a.ndim
+        self.shape = a.shape
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a).to(_device())
+        self.t = t.reshape(1, 1, -1) if a.ndim == 1 else t.unsqueeze(0)
+
+    def out(self, t: torch.Tensor):
+        if self.is_tensor:
+            return t.reshape(self.t.shape) if t.numel() == self.t.numel() else t
+        return t.cpu().numpy().reshape(self.shape)
+
+
+def resolve_filter_size(length: int, size):
+    """pylinac/core/array_utils.py:124-129: float in (0,1) -> int(round(len*size)) >= 1."""
+    if isinstance(size, float):
+        if 0 < size < 1:
+            size = int(round(length * size))
+            size = max(size, 1)
+        else:
+            raise ValueError("Float was passed but was not between 0 and 1")
+    return size
+
+
+def filter(array, size=0.05, kind: str = "median"):
+    """Mirror of ``pylinac.core.array_utils.filter`` (array_utils.py:105-138).
+    ``len(array)`` (the ROW count of a 2-D frame) scales a float ``size``."""
+    s = _Staged(array)
+    if s.is_tensor:
+        length = s.t.shape[-2] if s.t.dim() >= 2 else s.t.shape[0]
+    else:
+        length = s.shape[0]
+    size = resolve_filter_size(length, size)
+    if kind == "median":
+        return s.out(ops.median_filter(s.t, int(size)))
+    elif kind == "gaussian":
+        t = s.t
+        if t.dim() == 3 and t.shape[1] == 1:  # 1-D profile: a single pass along the data axis
+            return s.out(ops.gaussian_filter1d(t, size, axis=1))
+        return s.out(ops.gaussian_filter(t, size))
+    raise ValueError(f"Filter type {kind} unsupported. Use one of 'median', 'gaussian'")
+
+
+def normalize(array, value=None):
+    """array_utils.py:63-71."""
+    s = _Staged(array)
+    return s.out(ops.normalize(s.t, value))
+
+
+def invert(array):
+    """array_utils.py:74-77."""
+    s = _Staged(array)
+    return s.out(ops.invert(s.t))
+
+
+def ground(array, value: float = 0):
+    """array_utils.py:92-102."""
+    s = _Staged(array)
+    return s.out(ops.ground(s.t, value))
+
+
+def stretch(array, min: int = 0, max: int = 1):
+    """array_utils.py:141-168: ``ground(normalize(ground(a)) * (max-min), value=min)``."""
+    if max <= min:
+        raise ValueError(f"Max must be larger than min. Passed max of {max} was <= {min}")
+    a = array if isinstance(array, torch.Tensor) else np.asarray(array)
+    info_dtype = a.cpu().numpy().dtype if isinstance(a, torch.Tensor) else a.dtype
+    info = np.iinfo(info_dtype) if info_dtype.kind in "iu" else np.finfo(info_dtype)
+    if max > info.max:
+        raise ValueError(f"Max of {max} was larger than the allowed datatype maximum of {info.max}")
+    if min < info.min:
+        raise ValueError(f"Min of {min} was smaller than the allowed datatype minimum of {info.min}")
+    s = _Staged(array)
+    g = ops.ground(s.t)
+    nrm = ops.normalize(g)
+    scaled = ops.scale(nrm, float(max - min))
+    return s.out(ops.ground(scaled, value=float(min)))
+
+
+def geometric_center_idx(array) -> float:
+    """array_utils.py:37-44 (pure index arithmetic)."""
+    a = np.asarray(array)
+    array_not_empty(a)
+    if a.ndim > 1:
+        raise ValueError(f"Array was multidimensional. Must pass 1D array; found {a.ndim}")
+    return (a.shape[0] - 1) / 2.0
+
+
+def geometric_center_value(array) -> float:
+    """array_utils.py:47-60."""
+    a = np.asarray(array)
+    array_not_empty(a)
+    if a.ndim > 1:
+        raise ValueError(f"Array was multidimensional. Must pass 1D array; found {a.ndim}")
+    n = a.shape[0]
+    if n % 2 == 0:
+        return (a[int(n / 2)] + a[int(n / 2) - 1]) / 2.0
+    return a[int((n - 1) / 2)]

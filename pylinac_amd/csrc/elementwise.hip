@@ -5,6 +5,7 @@
 //   pl_ground      array - array.min() + value              pylinac/core/array_utils.py:92-102
 //   pl_normalize   array / val   (-> float64)               pylinac/core/array_utils.py:63-71
 //   pl_invert      -array + array.max() + array.min()       pylinac/core/array_utils.py:74-77
+//   pl_scale       array * scalar  (stretch)                pylinac/core/array_utils.py:168
 //   pl_threshold   np.where(a >= t, a, 0) / (a <= t)        pylinac/core/image.py:785-800
 //   pl_as_binary   np.where(a >= t, 1, 0)                   pylinac/core/image.py:802-815
 //
@@ -18,6 +19,9 @@ constexpr int kThreads = 256;
 constexpr int kChunkBytes = 64 * 1024;  // bytes of input one block streams
 
 template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };
+template <typename T> struct is_floating { static constexpr bool value = false; };
+template <> struct is_floating<float> { static constexpr bool value = true; };
+template <> struct is_floating<double> { static constexpr bool value = true; };
 
 struct Plan { int64_t chunk; int bpf; };  // elements per block, blocks per frame
 
@@ -126,9 +130,9 @@ __global__ void __launch_bounds__(kThreads)
 ground_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int64_t chunk, int bpf,
               const double* __restrict__ mn, double value) {
   stream_chunk<T, T>(in, out, count, chunk, bpf, [=](T a, int64_t fr) -> T {
-    if constexpr (sizeof(T) == 2) {
-      // numpy: uint16/int16 array - same-dtype scalar (+ python int 0): modular arithmetic
-      int v = (int)a - (int)mn[fr] + (int)value;
+    if constexpr (!is_floating<T>::value) {
+      // numpy: integer array - same-dtype scalar (+ python int): modular arithmetic in the dtype
+      long long v = (long long)a - (long long)mn[fr] + (long long)value;
       return (T)v;
     } else {
       return (T)(a - (T)mn[fr] + (T)value);
@@ -149,12 +153,22 @@ __global__ void __launch_bounds__(kThreads)
 invert_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int64_t chunk, int bpf,
               const double* __restrict__ mn, const double* __restrict__ mx) {
   stream_chunk<T, T>(in, out, count, chunk, bpf, [=](T a, int64_t fr) -> T {
-    if constexpr (sizeof(T) == 2) {
-      int v = -(int)a + (int)mx[fr] + (int)mn[fr];  // modular in the 16-bit dtype, like numpy
+    if constexpr (!is_floating<T>::value) {
+      long long v = -(long long)a + (long long)mx[fr] + (long long)mn[fr];  // modular, like numpy
       return (T)v;
     } else {
       return (T)((-a + (T)mx[fr]) + (T)mn[fr]);
     }
+  });
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+scale_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int64_t chunk, int bpf,
+             double factor) {
+  stream_chunk<T, T>(in, out, count, chunk, bpf, [=](T a, int64_t) -> T {
+    if constexpr (is_floating<T>::value) return (T)(a * (T)factor);
+    else return (T)((long long)a * (long long)factor);
   });
 }
 
@@ -244,6 +258,18 @@ extern "C" int pl_invert(const void* in, void* out, int dtype, int64_t n, int64_
                        (T*)out, count, p.chunk, p.bpf, d_min, d_max);
   });
   return pl_check_launch("pl_invert");
+}
+
+extern "C" int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,
+                        void* stream) {
+  PL_EW_PROLOGUE("pl_scale");
+  PL_DISPATCH_DTYPE(dtype, T, {
+    Plan p = make_plan<T>(count);
+    if (int rc = check_grid(n, p.bpf, "pl_scale")) return rc;
+    hipLaunchKernelGGL(scale_kernel<T>, dim3((unsigned)(n * p.bpf)), dim3(kThreads), 0, st, (const T*)in,
+                       (T*)out, count, p.chunk, p.bpf, factor);
+  });
+  return pl_check_launch("pl_scale");
 }
 
 extern "C" int pl_threshold(const void* in, void* out, int dtype, int64_t n, int64_t count,

@@ -31,6 +31,21 @@ template <> struct Key<short> {
   __device__ static K enc(short v) { return (unsigned int)((int)v + 32768); }
   __device__ static short dec(K k) { return (short)((int)k - 32768); }
 };
+template <> struct Key<unsigned char> {
+  using K = unsigned int; static constexpr int bits = 8;
+  __device__ static K enc(unsigned char v) { return v; }
+  __device__ static unsigned char dec(K k) { return (unsigned char)k; }
+};
+template <> struct Key<int> {
+  using K = unsigned int; static constexpr int bits = 32;
+  __device__ static K enc(int v) { return (unsigned int)v ^ 0x80000000u; }
+  __device__ static int dec(K k) { return (int)(k ^ 0x80000000u); }
+};
+template <> struct Key<long long> {
+  using K = unsigned long long; static constexpr int bits = 64;
+  __device__ static K enc(long long v) { return (unsigned long long)v ^ 0x8000000000000000ull; }
+  __device__ static long long dec(K k) { return (long long)(k ^ 0x8000000000000000ull); }
+};
 template <> struct Key<float> {
   using K = unsigned int; static constexpr int bits = 32;
   __device__ static K enc(float v) {

@@ -284,7 +284,44 @@ find_peaks_kernel(const double* __restrict__ x, int len, int64_t stride, pl_peak
   }
 }
 
+// FWXMProfile.field_edge_idx / center_idx / field_width_px from the single most prominent peak
+// (pylinac/core/profile.py:602-611, 322-327, 339-344): record = {n_peaks, peak_idx, height,
+// prominence, left, right, |r-l|/2+l, max(r,l)-min(r,l)}; NaN when the profile has no peak.
+__global__ void fwxm_record_kernel(const int32_t* __restrict__ count, const int32_t* __restrict__ idx,
+                                   const double* __restrict__ props, int cap, int64_t n,
+                                   double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double* o = out + i * 8;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  const int c = count[i];
+  o[0] = (double)c;
+  if (c <= 0) {
+    for (int k = 1; k < 8; ++k) o[k] = nan;
+    return;
+  }
+  const double* p = props + i * 6 * (int64_t)cap;
+  const double l = p[4 * cap], r = p[5 * cap];
+  o[1] = (double)idx[i * cap];
+  o[2] = p[0];
+  o[3] = p[1 * cap];
+  o[4] = l;
+  o[5] = r;
+  o[6] = fabs(r - l) / 2 + l;
+  o[7] = (r > l ? r : l) - (r < l ? r : l);
+}
+
 }  // namespace
+
+extern "C" int pl_fwxm_record(const int32_t* d_count, const int32_t* d_idx, const double* d_props,
+                              int cap, int64_t n, double* d_out, void* stream) {
+  PL_REQUIRE(d_count && d_idx && d_props && d_out, "null pointer");
+  PL_REQUIRE(n >= 0 && cap > 0, "bad shape");
+  if (n == 0) return PL_OK;
+  hipLaunchKernelGGL(fwxm_record_kernel, dim3((unsigned)pl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_count, d_idx, d_props, cap, n, d_out);
+  return pl_check_launch("pl_fwxm_record");
+}
 
 extern "C" int pl_find_peaks(const double* d_x, int64_t n, int len, int64_t stride,
                              const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,

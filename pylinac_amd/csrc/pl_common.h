@@ -61,6 +61,14 @@ __device__ __forceinline__ double pl_from_double<double>(double v) {
   return v;
 }
 template <>
+__device__ __forceinline__ int pl_from_double<int>(double v) {
+  return (int)v;
+}
+template <>
+__device__ __forceinline__ long long pl_from_double<long long>(double v) {
+  return (long long)v;
+}
+template <>
 __device__ __forceinline__ unsigned char pl_from_double<unsigned char>(double v) {
   return (unsigned char)(unsigned int)v;
 }
@@ -80,6 +88,9 @@ __device__ __forceinline__ T pl_wave_reduce(T v, F f) {
     case PL_I16: { using T = short; __VA_ARGS__; break; }        \
     case PL_F32: { using T = float; __VA_ARGS__; break; }        \
     case PL_F64: { using T = double; __VA_ARGS__; break; }       \
+    case PL_U8: { using T = unsigned char; __VA_ARGS__; break; } \
+    case PL_I32: { using T = int; __VA_ARGS__; break; }          \
+    case PL_I64: { using T = long long; __VA_ARGS__; break; }    \
     default:                                                     \
       pl_set_error("%s: unsupported dtype %d", __func__, (int)(dtype)); \
       return PL_ERR_UNSUPPORTED;                                 \

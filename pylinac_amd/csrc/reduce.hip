@@ -21,12 +21,15 @@ constexpr int kThreads = 256;
 template <typename T> struct Acc { using type = long long; };
 template <> struct Acc<float> { using type = float; };
 template <> struct Acc<double> { using type = double; };
+template <typename A> struct AccIsFloat { static constexpr bool value = false; };
+template <> struct AccIsFloat<float> { static constexpr bool value = true; };
+template <> struct AccIsFloat<double> { static constexpr bool value = true; };
 
 template <typename T>
 __device__ __forceinline__ double finish(typename Acc<T>::type acc, int op, int count) {
   using A = typename Acc<T>::type;
   if (op == PL_MEAN) {
-    if constexpr (sizeof(T) == 2) return (double)acc / (double)count;  // float64 mean of integers
+    if constexpr (!AccIsFloat<A>::value) return (double)acc / (double)count;  // float64 mean of integers
     else return (double)(A)(acc / (A)count);                            // mean in the frame's precision
   }
   return (double)acc;
@@ -131,7 +134,24 @@ threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* _
   }
 }
 
+__global__ void colsum_to_mean_kernel(const unsigned long long* __restrict__ cs, int64_t total, int h,
+                                      double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) out[i] = (double)cs[i] / (double)h;  // np.mean of integers: float64 sum / count
+}
+
 }  // namespace
+
+extern "C" int pl_colsum_to_mean(const unsigned long long* d_colsum, int64_t n, int w, int h,
+                                 double* d_out, void* stream) {
+  PL_REQUIRE(d_colsum && d_out, "null pointer");
+  PL_REQUIRE(n >= 0 && w > 0 && h > 0, "bad shape");
+  if (n == 0) return PL_OK;
+  const int64_t total = n * w;
+  hipLaunchKernelGGL(colsum_to_mean_kernel, dim3((unsigned)pl_cdiv(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_colsum, total, h, d_out);
+  return pl_check_launch("pl_colsum_to_mean");
+}
 
 extern "C" int pl_reduce_axis(const void* in, int dtype, int64_t n, int h, int w, int axis, int op,
                               double* d_out, void* stream) {

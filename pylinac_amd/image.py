@@ -1,0 +1,229 @@
+"""Mirror of the image classes on the hot path: ``pylinac.core.image.BaseImage`` mutators
+(pylinac/core/image.py:695-926) on a numpy-backed :class:`ArrayImage` (drop-in for
+``pylinac.core.image.ArrayImage``, image.py:1815-1869) and on a device-resident
+:class:`ImageBatch` ``[N,H,W]`` -- the batched fast path the reference does not have.
+
+``ArrayImage.array`` stays a public, mutable numpy attribute that every mutator REBINDS
+(``self.array = f(self.array)``), exactly like the reference, so analyzer code that reads
+``image.array``, indexes ``image[t:b, l:r]`` or passes the object to numpy keeps working.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import array_utils as au
+from . import ops
+
+MM_PER_INCH = 25.4
+
+
+class _MutatorMixin:
+    """The reference's in-place API; subclasses provide ``array`` (numpy or device tensor)."""
+
+    def filter(self, size=0.05, kind: str = "median") -> None:
+        """image.py:695-712."""
+        self.array = au.filter(self.array, size=size, kind=kind)
+
+    def invert(self) -> None:
+        """image.py:755-757."""
+        self.array = au.invert(self.array)
+
+    def normalize(self, norm_val=None) -> None:
+        """image.py:855-866 ("max" is the backwards-compatible alias of None)."""
+        if isinstance(norm_val, str) and norm_val == "max":
+            norm_val = None
+        self.array = au.normalize(self.array, value=norm_val)
+
+
+class ArrayImage(_MutatorMixin):
+    """An image constructed solely from a numpy array (image.py:1815-1869), GPU-computed."""
+
+    def __init__(self, array, *, dpi: float = None, sid: float = None, dtype=None):
+        if dtype is not None:
+            self.array = np.array(array, dtype=dtype)
+        else:
+            self.array = np.asarray(array)
+        self._dpi = dpi
+        self.sid = sid
+        self.metrics = []
+        self.metric_values = {}
+
+    # -- geometry / numpy protocol (image.py:1062-1102, 1851-1866)
+    @property
+    def dpi(self):
+        dpi = None
+        if self._dpi is not None:
+            dpi = self._dpi
+            if self.sid is not None:
+                dpi *= self.sid / 1000
+        return dpi
+
+    @property
+    def dpmm(self):
+        try:
+            return self.dpi / MM_PER_INCH
+        except Exception:
+            return None
+
+    @property
+    def shape(self):
+        return self.array.shape
+
+    @property
+    def size(self):
+        return self.array.size
+
+    @property
+    def ndim(self):
+        return self.array.ndim
+
+    @property
+    def dtype(self):
+        return self.array.dtype
+
+    def sum(self):
+        return self.array.sum()
+
+    def ravel(self):
+        return self.array.ravel()
+
+    def __len__(self):
+        return len(self.array)
+
+    def __getitem__(self, item):
+        return self.array[item]
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.array, dtype=dtype)
+
+    def __sub__(self, other):
+        return ArrayImage(self.array - other.array)
+
+    # -- mutators with reference-specific return values
+    def threshold(self, threshold: float, kind: str = "high") -> None:
+        """image.py:785-800: ``np.where(a >= t, a, 0)`` / ``np.where(a <= t, a, 0)``."""
+        s = au._Staged(self.array)
+        self.array = s.out(ops.threshold(s.t, threshold, kind))
+
+    def as_binary(self, threshold) -> "ArrayImage":
+        """image.py:802-815 -> new ArrayImage of int64 0/1."""
+        s = au._Staged(self.array)
+        return ArrayImage(s.out(ops.as_binary(s.t, threshold)).astype(np.int64))
+
+    def ground(self) -> float:
+        """image.py:839-853: returns the amount subtracted."""
+        min_val = self.array.min()
+        self.array = au.ground(self.array)
+        return min_val
+
+    def crop(self, pixels: int = 15, edges=("top", "bottom", "left", "right")) -> None:
+        """image.py:714-745 (pure slicing; stays on the host)."""
+        if pixels < 0:
+            raise ValueError("Pixels to remove must be a positive number")
+        if pixels == 0:
+            return
+        if "top" in edges:
+            self.array = self.array[pixels:, :]
+        if "bottom" in edges:
+            self.array = self.array[:-pixels, :]
+        if "left" in edges:
+            self.array = self.array[:, pixels:]
+        if "right" in edges:
+            self.array = self.array[:, :-pixels]
+        if self.array.size == 0:
+            raise ValueError("Too many pixels removed; array is empty. Pass a smaller crop value.")
+
+    def flipud(self) -> None:
+        self.array = np.flipud(self.array)
+
+    def fliplr(self) -> None:
+        self.array = np.fliplr(self.array)
+
+    def rot90(self, n: int = 1) -> None:
+        self.array = np.rot90(self.array, n)
+
+    def roll(self, direction: str = "x", amount: int = 1) -> None:
+        self.array = np.roll(self.array, amount, axis=1 if direction == "x" else 0)
+
+    def check_inversion_by_histogram(self, percentiles=(5, 50, 95)) -> bool:
+        """image.py:899-926: invert when |p_mid - p_low| > |p_mid - p_high|.  For 16-bit frames the
+        percentiles come from the exact device histogram."""
+        a = self.array
+        if a.dtype in (np.uint16, np.int16):
+            s = au._Staged(a)
+            p_low, p_mid, p_high = ops.percentile(s.t, list(percentiles))[0].tolist()
+        else:
+            raise TypeError("check_inversion_by_histogram needs a 16-bit integer frame on this backend")
+        if abs(p_mid - p_low) > abs(p_mid - p_high):
+            self.invert()
+            return True
+        return False
+
+    def profile(self, axis: int = 0, kind: str = "mean") -> np.ndarray:
+        """EXTENSION (the reference has no ``Image.profile()``): the axis
+        reductions the analyzers write by hand -- ``np.mean(image, axis)`` picketfence.py:747-750,
+        ``np.max`` starshot.py:216-217, ``np.sum`` picketfence.py:1513-1514."""
+        s = au._Staged(self.array)
+        out = ops.reduce_axis(s.t, axis, kind)[0].cpu().numpy()
+        if kind in ("max", "min"):
+            return out.astype(self.array.dtype)
+        if kind == "sum" and self.array.dtype.kind in "iu":
+            return out.astype(np.uint64 if self.array.dtype.kind == "u" else np.int64)
+        if self.array.dtype == np.float32:
+            return out.astype(np.float32)
+        return out
+
+
+class ImageBatch:
+    """``[N,H,W]`` frames resident in HBM; the reference's mutator names applied to every frame.
+    Per-frame scalars come back as device tensors; nothing leaves the GPU unless asked."""
+
+    def __init__(self, frames: torch.Tensor):
+        if not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.dim() != 3:
+            raise ValueError("ImageBatch needs a [N,H,W] tensor on the GPU")
+        if frames.numel() == 0:
+            raise ValueError("Array must not be empty")
+        self.array = frames.contiguous()
+
+    @property
+    def shape(self):
+        return tuple(self.array.shape)
+
+    def __len__(self):
+        return self.array.shape[0]
+
+    def filter(self, size=0.05, kind: str = "median") -> None:
+        size = au.resolve_filter_size(self.array.shape[1], size)
+        if kind == "median":
+            self.array = ops.median_filter(self.array, int(size))
+        elif kind == "gaussian":
+            self.array = ops.gaussian_filter(self.array, size)
+        else:
+            raise ValueError(f"Filter type {kind} unsupported. Use one of 'median', 'gaussian'")
+
+    def threshold(self, threshold, kind: str = "high") -> None:
+        self.array = ops.threshold(self.array, threshold, kind)
+
+    def as_binary(self, threshold) -> torch.Tensor:
+        return ops.as_binary(self.array, threshold)
+
+    def ground(self) -> torch.Tensor:
+        mn, _ = ops.minmax(self.array)
+        self.array = ops.ground(self.array, mn=mn)
+        return mn
+
+    def normalize(self, norm_val=None) -> None:
+        self.array = ops.normalize(self.array, None if norm_val in (None, "max") else norm_val)
+
+    def invert(self) -> None:
+        self.array = ops.invert(self.array)
+
+    def otsu(self) -> torch.Tensor:
+        return ops.threshold_otsu(self.array)
+
+    def percentile(self, q) -> torch.Tensor:
+        return ops.percentile(self.array, q)
+
+    def profile(self, axis: int = 0, kind: str = "mean") -> torch.Tensor:
+        return ops.reduce_axis(self.array, axis, kind)

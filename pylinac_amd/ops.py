@@ -15,9 +15,10 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import PL_F32, PL_F64, PL_I16, PL_U16, PeakParams, check
+from ._lib import PL_F32, PL_F64, PL_I16, PL_I32, PL_I64, PL_U8, PL_U16, PeakParams, check
 
-_DTYPES = {torch.uint16: PL_U16, torch.int16: PL_I16, torch.float32: PL_F32, torch.float64: PL_F64}
+_DTYPES = {torch.uint16: PL_U16, torch.int16: PL_I16, torch.float32: PL_F32, torch.float64: PL_F64,
+           torch.uint8: PL_U8, torch.int32: PL_I32, torch.int64: PL_I64}
 _REDUCE = {"sum": _lib.PL_SUM, "mean": _lib.PL_MEAN, "max": _lib.PL_MAX, "min": _lib.PL_MIN}
 
 
@@ -30,7 +31,7 @@ def _dt(t: torch.Tensor) -> int:
         return _DTYPES[t.dtype]
     except KeyError:
         raise TypeError(
-            f"unsupported dtype {t.dtype}; supported: uint16, int16, float32, float64"
+            f"unsupported dtype {t.dtype}; supported: uint8, uint16, int16, int32, int64, float32, float64"
         ) from None
 
 
@@ -187,6 +188,15 @@ def invert(frames: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(x)
     check(_lib.load().pl_invert(x.data_ptr(), out.data_ptr(), _dt(x), n, x[0].numel(), mn.data_ptr(),
                                 mx.data_ptr(), _stream()), "pl_invert")
+    return out
+
+
+def scale(frames: torch.Tensor, factor: float) -> torch.Tensor:
+    """``array * scalar`` in the array's dtype (the multiply inside ``stretch``)."""
+    x = _frames(frames)
+    out = torch.empty_like(x)
+    check(_lib.load().pl_scale(x.data_ptr(), out.data_ptr(), _dt(x), x.shape[0], x[0].numel(), float(factor),
+                               _stream()), "pl_scale")
     return out
 
 
@@ -392,3 +402,13 @@ def find_peaks_batch(profiles: torch.Tensor, cap: int | None = None, **kwargs) -
         "pl_find_peaks",
     )
     return res
+
+
+def fwxm_record(res: PeakBatch, out=None) -> torch.Tensor:
+    """FWXMProfile edges / centre / width from a ``max_number=1`` peak batch -> float64 [N, 8]."""
+    n = res.count.shape[0]
+    cap = res.idx.shape[1]
+    out = torch.empty((n, 8), dtype=torch.float64, device=res.count.device) if out is None else out
+    check(_lib.load().pl_fwxm_record(res.count.data_ptr(), res.idx.data_ptr(), res.props.data_ptr(), cap, n,
+                                     out.data_ptr(), _stream()), "pl_fwxm_record")
+    return out

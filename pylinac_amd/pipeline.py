@@ -1,0 +1,124 @@
+"""Batched EPID pipeline = BASELINE.json's metric: filter -> threshold -> profile -> peak.
+
+Per frame (SURVEY.md section 8d config #2 composed with rows a7/a8/a10):
+
+    Image.filter(5, "gaussian")      pylinac/core/image.py:695-712 -> array_utils.py:133
+    Image.filter(3, "median")        pylinac/core/image.py:695-712 -> array_utils.py:131
+    t = threshold_otsu(frame)        skimage semantics (pylinac/ct.py:3323)
+    Image.threshold(t, "high")       pylinac/core/image.py:785-800
+    profile = np.mean(frame, 0)      pylinac/picketfence.py:747-750
+    FWXMProfile(profile) edges/centre/width   pylinac/core/profile.py:578-611, 322-344
+
+All buffers are allocated once (workspace), every stage is a stream-ordered launch through the
+C ABI; nothing returns to the host inside ``run``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+RECORD_FIELDS = ("otsu_threshold", "n_peaks", "peak_idx", "peak_height", "prominence",
+                 "left_edge", "right_edge", "center", "width")
+
+STAGES = ("gauss_v", "gauss_h", "median3", "hist16", "otsu", "threshold_colsum", "colsum_to_mean",
+          "find_peaks", "fwxm_record")
+
+
+@dataclass
+class EpidResult:
+    frames: torch.Tensor     # uint16 [N,H,W]  thresholded frames
+    profile: torch.Tensor    # float64 [N,W]   column-mean profile
+    threshold: torch.Tensor  # int32 [N]       Otsu threshold
+    fwxm: torch.Tensor       # float64 [N,8]   ops.fwxm_record fields
+    status: torch.Tensor     # int32 [N]       0 = ok (find_peaks capacity status)
+
+    def record(self) -> torch.Tensor:
+        """float64 [N, 9] per-image scalar record (RECORD_FIELDS) -- what is all-gathered."""
+        return torch.cat([self.threshold.to(torch.float64)[:, None], self.fwxm], dim=1)
+
+
+@dataclass
+class EpidPipeline:
+    n: int
+    h: int
+    w: int
+    device: torch.device
+    sigma: float = 5
+    median_size: int = 3
+    fwxm_height: float = 50
+    timings: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        dev = self.device
+        n, h, w = self.n, self.h, self.w
+        u16 = dict(dtype=torch.uint16, device=dev)
+        self.buf_a = torch.empty((n, h, w), **u16)
+        self.buf_b = torch.empty((n, h, w), **u16)
+        self.out = torch.empty((n, h, w), **u16)
+        self.hist = torch.empty((n, 65536), dtype=torch.int32, device=dev)
+        self.thr = torch.empty(n, dtype=torch.int32, device=dev)
+        self.vmin = torch.empty(n, dtype=torch.int32, device=dev)
+        self.vmax = torch.empty(n, dtype=torch.int32, device=dev)
+        self.colsum = torch.empty((n, w), dtype=torch.int64, device=dev)
+        self.profile = torch.empty((n, w), dtype=torch.float64, device=dev)
+        self.fwxm = torch.empty((n, 8), dtype=torch.float64, device=dev)
+        self.peaks = ops.PeakBatch(
+            count=torch.empty(n, dtype=torch.int32, device=dev),
+            idx=torch.empty((n, 1), dtype=torch.int32, device=dev),
+            left_bases=torch.empty((n, 1), dtype=torch.int32, device=dev),
+            right_bases=torch.empty((n, 1), dtype=torch.int32, device=dev),
+            props=torch.empty((n, 6, 1), dtype=torch.float64, device=dev),
+            status=torch.empty(n, dtype=torch.int32, device=dev),
+        )
+        self.wts, self.radius = ops._device_weights(self.sigma, dev)
+        self.prm = ops.make_peak_params(w, fwxm_height=self.fwxm_height / 100, max_number=1)
+        self.lib = _lib.load()
+
+    def run(self, frames: torch.Tensor, events: dict | None = None) -> EpidResult:
+        """One pass over a resident batch.  ``events``: optional {stage: [(start, stop), ...]} sink;
+        when given, every stage is bracketed by HIP events on the launch stream."""
+        if frames.dtype != torch.uint16 or tuple(frames.shape) != (self.n, self.h, self.w):
+            raise ValueError(f"expected uint16 [{self.n},{self.h},{self.w}] frames")
+        if not frames.is_cuda:
+            raise ValueError("frames must be resident on the GPU")
+        lib, st = self.lib, torch.cuda.current_stream().cuda_stream
+        n, h, w = self.n, self.h, self.w
+        U16 = _lib.PL_U16
+
+        def stage(name, fn):
+            if events is None:
+                check(fn(), name)
+                return
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(fn(), name)
+            e1.record()
+            events.setdefault(name, []).append((e0, e1))
+
+        x = frames.contiguous()
+        stage("gauss_v", lambda: lib.pl_gaussian1d(x.data_ptr(), self.buf_a.data_ptr(), U16, n, h, w, 0,
+                                                   self.wts.data_ptr(), self.radius, st))
+        stage("gauss_h", lambda: lib.pl_gaussian1d(self.buf_a.data_ptr(), self.buf_b.data_ptr(), U16, n, h, w,
+                                                   1, self.wts.data_ptr(), self.radius, st))
+        stage("median3", lambda: lib.pl_median2d(self.buf_b.data_ptr(), self.buf_a.data_ptr(), U16, n, h, w,
+                                                 self.median_size, st))
+        stage("hist16", lambda: lib.pl_hist16(self.buf_a.data_ptr(), U16, n, h * w, self.hist.data_ptr(), st))
+        stage("otsu", lambda: lib.pl_otsu_from_hist(self.hist.data_ptr(), U16, n, self.thr.data_ptr(),
+                                                    self.vmin.data_ptr(), self.vmax.data_ptr(), st))
+        stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(
+            self.buf_a.data_ptr(), self.out.data_ptr(), n, h, w, self.thr.data_ptr(), self.colsum.data_ptr(), st))
+        stage("colsum_to_mean", lambda: lib.pl_colsum_to_mean(self.colsum.data_ptr(), n, w, h,
+                                                              self.profile.data_ptr(), st))
+        pk = self.peaks
+        stage("find_peaks", lambda: lib.pl_find_peaks(
+            self.profile.data_ptr(), n, w, w, C.byref(self.prm), 1, pk.count.data_ptr(), pk.idx.data_ptr(),
+            pk.left_bases.data_ptr(), pk.right_bases.data_ptr(), pk.props.data_ptr(), pk.status.data_ptr(), st))
+        stage("fwxm_record", lambda: lib.pl_fwxm_record(pk.count.data_ptr(), pk.idx.data_ptr(),
+                                                        pk.props.data_ptr(), 1, n, self.fwxm.data_ptr(), st))
+        return EpidResult(self.out, self.profile, self.thr, self.fwxm, pk.status)
