@@ -90,6 +90,11 @@ def load():
             f"{path} not found: build it with `python -m pylinac_amd._build` "
             "(or __graft_entry__.build()).  There is no CPU fallback by design."
         )
+    # PyTorch bundles its own libamdhip64.so.  Import torch FIRST so that the HIP runtime it loads
+    # is the one this library binds to (same soname): device pointers and stream handles passed
+    # across the C ABI are only meaningful inside a single runtime instance.
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(path))
     for name, (argtypes, restype) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
