@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz by running THE REFERENCE'S OWN CODE (read-only from
+/root/reference through oracle/ref_loader.py, real scipy 1.15.3 underneath) and, for the
+scikit-image bits, scikit-image 0.18.3 under /opt/conda/bin/python3.9 (helper: skimage_py39.py).
+
+Run in the build container only:   python tests/golden/make_golden.py
+The .npz files are committed; the GPU box (which has no /root/reference) only reads them.
+"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_loader  # noqa: E402
+
+PY39 = "/opt/conda/bin/python3.9"
+
+
+def synth_frames(n, h, w, seed, dtype=np.uint16):
+    """Small EPID-like frames: blurred square field + noise + dead/hot pixels (numpy, seeded)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+        cy, cx = h / 2 + rng.uniform(-3, 3), w / 2 + rng.uniform(-3, 3)
+        hy, hx = h * 0.28, w * 0.3
+        s = 2.5
+        from scipy.special import erf
+
+        fy = 0.5 * (erf((y - (cy - hy)) / s) - erf((y - (cy + hy)) / s))
+        fx = 0.5 * (erf((x - (cx - hx)) / s) - erf((x - (cx + hx)) / s))
+        img = 2000 + 38000 * fy * fx + rng.normal(0, 400, (h, w))
+        pos = rng.integers(0, h * w, 6)
+        img.ravel()[pos] = rng.choice([0, 65535], 6)
+        out.append(np.clip(np.round(img), 0, 65535))
+    a = np.stack(out)
+    if dtype == np.int16:
+        return (a - 32768).astype(np.int16)
+    return a.astype(dtype)
+
+
+def skimage_otsu(arrays: dict) -> dict:
+    """threshold_otsu via scikit-image 0.18.3 in the py3.9 interpreter."""
+    with tempfile.TemporaryDirectory() as td:
+        inp = os.path.join(td, "in.npz")
+        outp = os.path.join(td, "out.json")
+        np.savez(inp, **arrays)
+        subprocess.run([PY39, os.path.join(HERE, "skimage_py39.py"), inp, outp], check=True,
+                       stderr=subprocess.DEVNULL)
+        return json.load(open(outp))
+
+
+def main():
+    au = ref_loader.ref("core.array_utils")
+    prof = ref_loader.ref("core.profile")
+    image = ref_loader.ref("core.image")
+    meta = {
+        "generator": "tests/golden/make_golden.py",
+        "reference": "pylinac 3.46.0 (/root/reference, read-only)",
+        "numpy": np.__version__,
+        "scipy": __import__("scipy").__version__,
+        "skimage": "0.18.3 (py3.9 helper)",
+    }
+
+    # ---------------------------------------------------------------- 1. frame filters / mutators
+    g = {}
+    frames = synth_frames(3, 96, 128, seed=11)
+    rnd = np.random.default_rng(5).integers(0, 65536, (2, 64, 72), dtype=np.uint16)
+    small = np.random.default_rng(6).integers(0, 65536, (1, 7, 9), dtype=np.uint16)
+    sets = {"field": frames, "random": rnd, "tiny": small}
+    for name, fs in sets.items():
+        g[f"{name}.in"] = fs
+        for tag, size, kind in [("g5", 5, "gaussian"), ("g1", 1, "gaussian"), ("g2", 2, "gaussian"), ("gf03", 0.03, "gaussian"),
+                                ("m3", 3, "median"), ("m5", 5, "median"), ("m2", 2, "median"),
+                                ("mf05", 0.05, "median")]:
+            outs = []
+            for f in fs:
+                im = image.ArrayImage(f.copy())
+                im.filter(size=size, kind=kind)  # pylinac/core/image.py:695-712
+                outs.append(im.array)
+            g[f"{name}.filter.{tag}"] = np.stack(outs)
+        outs_hi, outs_lo, outs_bin, outs_gr, outs_no, outs_inv = [], [], [], [], [], []
+        for f in fs:
+            im = image.ArrayImage(f.copy()); im.threshold(30000); outs_hi.append(im.array)
+            im = image.ArrayImage(f.copy()); im.threshold(30000, kind="low"); outs_lo.append(im.array)
+            outs_bin.append(image.ArrayImage(f.copy()).as_binary(30000).array)
+            im = image.ArrayImage(f.copy()); im.ground(); outs_gr.append(im.array)
+            im = image.ArrayImage(f.copy()); im.normalize(); outs_no.append(im.array)
+            im = image.ArrayImage(f.copy()); im.invert(); outs_inv.append(im.array)
+        g[f"{name}.threshold.high"] = np.stack(outs_hi)
+        g[f"{name}.threshold.low"] = np.stack(outs_lo)
+        g[f"{name}.as_binary"] = np.stack(outs_bin)
+        g[f"{name}.ground"] = np.stack(outs_gr)
+        g[f"{name}.normalize"] = np.stack(outs_no)
+        g[f"{name}.invert"] = np.stack(outs_inv)
+        g[f"{name}.stretch"] = np.stack([au.stretch(f.astype(float), 0, 1) for f in fs])
+        g[f"{name}.percentiles"] = np.stack([np.percentile(f, [0.5, 5, 50, 95, 99.5, 99.9]) for f in fs])
+    # float and int16 frames
+    ff = (frames[:2].astype(np.float64) / 65535.0)
+    g["float64.in"] = ff
+    g["float64.filter.g2"] = np.stack([au.filter(f, 2, "gaussian") for f in ff])
+    g["float64.filter.m3"] = np.stack([au.filter(f, 3, "median") for f in ff])
+    f32 = ff.astype(np.float32)
+    g["float32.in"] = f32
+    g["float32.filter.g2"] = np.stack([au.filter(f, 2, "gaussian") for f in f32])
+    i16 = synth_frames(2, 64, 80, seed=3, dtype=np.int16)
+    g["int16.in"] = i16
+    g["int16.filter.g2"] = np.stack([au.filter(f, 2, "gaussian") for f in i16])
+    g["int16.filter.m3"] = np.stack([au.filter(f, 3, "median") for f in i16])
+    # reference KATs (tests_basic/core/test_array_utils.py:65-149, test_image.py:450-461, 522-535)
+    kat = np.array([0, 0, 0, 3, 0, 0, 0])
+    g["kat.filter.in"] = kat
+    g["kat.filter.median1"] = au.filter(kat, size=1, kind="median")
+    g["kat.filter.median_f01"] = au.filter(kat, size=0.1, kind="median")
+    g["kat.filter.median3"] = au.filter(kat, size=3, kind="median")
+    g["kat.filter.median3b"] = au.filter(np.array([0, 0, 3, 3, 0, 0, 0]), size=3, kind="median")
+    g["kat.filter.gauss1"] = au.filter(kat, size=1, kind="gaussian")
+    im = image.ArrayImage(np.arange(42).reshape(6, 7)); im.filter(3); g["kat.image.filter3"] = im.array
+    im = image.ArrayImage(np.arange(42).reshape(6, 7)); im.threshold(10); g["kat.image.threshold10"] = im.array
+    im = image.ArrayImage(np.arange(42).reshape(6, 7)); im.threshold(20, kind="low"); g["kat.image.threshold20low"] = im.array
+    g["kat.normalize"] = au.normalize(np.array((1, 2, 3, 4)))
+    g["kat.normalize2"] = au.normalize(np.array((1, 2, 3, 4), dtype=float), 2)
+    g["kat.invert"] = au.invert(np.array([0, 10]))
+    g["kat.invert_neg"] = au.invert(np.array([-5, -1]))
+    g["kat.ground"] = au.ground(np.array([3, 4, 5]))
+    g["kat.ground_neg"] = au.ground(np.array([-3, -4, -5]))
+    g["kat.ground10"] = au.ground(np.array([3, 4, 5]), value=10)
+    np.savez_compressed(os.path.join(HERE, "frames.npz"), **g)
+
+    # -------------------------------------------------------------------------- 2. Otsu (skimage)
+    o = {}
+    o["u16_field"] = np.stack([au.filter(f, 3, "gaussian") for f in frames])
+    o["u16_random"] = rnd
+    o["i16"] = i16
+    o["const"] = np.full((1, 16, 16), 1234, dtype=np.uint16)
+    o["two_level"] = np.where(np.arange(400).reshape(1, 20, 20) % 3 == 0, 100, 900).astype(np.uint16)
+    flat = {}
+    for k, v in o.items():
+        for i, f in enumerate(v):
+            flat[f"{k}.{i}"] = f
+    thr = skimage_otsu(flat)
+    og = {f"{k}.in": v for k, v in o.items()}
+    for k, v in o.items():
+        og[f"{k}.otsu"] = np.array([thr[f"{k}.{i}"] for i in range(len(v))], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "otsu.npz"), **og)
+
+    # ---------------------------------------------------------------------------------- 3. peaks
+    pk = {}
+    rng = np.random.default_rng(21)
+    import scipy.signal as sps
+
+    profiles = {
+        "simple9": np.array([0, 1, 2, 3, 4, 3, 2, 1, 0], dtype=float),
+        "simple8": np.array([0, 1, 2, 3, 3, 2, 1, 0], dtype=float),
+        "long23": np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0], dtype=float),
+        "long22": np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0], dtype=float),
+        "skewed19": np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 8, 6, 4, 2, 0], dtype=float),
+        "sigmoid21": np.array([0, 1, 2, 4, 6, 8, 9, 10, 10, 10, 10, 10, 10, 10, 9, 8, 6, 4, 2, 1, 0], dtype=float),
+        "sawtooth": sps.sawtooth(np.linspace(0, 8 * np.pi, num=200), width=0.5),
+        "walk600": np.abs(rng.normal(size=600).cumsum()),
+        "pickets": sum(np.exp(-0.5 * ((np.arange(1200) - c) / 6.0) ** 2) for c in np.arange(100, 1150, 110))
+                   + rng.normal(0, 0.01, 1200) + 0.05,
+        "noisy_field": np.convolve(np.r_[np.zeros(150), np.ones(500), np.zeros(150)], np.ones(25) / 25, "same")
+                       + rng.normal(0, 0.004, 800),
+    }
+    variants = {
+        "default": dict(),
+        "fwxm_top1": dict(fwxm_height=0.5, max_number=1),
+        "fwxm25_top1": dict(fwxm_height=0.25, max_number=1),
+        "fwxm75_top1": dict(fwxm_height=0.75, max_number=1),
+        "mp_default": dict(threshold=0.3, peak_separation=0.05),
+        "pf": dict(threshold=0.5, peak_separation=0.02, peak_sort="peak_heights", required_prominence=0.2),
+        "region": dict(threshold=0.3, peak_separation=0.05, search_region=(0.2, 0.8), max_number=2),
+        "region_int": dict(threshold=0.1, peak_separation=5, search_region=(3, 190)),
+    }
+    names = []
+    for pname, vals in profiles.items():
+        pk[f"{pname}.values"] = vals
+        for vname, kw in variants.items():
+            try:
+                idx, props = prof.find_peaks(vals.copy(), **kw)  # pylinac/core/profile.py:2545
+            except Exception as e:  # noqa: BLE001
+                pk[f"{pname}.{vname}.error"] = np.array(type(e).__name__)
+                continue
+            names.append(f"{pname}.{vname}")
+            pk[f"{pname}.{vname}.idx"] = idx
+            for k, v in props.items():
+                pk[f"{pname}.{vname}.{k}"] = v
+        mp = prof.MultiProfile(vals.copy())
+        a, b = mp.find_peaks(); pk[f"{pname}.mp.peaks.idx"], pk[f"{pname}.mp.peaks.val"] = a, b
+        a, b = mp.find_valleys(); pk[f"{pname}.mp.valleys.idx"], pk[f"{pname}.mp.valleys.val"] = a, b
+        a, b = mp.find_fwxm_peaks(); pk[f"{pname}.mp.fwxm.idx"], pk[f"{pname}.mp.fwxm.val"] = a, b
+        for hgt in (25, 50, 75):
+            try:
+                fp = prof.FWXMProfile(vals.copy(), fwxm_height=hgt)
+                pk[f"{pname}.fwxm{hgt}"] = np.array([fp.field_edge_idx("left"), fp.field_edge_idx("right"),
+                                                     fp.center_idx, fp.field_width_px])
+            except Exception as e:  # noqa: BLE001
+                pk[f"{pname}.fwxm{hgt}.error"] = np.array(type(e).__name__)
+    pk["variants"] = np.array(json.dumps(variants))
+    np.savez_compressed(os.path.join(HERE, "peaks.npz"), **pk)
+
+    # -------------------------------------------------- 4. composed EPID pipeline (config #2 + peak)
+    ep = {}
+    pf = synth_frames(3, 128, 160, seed=77)
+    ep["in"] = pf
+    med = []
+    for f in pf:
+        im = image.ArrayImage(f.copy())
+        im.filter(5, "gaussian")
+        im.filter(3, "median")
+        med.append(im.array)
+    med = np.stack(med)
+    thr = skimage_otsu({str(i): m for i, m in enumerate(med)})
+    ts = np.array([thr[str(i)] for i in range(len(med))], dtype=np.int64)
+    outs, profs, recs = [], [], []
+    for m, t in zip(med, ts):
+        im = image.ArrayImage(m.copy())
+        im.threshold(int(t))
+        outs.append(im.array)
+        p = np.mean(im.array, axis=0)  # pylinac/picketfence.py:747-750
+        profs.append(p)
+        fp = prof.FWXMProfile(p, fwxm_height=50)
+        recs.append([fp.field_edge_idx("left"), fp.field_edge_idx("right"), fp.center_idx, fp.field_width_px])
+    ep["median"] = med
+    ep["otsu"] = ts
+    ep["out"] = np.stack(outs)
+    ep["profile"] = np.stack(profs)
+    ep["fwxm"] = np.array(recs)
+    np.savez_compressed(os.path.join(HERE, "epid_pipeline.npz"), **ep)
+
+    json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    if not ref_loader.reference_available():
+        raise SystemExit("needs /root/reference (build container only)")
+    main()

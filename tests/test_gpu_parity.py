@@ -1,0 +1,481 @@
+"""GPU (-m gpu): parity of the HIP path -- called through the C ABI -- against
+  * the committed golden vectors produced by the reference's own code (tests/golden/),
+  * the CPU oracle on seeded inputs, and
+  * size-independent properties at BASELINE's full 1024x1024 size.
+Bars: bit-exact for integer frames / thresholds / indices; float results compared with
+np.array_equal where the reference's operation order is defined, otherwise rtol 1e-12
+(north_star asks 1e-5)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pylinac_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+FILTERS = [("g5", 5, "gaussian"), ("g1", 1, "gaussian"), ("g2", 2, "gaussian"), ("gf03", 0.03, "gaussian"),
+           ("m3", 3, "median"), ("m5", 5, "median"), ("m2", 2, "median"), ("mf05", 0.05, "median")]
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_native_library_is_loaded(dev):
+    from pylinac_amd import _lib
+
+    lib = _lib.load()
+    assert lib.pl_device_available() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libpylinac_hip.so" in maps
+
+
+# ------------------------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("name", ["field", "random", "tiny"])
+def test_filters_vs_reference_golden(golden, dev, name):
+    from pylinac_amd import array_utils as au
+    from pylinac_amd.image import ArrayImage, ImageBatch
+
+    g = golden("frames")
+    fs = g[f"{name}.in"]
+    for tag, size, kind in FILTERS:
+        ref = g[f"{name}.filter.{tag}"]
+        # batched device path
+        b = ImageBatch(T(fs, dev))
+        b.filter(size, kind)
+        got = b.array.cpu().numpy()
+        assert got.dtype == ref.dtype and np.array_equal(got, ref), (name, tag, "batch")
+        # numpy drop-in path (ArrayImage.filter, pylinac/core/image.py:695)
+        im = ArrayImage(fs[0].copy())
+        im.filter(size=size, kind=kind)
+        assert np.array_equal(im.array, ref[0]), (name, tag, "ArrayImage")
+        assert np.array_equal(au.filter(fs[-1], size, kind), ref[-1]), (name, tag, "array_utils")
+
+
+@pytest.mark.parametrize("name", ["field", "random", "tiny"])
+def test_mutators_vs_reference_golden(golden, dev, name):
+    from pylinac_amd import array_utils as au
+    from pylinac_amd import ops
+    from pylinac_amd.image import ArrayImage
+
+    g = golden("frames")
+    fs = g[f"{name}.in"]
+    t = T(fs, dev)
+    assert np.array_equal(ops.threshold(t, 30000).cpu().numpy(), g[f"{name}.threshold.high"])
+    assert np.array_equal(ops.threshold(t, 30000, "low").cpu().numpy(), g[f"{name}.threshold.low"])
+    assert np.array_equal(ops.as_binary(t, 30000).cpu().numpy(), g[f"{name}.as_binary"])
+    assert np.array_equal(ops.ground(t).cpu().numpy(), g[f"{name}.ground"])
+    assert np.array_equal(ops.normalize(t).cpu().numpy(), g[f"{name}.normalize"])
+    assert np.array_equal(ops.invert(t).cpu().numpy(), g[f"{name}.invert"])
+    assert np.array_equal(ops.percentile(t, [0.5, 5, 50, 95, 99.5, 99.9]).numpy(), g[f"{name}.percentiles"])
+    for i, f in enumerate(fs):
+        assert np.array_equal(au.stretch(f.astype(float), 0, 1), g[f"{name}.stretch"][i])
+        im = ArrayImage(f.copy())
+        im.threshold(30000)
+        assert im.array.dtype == f.dtype and np.array_equal(im.array, g[f"{name}.threshold.high"][i])
+        b = ArrayImage(f.copy()).as_binary(30000)
+        assert b.array.dtype == np.int64 and np.array_equal(b.array, g[f"{name}.as_binary"][i])
+        im = ArrayImage(f.copy())
+        mn = im.ground()
+        assert mn == f.min() and np.array_equal(im.array, g[f"{name}.ground"][i])
+        im = ArrayImage(f.copy())
+        im.normalize()
+        assert im.array.dtype == np.float64 and np.array_equal(im.array, g[f"{name}.normalize"][i])
+        im = ArrayImage(f.copy())
+        im.invert()
+        assert np.array_equal(im.array, g[f"{name}.invert"][i])
+
+
+def test_float_and_int16_filters_vs_golden(golden, dev):
+    from pylinac_amd import array_utils as au
+
+    g = golden("frames")
+    for key, size, kind in [("float64.filter.g2", 2, "gaussian"), ("float64.filter.m3", 3, "median"),
+                            ("float32.filter.g2", 2, "gaussian"), ("int16.filter.g2", 2, "gaussian"),
+                            ("int16.filter.m3", 3, "median")]:
+        fs = g[key.split(".")[0] + ".in"]
+        ref = g[key]
+        got = np.stack([au.filter(f, size, kind) for f in fs])
+        assert got.dtype == ref.dtype and np.array_equal(got, ref), key
+
+
+def test_reference_known_answer_tests_on_gpu(golden, dev):
+    """The reference's own KATs (tests_basic/core/test_array_utils.py:65-149,
+    tests_basic/core/test_image.py:450-461, 522-535) through the drop-in API."""
+    from pylinac_amd import array_utils as au
+    from pylinac_amd.image import ArrayImage
+
+    kat = np.array([0, 0, 0, 3, 0, 0, 0])
+    assert np.array_equal(au.filter(kat, size=1, kind="median"), [0, 0, 0, 3, 0, 0, 0])
+    assert np.array_equal(au.filter(kat, size=0.1, kind="median"), [0, 0, 0, 3, 0, 0, 0])
+    assert np.array_equal(au.filter(kat, size=3, kind="median"), [0, 0, 0, 0, 0, 0, 0])
+    assert np.array_equal(au.filter(np.array([0, 0, 3, 3, 0, 0, 0]), size=3, kind="median"), [0, 0, 3, 3, 0, 0, 0])
+    assert np.array_equal(au.filter(kat, size=1, kind="gaussian"), [0, 0, 0, 1, 0, 0, 0])
+    with pytest.raises(ValueError):
+        au.filter(kat, size=2.3, kind="gaussian")
+    with pytest.raises(ValueError):
+        au.filter(kat, size=1, kind="filterthis")
+    gf = golden("frames")
+    im = ArrayImage(np.arange(42).reshape(6, 7))
+    im.filter(3)
+    assert im.array[0, 0] == 1 and np.array_equal(im.array, gf["kat.image.filter3"])
+    im = ArrayImage(np.arange(42).reshape(6, 7))
+    im.threshold(10)
+    assert im.array[0, 4] == 0 and np.array_equal(im.array, gf["kat.image.threshold10"])
+    im = ArrayImage(np.arange(42).reshape(6, 7))
+    im.threshold(20, kind="low")
+    assert np.array_equal(im.array, gf["kat.image.threshold20low"])
+    n = au.normalize(np.array((1, 2, 3, 4)))
+    assert n.max() == 1.0 and n[-1] == 1.0 and n[0] == 0.25
+    assert np.array_equal(au.normalize(np.array((1, 2, 3, 4), dtype=float), 2), [0.5, 1, 1.5, 2])
+    assert np.array_equal(au.invert(np.array([0, 10])), [10, 0])
+    assert np.array_equal(au.invert(np.array([-5, -1])), [-1, -5])
+    assert np.array_equal(au.ground(np.array([3, 4, 5])), [0, 1, 2])
+    assert np.array_equal(au.ground(np.array([-3, -4, -5])), [2, 1, 0])
+    assert np.array_equal(au.ground(np.array([3, 4, 5]), value=10), [10, 11, 12])
+
+
+def test_otsu_vs_skimage_golden(golden, dev):
+    from pylinac_amd import ops
+
+    g = golden("otsu")
+    for k in ["u16_field", "u16_random", "i16", "const", "two_level"]:
+        got = ops.threshold_otsu(T(g[f"{k}.in"], dev)).cpu().numpy()
+        assert np.array_equal(got, g[f"{k}.otsu"]), k
+
+
+PROFILES = ["simple9", "simple8", "long23", "long22", "skewed19", "sigmoid21", "sawtooth", "walk600", "pickets",
+            "noisy_field"]
+
+
+def test_find_peaks_vs_reference_golden(golden, dev):
+    from pylinac_amd import profile as pp
+
+    g = golden("peaks")
+    variants = json.loads(str(g["variants"]))
+    checked = 0
+    for pname in PROFILES:
+        vals = g[f"{pname}.values"]
+        for vname, kw in variants.items():
+            kw = dict(kw)
+            if "search_region" in kw:
+                kw["search_region"] = tuple(kw["search_region"])
+            key = f"{pname}.{vname}"
+            if f"{key}.error" in g.files:
+                continue
+            idx, props = pp.find_peaks(vals, **kw)
+            assert np.array_equal(idx, g[f"{key}.idx"]), key
+            for k in ("peak_heights", "prominences", "left_bases", "right_bases", "widths", "width_heights",
+                      "left_ips", "right_ips"):
+                assert np.array_equal(props[k], g[f"{key}.{k}"]), (key, k)
+            checked += 1
+    assert checked > 50
+
+
+def test_multiprofile_and_fwxm_vs_reference_golden(golden, dev):
+    from pylinac_amd.profile import FWXMProfile, MultiProfile
+
+    g = golden("peaks")
+    for pname in PROFILES:
+        vals = g[f"{pname}.values"]
+        mp = MultiProfile(vals.copy())
+        for tag, fn in [("peaks", mp.find_peaks), ("valleys", mp.find_valleys), ("fwxm", mp.find_fwxm_peaks)]:
+            i, v = fn()
+            assert np.array_equal(i, g[f"{pname}.mp.{tag}.idx"]), (pname, tag)
+            assert np.array_equal(v, g[f"{pname}.mp.{tag}.val"]), (pname, tag)
+        for h in (25, 50, 75):
+            if f"{pname}.fwxm{h}.error" in g.files:
+                with pytest.raises(IndexError):
+                    FWXMProfile(vals.copy(), fwxm_height=h).field_edge_idx("left")
+            else:
+                fp = FWXMProfile(vals.copy(), fwxm_height=h)
+                got = np.array([fp.field_edge_idx("left"), fp.field_edge_idx("right"), fp.center_idx, fp.field_width_px])
+                assert np.array_equal(got, g[f"{pname}.fwxm{h}"]), (pname, h)
+
+
+def test_fwxm_known_answers_on_gpu(dev):
+    """tests_basic/core/test_profile.py:272-325."""
+    from pylinac_amd.profile import FWXMProfile
+
+    s9 = np.array([0, 1, 2, 3, 4, 3, 2, 1, 0], dtype=float)
+    s8 = np.array([0, 1, 2, 3, 3, 2, 1, 0], dtype=float)
+    sk = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 8, 6, 4, 2, 0], dtype=float)
+    p = FWXMProfile(s9)
+    assert (p.field_edge_idx("left"), p.field_edge_idx("right"), p.center_idx, p.field_width_px) == (2, 6, 4, 4)
+    p = FWXMProfile(s8)
+    assert (p.field_edge_idx("left"), p.field_edge_idx("right"), p.center_idx) == (1.5, 5.5, 3.5)
+    p = FWXMProfile(s9, fwxm_height=25)
+    assert (p.field_edge_idx("left"), p.field_edge_idx("right"), p.field_width_px) == (1, 7, 6)
+    p = FWXMProfile(s9, fwxm_height=75)
+    assert (p.field_edge_idx("left"), p.field_edge_idx("right")) == (3, 5)
+    p = FWXMProfile(sk)
+    assert (p.field_edge_idx("left"), p.field_edge_idx("right"), p.field_width_px) == (5, 14.5, 9.5)
+    # x-values that decrease are re-sorted (test_profile.py:216-226)
+    p = FWXMProfile(s9, x_values=np.arange(9)[::-1])
+    assert p.field_width_px == 4
+    x_bad = np.arange(9)
+    x_bad[2] = 5
+    with pytest.raises(ValueError):
+        FWXMProfile(s9, x_values=x_bad)
+    with pytest.raises(IndexError):  # no peak at all: same exception as the reference (profile.py:608)
+        FWXMProfile(np.zeros(12)).field_edge_idx("left")
+
+
+def test_pipeline_vs_reference_golden(golden, dev):
+    from pylinac_amd.pipeline import EpidPipeline
+
+    g = golden("epid_pipeline")
+    fr = g["in"]
+    n, h, w = fr.shape
+    res = EpidPipeline(n, h, w, dev).run(T(fr, dev))
+    assert np.array_equal(res.frames.cpu().numpy(), g["out"])
+    assert np.array_equal(res.threshold.cpu().numpy(), g["otsu"])
+    assert np.array_equal(res.profile.cpu().numpy(), g["profile"])
+    assert np.array_equal(res.fwxm.cpu().numpy()[:, 4:8], g["fwxm"])
+    assert int(res.status.abs().sum()) == 0
+
+
+# ------------------------------------------------------------------- oracle on seeded random inputs
+@pytest.mark.parametrize("shape", [(2, 50, 70), (1, 129, 1000), (3, 33, 17), (2, 1, 300), (2, 300, 1), (1, 5, 5)])
+def test_filters_vs_oracle_ragged_shapes(dev, shape):
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(sum(shape))
+    a = rng.integers(0, 65536, shape, dtype=np.uint16)
+    for sigma in (1, 2, 3, 5, 6):  # 6 -> radius 24: generic kernel; others: specialised kernels
+        ref = np.stack([o.filter(f, sigma, "gaussian") for f in a])
+        assert np.array_equal(ops.gaussian_filter(T(a, dev), sigma).cpu().numpy(), ref), sigma
+    for size in (1, 2, 3, 4, 7):
+        ref = np.stack([o.filter(f, size, "median") for f in a])
+        assert np.array_equal(ops.median_filter(T(a, dev), size).cpu().numpy(), ref), size
+
+
+def test_gaussian_extreme_values_and_constants(dev):
+    """Saturated / constant regions are where the float64 sum sits within 1e-11 of an integer:
+    the summation ORDER decides the truncated result."""
+    from pylinac_amd import ops
+
+    for v in (0, 1, 255, 4095, 32768, 65534, 65535):
+        a = np.full((1, 64, 96), v, dtype=np.uint16)
+        for sigma in (1, 2, 5):
+            assert np.array_equal(ops.gaussian_filter(T(a, dev), sigma).cpu().numpy()[0], o.filter(a[0], sigma, "gaussian"))
+    rng = np.random.default_rng(0)
+    a = (rng.integers(0, 2, (2, 80, 120)) * 65535).astype(np.uint16)  # only 0 / 65535
+    for sigma in (2, 5):
+        ref = np.stack([o.filter(f, sigma, "gaussian") for f in a])
+        assert np.array_equal(ops.gaussian_filter(T(a, dev), sigma).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.int32, np.int64, np.float32, np.float64])
+def test_other_dtypes_vs_oracle(dev, dtype):
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(3)
+    if np.dtype(dtype).kind == "f":
+        a = rng.normal(100, 30, (2, 40, 56)).astype(dtype)
+    else:
+        info = np.iinfo(dtype)
+        a = rng.integers(max(info.min, -30000), min(info.max, 30000), (2, 40, 56)).astype(dtype)
+    t = T(a, dev)
+    assert np.array_equal(ops.gaussian_filter(t, 2).cpu().numpy(), np.stack([o.filter(f, 2, "gaussian") for f in a]))
+    assert np.array_equal(ops.median_filter(t, 3).cpu().numpy(), np.stack([o.filter(f, 3, "median") for f in a]))
+    assert np.array_equal(ops.median_filter(t, 5).cpu().numpy(), np.stack([o.filter(f, 5, "median") for f in a]))
+    assert np.array_equal(ops.ground(t).cpu().numpy(), np.stack([o.ground(f) for f in a]))
+    assert np.array_equal(ops.invert(t).cpu().numpy(), np.stack([o.invert(f) for f in a]))
+    nrm = ops.normalize(t).cpu().numpy()
+    ref = np.stack([o.normalize(f) for f in a])
+    assert nrm.dtype == ref.dtype and np.array_equal(nrm, ref)
+    thr = float(np.median(a))
+    assert np.array_equal(ops.threshold(t, thr).cpu().numpy(), o.threshold(a, thr))
+    mn, mx = ops.minmax(t)
+    assert np.array_equal(mn.cpu().numpy(), a.min(axis=(1, 2)).astype(float))
+    assert np.array_equal(mx.cpu().numpy(), a.max(axis=(1, 2)).astype(float))
+
+
+def test_profiles_reductions_vs_numpy(dev):
+    from pylinac_amd import ops
+    from pylinac_amd.image import ArrayImage
+
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, 65536, (3, 77, 130), dtype=np.uint16)
+    for ax in (0, 1):
+        for op in ("mean", "sum", "max", "min"):
+            ref = getattr(np, op)(a, axis=ax + 1).astype(np.float64)
+            assert np.array_equal(ops.reduce_axis(T(a, dev), ax, op).cpu().numpy(), ref), (ax, op)
+    im = ArrayImage(a[0])
+    assert np.array_equal(im.profile(0, "mean"), np.mean(a[0], 0))
+    assert np.array_equal(im.profile(1, "max"), np.max(a[0], 1))
+    f = rng.normal(size=(2, 60, 90))
+    assert np.array_equal(ops.reduce_axis(T(f, dev), 0, "mean").cpu().numpy(), np.mean(f, axis=1))
+    # along the contiguous axis numpy sums pairwise: equal to rounding, not bitwise
+    assert np.allclose(ops.reduce_axis(T(f, dev), 1, "mean").cpu().numpy(), np.mean(f, axis=2), rtol=1e-12, atol=1e-15)
+
+
+def test_histogram_otsu_percentile_vs_oracle(dev):
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 65536, (3, 90, 111), dtype=np.uint16)
+    a[1] = a[1] // 257   # narrow range
+    a[2, :, :50] = 0     # long runs of equal values (run-length path of the histogram)
+    h = ops.histogram16(T(a, dev)).cpu().numpy().view(np.uint32)
+    for i in range(3):
+        assert np.array_equal(h[i], np.bincount(a[i].ravel(), minlength=65536))
+    assert np.array_equal(ops.threshold_otsu(T(a, dev)).cpu().numpy(), [int(o.threshold_otsu(f)) for f in a])
+    q = [0, 0.01, 0.5, 5, 50, 99.9, 99.99, 100]
+    assert np.array_equal(ops.percentile(T(a, dev), q).numpy(), np.stack([np.percentile(f, q) for f in a]))
+    ai = (a.astype(np.int32) - 32768).astype(np.int16)
+    assert np.array_equal(ops.threshold_otsu(T(ai, dev)).cpu().numpy(), [int(o.threshold_otsu(f)) for f in ai])
+    assert np.array_equal(ops.percentile(T(ai, dev), q).numpy(), np.stack([np.percentile(f, q) for f in ai]))
+
+
+def test_check_inversion_by_histogram(dev):
+    """pylinac/core/image.py:899-926."""
+    from pylinac_amd.image import ArrayImage
+
+    rng = np.random.default_rng(2)
+    a = (rng.normal(60000, 300, (64, 64))).clip(0, 65535).astype(np.uint16)
+    a[20:30, 20:30] = 1000  # mostly-high image with a small dark region
+    im = ArrayImage(a.copy())
+    p = [np.percentile(a, q) for q in (5, 50, 95)]
+    expect = abs(p[1] - p[0]) > abs(p[1] - p[2])
+    assert im.check_inversion_by_histogram() == expect
+    if expect:
+        assert np.array_equal(im.array, o.invert(a))
+
+
+def test_find_peaks_vs_oracle_random(dev):
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(17)
+    n_peaks = 0
+    for trial in range(80):
+        L = int(rng.integers(3, 6000))
+        if trial % 4 == 0:
+            x = rng.integers(0, 7, L).astype(float)  # plateaus
+        else:
+            x = np.abs(rng.normal(size=L).cumsum())
+        kws = [dict(), dict(threshold=0.3, peak_separation=0.05),
+               dict(threshold=0.5, peak_separation=0.02, peak_sort="peak_heights",
+                    required_prominence=0.1 * np.ptp(x), max_number=3),
+               dict(search_region=(0.2, 0.8), max_number=2), dict(fwxm_height=0.3, max_number=1),
+               dict(threshold=0.2, peak_separation=3, peak_sort="widths", max_number=4)]
+        kw = dict(kws[trial % len(kws)])
+        if trial % 4 == 0:
+            kw.pop("peak_separation", None)  # exact ties + distance: order is implementation-defined
+            kw.pop("max_number", None)
+        i1, p1 = o.find_peaks(x, **kw)
+        i2, p2 = ops.find_peaks_batch(T(x, dev), **kw).to_host(0)
+        assert np.array_equal(i1, i2), (trial, kw)
+        for k in p1:
+            assert np.array_equal(p1[k], p2[k]), (trial, k)
+        n_peaks += len(i1)
+    assert n_peaks > 1000
+
+
+def test_find_peaks_batch_rows_are_independent(dev):
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(23)
+    x = np.abs(rng.normal(size=(37, 777)).cumsum(axis=1))
+    res = ops.find_peaks_batch(T(x, dev), threshold=0.3, peak_separation=0.05)
+    for i in range(x.shape[0]):
+        i1, p1 = o.find_peaks(x[i], threshold=0.3, peak_separation=0.05)
+        i2, p2 = res.to_host(i)
+        assert np.array_equal(i1, i2)
+        assert np.array_equal(p1["left_ips"], p2["left_ips"]) and np.array_equal(p1["prominences"], p2["prominences"])
+
+
+def test_peak_capacity_overflow_is_reported_not_hidden(dev):
+    from pylinac_amd import _lib, ops
+
+    x = np.tile([0.0, 1.0], 200)
+    res = ops.find_peaks_batch(T(x, dev), cap=5)
+    assert int(res.status[0]) == 1 and int(res.count[0]) == 5
+    with pytest.raises(_lib.PylinacHipError):
+        res.to_host(0)
+
+
+# ------------------------------------------------------------------------ pipeline + full-size tests
+def test_epid_pipeline_vs_oracle_small(dev):
+    from pylinac_amd.pipeline import EpidPipeline
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    n, h, w = 5, 200, 264
+    fr = epid_open_field_frames(n, h, w, seed0=42, device=dev, field_mm=35.0)
+    res = EpidPipeline(n, h, w, dev).run(fr)
+    out, prof, rec = o.epid_pipeline(fr.cpu().numpy())
+    assert np.array_equal(res.frames.cpu().numpy(), out)
+    assert np.array_equal(res.profile.cpu().numpy(), prof)
+    got = res.record().cpu().numpy()
+    assert np.array_equal(got[:, :3], rec[:, :3])
+    assert np.allclose(got, rec, rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_full_size_frames_vs_oracle_and_properties(dev):
+    """BASELINE config #2 size (1024x1024): 2 frames against the oracle end-to-end, then
+    size-independent properties on a 24-frame batch: idempotence of thresholding, permutation
+    equivariance over the batch, histogram mass, profile/threshold consistency."""
+    from pylinac_amd import ops
+    from pylinac_amd.pipeline import EpidPipeline
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    n, h, w = 24, 1024, 1024
+    fr = epid_open_field_frames(n, h, w, seed0=1000, device=dev)
+    pipe = EpidPipeline(n, h, w, dev)
+    res = pipe.run(fr)
+    out = res.frames.clone()
+    thr = res.threshold.clone()
+    prof = res.profile.clone()
+    fw = res.fwxm.clone()
+    ref_out, ref_prof, ref_rec = o.epid_pipeline(fr[:2].cpu().numpy())
+    assert np.array_equal(out[:2].cpu().numpy(), ref_out)
+    assert np.array_equal(prof[:2].cpu().numpy(), ref_prof)
+    assert np.array_equal(thr[:2].cpu().numpy(), ref_rec[:, 0])
+    assert np.allclose(fw[:2].cpu().numpy(), ref_rec[:, 1:], rtol=1e-12, atol=0)
+    # idempotence: thresholding the thresholded frame again changes nothing
+    again = ops.threshold(out, thr.to(torch.float64))
+    assert torch.equal(again.view(torch.int16), out.view(torch.int16))
+    # every output pixel is 0 or >= its frame's threshold
+    o32 = out.to(torch.int32)
+    assert bool(((o32 == 0) | (o32 >= thr[:, None, None])).all())
+    # profile == column mean of the output frame (exact in float64)
+    assert torch.equal(prof, o32.to(torch.float64).sum(dim=1) / h)
+    # histogram mass
+    hist = ops.histogram16(out)
+    assert bool((hist.to(torch.int64).sum(dim=1) == h * w).all())
+    # permutation equivariance: frames are independent
+    perm = torch.randperm(n, device=dev)
+    res2 = pipe.run(fr[perm].contiguous())
+    assert torch.equal(res2.threshold, thr[perm])
+    assert torch.equal(res2.frames.view(torch.int16), out[perm].view(torch.int16))
+    assert torch.equal(res2.fwxm, fw[perm])
+    # physics sanity: a ~595 px (20 cm) field centred near the middle
+    assert bool(((fw[:, 7] > 560) & (fw[:, 7] < 630)).all()) and bool(((fw[:, 6] - 511.5).abs() < 8).all())
+
+
+def test_gaussian_linearity_property_full_size(dev):
+    """Property at full size without the oracle: the float64 pass is linear BEFORE truncation, so
+    G(a+b) - G(a) - G(b) stays within the accumulated truncation error of two passes."""
+    from pylinac_amd import ops
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    a = torch.randint(0, 30000, (2, 1024, 1024), generator=g, device=dev, dtype=torch.int32)
+    b = torch.randint(0, 30000, (2, 1024, 1024), generator=g, device=dev, dtype=torch.int32)
+
+    def u(x):
+        return (x & 0xFFFF).to(torch.int16).view(torch.uint16)
+
+    ga = ops.gaussian_filter(u(a), 5).to(torch.int32)
+    gb = ops.gaussian_filter(u(b), 5).to(torch.int32)
+    gab = ops.gaussian_filter(u(a + b), 5).to(torch.int32)
+    d = gab - ga - gb
+    assert int(d.min()) >= -1 and int(d.max()) <= 3
+    # median commutes with an order-reversing map: median3(65535 - x) == 65535 - median3(x)
+    x = a[0:1] * 2
+    m1 = ops.median_filter(u(x), 3).to(torch.int32)
+    m2 = ops.median_filter(u(65535 - x), 3).to(torch.int32)
+    assert torch.equal(m2, 65535 - m1)

@@ -1,0 +1,91 @@
+"""CPU: host-side logic of the mirror API (argument parsing, weights, sharding, error behaviour)."""
+import numpy as np
+import pytest
+from scipy.ndimage import _filters
+
+from oracle import pylinac_oracle as o
+from pylinac_amd import array_utils as au
+from pylinac_amd import dist as pdist
+from pylinac_amd import ops
+
+
+def test_gaussian_weights_bit_equal_scipy():
+    for sigma in (1, 2, 3, 5, 7, 27):
+        w, lw = ops.gaussian_weights(sigma)
+        ref = _filters._gaussian_kernel1d(float(sigma), 0, int(4.0 * float(sigma) + 0.5))[::-1]
+        assert lw == int(4.0 * sigma + 0.5) and np.array_equal(w, ref)
+        assert np.array_equal(w, w[::-1])  # exactly symmetric -> scipy's symmetric branch
+
+
+def test_resolve_filter_size_like_reference():
+    assert au.resolve_filter_size(1000, 0.05) == 50
+    assert au.resolve_filter_size(7, 0.1) == 1
+    assert au.resolve_filter_size(96, 0.05) == o.resolve_filter_size(np.zeros((96, 4)), 0.05) == 5
+    assert au.resolve_filter_size(10, 3) == 3
+    for bad in (2.3, 1.0, 0.0, -0.5):
+        with pytest.raises(ValueError, match="not between"):
+            au.resolve_filter_size(10, bad)
+
+
+def test_empty_and_bad_inputs_raise_like_reference():
+    with pytest.raises(ValueError, match="must not be empty"):
+        au.filter(np.array([]), 3)
+    with pytest.raises(ValueError, match="must not be empty"):
+        au.ground(np.array([]))
+    with pytest.raises(ValueError, match="Max must be larger"):
+        au.stretch(np.arange(5.0), min=1, max=1)
+    with pytest.raises(ValueError):
+        au.geometric_center_idx(np.zeros((2, 2)))
+    assert au.geometric_center_idx(np.arange(8)) == 3.5
+    assert au.geometric_center_value(np.array([1.0, 3.0, 5.0, 7.0])) == 4.0
+
+
+@pytest.mark.parametrize("length", [9, 200, 1024])
+def test_peak_params_match_parse_peak_args(length):
+    values = np.linspace(-1, 3, length)
+    cases = [dict(), dict(threshold=0.3, peak_separation=0.05), dict(threshold=15, peak_separation=7),
+             dict(search_region=(0.2, 0.8)), dict(search_region=(3, length - 2)), dict(threshold=1, peak_separation=1),
+             dict(threshold=0, peak_separation=0.001), dict(search_region=(0.9, 0.1))]
+    for kw in cases:
+        sep, shift, thr, trimmed = o.parse_peak_args(kw.get("peak_separation", 0), kw.get("search_region", (0.0, 1.0)),
+                                                     kw.get("threshold", -np.inf), values)
+        p = ops.make_peak_params(length, **kw)
+        assert p.distance == max(int(np.ceil(sep)), 1)
+        assert p.region_hi - p.region_lo == len(trimmed)
+        if len(trimmed):
+            assert p.region_lo == shift
+        if p.threshold_is_ratio:
+            assert values.min() + p.threshold * (values.max() - values.min()) == thr
+        else:
+            assert p.threshold == thr
+
+
+def test_peak_params_defaults_and_errors():
+    p = ops.make_peak_params(100, fwxm_height=0.3, max_number=1)
+    assert p.rel_height == 1 - 0.3 and p.max_number == 1 and p.sort_key == 0 and p.has_prominence == 0
+    assert ops.make_peak_params(100).max_number == -1
+    with pytest.raises(KeyError):
+        ops.make_peak_params(100, peak_sort="nonsense")
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 256, 10000):
+        for world in (1, 2, 3, 4, 8):
+            spans = [pdist.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_frames_are_deterministic_and_u16():
+    import torch
+
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    a = epid_open_field_frames(2, 64, 80, seed0=5)
+    b = epid_open_field_frames(2, 64, 80, seed0=5)
+    assert a.dtype == torch.uint16 and a.shape == (2, 64, 80)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    x = a.numpy()
+    assert x.max() > 30000 and x.min() < 5000

@@ -1,0 +1,213 @@
+"""CPU: pins the oracle (oracle/pylinac_oracle.py) against
+ (1) golden vectors produced by the reference's own code (tests/golden/make_golden.py),
+ (2) the literal known-answer tests of the reference, and
+ (3) real scipy, for the independent restatements that specify the HIP kernels."""
+import json
+
+import numpy as np
+import pytest
+from scipy import ndimage, signal
+
+from oracle import pylinac_oracle as o
+
+FILTERS = [("g5", 5, "gaussian"), ("g1", 1, "gaussian"), ("g2", 2, "gaussian"), ("gf03", 0.03, "gaussian"),
+           ("m3", 3, "median"), ("m5", 5, "median"), ("m2", 2, "median"), ("mf05", 0.05, "median")]
+
+
+@pytest.mark.parametrize("name", ["field", "random", "tiny"])
+def test_filters_match_reference_golden(golden, name):
+    g = golden("frames")
+    fs = g[f"{name}.in"]
+    for tag, size, kind in FILTERS:
+        ref = g[f"{name}.filter.{tag}"]
+        got = np.stack([o.filter(f, size, kind) for f in fs])
+        assert got.dtype == ref.dtype and np.array_equal(got, ref), (name, tag)
+        # the restatements that specify the kernels
+        s = o.resolve_filter_size(fs[0], size)
+        rest = np.stack([o.gaussian_filter_restated(f, s) if kind == "gaussian" else o.median_filter_restated(f, s)
+                         for f in fs])
+        assert np.array_equal(rest, ref), (name, tag, "restated")
+
+
+@pytest.mark.parametrize("name", ["field", "random", "tiny"])
+def test_mutators_match_reference_golden(golden, name):
+    g = golden("frames")
+    fs = g[f"{name}.in"]
+    assert np.array_equal(np.stack([o.threshold(f, 30000) for f in fs]), g[f"{name}.threshold.high"])
+    assert np.array_equal(np.stack([o.threshold(f, 30000, "low") for f in fs]), g[f"{name}.threshold.low"])
+    assert np.array_equal(np.stack([o.as_binary(f, 30000) for f in fs]), g[f"{name}.as_binary"])
+    assert np.array_equal(np.stack([o.ground(f) for f in fs]), g[f"{name}.ground"])
+    assert np.array_equal(np.stack([o.normalize(f) for f in fs]), g[f"{name}.normalize"])
+    assert np.array_equal(np.stack([o.invert(f) for f in fs]), g[f"{name}.invert"])
+    assert np.array_equal(np.stack([o.stretch(f.astype(float), 0, 1) for f in fs]), g[f"{name}.stretch"])
+    q = [0.5, 5, 50, 95, 99.5, 99.9]
+    assert np.array_equal(np.stack([o.percentile(f, q) for f in fs]), g[f"{name}.percentiles"])
+    # percentile rebuilt from two order statistics with numpy's _lerp
+    for f, ref in zip(fs, g[f"{name}.percentiles"]):
+        srt = np.sort(f.ravel())
+        for qq, r in zip(q, ref):
+            v = qq / 100 * (srt.size - 1)
+            lo = int(np.floor(v))
+            hi = min(lo + 1, srt.size - 1)
+            assert o.percentile_from_order_stats(srt[lo], srt[hi], v - lo) == r
+
+
+def test_float_and_int16_filters(golden):
+    g = golden("frames")
+    for key, size, kind in [("float64.filter.g2", 2, "gaussian"), ("float64.filter.m3", 3, "median"),
+                            ("float32.filter.g2", 2, "gaussian"), ("int16.filter.g2", 2, "gaussian"),
+                            ("int16.filter.m3", 3, "median")]:
+        fs = g[key.split(".")[0] + ".in"]
+        ref = g[key]
+        got = np.stack([o.filter(f, size, kind) for f in fs])
+        assert got.dtype == ref.dtype and np.array_equal(got, ref), key
+        rest = np.stack([o.gaussian_filter_restated(f, size) if kind == "gaussian" else o.median_filter_restated(f, size) for f in fs])
+        assert np.array_equal(rest, ref), key
+
+
+def test_reference_known_answer_tests(golden):
+    """tests_basic/core/test_array_utils.py:65-149, tests_basic/core/test_image.py:450-461,522-535."""
+    g = golden("frames")
+    kat = np.array([0, 0, 0, 3, 0, 0, 0])
+    assert np.array_equal(o.filter(kat, 1, "median"), [0, 0, 0, 3, 0, 0, 0])
+    assert np.array_equal(o.filter(kat, 0.1, "median"), [0, 0, 0, 3, 0, 0, 0])
+    assert np.array_equal(o.filter(kat, 3, "median"), [0, 0, 0, 0, 0, 0, 0])
+    assert np.array_equal(o.filter(np.array([0, 0, 3, 3, 0, 0, 0]), 3, "median"), [0, 0, 3, 3, 0, 0, 0])
+    assert np.array_equal(o.filter(kat, 1, "gaussian"), [0, 0, 0, 1, 0, 0, 0])
+    assert np.array_equal(o.gaussian_filter_restated(kat, 1), [0, 0, 0, 1, 0, 0, 0])
+    for k, v in [("median1", o.filter(kat, 1, "median")), ("median_f01", o.filter(kat, 0.1, "median")),
+                 ("median3", o.filter(kat, 3, "median")), ("gauss1", o.filter(kat, 1, "gaussian"))]:
+        assert np.array_equal(g[f"kat.filter.{k}"], v)
+    with pytest.raises(ValueError):
+        o.filter(kat, 2.3, "gaussian")
+    with pytest.raises(ValueError):
+        o.filter(kat, 1, "filterthis")
+    a = np.arange(42).reshape(6, 7)
+    assert o.filter(a, 3)[0, 0] == 1 and np.array_equal(o.filter(a, 3), g["kat.image.filter3"])
+    assert o.threshold(a, 10)[0, 4] == 0 and np.array_equal(o.threshold(a, 10), g["kat.image.threshold10"])
+    assert np.array_equal(o.threshold(a, 20, "low"), g["kat.image.threshold20low"])
+    n = o.normalize(np.array((1, 2, 3, 4)))
+    assert n.max() == 1.0 and n[0] == 0.25 and np.array_equal(n, g["kat.normalize"])
+    assert np.array_equal(o.normalize(np.array((1, 2, 3, 4), dtype=float), 2), g["kat.normalize2"])
+    assert np.array_equal(o.invert(np.array([0, 10])), [10, 0])
+    assert np.array_equal(o.invert(np.array([-5, -1])), [-1, -5])
+    assert np.array_equal(o.ground(np.array([3, 4, 5])), [0, 1, 2])
+    assert np.array_equal(o.ground(np.array([-3, -4, -5])), [2, 1, 0])
+    assert np.array_equal(o.ground(np.array([3, 4, 5]), value=10), [10, 11, 12])
+
+
+def test_otsu_matches_skimage_golden(golden):
+    g = golden("otsu")
+    for k in ["u16_field", "u16_random", "i16", "const", "two_level"]:
+        got = np.array([int(o.threshold_otsu(f)) for f in g[f"{k}.in"]])
+        assert np.array_equal(got, g[f"{k}.otsu"]), k
+
+
+def _variants(g):
+    return json.loads(str(g["variants"]))
+
+
+def _fix(kw):
+    kw = dict(kw)
+    if "search_region" in kw:
+        kw["search_region"] = tuple(kw["search_region"])
+    return kw
+
+
+PROFILES = ["simple9", "simple8", "long23", "long22", "skewed19", "sigmoid21", "sawtooth", "walk600", "pickets",
+            "noisy_field"]
+
+
+@pytest.mark.parametrize("impl", ["scipy", "restated"])
+def test_find_peaks_matches_reference_golden(golden, impl):
+    g = golden("peaks")
+    checked = 0
+    for pname in PROFILES:
+        vals = g[f"{pname}.values"]
+        for vname, kw in _variants(g).items():
+            key = f"{pname}.{vname}"
+            if f"{key}.error" in g.files:
+                with pytest.raises((IndexError, ValueError)):
+                    o.find_peaks(vals, impl=impl, **_fix(kw))
+                continue
+            idx, props = o.find_peaks(vals, impl=impl, **_fix(kw))
+            assert np.array_equal(idx, g[f"{key}.idx"]), key
+            for k, v in props.items():
+                assert np.array_equal(v, g[f"{key}.{k}"]), (key, k)
+            checked += 1
+    assert checked > 50
+
+
+def test_multiprofile_and_fwxm_match_reference_golden(golden):
+    g = golden("peaks")
+    for pname in PROFILES:
+        vals = g[f"{pname}.values"]
+        for tag, fn in [("peaks", o.multiprofile_find_peaks), ("valleys", o.multiprofile_find_valleys),
+                        ("fwxm", o.multiprofile_find_fwxm_peaks)]:
+            i, v = fn(vals)
+            assert np.array_equal(i, g[f"{pname}.mp.{tag}.idx"]), (pname, tag)
+            assert np.array_equal(v, g[f"{pname}.mp.{tag}.val"]), (pname, tag)
+        for h in (25, 50, 75):
+            if f"{pname}.fwxm{h}.error" in g.files:
+                with pytest.raises(IndexError):
+                    o.fwxm_edges(vals, h)
+            else:
+                assert np.array_equal(np.array(o.fwxm_edges(vals, h)), g[f"{pname}.fwxm{h}"]), (pname, h)
+
+
+def test_fwxm_known_answers():
+    """tests_basic/core/test_profile.py:272-325 (assertEqual == exact)."""
+    s9 = np.array([0, 1, 2, 3, 4, 3, 2, 1, 0], dtype=float)
+    s8 = np.array([0, 1, 2, 3, 3, 2, 1, 0], dtype=float)
+    sk = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 8, 6, 4, 2, 0], dtype=float)
+    assert o.fwxm_edges(s9, 50) == (2, 6, 4, 4)
+    assert o.fwxm_edges(s8, 50) == (1.5, 5.5, 3.5, 4)
+    assert o.fwxm_edges(s9, 25)[:2] == (1, 7) and o.fwxm_edges(s9, 25)[3] == 6
+    assert o.fwxm_edges(s9, 75)[:2] == (3, 5)
+    assert o.fwxm_edges(sk, 50)[:2] == (5, 14.5) and o.fwxm_edges(sk, 50)[3] == 9.5
+
+
+def test_sawtooth_multiprofile_known_answers(golden):
+    """tests_basic/core/test_profile.py:2717-2722 (+-1 index)."""
+    vals = golden("peaks")["sawtooth.values"]
+    assert np.allclose(o.multiprofile_find_peaks(vals)[0], (25, 75, 125, 175), atol=1)
+    assert np.allclose(o.multiprofile_find_fwxm_peaks(vals)[0], (25, 75, 125, 175), atol=1)
+    assert np.allclose(o.multiprofile_find_valleys(vals)[0], (50, 100, 150), atol=1)
+
+
+def test_pipeline_matches_reference_golden(golden):
+    g = golden("epid_pipeline")
+    out, prof, rec = o.epid_pipeline(g["in"])
+    assert np.array_equal(out, g["out"])
+    assert np.array_equal(prof, g["profile"])
+    assert np.array_equal(rec[:, 0], g["otsu"])
+    assert np.array_equal(rec[:, 5:9], g["fwxm"])
+
+
+def test_restatements_against_scipy_random():
+    rng = np.random.default_rng(99)
+    a = rng.integers(0, 65536, (70, 93), dtype=np.uint16)
+    for s in (1, 3, 5, 7):
+        assert np.array_equal(o.gaussian_filter_restated(a, s), ndimage.gaussian_filter(a, s))
+    for s in (2, 3, 4, 6):
+        assert np.array_equal(o.median_filter_restated(a, s), ndimage.median_filter(a, size=s))
+    const = np.full((40, 40), 65535, np.uint16)
+    assert np.array_equal(o.gaussian_filter_restated(const, 5), ndimage.gaussian_filter(const, 5))
+    for trial in range(120):
+        n = int(rng.integers(3, 300))
+        x = rng.normal(size=n).cumsum()
+        kw = dict(height=[None, -np.inf, x.min() + 0.3 * np.ptp(x)][trial % 3], distance=[None, 1, 5, 17][trial % 4],
+                  prominence=[None, 0.5, 2][(trial // 2) % 3], width=0, rel_height=[0.5, 0.2, 0.75][trial % 3])
+        p1, r1 = signal.find_peaks(x, **kw)
+        p2, r2 = o.scipy_find_peaks_restated(x, **kw)
+        assert np.array_equal(p1, p2)
+        for k in r1:
+            assert np.array_equal(r1[k], r2[k]), k
+    # plateaus (integer data) without a distance filter (tie order there is implementation-defined)
+    for trial in range(60):
+        x = rng.integers(0, 6, int(rng.integers(3, 200))).astype(float)
+        p1, r1 = signal.find_peaks(x, height=-np.inf, distance=1, width=0, rel_height=0.5)
+        p2, r2 = o.scipy_find_peaks_restated(x, height=-np.inf, distance=1, width=0, rel_height=0.5)
+        assert np.array_equal(p1, p2)
+        for k in r1:
+            assert np.array_equal(r1[k], r2[k]), k
