@@ -448,9 +448,9 @@ def test_full_size_frames_vs_oracle_and_properties(dev):
     assert bool((hist.to(torch.int64).sum(dim=1) == h * w).all())
     # permutation equivariance: frames are independent
     perm = torch.randperm(n, device=dev)
-    res2 = pipe.run(fr[perm].contiguous())
+    res2 = pipe.run(fr.view(torch.int16)[perm].contiguous().view(torch.uint16))
     assert torch.equal(res2.threshold, thr[perm])
-    assert torch.equal(res2.frames.view(torch.int16), out[perm].view(torch.int16))
+    assert torch.equal(res2.frames.view(torch.int16), out.view(torch.int16)[perm])
     assert torch.equal(res2.fwxm, fw[perm])
     # physics sanity: a ~595 px (20 cm) field centred near the middle
     assert bool(((fw[:, 7] > 560) & (fw[:, 7] < 630)).all()) and bool(((fw[:, 6] - 511.5).abs() < 8).all())
