@@ -1,0 +1,39 @@
+"""Condense rocprofv3 CSV output (kernel stats + PMC counter collection) into a small text/JSON
+summary: per-kernel launch count, average duration, and per-launch FETCH_SIZE / WRITE_SIZE."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name.split("(")[0][:70]
+
+
+summary = {}
+for f in glob.glob(os.path.join(out, "trace", "*kernel_stats.csv")):
+    print("== kernel stats:", os.path.basename(f))
+    for row in csv.DictReader(open(f)):
+        name = short(row["Name"])
+        print(f'{name:72s} calls={row["Calls"]:>6s} avg_ns={float(row["AverageNs"]):12.0f} total%={row["Percentage"]}')
+        summary.setdefault(name, {})["avg_us"] = float(row["AverageNs"]) / 1e3
+        summary[name]["calls"] = int(row["Calls"])
+for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(out, sub, "*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == counter:
+                acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    print(f"== {counter} per launch (raw counter units = KiB as reported by rocprofv3)")
+    for name, v in sorted(acc.items()):
+        avg = sum(v) / len(v)
+        print(f"{name:72s} n={len(v):4d} avg={avg:14.1f}")
+        summary.setdefault(name, {})[counter] = avg
+json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
