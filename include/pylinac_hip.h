@@ -66,6 +66,13 @@ int pl_gaussian1d(const void* in, void* out, int dtype, int64_t n, int h, int w,
 int pl_gaussian2d(const void* in, void* out, void* tmp, int dtype, int64_t n, int h, int w,
                   const double* d_weights, int radius, void* stream);
 
+/* Pipeline fusion of Image.filter(sigma,"gaussian")'s axis-1 pass with Image.filter(3,"median")
+ * (pylinac/core/image.py:695-712 twice; the PF noise filter, pylinac/picketfence.py:226):
+ * out = median3x3(gauss_axis1(in)); the intermediate never leaves LDS.  tmp is only touched by the
+ * unfused fallback (unsupported dtype / radius / very wide frames). */
+int pl_gauss_h_median3(const void* in, void* out, void* tmp, int dtype, int64_t n, int h, int w,
+                       const double* d_weights, int radius, void* stream);
+
 /* ---- a1: ndimage.median_filter(size=s) (pylinac/core/array_utils.py:131) ------------------------
  * s x s window (h > 1) or length-s window (h == 1), mode='reflect', origin 0, rank (s*s)/2. */
 int pl_median2d(const void* in, void* out, int dtype, int64_t n, int h, int w, int size,

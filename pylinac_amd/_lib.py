@@ -53,6 +53,7 @@ SIGNATURES = {
     "pl_device_available": ([], C.c_int),
     "pl_gaussian1d": ([_p, _p, _i, _l, _i, _i, _i, _p, _i, _p], C.c_int),
     "pl_gaussian2d": ([_p, _p, _p, _i, _l, _i, _i, _p, _i, _p], C.c_int),
+    "pl_gauss_h_median3": ([_p, _p, _p, _i, _l, _i, _i, _p, _i, _p], C.c_int),
     "pl_median2d": ([_p, _p, _i, _l, _i, _i, _i, _p], C.c_int),
     "pl_minmax": ([_p, _i, _l, _l, _p, _p, _p], C.c_int),
     "pl_ground": ([_p, _p, _i, _l, _l, _p, _d, _p], C.c_int),

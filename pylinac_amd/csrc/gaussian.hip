@@ -9,9 +9,11 @@
 //   in float64 without FMA contraction, borders 'reflect', result C-cast into the image dtype
 //   (integer dtypes: truncation toward zero), and that dtype feeds the next axis.
 //
-// This is 61 float64 VALU operations per pixel per pass at sigma=5 (radius 20): the pass is bound
-// by the FP64 issue rate (16 lanes/clk/SIMD), not by HBM -- see DESIGN.md.  The design therefore
-// minimises everything that is NOT one of those 61 operations:
+// The exact sequence is 61 float64 VALU operations per pixel per pass at sigma=5 (radius 20): the
+// pass is bound by the FP64 issue rate (16 lanes/clk/SIMD), not by HBM -- see DESIGN.md.  For integer
+// images a 41-op float64 FMA chain decides the truncated result whenever it is provably the same
+// (eval_window), the exact chain runs only on the ambiguous (constant/saturated) regions.  Everything
+// that is NOT one of those float64 operations is minimised:
 //   * vertical pass: one lane owns one column and NOUT consecutive rows; the NOUT+2*RAD inputs are
 //     loaded once (coalesced 64-lane row segments, rows wave-uniform so the reflect index is
 //     scalar) and converted once; the taps sit in SGPRs (uniform scalar loads).
@@ -25,9 +27,66 @@ namespace {
 
 constexpr int kThreads = 256;
 
+template <typename T> struct IsInt { static constexpr bool value = true; };
+template <> struct IsInt<float> { static constexpr bool value = false; };
+template <> struct IsInt<double> { static constexpr bool value = false; };
+
+// scipy's exact float64 sequence for one output centred at x[c] (no FMA; -ffp-contract=off).
+// OPAQUE = true launders every operand through an empty asm so that the compiler cannot share the
+// pair sums with the FMA chain of eval_window (sharing them keeps 8x20 doubles alive -> spills).
+template <int RAD, bool OPAQUE>
+__device__ __forceinline__ double taps_exact(const double* x, int c, const double* __restrict__ wts) {
+  auto ld = [](double v) -> double {
+    if constexpr (OPAQUE) asm volatile("" : "+v"(v));
+    return v;
+  };
+  double acc = ld(x[c]) * wts[RAD];
+#pragma unroll
+  for (int j = RAD; j >= 1; --j) acc = acc + (ld(x[c - j]) + ld(x[c + j])) * wts[RAD - j];
+  return acc;
+}
+
+// NOUT outputs from a register window x[NOUT + 2*RAD].
+// Integer dtypes: the result is trunc(S) where S is scipy's 61-op sequence.  A float64 FMA chain
+// (41 ops: the pair sums are exact either way) gives S' with |S' - S| <= (2*RAD+2) * 2^-52 * max|partial|,
+// so trunc(S') == trunc(S) unless S' lies within that bound of an integer -- which happens on
+// constant / saturated regions (S ~= c * sum(w) = c +- 1e-12), practically never on noisy data.
+// Only then is the exact sequence evaluated (for all NOUT outputs of the lane; rare, wave-coherent).
+// Float dtypes have no truncation to hide behind: always the exact sequence.
+template <typename T, int RAD, int NOUT>
+__device__ __forceinline__ void eval_window(const double* x, const double* __restrict__ wts, T* res) {
+  if constexpr (!IsInt<T>::value) {
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) res[i] = pl_from_double<T>(taps_exact<RAD, false>(x, i + RAD, wts));
+  } else {
+    double acc[NOUT];
+    bool ambiguous = false;
+    constexpr double kRel = (2 * RAD + 4) * 2.220446049250313e-16;  // 2x margin on the bound
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      double a = x[i + RAD] * wts[RAD];
+#pragma unroll
+      for (int j = RAD; j >= 1; --j) a = __builtin_fma(x[i + RAD - j] + x[i + RAD + j], wts[RAD - j], a);
+      acc[i] = a;
+      // |fract(|a|) - 0.5| > 0.5 - eps  <=>  a within eps of an integer (4 f64 ops)
+      const double mag = __builtin_fabs(a);
+      const double eps = (sizeof(T) <= 2) ? kRel * 65536.0 : kRel * mag;
+      const double off = __builtin_fabs(__builtin_amdgcn_fract(mag) - 0.5);
+      // a == 0 exactly: every product is zero (or cancels to < 1e-9) -> trunc is 0 either way
+      ambiguous |= (a != 0.0) && (off > 0.5 - eps);
+    }
+    if (ambiguous) {
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) acc[i] = taps_exact<RAD, true>(x, i + RAD, wts);
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) res[i] = pl_from_double<T>(acc[i]);
+  }
+}
+
 // ------------------------------------------------------------------ vertical (axis 0), fast path
 template <typename T, int RAD, int NOUT>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 4)
 gauss_v_fast(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_tiles,
              int row_groups, const double* __restrict__ wts) {
   const unsigned nwg = gridDim.x;
@@ -43,34 +102,41 @@ gauss_v_fast(const T* __restrict__ in, T* __restrict__ out, int h, int w, int co
   const T* f = in + frame * (size_t)h * w;
   T* o = out + frame * (size_t)h * w;
 
+  // row pointers are wave-uniform (SALU address arithmetic); the lane's 32-bit byte offset is
+  // constant -> global_load saddr + voffset form, no per-load VALU address arithmetic
+  const unsigned coff = (unsigned)c * (unsigned)sizeof(T);
   double x[NOUT + 2 * RAD];
   if (r0 - RAD >= 0 && r0 + NOUT + RAD <= h) {
-    const T* p = f + (size_t)(r0 - RAD) * w + c;
+    const T* row = f + (size_t)(r0 - RAD) * w;
 #pragma unroll
-    for (int k = 0; k < NOUT + 2 * RAD; ++k) x[k] = (double)p[(size_t)k * w];
+    for (int k = 0; k < NOUT + 2 * RAD; ++k) {
+      x[k] = (double)*reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + coff);
+      row += w;
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < NOUT + 2 * RAD; ++k) {
-      int r = pl_reflect(r0 - RAD + k, h);  // wave-uniform
-      x[k] = (double)f[(size_t)r * w + c];
+      const T* row = f + (size_t)pl_reflect(r0 - RAD + k, h) * w;  // wave-uniform
+      x[k] = (double)*reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + coff);
     }
   }
+  T res[NOUT];
+  eval_window<T, RAD, NOUT>(x, wts, res);
+  T* orow = o + (size_t)r0 * w;
 #pragma unroll
   for (int i = 0; i < NOUT; ++i) {
-    double acc = x[i + RAD] * wts[RAD];
-#pragma unroll
-    for (int j = RAD; j >= 1; --j) acc = acc + (x[i + RAD - j] + x[i + RAD + j]) * wts[RAD - j];
-    if (r0 + i < h) o[(size_t)(r0 + i) * w + c] = pl_from_double<T>(acc);
+    if (r0 + i < h) *reinterpret_cast<T*>(reinterpret_cast<char*>(orow) + coff) = res[i];
+    orow += w;
   }
 }
 
 // ---------------------------------------------------------------- horizontal (axis 1), fast path
 // LDS layout per wave: logical position p in [0, 64*NOUT + 2*RAD) <-> column c0 - RAD + p,
 // stored at p + 2*(p >> 3) doubles (16-byte pad after every 64 bytes).
-__device__ __forceinline__ int pad8(int p) { return p + ((p >> 3) << 1); }
+__device__ __forceinline__ constexpr int pad8(int p) { return p + ((p >> 3) << 1); }
 
 template <typename T, int RAD, int NOUT>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 3)
 gauss_h_fast(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, int w,
              int col_tiles, const double* __restrict__ wts) {
   static_assert(NOUT == 8, "pad8 assumes 8 outputs per lane");
@@ -99,12 +165,12 @@ gauss_h_fast(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, 
     union { uint4 v; T e[NOUT]; } u;
     u.v = *reinterpret_cast<const uint4*>(f + c);
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) s[pad8(RAD + lane * NOUT + k)] = (double)u.e[k];
+    for (int k = 0; k < NOUT; ++k) s[10 * lane + pad8(RAD + k)] = (double)u.e[k];
   } else {
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) {
       int cc = pl_reflect(c + k, w);
-      s[pad8(RAD + lane * NOUT + k)] = (double)f[cc];
+      s[10 * lane + pad8(RAD + k)] = (double)f[cc];
     }
   }
   if (lane < RAD) {
@@ -126,13 +192,7 @@ gauss_h_fast(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, 
   for (int k = 0; k < NOUT + 2 * RAD; ++k) x[k] = win[k + ((k >> 3) << 1)];
 
   T res[NOUT];
-#pragma unroll
-  for (int i = 0; i < NOUT; ++i) {
-    double acc = x[i + RAD] * wts[RAD];
-#pragma unroll
-    for (int j = RAD; j >= 1; --j) acc = acc + (x[i + RAD - j] + x[i + RAD + j]) * wts[RAD - j];
-    res[i] = pl_from_double<T>(acc);
-  }
+  eval_window<T, RAD, NOUT>(x, wts, res);
   if (c + NOUT <= w && (sizeof(T) * NOUT == 16) && ((reinterpret_cast<uintptr_t>(o + c) & 15) == 0)) {
     union { uint4 v; T e[NOUT]; } u;
 #pragma unroll
@@ -142,6 +202,145 @@ gauss_h_fast(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, 
 #pragma unroll
     for (int k = 0; k < NOUT; ++k)
       if (c + k < w) o[c + k] = res[k];
+  }
+}
+
+// ------------------------------------------------- horizontal pass fused with the 3x3 median filter
+// BaseImage.filter(s, "gaussian") followed by BaseImage.filter(3, "median") (pylinac/core/image.py:
+// 695-712 twice; the PF noise filter is the size-3 median, pylinac/picketfence.py:226).
+// One 768-lane workgroup owns TR output rows of one frame over the full width:
+//   phase 1  its 12 waves compute the horizontal Gaussian of the TR+2 rows the median needs
+//            (same per-wave LDS-staged window evaluation as gauss_h_fast) and keep the truncated
+//            results in LDS (u16/i16 rows, never written to HBM);
+//   phase 2  lane = column slides down the LDS rows: sorted horizontal triples, median of nine =
+//            med3(max3(lows), med3(mids), min3(highs)); one coalesced global store per row.
+// HBM traffic: reads the axis-0 result once (+2 halo rows per band from L2), writes the median
+// once -- the unfused pair costs an extra frame write + read.  The (TR+2)/TR recompute is the price.
+constexpr int kFusedThreads = 768;  // 12 waves = 3 per SIMD: <=168 VGPRs, no spills in the task loop
+
+template <typename T, int RAD>
+__global__ void __launch_bounds__(kFusedThreads)
+gauss_h_median3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w, int tr, int bands,
+                       int hpitch, const double* __restrict__ wts) {
+  constexpr int NOUT = 8;
+  constexpr int SEG = PL_WAVE * NOUT;
+  constexpr int LOGICAL = SEG + 2 * RAD;
+  constexpr int PADDED = LOGICAL + ((LOGICAL + 7) / 8) * 2;
+  constexpr int WAVES = kFusedThreads / PL_WAVE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
+  double* stage = reinterpret_cast<double*>(fused_smem);                 // [WAVES][PADDED]
+  T* hrows = reinterpret_cast<T*>(stage + WAVES * PADDED);               // [tr+2][hpitch]
+
+  const unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
+  const int band = id % bands;
+  const size_t frame = id / bands;
+  const int r0 = band * tr;
+  const int rows_here = (r0 + tr <= h) ? tr : (h - r0);
+  const T* f = in + frame * (size_t)h * w;
+  T* o = out + frame * (size_t)h * w;
+  const int lane = threadIdx.x & (PL_WAVE - 1);
+  const int wave = threadIdx.x / PL_WAVE;
+  const int segs = (w + SEG - 1) / SEG;
+  const int tasks = (rows_here + 2) * segs;
+  double* s = stage + wave * PADDED;
+
+  for (int task = wave; task < tasks; task += WAVES) {
+    const int k = task / segs;               // LDS row 0..rows_here+1  <->  frame row r0-1+k
+    const int c0 = (task % segs) * SEG;
+    const T* frow = f + (size_t)pl_reflect(r0 - 1 + k, h) * w;
+    const int c = c0 + lane * NOUT;
+    if (c + NOUT <= w && ((reinterpret_cast<uintptr_t>(frow + c) & 15) == 0)) {
+      union { uint4 v; T e[NOUT]; } u;
+      u.v = *reinterpret_cast<const uint4*>(frow + c);
+#pragma unroll
+      for (int q = 0; q < NOUT; ++q) s[10 * lane + pad8(RAD + q)] = (double)u.e[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NOUT; ++q) s[10 * lane + pad8(RAD + q)] = (double)frow[pl_reflect(c + q, w)];
+    }
+    if (lane < RAD) {
+      s[pad8(lane)] = (double)frow[pl_reflect(c0 - RAD + lane, w)];
+    } else if (lane < 2 * RAD) {
+      const int p = SEG + lane;
+      s[pad8(p)] = (double)frow[pl_reflect(c0 - RAD + p, w)];
+    }
+    // order this wave's LDS writes before its LDS reads (in-order per wave; compiler barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (c < w) {
+      double x[NOUT + 2 * RAD];
+      const double* win = s + 10 * lane;
+#pragma unroll
+      for (int q = 0; q < NOUT + 2 * RAD; ++q) x[q] = win[q + ((q >> 3) << 1)];
+      union { uint4 v; T e[NOUT]; } r;
+      eval_window<T, RAD, NOUT>(x, wts, r.e);
+      *reinterpret_cast<uint4*>(hrows + (size_t)k * hpitch + c) = r.v;  // hpitch % 8 == 0: aligned
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();   // the staging window is reused by this wave's next task
+  }
+  __syncthreads();
+
+  // phase 2: 3x3 median over the LDS rows.  Work item = (column pair, third of the band): the pair's
+  // four neighbours come from three 32-bit LDS reads, the sorted horizontal triples of the last
+  // three rows rotate through registers (loop unrolled by 3 so the slots are static).
+  {
+    const int npairs = (w + 1) >> 1;
+    const int rs = (rows_here + 2) / 3;                   // rows per item
+    const int items = npairs * 3;
+    const unsigned* hw = reinterpret_cast<const unsigned*>(hrows);
+    const int wpitch = hpitch >> 1;
+    for (int it = threadIdx.x; it < items; it += kFusedThreads) {
+      const int pi = it % npairs;
+      const int i0 = (it / npairs) * rs;
+      const int i1 = (i0 + rs < rows_here) ? i0 + rs : rows_here;
+      if (i0 >= i1) continue;
+      const int ca = 2 * pi;
+      const bool interior = (pi >= 1) && (ca + 2 < w);
+      const int c_m1 = pl_reflect(ca - 1, w), c_p1 = pl_reflect(ca + 1, w), c_p2 = pl_reflect(ca + 2, w);
+      int lo0[3], mi0[3], hi0[3], lo1[3], mi1[3], hi1[3];
+      auto load_row = [&](int k, int slot) {
+        int a, b, c, d;
+        if (interior) {
+          const unsigned* p = hw + (size_t)k * wpitch + pi;
+          const unsigned L = p[-1], C = p[0], R = p[1];
+          a = (int)(T)(L >> 16); b = (int)(T)(C & 0xffffu); c = (int)(T)(C >> 16); d = (int)(T)(R & 0xffffu);
+        } else {
+          const T* p = hrows + (size_t)k * hpitch;
+          a = (int)p[c_m1]; b = (int)p[ca]; c = (int)p[c_p1]; d = (int)p[c_p2];
+        }
+        lo0[slot] = min(min(a, b), c); hi0[slot] = max(max(a, b), c);
+        mi0[slot] = max(min(a, b), min(max(a, b), c));
+        lo1[slot] = min(min(b, c), d); hi1[slot] = max(max(b, c), d);
+        mi1[slot] = max(min(b, c), min(max(b, c), d));
+      };
+      auto emit = [&](int i) {
+        const int m0 = max(min(max(max(lo0[0], lo0[1]), lo0[2]), max(min(mi0[0], mi0[1]), min(max(mi0[0], mi0[1]), mi0[2]))),
+                           min(max(max(max(lo0[0], lo0[1]), lo0[2]), max(min(mi0[0], mi0[1]), min(max(mi0[0], mi0[1]), mi0[2]))),
+                               min(min(hi0[0], hi0[1]), hi0[2])));
+        const int m1 = max(min(max(max(lo1[0], lo1[1]), lo1[2]), max(min(mi1[0], mi1[1]), min(max(mi1[0], mi1[1]), mi1[2]))),
+                           min(max(max(max(lo1[0], lo1[1]), lo1[2]), max(min(mi1[0], mi1[1]), min(max(mi1[0], mi1[1]), mi1[2]))),
+                               min(min(hi1[0], hi1[1]), hi1[2])));
+        T* op = o + (size_t)(r0 + i) * w + ca;
+        if (ca + 1 < w && ((reinterpret_cast<uintptr_t>(op) & 3) == 0)) {
+          *reinterpret_cast<unsigned*>(op) = ((unsigned)m0 & 0xffffu) | ((unsigned)m1 << 16);
+        } else {
+          op[0] = (T)m0;
+          if (ca + 1 < w) op[1] = (T)m1;
+        }
+      };
+      // LDS row k holds frame row r0-1+k: output row i needs LDS rows i, i+1, i+2
+      load_row(i0, 0);
+      load_row(i0 + 1, 1);
+      int i = i0;
+      for (; i + 3 <= i1; i += 3) {
+        load_row(i + 2, 2); emit(i);
+        load_row(i + 3, 0); emit(i + 1);
+        load_row(i + 4, 1); emit(i + 2);
+      }
+      if (i < i1) { load_row(i + 2, 2); emit(i); ++i; }
+      if (i < i1) { load_row(i + 2, 0); emit(i); }
+    }
   }
 }
 
@@ -242,6 +441,79 @@ extern "C" int pl_gaussian1d(const void* in, void* out, int dtype, int64_t n, in
   PL_DISPATCH_DTYPE(dtype, T,
                     return gaussian1d_t<T>((const T*)in, (T*)out, n, h, w, axis, d_weights, radius, st));
   return PL_OK;
+}
+
+namespace {
+template <typename T, int RAD>
+int launch_fused(const T* in, T* out, int64_t n, int h, int w, const double* wts, hipStream_t st) {
+  constexpr int PADDED = (512 + 2 * RAD) + ((512 + 2 * RAD + 7) / 8) * 2;
+  const int hpitch = (w + 7) & ~7;
+  const size_t stage_bytes = (size_t)(kFusedThreads / PL_WAVE) * PADDED * sizeof(double);
+  const size_t lds_budget = 158 * 1024 - stage_bytes;
+  int tr = (int)(lds_budget / ((size_t)hpitch * sizeof(T))) - 2;
+  if (tr > 46) tr = 46;
+  if (tr > h) tr = h;
+  if (tr < 4) return -1;  // very wide frames: unfused path
+  // prefer a band height whose (tr+2) x segments task count divides evenly over the waves
+  {
+    const int segs = (int)pl_cdiv(w, 512), waves = kFusedThreads / PL_WAVE;
+    for (int t = tr; t >= tr - 8 && t >= 4; --t)
+      if (((t + 2) * segs) % waves == 0) { tr = t; break; }
+  }
+  const size_t lds = stage_bytes + (size_t)(tr + 2) * hpitch * sizeof(T);
+  const int bands = (int)pl_cdiv(h, tr);
+  if (n * bands > 0x7fffffffLL) return -1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)gauss_h_median3_kernel<T, RAD>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gauss_h_median3_kernel<T, RAD>), dim3((unsigned)(n * bands)), dim3(kFusedThreads), lds,
+                     st, in, out, h, w, tr, bands, hpitch, wts);
+  return 0;
+}
+}  // namespace
+
+// Horizontal Gaussian pass fused with a 3x3 median:  out = median3(gauss_axis1(in)).
+// Falls back to the two separate kernels (through tmp) for unsupported dtype/radius/width.
+extern "C" int pl_gauss_h_median3(const void* in, void* out, void* tmp, int dtype, int64_t n, int h,
+                                  int w, const double* d_weights, int radius, void* stream);
+extern "C" int pl_median2d(const void* in, void* out, int dtype, int64_t n, int h, int w, int size,
+                           void* stream);
+
+extern "C" int pl_gauss_h_median3(const void* in, void* out, void* tmp, int dtype, int64_t n, int h,
+                                  int w, const double* d_weights, int radius, void* stream) {
+  PL_REQUIRE(in && out && tmp && d_weights, "null pointer");
+  PL_REQUIRE(in != out && tmp != in && tmp != out, "buffers must be distinct");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0 && radius >= 0, "bad shape");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = -1;
+  if (h > 1 && (dtype == PL_U16 || dtype == PL_I16)) {
+#define PL_FUSED_CASE(R)                                                                                   \
+  case R:                                                                                                  \
+    rc = (dtype == PL_U16)                                                                                 \
+             ? launch_fused<unsigned short, R>((const unsigned short*)in, (unsigned short*)out, n, h, w,  \
+                                               d_weights, st)                                              \
+             : launch_fused<short, R>((const short*)in, (short*)out, n, h, w, d_weights, st);             \
+    break;
+    switch (radius) {
+      PL_FUSED_CASE(4)
+      PL_FUSED_CASE(8)
+      PL_FUSED_CASE(12)
+      PL_FUSED_CASE(20)
+      default: break;
+    }
+#undef PL_FUSED_CASE
+  }
+  if (rc == 0) return pl_check_launch("pl_gauss_h_median3");
+  rc = pl_gaussian1d(in, tmp, dtype, n, h, w, 1, d_weights, radius, stream);
+  if (rc != PL_OK) return rc;
+  return pl_median2d(tmp, out, dtype, n, h, w, 3, stream);
 }
 
 extern "C" int pl_gaussian2d(const void* in, void* out, void* tmp, int dtype, int64_t n, int h,

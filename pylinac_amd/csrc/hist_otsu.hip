@@ -56,15 +56,25 @@ hist16_kernel(const unsigned short* __restrict__ in, int64_t n, int64_t count, u
   unsigned prev = 0xffffffffu, run = 0;
   if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const int64_t nvec = count / 8;
-    for (int64_t v = threadIdx.x; v < nvec; v += kHistThreads) {
-      uint4 q = reinterpret_cast<const uint4*>(src)[v];
-      unsigned wds[4] = {q.x, q.y, q.z, q.w};
+    const uint4* vsrc = reinterpret_cast<const uint4*>(src);
+    auto tally4 = [&](uint4 q) {
+      const unsigned wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         tally(wds[k] & 0xffffu, prev, run);
         tally(wds[k] >> 16, prev, run);
       }
+    };
+    int64_t v = threadIdx.x;
+    constexpr int U = 4;  // independent 16-byte loads in flight per lane
+    for (; v + (int64_t)(U - 1) * kHistThreads < nvec; v += (int64_t)U * kHistThreads) {
+      uint4 q[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) q[k] = vsrc[v + (int64_t)k * kHistThreads];
+#pragma unroll
+      for (int k = 0; k < U; ++k) tally4(q[k]);
     }
+    for (; v < nvec; v += kHistThreads) tally4(vsrc[v]);
     for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally(src[i], prev, run);
   } else {
     for (int64_t i = threadIdx.x; i < count; i += kHistThreads) tally(src[i], prev, run);

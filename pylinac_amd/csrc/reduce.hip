@@ -11,7 +11,8 @@
 //
 // pl_threshold_colsum_u16 fuses BaseImage.threshold (pylinac/core/image.py:797-800) with the
 // axis-0 column sums of the thresholded frame: one read and one write of the frame, 16-byte
-// accesses, per-lane uint32 partial sums over a 32-row band, one uint64 atomic per column/band.
+// accesses (4 independent loads in flight per lane), per-lane uint32 partial sums over a 128-row
+// band, one uint64 atomic per column/band.
 #include "pl_common.h"
 
 namespace {
@@ -85,8 +86,9 @@ reduce_axis1_kernel(const T* __restrict__ in, int64_t rows_total, int w, int op,
 }
 
 // ------------------------------------------------------------- fused threshold + column sums
-constexpr int kBandRows = 32;
+constexpr int kBandRows = 128;
 constexpr int kTcThreads = 128;  // 128 lanes x 8 columns = 1024 columns per sweep
+constexpr int kTcUnroll = 4;     // independent 16-byte loads in flight per lane
 
 __global__ void __launch_bounds__(kTcThreads)
 threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, int h,
@@ -106,17 +108,27 @@ threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* _
   if (vec) {
     for (int c = threadIdx.x * 8; c < w; c += kTcThreads * 8) {
       unsigned s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int r = r0; r < r1; ++r) {
+      auto apply = [&](uint4 q) -> uint4 {
         union { uint4 q; unsigned short e[8]; } u;
-        u.q = *reinterpret_cast<const uint4*>(f + (size_t)r * w + c);
+        u.q = q;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          unsigned short v = ((int)u.e[k] >= t) ? u.e[k] : (unsigned short)0;
+          const unsigned short v = ((int)u.e[k] >= t) ? u.e[k] : (unsigned short)0;
           u.e[k] = v;
           s[k] += v;
         }
-        *reinterpret_cast<uint4*>(o + (size_t)r * w + c) = u.q;
+        return u.q;
+      };
+      int r = r0;
+      for (; r + kTcUnroll <= r1; r += kTcUnroll) {
+        uint4 q[kTcUnroll];
+#pragma unroll
+        for (int k = 0; k < kTcUnroll; ++k) q[k] = *reinterpret_cast<const uint4*>(f + (size_t)(r + k) * w + c);
+#pragma unroll
+        for (int k = 0; k < kTcUnroll; ++k) *reinterpret_cast<uint4*>(o + (size_t)(r + k) * w + c) = apply(q[k]);
       }
+      for (; r < r1; ++r)
+        *reinterpret_cast<uint4*>(o + (size_t)r * w + c) = apply(*reinterpret_cast<const uint4*>(f + (size_t)r * w + c));
 #pragma unroll
       for (int k = 0; k < 8; ++k) atomicAdd(cs + c + k, (unsigned long long)s[k]);
     }

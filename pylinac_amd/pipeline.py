@@ -25,7 +25,7 @@ from ._lib import check
 RECORD_FIELDS = ("otsu_threshold", "n_peaks", "peak_idx", "peak_height", "prominence",
                  "left_edge", "right_edge", "center", "width")
 
-STAGES = ("gauss_v", "gauss_h", "median3", "hist16", "otsu", "threshold_colsum", "colsum_to_mean",
+STAGES = ("gauss_v", "gauss_h_median3", "hist16", "otsu", "threshold_colsum", "colsum_to_mean",
           "find_peaks", "fwxm_record")
 
 
@@ -51,6 +51,7 @@ class EpidPipeline:
     sigma: float = 5
     median_size: int = 3
     fwxm_height: float = 50
+    fused: bool = True   # fuse the Gaussian's axis-1 pass with the 3x3 median (one HBM round trip less)
     timings: dict = field(default_factory=dict)
 
     def __post_init__(self):
@@ -104,15 +105,22 @@ class EpidPipeline:
         x = frames.contiguous()
         stage("gauss_v", lambda: lib.pl_gaussian1d(x.data_ptr(), self.buf_a.data_ptr(), U16, n, h, w, 0,
                                                    self.wts.data_ptr(), self.radius, st))
-        stage("gauss_h", lambda: lib.pl_gaussian1d(self.buf_a.data_ptr(), self.buf_b.data_ptr(), U16, n, h, w,
-                                                   1, self.wts.data_ptr(), self.radius, st))
-        stage("median3", lambda: lib.pl_median2d(self.buf_b.data_ptr(), self.buf_a.data_ptr(), U16, n, h, w,
-                                                 self.median_size, st))
-        stage("hist16", lambda: lib.pl_hist16(self.buf_a.data_ptr(), U16, n, h * w, self.hist.data_ptr(), st))
+        if self.fused and self.median_size == 3:
+            stage("gauss_h_median3", lambda: lib.pl_gauss_h_median3(
+                self.buf_a.data_ptr(), self.buf_b.data_ptr(), self.out.data_ptr(), U16, n, h, w,
+                self.wts.data_ptr(), self.radius, st))
+            med = self.buf_b
+        else:
+            stage("gauss_h", lambda: lib.pl_gaussian1d(self.buf_a.data_ptr(), self.buf_b.data_ptr(), U16, n, h,
+                                                       w, 1, self.wts.data_ptr(), self.radius, st))
+            stage("median3", lambda: lib.pl_median2d(self.buf_b.data_ptr(), self.buf_a.data_ptr(), U16, n, h, w,
+                                                     self.median_size, st))
+            med = self.buf_a
+        stage("hist16", lambda: lib.pl_hist16(med.data_ptr(), U16, n, h * w, self.hist.data_ptr(), st))
         stage("otsu", lambda: lib.pl_otsu_from_hist(self.hist.data_ptr(), U16, n, self.thr.data_ptr(),
                                                     self.vmin.data_ptr(), self.vmax.data_ptr(), st))
         stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(
-            self.buf_a.data_ptr(), self.out.data_ptr(), n, h, w, self.thr.data_ptr(), self.colsum.data_ptr(), st))
+            med.data_ptr(), self.out.data_ptr(), n, h, w, self.thr.data_ptr(), self.colsum.data_ptr(), st))
         stage("colsum_to_mean", lambda: lib.pl_colsum_to_mean(self.colsum.data_ptr(), n, w, h,
                                                               self.profile.data_ptr(), st))
         pk = self.peaks

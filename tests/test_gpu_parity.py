@@ -268,6 +268,35 @@ def test_gaussian_extreme_values_and_constants(dev):
         assert np.array_equal(ops.gaussian_filter(T(a, dev), sigma).cpu().numpy(), ref)
 
 
+def test_gaussian_fma_decision_and_exact_fallback_mix(dev):
+    """Integer frames take a float64-FMA chain whose truncation is provably scipy's unless the sum
+    lies within ~1e-9 of an integer; then the exact chain runs.  Frames that mix noisy areas
+    (fast path) with constant blocks, ramps and saturated areas (fallback) exercise both in one
+    wave, for every specialised radius and for the signed dtypes."""
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(12)
+    a = rng.integers(0, 65536, (3, 150, 1100), dtype=np.uint16)
+    a[0, 20:90, 100:700] = 2000
+    a[0, 60:140, 650:1000] = 65535
+    a[1, :, :550] = 0
+    a[1, 40:100, 560:900] = np.arange(340, dtype=np.uint16)[None, :] * 3
+    a[2, 10:140, :] = (np.arange(130, dtype=np.uint16)[:, None] * 500)
+    for sigma in (1, 2, 3, 5):
+        ref = np.stack([o.filter(f, sigma, "gaussian") for f in a])
+        assert np.array_equal(ops.gaussian_filter(T(a, dev), sigma).cpu().numpy(), ref), sigma
+    ai = (a.astype(np.int32) - 32768).astype(np.int16)
+    for sigma in (2, 5):
+        ref = np.stack([o.filter(f, sigma, "gaussian") for f in ai])
+        assert np.array_equal(ops.gaussian_filter(T(ai, dev), sigma).cpu().numpy(), ref), sigma
+    a32 = (a.astype(np.int32) - 30000) * 30000   # large magnitudes: bound scales with |sum|
+    ref = np.stack([o.filter(f, 2, "gaussian") for f in a32])
+    assert np.array_equal(ops.gaussian_filter(T(a32, dev), 2).cpu().numpy(), ref)
+    a64 = a.astype(np.int64) * (1 << 40)          # beyond 2^52: every output must take the exact chain
+    ref = np.stack([o.filter(f, 2, "gaussian") for f in a64[:1, :40, :300]])
+    assert np.array_equal(ops.gaussian_filter(T(a64[:1, :40, :300], dev), 2).cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.int32, np.int64, np.float32, np.float64])
 def test_other_dtypes_vs_oracle(dev, dtype):
     from pylinac_amd import ops
@@ -399,13 +428,51 @@ def test_peak_capacity_overflow_is_reported_not_hidden(dev):
 
 
 # ------------------------------------------------------------------------ pipeline + full-size tests
-def test_epid_pipeline_vs_oracle_small(dev):
+def test_fused_gauss_h_median3_vs_oracle(dev):
+    """pl_gauss_h_median3 == median3(gauss axis-1 pass): ragged widths/heights (several column
+    segments, partial bands, band height limited by LDS), both 16-bit dtypes, every specialised
+    radius, and the unfused fallback (unsupported radius)."""
+    from pylinac_amd import _lib, ops
+
+    lib = _lib.load()
+    rng = np.random.default_rng(31)
+    for shape in [(2, 61, 700), (1, 95, 1024), (3, 7, 40), (1, 33, 2100), (2, 2, 9)]:
+        a = rng.integers(0, 65536, shape, dtype=np.uint16)
+        a[0, : shape[1] // 2, : shape[2] // 3] = 4000  # constant block -> exact-chain fallback
+        for sigma in (1, 2, 3, 5, 6):
+            w, lw = o.gaussian_kernel1d(sigma)
+            ref = np.stack([o.median_filter_restated(
+                o.cast_like_scipy(o._correlate1d_symmetric(f, w, lw, 1), f.dtype), 3) for f in a])
+            for arr, refa, dt in ((a, ref, _lib.PL_U16),):
+                t = T(arr, dev)
+                out = torch.empty_like(t)
+                tmp = torch.empty_like(t)
+                wts, rad = ops._device_weights(sigma, dev)
+                rc = lib.pl_gauss_h_median3(t.data_ptr(), out.data_ptr(), tmp.data_ptr(), dt, *arr.shape,
+                                            wts.data_ptr(), rad, torch.cuda.current_stream().cuda_stream)
+                assert rc == 0
+                assert np.array_equal(out.cpu().numpy(), refa), (shape, sigma)
+    ai = rng.integers(-32768, 32768, (2, 50, 600)).astype(np.int16)
+    w, lw = o.gaussian_kernel1d(5)
+    ref = np.stack([o.median_filter_restated(o.cast_like_scipy(o._correlate1d_symmetric(f, w, lw, 1), f.dtype), 3)
+                    for f in ai])
+    t = T(ai, dev)
+    out = torch.empty_like(t)
+    tmp = torch.empty_like(t)
+    wts, rad = ops._device_weights(5, dev)
+    assert lib.pl_gauss_h_median3(t.data_ptr(), out.data_ptr(), tmp.data_ptr(), _lib.PL_I16, *ai.shape,
+                                  wts.data_ptr(), rad, torch.cuda.current_stream().cuda_stream) == 0
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_epid_pipeline_vs_oracle_small(dev, fused):
     from pylinac_amd.pipeline import EpidPipeline
     from pylinac_amd.synthetic import epid_open_field_frames
 
     n, h, w = 5, 200, 264
     fr = epid_open_field_frames(n, h, w, seed0=42, device=dev, field_mm=35.0)
-    res = EpidPipeline(n, h, w, dev).run(fr)
+    res = EpidPipeline(n, h, w, dev, fused=fused).run(fr)
     out, prof, rec = o.epid_pipeline(fr.cpu().numpy())
     assert np.array_equal(res.frames.cpu().numpy(), out)
     assert np.array_equal(res.profile.cpu().numpy(), prof)
