@@ -132,6 +132,42 @@ int pl_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_t n, int h,
 int pl_colsum_to_mean(const unsigned long long* d_colsum, int64_t n, int w, int h, double* d_out,
                       void* stream);
 
+/* ---- a12: CircleProfile / CollapsedCircleProfile (pylinac/core/profile.py:2279-2283, 2473-2483) --
+ * out[i][s] = ( sum_k img_i[ nearest(sin[s]*r_ik + cy_i), nearest(cos[s]*r_ik + cx_i) ] ) / divisor
+ * with ndimage.map_coordinates(order=0, mode='constant', cval=0) sampling (coordinates outside
+ * [0, n-1] give 0).  d_cos/d_sin: float64[nsamp] host-computed tables; d_radii: float64[n][nr];
+ * d_cx/d_cy: float64[n]; d_out: float64[n][nsamp]. */
+int pl_circle_profile(const void* img, int dtype, int64_t n, int h, int w, const double* d_cos,
+                      const double* d_sin, int nsamp, const double* d_radii, int nr,
+                      const double* d_cx, const double* d_cy, double divisor, double* d_out,
+                      void* stream);
+
+/* ---- a15: ndimage.sobel(image, axis) (pylinac/core/image.py:1006-1007): [-1,0,1] along `axis`
+ * then [1,2,1] along the other axis, mode='reflect', each pass cast into the image dtype. */
+int pl_sobel(const void* in, void* out, int dtype, int64_t n, int h, int w, int axis, void* stream);
+
+/* ---- a13/a14: connected components, hole filling, binary centroid ------------------------------
+ * Masks are uint8 [n][h][w] (non-zero = foreground).  d_work: int32 [n][h][w] scratch owned by the
+ * caller (union-find forest); d_flags: uint8 [n][h][w] scratch.
+ * pl_label: skimage.measure.label(mask, connectivity) / scipy.ndimage.label numbering (raster order
+ *   of each component's first pixel; pylinac/metrics/utils.py:131, pylinac/ct.py:3345);
+ *   connectivity 4 or 8; d_nlabels int32[n] (may be NULL).
+ * pl_fill_holes: scipy.ndimage.binary_fill_holes (pylinac/winston_lutz.py:777); connectivity_bg is the
+ *   BACKGROUND connectivity: 4 for scipy's default structure, 8 for skimage's filled_area
+ *   (structure ones((3,3))).
+ * pl_binary_centroid: scipy.ndimage.center_of_mass of a mask (winston_lutz.py:778):
+ *   d_out float64 [n][3] = row, col, count;  d_sums: uint64 [n][3] scratch.
+ * pl_scaled_binary: the threshold_img of find_field_centroids on a ground()+normalize()d frame
+ *   without materialising the float64 frame: out = ((a - sub_i) / div_i) >= thr_i  (float64). */
+int pl_label(const uint8_t* d_mask, int64_t n, int h, int w, int connectivity, int32_t* d_labels,
+             int32_t* d_work, int32_t* d_nlabels, void* stream);
+int pl_fill_holes(const uint8_t* d_mask, uint8_t* d_out, int64_t n, int h, int w, int connectivity_bg,
+                  int32_t* d_work, uint8_t* d_flags, void* stream);
+int pl_binary_centroid(const uint8_t* d_mask, int64_t n, int h, int w, unsigned long long* d_sums,
+                       double* d_out, void* stream);
+int pl_scaled_binary(const void* in, int dtype, int64_t n, int64_t count, const double* d_sub,
+                     const double* d_div, const double* d_thr, uint8_t* d_out, void* stream);
+
 /* ---- a8-a10: pylinac.core.profile.find_peaks over scipy.signal.find_peaks -----------------------
  * (pylinac/core/profile.py:2545-2649).  One 1-D float64 profile per batch item. */
 typedef struct pl_peak_params {

@@ -475,6 +475,84 @@ def fwxm_edges(values, fwxm_height: float = 50, impl="scipy"):
 
 
 # --------------------------------------------------------------------------------------
+# a12  circle profiles  (pylinac/core/profile.py:2244-2283, 2442-2483)
+# --------------------------------------------------------------------------------------
+
+
+def circle_radians(size, start_angle=0, ccw=True):
+    """CircleProfile._radians, profile.py:2244-2252."""
+    interval = (2 * np.pi) / size
+    rads = np.arange(0 + start_angle, (2 * np.pi) + start_angle - interval, interval)
+    if ccw:
+        rads = rads[::-1]
+    return rads
+
+
+def circle_profile(image, center_xy, radius, start_angle=0, ccw=True, sampling_ratio=1.0):
+    """CircleProfile._profile, profile.py:2279-2283."""
+    rads = circle_radians(np.pi * radius * 2 * sampling_ratio, start_angle, ccw)
+    x = np.cos(rads) * radius + center_xy[0]
+    y = np.sin(rads) * radius + center_xy[1]
+    return ndimage.map_coordinates(image, [y, x], order=0)
+
+
+def collapsed_circle_profile(image, center_xy, radius, start_angle=0, ccw=True, sampling_ratio=1.0,
+                             width_ratio=0.1, num_profiles=20):
+    """CollapsedCircleProfile._profile, profile.py:2442-2483."""
+    radii = np.linspace(start=radius * (1 - width_ratio), stop=radius * (1 + width_ratio), num=num_profiles)
+    rads = circle_radians(np.pi * max(radii) * 2 * sampling_ratio, start_angle, ccw)
+    cos, sin = np.cos(rads), np.sin(rads)
+    profile = np.zeros(len(rads))
+    for r in radii:
+        profile += ndimage.map_coordinates(image, [sin * r + center_xy[1], cos * r + center_xy[0]], order=0)
+    profile /= num_profiles
+    return profile
+
+
+def map_coordinates_nearest_restated(image, y, x):
+    """scipy map_coordinates(order=0, mode='constant', cval=0): index floor(c+0.5); any coordinate
+    outside [0, n-1] gives 0 (probed on scipy 1.15.3)."""
+    h, w = image.shape
+    ok = (x >= 0) & (x <= w - 1) & (y >= 0) & (y <= h - 1)
+    xi = np.floor(np.where(ok, x, 0) + 0.5).astype(np.intp)
+    yi = np.floor(np.where(ok, y, 0) + 0.5).astype(np.intp)
+    return np.where(ok, image[yi, xi], 0).astype(image.dtype)
+
+
+# --------------------------------------------------------------------------------------
+# a15  Sobel  (pylinac/core/image.py:1006-1007)
+# --------------------------------------------------------------------------------------
+
+
+def sobel(image, axis):
+    return ndimage.sobel(image, axis)
+
+
+# --------------------------------------------------------------------------------------
+# a14  Winston-Lutz field centroid  (pylinac/winston_lutz.py:711-712, 764-780)
+# --------------------------------------------------------------------------------------
+
+
+def wl_field_centroid(frame: np.ndarray):
+    """ground -> normalize -> percentile threshold -> binary_fill_holes -> center_of_mass.
+    Returns (x, y, filled pixel count)."""
+    arr = ground(frame)                     # winston_lutz.py:711 (image.py:839-853)
+    arr = normalize(arr)                    # winston_lutz.py:712
+    mn, mx = np.percentile(arr, [5, 99.9])  # winston_lutz.py:775
+    threshold_img = as_binary(arr, (mx - mn) / 2 + mn)
+    filled = ndimage.binary_fill_holes(threshold_img)
+    coords = ndimage.center_of_mass(filled)
+    return coords[-1], coords[0], float(filled.sum())
+
+
+def label_like_skimage(mask: np.ndarray, connectivity: int = 4):
+    """skimage.measure.label numbering == scipy.ndimage.label numbering (raster order of the first
+    pixel of each component); connectivity 4 -> cross structure, 8 -> full 3x3."""
+    structure = ndimage.generate_binary_structure(2, 1 if connectivity == 4 else 2)
+    return ndimage.label(mask, structure=structure)
+
+
+# --------------------------------------------------------------------------------------
 # BASELINE config #2 + profile/peak: the pipeline bench.py measures
 # --------------------------------------------------------------------------------------
 

@@ -1,0 +1,289 @@
+// Connected components, hole filling and binary centroids.
+//
+// Replaces:
+//   scipy.ndimage.binary_fill_holes(mask)   pylinac/winston_lutz.py:777  (default structure:
+//        4-connected background; a hole = background component not connected to the border)
+//   scipy.ndimage.center_of_mass(mask)      pylinac/winston_lutz.py:778  (mean of the True
+//        coordinates: exact integer sums / count in float64)
+//   skimage.measure.label(mask, connectivity) pylinac/metrics/utils.py:131, pylinac/ct.py:3345
+//        (labels numbered in raster order of each component's first pixel)
+//
+// Labelling is a lock-free union-find on the frame's own index space (Playne/Hawick/Komura):
+// every foreground pixel starts as its own root, is united with its already-visited neighbours
+// (left, up; plus the two upper diagonals for 8-connectivity) with atomicMin links that always
+// point to the SMALLER index, then paths are compressed.  The root of a component is therefore
+// its first pixel in raster order -- exactly the order skimage/scipy number labels in -- and
+// sequential numbering is a prefix count of roots.
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ int find_root(const int* __restrict__ L, int i) {
+  int p = L[i];
+  while (p != i) {
+    i = p;
+    p = L[i];
+  }
+  return i;
+}
+
+__device__ __forceinline__ void unite(int* L, int a, int b) {
+  bool done;
+  do {
+    a = find_root(L, a);
+    b = find_root(L, b);
+    if (a < b) {
+      const int old = atomicMin(&L[b], a);
+      done = (old == b);
+      b = old;
+    } else if (b < a) {
+      const int old = atomicMin(&L[a], b);
+      done = (old == a);
+      a = old;
+    } else {
+      done = true;
+    }
+  } while (!done);
+}
+
+// fg(i) = (mask[i] != 0) ^ invert
+__global__ void ccl_init_kernel(const uint8_t* __restrict__ mask, int invert, int64_t total, int64_t per_frame,
+                                int* __restrict__ L) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= total) return;
+  const bool fg = ((mask[g] != 0) ? 1 : 0) != invert;
+  L[g] = fg ? (int)(g % per_frame) : -1;
+}
+
+__global__ void ccl_merge_kernel(int* __restrict__ Lall, int64_t total, int h, int w, int conn8) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= total) return;
+  const int64_t per_frame = (int64_t)h * w;
+  int* L = Lall + (g / per_frame) * per_frame;
+  const int i = (int)(g % per_frame);
+  if (L[i] < 0) return;
+  const int r = i / w, c = i % w;
+  if (c > 0 && L[i - 1] >= 0) unite(L, i, i - 1);
+  if (r > 0) {
+    if (L[i - w] >= 0) unite(L, i, i - w);
+    if (conn8) {
+      if (c > 0 && L[i - w - 1] >= 0) unite(L, i, i - w - 1);
+      if (c + 1 < w && L[i - w + 1] >= 0) unite(L, i, i - w + 1);
+    }
+  }
+}
+
+__global__ void ccl_compress_kernel(int* __restrict__ Lall, int64_t total, int64_t per_frame) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= total) return;
+  int* L = Lall + (g / per_frame) * per_frame;
+  const int i = (int)(g % per_frame);
+  if (L[i] < 0) return;
+  L[i] = find_root(L, i);
+}
+
+// labels := root index + 1 (0 = background); used as the public "raw" labelling
+__global__ void ccl_export_kernel(const int* __restrict__ L, int64_t total, int32_t* __restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= total) return;
+  out[g] = L[g] < 0 ? 0 : L[g] + 1;
+}
+
+// sequential numbering: one 1024-lane workgroup per frame walks the frame in raster order with a
+// running count of roots; rank[root] is written in place of the root's own entry (as -(rank) - 2 so
+// that it cannot be mistaken for an index), then every pixel reads its root's rank.
+__global__ void __launch_bounds__(1024)
+ccl_rank_roots_kernel(int* __restrict__ Lall, int64_t per_frame, int32_t* __restrict__ nlabels) {
+  __shared__ int wave_tot[16];
+  __shared__ int base;
+  int* L = Lall + (int64_t)blockIdx.x * per_frame;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int64_t off = 0; off < per_frame; off += 1024) {
+    const int64_t i = off + threadIdx.x;
+    const int is_root = (i < per_frame && L[i] == (int)i) ? 1 : 0;
+    const unsigned long long b = __ballot(is_root);
+    const int pre = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(b);
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+      if (k < wv) wbase += wave_tot[k];
+      tot += wave_tot[k];
+    }
+    const int cur = base;
+    if (is_root) L[i] = -(cur + wbase + pre + 1) - 1;  // label k (1-based) stored as -(k) - 1 <= -2
+    __syncthreads();
+    if (threadIdx.x == 0) base = cur + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && nlabels) nlabels[blockIdx.x] = base;
+}
+
+__global__ void ccl_apply_rank_kernel(const int* __restrict__ Lall, int64_t total, int64_t per_frame,
+                                      int32_t* __restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= total) return;
+  const int* L = Lall + (g / per_frame) * per_frame;
+  int v = L[g % per_frame];
+  if (v == -1) { out[g] = 0; return; }
+  if (v >= 0) v = L[v];  // non-root pixel: its root holds the encoded rank
+  out[g] = -(v + 1);
+}
+
+// ---- fill holes: background components that do not touch the frame border become foreground ----
+__global__ void border_flag_kernel(const int* __restrict__ Lall, int64_t n, int h, int w,
+                                   uint8_t* __restrict__ flags /* [n][h*w], zeroed */) {
+  const int64_t per_frame = (int64_t)h * w;
+  const int64_t border = 2LL * w + 2LL * h;
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= n * border) return;
+  const int64_t frame = g / border;
+  int64_t k = g % border;
+  int r, c;
+  if (k < w) { r = 0; c = (int)k; }
+  else if (k < 2LL * w) { r = h - 1; c = (int)(k - w); }
+  else if (k < 2LL * w + h) { r = (int)(k - 2LL * w); c = 0; }
+  else { r = (int)(k - 2LL * w - h); c = w - 1; }
+  const int* L = Lall + frame * per_frame;
+  const int root = L[(int64_t)r * w + c];
+  if (root >= 0) flags[frame * per_frame + root] = 1;
+}
+
+__global__ void fill_apply_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ Lall,
+                                  const uint8_t* __restrict__ flags, int64_t total, int64_t per_frame,
+                                  uint8_t* __restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= total) return;
+  const int64_t fbase = (g / per_frame) * per_frame;
+  const int root = Lall[g];  // labelling of the BACKGROUND: -1 where the mask is set
+  uint8_t v = mask[g] != 0 ? 1 : 0;
+  if (root >= 0 && !flags[fbase + root]) v = 1;
+  out[g] = v;
+}
+
+// ---- binary centroid: exact integer sums of row / column indices and the pixel count -----------
+__global__ void __launch_bounds__(kThreads)
+centroid_kernel(const uint8_t* __restrict__ mask, int h, int w, int bpf,
+                unsigned long long* __restrict__ sums /* [n][3], zeroed */) {
+  const int64_t frame = blockIdx.x / bpf;
+  const int chunk = blockIdx.x % bpf;
+  const int64_t per_frame = (int64_t)h * w;
+  const uint8_t* m = mask + frame * per_frame;
+  unsigned long long sr = 0, sc = 0, cnt = 0;
+  const int64_t lo = (int64_t)chunk * 65536, hi = (lo + 65536 < per_frame) ? lo + 65536 : per_frame;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+    if (m[i]) { sr += (unsigned long long)(i / w); sc += (unsigned long long)(i % w); ++cnt; }
+  }
+  auto add = [](unsigned long long a, unsigned long long b) { return a + b; };
+  sr = pl_wave_reduce(sr, add); sc = pl_wave_reduce(sc, add); cnt = pl_wave_reduce(cnt, add);
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    atomicAdd(&sums[frame * 3 + 0], sr);
+    atomicAdd(&sums[frame * 3 + 1], sc);
+    atomicAdd(&sums[frame * 3 + 2], cnt);
+  }
+}
+
+__global__ void centroid_finish_kernel(const unsigned long long* __restrict__ sums, int64_t n,
+                                       double* __restrict__ out /* [n][3]: row, col, count */) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const double cnt = (double)sums[i * 3 + 2];
+  out[i * 3 + 0] = (double)sums[i * 3 + 0] / cnt;  // 0/0 -> NaN, like scipy on an empty mask
+  out[i * 3 + 1] = (double)sums[i * 3 + 1] / cnt;
+  out[i * 3 + 2] = cnt;
+}
+
+// a >= thr after ground+normalize in the reference's float64 arithmetic: ((a - sub) / div) >= thr
+template <typename T>
+__global__ void scaled_binary_kernel(const T* __restrict__ in, int64_t total, int64_t per_frame,
+                                     const double* __restrict__ sub, const double* __restrict__ div,
+                                     const double* __restrict__ thr, uint8_t* __restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= total) return;
+  const int64_t f = g / per_frame;
+  const double grounded = (double)in[g] - sub[f];  // exact for integer dtypes (array - array.min())
+  out[g] = (grounded / div[f] >= thr[f]) ? 1 : 0;
+}
+
+int run_ccl(const uint8_t* mask, int invert, int64_t n, int h, int w, int conn, int* L, hipStream_t st) {
+  const int64_t per_frame = (int64_t)h * w, total = n * per_frame;
+  const unsigned blocks = (unsigned)pl_cdiv(total, kThreads);
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(blocks), dim3(kThreads), 0, st, mask, invert, total, per_frame, L);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, h, w, conn == 8 ? 1 : 0);
+  hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame);
+  return pl_check_launch("ccl");
+}
+
+}  // namespace
+
+#define PL_CCL_CHECK_SHAPE()                                                          \
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");                                  \
+  PL_REQUIRE((int64_t)h * w <= 0x7fffffffLL, "frame too large for 32-bit labels");    \
+  PL_REQUIRE(pl_cdiv(n * (int64_t)h * w, kThreads) <= 0x7fffffffLL, "batch too large"); \
+  if (n == 0) return PL_OK;
+
+extern "C" int pl_label(const uint8_t* d_mask, int64_t n, int h, int w, int connectivity,
+                        int32_t* d_labels, int32_t* d_work, int32_t* d_nlabels, void* stream) {
+  PL_REQUIRE(d_mask && d_labels && d_work, "null pointer");
+  PL_REQUIRE(connectivity == 4 || connectivity == 8, "connectivity must be 4 or 8");
+  PL_CCL_CHECK_SHAPE();
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per_frame = (int64_t)h * w, total = n * per_frame;
+  if (int rc = run_ccl(d_mask, 0, n, h, w, connectivity, d_work, st)) return rc;
+  PL_REQUIRE(n <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(ccl_rank_roots_kernel, dim3((unsigned)n), dim3(1024), 0, st, d_work, per_frame, d_nlabels);
+  hipLaunchKernelGGL(ccl_apply_rank_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0, st,
+                     d_work, total, per_frame, d_labels);
+  return pl_check_launch("pl_label");
+}
+
+extern "C" int pl_fill_holes(const uint8_t* d_mask, uint8_t* d_out, int64_t n, int h, int w,
+                             int connectivity_bg, int32_t* d_work, uint8_t* d_flags, void* stream) {
+  PL_REQUIRE(d_mask && d_out && d_work && d_flags, "null pointer");
+  PL_REQUIRE(connectivity_bg == 4 || connectivity_bg == 8, "connectivity must be 4 or 8");
+  PL_CCL_CHECK_SHAPE();
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per_frame = (int64_t)h * w, total = n * per_frame;
+  if (int rc = run_ccl(d_mask, 1, n, h, w, connectivity_bg, d_work, st)) return rc;
+  hipError_t e = hipMemsetAsync(d_flags, 0, (size_t)total, st);
+  if (e != hipSuccess) { pl_set_error("pl_fill_holes: memset: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+  const int64_t border = n * (2LL * w + 2LL * h);
+  hipLaunchKernelGGL(border_flag_kernel, dim3((unsigned)pl_cdiv(border, kThreads)), dim3(kThreads), 0, st, d_work,
+                     n, h, w, d_flags);
+  hipLaunchKernelGGL(fill_apply_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0, st, d_mask,
+                     d_work, d_flags, total, per_frame, d_out);
+  return pl_check_launch("pl_fill_holes");
+}
+
+extern "C" int pl_binary_centroid(const uint8_t* d_mask, int64_t n, int h, int w,
+                                  unsigned long long* d_sums, double* d_out, void* stream) {
+  PL_REQUIRE(d_mask && d_sums && d_out, "null pointer");
+  PL_CCL_CHECK_SHAPE();
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_sums, 0, (size_t)n * 3 * sizeof(unsigned long long), st);
+  if (e != hipSuccess) { pl_set_error("pl_binary_centroid: memset: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+  const int bpf = (int)pl_cdiv((int64_t)h * w, 65536);
+  PL_REQUIRE(n * bpf <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)(n * bpf)), dim3(kThreads), 0, st, d_mask, h, w, bpf, d_sums);
+  hipLaunchKernelGGL(centroid_finish_kernel, dim3((unsigned)pl_cdiv(n, kThreads)), dim3(kThreads), 0, st, d_sums, n,
+                     d_out);
+  return pl_check_launch("pl_binary_centroid");
+}
+
+extern "C" int pl_scaled_binary(const void* in, int dtype, int64_t n, int64_t count, const double* d_sub,
+                                const double* d_div, const double* d_thr, uint8_t* d_out, void* stream) {
+  PL_REQUIRE(in && d_sub && d_div && d_thr && d_out, "null pointer");
+  PL_REQUIRE(n >= 0 && count > 0, "bad shape");
+  if (n == 0) return PL_OK;
+  const int64_t total = n * count;
+  PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "batch too large");
+  PL_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL(scaled_binary_kernel<T>, dim3((unsigned)pl_cdiv(total, kThreads)),
+                                       dim3(kThreads), 0, (hipStream_t)stream, (const T*)in, total, count, d_sub,
+                                       d_div, d_thr, d_out));
+  return pl_check_launch("pl_scaled_binary");
+}

@@ -255,32 +255,48 @@ def threshold_otsu(frames: torch.Tensor) -> torch.Tensor:
     return otsu_from_hist(histogram16(x), x.dtype)[0]
 
 
+def _percentile_plan(cnt: int, q):
+    """numpy's default 'linear' method: virtual index q/100*(n-1) -> (lower rank, upper rank, gamma)."""
+    qs = np.atleast_1d(np.asarray(q, dtype=np.float64))
+    if np.any(qs < 0) or np.any(qs > 100):
+        raise ValueError("Percentiles must be in the range [0, 100]")
+    virt = (qs / 100.0) * (cnt - 1)
+    lo = np.floor(virt).astype(np.int64)
+    hi = np.minimum(lo + 1, cnt - 1)
+    return qs, lo, hi, virt - lo
+
+
+def order_stats(frames: torch.Tensor, ranks, hist=None) -> torch.Tensor:
+    """Exact order statistics (0-based ranks) of every 16-bit frame -> int32 [N, len(ranks)] on the
+    device (no host synchronisation)."""
+    x = _frames(frames)
+    n = x.shape[0]
+    r = torch.as_tensor(np.asarray(ranks, dtype=np.int64)).to(x.device)
+    out = torch.empty((n, r.numel()), dtype=torch.int32, device=x.device)
+    hist = histogram16(x) if hist is None else hist
+    check(_lib.load().pl_order_stats_from_hist(hist.data_ptr(), _dt(x), n, r.data_ptr(), r.numel(),
+                                               out.data_ptr(), _stream()), "pl_order_stats_from_hist")
+    return out
+
+
+def lerp_like_numpy(a: torch.Tensor, b: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """numpy ``_lerp`` on float64 tensors: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5."""
+    d = b - a
+    return torch.where(t >= 0.5, b - d * (1 - t), a + d * t)
+
+
 def percentile(frames: torch.Tensor, q) -> torch.Tensor:
     """``np.percentile(frame, q)`` (default linear method) per 16-bit frame -> float64 [N, len(q)].
     The two neighbouring order statistics come from the exact device histogram; the final
     interpolation is numpy's ``_lerp`` formula evaluated in float64 on the host."""
     x = _frames(frames)
-    n = x.shape[0]
     cnt = x[0].numel()
-    qs = np.atleast_1d(np.asarray(q, dtype=np.float64))
-    if np.any(qs < 0) or np.any(qs > 100):
-        raise ValueError("Percentiles must be in the range [0, 100]")
-    virt = (qs / 100.0) * (cnt - 1)  # numpy: quantile * (n - 1)
-    lo = np.floor(virt).astype(np.int64)
-    hi = np.minimum(lo + 1, cnt - 1)
-    frac = virt - lo
-    ranks = torch.from_numpy(np.concatenate([lo, hi])).to(x.device)
-    out = torch.empty((n, ranks.numel()), dtype=torch.int32, device=x.device)
-    hist = histogram16(x)
-    check(_lib.load().pl_order_stats_from_hist(hist.data_ptr(), _dt(x), n, ranks.data_ptr(), ranks.numel(),
-                                               out.data_ptr(), _stream()), "pl_order_stats_from_hist")
-    st = out.cpu().numpy().astype(np.float64)
+    qs, lo, hi, frac = _percentile_plan(cnt, q)
+    st = order_stats(x, np.concatenate([lo, hi])).cpu().numpy().astype(np.float64)
     a, b = st[:, : len(qs)], st[:, len(qs):]
     d = b - a
     res = a + d * frac
-    hi_t = frac >= 0.5
-    res = np.where(hi_t[None, :], b - d * (1 - frac), res)
-    res = np.where(d == 0, a, res)
+    res = np.where((frac >= 0.5)[None, :], b - d * (1 - frac), res)
     return torch.from_numpy(res)
 
 
@@ -411,4 +427,106 @@ def fwxm_record(res: PeakBatch, out=None) -> torch.Tensor:
     out = torch.empty((n, 8), dtype=torch.float64, device=res.count.device) if out is None else out
     check(_lib.load().pl_fwxm_record(res.count.data_ptr(), res.idx.data_ptr(), res.props.data_ptr(), cap, n,
                                      out.data_ptr(), _stream()), "pl_fwxm_record")
+    return out
+
+
+# ------------------------------------------------------------------------- circle profiles, Sobel
+def circle_radians(size: float, start_angle: float = 0, ccw: bool = True) -> np.ndarray:
+    """``CircleProfile._radians`` (pylinac/core/profile.py:2244-2252)."""
+    interval = (2 * np.pi) / size
+    rads = np.arange(0 + start_angle, (2 * np.pi) + start_angle - interval, interval)
+    if ccw:
+        rads = rads[::-1]
+    return rads
+
+
+def circle_profile(frames: torch.Tensor, cx, cy, radii, size: float, start_angle: float = 0,
+                   ccw: bool = True, divisor: float = 1.0) -> torch.Tensor:
+    """``ndimage.map_coordinates(order=0)`` along circles, summed over ``radii`` and divided by
+    ``divisor`` (pylinac/core/profile.py:2279-2283, 2473-2483).  ``cx, cy``: scalar or [N];
+    ``radii``: [nr] or [N, nr]; ``size`` = pi * r_max * 2 * sampling_ratio.  -> float64 [N, nsamp]."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    rads = circle_radians(size, start_angle, ccw)
+    dev = x.device
+    d_cos = torch.from_numpy(np.cos(rads)).to(dev)
+    d_sin = torch.from_numpy(np.sin(rads)).to(dev)
+    r = torch.as_tensor(np.asarray(radii, dtype=np.float64))
+    if r.dim() == 1:
+        r = r[None, :].expand(n, -1)
+    r = r.contiguous().to(dev)
+    cxs = torch.as_tensor(np.broadcast_to(np.asarray(cx, dtype=np.float64), (n,)).copy()).to(dev)
+    cys = torch.as_tensor(np.broadcast_to(np.asarray(cy, dtype=np.float64), (n,)).copy()).to(dev)
+    out = torch.empty((n, len(rads)), dtype=torch.float64, device=dev)
+    check(_lib.load().pl_circle_profile(x.data_ptr(), _dt(x), n, h, w, d_cos.data_ptr(), d_sin.data_ptr(),
+                                        len(rads), r.data_ptr(), r.shape[1], cxs.data_ptr(), cys.data_ptr(),
+                                        float(divisor), out.data_ptr(), _stream()), "pl_circle_profile")
+    return out
+
+
+def sobel(frames: torch.Tensor, axis: int) -> torch.Tensor:
+    """``scipy.ndimage.sobel(frame, axis)`` per frame (pylinac/core/image.py:1006-1007)."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    out = torch.empty_like(x)
+    check(_lib.load().pl_sobel(x.data_ptr(), out.data_ptr(), _dt(x), n, h, w, int(axis), _stream()), "pl_sobel")
+    return out
+
+
+# ------------------------------------------------------------ components / fill holes / centroid
+def _mask(m: torch.Tensor) -> torch.Tensor:
+    if m.dtype == torch.bool:
+        m = m.to(torch.uint8)
+    x = _frames(m)
+    if x.dtype != torch.uint8:
+        raise TypeError("mask must be uint8 or bool")
+    return x
+
+
+def label(mask: torch.Tensor, connectivity: int = 4):
+    """``skimage.measure.label`` numbering per frame -> (int32 labels [N,H,W], int32 count [N]).
+    ``connectivity``: 4 (skimage connectivity=1) or 8 (skimage default in 2-D)."""
+    x = _mask(mask)
+    n, h, w = x.shape
+    labels = torch.empty((n, h, w), dtype=torch.int32, device=x.device)
+    work = torch.empty((n, h, w), dtype=torch.int32, device=x.device)
+    count = torch.empty(n, dtype=torch.int32, device=x.device)
+    check(_lib.load().pl_label(x.data_ptr(), n, h, w, int(connectivity), labels.data_ptr(), work.data_ptr(),
+                               count.data_ptr(), _stream()), "pl_label")
+    return labels, count
+
+
+def fill_holes(mask: torch.Tensor, connectivity_bg: int = 4) -> torch.Tensor:
+    """``scipy.ndimage.binary_fill_holes`` per frame (uint8 0/1)."""
+    x = _mask(mask)
+    n, h, w = x.shape
+    out = torch.empty_like(x)
+    work = torch.empty((n, h, w), dtype=torch.int32, device=x.device)
+    flags = torch.empty((n, h, w), dtype=torch.uint8, device=x.device)
+    check(_lib.load().pl_fill_holes(x.data_ptr(), out.data_ptr(), n, h, w, int(connectivity_bg), work.data_ptr(),
+                                    flags.data_ptr(), _stream()), "pl_fill_holes")
+    return out
+
+
+def binary_centroid(mask: torch.Tensor) -> torch.Tensor:
+    """``scipy.ndimage.center_of_mass`` of each mask -> float64 [N,3] = (row, col, count)."""
+    x = _mask(mask)
+    n, h, w = x.shape
+    sums = torch.empty((n, 3), dtype=torch.int64, device=x.device)
+    out = torch.empty((n, 3), dtype=torch.float64, device=x.device)
+    check(_lib.load().pl_binary_centroid(x.data_ptr(), n, h, w, sums.data_ptr(), out.data_ptr(), _stream()),
+          "pl_binary_centroid")
+    return out
+
+
+def scaled_binary(frames: torch.Tensor, sub, div, thr) -> torch.Tensor:
+    """``((a - sub) / div) >= thr`` in float64 per frame -> uint8 mask."""
+    x = _frames(frames)
+    n = x.shape[0]
+    dev = x.device
+    a = [_per_frame(v, n, dev)[0].expand(n).contiguous() if _per_frame(v, n, dev)[1] == 0 else _per_frame(v, n, dev)[0]
+         for v in (sub, div, thr)]
+    out = torch.empty(x.shape, dtype=torch.uint8, device=dev)
+    check(_lib.load().pl_scaled_binary(x.data_ptr(), _dt(x), n, x[0].numel(), a[0].data_ptr(), a[1].data_ptr(),
+                                       a[2].data_ptr(), out.data_ptr(), _stream()), "pl_scaled_binary")
     return out

@@ -226,6 +226,83 @@ class FWXMProfile:
         return max(right, left) - min(right, left)
 
 
+class CircleProfile(MultiProfile):
+    """pylinac/core/profile.py:2179-2402: a profile sampled along a circle
+    (``ndimage.map_coordinates(image, [y, x], order=0)``)."""
+
+    def __init__(self, center, radius: float, image_array, start_angle=0, ccw: bool = True,
+                 sampling_ratio: float = 1.0):
+        self.center = center if hasattr(center, "x") else Point(x=center[0], y=center[1])
+        self.radius = radius
+        image_array = np.asarray(image_array)
+        self._ensure_array_size(image_array, self.radius + self.center.x, self.radius + self.center.y)
+        self.image_array = image_array
+        self.start_angle = start_angle
+        self.ccw = ccw
+        self.sampling_ratio = sampling_ratio
+        super().__init__(self._profile)
+
+    @staticmethod
+    def _ensure_array_size(array, min_width: float, min_height: float) -> None:
+        """profile.py:2394-2402 (only the +x / +y extents are checked, like the reference)."""
+        if array.shape[1] < min_width or array.shape[0] < min_height:
+            raise ValueError("Array size not large enough to compute profile")
+
+    @property
+    def _radii(self):
+        return np.array([self.radius], dtype=float)
+
+    @property
+    def _divisor(self) -> float:
+        return 1.0
+
+    @property
+    def size(self) -> float:
+        return np.pi * max(self._radii) * 2 * self.sampling_ratio
+
+    @property
+    def _radians(self):
+        return ops.circle_radians(self.size, self.start_angle, self.ccw)
+
+    @property
+    def x_locations(self):
+        return np.cos(self._radians) * self.radius + self.center.x
+
+    @property
+    def y_locations(self):
+        return np.sin(self._radians) * self.radius + self.center.y
+
+    @property
+    def _profile(self):
+        s = au._Staged(self.image_array)
+        out = ops.circle_profile(s.t, self.center.x, self.center.y, self._radii, self.size,
+                                 self.start_angle, self.ccw, self._divisor)[0].cpu().numpy()
+        if self._divisor == 1.0:  # map_coordinates returns the image dtype
+            return out.astype(self.image_array.dtype)
+        return out
+
+
+class CollapsedCircleProfile(CircleProfile):
+    """pylinac/core/profile.py:2405-2483: mean of ``num_profiles`` concentric circle profiles."""
+
+    def __init__(self, center, radius: float, image_array, start_angle=0, ccw: bool = True,
+                 sampling_ratio: float = 1.0, width_ratio: float = 0.1, num_profiles: int = 20):
+        if not 0 <= width_ratio <= 1:
+            raise ValueError("width_ratio must be within (0, 1)")
+        self.width_ratio = width_ratio
+        self.num_profiles = num_profiles
+        super().__init__(center, radius, image_array, start_angle, ccw, sampling_ratio)
+
+    @property
+    def _radii(self):
+        return np.linspace(start=self.radius * (1 - self.width_ratio),
+                           stop=self.radius * (1 + self.width_ratio), num=self.num_profiles)
+
+    @property
+    def _divisor(self) -> float:
+        return float(self.num_profiles)
+
+
 # ------------------------------------------------------------------------ device-resident batch
 FWXM_FIELDS = ("n_peaks", "peak_idx", "peak_height", "prominence", "left_edge", "right_edge",
                "center", "width")

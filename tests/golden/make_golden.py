@@ -48,6 +48,42 @@ def synth_frames(n, h, w, seed, dtype=np.uint16):
     return a.astype(dtype)
 
 
+def ndimage_gaussian(a, s):
+    from scipy import ndimage as ndi
+
+    return ndi.gaussian_filter(a, s)
+
+
+def ring_mask(h, w):
+    y, x = np.mgrid[0:h, 0:w]
+    r = np.hypot(y - h / 2, x - w / 2)
+    m = ((r > 10) & (r < 18)) | ((r > 25) & (r < 33)) | (r < 4)
+    m[5:12, 5:12] = 1
+    m[7:10, 7:10] = 0      # a hole away from the rings
+    m[0:6, 60:70] = 1      # touches the border
+    m[1:5, 62:68] = 0      # enclosed hole inside a border-touching blob
+    m[0, 64] = 0           # ...opened to the border through one pixel
+    return m.astype(np.uint8)
+
+
+def wl_frames(n, h, w, seed):
+    """WL-like frames: blurred 20 mm-ish field with a dark BB near the centre + noise."""
+    from scipy import ndimage as ndi
+
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        img = np.full((h, w), 1500.0)
+        cy, cx = h / 2 + rng.uniform(-6, 6), w / 2 + rng.uniform(-6, 6)
+        img[int(cy - 30):int(cy + 30), int(cx - 30):int(cx + 30)] = 42000.0
+        y, x = np.mgrid[0:h, 0:w]
+        bb = np.hypot(y - (cy + rng.uniform(-3, 3)), x - (cx + rng.uniform(-3, 3))) < 7.5
+        img[bb] *= 0.2
+        img = ndi.gaussian_filter(img, 2.0) + rng.normal(0, 150, (h, w))
+        out.append(np.clip(np.round(img), 0, 65535))
+    return np.stack(out).astype(np.uint16)
+
+
 def skimage_otsu(arrays: dict) -> dict:
     """threshold_otsu via scikit-image 0.18.3 in the py3.9 interpreter."""
     with tempfile.TemporaryDirectory() as td:
@@ -237,6 +273,68 @@ def main():
     ep["profile"] = np.stack(profs)
     ep["fwxm"] = np.array(recs)
     np.savez_compressed(os.path.join(HERE, "epid_pipeline.npz"), **ep)
+
+    # ------------------------------------------- 5. labels (skimage), circle profiles, Sobel, WL field
+    rng = np.random.default_rng(8)
+    masks = {
+        "random40": (rng.random((40, 56)) > 0.55).astype(np.uint8),
+        "random_dense": (rng.random((33, 47)) > 0.3).astype(np.uint8),
+        "blobs": (ndimage_gaussian(rng.random((96, 128)), 3) > 0.5).astype(np.uint8),
+        "rings": ring_mask(90, 110),
+        "empty": np.zeros((8, 9), np.uint8),
+        "full": np.ones((7, 5), np.uint8),
+    }
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "m.npz"), os.path.join(td, "l.npz")
+        np.savez(inp, **masks)
+        subprocess.run([PY39, os.path.join(HERE, "skimage_label_py39.py"), inp, outp], check=True,
+                       stderr=subprocess.DEVNULL)
+        lab = dict(np.load(outp))
+    from scipy import ndimage as ndi
+
+    misc = {f"mask.{k}": v for k, v in masks.items()}
+    for k, v in lab.items():
+        misc[f"label.{k}"] = v
+    for k, m in masks.items():
+        misc[f"fill.{k}"] = ndi.binary_fill_holes(m).astype(np.uint8)   # winston_lutz.py:777
+    # circle profiles through the reference classes (pylinac/core/profile.py:2179-2483)
+    geo = ref_loader.ref("core.geometry")
+    img16 = synth_frames(1, 160, 200, seed=5)[0]
+    imgf = img16.astype(float) / 65535.0
+    misc["circle.img16"] = img16
+    cases = [(100.3, 80.7, 50.0, 0.0, True, 1.0), (90.0, 70.0, 60.2, 0.7, False, 2.0), (120.0, 85.0, 70.0, 0.0, True, 1.5)]
+    misc["circle.cases"] = np.array(cases)
+    for i, (cx, cy, r, sa, ccw, sr) in enumerate(cases):
+        cp = prof.CircleProfile(geo.Point(cx, cy), r, img16, start_angle=sa, ccw=bool(ccw), sampling_ratio=sr)
+        misc[f"circle.{i}.u16"] = np.asarray(cp.values)
+        cp = prof.CircleProfile(geo.Point(cx, cy), r, imgf, start_angle=sa, ccw=bool(ccw), sampling_ratio=sr)
+        misc[f"circle.{i}.f64"] = np.asarray(cp.values)
+        ccp = prof.CollapsedCircleProfile(geo.Point(cx, cy), r, imgf, start_angle=sa, ccw=bool(ccw), sampling_ratio=sr,
+                                          width_ratio=0.1, num_profiles=20)
+        misc[f"collapsed.{i}.f64"] = np.asarray(ccp.values)
+        ccp = prof.CollapsedCircleProfile(geo.Point(cx, cy), r, img16, sampling_ratio=sr, width_ratio=0.05, num_profiles=5)
+        misc[f"collapsed.{i}.u16"] = np.asarray(ccp.values)
+    # Sobel as BaseImage.gamma calls it (pylinac/core/image.py:1006-1007): float32
+    f32img = imgf.astype(np.float32)
+    misc["sobel.in"] = f32img
+    misc["sobel.axis1"] = ndi.sobel(f32img, 1)
+    misc["sobel.axis0"] = ndi.sobel(f32img, 0)
+    # WL field centroid on synthetic WL frames (field + BB): reference expressions of
+    # winston_lutz.py:711-712, 775-779 via the reference's ArrayImage
+    wl = wl_frames(3, 200, 240, seed=31)
+    misc["wl.in"] = wl
+    cen = []
+    for f in wl:
+        im = image.ArrayImage(f.copy())
+        im.ground()
+        im.normalize()
+        mn, mx = np.percentile(im.array, [5, 99.9])
+        thr_img = im.as_binary((mx - mn) / 2 + mn)
+        filled = ndi.binary_fill_holes(thr_img.array)
+        c = ndi.center_of_mass(filled)
+        cen.append([c[-1], c[0], filled.sum()])
+    misc["wl.centroid"] = np.array(cen)
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc)
 
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):

@@ -546,3 +546,114 @@ def test_gaussian_linearity_property_full_size(dev):
     m1 = ops.median_filter(u(x), 3).to(torch.int32)
     m2 = ops.median_filter(u(65535 - x), 3).to(torch.int32)
     assert torch.equal(m2, 65535 - m1)
+
+
+# ------------------------------------------------- components, circle profiles, Sobel, WL field CAX
+def test_label_fill_centroid_vs_golden(golden, dev):
+    from pylinac_amd import ops
+
+    g = golden("misc")
+    for k in ["random40", "random_dense", "blobs", "rings", "empty", "full"]:
+        m = g[f"mask.{k}"]
+        t = T(m[None], dev)
+        for conn, sk in ((4, 1), (8, 2)):
+            lab, cnt = ops.label(t, conn)
+            ref = g[f"label.{k}.conn{sk}"]
+            assert np.array_equal(lab[0].cpu().numpy(), ref), (k, conn)
+            assert int(cnt[0]) == int(ref.max())
+        assert np.array_equal(ops.fill_holes(t, 4)[0].cpu().numpy(), g[f"fill.{k}"]), k
+        if m.any():
+            rr, cc = np.nonzero(m)
+            cen = ops.binary_centroid(t)[0].cpu().numpy()
+            assert np.array_equal(cen, [rr.sum() / len(rr), cc.sum() / len(cc), len(rr)])
+
+
+def test_label_and_fill_vs_scipy_random_batch(dev):
+    from scipy import ndimage
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(77)
+    for shape, p in [((5, 64, 80), 0.5), ((2, 257, 300), 0.62), ((3, 31, 1), 0.5), ((1, 1, 40), 0.4)]:
+        m = (rng.random(shape) > p).astype(np.uint8)
+        t = T(m, dev)
+        for conn in (4, 8):
+            lab, cnt = ops.label(t, conn)
+            for i in range(shape[0]):
+                ref, num = o.label_like_skimage(m[i], conn)
+                assert np.array_equal(lab[i].cpu().numpy(), ref), (shape, conn, i)
+                assert int(cnt[i]) == num
+        f4 = ops.fill_holes(t, 4).cpu().numpy()
+        f8 = ops.fill_holes(t, 8).cpu().numpy()
+        for i in range(shape[0]):
+            assert np.array_equal(f4[i], ndimage.binary_fill_holes(m[i]).astype(np.uint8))
+            assert np.array_equal(f8[i], ndimage.binary_fill_holes(m[i], np.ones((3, 3))).astype(np.uint8))
+
+
+def test_circle_profiles_vs_reference_golden(golden, dev):
+    from pylinac_amd.profile import CircleProfile, CollapsedCircleProfile, Point
+
+    g = golden("misc")
+    img16 = g["circle.img16"]
+    imgf = img16.astype(float) / 65535.0
+    for i, (cx, cy, r, sa, ccw, sr) in enumerate(g["circle.cases"]):
+        c = Point(x=cx, y=cy)
+        p = CircleProfile(c, r, img16, start_angle=sa, ccw=bool(ccw), sampling_ratio=sr)
+        assert p.values.dtype == img16.dtype and np.array_equal(p.values, g[f"circle.{i}.u16"])
+        p = CircleProfile(c, r, imgf, start_angle=sa, ccw=bool(ccw), sampling_ratio=sr)
+        assert np.array_equal(p.values, g[f"circle.{i}.f64"])
+        p = CollapsedCircleProfile(c, r, imgf, start_angle=sa, ccw=bool(ccw), sampling_ratio=sr, width_ratio=0.1,
+                                   num_profiles=20)
+        assert np.array_equal(p.values, g[f"collapsed.{i}.f64"])
+        p = CollapsedCircleProfile(c, r, img16, sampling_ratio=sr, width_ratio=0.05, num_profiles=5)
+        assert np.array_equal(p.values, g[f"collapsed.{i}.u16"])
+        # MultiProfile API on top of the sampled ring (Starshot / CTP528 use find_peaks on it)
+        i1, v1 = p.find_peaks(threshold=0.3, min_distance=0.05)
+        i2, v2 = o.multiprofile_find_peaks(g[f"collapsed.{i}.u16"], 0.3, 0.05)
+        assert np.array_equal(i1, i2) and np.array_equal(v1, v2)
+    with pytest.raises(ValueError, match="not large enough"):
+        CircleProfile(Point(x=150, y=80), 100.0, img16)
+
+
+def test_circle_profile_out_of_bounds_is_zero(dev):
+    """A ring that leaves the image on the low side: out-of-range samples read 0, even when only
+    fractionally outside (scipy mode='constant')."""
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(1)
+    img = rng.integers(1, 65536, (60, 70), dtype=np.uint16)
+    got = ops.circle_profile(T(img[None], dev), 20.2, 15.7, [30.0], np.pi * 30 * 2)[0].cpu().numpy()
+    ref = o.circle_profile(img, (20.2, 15.7), 30.0)
+    assert np.array_equal(got, ref.astype(float)) and (ref == 0).any() and (ref != 0).any()
+
+
+def test_sobel_vs_scipy(golden, dev):
+    from pylinac_amd import ops
+
+    g = golden("misc")
+    x = g["sobel.in"]
+    assert np.array_equal(ops.sobel(T(x[None], dev), 1)[0].cpu().numpy(), g["sobel.axis1"])
+    assert np.array_equal(ops.sobel(T(x[None], dev), 0)[0].cpu().numpy(), g["sobel.axis0"])
+    rng = np.random.default_rng(6)
+    for dt in (np.float64, np.float32, np.int16):
+        a = (rng.normal(0, 300, (2, 37, 53))).astype(dt)
+        for ax in (0, 1):
+            ref = np.stack([o.sobel(f, ax) for f in a])
+            assert np.array_equal(ops.sobel(T(a, dev), ax).cpu().numpy(), ref), (dt, ax)
+
+
+def test_wl_field_centroid_vs_reference_golden(golden, dev):
+    from pylinac_amd.winston_lutz import field_centroids_batch
+
+    g = golden("misc")
+    got = field_centroids_batch(T(g["wl.in"], dev)).cpu().numpy()
+    assert np.array_equal(got, g["wl.centroid"])
+    # seeded extra frames against the oracle, incl. a field with an interior hole and int16 data
+    rng = np.random.default_rng(3)
+    fr = g["wl.in"].copy()
+    fr[0, 95:105, 115:125] = 0
+    ref = np.array([o.wl_field_centroid(f) for f in fr])
+    assert np.array_equal(field_centroids_batch(T(fr, dev)).cpu().numpy(), ref)
+    fi = (fr.astype(np.int32) - 32768).astype(np.int16)
+    ref = np.array([o.wl_field_centroid(f) for f in fi])
+    assert np.array_equal(field_centroids_batch(T(fi, dev)).cpu().numpy(), ref)

@@ -211,3 +211,41 @@ def test_restatements_against_scipy_random():
         assert np.array_equal(p1, p2)
         for k in r1:
             assert np.array_equal(r1[k], r2[k]), k
+
+
+MASKS = ["random40", "random_dense", "blobs", "rings", "empty", "full"]
+
+
+def test_label_and_fill_holes_match_skimage_scipy_golden(golden):
+    g = golden("misc")
+    for k in MASKS:
+        m = g[f"mask.{k}"]
+        for conn, sk in ((4, 1), (8, 2)):
+            lab, num = o.label_like_skimage(m, conn)
+            assert np.array_equal(lab, g[f"label.{k}.conn{sk}"]), (k, conn)
+        assert np.array_equal(ndimage.binary_fill_holes(m).astype(np.uint8), g[f"fill.{k}"])
+
+
+def test_circle_profiles_match_reference_golden(golden):
+    g = golden("misc")
+    img16 = g["circle.img16"]
+    imgf = img16.astype(float) / 65535.0
+    for i, (cx, cy, r, sa, ccw, sr) in enumerate(g["circle.cases"]):
+        assert np.array_equal(o.circle_profile(img16, (cx, cy), r, sa, bool(ccw), sr), g[f"circle.{i}.u16"])
+        assert np.array_equal(o.circle_profile(imgf, (cx, cy), r, sa, bool(ccw), sr), g[f"circle.{i}.f64"])
+        assert np.array_equal(o.collapsed_circle_profile(imgf, (cx, cy), r, sa, bool(ccw), sr, 0.1, 20),
+                              g[f"collapsed.{i}.f64"])
+        assert np.array_equal(o.collapsed_circle_profile(img16, (cx, cy), r, 0, True, sr, 0.05, 5),
+                              g[f"collapsed.{i}.u16"])
+        # restated sampling rule
+        rads = o.circle_radians(np.pi * r * 2 * sr, sa, bool(ccw))
+        x, y = np.cos(rads) * r + cx, np.sin(rads) * r + cy
+        assert np.array_equal(o.map_coordinates_nearest_restated(img16, y, x), g[f"circle.{i}.u16"])
+
+
+def test_sobel_and_wl_centroid_match_reference_golden(golden):
+    g = golden("misc")
+    assert np.array_equal(o.sobel(g["sobel.in"], 1), g["sobel.axis1"])
+    assert np.array_equal(o.sobel(g["sobel.in"], 0), g["sobel.axis0"])
+    got = np.array([o.wl_field_centroid(f) for f in g["wl.in"]])
+    assert np.array_equal(got, g["wl.centroid"])
