@@ -26,8 +26,10 @@ from . import ops
 def field_centroids_batch(frames: torch.Tensor) -> torch.Tensor:
     """-> float64 [N, 3] = (x, y, filled_pixel_count) of the field centroid of every frame."""
     x = ops._frames(frames)
-    if x.dtype not in (torch.uint16, torch.int16):
-        raise TypeError("field_centroids_batch needs 16-bit integer frames")
+    if x.dtype != torch.uint16:
+        # int16: the reference's ground() (`array - array.min()`, array_utils.py:102) wraps around in
+        # int16 for any frame whose range exceeds 32767, i.e. its own result is an overflow artefact
+        raise TypeError("field_centroids_batch needs uint16 frames")
     cnt = x[0].numel()
     hist = ops.histogram16(x)
     qs, lo, hi, frac = ops._percentile_plan(cnt, [5, 99.9])

@@ -654,6 +654,5 @@ def test_wl_field_centroid_vs_reference_golden(golden, dev):
     fr[0, 95:105, 115:125] = 0
     ref = np.array([o.wl_field_centroid(f) for f in fr])
     assert np.array_equal(field_centroids_batch(T(fr, dev)).cpu().numpy(), ref)
-    fi = (fr.astype(np.int32) - 32768).astype(np.int16)
-    ref = np.array([o.wl_field_centroid(f) for f in fi])
-    assert np.array_equal(field_centroids_batch(T(fi, dev)).cpu().numpy(), ref)
+    with pytest.raises(TypeError):  # int16 ground() wraps in the reference itself: refused, not emulated
+        field_centroids_batch(T((fr.astype(np.int32) - 32768).astype(np.int16), dev))
