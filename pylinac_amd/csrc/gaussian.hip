@@ -136,7 +136,7 @@ gauss_v_fast(const T* __restrict__ in, T* __restrict__ out, int h, int w, int co
 __device__ __forceinline__ constexpr int pad8(int p) { return p + ((p >> 3) << 1); }
 
 template <typename T, int RAD, int NOUT>
-__global__ void __launch_bounds__(kThreads, 3)
+__global__ void __launch_bounds__(kThreads, 4)
 gauss_h_fast(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, int w,
              int col_tiles, const double* __restrict__ wts) {
   static_assert(NOUT == 8, "pad8 assumes 8 outputs per lane");
@@ -309,18 +309,14 @@ gauss_h_median3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int
           const T* p = hrows + (size_t)k * hpitch;
           a = (int)p[c_m1]; b = (int)p[ca]; c = (int)p[c_p1]; d = (int)p[c_p2];
         }
-        lo0[slot] = min(min(a, b), c); hi0[slot] = max(max(a, b), c);
-        mi0[slot] = max(min(a, b), min(max(a, b), c));
-        lo1[slot] = min(min(b, c), d); hi1[slot] = max(max(b, c), d);
-        mi1[slot] = max(min(b, c), min(max(b, c), d));
+        lo0[slot] = min(min(a, b), c); hi0[slot] = max(max(a, b), c); mi0[slot] = pl_smed3(a, b, c);
+        lo1[slot] = min(min(b, c), d); hi1[slot] = max(max(b, c), d); mi1[slot] = pl_smed3(b, c, d);
       };
       auto emit = [&](int i) {
-        const int m0 = max(min(max(max(lo0[0], lo0[1]), lo0[2]), max(min(mi0[0], mi0[1]), min(max(mi0[0], mi0[1]), mi0[2]))),
-                           min(max(max(max(lo0[0], lo0[1]), lo0[2]), max(min(mi0[0], mi0[1]), min(max(mi0[0], mi0[1]), mi0[2]))),
-                               min(min(hi0[0], hi0[1]), hi0[2])));
-        const int m1 = max(min(max(max(lo1[0], lo1[1]), lo1[2]), max(min(mi1[0], mi1[1]), min(max(mi1[0], mi1[1]), mi1[2]))),
-                           min(max(max(max(lo1[0], lo1[1]), lo1[2]), max(min(mi1[0], mi1[1]), min(max(mi1[0], mi1[1]), mi1[2]))),
-                               min(min(hi1[0], hi1[1]), hi1[2])));
+        const int m0 = pl_smed3(max(max(lo0[0], lo0[1]), lo0[2]), pl_smed3(mi0[0], mi0[1], mi0[2]),
+                                min(min(hi0[0], hi0[1]), hi0[2]));
+        const int m1 = pl_smed3(max(max(lo1[0], lo1[1]), lo1[2]), pl_smed3(mi1[0], mi1[1], mi1[2]),
+                                min(min(hi1[0], hi1[1]), hi1[2]));
         T* op = o + (size_t)(r0 + i) * w + ca;
         if (ca + 1 < w && ((reinterpret_cast<uintptr_t>(op) & 3) == 0)) {
           *reinterpret_cast<unsigned*>(op) = ((unsigned)m0 & 0xffffu) | ((unsigned)m1 << 16);

@@ -25,10 +25,25 @@ static inline int64_t pl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // scipy 'reflect' (half-sample symmetric:  d c b a | a b c d | d c b a), valid for any distance.
 __device__ __forceinline__ int pl_reflect(int i, int n) {
   if ((unsigned)i < (unsigned)n) return i;
-  int p = 2 * n;
+  // single reflection (the only case for halos narrower than the frame): no integer division
+  const int m1 = (i < 0) ? (-i - 1) : (2 * n - 1 - i);
+  if ((unsigned)m1 < (unsigned)n) return m1;
+  const int p = 2 * n;
   int m = i % p;
   if (m < 0) m += p;
   return m >= n ? p - 1 - m : m;
+}
+
+// three-operand VALU median/min/max on 32-bit keys (the compiler only forms min3/max3 on its own)
+__device__ __forceinline__ unsigned pl_umed3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ int pl_smed3(int a, int b, int c) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
 // Blocks b and b+8 share an XCD (observed dispatch, speed only).  Map the hardware block id onto

@@ -51,7 +51,9 @@ class EpidPipeline:
     sigma: float = 5
     median_size: int = 3
     fwxm_height: float = 50
-    fused: bool = True   # fuse the Gaussian's axis-1 pass with the 3x3 median (one HBM round trip less)
+    # fuse the Gaussian's axis-1 pass with the 3x3 median: one HBM round trip less, but measured
+    # slower than the two specialised kernels on MI355X (VALU-issue-bound either way) -> opt-in
+    fused: bool = False
     timings: dict = field(default_factory=dict)
 
     def __post_init__(self):
