@@ -49,17 +49,46 @@ __device__ __forceinline__ int block_flag_scan(int flag, int* total, Scan* s) {
 
 struct Widths { double width, height, lip, rip; };
 
+// The walks below are sequential by definition (scipy's while loops), but each step is an LDS
+// round trip.  They therefore fetch four samples per trip (indices clamped into the profile) and
+// evaluate scipy's loop condition on them in order -- same result, a quarter of the latency.
+
+// first i (walking left from `start`, stopping at `stop`) with !(h < x[i]);  scipy:
+//   i = peak; while (i_min < i && height < x[i]) --i;
+__device__ __forceinline__ int walk_left_while_above(const double* xs, int start, int stop, double h) {
+  int i = start;
+  while (stop < i) {
+    const double v0 = xs[i], v1 = xs[max(i - 1, 0)], v2 = xs[max(i - 2, 0)], v3 = xs[max(i - 3, 0)];
+    if (!(h < v0)) return i;
+    if (!(stop < i - 1) || !(h < v1)) return i - 1;
+    if (!(stop < i - 2) || !(h < v2)) return i - 2;
+    if (!(stop < i - 3) || !(h < v3)) return i - 3;
+    i -= 4;
+  }
+  return i;
+}
+__device__ __forceinline__ int walk_right_while_above(const double* xs, int start, int stop, double h, int m) {
+  int i = start;
+  while (i < stop) {
+    const double v0 = xs[i], v1 = xs[min(i + 1, m - 1)], v2 = xs[min(i + 2, m - 1)], v3 = xs[min(i + 3, m - 1)];
+    if (!(h < v0)) return i;
+    if (!(i + 1 < stop) || !(h < v1)) return i + 1;
+    if (!(i + 2 < stop) || !(h < v2)) return i + 2;
+    if (!(i + 3 < stop) || !(h < v3)) return i + 3;
+    i += 4;
+  }
+  return i;
+}
+
 __device__ __forceinline__ Widths peak_width(const double* xs, int pk, int lb, int rb, double prom,
-                                             double rel_height) {
+                                             double rel_height, int m) {
   Widths r;
   const double h = xs[pk] - prom * rel_height;
   r.height = h;
-  int i = pk;
-  while (lb < i && h < xs[i]) --i;
+  int i = walk_left_while_above(xs, pk, lb, h);
   double lip = (double)i;
   if (xs[i] < h) lip += (h - xs[i]) / (xs[i + 1] - xs[i]);
-  i = pk;
-  while (i < rb && h < xs[i]) ++i;
+  i = walk_right_while_above(xs, pk, rb, h, m);
   double rip = (double)i;
   if (xs[i] < h) rip -= (h - xs[i]) / (xs[i - 1] - xs[i]);
   r.lip = lip;
@@ -68,9 +97,41 @@ __device__ __forceinline__ Widths peak_width(const double* xs, int pk, int lb, i
   return r;
 }
 
+// scipy _peak_prominences, one side:  i = base = peak; min = x[peak];
+//   while (in range && x[i] <= x[peak]) { if (x[i] < min) { min = x[i]; base = i; } i += dir; }
+template <int DIR>
+__device__ __forceinline__ void prominence_side(const double* xs, int pk, int m, double& out_min, int& out_base) {
+  const double xp = xs[pk];
+  double mn = xp;
+  int base = pk, i = pk;
+  for (;;) {
+    if (DIR < 0 ? (i < 0) : (i > m - 1)) break;
+    const int i1 = DIR < 0 ? max(i - 1, 0) : min(i + 1, m - 1);
+    const int i2 = DIR < 0 ? max(i - 2, 0) : min(i + 2, m - 1);
+    const int i3 = DIR < 0 ? max(i - 3, 0) : min(i + 3, m - 1);
+    const double v[4] = {xs[i], xs[i1], xs[i2], xs[i3]};
+    bool stop = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ik = i + DIR * k;
+      if (DIR < 0 ? (ik < 0) : (ik > m - 1)) { stop = true; break; }
+      if (!(v[k] <= xp)) { stop = true; break; }
+      if (v[k] < mn) { mn = v[k]; base = ik; }
+    }
+    if (stop) break;
+    i += DIR * 4;
+  }
+  out_min = mn;
+  out_base = base;
+}
+
+// STAGE = true: the (trimmed) profile lives in LDS and every walk below is a ds_read; keeping the two
+// cases in separate instantiations lets the compiler know the address space (a runtime select
+// between an LDS and a global pointer degrades every access to a slow FLAT load).
+template <bool STAGE>
 __global__ void __launch_bounds__(kThreads)
 find_peaks_kernel(const double* __restrict__ x, int len, int64_t stride, pl_peak_params prm, int cap,
-                  int maxc, int stage_x, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
+                  int maxc, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
                   int32_t* __restrict__ d_lb, int32_t* __restrict__ d_rb, double* __restrict__ d_props,
                   int32_t* __restrict__ d_status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -114,10 +175,12 @@ find_peaks_kernel(const double* __restrict__ x, int len, int64_t stride, pl_peak
     height = mn + prm.threshold * (mx - mn);  // pylinac/core/profile.py:2633-2635
   }
 
-  const double* xs = xfull + lo;
-  if (stage_x) {
-    for (int i = threadIdx.x; i < m; i += kThreads) s_x[i] = xs[i];
+  const double* xs;
+  if constexpr (STAGE) {
+    for (int i = threadIdx.x; i < m; i += kThreads) s_x[i] = xfull[lo + i];
     xs = s_x;
+  } else {
+    xs = xfull + lo;
   }
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
@@ -198,22 +261,13 @@ find_peaks_kernel(const double* __restrict__ x, int len, int64_t stride, pl_peak
   for (int p = threadIdx.x; p < P; p += kThreads) {
     const int pk = s_idx[p];
     const double xp = xs[pk];
-    int i = pk, lb = pk;
-    double left_min = xp;
-    while (0 <= i && xs[i] <= xp) {
-      if (xs[i] < left_min) { left_min = xs[i]; lb = i; }
-      --i;
-    }
-    i = pk;
-    int rb = pk;
-    double right_min = xp;
-    while (i <= m - 1 && xs[i] <= xp) {
-      if (xs[i] < right_min) { right_min = xs[i]; rb = i; }
-      ++i;
-    }
+    double left_min, right_min;
+    int lb, rb;
+    prominence_side<-1>(xs, pk, m, left_min, lb);
+    prominence_side<+1>(xs, pk, m, right_min, rb);
     const double prom = xp - (left_min > right_min ? left_min : right_min);
     int keep = (!prm.has_prominence || prom >= prm.prominence_min) ? 1 : 0;
-    const Widths wd = peak_width(xs, pk, lb, rb, prom, prm.rel_height);
+    const Widths wd = peak_width(xs, pk, lb, rb, prom, prm.rel_height, m);
     keep = keep && (wd.width >= prm.width_min);
     s_prom[p] = prom;
     s_width[p] = wd.width;
@@ -262,7 +316,7 @@ find_peaks_kernel(const double* __restrict__ x, int len, int64_t stride, pl_peak
     const int dst = cur + off;
     if (flag && dst < cap) {
       const int pk = s_idx[p];
-      const Widths wd = peak_width(xs, pk, s_lb[p], s_rb[p], s_prom[p], prm.rel_height);
+      const Widths wd = peak_width(xs, pk, s_lb[p], s_rb[p], s_prom[p], prm.rel_height, m);
       o_idx[dst] = pk + lo;  // only the indices are shifted (pylinac/core/profile.py:2613)
       o_lb[dst] = s_lb[p];
       o_rb[dst] = s_rb[p];
@@ -341,13 +395,21 @@ extern "C" int pl_find_peaks(const double* d_x, int64_t n, int len, int64_t stri
   size_t lds = (size_t)maxc * (8 + 8 + 4 * 4) + 8 + (stage_x ? (size_t)m * 8 : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)find_peaks_kernel,
+    hipError_t e = hipFuncSetAttribute((const void*)find_peaks_kernel<true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)find_peaks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024);
     if (e != hipSuccess) { pl_set_error("pl_find_peaks: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(find_peaks_kernel, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
-                     len, stride, *params, cap, maxc, stage_x, d_count, d_idx, d_left_base, d_right_base,
-                     d_props, d_status);
+  if (stage_x)
+    hipLaunchKernelGGL(find_peaks_kernel<true>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
+                       len, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base, d_props,
+                       d_status);
+  else
+    hipLaunchKernelGGL(find_peaks_kernel<false>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
+                       len, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base, d_props,
+                       d_status);
   return pl_check_launch("pl_find_peaks");
 }
