@@ -168,6 +168,36 @@ int pl_binary_centroid(const uint8_t* d_mask, int64_t n, int h, int w, unsigned 
 int pl_scaled_binary(const void* in, int dtype, int64_t n, int64_t count, const double* d_sub,
                      const double* d_div, const double* d_thr, uint8_t* d_out, void* stream);
 
+/* ---- a16: CatPhan slice localisation (pylinac/ct.py:381-425, 3315-3348) --------------------------
+ * pl_scharr: skimage.filters.scharr(float image) -> float64 edge magnitude.
+ * pl_gaussian2d_mode: ndimage.gaussian_filter with border mode 0 'reflect' / 1 'nearest'
+ *   (skimage.filters.gaussian uses 'nearest').
+ * pl_clip: np.clip.   pl_compare: op 0 >=, 1 >, 2 <=, 3 < against per-frame / broadcast thresholds.
+ * pl_hist_uniform: np.histogram(values[mask], bins=nbins) with caller-supplied float64 edges
+ *   [n][nbins+1] (np.linspace(min, max, nbins+1)); d_mask uint8[count] shared by all frames or NULL;
+ *   d_counts uint32[n][nbins].
+ * pl_clear_border: skimage.segmentation.clear_border(bw, buffer_size) (8-connected labelling).
+ * pl_region_stats: regionprops raw sums, float64 [n][max_labels][10] = area, bbox(r0,c0,r1,c1),
+ *   sum r, sum c, sum w, sum w*r, sum w*c;  d_isum uint64[n][max_labels][7], d_wsum float64
+ *   [n][max_labels][3] scratch; d_overflow int32[n] set when a label exceeds max_labels. */
+int pl_scharr(const void* in, double* out, int dtype, int64_t n, int h, int w, void* stream);
+int pl_gaussian2d_mode(const void* in, void* out, void* tmp, int dtype, int64_t n, int h, int w,
+                       const double* d_weights, int radius, int mode, void* stream);
+/* min/max over the pixels selected by a frame-shared uint8 mask (edges[rr, cc] of the disk) */
+int pl_minmax_masked(const double* in, const uint8_t* d_mask, int64_t n, int64_t count, double* d_min,
+                     double* d_max, void* stream);
+int pl_clip(const void* in, void* out, int dtype, int64_t n, int64_t count, double lo, double hi,
+            void* stream);
+int pl_hist_uniform(const double* in, const uint8_t* d_mask, int64_t n, int64_t count,
+                    const double* d_edges, int nbins, uint32_t* d_counts, void* stream);
+int pl_compare(const void* in, int dtype, int64_t n, int64_t count, const double* d_thr, int thr_stride,
+               int op, uint8_t* d_out, void* stream);
+int pl_clear_border(const uint8_t* d_mask, uint8_t* d_out, int64_t n, int h, int w, int buffer_size,
+                    int32_t* d_work, uint8_t* d_flags, void* stream);
+int pl_region_stats(const int32_t* d_labels, const double* d_intensity, int64_t n, int h, int w,
+                    int max_labels, unsigned long long* d_isum, double* d_wsum, double* d_stats,
+                    int32_t* d_overflow, void* stream);
+
 /* ---- a8-a10: pylinac.core.profile.find_peaks over scipy.signal.find_peaks -----------------------
  * (pylinac/core/profile.py:2545-2649).  One 1-D float64 profile per batch item. */
 typedef struct pl_peak_params {

@@ -553,6 +553,119 @@ def label_like_skimage(mask: np.ndarray, connectivity: int = 4):
 
 
 # --------------------------------------------------------------------------------------
+# a16  CatPhan slice localisation  (pylinac/ct.py:381-425, 3315-3348; skimage 0.18.3 semantics)
+# --------------------------------------------------------------------------------------
+
+_SCHARR_EDGE = np.array([1, 0, -1])
+_SCHARR_SMOOTH = np.array([3, 10, 3]) / 16
+
+
+def scharr_like_skimage(image: np.ndarray) -> np.ndarray:
+    """skimage.filters.scharr (0.18.3 filters/edges.py:_generic_edge_filter): per axis
+    ndi.convolve(image, edge (x) smooth, mode='reflect'), squared and summed, sqrt / sqrt(ndim)."""
+    image = image.astype(float)
+    out = np.zeros(image.shape, dtype=float)
+    for edge_dim in (0, 1):
+        k = _SCHARR_EDGE.reshape((3, 1) if edge_dim == 0 else (1, 3)) * \
+            _SCHARR_SMOOTH.reshape((1, 3) if edge_dim == 0 else (3, 1))
+        ax = ndimage.convolve(image, k, mode="reflect")
+        ax *= ax
+        out += ax
+    return np.sqrt(out) / np.sqrt(2)
+
+
+def gaussian_like_skimage(image: np.ndarray, sigma=1) -> np.ndarray:
+    """skimage.filters.gaussian defaults: mode='nearest', truncate=4.0 on a float image."""
+    return ndimage.gaussian_filter(image.astype(float), sigma, mode="nearest", truncate=4.0)
+
+
+def disk_mask_like_skimage(center_rc, radius, shape) -> np.ndarray:
+    """skimage.draw.disk(center, radius, shape=shape) (draw.py ellipse + _ellipse_in_shape,
+    rotation 0) as a uint8 mask."""
+    center = np.array(center_rc, dtype=float)
+    radii = np.array([radius, radius], dtype=float)
+    rot = 0.0 % np.pi
+    r_rot = abs(radius * np.cos(rot)) + radius * np.sin(rot)
+    c_rot = radius * np.sin(rot) + abs(radius * np.cos(rot))
+    radii_rot = np.array([r_rot, c_rot])
+    upper_left = np.maximum(np.ceil(center - radii_rot).astype(int), 0)
+    lower_right = np.minimum(np.floor(center + radii_rot).astype(int), np.array(shape[:2]) - 1)
+    shifted = center - upper_left
+    bshape = lower_right - upper_left + 1
+    r_lim, c_lim = np.ogrid[0:float(bshape[0]), 0:float(bshape[1])]
+    sin_a, cos_a = np.sin(rot), np.cos(rot)
+    r, c = (r_lim - shifted[0]), (c_lim - shifted[1])
+    dist = ((r * cos_a + c * sin_a) / radii[0]) ** 2 + ((r * sin_a - c * cos_a) / radii[1]) ** 2
+    rr, cc = np.nonzero(dist < 1)
+    m = np.zeros(shape, np.uint8)
+    m[rr + upper_left[0], cc + upper_left[1]] = 1
+    return m
+
+
+def clear_border_like_skimage(bw: np.ndarray, buffer_size: int) -> np.ndarray:
+    """skimage.segmentation.clear_border(bw, buffer_size) (0.18.3 _clear_border.py): 8-connected
+    labelling; every label owning a pixel in the (buffer_size+1)-wide border band is removed."""
+    lab, _ = ndimage.label(bw, structure=np.ones((3, 3)))
+    ext = buffer_size + 1
+    band = np.zeros(bw.shape, bool)
+    band[:ext, :] = band[-ext:, :] = True
+    band[:, :ext] = band[:, -ext:] = True
+    bad = np.unique(lab[band])
+    out = bw.copy()
+    out[np.isin(lab, bad[bad > 0])] = 0
+    return out
+
+
+def catphan_get_regions(arr: np.ndarray, mm_per_pixel: float, fill_holes: bool = True, clear_borders: bool = True):
+    """pylinac/ct.py:3315-3348 for a Slice (default clip_in_localization=False, ct.py:2043):
+    scharr -> gaussian(1) -> Otsu (256 bins) on the 110 mm disk * 0.8 -> '>' -> clear_border ->
+    binary_fill_holes -> label (8-conn).  Returns (edges, bw, labels, n)."""
+    edges = gaussian_like_skimage(scharr_like_skimage(arr), 1)
+    cy, cx = arr.shape[0] / 2 - 0.5, arr.shape[1] / 2 - 0.5               # image.py:527-533
+    disk = disk_mask_like_skimage((cy, cx), 110 / mm_per_pixel, edges.shape)
+    thres = threshold_otsu(edges[disk.astype(bool)]) * 0.8
+    bw = edges > thres
+    if clear_borders:
+        bw = clear_border_like_skimage(bw, min(int(max(bw.shape) / 100), 3))
+    if fill_holes:
+        bw = ndimage.binary_fill_holes(bw)
+    lab, n = ndimage.label(bw, structure=np.ones((3, 3)))
+    return edges, bw, lab, n
+
+
+def region_table(lab: np.ndarray, n: int, intensity: np.ndarray) -> np.ndarray:
+    """[n, 10]: area, bbox(r0,c0,r1,c1), centroid(r,c), filled_area, weighted_centroid(r,c) --
+    skimage.measure.regionprops semantics (measure/_regionprops.py)."""
+    rows = []
+    for k in range(1, n + 1):
+        m = lab == k
+        rr, cc = np.nonzero(m)
+        r0, r1, c0, c1 = rr.min(), rr.max() + 1, cc.min(), cc.max() + 1
+        crop = m[r0:r1, c0:c1]
+        filled = ndimage.binary_fill_holes(crop, np.ones((3, 3))).sum()
+        w = intensity[m]
+        rows.append([m.sum(), r0, c0, r1, c1, rr.mean(), cc.mean(), filled,
+                     (w * rr).sum() / w.sum(), (w * cc).sum() / w.sum()])
+    return np.array(rows, dtype=float).reshape(-1, 10)
+
+
+def catphan_phantom_roi(arr: np.ndarray, mm_per_pixel: float, catphan_size: float):
+    """Slice.phantom_roi (pylinac/ct.py:381-425): region whose filled_area is closest to the expected
+    phantom size; ValueError when none / out of the 1.3x size window.  -> (label, table row)."""
+    edges0 = scharr_like_skimage(arr)
+    if np.max(edges0) < 0.1:
+        raise ValueError("No edges were found in the image that look like the phantom")
+    edges, bw, lab, n = catphan_get_regions(arr, mm_per_pixel)
+    if n < 1:
+        raise ValueError(f"The number of ROIs detected {n} was not the number expected (1)")
+    tab = region_table(lab, n, edges)
+    k = int(np.argsort(np.abs(tab[:, 7] - catphan_size), kind="stable")[0])
+    if catphan_size * 1.3 < tab[k, 7] or tab[k, 7] < catphan_size / 1.3:
+        raise ValueError("Unable to find ROI of expected size of the phantom")
+    return k + 1, tab[k]
+
+
+# --------------------------------------------------------------------------------------
 # BASELINE config #2 + profile/peak: the pipeline bench.py measures
 # --------------------------------------------------------------------------------------
 

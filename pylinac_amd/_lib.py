@@ -73,6 +73,14 @@ SIGNATURES = {
     "pl_fill_holes": ([_p, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_binary_centroid": ([_p, _l, _i, _i, _p, _p, _p], C.c_int),
     "pl_scaled_binary": ([_p, _i, _l, _l, _p, _p, _p, _p, _p], C.c_int),
+    "pl_scharr": ([_p, _p, _i, _l, _i, _i, _p], C.c_int),
+    "pl_gaussian2d_mode": ([_p, _p, _p, _i, _l, _i, _i, _p, _i, _i, _p], C.c_int),
+    "pl_minmax_masked": ([_p, _p, _l, _l, _p, _p, _p], C.c_int),
+    "pl_clip": ([_p, _p, _i, _l, _l, _d, _d, _p], C.c_int),
+    "pl_hist_uniform": ([_p, _p, _l, _l, _p, _i, _p, _p], C.c_int),
+    "pl_compare": ([_p, _i, _l, _l, _p, _i, _i, _p, _p], C.c_int),
+    "pl_clear_border": ([_p, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
+    "pl_region_stats": ([_p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p], C.c_int),
     "pl_colsum_to_mean": ([_p, _l, _i, _i, _p, _p], C.c_int),
     "pl_fwxm_record": ([_p, _p, _p, _i, _l, _p, _p], C.c_int),
     "pl_find_peaks": (

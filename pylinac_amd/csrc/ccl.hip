@@ -220,6 +220,11 @@ int run_ccl(const uint8_t* mask, int invert, int64_t n, int h, int w, int conn, 
 
 }  // namespace
 
+// shared with ct.hip (clear_border): union-find roots of the (optionally inverted) mask
+int pl_ccl_roots(const uint8_t* mask, int invert, int64_t n, int h, int w, int conn, int* L, hipStream_t st) {
+  return run_ccl(mask, invert, n, h, w, conn, L, st);
+}
+
 #define PL_CCL_CHECK_SHAPE()                                                          \
   PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");                                  \
   PL_REQUIRE((int64_t)h * w <= 0x7fffffffLL, "frame too large for 32-bit labels");    \

@@ -124,6 +124,24 @@ minmax_kernel(const T* __restrict__ in, int64_t count, int64_t chunk, int bpf, d
   }
 }
 
+// min/max of the pixels selected by a (frame-shared) uint8 mask: edges[rr, cc].min()/max() of
+// get_regions' disk selection (pylinac/ct.py:3334-3338)
+__global__ void __launch_bounds__(kThreads)
+minmax_masked_kernel(const double* __restrict__ in, const unsigned char* __restrict__ mask, int64_t count,
+                     int bpf, double* mn, double* mx) {
+  const int64_t frame = blockIdx.x / bpf;
+  const int64_t chunk = 65536;
+  const int64_t lo_i = (int64_t)(blockIdx.x % bpf) * chunk;
+  const int64_t hi_i = (lo_i + chunk < count) ? lo_i + chunk : count;
+  const double* src = in + frame * count;
+  double lo = __longlong_as_double(0x7ff0000000000000LL), hi = __longlong_as_double((long long)0xfff0000000000000ULL);
+  for (int64_t i = lo_i + threadIdx.x; i < hi_i; i += kThreads)
+    if (mask[i]) { const double v = src[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+  lo = pl_wave_reduce(lo, [](double a, double b) { return a < b ? a : b; });
+  hi = pl_wave_reduce(hi, [](double a, double b) { return a > b ? a : b; });
+  if ((threadIdx.x & 63) == 0) { atomic_min_f64(mn + frame, lo); atomic_max_f64(mx + frame, hi); }
+}
+
 // ----------------------------------------------------------------------------- elementwise ops
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
@@ -219,6 +237,20 @@ extern "C" int pl_minmax(const void* in, int dtype, int64_t n, int64_t count, do
                        count, p.chunk, p.bpf, d_min, d_max);
   });
   return pl_check_launch("pl_minmax");
+}
+
+extern "C" int pl_minmax_masked(const double* in, const uint8_t* d_mask, int64_t n, int64_t count, double* d_min,
+                                double* d_max, void* stream) {
+  PL_REQUIRE(in && d_mask && d_min && d_max, "null pointer");
+  PL_REQUIRE(n >= 0 && count > 0, "bad shape");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(minmax_init, dim3((unsigned)pl_cdiv(n, kThreads)), dim3(kThreads), 0, st, d_min, d_max, n);
+  const int bpf = (int)pl_cdiv(count, 65536);
+  if (int rc = check_grid(n, bpf, "pl_minmax_masked")) return rc;
+  hipLaunchKernelGGL(minmax_masked_kernel, dim3((unsigned)(n * bpf)), dim3(kThreads), 0, st, in, d_mask, count, bpf,
+                     d_min, d_max);
+  return pl_check_launch("pl_minmax_masked");
 }
 
 extern "C" int pl_ground(const void* in, void* out, int dtype, int64_t n, int64_t count,

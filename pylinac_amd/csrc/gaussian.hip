@@ -346,7 +346,9 @@ gauss_h_median3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 gauss_generic(const T* __restrict__ in, T* __restrict__ out, int64_t total, int h, int w, int axis,
-              const double* __restrict__ wts, int rad) {
+              const double* __restrict__ wts, int rad, int mode) {
+  // mode 0: scipy 'reflect'; mode 1: scipy 'nearest' (skimage.filters.gaussian's default)
+  auto border = [mode](int i, int n) { return mode == 0 ? pl_reflect(i, n) : (i < 0 ? 0 : (i >= n ? n - 1 : i)); };
   int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % w);
@@ -357,16 +359,16 @@ gauss_generic(const T* __restrict__ in, T* __restrict__ out, int64_t total, int 
   if (axis == 0) {
     acc = (double)f[(size_t)r * w + c] * wts[rad];
     for (int j = rad; j >= 1; --j) {
-      double a = (double)f[(size_t)pl_reflect(r - j, h) * w + c];
-      double b = (double)f[(size_t)pl_reflect(r + j, h) * w + c];
+      double a = (double)f[(size_t)border(r - j, h) * w + c];
+      double b = (double)f[(size_t)border(r + j, h) * w + c];
       acc = acc + (a + b) * wts[rad - j];
     }
   } else {
     const T* frow = f + (size_t)r * w;
     acc = (double)frow[c] * wts[rad];
     for (int j = rad; j >= 1; --j) {
-      double a = (double)frow[pl_reflect(c - j, w)];
-      double b = (double)frow[pl_reflect(c + j, w)];
+      double a = (double)frow[border(c - j, w)];
+      double b = (double)frow[border(c + j, w)];
       acc = acc + (a + b) * wts[rad - j];
     }
   }
@@ -397,11 +399,11 @@ int launch_fast(const T* in, T* out, int64_t n, int h, int w, int axis, const do
 
 template <typename T>
 int gaussian1d_t(const T* in, T* out, int64_t n, int h, int w, int axis, const double* wts,
-                 int radius, hipStream_t st) {
+                 int radius, hipStream_t st, int mode = 0) {
   int rc = -1;
   // specialised instances: radius = int(4*sigma+0.5) for sigma 1, 2, 3, 5
   const bool big_enough = (axis == 0 ? h : w) >= 1;
-  if (big_enough && sizeof(T) == 2) {
+  if (big_enough && sizeof(T) == 2 && mode == 0) {
     switch (radius) {
       case 4: rc = launch_fast<T, 4>(in, out, n, h, w, axis, wts, st); break;
       case 8: rc = launch_fast<T, 8>(in, out, n, h, w, axis, wts, st); break;
@@ -418,7 +420,7 @@ int gaussian1d_t(const T* in, T* out, int64_t n, int h, int w, int axis, const d
       return PL_ERR_INVALID_ARG;
     }
     hipLaunchKernelGGL(gauss_generic<T>, dim3((unsigned)blocks), dim3(kThreads), 0, st, in, out,
-                       total, h, w, axis, wts, radius);
+                       total, h, w, axis, wts, radius, mode);
   }
   return pl_check_launch("pl_gaussian1d");
 }
@@ -510,6 +512,22 @@ extern "C" int pl_gauss_h_median3(const void* in, void* out, void* tmp, int dtyp
   rc = pl_gaussian1d(in, tmp, dtype, n, h, w, 1, d_weights, radius, stream);
   if (rc != PL_OK) return rc;
   return pl_median2d(tmp, out, dtype, n, h, w, 3, stream);
+}
+
+extern "C" int pl_gaussian2d_mode(const void* in, void* out, void* tmp, int dtype, int64_t n, int h, int w,
+                                  const double* d_weights, int radius, int mode, void* stream) {
+  PL_REQUIRE(in && out && tmp && d_weights, "null pointer");
+  PL_REQUIRE(tmp != in && tmp != out && in != out, "buffers must be distinct");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0 && radius >= 0, "bad shape");
+  PL_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (reflect) or 1 (nearest)");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  PL_DISPATCH_DTYPE(dtype, T, {
+    int rc = gaussian1d_t<T>((const T*)in, (T*)tmp, n, h, w, 0, d_weights, radius, st, mode);
+    if (rc != PL_OK) return rc;
+    return gaussian1d_t<T>((const T*)tmp, (T*)out, n, h, w, 1, d_weights, radius, st, mode);
+  });
+  return PL_OK;
 }
 
 extern "C" int pl_gaussian2d(const void* in, void* out, void* tmp, int dtype, int64_t n, int h,

@@ -530,3 +530,102 @@ def scaled_binary(frames: torch.Tensor, sub, div, thr) -> torch.Tensor:
     check(_lib.load().pl_scaled_binary(x.data_ptr(), _dt(x), n, x[0].numel(), a[0].data_ptr(), a[1].data_ptr(),
                                        a[2].data_ptr(), out.data_ptr(), _stream()), "pl_scaled_binary")
     return out
+
+
+# ----------------------------------------------------------------- CatPhan localisation primitives
+def scharr(frames: torch.Tensor) -> torch.Tensor:
+    """``skimage.filters.scharr(frame.astype(float))`` -> float64 [N,H,W] (pylinac/ct.py:391,3327)."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    out = torch.empty((n, h, w), dtype=torch.float64, device=x.device)
+    check(_lib.load().pl_scharr(x.data_ptr(), out.data_ptr(), _dt(x), n, h, w, _stream()), "pl_scharr")
+    return out
+
+
+def gaussian_filter_mode(frames: torch.Tensor, sigma: float, mode: str = "nearest") -> torch.Tensor:
+    """``ndimage.gaussian_filter(frame, sigma, mode=...)``; ``skimage.filters.gaussian`` uses 'nearest'."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    wts, lw = _device_weights(sigma, x.device)
+    out, tmp = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.load().pl_gaussian2d_mode(x.data_ptr(), out.data_ptr(), tmp.data_ptr(), _dt(x), n, h, w,
+                                         wts.data_ptr(), lw, {"reflect": 0, "nearest": 1}[mode], _stream()),
+          "pl_gaussian2d_mode")
+    return out
+
+
+def minmax_masked(frames: torch.Tensor, mask: torch.Tensor):
+    """min/max of ``frame[mask]`` for a mask shared by all frames (float64 frames)."""
+    x = _frames(frames)
+    if x.dtype != torch.float64:
+        raise TypeError("minmax_masked needs float64 frames")
+    n = x.shape[0]
+    mn = torch.empty(n, dtype=torch.float64, device=x.device)
+    mx = torch.empty(n, dtype=torch.float64, device=x.device)
+    check(_lib.load().pl_minmax_masked(x.data_ptr(), mask.contiguous().data_ptr(), n, x[0].numel(), mn.data_ptr(),
+                                       mx.data_ptr(), _stream()), "pl_minmax_masked")
+    return mn, mx
+
+
+def clip(frames: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    x = _frames(frames)
+    out = torch.empty_like(x)
+    check(_lib.load().pl_clip(x.data_ptr(), out.data_ptr(), _dt(x), x.shape[0], x[0].numel(), float(lo), float(hi),
+                              _stream()), "pl_clip")
+    return out
+
+
+_OPS = {">=": 0, ">": 1, "<=": 2, "<": 3}
+
+
+def compare(frames: torch.Tensor, thr, op: str = ">") -> torch.Tensor:
+    x = _frames(frames)
+    n = x.shape[0]
+    t, stride = _per_frame(thr, n, x.device)
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(_lib.load().pl_compare(x.data_ptr(), _dt(x), n, x[0].numel(), t.data_ptr(), stride, _OPS[op],
+                                 out.data_ptr(), _stream()), "pl_compare")
+    return out
+
+
+def hist_uniform(frames: torch.Tensor, edges: torch.Tensor, mask: torch.Tensor | None = None) -> torch.Tensor:
+    """``np.histogram(frame[mask], bins=edges)`` for uniform float64 ``edges`` [N, nbins+1] -> int32 [N, nbins]."""
+    x = _frames(frames)
+    if x.dtype != torch.float64:
+        raise TypeError("hist_uniform needs float64 frames")
+    n = x.shape[0]
+    nb = edges.shape[1] - 1
+    out = torch.empty((n, nb), dtype=torch.int32, device=x.device)
+    check(_lib.load().pl_hist_uniform(x.data_ptr(), 0 if mask is None else mask.data_ptr(), n, x[0].numel(),
+                                      edges.contiguous().data_ptr(), nb, out.data_ptr(), _stream()), "pl_hist_uniform")
+    return out
+
+
+def clear_border(mask: torch.Tensor, buffer_size: int = 0) -> torch.Tensor:
+    """``skimage.segmentation.clear_border(bw, buffer_size)`` per frame (uint8 0/1)."""
+    x = _mask(mask)
+    n, h, w = x.shape
+    out = torch.empty_like(x)
+    work = torch.empty((n, h, w), dtype=torch.int32, device=x.device)
+    flags = torch.empty((n, h, w), dtype=torch.uint8, device=x.device)
+    check(_lib.load().pl_clear_border(x.data_ptr(), out.data_ptr(), n, h, w, int(buffer_size), work.data_ptr(),
+                                      flags.data_ptr(), _stream()), "pl_clear_border")
+    return out
+
+
+REGION_FIELDS = ("area", "bbox_r0", "bbox_c0", "bbox_r1", "bbox_c1", "sum_r", "sum_c", "sum_w", "sum_wr", "sum_wc")
+
+
+def region_stats(labels: torch.Tensor, intensity: torch.Tensor | None, max_labels: int):
+    """Raw regionprops sums per label -> (float64 [N, max_labels, 10] in REGION_FIELDS order,
+    int32 overflow [N])."""
+    n, h, w = labels.shape
+    dev = labels.device
+    isum = torch.empty((n, max_labels, 7), dtype=torch.int64, device=dev)
+    wsum = torch.empty((n, max_labels, 3), dtype=torch.float64, device=dev)
+    stats = torch.empty((n, max_labels, 10), dtype=torch.float64, device=dev)
+    ovf = torch.empty(n, dtype=torch.int32, device=dev)
+    check(_lib.load().pl_region_stats(labels.contiguous().data_ptr(), 0 if intensity is None else intensity.data_ptr(),
+                                      n, h, w, int(max_labels), isum.data_ptr(), wsum.data_ptr(), stats.data_ptr(),
+                                      ovf.data_ptr(), _stream()), "pl_region_stats")
+    return stats, ovf

@@ -84,6 +84,28 @@ def wl_frames(n, h, w, seed):
     return np.stack(out).astype(np.uint16)
 
 
+def catphan_slices(n, size, seed):
+    """CatPhan-like int16 HU slices: air (-1000), a 200 mm acrylic-ish cylinder (~90 HU) slightly off
+    centre, a few inserts and air holes, a couch bar that touches the image border, noise."""
+    rng = np.random.default_rng(seed)
+    mmpp = 250.0 / size
+    out = []
+    for i in range(n):
+        y, x = np.mgrid[0:size, 0:size].astype(float)
+        cy, cx = size / 2 + rng.uniform(-6, 6), size / 2 + rng.uniform(-6, 6)
+        r = np.hypot(y - cy, x - cx) * mmpp
+        img = np.full((size, size), -1000.0)
+        img[r < 100] = 90.0
+        for k in range(6):
+            a = k * np.pi / 3 + 0.2 * i
+            iy, ix = cy + 58 / mmpp * np.sin(a), cx + 58 / mmpp * np.cos(a)
+            img[np.hypot(y - iy, x - ix) * mmpp < 6] = [-1000, 340, -200, 950, -100, 120][k]
+        img[int(size * 0.975):int(size * 0.995), :] = 200.0        # couch: touches the border band
+        img += rng.normal(0, 12, img.shape)
+        out.append(np.round(img))
+    return np.stack(out).astype(np.int16), mmpp
+
+
 def skimage_otsu(arrays: dict) -> dict:
     """threshold_otsu via scikit-image 0.18.3 in the py3.9 interpreter."""
     with tempfile.TemporaryDirectory() as td:
@@ -335,6 +357,32 @@ def main():
         cen.append([c[-1], c[0], filled.sum()])
     misc["wl.centroid"] = np.array(cen)
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc)
+
+    # ------------------------------------------ 6. CatPhan slice localisation (skimage 0.18.3, py3.9)
+    slices, mmpp = catphan_slices(3, 256, seed=17)
+    from scipy import ndimage as ndi2
+
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "s.npz"), os.path.join(td, "o.npz")
+        common = dict(slices=slices, mm_per_pixel=mmpp, catphan_size=np.pi * 101**2 / mmpp**2)
+        np.savez(inp, stage="scharr", **common)
+        subprocess.run([PY39, os.path.join(HERE, "skimage_ct_py39.py"), inp, outp], check=True,
+                       stderr=subprocess.DEVNULL)
+        sch = dict(np.load(outp))
+        gauss = {f"gauss{i}": ndi2.gaussian_filter(sch[f"{i}.scharr"], 1, mode="nearest", truncate=4.0)
+                 for i in range(len(slices))}          # skimage.filters.gaussian defaults, scipy 1.15.3
+        np.savez(inp, stage="rest", **common, **gauss)
+        subprocess.run([PY39, os.path.join(HERE, "skimage_ct_py39.py"), inp, outp], check=True,
+                       stderr=subprocess.DEVNULL)
+        ctg = dict(np.load(outp))
+        ctg.update(sch)
+    for i in (1, 2):   # the float stages of one slice are enough to pin the oracle; keep the file small
+        ctg.pop(f"{i}.scharr"); ctg.pop(f"{i}.gauss")
+    ctg["slices"] = slices
+    ctg["mm_per_pixel"] = np.float64(mmpp)
+    ctg["catphan_size"] = np.float64(np.pi * 101**2 / mmpp**2)   # pylinac/ct.py:2581-2584 (radius 101 mm)
+    # float64 is kept for the two float stages; the masks/labels are small once compressed
+    np.savez_compressed(os.path.join(HERE, "catphan.npz"), **ctg)
 
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):

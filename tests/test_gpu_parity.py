@@ -656,3 +656,84 @@ def test_wl_field_centroid_vs_reference_golden(golden, dev):
     assert np.array_equal(field_centroids_batch(T(fr, dev)).cpu().numpy(), ref)
     with pytest.raises(TypeError):  # int16 ground() wraps in the reference itself: refused, not emulated
         field_centroids_batch(T((fr.astype(np.int32) - 32768).astype(np.int16), dev))
+
+
+# ------------------------------------------------------------------------- CatPhan localisation (a16)
+def test_catphan_stages_vs_skimage_golden(golden, dev):
+    from pylinac_amd import ct, ops
+
+    g = golden("catphan")
+    sl, mm = g["slices"], float(g["mm_per_pixel"])
+    t = T(sl, dev)
+    sch = ops.scharr(t)
+    assert np.array_equal(sch[0].cpu().numpy(), g["0.scharr"])
+    gs = ops.gaussian_filter_mode(sch, 1, "nearest")
+    assert np.array_equal(gs[0].cpu().numpy(), g["0.gauss"])
+    reg = ct.get_regions_batch(t, mm)
+    n = len(sl)
+    assert np.array_equal(reg["otsu"], [float(g[f"{i}.otsu"]) for i in range(n)])
+    assert np.array_equal(reg["bw"].cpu().numpy(), np.stack([g[f"{i}.filled"] for i in range(n)]))
+    assert np.array_equal(reg["labels"].cpu().numpy(), np.stack([g[f"{i}.labels"] for i in range(n)]))
+    stats = reg["stats"].cpu().numpy()
+    for i in range(n):
+        p = g[f"{i}.props"]          # area, bbox4, centroid2, filled_area, weighted_centroid2
+        k = len(p)
+        assert int(reg["num"][i]) == k
+        s = stats[i, :k]
+        assert np.array_equal(s[:, 0], p[:, 0]) and np.array_equal(s[:, 1:5], p[:, 1:5])
+        assert np.array_equal(s[:, 5] / s[:, 0], p[:, 5]) and np.array_equal(s[:, 6] / s[:, 0], p[:, 6])
+        assert np.array_equal(s[:, 0], p[:, 7])          # filled_area == area after binary_fill_holes
+        assert np.allclose(s[:, 8] / s[:, 7], p[:, 8], rtol=1e-9, atol=0)
+        assert np.allclose(s[:, 9] / s[:, 7], p[:, 9], rtol=1e-9, atol=0)
+    # intermediate masks: '>' threshold and clear_border
+    thr = torch.from_numpy(reg["otsu"] * 0.8).to(dev)
+    bw = ops.compare(reg["edges"], thr, ">")
+    assert np.array_equal(bw.cpu().numpy(), np.stack([g[f"{i}.bw"] for i in range(n)]))
+    cl = ops.clear_border(bw, min(int(max(sl.shape[1:]) / 100), 3))
+    assert np.array_equal(cl.cpu().numpy(), np.stack([g[f"{i}.cleared"] for i in range(n)]))
+
+
+def test_catphan_phantom_roi_batch(golden, dev):
+    from pylinac_amd import ct
+
+    g = golden("catphan")
+    sl, mm = g["slices"], float(g["mm_per_pixel"])
+    bad = np.concatenate([sl, np.zeros_like(sl[:1]), np.full_like(sl[:1], -1000)])
+    bad[4, 100:110, 100:110] = 500        # a small square: edges exist, but no phantom-sized ROI
+    out = ct.phantom_roi_batch(T(bad, dev), mm)
+    for i in range(len(sl)):
+        best = g[f"{i}.best"]              # label, filled_area, centroid r, c, bbox
+        assert out[i, 0] == 0 and out[i, 1] == best[0] and out[i, 2] == best[1]
+        assert np.array_equal(out[i, 3:5], best[2:4]) and np.array_equal(out[i, 5:8], best[4:7])
+        k, row = o.catphan_phantom_roi(sl[i], mm, float(g["catphan_size"]))
+        assert k == out[i, 1]
+    assert out[3, 0] == 1                  # blank slice: "No edges were found" in the reference
+    assert out[4, 0] in (2, 3)             # reference raises ValueError (no ROI of the expected size)
+    with pytest.raises(ValueError):
+        o.catphan_phantom_roi(bad[4], mm, float(g["catphan_size"]))
+
+
+def test_clip_compare_hist_uniform_vs_numpy(dev):
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(9)
+    a = rng.normal(0, 600, (3, 50, 70))
+    assert np.array_equal(ops.clip(T(a, dev), -1000, 1000).cpu().numpy(), np.clip(a, -1000, 1000))
+    ai = a.astype(np.int16)
+    assert np.array_equal(ops.clip(T(ai, dev), -1000, 1000).cpu().numpy(), np.clip(ai, -1000, 1000))
+    for op, f in ((">", np.greater), (">=", np.greater_equal), ("<", np.less), ("<=", np.less_equal)):
+        assert np.array_equal(ops.compare(T(a, dev), 100.0, op).cpu().numpy(), f(a, 100.0).astype(np.uint8))
+    b = np.abs(a) ** 1.5
+    b[1] = np.round(b[1], 0)              # many values exactly on bin edges
+    edges = np.stack([np.linspace(f.min(), f.max(), 257) for f in b])
+    got = ops.hist_uniform(T(b, dev), T(edges, dev)).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], np.histogram(b[i], bins=256)[0])
+    m = (rng.random((50, 70)) > 0.4).astype(np.uint8)
+    edges = np.stack([np.linspace(f[m.astype(bool)].min(), f[m.astype(bool)].max(), 257) for f in b])
+    got = ops.hist_uniform(T(b, dev), T(edges, dev), T(m, dev)).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], np.histogram(b[i][m.astype(bool)], bins=256)[0])
+    mn, mx = ops.minmax_masked(T(b, dev), T(m, dev))
+    assert np.array_equal(mn.cpu().numpy(), [f[m.astype(bool)].min() for f in b])
+    assert np.array_equal(mx.cpu().numpy(), [f[m.astype(bool)].max() for f in b])

@@ -249,3 +249,30 @@ def test_sobel_and_wl_centroid_match_reference_golden(golden):
     assert np.array_equal(o.sobel(g["sobel.in"], 0), g["sobel.axis0"])
     got = np.array([o.wl_field_centroid(f) for f in g["wl.in"]])
     assert np.array_equal(got, g["wl.centroid"])
+
+
+def test_catphan_localisation_matches_skimage_golden(golden):
+    """pylinac/ct.py:3315-3348 + 381-425 stage by stage against scikit-image 0.18.3 (py3.9 helper)."""
+    g = golden("catphan")
+    sl, mm, cs = g["slices"], float(g["mm_per_pixel"]), float(g["catphan_size"])
+    assert np.array_equal(o.scharr_like_skimage(sl[0]), g["0.scharr"])
+    assert np.array_equal(o.gaussian_like_skimage(g["0.scharr"], 1), g["0.gauss"])
+    for i in range(len(sl)):
+        edges, bw, lab, n = o.catphan_get_regions(sl[i], mm)
+        disk = o.disk_mask_like_skimage((sl[i].shape[0] / 2 - 0.5, sl[i].shape[1] / 2 - 0.5), 110 / mm, sl[i].shape)
+        assert np.array_equal(disk, g[f"{i}.disk"])
+        ot = o.threshold_otsu(edges[disk.astype(bool)])
+        assert ot == g[f"{i}.otsu"]
+        assert np.array_equal((edges > ot * 0.8).astype(np.uint8), g[f"{i}.bw"])
+        cl = o.clear_border_like_skimage(edges > ot * 0.8, min(int(max(edges.shape) / 100), 3))
+        assert np.array_equal(cl.astype(np.uint8), g[f"{i}.cleared"])
+        assert np.array_equal(bw.astype(np.uint8), g[f"{i}.filled"])
+        assert np.array_equal(lab, g[f"{i}.labels"])
+        tab = o.region_table(lab, n, edges)
+        assert np.array_equal(tab[:, :8], g[f"{i}.props"][:, :8])
+        assert np.allclose(tab[:, 8:], g[f"{i}.props"][:, 8:], rtol=1e-12, atol=0)
+        k, row = o.catphan_phantom_roi(sl[i], mm, cs)
+        assert k == int(g[f"{i}.best"][0]) and row[7] == g[f"{i}.best"][1]
+        assert np.array_equal(row[5:7], g[f"{i}.best"][2:4])
+    with pytest.raises(ValueError, match="No edges"):
+        o.catphan_phantom_roi(np.zeros((64, 64), np.int16), mm, cs)
