@@ -737,3 +737,46 @@ def test_clip_compare_hist_uniform_vs_numpy(dev):
     mn, mx = ops.minmax_masked(T(b, dev), T(m, dev))
     assert np.array_equal(mn.cpu().numpy(), [f[m.astype(bool)].min() for f in b])
     assert np.array_equal(mx.cpu().numpy(), [f[m.astype(bool)].max() for f in b])
+
+
+def test_ctp528_style_peak_valley_mtf(dev):
+    """pylinac/ct.py:1511-1580: collapsed circle profile -> filter(0.001,'gaussian') -> ground ->
+    per-region find_peaks / find_valleys -> Michelson MTF, device path vs the oracle composition."""
+    from pylinac_amd import mtf as pmtf
+    from pylinac_amd.profile import CollapsedCircleProfile, Point
+
+    size, cx, cy, r = 400, 200.3, 199.1, 120.0
+    y, x = np.mgrid[0:size, 0:size].astype(float)
+    ang = np.mod(np.arctan2(y - cy, x - cx), 2 * np.pi)
+    img = np.full((size, size), 100.0)
+    settings = {}
+    for k, (a0, a1, npk, lp) in enumerate([(0.05, 0.17, 2, 0.1), (0.2, 0.32, 3, 0.2), (0.35, 0.47, 4, 0.3), (0.5, 0.62, 5, 0.4)]):
+        seg = (ang >= a0 * 2 * np.pi) & (ang < a1 * 2 * np.pi)
+        phase = (ang - a0 * 2 * np.pi) / ((a1 - a0) * 2 * np.pi)
+        img[seg] = 100 + (900 - 150 * k) * (0.5 + 0.5 * np.cos(2 * np.pi * (npk + 0.0) * phase[seg] - np.pi))
+        settings[f"region {k+1}"] = {"start": a0 - 0.01, "end": a1 + 0.01, "num peaks": npk, "num valleys": npk - 1,
+                                     "peak spacing": 0.01 + 0.002 * (4 - npk), "lp/mm": lp}
+    img += np.random.default_rng(0).normal(0, 2, img.shape)
+    img = np.round(img).astype(np.int16)
+    kw = dict(start_angle=0.0, ccw=False, sampling_ratio=2, width_ratio=0.04, num_profiles=20)
+    prof = CollapsedCircleProfile(Point(x=cx, y=cy), r, img, **kw)
+    prof.filter(0.001, kind="gaussian")
+    prof.ground()
+    got = pmtf.peak_valley_mtf(prof, settings)
+    # oracle composition
+    vals = o.collapsed_circle_profile(img, (cx, cy), r, **kw)
+    vals = o.ground(o.filter(vals, 0.001, "gaussian"))
+    assert np.array_equal(np.asarray(prof.values), vals)
+    maxs, mins = [], []
+    for v in settings.values():
+        i, pv = o.multiprofile_find_peaks(vals, min_distance=v["peak spacing"], max_number=v["num peaks"],
+                                          search_region=(v["start"], v["end"]))
+        assert len(pv) == v["num peaks"]
+        maxs.append(pv.mean())
+        _, vv = o.multiprofile_find_valleys(vals, min_distance=v["peak spacing"], max_number=v["num valleys"],
+                                            search_region=(min(i), max(i)))
+        mins.append(vv.mean())
+    assert got.maximums == maxs and got.minimums == mins
+    ref = pmtf.MTF([s["lp/mm"] for s in settings.values()], maxs, mins)
+    assert got.norm_mtfs == ref.norm_mtfs and got.relative_resolution(50) == ref.relative_resolution(50)
+    assert 0.1 < got.relative_resolution(50) < 0.45
