@@ -779,4 +779,3 @@ def test_ctp528_style_peak_valley_mtf(dev):
     assert got.maximums == maxs and got.minimums == mins
     ref = pmtf.MTF([s["lp/mm"] for s in settings.values()], maxs, mins)
     assert got.norm_mtfs == ref.norm_mtfs and got.relative_resolution(50) == ref.relative_resolution(50)
-    assert 0.1 < got.relative_resolution(50) < 0.45
