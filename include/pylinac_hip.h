@@ -224,6 +224,35 @@ int pl_find_peaks(const double* d_x, int64_t n, int len, int64_t stride, const p
                   int cap, int32_t* d_count, int32_t* d_idx, int32_t* d_left_base,
                   int32_t* d_right_base, double* d_props, int32_t* d_status, void* stream);
 
+/* ragged form of pl_find_peaks: profile i has d_lens[i] <= len samples */
+int pl_find_peaks_var(const double* d_x, int64_t n, int len, const int32_t* d_lens, int64_t stride,
+                      const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,
+                      int32_t* d_left_base, int32_t* d_right_base, double* d_props, int32_t* d_status,
+                      void* stream);
+
+/* ---- BASELINE config #3: PicketFence.analyze per-image measurement, UP_DOWN pickets ------------
+ * (pylinac/picketfence.py:745-803, 847-912, 1605-1628) on uint16 frames whose float64 image would be
+ * q = (a - sub_i) / div_i (the constructor's ground()/normalize(), picketfence.py:322-323).
+ * pl_scaled_colmean: np.mean(q, 0) -> float64 [n][w] (row-sequential float64 sum, like numpy).
+ * pl_pf_pickets: from a pl_find_peaks result on the max-normalised leaf profile: FWXM picket centres
+ *   int(round(l + (r - l)/2)), their profile values, and np.median(np.diff(np.sort(idx))) per frame.
+ * pl_pf_windows: one window per (frame, leaf, picket slot): status (0 ok, 1 no such picket, 2 rejected by
+ *   _is_mlc_peak_in_window, 3 empty/too large), np.median(window, axis=0) grounded and max-normalised
+ *   into d_prof [n*nleaves*cap][lmax], its length, and max(approx_idx - spacing/2, 0).
+ *   d_leaf_top/d_leaf_bottom: int32 [nleaves] window rows (host geometry, _get_mlc_window).
+ * pl_pf_positions: position = FWXM centre (pl_fwxm_record) + offset, NaN where status != 0. */
+int pl_scaled_colmean(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                      double* d_out, void* stream);
+int pl_pf_pickets(const int32_t* d_count, const double* d_props, int cap, const double* d_prof, int w, int64_t n,
+                  int32_t* d_pk_idx, double* d_pk_val, double* d_spacing, void* stream);
+int pl_pf_windows(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                  const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap,
+                  const double* d_spacing, const int32_t* d_leaf_top, const int32_t* d_leaf_bottom, int nleaves,
+                  double height_threshold, double edge_threshold, int lmax, double* d_prof, int32_t* d_len,
+                  double* d_offset, int32_t* d_status, void* stream);
+int pl_pf_positions(const int32_t* d_status, const double* d_fwxm, const double* d_offset, int64_t m,
+                    double* d_pos, void* stream);
+
 /* FWXMProfile.field_edge_idx/center_idx/field_width_px (pylinac/core/profile.py:602-611, 322-344)
  * from a pl_find_peaks result obtained with max_number = 1:
  * d_out float64 [n][8] = n_peaks, peak_idx, height, prominence, left, right, centre, width

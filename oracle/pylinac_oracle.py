@@ -666,6 +666,83 @@ def catphan_phantom_roi(arr: np.ndarray, mm_per_pixel: float, catphan_size: floa
 
 
 # --------------------------------------------------------------------------------------
+# config #3  Picket fence per-image measurement  (pylinac/picketfence.py:67-100, 745-803, 847-912,
+#            1605-1628).  Input: the frame AFTER the constructor's crop/ground/normalize (float64).
+# --------------------------------------------------------------------------------------
+
+MLC_ARRANGEMENTS = {  # picketfence.py:103-135
+    "MILLENNIUM": [(10, 10), (40, 5), (10, 10)],
+    "HD_MILLENNIUM": [(14, 5), (32, 2.5), (14, 5)],
+    "BMOD": [(40, 4)],
+    "AGILITY": [(80, 5)],
+    "MLCI": [(40, 10)],
+    "HALCYON_DISTAL": [(28, 10)],
+    "HALCYON_PROXIMAL": [(29, 10)],
+}
+
+
+def mlc_arrangement(leaf_arrangement, offset: float = 0):
+    """MLCArrangement.__init__/leaves, picketfence.py:67-100 -> (leaf numbers, centers mm, widths mm)."""
+    centers, widths = [], []
+    rolling_edge = 0
+    for leaf_num, width in leaf_arrangement:
+        centers += np.arange(start=rolling_edge + width / 2, stop=leaf_num * width + rolling_edge + width / 2,
+                             step=width).tolist()
+        rolling_edge = centers[-1] + width / 2
+        widths += [width] * leaf_num
+    mean = np.mean(centers)
+    centers = [c - mean + offset for c in centers]
+    leaves = np.arange(1, len(centers) + 1, dtype=int)[::-1].tolist()
+    return leaves, centers, widths
+
+
+def pf_leaves_in_view(shape, dpmm, leaves, centers, widths, analysis_width=0.4):
+    """PicketFence._leaves_in_view (UP_DOWN), picketfence.py:888-912."""
+    pixel_range = shape[0] / 2
+    pixel_range -= max(widths[0] * analysis_width, widths[-1] * analysis_width) * dpmm
+    return [(n, c, w) for n, c, w in zip(leaves, centers, widths) if abs(c) < pixel_range / dpmm]
+
+
+def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=None, leaf_analysis_width_ratio=0.4,
+               picket_spacing=None, height_threshold=0.5, edge_threshold=1.5, peak_sort="peak_heights",
+               required_prominence=0.2, fwxm=50):
+    """The per-image measurement loop of PicketFence.analyze for UP_DOWN pickets
+    (picketfence.py:745-803): returns dict(peak_idxs, peak_vals, spacing, leaves [(num, center, width)],
+    position [n_leaves, P] float64 (NaN where the window failed _is_mlc_peak_in_window))."""
+    leaf_prof = np.mean(image, 0)                                        # :747
+    leaf_prof = normalize(leaf_prof)                                     # MultiProfile.normalize :752
+    peak_idxs, peak_vals = multiprofile_find_fwxm_peaks(                 # :753-759
+        leaf_prof, min_distance=0.02, threshold=height_threshold, max_number=num_pickets,
+        peak_sort=peak_sort, required_prominence=required_prominence)
+    if len(peak_idxs) == 0:
+        raise ValueError("No pickets were found.")
+    if picket_spacing is None:
+        picket_spacing = np.median(np.diff(np.sort(peak_idxs)))          # :766-767
+    leaves, centers, widths = mlc_arrangement(MLC_ARRANGEMENTS[mlc])
+    in_view = pf_leaves_in_view(image.shape, dpmm, leaves, centers, widths, leaf_analysis_width_ratio)
+    pos = np.full((len(in_view), len(peak_idxs)), np.nan)
+    for li, (leaf_num, center, width) in enumerate(in_view):
+        leaf_width_px = width * dpmm                                     # _get_mlc_window :859-886
+        leaf_center_px = center * dpmm + image.shape[0] / 2
+        top = max(int(leaf_center_px - leaf_width_px / 2), 0)
+        bottom = min(int(leaf_center_px + leaf_width_px / 2), image.shape[0])
+        for pi, (approx_idx, peak_val) in enumerate(zip(peak_idxs, peak_vals)):
+            left = max(int(approx_idx - picket_spacing / 2), 0)
+            right = min(int(approx_idx + picket_spacing / 2), image.shape[1])
+            window = image[top:bottom, left:right]
+            std = np.std(window, axis=1)                                 # _is_mlc_peak_in_window :847-857
+            if not (np.max(window) > height_threshold * peak_val and max(std) < edge_threshold * np.median(std)):
+                continue
+            pix_vals = np.median(window, axis=0)                         # MLCValue.get_peak_positions :1605-1628
+            vals = ground(pix_vals)                                      # FWXMProfilePhysical(ground=True,
+            vals = normalize(vals)                                       #   normalization=MAX)
+            _, _, centre, _ = fwxm_edges(vals, fwxm)
+            pos[li, pi] = centre + max(approx_idx - picket_spacing / 2, 0)
+    return dict(peak_idxs=np.asarray(peak_idxs), peak_vals=np.asarray(peak_vals), spacing=float(picket_spacing),
+                leaves=in_view, position=pos)
+
+
+# --------------------------------------------------------------------------------------
 # BASELINE config #2 + profile/peak: the pipeline bench.py measures
 # --------------------------------------------------------------------------------------
 

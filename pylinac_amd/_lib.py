@@ -82,6 +82,15 @@ SIGNATURES = {
     "pl_clear_border": ([_p, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_region_stats": ([_p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p], C.c_int),
     "pl_colsum_to_mean": ([_p, _l, _i, _i, _p, _p], C.c_int),
+    "pl_find_peaks_var": (
+        [_p, _l, _i, _p, _l, C.POINTER(PeakParams), _i, _p, _p, _p, _p, _p, _p, _p],
+        C.c_int,
+    ),
+    "pl_scaled_colmean": ([_p, _l, _i, _i, _p, _p, _p, _p], C.c_int),
+    "pl_pf_pickets": ([_p, _p, _i, _p, _i, _l, _p, _p, _p, _p], C.c_int),
+    "pl_pf_windows": ([_p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _d, _d, _i, _p, _p, _p, _p, _p],
+                      C.c_int),
+    "pl_pf_positions": ([_p, _p, _p, _l, _p, _p], C.c_int),
     "pl_fwxm_record": ([_p, _p, _p, _i, _l, _p, _p], C.c_int),
     "pl_find_peaks": (
         [_p, _l, _i, _l, C.POINTER(PeakParams), _i, _p, _p, _p, _p, _p, _p, _p],

@@ -130,8 +130,8 @@ __device__ __forceinline__ void prominence_side(const double* xs, int pk, int m,
 // between an LDS and a global pointer degrades every access to a slow FLAT load).
 template <bool STAGE>
 __global__ void __launch_bounds__(kThreads)
-find_peaks_kernel(const double* __restrict__ x, int len, int64_t stride, pl_peak_params prm, int cap,
-                  int maxc, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
+find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __restrict__ lens, int64_t stride,
+                  pl_peak_params prm, int cap, int maxc, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
                   int32_t* __restrict__ d_lb, int32_t* __restrict__ d_rb, double* __restrict__ d_props,
                   int32_t* __restrict__ d_status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -140,6 +140,7 @@ find_peaks_kernel(const double* __restrict__ x, int len, int64_t stride, pl_peak
   __shared__ int s_cnt;
 
   const int64_t prof = blockIdx.x;
+  const int len = lens ? lens[prof] : len_all;   // ragged batches: per-profile length
   const double* xfull = x + prof * stride;
   int lo = prm.region_lo < 0 ? 0 : prm.region_lo;
   int hi = prm.region_hi > len ? len : prm.region_hi;
@@ -155,6 +156,10 @@ find_peaks_kernel(const double* __restrict__ x, int len, int64_t stride, pl_peak
   int* s_keep = s_rb + maxc;
   double* s_x = reinterpret_cast<double*>(s_keep + maxc + (maxc & 1));
 
+  if (len <= 0) {   // empty profile (e.g. a window that was rejected upstream)
+    if (threadIdx.x == 0) { d_count[prof] = 0; d_status[prof] = 0; }
+    return;
+  }
   // ---- A: height threshold -------------------------------------------------------------------
   double height = prm.threshold;
   if (prm.threshold_is_ratio) {
@@ -377,10 +382,25 @@ extern "C" int pl_fwxm_record(const int32_t* d_count, const int32_t* d_idx, cons
   return pl_check_launch("pl_fwxm_record");
 }
 
+extern "C" int pl_find_peaks_var(const double* d_x, int64_t n, int len, const int32_t* d_lens, int64_t stride,
+                                 const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,
+                                 int32_t* d_left_base, int32_t* d_right_base, double* d_props,
+                                 int32_t* d_status, void* stream);
+
 extern "C" int pl_find_peaks(const double* d_x, int64_t n, int len, int64_t stride,
                              const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,
                              int32_t* d_left_base, int32_t* d_right_base, double* d_props,
                              int32_t* d_status, void* stream) {
+  return pl_find_peaks_var(d_x, n, len, nullptr, stride, params, cap, d_count, d_idx, d_left_base, d_right_base,
+                           d_props, d_status, stream);
+}
+
+// ragged form: profile i has d_lens[i] <= len samples (row stride `stride`); the search region of
+// `params` is clipped to each profile's own length
+extern "C" int pl_find_peaks_var(const double* d_x, int64_t n, int len, const int32_t* d_lens, int64_t stride,
+                                 const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,
+                                 int32_t* d_left_base, int32_t* d_right_base, double* d_props,
+                                 int32_t* d_status, void* stream) {
   PL_REQUIRE(d_x && params && d_count && d_idx && d_left_base && d_right_base && d_props && d_status,
              "null pointer");
   PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && len > 0 && stride >= len && cap > 0, "bad shape");
@@ -405,11 +425,11 @@ extern "C" int pl_find_peaks(const double* d_x, int64_t n, int len, int64_t stri
   }
   if (stage_x)
     hipLaunchKernelGGL(find_peaks_kernel<true>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
-                       len, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base, d_props,
+                       len, d_lens, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base, d_props,
                        d_status);
   else
     hipLaunchKernelGGL(find_peaks_kernel<false>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
-                       len, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base, d_props,
+                       len, d_lens, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base, d_props,
                        d_status);
   return pl_check_launch("pl_find_peaks");
 }

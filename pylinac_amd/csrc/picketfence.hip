@@ -1,0 +1,268 @@
+// Picket-fence per-image measurement (BASELINE config #3).
+//
+// Replaces the numpy/scipy work inside PicketFence.analyze for UP_DOWN pickets
+// (pylinac/picketfence.py:745-803) on frames that went through the constructor's
+// ground()/normalize() (picketfence.py:322-323) -- WITHOUT materialising the float64 frame: every
+// pixel value is the float64 quotient q = (a - sub_i) / div_i of the integer frame, evaluated
+// wherever the reference would read the normalised image, so all results stay bit-identical.
+//
+//   pl_scaled_colmean   np.mean(image, 0)                         picketfence.py:747
+//   pl_pf_pickets       FWXM picket centres int(round(l + (r-l)/2)), their heights, and the
+//                       picket spacing np.median(np.diff(np.sort(idx)))   profile.py:2165-2170,
+//                                                                          picketfence.py:766-767
+//   pl_pf_windows       per (frame, leaf, picket): the window of _get_mlc_window (:859-886), the
+//                       _is_mlc_peak_in_window test (:847-857: np.std(axis=1) with numpy's pairwise
+//                       summation, np.max, np.median), np.median(window, axis=0), then
+//                       ground + normalize-to-max of that profile (FWXMProfilePhysical(ground=True,
+//                       normalization=MAX), :1609-1614)
+//   pl_pf_positions     centre + max(approx_idx - spacing/2, 0)    picketfence.py:1624-1627
+// One wave per window; the window's integer pixels are staged in LDS once.
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxRows = 48;    // window rows  (leaf width in pixels)
+constexpr int kMaxCols = 128;   // window cols  (picket spacing in pixels); numpy pairwise-sum single block
+
+__global__ void __launch_bounds__(kThreads)
+scaled_colmean_kernel(const unsigned short* __restrict__ in, int h, int w, int col_tiles,
+                      const double* __restrict__ sub, const double* __restrict__ div, double* __restrict__ out) {
+  const int ct = blockIdx.x % col_tiles;
+  const size_t frame = blockIdx.x / col_tiles;
+  const int c = ct * kThreads + threadIdx.x;
+  if (c >= w) return;
+  const unsigned short* p = in + frame * (size_t)h * w + c;
+  const double s = sub[frame], d = div[frame];
+  double acc = 0.0;
+  for (int r = 0; r < h; ++r) acc = acc + ((double)p[(size_t)r * w] - s) / d;   // numpy adds row by row
+  out[frame * w + c] = acc / (double)h;
+}
+
+__global__ void pf_pickets_kernel(const int32_t* __restrict__ count, const double* __restrict__ props, int cap,
+                                  const double* __restrict__ prof, int w, int64_t n,
+                                  int32_t* __restrict__ pk_idx, double* __restrict__ pk_val,
+                                  double* __restrict__ spacing) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = count[i];
+  const double* p = props + i * 6 * (int64_t)cap;
+  int* idx = pk_idx + i * cap;
+  double* val = pk_val + i * cap;
+  for (int k = 0; k < c; ++k) {
+    const double lt = p[4 * cap + k], rt = p[5 * cap + k];
+    const int id = (int)rint(lt + (rt - lt) / 2);      // python round(): half to even
+    idx[k] = id;
+    val[k] = (id >= 0 && id < w) ? prof[i * w + id] : __longlong_as_double(0x7ff8000000000000LL);
+  }
+  // np.median(np.diff(np.sort(idx))) on a private sorted copy (cap is small)
+  double sp = __longlong_as_double(0x7ff8000000000000LL);
+  if (c >= 2 && c <= 64) {
+    int s[64];
+    for (int k = 0; k < c; ++k) s[k] = idx[k];
+    for (int a = 1; a < c; ++a) { int v = s[a], b = a - 1; while (b >= 0 && s[b] > v) { s[b + 1] = s[b]; --b; } s[b + 1] = v; }
+    int d[64];
+    for (int k = 0; k + 1 < c; ++k) d[k] = s[k + 1] - s[k];
+    const int m = c - 1;
+    for (int a = 1; a < m; ++a) { int v = d[a], b = a - 1; while (b >= 0 && d[b] > v) { d[b + 1] = d[b]; --b; } d[b + 1] = v; }
+    sp = (m & 1) ? (double)d[m / 2] : ((double)d[m / 2 - 1] + (double)d[m / 2]) / 2.0;
+  }
+  spacing[i] = sp;
+}
+
+// numpy's pairwise_sum for one contiguous block of n <= 128 float64 values (numpy/_core/src/umath/
+// loops_utils.h.src): n < 8 plain loop, otherwise 8 running partial sums combined as a tree.
+template <typename F>
+__device__ __forceinline__ double pairwise_sum_block(int n, F at) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res = res + at(i);
+    return res;
+  }
+  double r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = at(j);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = r[j] + at(i + j);
+  }
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res = res + at(i);
+  return res;
+}
+
+__global__ void __launch_bounds__(kThreads)
+pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const double* __restrict__ sub,
+                  const double* __restrict__ div, const int32_t* __restrict__ pk_count,
+                  const int32_t* __restrict__ pk_idx, const double* __restrict__ pk_val, int cap,
+                  const double* __restrict__ spacing, const int32_t* __restrict__ leaf_top,
+                  const int32_t* __restrict__ leaf_bottom, int nleaves, double height_threshold,
+                  double edge_threshold, int lmax, double* __restrict__ prof_out, int32_t* __restrict__ len_out,
+                  double* __restrict__ offset_out, int32_t* __restrict__ status_out, int64_t total_windows) {
+  __shared__ unsigned short s_win[kThreads / PL_WAVE][kMaxRows * kMaxCols];
+  __shared__ double s_std[kThreads / PL_WAVE][kMaxRows];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t win = (int64_t)blockIdx.x * (kThreads / PL_WAVE) + wv;
+  if (win >= total_windows) return;
+  const int pi = (int)(win % cap);
+  const int li = (int)((win / cap) % nleaves);
+  const int64_t frame = win / ((int64_t)cap * nleaves);
+  int status = 0;   // 0 valid, 1 no such picket, 2 failed _is_mlc_peak_in_window, 3 window too large / empty
+  double* pout = prof_out + win * lmax;
+  if (pi >= pk_count[frame]) {
+    if (lane == 0) { status_out[win] = 1; len_out[win] = 0; offset_out[win] = 0.0; }
+    return;
+  }
+  const double approx = (double)pk_idx[frame * cap + pi];
+  const double sp = spacing[frame];
+  const int top = leaf_top[li], bottom = leaf_bottom[li];
+  int left = (int)(approx - sp / 2);            // python int(): truncation toward zero
+  if (left < 0) left = 0;
+  int right = (int)(approx + sp / 2);
+  if (right > w) right = w;
+  const int nrows = bottom - top, ncols = right - left;
+  const double off = (approx - sp / 2 > 0.0) ? (approx - sp / 2) : 0.0;   // max(approx_idx - spacing/2, 0)
+  if (nrows <= 0 || ncols <= 2 || nrows > kMaxRows || ncols > kMaxCols || !(sp == sp)) {
+    if (lane == 0) { status_out[win] = 3; len_out[win] = 0; offset_out[win] = off; }
+    return;
+  }
+  const unsigned short* f = in + frame * (size_t)h * w;
+  unsigned short* sw = s_win[wv];
+  for (int e = lane; e < nrows * ncols; e += PL_WAVE) {
+    const int r = e / ncols, c = e % ncols;
+    sw[r * ncols + c] = f[(size_t)(top + r) * w + left + c];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const double s = sub[frame], d = div[frame];
+  auto q = [&](int r, int c) { return ((double)sw[r * ncols + c] - s) / d; };
+
+  // np.max(window) > height_threshold * picket_peak_val   (q is monotone in the integer pixel)
+  int vmax = 0;
+  for (int e = lane; e < nrows * ncols; e += PL_WAVE) vmax = max(vmax, (int)sw[e]);
+  vmax = pl_wave_reduce(vmax, [](int a, int b) { return a > b ? a : b; });
+  const bool above = (((double)vmax - s) / d) > height_threshold * pk_val[frame * cap + pi];
+
+  // np.std(window, axis=1): lane r handles row r serially with numpy's summation order
+  for (int r = lane; r < nrows; r += PL_WAVE) {
+    const double mean = pairwise_sum_block(ncols, [&](int c) { return q(r, c); }) / (double)ncols;
+    const double ss = pairwise_sum_block(ncols, [&](int c) { const double x = q(r, c) - mean; return x * x; });
+    s_std[wv][r] = sqrt(ss / (double)ncols);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  // max(std) < edge_threshold * np.median(std): evaluated redundantly by every lane (nrows <= 64)
+  double smax = s_std[wv][0];
+  for (int r = 1; r < nrows; ++r) smax = s_std[wv][r] > smax ? s_std[wv][r] : smax;
+  double med;
+  {
+    // rank selection without a private array: the k-th smallest is the element with exactly k
+    // smaller-or-(equal and earlier) elements
+    const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
+    double v_lo = 0.0, v_hi = 0.0;
+    for (int a = 0; a < nrows; ++a) {
+      const double va = s_std[wv][a];
+      int rank = 0;
+      for (int b = 0; b < nrows; ++b) {
+        const double vb = s_std[wv][b];
+        rank += (vb < va || (vb == va && b < a)) ? 1 : 0;
+      }
+      if (rank == k_lo) v_lo = va;
+      if (rank == k_hi) v_hi = va;
+    }
+    med = (nrows & 1) ? v_hi : (v_lo + v_hi) / 2.0;
+  }
+  const bool not_edge = smax < edge_threshold * med;
+  if (!(above && not_edge)) status = 2;
+
+  // np.median(window, axis=0): lane c (and c+64) selects the middle order statistic(s) of its column
+  double* pv = pout;
+  for (int c = lane; c < ncols; c += PL_WAVE) {
+    const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
+    int v_lo = 0, v_hi = 0;
+    for (int a = 0; a < nrows; ++a) {
+      const int va = sw[a * ncols + c];
+      int rank = 0;
+      for (int b = 0; b < nrows; ++b) {
+        const int vb = sw[b * ncols + c];
+        rank += (vb < va || (vb == va && b < a)) ? 1 : 0;
+      }
+      if (rank == k_lo) v_lo = va;
+      if (rank == k_hi) v_hi = va;
+    }
+    const double qh = ((double)v_hi - s) / d;
+    pv[c] = (nrows & 1) ? qh : ((((double)v_lo - s) / d) + qh) / 2.0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  // ground (values - min) then normalize (/ max of the grounded profile)
+  double mn = __longlong_as_double(0x7ff0000000000000LL);
+  for (int c = lane; c < ncols; c += PL_WAVE) mn = pv[c] < mn ? pv[c] : mn;
+  mn = pl_wave_reduce(mn, [](double a, double b) { return a < b ? a : b; });
+  double mx = __longlong_as_double((long long)0xfff0000000000000ULL);
+  for (int c = lane; c < ncols; c += PL_WAVE) { const double g = pv[c] - mn; mx = g > mx ? g : mx; }
+  mx = pl_wave_reduce(mx, [](double a, double b) { return a > b ? a : b; });
+  for (int c = lane; c < ncols; c += PL_WAVE) pv[c] = (pv[c] - mn) / mx;
+  if (lane == 0) { status_out[win] = status; len_out[win] = ncols; offset_out[win] = off; }
+}
+
+__global__ void pf_positions_kernel(const int32_t* __restrict__ status, const double* __restrict__ fwxm /*[M][8]*/,
+                                    const double* __restrict__ offset, int64_t m, double* __restrict__ pos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  pos[i] = (status[i] == 0 && fwxm[i * 8] > 0.0) ? fwxm[i * 8 + 6] + offset[i] : nan;
+}
+
+}  // namespace
+
+extern "C" int pl_scaled_colmean(const uint16_t* in, int64_t n, int h, int w, const double* d_sub,
+                                 const double* d_div, double* d_out, void* stream) {
+  PL_REQUIRE(in && d_sub && d_div && d_out, "null pointer");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");
+  if (n == 0) return PL_OK;
+  const int col_tiles = (int)pl_cdiv(w, kThreads);
+  PL_REQUIRE(n * col_tiles <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(scaled_colmean_kernel, dim3((unsigned)(n * col_tiles)), dim3(kThreads), 0, (hipStream_t)stream,
+                     in, h, w, col_tiles, d_sub, d_div, d_out);
+  return pl_check_launch("pl_scaled_colmean");
+}
+
+extern "C" int pl_pf_pickets(const int32_t* d_count, const double* d_props, int cap, const double* d_prof, int w,
+                             int64_t n, int32_t* d_pk_idx, double* d_pk_val, double* d_spacing, void* stream) {
+  PL_REQUIRE(d_count && d_props && d_prof && d_pk_idx && d_pk_val && d_spacing, "null pointer");
+  PL_REQUIRE(n >= 0 && cap > 0 && cap <= 64 && w > 0, "bad shape (cap <= 64)");
+  if (n == 0) return PL_OK;
+  hipLaunchKernelGGL(pf_pickets_kernel, dim3((unsigned)pl_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, d_count,
+                     d_props, cap, d_prof, w, n, d_pk_idx, d_pk_val, d_spacing);
+  return pl_check_launch("pl_pf_pickets");
+}
+
+extern "C" int pl_pf_windows(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                             const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap,
+                             const double* d_spacing, const int32_t* d_leaf_top, const int32_t* d_leaf_bottom,
+                             int nleaves, double height_threshold, double edge_threshold, int lmax,
+                             double* d_prof, int32_t* d_len, double* d_offset, int32_t* d_status, void* stream) {
+  PL_REQUIRE(in && d_sub && d_div && d_pk_count && d_pk_idx && d_pk_val && d_spacing && d_leaf_top && d_leaf_bottom &&
+                 d_prof && d_len && d_offset && d_status, "null pointer");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0 && cap > 0 && nleaves > 0 && lmax >= kMaxCols, "bad shape (lmax >= 128)");
+  if (n == 0) return PL_OK;
+  const int64_t total = n * (int64_t)nleaves * cap;
+  const int64_t blocks = pl_cdiv(total, kThreads / PL_WAVE);
+  PL_REQUIRE(blocks <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(pf_windows_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, in, h, w,
+                     d_sub, d_div, d_pk_count, d_pk_idx, d_pk_val, cap, d_spacing, d_leaf_top, d_leaf_bottom, nleaves,
+                     height_threshold, edge_threshold, lmax, d_prof, d_len, d_offset, d_status, total);
+  return pl_check_launch("pl_pf_windows");
+}
+
+extern "C" int pl_pf_positions(const int32_t* d_status, const double* d_fwxm, const double* d_offset, int64_t m,
+                               double* d_pos, void* stream) {
+  PL_REQUIRE(d_status && d_fwxm && d_offset && d_pos, "null pointer");
+  PL_REQUIRE(m >= 0, "bad shape");
+  if (m == 0) return PL_OK;
+  hipLaunchKernelGGL(pf_positions_kernel, dim3((unsigned)pl_cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, d_status,
+                     d_fwxm, d_offset, m, d_pos);
+  return pl_check_launch("pl_pf_positions");
+}

@@ -384,8 +384,10 @@ def make_peak_params(length: int, threshold=-np.inf, peak_separation=0, max_numb
     return p
 
 
-def find_peaks_batch(profiles: torch.Tensor, cap: int | None = None, **kwargs) -> PeakBatch:
-    """``pylinac.core.profile.find_peaks`` for every row of ``profiles`` [N, L] (float64)."""
+def find_peaks_batch(profiles: torch.Tensor, cap: int | None = None, lens: torch.Tensor | None = None,
+                     **kwargs) -> PeakBatch:
+    """``pylinac.core.profile.find_peaks`` for every row of ``profiles`` [N, L] (float64).
+    ``lens`` (int32 [N]) makes the batch ragged: row i holds ``lens[i] <= L`` samples."""
     x = profiles
     if x.dim() == 1:
         x = x.unsqueeze(0)
@@ -411,11 +413,11 @@ def find_peaks_batch(profiles: torch.Tensor, cap: int | None = None, **kwargs) -
         status=torch.empty(n, dtype=torch.int32, device=dev),
     )
     check(
-        _lib.load().pl_find_peaks(x.data_ptr(), n, length, x.stride(0), C.byref(prm), cap,
-                                  res.count.data_ptr(), res.idx.data_ptr(), res.left_bases.data_ptr(),
-                                  res.right_bases.data_ptr(), res.props.data_ptr(), res.status.data_ptr(),
-                                  _stream()),
-        "pl_find_peaks",
+        _lib.load().pl_find_peaks_var(x.data_ptr(), n, length, 0 if lens is None else lens.data_ptr(), x.stride(0),
+                                      C.byref(prm), cap, res.count.data_ptr(), res.idx.data_ptr(),
+                                      res.left_bases.data_ptr(), res.right_bases.data_ptr(), res.props.data_ptr(),
+                                      res.status.data_ptr(), _stream()),
+        "pl_find_peaks_var",
     )
     return res
 

@@ -106,6 +106,23 @@ def catphan_slices(n, size, seed):
     return np.stack(out).astype(np.int16), mmpp
 
 
+def pf_frame(h, w, pixel, seed, n_pickets=10, spacing_mm=15.0, gap_mm=2.0):
+    """Synthetic UP_DOWN picket fence (config #3 restated): Gaussian pickets with N(0, 0.2 mm) offsets,
+    one closed leaf pair region (jaw-blocked rows) and noise."""
+    from scipy import ndimage as ndi
+
+    rng = np.random.default_rng(seed)
+    x = (np.arange(w) - (w - 1) / 2) * pixel
+    centers = (np.arange(n_pickets) - (n_pickets - 1) / 2) * spacing_mm + rng.normal(0, 0.2, n_pickets)
+    prof = np.zeros(w)
+    for c in centers:
+        prof += np.exp(-0.5 * ((x - c) / (gap_mm / 2.355 * 1.6)) ** 2)
+    img = 1000.0 + 30000.0 * np.repeat(prof[None, :], h, axis=0)
+    img[: int(h * 0.06), :] = 1000.0                       # rows hidden by a jaw: windows there must be rejected
+    img = ndi.gaussian_filter(img, 1.0) + rng.normal(0, 60, (h, w))
+    return np.clip(np.round(img), 0, 65535).astype(np.uint16)
+
+
 def skimage_otsu(arrays: dict) -> dict:
     """threshold_otsu via scikit-image 0.18.3 in the py3.9 interpreter."""
     with tempfile.TemporaryDirectory() as td:
@@ -383,6 +400,34 @@ def main():
     ctg["catphan_size"] = np.float64(np.pi * 101**2 / mmpp**2)   # pylinac/ct.py:2581-2584 (radius 101 mm)
     # float64 is kept for the two float stages; the masks/labels are small once compressed
     np.savez_compressed(os.path.join(HERE, "catphan.npz"), **ctg)
+
+    # ----------------------------- 7. picket fence: the reference's REAL PicketFence.analyze() (config #3)
+    pfm = ref_loader.ref("picketfence")
+
+    class PFImg(image.ArrayImage):          # what PFDicomImage adds to the array image (picketfence.py:204-260)
+        _central_axis = None
+
+        def adjust_for_sag(self, sag, orientation):
+            pass
+
+    pfg = {}
+    for k, (hh, ww, pixel, seed) in enumerate([(400, 520, 0.78125, 2000), (384, 512, 0.8, 2001)]):
+        raw = pf_frame(hh, ww, pixel, seed)
+        dpmm = 1 / pixel
+        im = PFImg(raw.copy(), dpi=dpmm * 25.4, sid=1000)
+        im.crop(pixels=int(round(3 * im.dpmm)))             # picketfence.py:214-215
+        cropped = np.ascontiguousarray(im.array)
+        im.ground()
+        im.normalize()                                       # picketfence.py:322-323
+        pf = pfm.PicketFence(None)                           # skips image loading (picketfence.py:315)
+        pf.image = im
+        pf.analyze(orientation="Up-Down")
+        pfg[f"{k}.cropped"] = cropped
+        pfg[f"{k}.dpmm"] = np.float64(im.dpmm)
+        pfg[f"{k}.meas"] = np.array([[m.leaf_num, m.picket_num, m.position[0], m._approximate_idx] for m in pf.mlc_meas])
+        pfg[f"{k}.spacing"] = np.float64(pf.mlc_meas[0]._spacing)
+        pfg[f"{k}.max_error"] = np.float64(pf.max_error)
+    np.savez_compressed(os.path.join(HERE, "picketfence.npz"), **pfg)
 
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):

@@ -779,3 +779,43 @@ def test_ctp528_style_peak_valley_mtf(dev):
     assert got.maximums == maxs and got.minimums == mins
     ref = pmtf.MTF([s["lp/mm"] for s in settings.values()], maxs, mins)
     assert got.norm_mtfs == ref.norm_mtfs and got.relative_resolution(50) == ref.relative_resolution(50)
+
+
+# --------------------------------------------------------------- picket fence (BASELINE config #3)
+def test_picket_fence_batch_vs_reference_analyze(golden, dev):
+    """Device pipeline against the reference's real PicketFence.analyze() output (golden) and against
+    the oracle for the windows the reference later drops."""
+    from pylinac_amd import picketfence as ppf
+
+    g = golden("picketfence")
+    for k in (0, 1):
+        raw, dpmm = g[f"{k}.cropped"], float(g[f"{k}.dpmm"])
+        res = ppf.analyze_batch(T(raw[None], dev), dpmm)
+        ref = o.pf_measure(o.normalize(o.ground(raw)), dpmm)
+        P = len(ref["peak_idxs"])
+        assert int(res.picket_count[0]) == P
+        assert np.array_equal(res.picket_idx[0, :P].cpu().numpy(), ref["peak_idxs"])
+        assert float(res.spacing[0]) == ref["spacing"] == float(g[f"{k}.spacing"])
+        assert res.leaf_nums == [n for n, _, _ in ref["leaves"]]
+        pos = res.position[0, :, :P].cpu().numpy()
+        assert np.array_equal(np.isnan(pos), np.isnan(ref["position"]))
+        assert np.array_equal(pos[~np.isnan(pos)], ref["position"][~np.isnan(pos)])
+        idx = {n: i for i, n in enumerate(res.leaf_nums)}
+        for leaf, picket, p, _ in g[f"{k}.meas"]:          # what the reference itself measured
+            assert pos[idx[int(leaf)], int(picket)] == p
+        st = res.status[0].cpu().numpy()
+        assert (st[:, P:] == 1).all() and set(np.unique(st[:, :P])) <= {0, 2}
+
+
+def test_picket_fence_batch_of_frames(dev):
+    from pylinac_amd import picketfence as ppf
+    from tests.golden.make_golden import pf_frame
+
+    frames = np.stack([pf_frame(300, 520, 0.78125, 2100 + i)[4:-4, 4:-4] for i in range(5)])
+    res = ppf.analyze_batch(T(np.ascontiguousarray(frames), dev), 1 / 0.78125)
+    for i, f in enumerate(frames):
+        ref = o.pf_measure(o.normalize(o.ground(f)), 1 / 0.78125)
+        P = len(ref["peak_idxs"])
+        pos = res.position[i, :, :P].cpu().numpy()
+        assert np.array_equal(np.isnan(pos), np.isnan(ref["position"]))
+        assert np.array_equal(pos[~np.isnan(pos)], ref["position"][~np.isnan(pos)])

@@ -276,3 +276,21 @@ def test_catphan_localisation_matches_skimage_golden(golden):
         assert np.array_equal(row[5:7], g[f"{i}.best"][2:4])
     with pytest.raises(ValueError, match="No edges"):
         o.catphan_phantom_roi(np.zeros((64, 64), np.int16), mm, cs)
+
+
+def test_picket_fence_measurement_matches_reference_analyze(golden):
+    """oracle.pf_measure against the reference's REAL PicketFence.analyze() (driven on a synthetic
+    frame through the stub loader, tests/golden/make_golden.py section 7): every MLC position the
+    reference kept is reproduced bit-for-bit; the spacing too."""
+    g = golden("picketfence")
+    for k in (0, 1):
+        raw, dpmm = g[f"{k}.cropped"], float(g[f"{k}.dpmm"])
+        r = o.pf_measure(o.normalize(o.ground(raw)), dpmm)
+        assert r["spacing"] == float(g[f"{k}.spacing"])
+        idx = {n: i for i, (n, c, w) in enumerate(r["leaves"])}
+        meas = g[f"{k}.meas"]
+        assert len(meas) > 400
+        for leaf, picket, pos, approx in meas:
+            assert r["position"][idx[int(leaf)], int(picket)] == pos
+            assert r["peak_idxs"][int(picket)] == approx
+        assert np.isnan(r["position"]).sum() > 0     # the jaw-blocked rows were rejected
