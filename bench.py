@@ -74,7 +74,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # PL_BENCH_FORCE_DIST=1 exercises the RCCL init / all-gather / barrier path with a single rank too
+    if world > 1 or os.environ.get("PL_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist  # noqa: F811
 
         dist.init_process_group(backend="nccl", device_id=dev)
@@ -93,7 +94,7 @@ def main():
     def step(events=None):
         res = pipe.run(frames, events)
         rec = res.record()
-        return pdist.all_gather_records(rec, n * world) if world > 1 else rec
+        return pdist.all_gather_records(rec, n * world) if dist is not None else rec
 
     for _ in range(args.warmup):
         step()
@@ -159,8 +160,9 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "note": "dominant kernel reads+writes one u16 frame (4 MiB/frame algorithmic); it is "
-                        "FP64-issue-bound (61 f64 ops/px/pass at sigma=5), see DESIGN.md",
+                "note": "dominant kernel reads+writes one u16 frame (4 MiB/frame algorithmic; PMC traffic "
+                        "matches); it is VALU/FP64-issue-bound, not HBM-bound: scipy-exact float64 "
+                        "accumulation, ~61 VALU instr/px/pass at sigma=5 (DESIGN.md section 5)",
                 "pipeline_frac": round(value / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             },

@@ -24,7 +24,7 @@ def all_gather_records(local: torch.Tensor, n_total: int | None = None) -> torch
     """Gather per-image records ``[n_local, K]`` from every rank into ``[n_total, K]`` (rank
     order == frame order for ``shard_range`` shards).  Uneven shards are padded to the largest
     shard for the single ``all_gather_into_tensor`` and trimmed afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size()
     k = local.shape[1:]
