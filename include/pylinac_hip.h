@@ -198,6 +198,22 @@ int pl_region_stats(const int32_t* d_labels, const double* d_intensity, int64_t 
                     int max_labels, unsigned long long* d_isum, double* d_wsum, double* d_stats,
                     int32_t* d_overflow, void* stream);
 
+/* ---- a13: one threshold level of find_features (pylinac/metrics/utils.py:128-180 + features.py) ---
+ * Inputs per window i: d_sample float64 [n][h][w] (the stretched sample), the 4-connected label image of
+ * `sample > cutoff` (pl_label), its label count and its region table (pl_region_stats, max_labels rows).
+ * Every region that does not touch the frame and passes is_right_size_bb / is_round /
+ * is_right_circumference / is_symmetric / is_solid appends its weighted centroid (x, y) to
+ * d_xy float64 [n][8][2] unless it lies within min_sep_px of a point found at an EARLIER level;
+ * d_count int32[n] (zeroed by the caller before level 0), d_prev_count int32[n] scratch,
+ * d_level int32[n] (initialised to -1: first level with a hit), d_done int32[n] (zeroed; set once
+ * d_count >= max_number, later calls skip the window), d_status int32[n] (0 ok; 1 label table
+ * overflow, 2 > 32 candidate regions, 3 region bbox > 160 px, 4 > 8 features). */
+int pl_features_level(const double* d_sample, const int32_t* d_labels, const int32_t* d_nlabels,
+                      const double* d_stats, int max_labels, int64_t n, int h, int w, double dpmm,
+                      double radius_mm, double tol_mm, double min_sep_px, int max_number, int level,
+                      int32_t* d_done, int32_t* d_count, int32_t* d_prev_count, double* d_xy,
+                      int32_t* d_level, int32_t* d_status, void* stream);
+
 /* ---- a8-a10: pylinac.core.profile.find_peaks over scipy.signal.find_peaks -----------------------
  * (pylinac/core/profile.py:2545-2649).  One 1-D float64 profile per batch item. */
 typedef struct pl_peak_params {

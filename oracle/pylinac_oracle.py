@@ -666,6 +666,149 @@ def catphan_phantom_roi(arr: np.ndarray, mm_per_pixel: float, catphan_size: floa
 
 
 # --------------------------------------------------------------------------------------
+# a13  BB finder: find_features + predicates  (pylinac/metrics/utils.py:66-190, metrics/features.py,
+#      metrics/image.py:564-612; scikit-image 0.18.3 regionprops semantics)
+# --------------------------------------------------------------------------------------
+
+_PERIM_W = np.zeros(50)
+_PERIM_W[[5, 7, 15, 17, 25, 27]] = 1
+_PERIM_W[[21, 33]] = math.sqrt(2)
+_PERIM_W[[13, 23]] = (1 + math.sqrt(2)) / 2
+
+
+def perimeter_like_skimage(mask: np.ndarray) -> float:
+    """skimage.measure.perimeter(image, neighbourhood=4) (measure/_regionprops_utils.py)."""
+    img = mask.astype(np.uint8)
+    eroded = ndimage.binary_erosion(img, ndimage.generate_binary_structure(2, 1), border_value=0)
+    border = img - eroded
+    codes = ndimage.convolve(border, np.array([[10, 2, 10], [2, 1, 2], [10, 2, 10]]), mode="constant", cval=0)
+    hist = np.bincount(codes.ravel(), minlength=50)
+    return float(_PERIM_W @ hist)
+
+
+def _hull_ccw(points):
+    """Andrew's monotone chain on integer points; strictly convex vertices, counter-clockwise in the
+    (x0, x1) plane -- the orientation scipy.spatial.ConvexHull reports for 2-D input."""
+    pts = sorted(set(map(tuple, points)))
+    if len(pts) <= 2:
+        return pts
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    lower, upper = [], []
+    for p in pts:
+        while len(lower) >= 2 and cross(lower[-2], lower[-1], p) <= 0:
+            lower.pop()
+        lower.append(p)
+    for p in reversed(pts):
+        while len(upper) >= 2 and cross(upper[-2], upper[-1], p) <= 0:
+            upper.pop()
+        upper.append(p)
+    return lower[:-1] + upper[:-1]
+
+
+def convex_area_like_skimage(mask: np.ndarray) -> int:
+    """np.sum(skimage.morphology.convex_hull_image(mask)) for a 2-D region image (0.18.3):
+    hull of the pixel centres, each hull vertex expanded to the 4 mid-edge points (+-0.5), hull
+    again, then every pixel centre tested for membership in the closed hull polygon."""
+    rr, cc = np.nonzero(mask)
+    base = _hull_ccw(zip((2 * rr).tolist(), (2 * cc).tolist()))           # doubled integer coordinates
+    cand = []
+    for r2, c2 in base:
+        cand += [(r2, c2 - 1), (r2, c2 + 1), (r2 - 1, c2), (r2 + 1, c2)]
+    hull = _hull_ccw(cand)
+    # skimage's point_in_polygon (>= 0.17) labels boundary points VERTEX / EDGE and the mask keeps every
+    # non-zero label: membership in the CLOSED polygon.  All coordinates are half-integers, so the
+    # test is exact in doubled integer arithmetic: inside <=> on the left of (or on) every CCW edge.
+    h, w = mask.shape
+    x2 = 2 * np.arange(h, dtype=np.int64)[:, None]
+    y2 = 2 * np.arange(w, dtype=np.int64)[None, :]
+    inside = np.ones((h, w), bool)
+    n = len(hull)
+    for i in range(n):
+        ax, ay = hull[i]
+        bx, by = hull[(i + 1) % n]
+        inside &= ((bx - ax) * (y2 - ay) - (by - ay) * (x2 - ax)) >= 0
+    return int(inside.sum())
+
+
+def region_props_like_skimage(lab: np.ndarray, k: int, intensity: np.ndarray) -> dict:
+    """The regionprops the BB predicates read, for label k of a label image."""
+    m = lab == k
+    rr, cc = np.nonzero(m)
+    r0, r1, c0, c1 = rr.min(), rr.max() + 1, cc.min(), cc.max() + 1
+    crop = m[r0:r1, c0:c1]
+    area = int(m.sum())
+    filled = int(ndimage.binary_fill_holes(crop, np.ones((3, 3))).sum())
+    convex = convex_area_like_skimage(crop)
+    w = intensity[r0:r1, c0:c1] * crop
+    m00 = w.sum()
+    lr, lc = np.mgrid[0:crop.shape[0], 0:crop.shape[1]]
+    return dict(label=k, area=area, filled_area=filled, bbox=(r0, c0, r1, c1), bbox_area=(r1 - r0) * (c1 - c0),
+                perimeter=perimeter_like_skimage(crop), convex_area=convex, solidity=area / convex,
+                weighted_centroid=((w * lr).sum() / m00 + r0, (w * lc).sum() / m00 + c0))
+
+
+def bb_predicates(p: dict, dpmm: float, bb_size: float, tolerance: float) -> bool:
+    """is_right_size_bb, is_round, is_right_circumference, is_symmetric, is_solid
+    (pylinac/metrics/features.py:7-68), ANDed like find_features' filtering loop."""
+    bb_area = p["filled_area"] / (dpmm**2)
+    larger = np.pi * (bb_size + tolerance) ** 2
+    smaller = max((np.pi * (bb_size - tolerance) ** 2, 2))
+    if not (smaller < bb_area < larger):
+        return False
+    fill_ratio = p["filled_area"] / p["bbox_area"]
+    if not (np.pi / 4 * 1.2 > fill_ratio > np.pi / 4 * 0.8):
+        return False
+    per = p["perimeter"] / dpmm
+    if not (2 * np.pi * (bb_size + tolerance) > per > 2 * np.pi * (bb_size - tolerance)):
+        return False
+    ymin, xmin, ymax, xmax = p["bbox"]
+    y, x = abs(ymax - ymin), abs(xmax - xmin)
+    if x > max(y * 1.05, y + 3) or x < min(y * 0.95, y - 3):
+        return False
+    return p["solidity"] > 0.9
+
+
+def find_features_restated(sample: np.ndarray, dpmm: float, radius_mm: float, radius_tolerance_mm: float,
+                           max_number: int = 1, min_number: int = 1, min_separation_mm: float = 5):
+    """pylinac/metrics/utils.py:66-190 with zero offsets: 50-step threshold sweep, 4-connected label,
+    clear_border, predicates, weighted centroids (x, y).  Returns (points [(x, y)], level)."""
+    s = stretch(sample, min=0, max=1)
+    imin, imax = s.min(), s.max()
+    step = (imax - imin) / 50
+    cutoff = imin + step
+    total, level, found_level = [], 0, -1
+    while cutoff <= imax and len(total) < max_number:
+        lab, n = ndimage.label(s > cutoff)                                       # connectivity=1
+        border = np.unique(np.concatenate([lab[0], lab[-1], lab[:, 0], lab[:, -1]]))
+        new = []
+        for k in range(1, n + 1):
+            if k in border:
+                continue
+            p = region_props_like_skimage(lab, k, s)
+            if bb_predicates(p, dpmm, radius_mm, radius_tolerance_mm):
+                new.append((p["weighted_centroid"][1], p["weighted_centroid"][0]))
+        for pt in new:                                                           # deduplicate vs earlier levels
+            if all(math.hypot(pt[0] - q[0], pt[1] - q[1]) >= min_separation_mm * dpmm for q in total_before(total, new)):
+                total.append(pt)
+        if new and found_level < 0:
+            found_level = level
+        cutoff += step
+        level += 1
+    if len(total) < min_number:
+        raise ValueError(f"Couldn't find the minimum number of disks in the image. Found {len(total)}; required: {min_number}")
+    return total, found_level
+
+
+def total_before(total, new):
+    """deduplicate_points_and_boundaries compares new points with the ORIGINAL list only
+    (pylinac/metrics/utils.py:14-38): points found at the same level never suppress each other."""
+    return [q for q in total if q not in new]
+
+
+# --------------------------------------------------------------------------------------
 # config #3  Picket fence per-image measurement  (pylinac/picketfence.py:67-100, 745-803, 847-912,
 #            1605-1628).  Input: the frame AFTER the constructor's crop/ground/normalize (float64).
 # --------------------------------------------------------------------------------------

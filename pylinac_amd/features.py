@@ -1,0 +1,98 @@
+"""Batched BB / disk finder.
+
+Mirrors ``pylinac.metrics.utils.find_features`` (pylinac/metrics/utils.py:66-190) with the detection
+conditions of ``SizedDiskLocator`` (pylinac/metrics/image.py:529-535: is_right_size_bb, is_round,
+is_right_circumference, is_symmetric, is_solid) for a batch of equally-sized float64 samples resident on
+the GPU, and ``SizedDiskRegion.calculate``'s window + invert (metrics/image.py:564-612) for WL frames.
+
+The 50-step threshold sweep runs level by level for the whole batch; a window stops taking part once it
+has ``max_number`` features (the reference's ``while ... len(total_features) < max_number``).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+
+def stretch_device(frames: torch.Tensor) -> torch.Tensor:
+    """``stretch(sample, 0, 1)`` = ground(normalize(ground(a)) * (1 - 0), value=0) (array_utils.py:168)."""
+    g = ops.ground(frames)
+    return ops.ground(ops.scale(ops.normalize(g), 1.0), value=0.0)
+
+
+def sweep_cutoffs() -> list[float]:
+    """cutoff = imin + step; while cutoff <= imax: ...; cutoff += step  with imin = 0, imax = 1 after
+    stretch (metrics/utils.py:121-128, 180)."""
+    imin, imax = 0.0, 1.0
+    step = (imax - imin) / 50
+    out, cutoff = [], imin + step
+    while cutoff <= imax:
+        out.append(cutoff)
+        cutoff += step
+    return out
+
+
+def find_features_batch(samples: torch.Tensor, dpmm: float, radius_mm: float, radius_tolerance_mm: float,
+                        max_number: int = 1, min_separation_mm: float = 5, max_labels: int = 4096,
+                        poll_every: int = 8):
+    """-> dict(xy float64 [N,8,2] (x, y) window coordinates, count int32 [N], level int32 [N],
+    status int32 [N]).  ``count < min_number`` is the reference's ValueError("Couldn't find the minimum
+    number of disks"); the batch reports it per window instead of raising."""
+    s = ops._frames(samples)
+    if s.dtype != torch.float64:
+        raise TypeError("find_features_batch needs float64 samples")
+    n, h, w = s.shape
+    dev = s.device
+    s = stretch_device(s)
+    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    done = torch.zeros(n, dtype=torch.int32, device=dev)
+    count = torch.zeros(n, dtype=torch.int32, device=dev)
+    prev = torch.zeros(n, dtype=torch.int32, device=dev)
+    level = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    xy = torch.zeros((n, 8, 2), dtype=torch.float64, device=dev)
+    for lvl, cutoff in enumerate(sweep_cutoffs()):
+        bw = ops.compare(s, cutoff, ">")
+        labels, num = ops.label(bw, 4)
+        stats, _ = ops.region_stats(labels, None, max_labels)
+        check(lib.pl_features_level(s.data_ptr(), labels.data_ptr(), num.data_ptr(), stats.data_ptr(), max_labels, n, h,
+                                    w, float(dpmm), float(radius_mm), float(radius_tolerance_mm),
+                                    float(min_separation_mm * dpmm), int(max_number), lvl, done.data_ptr(),
+                                    count.data_ptr(), prev.data_ptr(), xy.data_ptr(), level.data_ptr(),
+                                    status.data_ptr(), st), "pl_features_level")
+        if poll_every and (lvl + 1) % poll_every == 0 and bool(done.all()):
+            break
+    return dict(xy=xy, count=count, level=level, status=status)
+
+
+def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float, low_density: bool = False,
+                       bb_tolerance_mm: float | None = None):
+    """``WLBaseImage.find_bb_centroids`` (pylinac/winston_lutz.py:788-806) for uint16 frames:
+    SizedDiskLocator.from_center_physical(expected (0, 0) mm, window (40 + d) mm, radius d/2,
+    invert = not low_density) on the ground()/normalize()d frame.  Returns the find_features result
+    with ``xy`` shifted to frame coordinates."""
+    x = ops._frames(frames)
+    if x.dtype != torch.uint16:
+        raise TypeError("bb_centroids_batch needs uint16 frames")
+    n, h, w = x.shape
+    if bb_tolerance_mm is None:                         # _calculate_bb_tolerance, winston_lutz.py:1062-1067
+        bb_tolerance_mm = float(np.interp(bb_diameter_mm, (1.5, 30), (2, 4)))
+    win = (40 + bb_diameter_mm) * dpmm                  # search window in pixels
+    ex, ey = w / 2, h / 2                               # expected position (0, 0) mm from the centre
+    left = max(math.floor(ex - win / 2), 0)
+    right = math.ceil(ex + win / 2)
+    top = max(math.floor(ey - win / 2), 0)
+    bottom = math.ceil(ey + win / 2)
+    vmin, vmax = ops.minmax(x)                          # frame-level ground()/normalize()
+    crop = x.view(torch.int16)[:, top:bottom, left:right].contiguous().view(torch.uint16)
+    q = ops.normalize(ops.ground(crop, mn=vmin), vmax - vmin)        # float64 (a - min) / (max - min)
+    sample = ops.invert(q) if not low_density else q
+    res = find_features_batch(sample, dpmm, bb_diameter_mm / 2, bb_tolerance_mm)
+    res["xy"] = res["xy"] + torch.tensor([left, top], dtype=torch.float64, device=x.device)
+    res["window"] = (top, bottom, left, right)
+    return res

@@ -123,6 +123,28 @@ def pf_frame(h, w, pixel, seed, n_pickets=10, spacing_mm=15.0, gap_mm=2.0):
     return np.clip(np.round(img), 0, 65535).astype(np.uint16)
 
 
+def bb_windows(n, seed):
+    """The ~134 x 134 px search window of WL's SizedDiskLocator ((40 + 5) mm at 2.98 dpmm,
+    pylinac/winston_lutz.py:795-805): normalised float64 field plateau with a dark 5 mm BB, mild blur,
+    noise, and (window 2) a thin rod attached to the BB."""
+    from scipy import ndimage as ndi
+
+    rng = np.random.default_rng(seed)
+    dpmm = 1 / 0.336
+    size = int(np.ceil(45 * dpmm))
+    out = []
+    for i in range(n):
+        y, x = np.mgrid[0:size, 0:size].astype(float)
+        cy, cx = size / 2 + rng.uniform(-8, 8), size / 2 + rng.uniform(-8, 8)
+        img = np.full((size, size), 0.92)
+        img[np.hypot(y - cy, x - cx) < 2.5 * dpmm] = 0.35
+        if i == 2:
+            img[int(cy):, int(cx) - 1:int(cx) + 2] = 0.5       # BB rod: spiculated region
+        img = ndi.gaussian_filter(img, 1.2) + rng.normal(0, 0.004, img.shape)
+        out.append(img)
+    return out, dpmm
+
+
 def skimage_otsu(arrays: dict) -> dict:
     """threshold_otsu via scikit-image 0.18.3 in the py3.9 interpreter."""
     with tempfile.TemporaryDirectory() as td:
@@ -428,6 +450,18 @@ def main():
         pfg[f"{k}.spacing"] = np.float64(pf.mlc_meas[0]._spacing)
         pfg[f"{k}.max_error"] = np.float64(pf.max_error)
     np.savez_compressed(os.path.join(HERE, "picketfence.npz"), **pfg)
+
+    # ----------------- 8. BB finder: the reference's own find_features under scikit-image 0.18.3 (a13)
+    bbw, bb_dpmm = bb_windows(4, seed=51)
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "w.npz"), os.path.join(td, "f.npz")
+        np.savez(inp, count=len(bbw), dpmm=bb_dpmm, radius_mm=2.5, tol_mm=0.5, **{f"w{i}": w for i, w in enumerate(bbw)})
+        subprocess.run([PY39, os.path.join(HERE, "skimage_features_py39.py"), inp, outp, ROOT], check=True)
+        bbg = dict(np.load(outp))
+    for i, w in enumerate(bbw):
+        bbg[f"{i}.window"] = w
+    bbg["dpmm"] = np.float64(bb_dpmm)
+    np.savez_compressed(os.path.join(HERE, "features.npz"), **bbg)
 
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):

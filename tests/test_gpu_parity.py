@@ -819,3 +819,66 @@ def test_picket_fence_batch_of_frames(dev):
         pos = res.position[i, :, :P].cpu().numpy()
         assert np.array_equal(np.isnan(pos), np.isnan(ref["position"]))
         assert np.array_equal(pos[~np.isnan(pos)], ref["position"][~np.isnan(pos)])
+
+
+# ------------------------------------------------------------------------------- BB finder (a13)
+def test_find_features_batch_vs_reference_golden(golden, dev):
+    """Device sweep against the reference's own find_features (scikit-image 0.18.3, py3.9 helper):
+    same first level, same number of features, weighted centroids within 1e-12 relative
+    (north_star asks 1e-5)."""
+    from pylinac_amd import features as pf
+
+    g = golden("features")
+    dpmm = float(g["dpmm"])
+    wins = np.stack([o.invert(g[f"{i}.window"]) for i in range(4)])
+    res = pf.find_features_batch(T(wins, dev), dpmm, 2.5, 0.5)
+    assert int(res["status"].abs().sum()) == 0
+    for i in range(4):
+        ref_pts, ref_level = o.find_features_restated(wins[i], dpmm, 2.5, 0.5)
+        assert int(res["count"][i]) == len(g[f"{i}.points"]) == len(ref_pts)
+        assert int(res["level"][i]) == ref_level
+        got = res["xy"][i, : len(ref_pts)].cpu().numpy()
+        assert np.allclose(got, g[f"{i}.points"], rtol=1e-12, atol=0)
+    # nothing BB-like: the reference raises ValueError("Couldn't find the minimum number of disks")
+    rng = np.random.default_rng(0)
+    flat = 0.5 + rng.normal(0, 0.01, (1, 134, 134))
+    r2 = pf.find_features_batch(T(flat, dev), dpmm, 2.5, 0.5)
+    assert int(r2["count"][0]) == 0 and int(r2["level"][0]) == -1
+    with pytest.raises(ValueError):
+        o.find_features_restated(flat[0], dpmm, 2.5, 0.5)
+
+
+def test_wl_bb_centroids_batch_vs_oracle(dev):
+    """WLBaseImage.find_bb_centroids (pylinac/winston_lutz.py:788-806) on synthetic WL frames: window
+    crop (floor/ceil), frame-level ground/normalize, invert, sweep -- against the oracle composition."""
+    import math
+
+    from scipy import ndimage as ndi
+
+    from pylinac_amd import features as pf
+
+    rng = np.random.default_rng(12)
+    dpmm, n, size = 1 / 0.336, 3, 400
+    frames = []
+    for i in range(n):
+        y, x = np.mgrid[0:size, 0:size].astype(float)
+        cy, cx = size / 2 + rng.uniform(-5, 5), size / 2 + rng.uniform(-5, 5)
+        img = np.full((size, size), 1500.0)
+        img[int(cy - 30):int(cy + 30), int(cx - 30):int(cx + 30)] = 42000.0
+        img[np.hypot(y - (cy + rng.uniform(-4, 4)), x - (cx + rng.uniform(-4, 4))) < 2.5 * dpmm] *= 0.3
+        img = ndi.gaussian_filter(img, 1.5) + rng.normal(0, 120, img.shape)
+        frames.append(np.clip(np.round(img), 0, 65535))
+    frames = np.stack(frames).astype(np.uint16)
+    res = pf.bb_centroids_batch(T(frames, dev), dpmm, 5.0)
+    tol = float(np.interp(5.0, (1.5, 30), (2, 4)))
+    for i in range(n):
+        arr = o.normalize(o.ground(frames[i]))
+        win = (40 + 5.0) * dpmm
+        left = max(math.floor(size / 2 - win / 2), 0)
+        right = math.ceil(size / 2 + win / 2)
+        top, bottom = left, right
+        sample = o.invert(arr[top:bottom, left:right])
+        pts, level = o.find_features_restated(sample, dpmm, 2.5, tol)
+        assert int(res["count"][i]) == len(pts) == 1 and int(res["level"][i]) == level
+        got = res["xy"][i, 0].cpu().numpy()
+        assert np.allclose(got, [pts[0][0] + left, pts[0][1] + top], rtol=1e-12, atol=0)

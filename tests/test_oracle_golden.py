@@ -294,3 +294,34 @@ def test_picket_fence_measurement_matches_reference_analyze(golden):
             assert r["position"][idx[int(leaf)], int(picket)] == pos
             assert r["peak_idxs"][int(picket)] == approx
         assert np.isnan(r["position"]).sum() > 0     # the jaw-blocked rows were rejected
+
+
+def test_bb_finder_restatement_matches_reference_find_features(golden):
+    """oracle.find_features_restated / region_props_like_skimage against the reference's own
+    find_features + scikit-image 0.18.3 regionprops (py3.9 helper): every region the sweep saw
+    (area, filled_area, bbox, perimeter, convex_area, weighted centroid) and the final points."""
+    from scipy import ndimage as ndi
+
+    g = golden("features")
+    dpmm = float(g["dpmm"])
+    checked = 0
+    for i in range(4):
+        win = g[f"{i}.window"]
+        s = o.stretch(o.invert(win), 0, 1)
+        labs = {}
+        for row in g[f"{i}.levels"]:
+            lvl, label = int(row[0]), int(row[1])
+            if lvl not in labs:
+                cutoff = 0.0 + 1 / 50
+                for _ in range(lvl):
+                    cutoff += 1 / 50
+                labs[lvl] = ndi.label(s > cutoff)[0]
+            p = o.region_props_like_skimage(labs[lvl], label, s)
+            assert (p["area"], p["filled_area"], p["convex_area"]) == (row[2], row[3], row[9])
+            assert tuple(p["bbox"]) == tuple(row[4:8])
+            assert abs(p["perimeter"] - row[8]) <= 1e-12 * row[8]
+            assert np.allclose(p["weighted_centroid"], row[11:13], rtol=1e-12, atol=0)
+            checked += 1
+        pts, _ = o.find_features_restated(o.invert(win), dpmm, 2.5, 0.5)
+        assert np.allclose(np.array(pts), g[f"{i}.points"], rtol=1e-13, atol=0)
+    assert checked > 150
