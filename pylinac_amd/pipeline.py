@@ -54,6 +54,10 @@ class EpidPipeline:
     # fuse the Gaussian's axis-1 pass with the 3x3 median: one HBM round trip less, but measured
     # slower than the two specialised kernels on MI355X (VALU-issue-bound either way) -> opt-in
     fused: bool = False
+    # software pipelining over frame chunks: the two Gaussian passes (FP64-issue-bound) of chunk i+1 run
+    # on a second HIP stream while the median/histogram/threshold/profile stages (memory-bound) of chunk i
+    # run on the first.  1 = a single stream, whole batch per launch.
+    chunks: int = 1
     timings: dict = field(default_factory=dict)
 
     def __post_init__(self):
@@ -81,6 +85,10 @@ class EpidPipeline:
         self.wts, self.radius = ops._device_weights(self.sigma, dev)
         self.prm = ops.make_peak_params(w, fwxm_height=self.fwxm_height / 100, max_number=1)
         self.lib = _lib.load()
+        if self.chunks < 1 or self.n % self.chunks:
+            raise ValueError("chunks must divide the batch")
+        if self.chunks > 1:
+            self._filter_stream = torch.cuda.Stream(device=dev)
 
     def run(self, frames: torch.Tensor, events: dict | None = None) -> EpidResult:
         """One pass over a resident batch.  ``events``: optional {stage: [(start, stop), ...]} sink;
@@ -89,46 +97,74 @@ class EpidPipeline:
             raise ValueError(f"expected uint16 [{self.n},{self.h},{self.w}] frames")
         if not frames.is_cuda:
             raise ValueError("frames must be resident on the GPU")
-        lib, st = self.lib, torch.cuda.current_stream().cuda_stream
-        n, h, w = self.n, self.h, self.w
+        lib = self.lib
+        h, w = self.h, self.w
         U16 = _lib.PL_U16
+        x = frames.contiguous()
+        main = torch.cuda.current_stream()
 
-        def stage(name, fn):
+        def stage(name, fn, stream):
             if events is None:
                 check(fn(), name)
                 return
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0.record(stream)
             check(fn(), name)
-            e1.record()
+            e1.record(stream)
             events.setdefault(name, []).append((e0, e1))
 
-        x = frames.contiguous()
-        stage("gauss_v", lambda: lib.pl_gaussian1d(x.data_ptr(), self.buf_a.data_ptr(), U16, n, h, w, 0,
-                                                   self.wts.data_ptr(), self.radius, st))
-        if self.fused and self.median_size == 3:
-            stage("gauss_h_median3", lambda: lib.pl_gauss_h_median3(
-                self.buf_a.data_ptr(), self.buf_b.data_ptr(), self.out.data_ptr(), U16, n, h, w,
-                self.wts.data_ptr(), self.radius, st))
-            med = self.buf_b
+        fb = h * w * 2                                   # bytes per uint16 frame
+        xp, ap, bp, op = x.data_ptr(), self.buf_a.data_ptr(), self.buf_b.data_ptr(), self.out.data_ptr()
+        wts, pk = self.wts.data_ptr(), self.peaks
+        hist, thr, vmin, vmax = (t.data_ptr() for t in (self.hist, self.thr, self.vmin, self.vmax))
+        colsum, profile, fwxm = self.colsum.data_ptr(), self.profile.data_ptr(), self.fwxm.data_ptr()
+        cnt, idx, lb, rb, props, status = (t.data_ptr() for t in (pk.count, pk.idx, pk.left_bases,
+                                                                   pk.right_bases, pk.props, pk.status))
+
+        def filters(lo, m, stream):
+            """Image.filter(sigma, "gaussian"): axis 0 then axis 1, frames [lo, lo+m)."""
+            st, o = stream.cuda_stream, lo * fb
+            stage("gauss_v", lambda: lib.pl_gaussian1d(xp + o, ap + o, U16, m, h, w, 0, wts, self.radius, st), stream)
+            if self.fused and self.median_size == 3:
+                stage("gauss_h_median3", lambda: lib.pl_gauss_h_median3(ap + o, bp + o, op + o, U16, m, h, w, wts,
+                                                                        self.radius, st), stream)
+            else:
+                stage("gauss_h", lambda: lib.pl_gaussian1d(ap + o, bp + o, U16, m, h, w, 1, wts, self.radius, st),
+                      stream)
+
+        def rest(lo, m, stream):
+            """median -> Otsu -> threshold -> column profile -> FWXM record, frames [lo, lo+m)."""
+            st, o = stream.cuda_stream, lo * fb
+            if self.fused and self.median_size == 3:
+                med = bp + o
+            else:
+                stage("median3", lambda: lib.pl_median2d(bp + o, ap + o, U16, m, h, w, self.median_size, st), stream)
+                med = ap + o
+            stage("hist16", lambda: lib.pl_hist16(med, U16, m, h * w, hist + lo * 65536 * 4, st), stream)
+            stage("otsu", lambda: lib.pl_otsu_from_hist(hist + lo * 65536 * 4, U16, m, thr + lo * 4, vmin + lo * 4,
+                                                        vmax + lo * 4, st), stream)
+            stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(med, op + o, m, h, w, thr + lo * 4,
+                                                                          colsum + lo * w * 8, st), stream)
+            stage("colsum_to_mean", lambda: lib.pl_colsum_to_mean(colsum + lo * w * 8, m, w, h,
+                                                                  profile + lo * w * 8, st), stream)
+            stage("find_peaks", lambda: lib.pl_find_peaks(
+                profile + lo * w * 8, m, w, w, C.byref(self.prm), 1, cnt + lo * 4, idx + lo * 4, lb + lo * 4,
+                rb + lo * 4, props + lo * 48, status + lo * 4, st), stream)
+            stage("fwxm_record", lambda: lib.pl_fwxm_record(cnt + lo * 4, idx + lo * 4, props + lo * 48, 1, m,
+                                                            fwxm + lo * 64, st), stream)
+
+        if self.chunks == 1:
+            filters(0, self.n, main)
+            rest(0, self.n, main)
         else:
-            stage("gauss_h", lambda: lib.pl_gaussian1d(self.buf_a.data_ptr(), self.buf_b.data_ptr(), U16, n, h,
-                                                       w, 1, self.wts.data_ptr(), self.radius, st))
-            stage("median3", lambda: lib.pl_median2d(self.buf_b.data_ptr(), self.buf_a.data_ptr(), U16, n, h, w,
-                                                     self.median_size, st))
-            med = self.buf_a
-        stage("hist16", lambda: lib.pl_hist16(med.data_ptr(), U16, n, h * w, self.hist.data_ptr(), st))
-        stage("otsu", lambda: lib.pl_otsu_from_hist(self.hist.data_ptr(), U16, n, self.thr.data_ptr(),
-                                                    self.vmin.data_ptr(), self.vmax.data_ptr(), st))
-        stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(
-            med.data_ptr(), self.out.data_ptr(), n, h, w, self.thr.data_ptr(), self.colsum.data_ptr(), st))
-        stage("colsum_to_mean", lambda: lib.pl_colsum_to_mean(self.colsum.data_ptr(), n, w, h,
-                                                              self.profile.data_ptr(), st))
-        pk = self.peaks
-        stage("find_peaks", lambda: lib.pl_find_peaks(
-            self.profile.data_ptr(), n, w, w, C.byref(self.prm), 1, pk.count.data_ptr(), pk.idx.data_ptr(),
-            pk.left_bases.data_ptr(), pk.right_bases.data_ptr(), pk.props.data_ptr(), pk.status.data_ptr(), st))
-        stage("fwxm_record", lambda: lib.pl_fwxm_record(pk.count.data_ptr(), pk.idx.data_ptr(),
-                                                        pk.props.data_ptr(), 1, n, self.fwxm.data_ptr(), st))
-        return EpidResult(self.out, self.profile, self.thr, self.fwxm, pk.status)
+            m = self.n // self.chunks
+            fs = self._filter_stream
+            fs.wait_stream(main)                      # frames (and the previous step's readers) are ready
+            for c in range(self.chunks):
+                filters(c * m, m, fs)
+                done = torch.cuda.Event()
+                done.record(fs)
+                main.wait_event(done)
+                rest(c * m, m, main)
+        return EpidResult(self.out, self.profile, self.thr, self.fwxm, self.peaks.status)
