@@ -21,6 +21,8 @@
 //     to float64 ONCE while being staged into LDS, with a 16-byte pad every 64 bytes so that the
 //     per-lane ds_read_b128 windows (80-byte lane stride) are bank-conflict-free.
 //   * block ids are remapped so that consecutive tiles of a frame share an XCD's L2 (halo rows).
+#include <stdlib.h>
+
 #include "pl_common.h"
 
 namespace {
@@ -397,10 +399,31 @@ int launch_fast(const T* in, T* out, int64_t n, int h, int w, int axis, const do
   return 0;
 }
 
+}  // namespace
+
+// gaussian_pk.hip: packed-float32 decision kernels for 16-bit images (0 = launched, -1 = not covered)
+int pl_gauss_pk_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, int axis,
+                       const double* wts, int radius, hipStream_t st);
+
+namespace {
+// PL_GAUSS_PK=1 opts into the packed-float32 decision kernels (gaussian_pk.hip: bit-identical, measured
+// only ~3 % faster end to end so far); the float64 kernels below are the default.
+bool use_pk_path() {
+  static const bool on = [] {
+    const char* e = getenv("PL_GAUSS_PK");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+
 template <typename T>
 int gaussian1d_t(const T* in, T* out, int64_t n, int h, int w, int axis, const double* wts,
                  int radius, hipStream_t st, int mode = 0) {
   int rc = -1;
+  if (sizeof(T) == 2 && mode == 0 && use_pk_path()) {
+    rc = pl_gauss_pk_launch(in, out, (T)-1 < (T)0, n, h, w, axis, wts, radius, st);
+    if (rc == 0) return pl_check_launch("pl_gaussian1d");
+  }
   // specialised instances: radius = int(4*sigma+0.5) for sigma 1, 2, 3, 5
   const bool big_enough = (axis == 0 ? h : w) >= 1;
   if (big_enough && sizeof(T) == 2 && mode == 0) {

@@ -882,3 +882,58 @@ def test_wl_bb_centroids_batch_vs_oracle(dev):
         assert int(res["count"][i]) == len(pts) == 1 and int(res["level"][i]) == level
         got = res["xy"][i, 0].cpu().numpy()
         assert np.allclose(got, [pts[0][0] + left, pts[0][1] + top], rtol=1e-12, atol=0)
+
+
+def _gaussian_cases(dev):
+    """(frames, sigmas) covering sparse undecided pixels, list overflow, zero shortcut, ragged shapes."""
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    cases = [(epid_open_field_frames(3, 1024, 1024, seed0=77, device=dev).cpu().numpy(), (1, 2, 3, 5))]
+    rng = np.random.default_rng(5)
+    for shape in [(2, 37, 530), (1, 9, 1026), (3, 3, 6), (1, 301, 77), (2, 64, 64), (1, 1, 40), (1, 40, 2)]:
+        smooth = 30000 + 8000 * np.sin(np.arange(shape[2]) / 17.0)[None, None, :] * np.cos(
+            np.arange(shape[1]) / 11.0)[None, :, None]
+        b = np.clip(smooth + rng.normal(0, 300, shape), 0, 65535).astype(np.uint16)
+        b[0, : shape[1] // 3, : shape[2] // 2] = 0
+        b[-1, shape[1] // 2:, shape[2] // 2:] = 41234
+        cases.append((b, (1, 2, 3, 5)))
+        cases.append(((b.astype(np.int32) - 31000).astype(np.int16), (2, 5)))
+    full = rng.integers(0, 65536, (2, 90, 1100), dtype=np.uint16)   # full-range noise: list overflow
+    cases.append((full, (2, 5)))
+    cases.append((np.full((1, 70, 260), 65535, dtype=np.uint16), (1, 5)))
+    return cases
+
+
+def _check_gaussian_cases(dev):
+    from pylinac_amd import ops
+
+    for arr, sigmas in _gaussian_cases(dev):
+        for sigma in sigmas:
+            ref = np.stack([o.filter(f, sigma, "gaussian") for f in arr])
+            got = ops.gaussian_filter(T(arr, dev), sigma).cpu().numpy()
+            assert np.array_equal(got, ref), (arr.shape, arr.dtype, sigma)
+
+
+def test_gaussian_float64_kernels_on_epid_and_ragged_frames(dev):
+    """Default path: EPID-like frames, zero regions, constant blocks, ragged shapes, int16 plateaus."""
+    _check_gaussian_cases(dev)
+
+
+def test_gaussian_packed_f32_decision_path_opt_in(dev):
+    """PL_GAUSS_PK=1 (gaussian_pk.hip): trunc(S) decided in packed float32, undecided pixels recomputed with
+    scipy's float64 sequence from the LDS tile.  Same cases as the default path, in a fresh process (the
+    switch is read once per process): sparse undecided pixels (workgroup list), list overflow (full-range
+    noise, saturated frames -> whole-tile recompute), zero regions (S == 0 shortcut), odd widths (axis 0 falls
+    back to the float64 kernel), an odd number of rows (unpaired last row on axis 1), int16."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch\n"
+            "from tests import test_gpu_parity as t\n"
+            "t._check_gaussian_cases(torch.device('cuda', 0))\n"
+            "print('PK_OK')\n")
+    env = dict(os.environ, PL_GAUSS_PK="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0 and "PK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
