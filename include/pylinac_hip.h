@@ -214,6 +214,24 @@ int pl_features_level(const double* d_sample, const int32_t* d_labels, const int
                       int32_t* d_done, int32_t* d_count, int32_t* d_prev_count, double* d_xy,
                       int32_t* d_level, int32_t* d_status, void* stream);
 
+/* ---- a18: noise power spectrum, radial average, ESF-FFT MTF ---------------------------------------
+ * pl_nps2d: pylinac/core/nps.py:35-79 noise_power_spectrum_2d.  d_rois float64, n_rois ROIs of which the
+ * top-left length x length block is used (roi_stride / row_stride in elements, so ROIs of different shapes
+ * can sit zero-padded in one buffer); per ROI: subtract the block mean, |fft2|^2, fftshift; mean over ROIs;
+ * times pixel_size^2 / length^2 -> d_out float64 [length][length].  d_work: pl_nps2d_work_doubles() doubles. */
+int pl_nps2d(const double* d_rois, int64_t n_rois, int length, int64_t roi_stride, int row_stride,
+             double pixel_size, double* d_work, double* d_out, void* stream);
+int64_t pl_nps2d_work_doubles(int64_t n_rois, int length);
+/* pylinac/core/nps.py:12-32 radial_average about floor(shape/2): bin = int(sqrt(dx^2+dy^2)), mean per bin
+ * (sums in numpy's raster order -> bit-identical), d_out float64 [nbins], nbins = 1 + the largest bin. */
+int pl_radial_average(const double* d_arr, int h, int w, int nbins, double* d_out, void* stream);
+/* pylinac/core/mtf.py:448-456 _compute_esf_mtf for n_esf edge spread functions (float64 [n_esf][lmax], valid
+ * lengths d_lens >= 2, d_window float64 [n_esf][lmax] = the window samples of each ESF's own length):
+ * |fft(gradient(esf) * window, num_samples)| / DC for k < num_samples/2 -> d_mtf_each [n_esf][num_samples/2];
+ * d_mtf_mean [num_samples/2] = mean over the ESFs (mtf.py:375).  d_work: n_esf * (num_samples/2) doubles. */
+int pl_esf_mtf(const double* d_esf, const int32_t* d_lens, const double* d_window, int n_esf, int lmax,
+               int num_samples, double* d_work, double* d_mtf_each, double* d_mtf_mean, void* stream);
+
 /* ---- a8-a10: pylinac.core.profile.find_peaks over scipy.signal.find_peaks -----------------------
  * (pylinac/core/profile.py:2545-2649).  One 1-D float64 profile per batch item. */
 typedef struct pl_peak_params {

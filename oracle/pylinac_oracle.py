@@ -886,6 +886,70 @@ def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=Non
 
 
 # --------------------------------------------------------------------------------------
+# a18: noise power spectrum / radial average / ESF-FFT MTF (numpy pocketfft, as the reference calls it)
+# --------------------------------------------------------------------------------------
+def radial_average(arr: np.ndarray) -> np.ndarray:
+    """pylinac/core/nps.py:12-32."""
+    center = np.floor(np.array(arr.shape) / 2)
+    y, x = np.indices(arr.shape)
+    r = np.sqrt((x - center[1]) ** 2 + (y - center[0]) ** 2).astype(int)
+    tbin = np.bincount(r.ravel(), arr.ravel())
+    nr = np.bincount(r.ravel())
+    nonzero = nr != 0
+    radial_mean = np.zeros(nr.shape)
+    radial_mean[nonzero] = tbin[nonzero] / nr[nonzero]
+    return radial_mean
+
+
+def noise_power_spectrum_2d(pixel_size: float, rois) -> np.ndarray:
+    """pylinac/core/nps.py:35-79."""
+    length = min(min(roi.shape) for roi in rois)
+    ffts = np.zeros((length, length, len(rois)))
+    for idx, roi in enumerate(rois):
+        rroi = roi[0:length, 0:length]
+        b = np.abs(np.fft.fft2(rroi - np.mean(rroi))) ** 2
+        ffts[:, :, idx] = np.fft.fftshift(b)
+    return pixel_size**2 / length**2 * np.mean(ffts, axis=-1)
+
+
+def average_power(nps1d: np.ndarray) -> float:
+    """pylinac/core/nps.py:99-115."""
+    return float(np.average(np.linspace(0, 1, len(nps1d)), weights=nps1d))
+
+
+def max_frequency(nps1d: np.ndarray) -> float:
+    """pylinac/core/nps.py:118-121."""
+    return float(np.argmax(nps1d) / len(nps1d))
+
+
+def esf_mtf(esf_list, sample_spacing=None, padding_mode="auto", num_samples=1024, windowing=None, **kwargs):
+    """pylinac/core/mtf.py:336-376 + _compute_esf_mtf :448-456 -> (freq, mtf, [mtf per esf]).
+    ``windowing``: callable(len, **kwargs); None = boxcar (the reference's default is scipy's hann)."""
+    windowing = windowing or (lambda m: np.ones(m))
+    len_esf = np.unique([len(e) for e in esf_list])
+    if padding_mode == "none":
+        if len(len_esf) > 1:
+            raise ValueError("If padding_mode='none', all ESF samples must have the same size")
+        num_samples = len_esf[0]
+    elif padding_mode == "fixed":
+        if num_samples < max(len_esf):
+            raise ValueError("num_samples must be larger than the largest array")
+    elif padding_mode == "auto":
+        num_samples = int(max(max(2 ** np.ceil(np.log2(len_esf))), num_samples))
+    from scipy.fft import fft, fftfreq   # what pylinac/core/mtf.py:13 imports (not numpy.fft)
+
+    pixel_spacing = 1 if sample_spacing is None else sample_spacing
+    freq = fftfreq(num_samples, d=pixel_spacing)[: num_samples // 2]
+    each = []
+    for e in esf_list:
+        lsf = np.gradient(e)
+        m = np.abs(fft(lsf * windowing(len(e), **kwargs), num_samples))
+        m /= m[0]
+        each.append(m[: num_samples // 2])
+    return freq, np.mean(np.array(each), axis=0), each
+
+
+# --------------------------------------------------------------------------------------
 # BASELINE config #2 + profile/peak: the pipeline bench.py measures
 # --------------------------------------------------------------------------------------
 

@@ -82,6 +82,10 @@ SIGNATURES = {
     "pl_clear_border": ([_p, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_region_stats": ([_p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p], C.c_int),
     "pl_features_level": ([_p, _p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _p, _p, _p, _p, _p, _p, _p], C.c_int),
+    "pl_nps2d": ([_p, _l, _i, _l, _i, _d, _p, _p, _p], C.c_int),
+    "pl_nps2d_work_doubles": ([_l, _i], C.c_int64),
+    "pl_radial_average": ([_p, _i, _i, _i, _p, _p], C.c_int),
+    "pl_esf_mtf": ([_p, _p, _p, _i, _i, _i, _p, _p, _p, _p], C.c_int),
     "pl_colsum_to_mean": ([_p, _l, _i, _i, _p, _p], C.c_int),
     "pl_find_peaks_var": (
         [_p, _l, _i, _p, _l, C.POINTER(PeakParams), _i, _p, _p, _p, _p, _p, _p, _p],

@@ -85,3 +85,82 @@ def peak_valley_mtf(circle_profile, roi_settings: dict) -> MTF:
         raise ValueError("Did not find any spatial resolution pairs to analyze.")
     spacings = [roi["lp/mm"] for roi in roi_settings.values()]
     return MTF(lp_spacings=spacings, lp_maximums=maxs, lp_minimums=mins)
+
+
+# ---------------------------------------------------------------------------- ESF-FFT MTF (a18)
+def hann(m: int) -> np.ndarray:
+    """``scipy.signal.windows.hann(m)`` (symmetric), restated: general_cosine with a = [0.5, 0.5] over
+    ``linspace(-pi, pi, m)`` (scipy/signal/windows/_windows.py, not vendored in the reference tree)."""
+    if m <= 1:
+        return np.ones(max(m, 0))
+    fac = np.linspace(-np.pi, np.pi, m)
+    w = np.zeros(m)
+    for k, a in enumerate((0.5, 0.5)):
+        w += a * np.cos(k * fac)
+    return w
+
+
+def boxcar(m: int) -> np.ndarray:
+    return np.ones(m)
+
+
+class EdgeSpreadFunctionMTF:
+    """pylinac/core/mtf.py:308-376: relative MTF from edge spread functions, averaged over the ESFs.
+
+    Same constructor arguments (``esf, sample_spacing, padding_mode, num_samples, windowing, **kwargs``) and
+    attributes (``freq``, ``mtf``, ``relative_resolution``).  ``windowing`` is any callable ``f(len, **kwargs)``
+    (default: the Hann window); gradient, windowing, the zero-padded DFT magnitude, normalisation and the mean
+    over ESFs run on the GPU (``pl_esf_mtf``).
+    """
+
+    def __init__(self, esf, sample_spacing: float | None = None, padding_mode: str = "auto",
+                 num_samples: int = 1024, windowing=hann, device=None, **kwargs):
+        import torch
+
+        from . import _lib
+        from ._lib import check
+
+        self.sample_spacing = sample_spacing
+        windowing = windowing or boxcar
+        esf = [np.asarray(e.detach().cpu().numpy() if hasattr(e, "detach") else e, dtype=np.float64) for e in esf]
+        len_esf = np.unique([len(e) for e in esf])
+        if padding_mode == "none":
+            if len(len_esf) > 1:
+                raise ValueError("If padding_mode='none', all ESF samples must have the same size")
+            num_samples = int(len_esf[0])
+        elif padding_mode == "fixed":
+            if num_samples < max(len_esf):
+                raise ValueError("num_samples must be larger than the largest array")
+        elif padding_mode == "auto":
+            next_power_of_two = max(2 ** np.ceil(np.log2(len_esf)))
+            num_samples = int(max(next_power_of_two, num_samples))
+        if min(len_esf) < 2:
+            raise ValueError("Shape of array too small to calculate a numerical gradient, "
+                             "at least (edge_order + 1) elements are required.")   # np.gradient's message
+        pixel_spacing = 1 if sample_spacing is None else sample_spacing
+        # np.fft.fftfreq(n, d)[: n // 2] = k / (n * d), computed as numpy does (integer k times 1/(n d))
+        self.freq = np.arange(0, num_samples // 2, dtype=int) * (1.0 / (num_samples * pixel_spacing))
+
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        n_esf, lmax, half = len(esf), int(max(len_esf)), num_samples // 2
+        host = np.zeros((2, n_esf, lmax))
+        for i, e in enumerate(esf):
+            host[0, i, : len(e)] = e
+            host[1, i, : len(e)] = np.asarray(windowing(len(e), **kwargs), dtype=np.float64)
+        both = torch.from_numpy(host).to(dev)
+        lens = torch.tensor([len(e) for e in esf], dtype=torch.int32, device=dev)
+        work = torch.empty((n_esf, half), dtype=torch.float64, device=dev)
+        each = torch.empty((n_esf, half), dtype=torch.float64, device=dev)
+        mean = torch.empty(half, dtype=torch.float64, device=dev)
+        check(_lib.load().pl_esf_mtf(both[0].data_ptr(), lens.data_ptr(), both[1].data_ptr(), n_esf, lmax,
+                                     num_samples, work.data_ptr(), each.data_ptr(), mean.data_ptr(),
+                                     torch.cuda.current_stream(dev).cuda_stream), "pl_esf_mtf")
+        self._mtf = list(each.cpu().numpy())
+        self._esf = esf
+        self.mtf = mean.cpu().numpy()
+
+    def relative_resolution(self, x: float = 50) -> float:
+        """pylinac/core/mtf.py:378-388 (``argue.bounds(x=(0, 100))`` -> ValueError)."""
+        if not 0 <= x <= 100:
+            raise ValueError("x must be within (0, 100)")
+        return float(np.interp(-x / 100, -self.mtf, self.freq))

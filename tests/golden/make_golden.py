@@ -463,6 +463,63 @@ def main():
     bbg["dpmm"] = np.float64(bb_dpmm)
     np.savez_compressed(os.path.join(HERE, "features.npz"), **bbg)
 
+    # ------------------- 9. NPS / radial average / ESF-FFT MTF: the reference's own functions (a18)
+    nps = ref_loader.ref("core.nps")
+    rmtf = ref_loader.ref("core.mtf")
+    from scipy.signal import windows
+
+    def noisy(shape, scale, intensity, seed=123):      # tests_basic/core/test_nps.py:14-80, seeded the same way
+        rng = np.random.default_rng(seed=seed)
+        low = rng.normal(loc=0, scale=intensity, size=(shape[0] // scale, shape[1] // scale))
+        m = np.kron(low, np.ones((scale, scale)))[: shape[0], : shape[1]]
+        return np.clip(np.zeros(shape, dtype=np.uint16) + m, 0, 65535)
+
+    sp = {}
+    roi1, roi2, roi3 = noisy((300, 300), 30, 500), noisy((200, 200), 10, 100), noisy((65, 50), 5, 80, seed=9)[:61, :47]
+    hu = np.random.default_rng(77).normal(40, 12, (4, 45, 45))          # CT-like uniformity ROIs (float)
+    sp.update(roi1=roi1, roi2=roi2, roi3=roi3, hu=hu)
+    sp["nps_single"] = nps.noise_power_spectrum_2d(pixel_size=1, rois=[roi1])
+    sp["nps_two"] = nps.noise_power_spectrum_2d(pixel_size=0.5, rois=[roi1, roi2])
+    sp["nps_ragged"] = nps.noise_power_spectrum_2d(pixel_size=0.39, rois=[roi2, roi3])
+    sp["nps_odd"] = nps.noise_power_spectrum_2d(pixel_size=1, rois=[roi1[:-1, :-1]])
+    sp["nps_hu"] = nps.noise_power_spectrum_2d(pixel_size=0.48, rois=list(hu))
+    for k in ("single", "two", "ragged", "odd", "hu"):
+        one = nps.noise_power_spectrum_1d(sp[f"nps_{k}"])
+        sp[f"nps1d_{k}"] = one
+        sp[f"scalars_{k}"] = np.array([nps.average_power(one), nps.max_frequency(one)])
+    sp["radial_ones"] = nps.radial_average(np.ones((300, 300)))
+    rect = np.random.default_rng(3).normal(5, 2, (37, 64))
+    sp["rect"], sp["radial_rect"] = rect, nps.radial_average(rect)
+    # ESF-FFT MTF: the reference's KAT inputs (tests_basic/core/test_mtf.py:59-132) + a blurred noisy edge
+    step = lambda n: np.append(np.zeros(n // 2), np.ones(n // 2))  # noqa: E731
+    shifted = np.zeros(256)
+    shifted[228:] = 1
+    from scipy.special import erf
+
+    rng = np.random.default_rng(8)
+    blur = [0.5 * (1 + erf((np.arange(n) - n / 2 + d) / 3.0)) * 900 + 50 + rng.normal(0, 2, n)
+            for n, d in ((120, 0.3), (97, -1.2), (150, 2.0))]
+    cases = {
+        "single": dict(esf=[step(8)]),
+        "multi": dict(esf=[step(8), step(6)]),
+        "spacing": dict(esf=[step(8), step(6)], sample_spacing=10),
+        "kaiser": dict(esf=[step(8), step(6)], windowing=windows.kaiser, beta=0.5),
+        "shift_none": dict(esf=[shifted], windowing=None),
+        "shift_hann": dict(esf=[shifted]),
+        "shift_tukey": dict(esf=[shifted], windowing=windows.tukey, alpha=0.2),
+        "pad_none": dict(esf=[step(256), step(256)], padding_mode="none"),
+        "pad_fixed": dict(esf=[step(8), step(6)], padding_mode="fixed", num_samples=100),
+        "blur": dict(esf=blur, sample_spacing=0.25),
+    }
+    for name, kw in cases.items():
+        m = rmtf.EdgeSpreadFunctionMTF(**kw)
+        sp[f"esf_{name}.freq"], sp[f"esf_{name}.mtf"] = m.freq, m.mtf
+        sp[f"esf_{name}.each"] = np.array(m._mtf)
+        sp[f"esf_{name}.res"] = np.array([m.relative_resolution(t) for t in (30, 50, 80)])
+        for i, e in enumerate(kw["esf"]):
+            sp[f"esf_{name}.in{i}"] = e
+    np.savez_compressed(os.path.join(HERE, "spectral.npz"), **sp)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

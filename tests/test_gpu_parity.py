@@ -937,3 +937,70 @@ def test_gaussian_packed_f32_decision_path_opt_in(dev):
     env = dict(os.environ, PL_GAUSS_PK="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, timeout=600, capture_output=True, text=True)
     assert r.returncode == 0 and "PK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------ spectral measures (a18)
+def test_nps_and_radial_average_vs_reference_golden(golden, dev):
+    """pl_nps2d / pl_radial_average against pylinac.core.nps (golden from the reference itself): the 2-D
+    spectrum within 1e-9 of its maximum (plain DFT vs pocketfft summation order), the radial average of a
+    GIVEN spectrum bit-identical (same bins, numpy's accumulation order), scalars to 1e-9."""
+    from pylinac_amd import nps
+
+    g = golden("spectral")
+    rois = {"single": (1, ["roi1"]), "two": (0.5, ["roi1", "roi2"]), "ragged": (0.39, ["roi2", "roi3"]),
+            "hu": (0.48, None)}
+    for k, (px, names) in rois.items():
+        rr = [g[n] for n in names] if names else list(g["hu"])
+        got = nps.noise_power_spectrum_2d(px, rr, device=dev).cpu().numpy()
+        ref = g[f"nps_{k}"]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-9 * ref.max(), k
+        # radial average of the reference's spectrum: bit-identical bins
+        one = nps.noise_power_spectrum_1d(torch.from_numpy(ref).to(dev))
+        assert np.array_equal(one.cpu().numpy(), g[f"nps1d_{k}"]), k
+        # and end to end from the device spectrum
+        one2 = nps.noise_power_spectrum_1d(torch.from_numpy(got).to(dev))
+        assert np.allclose(one2.cpu().numpy(), g[f"nps1d_{k}"], rtol=0, atol=1e-9 * g[f"nps1d_{k}"].max())
+        assert abs(nps.average_power(one2) - g[f"scalars_{k}"][0]) < 1e-9
+        assert nps.max_frequency(one2) == g[f"scalars_{k}"][1]
+    odd = nps.noise_power_spectrum_2d(1, [g["roi1"][:-1, :-1]], device=dev).cpu().numpy()
+    assert np.abs(odd - g["nps_odd"]).max() <= 1e-9 * g["nps_odd"].max()
+    stacked = nps.noise_power_spectrum_2d(0.48, torch.from_numpy(g["hu"]).to(dev)).cpu().numpy()
+    assert np.abs(stacked - g["nps_hu"]).max() <= 1e-9 * g["nps_hu"].max()
+    assert np.array_equal(nps.radial_average(g["rect"], device=dev).cpu().numpy(), g["radial_rect"])
+    assert np.array_equal(nps.radial_average(np.ones((300, 300)), device=dev).cpu().numpy(), g["radial_ones"])
+    with pytest.raises(ValueError):
+        nps.noise_power_spectrum_1d(torch.zeros(5, device=dev))
+
+
+def test_esf_mtf_vs_reference_golden(golden, dev):
+    """EdgeSpreadFunctionMTF (pl_esf_mtf) on the reference's known-answer inputs
+    (tests_basic/core/test_mtf.py:59-132: ideal steps of 8 / 6 / 256 samples, Hann / Kaiser / Tukey / no
+    window, sample spacing, every padding mode) and on blurred noisy edges: frequency axis exact, MTF within
+    1e-12 absolute of the reference, resolutions to 1e-9; same ValueErrors."""
+    from scipy.signal import windows
+
+    from pylinac_amd import mtf
+
+    g = golden("spectral")
+    kws = {"single": {}, "multi": {}, "spacing": dict(sample_spacing=10),
+           "kaiser": dict(windowing=windows.kaiser, beta=0.5), "shift_none": dict(windowing=None),
+           "shift_hann": {}, "shift_tukey": dict(windowing=windows.tukey, alpha=0.2),
+           "pad_none": dict(padding_mode="none"), "pad_fixed": dict(padding_mode="fixed", num_samples=100),
+           "blur": dict(sample_spacing=0.25)}
+    for name, kw in kws.items():
+        esf = [g[f"esf_{name}.in{i}"] for i in range(sum(k.startswith(f"esf_{name}.in") for k in g.files))]
+        m = mtf.EdgeSpreadFunctionMTF(esf, device=dev, **kw)
+        assert np.array_equal(m.freq, g[f"esf_{name}.freq"]), name
+        assert np.abs(m.mtf - g[f"esf_{name}.mtf"]).max() < 1e-12, name
+        assert np.abs(np.array(m._mtf) - g[f"esf_{name}.each"]).max() < 1e-12, name
+        res = [m.relative_resolution(t) for t in (30, 50, 80)]
+        assert np.allclose(res, g[f"esf_{name}.res"], rtol=1e-9, atol=1e-12), name
+    ideal = mtf.EdgeSpreadFunctionMTF([np.append(np.zeros(4), np.ones(4))], device=dev)
+    assert np.allclose(ideal.mtf, np.cos(np.pi * ideal.freq))
+    with pytest.raises(ValueError):
+        mtf.EdgeSpreadFunctionMTF([np.zeros(8), np.zeros(6)], padding_mode="none", device=dev)
+    with pytest.raises(ValueError):
+        mtf.EdgeSpreadFunctionMTF([np.zeros(8)], padding_mode="fixed", num_samples=4, device=dev)
+    with pytest.raises(ValueError):
+        ideal.relative_resolution(101)

@@ -89,3 +89,14 @@ def test_synthetic_frames_are_deterministic_and_u16():
     assert torch.equal(a.view(torch.int16), b.view(torch.int16))
     x = a.numpy()
     assert x.max() > 30000 and x.min() < 5000
+
+
+def test_hann_window_restatement_is_scipys():
+    """mtf.hann restates scipy.signal.windows.hann (the reference's default ESF window) bit for bit."""
+    from scipy.signal import windows
+
+    from pylinac_amd import mtf
+
+    for m in (1, 2, 3, 6, 8, 97, 256, 1001):
+        assert np.array_equal(mtf.hann(m), windows.hann(m)), m
+    assert np.array_equal(mtf.boxcar(5), windows.boxcar(5))

@@ -325,3 +325,41 @@ def test_bb_finder_restatement_matches_reference_find_features(golden):
         pts, _ = o.find_features_restated(o.invert(win), dpmm, 2.5, 0.5)
         assert np.allclose(np.array(pts), g[f"{i}.points"], rtol=1e-13, atol=0)
     assert checked > 150
+
+
+def test_spectral_restatements_match_reference(golden):
+    """a18: oracle.noise_power_spectrum_2d / radial_average / esf_mtf against the reference's own
+    pylinac.core.nps and EdgeSpreadFunctionMTF outputs (numpy pocketfft in both: bit-identical), plus the
+    reference's known answers: average power 0.0145 +- 0.005 and peak frequency 0.0094 +- 1e-4
+    (tests_basic/core/test_nps.py:128-151), ideal-step MTF = cos(pi f) (tests_basic/core/test_mtf.py:59-83)."""
+    from scipy.signal import windows
+
+    g = golden("spectral")
+    rois = {"single": (1, ["roi1"]), "two": (0.5, ["roi1", "roi2"]), "ragged": (0.39, ["roi2", "roi3"])}
+    for k, (px, names) in rois.items():
+        n2 = o.noise_power_spectrum_2d(px, [g[n] for n in names])
+        assert np.array_equal(n2, g[f"nps_{k}"])
+        one = o.radial_average(n2)
+        assert np.array_equal(one, g[f"nps1d_{k}"])
+        assert np.array_equal([o.average_power(one), o.max_frequency(one)], g[f"scalars_{k}"])
+    assert np.array_equal(o.noise_power_spectrum_2d(0.48, list(g["hu"])), g["nps_hu"])
+    assert abs(g["scalars_single"][0] - 0.0145) < 0.005 and abs(g["scalars_single"][1] - 0.0094) < 1e-4
+    assert abs(g["radial_ones"][0] - 1) < 1e-4 and len(g["nps1d_single"]) == int(np.ceil(300 * np.sqrt(2) / 2))
+    assert np.array_equal(o.radial_average(g["rect"]), g["radial_rect"])
+    kws = {"single": {}, "multi": {}, "spacing": dict(sample_spacing=10),
+           "kaiser": dict(windowing=windows.kaiser, beta=0.5), "shift_none": dict(windowing=None),
+           "shift_tukey": dict(windowing=windows.tukey, alpha=0.2), "pad_none": dict(padding_mode="none"),
+           "pad_fixed": dict(padding_mode="fixed", num_samples=100), "blur": dict(sample_spacing=0.25),
+           "shift_hann": {}}
+    for name, kw in kws.items():
+        esf = [g[f"esf_{name}.in{i}"] for i in range(sum(k.startswith(f"esf_{name}.in") for k in g.files))]
+        kw = dict(kw)
+        kw.setdefault("windowing", windows.hann)
+        freq, m, each = o.esf_mtf(esf, **kw)
+        assert np.array_equal(freq, g[f"esf_{name}.freq"]) and np.array_equal(m, g[f"esf_{name}.mtf"]), name
+        assert np.array_equal(np.array(each), g[f"esf_{name}.each"])
+    for name in ("single", "multi", "kaiser", "shift_none", "shift_tukey"):
+        f = g[f"esf_{name}.freq"]
+        assert np.allclose(g[f"esf_{name}.mtf"], np.cos(np.pi * f))
+        assert np.allclose(g[f"esf_{name}.res"], np.arccos(np.array([30, 50, 80]) / 100) / np.pi)
+    assert not np.allclose(g["esf_shift_hann.mtf"], np.cos(np.pi * g["esf_shift_hann.freq"]))
