@@ -214,6 +214,16 @@ int pl_features_level(const double* d_sample, const int32_t* d_labels, const int
                       int32_t* d_done, int32_t* d_count, int32_t* d_prev_count, double* d_xy,
                       int32_t* d_level, int32_t* d_status, void* stream);
 
+/* ---- a11: profile resampling -----------------------------------------------------------------------
+ * scipy.interpolate.interp1d(x, y, kind, bounds_error=False, fill_value="extrapolate")(xq) as called by
+ * SingleProfile._interpolate (pylinac/core/profile.py:1349-1358).  d_x float64 abscissae (x_stride elements
+ * between profiles, 0 = shared by all), d_y float64 [n_profiles][length], d_xq float64 [n_query] (shared),
+ * kind 0 = "linear" (scipy's slope form, bit-identical), 1 = "cubic" (the not-a-knot interpolating cubic
+ * spline, ~1e-13 relative to scipy's B-spline evaluation; length >= 4).  d_work: 3*n_profiles*length doubles
+ * for kind 1 (may be NULL for kind 0).  d_out float64 [n_profiles][n_query]. */
+int pl_interp1d(const double* d_x, int64_t x_stride, const double* d_y, int64_t n_profiles, int length,
+                const double* d_xq, int n_query, int kind, double* d_work, double* d_out, void* stream);
+
 /* ---- a18: noise power spectrum, radial average, ESF-FFT MTF ---------------------------------------
  * pl_nps2d: pylinac/core/nps.py:35-79 noise_power_spectrum_2d.  d_rois float64, n_rois ROIs of which the
  * top-left length x length block is used (roi_stride / row_stride in elements, so ROIs of different shapes

@@ -886,6 +886,123 @@ def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=Non
 
 
 # --------------------------------------------------------------------------------------
+# a11: SingleProfile (FWHM edge method) -- scipy interp1d / find_peaks / linregress / minimize as the reference
+# --------------------------------------------------------------------------------------
+class SingleProfileRestated:
+    """pylinac/core/profile.py:1118-1633 restated for Edge.FWHM: __init__ :1125-1215, _interpolate :1306-1360,
+    _normalize :1362-1371, fwxm_data :1411-1461, _sample_points_in_physical_window :1237-1283,
+    field_data :1463-1633, field_calculation :1910-1937."""
+
+    def __init__(self, values, dpmm=None, interpolation="Linear", ground=True, interpolation_resolution_mm=0.1,
+                 interpolation_factor=10, normalization_method="Beam center", x_values=None,
+                 centering="Beam center"):
+        from scipy.interpolate import interp1d
+
+        values = np.asarray(values, dtype=float)
+        self.dpmm, self._centering = dpmm, centering
+        if x_values is None:
+            x_values = np.array(range(len(values)))
+        if np.diff(x_values).min() < 0:
+            raise ValueError("Profile values must be monotonically increasing")
+        if interpolation is None:
+            fitted, x_indices = values.copy(), np.asarray(x_values)
+        else:
+            if dpmm is not None:
+                samples = int(round(len(x_values) / (dpmm * interpolation_resolution_mm)))
+            else:
+                samples = int(round(len(x_values) * interpolation_factor))
+            offset = 0.5 - 1 / (2 * (samples / len(values)))
+            f = interp1d(x_values, values, kind="linear" if interpolation == "Linear" else "cubic",
+                         bounds_error=False, fill_value="extrapolate")
+            x_indices = np.linspace(x_values[0] - offset, x_values[-1] + offset, num=samples)
+            fitted = f(x_indices)
+        self.x_indices = x_indices
+        self._x = interp1d(list(range(len(x_indices))), x_indices)
+        if ground:
+            fitted = fitted - fitted.min()
+        self._set(fitted)
+        if normalization_method == "Max":
+            self._set(fitted / fitted.max())
+        elif normalization_method == "Geometric center":
+            n = len(fitted)
+            cv = (fitted[n // 2] + fitted[n // 2 - 1]) / 2.0 if n % 2 == 0 else fitted[(n - 1) // 2]
+            self._set(fitted / cv)
+        elif normalization_method == "Beam center":
+            self._set(fitted / self.fwxm_data(50)["center value (@rounded)"])
+
+    def _set(self, v):
+        from scipy.interpolate import interp1d
+
+        self.values = v
+        self._y = interp1d(self.x_indices, v, bounds_error=False, fill_value="extrapolate")
+
+    def _yat(self, loc):
+        y = self._y(loc)
+        return float(y) if np.size(loc) == 1 else y
+
+    def fwxm_data(self, x=50):
+        _, props = find_peaks(self.values, fwxm_height=x / 100, max_number=1)
+        left, right = float(self._x(props["left_ips"][0])), float(self._x(props["right_ips"][0]))
+        center = (right - left) / 2 + left
+        return {"width (exact)": right - left, "center index (exact)": center,
+                "center value (@rounded)": self._yat(int(round(center))), "left index (exact)": left,
+                "left value (@rounded)": self._yat(int(round(left))), "right index (exact)": right,
+                "right value (@rounded)": self._yat(int(round(right))),
+                "field values": self._yat(self.x_indices[int(round(left)): int(round(right))])}
+
+    def _window(self, a, b):
+        lower, upper = sorted((a, b))
+        xi = self.x_indices
+        start = int(np.searchsorted(xi, lower, side="left"))
+        stop = int(np.searchsorted(xi, upper, side="right"))
+        if stop - start < 3:
+            li, ri = int(np.abs(xi - lower).argmin()), int(np.abs(xi - upper).argmin())
+            start, stop = min(li, ri), max(li, ri) + 1
+        if stop - start < 3:
+            c = int(np.abs(xi - (lower + upper) / 2).argmin())
+            start = max(0, c - 1)
+            stop = min(len(xi), start + 3)
+            start = max(0, stop - 3)
+        return xi[start:stop], self._yat(xi[start:stop])
+
+    def field_data(self, in_field_ratio=0.8, slope_exclusion_ratio=0.2):
+        from scipy.optimize import minimize
+        from scipy.stats import linregress
+
+        if slope_exclusion_ratio >= in_field_ratio:
+            raise ValueError("The exclusion region must be smaller than the field ratio")
+        d = self.fwxm_data(50)
+        beam, full = d["center index (exact)"], d["width (exact)"]
+        cax = float(self._x((len(self.values) - 1) / 2.0))
+        center = cax if self._centering == "Geometric center" else beam
+        fl, fr = center - in_field_ratio * full / 2, center + in_field_ratio * full / 2
+        fw = fr - fl
+        il, ir = center - slope_exclusion_ratio * fw / 2, center + slope_exclusion_ratio * fw / 2
+        lfit = linregress(*self._window(fl, il))
+        rfit = linregress(*self._window(ir, fr))
+        tx, ty = self._window(il, ir)
+        prm = np.polyfit(tx, ty, deg=2)
+        width = abs(tx[-1] - tx[0])
+        mf = minimize(lambda x: -(prm[0] * (x**2) + prm[1] * x + prm[2]), x0=(tx[0] + width / 2,),
+                      bounds=((tx[0], tx[-1]),))
+        shifted = self.x_indices + (center - int(round(center)))
+        i0, i1 = int(np.abs(shifted - fl).argmin()), int(np.abs(shifted - fr).argmin())
+        return {"width (exact)": fw, "beam center index (exact)": beam,
+                "beam center value (@rounded)": self._yat(round(beam)), "cax index (exact)": cax,
+                "cax value (@rounded)": self._yat(round(cax)), "left index (exact)": fl,
+                "left value (@rounded)": self._yat(round(fl)), "left slope": lfit.slope,
+                "left intercept": lfit.intercept, "right slope": rfit.slope, "right intercept": rfit.intercept,
+                "left inner index (exact)": il, "right inner index (exact)": ir,
+                '"top" index (exact)': mf.x[0], '"top" value (@exact)': -mf.fun, "top params": prm,
+                "right index (exact)": fr, "right value (@rounded)": self._yat(round(fr)),
+                "field values": self._yat(shifted[i0: i1 + 1])}
+
+    def field_calculation(self, in_field_ratio=0.8, calculation="mean", slope_exclusion_ratio=0.2):
+        fv = self.field_data(in_field_ratio, slope_exclusion_ratio)["field values"]
+        return {"mean": fv.mean, "median": lambda: float(np.median(fv)), "max": fv.max, "min": fv.min}[calculation]()
+
+
+# --------------------------------------------------------------------------------------
 # a18: noise power spectrum / radial average / ESF-FFT MTF (numpy pocketfft, as the reference calls it)
 # --------------------------------------------------------------------------------------
 def radial_average(arr: np.ndarray) -> np.ndarray:

@@ -631,3 +631,24 @@ def region_stats(labels: torch.Tensor, intensity: torch.Tensor | None, max_label
                                       n, h, w, int(max_labels), isum.data_ptr(), wsum.data_ptr(), stats.data_ptr(),
                                       ovf.data_ptr(), _stream()), "pl_region_stats")
     return stats, ovf
+
+
+def interp1d(x: torch.Tensor, y: torch.Tensor, xq: torch.Tensor, kind: str = "linear") -> torch.Tensor:
+    """``scipy.interpolate.interp1d(x, y, kind, bounds_error=False, fill_value="extrapolate")(xq)`` for a batch
+    of profiles: ``x`` float64 [L] (shared) or [N, L], ``y`` float64 [N, L] (or [L]), ``xq`` float64 [S]
+    -> float64 [N, S] (pylinac/core/profile.py:1349-1358)."""
+    if kind not in ("linear", "cubic"):
+        raise ValueError("kind must be 'linear' or 'cubic'")
+    y2 = (y if y.ndim == 2 else y[None]).to(torch.float64).contiguous()
+    n, length = y2.shape
+    xs = x.to(torch.float64).contiguous()
+    if xs.shape[-1] != length or (xs.ndim == 2 and xs.shape[0] != n):
+        raise ValueError("x and y must have the same length")
+    stride = 0 if xs.ndim == 1 else length
+    q = xq.to(torch.float64).contiguous()
+    out = torch.empty((n, q.numel()), dtype=torch.float64, device=y2.device)
+    work = torch.empty(3 * n * length, dtype=torch.float64, device=y2.device) if kind == "cubic" else None
+    check(_lib.load().pl_interp1d(xs.data_ptr(), stride, y2.data_ptr(), n, length, q.data_ptr(), q.numel(),
+                                  0 if kind == "linear" else 1, work.data_ptr() if work is not None else None,
+                                  out.data_ptr(), _stream()), "pl_interp1d")
+    return out if y.ndim == 2 else out[0]

@@ -313,3 +313,329 @@ def fwxm_batch(profiles: torch.Tensor, fwxm_height: float = 50) -> torch.Tensor:
     (FWXM_FIELDS; NaN where a profile has no peak).  Stays on the device."""
     res = ops.find_peaks_batch(profiles, cap=1, fwxm_height=fwxm_height / 100, max_number=1)
     return ops.fwxm_record(res)
+
+
+# ------------------------------------------------------------------------------ SingleProfile (a11)
+class Interpolation(enum.Enum):
+    """pylinac/core/profile.py:162-167."""
+
+    NONE = None
+    LINEAR = "Linear"
+    SPLINE = "Spline"
+
+
+class Edge(enum.Enum):
+    """pylinac/core/profile.py:179-184."""
+
+    FWHM = "FWHM"
+    INFLECTION_DERIVATIVE = "Inflection Derivative"
+    INFLECTION_HILL = "Inflection Hill"
+
+
+class Centering(enum.Enum):
+    """pylinac/core/profile.py:187-192."""
+
+    MANUAL = "Manual"
+    BEAM_CENTER = "Beam center"
+    GEOMETRIC_CENTER = "Geometric center"
+
+
+def _enum(value, cls):
+    """pylinac.core.utilities.convert_to_enum."""
+    return value if isinstance(value, cls) else cls(value)
+
+
+class _Linear1d:
+    """``scipy.interpolate.interp1d(x, y)`` (linear) for the scalar look-ups SingleProfile makes on the host:
+    scipy's slope form ``(y_hi - y_lo) / (x_hi - x_lo) * (x_new - x_lo) + y_lo`` with
+    ``hi = clip(searchsorted(x, x_new), 1, len - 1)``; out of range -> ValueError unless ``extrapolate``."""
+
+    def __init__(self, x, y, extrapolate: bool):
+        self.x = np.asarray(x, dtype=np.float64)
+        self.y = np.asarray(y, dtype=np.float64)
+        self.extrapolate = extrapolate
+
+    def __call__(self, x_new):
+        xn = np.asarray(x_new, dtype=np.float64)
+        if not self.extrapolate:
+            if (xn < self.x[0]).any():
+                raise ValueError(f"A value ({xn.min()}) in x_new is below the interpolation range's minimum value ({self.x[0]}).")
+            if (xn > self.x[-1]).any():
+                raise ValueError(f"A value ({xn.max()}) in x_new is above the interpolation range's maximum value ({self.x[-1]}).")
+        hi = np.clip(np.searchsorted(self.x, xn), 1, len(self.x) - 1).astype(int)
+        lo = hi - 1
+        slope = (self.y[hi] - self.y[lo]) / (self.x[hi] - self.x[lo])
+        return slope * (xn - self.x[lo]) + self.y[lo]
+
+
+class SingleProfile:
+    """pylinac/core/profile.py:1118-1633: a profile with one large signal (a beam profile).
+
+    Same constructor arguments, dictionary keys and error behaviour as the reference for the FWHM edge
+    method (the inflection / Hill edge methods are row f4 and raise
+    NotImplementedError).  Resampling (``pl_interp1d``), grounding / normalisation (elementwise kernels) and
+    the FWXM search (``pl_find_peaks``) run on the GPU; ``values`` is the host copy the reference's users
+    read, ``values_device`` the resident tensor.  The handful of scalar look-ups and three-parameter fits of
+    ``field_data`` are host numpy, like the reference's.
+    """
+
+    def __init__(self, values, dpmm: float | None = None, interpolation=Interpolation.LINEAR, ground: bool = True,
+                 interpolation_resolution_mm: float = 0.1, interpolation_factor: float = 10,
+                 normalization_method=Normalization.BEAM_CENTER, edge_detection_method=Edge.FWHM,
+                 edge_smoothing_ratio: float = 0.003, hill_window_ratio: float = 0.1, x_values=None,
+                 centering=Centering.BEAM_CENTER):
+        self._interp_method = _enum(interpolation, Interpolation)
+        self._interpolation_res = interpolation_resolution_mm
+        self._interpolation_factor = interpolation_factor
+        self._norm_method = _enum(normalization_method, Normalization)
+        self._edge_method = _enum(edge_detection_method, Edge)
+        self._edge_smoothing_ratio = edge_smoothing_ratio
+        self._hill_window_ratio = hill_window_ratio
+        self._centering = _enum(centering, Centering)
+        if self._edge_method != Edge.FWHM:
+            raise NotImplementedError("inflection / Hill edge detection is SURVEY.md row f4; only Edge.FWHM is built")
+        self.dpmm = dpmm
+        dev_values = _to_device_profile(values)
+        fitted, new_dpmm, x_indices = self._interpolate(dev_values, x_values, dpmm, interpolation_resolution_mm,
+                                                        interpolation_factor, self._interp_method)
+        self.x_indices = x_indices
+        self._x_interp1d = _Linear1d(np.arange(len(x_indices)), x_indices, extrapolate=False)
+        self._ground = ground
+        if ground:
+            fitted = ops.ground(fitted[None, None])[0, 0]           # fitted_values -= fitted_values.min()
+        self._set_values(fitted)
+        norm = self._normalize(fitted, self._norm_method)
+        self._set_values(norm)
+
+    def _set_values(self, t: torch.Tensor) -> None:
+        self.values_device = t
+        self.values = t.cpu().numpy()
+        self._y_interp1d = _Linear1d(self.x_indices, self.values, extrapolate=True)
+
+    # --- interpolation (profile.py:1306-1360)
+    @staticmethod
+    def _interpolate(values: torch.Tensor, x_values, dpmm, interpolation_resolution, interpolation_factor,
+                     interp_method: Interpolation):
+        n = values.numel()
+        if x_values is None:
+            x_values = np.array(range(n))
+        x_values = np.asarray(x_values)
+        if np.diff(x_values).min() < 0:
+            raise ValueError("Profile values must be monotonically increasing")
+        if interp_method == Interpolation.NONE:
+            return values, dpmm, x_values
+        if dpmm is not None:
+            samples = int(round(len(x_values) / (dpmm * interpolation_resolution)))
+            new_dpmm = 1 / interpolation_resolution
+        else:
+            samples = int(round(len(x_values) * interpolation_factor))
+            new_dpmm = None
+        resampling_factor = samples / n
+        offset = 0.5 - 1 / (2 * resampling_factor)
+        new_x = np.linspace(x_values[0] - offset, x_values[-1] + offset, num=samples)
+        dev = values.device
+        xs = torch.from_numpy(np.ascontiguousarray(x_values, dtype=np.float64)).to(dev)
+        xq = torch.from_numpy(new_x).to(dev)
+        kind = "linear" if interp_method == Interpolation.LINEAR else "cubic"
+        return ops.interp1d(xs, values, xq, kind=kind), new_dpmm, new_x
+
+    def _normalize(self, values: torch.Tensor, method: Normalization) -> torch.Tensor:
+        """profile.py:1362-1371."""
+        if method == Normalization.NONE:
+            return values
+        if method == Normalization.MAX:
+            return ops.normalize(values[None, None])[0, 0]
+        if method == Normalization.GEOMETRIC_CENTER:
+            norm = self._geometric_center(self.values)["value (exact)"]
+        else:
+            norm = self.beam_center()["value (@rounded)"]
+        return ops.normalize(values[None, None], float(norm))[0, 0]
+
+    # --- scalar look-ups (profile.py:1217-1235)
+    def _x_interp_to_original(self, location):
+        x = self._x_interp1d(location)
+        if isinstance(location, (float, int)) or np.size(location) == 1:
+            return float(x)
+        return x
+
+    def _y_original_to_interp(self, location):
+        y = self._y_interp1d(location)
+        if isinstance(location, (float, int)) or np.size(location) == 1:
+            return float(y)
+        return y
+
+    def _geometric_center(self, values) -> dict:
+        """profile.py:1373-1385."""
+        return {"index (exact)": self._x_interp_to_original(au.geometric_center_idx(values)),
+                "value (exact)": au.geometric_center_value(values)}
+
+    def geometric_center(self) -> dict:
+        return self._geometric_center(self.values)
+
+    def beam_center(self) -> dict:
+        """profile.py:1390-1409 (FWHM branch)."""
+        data = self.fwxm_data(x=50)
+        return {"index (rounded)": data["center index (rounded)"], "index (exact)": data["center index (exact)"],
+                "value (@rounded)": data["center value (@rounded)"]}
+
+    def fwxm_data(self, x: int = 50) -> dict:
+        """profile.py:1411-1461.  The slice of ``x_indices`` by ROUNDED PHYSICAL positions for
+        "field values" is the reference's own (negative positions slice from the end)."""
+        if not 0 <= x <= 100:
+            raise ValueError("x must be within (0, 100)")
+        _, peak_props = find_peaks(self.values_device, fwxm_height=x / 100, max_number=1)
+        left_idx = float(self._x_interp_to_original(peak_props["left_ips"][0]))
+        right_idx = float(self._x_interp_to_original(peak_props["right_ips"][0]))
+        width = right_idx - left_idx
+        fwxm_center_idx = (right_idx - left_idx) / 2 + left_idx
+        data = {
+            "width (exact)": width,
+            "width (rounded)": int(round(width)),
+            "center index (rounded)": int(round(fwxm_center_idx)),
+            "center index (exact)": fwxm_center_idx,
+            "center value (@rounded)": float(self._y_original_to_interp(int(round(fwxm_center_idx)))),
+            "left index (exact)": left_idx,
+            "left index (rounded)": int(round(left_idx)),
+            "left value (@rounded)": float(self._y_original_to_interp(int(round(left_idx)))),
+            "right index (exact)": right_idx,
+            "right index (rounded)": int(round(right_idx)),
+            "right value (@rounded)": float(self._y_original_to_interp(int(round(right_idx)))),
+            "field values": self._y_original_to_interp(self.x_indices[int(round(left_idx)): int(round(right_idx))]),
+            "peak_props": peak_props,
+        }
+        if self.dpmm:
+            data["width (exact) mm"] = data["width (exact)"] / self.dpmm
+            data["left distance (exact) mm"] = abs(data["center index (exact)"] - data["left index (exact)"]) / self.dpmm
+            data["right distance (exact) mm"] = abs(data["right index (exact)"] - data["center index (exact)"]) / self.dpmm
+        return data
+
+    def _sample_points_in_physical_window(self, left_edge: float, right_edge: float):
+        """profile.py:1237-1283."""
+        lower, upper = sorted((left_edge, right_edge))
+        start = int(np.searchsorted(self.x_indices, lower, side="left"))
+        stop = int(np.searchsorted(self.x_indices, upper, side="right"))
+        if stop - start < 3:
+            left_idx = int(np.abs(self.x_indices - lower).argmin())
+            right_idx = int(np.abs(self.x_indices - upper).argmin())
+            start = min(left_idx, right_idx)
+            stop = max(left_idx, right_idx) + 1
+        if stop - start < 3:
+            center_sample_idx = int(np.abs(self.x_indices - (lower + upper) / 2).argmin())
+            start = max(0, center_sample_idx - 1)
+            stop = min(len(self.x_indices), start + 3)
+            start = max(0, stop - 3)
+        x_samples = self.x_indices[start:stop]
+        return x_samples, self._y_original_to_interp(x_samples)
+
+    def field_data(self, in_field_ratio: float = 0.8, slope_exclusion_ratio=0.2) -> dict:
+        """profile.py:1463-1633 (FWHM branch): in-field window, two edge-slope regressions, quadratic "top"."""
+        if not 0 <= in_field_ratio <= 1.0 or not 0 <= slope_exclusion_ratio <= 1.0:
+            raise ValueError("in_field_ratio and slope_exclusion_ratio must be within (0, 1)")
+        if slope_exclusion_ratio >= in_field_ratio:
+            raise ValueError("The exclusion region must be smaller than the field ratio")
+        data = self.fwxm_data(x=50)
+        beam_center_idx = data["center index (exact)"]
+        full_width = data["width (exact)"]
+        beam_center_idx_r = int(round(beam_center_idx))
+        cax_idx = self.geometric_center()["index (exact)"]
+        cax_idx_r = int(round(cax_idx))
+        center_idx = cax_idx if self._centering == Centering.GEOMETRIC_CENTER else beam_center_idx
+
+        field_left_idx = center_idx - in_field_ratio * full_width / 2
+        field_right_idx = center_idx + in_field_ratio * full_width / 2
+        field_width = field_right_idx - field_left_idx
+        inner_left_idx = center_idx - slope_exclusion_ratio * field_width / 2
+        inner_right_idx = center_idx + slope_exclusion_ratio * field_width / 2
+        left_slope_x, left_slope_y = self._sample_points_in_physical_window(field_left_idx, inner_left_idx)
+        right_slope_x, right_slope_y = self._sample_points_in_physical_window(inner_right_idx, field_right_idx)
+        left_slope, left_intercept = _linregress(left_slope_x, left_slope_y)
+        right_slope, right_intercept = _linregress(right_slope_x, right_slope_y)
+
+        top_x, top_y = self._sample_points_in_physical_window(inner_left_idx, inner_right_idx)
+        fit_params = np.polyfit(top_x, top_y, deg=2)
+        width = abs(top_x[-1] - top_x[0])
+        top_idx, top_val = _bounded_top(fit_params, top_x[0] + width / 2, top_x[0], top_x[-1])
+
+        pixel_offset = center_idx - int(round(center_idx))
+        x_indices_shifted = self.x_indices + pixel_offset
+        x_index_min = int(np.abs(x_indices_shifted - field_left_idx).argmin())
+        x_index_max = int(np.abs(x_indices_shifted - field_right_idx).argmin())
+        out = {
+            "width (exact)": field_width,
+            "beam center index (exact)": beam_center_idx,
+            "beam center index (rounded)": beam_center_idx_r,
+            "beam center value (@rounded)": self._y_original_to_interp(round(beam_center_idx)),
+            "cax index (exact)": cax_idx,
+            "cax index (rounded)": cax_idx_r,
+            "cax value (@rounded)": self._y_original_to_interp(round(cax_idx)),
+            "left index (exact)": field_left_idx,
+            "left index (rounded)": int(round(field_left_idx)),
+            "left value (@rounded)": self._y_original_to_interp(round(field_left_idx)),
+            "left slope": left_slope,
+            "left intercept": left_intercept,
+            "right slope": right_slope,
+            "right intercept": right_intercept,
+            "left inner index (exact)": inner_left_idx,
+            "left inner index (rounded)": int(round(inner_left_idx)),
+            "right inner index (exact)": inner_right_idx,
+            "right inner index (rounded)": int(round(inner_right_idx)),
+            '"top" index (exact)': top_idx,
+            '"top" index (rounded)': int(round(top_idx)),
+            '"top" value (@exact)': top_val,
+            "top params": fit_params,
+            "right index (exact)": field_right_idx,
+            "right index (rounded)": int(round(field_right_idx)),
+            "right value (@rounded)": self._y_original_to_interp(round(field_right_idx)),
+            "field values": self._y_original_to_interp(x_indices_shifted[x_index_min: x_index_max + 1]),
+        }
+        if self.dpmm:
+            d = self.dpmm
+            out["width (exact) mm"] = out["width (exact)"] / d
+            out["left slope (%/mm)"] = out["left slope"] * d * 100
+            out["right slope (%/mm)"] = out["right slope"] * d * 100
+            out["left distance->beam center (exact) mm"] = abs(out["beam center index (exact)"] - out["left index (exact)"]) / d
+            out["right distance->beam center (exact) mm"] = abs(out["right index (exact)"] - out["beam center index (exact)"]) / d
+            out["left distance->CAX (exact) mm"] = abs(out["cax index (exact)"] - out["left index (exact)"]) / d
+            out["right distance->CAX (exact) mm"] = abs(out["cax index (exact)"] - out["right index (exact)"]) / d
+            out["left distance->top (exact) mm"] = abs(out['"top" index (exact)'] - out["left index (exact)"]) / d
+            out["right distance->top (exact) mm"] = abs(out['"top" index (exact)'] - out["right index (exact)"]) / d
+            out['"top"->beam center (exact) mm'] = (out['"top" index (exact)'] - out["beam center index (exact)"]) / d
+            out['"top"->CAX (exact) mm'] = abs(out['"top" index (exact)'] - out["cax index (exact)"]) / d
+        return out
+
+    def field_calculation(self, in_field_ratio: float = 0.8, calculation: str = "mean",
+                          slope_exclusion_ratio: float = 0.2):
+        """profile.py:1910-1937."""
+        fv = self.field_data(in_field_ratio, slope_exclusion_ratio=slope_exclusion_ratio)["field values"]
+        if calculation == "mean":
+            return fv.mean()
+        if calculation == "median":
+            return float(np.median(fv))
+        if calculation == "max":
+            return fv.max()
+        if calculation == "min":
+            return fv.min()
+
+
+def _linregress(x, y):
+    """slope / intercept of ``scipy.stats.linregress`` (ssxym / ssxm from the biased covariance matrix)."""
+    x = np.asarray(x, dtype=float)
+    y = np.asarray(y, dtype=float)
+    xmean, ymean = np.mean(x), np.mean(y)
+    ssxm, ssxym, _, _ = np.cov(x, y, bias=1).flat
+    slope = ssxym / ssxm
+    return slope, ymean - slope * xmean
+
+
+def _bounded_top(fit_params, x0: float, lo: float, hi: float):
+    """The reference maximises the fitted parabola with ``scipy.optimize.minimize(-p, x0, bounds)`` (L-BFGS-B,
+    profile.py:1537-1548) and reports wherever that stops -- on a flat top it can stop well short of the
+    vertex -- so the same routine is called here: one scalar problem per profile, on the host like the
+    reference."""
+    from scipy.optimize import minimize
+
+    def poly_func(x):
+        return -(fit_params[0] * (x**2) + fit_params[1] * x + fit_params[2])
+
+    min_f = minimize(poly_func, x0=(x0,), bounds=((lo, hi),))
+    return min_f.x[0], -min_f.fun

@@ -520,6 +520,70 @@ def main():
             sp[f"esf_{name}.in{i}"] = e
     np.savez_compressed(os.path.join(HERE, "spectral.npz"), **sp)
 
+    # ---- 10. SingleProfile (a11): the reference's 20 frozen profile fixtures x 6 resampling modes + EPID cases
+    import importlib.util
+
+    fa = ref_loader.ref("field_analysis")
+    spec = importlib.util.spec_from_file_location(
+        "profile_regression_fixtures", "/root/reference/tests_basic/core/profile_regression_fixtures.py")
+    fxm = importlib.util.module_from_spec(spec)
+    sys.modules["profile_regression_fixtures"] = fxm
+    spec.loader.exec_module(fxm)
+    calcs = {"varian_flatness_difference": fa.flatness_dose_difference,
+             "varian_symmetry_point_difference": fa.symmetry_point_difference,
+             "elekta_flatness_ratio": fa.flatness_dose_ratio, "elekta_symmetry_pdq": fa.symmetry_pdq_iec,
+             "siemens_flatness_difference": fa.flatness_dose_difference, "siemens_symmetry_area": fa.symmetry_area}
+    METRICS = list(calcs)
+    FIELD_KEYS = ["width (exact)", "beam center index (exact)", "beam center value (@rounded)", "cax index (exact)",
+                  "cax value (@rounded)", "left index (exact)", "left value (@rounded)", "left slope",
+                  "left intercept", "right slope", "right intercept", "left inner index (exact)",
+                  "right inner index (exact)", '"top" index (exact)', '"top" value (@exact)', "right index (exact)",
+                  "right value (@rounded)"]
+    FWXM_KEYS = ["width (exact)", "center index (exact)", "center value (@rounded)", "left index (exact)",
+                 "left value (@rounded)", "right index (exact)", "right value (@rounded)"]
+    sg = {"metric_names": np.array(METRICS), "field_keys": np.array(FIELD_KEYS), "fwxm_keys": np.array(FWXM_KEYS)}
+
+    def record(tag, p):
+        fd = p.field_data(in_field_ratio=0.8, slope_exclusion_ratio=0.2)
+        sg[f"{tag}.values"], sg[f"{tag}.x_indices"] = np.asarray(p.values, float), np.asarray(p.x_indices, float)
+        sg[f"{tag}.field"] = np.array([float(fd[k]) for k in FIELD_KEYS])
+        sg[f"{tag}.field_values"] = np.asarray(fd["field values"], float)
+        sg[f"{tag}.top_params"] = np.asarray(fd["top params"], float)
+        for hgt in (50, 25, 80):
+            fw = p.fwxm_data(hgt)
+            sg[f"{tag}.fwxm{hgt}"] = np.array([float(fw[k]) for k in FWXM_KEYS])
+            sg[f"{tag}.fwxm{hgt}_values"] = np.asarray(fw["field values"], float)
+        sg[f"{tag}.metrics"] = np.array([float(calcs[m](p, in_field_ratio=0.8)) for m in METRICS])
+
+    modes = {"none": (prof.Interpolation.NONE, True, "expected_metrics"),
+             "linear": (prof.Interpolation.LINEAR, True, "expected_metrics_linear"),
+             "spline": (prof.Interpolation.SPLINE, True, "expected_metrics_spline"),
+             "none_nox": (prof.Interpolation.NONE, False, "expected_metrics_no_x"),
+             "linear_nox": (prof.Interpolation.LINEAR, False, "expected_metrics_linear_no_x"),
+             "spline_nox": (prof.Interpolation.SPLINE, False, "expected_metrics_spline_no_x")}
+    sg["n_fixtures"] = np.int64(len(fxm.PROFILE_REGRESSION_FIXTURES))
+    for i, fx in enumerate(fxm.PROFILE_REGRESSION_FIXTURES):
+        sg[f"fx{i}.x"], sg[f"fx{i}.y"] = np.asarray(fx.x_values, float), np.asarray(fx.values, float)
+        # the reference's FROZEN expectations (tests_basic/core/test_profile.py:2546-2688; 1e-9 / 1e-4)
+        sg[f"fx{i}.frozen_field_keys"] = np.array(list(fx.expected_field_data))
+        sg[f"fx{i}.frozen_field"] = np.array([fx.expected_field_data[k] for k in fx.expected_field_data])
+        for mode, (interp, use_x, attr) in modes.items():
+            p = prof.SingleProfile(fx.values, x_values=fx.x_values if use_x else None, interpolation=interp)
+            record(f"fx{i}.{mode}", p)
+            frozen = getattr(fx, attr)
+            sg[f"fx{i}.{mode}.frozen_metrics"] = np.array([frozen[m] for m in METRICS])
+    # EPID-style profiles (pixel units, dpmm) through the options the fixtures do not touch
+    epid = np.mean(synth_frames(1, 96, 400, seed=91)[0][40:56].astype(float), axis=0)
+    opts = {"dpmm": dict(dpmm=1 / 0.336),
+            "dpmm_spline": dict(dpmm=1 / 0.336, interpolation="Spline", interpolation_resolution_mm=0.05),
+            "factor3": dict(interpolation_factor=3), "max": dict(normalization_method="Max"),
+            "geo": dict(normalization_method="Geometric center", centering="Geometric center"),
+            "raw": dict(normalization_method=None, ground=False, interpolation=None)}
+    sg["epid.y"] = epid
+    for name, kw in opts.items():
+        record(f"epid.{name}", prof.SingleProfile(epid.copy(), **kw))
+    np.savez_compressed(os.path.join(HERE, "single_profile.npz"), **sg)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

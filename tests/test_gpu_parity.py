@@ -1004,3 +1004,70 @@ def test_esf_mtf_vs_reference_golden(golden, dev):
         mtf.EdgeSpreadFunctionMTF([np.zeros(8)], padding_mode="fixed", num_samples=4, device=dev)
     with pytest.raises(ValueError):
         ideal.relative_resolution(101)
+
+
+# ------------------------------------------------------------------------------ SingleProfile (a11)
+def test_single_profile_vs_reference_frozen_fixtures(golden, dev):
+    """Device SingleProfile (pl_interp1d + ground/normalize kernels + pl_find_peaks) on the reference's 20 frozen
+    detector profiles x 6 resampling modes and on EPID-style profiles with dpmm / normalisation / centering
+    options: resampled values bit-identical for NONE / LINEAR, 1e-10 for SPLINE (not-a-knot spline computed
+    directly, scipy evaluates the B-spline form); every scalar of fwxm_data / field_data to 1e-9; the six
+    protocol metrics to 1e-9 of the reference run AND of the reference's frozen exports
+    (tests_basic/core/test_profile.py:2546-2688); frozen field geometry to 1e-4."""
+    from pylinac_amd import profile as pp
+    from tests.test_oracle_golden import _SP_EPID, _SP_MODES, _sp_calculators, _sp_check
+
+    g = golden("single_profile")
+    calcs = _sp_calculators()
+    for i in range(20):
+        for mode, (interp, use_x) in _SP_MODES.items():
+            p = pp.SingleProfile(g[f"fx{i}.y"], x_values=g[f"fx{i}.x"] if use_x else None, interpolation=interp)
+            vtol = 1e-10 if interp == "Spline" else 0
+            got, fd = _sp_check(g, f"fx{i}.{mode}", p, calcs, vtol=vtol, ftol=1e-9)
+            assert np.allclose(got, g[f"fx{i}.{mode}.frozen_metrics"], rtol=0, atol=1e-9), (i, mode)
+            if mode == "none":
+                for k, v in zip(g[f"fx{i}.frozen_field_keys"], g[f"fx{i}.frozen_field"]):
+                    assert abs(float(fd[str(k)]) - v) < 1e-4, (i, k)
+    for name, kw in _SP_EPID.items():
+        vtol = 1e-10 if kw.get("interpolation") == "Spline" else 0
+        p = pp.SingleProfile(g["epid.y"].copy(), **kw)
+        _sp_check(g, f"epid.{name}", p, calcs, vtol=vtol, ftol=1e-9)
+        if "dpmm" in kw:
+            fd = p.field_data()
+            assert abs(fd["width (exact) mm"] - fd["width (exact)"] / kw["dpmm"]) < 1e-12
+    # error behaviour
+    with pytest.raises(ValueError):
+        pp.SingleProfile(np.arange(10.0), x_values=np.arange(10.0)[::-1])
+    with pytest.raises(ValueError):
+        pp.SingleProfile(g["epid.y"]).field_data(in_field_ratio=0.2, slope_exclusion_ratio=0.5)
+    with pytest.raises(NotImplementedError):
+        pp.SingleProfile(g["epid.y"], edge_detection_method="Inflection Derivative")
+
+
+def test_interp1d_batch_vs_scipy(dev):
+    """pl_interp1d on a batch: shared and per-profile abscissae (non-uniform), extrapolation on both sides,
+    queries exactly on nodes; linear bit-identical to scipy's interp1d, cubic within 1e-10 relative."""
+    from scipy.interpolate import interp1d
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(4)
+    for length in (4, 5, 33, 257):
+        x = np.cumsum(rng.uniform(0.2, 1.7, (3, length)), axis=1)
+        y = 100 * np.exp(-((x - x.mean(1, keepdims=True)) / (0.2 * np.ptp(x, axis=1, keepdims=True))) ** 4) + \
+            rng.normal(0, 0.5, (3, length))
+        xq = np.sort(np.concatenate([np.linspace(x.min() - 0.4, x.max() + 0.4, 7 * length), x[0, ::3]]))
+        for kind in ("linear", "cubic"):
+            got = ops.interp1d(T(x, dev), T(y, dev), T(xq, dev), kind=kind).cpu().numpy()
+            ref = np.stack([interp1d(x[i], y[i], kind=kind, bounds_error=False, fill_value="extrapolate")(xq)
+                            for i in range(3)])
+            if kind == "linear":
+                assert np.array_equal(got, ref), length
+            else:
+                assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max(), length
+            shared = ops.interp1d(T(x[0], dev), T(y, dev), T(xq, dev), kind=kind).cpu().numpy()
+            ref0 = np.stack([interp1d(x[0], y[i], kind=kind, bounds_error=False, fill_value="extrapolate")(xq)
+                             for i in range(3)])
+            assert np.abs(shared - ref0).max() <= 1e-10 * np.abs(ref0).max()
+    with pytest.raises(Exception):
+        ops.interp1d(T(np.arange(3.0), dev), T(np.arange(3.0), dev), T(np.arange(3.0), dev), kind="cubic")
