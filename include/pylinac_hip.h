@@ -203,16 +203,29 @@ int pl_region_stats(const int32_t* d_labels, const double* d_intensity, int64_t 
  * `sample > cutoff` (pl_label), its label count and its region table (pl_region_stats, max_labels rows).
  * Every region that does not touch the frame and passes is_right_size_bb / is_round /
  * is_right_circumference / is_symmetric / is_solid appends its weighted centroid (x, y) to
- * d_xy float64 [n][8][2] unless it lies within min_sep_px of a point found at an EARLIER level;
- * d_count int32[n] (zeroed by the caller before level 0), d_prev_count int32[n] scratch,
+ * d_xy float64 [n][8][2] unless it lies within min_sep_px of a point accepted before it (earlier levels
+ * AND earlier regions of this level, in label order: metrics/utils.py:28-36 iterates the list it appends to);
+ * d_count int32[n] (zeroed by the caller before level 0),
  * d_level int32[n] (initialised to -1: first level with a hit), d_done int32[n] (zeroed; set once
  * d_count >= max_number, later calls skip the window), d_status int32[n] (0 ok; 1 label table
  * overflow, 2 > 32 candidate regions, 3 region bbox > 160 px, 4 > 8 features). */
 int pl_features_level(const double* d_sample, const int32_t* d_labels, const int32_t* d_nlabels,
                       const double* d_stats, int max_labels, int64_t n, int h, int w, double dpmm,
                       double radius_mm, double tol_mm, double min_sep_px, int max_number, int level,
-                      int32_t* d_done, int32_t* d_count, int32_t* d_prev_count, double* d_xy,
-                      int32_t* d_level, int32_t* d_status, void* stream);
+                      int32_t* d_done, int32_t* d_count, double* d_xy, int32_t* d_level, int32_t* d_status,
+                      void* stream);
+
+/* ---- a13 (fields): one threshold level of GlobalSizedFieldLocator.calculate (pylinac/metrics/image.py:817-897)
+ * Inputs per frame: the 8-connected label image of `sample > cutoff` (pl_label), its label count and region
+ * table (pl_region_stats).  Regions whose bbox keeps clear of the (buffer_size + 1)-pixel border band
+ * (segmentation.clear_border before labelling) and that pass is_right_square_perimeter and
+ * is_right_area_square (pylinac/metrics/features.py:69-101) append their UNWEIGHTED centroid (x, y) to
+ * d_xy [n][8][2] unless within max(equivalent_diameter of this level's hits) / dpmm of an accepted point.
+ * d_done / d_count / d_level / d_status as for pl_features_level. */
+int pl_fields_level(const int32_t* d_labels, const int32_t* d_nlabels, const double* d_stats, int max_labels,
+                    int64_t n, int h, int w, double dpmm, double field_width_mm, double field_height_mm,
+                    double field_tol_mm, int buffer_size, int max_number, int level, int32_t* d_done,
+                    int32_t* d_count, double* d_xy, int32_t* d_level, int32_t* d_status, void* stream);
 
 /* ---- a11: profile resampling -----------------------------------------------------------------------
  * scipy.interpolate.interp1d(x, y, kind, bounds_error=False, fill_value="extrapolate")(xq) as called by

@@ -790,8 +790,9 @@ def find_features_restated(sample: np.ndarray, dpmm: float, radius_mm: float, ra
             p = region_props_like_skimage(lab, k, s)
             if bb_predicates(p, dpmm, radius_mm, radius_tolerance_mm):
                 new.append((p["weighted_centroid"][1], p["weighted_centroid"][0]))
-        for pt in new:                                                           # deduplicate vs earlier levels
-            if all(math.hypot(pt[0] - q[0], pt[1] - q[1]) >= min_separation_mm * dpmm for q in total_before(total, new)):
+        for pt in new:   # deduplicate_points_and_boundaries (utils.py:14-38): `combined_points` ALIASES
+            # `original_points`, so a point accepted at this level already suppresses the next ones
+            if all(math.hypot(pt[0] - q[0], pt[1] - q[1]) >= min_separation_mm * dpmm for q in total):
                 total.append(pt)
         if new and found_level < 0:
             found_level = level
@@ -800,12 +801,6 @@ def find_features_restated(sample: np.ndarray, dpmm: float, radius_mm: float, ra
     if len(total) < min_number:
         raise ValueError(f"Couldn't find the minimum number of disks in the image. Found {len(total)}; required: {min_number}")
     return total, found_level
-
-
-def total_before(total, new):
-    """deduplicate_points_and_boundaries compares new points with the ORIGINAL list only
-    (pylinac/metrics/utils.py:14-38): points found at the same level never suppress each other."""
-    return [q for q in total if q not in new]
 
 
 # --------------------------------------------------------------------------------------
@@ -883,6 +878,48 @@ def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=Non
             pos[li, pi] = centre + max(approx_idx - picket_spacing / 2, 0)
     return dict(peak_idxs=np.asarray(peak_idxs), peak_vals=np.asarray(peak_vals), spacing=float(picket_spacing),
                 leaves=in_view, position=pos)
+
+
+# --------------------------------------------------------------------------------------
+# a13 (fields): GlobalSizedFieldLocator -- skimage 0.18.3 regionprops restated, scipy labelling
+# --------------------------------------------------------------------------------------
+def find_fields_restated(sample: np.ndarray, dpmm: float, field_width_mm: float, field_height_mm: float,
+                         field_tolerance_mm: float, max_number: int | None = None, min_number: int = 1):
+    """pylinac/metrics/image.py:817-897 (from_physical): threshold ladder from 10 % height, clear_border(3),
+    8-connected label, is_right_square_perimeter + is_right_area_square (metrics/features.py:69-101), unweighted
+    centroid (x, y), de-duplication radius max(equivalent_diameter) / dpmm.  Returns (points, first level)."""
+    max_number = max_number or 1e6
+    imin, imax = sample.min(), sample.max()
+    step = (imax - imin) / 50
+    cutoff = imin + step * 5
+    fields, level, found = [], 0, -1
+    fw, fh, ft = field_width_mm, field_height_mm, field_tolerance_mm
+    while cutoff <= imax and len(fields) < max_number:
+        bw = clear_border_like_skimage(sample > cutoff, 3)
+        lab, n = ndimage.label(bw, structure=np.ones((3, 3)))
+        hits = []
+        for k in range(1, n + 1):
+            rr, cc = np.nonzero(lab == k)
+            crop = (lab == k)[rr.min(): rr.max() + 1, cc.min(): cc.max() + 1]
+            filled = ndimage.binary_fill_holes(crop, structure=np.ones((3, 3))).sum()
+            per_mm = perimeter_like_skimage(crop) / dpmm
+            upper = 1.20 * 2 * (fw + ft) + 2 * (fh + ft)
+            lower = 2 * (fw - ft) + 2 * (fh - ft)
+            area_mm = filled / (dpmm**2)
+            if upper > per_mm > lower and (fw - ft) * (fh - ft) < area_mm < (fw + ft) * (fh + ft):
+                hits.append((cc.mean(), rr.mean(), math.sqrt(4 * len(rr) / math.pi)))
+        if hits:
+            sep = max(hh[2] for hh in hits) / dpmm
+            for x, y, _ in hits:
+                if all(math.hypot(x - q[0], y - q[1]) >= sep for q in fields):
+                    fields.append((x, y))
+                    if found < 0:
+                        found = level
+        cutoff += step
+        level += 1
+    if len(fields) < min_number:
+        raise ValueError(f"Couldn't find the minimum number of fields in the image. Found {len(fields)}; required: {min_number}")
+    return fields, found
 
 
 # --------------------------------------------------------------------------------------

@@ -29,19 +29,26 @@ constexpr int kMaxHullPts = 8 * kMaxCrop;
 constexpr int kMaxOut = 8;
 
 struct FeatureParams {
-  double dpmm, radius_mm, tol_mm, min_sep_px;
+  double dpmm, radius_mm, tol_mm, min_sep_px;   // field mode: radius_mm = field width, min_sep_px = field height
   int max_number;
+  int border;                                   // field mode: clear_border band (buffer_size + 1)
 };
 
 __device__ __forceinline__ long long cross2(int ax, int ay, int bx, int by, int cx, int cy) {
   return (long long)(bx - ax) * (cy - ay) - (long long)(by - ay) * (cx - ax);
 }
 
+// FIELD = false: the BB finder above.  FIELD = true: one level of GlobalSizedFieldLocator.calculate
+// (pylinac/metrics/image.py:817-897): 8-connected labels of `sample > cutoff` whose bbox keeps clear of the
+// border band (segmentation.clear_border(buffer_size=3) before labelling), predicates
+// is_right_square_perimeter and is_right_area_square (metrics/features.py:69-101), UNWEIGHTED centroid,
+// de-duplication radius max(equivalent_diameter of this level's hits) / dpmm.
+template <bool FIELD>
 __global__ void __launch_bounds__(kThreads)
 features_level_kernel(const double* __restrict__ sample, const int32_t* __restrict__ labels,
                       const int32_t* __restrict__ nlabels, const double* __restrict__ stats, int max_labels,
                       int h, int w, FeatureParams prm, int level, int32_t* __restrict__ done,
-                      int32_t* __restrict__ out_count, int32_t* __restrict__ prev_count,
+                      int32_t* __restrict__ out_count,
                       double* __restrict__ out_xy, int32_t* __restrict__ out_level, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_cand[32];
@@ -51,6 +58,9 @@ features_level_kernel(const double* __restrict__ sample, const int32_t* __restri
   __shared__ int s_nh;
   __shared__ int s_cnt[4];                                  // holes changed flag / n1 / n2 / n3
   __shared__ double s_red[3][kThreads / PL_WAVE];
+  __shared__ double s_hit[32][3];                           // field mode: x, y, equivalent diameter of this level's hits
+  __shared__ int s_nhit;
+  __shared__ int s_inside;
   const int64_t img = blockIdx.x;
   if (done[img]) return;
   const int nl = nlabels[img] < max_labels ? nlabels[img] : max_labels;
@@ -63,7 +73,7 @@ features_level_kernel(const double* __restrict__ sample, const int32_t* __restri
   const double larger = pi * ((prm.radius_mm + prm.tol_mm) * (prm.radius_mm + prm.tol_mm));
   double smaller = pi * ((prm.radius_mm - prm.tol_mm) * (prm.radius_mm - prm.tol_mm));
   if (!(smaller > 2.0)) smaller = 2.0;                      // max((pi*(r-t)**2, 2))
-  if (threadIdx.x == 0) { s_ncand = 0; prev_count[img] = out_count[img]; }
+  if (threadIdx.x == 0) { s_ncand = 0; s_nhit = 0; }
   __syncthreads();
   // ---- candidate labels: necessary conditions from (area, bbox) only -----------------------------
   for (int k = threadIdx.x; k < nl; k += kThreads) {
@@ -71,14 +81,23 @@ features_level_kernel(const double* __restrict__ sample, const int32_t* __restri
     const double area = s[0];
     if (area < 1.0) continue;
     const int r0 = (int)s[1], c0 = (int)s[2], r1 = (int)s[3], c1 = (int)s[4];
-    if (r0 == 0 || c0 == 0 || r1 == h || c1 == w) continue;          // clear_border
     const double bbox_area = (double)(r1 - r0) * (double)(c1 - c0);
-    if (!(area / dp2 < larger)) continue;                            // filled_area >= area
-    if (!(bbox_area / dp2 > smaller)) continue;                      // filled_area <= bbox_area
-    const double y = (double)(r1 - r0), x = (double)(c1 - c0);       // is_symmetric (features.py:7-14)
-    const double hi = (y * 1.05 > y + 3) ? y * 1.05 : y + 3, lo = (y * 0.95 < y - 3) ? y * 0.95 : y - 3;
-    if (x > hi || x < lo) continue;
-    if (!(area / bbox_area < pi / 4 * 1.2)) continue;                // is_round upper bound needs filled >= area
+    if constexpr (FIELD) {
+      const int b = prm.border;
+      if (r0 < b || c0 < b || r1 > h - b || c1 > w - b) continue;    // clear_border(buffer_size = b - 1)
+      const double lo_a = (prm.radius_mm - prm.tol_mm) * (prm.min_sep_px - prm.tol_mm);
+      const double hi_a = (prm.radius_mm + prm.tol_mm) * (prm.min_sep_px + prm.tol_mm);
+      if (!(area / dp2 < hi_a)) continue;                              // filled_area >= area
+      if (!(bbox_area / dp2 > lo_a)) continue;                         // filled_area <= bbox_area
+    } else {
+      if (r0 == 0 || c0 == 0 || r1 == h || c1 == w) continue;          // clear_border
+      if (!(area / dp2 < larger)) continue;                            // filled_area >= area
+      if (!(bbox_area / dp2 > smaller)) continue;                      // filled_area <= bbox_area
+      const double y = (double)(r1 - r0), x = (double)(c1 - c0);       // is_symmetric (features.py:7-14)
+      const double hi = (y * 1.05 > y + 3) ? y * 1.05 : y + 3, lo = (y * 0.95 < y - 3) ? y * 0.95 : y - 3;
+      if (x > hi || x < lo) continue;
+      if (!(area / bbox_area < pi / 4 * 1.2)) continue;                // is_round upper bound needs filled >= area
+    }
     const int slot = atomicAdd(&s_ncand, 1);
     if (slot < 32) s_cand[slot] = k;
   }
@@ -148,9 +167,11 @@ features_level_kernel(const double* __restrict__ sample, const int32_t* __restri
         else if (code == 21 || code == 33) ++n2;
         else if (code == 13 || code == 23) ++n3;
       }
-      if (m[e]) {
-        const double v = smp[(int64_t)(r0 + r) * w + c0 + c];
-        w0 += v; wr += v * (double)r; wc += v * (double)c;
+      if constexpr (!FIELD) {
+        if (m[e]) {
+          const double v = smp[(int64_t)(r0 + r) * w + c0 + c];
+          w0 += v; wr += v * (double)r; wc += v * (double)c;
+        }
       }
     }
     auto addi = [](int a, int b) { return a + b; };
@@ -162,109 +183,154 @@ features_level_kernel(const double* __restrict__ sample, const int32_t* __restri
       atomicAdd(&s_cnt[0], holes); atomicAdd(&s_cnt[1], n1); atomicAdd(&s_cnt[2], n2); atomicAdd(&s_cnt[3], n3);
       s_red[0][wv] = w0; s_red[1][wv] = wr; s_red[2][wv] = wc;
     }
-    // ---- convex hull candidates: mid-edge points of the row-extreme pixels -------------------------
-    for (int r = threadIdx.x; r < ch; r += kThreads) {
-      int cl = -1, cr = -1;
-      for (int c = 0; c < cw; ++c) if (m[r * cw + c]) { if (cl < 0) cl = c; cr = c; }
-      int* px = s_hx + r * 8; int* py = s_hy + r * 8;
-      // a crop row always holds at least one region pixel?  no (concave shapes): mark unused slots
-      for (int q = 0; q < 8; ++q) { px[q] = 0x7fffffff; py[q] = 0; }
-      if (cl >= 0) {
-        const int xs[2] = {cl, cr};
-        for (int q = 0; q < 2; ++q) {
-          const int X = 2 * r, Y = 2 * xs[q];
-          px[4 * q + 0] = X;     py[4 * q + 0] = Y - 1;
-          px[4 * q + 1] = X;     py[4 * q + 1] = Y + 1;
-          px[4 * q + 2] = X - 1; py[4 * q + 2] = Y;
-          px[4 * q + 3] = X + 1; py[4 * q + 3] = Y;
+    if constexpr (!FIELD) {
+      // ---- convex hull candidates: mid-edge points of the row-extreme pixels -------------------------
+      for (int r = threadIdx.x; r < ch; r += kThreads) {
+        int cl = -1, cr = -1;
+        for (int c = 0; c < cw; ++c) if (m[r * cw + c]) { if (cl < 0) cl = c; cr = c; }
+        int* px = s_hx + r * 8; int* py = s_hy + r * 8;
+        // a crop row always holds at least one region pixel?  no (concave shapes): mark unused slots
+        for (int q = 0; q < 8; ++q) { px[q] = 0x7fffffff; py[q] = 0; }
+        if (cl >= 0) {
+          const int xs[2] = {cl, cr};
+          for (int q = 0; q < 2; ++q) {
+            const int X = 2 * r, Y = 2 * xs[q];
+            px[4 * q + 0] = X;     py[4 * q + 0] = Y - 1;
+            px[4 * q + 1] = X;     py[4 * q + 1] = Y + 1;
+            px[4 * q + 2] = X - 1; py[4 * q + 2] = Y;
+            px[4 * q + 3] = X + 1; py[4 * q + 3] = Y;
+          }
         }
       }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        // sort the <= 8*ch points by (x, y) (insertion sort: points arrive nearly sorted), then Andrew's chain
+        const int np = ch * 8;
+        for (int a = 1; a < np; ++a) {
+          const int vx = s_hx[a], vy = s_hy[a];
+          int b = a - 1;
+          while (b >= 0 && (s_hx[b] > vx || (s_hx[b] == vx && s_hy[b] > vy))) { s_hx[b + 1] = s_hx[b]; s_hy[b + 1] = s_hy[b]; --b; }
+          s_hx[b + 1] = vx; s_hy[b + 1] = vy;
+        }
+        int n = 0;
+        while (n < np && s_hx[n] != 0x7fffffff) ++n;
+        // drop duplicates
+        int u = 0;
+        for (int a = 0; a < n; ++a) if (a == 0 || s_hx[a] != s_hx[a - 1] || s_hy[a] != s_hy[a - 1]) { s_hx[u] = s_hx[a]; s_hy[u] = s_hy[a]; ++u; }
+        n = u;
+        int kk = 0;
+        for (int a = 0; a < n; ++a) {           // lower chain
+          while (kk >= 2 && cross2(s_hull_x[kk - 2], s_hull_y[kk - 2], s_hull_x[kk - 1], s_hull_y[kk - 1], s_hx[a], s_hy[a]) <= 0) --kk;
+          s_hull_x[kk] = s_hx[a]; s_hull_y[kk] = s_hy[a]; ++kk;
+        }
+        const int lower = kk + 1;
+        for (int a = n - 2; a >= 0; --a) {      // upper chain
+          while (kk >= lower && cross2(s_hull_x[kk - 2], s_hull_y[kk - 2], s_hull_x[kk - 1], s_hull_y[kk - 1], s_hx[a], s_hy[a]) <= 0) --kk;
+          s_hull_x[kk] = s_hx[a]; s_hull_y[kk] = s_hy[a]; ++kk;
+        }
+        s_nh = kk - 1;                          // last point == first point
+      }
+      __syncthreads();
+      const int nh = s_nh;
+      int inside = 0;
+      for (int e = threadIdx.x; e < npx; e += kThreads) {
+        const int X = 2 * (e / cw), Y = 2 * (e % cw);
+        bool in = true;
+        for (int a = 0; a < nh && in; ++a) {
+          const int b = (a + 1 == nh) ? 0 : a + 1;
+          in = cross2(s_hull_x[a], s_hull_y[a], s_hull_x[b], s_hull_y[b], X, Y) >= 0;
+        }
+        inside += in ? 1 : 0;
+      }
+      inside = pl_wave_reduce(inside, addi);
+      if (threadIdx.x == 0) s_inside = 0;
+      __syncthreads();
+      if (lane == 0) atomicAdd(&s_inside, inside);
+      __syncthreads();
+    } else {
+      __syncthreads();   // s_cnt / s_red complete
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      // sort the <= 8*ch points by (x, y) (insertion sort: points arrive nearly sorted), then Andrew's chain
-      const int np = ch * 8;
-      for (int a = 1; a < np; ++a) {
-        const int vx = s_hx[a], vy = s_hy[a];
-        int b = a - 1;
-        while (b >= 0 && (s_hx[b] > vx || (s_hx[b] == vx && s_hy[b] > vy))) { s_hx[b + 1] = s_hx[b]; s_hy[b + 1] = s_hy[b]; --b; }
-        s_hx[b + 1] = vx; s_hy[b + 1] = vy;
-      }
-      int n = 0;
-      while (n < np && s_hx[n] != 0x7fffffff) ++n;
-      // drop duplicates
-      int u = 0;
-      for (int a = 0; a < n; ++a) if (a == 0 || s_hx[a] != s_hx[a - 1] || s_hy[a] != s_hy[a - 1]) { s_hx[u] = s_hx[a]; s_hy[u] = s_hy[a]; ++u; }
-      n = u;
-      int kk = 0;
-      for (int a = 0; a < n; ++a) {           // lower chain
-        while (kk >= 2 && cross2(s_hull_x[kk - 2], s_hull_y[kk - 2], s_hull_x[kk - 1], s_hull_y[kk - 1], s_hx[a], s_hy[a]) <= 0) --kk;
-        s_hull_x[kk] = s_hx[a]; s_hull_y[kk] = s_hy[a]; ++kk;
-      }
-      const int lower = kk + 1;
-      for (int a = n - 2; a >= 0; --a) {      // upper chain
-        while (kk >= lower && cross2(s_hull_x[kk - 2], s_hull_y[kk - 2], s_hull_x[kk - 1], s_hull_y[kk - 1], s_hx[a], s_hy[a]) <= 0) --kk;
-        s_hull_x[kk] = s_hx[a]; s_hull_y[kk] = s_hy[a]; ++kk;
-      }
-      s_nh = kk - 1;                          // last point == first point
-    }
-    __syncthreads();
-    const int nh = s_nh;
-    int inside = 0;
-    for (int e = threadIdx.x; e < npx; e += kThreads) {
-      const int X = 2 * (e / cw), Y = 2 * (e % cw);
-      bool in = true;
-      for (int a = 0; a < nh && in; ++a) {
-        const int b = (a + 1 == nh) ? 0 : a + 1;
-        in = cross2(s_hull_x[a], s_hull_y[a], s_hull_x[b], s_hull_y[b], X, Y) >= 0;
-      }
-      inside += in ? 1 : 0;
-    }
-    inside = pl_wave_reduce(inside, addi);
-    __shared__ int s_inside;
-    if (threadIdx.x == 0) s_inside = 0;
-    __syncthreads();
-    if (lane == 0) atomicAdd(&s_inside, inside);
-    __syncthreads();
     // ---- predicates (pylinac/metrics/features.py) and output ---------------------------------------
     if (threadIdx.x == 0) {
       const double area = s[0];
       const double filled = area + (double)s_cnt[0];
-      const double bbox_area = (double)ch * (double)cw;
-      bool ok = true;
-      const double bb_area = filled / dp2;
-      ok = ok && (smaller < bb_area && bb_area < larger);                            // is_right_size_bb
-      const double ratio = filled / bbox_area;
-      ok = ok && (pi / 4 * 1.2 > ratio && ratio > pi / 4 * 0.8);                     // is_round
       const double perim = ((double)s_cnt[1] * 1.0 + (double)s_cnt[2] * 1.4142135623730951) +
                            (double)s_cnt[3] * ((1 + 1.4142135623730951) / 2);
       const double per_mm = perim / prm.dpmm;
-      ok = ok && (2 * pi * (prm.radius_mm + prm.tol_mm) > per_mm && per_mm > 2 * pi * (prm.radius_mm - prm.tol_mm));
-      ok = ok && (area / (double)s_inside > 0.9);                                    // is_solid
-      if (ok) {
-        double m0 = 0.0, mr = 0.0, mc = 0.0;
-        for (int q = 0; q < kThreads / PL_WAVE; ++q) { m0 += s_red[0][q]; mr += s_red[1][q]; mc += s_red[2][q]; }
-        const double py = mr / m0 + (double)r0, px = mc / m0 + (double)c0;
-        // de-duplicate against the points of EARLIER levels only (metrics/utils.py:14-38)
-        bool keep = true;
-        for (int q = 0; q < prev_count[img]; ++q) {
-          const double dx = px - out_xy[(img * kMaxOut + q) * 2], dy = py - out_xy[(img * kMaxOut + q) * 2 + 1];
-          if (sqrt(dx * dx + dy * dy) < prm.min_sep_px) { keep = false; break; }
+      if constexpr (FIELD) {
+        const double fw = prm.radius_mm, fh = prm.min_sep_px, ft = prm.tol_mm;
+        const double upper = 1.20 * 2 * (fw + ft) + 2 * (fh + ft);   // precedence as written, features.py:75-77
+        const double lower = 2 * (fw - ft) + 2 * (fh - ft);
+        bool ok = upper > per_mm && per_mm > lower;                                      // is_right_square_perimeter
+        const double field_area = filled / dp2;
+        ok = ok && ((fw - ft) * (fh - ft) < field_area && field_area < (fw + ft) * (fh + ft));  // is_right_area_square
+        if (ok && s_nhit < 32) {
+          s_hit[s_nhit][0] = s[6] / area;                 // centroid[1] = mean column
+          s_hit[s_nhit][1] = s[5] / area;                 // centroid[0] = mean row
+          s_hit[s_nhit][2] = sqrt(4.0 * area / pi);       // equivalent_diameter_area
+          ++s_nhit;
         }
-        if (keep) {
-          const int slot = out_count[img];
-          if (slot < kMaxOut) {
-            out_xy[(img * kMaxOut + slot) * 2] = px;
-            out_xy[(img * kMaxOut + slot) * 2 + 1] = py;
-            out_count[img] = slot + 1;
-            if (out_level[img] < 0) out_level[img] = level;
-          } else {
-            status[img] = 4;
+      } else {
+        const double bbox_area = (double)ch * (double)cw;
+        bool ok = true;
+        const double bb_area = filled / dp2;
+        ok = ok && (smaller < bb_area && bb_area < larger);                            // is_right_size_bb
+        const double ratio = filled / bbox_area;
+        ok = ok && (pi / 4 * 1.2 > ratio && ratio > pi / 4 * 0.8);                     // is_round
+        ok = ok && (2 * pi * (prm.radius_mm + prm.tol_mm) > per_mm && per_mm > 2 * pi * (prm.radius_mm - prm.tol_mm));
+        ok = ok && (area / (double)s_inside > 0.9);                                    // is_solid
+        if (ok) {
+          double m0 = 0.0, mr = 0.0, mc = 0.0;
+          for (int q = 0; q < kThreads / PL_WAVE; ++q) { m0 += s_red[0][q]; mr += s_red[1][q]; mc += s_red[2][q]; }
+          const double py = mr / m0 + (double)r0, px = mc / m0 + (double)c0;
+          // de-duplicate against every point accepted so far, INCLUDING this level's (metrics/utils.py:28-36:
+          // `combined_points` aliases `original_points`, so the list being iterated grows; candidates come in
+          // label order, which is the order regionprops yields them in)
+          bool keep = true;
+          for (int q = 0; q < out_count[img]; ++q) {
+            const double dx = px - out_xy[(img * kMaxOut + q) * 2], dy = py - out_xy[(img * kMaxOut + q) * 2 + 1];
+            if (sqrt(dx * dx + dy * dy) < prm.min_sep_px) { keep = false; break; }
+          }
+          if (keep) {
+            const int slot = out_count[img];
+            if (slot < kMaxOut) {
+              out_xy[(img * kMaxOut + slot) * 2] = px;
+              out_xy[(img * kMaxOut + slot) * 2 + 1] = py;
+              out_count[img] = slot + 1;
+              if (out_level[img] < 0) out_level[img] = level;
+            } else {
+              status[img] = 4;
+            }
           }
         }
       }
     }
     __syncthreads();
+  }
+  if constexpr (FIELD) {
+    if (threadIdx.x == 0 && s_nhit > 0) {
+      double sep = 0.0;                                    // max(r.equivalent_diameter_area) / dpmm (image.py:876-879)
+      for (int q = 0; q < s_nhit; ++q) sep = s_hit[q][2] > sep ? s_hit[q][2] : sep;
+      sep /= prm.dpmm;
+      for (int a = 0; a < s_nhit; ++a) {
+        bool keep = true;
+        for (int q = 0; q < out_count[img]; ++q) {
+          const double dx = s_hit[a][0] - out_xy[(img * kMaxOut + q) * 2];
+          const double dy = s_hit[a][1] - out_xy[(img * kMaxOut + q) * 2 + 1];
+          if (sqrt(dx * dx + dy * dy) < sep) { keep = false; break; }
+        }
+        if (!keep) continue;
+        const int slot = out_count[img];
+        if (slot < kMaxOut) {
+          out_xy[(img * kMaxOut + slot) * 2] = s_hit[a][0];
+          out_xy[(img * kMaxOut + slot) * 2 + 1] = s_hit[a][1];
+          out_count[img] = slot + 1;
+          if (out_level[img] < 0) out_level[img] = level;
+        } else {
+          status[img] = 4;
+        }
+      }
+    }
   }
   if (threadIdx.x == 0 && out_count[img] >= prm.max_number) done[img] = 1;
 }
@@ -274,24 +340,48 @@ features_level_kernel(const double* __restrict__ sample, const int32_t* __restri
 extern "C" int pl_features_level(const double* d_sample, const int32_t* d_labels, const int32_t* d_nlabels,
                                  const double* d_stats, int max_labels, int64_t n, int h, int w, double dpmm,
                                  double radius_mm, double tol_mm, double min_sep_px, int max_number, int level,
-                                 int32_t* d_done, int32_t* d_count, int32_t* d_prev_count, double* d_xy,
+                                 int32_t* d_done, int32_t* d_count, double* d_xy,
                                  int32_t* d_level, int32_t* d_status, void* stream) {
-  PL_REQUIRE(d_sample && d_labels && d_nlabels && d_stats && d_done && d_count && d_prev_count && d_xy && d_level &&
+  PL_REQUIRE(d_sample && d_labels && d_nlabels && d_stats && d_done && d_count && d_xy && d_level &&
                  d_status, "null pointer");
   PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && h > 0 && w > 0 && max_labels > 0 && max_number > 0, "bad arguments");
   PL_REQUIRE(dpmm > 0 && radius_mm > 0, "bad physical parameters");
   if (n == 0) return PL_OK;
-  FeatureParams prm{dpmm, radius_mm, tol_mm, min_sep_px, max_number};
+  FeatureParams prm{dpmm, radius_mm, tol_mm, min_sep_px, max_number, 0};
   const size_t lds = (size_t)3 * kMaxCrop * kMaxCrop;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)features_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)features_level_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { pl_set_error("pl_features_level: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
     attr = true;
   }
-  hipLaunchKernelGGL(features_level_kernel, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_sample,
-                     d_labels, d_nlabels, d_stats, max_labels, h, w, prm, level, d_done, d_count, d_prev_count, d_xy,
+  hipLaunchKernelGGL(features_level_kernel<false>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream,
+                     d_sample, d_labels, d_nlabels, d_stats, max_labels, h, w, prm, level, d_done, d_count, d_xy,
                      d_level, d_status);
   return pl_check_launch("pl_features_level");
+}
+
+extern "C" int pl_fields_level(const int32_t* d_labels, const int32_t* d_nlabels, const double* d_stats,
+                               int max_labels, int64_t n, int h, int w, double dpmm, double field_width_mm,
+                               double field_height_mm, double field_tol_mm, int buffer_size, int max_number,
+                               int level, int32_t* d_done, int32_t* d_count, double* d_xy, int32_t* d_level,
+                               int32_t* d_status, void* stream) {
+  PL_REQUIRE(d_labels && d_nlabels && d_stats && d_done && d_count && d_xy && d_level && d_status, "null pointer");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && h > 0 && w > 0 && max_labels > 0 && max_number > 0, "bad arguments");
+  PL_REQUIRE(dpmm > 0 && field_width_mm > 0 && field_height_mm > 0 && buffer_size >= 0, "bad physical parameters");
+  if (n == 0) return PL_OK;
+  FeatureParams prm{dpmm, field_width_mm, field_tol_mm, field_height_mm, max_number, buffer_size + 1};
+  const size_t lds = (size_t)3 * kMaxCrop * kMaxCrop;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)features_level_kernel<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { pl_set_error("pl_fields_level: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+    attr = true;
+  }
+  hipLaunchKernelGGL(features_level_kernel<true>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream,
+                     (const double*)nullptr, d_labels, d_nlabels, d_stats, max_labels, h, w, prm, level, d_done,
+                     d_count, d_xy, d_level, d_status);
+  return pl_check_launch("pl_fields_level");
 }

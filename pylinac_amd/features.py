@@ -52,7 +52,6 @@ def find_features_batch(samples: torch.Tensor, dpmm: float, radius_mm: float, ra
     lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
     done = torch.zeros(n, dtype=torch.int32, device=dev)
     count = torch.zeros(n, dtype=torch.int32, device=dev)
-    prev = torch.zeros(n, dtype=torch.int32, device=dev)
     level = torch.full((n,), -1, dtype=torch.int32, device=dev)
     status = torch.zeros(n, dtype=torch.int32, device=dev)
     xy = torch.zeros((n, 8, 2), dtype=torch.float64, device=dev)
@@ -63,7 +62,7 @@ def find_features_batch(samples: torch.Tensor, dpmm: float, radius_mm: float, ra
         check(lib.pl_features_level(s.data_ptr(), labels.data_ptr(), num.data_ptr(), stats.data_ptr(), max_labels, n, h,
                                     w, float(dpmm), float(radius_mm), float(radius_tolerance_mm),
                                     float(min_separation_mm * dpmm), int(max_number), lvl, done.data_ptr(),
-                                    count.data_ptr(), prev.data_ptr(), xy.data_ptr(), level.data_ptr(),
+                                    count.data_ptr(), xy.data_ptr(), level.data_ptr(),
                                     status.data_ptr(), st), "pl_features_level")
         if poll_every and (lvl + 1) % poll_every == 0 and bool(done.all()):
             break
@@ -96,3 +95,58 @@ def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float,
     res["xy"] = res["xy"] + torch.tensor([left, top], dtype=torch.float64, device=x.device)
     res["window"] = (top, bottom, left, right)
     return res
+
+
+def field_cutoffs(imin: float, imax: float) -> list[float]:
+    """The threshold ladder of GlobalSizedFieldLocator.calculate (pylinac/metrics/image.py:836-842, 889):
+    50 steps of the spread, starting at 10 % height, accumulated by repeated addition like the reference."""
+    step = (imax - imin) / 50
+    cutoff = imin + step * 5
+    out = []
+    while cutoff <= imax and len(out) < 64:
+        out.append(cutoff)
+        cutoff += step
+    return out
+
+
+def find_fields_batch(frames: torch.Tensor, dpmm: float, field_width_mm: float, field_height_mm: float,
+                      field_tolerance_mm: float, max_number: int | None = None, is_from_physical: bool = True,
+                      max_labels: int = 4096):
+    """Batched ``GlobalSizedFieldLocator.calculate`` (pylinac/metrics/image.py:817-897; driven for multi-target WL
+    at pylinac/winston_lutz.py:2734-2766) -> dict(xy float64 [N,8,2] (x, y), count, level, status int32 [N]).
+
+    Per level: ``frame > cutoff`` -> 8-connected labels -> region table -> ``pl_fields_level`` (border band,
+    perimeter / filled-area predicates, unweighted centroid, the level's own de-duplication radius).  A frame stops
+    once ``max_number`` fields are found; ``count < min_number`` is the reference's ValueError, reported per frame.
+    """
+    f = ops._frames(frames)
+    n, h, w = f.shape
+    dev = f.device
+    if not is_from_physical:                       # image.py:829-832: sizes given in pixels
+        field_width_mm, field_height_mm = field_width_mm / dpmm, field_height_mm / dpmm
+        field_tolerance_mm = field_tolerance_mm / dpmm
+    max_number = int(max_number or 8)
+    if max_number > 8:
+        raise ValueError("at most 8 fields per frame are reported")
+    mn, mx = ops.minmax(f)
+    lad = [field_cutoffs(a, b) for a, b in zip(mn.cpu().tolist(), mx.cpu().tolist())]
+    levels = max((len(x) for x in lad), default=0)
+    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    done = torch.zeros(n, dtype=torch.int32, device=dev)
+    count = torch.zeros(n, dtype=torch.int32, device=dev)
+    level = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    xy = torch.zeros((n, 8, 2), dtype=torch.float64, device=dev)
+    for lvl in range(levels):
+        # a frame whose ladder ended gets +inf: an empty mask, like the reference's finished while-loop
+        cut = torch.tensor([x[lvl] if lvl < len(x) else float("inf") for x in lad], dtype=torch.float64, device=dev)
+        bw = ops.compare(f, cut, ">")
+        labels, num = ops.label(bw, 8)
+        stats, _ = ops.region_stats(labels, None, max_labels)
+        check(lib.pl_fields_level(labels.data_ptr(), num.data_ptr(), stats.data_ptr(), max_labels, n, h, w,
+                                  float(dpmm), float(field_width_mm), float(field_height_mm),
+                                  float(field_tolerance_mm), 3, max_number, lvl, done.data_ptr(), count.data_ptr(),
+                                  xy.data_ptr(), level.data_ptr(), status.data_ptr(), st), "pl_fields_level")
+        if (lvl + 1) % 8 == 0 and bool(done.all()):
+            break
+    return dict(xy=xy, count=count, level=level, status=status)

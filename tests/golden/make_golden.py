@@ -140,9 +140,45 @@ def bb_windows(n, seed):
         img[np.hypot(y - cy, x - cx) < 2.5 * dpmm] = 0.35
         if i == 2:
             img[int(cy):, int(cx) - 1:int(cx) + 2] = 0.5       # BB rod: spiculated region
+        if i in (4, 5):   # a second BB 8 mm (i == 4) / 20 mm (i == 5) to the right: same-level duplicates
+            sep = (8 if i == 4 else 20) * dpmm
+            cx = size / 2 - sep / 2
+            cy = size / 2
+            img = np.full((size, size), 0.92)
+            img[np.hypot(y - cy, x - cx) < 2.5 * dpmm] = 0.35
+            img[np.hypot(y - cy - 1.3, x - cx - sep) < 2.5 * dpmm] = 0.35
         img = ndi.gaussian_filter(img, 1.2) + rng.normal(0, 0.004, img.shape)
         out.append(img)
     return out, dpmm
+
+
+def field_frames(seed):
+    """Multi-target WL style frames (float64, normalised): several small square fields on a dark background,
+    one of them touching the border band, one of the wrong size, one with an interior BB shadow (a hole at high
+    thresholds), mild blur + noise.  Returns frames, dpmm and per-frame locator arguments."""
+    from scipy import ndimage as ndi
+
+    rng = np.random.default_rng(seed)
+    dpmm = 1 / 0.336
+    frames, args = [], []
+    for i in range(3):
+        h, w = (420, 560) if i != 2 else (300, 300)
+        img = np.full((h, w), 0.04)
+        side = 15 * dpmm
+        centres = [(110, 130), (300, 150), (200, 400)] if i != 2 else [(150, 150)]
+        if i == 1:
+            centres += [(int(side / 2) + 2, 300)]                   # inside the clear_border band -> ignored
+            img[330:330 + int(8 * dpmm), 450:450 + int(8 * dpmm)] = 0.9   # 8 mm field: wrong size
+        for (cy, cx) in centres:
+            cy, cx = cy + rng.uniform(-0.5, 0.5), cx + rng.uniform(-0.5, 0.5)
+            y, x = np.mgrid[0:h, 0:w].astype(float)
+            sq = (np.abs(y - cy) < side / 2) & (np.abs(x - cx) < side / 2)
+            img[sq] = 0.8 + 0.15 * rng.uniform()
+            img[np.hypot(y - cy - 2, x - cx + 3) < 2.5 * dpmm] *= 0.55     # BB shadow inside the field
+        img = ndi.gaussian_filter(img, 1.5) + rng.normal(0, 0.006, img.shape)
+        frames.append(img)
+        args.append(dict(fw=15.0, fh=15.0, tol=3.0 if i != 2 else 1.5, maxn=3 if i != 2 else 1))
+    return frames, dpmm, args
 
 
 def skimage_otsu(arrays: dict) -> dict:
@@ -452,15 +488,18 @@ def main():
     np.savez_compressed(os.path.join(HERE, "picketfence.npz"), **pfg)
 
     # ----------------- 8. BB finder: the reference's own find_features under scikit-image 0.18.3 (a13)
-    bbw, bb_dpmm = bb_windows(4, seed=51)
+    bbw, bb_dpmm = bb_windows(6, seed=51)
+    bb_maxn, bb_minsep = [1, 1, 1, 1, 3, 2], [5, 5, 5, 5, 12, 5]   # windows 4/5: twin BBs
     with tempfile.TemporaryDirectory() as td:
         inp, outp = os.path.join(td, "w.npz"), os.path.join(td, "f.npz")
-        np.savez(inp, count=len(bbw), dpmm=bb_dpmm, radius_mm=2.5, tol_mm=0.5, **{f"w{i}": w for i, w in enumerate(bbw)})
+        np.savez(inp, count=len(bbw), dpmm=bb_dpmm, radius_mm=2.5, tol_mm=0.5, maxn=bb_maxn, minsep=bb_minsep,
+                 **{f"w{i}": w for i, w in enumerate(bbw)})
         subprocess.run([PY39, os.path.join(HERE, "skimage_features_py39.py"), inp, outp, ROOT], check=True)
         bbg = dict(np.load(outp))
     for i, w in enumerate(bbw):
         bbg[f"{i}.window"] = w
     bbg["dpmm"] = np.float64(bb_dpmm)
+    bbg["maxn"], bbg["minsep"] = np.array(bb_maxn), np.array(bb_minsep, dtype=float)
     np.savez_compressed(os.path.join(HERE, "features.npz"), **bbg)
 
     # ------------------- 9. NPS / radial average / ESF-FFT MTF: the reference's own functions (a18)
@@ -583,6 +622,22 @@ def main():
     for name, kw in opts.items():
         record(f"epid.{name}", prof.SingleProfile(epid.copy(), **kw))
     np.savez_compressed(os.path.join(HERE, "single_profile.npz"), **sg)
+
+    # ---- 11. field finder: the reference's own GlobalSizedFieldLocator under scikit-image 0.18.3 (a13, fields)
+    ff, ff_dpmm, ff_args = field_frames(seed=61)
+    ff = [f.astype(np.float32).astype(np.float64) for f in ff]
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "w.npz"), os.path.join(td, "f.npz")
+        np.savez(inp, count=len(ff), dpmm=ff_dpmm, **{k: np.array([a[k] for a in ff_args], dtype=float) for k in ff_args[0]},
+                 **{f"f{i}": f for i, f in enumerate(ff)})
+        subprocess.run([PY39, os.path.join(HERE, "skimage_fields_py39.py"), inp, outp, ROOT], check=True)
+        fg = dict(np.load(outp))
+    for i, f in enumerate(ff):
+        fg[f"{i}.frame"] = f.astype(np.float32)   # float32-representable by construction: exact, half the size
+    fg["dpmm"] = np.float64(ff_dpmm)
+    for k in ff_args[0]:
+        fg[k] = np.array([a[k] for a in ff_args], dtype=float)
+    np.savez_compressed(os.path.join(HERE, "fields.npz"), **fg)
 
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):

@@ -31,9 +31,10 @@ for k in range(int(d["count"])):
     window = d[f"w{k}"]
     sample = au.invert(window)                      # SizedDiskRegion.calculate, metrics/image.py:594-595
     try:
-        pts, _, regions = mu.find_features(sample, top_offset=0, left_offset=0, min_number=1, max_number=1, dpmm=dpmm,
+        pts, _, regions = mu.find_features(sample, top_offset=0, left_offset=0, min_number=1,
+                                           max_number=int(d["maxn"][k]), dpmm=dpmm,
                                            detection_conditions=conds, radius_mm=radius_mm,
-                                           radius_tolerance_mm=tol_mm, min_separation_mm=5)
+                                           radius_tolerance_mm=tol_mm, min_separation_mm=float(d["minsep"][k]))
         out[f"{k}.points"] = np.array([[p.x, p.y] for p in pts], dtype=float)
     except ValueError:
         out[f"{k}.points"] = np.zeros((0, 2))

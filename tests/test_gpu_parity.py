@@ -830,15 +830,19 @@ def test_find_features_batch_vs_reference_golden(golden, dev):
 
     g = golden("features")
     dpmm = float(g["dpmm"])
-    wins = np.stack([o.invert(g[f"{i}.window"]) for i in range(4)])
-    res = pf.find_features_batch(T(wins, dev), dpmm, 2.5, 0.5)
-    assert int(res["status"].abs().sum()) == 0
-    for i in range(4):
-        ref_pts, ref_level = o.find_features_restated(wins[i], dpmm, 2.5, 0.5)
-        assert int(res["count"][i]) == len(g[f"{i}.points"]) == len(ref_pts)
-        assert int(res["level"][i]) == ref_level
-        got = res["xy"][i, : len(ref_pts)].cpu().numpy()
-        assert np.allclose(got, g[f"{i}.points"], rtol=1e-12, atol=0)
+    wins = np.stack([o.invert(g[f"{i}.window"]) for i in range(6)])
+    # windows 4 / 5 hold two BBs (near: suppressed as a same-level duplicate; far: both reported)
+    for sel in ([0, 1, 2, 3], [4], [5]):
+        maxn, minsep = int(g["maxn"][sel[0]]), float(g["minsep"][sel[0]])
+        res = pf.find_features_batch(T(wins[sel], dev), dpmm, 2.5, 0.5, max_number=maxn, min_separation_mm=minsep)
+        assert int(res["status"].abs().sum()) == 0
+        for j, i in enumerate(sel):
+            ref_pts, ref_level = o.find_features_restated(wins[i], dpmm, 2.5, 0.5, max_number=maxn,
+                                                          min_separation_mm=minsep)
+            assert int(res["count"][j]) == len(g[f"{i}.points"]) == len(ref_pts)
+            assert int(res["level"][j]) == ref_level
+            got = res["xy"][j, : len(ref_pts)].cpu().numpy()
+            assert np.allclose(got, g[f"{i}.points"], rtol=1e-12, atol=0), i
     # nothing BB-like: the reference raises ValueError("Couldn't find the minimum number of disks")
     rng = np.random.default_rng(0)
     flat = 0.5 + rng.normal(0, 0.01, (1, 134, 134))
@@ -1071,3 +1075,35 @@ def test_interp1d_batch_vs_scipy(dev):
             assert np.abs(shared - ref0).max() <= 1e-10 * np.abs(ref0).max()
     with pytest.raises(Exception):
         ops.interp1d(T(np.arange(3.0), dev), T(np.arange(3.0), dev), T(np.arange(3.0), dev), kind="cubic")
+
+
+def test_find_fields_batch_vs_reference_golden(golden, dev):
+    """Device GlobalSizedFieldLocator (pl_fields_level) against the reference's own run under scikit-image
+    0.18.3: same fields, same order, centroids to 1e-12; same first level as the oracle; a frame without any
+    matching field reports count 0 (the reference's ValueError)."""
+    from pylinac_amd import features as pf
+
+    g = golden("fields")
+    dpmm = float(g["dpmm"])
+    for sel in ([0, 1], [2]):
+        frames = np.stack([g[f"{i}.frame"].astype(np.float64) for i in sel])
+        i0 = sel[0]
+        res = pf.find_fields_batch(T(frames, dev), dpmm, float(g["fw"][i0]), float(g["fh"][i0]), float(g["tol"][i0]),
+                                   max_number=int(g["maxn"][i0]))
+        assert int(res["status"].abs().sum()) == 0
+        for j, i in enumerate(sel):
+            ref = g[f"{i}.points"]
+            pts, lvl = o.find_fields_restated(frames[j], dpmm, g["fw"][i], g["fh"][i], g["tol"][i],
+                                              max_number=int(g["maxn"][i]))
+            assert int(res["count"][j]) == len(ref) == len(pts)
+            assert int(res["level"][j]) == lvl
+            assert np.allclose(res["xy"][j, : len(ref)].cpu().numpy(), ref, rtol=1e-12, atol=0), i
+    # pixel-unit construction (is_from_physical=False divides by dpmm, image.py:829-832)
+    f2 = g["2.frame"].astype(np.float64)[None]
+    r2 = pf.find_fields_batch(T(f2, dev), dpmm, 15.0 * dpmm, 15.0 * dpmm, 1.5 * dpmm, max_number=1,
+                              is_from_physical=False)
+    assert np.allclose(r2["xy"][0, 0].cpu().numpy(), g["2.points"][0], rtol=1e-12)
+    none = pf.find_fields_batch(T(f2, dev), dpmm, 40.0, 40.0, 1.0, max_number=1)
+    assert int(none["count"][0]) == 0 and int(none["level"][0]) == -1
+    with pytest.raises(ValueError):
+        o.find_fields_restated(f2[0], dpmm, 40.0, 40.0, 1.0, max_number=1)

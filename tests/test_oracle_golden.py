@@ -305,7 +305,7 @@ def test_bb_finder_restatement_matches_reference_find_features(golden):
     g = golden("features")
     dpmm = float(g["dpmm"])
     checked = 0
-    for i in range(4):
+    for i in range(6):
         win = g[f"{i}.window"]
         s = o.stretch(o.invert(win), 0, 1)
         labs = {}
@@ -322,7 +322,11 @@ def test_bb_finder_restatement_matches_reference_find_features(golden):
             assert abs(p["perimeter"] - row[8]) <= 1e-12 * row[8]
             assert np.allclose(p["weighted_centroid"], row[11:13], rtol=1e-12, atol=0)
             checked += 1
-        pts, _ = o.find_features_restated(o.invert(win), dpmm, 2.5, 0.5)
+        # windows 4 / 5 hold two BBs: same-level duplicates are suppressed in label order (the reference's
+        # de-duplication iterates the list it appends to), distinct ones are both reported
+        pts, _ = o.find_features_restated(o.invert(win), dpmm, 2.5, 0.5, max_number=int(g["maxn"][i]),
+                                          min_separation_mm=float(g["minsep"][i]))
+        assert len(pts) == len(g[f"{i}.points"]) == (2 if i == 5 else 1)
         assert np.allclose(np.array(pts), g[f"{i}.points"], rtol=1e-13, atol=0)
     assert checked > 150
 
@@ -426,3 +430,16 @@ def test_single_profile_restatement_matches_reference_and_frozen_exports(golden)
                     assert abs(float(fd[str(k)]) - v) < 1e-4, (i, k)
     for name, kw in _SP_EPID.items():
         _sp_check(g, f"epid.{name}", o.SingleProfileRestated(g["epid.y"].copy(), **kw), calcs, vtol=0, ftol=1e-12)
+
+
+def test_field_finder_restatement_matches_reference(golden):
+    """a13 (fields): oracle.find_fields_restated against the reference's own GlobalSizedFieldLocator.calculate
+    under scikit-image 0.18.3 (py3.9 helper): same fields in the same order, centroids to 1e-12.  The frames
+    carry a field inside the clear_border band, a wrong-size field and BB shadows (holes at high thresholds)."""
+    g = golden("fields")
+    dpmm = float(g["dpmm"])
+    for i in range(3):
+        frame = g[f"{i}.frame"].astype(np.float64)
+        pts, _ = o.find_fields_restated(frame, dpmm, g["fw"][i], g["fh"][i], g["tol"][i], max_number=int(g["maxn"][i]))
+        assert len(pts) == len(g[f"{i}.points"]) == (1 if i == 2 else 3)
+        assert np.allclose(np.array(pts), g[f"{i}.points"], rtol=1e-12, atol=0)
