@@ -49,46 +49,43 @@ __device__ __forceinline__ int block_flag_scan(int flag, int* total, Scan* s) {
 
 struct Widths { double width, height, lip, rip; };
 
-// The walks below are sequential by definition (scipy's while loops), but each step is an LDS
-// round trip.  They therefore fetch four samples per trip (indices clamped into the profile) and
-// evaluate scipy's loop condition on them in order -- same result, a quarter of the latency.
+// scipy's walks are sequential by definition (while loops over neighbouring samples).  A lane-private walk pays
+// one LDS round trip per step, and a beam profile has a handful of peaks whose walks cross the whole profile
+// (measured: 190 us per launch, one lane busy).  So every walk is done by a whole WAVE for one peak at a time:
+// the 64 lanes test 64 consecutive steps at once, a ballot finds the first step at which scipy's loop
+// condition fails, and only the steps before it take part in the result.  Same result, 1/64 of the trips.
+// All arguments are wave-uniform; every lane returns the same value.
 
-// first i (walking left from `start`, stopping at `stop`) with !(h < x[i]);  scipy:
-//   i = peak; while (i_min < i && height < x[i]) --i;
+// scipy:  i = peak; while (i_min < i && height < x[i]) --i;
 __device__ __forceinline__ int walk_left_while_above(const double* xs, int start, int stop, double h) {
-  int i = start;
-  while (stop < i) {
-    const double v0 = xs[i], v1 = xs[max(i - 1, 0)], v2 = xs[max(i - 2, 0)], v3 = xs[max(i - 3, 0)];
-    if (!(h < v0)) return i;
-    if (!(stop < i - 1) || !(h < v1)) return i - 1;
-    if (!(stop < i - 2) || !(h < v2)) return i - 2;
-    if (!(stop < i - 3) || !(h < v3)) return i - 3;
-    i -= 4;
+  const int lane = threadIdx.x & (PL_WAVE - 1);
+  for (int t0 = 0;; t0 += PL_WAVE) {
+    const int j = start - (t0 + lane);
+    const bool fail = !(stop < j) || !(h < xs[j]);   // j > stop >= 0 whenever xs[j] is read
+    const unsigned long long b = __ballot(fail);
+    if (b) return start - (t0 + __builtin_ctzll(b));
   }
-  return i;
 }
-__device__ __forceinline__ int walk_right_while_above(const double* xs, int start, int stop, double h, int m) {
-  int i = start;
-  while (i < stop) {
-    const double v0 = xs[i], v1 = xs[min(i + 1, m - 1)], v2 = xs[min(i + 2, m - 1)], v3 = xs[min(i + 3, m - 1)];
-    if (!(h < v0)) return i;
-    if (!(i + 1 < stop) || !(h < v1)) return i + 1;
-    if (!(i + 2 < stop) || !(h < v2)) return i + 2;
-    if (!(i + 3 < stop) || !(h < v3)) return i + 3;
-    i += 4;
+// scipy:  i = peak; while (i < i_max && height < x[i]) ++i;
+__device__ __forceinline__ int walk_right_while_above(const double* xs, int start, int stop, double h) {
+  const int lane = threadIdx.x & (PL_WAVE - 1);
+  for (int t0 = 0;; t0 += PL_WAVE) {
+    const int j = start + (t0 + lane);
+    const bool fail = !(j < stop) || !(h < xs[j]);   // j < stop <= m - 1 whenever xs[j] is read
+    const unsigned long long b = __ballot(fail);
+    if (b) return start + (t0 + __builtin_ctzll(b));
   }
-  return i;
 }
 
 __device__ __forceinline__ Widths peak_width(const double* xs, int pk, int lb, int rb, double prom,
-                                             double rel_height, int m) {
+                                             double rel_height) {
   Widths r;
   const double h = xs[pk] - prom * rel_height;
   r.height = h;
   int i = walk_left_while_above(xs, pk, lb, h);
   double lip = (double)i;
   if (xs[i] < h) lip += (h - xs[i]) / (xs[i + 1] - xs[i]);
-  i = walk_right_while_above(xs, pk, rb, h, m);
+  i = walk_right_while_above(xs, pk, rb, h);
   double rip = (double)i;
   if (xs[i] < h) rip -= (h - xs[i]) / (xs[i - 1] - xs[i]);
   r.lip = lip;
@@ -99,30 +96,34 @@ __device__ __forceinline__ Widths peak_width(const double* xs, int pk, int lb, i
 
 // scipy _peak_prominences, one side:  i = base = peak; min = x[peak];
 //   while (in range && x[i] <= x[peak]) { if (x[i] < min) { min = x[i]; base = i; } i += dir; }
+// Step t visits peak + DIR*t.  Each lane keeps the minimum over its own steps (strict <, so its earliest step
+// wins a tie); the final reduction takes the smallest value and, among equal values, the earliest step --
+// the sample the sequential loop would have kept.
 template <int DIR>
 __device__ __forceinline__ void prominence_side(const double* xs, int pk, int m, double& out_min, int& out_base) {
+  const int lane = threadIdx.x & (PL_WAVE - 1);
   const double xp = xs[pk];
   double mn = xp;
-  int base = pk, i = pk;
-  for (;;) {
-    if (DIR < 0 ? (i < 0) : (i > m - 1)) break;
-    const int i1 = DIR < 0 ? max(i - 1, 0) : min(i + 1, m - 1);
-    const int i2 = DIR < 0 ? max(i - 2, 0) : min(i + 2, m - 1);
-    const int i3 = DIR < 0 ? max(i - 3, 0) : min(i + 3, m - 1);
-    const double v[4] = {xs[i], xs[i1], xs[i2], xs[i3]};
-    bool stop = false;
+  int step = 0;
+  for (int t0 = 0;; t0 += PL_WAVE) {
+    const int t = t0 + lane;
+    const int j = pk + DIR * t;
+    const bool inside = DIR < 0 ? (j >= 0) : (j <= m - 1);
+    const double v = inside ? xs[j] : xp;
+    const bool fail = !inside || !(v <= xp);
+    const unsigned long long b = __ballot(fail);
+    const int first = b ? __builtin_ctzll(b) : PL_WAVE;
+    if (lane < first && v < mn) { mn = v; step = t; }
+    if (b) break;
+  }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int ik = i + DIR * k;
-      if (DIR < 0 ? (ik < 0) : (ik > m - 1)) { stop = true; break; }
-      if (!(v[k] <= xp)) { stop = true; break; }
-      if (v[k] < mn) { mn = v[k]; base = ik; }
-    }
-    if (stop) break;
-    i += DIR * 4;
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(mn, o, 64);
+    const int os = __shfl_xor(step, o, 64);
+    if (ov < mn || (ov == mn && os < step)) { mn = ov; step = os; }
   }
   out_min = mn;
-  out_base = base;
+  out_base = pk + DIR * step;
 }
 
 // STAGE = true: the (trimmed) profile lives in LDS and every walk below is a ds_read; keeping the two
@@ -262,8 +263,8 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
     __syncthreads();
   }
 
-  // ---- D/E/F: prominences, bases, widths, filters ---------------------------------------------
-  for (int p = threadIdx.x; p < P; p += kThreads) {
+  // ---- D/E/F: prominences, bases, widths, filters (one wave per peak, see the walk helpers) -------
+  for (int p = threadIdx.x / PL_WAVE; p < P; p += kThreads / PL_WAVE) {
     const int pk = s_idx[p];
     const double xp = xs[pk];
     double left_min, right_min;
@@ -272,13 +273,15 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
     prominence_side<+1>(xs, pk, m, right_min, rb);
     const double prom = xp - (left_min > right_min ? left_min : right_min);
     int keep = (!prm.has_prominence || prom >= prm.prominence_min) ? 1 : 0;
-    const Widths wd = peak_width(xs, pk, lb, rb, prom, prm.rel_height, m);
+    const Widths wd = peak_width(xs, pk, lb, rb, prom, prm.rel_height);
     keep = keep && (wd.width >= prm.width_min);
-    s_prom[p] = prom;
-    s_width[p] = wd.width;
-    s_lb[p] = lb;
-    s_rb[p] = rb;
-    s_keep[p] = keep;
+    if ((threadIdx.x & (PL_WAVE - 1)) == 0) {
+      s_prom[p] = prom;
+      s_width[p] = wd.width;
+      s_lb[p] = lb;
+      s_rb[p] = rb;
+      s_keep[p] = keep;
+    }
   }
   __syncthreads();
 
@@ -305,23 +308,30 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
     __syncthreads();
   }
 
-  // ---- H: ordered output ----------------------------------------------------------------------
+  // ---- H: ordered output: destinations by an ordered scan, then one wave per kept peak ---------------
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
-  int32_t* o_idx = d_idx + prof * cap;
-  int32_t* o_lb = d_lb + prof * cap;
-  int32_t* o_rb = d_rb + prof * cap;
-  double* o_p = d_props + prof * 6 * (int64_t)cap;
   for (int base = 0; base < P; base += kThreads) {
     const int p = base + threadIdx.x;
     const int flag = (p < P) ? s_keep[p] : 0;
     int tot;
     const int off = block_flag_scan(flag, &tot, &scan);
     const int cur = s_cnt;
-    const int dst = cur + off;
-    if (flag && dst < cap) {
-      const int pk = s_idx[p];
-      const Widths wd = peak_width(xs, pk, s_lb[p], s_rb[p], s_prom[p], prm.rel_height, m);
+    if (p < P) s_keep[p] = flag ? (cur + off + 1) : 0;   // destination + 1
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt = cur + tot;
+    __syncthreads();
+  }
+  int32_t* o_idx = d_idx + prof * cap;
+  int32_t* o_lb = d_lb + prof * cap;
+  int32_t* o_rb = d_rb + prof * cap;
+  double* o_p = d_props + prof * 6 * (int64_t)cap;
+  for (int p = threadIdx.x / PL_WAVE; p < P; p += kThreads / PL_WAVE) {
+    const int dst = s_keep[p] - 1;
+    if (dst < 0 || dst >= cap) continue;                 // wave-uniform
+    const int pk = s_idx[p];
+    const Widths wd = peak_width(xs, pk, s_lb[p], s_rb[p], s_prom[p], prm.rel_height);
+    if ((threadIdx.x & (PL_WAVE - 1)) == 0) {
       o_idx[dst] = pk + lo;  // only the indices are shifted (pylinac/core/profile.py:2613)
       o_lb[dst] = s_lb[p];
       o_rb[dst] = s_rb[p];
@@ -332,9 +342,6 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
       o_p[4 * cap + dst] = wd.lip;
       o_p[5 * cap + dst] = wd.rip;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) s_cnt = cur + tot;
-    __syncthreads();
   }
   if (threadIdx.x == 0) {
     const int total = s_cnt;
