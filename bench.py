@@ -161,8 +161,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "note": "dominant kernel reads+writes one u16 frame (4 MiB/frame algorithmic; PMC traffic "
-                        "matches); it is VALU/FP64-issue-bound, not HBM-bound: scipy-exact float64 "
-                        "accumulation, ~61 VALU instr/px/pass at sigma=5 (DESIGN.md section 5)",
+                        "matches); it is VALU-issue-bound, not HBM-bound: scipy-exact float64 accumulation "
+                        "(axis 0: ~61 VALU instr/px at sigma=5; axis 1 decides in packed float32, ~52/px) "
+                        "(DESIGN.md section 5)",
                 "pipeline_frac": round(value / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             },

@@ -406,21 +406,23 @@ int pl_gauss_pk_launch(const void* in, void* out, int is_signed, int64_t n, int 
                        const double* wts, int radius, hipStream_t st);
 
 namespace {
-// PL_GAUSS_PK=1 opts into the packed-float32 decision kernels (gaussian_pk.hip: bit-identical, measured
-// only ~3 % faster end to end so far); the float64 kernels below are the default.
-bool use_pk_path() {
-  static const bool on = [] {
+// Packed-float32 decision kernels (gaussian_pk.hip, bit-identical to the float64 kernels below).
+// Default: used for axis 1 (0.51 vs 0.62 ms per pass on 256 x 1024^2, sigma 5); axis 0 stays on the float64
+// kernel (the packed axis-0 kernel measures the same 0.60 ms).  PL_GAUSS_PK=1 forces both axes onto the
+// packed kernels, PL_GAUSS_PK=0 both onto the float64 kernels (A/B measurements, parity tests of every path).
+bool use_pk_path(int axis) {
+  static const int mode = [] {
     const char* e = getenv("PL_GAUSS_PK");
-    return e && e[0] == '1';
+    return e ? (e[0] == '1' ? 1 : 0) : -1;
   }();
-  return on;
+  return mode < 0 ? axis == 1 : mode == 1;
 }
 
 template <typename T>
 int gaussian1d_t(const T* in, T* out, int64_t n, int h, int w, int axis, const double* wts,
                  int radius, hipStream_t st, int mode = 0) {
   int rc = -1;
-  if (sizeof(T) == 2 && mode == 0 && use_pk_path()) {
+  if (sizeof(T) == 2 && mode == 0 && use_pk_path(axis)) {
     rc = pl_gauss_pk_launch(in, out, (T)-1 < (T)0, n, h, w, axis, wts, radius, st);
     if (rc == 0) return pl_check_launch("pl_gaussian1d");
   }

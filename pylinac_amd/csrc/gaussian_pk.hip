@@ -29,13 +29,13 @@
 // Bit-identical to gauss_v_fast / gauss_h_fast by construction; tests compare against scipy on noisy,
 // constant, saturated and ragged frames.
 //
-// STATUS: opt-in (PL_GAUSS_PK=1).  Measured on MI355X, 256 x 1024^2 uint16, sigma 5 (profiles/r01c_*): axis 0
-// 0.63 ms (float64 kernel 0.62), axis 1 0.51 ms (float64 0.61): the decision arithmetic alone runs in
-// 0.39 ms per pass, but the wave-wide row minimum of the axis-1 pass leaves ~6 % of the in-field pixels
-// undecided wherever a 552-sample span contains a field edge (PMC: 956 VALU instructions per wave, as many as
-// the float64 kernel), and the three-barrier axis-0 kernel sits at 53 % VALU utilisation.  A persistent
-// strip-walking variant with register prefetch was slower still (0.84 ms).  Next step if pursued: lane-local
-// minima on axis 1 (+5 VALU/px) and a transposing axis-0 kernel used for both passes.
+// STATUS: the axis-1 kernel is the default for 16-bit frames (0.51 ms vs 0.62 ms for the float64 kernel on
+// 256 x 1024^2, sigma 5, MI355X); the axis-0 kernel is opt-in (PL_GAUSS_PK=1: 0.60 ms, no better than float64 --
+// its three-barrier structure sits at 53 % VALU utilisation).  History (profiles/r01c_*): with a wave-wide row
+// minimum the axis-1 kernel left ~6 % of the in-field pixels undecided (every 552-sample span that contains a
+// field edge) and ran 0.54 ms; the lane-local minimum below brought that to 0.51 ms once the register spills it
+// first caused (20 scratch accesses per wave doubled the run time) were removed.  A persistent strip-walking
+// axis-0 variant with register prefetch was slower (0.84 ms).
 //
 // u16 -> f32 without cvt instructions: (x16 | 0x4B000000) is the float 2^23 + x16; one v_pk_add_f32 with
 // -(2^23 + m) yields x - m for two pixels (exact).  int16 is XOR-biased into the unsigned domain first.
@@ -174,7 +174,7 @@ __device__ __forceinline__ void push_fails(FixList& fl, unsigned failmask, unsig
 // float pairs; lane = column pair, wave w owns kVRows/4 rows in groups of 8 outputs.
 // m = per-column minimum over the whole staged tile (a valid lower bound for every window in it).
 template <typename T, int RAD, int kVRows>
-__global__ void __launch_bounds__(kPkThreads, kVRows == 64 ? 2 : 4)
+__global__ void __launch_bounds__(kPkThreads, kVRows == 64 ? 2 : 3)
 gauss_v_pk(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_tiles, int row_tiles,
            const double* __restrict__ wts) {
   constexpr int NOUT = 8, WIN = NOUT + 2 * RAD;
@@ -334,6 +334,7 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
   constexpr unsigned kBias1 = kSigned ? 0x8000u : 0u;
   static_assert(2 * RAD <= PL_WAVE, "halo is loaded by one wave pass");
   __shared__ __attribute__((aligned(16))) f2 lds[WAVES * PADDED];
+  __shared__ __attribute__((aligned(16))) f2 s_blockmin[WAVES][LOGICAL / 8 + 1];  // minima of 8-position blocks
   __shared__ FixList fix;
   __shared__ unsigned s_rowmin[2 * WAVES];
   __shared__ float s_c0;
@@ -428,14 +429,48 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
   unsigned failmask = 0;
   unsigned res[NOUT];  // res[i] = {row a px i, row b px i}
   {
-    f2 x[WIN];
     const f2* win = s + 10 * lane;
+    // ---- lane-local minimum.  The staged samples are relative to the wave-wide row minimum; wherever the
+    // 552-sample span holds a field edge that offset leaves t ~ 40 000 on the plateau and 10 % of those pixels
+    // undecided.  Lane l's window is exactly the 8-position blocks l .. l+NBLK-1: every lane reduces its
+    // own first block (the first NBLK-1 lanes also the blocks past lane 63), the block minima are exchanged through
+    // LDS, and the window is re-offset by their minimum d >= 0 (exact: integers < 2^17) while it is loaded
+    // (d first, window second: holding the whole window across the exchange spilled and doubled the run time).
+    static_assert(WIN % 8 == 0, "a window must be a whole number of 8-position blocks");
+    constexpr int NBLK = WIN / 8;            // blocks a window covers (RAD 20: 6)
+    f2 d;
+    {
+      f2 bmin = win[0];
 #pragma unroll
-    for (int k = 0; k < WIN; ++k) x[k] = win[k + ((k >> 3) << 1)];
+      for (int k = 1; k < 8; ++k) bmin = f2{__builtin_fminf(bmin.x, win[k].x), __builtin_fminf(bmin.y, win[k].y)};
+      f2* bm = s_blockmin[wave];
+      bm[lane] = bmin;
+      if (lane < NBLK - 1) {                 // blocks 64 .. 64+NBLK-2 start past the last lane's own block
+        const f2* extra = s + pad8(8 * (PL_WAVE + lane));
+        f2 e = extra[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) e = f2{__builtin_fminf(e.x, extra[k].x), __builtin_fminf(e.y, extra[k].y)};
+        bm[PL_WAVE + lane] = e;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      d = bmin;
+#pragma unroll
+      for (int q = 1; q < NBLK; ++q) {
+        const f2 v = bm[lane + q];
+        d = f2{__builtin_fminf(d.x, v.x), __builtin_fminf(d.y, v.y)};
+      }
+    }
+    f2 x[WIN];
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) x[k] = win[k + ((k >> 3) << 1)] - d;
+    const f2 mfl = mf + d;
+    const bool z0 = m0z && d.x == 0.0f, z1 = m1z && d.y == 0.0f;
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
       unsigned fbits;
-      res[i] = decide_pair<RAD>(x + i, taps, mf, m0z, m1z, kSigned, fbits) ^ kBias;
+      res[i] = decide_pair<RAD>(x + i, taps, mfl, z0, z1, kSigned, fbits) ^ kBias;
       failmask |= fbits << (2 * i);
     }
   }

@@ -918,17 +918,13 @@ def _check_gaussian_cases(dev):
             assert np.array_equal(got, ref), (arr.shape, arr.dtype, sigma)
 
 
-def test_gaussian_float64_kernels_on_epid_and_ragged_frames(dev):
-    """Default path: EPID-like frames, zero regions, constant blocks, ragged shapes, int16 plateaus."""
+def test_gaussian_default_kernels_on_epid_and_ragged_frames(dev):
+    """Default dispatch (float64 kernel on axis 0, packed-float32 decision kernel on axis 1): EPID-like frames,
+    zero regions, constant blocks, full-range noise, ragged shapes, int16 plateaus."""
     _check_gaussian_cases(dev)
 
 
-def test_gaussian_packed_f32_decision_path_opt_in(dev):
-    """PL_GAUSS_PK=1 (gaussian_pk.hip): trunc(S) decided in packed float32, undecided pixels recomputed with
-    scipy's float64 sequence from the LDS tile.  Same cases as the default path, in a fresh process (the
-    switch is read once per process): sparse undecided pixels (workgroup list), list overflow (full-range
-    noise, saturated frames -> whole-tile recompute), zero regions (S == 0 shortcut), odd widths (axis 0 falls
-    back to the float64 kernel), an odd number of rows (unpaired last row on axis 1), int16."""
+def _gaussian_cases_in_subprocess(pk: str):
     import os
     import subprocess
     import sys
@@ -937,12 +933,24 @@ def test_gaussian_packed_f32_decision_path_opt_in(dev):
     code = ("import torch\n"
             "from tests import test_gpu_parity as t\n"
             "t._check_gaussian_cases(torch.device('cuda', 0))\n"
-            "print('PK_OK')\n")
-    env = dict(os.environ, PL_GAUSS_PK="1")
+            "print('CASES_OK')\n")
+    env = dict(os.environ, PL_GAUSS_PK=pk)
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, timeout=600, capture_output=True, text=True)
-    assert r.returncode == 0 and "PK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "CASES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_gaussian_packed_f32_kernels_on_both_axes(dev):
+    """PL_GAUSS_PK=1 (gaussian_pk.hip on both axes): trunc(S) decided in packed float32, undecided pixels
+    recomputed with scipy's float64 sequence from the LDS tile.  Same cases, in a fresh process (the switch is
+    read once per process): sparse undecided pixels (workgroup list), list overflow (full-range noise, saturated
+    frames -> whole-tile recompute), zero regions (S == 0 shortcut), odd widths (axis 0 falls back to the float64
+    kernel), an odd number of rows (unpaired last row on axis 1), int16."""
+    _gaussian_cases_in_subprocess("1")
+
+
+def test_gaussian_float64_kernels_on_both_axes(dev):
+    """PL_GAUSS_PK=0: the float64 FMA-decision kernels on both axes stay reachable and agree with scipy."""
+    _gaussian_cases_in_subprocess("0")
 # ------------------------------------------------------------------------ spectral measures (a18)
 def test_nps_and_radial_average_vs_reference_golden(golden, dev):
     """pl_nps2d / pl_radial_average against pylinac.core.nps (golden from the reference itself): the 2-D
