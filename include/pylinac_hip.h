@@ -227,6 +227,17 @@ int pl_fields_level(const int32_t* d_labels, const int32_t* d_nlabels, const dou
                     double field_tol_mm, int buffer_size, int max_number, int level, int32_t* d_done,
                     int32_t* d_count, double* d_xy, int32_t* d_level, int32_t* d_status, void* stream);
 
+/* ---- f3 ("next" row): ROI statistics after phantom localisation ---------------------------------------
+ * DiskROI.circle_mask + pixel_value/mean/std/min/max (pylinac/core/roi.py:104-140) and axis-aligned
+ * RectangleROI.pixel_array statistics (:664-704).  d_rois float64 [..][rois_per_frame][4] (roi_frame_stride
+ * doubles between frames, 0 = the same ROIs for every frame): kind 0 disk = (cx, cy, radius, unused) with
+ * skimage.draw.disk membership; kind 1 rectangle = (r0, r1, c0, c1) half-open.  d_out float64
+ * [n][rois_per_frame][6] = count, mean, std (population), min, max, median (np.median).  d_status int32
+ * [n][rois_per_frame]: 0 ok, 1 ROI box leaves the frame, 2 more than 16384 pixels, 3 empty. */
+int pl_roi_stats(const void* d_frames, int dtype, int64_t n, int h, int w, const double* d_rois,
+                 int rois_per_frame, int64_t roi_frame_stride, int kind, double* d_out, int32_t* d_status,
+                 void* stream);
+
 /* ---- a11: profile resampling -----------------------------------------------------------------------
  * scipy.interpolate.interp1d(x, y, kind, bounds_error=False, fill_value="extrapolate")(xq) as called by
  * SingleProfile._interpolate (pylinac/core/profile.py:1349-1358).  d_x float64 abscissae (x_stride elements

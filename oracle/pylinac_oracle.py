@@ -881,6 +881,16 @@ def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=Non
 
 
 # --------------------------------------------------------------------------------------
+# f3: DiskROI statistics (skimage.draw.disk restated by disk_mask_like_skimage)
+# --------------------------------------------------------------------------------------
+def disk_roi_stats(arr: np.ndarray, cx: float, cy: float, radius: float) -> np.ndarray:
+    """pylinac/core/roi.py:104-138: circle_mask() = array[draw.disk((cy, cx), radius)] -> count, mean, std, min, max,
+    median (pixel_value)."""
+    v = arr[disk_mask_like_skimage((cy, cx), radius, arr.shape).astype(bool)]
+    return np.array([v.size, np.mean(v), np.std(v), np.min(v), np.max(v), np.median(v)], dtype=float)
+
+
+# --------------------------------------------------------------------------------------
 # a13 (fields): GlobalSizedFieldLocator -- skimage 0.18.3 regionprops restated, scipy labelling
 # --------------------------------------------------------------------------------------
 def find_fields_restated(sample: np.ndarray, dpmm: float, field_width_mm: float, field_height_mm: float,

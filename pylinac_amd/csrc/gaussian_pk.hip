@@ -217,13 +217,24 @@ gauss_v_pk(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_
   // ---- load: wave `wave` takes staged rows wave, wave+4, ... (row index wave-uniform -> scalar reflect)
   unsigned raw[PER];
   const unsigned coff = (unsigned)c * (unsigned)sizeof(T);
+  if (r0 - RAD >= 0 && r0 - RAD + TROWS <= h) {   // interior tile: no reflection, one pointer bump per row
+    const T* row = f + (size_t)(r0 - RAD + wave) * w;
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int tr = wave + k * WAVES;
-    raw[k] = 0xffffffffu;   // neutral for the minimum (biased domain)
-    if (tr < TROWS && active) {
-      const T* row = f + (size_t)pl_reflect(r0 - RAD + tr, h) * w;
-      raw[k] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(row) + coff) ^ kBias;
+    for (int k = 0; k < PER; ++k) {
+      raw[k] = 0xffffffffu;   // neutral for the minimum (biased domain)
+      if (wave + k * WAVES < TROWS && active)
+        raw[k] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(row) + coff) ^ kBias;
+      row += (size_t)WAVES * w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int tr = wave + k * WAVES;
+      raw[k] = 0xffffffffu;
+      if (tr < TROWS && active) {
+        const T* row = f + (size_t)pl_reflect(r0 - RAD + tr, h) * w;
+        raw[k] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(row) + coff) ^ kBias;
+      }
     }
   }
   us2 mn = as_us2(raw[0]);

@@ -639,6 +639,20 @@ def main():
         fg[k] = np.array([a[k] for a in ff_args], dtype=float)
     np.savez_compressed(os.path.join(HERE, "fields.npz"), **fg)
 
+    # ---- 12. DiskROI statistics: the reference's own class under scikit-image 0.18.3 (next row f3)
+    rng = np.random.default_rng(71)
+    ct_slice = catphan_slices(1, 512, seed=72)[0][0]
+    rois = np.array([[256, 256, 10], [180.4, 300.7, 7.5], [330.5, 199.5, 12.25], [100, 120, 1], [256.2, 90.9, 30],
+                     [400.75, 410.1, 45.5], [20.5, 20.5, 15]], dtype=float)
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "w.npz"), os.path.join(td, "f.npz")
+        sl_f = (ct_slice.astype(np.float64) * 0.731 + rng.normal(0, 3, ct_slice.shape)).astype(np.float32).astype(np.float64)
+        np.savez(inp, slice_i16=ct_slice, slice_f64=sl_f, rois=rois)
+        subprocess.run([PY39, os.path.join(HERE, "skimage_roi_py39.py"), inp, outp, ROOT], check=True)
+        rg = dict(np.load(outp))
+    rg.update(slice_i16=ct_slice, slice_f32=sl_f.astype(np.float32), rois=rois)   # slice_f64 = slice_f32 exactly
+    np.savez_compressed(os.path.join(HERE, "roi.npz"), **rg)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

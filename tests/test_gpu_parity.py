@@ -1115,3 +1115,49 @@ def test_find_fields_batch_vs_reference_golden(golden, dev):
     assert int(none["count"][0]) == 0 and int(none["level"][0]) == -1
     with pytest.raises(ValueError):
         o.find_fields_restated(f2[0], dpmm, 40.0, 40.0, 1.0, max_number=1)
+
+
+# -------------------------------------------------------------------------------- ROI statistics (f3)
+def test_disk_roi_stats_vs_reference_golden(golden, dev):
+    """pl_roi_stats against the reference's own DiskROI (scikit-image 0.18.3 draw.disk): pixel count, min, max and
+    median exact, mean / std to 1e-12; batch form with shared and per-frame ROIs; the DiskROI class incl.
+    from_phantom_center; rectangle windows against numpy slices; ROIs leaving the frame are reported."""
+    from pylinac_amd import roi
+
+    g = golden("roi")
+    rois = g["rois"]
+    for name, arr in (("i16", g["slice_i16"]), ("f64", g["slice_f32"].astype(np.float64))):
+        ref = g[f"stats_{name}"]
+        out, status = roi.disk_roi_stats_batch(T(np.stack([arr, arr[::-1].copy()]), dev), rois[:, :2], rois[:, 2])
+        assert int(status.abs().sum()) == 0
+        got = out[0].cpu().numpy()
+        assert np.array_equal(got[:, [0, 3, 4, 5]], ref[:, [0, 3, 4, 5]]), name
+        assert np.allclose(got[:, 1:3], ref[:, 1:3], rtol=1e-12, atol=0), name
+        flipped = np.array([o.disk_roi_stats(arr[::-1], cx, cy, r) for cx, cy, r in rois])
+        got1 = out[1].cpu().numpy()
+        assert np.array_equal(got1[:, [0, 3, 4, 5]], flipped[:, [0, 3, 4, 5]])
+        assert np.allclose(got1[:, 1:3], flipped[:, 1:3], rtol=1e-12, atol=0)
+        per_frame = np.stack([rois[:, :2], rois[::-1, :2]])
+        out2, _ = roi.disk_roi_stats_batch(T(np.stack([arr, arr]), dev), per_frame, np.stack([rois[:, 2], rois[::-1, 2]]))
+        assert np.array_equal(out2[1].cpu().numpy()[::-1][:, [0, 3, 4, 5]], ref[:, [0, 3, 4, 5]])
+    d = roi.DiskROI(g["slice_i16"], radius=float(rois[1, 2]), center=(float(rois[1, 0]), float(rois[1, 1])))
+    assert (d.pixel_value, d.min, d.max) == tuple(g["stats_i16"][1, [5, 3, 4]])
+    assert abs(d.mean - g["stats_i16"][1, 1]) < 1e-12 and abs(d.std - g["stats_i16"][1, 2]) < 1e-12
+    pc = roi.DiskROI.from_phantom_center(g["slice_i16"], angle=30.0, roi_radius=7.5, dist_from_center=60.25,
+                                         phantom_center=(250.3, 260.7))
+    fc = g["from_center"]
+    assert np.allclose(pc._xy, fc[:2], rtol=1e-15) and abs(pc.mean - fc[2]) < 1e-12 and abs(pc.std - fc[3]) < 1e-12
+    assert pc.pixel_value == fc[4]
+    arr = g["slice_f32"].astype(np.float64)
+    boxes = np.array([[10, 40, 20, 90], [0, 512, 0, 17], [300, 301, 5, 6], [100, 228, 100, 228]], dtype=float)
+    outr, st = roi.rectangle_stats_batch(T(arr[None], dev), boxes)
+    assert int(st.abs().sum()) == 0
+    for k, (r0, r1, c0, c1) in enumerate(boxes.astype(int)):
+        v = arr[r0:r1, c0:c1]
+        got = outr[0, k].cpu().numpy()
+        assert got[0] == v.size and got[3] == v.min() and got[4] == v.max() and got[5] == np.median(v)
+        assert abs(got[1] - v.mean()) <= 1e-12 * abs(v.mean()) and abs(got[2] - v.std()) <= 1e-12 * v.std() + 1e-15
+    _, st = roi.disk_roi_stats_batch(T(arr[None], dev), [[5.0, 5.0]], 12.0)
+    assert int(st[0, 0]) == 1
+    with pytest.raises(IndexError):
+        roi.DiskROI(arr, radius=12.0, center=(5.0, 5.0)).mean

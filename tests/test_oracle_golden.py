@@ -443,3 +443,15 @@ def test_field_finder_restatement_matches_reference(golden):
         pts, _ = o.find_fields_restated(frame, dpmm, g["fw"][i], g["fh"][i], g["tol"][i], max_number=int(g["maxn"][i]))
         assert len(pts) == len(g[f"{i}.points"]) == (1 if i == 2 else 3)
         assert np.allclose(np.array(pts), g[f"{i}.points"], rtol=1e-12, atol=0)
+
+
+def test_disk_roi_restatement_matches_reference(golden):
+    """f3: oracle.disk_roi_stats (skimage.draw.disk restated) against the reference's own DiskROI under
+    scikit-image 0.18.3: pixel count, mean, std, min, max, median for integer and float slices, integer and
+    fractional centres / radii."""
+    g = golden("roi")
+    for name, arr in (("i16", g["slice_i16"]), ("f64", g["slice_f32"].astype(np.float64))):
+        got = np.array([o.disk_roi_stats(arr, cx, cy, r) for cx, cy, r in g["rois"]])
+        ref = g[f"stats_{name}"]
+        assert np.array_equal(got[:, [0, 3, 4, 5]], ref[:, [0, 3, 4, 5]]), name
+        assert np.allclose(got[:, 1:3], ref[:, 1:3], rtol=1e-13, atol=0), name
