@@ -173,13 +173,13 @@ __device__ __forceinline__ void push_fails(FixList& fl, unsigned failmask, unsig
 // Workgroup tile = 128 columns x kVRows rows (+ 2*RAD halo rows) staged ONCE through LDS as m-subtracted
 // float pairs; lane = column pair, wave w owns kVRows/4 rows in groups of 8 outputs.
 // m = per-column minimum over the whole staged tile (a valid lower bound for every window in it).
-template <typename T, int RAD, int kVRows>
-__global__ void __launch_bounds__(kPkThreads, kVRows == 64 ? 2 : 3)
+template <typename T, int RAD, int kVRows, int NW>
+__global__ void __launch_bounds__(NW * PL_WAVE, (NW == 8 ? 2 : (kVRows == 64 ? 2 : 3)))
 gauss_v_pk(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_tiles, int row_tiles,
            const double* __restrict__ wts) {
   constexpr int NOUT = 8, WIN = NOUT + 2 * RAD;
   constexpr int TROWS = kVRows + 2 * RAD;          // staged rows
-  constexpr int WAVES = kPkThreads / PL_WAVE;
+  constexpr int WAVES = NW;
   constexpr int SHARE = kVRows / WAVES;             // output rows per wave
   constexpr int PER = (TROWS + WAVES - 1) / WAVES;  // staged rows per wave
   constexpr bool kSigned = (T)-1 < (T)0;
@@ -315,7 +315,7 @@ gauss_v_pk(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_
     o[(size_t)rr * w + cc] = pl_from_double<T>(acc);
   };
   if (cnt <= (unsigned)kListCap) {
-    for (unsigned e = tid; e < cnt; e += kPkThreads) {
+    for (unsigned e = tid; e < cnt; e += NW * PL_WAVE) {
       const unsigned code = fix.item[e];
       fix_one(code >> 5, code & 31u);
     }
@@ -558,7 +558,8 @@ int launch_pk_t(const T* in, T* out, int64_t n, int h, int w, int axis, const do
     const int row_tiles = (int)pl_cdiv(h, kVRows);
     const int64_t blocks = n * col_tiles * row_tiles;
     if (blocks > 0x7fffffffLL) return -1;
-    hipLaunchKernelGGL((gauss_v_pk<T, RAD, kVRows>), dim3((unsigned)blocks), dim3(kPkThreads), 0, st, in, out,
+    // measured alternatives: 64-row tiles with 4 waves 0.69 ms, 64-row tiles with 8 waves 0.78 ms (32 rows: 0.58)
+    hipLaunchKernelGGL((gauss_v_pk<T, RAD, kVRows, 4>), dim3((unsigned)blocks), dim3(kPkThreads), 0, st, in, out,
                        h, w, col_tiles, row_tiles, wts);
   } else {
     const int col_tiles = (int)pl_cdiv(w, PL_WAVE * 8);
@@ -578,14 +579,9 @@ int pl_gauss_pk_launch(const void* in, void* out, int is_signed, int64_t n, int 
                        const double* wts, int radius, hipStream_t st) {
 #define PL_PK_CASE(R)                                                                                        \
   case R:                                                                                                    \
-    if (vr64)                                                                                                \
-      return is_signed ? launch_pk_t<short, R, 64>((const short*)in, (short*)out, n, h, w, axis, wts, st)   \
-                       : launch_pk_t<unsigned short, R, 64>((const unsigned short*)in, (unsigned short*)out, \
-                                                            n, h, w, axis, wts, st);                         \
     return is_signed ? launch_pk_t<short, R, 32>((const short*)in, (short*)out, n, h, w, axis, wts, st)     \
                      : launch_pk_t<unsigned short, R, 32>((const unsigned short*)in, (unsigned short*)out,   \
                                                           n, h, w, axis, wts, st);
-  static const bool vr64 = [] { const char* e = getenv("PL_PK_VROWS"); return e && e[0] == '6'; }();
   switch (radius) {
     PL_PK_CASE(4)
     PL_PK_CASE(8)
