@@ -34,13 +34,15 @@
 // its three-barrier structure sits at 53 % VALU utilisation).  History (profiles/r01c_*): with a wave-wide row
 // minimum the axis-1 kernel left ~6 % of the in-field pixels undecided (every 552-sample span that contains a
 // field edge) and ran 0.54 ms; the lane-local minimum below brought that to 0.51 ms once the register spills it
-// first caused (20 scratch accesses per wave doubled the run time) were removed.  A persistent strip-walking
-// axis-0 variant with register prefetch was slower (0.84 ms).
+// first caused (20 scratch accesses per wave doubled the run time) were removed.  Axis-0 variants that were
+// measured and dropped: a persistent strip-walking version of the LDS-tile kernel with register prefetch
+// (0.84 ms); a barrier-free sliding REGISTER window (one wave walks down 64 column pairs, window shift and
+// re-offset fused into one packed add per sample, undecided outputs re-read from a per-wave LDS dump of the
+// window): 46.8 VALU/px but 0.75-0.92 ms -- 96 window registers + prefetch leave two waves per SIMD, the
+// compiler still spills, and the steps that cross a field edge (every lane undecided) serialise.
 //
 // u16 -> f32 without cvt instructions: (x16 | 0x4B000000) is the float 2^23 + x16; one v_pk_add_f32 with
 // -(2^23 + m) yields x - m for two pixels (exact).  int16 is XOR-biased into the unsigned domain first.
-#include <stdlib.h>
-
 #include "pl_common.h"
 
 namespace {
@@ -61,18 +63,17 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 // exact small integer in float64, so every pair sum, product and running sum rounds as scipy's does.
 template <int RAD, typename F>
 __device__ __forceinline__ double exact_from_lds(F v, double m, double wsum, const double* __restrict__ wts) {
-  double x[2 * RAD + 1];
+  // samples are re-read per tier instead of being held: 41 doubles would cost 82 registers on top of the caller's
+  double a = (double)v(RAD) * wts[RAD];
 #pragma unroll
-  for (int k = 0; k <= 2 * RAD; ++k) x[k] = (double)v(k);
-  double a = x[RAD] * wts[RAD];
-#pragma unroll
-  for (int j = RAD; j >= 1; --j) a = __builtin_fma(x[RAD - j] + x[RAD + j], wts[RAD - j], a);
+  for (int j = RAD; j >= 1; --j) a = __builtin_fma((double)v(RAD - j) + (double)v(RAD + j), wts[RAD - j], a);
   a = __builtin_fma(m, wsum, a);
   const double off = __builtin_fabs(__builtin_amdgcn_fract(__builtin_fabs(a)) - 0.5);
   if (off > 0.5 - 4e-9) {
-    a = (x[RAD] + m) * wts[RAD];
+    a = ((double)v(RAD) + m) * wts[RAD];
 #pragma unroll
-    for (int j = RAD; j >= 1; --j) a = a + ((x[RAD - j] + m) + (x[RAD + j] + m)) * wts[RAD - j];
+    for (int j = RAD; j >= 1; --j)
+      a = a + (((double)v(RAD - j) + m) + ((double)v(RAD + j) + m)) * wts[RAD - j];
   }
   return a;
 }
