@@ -162,7 +162,7 @@ def main():
                 "traffic": traffic,
                 "note": "dominant kernel reads+writes one u16 frame (4 MiB/frame algorithmic; PMC traffic "
                         "matches); it is VALU-issue-bound, not HBM-bound: scipy-exact float64 accumulation "
-                        "(axis 0: ~61 VALU instr/px at sigma=5; axis 1 decides in packed float32, ~52/px) "
+                        "decided in packed float32 (~47-52 VALU instr/px at sigma=5; float64 kernels 61/px) "
                         "(DESIGN.md section 5)",
                 "pipeline_frac": round(value / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

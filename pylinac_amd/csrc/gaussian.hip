@@ -406,16 +406,16 @@ int pl_gauss_pk_launch(const void* in, void* out, int is_signed, int64_t n, int 
                        const double* wts, int radius, hipStream_t st);
 
 namespace {
-// Packed-float32 decision kernels (gaussian_pk.hip, bit-identical to the float64 kernels below).
-// Default: used for axis 1 (0.51 vs 0.62 ms per pass on 256 x 1024^2, sigma 5); axis 0 stays on the float64
-// kernel (the packed axis-0 kernel measures the same 0.60 ms).  PL_GAUSS_PK=1 forces both axes onto the
-// packed kernels, PL_GAUSS_PK=0 both onto the float64 kernels (A/B measurements, parity tests of every path).
-bool use_pk_path(int axis) {
-  static const int mode = [] {
+// Packed-float32 decision kernels (gaussian_pk.hip, bit-identical to the float64 kernels below): the default
+// for 16-bit frames on both axes (256 x 1024^2, sigma 5: axis 1 0.51 vs 0.62 ms, axis 0 0.58 vs 0.61 ms; shapes
+// they do not cover -- odd widths on axis 0, other radii -- fall through to the float64 kernels).
+// PL_GAUSS_PK=0 pins the float64 kernels (A/B measurements, parity tests of both paths).
+bool use_pk_path(int /*axis*/) {
+  static const bool on = [] {
     const char* e = getenv("PL_GAUSS_PK");
-    return e ? (e[0] == '1' ? 1 : 0) : -1;
+    return !(e && e[0] == '0');
   }();
-  return mode < 0 ? axis == 1 : mode == 1;
+  return on;
 }
 
 template <typename T>

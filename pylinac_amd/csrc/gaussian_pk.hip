@@ -29,9 +29,9 @@
 // Bit-identical to gauss_v_fast / gauss_h_fast by construction; tests compare against scipy on noisy,
 // constant, saturated and ragged frames.
 //
-// STATUS: the axis-1 kernel is the default for 16-bit frames (0.51 ms vs 0.62 ms for the float64 kernel on
-// 256 x 1024^2, sigma 5, MI355X); the axis-0 kernel is opt-in (PL_GAUSS_PK=1: 0.60 ms, no better than float64 --
-// its three-barrier structure sits at 53 % VALU utilisation).  History (profiles/r01c_*): with a wave-wide row
+// STATUS: default for 16-bit frames on both axes (256 x 1024^2, sigma 5, MI355X: axis 1 0.51 ms vs 0.62 ms for the
+// float64 kernel; axis 0 0.58 vs 0.61 ms -- its three-barrier structure sits at 53 % VALU utilisation).
+// PL_GAUSS_PK=0 pins the float64 kernels.  History (profiles/r01c_*): with a wave-wide row
 // minimum the axis-1 kernel left ~6 % of the in-field pixels undecided (every 552-sample span that contains a
 // field edge) and ran 0.54 ms; the lane-local minimum below brought that to 0.51 ms once the register spills it
 // first caused (20 scratch accesses per wave doubled the run time) were removed.  Axis-0 variants that were
@@ -85,13 +85,18 @@ struct PkTaps {
   float c0, c1;
 };
 
+// s_wf: the taps converted to float32 ONCE per workgroup (wave 0, before the staging barrier); every wave then
+// reads them from LDS -- 21 v_cvt_f32_f64 per wave in the hot segment were ~10 % of its issue time
 template <int RAD>
-__device__ __forceinline__ void load_taps(const double* __restrict__ wts, PkTaps<RAD>& t, float c0) {
+__device__ __forceinline__ void load_taps(const float* __restrict__ s_wf, PkTaps<RAD>& t, float c0) {
 #pragma unroll
-  for (int j = 0; j <= RAD; ++j)
-    t.w[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)wts[RAD - j])));
+  for (int j = 0; j <= RAD; ++j) t.w[j] = s_wf[j];
   t.c0 = c0;
   t.c1 = (RAD + 2) * 5.9604645e-08f * 1.02f;
+}
+template <int RAD>
+__device__ __forceinline__ void publish_taps(const double* __restrict__ wts, float* __restrict__ s_wf, int lane) {
+  if (lane <= RAD) s_wf[lane] = (float)wts[RAD - lane];
 }
 
 // margin constant c0 = 65535*|W-1| + 1e-6 (float64 sum of the taps; its own error <= 1e-14 is added)
@@ -189,6 +194,7 @@ gauss_v_pk(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_
   __shared__ unsigned s_min[(WAVES + 1) * PL_WAVE];  // per-wave partial minima, then the final ones
   __shared__ FixList fix;
   __shared__ float s_c0;
+  __shared__ float s_wf[RAD + 1];
   __shared__ double s_wsum;
 
   unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
@@ -209,6 +215,7 @@ gauss_v_pk(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_
   if (wave == 0) {
     double ws;
     const float c0 = margin_c0<RAD>(wts, ws);
+    publish_taps<RAD>(wts, s_wf, lane);
     if (tid == 0) {
       s_c0 = c0;
       s_wsum = ws;
@@ -264,7 +271,7 @@ gauss_v_pk(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_
   __syncthreads();
 
   PkTaps<RAD> taps;
-  load_taps<RAD>(wts, taps, s_c0);
+  load_taps<RAD>(s_wf, taps, s_c0);
   const bool m0z = kSigned ? (mn.x == 32768) : (mn.x == 0);
   const bool m1z = kSigned ? (mn.y == 32768) : (mn.y == 0);
 
@@ -350,6 +357,7 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
   __shared__ FixList fix;
   __shared__ unsigned s_rowmin[2 * WAVES];
   __shared__ float s_c0;
+  __shared__ float s_wf[RAD + 1];
   __shared__ double s_wsum;
 
   const int tid = threadIdx.x;
@@ -371,6 +379,7 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
   if (wave == 0) {
     double ws;
     const float cc0 = margin_c0<RAD>(wts, ws);
+    publish_taps<RAD>(wts, s_wf, lane);
     if (tid == 0) {
       s_c0 = cc0;
       s_wsum = ws;
@@ -435,7 +444,7 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
   __syncthreads();  // staging visible (per wave), fix.cnt / s_c0 / s_rowmin visible (workgroup)
 
   PkTaps<RAD> taps;
-  load_taps<RAD>(wts, taps, s_c0);
+  load_taps<RAD>(s_wf, taps, s_c0);
   const bool m0z = mna == kBias1, m1z = mnb == kBias1;
 
   unsigned failmask = 0;

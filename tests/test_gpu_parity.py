@@ -919,8 +919,8 @@ def _check_gaussian_cases(dev):
 
 
 def test_gaussian_default_kernels_on_epid_and_ragged_frames(dev):
-    """Default dispatch (float64 kernel on axis 0, packed-float32 decision kernel on axis 1): EPID-like frames,
-    zero regions, constant blocks, full-range noise, ragged shapes, int16 plateaus."""
+    """Default dispatch (packed-float32 decision kernels on both axes, float64 kernels where they do not apply):
+    EPID-like frames, zero regions, constant blocks, full-range noise, ragged shapes, int16 plateaus."""
     _check_gaussian_cases(dev)
 
 
@@ -940,7 +940,7 @@ def _gaussian_cases_in_subprocess(pk: str):
 
 
 def test_gaussian_packed_f32_kernels_on_both_axes(dev):
-    """PL_GAUSS_PK=1 (gaussian_pk.hip on both axes): trunc(S) decided in packed float32, undecided pixels
+    """PL_GAUSS_PK=1 (= the default; gaussian_pk.hip on both axes): trunc(S) decided in packed float32, undecided pixels
     recomputed with scipy's float64 sequence from the LDS tile.  Same cases, in a fresh process (the switch is
     read once per process): sparse undecided pixels (workgroup list), list overflow (full-range noise, saturated
     frames -> whole-tile recompute), zero regions (S == 0 shortcut), odd widths (axis 0 falls back to the float64
