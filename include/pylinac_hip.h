@@ -247,6 +247,9 @@ int pl_roi_stats(const void* d_frames, int dtype, int64_t n, int h, int w, const
  * for kind 1 (may be NULL for kind 0).  d_out float64 [n_profiles][n_query]. */
 int pl_interp1d(const double* d_x, int64_t x_stride, const double* d_y, int64_t n_profiles, int length,
                 const double* d_xq, int n_query, int kind, double* d_work, double* d_out, void* stream);
+/* np.gradient(y) (unit spacing, edge_order 1) per profile, as SingleProfile.inflection_data takes it of the
+ * smoothed profile (pylinac/core/profile.py:1643-1647).  float64 [n_profiles][length] -> same shape. */
+int pl_gradient1d(const double* d_y, int64_t n_profiles, int length, double* d_out, void* stream);
 
 /* ---- a18: noise power spectrum, radial average, ESF-FFT MTF ---------------------------------------
  * pl_nps2d: pylinac/core/nps.py:35-79 noise_power_spectrum_2d.  d_rois float64, n_rois ROIs of which the

@@ -942,11 +942,12 @@ class SingleProfileRestated:
 
     def __init__(self, values, dpmm=None, interpolation="Linear", ground=True, interpolation_resolution_mm=0.1,
                  interpolation_factor=10, normalization_method="Beam center", x_values=None,
-                 centering="Beam center"):
+                 centering="Beam center", edge_detection_method="FWHM", edge_smoothing_ratio=0.003):
         from scipy.interpolate import interp1d
 
         values = np.asarray(values, dtype=float)
         self.dpmm, self._centering = dpmm, centering
+        self._edge, self._smooth = edge_detection_method, edge_smoothing_ratio
         if x_values is None:
             x_values = np.array(range(len(values)))
         if np.diff(x_values).min() < 0:
@@ -975,7 +976,7 @@ class SingleProfileRestated:
             cv = (fitted[n // 2] + fitted[n // 2 - 1]) / 2.0 if n % 2 == 0 else fitted[(n - 1) // 2]
             self._set(fitted / cv)
         elif normalization_method == "Beam center":
-            self._set(fitted / self.fwxm_data(50)["center value (@rounded)"])
+            self._set(fitted / self.beam_center()["value (@rounded)"])
 
     def _set(self, v):
         from scipy.interpolate import interp1d
@@ -996,6 +997,25 @@ class SingleProfileRestated:
                 "left value (@rounded)": self._yat(int(round(left))), "right index (exact)": right,
                 "right value (@rounded)": self._yat(int(round(right))),
                 "field values": self._yat(self.x_indices[int(round(left)): int(round(right))])}
+
+    def inflection_data(self):
+        """profile.py:1635-1670 (INFLECTION_DERIVATIVE; MultiProfile.find_peaks / find_valleys :2050-2133)."""
+        d1 = np.gradient(ndimage.gaussian_filter1d(self.values, sigma=self._smooth * len(self.values)))
+        pk, _ = find_peaks(d1, threshold=0.8, peak_separation=0.05)
+        vl, _ = find_peaks(-d1, threshold=0.8, peak_separation=0.05)
+        left, right = float(self._x(pk[0])), float(self._x(vl[-1]))
+        return {"left index (exact)": left, "right index (exact)": right,
+                "left value (@rounded)": self._yat(int(round(left))), "left value (@exact)": self._yat(left),
+                "right value (@rounded)": self._yat(int(round(right))), "right value (@exact)": self._yat(right)}
+
+    def beam_center(self):
+        """profile.py:1390-1409."""
+        if self._edge == "FWHM":
+            d = self.fwxm_data(50)
+            return {"index (exact)": d["center index (exact)"], "value (@rounded)": d["center value (@rounded)"]}
+        infl = self.inflection_data()
+        mid = infl["left index (exact)"] + (infl["right index (exact)"] - infl["left index (exact)"]) / 2
+        return {"index (exact)": mid, "value (@rounded)": self._yat(int(round(mid)))}
 
     def _window(self, a, b):
         lower, upper = sorted((a, b))
@@ -1018,8 +1038,12 @@ class SingleProfileRestated:
 
         if slope_exclusion_ratio >= in_field_ratio:
             raise ValueError("The exclusion region must be smaller than the field ratio")
-        d = self.fwxm_data(50)
-        beam, full = d["center index (exact)"], d["width (exact)"]
+        if self._edge == "FWHM":
+            d = self.fwxm_data(50)
+            beam, full = d["center index (exact)"], d["width (exact)"]
+        else:
+            d = self.inflection_data()
+            beam, full = self.beam_center()["index (exact)"], d["right index (exact)"] - d["left index (exact)"]
         cax = float(self._x((len(self.values) - 1) / 2.0))
         center = cax if self._centering == "Geometric center" else beam
         fl, fr = center - in_field_ratio * full / 2, center + in_field_ratio * full / 2

@@ -119,7 +119,27 @@ __global__ void spline_eval_kernel(const double* __restrict__ x, int64_t x_strid
            (ys[hi] / hh - m[hi] * hh / 6.0) * b;
 }
 
+// np.gradient(y) with unit spacing, edge_order 1: central differences inside, one-sided at the two ends
+__global__ void gradient_kernel(const double* __restrict__ y, int L, int64_t total, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % L);
+  const double* p = y + (i - k);
+  out[i] = k == 0 ? p[1] - p[0] : (k == L - 1 ? p[L - 1] - p[L - 2] : (p[k + 1] - p[k - 1]) / 2.0);
+}
+
 }  // namespace
+
+extern "C" int pl_gradient1d(const double* y, int64_t n_profiles, int length, double* out, void* stream) {
+  PL_REQUIRE(y && out, "null pointer");
+  PL_REQUIRE(n_profiles >= 0 && length >= 2, "np.gradient needs at least 2 samples");
+  if (n_profiles == 0) return PL_OK;
+  const int64_t total = n_profiles * (int64_t)length;
+  PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "batch too large for one launch");
+  hipLaunchKernelGGL(gradient_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                     y, length, total, out);
+  return pl_check_launch("pl_gradient1d");
+}
 
 extern "C" int pl_interp1d(const double* x, int64_t x_stride, const double* y, int64_t n_profiles, int length,
                            const double* xq, int n_query, int kind, double* work, double* out, void* stream) {

@@ -652,3 +652,11 @@ def interp1d(x: torch.Tensor, y: torch.Tensor, xq: torch.Tensor, kind: str = "li
                                   0 if kind == "linear" else 1, work.data_ptr() if work is not None else None,
                                   out.data_ptr(), _stream()), "pl_interp1d")
     return out if y.ndim == 2 else out[0]
+
+
+def gradient1d(y: torch.Tensor) -> torch.Tensor:
+    """``np.gradient(y)`` (unit spacing) for [L] or [N, L] float64 profiles."""
+    y2 = (y if y.ndim == 2 else y[None]).to(torch.float64).contiguous()
+    out = torch.empty_like(y2)
+    check(_lib.load().pl_gradient1d(y2.data_ptr(), y2.shape[0], y2.shape[1], out.data_ptr(), _stream()), "pl_gradient1d")
+    return out if y.ndim == 2 else out[0]

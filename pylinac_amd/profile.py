@@ -371,9 +371,9 @@ class _Linear1d:
 class SingleProfile:
     """pylinac/core/profile.py:1118-1633: a profile with one large signal (a beam profile).
 
-    Same constructor arguments, dictionary keys and error behaviour as the reference for the FWHM edge
-    method (the inflection / Hill edge methods are row f4 and raise
-    NotImplementedError).  Resampling (``pl_interp1d``), grounding / normalisation (elementwise kernels) and
+    Same constructor arguments, dictionary keys and error behaviour as the reference for the FWHM and
+    INFLECTION_DERIVATIVE edge methods (SURVEY.md section 8 row a11 and part of row f4; the Hill-fit edge method
+    raises NotImplementedError).  Resampling (``pl_interp1d``), grounding / normalisation (elementwise kernels) and
     the FWXM search (``pl_find_peaks``) run on the GPU; ``values`` is the host copy the reference's users
     read, ``values_device`` the resident tensor.  The handful of scalar look-ups and three-parameter fits of
     ``field_data`` are host numpy, like the reference's.
@@ -392,8 +392,9 @@ class SingleProfile:
         self._edge_smoothing_ratio = edge_smoothing_ratio
         self._hill_window_ratio = hill_window_ratio
         self._centering = _enum(centering, Centering)
-        if self._edge_method != Edge.FWHM:
-            raise NotImplementedError("inflection / Hill edge detection is SURVEY.md row f4; only Edge.FWHM is built")
+        if self._edge_method == Edge.INFLECTION_HILL:
+            raise NotImplementedError("Hill-fit edge detection (SURVEY.md row f4) is not built; "
+                                      "Edge.FWHM and Edge.INFLECTION_DERIVATIVE are")
         self.dpmm = dpmm
         dev_values = _to_device_profile(values)
         fitted, new_dpmm, x_indices = self._interpolate(dev_values, x_values, dpmm, interpolation_resolution_mm,
@@ -473,10 +474,37 @@ class SingleProfile:
         return self._geometric_center(self.values)
 
     def beam_center(self) -> dict:
-        """profile.py:1390-1409 (FWHM branch)."""
-        data = self.fwxm_data(x=50)
-        return {"index (rounded)": data["center index (rounded)"], "index (exact)": data["center index (exact)"],
-                "value (@rounded)": data["center value (@rounded)"]}
+        """profile.py:1390-1409."""
+        if self._edge_method == Edge.FWHM:
+            data = self.fwxm_data(x=50)
+            return {"index (rounded)": data["center index (rounded)"], "index (exact)": data["center index (exact)"],
+                    "value (@rounded)": data["center value (@rounded)"]}
+        infl = self.inflection_data()
+        mid_point = infl["left index (exact)"] + (infl["right index (exact)"] - infl["left index (exact)"]) / 2
+        return {"index (rounded)": int(round(mid_point)), "index (exact)": mid_point,
+                "value (@rounded)": self._y_original_to_interp(int(round(mid_point)))}
+
+    def inflection_data(self) -> dict:
+        """profile.py:1635-1670 (INFLECTION_DERIVATIVE): edges = outermost extrema of the gradient of the
+        Gaussian-smoothed profile.  Smoothing, gradient and both peak searches run on the device."""
+        if self._edge_method == Edge.FWHM:
+            raise ValueError("FWHM edge method does not have inflection points. Use a different edge detection method")
+        sm = ops.gaussian_filter1d(self.values_device[None], self._edge_smoothing_ratio * len(self.values))[0]
+        d1 = ops.gradient1d(sm)
+        peak_idxs, _ = find_peaks(d1, threshold=0.8, peak_separation=0.05)        # MultiProfile(d1).find_peaks
+        valley_idxs, _ = find_peaks(-d1, threshold=0.8, peak_separation=0.05)     # MultiProfile(d1).find_valleys
+        left_idx = self._x_interp_to_original(peak_idxs[0])
+        right_idx = self._x_interp_to_original(valley_idxs[-1])
+        return {
+            "left index (rounded)": int(round(left_idx)),
+            "left index (exact)": left_idx,
+            "right index (rounded)": int(round(right_idx)),
+            "right index (exact)": right_idx,
+            "left value (@rounded)": self._y_original_to_interp(int(round(left_idx))),
+            "left value (@exact)": self._y_original_to_interp(left_idx),
+            "right value (@rounded)": self._y_original_to_interp(int(round(right_idx))),
+            "right value (@exact)": self._y_original_to_interp(right_idx),
+        }
 
     def fwxm_data(self, x: int = 50) -> dict:
         """profile.py:1411-1461.  The slice of ``x_indices`` by ROUNDED PHYSICAL positions for
@@ -528,14 +556,19 @@ class SingleProfile:
         return x_samples, self._y_original_to_interp(x_samples)
 
     def field_data(self, in_field_ratio: float = 0.8, slope_exclusion_ratio=0.2) -> dict:
-        """profile.py:1463-1633 (FWHM branch): in-field window, two edge-slope regressions, quadratic "top"."""
+        """profile.py:1463-1633: in-field window, two edge-slope regressions, quadratic "top"."""
         if not 0 <= in_field_ratio <= 1.0 or not 0 <= slope_exclusion_ratio <= 1.0:
             raise ValueError("in_field_ratio and slope_exclusion_ratio must be within (0, 1)")
         if slope_exclusion_ratio >= in_field_ratio:
             raise ValueError("The exclusion region must be smaller than the field ratio")
-        data = self.fwxm_data(x=50)
-        beam_center_idx = data["center index (exact)"]
-        full_width = data["width (exact)"]
+        if self._edge_method == Edge.FWHM:
+            data = self.fwxm_data(x=50)
+            beam_center_idx = data["center index (exact)"]
+            full_width = data["width (exact)"]
+        else:
+            data = self.inflection_data()
+            beam_center_idx = self.beam_center()["index (exact)"]
+            full_width = data["right index (exact)"] - data["left index (exact)"]
         beam_center_idx_r = int(round(beam_center_idx))
         cax_idx = self.geometric_center()["index (exact)"]
         cax_idx_r = int(round(cax_idx))

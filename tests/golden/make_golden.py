@@ -611,6 +611,20 @@ def main():
             record(f"fx{i}.{mode}", p)
             frozen = getattr(fx, attr)
             sg[f"fx{i}.{mode}.frozen_metrics"] = np.array([frozen[m] for m in METRICS])
+    # inflection-derivative edge method (row f4, first half) on the same fixtures
+    INFL_KEYS = ["left index (exact)", "right index (exact)", "left value (@rounded)", "left value (@exact)",
+                 "right value (@rounded)", "right value (@exact)"]
+    sg["infl_keys"] = np.array(INFL_KEYS)
+    for i, fx in enumerate(fxm.PROFILE_REGRESSION_FIXTURES):
+        for mode, interp in (("none", prof.Interpolation.NONE), ("linear", prof.Interpolation.LINEAR)):
+            try:
+                p = prof.SingleProfile(fx.values, x_values=fx.x_values, interpolation=interp,
+                                       edge_detection_method=prof.Edge.INFLECTION_DERIVATIVE)
+                record(f"fx{i}.infl_{mode}", p)
+                inf = p.inflection_data()
+                sg[f"fx{i}.infl_{mode}.infl"] = np.array([float(inf[k]) for k in INFL_KEYS])
+            except Exception as exc:   # a few coarse profiles have no gradient peak above 80 %: recorded as such
+                sg[f"fx{i}.infl_{mode}.error"] = np.array(type(exc).__name__)
     # EPID-style profiles (pixel units, dpmm) through the options the fixtures do not touch
     epid = np.mean(synth_frames(1, 96, 400, seed=91)[0][40:56].astype(float), axis=0)
     opts = {"dpmm": dict(dpmm=1 / 0.336),

@@ -1053,7 +1053,7 @@ def test_single_profile_vs_reference_frozen_fixtures(golden, dev):
     with pytest.raises(ValueError):
         pp.SingleProfile(g["epid.y"]).field_data(in_field_ratio=0.2, slope_exclusion_ratio=0.5)
     with pytest.raises(NotImplementedError):
-        pp.SingleProfile(g["epid.y"], edge_detection_method="Inflection Derivative")
+        pp.SingleProfile(g["epid.y"], edge_detection_method="Inflection Hill")
 
 
 def test_interp1d_batch_vs_scipy(dev):
@@ -1237,3 +1237,27 @@ def test_translation_equivariance_at_batch_size(dev):
     assert bool(ok[0].any()) and torch.equal(torch.isfinite(res.position), ok)
     diff = (res.position - pos0 - dx.to(dev, torch.float64)[:, None, None])[ok]
     assert float(diff.abs().max()) < 1e-9
+
+
+def test_single_profile_inflection_derivative_vs_reference(golden, dev):
+    """Edge.INFLECTION_DERIVATIVE on the device (Gaussian smoothing, np.gradient, peak / valley search of the
+    gradient): inflection indices exact, values and every field_data scalar to 1e-9, protocol metrics to 1e-9
+    of the reference run on its 20 frozen profiles; the Hill-fit edge method reports NotImplementedError."""
+    from pylinac_amd import profile as pp
+    from tests.test_oracle_golden import _sp_calculators, _sp_check
+
+    g = golden("single_profile")
+    calcs = _sp_calculators()
+    for i in range(20):
+        for mode, interp in (("none", None), ("linear", "Linear")):
+            p = pp.SingleProfile(g[f"fx{i}.y"], x_values=g[f"fx{i}.x"], interpolation=interp,
+                                 edge_detection_method="Inflection Derivative")
+            _sp_check(g, f"fx{i}.infl_{mode}", p, calcs, vtol=0, ftol=1e-9)
+            inf = p.inflection_data()
+            ref = g[f"fx{i}.infl_{mode}.infl"]
+            got = np.array([inf[str(k)] for k in g["infl_keys"]])
+            assert np.array_equal(got[:2], ref[:2]) and np.allclose(got[2:], ref[2:], rtol=1e-9, atol=1e-12), (i, mode)
+    with pytest.raises(ValueError):
+        pp.SingleProfile(g["fx0.y"], x_values=g["fx0.x"], interpolation=None).inflection_data()
+    with pytest.raises(NotImplementedError):
+        pp.SingleProfile(g["fx0.y"], edge_detection_method="Inflection Hill")

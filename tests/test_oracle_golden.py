@@ -455,3 +455,17 @@ def test_disk_roi_restatement_matches_reference(golden):
         ref = g[f"stats_{name}"]
         assert np.array_equal(got[:, [0, 3, 4, 5]], ref[:, [0, 3, 4, 5]]), name
         assert np.allclose(got[:, 1:3], ref[:, 1:3], rtol=1e-13, atol=0), name
+
+
+def test_single_profile_inflection_derivative_restatement(golden):
+    """Row f4 (first half): Edge.INFLECTION_DERIVATIVE -- oracle against the reference run on the 20 frozen
+    profiles (no interpolation / linear): inflection indices and values, field_data, protocol metrics."""
+    g = golden("single_profile")
+    calcs = _sp_calculators()
+    for i in range(20):
+        for mode, interp in (("none", None), ("linear", "Linear")):
+            p = o.SingleProfileRestated(g[f"fx{i}.y"], x_values=g[f"fx{i}.x"], interpolation=interp,
+                                        edge_detection_method="Inflection Derivative")
+            _sp_check(g, f"fx{i}.infl_{mode}", p, calcs, vtol=0, ftol=1e-12)
+            inf = p.inflection_data()
+            assert np.allclose([inf[str(k)] for k in g["infl_keys"]], g[f"fx{i}.infl_{mode}.infl"], rtol=1e-12, atol=1e-12)
