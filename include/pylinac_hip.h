@@ -238,6 +238,18 @@ int pl_roi_stats(const void* d_frames, int dtype, int64_t n, int h, int w, const
                  int rois_per_frame, int64_t roi_frame_stride, int kind, double* d_out, int32_t* d_status,
                  void* stream);
 
+/* ---- f4 ("next" row, gamma part): pylinac.core.gamma.gamma_2d (pylinac/core/gamma.py:229-330) --------------
+ * d_reference / d_evaluation float64 [n][h][w]; dose_fraction = dose_to_agreement / 100; global_dose != 0:
+ * dose_ta = dose_fraction * d_ref_max[frame] (reference.max()), else dose_fraction * reference (elementwise).
+ * d_dr / d_dc / d_dist2 [n_offsets]: the skimage.draw.disk((0, 0), DTA + 1) offsets and
+ * (dr / DTA)^2 + (dc / DTA)^2, from the host.  threshold_normalized = dose_threshold / 100.  d_work:
+ * 2 * n * h * w doubles.  d_out float64 [n][h][w]: gamma, gamma_cap where Gamma^2 >= cap^2, fill_value where the
+ * normalised reference is NaN or below the threshold.  Bit-identical to the reference. */
+int pl_gamma2d(const double* d_reference, const double* d_evaluation, int64_t n, int h, int w, double dose_fraction,
+               int global_dose, const double* d_ref_max, const int32_t* d_dr, const int32_t* d_dc,
+               const double* d_dist2, int n_offsets, double threshold_normalized, double gamma_cap,
+               double fill_value, double* d_work, double* d_out, void* stream);
+
 /* ---- a11: profile resampling -----------------------------------------------------------------------
  * scipy.interpolate.interp1d(x, y, kind, bounds_error=False, fill_value="extrapolate")(xq) as called by
  * SingleProfile._interpolate (pylinac/core/profile.py:1349-1358).  d_x float64 abscissae (x_stride elements

@@ -881,6 +881,37 @@ def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=Non
 
 
 # --------------------------------------------------------------------------------------
+# f4 (gamma part): gamma_2d restated with array operations (the reference loops over pixels in Python)
+# --------------------------------------------------------------------------------------
+def gamma_2d(reference, evaluation, dose_to_agreement=1, distance_to_agreement=1, gamma_cap_value=2,
+             global_dose=True, dose_threshold=5, fill_value=np.nan):
+    """pylinac/core/gamma.py:229-330: same operations per pixel, the disk offsets iterated instead of the pixels."""
+    if reference.ndim != 2 or evaluation.ndim != 2:
+        raise ValueError("Reference and evaluation arrays must be 2D.")
+    dose_ta = dose_to_agreement / 100 * (reference.max() if global_dose else reference)
+    with np.errstate(all="ignore"):
+        ev = np.pad(evaluation / dose_ta, distance_to_agreement, mode="edge")
+        rn = reference / dose_ta
+    r = distance_to_agreement + 1                                 # skimage.draw.disk((0, 0), DTA + 1)
+    grid = np.arange(-r, r + 1, dtype=float)
+    rr, cc = np.nonzero((grid[:, None] / r) ** 2 + (grid[None, :] / r) ** 2 < 1)
+    rr, cc = rr - r, cc - r
+    h, w = reference.shape
+    best = np.full(reference.shape, np.nan)
+    for dr, dc in zip(rr, cc):
+        d2 = (dr / distance_to_agreement) ** 2 + (dc / distance_to_agreement) ** 2
+        roi = ev[distance_to_agreement + dr: distance_to_agreement + dr + h, distance_to_agreement + dc: distance_to_agreement + dc + w]
+        dd = roi - rn
+        best = np.fmin(best, d2 + dd * dd)                        # nanmin over the disk
+    gamma = np.full(reference.shape, float(gamma_cap_value))
+    with np.errstate(all="ignore"):
+        calc = ~(best >= gamma_cap_value**2)
+        gamma[calc] = np.sqrt(best[calc])
+        gamma[np.isnan(rn) | (rn < dose_threshold / 100)] = fill_value
+    return gamma
+
+
+# --------------------------------------------------------------------------------------
 # f3: DiskROI statistics (skimage.draw.disk restated by disk_mask_like_skimage)
 # --------------------------------------------------------------------------------------
 def disk_roi_stats(arr: np.ndarray, cx: float, cy: float, radius: float) -> np.ndarray:

@@ -1,0 +1,82 @@
+// 2-D gamma index (SURVEY.md section 8 "next" row f4, gamma part).
+//
+// Replaces: pylinac.core.gamma.gamma_2d (pylinac/core/gamma.py:229-330) -- a Python double loop over every
+// reference pixel that gathers an evaluation disk of radius DTA + 1 (skimage.draw.disk) and takes
+//   Gamma^2 = nanmin_k ( dist2[k] + (eval_n[r + dr_k, c + dc_k] - ref_n[r, c])^2 ),
+// with both images divided by the dose-to-agreement first (global: pct/100 * reference.max(); local:
+// pct/100 * reference, elementwise -- the evaluation image is divided by the REFERENCE pixel at its own
+// position, as the reference writes it), the evaluation edge-padded by DTA, pixels with NaN or
+// ref_n < threshold/100 set to fill_value, Gamma capped.  Same float64 operations in the same order, IEEE
+// sqrt: bit-identical.  One lane per reference pixel, the disk offsets and their squared distances come
+// from the host (a few dozen entries, computed with skimage's own formula).
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// out = a / (scale * b)   (b == nullptr: out = a / scale)
+__global__ void gamma_normalize_kernel(const double* __restrict__ a, const double* __restrict__ b, double scale,
+                                       const double* __restrict__ frame_scale, int64_t per_frame, int64_t total,
+                                       double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const double dose_ta = b ? scale * b[i] : scale * frame_scale[i / per_frame];
+  out[i] = a[i] / dose_ta;
+}
+
+__global__ void gamma2d_kernel(const double* __restrict__ ref_n, const double* __restrict__ ev_n, int h, int w,
+                               const int* __restrict__ dr, const int* __restrict__ dc,
+                               const double* __restrict__ dist2, int k, double thr, double cap, double fill,
+                               int64_t total, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % w);
+  const int64_t t = i / w;
+  const int r = (int)(t % h);
+  const double* ev = ev_n + (t / h) * (int64_t)h * w;
+  const double rp = ref_n[i];
+  if (rp != rp || rp < thr) {            // math.isnan(ref_point) or ref_point < threshold_normalized
+    out[i] = fill;
+    return;
+  }
+  double best = __longlong_as_double(0x7ff8000000000000LL);   // nanmin of nothing but NaNs is NaN
+  bool any = false;
+  for (int q = 0; q < k; ++q) {
+    int rr = r + dr[q], cc = c + dc[q];   // np.pad(mode="edge"): clamp
+    rr = rr < 0 ? 0 : (rr >= h ? h - 1 : rr);
+    cc = cc < 0 ? 0 : (cc >= w ? w - 1 : cc);
+    const double d = ev[(int64_t)rr * w + cc] - rp;
+    const double v = dist2[q] + d * d;
+    if (v == v && (!any || v < best)) { best = v; any = true; }
+  }
+  const double cap2 = cap * cap;
+  if (best >= cap2) { out[i] = cap; return; }   // NaN compares false: falls through to sqrt(NaN) = NaN
+  out[i] = sqrt(best);
+}
+
+}  // namespace
+
+extern "C" int pl_gamma2d(const double* d_reference, const double* d_evaluation, int64_t n, int h, int w,
+                          double dose_fraction, int global_dose, const double* d_ref_max, const int32_t* d_dr,
+                          const int32_t* d_dc, const double* d_dist2, int n_offsets, double threshold_normalized,
+                          double gamma_cap, double fill_value, double* d_work, double* d_out, void* stream) {
+  PL_REQUIRE(d_reference && d_evaluation && d_dr && d_dc && d_dist2 && d_work && d_out, "null pointer");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0 && n_offsets > 0, "bad shape");
+  PL_REQUIRE(!global_dose || d_ref_max, "global dose needs the per-frame reference maxima");
+  if (n == 0) return PL_OK;
+  const int64_t per = (int64_t)h * w, total = n * per;
+  PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "batch too large for one launch");
+  hipStream_t st = (hipStream_t)stream;
+  double* ref_n = d_work;
+  double* ev_n = d_work + total;
+  const unsigned blocks = (unsigned)pl_cdiv(total, kThreads);
+  const double* local = global_dose ? nullptr : d_reference;
+  hipLaunchKernelGGL(gamma_normalize_kernel, dim3(blocks), dim3(kThreads), 0, st, d_reference, local, dose_fraction,
+                     d_ref_max, per, total, ref_n);
+  hipLaunchKernelGGL(gamma_normalize_kernel, dim3(blocks), dim3(kThreads), 0, st, d_evaluation, local, dose_fraction,
+                     d_ref_max, per, total, ev_n);
+  hipLaunchKernelGGL(gamma2d_kernel, dim3(blocks), dim3(kThreads), 0, st, ref_n, ev_n, h, w, d_dr, d_dc, d_dist2,
+                     n_offsets, threshold_normalized, gamma_cap, fill_value, total, d_out);
+  return pl_check_launch("pl_gamma2d");
+}

@@ -1,0 +1,70 @@
+"""2-D gamma index on the device (SURVEY.md section 8 "next" row f4): mirror of ``pylinac.core.gamma.gamma_2d``.
+
+Same arguments, defaults and errors as pylinac/core/gamma.py:229-330; ``reference`` / ``evaluation`` may also be
+[N, H, W] batches (one gamma map per pair).  The reference runs a Python loop over every pixel; here one lane
+computes one reference pixel (``pl_gamma2d``), bit-identical.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+
+def disk_offsets(distance_to_agreement: int):
+    """``skimage.draw.disk((0, 0), distance_to_agreement + 1)`` (draw.py ``ellipse`` / ``_ellipse_in_shape``, rotation 0,
+    no shape clipping) -> (rr, cc) int arrays in ``np.nonzero`` order."""
+    radius = float(distance_to_agreement + 1)
+    center = np.array([0.0, 0.0])
+    radii = np.array([radius, radius])
+    upper_left = np.ceil(center - radii).astype(int)
+    lower_right = np.floor(center + radii).astype(int)
+    shifted = center - upper_left
+    bshape = lower_right - upper_left + 1
+    r_lim, c_lim = np.ogrid[0:float(bshape[0]), 0:float(bshape[1])]
+    r, c = (r_lim - shifted[0]), (c_lim - shifted[1])
+    dist = ((r * 1.0 + c * 0.0) / radii[0]) ** 2 + ((r * 0.0 - c * 1.0) / radii[1]) ** 2
+    rr, cc = np.nonzero(dist < 1)
+    return rr + upper_left[0], cc + upper_left[1]
+
+
+def gamma_2d(reference, evaluation, dose_to_agreement: float = 1, distance_to_agreement: int = 1,
+             gamma_cap_value: float = 2, global_dose: bool = True, dose_threshold: float = 5,
+             fill_value: float = np.nan, device=None) -> torch.Tensor:
+    """pylinac/core/gamma.py:229-330 -> float64 tensor with the shape of ``reference``."""
+    def dev_of(a):
+        return a.device if isinstance(a, torch.Tensor) and a.is_cuda else None
+
+    dev = dev_of(reference) or dev_of(evaluation) or (torch.device(device) if device is not None
+                                                      else torch.device("cuda", torch.cuda.current_device()))
+
+    def to_t(a):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(device=dev, dtype=torch.float64).contiguous()
+
+    ref, ev = to_t(reference), to_t(evaluation)
+    batched = ref.ndim == 3
+    if (ref.ndim, ev.ndim) not in ((2, 2), (3, 3)):
+        raise ValueError(f"Reference and evaluation arrays must be 2D. Got reference: {ref.ndim} and evaluation: {ev.ndim}")
+    if ref.shape != ev.shape:
+        raise ValueError("reference and evaluation must have the same shape")   # the reference would IndexError
+    if not batched:
+        ref, ev = ref[None], ev[None]
+    n, h, w = ref.shape
+    dta = int(distance_to_agreement)
+    rr, cc = disk_offsets(dta)
+    dist2 = (rr / dta) ** 2 + (cc / dta) ** 2            # dist_row**2 + dist_col**2 (gamma.py:296-298)
+    d_dr = torch.from_numpy(rr.astype(np.int32)).to(dev)
+    d_dc = torch.from_numpy(cc.astype(np.int32)).to(dev)
+    d_d2 = torch.from_numpy(np.ascontiguousarray(dist2, dtype=np.float64)).to(dev)
+    _, ref_max = ops.minmax(ref)
+    work = torch.empty(2 * n * h * w, dtype=torch.float64, device=dev)
+    out = torch.empty((n, h, w), dtype=torch.float64, device=dev)
+    check(_lib.load().pl_gamma2d(ref.data_ptr(), ev.data_ptr(), n, h, w, dose_to_agreement / 100,
+                                 1 if global_dose else 0, ref_max.data_ptr(), d_dr.data_ptr(), d_dc.data_ptr(),
+                                 d_d2.data_ptr(), len(rr), dose_threshold / 100, float(gamma_cap_value),
+                                 float(fill_value), work.data_ptr(), out.data_ptr(),
+                                 torch.cuda.current_stream(dev).cuda_stream), "pl_gamma2d")
+    return out if batched else out[0]

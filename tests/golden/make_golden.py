@@ -667,6 +667,50 @@ def main():
     rg.update(slice_i16=ct_slice, slice_f32=sl_f.astype(np.float32), rois=rois)   # slice_f64 = slice_f32 exactly
     np.savez_compressed(os.path.join(HERE, "roi.npz"), **rg)
 
+    # ---- 13. 2-D gamma: the reference's own gamma_2d (next row f4), its known-answer inputs + dose-like images
+    rng = np.random.default_rng(81)
+    cases = []
+
+    def add(ref, ev, **kw):
+        cases.append((np.asarray(ref, float), np.asarray(ev, float), kw))
+
+    one = np.ones((5, 5))
+    add(one, one)                                                     # test_gamma.py:108-121: all zeros
+    add(one * 50, one * 50)
+    add(one, one * 1.01, dose_to_agreement=1)                         # :122-136: exactly 1
+    add(one, one * 0.99, dose_to_agreement=1)
+    ev = one.copy(); ev[(0, 0, 1, 1), (0, 1, 1, 0)] = 1.03           # :137-170
+    add(one, ev, dose_to_agreement=1, distance_to_agreement=1, gamma_cap_value=5)
+    ref = one.copy(); ref[0, 0] = 100; ev = one.copy(); ev[0, 0] = 103; ev[0, 1] = 1.03   # :171-191 local dose
+    add(ref, ev, dose_to_agreement=3, distance_to_agreement=1, gamma_cap_value=5, global_dose=False, dose_threshold=0)
+    z = np.zeros((5, 5)); z[0, 0] = 1                                 # :193-230 threshold / fill value
+    add(z, z, dose_to_agreement=3, distance_to_agreement=1, gamma_cap_value=5, global_dose=False, dose_threshold=5)
+    add(z, z, dose_to_agreement=3, distance_to_agreement=1, gamma_cap_value=5, global_dose=False, dose_threshold=5,
+        fill_value=0.666)
+    add(one, one / 1.005, dose_to_agreement=1)                        # :232-238 half
+    add(one, one * 10, dose_to_agreement=1, gamma_cap_value=2)        # :240-248 cap
+    yy, xx = np.mgrid[0:72, 0:90]
+    dose = 100 * np.exp(-(((yy - 35) / 22.0) ** 4 + ((xx - 44) / 28.0) ** 4))
+    meas = 100 * np.exp(-(((yy - 35.6) / 22.3) ** 4 + ((xx - 43.2) / 27.7) ** 4)) * (1 + rng.normal(0, 0.01, dose.shape))
+    for dta, dd, glob, thr in ((1, 1, True, 5), (2, 2, True, 10), (3, 3, False, 10), (4, 1, True, 0), (2, 3, False, 0)):
+        add(dose, meas, dose_to_agreement=dd, distance_to_agreement=dta, global_dose=glob, dose_threshold=thr,
+            gamma_cap_value=2 if dta < 3 else 1.5, fill_value=np.nan if dta != 2 else 0.0)
+    hole = meas.copy(); hole[30:34, 40:47] = np.nan                  # NaNs in the evaluation are skipped by nanmin
+    add(dose, hole, dose_to_agreement=2, distance_to_agreement=2)
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "w.npz"), os.path.join(td, "f.npz")
+        pack = {"count": len(cases)}
+        for k, (r_, e_, kw) in enumerate(cases):
+            pack[f"ref{k}"], pack[f"ev{k}"], pack[f"kw{k}"] = r_, e_, np.array(kw, dtype=object)
+        np.savez(inp, **pack)
+        subprocess.run([PY39, os.path.join(HERE, "skimage_gamma_py39.py"), inp, outp, ROOT], check=True)
+        gg = dict(np.load(outp))
+    gg["count"] = np.int64(len(cases))
+    for k, (r_, e_, kw) in enumerate(cases):
+        gg[f"ref{k}"], gg[f"ev{k}"] = r_, e_
+        gg[f"kw{k}"] = np.array(json.dumps({a: (None if isinstance(b, float) and np.isnan(b) else b) for a, b in kw.items()}))
+    np.savez_compressed(os.path.join(HERE, "gamma.npz"), **gg)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

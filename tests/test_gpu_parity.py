@@ -1261,3 +1261,27 @@ def test_single_profile_inflection_derivative_vs_reference(golden, dev):
         pp.SingleProfile(g["fx0.y"], x_values=g["fx0.x"], interpolation=None).inflection_data()
     with pytest.raises(NotImplementedError):
         pp.SingleProfile(g["fx0.y"], edge_detection_method="Inflection Hill")
+
+
+# ------------------------------------------------------------------------------------ 2-D gamma (f4)
+def test_gamma_2d_vs_reference_golden(golden, dev):
+    """pl_gamma2d against the reference's own gamma_2d: bit-identical gamma maps (NaN positions included) for its
+    known-answer inputs and for dose-like images (DTA 1-4, global / local dose, thresholds, fill values, NaNs in
+    the evaluation); batch form = per-pair results; same ValueError for non-2-D input."""
+    from pylinac_amd import gamma as pg
+    from tests.test_oracle_golden import _gamma_cases
+
+    g = golden("gamma")
+    for k, ref, ev, kw, want in _gamma_cases(g):
+        got = pg.gamma_2d(ref, ev, device=dev, **kw).cpu().numpy()
+        assert np.array_equal(got, want, equal_nan=True), (k, kw)
+    _, ref, ev, kw, want = list(_gamma_cases(g))[11]
+    both = pg.gamma_2d(np.stack([ref, ref[::-1].copy()]), np.stack([ev, ev[::-1].copy()]), device=dev, **kw).cpu().numpy()
+    assert np.array_equal(both[0], want, equal_nan=True)
+    assert np.array_equal(both[1], o.gamma_2d(ref[::-1], ev[::-1], **kw), equal_nan=True)
+    with pytest.raises(ValueError):
+        pg.gamma_2d(np.ones(5), np.ones((5, 5)), device=dev)
+    # full-size property (no oracle): gamma of an image against itself is 0 wherever it is evaluated
+    big = torch.rand((4, 1024, 1024), device=dev, dtype=torch.float64) + 0.5
+    z = pg.gamma_2d(big, big, distance_to_agreement=3)
+    assert float(z.max()) == 0.0

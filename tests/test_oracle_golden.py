@@ -469,3 +469,28 @@ def test_single_profile_inflection_derivative_restatement(golden):
             _sp_check(g, f"fx{i}.infl_{mode}", p, calcs, vtol=0, ftol=1e-12)
             inf = p.inflection_data()
             assert np.allclose([inf[str(k)] for k in g["infl_keys"]], g[f"fx{i}.infl_{mode}.infl"], rtol=1e-12, atol=1e-12)
+
+
+def _gamma_cases(g):
+    import json
+
+    for k in range(int(g["count"])):
+        kw = json.loads(str(g[f"kw{k}"]))
+        if "fill_value" in kw and kw["fill_value"] is None:
+            kw["fill_value"] = np.nan
+        yield k, g[f"ref{k}"], g[f"ev{k}"], kw, g[f"g{k}"]
+
+
+def test_gamma_2d_restatement_matches_reference(golden):
+    """f4 (gamma): oracle.gamma_2d against the reference's own gamma_2d (its known-answer inputs from
+    tests_basic/core/test_gamma.py:107-260 and dose-like images with DTA 1-4, global / local dose, thresholds,
+    fill values, NaNs in the evaluation): bit-identical maps."""
+    g = golden("gamma")
+    for k, ref, ev, kw, want in _gamma_cases(g):
+        got = o.gamma_2d(ref, ev, **kw)
+        assert np.array_equal(got, want, equal_nan=True), (k, kw)
+    # the reference's own expectations for its known-answer inputs
+    assert g["g0"].max() == 0 and g["g1"].max() == 0
+    assert abs(g["g2"].max() - 1) < 1e-3 and abs(g["g3"].min() - 1) < 1e-3
+    assert abs(g["g4"][0, 0] - 3) < 0.01 and abs(g["g4"][0, 1] - 1) < 0.01 and abs(g["g4"][-1, -1]) < 0.01
+    assert np.isnan(g["g6"][0, 1]) and abs(g["g7"][0, 1] - 0.666) < 0.01 and g["g9"].max() == 2 == g["g9"].min()
