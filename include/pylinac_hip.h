@@ -250,6 +250,17 @@ int pl_gamma2d(const double* d_reference, const double* d_evaluation, int64_t n,
                const double* d_dist2, int n_offsets, double threshold_normalized, double gamma_cap,
                double fill_value, double* d_work, double* d_out, void* stream);
 
+/* pylinac.core.gamma.gamma_1d (pylinac/core/gamma.py:333-455).  d_ref / d_ref_x [n_ref], d_eval / d_eval_x [n_eval]
+ * (abscissae ascending), n_samples = int(DTA * resolution_factor * 2 + 1) search samples per reference point,
+ * threshold = reference.max() / 100 * dose_threshold, dose_ta_global = dose_to_agreement / 100 * reference.max(),
+ * dose_fraction = dose_to_agreement / 100 (local dose), dta_squared = distance_to_agreement ** 2.
+ * d_gamma [n_ref]; d_eval_vals / d_eval_xs [n_ref][n_samples] (rows of skipped points undefined), d_computed int32
+ * [n_ref] (0: below the threshold -> fill_value). */
+int pl_gamma1d(const double* d_ref, const double* d_ref_x, int n_ref, const double* d_eval, const double* d_eval_x,
+               int n_eval, double distance_to_agreement, double dta_squared, int n_samples, double threshold,
+               double dose_ta_global, double dose_fraction, int global_dose, double gamma_cap, double fill_value,
+               double* d_gamma, double* d_eval_vals, double* d_eval_xs, int32_t* d_computed, void* stream);
+
 /* ---- a11: profile resampling -----------------------------------------------------------------------
  * scipy.interpolate.interp1d(x, y, kind, bounds_error=False, fill_value="extrapolate")(xq) as called by
  * SingleProfile._interpolate (pylinac/core/profile.py:1349-1358).  d_x float64 abscissae (x_stride elements

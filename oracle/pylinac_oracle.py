@@ -911,6 +911,41 @@ def gamma_2d(reference, evaluation, dose_to_agreement=1, distance_to_agreement=1
     return gamma
 
 
+def gamma_1d(reference, evaluation, reference_coordinates=None, evaluation_coordinates=None, dose_to_agreement=1,
+             distance_to_agreement=1, gamma_cap_value=2, global_dose=True, dose_threshold=5, resolution_factor=3,
+             fill_value=np.nan):
+    """pylinac/core/gamma.py:333-455 (validation :399-428 omitted): per reference point a linspace of search
+    positions, the evaluation read through a linear extrapolating interp1d, Gamma minimum capped."""
+    from scipy.interpolate import interp1d
+
+    if reference_coordinates is None:
+        reference_coordinates = np.arange(len(reference), dtype=float)
+    if evaluation_coordinates is None:
+        evaluation_coordinates = np.arange(len(evaluation), dtype=float)
+    threshold = reference.max() / 100 * dose_threshold
+    dose_ta = dose_to_agreement / 100 * reference.max()
+    f = interp1d(evaluation_coordinates, evaluation, kind="linear", fill_value="extrapolate")
+    vals, xs, gamma = [], [], []
+    for ref_x, ref_point in zip(reference_coordinates, reference):
+        if ref_point < threshold:
+            gamma.append(fill_value)
+            continue
+        eval_xs = np.linspace(ref_x - distance_to_agreement, ref_x + distance_to_agreement,
+                              num=int(distance_to_agreement * resolution_factor * 2 + 1))
+        eval_vals = f(eval_xs)
+        xs.extend(eval_xs)
+        vals.extend(eval_vals)
+        cgs = []
+        for eval_x, eval_point in zip(eval_xs, eval_vals):
+            dist = abs(ref_x - eval_x)
+            dose = float(ref_point) - float(eval_point)
+            if not global_dose:
+                dose_ta = dose_to_agreement / 100 * ref_point
+            cgs.append(math.sqrt(dist**2 / distance_to_agreement**2 + dose**2 / dose_ta**2))
+        gamma.append(min(min(cgs), gamma_cap_value))
+    return np.asarray(gamma), np.asarray(vals), np.asarray(xs)
+
+
 # --------------------------------------------------------------------------------------
 # f3: DiskROI statistics (skimage.draw.disk restated by disk_mask_like_skimage)
 # --------------------------------------------------------------------------------------

@@ -55,7 +55,68 @@ __global__ void gamma2d_kernel(const double* __restrict__ ref_n, const double* _
   out[i] = sqrt(best);
 }
 
+// gamma_1d (pylinac/core/gamma.py:333-455): one lane per reference point; the search samples are
+// np.linspace(x - DTA, x + DTA, num) (start + k*step, last sample forced to the stop value), the evaluation
+// profile is read through scipy's linear interp1d (slope form, extrapolating), Gamma = sqrt(dist^2 / DTA^2 +
+// dose^2 / dose_ta^2) in Python's operation order, minimum taken sequentially like Python's min().  Agreement:
+// sample positions and values bit-identical; gamma within 2 ulp (the reference squares with float ** 2 = libm
+// pow, not always the correctly rounded product x*x).
+__global__ void gamma1d_kernel(const double* __restrict__ ref, const double* __restrict__ ref_x, int n_ref,
+                               const double* __restrict__ ev, const double* __restrict__ ev_x, int n_ev, double dta,
+                               double dta2, int num, double threshold, double dose_ta_global, double dose_fraction,
+                               int global_dose, double cap, double fill, double* __restrict__ gamma,
+                               double* __restrict__ eval_vals, double* __restrict__ eval_xs, int* __restrict__ computed) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_ref) return;
+  const double x = ref_x[i], v = ref[i];
+  if (v < threshold) {
+    gamma[i] = fill;
+    computed[i] = 0;
+    return;
+  }
+  computed[i] = 1;
+  const double start = x - dta, stop = x + dta;
+  const double step = (stop - start) / (double)(num - 1);
+  const double dose_ta = global_dose ? dose_ta_global : dose_fraction * v;
+  double best = 0.0;
+  for (int k = 0; k < num; ++k) {
+    const double ex = (k == num - 1) ? stop : ((double)k * step + start);
+    // scipy interp1d._call_linear with extrapolation
+    int lo = 0, hi = n_ev;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (ev_x[mid] < ex) lo = mid + 1; else hi = mid;
+    }
+    int h1 = lo < 1 ? 1 : (lo > n_ev - 1 ? n_ev - 1 : lo);
+    const int l1 = h1 - 1;
+    const double slope = (ev[h1] - ev[l1]) / (ev_x[h1] - ev_x[l1]);
+    const double evv = slope * (ex - ev_x[l1]) + ev[l1];
+    eval_xs[(int64_t)i * num + k] = ex;
+    eval_vals[(int64_t)i * num + k] = evv;
+    const double dist = fabs(x - ex);
+    const double dose = v - evv;
+    const double cg = sqrt(dist * dist / dta2 + dose * dose / (dose_ta * dose_ta));
+    if (k == 0 || cg < best) best = cg;
+  }
+  gamma[i] = cap < best ? cap : best;
+}
+
 }  // namespace
+
+extern "C" int pl_gamma1d(const double* d_ref, const double* d_ref_x, int n_ref, const double* d_eval,
+                          const double* d_eval_x, int n_eval, double distance_to_agreement, double dta_squared,
+                          int n_samples, double threshold, double dose_ta_global, double dose_fraction,
+                          int global_dose, double gamma_cap, double fill_value, double* d_gamma, double* d_eval_vals,
+                          double* d_eval_xs, int32_t* d_computed, void* stream) {
+  PL_REQUIRE(d_ref && d_ref_x && d_eval && d_eval_x && d_gamma && d_eval_vals && d_eval_xs && d_computed, "null pointer");
+  PL_REQUIRE(n_ref >= 0 && n_eval >= 2 && n_samples >= 2, "bad shape");
+  if (n_ref == 0) return PL_OK;
+  hipLaunchKernelGGL(gamma1d_kernel, dim3((unsigned)pl_cdiv(n_ref, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                     d_ref, d_ref_x, n_ref, d_eval, d_eval_x, n_eval, distance_to_agreement, dta_squared, n_samples,
+                     threshold, dose_ta_global, dose_fraction, global_dose, gamma_cap, fill_value, d_gamma,
+                     d_eval_vals, d_eval_xs, d_computed);
+  return pl_check_launch("pl_gamma1d");
+}
 
 extern "C" int pl_gamma2d(const double* d_reference, const double* d_evaluation, int64_t n, int h, int w,
                           double dose_fraction, int global_dose, const double* d_ref_max, const int32_t* d_dr,

@@ -68,3 +68,53 @@ def gamma_2d(reference, evaluation, dose_to_agreement: float = 1, distance_to_ag
                                  float(fill_value), work.data_ptr(), out.data_ptr(),
                                  torch.cuda.current_stream(dev).cuda_stream), "pl_gamma2d")
     return out if batched else out[0]
+
+
+def gamma_1d(reference, evaluation, reference_coordinates=None, evaluation_coordinates=None,
+             dose_to_agreement: float = 1, distance_to_agreement: int = 1, gamma_cap_value: float = 2,
+             global_dose: bool = True, dose_threshold: float = 5, resolution_factor: int = 3,
+             fill_value: float = np.nan, device=None):
+    """pylinac/core/gamma.py:333-455 -> (gamma, evaluation samples, their x-values) as numpy arrays, like the
+    reference (the two sample arrays are the concatenation over the reference points that were evaluated)."""
+    reference = np.asarray(reference.cpu() if isinstance(reference, torch.Tensor) else reference)
+    evaluation = np.asarray(evaluation.cpu() if isinstance(evaluation, torch.Tensor) else evaluation)
+    if reference.ndim != 1 or evaluation.ndim != 1:
+        raise ValueError(f"Reference and evaluation arrays must be 1D. Got reference: {reference.ndim} and evaluation: {evaluation.ndim}")
+    if reference_coordinates is None:
+        reference_coordinates = np.arange(len(reference), dtype=float)
+    if len(reference) != len(reference_coordinates):
+        raise ValueError(f"Reference and reference_x_values must be the same length. Got reference: {len(reference)} and reference_x_values: {len(reference_coordinates)}")
+    if evaluation_coordinates is None:
+        evaluation_coordinates = np.arange(len(evaluation), dtype=float)
+    if len(evaluation) != len(evaluation_coordinates):
+        raise ValueError(f"Evaluation and evaluation_x_values must be the same length. Got evaluation: {len(evaluation)} and evaluation_x_values: {len(evaluation_coordinates)}")
+    if min(evaluation_coordinates) - 1 > min(reference_coordinates) or max(evaluation_coordinates) + 1 < max(reference_coordinates):
+        raise ValueError("The reference x-values must be within the range of the evaluation x-values")
+    if resolution_factor < 1 or not isinstance(resolution_factor, int):
+        raise ValueError("Resolution factor must be an integer greater than 0")
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    ref64 = np.asarray(reference, dtype=np.float64)
+    threshold = reference.max() / 100 * dose_threshold
+    dose_ta = dose_to_agreement / 100 * reference.max()
+    ex = np.asarray(evaluation_coordinates, dtype=np.float64)
+    order = np.argsort(ex, kind="mergesort")                    # interp1d(assume_sorted=False) sorts its abscissae
+    ex, ev = ex[order], np.asarray(evaluation, dtype=np.float64)[order]
+    num = int(distance_to_agreement * resolution_factor * 2 + 1)
+    n_ref = len(ref64)
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+    d_ref, d_rx, d_ev, d_ex = up(ref64), up(reference_coordinates), up(ev), up(ex)
+    gamma = torch.empty(n_ref, dtype=torch.float64, device=dev)
+    vals = torch.empty((n_ref, num), dtype=torch.float64, device=dev)
+    xs = torch.empty((n_ref, num), dtype=torch.float64, device=dev)
+    computed = torch.empty(n_ref, dtype=torch.int32, device=dev)
+    check(_lib.load().pl_gamma1d(d_ref.data_ptr(), d_rx.data_ptr(), n_ref, d_ev.data_ptr(), d_ex.data_ptr(), len(ev),
+                                 float(distance_to_agreement), float(distance_to_agreement**2), num, float(threshold),
+                                 float(dose_ta), dose_to_agreement / 100, 1 if global_dose else 0,
+                                 float(gamma_cap_value), float(fill_value), gamma.data_ptr(), vals.data_ptr(),
+                                 xs.data_ptr(), computed.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+          "pl_gamma1d")
+    keep = computed.bool().cpu().numpy()
+    return gamma.cpu().numpy(), vals.cpu().numpy()[keep].ravel(), xs.cpu().numpy()[keep].ravel()

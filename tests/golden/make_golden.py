@@ -711,6 +711,43 @@ def main():
         gg[f"kw{k}"] = np.array(json.dumps({a: (None if isinstance(b, float) and np.isnan(b) else b) for a, b in kw.items()}))
     np.savez_compressed(os.path.join(HERE, "gamma.npz"), **gg)
 
+    # ---- 14. 1-D gamma: the reference's own gamma_1d (py3.10: only scipy's interp1d underneath)
+    gmod = ref_loader.ref("core.gamma")
+    rng = np.random.default_rng(91)
+    xr = np.linspace(-60, 60, 241)
+    prof_r = 100 / (1 + np.exp((np.abs(xr) - 40) / 2.5)) + 0.5
+    xe = np.sort(np.concatenate([np.linspace(-61, 61, 170), rng.uniform(-50, 50, 30)]))
+    prof_e = (100 / (1 + np.exp((np.abs(xe - 0.4) - 40.3) / 2.6)) + 0.5) * (1 + rng.normal(0, 0.008, xe.size))
+    g1 = {}
+    g1_cases = [
+        dict(reference=np.ones(5), evaluation=np.ones(5)),                                     # test_gamma.py:304-316
+        dict(reference=np.ones(5), evaluation=np.ones(5) * 1.01, dose_to_agreement=1),          # :318-331
+        dict(reference=np.ones(5), evaluation=np.ones(5) / 1.005, dose_to_agreement=1),         # :333-339
+        dict(reference=np.ones(5), evaluation=np.array([1.03, 1.03, 1, 1, 1]), dose_to_agreement=1,
+             distance_to_agreement=1, gamma_cap_value=5),                                       # :341-367
+        dict(reference=np.array([100, 1, 1, 1, 1.0]), evaluation=np.array([103, 1.03, 1, 1, 1]), dose_to_agreement=3,
+             gamma_cap_value=5, global_dose=False, dose_threshold=0),                           # :369-380
+        dict(reference=np.array([1, 0, 0, 0, 0.0]), evaluation=np.array([1, 0, 0, 0, 0.0]), dose_to_agreement=3,
+             gamma_cap_value=5, global_dose=False, dose_threshold=5, fill_value=0.666),         # :382-415
+        dict(reference=np.ones(5), evaluation=np.ones(5) * 10, dose_to_agreement=1, gamma_cap_value=2),   # :417-425
+        dict(reference=prof_r, evaluation=prof_e, reference_coordinates=xr, evaluation_coordinates=xe,
+             dose_to_agreement=1, distance_to_agreement=1, resolution_factor=5),
+        dict(reference=prof_r, evaluation=prof_e, reference_coordinates=xr, evaluation_coordinates=xe,
+             dose_to_agreement=2, distance_to_agreement=2, global_dose=False, dose_threshold=10, fill_value=0.0),
+        dict(reference=prof_r, evaluation=prof_e[::-1].copy(), reference_coordinates=xr,
+             evaluation_coordinates=xe[::-1].copy(), dose_to_agreement=3, distance_to_agreement=0.5,
+             resolution_factor=8, gamma_cap_value=1.2),                                         # reversed abscissae
+    ]
+    g1["count"] = np.int64(len(g1_cases))
+    for k, kw in enumerate(g1_cases):
+        gam, vals, xs_ = gmod.gamma_1d(**kw)
+        g1[f"gamma{k}"], g1[f"vals{k}"], g1[f"xs{k}"] = gam, vals, xs_
+        for name in ("reference", "evaluation", "reference_coordinates", "evaluation_coordinates"):
+            if name in kw:
+                g1[f"{name}{k}"] = np.asarray(kw[name], float)
+        g1[f"kw{k}"] = np.array(json.dumps({a: b for a, b in kw.items() if not isinstance(b, np.ndarray)}))
+    np.savez_compressed(os.path.join(HERE, "gamma1d.npz"), **g1)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

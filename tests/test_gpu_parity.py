@@ -1285,3 +1285,26 @@ def test_gamma_2d_vs_reference_golden(golden, dev):
     big = torch.rand((4, 1024, 1024), device=dev, dtype=torch.float64) + 0.5
     z = pg.gamma_2d(big, big, distance_to_agreement=3)
     assert float(z.max()) == 0.0
+
+
+def test_gamma_1d_vs_reference_golden(golden, dev):
+    """pl_gamma1d against the reference's own gamma_1d (known-answer inputs, non-uniform / reversed evaluation
+    abscissae, local dose, fractional DTA): sample positions and sampled evaluation values bit-identical; gamma
+    within 2 ulp -- the reference squares with Python's ``float ** 2`` (libm pow), which is not always the
+    correctly rounded product x*x the device (and numpy) computes: 1 value in ~2000 differs in the last bit.
+    Also the reference's ValueErrors."""
+    from pylinac_amd import gamma as pg
+    from tests.test_oracle_golden import _gamma1d_cases
+
+    g = golden("gamma1d")
+    for k, kw, want in _gamma1d_cases(g):
+        got = pg.gamma_1d(device=dev, **kw)
+        assert np.array_equal(np.isnan(got[0]), np.isnan(want[0]))
+        assert np.allclose(got[0], want[0], rtol=4.5e-16, atol=0, equal_nan=True), k
+        assert np.array_equal(got[1], want[1], equal_nan=True) and np.array_equal(got[2], want[2]), k
+    with pytest.raises(ValueError):
+        pg.gamma_1d(np.ones((2, 2)), np.ones(4), device=dev)
+    with pytest.raises(ValueError):
+        pg.gamma_1d(np.ones(5), np.ones(5), resolution_factor=1.5, device=dev)
+    with pytest.raises(ValueError):
+        pg.gamma_1d(np.ones(5), np.ones(5), reference_coordinates=np.arange(5.0) + 10, device=dev)

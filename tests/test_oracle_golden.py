@@ -494,3 +494,27 @@ def test_gamma_2d_restatement_matches_reference(golden):
     assert abs(g["g2"].max() - 1) < 1e-3 and abs(g["g3"].min() - 1) < 1e-3
     assert abs(g["g4"][0, 0] - 3) < 0.01 and abs(g["g4"][0, 1] - 1) < 0.01 and abs(g["g4"][-1, -1]) < 0.01
     assert np.isnan(g["g6"][0, 1]) and abs(g["g7"][0, 1] - 0.666) < 0.01 and g["g9"].max() == 2 == g["g9"].min()
+
+
+def _gamma1d_cases(g):
+    import json
+
+    for k in range(int(g["count"])):
+        kw = json.loads(str(g[f"kw{k}"]))
+        for name in ("reference", "evaluation", "reference_coordinates", "evaluation_coordinates"):
+            if f"{name}{k}" in g.files:
+                kw[name] = g[f"{name}{k}"]
+        yield k, kw, (g[f"gamma{k}"], g[f"vals{k}"], g[f"xs{k}"])
+
+
+def test_gamma_1d_restatement_matches_reference(golden):
+    """f4 (gamma): oracle.gamma_1d against the reference's own gamma_1d on its known-answer inputs
+    (tests_basic/core/test_gamma.py:304-425) and on physical-coordinate profiles (non-uniform and reversed
+    evaluation abscissae, local dose, fractional DTA): gamma, sampled values and sample positions bit-identical."""
+    g = golden("gamma1d")
+    for k, kw, want in _gamma1d_cases(g):
+        got = o.gamma_1d(**kw)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b, equal_nan=True), k
+    assert g["gamma0"].max() == 0 and abs(g["gamma1"].max() - 1) < 1e-3 and abs(g["gamma2"].min() - 0.5) < 0.01
+    assert abs(g["gamma3"][0] - 3) < 0.01 and g["gamma6"].max() == 2
