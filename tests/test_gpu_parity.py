@@ -1308,3 +1308,18 @@ def test_gamma_1d_vs_reference_golden(golden, dev):
         pg.gamma_1d(np.ones(5), np.ones(5), resolution_factor=1.5, device=dev)
     with pytest.raises(ValueError):
         pg.gamma_1d(np.ones(5), np.ones(5), reference_coordinates=np.arange(5.0) + 10, device=dev)
+
+
+def test_median3_eight_columns_per_lane_shapes(dev):
+    """median3_oct_kernel (width % 8 == 0, 16-byte aligned frames): one lane, partial waves, several waves per row
+    (neighbour columns fetched across a wave boundary), heights that are not a multiple of the 16-row group, uint16
+    and int16 -- against scipy's median_filter via the oracle; other widths take the pair / scalar kernels."""
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(17)
+    for shape in [(2, 5, 8), (1, 33, 16), (2, 40, 520), (1, 70, 1032), (1, 17, 2048), (3, 2, 512), (1, 16, 504)]:
+        a = rng.integers(0, 65536, shape, dtype=np.uint16)
+        a[0, : shape[1] // 2] = (a[0, : shape[1] // 2] // 4096) * 4096            # plateaus: many ties
+        for arr in (a, (a.astype(np.int32) - 32768).astype(np.int16)):
+            ref = np.stack([o.filter(f, 3, "median") for f in arr])
+            assert np.array_equal(ops.median_filter(T(arr, dev), 3).cpu().numpy(), ref), (shape, arr.dtype)
