@@ -227,6 +227,18 @@ int pl_fields_level(const int32_t* d_labels, const int32_t* d_nlabels, const dou
                     double field_tol_mm, int buffer_size, int max_number, int level, int32_t* d_done,
                     int32_t* d_count, double* d_xy, int32_t* d_level, int32_t* d_status, void* stream);
 
+/* ---- f1 ("next" row): Varian XIM compressed pixels (pylinac/core/image.py:1180-1296) -----------------------
+ * d_lookup: the file's lookup table (2-bit size codes, 4 per byte); d_stream: the compressed pixel buffer that
+ * follows its 4-byte length in the file ((width + 1) int32 values, then one 1/2/4-byte little-endian difference per
+ * remaining pixel).  d_out: int8/16/32/64 [height][width] by bytes_per_pixel (1/2/4/8), wrap-around arithmetic like
+ * the reference's numpy arrays.  d_work: pl_xim_work_bytes() bytes; its first int32 is a status the caller may read
+ * after the stream completes (bit 0: size code 3 in the lookup table -- the reference raises KeyError --,
+ * bit 1: stream shorter than the lookup table implies). */
+int64_t pl_xim_work_bytes(int width, int height);
+int pl_xim_decode(const unsigned char* d_lookup, int64_t lookup_bytes, const unsigned char* d_stream,
+                  int64_t stream_bytes, int width, int height, int bytes_per_pixel, void* d_out,
+                  unsigned char* d_work, void* stream);
+
 /* ---- f3 ("next" row): ROI statistics after phantom localisation ---------------------------------------
  * DiskROI.circle_mask + pixel_value/mean/std/min/max (pylinac/core/roi.py:104-140) and axis-aligned
  * RectangleROI.pixel_array statistics (:664-704).  d_rois float64 [..][rois_per_frame][4] (roi_frame_stride

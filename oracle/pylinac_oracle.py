@@ -881,6 +881,102 @@ def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=Non
 
 
 # --------------------------------------------------------------------------------------
+# f1: XIM compressed-pixel decoding (pylinac/core/image.py:1180-1296)
+# --------------------------------------------------------------------------------------
+XIM_DTYPES = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}
+
+
+def xim_encode(pixels: np.ndarray):
+    """Inverse of the reference's decoder, for building test streams: -> (lookup_table_bytes uint8, byte_stream uint8).
+    The stream is what follows the 4-byte buffer size in the file: (W + 1) int32 values (first row and the first pixel of
+    the second row), then one 1 / 2 / 4-byte little-endian difference per remaining pixel,
+    diff = P[i] - P[i-1] - P[i-W] + P[i-W-1] on the FLAT pixel index; the lookup table holds 2-bit size codes, 4 per
+    byte, low bits first."""
+    h, w = pixels.shape
+    flat = pixels.astype(np.int64).ravel()
+    i = np.arange(w + 1, h * w)
+    diffs = flat[i] - flat[i - 1] - flat[i - w] + flat[i - w - 1]
+    codes = np.where((diffs >= -128) & (diffs <= 127), 0, np.where((diffs >= -32768) & (diffs <= 32767), 1, 2)).astype(np.uint8)
+    pad = (-len(codes)) % 4
+    c4 = np.concatenate([codes, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    lut = (c4[:, 0] | (c4[:, 1] << 2) | (c4[:, 2] << 4) | (c4[:, 3] << 6)).astype(np.uint8)
+    parts = [flat[: w + 1].astype("<i4").tobytes()]
+    for d, c in zip(diffs, codes):
+        parts.append(int(d).to_bytes(1 << int(c), "little", signed=True))
+    return lut, np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+
+
+def xim_decode(lookup_table_bytes: np.ndarray, stream: np.ndarray, width: int, height: int, bytes_per_pixel: int):
+    """XIM._parse_lookup_table (image.py:1180-1204) + _get_diffs (:1258-1296) + _parse_compressed_bytes (:1206-1256),
+    restated without the per-row Python loop: with S_r = row-wise prefix sums of the raw differences, the reference's
+    recurrence is P[r] = P[r-1] + S_r + c_r, c_1 = -P[0][0], c_r = c_{r-1} + S_{r-1}[W-1], all in the array dtype's
+    wrap-around arithmetic."""
+    dtype = XIM_DTYPES[bytes_per_pixel]
+    codes = ((lookup_table_bytes[:, None] >> np.array([0, 2, 4, 6])[None, :]) & 3).ravel()
+    n = width * height - width - 1
+    codes = codes[:n].astype(np.int64)
+    if (codes > 2).any():
+        raise KeyError(3)                                     # LOOKUP_CONVERSION has no entry for code 3
+    sizes = 1 << codes
+    offs = (width + 1) * 4 + np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    b = stream.astype(np.int64)
+    val = np.zeros(n, np.int64)
+    for k in range(4):
+        use = sizes > k
+        val[use] |= b[offs[use] + k] << (8 * k)
+    bits = 8 * sizes
+    val = np.where(val >= (1 << (bits - 1)), val - (1 << bits), val)          # sign extension
+    a = np.zeros(width * height, np.int64)
+    a[: width + 1] = stream[: (width + 1) * 4].view("<i4")
+    a[width + 1:] = val
+    a = a.astype(dtype).astype(np.int64).reshape(height, width)               # stored in the array dtype
+    mask = (1 << (8 * bytes_per_pixel)) - 1
+
+    def wrap(v):
+        v = v & mask
+        return np.where(v >= (mask + 1) // 2, v - (mask + 1), v)
+
+    s_rows = np.cumsum(a[1:], axis=1)
+    tot = s_rows[:, -1]
+    c = np.concatenate([[-a[0, 0]], -a[0, 0] + np.cumsum(tot[:-1])])
+    e = s_rows + c[:, None]
+    out = np.vstack([a[0:1], a[0:1] + np.cumsum(e, axis=0)])
+    return wrap(out).astype(dtype)
+
+
+def xim_file_bytes(pixels: np.ndarray, bytes_per_pixel: int = 4, properties=None, histogram=()) -> bytes:
+    """A complete compressed .xim file in the layout the reference's reader walks (image.py:1123-1178): header, lookup
+    table, pixel buffer, histogram, typed properties.  Test infrastructure (the reference has no writer)."""
+    import struct
+
+    h, w = pixels.shape
+    lut, stream = xim_encode(pixels)
+    out = [b"VMS.XI\x00\x00", struct.pack("<6i", 1, w, h, 8 * bytes_per_pixel, bytes_per_pixel, 1),
+           struct.pack("<i", len(lut)), lut.tobytes(), struct.pack("<i", len(stream)), stream.tobytes(),
+           struct.pack("<i", w * h * bytes_per_pixel), struct.pack("<i", len(histogram)),
+           struct.pack(f"<{len(histogram)}i", *histogram)]
+    props = properties or {}
+    out.append(struct.pack("<i", len(props)))
+    for name, value in props.items():
+        nb = name.encode()
+        out.append(struct.pack("<i", len(nb)) + nb)
+        if isinstance(value, (int, np.integer)):
+            out.append(struct.pack("<ii", 0, int(value)))
+        elif isinstance(value, float):
+            out.append(struct.pack("<id", 1, value))
+        elif isinstance(value, str):
+            vb = value.encode()
+            out.append(struct.pack("<ii", 2, len(vb)) + vb)
+        elif np.asarray(value).dtype.kind == "f":
+            v = np.asarray(value, dtype="<f8")
+            out.append(struct.pack("<ii", 4, v.nbytes) + v.tobytes())
+        else:
+            v = np.asarray(value, dtype="<i4")
+            out.append(struct.pack("<ii", 5, v.nbytes) + v.tobytes())
+    return b"".join(out)
+
+
+# --------------------------------------------------------------------------------------
 # f4 (gamma part): gamma_2d restated with array operations (the reference loops over pixels in Python)
 # --------------------------------------------------------------------------------------
 def gamma_2d(reference, evaluation, dose_to_agreement=1, distance_to_agreement=1, gamma_cap_value=2,

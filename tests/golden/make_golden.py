@@ -748,6 +748,39 @@ def main():
         g1[f"kw{k}"] = np.array(json.dumps({a: b for a, b in kw.items() if not isinstance(b, np.ndarray)}))
     np.savez_compressed(os.path.join(HERE, "gamma1d.npz"), **g1)
 
+    # ---- 15. XIM files: synthetic compressed .xim files read by the reference's own XIM reader (next row f1)
+    image_mod = ref_loader.ref("core.image")
+    from oracle import pylinac_oracle as orc
+
+    rng = np.random.default_rng(101)
+    xg = {}
+
+    def blob(h, w, noise, spikes):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = 20000 + 15000 * np.exp(-(((yy - h / 2) / (h / 3)) ** 2 + ((xx - w / 2) / (w / 3)) ** 2)) + rng.normal(0, noise, (h, w))
+        img = img.round().astype(np.int64)
+        img.ravel()[rng.integers(0, h * w, spikes)] = rng.choice([0, 65535, 1 << 20, -(1 << 18)], spikes)
+        return img
+
+    xim_cases = {"a": (blob(260, 300, 40, 6), 4), "b": (blob(150, 200, 300, 4), 2), "c": (blob(64, 64, 40000, 30), 4),
+                 "d": (blob(2, 5, 10, 0), 4)}   # (a one-row image has an empty lookup table: the reference raises IndexError)
+    for name, (img, bpp) in xim_cases.items():
+        props = {"PixelWidth": 0.0336, "PixelHeight": 0.0336, "MVBeamOn": 1, "AcquisitionSystemVersion": "3.1.2",
+                 "KVCollimatorShape": np.array([1.5, 2.5, -3.0]), "Couch": np.array([3, 4, 5])}
+        data = orc.xim_file_bytes(img, bpp, props, histogram=tuple(range(7)))
+        with tempfile.NamedTemporaryFile(suffix=".xim", delete=False) as f:
+            f.write(data)
+            path = f.name
+        x = image_mod.XIM(path)
+        os.unlink(path)
+        xg[f"{name}.file"] = np.frombuffer(data, dtype=np.uint8)
+        xg[f"{name}.array"] = x.array
+        xg[f"{name}.dpmm"] = np.float64(x.dpmm)
+        xg[f"{name}.histogram"] = np.asarray(x.histogram)
+        xg[f"{name}.props"] = np.array(json.dumps({k: (np.asarray(v).tolist() if not isinstance(v, (str, int, float)) else v)
+                                                   for k, v in x.properties.items()}))
+    np.savez_compressed(os.path.join(HERE, "xim.npz"), **xg)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

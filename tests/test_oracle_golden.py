@@ -518,3 +518,32 @@ def test_gamma_1d_restatement_matches_reference(golden):
             assert np.array_equal(a, b, equal_nan=True), k
     assert g["gamma0"].max() == 0 and abs(g["gamma1"].max() - 1) < 1e-3 and abs(g["gamma2"].min() - 0.5) < 0.01
     assert abs(g["gamma3"][0] - 3) < 0.01 and g["gamma6"].max() == 2
+
+
+def _xim_split(file_bytes: np.ndarray):
+    """(width, height, bytes_per_pixel, lookup table, pixel buffer) of a compressed .xim file image."""
+    import struct
+
+    b = file_bytes.tobytes()
+    _, w, h, _, bpp, comp = struct.unpack_from("<6i", b, 8)
+    assert comp == 1
+    n_lut = struct.unpack_from("<i", b, 32)[0]
+    lut = np.frombuffer(b, np.uint8, n_lut, 36)
+    n_buf = struct.unpack_from("<i", b, 36 + n_lut)[0]
+    buf = np.frombuffer(b, np.uint8, n_buf, 40 + n_lut)
+    return w, h, bpp, lut, buf
+
+
+def test_xim_decode_restatement_matches_reference_reader(golden):
+    """f1: oracle.xim_decode (scan formulation) against the arrays the reference's own XIM reader produced from
+    synthetic compressed .xim files (int32 and int16 pixels, 1/2/4-byte differences, wrap-around for values that do
+    not fit int16, a 2-row image); encode -> decode round trip."""
+    g = golden("xim")
+    for name in "abcd":
+        w, h, bpp, lut, buf = _xim_split(g[f"{name}.file"])
+        got = o.xim_decode(lut, buf, w, h, bpp)
+        assert got.dtype == g[f"{name}.array"].dtype and np.array_equal(got, g[f"{name}.array"]), name
+    rng = np.random.default_rng(1)
+    img = rng.integers(-(1 << 20), 1 << 20, (37, 41))
+    lut, buf = o.xim_encode(img)
+    assert np.array_equal(o.xim_decode(lut, buf, 41, 37, 4), img.astype(np.int32))
