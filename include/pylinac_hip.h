@@ -170,7 +170,7 @@ int pl_scaled_binary(const void* in, int dtype, int64_t n, int64_t count, const 
 
 /* ---- a16: CatPhan slice localisation (pylinac/ct.py:381-425, 3315-3348) --------------------------
  * pl_scharr: skimage.filters.scharr(float image) -> float64 edge magnitude.
- * pl_gaussian2d_mode: ndimage.gaussian_filter with border mode 0 'reflect' / 1 'nearest'
+ * pl_gaussian2d_mode: ndimage.gaussian_filter with border mode 0 'reflect' / 1 'nearest' / 2 'constant' (cval 0),
  *   (skimage.filters.gaussian uses 'nearest').
  * pl_clip: np.clip.   pl_compare: op 0 >=, 1 >, 2 <=, 3 < against per-frame / broadcast thresholds.
  * pl_hist_uniform: np.histogram(values[mask], bins=nbins) with caller-supplied float64 edges
@@ -238,6 +238,23 @@ int64_t pl_xim_work_bytes(int width, int height);
 int pl_xim_decode(const unsigned char* d_lookup, int64_t lookup_bytes, const unsigned char* d_stream,
                   int64_t stream_bytes, int width, int height, int bytes_per_pixel, void* d_out,
                   unsigned char* d_work, void* stream);
+
+/* ---- f2 ("next" row, first half): skimage.feature.canny as called at pylinac/planar_imaging.py:574-588 -------
+ * float64 images, mask=None.  The caller composes: G = pl_gaussian2d_mode(mode 2) of the image and of an all-ones
+ * frame; pl_canny_normalise: smoothed = G(image) / (G(ones) + eps); pl_sobel on axis 1 (jsobel) and axis 0 (isobel);
+ * pl_canny_nms: magnitude = hypot and the interpolated non-maximum suppression (uint8 local maxima);
+ * pl_order_stats_f64: exact order statistics of the magnitude image for np.percentile thresholds;
+ * pl_canny_hysteresis phase 0: low / high masks from d_thresholds [n][2]; the caller labels d_low with pl_label
+ * (8-connected); phase 1: keep the labelled segments that contain a high pixel (d_good: n*h*w int32 scratch). */
+int pl_canny_normalise(const double* d_g_img, const double* d_g_ones, int64_t n, int64_t per_frame, double* d_out,
+                       void* stream);
+int pl_canny_nms(const double* d_isobel, const double* d_jsobel, int64_t n, int h, int w, double* d_magnitude,
+                 unsigned char* d_local_max, void* stream);
+int pl_order_stats_f64(const double* d_values, int64_t n, int64_t count, const int64_t* d_ranks, int n_ranks,
+                       double* d_out, void* stream);
+int pl_canny_hysteresis(const unsigned char* d_local_max, const double* d_magnitude, const double* d_thresholds,
+                        int64_t n, int h, int w, unsigned char* d_low, unsigned char* d_high, const int32_t* d_labels,
+                        int32_t* d_good, unsigned char* d_out, int phase, void* stream);
 
 /* ---- f3 ("next" row): ROI statistics after phantom localisation ---------------------------------------
  * DiskROI.circle_mask + pixel_value/mean/std/min/max (pylinac/core/roi.py:104-140) and axis-aligned

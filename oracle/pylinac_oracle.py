@@ -881,6 +881,53 @@ def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=Non
 
 
 # --------------------------------------------------------------------------------------
+# f2 (first half): skimage.feature.canny 0.18.3 restated on scipy.ndimage (float64 image, mask=None)
+# --------------------------------------------------------------------------------------
+def canny(image: np.ndarray, sigma=1.0, low_threshold=None, high_threshold=None, use_quantiles=False) -> np.ndarray:
+    """skimage/feature/_canny.py (0.18.3; third-party, absent from /root/reference) as called at
+    pylinac/planar_imaging.py:577-583.  Gaussian(mode='constant') normalised by the smoothed all-ones mask, Sobel,
+    hypot, interior mask, four-sector interpolated non-maximum suppression, thresholds (absolute / np.percentile of the
+    magnitude), hysteresis over 8-connected segments of the low mask."""
+    low_threshold = 0.1 if low_threshold is None else low_threshold
+    high_threshold = 0.2 if high_threshold is None else high_threshold
+    g = lambda a: ndimage.gaussian_filter(a, sigma, mode="constant", cval=0, truncate=4.0)   # noqa: E731
+    smoothed = g(image.astype(float)) / (g(np.ones(image.shape)) + np.finfo(float).eps)
+    js, is_ = ndimage.sobel(smoothed, axis=1), ndimage.sobel(smoothed, axis=0)
+    ai, aj, mag = np.abs(is_), np.abs(js), np.hypot(is_, js)
+    inner = np.zeros(image.shape, bool)
+    inner[1:-1, 1:-1] = True
+    inner &= mag > 0
+    pad = np.pad(mag, 1)                                     # neighbours of border pixels are never used (inner)
+    nb = lambda dr, dc: pad[1 + dr: 1 + dr + image.shape[0], 1 + dc: 1 + dc + image.shape[1]]   # noqa: E731
+    same = ((is_ >= 0) & (js >= 0)) | ((is_ <= 0) & (js <= 0))
+    opp = ((is_ <= 0) & (js >= 0)) | ((is_ >= 0) & (js <= 0))
+    local = np.zeros(image.shape, bool)
+    with np.errstate(all="ignore"):
+        sectors = [  # (selector, weight, (+c2, +c1), (-c2, -c1))
+            (same & (ai >= aj), aj / ai, ((1, 1), (1, 0)), ((-1, -1), (-1, 0))),
+            (same & (ai <= aj), ai / aj, ((1, 1), (0, 1)), ((-1, -1), (0, -1))),
+            (opp & (ai <= aj), ai / aj, ((-1, 1), (0, 1)), ((1, -1), (0, -1))),
+            (opp & (ai >= aj), aj / ai, ((-1, 1), (-1, 0)), ((1, -1), (1, 0))),
+        ]
+        for sel, wgt, (p2, p1), (m2, m1) in sectors:
+            pts = inner & sel
+            cp = nb(*p2) * wgt + nb(*p1) * (1 - wgt) <= mag
+            cm = nb(*m2) * wgt + nb(*m1) * (1 - wgt) <= mag
+            local[pts] = (cp & cm)[pts]
+    if use_quantiles:
+        high_threshold = np.percentile(mag, 100.0 * high_threshold)
+        low_threshold = np.percentile(mag, 100.0 * low_threshold)
+    high_mask, low_mask = local & (mag >= high_threshold), local & (mag >= low_threshold)
+    labels, count = ndimage.label(low_mask, np.ones((3, 3), bool))
+    if count == 0:
+        return low_mask
+    sums = np.atleast_1d(ndimage.sum(high_mask, labels, np.arange(count, dtype=np.int32) + 1))
+    good = np.zeros(count + 1, bool)
+    good[1:] = sums > 0
+    return good[labels]
+
+
+# --------------------------------------------------------------------------------------
 # f1: XIM compressed-pixel decoding (pylinac/core/image.py:1180-1296)
 # --------------------------------------------------------------------------------------
 XIM_DTYPES = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}

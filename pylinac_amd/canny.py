@@ -1,0 +1,88 @@
+"""Canny edges on the device (SURVEY.md section 8 "next" row f2): ``skimage.feature.canny`` as pylinac's planar
+phantom finder calls it (pylinac/planar_imaging.py:574-588: ``feature.canny(image, sigma, low_threshold,
+high_threshold, use_quantiles=True)``; scikit-image 0.18.3 semantics, skimage/feature/_canny.py).
+
+Float64 images, ``mask=None``.  Every stage is a kernel: Gaussian smoothing with zero padding normalised by the
+smoothed all-ones frame, the two Sobel gradients, hypot + interpolated non-maximum suppression, exact float64 order
+statistics for the quantile thresholds, and hysteresis by 8-connected labelling.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+
+def canny(image, sigma: float = 1.0, low_threshold=None, high_threshold=None, mask=None,
+          use_quantiles: bool = False, device=None) -> torch.Tensor:
+    """-> uint8 edge map(s) with the shape of ``image`` ([H, W] or a batch [N, H, W])."""
+    if mask is not None:
+        raise NotImplementedError("canny(mask=...) is not built; pylinac calls it without a mask")
+    t = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image))
+    if t.dtype != torch.float64:
+        raise TypeError("canny needs a float64 image (integer images are rescaled by skimage's img_as_float: not built)")
+    dev = t.device if t.is_cuda else (torch.device(device) if device is not None
+                                      else torch.device("cuda", torch.cuda.current_device()))
+    t = t.to(dev).contiguous()
+    batched = t.ndim == 3
+    if t.ndim not in (2, 3):
+        raise ValueError("The parameter `image` must be a 2-dimensional array")      # check_nD(image, 2)
+    x = t if batched else t[None]
+    n, h, w = x.shape
+    # dtype_limits(float image, clip_negative=False)[1] == 1
+    if low_threshold is None:
+        low_threshold = 0.1
+    elif use_quantiles:
+        if not 0.0 <= low_threshold <= 1.0:
+            raise ValueError("Quantile thresholds must be between 0 and 1.")
+    else:
+        low_threshold = low_threshold / 1.0
+    if high_threshold is None:
+        high_threshold = 0.2
+    elif use_quantiles:
+        if not 0.0 <= high_threshold <= 1.0:
+            raise ValueError("Quantile thresholds must be between 0 and 1.")
+    else:
+        high_threshold = high_threshold / 1.0
+    lib, st = _lib.load(), torch.cuda.current_stream(dev).cuda_stream
+    g_img = ops.gaussian_filter_mode(x, sigma, mode="constant")
+    g_one = ops.gaussian_filter_mode(torch.ones((1, h, w), dtype=torch.float64, device=dev), sigma, mode="constant")
+    smoothed = torch.empty_like(x)
+    check(lib.pl_canny_normalise(g_img.data_ptr(), g_one.data_ptr(), n, h * w, smoothed.data_ptr(), st),
+          "pl_canny_normalise")
+    jsobel = ops.sobel(smoothed, 1)
+    isobel = ops.sobel(smoothed, 0)
+    mag = torch.empty_like(x)
+    local_max = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+    check(lib.pl_canny_nms(isobel.data_ptr(), jsobel.data_ptr(), n, h, w, mag.data_ptr(), local_max.data_ptr(), st),
+          "pl_canny_nms")
+    if use_quantiles:
+        thr = torch.stack([_percentile_f64(mag, 100.0 * low_threshold), _percentile_f64(mag, 100.0 * high_threshold)],
+                          dim=1).contiguous()
+    else:
+        thr = torch.tensor([[low_threshold, high_threshold]] * n, dtype=torch.float64, device=dev)
+    low = torch.empty_like(local_max)
+    high = torch.empty_like(local_max)
+    check(lib.pl_canny_hysteresis(local_max.data_ptr(), mag.data_ptr(), thr.data_ptr(), n, h, w, low.data_ptr(),
+                                  high.data_ptr(), None, None, None, 0, st), "pl_canny_hysteresis")
+    labels, _ = ops.label(low, 8)
+    good = torch.empty((n, h, w), dtype=torch.int32, device=dev)
+    out = torch.empty_like(local_max)
+    check(lib.pl_canny_hysteresis(None, None, None, n, h, w, None, high.data_ptr(), labels.data_ptr(), good.data_ptr(),
+                                  out.data_ptr(), 1, st), "pl_canny_hysteresis")
+    return out if batched else out[0]
+
+
+def _percentile_f64(values: torch.Tensor, q: float) -> torch.Tensor:
+    """``np.percentile(frame, q)`` (linear interpolation, numpy's ``_lerp``) per frame of a float64 batch."""
+    x = values.reshape(values.shape[0], -1).contiguous()
+    n, count = x.shape
+    _, lo, hi, frac = ops._percentile_plan(count, [q])
+    ranks = torch.tensor([int(lo[0]), int(hi[0])], dtype=torch.int64, device=x.device)
+    st = torch.empty((n, 2), dtype=torch.float64, device=x.device)
+    check(_lib.load().pl_order_stats_f64(x.data_ptr(), n, count, ranks.data_ptr(), 2, st.data_ptr(),
+                                         torch.cuda.current_stream(x.device).cuda_stream), "pl_order_stats_f64")
+    t = torch.full((n,), float(frac[0]), dtype=torch.float64, device=x.device)
+    return ops.lerp_like_numpy(st[:, 0].contiguous(), st[:, 1].contiguous(), t)

@@ -349,8 +349,13 @@ template <typename T>
 __global__ void __launch_bounds__(kThreads)
 gauss_generic(const T* __restrict__ in, T* __restrict__ out, int64_t total, int h, int w, int axis,
               const double* __restrict__ wts, int rad, int mode) {
-  // mode 0: scipy 'reflect'; mode 1: scipy 'nearest' (skimage.filters.gaussian's default)
-  auto border = [mode](int i, int n) { return mode == 0 ? pl_reflect(i, n) : (i < 0 ? 0 : (i >= n ? n - 1 : i)); };
+  // mode 0: scipy 'reflect'; 1: 'nearest' (skimage.filters.gaussian's default); 2: 'constant' with cval 0
+  // (skimage.feature.canny smooths with mode='constant'): an index outside the line reads 0
+  auto border = [mode](int i, int n) {
+    if (mode == 0) return pl_reflect(i, n);
+    if (mode == 1) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+    return (i < 0 || i >= n) ? -1 : i;
+  };
   int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % w);
@@ -361,16 +366,18 @@ gauss_generic(const T* __restrict__ in, T* __restrict__ out, int64_t total, int 
   if (axis == 0) {
     acc = (double)f[(size_t)r * w + c] * wts[rad];
     for (int j = rad; j >= 1; --j) {
-      double a = (double)f[(size_t)border(r - j, h) * w + c];
-      double b = (double)f[(size_t)border(r + j, h) * w + c];
+      const int ia = border(r - j, h), ib = border(r + j, h);
+      double a = ia < 0 ? 0.0 : (double)f[(size_t)ia * w + c];
+      double b = ib < 0 ? 0.0 : (double)f[(size_t)ib * w + c];
       acc = acc + (a + b) * wts[rad - j];
     }
   } else {
     const T* frow = f + (size_t)r * w;
     acc = (double)frow[c] * wts[rad];
     for (int j = rad; j >= 1; --j) {
-      double a = (double)frow[border(c - j, w)];
-      double b = (double)frow[border(c + j, w)];
+      const int ia = border(c - j, w), ib = border(c + j, w);
+      double a = ia < 0 ? 0.0 : (double)frow[ia];
+      double b = ib < 0 ? 0.0 : (double)frow[ib];
       acc = acc + (a + b) * wts[rad - j];
     }
   }
@@ -544,7 +551,7 @@ extern "C" int pl_gaussian2d_mode(const void* in, void* out, void* tmp, int dtyp
   PL_REQUIRE(in && out && tmp && d_weights, "null pointer");
   PL_REQUIRE(tmp != in && tmp != out && in != out, "buffers must be distinct");
   PL_REQUIRE(n >= 0 && h > 0 && w > 0 && radius >= 0, "bad shape");
-  PL_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (reflect) or 1 (nearest)");
+  PL_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (reflect), 1 (nearest) or 2 (constant, cval 0)");
   if (n == 0) return PL_OK;
   hipStream_t st = (hipStream_t)stream;
   PL_DISPATCH_DTYPE(dtype, T, {

@@ -551,7 +551,7 @@ def gaussian_filter_mode(frames: torch.Tensor, sigma: float, mode: str = "neares
     wts, lw = _device_weights(sigma, x.device)
     out, tmp = torch.empty_like(x), torch.empty_like(x)
     check(_lib.load().pl_gaussian2d_mode(x.data_ptr(), out.data_ptr(), tmp.data_ptr(), _dt(x), n, h, w,
-                                         wts.data_ptr(), lw, {"reflect": 0, "nearest": 1}[mode], _stream()),
+                                         wts.data_ptr(), lw, {"reflect": 0, "nearest": 1, "constant": 2}[mode], _stream()),
           "pl_gaussian2d_mode")
     return out
 

@@ -781,6 +781,42 @@ def main():
                                                    for k, v in x.properties.items()}))
     np.savez_compressed(os.path.join(HERE, "xim.npz"), **xg)
 
+    # ---- 16. Canny: scikit-image 0.18.3's own feature.canny with pylinac's parameters (next row f2)
+    from scipy import ndimage as ndi
+
+    rng = np.random.default_rng(111)
+
+    def planar_phantom(h, w, noise):
+        """kV-phantom-like frame: rotated square body on a gradient background, inner discs, blur, noise; float64."""
+        yy, xx = np.mgrid[0:h, 0:w].astype(float)
+        a = np.deg2rad(7.0)
+        u = (xx - w / 2) * np.cos(a) + (yy - h / 2) * np.sin(a)
+        v = -(xx - w / 2) * np.sin(a) + (yy - h / 2) * np.cos(a)
+        img = 0.25 + 0.1 * xx / w
+        img[(np.abs(u) < w * 0.28) & (np.abs(v) < h * 0.3)] = 0.7
+        for k, (du, dv) in enumerate([(-0.12, -0.1), (0.1, -0.12), (0.0, 0.1), (0.15, 0.12)]):
+            img[np.hypot(u - du * w, v - dv * h) < 9 + 2 * k] = 0.45 + 0.1 * k
+        return ndi.gaussian_filter(img, 1.2) + rng.normal(0, noise, img.shape)
+
+    cimgs = [planar_phantom(200, 260, 0.004), planar_phantom(200, 260, 0.004) * 4000.0, planar_phantom(151, 97, 0.01),
+             np.pad(np.ones((40, 40)), 30) + 0.2 * rng.random((100, 100)), np.zeros((32, 48))]
+    ckw = [dict(sigma=2, low_threshold=0.001, high_threshold=0.01, use_quantiles=True),          # planar_imaging.py:198
+           dict(sigma=4, low_threshold=0.001, high_threshold=0.01, use_quantiles=True),          # :1978
+           dict(sigma=1.5, low_threshold=0.5, high_threshold=0.9, use_quantiles=True),
+           dict(sigma=1.0), dict(sigma=2.0, low_threshold=0.02, high_threshold=0.05)]
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "w.npz"), os.path.join(td, "f.npz")
+        pack = {"count": len(cimgs)}
+        for k, (im, kw) in enumerate(zip(cimgs, ckw)):
+            pack[f"img{k}"], pack[f"kw{k}"] = im, np.array(kw, dtype=object)
+        np.savez(inp, **pack)
+        subprocess.run([PY39, os.path.join(HERE, "skimage_canny_py39.py"), inp, outp, ROOT], check=True)
+        cg = dict(np.load(outp))
+    cg["count"] = np.int64(len(cimgs))
+    for k, (im, kw) in enumerate(zip(cimgs, ckw)):
+        cg[f"img{k}"], cg[f"kw{k}"] = im, np.array(json.dumps(kw))
+    np.savez_compressed(os.path.join(HERE, "canny.npz"), **cg)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -1366,3 +1366,32 @@ def test_xim_reader_vs_reference_reader(golden, dev, tmp_path):
     lut, buf = o.xim_encode(img)
     got = px.decode_xim_pixels(lut, buf, 1280, 1280, 4, device=dev).cpu().numpy()
     assert np.array_equal(got, img.astype(np.int32))
+
+
+# ----------------------------------------------------------------------------------------- Canny (f2)
+def test_canny_vs_skimage_golden(golden, dev):
+    """Device canny against scikit-image 0.18.3's own feature.canny with pylinac's parameters (sigma 2 / 4, quantile
+    thresholds), absolute thresholds, large-valued float images, an empty result: identical edge maps; batch form;
+    the label count of the edge map (what planar_imaging.py:585-587 consumes) equals scipy's."""
+    from scipy import ndimage as ndi
+
+    from pylinac_amd import canny as pc
+    from pylinac_amd import ops
+
+    g = golden("canny")
+    from tests.test_oracle_golden import _canny_cases
+
+    for k, img, kw, want in _canny_cases(g):
+        got = pc.canny(img, device=dev, **kw)
+        assert got.shape == want.shape
+        diff = int((got.cpu().numpy().astype(bool) != want).sum())
+        assert diff == 0, (k, kw, diff)
+    _, img, kw, want = next(iter(_canny_cases(g)))
+    both = pc.canny(np.stack([img, img[::-1].copy()]), device=dev, **kw).cpu().numpy().astype(bool)
+    assert np.array_equal(both[0], want) and np.array_equal(both[1], o.canny(img[::-1], **kw))
+    labels, num = ops.label(T(want.astype(np.uint8)[None], dev), 8)
+    assert int(num[0]) == ndi.label(want, np.ones((3, 3)))[1]
+    with pytest.raises(ValueError):
+        pc.canny(img, low_threshold=1.5, use_quantiles=True, device=dev)
+    with pytest.raises(TypeError):
+        pc.canny(img.astype(np.float32), device=dev)

@@ -547,3 +547,19 @@ def test_xim_decode_restatement_matches_reference_reader(golden):
     img = rng.integers(-(1 << 20), 1 << 20, (37, 41))
     lut, buf = o.xim_encode(img)
     assert np.array_equal(o.xim_decode(lut, buf, 41, 37, 4), img.astype(np.int32))
+
+
+def _canny_cases(g):
+    import json
+
+    for k in range(int(g["count"])):
+        yield k, g[f"img{k}"], json.loads(str(g[f"kw{k}"])), g[f"edges{k}"]
+
+
+def test_canny_restatement_matches_skimage(golden):
+    """f2: oracle.canny against scikit-image 0.18.3's own feature.canny (py3.9 helper) with the parameters pylinac
+    passes (sigma 2 / 4, quantile thresholds 0.001 / 0.01), default absolute thresholds, an image with values in the
+    thousands, an empty result: identical edge maps."""
+    g = golden("canny")
+    for k, img, kw, want in _canny_cases(g):
+        assert np.array_equal(o.canny(img, **kw), want), (k, kw)
