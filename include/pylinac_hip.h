@@ -252,6 +252,12 @@ int pl_canny_nms(const double* d_isobel, const double* d_jsobel, int64_t n, int 
                  unsigned char* d_local_max, void* stream);
 int pl_order_stats_f64(const double* d_values, int64_t n, int64_t count, const int64_t* d_ranks, int n_ranks,
                        double* d_out, void* stream);
+/* skimage.transform.hough_line(image, theta) accumulator (pylinac/planar_imaging.py:3158): d_image uint8 [h][w]
+ * (non-zero = edge), d_cos / d_sin float64 [n_theta] (np.cos / np.sin of the angles, from the host), d_accum uint64
+ * [2 * ceil(sqrt(h^2 + w^2))][n_theta] (zeroed here; scikit-image 0.18.3 layout).  The distance bins are
+ * np.linspace(-offset, offset, rows). */
+int pl_hough_line(const unsigned char* d_image, int h, int w, const double* d_cos, const double* d_sin, int n_theta,
+                  unsigned long long* d_accum, void* stream);
 int pl_canny_hysteresis(const unsigned char* d_local_max, const double* d_magnitude, const double* d_thresholds,
                         int64_t n, int h, int w, unsigned char* d_low, unsigned char* d_high, const int32_t* d_labels,
                         int32_t* d_good, unsigned char* d_out, int phase, void* stream);

@@ -927,6 +927,22 @@ def canny(image: np.ndarray, sigma=1.0, low_threshold=None, high_threshold=None,
     return good[labels]
 
 
+def hough_line(image: np.ndarray, theta=None):
+    """skimage.transform.hough_line of scikit-image 0.18.3 (compiled _hough_transform; behaviour pinned by probing the
+    installed build, tests/golden/hough.npz): votes at round(cos*x + sin*y) + offset with C rounding, 2*offset rows."""
+    if theta is None:
+        theta = np.linspace(-np.pi / 2, np.pi / 2, 180)
+    h, w = image.shape
+    off = int(np.ceil(np.sqrt(h * h + w * w)))
+    acc = np.zeros((2 * off, len(theta)), np.uint64)
+    ys, xs = np.nonzero(image)
+    v = np.cos(theta)[None, :] * xs[:, None] + np.sin(theta)[None, :] * ys[:, None]
+    idx = (np.sign(v) * np.floor(np.abs(v) + 0.5)).astype(int) + off
+    for j in range(len(theta)):
+        np.add.at(acc[:, j], idx[:, j], 1)
+    return acc, theta, np.linspace(-off, off, 2 * off)
+
+
 # --------------------------------------------------------------------------------------
 # f1: XIM compressed-pixel decoding (pylinac/core/image.py:1180-1296)
 # --------------------------------------------------------------------------------------

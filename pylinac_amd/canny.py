@@ -86,3 +86,26 @@ def _percentile_f64(values: torch.Tensor, q: float) -> torch.Tensor:
                                          torch.cuda.current_stream(x.device).cuda_stream), "pl_order_stats_f64")
     t = torch.full((n,), float(frac[0]), dtype=torch.float64, device=x.device)
     return ops.lerp_like_numpy(st[:, 0].contiguous(), st[:, 1].contiguous(), t)
+
+
+def hough_line(image, theta=None, device=None):
+    """``skimage.transform.hough_line(image, theta)`` (pylinac/planar_imaging.py:3158) -> (hspace uint64 tensor
+    [n_dist, n_theta] on the device, theta, dists) -- the accumulation runs on the GPU, one lane per (pixel, angle)."""
+    t = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image))
+    if t.ndim != 2:
+        raise ValueError("The input image `image` must be 2D.")
+    dev = t.device if t.is_cuda else (torch.device(device) if device is not None
+                                      else torch.device("cuda", torch.cuda.current_device()))
+    img = (t.to(dev) != 0).to(torch.uint8).contiguous()
+    if theta is None:
+        theta = np.linspace(-np.pi / 2, np.pi / 2, 180)
+    theta = np.asarray(theta, dtype=np.float64)
+    h, w = img.shape
+    offset = int(np.ceil(np.sqrt(h * h + w * w)))
+    n_dist = 2 * offset                     # scikit-image 0.18.3 (>= 0.19 allocates one more row)
+    ct = torch.from_numpy(np.cos(theta)).to(dev)
+    sn = torch.from_numpy(np.sin(theta)).to(dev)
+    accum = torch.empty((n_dist, len(theta)), dtype=torch.int64, device=dev)      # uint64 counts, int64 storage
+    check(_lib.load().pl_hough_line(img.data_ptr(), h, w, ct.data_ptr(), sn.data_ptr(), len(theta), accum.data_ptr(),
+                                    torch.cuda.current_stream(dev).cuda_stream), "pl_hough_line")
+    return accum, theta, np.linspace(-offset, offset, n_dist)

@@ -142,7 +142,42 @@ __global__ void canny_select_kernel(const int32_t* __restrict__ labels, const in
   out[i] = (l > 0 && good[(i / per_frame) * per_frame + (l - 1)]) ? 1 : 0;
 }
 
+// skimage.transform.hough_line (0.18.3, _hough_transform.pyx; behaviour pinned by probing the installed build): every
+// non-zero pixel (x = column, y = row) votes, for every angle j, into
+// accum[round(cos(theta_j) * x + sin(theta_j) * y) + offset][j], offset = ceil(sqrt(h^2 + w^2)), C round() (half away
+// from zero); the accumulator has 2 * offset rows (scikit-image >= 0.19 has one more).  cos / sin tables come from the
+// host (numpy's values).
+__global__ void hough_line_kernel(const unsigned char* __restrict__ img, int h, int w, const double* __restrict__ ct,
+                                  const double* __restrict__ st, int n_theta, int offset, int64_t total,
+                                  unsigned long long* __restrict__ accum) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i % n_theta);
+  const int64_t p = i / n_theta;
+  if (!img[p]) return;
+  const double x = (double)(p % w), y = (double)(p / w);
+  const long long idx = (long long)round(ct[j] * x + st[j] * y) + offset;
+  if (idx >= 0 && idx < 2ll * offset) atomicAdd(&accum[idx * n_theta + j], 1ull);
+}
+
 }  // namespace
+
+extern "C" int pl_hough_line(const unsigned char* d_image, int h, int w, const double* d_cos, const double* d_sin,
+                             int n_theta, unsigned long long* d_accum, void* stream) {
+  PL_REQUIRE(d_image && d_cos && d_sin && d_accum, "null pointer");
+  PL_REQUIRE(h > 0 && w > 0 && n_theta > 0, "bad shape");
+  const int offset = (int)ceil(sqrt((double)h * h + (double)w * w));
+  const int64_t total = (int64_t)h * w * n_theta;
+  PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "image x angles too large for one launch");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(d_accum, 0, (size_t)(2 * offset) * n_theta * sizeof(unsigned long long), st) != hipSuccess) {
+    pl_set_error("pl_hough_line: memset failed");
+    return PL_ERR_HIP;
+  }
+  hipLaunchKernelGGL(hough_line_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0, st, d_image, h, w,
+                     d_cos, d_sin, n_theta, offset, total, d_accum);
+  return pl_check_launch("pl_hough_line");
+}
 
 extern "C" int pl_canny_normalise(const double* d_g_img, const double* d_g_ones, int64_t n, int64_t per_frame,
                                   double* d_out, void* stream) {

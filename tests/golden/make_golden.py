@@ -817,6 +817,9 @@ def main():
         cg[f"img{k}"], cg[f"kw{k}"] = im, np.array(json.dumps(kw))
     np.savez_compressed(os.path.join(HERE, "canny.npz"), **cg)
 
+    # ---- 17. hough_line: scikit-image 0.18.3's own compiled transform.hough_line (next row f2, second half)
+    subprocess.run([PY39, os.path.join(HERE, "skimage_hough_py39.py"), os.path.join(HERE, "hough.npz")], check=True)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -1395,3 +1395,17 @@ def test_canny_vs_skimage_golden(golden, dev):
         pc.canny(img, low_threshold=1.5, use_quantiles=True, device=dev)
     with pytest.raises(TypeError):
         pc.canny(img.astype(np.float32), device=dev)
+
+
+def test_hough_line_vs_skimage_golden(golden, dev):
+    """pl_hough_line against scikit-image 0.18.3's transform.hough_line: identical accumulators, angles and bins."""
+    from pylinac_amd import canny as pc
+
+    g = golden("hough")
+    for k in range(3):
+        theta = None if k == 0 else g[f"a{k}"]
+        acc, a, d = pc.hough_line(g[f"img{k}"], theta, device=dev)
+        assert np.array_equal(acc.cpu().numpy().astype(np.uint64), g[f"h{k}"]), k
+        assert np.array_equal(a, g[f"a{k}"]) and np.array_equal(d, g[f"d{k}"])
+    with pytest.raises(ValueError):
+        pc.hough_line(np.zeros(5), device=dev)

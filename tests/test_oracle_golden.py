@@ -563,3 +563,13 @@ def test_canny_restatement_matches_skimage(golden):
     g = golden("canny")
     for k, img, kw, want in _canny_cases(g):
         assert np.array_equal(o.canny(img, **kw), want), (k, kw)
+
+
+def test_hough_line_restatement_matches_skimage(golden):
+    """f2 (second half): oracle.hough_line against scikit-image 0.18.3's compiled transform.hough_line (default angles,
+    pylinac's 40-50 degree band at 0.01 degree, a half-degree sweep): accumulator, angles and distance bins identical."""
+    g = golden("hough")
+    for k in range(3):
+        theta = None if k == 0 else g[f"a{k}"]
+        acc, a, d = o.hough_line(g[f"img{k}"], theta)
+        assert np.array_equal(acc, g[f"h{k}"]) and np.array_equal(a, g[f"a{k}"]) and np.array_equal(d, g[f"d{k}"]), k
