@@ -273,6 +273,15 @@ int pl_roi_stats(const void* d_frames, int dtype, int64_t n, int h, int w, const
                  int rois_per_frame, int64_t roi_frame_stride, int kind, double* d_out, int32_t* d_status,
                  void* stream);
 
+/* ---- a15: BaseImage.gamma, the Bakai gamma map (pylinac/core/image.py:994-1016) ---------------------------------
+ * pl_bakai_mask: ref[ref < d_frame_cut[frame]] = NaN (float64) and its float32 copy (the Sobel input: pl_sobel on
+ * axis 1 / 0 gives d_grad_x / d_grad_y).  pl_bakai_gamma: |comp - ref| / sqrt(dose_term + dist_term * hypot(gx, gy)^2)
+ * with the float32 / float64 mix numpy uses (dose_term = float32((doseTA/100)^2), dist_term = float32(distTA_px^2)). */
+int pl_bakai_mask(const double* d_ref, const double* d_frame_cut, int64_t n, int64_t per_frame, double* d_ref_masked,
+                  float* d_ref32, void* stream);
+int pl_bakai_gamma(const double* d_ref_masked, const double* d_comp, const float* d_grad_x, const float* d_grad_y,
+                   float dose_term, float dist_term, int64_t total, double* d_out, void* stream);
+
 /* ---- f4 ("next" row, gamma part): pylinac.core.gamma.gamma_2d (pylinac/core/gamma.py:229-330) --------------
  * d_reference / d_evaluation float64 [n][h][w]; dose_fraction = dose_to_agreement / 100; global_dose != 0:
  * dose_ta = dose_fraction * d_ref_max[frame] (reference.max()), else dose_fraction * reference (elementwise).

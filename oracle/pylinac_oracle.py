@@ -1040,6 +1040,33 @@ def xim_file_bytes(pixels: np.ndarray, bytes_per_pixel: int = 4, properties=None
 
 
 # --------------------------------------------------------------------------------------
+# a15: BaseImage.gamma (Bakai gamma map), pylinac/core/image.py:929-1016
+# --------------------------------------------------------------------------------------
+def bakai_gamma(reference: np.ndarray, comparison: np.ndarray, dpmm: float, doseTA=1, distTA=1, threshold=0.1,
+                ground_images=True, normalize_images=True) -> np.ndarray:
+    """image.py:981-1016 restated on plain arrays: inversion check (:899-926), ground, normalize, NaN below the dose
+    threshold, float32 Sobel gradient, |comp - ref| / sqrt(doseTA^2 + distTA_px^2 * grad^2)."""
+    def prep(a):
+        a = np.array(a, copy=True)
+        p5, p50, p95 = np.percentile(a, [5, 50, 95])
+        if abs(p50 - p5) > abs(p50 - p95):
+            a = invert(a)
+        if ground_images:
+            a = ground(a)
+        if normalize_images:
+            a = normalize(a)
+        return a
+
+    ref, comp = prep(reference), prep(comparison)
+    ref[ref < threshold * np.max(ref)] = np.nan
+    img_x = ndimage.sobel(ref.astype(np.float32), 1)
+    img_y = ndimage.sobel(ref.astype(np.float32), 0)
+    grad = np.hypot(img_x, img_y)
+    denominator = np.sqrt(((doseTA / 100.0) ** 2) + (((dpmm * distTA) ** 2) * (grad**2)))
+    return np.abs(comp - ref) / denominator
+
+
+# --------------------------------------------------------------------------------------
 # f4 (gamma part): gamma_2d restated with array operations (the reference loops over pixels in Python)
 # --------------------------------------------------------------------------------------
 def gamma_2d(reference, evaluation, dose_to_agreement=1, distance_to_agreement=1, gamma_cap_value=2,

@@ -91,6 +91,8 @@ SIGNATURES = {
     "pl_canny_hysteresis": ([_p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p], C.c_int),
     "pl_xim_work_bytes": ([_i, _i], C.c_int64),
     "pl_xim_decode": ([_p, _l, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
+    "pl_bakai_mask": ([_p, _p, _l, _l, _p, _p, _p], C.c_int),
+    "pl_bakai_gamma": ([_p, _p, _p, _p, C.c_float, C.c_float, _l, _p, _p], C.c_int),
     "pl_gamma1d": ([_p, _p, _i, _p, _p, _i, _d, _d, _i, _d, _d, _d, _i, _d, _d, _p, _p, _p, _p, _p], C.c_int),
     "pl_gamma2d": ([_p, _p, _l, _i, _i, _d, _i, _p, _p, _p, _p, _i, _d, _d, _d, _p, _p, _p], C.c_int),
     "pl_gradient1d": ([_p, _l, _i, _p, _p], C.c_int),

@@ -101,7 +101,58 @@ __global__ void gamma1d_kernel(const double* __restrict__ ref, const double* __r
   gamma[i] = cap < best ? cap : best;
 }
 
+// BaseImage.gamma (Bakai et al. eq. 6; pylinac/core/image.py:994-1016), in numpy's own mixed precision:
+//   ref[ref < threshold * max(ref)] = nan                          (float64)
+//   img_x, img_y = sobel(ref.astype(float32), 1 / 0)               (float32: pl_sobel on the array written here)
+//   grad = hypot(img_x, img_y)                                     (float32: hypotf = sqrt in double, rounded)
+//   denominator = sqrt((doseTA/100)**2 + (distTA_px**2) * grad**2) (float32: the Python scalars are weak, NEP 50)
+//   gamma = abs(comp - ref) / denominator                          (float64 / float32 -> float64)
+__global__ void bakai_mask_kernel(const double* __restrict__ ref, const double* __restrict__ frame_cut, int64_t per_frame,
+                                  int64_t total, double* __restrict__ ref_masked, float* __restrict__ ref32) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  double v = ref[i];
+  if (v < frame_cut[i / per_frame]) v = __longlong_as_double(0x7ff8000000000000LL);
+  ref_masked[i] = v;
+  ref32[i] = (float)v;
+}
+
+__global__ void bakai_gamma_kernel(const double* __restrict__ ref_masked, const double* __restrict__ comp,
+                                   const float* __restrict__ gx, const float* __restrict__ gy, float dose2, float dist2,
+                                   int64_t total, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const float grad = (float)sqrt((double)gx[i] * (double)gx[i] + (double)gy[i] * (double)gy[i]);   // hypotf
+  const float g2 = grad * grad;
+  const float den = sqrtf(dose2 + dist2 * g2);
+  out[i] = fabs(comp[i] - ref_masked[i]) / (double)den;
+}
+
 }  // namespace
+
+extern "C" int pl_bakai_mask(const double* d_ref, const double* d_frame_cut, int64_t n, int64_t per_frame,
+                             double* d_ref_masked, float* d_ref32, void* stream) {
+  PL_REQUIRE(d_ref && d_frame_cut && d_ref_masked && d_ref32, "null pointer");
+  PL_REQUIRE(n >= 0 && per_frame > 0, "bad shape");
+  const int64_t total = n * per_frame;
+  if (total == 0) return PL_OK;
+  PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "batch too large for one launch");
+  hipLaunchKernelGGL(bakai_mask_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                     d_ref, d_frame_cut, per_frame, total, d_ref_masked, d_ref32);
+  return pl_check_launch("pl_bakai_mask");
+}
+
+extern "C" int pl_bakai_gamma(const double* d_ref_masked, const double* d_comp, const float* d_grad_x,
+                              const float* d_grad_y, float dose_term, float dist_term, int64_t total, double* d_out,
+                              void* stream) {
+  PL_REQUIRE(d_ref_masked && d_comp && d_grad_x && d_grad_y && d_out, "null pointer");
+  PL_REQUIRE(total >= 0, "bad shape");
+  if (total == 0) return PL_OK;
+  PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "batch too large for one launch");
+  hipLaunchKernelGGL(bakai_gamma_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                     d_ref_masked, d_comp, d_grad_x, d_grad_y, dose_term, dist_term, total, d_out);
+  return pl_check_launch("pl_bakai_gamma");
+}
 
 extern "C" int pl_gamma1d(const double* d_ref, const double* d_ref_x, int n_ref, const double* d_eval,
                           const double* d_eval_x, int n_eval, double distance_to_agreement, double dta_squared,

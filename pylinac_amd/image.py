@@ -153,12 +153,62 @@ class ArrayImage(_MutatorMixin):
         if a.dtype in (np.uint16, np.int16):
             s = au._Staged(a)
             p_low, p_mid, p_high = ops.percentile(s.t, list(percentiles))[0].tolist()
+        elif a.dtype == np.float64:
+            from .canny import _percentile_f64      # exact float64 order statistics (pl_order_stats_f64)
+
+            t = au._Staged(a).t
+            p_low, p_mid, p_high = (float(_percentile_f64(t, q)[0]) for q in percentiles)
         else:
-            raise TypeError("check_inversion_by_histogram needs a 16-bit integer frame on this backend")
+            raise TypeError("check_inversion_by_histogram needs a 16-bit integer or float64 frame on this backend")
         if abs(p_mid - p_low) > abs(p_mid - p_high):
             self.invert()
             return True
         return False
+
+    def gamma(self, comparison_image: "ArrayImage", doseTA: float = 1, distTA: float = 1, threshold: float = 0.1,
+              ground: bool = True, normalize: bool = True) -> np.ndarray:
+        """image.py:929-1016: the Bakai gamma map of this image against ``comparison_image`` (same DPI and size).
+        Inversion check, ground, normalise, NaN below ``threshold * max``, float32 Sobel gradient, gamma map --
+        every array operation on the device, in numpy's precision mix (``pl_bakai_mask`` / ``pl_bakai_gamma``)."""
+        from . import _lib
+        from ._lib import check
+
+        if not 0 <= threshold <= 1:
+            raise ValueError("threshold must be within (0, 1)")
+        if abs(self.dpi - comparison_image.dpi) > 0.1:
+            raise AttributeError(f"The image DPIs to not match: {self.dpi:.2f} vs. {comparison_image.dpi:.2f}")
+        same_x = abs(self.shape[1] - comparison_image.shape[1]) <= 1.1
+        same_y = abs(self.shape[0] - comparison_image.shape[0]) <= 1.1
+        if not (same_x and same_y):
+            raise AttributeError(f"The images are not the same size: {self.shape} vs. {comparison_image.shape}")
+        imgs = []
+        for src in (self, comparison_image):
+            im = ArrayImage(np.array(src.array, copy=True))
+            im.check_inversion_by_histogram()
+            if ground:
+                im.ground()
+            if normalize:
+                im.normalize()
+            imgs.append(np.ascontiguousarray(im.array, dtype=np.float64))
+        if imgs[0].shape != imgs[1].shape:
+            raise ValueError("operands could not be broadcast together")      # what numpy raises in the reference
+        dev = au._device()
+        ref, comp = (torch.from_numpy(a).to(dev) for a in imgs)
+        h, w = ref.shape
+        _, mx = ops.minmax(ref[None])
+        cut = (mx * threshold).contiguous()
+        masked = torch.empty_like(ref)
+        ref32 = torch.empty((1, h, w), dtype=torch.float32, device=dev)
+        lib, st = _lib.load(), torch.cuda.current_stream(dev).cuda_stream
+        check(lib.pl_bakai_mask(ref.data_ptr(), cut.data_ptr(), 1, h * w, masked.data_ptr(), ref32.data_ptr(), st),
+              "pl_bakai_mask")
+        gx, gy = ops.sobel(ref32, 1), ops.sobel(ref32, 0)
+        dist_px = self.dpmm * distTA
+        out = torch.empty_like(ref)
+        check(lib.pl_bakai_gamma(masked.data_ptr(), comp.data_ptr(), gx.data_ptr(), gy.data_ptr(),
+                                 float(np.float32((doseTA / 100.0) ** 2)), float(np.float32(dist_px**2)), h * w,
+                                 out.data_ptr(), st), "pl_bakai_gamma")
+        return out.cpu().numpy()
 
     def profile(self, axis: int = 0, kind: str = "mean") -> np.ndarray:
         """EXTENSION (the reference has no ``Image.profile()``): the axis

@@ -820,6 +820,23 @@ def main():
     # ---- 17. hough_line: scikit-image 0.18.3's own compiled transform.hough_line (next row f2, second half)
     subprocess.run([PY39, os.path.join(HERE, "skimage_hough_py39.py"), os.path.join(HERE, "hough.npz")], check=True)
 
+    # ---- 18. BaseImage.gamma (Bakai map, a15): the reference's own ArrayImage.gamma (its unit test is @skip)
+    rng = np.random.default_rng(121)
+    fr = synth_frames(2, 160, 200, seed=122).astype(np.float64)
+    ref_u16 = fr[0].astype(np.uint16)
+    cmp_u16 = np.clip(np.roll(fr[0], (1, -2), (0, 1)) * 1.01 + rng.normal(0, 150, fr[0].shape), 0, 65535).astype(np.uint16)
+    bg = {}
+    bk_cases = {"u16": (ref_u16, cmp_u16, dict()), "u16_opts": (ref_u16, cmp_u16, dict(doseTA=2, distTA=3, threshold=0.3)),
+                "f64": (ref_u16 / 65535.0, cmp_u16 / 65535.0, dict(doseTA=3, distTA=1, ground=False)),
+                "f64_raw": (fr[1] / 1000.0, fr[1] / 1000.0 * (1 + rng.normal(0, 0.01, fr[1].shape)),
+                            dict(doseTA=1, distTA=2, ground=False, normalize=False, threshold=0.05))}
+    for name, (a, b, kw) in bk_cases.items():
+        ia, ib = image.ArrayImage(a.copy(), dpi=75.6), image.ArrayImage(b.copy(), dpi=75.6)
+        bg[f"{name}.ref"], bg[f"{name}.cmp"] = a, b
+        bg[f"{name}.kw"] = np.array(json.dumps(kw))
+        bg[f"{name}.gamma"] = ia.gamma(ib, **kw)
+    np.savez_compressed(os.path.join(HERE, "bakai.npz"), **bg)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -1409,3 +1409,22 @@ def test_hough_line_vs_skimage_golden(golden, dev):
         assert np.array_equal(a, g[f"a{k}"]) and np.array_equal(d, g[f"d{k}"])
     with pytest.raises(ValueError):
         pc.hough_line(np.zeros(5), device=dev)
+
+
+def test_image_gamma_bakai_vs_reference_golden(golden, dev):
+    """ArrayImage.gamma (pl_bakai_mask, float32 pl_sobel, pl_bakai_gamma, exact float64 percentiles for the inversion
+    check) against the reference's own ArrayImage.gamma: identical float64 maps incl. the NaN pattern, for uint16 and
+    float64 inputs and every option; the reference's AttributeErrors for mismatched DPI / size."""
+    from pylinac_amd.image import ArrayImage
+    from tests.test_oracle_golden import _bakai_cases
+
+    g = golden("bakai")
+    for name, ref, cmp_, kw, want in _bakai_cases(g):
+        got = ArrayImage(ref.copy(), dpi=75.6).gamma(ArrayImage(cmp_.copy(), dpi=75.6), **kw)
+        assert got.dtype == np.float64 and np.array_equal(np.isnan(got), np.isnan(want)), name
+        assert np.array_equal(got, want, equal_nan=True), (name, float(np.nanmax(np.abs(got - want))))
+    a = ArrayImage(g["u16.ref"].copy(), dpi=75.6)
+    with pytest.raises(AttributeError):
+        a.gamma(ArrayImage(g["u16.cmp"].copy(), dpi=100))
+    with pytest.raises(AttributeError):
+        a.gamma(ArrayImage(g["u16.cmp"][:-5].copy(), dpi=75.6))

@@ -573,3 +573,22 @@ def test_hough_line_restatement_matches_skimage(golden):
         theta = None if k == 0 else g[f"a{k}"]
         acc, a, d = o.hough_line(g[f"img{k}"], theta)
         assert np.array_equal(acc, g[f"h{k}"]) and np.array_equal(a, g[f"a{k}"]) and np.array_equal(d, g[f"d{k}"]), k
+
+
+def _bakai_cases(g):
+    import json
+
+    for name in ("u16", "u16_opts", "f64", "f64_raw"):
+        yield name, g[f"{name}.ref"], g[f"{name}.cmp"], json.loads(str(g[f"{name}.kw"])), g[f"{name}.gamma"]
+
+
+def test_bakai_gamma_restatement_matches_reference(golden):
+    """a15: oracle.bakai_gamma against the reference's own ArrayImage.gamma (whose unit test is @skip: parity
+    otherwise unpinned) on uint16 and float64 image pairs, default and non-default doseTA / distTA / threshold /
+    ground / normalize: identical maps, NaN pattern included."""
+    g = golden("bakai")
+    for name, ref, cmp_, kw, want in _bakai_cases(g):
+        got = o.bakai_gamma(ref, cmp_, 75.6 / 25.4, doseTA=kw.get("doseTA", 1), distTA=kw.get("distTA", 1),
+                            threshold=kw.get("threshold", 0.1), ground_images=kw.get("ground", True),
+                            normalize_images=kw.get("normalize", True))
+        assert np.array_equal(got, want, equal_nan=True), name
