@@ -1040,6 +1040,52 @@ def xim_file_bytes(pixels: np.ndarray, bytes_per_pixel: int = 4, properties=None
 
 
 # --------------------------------------------------------------------------------------
+# a6: percentile-driven decisions, restated line by line
+# --------------------------------------------------------------------------------------
+def has_noise(a: np.ndarray) -> bool:
+    """pylinac/picketfence.py:229-238."""
+    mn, mx = a.min(), a.max()
+    near_min, near_max = np.percentile(a, [0.5, 99.5])
+    return bool(mx > near_max * 1.25 or ((mn < near_min * 0.75) and (abs(mn - near_min) > 0.1 * (near_max - near_min))))
+
+
+def pf_orientation(a: np.ndarray) -> str:
+    """pylinac/picketfence.py:1501-1526."""
+    temp = a.copy()
+    temp[temp < np.median(temp)] = np.median(temp)
+    row_sum, col_sum = np.sum(temp, 0), np.sum(temp, 1)
+    row80, row90 = np.percentile(row_sum, [85, 99])
+    col80, col90 = np.percentile(col_sum, [85, 99])
+    return "Left-Right" if (row90 - row80) < (col90 - col80) else "Up-Down"
+
+
+def corners_inverted(a: np.ndarray, box_size=20, position=(0.0, 0.0)) -> bool:
+    """pylinac/core/image.py:868-897 (the comparison; the reference then inverts)."""
+    row_pos = max(int(position[0] * a.shape[0]), 1)
+    col_pos = max(int(position[1] * a.shape[1]), 1)
+    boxes = (a[row_pos: row_pos + box_size, col_pos: col_pos + box_size],
+             a[-row_pos - box_size: -row_pos, col_pos: col_pos + box_size],
+             a[row_pos: row_pos + box_size, -col_pos - box_size: -col_pos],
+             a[-row_pos - box_size: -row_pos, -col_pos - box_size: -col_pos])
+    return bool(np.mean(boxes) > np.mean(a.flatten()))
+
+
+def clean_edges(a: np.ndarray, window_size=2) -> np.ndarray:
+    """pylinac/winston_lutz.py:1109-1133."""
+    safety_stop = np.min(a.shape) / 10
+    while safety_stop > 0:
+        near_min, near_max = np.percentile(a, [5, 99.5])
+        rng = near_max - near_min
+        ws = window_size
+        edge = np.concatenate((a[:ws, :].flatten(), a[:, :ws].flatten(), a[-ws:, :].flatten(), a[:, -ws:].flatten()))
+        if not (edge.min() < (near_min - rng / 10) or edge.max() > (near_max + rng / 10)):
+            break
+        a = a[ws:-ws, ws:-ws]
+        safety_stop -= 1
+    return a
+
+
+# --------------------------------------------------------------------------------------
 # a15: BaseImage.gamma (Bakai gamma map), pylinac/core/image.py:929-1016
 # --------------------------------------------------------------------------------------
 def bakai_gamma(reference: np.ndarray, comparison: np.ndarray, dpmm: float, doseTA=1, distTA=1, threshold=0.1,

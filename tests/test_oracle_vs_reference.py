@@ -49,3 +49,50 @@ def test_reference_kats_through_loader():
     im = image.ArrayImage(np.arange(42).reshape(6, 7))
     im.filter(3)
     assert im.array[0, 0] == 1
+
+
+def _decision_frames():
+    rng = np.random.default_rng(7)
+    out = []
+    for k in range(6):
+        h, w = (180, 240) if k % 2 == 0 else (210, 160)
+        yy, xx = np.mgrid[0:h, 0:w].astype(float)
+        img = 2000 + 30000 * np.exp(-(((yy - h / 2) / (h / 4)) ** 4 + ((xx - w / 2) / (w / 4)) ** 4)) + rng.normal(0, 300, (h, w))
+        if k in (2, 3):      # picket-like stripes along one axis
+            img += 15000 * (np.sin((xx if k == 2 else yy) / 6.0) > 0.6)
+        if k == 4:           # inverted
+            img = 40000 - img
+        img = np.clip(img, 0, 65535)
+        if k in (1, 5):      # dead / hot pixels
+            img.ravel()[rng.integers(0, img.size, 4)] = [0, 65535, 65535, 0]
+        out.append(img.astype(np.uint16))
+    return out
+
+
+def test_decision_restatements_live():
+    """a6: oracle.has_noise / pf_orientation / corners_inverted / clean_edges against the reference's own methods
+    (PFDicomImage._has_noise, PicketFence.orientation, BaseImage.check_inversion, WLBaseImage._clean_edges), driven
+    with stand-in objects that carry only the attributes those methods read."""
+    pf, image, wl = ref_loader.ref("picketfence"), ref_loader.ref("core.image"), ref_loader.ref("winston_lutz")
+
+    class Obj:
+        pass
+
+    for a in _decision_frames():
+        f = Obj()
+        f.array = a
+        assert bool(pf.PFDicomImage._has_noise(f)) == o.has_noise(a)
+        p = Obj()
+        p._orientation, p.image = None, Obj()
+        p.image.array = a
+        assert pf.PicketFence.orientation.func(p).value == o.pf_orientation(a)
+        im = image.ArrayImage(a.copy())
+        im.check_inversion()
+        assert (not np.array_equal(im.array, a)) == o.corners_inverted(a)
+        b = a.copy()
+        b[0, :40] = 65535
+        b[:, -1] = 0
+        b[-2:, 10:30] = 65535
+        w = image.ArrayImage(b.copy())
+        wl.WLBaseImage._clean_edges(w)
+        assert np.array_equal(w.array, o.clean_edges(b)) and w.array.shape != b.shape
