@@ -414,7 +414,7 @@ int pl_gauss_pk_launch(const void* in, void* out, int is_signed, int64_t n, int 
 
 namespace {
 // Packed-float32 decision kernels (gaussian_pk.hip, bit-identical to the float64 kernels below): the default
-// for 16-bit frames on both axes (256 x 1024^2, sigma 5: axis 1 0.51 vs 0.62 ms, axis 0 0.58 vs 0.61 ms; shapes
+// for 16-bit frames on both axes (256 x 1024^2, sigma 5: axis 1 0.48 vs 0.62 ms, axis 0 0.57 vs 0.61 ms; shapes
 // they do not cover -- odd widths on axis 0, other radii -- fall through to the float64 kernels).
 // PL_GAUSS_PK=0 pins the float64 kernels (A/B measurements, parity tests of both paths).
 bool use_pk_path(int /*axis*/) {

@@ -10,8 +10,8 @@
 //
 //   S = m*W + t,  t = sum_j w_j * (x[-j] + x[+j] - 2m) + w_0 * (x[0] - m)       (real arithmetic)
 //
-//   m   a lower bound of every sample in the window (lane-private column minimum in the axis-0 pass,
-//       wave-wide row minimum in the axis-1 pass), so every term of t is >= 0 and the partial sums of the
+//   m   a lower bound of every sample in the window (per-column minimum of the staged tile in the axis-0 pass,
+//       minimum of the 8-sample blocks the lane's own window covers in the axis-1 pass), so every term of t is >= 0 and the partial sums of the
 //       float32 chain grow monotonically: |t_hat - t| <= (RAD + 2) * 2^-24 * t   (RAD+1 roundings of the
 //       chain + the float32 rounding of the taps; the pair sums and x - m are exact, < 2^24);
 //   W   = w_0 + 2*sum w_j in float64; |m * (W - 1)| <= 65535 * |W - 1| is added to the margin (unnormalised
@@ -29,11 +29,12 @@
 // Bit-identical to gauss_v_fast / gauss_h_fast by construction; tests compare against scipy on noisy,
 // constant, saturated and ragged frames.
 //
-// STATUS: default for 16-bit frames on both axes (256 x 1024^2, sigma 5, MI355X: axis 1 0.51 ms vs 0.62 ms for the
-// float64 kernel; axis 0 0.58 vs 0.61 ms -- its three-barrier structure sits at 53 % VALU utilisation).
+// STATUS: default for 16-bit frames on both axes (256 x 1024^2, sigma 5, MI355X: axis 1 0.48 ms vs 0.62 ms for the
+// float64 kernel; axis 0 0.57 vs 0.61 ms -- its three-barrier structure sits at 53 % VALU utilisation; taking the
+// axis-0 offset from block minima like axis 1, which removes the first barrier, measured 0.59 ms: no gain).
 // PL_GAUSS_PK=0 pins the float64 kernels.  History (profiles/r01c_*): with a wave-wide row
 // minimum the axis-1 kernel left ~6 % of the in-field pixels undecided (every 552-sample span that contains a
-// field edge) and ran 0.54 ms; the lane-local minimum below brought that to 0.51 ms once the register spills it
+// field edge) and ran 0.54 ms; the lane-local minimum below brought that to 0.51 ms (0.48 without the wave-wide offset) once the register spills it
 // first caused (20 scratch accesses per wave doubled the run time) were removed.  Axis-0 variants that were
 // measured and dropped: a persistent strip-walking version of the LDS-tile kernel with register prefetch
 // (0.84 ms); a barrier-free sliding REGISTER window (one wave walks down 64 column pairs, window shift and
@@ -355,7 +356,6 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
   __shared__ __attribute__((aligned(16))) f2 lds[WAVES * PADDED];
   __shared__ __attribute__((aligned(16))) f2 s_blockmin[WAVES][LOGICAL / 8 + 1];  // minima of 8-position blocks
   __shared__ FixList fix;
-  __shared__ unsigned s_rowmin[2 * WAVES];
   __shared__ float s_c0;
   __shared__ float s_wf[RAD + 1];
   __shared__ double s_wsum;
@@ -411,28 +411,11 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
     ha = ((unsigned)(unsigned short)fa[cc]) ^ kBias1;
     hb = ((unsigned)(unsigned short)fb[cc]) ^ kBias1;
   }
-  // ---- row minima over everything the wave staged
-  us2 ma = as_us2(qa[0]), mb = as_us2(qb[0]);
-#pragma unroll
-  for (int k = 1; k < NOUT / 2; ++k) {
-    ma = __builtin_elementwise_min(ma, as_us2(qa[k]));
-    mb = __builtin_elementwise_min(mb, as_us2(qb[k]));
-  }
-  unsigned mna = min((unsigned)ma.x, (unsigned)ma.y), mnb = min((unsigned)mb.x, (unsigned)mb.y);
-  if (hp >= 0) {
-    mna = min(mna, ha);
-    mnb = min(mnb, hb);
-  }
-  mna = pl_wave_reduce(mna, [](unsigned a, unsigned b) { return min(a, b); });
-  mnb = pl_wave_reduce(mnb, [](unsigned a, unsigned b) { return min(a, b); });
-  mna = __builtin_amdgcn_readfirstlane(mna);
-  mnb = __builtin_amdgcn_readfirstlane(mnb);
-  if (lane == 0) {
-    s_rowmin[2 * wave] = mna;
-    s_rowmin[2 * wave + 1] = mnb;
-  }
-  const f2 mf = f2{(float)mna, (float)mnb};
-  const f2 nb = -(splat(8388608.0f) + mf);
+  // The staged samples carry NO wave-wide offset (biased 16-bit values are exact in float32 as they are); the
+  // lane-local minimum below is the only offset.  (An earlier version subtracted the wave-wide row minimum first:
+  // two 6-step wave reductions per wave for nothing once the local minimum exists.)
+  const f2 mf = splat(0.0f);
+  const f2 nb = splat(-8388608.0f);
 
   // ---- stage {row a, row b} pairs, m-subtracted, as float2
 #pragma unroll
@@ -441,11 +424,10 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
     s[10 * lane + pad8(RAD + 2 * k + 1)] = f2{magic_hi(qa[k]), magic_hi(qb[k])} + nb;
   }
   if (hp >= 0) s[pad8(hp)] = f2{magic_lo(ha), magic_lo(hb)} + nb;
-  __syncthreads();  // staging visible (per wave), fix.cnt / s_c0 / s_rowmin visible (workgroup)
+  __syncthreads();  // staging visible (per wave), fix.cnt / s_c0 / taps visible (workgroup)
 
   PkTaps<RAD> taps;
   load_taps<RAD>(s_wf, taps, s_c0);
-  const bool m0z = mna == kBias1, m1z = mnb == kBias1;
 
   unsigned failmask = 0;
   unsigned res[NOUT];  // res[i] = {row a px i, row b px i}
@@ -486,8 +468,9 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
     f2 x[WIN];
 #pragma unroll
     for (int k = 0; k < WIN; ++k) x[k] = win[k + ((k >> 3) << 1)] - d;
-    const f2 mfl = mf + d;
-    const bool z0 = m0z && d.x == 0.0f, z1 = m1z && d.y == 0.0f;
+    const f2 mfl = mf + d;                                       // = the local minimum itself (biased domain)
+    const float zero_b = kSigned ? 32768.0f : 0.0f;               // actual value 0 in the biased domain
+    const bool z0 = mfl.x == zero_b, z1 = mfl.y == zero_b;
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
       unsigned fbits;
@@ -537,7 +520,7 @@ gauss_h_pk(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
     const int64_t row = (pair0 + wv) * 2 + sel;
     const int cc = c0 + l * NOUT + i;
     if (row >= rows_total || cc >= w) return;
-    const double m = (double)s_rowmin[2 * wv + sel] - (kSigned ? 32768.0 : 0.0);
+    const double m = kSigned ? -32768.0 : 0.0;                  // the staged samples are the biased values themselves
     const float* base = reinterpret_cast<const float*>(lds + wv * PADDED) + sel;
     // window position p0 + k lives at 10*l + pad8(i + k): one lane-dependent shift per 8 positions
     const float* win = base + 20 * l;
