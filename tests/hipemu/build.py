@@ -1,0 +1,55 @@
+"""TEST INFRASTRUCTURE ONLY: compile csrc/*.hip for the CPU wave64 emulator (tests/hipemu/hip/hip_runtime.h).
+
+    python tests/hipemu/build.py            # -> tests/hipemu/_build/libpylinac_emu.so
+
+The product (pylinac_amd/) never loads this library; tests/test_emulated_kernels.py does, to check kernel logic
+against the oracle where there is no GPU.  Only the files listed in SOURCES are built: the ones whose device code
+is plain C++ plus barriers / wave intrinsics (no gfx950 inline assembly or clang vector builtins on the live path).
+"""
+from __future__ import annotations
+
+import pathlib
+import re
+import subprocess
+import sys
+
+HERE = pathlib.Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+CSRC = ROOT / "pylinac_amd" / "csrc"
+BUILD = HERE / "_build"
+LIB = BUILD / "libpylinac_emu.so"
+
+SOURCES = ["runtime.hip", "interp.hip", "gamma.hip", "roi.hip", "canny.hip", "elementwise.hip", "reduce.hip",
+           "edge.hip", "circle.hip", "spectral.hip", "xim.hip", "planar.hip"]
+
+_DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([\w\s]+?)\s+(\w+)\[\];")
+
+
+def _rewrite(text: str) -> str:
+    # `extern __shared__ T name[];`  ->  a pointer to the emulator's dynamic-LDS buffer
+    return _DYN.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(hipemu::dyn_lds());", text)
+
+
+def build(sources=None, verbose: bool = False) -> pathlib.Path:
+    sources = [s for s in (sources or SOURCES) if (CSRC / s).exists()]
+    BUILD.mkdir(exist_ok=True)
+    inputs = [CSRC / s for s in sources] + [HERE / "hipemu.cpp", HERE / "hip" / "hip_runtime.h", CSRC / "pl_common.h",
+                                            ROOT / "include" / "pylinac_hip.h", pathlib.Path(__file__)]
+    if LIB.exists() and all(LIB.stat().st_mtime >= p.stat().st_mtime for p in inputs):
+        return LIB
+    cpps = []
+    for s in sources:
+        out = BUILD / (pathlib.Path(s).stem + "_emu.cpp")
+        out.write_text(f'#line 1 "{CSRC / s}"\n' + _rewrite((CSRC / s).read_text()))
+        cpps.append(str(out))
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+           "-Wno-attributes", "-Wno-unknown-pragmas", f"-I{HERE}", f"-I{CSRC}", *cpps, str(HERE / "hipemu.cpp"),
+           "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,181 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny wave64 execution model for running the HIP kernels of pylinac_amd/csrc on
+// the CPU, so that kernel LOGIC can be checked against the oracle in the `-m "not gpu"` suite (this container has
+// no GPU and a round has 90 GPU-minutes).  Nothing under pylinac_amd/ includes, loads or links this: the product
+// has no CPU path (tests/test_cabi.py checks that).  tests/hipemu/build.py compiles selected csrc/*.hip files with
+// g++ against THIS header (it shadows <hip/hip_runtime.h>) into tests/hipemu/_build/libpylinac_emu.so.
+//
+// Execution model: one workgroup at a time, every work-item a ucontext fiber on ONE OS thread.
+//   __syncthreads()              fiber parks until every live fiber of the workgroup is parked at a block barrier
+//   __shfl* / __ballot / ...     the 64 lanes of a wave exchange through a slot table: park, the scheduler snapshots
+//                                the slots of the lanes that arrived (= the active mask) and releases them together
+//   __shared__                   `static` (one workgroup runs at a time); dynamic LDS: build.py rewrites the
+//                                `extern __shared__ T name[];` declaration into a pointer to hipemu::dyn_lds()
+//   atomics                      plain read-modify-write (single OS thread)
+// What it does NOT model: timing, memory coalescing, cross-workgroup spinning, code that relies on implicit wave
+// lock-step without a barrier or wave intrinsic.  Floating point is IEEE double / float on both sides (g++ builds
+// with -ffp-contract=off like hipcc does for this library); libm functions may differ from ROCm's in the last ulp.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <type_traits>
+
+#define PL_HIPEMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+#define HIPEMU_VEC(T, name)                                   \
+  struct name##2 { T x, y; };                                  \
+  struct name##3 { T x, y, z; };                               \
+  struct alignas(4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T)) name##4 { T x, y, z, w; };
+HIPEMU_VEC(unsigned, uint)
+HIPEMU_VEC(int, int)
+HIPEMU_VEC(float, float)
+HIPEMU_VEC(double, double)
+HIPEMU_VEC(unsigned short, ushort)
+HIPEMU_VEC(short, short)
+HIPEMU_VEC(unsigned char, uchar)
+HIPEMU_VEC(unsigned long long, ulonglong)
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+typedef struct ihipStream_t* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorLaunchFailure = 719 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+namespace hipemu {
+struct Idx { unsigned x, y, z; };
+extern Idx g_threadIdx, g_blockIdx;
+extern dim3 g_blockDim, g_gridDim;
+void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, const std::function<void()>& body);
+void* dyn_lds();
+void block_barrier();
+int block_barrier_or(int pred);
+// park this lane with `mine`; returns the values of the whole wave and the mask of the lanes that took part
+void wave_exchange(uint64_t mine, uint64_t out[64], uint64_t* active);
+hipError_t take_error();
+inline int lane_id() { return (int)((g_threadIdx.x + g_blockDim.x * (g_threadIdx.y + g_blockDim.y * g_threadIdx.z)) & 63u); }
+
+template <typename T>
+inline uint64_t to_bits(T v) {
+  static_assert(sizeof(T) <= 8, "wave exchange moves at most 8 bytes");
+  uint64_t b = 0;
+  memcpy(&b, &v, sizeof(T));
+  return b;
+}
+template <typename T>
+inline T from_bits(uint64_t b) {
+  T v;
+  memcpy(&v, &b, sizeof(T));
+  return v;
+}
+template <typename T>
+inline T shfl_from(T v, int src) {
+  uint64_t all[64], act;
+  wave_exchange(to_bits(v), all, &act);
+  if (src < 0 || src > 63 || !((act >> src) & 1ull)) return v;
+  return from_bits<T>(all[src]);
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g_threadIdx)
+#define blockIdx (hipemu::g_blockIdx)
+#define blockDim (hipemu::g_blockDim)
+#define gridDim (hipemu::g_gridDim)
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+  hipemu::launch((grid), (block), (size_t)(lds), [&]() { (kernel)(__VA_ARGS__); })
+
+inline const char* hipGetErrorString(hipError_t) { return "hipemu: kernel deadlocked (divergent barrier?)"; }
+inline hipError_t hipGetLastError() { return hipemu::take_error(); }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+template <typename F>
+inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+
+// ---- barriers and wave intrinsics ------------------------------------------------------------------------
+inline void __syncthreads() { hipemu::block_barrier(); }
+inline int __syncthreads_or(int p) { return hipemu::block_barrier_or(p); }
+#define __builtin_amdgcn_wave_barrier() ((void)hipemu::shfl_from(0, 0))
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_readfirstlane(v) (hipemu::readfirstlane(v))
+namespace hipemu {
+template <typename T>
+inline T readfirstlane(T v) {
+  uint64_t all[64], act;
+  wave_exchange(to_bits(v), all, &act);
+  return from_bits<T>(all[__builtin_ctzll(act)]);
+}
+}  // namespace hipemu
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) { (void)width; return hipemu::shfl_from(v, src); }
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return hipemu::shfl_from(v, hipemu::lane_id() ^ mask); }
+template <typename T>
+inline T __shfl_up(T v, unsigned d, int width = 64) { (void)width; return hipemu::shfl_from(v, hipemu::lane_id() - (int)d); }
+template <typename T>
+inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; return hipemu::shfl_from(v, hipemu::lane_id() + (int)d); }
+inline unsigned long long __ballot(int pred) {
+  uint64_t all[64], act;
+  hipemu::wave_exchange(pred ? 1u : 0u, all, &act);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if (((act >> l) & 1ull) && all[l]) m |= 1ull << l;
+  return m;
+}
+
+// ---- device math that is global-namespace in HIP ---------------------------------------------------------------
+using std::max;
+using std::min;
+inline void sincospi(double x, double* s, double* c) {
+  // exact at the multiples of 1/2 like ROCm's sincospi (the kernels reduce their twiddle indices first)
+  double r = fmod(x, 2.0);
+  if (r < 0) r += 2.0;
+  if (r == 0.0) { *s = 0.0; *c = 1.0; }
+  else if (r == 0.5) { *s = 1.0; *c = 0.0; }
+  else if (r == 1.0) { *s = 0.0; *c = -1.0; }
+  else if (r == 1.5) { *s = -1.0; *c = 0.0; }
+  else { *s = sin(M_PI * r); *c = cos(M_PI * r); }
+}
+
+// ---- bit casts / integer intrinsics ----------------------------------------------------------------------
+inline double __longlong_as_double(long long v) { return hipemu::from_bits<double>((uint64_t)v); }
+inline long long __double_as_longlong(double v) { return (long long)hipemu::to_bits(v); }
+inline float __uint_as_float(unsigned v) { return hipemu::from_bits<float>(v); }
+inline unsigned __float_as_uint(float v) { return (unsigned)hipemu::to_bits(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+
+// ---- atomics (one OS thread: plain read-modify-write, returning the old value) -------------------------------
+template <typename T, typename U>
+inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
+template <typename T, typename U>
+inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
+template <typename T, typename U>
+inline T atomicAnd(T* p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }
+template <typename T, typename U>
+inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <typename T, typename U>
+inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+template <typename T, typename U>
+inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
+template <typename T, typename U, typename V>
+inline T atomicCAS(T* p, U expected, V desired) { T o = *p; if (o == (T)expected) *p = (T)desired; return o; }

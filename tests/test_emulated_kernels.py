@@ -1,0 +1,114 @@
+"""Kernel LOGIC on the CPU: csrc/*.hip compiled for the wave64 fiber emulator of tests/hipemu and driven through the
+same C ABI with host pointers, against the oracle.  This is NOT a product path (the product has no CPU path; see
+tests/test_cabi.py) -- it lets kernel changes be checked where there is no GPU.  The `-m gpu` parity tests remain the
+proof on hardware.  The first tests re-run kernels that are parity-green on the MI355X: they validate the emulator.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests" / "hipemu"))
+
+from oracle import pylinac_oracle as orc  # noqa: E402
+from pylinac_amd import _lib as binding  # noqa: E402  (argtypes only; the emulated library is loaded here, not there)
+
+PL_U16, PL_I16, PL_F32, PL_F64, PL_U8, PL_I32, PL_I64 = 0, 1, 2, 3, 4, 5, 6
+_DT = {np.dtype(np.uint16): PL_U16, np.dtype(np.int16): PL_I16, np.dtype(np.float32): PL_F32,
+       np.dtype(np.float64): PL_F64, np.dtype(np.uint8): PL_U8, np.dtype(np.int32): PL_I32, np.dtype(np.int64): PL_I64}
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import build as emu_build  # tests/hipemu/build.py
+
+    lib = C.CDLL(str(emu_build.build()))
+    for name, (argtypes, restype) in binding.SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes = argtypes
+            fn.restype = restype
+    lib.pl_last_error.restype = C.c_char_p
+    return lib
+
+
+def _p(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _ok(lib, rc):
+    assert rc == 0, lib.pl_last_error().decode()
+
+
+# ---- emulator validation on kernels that are parity-green on the GPU ---------------------------------------
+
+def test_emu_interp1d_linear_and_cubic(emu):
+    from scipy.interpolate import interp1d
+
+    rng = np.random.default_rng(0)
+    x = np.cumsum(rng.uniform(0.5, 1.5, 40))
+    y = rng.normal(size=(3, 40))
+    xq = np.linspace(x[0] - 1.0, x[-1] + 1.0, 333)
+    for kind, name in ((0, "linear"), (1, "cubic")):
+        out = np.empty((3, xq.size))
+        work = np.empty(3 * 3 * 40)
+        _ok(emu, emu.pl_interp1d(_p(x), 0, _p(y), 3, 40, _p(xq), xq.size, kind, _p(work), _p(out), None))
+        ref = np.stack([interp1d(x, yy, kind=name, bounds_error=False, fill_value="extrapolate")(xq) for yy in y])
+        if kind == 0:
+            np.testing.assert_array_equal(out, ref)
+        else:
+            np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-10)
+
+
+def test_emu_roi_stats_barriers_ballot_dynamic_lds(emu):
+    rng = np.random.default_rng(1)
+    frames = rng.integers(0, 4000, (2, 64, 80)).astype(np.uint16)
+    rois = np.array([[30.2, 31.7, 9.3, 0], [50.0, 20.0, 5.0, 0], [12.5, 40.5, 11.0, 0]])
+    out = np.empty((2, 3, 6))
+    status = np.empty((2, 3), np.int32)
+    _ok(emu, emu.pl_roi_stats(_p(frames), PL_U16, 2, 64, 80, _p(rois), 3, 0, 0, _p(out), _p(status), None))
+    assert (status == 0).all()
+    for f in range(2):
+        for k, (cx, cy, r, _) in enumerate(rois):
+            want = orc.disk_roi_stats(frames[f], cx, cy, r)
+            np.testing.assert_array_equal(out[f, k][[0, 3, 4, 5]], want[[0, 3, 4, 5]])
+            np.testing.assert_allclose(out[f, k][[1, 2]], want[[1, 2]], rtol=1e-12)   # summation order
+
+
+def test_emu_gamma2d(emu):
+    rng = np.random.default_rng(2)
+    ref = rng.uniform(0, 100, (1, 24, 28))
+    ev = ref * rng.uniform(0.97, 1.03, ref.shape)
+    dta = 2
+    want = orc.gamma_2d(ref[0], ev[0], dose_to_agreement=2, distance_to_agreement=dta, gamma_cap_value=2,
+                        global_dose=True, dose_threshold=5, fill_value=np.nan)
+    from pylinac_amd.gamma import disk_offsets
+
+    rr, cc = disk_offsets(dta)
+    dr, dc = rr.astype(np.int32), cc.astype(np.int32)
+    d2 = np.ascontiguousarray((rr / dta) ** 2 + (cc / dta) ** 2, dtype=np.float64)
+    work = np.empty(2 * ref.size)
+    out = np.empty_like(ref)
+    rmax = np.array([ref.max()])
+    _ok(emu, emu.pl_gamma2d(_p(ref), _p(ev), 1, 24, 28, 0.02, 1, _p(rmax), _p(dr), _p(dc), _p(d2), dr.size,
+                            0.05, 2.0, float("nan"), _p(work), _p(out), None))
+    np.testing.assert_array_equal(out[0], want)
+
+
+def test_emu_xim_decode_scans(emu):
+    rng = np.random.default_rng(3)
+    h, w = 37, 53
+    img = np.cumsum(rng.integers(-300, 300, (h, w)), axis=1).astype(np.int32)
+    lookup, stream = orc.xim_encode(img)
+    want = orc.xim_decode(lookup, stream, w, h, 4)
+    np.testing.assert_array_equal(want.reshape(h, w), img)
+    work = np.empty(emu.pl_xim_work_bytes(w, h), np.uint8)
+    out = np.empty((h, w), np.int32)
+    _ok(emu, emu.pl_xim_decode(_p(lookup), lookup.size, _p(stream), stream.size, w, h, 4, _p(out), _p(work), None))
+    np.testing.assert_array_equal(out, img)
