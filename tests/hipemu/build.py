@@ -20,12 +20,20 @@ BUILD = HERE / "_build"
 LIB = BUILD / "libpylinac_emu.so"
 
 SOURCES = ["runtime.hip", "interp.hip", "gamma.hip", "roi.hip", "canny.hip", "elementwise.hip", "reduce.hip",
-           "edge.hip", "circle.hip", "spectral.hip", "xim.hip", "planar.hip"]
+           "edge.hip", "circle.hip", "spectral.hip", "xim.hip", "planar.hip", "ccl.hip", "ct.hip", "features.hip", "peaks.hip",
+           "hist_otsu.hip", "picketfence.hip", "median.hip", "gaussian.hip"]
 
 _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([\w\s]+?)\s+(\w+)\[\];")
 
 
+_WAITCNT = re.compile(r'asm\s+volatile\s*\(\s*"s_waitcnt[^;]*;')
+_MED3 = re.compile(r'asm\("v_med3_[ui]32[^;]*;')
+
+
 def _rewrite(text: str) -> str:
+    # gfx950 inline assembly: waits are meaningless here; v_med3 (operands a, b, c -> r) is spelled out
+    text = _WAITCNT.sub(";", text)
+    text = _MED3.sub("r = std::max(std::min(a, b), std::min(std::max(a, b), c));", text)
     # `extern __shared__ T name[];`  ->  a pointer to the emulator's dynamic-LDS buffer
     return _DYN.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(hipemu::dyn_lds());", text)
 
@@ -33,17 +41,19 @@ def _rewrite(text: str) -> str:
 def build(sources=None, verbose: bool = False) -> pathlib.Path:
     sources = [s for s in (sources or SOURCES) if (CSRC / s).exists()]
     BUILD.mkdir(exist_ok=True)
-    inputs = [CSRC / s for s in sources] + [HERE / "hipemu.cpp", HERE / "hip" / "hip_runtime.h", CSRC / "pl_common.h",
+    inputs = [CSRC / s for s in sources] + [HERE / "hipemu.cpp", HERE / "emu_stubs.cpp", HERE / "hip" / "hip_runtime.h", CSRC / "pl_common.h",
                                             ROOT / "include" / "pylinac_hip.h", pathlib.Path(__file__)]
     if LIB.exists() and all(LIB.stat().st_mtime >= p.stat().st_mtime for p in inputs):
         return LIB
+    (BUILD / "pl_common.h").write_text(f'#line 1 "{CSRC / "pl_common.h"}"\n' + _rewrite((CSRC / "pl_common.h").read_text())
+                                       .replace('"../../include/pylinac_hip.h"', f'"{ROOT / "include" / "pylinac_hip.h"}"'))
     cpps = []
     for s in sources:
         out = BUILD / (pathlib.Path(s).stem + "_emu.cpp")
         out.write_text(f'#line 1 "{CSRC / s}"\n' + _rewrite((CSRC / s).read_text()))
         cpps.append(str(out))
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-           "-Wno-attributes", "-Wno-unknown-pragmas", f"-I{HERE}", f"-I{CSRC}", *cpps, str(HERE / "hipemu.cpp"),
+           "-Wno-attributes", "-Wno-unknown-pragmas", f"-I{HERE}", f"-I{BUILD}", f"-I{CSRC}", *cpps, str(HERE / "hipemu.cpp"), str(HERE / "emu_stubs.cpp"),
            "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))

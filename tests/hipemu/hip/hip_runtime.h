@@ -114,6 +114,7 @@ inline void __syncthreads() { hipemu::block_barrier(); }
 inline int __syncthreads_or(int p) { return hipemu::block_barrier_or(p); }
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::shfl_from(0, 0))
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_fract(x) ((x) - floor(x))
 #define __builtin_amdgcn_readfirstlane(v) (hipemu::readfirstlane(v))
 namespace hipemu {
 template <typename T>

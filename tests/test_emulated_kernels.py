@@ -112,3 +112,47 @@ def test_emu_xim_decode_scans(emu):
     out = np.empty((h, w), np.int32)
     _ok(emu, emu.pl_xim_decode(_p(lookup), lookup.size, _p(stream), stream.size, w, h, 4, _p(out), _p(work), None))
     np.testing.assert_array_equal(out, img)
+
+
+def test_emu_gaussian_f64_kernels_match_scipy(emu):
+    from scipy import ndimage
+
+    rng = np.random.default_rng(4)
+    frames = rng.integers(0, 65535, (2, 70, 96)).astype(np.uint16)
+    for sigma in (1.0, 2.3):
+        radius = int(4.0 * sigma + 0.5)
+        x = np.arange(-radius, radius + 1)
+        wts = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+        wts = np.ascontiguousarray(wts / wts.sum())
+        out = np.empty_like(frames)
+        tmp = np.empty_like(frames)
+        _ok(emu, emu.pl_gaussian2d(_p(frames), _p(out), _p(tmp), PL_U16, 2, 70, 96, _p(wts), radius, None))
+        want = np.stack([ndimage.gaussian_filter(f, sigma) for f in frames])
+        np.testing.assert_array_equal(out, want)
+
+
+def test_emu_median3_packed_kernels(emu):
+    from scipy import ndimage
+
+    rng = np.random.default_rng(5)
+    for shape in ((2, 40, 64), (1, 33, 50), (1, 21, 37)):     # eight-column, pair and generic paths
+        frames = rng.integers(0, 65535, shape).astype(np.uint16)
+        out = np.empty_like(frames)
+        _ok(emu, emu.pl_median2d(_p(frames), _p(out), PL_U16, shape[0], shape[1], shape[2], 3, None))
+        np.testing.assert_array_equal(out, np.stack([ndimage.median_filter(f, size=3) for f in frames]))
+
+
+def test_emu_label_matches_scipy(emu):
+    from scipy import ndimage
+
+    rng = np.random.default_rng(6)
+    mask = (rng.random((2, 45, 61)) > 0.55).astype(np.uint8)
+    for conn, structure in ((4, None), (8, np.ones((3, 3)))):
+        labels = np.empty(mask.shape, np.int32)
+        work = np.empty(mask.shape, np.int32)
+        count = np.empty(2, np.int32)
+        _ok(emu, emu.pl_label(_p(mask), 2, 45, 61, conn, _p(labels), _p(work), _p(count), None))
+        for f in range(2):
+            want, nl = ndimage.label(mask[f], structure=structure)
+            assert count[f] == nl
+            np.testing.assert_array_equal(labels[f], want)
