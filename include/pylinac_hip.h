@@ -258,6 +258,14 @@ int pl_order_stats_f64(const double* d_values, int64_t n, int64_t count, const i
  * np.linspace(-offset, offset, rows). */
 int pl_hough_line(const unsigned char* d_image, int h, int w, const double* d_cos, const double* d_sin, int n_theta,
                   unsigned long long* d_accum, void* stream);
+/* f2, second half: the dense part of skimage.transform.hough_line_peaks -> skimage.feature.peak._prominent_peaks
+ * (scikit-image 0.18.3) as called at pylinac/planar_imaging.py:3160-3166.
+ * pl_max_filter1d: ndimage.maximum_filter1d(img, size = 2 * half + 1, axis, mode="constant", cval=0) per frame of
+ *   [n][h][w] (any dtype of the enum; the Hough accumulator is passed as PL_I64: counts < 2^63).  Not in place.
+ * pl_peak_candidates: mask = (img == img_max) & (double(img) > threshold), uint8 [count]. */
+int pl_max_filter1d(const void* in, void* out, int dtype, int64_t n, int h, int w, int axis, int half, void* stream);
+int pl_peak_candidates(const void* img, const void* img_max, int dtype, int64_t count, double threshold,
+                       unsigned char* mask, void* stream);
 int pl_canny_hysteresis(const unsigned char* d_local_max, const double* d_magnitude, const double* d_thresholds,
                         int64_t n, int h, int w, unsigned char* d_low, unsigned char* d_high, const int32_t* d_labels,
                         int32_t* d_good, unsigned char* d_out, int phase, void* stream);

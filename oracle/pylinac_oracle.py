@@ -1482,3 +1482,113 @@ def epid_pipeline(frames: np.ndarray, **kw):
         profs.append(prof)
         recs.append(rec)
     return np.stack(outs), np.stack(profs), np.stack(recs)
+
+
+# --------------------------------------------------------------------------------------
+# "next" row f2, second half: Hough peaks and the planar phantom outline (pylinac/planar_imaging.py:300-341, 3136-3179)
+# --------------------------------------------------------------------------------------
+
+def prominent_peaks(image: np.ndarray, min_xdistance=1, min_ydistance=1, threshold=None, num_peaks=np.inf):
+    """skimage.feature.peak._prominent_peaks (scikit-image 0.18.3; third-party, absent from /root/reference), the
+    engine of transform.hough_line_peaks: separable maximum filter with zero padding, candidates = pixels equal to
+    their window maximum and above the threshold, 8-connected candidate groups ranked by height (ties: the later
+    label first, because the stable ascending sort is reversed), then greedy suppression of a (2*min_y+1) x
+    (2*min_x+1) neighbourhood around each accepted group's rounded centroid -- rows do not wrap and row 0 is never
+    suppressed (`ycoords_nh > 0`), columns wrap with the row mirrored (angles are periodic).
+    -> (heights, x (column) indices, y (row) indices)."""
+    img = image.copy()
+    rows, cols = img.shape
+    if threshold is None:
+        threshold = 0.5 * np.max(img)
+    img_max = ndimage.maximum_filter1d(img, size=2 * min_ydistance + 1, axis=0, mode="constant", cval=0)
+    img_max = ndimage.maximum_filter1d(img_max, size=2 * min_xdistance + 1, axis=1, mode="constant", cval=0)
+    candidates = (img == img_max) & (img > threshold)
+    lab, nlab = ndimage.label(candidates, structure=np.ones((3, 3)))
+    groups = []
+    for k in range(1, nlab + 1):
+        rr, cc = np.nonzero(lab == k)
+        groups.append((img_max[rr, cc].max(), np.round(rr.mean()).astype(int), np.round(cc.mean()).astype(int)))
+    groups = sorted(groups, key=lambda g: g[0])[::-1]
+    heights, xs, ys = [], [], []
+    dy, dx = np.mgrid[-min_ydistance:min_ydistance + 1, -min_xdistance:min_xdistance + 1]
+    for _, y0, x0 in groups:
+        accum = img_max[y0, x0]
+        if not accum > threshold:
+            continue
+        yn, xn = y0 + dy, x0 + dx
+        keep = (yn > 0) & (yn < rows)
+        yn, xn = yn[keep], xn[keep]
+        low = xn < 0
+        yn[low] = rows - yn[low]
+        xn[low] += cols
+        high = xn >= cols
+        yn[high] = rows - yn[high]
+        xn[high] -= cols
+        img_max[yn, xn] = 0
+        heights.append(accum)
+        xs.append(x0)
+        ys.append(y0)
+    heights, xs, ys = np.array(heights), np.array(xs), np.array(ys)
+    if num_peaks < len(heights):
+        top = np.argsort(heights)[::-1][:num_peaks]
+        heights, xs, ys = heights[top], xs[top], ys[top]
+    return heights, xs, ys
+
+
+def hough_line_peaks(hspace, angles, dists, min_distance=9, min_angle=10, threshold=None, num_peaks=np.inf):
+    """skimage.transform.hough_line_peaks (0.18.3) as called at pylinac/planar_imaging.py:3160-3166."""
+    min_angle = min(min_angle, hspace.shape[1])
+    h, a, d = prominent_peaks(hspace, min_xdistance=min_angle, min_ydistance=min_distance, threshold=threshold,
+                              num_peaks=num_peaks)
+    if a.any():
+        return h, angles[a], dists[d]
+    return h, np.array([]), np.array([])
+
+
+def region_bboxes(edges: np.ndarray):
+    """measure.label(canny_img) (2-D default: 8-connected) + regionprops(...).bbox for every region, in label order
+    (pylinac/planar_imaging.py:585-587) -> int array [n_regions, 4] = (min_row, min_col, max_row, max_col), half-open."""
+    lab, nlab = ndimage.label(edges, structure=np.ones((3, 3)))
+    out = np.zeros((nlab, 4), dtype=np.int64)
+    for k, sl in enumerate(ndimage.find_objects(lab)):
+        out[k] = (sl[0].start, sl[1].start, sl[0].stop, sl[1].stop)
+    return lab, out
+
+
+def select_phantom_region(bboxes: np.ndarray, image_shape, phantom_bbox_size_px: float,
+                          conditions=("is_centered", "is_right_size"), roi_match_condition="max"):
+    """ImagePhantomBase.phantom_ski_region (pylinac/planar_imaging.py:300-341) on the bbox table of the canny regions:
+    keep area_bbox > 100, order by area_bbox descending (stable), apply the detection conditions
+    (:115-137: is_square rel_tol 0.2 via math.isclose; is_centered np.allclose(rtol 0.3) of the bbox middle against
+    the image centre; is_right_size np.isclose(rtol 0.1) against phantom_bbox_size_px), then the biggest / the
+    closest-in-size passing region.  -> index into `bboxes` (label - 1).  Raises ValueError like the reference."""
+    b = np.asarray(bboxes)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    cand = [i for i in range(len(b)) if area[i] > 100]
+    cand = sorted(cand, key=lambda i: area[i], reverse=True)
+    # image.center (pylinac/core/image.py:526-533): Point(x = shape[1] / 2 - 0.5, y = shape[0] / 2 - 0.5)
+    centre = (image_shape[0] / 2 - 0.5, image_shape[1] / 2 - 0.5)
+    passing = []
+    for i in cand:
+        r0, c0, r1, c1 = (int(v) for v in b[i])
+        ok = True
+        for cond in conditions:
+            if cond == "is_square":
+                ok &= math.isclose((r1 - r0) / (c1 - c0), 1, rel_tol=0.2)
+            elif cond == "is_centered":
+                ok &= bool(np.allclose(((r1 - r0) / 2 + r0, (c1 - c0) / 2 + c0), centre, rtol=0.3))
+            elif cond == "is_right_size":
+                ok &= bool(np.isclose(area[i], phantom_bbox_size_px, rtol=0.1))
+            else:
+                raise ValueError(cond)
+        if ok:
+            passing.append(i)
+    if not passing:
+        raise ValueError("Unable to find the phantom in the image.")
+    if roi_match_condition == "max":
+        best = np.argsort([area[i] for i in passing])[-1]
+    elif roi_match_condition == "closest":
+        best = np.argsort([abs(area[i] - phantom_bbox_size_px) for i in passing])[0]
+    else:
+        raise ValueError(roi_match_condition)
+    return passing[best]

@@ -88,6 +88,8 @@ SIGNATURES = {
     "pl_canny_nms": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
     "pl_order_stats_f64": ([_p, _l, _l, _p, _i, _p, _p], C.c_int),
     "pl_hough_line": ([_p, _i, _i, _p, _p, _i, _p, _p], C.c_int),
+    "pl_max_filter1d": ([_p, _p, _i, _l, _i, _i, _i, _i, _p], C.c_int),
+    "pl_peak_candidates": ([_p, _p, _i, _l, _d, _p, _p], C.c_int),
     "pl_canny_hysteresis": ([_p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p], C.c_int),
     "pl_xim_work_bytes": ([_i, _i], C.c_int64),
     "pl_xim_decode": ([_p, _l, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),

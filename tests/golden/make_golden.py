@@ -837,6 +837,10 @@ def main():
         bg[f"{name}.gamma"] = ia.gamma(ib, **kw)
     np.savez_compressed(os.path.join(HERE, "bakai.npz"), **bg)
 
+    # ---- 19. planar phantom outline + hough_line_peaks: scikit-image 0.18.3's own canny / label / regionprops /
+    #          hough_line / hough_line_peaks on synthetic phantom frames (next row f2: planar_imaging.py:300-341, 3136-3179)
+    subprocess.run([PY39, os.path.join(HERE, "skimage_planar_py39.py"), os.path.join(HERE, "planar.npz")], check=True)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

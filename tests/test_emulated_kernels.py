@@ -156,3 +156,28 @@ def test_emu_label_matches_scipy(emu):
             want, nl = ndimage.label(mask[f], structure=structure)
             assert count[f] == nl
             np.testing.assert_array_equal(labels[f], want)
+
+
+# ---- host layer + kernels together on the emulated device (tests/emu_backend.py) ---------------------------------
+# Same check functions as the `-m gpu` tests (tests/next_row_checks.py); sized for the fiber emulator.
+
+@pytest.fixture()
+def emulated():
+    from emu_backend import emulated_device
+
+    with emulated_device():
+        import torch
+
+        yield torch.device("cuda:0")
+
+
+def test_emulated_hough_line_peaks(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_hough_line_peaks(golden, emulated)
+
+
+def test_emulated_phantom_outline(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_phantom_outline(golden, emulated, names=["sq0"])

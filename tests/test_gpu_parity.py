@@ -1411,6 +1411,44 @@ def test_hough_line_vs_skimage_golden(golden, dev):
         pc.hough_line(np.zeros(5), device=dev)
 
 
+def test_hough_line_peaks_vs_skimage_golden(golden, dev):
+    """f2 (second half): planar.hough_line_peaks (pl_max_filter1d x2, pl_peak_candidates, pl_label + the host's greedy
+    walk) against scikit-image 0.18.3's transform.hough_line_peaks: identical heights, angles and distances."""
+    import next_row_checks as checks
+
+    checks.check_hough_line_peaks(golden, dev)
+
+
+def test_phantom_outline_vs_skimage_golden(golden, dev):
+    """f2 (second half): canny -> label -> bbox table -> phantom_ski_region -> region.image -> hough_line on three
+    synthetic phantom frames against scikit-image's own canny / label / regionprops / hough_line."""
+    import next_row_checks as checks
+
+    checks.check_phantom_outline(golden, dev)
+    from pylinac_amd import planar
+
+    g = golden("planar")
+    with pytest.raises(ValueError, match="Unable to find the phantom"):
+        planar.find_phantom_region(torch.from_numpy(g["sq0.img"]).to(dev), 10.0, sigma=4)
+
+
+def test_max_filter1d_vs_scipy(dev):
+    """pl_max_filter1d == ndimage.maximum_filter1d(mode='constant', cval=0) on int64 / float64 / uint16 frames with
+    negative values (the zero padding wins at the borders), windows wider than the frame, both axes."""
+    from scipy import ndimage as ndi
+
+    from pylinac_amd import planar
+
+    rng = np.random.default_rng(77)
+    for arr in (rng.integers(-50, 50, (2, 37, 29)).astype(np.int64), rng.normal(size=(1, 40, 33)),
+                rng.integers(0, 65535, (1, 21, 64)).astype(np.uint16)):
+        for axis in (0, 1):
+            for half in (0, 1, 5, 70):
+                got = planar.max_filter1d(T(arr, dev), half, axis).cpu().numpy()
+                want = np.stack([ndi.maximum_filter1d(f, size=2 * half + 1, axis=axis, mode="constant", cval=0) for f in arr])
+                assert got.dtype == want.dtype and np.array_equal(got, want), (arr.dtype, axis, half)
+
+
 def test_image_gamma_bakai_vs_reference_golden(golden, dev):
     """ArrayImage.gamma (pl_bakai_mask, float32 pl_sobel, pl_bakai_gamma, exact float64 percentiles for the inversion
     check) against the reference's own ArrayImage.gamma: identical float64 maps incl. the NaN pattern, for uint16 and

@@ -575,6 +575,48 @@ def test_hough_line_restatement_matches_skimage(golden):
         assert np.array_equal(acc, g[f"h{k}"]) and np.array_equal(a, g[f"a{k}"]) and np.array_equal(d, g[f"d{k}"]), k
 
 
+def test_hough_line_peaks_and_phantom_outline_restatements_match_skimage(golden):
+    """f2 (second half): oracle.hough_line_peaks / prominent_peaks against scikit-image 0.18.3's own
+    transform.hough_line_peaks (random accumulators with plateaus, ties, wrapping columns, explicit thresholds and
+    num_peaks; and the accumulators of three synthetic phantom outlines); oracle.region_bboxes against
+    measure.label + regionprops bboxes of scikit-image's canny maps; select_phantom_region picks the region the
+    golden marks."""
+    g = golden("planar")
+    for k in range(4):
+        hs, an, di = g[f"acc{k}.hspace"], g[f"acc{k}.angles"], g[f"acc{k}.dists"]
+        for j in range(4):
+            md, ma, thr, npk = g[f"acc{k}.kw{j}"]
+            kw = dict(min_distance=int(md), min_angle=int(ma))
+            if thr >= 0:
+                kw["threshold"] = float(thr)
+            if npk >= 0:
+                kw["num_peaks"] = int(npk)
+            h, a, d = o.hough_line_peaks(hs, an, di, **kw)
+            assert np.array_equal(h, g[f"acc{k}.p{j}.h"]), (k, j)
+            if (k, j) != (2, 2):     # the cut falls inside a run of equal heights: np.argsort's unstable tie order
+                assert np.array_equal(a, g[f"acc{k}.p{j}.a"]) and np.array_equal(d, g[f"acc{k}.p{j}.d"]), (k, j)
+    for n in g["names"]:
+        for md in (17, 9):
+            for npk, tag in ((2, "2"), (np.inf, "inf")):
+                h, a, d = o.hough_line_peaks(g[f"{n}.hspace"], g[f"{n}.theta"], g[f"{n}.dists"], min_distance=md,
+                                             num_peaks=npk)
+                t = f"{n}.peaks.md{md}.n{tag}"
+                assert np.array_equal(h, g[t + ".h"]) and np.array_equal(a, g[t + ".a"]) and np.array_equal(d, g[t + ".d"]), t
+        sigma, lo, hi = g[f"{n}.kw"]
+        edges = o.canny(g[f"{n}.img"], sigma=sigma, low_threshold=lo, high_threshold=hi, use_quantiles=True)
+        assert np.array_equal(edges, g[f"{n}.edges"]), n
+        lab, bb = o.region_bboxes(edges)
+        assert np.array_equal(bb, g[f"{n}.bbox"]), n
+        big = int(g[f"{n}.big"])
+        assert o.select_phantom_region(bb, g[f"{n}.img"].shape, float(g[f"{n}.bbox_area"][big])) == big
+        r0, c0, r1, c1 = bb[big]
+        assert np.array_equal(lab[r0:r1, c0:c1] == big + 1, g[f"{n}.region_image"]), n
+        acc, _, dd = o.hough_line(g[f"{n}.region_image"], g[f"{n}.theta"])
+        assert np.array_equal(acc, g[f"{n}.hspace"]) and np.array_equal(dd, g[f"{n}.dists"]), n
+    with pytest.raises(ValueError):
+        o.select_phantom_region(g["sq0.bbox"], g["sq0.img"].shape, 10.0)
+
+
 def _bakai_cases(g):
     import json
 
