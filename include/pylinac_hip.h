@@ -281,6 +281,14 @@ int pl_roi_stats(const void* d_frames, int dtype, int64_t n, int h, int w, const
                  int rois_per_frame, int64_t roi_frame_stride, int kind, double* d_out, int32_t* d_status,
                  void* stream);
 
+/* RectangleROI.pixels_flat statistics (pylinac/core/roi.py:644-704) for rotated rectangles, as general polygons:
+ * d_vertices float64 [..][rois_per_frame][n_vertices][2] = (row, col) (roi_frame_stride doubles between frames, 0 =
+ * the same polygons for every frame); membership = skimage.draw.polygon(r, c, shape=(h, w)) of scikit-image 0.18.3
+ * (edge and vertex points included).  Output and status as pl_roi_stats (status 3: the polygon misses the frame). */
+int pl_polygon_roi_stats(const void* d_frames, int dtype, int64_t n, int h, int w, const double* d_vertices,
+                         int n_vertices, int rois_per_frame, int64_t roi_frame_stride, double* d_out,
+                         int32_t* d_status, void* stream);
+
 /* ---- a15: BaseImage.gamma, the Bakai gamma map (pylinac/core/image.py:994-1016) ---------------------------------
  * pl_bakai_mask: ref[ref < d_frame_cut[frame]] = NaN (float64) and its float32 copy (the Sobel input: pl_sobel on
  * axis 1 / 0 gives d_grad_x / d_grad_y).  pl_bakai_gamma: |comp - ref| / sqrt(dose_term + dist_term * hypot(gx, gy)^2)

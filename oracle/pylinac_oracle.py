@@ -1592,3 +1592,76 @@ def select_phantom_region(bboxes: np.ndarray, image_shape, phantom_bbox_size_px:
     else:
         raise ValueError(roi_match_condition)
     return passing[best]
+
+
+# --------------------------------------------------------------------------------------
+# "next" row f3, second half: RectangleROI (pylinac/core/roi.py:481-704, pylinac/core/geometry.py:692-724)
+# --------------------------------------------------------------------------------------
+
+def point_in_polygon(xp, yp, x: float, y: float) -> int:
+    """skimage._shared.geometry.point_in_polygon (0.18.3; compiled, behaviour pinned by tests/golden/rect.npz): the
+    crossing test of Hao et al. 2018 with left and right rays -- 0 outside, 1 inside, 2 on a vertex (|dx|, |dy| <
+    1e-12), 3 on an edge (the two rays disagree in parity)."""
+    eps = 1e-12
+    r_cross = l_cross = 0
+    x1, y1 = xp[-1] - x, yp[-1] - y
+    for i in range(len(xp)):
+        x0, y0 = x1, y1
+        x1, y1 = xp[i] - x, yp[i] - y
+        if -eps < x0 < eps and -eps < y0 < eps:
+            return 2
+        if (y0 > 0) != (y1 > 0) and (x1 * y0 - x0 * y1) / (y0 - y1) > 0:
+            r_cross += 1
+        if (y0 < 0) != (y1 < 0) and (x1 * y0 - x0 * y1) / (y0 - y1) < 0:
+            l_cross += 1
+    if (r_cross & 1) != (l_cross & 1):
+        return 3
+    return r_cross & 1
+
+
+def polygon_pixels(r, c, shape=None):
+    """skimage.draw.polygon (scikit-image 0.18.3: _draw._polygon; third-party, compiled, absent from /root/reference --
+    behaviour pinned by tests/golden/rect.npz): the bounding box int(max(0, min)) .. int(ceil(max)) clipped to `shape`,
+    every integer point kept unless point_in_polygon says "outside" (so vertices and edge points belong to the
+    polygon); pixels in raster order."""
+    r = np.atleast_1d(np.asarray(r, dtype=np.float64))
+    c = np.atleast_1d(np.asarray(c, dtype=np.float64))
+    minr, maxr = int(max(0, r.min())), int(math.ceil(r.max()))
+    minc, maxc = int(max(0, c.min())), int(math.ceil(c.max()))
+    if shape is not None:
+        maxr, maxc = min(shape[0] - 1, maxr), min(shape[1] - 1, maxc)
+    rr, cc = [], []
+    for y in range(minr, maxr + 1):
+        for x in range(minc, maxc + 1):
+            if point_in_polygon(c, r, float(x), float(y)):
+                rr.append(y)
+                cc.append(x)
+    return np.array(rr, dtype=np.int64), np.array(cc, dtype=np.int64)
+
+
+def rectangle_vertices(width: float, height: float, cx: float, cy: float, rotation: float = 0.0) -> np.ndarray:
+    """Rectangle.vertices (pylinac/core/geometry.py:692-704) -> [4, 2] (x, y): tl, tr, br, bl of the unrotated
+    rectangle, rotated by `rotation` degrees about the origin, then translated to the centre (the homogeneous matrix
+    product of skimage's EuclideanTransform written out: x' = cos*x - sin*y + tx, y' = sin*x + cos*y + ty)."""
+    square = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]])
+    scaled = square @ np.diag((width, height)) / 2
+    a = np.deg2rad(rotation)
+    m = np.array([[math.cos(a), -math.sin(a), cx], [math.sin(a), math.cos(a), cy], [0, 0, 1]])
+    src = np.vstack((scaled[:, 0], scaled[:, 1], np.ones(4)))
+    dst = src.T @ m.T
+    return dst[:, :2] / dst[:, 2:3]
+
+
+def rectangle_roi_pixels(arr: np.ndarray, width, height, cx, cy, rotation=0.0) -> np.ndarray:
+    """RectangleROI.pixels_flat (pylinac/core/roi.py:644-662): the polygon through (bl.x, bl.y - 1), (br.x - 1,
+    br.y - 1), (tr.x - 1, tr.y), (tl.x, tl.y), clipped to the array."""
+    tl, tr, br, bl = rectangle_vertices(width, height, cx, cy, rotation)
+    corners = np.array([(bl[0], bl[1] - 1), (br[0] - 1, br[1] - 1), (tr[0] - 1, tr[1]), (tl[0], tl[1])])
+    rr, cc = polygon_pixels(corners[:, 1], corners[:, 0], arr.shape)
+    return arr[rr, cc]
+
+
+def rectangle_roi_stats(arr: np.ndarray, width, height, cx, cy, rotation=0.0) -> np.ndarray:
+    """-> count, mean, std, min, max, median of pixels_flat (roi.py:683-704; pixel_value is the MEAN for rectangles)."""
+    v = rectangle_roi_pixels(arr, width, height, cx, cy, rotation)
+    return np.array([v.size, np.mean(v), np.std(v), np.min(v), np.max(v), np.median(v)], dtype=float)

@@ -9,6 +9,10 @@
 //                 (r_org, c_org) = center - upper_left, float64 in skimage's operation order (draw.py ellipse /
 //                 _ellipse_in_shape, rotation 0); pixels in raster order like np.nonzero
 //   rectangle     array[r0:r1, c0:c1] (the caller applies the reference's rounding)
+//   polygon       skimage.draw.polygon(r, c, shape) as RectangleROI.pixels_flat calls it for (rotated) rectangles
+//                 (pylinac/core/roi.py:644-662): bounding box int(max(0, min)) .. min(size - 1, int(ceil(max))), every
+//                 integer point kept unless scikit-image 0.18.3's point_in_polygon (the two-ray crossing test of Hao
+//                 et al. 2018, 1e-12 vertex tolerance) says "outside": vertices and edge points belong to the ROI
 //   statistics    np.mean / np.std (population, two-pass) / np.min / np.max / np.median (exact order statistics,
 //                 mean of the two middle values for an even count)
 //
@@ -30,10 +34,27 @@ __device__ __forceinline__ double value_of(unsigned long long k) {
   return __longlong_as_double((long long)b);
 }
 
+// v: nv (row, col) pairs.  float64, no contraction: the quotient decides membership on edges.
+__device__ __forceinline__ bool in_polygon(const double* __restrict__ v, int nv, double x, double y) {
+  const double eps = 1e-12;
+  int r_cross = 0, l_cross = 0;
+  double x1 = v[2 * (nv - 1) + 1] - x, y1 = v[2 * (nv - 1)] - y;
+  for (int i = 0; i < nv; ++i) {
+    const double x0 = x1, y0 = y1;
+    x1 = v[2 * i + 1] - x;
+    y1 = v[2 * i] - y;
+    if (-eps < x0 && x0 < eps && -eps < y0 && y0 < eps) return true;            // on a vertex
+    if ((y0 > 0) != (y1 > 0) && (x1 * y0 - x0 * y1) / (y0 - y1) > 0) ++r_cross;
+    if ((y0 < 0) != (y1 < 0) && (x1 * y0 - x0 * y1) / (y0 - y1) < 0) ++l_cross;
+  }
+  return ((r_cross & 1) != (l_cross & 1)) || (r_cross & 1);                     // on an edge, or inside
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 roi_stats_kernel(const T* __restrict__ frames, int h, int w, const double* __restrict__ rois, int rois_per_frame,
-                 int64_t roi_frame_stride, int kind, double* __restrict__ out, int32_t* __restrict__ status) {
+                 int64_t roi_frame_stride, int kind, int roi_doubles, double* __restrict__ out,
+                 int32_t* __restrict__ status) {
   extern __shared__ double vals[];   // kMaxPix
   __shared__ int s_n;
   __shared__ double s_red[4][kThreads / PL_WAVE];
@@ -41,7 +62,8 @@ roi_stats_kernel(const T* __restrict__ frames, int h, int w, const double* __res
   const int64_t item = blockIdx.x;
   const int64_t frame = item / rois_per_frame;
   const int k = (int)(item % rois_per_frame);
-  const double* roi = rois + frame * roi_frame_stride + (int64_t)k * 4;
+  const double* roi = rois + frame * roi_frame_stride + (int64_t)k * roi_doubles;
+  const int nv = roi_doubles / 2;   // kind 2
   const T* f = frames + frame * (int64_t)h * w;
   double* o = out + item * 6;
 
@@ -56,11 +78,31 @@ roi_stats_kernel(const T* __restrict__ frames, int h, int w, const double* __res
     nc = (int)floor(cx + rad) - c_lo + 1;
     r_org = cy - (double)r_lo;
     c_org = cx - (double)c_lo;
-  } else {                    // rectangle: roi = (r0, r1, c0, c1), half-open
+  } else if (kind == 1) {     // rectangle: roi = (r0, r1, c0, c1), half-open
     r_lo = (int)roi[0];
     c_lo = (int)roi[2];
     nr = (int)roi[1] - r_lo;
     nc = (int)roi[3] - c_lo;
+  } else {                    // polygon: roi = nv x (row, col); the box is clipped to the frame like polygon(shape=...)
+    double rmin = roi[0], rmax = roi[0], cmin = roi[1], cmax = roi[1];
+    for (int i = 1; i < nv; ++i) {
+      rmin = roi[2 * i] < rmin ? roi[2 * i] : rmin;
+      rmax = roi[2 * i] > rmax ? roi[2 * i] : rmax;
+      cmin = roi[2 * i + 1] < cmin ? roi[2 * i + 1] : cmin;
+      cmax = roi[2 * i + 1] > cmax ? roi[2 * i + 1] : cmax;
+    }
+    // int(max(0, min)) .. min(size - 1, int(ceil(max))); the clamps keep the casts in range for far-away vertices
+    r_lo = (int)(rmin > 0 ? (rmin < (double)h ? rmin : (double)h) : 0.0);
+    c_lo = (int)(cmin > 0 ? (cmin < (double)w ? cmin : (double)w) : 0.0);
+    const double r_top = ceil(rmax), c_top = ceil(cmax);
+    const int r_hi = r_top < (double)(h - 1) ? (r_top < -1.0 ? -1 : (int)r_top) : h - 1;
+    const int c_hi = c_top < (double)(w - 1) ? (c_top < -1.0 ? -1 : (int)c_top) : w - 1;
+    nr = r_hi - r_lo + 1;
+    nc = c_hi - c_lo + 1;
+    if (nr <= 0 || nc <= 0) {   // the polygon misses the frame: np.mean of nothing
+      if (threadIdx.x == 0) { status[item] = 3; for (int q = 0; q < 6; ++q) o[q] = __longlong_as_double(0x7ff8000000000000LL); }
+      return;
+    }
   }
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
@@ -80,8 +122,10 @@ roi_stats_kernel(const T* __restrict__ frames, int h, int w, const double* __res
       if (kind == 0) {
         const double a = ((double)ri - r_org) / rad, b = ((double)ci - c_org) / rad;
         in = (a * a + b * b) < 1.0;
-      } else {
+      } else if (kind == 1) {
         in = true;
+      } else {
+        in = in_polygon(roi, nv, (double)(c_lo + ci), (double)(r_lo + ri));
       }
       if (in) v = (double)f[(int64_t)(r_lo + ri) * w + (c_lo + ci)];
     }
@@ -184,7 +228,34 @@ extern "C" int pl_roi_stats(const void* frames, int dtype, int64_t n, int h, int
       attr = true;
     }
     hipLaunchKernelGGL(roi_stats_kernel<T>, dim3((unsigned)items), dim3(kThreads), lds, st, (const T*)frames, h, w,
-                       d_rois, rois_per_frame, roi_frame_stride, kind, d_out, d_status);
+                       d_rois, rois_per_frame, roi_frame_stride, kind, 4, d_out, d_status);
   });
   return pl_check_launch("pl_roi_stats");
+}
+
+extern "C" int pl_polygon_roi_stats(const void* frames, int dtype, int64_t n, int h, int w, const double* d_vertices,
+                                    int n_vertices, int rois_per_frame, int64_t roi_frame_stride, double* d_out,
+                                    int32_t* d_status, void* stream) {
+  PL_REQUIRE(frames && d_vertices && d_out && d_status, "null pointer");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0 && rois_per_frame > 0, "bad shape");
+  PL_REQUIRE(n_vertices >= 3 && n_vertices <= 64, "a polygon has 3..64 vertices");
+  const int roi_doubles = 2 * n_vertices;
+  PL_REQUIRE(roi_frame_stride == 0 || roi_frame_stride >= roi_doubles * (int64_t)rois_per_frame, "bad ROI stride");
+  if (n == 0) return PL_OK;
+  const int64_t items = n * rois_per_frame;
+  PL_REQUIRE(items <= 0x7fffffffLL, "batch too large");
+  const size_t lds = (size_t)kMaxPix * sizeof(double);
+  hipStream_t st = (hipStream_t)stream;
+  PL_DISPATCH_DTYPE(dtype, T, {
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)roi_stats_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) { pl_set_error("pl_polygon_roi_stats: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+      attr = true;
+    }
+    hipLaunchKernelGGL(roi_stats_kernel<T>, dim3((unsigned)items), dim3(kThreads), lds, st, (const T*)frames, h, w,
+                       d_vertices, rois_per_frame, roi_frame_stride, 2, roi_doubles, d_out, d_status);
+  });
+  return pl_check_launch("pl_polygon_roi_stats");
 }

@@ -103,3 +103,133 @@ class DiskROI:
     @property
     def max(self) -> float:
         return float(self._s()[4])
+
+
+# ------------------------------------------------------------------------------------------- rectangles
+def rectangle_vertices(width: float, height: float, center_xy, rotation: float = 0.0) -> np.ndarray:
+    """``Rectangle.vertices`` (pylinac/core/geometry.py:692-704) -> float64 [4, 2] (x, y) in tl, tr, br, bl order:
+    the half-size square scaled, rotated by ``rotation`` degrees and translated -- the homogeneous matrix product that
+    scikit-image's ``EuclideanTransform`` + ``matrix_transform`` evaluate."""
+    square = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]])
+    scaled = square @ np.diag((width, height)) / 2
+    a = np.deg2rad(rotation)
+    m = np.array([[np.cos(a), -np.sin(a), center_xy[0]], [np.sin(a), np.cos(a), center_xy[1]], [0, 0, 1]])
+    src = np.vstack((scaled[:, 0], scaled[:, 1], np.ones(4)))
+    dst = src.T @ m.T
+    return dst[:, :2] / dst[:, 2:3]
+
+
+def _pixels_flat_polygon(vertices_xy: np.ndarray) -> np.ndarray:
+    """The (row, col) polygon ``RectangleROI.pixels_flat`` rasterises (roi.py:650-661): bl, br, tr, tl with the
+    reference's -1 adjustments."""
+    tl, tr, br, bl = vertices_xy
+    return np.array([(bl[1] - 1, bl[0]), (br[1] - 1, br[0] - 1), (tr[1], tr[0] - 1), (tl[1], tl[0])], dtype=np.float64)
+
+
+def polygon_roi_stats_batch(frames: torch.Tensor, polygons_rc) -> tuple[torch.Tensor, torch.Tensor]:
+    """Statistics over ``skimage.draw.polygon(r, c, shape=frame.shape)`` pixels -> (float64 [N, K, 6] in STAT_FIELDS
+    order, int32 status [N, K]).  ``polygons_rc``: [K, V, 2] (shared) or [N, K, V, 2] (row, col) vertices."""
+    f = ops._frames(frames)
+    n, h, w = f.shape
+    p = polygons_rc if isinstance(polygons_rc, torch.Tensor) else torch.as_tensor(np.asarray(polygons_rc, dtype=np.float64))
+    p = p.to(device=f.device, dtype=torch.float64).contiguous()
+    if p.ndim == 3:
+        k, nv, stride = p.shape[0], p.shape[1], 0
+    elif p.ndim == 4 and p.shape[0] == n:
+        k, nv, stride = p.shape[1], p.shape[2], p.shape[1] * p.shape[2] * 2
+    else:
+        raise ValueError("polygons must be [K, V, 2] (shared) or [N, K, V, 2]")
+    if p.shape[-1] != 2:
+        raise ValueError("each vertex is (row, col)")
+    out = torch.empty((n, k, 6), dtype=torch.float64, device=f.device)
+    status = torch.empty((n, k), dtype=torch.int32, device=f.device)
+    check(_lib.load().pl_polygon_roi_stats(f.data_ptr(), ops._dt(f), n, h, w, p.data_ptr(), nv, k, stride,
+                                           out.data_ptr(), status.data_ptr(),
+                                           torch.cuda.current_stream(f.device).cuda_stream), "pl_polygon_roi_stats")
+    return out, status
+
+
+def rectangle_roi_stats_batch(frames: torch.Tensor, rects) -> tuple[torch.Tensor, torch.Tensor]:
+    """``RectangleROI`` statistics for ``rects`` = [K, 5] rows of (width, height, center x, center y, rotation degrees),
+    the same on every frame -> like ``polygon_roi_stats_batch``."""
+    r = np.asarray(rects, dtype=np.float64).reshape(-1, 5)
+    polys = np.stack([_pixels_flat_polygon(rectangle_vertices(w, h, (cx, cy), rot)) for w, h, cx, cy, rot in r])
+    return polygon_roi_stats_batch(frames, polys)
+
+
+class RectangleROI:
+    """pylinac/core/roi.py:481-704 (``Rectangle`` geometry of pylinac/core/geometry.py:634-724 reduced to what the
+    statistics need)."""
+
+    def __init__(self, array, width: float, height: float, center, rotation: float = 0.0):
+        if width < 2:
+            raise ValueError(f"The width must be >= 2. Given {width}")
+        if height < 2:
+            raise ValueError(f"The height must be >= 2. Given {height}")
+        self.width, self.height, self.rotation = width, height, rotation
+        self.center = center
+        self._xy = (float(center.x), float(center.y)) if hasattr(center, "x") else (float(center[0]), float(center[1]))
+        t = array if isinstance(array, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(array))
+        if not t.is_cuda:
+            t = t.to(torch.device("cuda", torch.cuda.current_device()))
+        self._array = t
+        self._cache = None
+
+    @classmethod
+    def from_phantom_center(cls, array, width: float, height: float, angle: float, dist_from_center: float,
+                            phantom_center, rotation: float = 0.0):
+        """roi.py:484-533"""
+        px, py = (phantom_center.x, phantom_center.y) if hasattr(phantom_center, "x") else phantom_center[:2]
+        y_shift = np.sin(np.deg2rad(angle)) * dist_from_center
+        x_shift = np.cos(np.deg2rad(angle)) * dist_from_center
+        return cls(array=array, width=width, height=height, center=(px + x_shift, py + y_shift), rotation=rotation)
+
+    @property
+    def area(self) -> float:
+        return self.width * self.height
+
+    @property
+    def vertices(self) -> np.ndarray:
+        """[4, 2] (x, y): tl, tr, br, bl"""
+        return rectangle_vertices(self.width, self.height, self._xy, self.rotation)
+
+    tl_corner = property(lambda self: self.vertices[0])
+    tr_corner = property(lambda self: self.vertices[1])
+    br_corner = property(lambda self: self.vertices[2])
+    bl_corner = property(lambda self: self.vertices[3])
+
+    def _s(self) -> np.ndarray:
+        if self._cache is None:
+            out, status = polygon_roi_stats_batch(self._array[None], _pixels_flat_polygon(self.vertices)[None])
+            st = int(status[0, 0])
+            if st == 2:
+                raise ValueError("rectangle ROI is larger than 16384 pixels")
+            self._cache = out[0, 0].cpu().numpy()        # status 3 (no pixels): NaNs, like np.mean of an empty array
+        return self._cache
+
+    @property
+    def pixel_array(self) -> torch.Tensor:
+        """roi.py:664-681: the unrotated window ``array[round(tl.y):round(bl.y), round(bl.x):round(br.x)]``."""
+        if self.rotation != 0:
+            raise ValueError("The pixel array cannot be reshaped into a 2D array when the rotation is not 0.")
+        v = self.vertices
+        return self._array[int(np.round(v[0][1])):int(np.round(v[3][1])), int(np.round(v[3][0])):int(np.round(v[2][0]))]
+
+    @property
+    def pixel_value(self) -> float:
+        """The MEAN of the ROI pixels (roi.py:683-686)."""
+        return float(self._s()[1])
+
+    mean = pixel_value
+
+    @property
+    def std(self) -> float:
+        return float(self._s()[2])
+
+    @property
+    def min(self) -> float:
+        return float(self._s()[3])
+
+    @property
+    def max(self) -> float:
+        return float(self._s()[4])

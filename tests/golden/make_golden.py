@@ -841,6 +841,11 @@ def main():
     #          hough_line / hough_line_peaks on synthetic phantom frames (next row f2: planar_imaging.py:300-341, 3136-3179)
     subprocess.run([PY39, os.path.join(HERE, "skimage_planar_py39.py"), os.path.join(HERE, "planar.npz")], check=True)
 
+    # ---- 20. RectangleROI: the reference's own class (rotated and unrotated) + raw skimage.draw.polygon pixel lists
+    #          (next row f3, second half); reads the slices of roi.npz
+    subprocess.run([PY39, os.path.join(HERE, "skimage_rect_py39.py"), os.path.join(HERE, "roi.npz"),
+                    os.path.join(HERE, "rect.npz"), ROOT], check=True)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -62,3 +62,55 @@ def check_phantom_outline(golden, dev, names=None):
         hs, _, di = canny.hough_line(region.image, theta=g[f"{n}.theta"])
         assert np.array_equal(hs.cpu().numpy().astype(np.uint64), g[f"{n}.hspace"]), n
         assert np.array_equal(di, g[f"{n}.dists"]), n
+
+
+def check_rectangle_roi(golden, dev):
+    """RectangleROI / polygon statistics against the reference's own RectangleROI and raw skimage.draw.polygon pixel
+    lists (tests/golden/rect.npz): counts, min, max, median exact; mean / std to 1e-12 (summation order)."""
+    from pylinac_amd import roi
+
+    g, d = golden("rect"), golden("roi")
+    for name, arr in (("i16", d["slice_i16"]), ("f32", d["slice_f32"])):
+        frames = torch.from_numpy(arr).to(dev)[None]
+        out, status = roi.rectangle_roi_stats_batch(frames, g["rects"])
+        out, status = out.cpu().numpy()[0], status.cpu().numpy()[0]
+        assert (status == 0).all()
+        want = g["stats_" + name]
+        assert np.array_equal(out[:, [0, 3, 4, 5]], want[:, [0, 3, 4, 5]]), name
+        np.testing.assert_allclose(out[:, 1:3], want[:, 1:3], rtol=1e-12, atol=1e-12)
+    # the class, with the reference's attribute names
+    k = 2
+    w, h, cx, cy, rot = g["rects"][k]
+    m = roi.RectangleROI(d["slice_i16"], width=w, height=h, center=(cx, cy), rotation=rot)
+    assert np.allclose(m.vertices, g["vertices"][k], rtol=0, atol=1e-12)
+    want = g["stats_i16"][k]
+    assert m.min == want[3] and m.max == want[4] and abs(m.mean - want[1]) < 1e-10 and abs(m.std - want[2]) < 1e-10
+    assert m.pixel_value == m.mean and m.area == w * h
+    with np.testing.assert_raises(ValueError):
+        m.pixel_array
+    pa = [r for r in g["rects"] if r[4] == 0]
+    for (w, h, cx, cy, rot), (nr, nc, mean, std) in zip(pa, g["pixel_array"]):
+        a = roi.RectangleROI(d["slice_i16"], width=w, height=h, center=(cx, cy)).pixel_array.cpu().numpy()
+        assert a.shape == (int(nr), int(nc)) and abs(a.mean() - mean) < 1e-10 and abs(a.std() - std) < 1e-10
+    fc = roi.RectangleROI.from_phantom_center(d["slice_i16"], width=14.5, height=9.25, angle=-60.0, dist_from_center=80.5,
+                                              phantom_center=(250.3, 260.7), rotation=22.5)
+    wfc = g["from_center"]
+    assert abs(fc._xy[0] - wfc[0]) < 1e-12 and abs(fc._xy[1] - wfc[1]) < 1e-12
+    assert fc._s()[0] == wfc[2] and fc.min == wfc[5] and fc.max == wfc[6] and abs(fc.mean - wfc[3]) < 1e-10
+    with np.testing.assert_raises(ValueError):
+        roi.RectangleROI(d["slice_i16"], width=1.5, height=5, center=(10, 10))
+    # raw polygons: the pixel COUNT and the sum of an index image identify the pixel set
+    shape = tuple(int(v) for v in g["poly_shape"])
+    idx = np.arange(shape[0] * shape[1], dtype=np.float64).reshape(shape)
+    off = g["poly_offsets"]
+    for k in range(len(g["poly_nverts"])):
+        nv = int(g["poly_nverts"][k])
+        out, status = roi.polygon_roi_stats_batch(torch.from_numpy(idx).to(dev)[None], g["poly_vertices"][k][None, :nv])
+        rr, cc = g["poly_rr"][off[k]:off[k + 1]], g["poly_cc"][off[k]:off[k + 1]]
+        if len(rr) == 0:
+            assert int(status[0, 0]) == 3, k
+            continue
+        o6 = out.cpu().numpy()[0, 0]
+        vals = idx[rr, cc]
+        assert int(status[0, 0]) == 0 and o6[0] == len(rr) and o6[3] == vals.min() and o6[4] == vals.max() \
+            and o6[5] == np.median(vals) and abs(o6[1] - vals.mean()) < 1e-9, k

@@ -181,3 +181,9 @@ def test_emulated_phantom_outline(golden, emulated):
     import next_row_checks as checks
 
     checks.check_phantom_outline(golden, emulated, names=["sq0"])
+
+
+def test_emulated_rectangle_roi(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_rectangle_roi(golden, emulated)

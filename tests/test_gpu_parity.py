@@ -1449,6 +1449,14 @@ def test_max_filter1d_vs_scipy(dev):
                 assert got.dtype == want.dtype and np.array_equal(got, want), (arr.dtype, axis, half)
 
 
+def test_rectangle_roi_vs_reference_golden(golden, dev):
+    """f3 (second half): pl_polygon_roi_stats / RectangleROI against the reference's own RectangleROI (rotated,
+    unrotated, clipped) and scikit-image 0.18.3's draw.polygon pixel sets."""
+    import next_row_checks as checks
+
+    checks.check_rectangle_roi(golden, dev)
+
+
 def test_image_gamma_bakai_vs_reference_golden(golden, dev):
     """ArrayImage.gamma (pl_bakai_mask, float32 pl_sobel, pl_bakai_gamma, exact float64 percentiles for the inversion
     check) against the reference's own ArrayImage.gamma: identical float64 maps incl. the NaN pattern, for uint16 and

@@ -617,6 +617,28 @@ def test_hough_line_peaks_and_phantom_outline_restatements_match_skimage(golden)
         o.select_phantom_region(g["sq0.bbox"], g["sq0.img"].shape, 10.0)
 
 
+def test_rectangle_roi_and_polygon_restatements_match_reference(golden):
+    """f3 (second half): oracle.polygon_pixels against scikit-image 0.18.3's draw.polygon on 40 polygons (integer /
+    half-integer / float vertices, concave, leaving the image): identical pixel lists, edge and vertex points included;
+    oracle.rectangle_vertices / rectangle_roi_stats against the reference's own RectangleROI on 10 rectangles
+    (rotations 0, 30, -47.5, 45, 90, ..., clipped by the image border, the 2 x 2 minimum) x 2 dtypes: vertices to
+    2e-15, statistics identical."""
+    g, d = golden("rect"), golden("roi")
+    off = g["poly_offsets"]
+    shape = tuple(int(v) for v in g["poly_shape"])
+    for k in range(len(g["poly_nverts"])):
+        nv = int(g["poly_nverts"][k])
+        p = g["poly_vertices"][k][:nv]
+        rr, cc = o.polygon_pixels(p[:, 0], p[:, 1], shape)
+        assert np.array_equal(rr, g["poly_rr"][off[k]:off[k + 1]]) and np.array_equal(cc, g["poly_cc"][off[k]:off[k + 1]]), k
+    for name, arr in (("i16", d["slice_i16"]), ("f32", d["slice_f32"].astype(np.float64))):
+        for k, (w, h, cx, cy, rot) in enumerate(g["rects"]):
+            assert np.abs(o.rectangle_vertices(w, h, cx, cy, rot) - g["vertices"][k]).max() < 4e-15
+            got = o.rectangle_roi_stats(arr, w, h, cx, cy, rot)
+            want = g["stats_" + name][k]
+            assert np.array_equal(got, want[:6]) and want[6] == got[1], (name, k)     # pixel_value == mean
+
+
 def _bakai_cases(g):
     import json
 
