@@ -1233,6 +1233,40 @@ def find_fields_restated(sample: np.ndarray, dpmm: float, field_width_mm: float,
 # --------------------------------------------------------------------------------------
 # a11: SingleProfile (FWHM edge method) -- scipy interp1d / find_peaks / linregress / minimize as the reference
 # --------------------------------------------------------------------------------------
+def hill_func(x, a, b, c, d):
+    """pylinac/core/hill.py:67-78"""
+    return a + (b - a) / (1.0 + (c / x) ** d)
+
+
+def hill_fit(x_data, y_data) -> np.ndarray:
+    """Hill.fit (pylinac/core/hill.py:19-31)."""
+    from scipy.optimize import curve_fit
+
+    params, _ = curve_fit(hill_func, x_data, y_data, p0=(min(y_data), max(y_data), np.median(x_data), 0))
+    return params
+
+
+def hill_inflection(p) -> float:
+    """Hill.inflection_idx (hill.py:33-38)"""
+    return p[2] * math.pow((p[3] - 1) / (p[3] + 1), 1 / p[3])
+
+
+def hill_y(p, x) -> float:
+    """Hill.y (hill.py:61-65)"""
+    return p[0] + (p[1] - p[0]) / (1 + (p[2] / x) ** p[3])
+
+
+def hill_x(p, y) -> float:
+    """Hill.x (hill.py:55-59)"""
+    return p[2] * math.pow((y - p[0]) / (p[1] - y), 1 / p[3])
+
+
+def hill_gradient(p, x) -> float:
+    """Hill.gradient_at (hill.py:47-53)"""
+    cxd = math.pow(p[2] / x, p[3])
+    return (p[1] - p[0]) * p[3] * cxd / (math.pow(cxd + 1, 2) * x)
+
+
 class SingleProfileRestated:
     """pylinac/core/profile.py:1118-1633 restated for Edge.FWHM: __init__ :1125-1215, _interpolate :1306-1360,
     _normalize :1362-1371, fwxm_data :1411-1461, _sample_points_in_physical_window :1237-1283,
@@ -1240,8 +1274,11 @@ class SingleProfileRestated:
 
     def __init__(self, values, dpmm=None, interpolation="Linear", ground=True, interpolation_resolution_mm=0.1,
                  interpolation_factor=10, normalization_method="Beam center", x_values=None,
-                 centering="Beam center", edge_detection_method="FWHM", edge_smoothing_ratio=0.003):
+                 centering="Beam center", edge_detection_method="FWHM", edge_smoothing_ratio=0.003,
+                 hill_window_ratio=0.1):
         from scipy.interpolate import interp1d
+
+        self._hill_window_ratio = hill_window_ratio
 
         values = np.asarray(values, dtype=float)
         self.dpmm, self._centering = dpmm, centering
@@ -1302,9 +1339,78 @@ class SingleProfileRestated:
         pk, _ = find_peaks(d1, threshold=0.8, peak_separation=0.05)
         vl, _ = find_peaks(-d1, threshold=0.8, peak_separation=0.05)
         left, right = float(self._x(pk[0])), float(self._x(vl[-1]))
-        return {"left index (exact)": left, "right index (exact)": right,
-                "left value (@rounded)": self._yat(int(round(left))), "left value (@exact)": self._yat(left),
-                "right value (@rounded)": self._yat(int(round(right))), "right value (@exact)": self._yat(right)}
+        if self._edge != "Inflection Hill":
+            return {"left index (exact)": left, "right index (exact)": right,
+                    "left value (@rounded)": self._yat(int(round(left))), "left value (@exact)": self._yat(left),
+                    "right value (@rounded)": self._yat(int(round(right))), "right value (@exact)": self._yat(right)}
+        # profile.py:1675-1721: a Hill function fitted to a window about each derivative extremum
+        # (pylinac/core/hill.py:19-36; scipy.optimize.curve_fit = MINPACK lmdif, third-party, called like the reference)
+        half = int(round(self._hill_window_ratio * abs(right - left) / 2))
+        xl = np.array([x for x in np.arange(left - half, left + half) if x >= 0])
+        lp = hill_fit(xl, self._yat(xl))
+        xr = np.array([x for x in np.arange(right - half, right + half) if x < len(d1)])
+        rp = hill_fit(xr, self._yat(xr))
+        li, ri = hill_inflection(lp), hill_inflection(rp)
+        return {"left index (rounded)": int(round(li)), "left index (exact)": li,
+                "right index (rounded)": int(round(ri)), "right index (exact)": ri,
+                "left value (@exact)": hill_y(lp, li), "right value (@exact)": hill_y(rp, ri),
+                "left Hill params": lp, "right Hill params": rp}
+
+    def penumbra(self, lower=20, upper=80):
+        """profile.py:1723-1908."""
+        if lower > upper:
+            raise ValueError("Upper penumbra value must be larger than the lower penumbra value")
+        if self._edge == "FWHM":
+            up, lo = self.fwxm_data(upper), self.fwxm_data(lower)
+            data = {f"left {lower}% index (exact)": lo["left index (exact)"],
+                    f"left {lower}% value (@rounded)": lo["left value (@rounded)"],
+                    f"left {upper}% index (exact)": up["left index (exact)"],
+                    f"left {upper}% value (@rounded)": up["left value (@rounded)"],
+                    f"right {lower}% index (exact)": lo["right index (exact)"],
+                    f"right {lower}% value (@rounded)": lo["right value (@rounded)"],
+                    f"right {upper}% index (exact)": up["right index (exact)"],
+                    f"right {upper}% value (@rounded)": up["right value (@rounded)"],
+                    "left values": self.values[int(round(lo["left index (exact)"])):int(round(up["left index (exact)"]))],
+                    "right values": self.values[int(round(up["right index (exact)"])):int(round(lo["right index (exact)"]))],
+                    "left penumbra width (exact)": abs(up["left index (exact)"] - lo["left index (exact)"]),
+                    "right penumbra width (exact)": abs(up["right index (exact)"] - lo["right index (exact)"])}
+        elif self._edge == "Inflection Derivative":
+            infl = self.inflection_data()
+            vmax = self.values.max()
+            ll = self.fwxm_data(max(infl["left value (@exact)"] / vmax * lower / 50 * 100, 1))
+            ul = self.fwxm_data(min(infl["left value (@exact)"] / vmax * upper / 50 * 100, 99))
+            lr = self.fwxm_data(max(infl["right value (@exact)"] / vmax * lower / 50 * 100, 1))
+            ur = self.fwxm_data(min(infl["right value (@exact)"] / vmax * upper / 50 * 100, 99))
+            data = {f"left {lower}% index (exact)": ll["left index (exact)"],
+                    f"left {upper}% index (exact)": ul["left index (exact)"],
+                    f"right {lower}% index (exact)": lr["right index (exact)"],
+                    f"right {upper}% index (exact)": ur["right index (exact)"],
+                    "left values": self._yat(np.arange(int(round(ll["left index (exact)"])), int(round(ul["left index (exact)"])))),
+                    "right values": self._yat(np.arange(int(round(ur["right index (exact)"])), int(round(lr["right index (exact)"])))),
+                    "left penumbra width (exact)": abs(ul["left index (exact)"] - ll["left index (exact)"]),
+                    "right penumbra width (exact)": abs(ur["right index (exact)"] - lr["right index (exact)"])}
+        else:
+            infl = self.inflection_data()
+            lp, rp = infl["left Hill params"], infl["right Hill params"]
+            llv, ulv = infl["left value (@exact)"] * lower / 50, infl["left value (@exact)"] * upper / 50
+            lrv, urv = infl["right value (@exact)"] * lower / 50, infl["right value (@exact)"] * upper / 50
+            lli, uli, lri, uri = hill_x(lp, llv), hill_x(lp, ulv), hill_x(rp, lrv), hill_x(rp, urv)
+            data = {f"left {lower}% index (exact)": lli, f"left {lower}% value (exact)": llv,
+                    f"left {upper}% index (exact)": uli, f"left {upper}% value (exact)": ulv,
+                    f"right {lower}% index (exact)": lri, f"right {lower}% value (exact)": lrv,
+                    f"right {upper}% index (exact)": uri, f"right {upper}% value (exact)": urv,
+                    "left values": self.values[int(round(lli)):int(round(uli))],
+                    "right values": self.values[int(round(uri)):int(round(lri))],
+                    "left penumbra width (exact)": abs(uli - lli), "right penumbra width (exact)": abs(uri - lri),
+                    "left gradient (exact)": hill_gradient(lp, infl["left index (exact)"]),
+                    "right gradient (exact)": hill_gradient(rp, infl["right index (exact)"])}
+            if self.dpmm:
+                data["left gradient (exact) %/mm"] = data["left gradient (exact)"] * self.dpmm * 100
+                data["right gradient (exact) %/mm"] = data["right gradient (exact)"] * self.dpmm * 100
+        if self.dpmm:
+            data["left penumbra width (exact) mm"] = data["left penumbra width (exact)"] / self.dpmm
+            data["right penumbra width (exact) mm"] = data["right penumbra width (exact)"] / self.dpmm
+        return data
 
     def beam_center(self):
         """profile.py:1390-1409."""

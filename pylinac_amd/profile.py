@@ -11,6 +11,7 @@ batch forms used by the pipelines.
 from __future__ import annotations
 
 import enum
+import math
 from dataclasses import dataclass
 
 import numpy as np
@@ -368,12 +369,49 @@ class _Linear1d:
         return slope * (xn - self.x[lo]) + self.y[lo]
 
 
+class Hill:
+    """pylinac/core/hill.py:11-65: the four-parameter sigmoid ``a + (b - a) / (1 + (c / x) ** d)`` fitted to a
+    penumbra window.  ``fit`` calls ``scipy.optimize.curve_fit`` with the reference's start values."""
+
+    params: np.ndarray
+
+    @staticmethod
+    def _func(x, a, b, c, d):
+        return a + (b - a) / (1.0 + (c / x) ** d)
+
+    @classmethod
+    def fit(cls, x_data: np.ndarray, y_data: np.ndarray) -> "Hill":
+        from scipy.optimize import curve_fit
+
+        params, _ = curve_fit(cls._func, x_data, y_data, p0=(min(y_data), max(y_data), np.median(x_data), 0))
+        return cls.from_params(params)
+
+    @classmethod
+    def from_params(cls, params) -> "Hill":
+        inst = cls()
+        inst.params = params
+        return inst
+
+    def inflection_idx(self) -> dict:
+        idx = self.params[2] * math.pow((self.params[3] - 1) / (self.params[3] + 1), 1 / self.params[3])
+        return {"index (exact)": idx, "index (rounded)": int(round(idx))}
+
+    def gradient_at(self, x: float) -> float:
+        cxd = math.pow(self.params[2] / x, self.params[3])
+        return (self.params[1] - self.params[0]) * self.params[3] * cxd / (math.pow(cxd + 1, 2) * x)
+
+    def x(self, y: float) -> float:
+        return self.params[2] * math.pow((y - self.params[0]) / (self.params[1] - y), 1 / self.params[3])
+
+    def y(self, x: float) -> float:
+        return self.params[0] + (self.params[1] - self.params[0]) / (1 + (self.params[2] / x) ** self.params[3])
+
+
 class SingleProfile:
     """pylinac/core/profile.py:1118-1633: a profile with one large signal (a beam profile).
 
-    Same constructor arguments, dictionary keys and error behaviour as the reference for the FWHM and
-    INFLECTION_DERIVATIVE edge methods (SURVEY.md section 8 row a11 and part of row f4; the Hill-fit edge method
-    raises NotImplementedError).  Resampling (``pl_interp1d``), grounding / normalisation (elementwise kernels) and
+    Same constructor arguments, dictionary keys and error behaviour as the reference for the FWHM,
+    INFLECTION_DERIVATIVE and INFLECTION_HILL edge methods.  Resampling (``pl_interp1d``), grounding / normalisation (elementwise kernels) and
     the FWXM search (``pl_find_peaks``) run on the GPU; ``values`` is the host copy the reference's users
     read, ``values_device`` the resident tensor.  The handful of scalar look-ups and three-parameter fits of
     ``field_data`` are host numpy, like the reference's.
@@ -392,9 +430,6 @@ class SingleProfile:
         self._edge_smoothing_ratio = edge_smoothing_ratio
         self._hill_window_ratio = hill_window_ratio
         self._centering = _enum(centering, Centering)
-        if self._edge_method == Edge.INFLECTION_HILL:
-            raise NotImplementedError("Hill-fit edge detection (SURVEY.md row f4) is not built; "
-                                      "Edge.FWHM and Edge.INFLECTION_DERIVATIVE are")
         self.dpmm = dpmm
         dev_values = _to_device_profile(values)
         fitted, new_dpmm, x_indices = self._interpolate(dev_values, x_values, dpmm, interpolation_resolution_mm,
@@ -456,13 +491,13 @@ class SingleProfile:
     def _x_interp_to_original(self, location):
         x = self._x_interp1d(location)
         if isinstance(location, (float, int)) or np.size(location) == 1:
-            return float(x)
+            return float(np.asarray(x).reshape(-1)[0])
         return x
 
     def _y_original_to_interp(self, location):
         y = self._y_interp1d(location)
         if isinstance(location, (float, int)) or np.size(location) == 1:
-            return float(y)
+            return float(np.asarray(y).reshape(-1)[0])
         return y
 
     def _geometric_center(self, values) -> dict:
@@ -495,6 +530,27 @@ class SingleProfile:
         valley_idxs, _ = find_peaks(-d1, threshold=0.8, peak_separation=0.05)     # MultiProfile(d1).find_valleys
         left_idx = self._x_interp_to_original(peak_idxs[0])
         right_idx = self._x_interp_to_original(valley_idxs[-1])
+        if self._edge_method == Edge.INFLECTION_HILL:
+            # profile.py:1675-1721: a Hill function fitted to a window about each derivative extremum.  The window is
+            # a few dozen samples and the fit four parameters: the reference's own per-profile optimiser
+            # (scipy.optimize.curve_fit = MINPACK lmdif) runs on the host, like the "top" fit of field_data
+            # (a device Levenberg-Marquardt only pays off for IC-Profiler-scale batches).
+            half = int(round(self._hill_window_ratio * abs(right_idx - left_idx) / 2))
+            x_left = np.array([x for x in np.arange(left_idx - half, left_idx + half) if x >= 0])
+            left_hill = Hill.fit(x_left, self._y_original_to_interp(x_left))
+            x_right = np.array([x for x in np.arange(right_idx - half, right_idx + half) if x < d1.numel()])
+            right_hill = Hill.fit(x_right, self._y_original_to_interp(x_right))
+            left_infl, right_infl = left_hill.inflection_idx(), right_hill.inflection_idx()
+            return {
+                "left index (rounded)": left_infl["index (rounded)"],
+                "left index (exact)": left_infl["index (exact)"],
+                "right index (rounded)": right_infl["index (rounded)"],
+                "right index (exact)": right_infl["index (exact)"],
+                "left value (@exact)": left_hill.y(left_infl["index (exact)"]),
+                "right value (@exact)": right_hill.y(right_infl["index (exact)"]),
+                "left Hill params": left_hill.params,
+                "right Hill params": right_hill.params,
+            }
         return {
             "left index (rounded)": int(round(left_idx)),
             "left index (exact)": left_idx,
@@ -505,6 +561,80 @@ class SingleProfile:
             "right value (@rounded)": self._y_original_to_interp(int(round(right_idx))),
             "right value (@exact)": self._y_original_to_interp(right_idx),
         }
+
+    def penumbra(self, lower: int = 20, upper: int = 80) -> dict:
+        """profile.py:1723-1908: penumbra positions / widths (and, for the Hill method, the edge gradients), with the
+        reference's keys for each edge method."""
+        if lower > upper:
+            raise ValueError("Upper penumbra value must be larger than the lower penumbra value")
+        if self._edge_method == Edge.FWHM:
+            upper_data, lower_data = self.fwxm_data(x=upper), self.fwxm_data(x=lower)
+            data = {
+                f"left {lower}% index (exact)": lower_data["left index (exact)"],
+                f"left {lower}% value (@rounded)": lower_data["left value (@rounded)"],
+                f"left {upper}% index (exact)": upper_data["left index (exact)"],
+                f"left {upper}% value (@rounded)": upper_data["left value (@rounded)"],
+                f"right {lower}% index (exact)": lower_data["right index (exact)"],
+                f"right {lower}% value (@rounded)": lower_data["right value (@rounded)"],
+                f"right {upper}% index (exact)": upper_data["right index (exact)"],
+                f"right {upper}% value (@rounded)": upper_data["right value (@rounded)"],
+                "left values": self.values[lower_data["left index (rounded)"]:upper_data["left index (rounded)"]],
+                "right values": self.values[upper_data["right index (rounded)"]:lower_data["right index (rounded)"]],
+                "left penumbra width (exact)": abs(upper_data["left index (exact)"] - lower_data["left index (exact)"]),
+                "right penumbra width (exact)": abs(upper_data["right index (exact)"] - lower_data["right index (exact)"]),
+            }
+        elif self._edge_method == Edge.INFLECTION_DERIVATIVE:
+            infl = self.inflection_data()
+            vmax = self.values.max()
+            lower_left = self.fwxm_data(x=max(infl["left value (@exact)"] / vmax * lower / 50 * 100, 1))
+            upper_left = self.fwxm_data(x=min(infl["left value (@exact)"] / vmax * upper / 50 * 100, 99))
+            lower_right = self.fwxm_data(x=max(infl["right value (@exact)"] / vmax * lower / 50 * 100, 1))
+            upper_right = self.fwxm_data(x=min(infl["right value (@exact)"] / vmax * upper / 50 * 100, 99))
+            data = {
+                f"left {lower}% index (exact)": lower_left["left index (exact)"],
+                f"left {upper}% index (exact)": upper_left["left index (exact)"],
+                f"right {lower}% index (exact)": lower_right["right index (exact)"],
+                f"right {upper}% index (exact)": upper_right["right index (exact)"],
+                "left values": self._y_original_to_interp(
+                    np.arange(lower_left["left index (rounded)"], upper_left["left index (rounded)"])),
+                "right values": self._y_original_to_interp(
+                    np.arange(upper_right["right index (rounded)"], lower_right["right index (rounded)"])),
+                "left penumbra width (exact)": abs(upper_left["left index (exact)"] - lower_left["left index (exact)"]),
+                "right penumbra width (exact)": abs(upper_right["right index (exact)"] - lower_right["right index (exact)"]),
+            }
+        else:
+            infl = self.inflection_data()
+            left_hill = Hill.from_params(infl["left Hill params"])
+            right_hill = Hill.from_params(infl["right Hill params"])
+            lower_left_value = infl["left value (@exact)"] * lower / 50
+            upper_left_value = infl["left value (@exact)"] * upper / 50
+            lower_right_value = infl["right value (@exact)"] * lower / 50
+            upper_right_value = infl["right value (@exact)"] * upper / 50
+            lower_left_index, upper_left_index = left_hill.x(lower_left_value), left_hill.x(upper_left_value)
+            lower_right_index, upper_right_index = right_hill.x(lower_right_value), right_hill.x(upper_right_value)
+            data = {
+                f"left {lower}% index (exact)": lower_left_index,
+                f"left {lower}% value (exact)": lower_left_value,
+                f"left {upper}% index (exact)": upper_left_index,
+                f"left {upper}% value (exact)": upper_left_value,
+                f"right {lower}% index (exact)": lower_right_index,
+                f"right {lower}% value (exact)": lower_right_value,
+                f"right {upper}% index (exact)": upper_right_index,
+                f"right {upper}% value (exact)": upper_right_value,
+                "left values": self.values[int(round(lower_left_index)):int(round(upper_left_index))],
+                "right values": self.values[int(round(upper_right_index)):int(round(lower_right_index))],
+                "left penumbra width (exact)": abs(upper_left_index - lower_left_index),
+                "right penumbra width (exact)": abs(upper_right_index - lower_right_index),
+                "left gradient (exact)": left_hill.gradient_at(infl["left index (exact)"]),
+                "right gradient (exact)": right_hill.gradient_at(infl["right index (exact)"]),
+            }
+            if self.dpmm:
+                data["left gradient (exact) %/mm"] = data["left gradient (exact)"] * self.dpmm * 100
+                data["right gradient (exact) %/mm"] = data["right gradient (exact)"] * self.dpmm * 100
+        if self.dpmm:
+            data["left penumbra width (exact) mm"] = data["left penumbra width (exact)"] / self.dpmm
+            data["right penumbra width (exact) mm"] = data["right penumbra width (exact)"] / self.dpmm
+        return data
 
     def fwxm_data(self, x: int = 50) -> dict:
         """profile.py:1411-1461.  The slice of ``x_indices`` by ROUNDED PHYSICAL positions for

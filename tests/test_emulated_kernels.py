@@ -187,3 +187,16 @@ def test_emulated_rectangle_roi(golden, emulated):
     import next_row_checks as checks
 
     checks.check_rectangle_roi(golden, emulated)
+
+
+def test_emulated_single_profile_hill_and_penumbra(golden, emulated):
+    """SingleProfile (Hill edge, penumbra for the three edge methods) on the emulated device, a subset of hill.npz."""
+    import next_row_checks as checks
+    from pylinac_amd import profile
+
+    def make(values, edge, **kw):
+        return profile.SingleProfile(values, edge_detection_method=edge, **kw)
+
+    n = checks.check_hill_and_penumbra(golden("hill"), make, tol=1e-9, spline_tol=1e-6,
+                                       only=lambda t: t.startswith(("fx3.", "fx12.", "epid.", "fff0.", "fff2.")))
+    assert n >= 20

@@ -1449,6 +1449,24 @@ def test_max_filter1d_vs_scipy(dev):
                 assert got.dtype == want.dtype and np.array_equal(got, want), (arr.dtype, axis, half)
 
 
+def test_single_profile_hill_and_penumbra_vs_reference_golden(golden, dev):
+    """f4 (second half): SingleProfile with Edge.INFLECTION_HILL (device smoothing / gradient / peak searches /
+    resampling; the four-parameter Hill fits by scipy's curve_fit on the host, like the reference) and penumbra() for the
+    three edge methods against the reference's own numbers (tests/golden/hill.npz: 132 profiles + the ones it rejects).
+    1e-9 relative; 1e-6 for the spline-resampled Hill fits (MINPACK's own stopping tolerance is 1.5e-8)."""
+    import warnings
+
+    import next_row_checks as checks
+    from pylinac_amd import profile
+
+    def make(values, edge, **kw):
+        return profile.SingleProfile(values, edge_detection_method=edge, **kw)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert checks.check_hill_and_penumbra(golden("hill"), make, tol=1e-9, spline_tol=1e-6) == 132
+
+
 def test_rectangle_roi_vs_reference_golden(golden, dev):
     """f3 (second half): pl_polygon_roi_stats / RectangleROI against the reference's own RectangleROI (rotated,
     unrotated, clipped) and scikit-image 0.18.3's draw.polygon pixel sets."""

@@ -432,6 +432,24 @@ def test_single_profile_restatement_matches_reference_and_frozen_exports(golden)
         _sp_check(g, f"epid.{name}", o.SingleProfileRestated(g["epid.y"].copy(), **kw), calcs, vtol=0, ftol=1e-12)
 
 
+def test_hill_edge_and_penumbra_restatement_matches_reference(golden):
+    """f4 (second half): oracle.SingleProfileRestated with the Hill-fit edge method, and penumbra() for the FWHM /
+    inflection-derivative / Hill methods, against the reference's own SingleProfile + Hill (scipy curve_fit) on its 20
+    frozen profiles (index abscissae, window ratio 0.5), an EPID profile (dpmm; linear and spline resampling) and four
+    FFF-style profiles: inflection data, Hill parameters, beam centre, field data, penumbra positions / widths /
+    gradients, and the profiles on which the reference raises."""
+    import next_row_checks as checks
+
+    def make(values, edge, **kw):
+        return o.SingleProfileRestated(values, edge_detection_method=edge, **kw)
+
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert checks.check_hill_and_penumbra(golden("hill"), make, tol=1e-12) == 132
+
+
 def test_field_finder_restatement_matches_reference(golden):
     """a13 (fields): oracle.find_fields_restated against the reference's own GlobalSizedFieldLocator.calculate
     under scikit-image 0.18.3 (py3.9 helper): same fields in the same order, centroids to 1e-12.  The frames
