@@ -83,7 +83,7 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     from pylinac_amd import dist as pdist
-    from pylinac_amd.pipeline import STAGES, EpidPipeline
+    from pylinac_amd.pipeline import EpidPipeline
     from pylinac_amd.synthetic import epid_open_field_frames
 
     n, h, w = args.frames, args.height, args.width

@@ -1771,3 +1771,111 @@ def rectangle_roi_stats(arr: np.ndarray, width, height, cx, cy, rotation=0.0) ->
     """-> count, mean, std, min, max, median of pixels_flat (roi.py:683-704; pixel_value is the MEAN for rectangles)."""
     v = rectangle_roi_pixels(arr, width, height, cx, cy, rotation)
     return np.array([v.size, np.mean(v), np.std(v), np.min(v), np.max(v), np.median(v)], dtype=float)
+
+
+# --------------------------------------------------------------------------------------
+# Starshot per-image measurement (pylinac/starshot.py:197-401, 701-834; SURVEY.md section 3.3)
+# --------------------------------------------------------------------------------------
+
+class _Pt:
+    def __init__(self, x=0.0, y=0.0, z=0.0, idx=None, value=None):
+        self.x, self.y, self.z, self.idx, self.value = x, y, z, idx, value
+
+
+def _line_distance(p1, p2, pt) -> float:
+    """Line.distance_to (pylinac/core/geometry.py:569-584)"""
+    lp1, lp2, p = (np.array([q.x, q.y, q.z], dtype=float) for q in (p1, p2, pt))
+    return np.sqrt(np.sum(np.power(np.cross(lp2 - lp1, lp1 - p), 2))) / np.sqrt(np.sum(np.power(lp2 - lp1, 2)))
+
+
+class StarshotRestated:
+    """Starshot.analyze for an array: check_inversion_by_histogram([4, 50, 96]) (image.py:899-926), ground, start point
+    (starshot.py:197-227), StarProfile (:765-814), LineManager (:701-762), Nelder-Mead wobble (:378-401), the retry
+    sweep (:306-376) and calculate_angles (:817-834)."""
+
+    def __init__(self, array, dpi, sid=1000):
+        self.array = np.array(array)
+        self.dpmm = dpi * (sid / 1000) / 25.4
+        self.tolerance = 1
+
+    def _get_reasonable_start_point(self):
+        a = self.array
+        t3 = int(a.shape[0] / 3)
+        l3 = int(a.shape[1] / 3)
+        central = a[t3:int(t3 * 2), l3:int(l3 * 2)]
+        cx = round(fwxm_edges(np.max(central, 0), 80)[2]) + l3
+        cy = round(fwxm_edges(np.max(central, 1), 80)[2]) + t3
+        return _Pt(cx, cy), np.percentile(central, 90)
+
+    def _star_profile(self, centre, radius_ratio, min_height, fwhm):
+        rows, cols = self.array.shape
+        radius = min(rows - centre.y, cols - centre.x, centre.y, centre.x) * radius_ratio
+        if self.array.shape[1] < radius + centre.x or self.array.shape[0] < radius + centre.y:
+            raise ValueError("Array size not large enough to compute profile")
+        radii = np.linspace(radius * 0.9, radius * 1.1, 20)
+        rads = circle_radians(np.pi * max(radii) * 2 * 3)
+        values = collapsed_circle_profile(self.array, (centre.x, centre.y), radius, sampling_ratio=3)
+        xs, ys = np.cos(rads) * radius + centre.x, np.sin(rads) * radius + centre.y
+        roll = np.where(values == values.min())[0][0]
+        values, xs, ys = np.roll(values, -roll), np.roll(xs, -roll), np.roll(ys, -roll)
+        values = filter(values, size=0.003, kind="gaussian")
+        values = ground(values)
+        if fwhm:
+            idx, vals = multiprofile_find_fwxm_peaks(values, threshold=min_height, min_distance=0.02)
+        else:
+            idx, vals = multiprofile_find_peaks(values, threshold=min_height, min_distance=0.02)
+        peaks = [_Pt(xs[int(i)], ys[int(i)], idx=i, value=v) for i, v in zip(idx, vals)]
+        return values, radius, peaks
+
+    def analyze(self, radius=0.85, min_peak_height=0.25, max_wobble_diameter=2.0, tolerance=1.0, start_point=None,
+                fwhm=True, recursive=True, invert_image=False):
+        from itertools import product
+
+        from scipy import optimize
+
+        self.tolerance = tolerance
+        p_low, p_mid, p_high = (np.percentile(self.array, q) for q in (4, 50, 96))
+        if abs(p_mid - p_low) > abs(p_mid - p_high):
+            self.array = invert(self.array)
+        self.array = ground(self.array)
+        if invert_image:
+            self.array = invert(self.array)
+        auto, local_max = self._get_reasonable_start_point()
+        focus = auto if start_point is None else _Pt(start_point[0], start_point[1])
+        gen = product(np.append(radius, np.linspace(0.95, 0.1, 10)), np.append(min_peak_height, np.linspace(0.05, 0.95, 10)))
+        while True:
+            try:
+                self.profile, self.radius, self.peaks = self._star_profile(focus, radius, min_peak_height * local_max, fwhm)
+                self.centre = focus
+                n = len(self.peaks)
+                if n < 6 or n % 2:
+                    if not recursive:
+                        raise RuntimeError("The algorithm was unable to properly detect the radiation lines.")
+                    raise ValueError
+                half = int(n / 2)
+                self.lines = [(self.peaks[k], self.peaks[k + half]) for k in range(half)]
+                if any(_line_distance(a, b, focus) > 10 * self.dpmm for a, b in self.lines):
+                    raise ValueError
+                res = optimize.minimize(
+                    lambda p, lines: max(_line_distance(a, b, _Pt(p[0], p[1])) for a, b in lines),
+                    np.array([focus.x, focus.y, focus.z]), args=(self.lines,), method="Nelder-Mead",
+                    options={"fatol": 0.001})
+                self.wobble_radius, self.wobble_centre = res.fun, (res.x[0], res.x[1])
+                self.wobble_radius_mm = res.fun / self.dpmm
+                near = math.sqrt((res.x[0] - focus.x) ** 2 + (res.x[1] - focus.y) ** 2) < 10 * self.dpmm
+                if (self.wobble_radius_mm * 2 < max_wobble_diameter and near) or not recursive:
+                    break
+                raise ValueError
+            except ValueError:
+                try:
+                    radius, min_peak_height = next(gen)
+                except StopIteration:
+                    raise RuntimeError("The algorithm was unable to determine a reasonable wobble.")
+        self.angles = []
+        for a, b in self.lines:
+            with np.errstate(divide="ignore"):
+                m = (a.y - b.y) / (a.x - b.x)
+            phi = math.degrees(math.atan(m)) - 90
+            phi = phi - 180 if phi > 90 else (phi + 180 if phi <= -90 else phi)
+            self.angles.append(phi)
+        self.passed = bool(self.wobble_radius_mm * 2 < self.tolerance)

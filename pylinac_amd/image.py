@@ -153,13 +153,15 @@ class ArrayImage(_MutatorMixin):
         if a.dtype in (np.uint16, np.int16):
             s = au._Staged(a)
             p_low, p_mid, p_high = ops.percentile(s.t, list(percentiles))[0].tolist()
-        elif a.dtype == np.float64:
+        elif a.dtype in (np.float64, np.float32):
             from .canny import _percentile_f64      # exact float64 order statistics (pl_order_stats_f64)
 
-            t = au._Staged(a).t
+            # float32 frames: the order statistics are exact in float64; numpy interpolates between them in float32,
+            # which can only matter to this comparison when the two distances tie to ~1e-7 relative
+            t = au._Staged(a.astype(np.float64, copy=False)).t
             p_low, p_mid, p_high = (float(_percentile_f64(t, q)[0]) for q in percentiles)
         else:
-            raise TypeError("check_inversion_by_histogram needs a 16-bit integer or float64 frame on this backend")
+            raise TypeError("check_inversion_by_histogram needs a 16-bit integer or float32 / float64 frame on this backend")
         if abs(p_mid - p_low) > abs(p_mid - p_high):
             self.invert()
             return True

@@ -125,8 +125,6 @@ def gaussian_filter1d(x: torch.Tensor, sigma: float, axis: int = -1) -> torch.Te
 def median_filter(frames: torch.Tensor, size: int, out=None) -> torch.Tensor:
     """``ndimage.median_filter(frame, size=size)`` per frame (pylinac/core/array_utils.py:131).
     [N,L] input is filtered as N 1-D profiles."""
-    if frames.dim() == 2 and False:
-        pass
     x = _frames(frames)
     n, h, w = x.shape
     out = torch.empty_like(x) if out is None else out

@@ -13,7 +13,6 @@ kisses :810-824, per-picket line fits :831-843, error in mm :1701-1718) works on
 """
 from __future__ import annotations
 
-import ctypes as C
 from dataclasses import dataclass
 
 import numpy as np

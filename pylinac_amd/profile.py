@@ -241,6 +241,7 @@ class CircleProfile(MultiProfile):
         self.start_angle = start_angle
         self.ccw = ccw
         self.sampling_ratio = sampling_ratio
+        self._x_locations = self._y_locations = None
         super().__init__(self._profile)
 
     @staticmethod
@@ -265,13 +266,56 @@ class CircleProfile(MultiProfile):
     def _radians(self):
         return ops.circle_radians(self.size, self.start_angle, self.ccw)
 
+    # x_locations / y_locations are cached properties in the reference, and ``roll`` replaces them
     @property
     def x_locations(self):
-        return np.cos(self._radians) * self.radius + self.center.x
+        if self._x_locations is None:
+            self._x_locations = np.cos(self._radians) * self.radius + self.center.x
+        return self._x_locations
+
+    @x_locations.setter
+    def x_locations(self, v):
+        self._x_locations = v
 
     @property
     def y_locations(self):
-        return np.sin(self._radians) * self.radius + self.center.y
+        if self._y_locations is None:
+            self._y_locations = np.sin(self._radians) * self.radius + self.center.y
+        return self._y_locations
+
+    @y_locations.setter
+    def y_locations(self, v):
+        self._y_locations = v
+
+    def find_peaks(self, threshold=0.3, min_distance=0.05, max_number=None, search_region=(0.0, 1.0)):
+        """profile.py:2284-2296: MultiProfile.find_peaks + the peaks' image coordinates."""
+        out = super().find_peaks(threshold, min_distance, max_number, search_region)
+        self._map_peaks()
+        return out
+
+    def find_valleys(self, threshold=0.3, min_distance=0.05, max_number=None, search_region=(0.0, 1.0)):
+        """profile.py:2298-2310 (like the reference, it is ``self.peaks`` that gets mapped)."""
+        out = super().find_valleys(threshold, min_distance, max_number, search_region)
+        self._map_peaks()
+        return out
+
+    def find_fwxm_peaks(self, threshold=0.3, min_distance=0.05, max_number=None, search_region=(0.0, 1.0)):
+        """profile.py:2312-2324"""
+        out = super().find_fwxm_peaks(threshold, min_distance, max_number, search_region=search_region)
+        self._map_peaks()
+        return out
+
+    def _map_peaks(self) -> None:
+        """profile.py:2326-2329"""
+        for peak in self.peaks:
+            peak.x = self.x_locations[int(peak.idx)]
+            peak.y = self.y_locations[int(peak.idx)]
+
+    def roll(self, amount: int) -> None:
+        """profile.py:2331-2340: roll the profile and its x / y coordinates to the left."""
+        self.values = np.roll(self.values, -amount)
+        self.x_locations = np.roll(self.x_locations, -amount)
+        self.y_locations = np.roll(self.y_locations, -amount)
 
     @property
     def _profile(self):

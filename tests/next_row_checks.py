@@ -196,3 +196,40 @@ def check_hill_and_penumbra(g, make_profile, tol=1e-9, only=None, spline_tol=Non
             close(pen["right values"], g[f"{tag}.pen{lower}_{upper}.right_values"], "right values")
         n += 1
     return n
+
+
+# ---------------------------------------------------------------------------------------------- Starshot
+def starshot_cases(g):
+    for name in g["names"]:
+        name = str(name)
+        frame = g["four.frame"] if name == "startpt" else g[f"{name}.frame"]
+        yield name, frame, float(g[f"{name}.dpi"]), eval(str(g[f"{name}.kw"]), {"__builtins__": {}}, {})
+
+
+def check_starshot(g, make, only=None, tol=1e-9):
+    """`make(frame, dpi, sid)` -> an object with the reference's Starshot interface; compared with the reference's own
+    Starshot.analyze() on the synthetic frames of tests/golden/starshot.npz: automatic start point and local maximum,
+    the rolled / filtered / grounded star profile, peak indices / values / image coordinates, the paired lines, wobble
+    centre / radius (the Nelder-Mead fit sees identical lines, so identical iterates), angles, pass flag."""
+    n = 0
+    for name, frame, dpi, kw in starshot_cases(g):
+        if only and name not in only:
+            continue
+        s = make(frame.copy(), dpi, 1000)
+        s.analyze(**kw)
+        sp, local_max = s._get_reasonable_start_point()
+        want = g[f"{name}.start"]
+        assert (sp.x, sp.y) == (want[0], want[1]) and abs(local_max - want[2]) <= 1e-6 * abs(want[2]), (name, "start")
+        cp = s.circle_profile
+        assert np.allclose([cp.center.x, cp.center.y, cp.radius], g[f"{name}.circle"], rtol=0, atol=1e-12), name
+        assert np.allclose(np.asarray(cp.values, float), g[f"{name}.profile"], rtol=tol, atol=tol), (name, "profile")
+        peaks = np.array([[p.idx, p.value, p.x, p.y] for p in cp.peaks], dtype=float)
+        assert peaks.shape == g[f"{name}.peaks"].shape and np.allclose(peaks, g[f"{name}.peaks"], rtol=tol, atol=tol), name
+        lines = np.array([[ln.point1.x, ln.point1.y, ln.point2.x, ln.point2.y] for ln in s.lines.lines], dtype=float)
+        assert np.allclose(lines, g[f"{name}.lines"], rtol=tol, atol=tol), (name, "lines")
+        w = [s.wobble.center.x, s.wobble.center.y, s.wobble.radius, s.wobble.radius_mm, s.wobble.diameter_mm]
+        assert np.allclose(w, g[f"{name}.wobble"], rtol=1e-7, atol=1e-7), (name, "wobble", w, g[f"{name}.wobble"])
+        assert np.allclose(s.angles, g[f"{name}.angles"], rtol=1e-9, atol=1e-9), (name, "angles")
+        assert s.passed == bool(g[f"{name}.passed"]), name
+        n += 1
+    return n

@@ -200,3 +200,13 @@ def test_emulated_single_profile_hill_and_penumbra(golden, emulated):
     n = checks.check_hill_and_penumbra(golden("hill"), make, tol=1e-9, spline_tol=1e-6,
                                        only=lambda t: t.startswith(("fx3.", "fx12.", "epid.", "fff0.", "fff2.")))
     assert n >= 20
+
+
+def test_emulated_starshot(golden, emulated):
+    """Starshot.analyze on the emulated device (one integer and the float32 frame; the full set runs with -m gpu)."""
+    import next_row_checks as checks
+    from pylinac_amd import starshot
+
+    n = checks.check_starshot(golden("starshot"), lambda f, dpi, sid: starshot.Starshot(f, dpi=dpi, sid=sid),
+                              only=("inverted", "float"))
+    assert n == 2

@@ -1467,6 +1467,21 @@ def test_single_profile_hill_and_penumbra_vs_reference_golden(golden, dev):
         assert checks.check_hill_and_penumbra(golden("hill"), make, tol=1e-9, spline_tol=1e-6) == 132
 
 
+def test_starshot_vs_reference_golden(golden, dev):
+    """Starshot.analyze (device: percentiles, inversion, grounding, axis maxima, 20-radius circle gather, 1-D Gaussian,
+    FWXM peaks; host: line pairing, Nelder-Mead wobble, retry sweep) against the reference's own Starshot on six
+    synthetic frames: start point, star profile, peaks, lines to 1e-9; wobble to 1e-7; angles; pass flag."""
+    import next_row_checks as checks
+    from pylinac_amd import starshot
+
+    assert checks.check_starshot(golden("starshot"), lambda f, dpi, sid: starshot.Starshot(f, dpi=dpi, sid=sid)) == 6
+    with pytest.raises(ValueError, match="DPI"):
+        starshot.Starshot(np.zeros((10, 10), np.uint16))
+    s = starshot.Starshot(golden("starshot")["four.frame"].copy(), dpi=100, sid=1000)
+    with pytest.raises(ValueError):
+        s.analyze(radius=0.1)
+
+
 def test_rectangle_roi_vs_reference_golden(golden, dev):
     """f3 (second half): pl_polygon_roi_stats / RectangleROI against the reference's own RectangleROI (rotated,
     unrotated, clipped) and scikit-image 0.18.3's draw.polygon pixel sets."""

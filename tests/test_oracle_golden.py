@@ -450,6 +450,24 @@ def test_hill_edge_and_penumbra_restatement_matches_reference(golden):
         assert checks.check_hill_and_penumbra(golden("hill"), make, tol=1e-12) == 132
 
 
+def test_starshot_restatement_matches_reference(golden):
+    """Starshot (north_star's third analyzer): oracle.StarshotRestated against the reference's own
+    Starshot.analyze() on six synthetic star-shot frames (uint16 / float32, inverted, 3-6 spokes, peak instead of FWHM
+    centres, a manual start point without the retry sweep): star profile, peaks, lines, wobble, angles identical."""
+    import next_row_checks as checks
+
+    g = golden("starshot")
+    for name, frame, dpi, kw in checks.starshot_cases(g):
+        s = o.StarshotRestated(frame, dpi)
+        s.analyze(**kw)
+        assert np.array_equal(s.profile, g[f"{name}.profile"]), name
+        peaks = np.array([[p.idx, p.value, p.x, p.y] for p in s.peaks], dtype=float)
+        assert np.array_equal(peaks, g[f"{name}.peaks"]), name
+        w = [s.wobble_centre[0], s.wobble_centre[1], s.wobble_radius, s.wobble_radius_mm, 2 * s.wobble_radius_mm]
+        assert np.array_equal(w, g[f"{name}.wobble"]) and np.array_equal(s.angles, g[f"{name}.angles"]), name
+        assert s.passed == bool(g[f"{name}.passed"]) and [s.centre.x, s.centre.y, s.radius] == list(g[f"{name}.circle"])
+
+
 def test_field_finder_restatement_matches_reference(golden):
     """a13 (fields): oracle.find_fields_restated against the reference's own GlobalSizedFieldLocator.calculate
     under scikit-image 0.18.3 (py3.9 helper): same fields in the same order, centroids to 1e-12.  The frames
