@@ -115,6 +115,22 @@ inline int __syncthreads_or(int p) { return hipemu::block_barrier_or(p); }
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::shfl_from(0, 0))
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_fract(x) ((x) - floor(x))
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {src1 (bytes 0-3), src0 (bytes 4-7)}; 0x0c -> 0x00
+inline unsigned hipemu_perm(unsigned src0, unsigned src1, unsigned sel) {
+  const unsigned long long pool = ((unsigned long long)src0 << 32) | src1;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) {
+    const unsigned s = (sel >> (8 * i)) & 0xffu;
+    unsigned b = 0;
+    if (s <= 7) b = (unsigned)((pool >> (8 * s)) & 0xffu);
+    else if (s == 0x0c) b = 0;
+    else if (s >= 0x0d) b = 0xffu;
+    else b = ((pool >> (16 * (s - 8) + 15)) & 1u) ? 0xffu : 0u;   // 8..11: sign of a 16-bit half
+    r |= b << (8 * i);
+  }
+  return r;
+}
+#define __builtin_amdgcn_perm(a, b, s) hipemu_perm((a), (b), (s))
 #define __builtin_amdgcn_readfirstlane(v) (hipemu::readfirstlane(v))
 namespace hipemu {
 template <typename T>

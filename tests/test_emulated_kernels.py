@@ -131,6 +131,33 @@ def test_emu_gaussian_f64_kernels_match_scipy(emu):
         np.testing.assert_array_equal(out, want)
 
 
+def test_emu_gaussian_packed_f32_decision_kernels(emu):
+    """gaussian_pk.hip (the bench's default Gaussian for 16-bit frames) under the emulator (needs the ROCm clang++ as
+    host compiler: clang vector types): radii 4 / 8 / 12 / 20, uint16 and int16, frames with flat and saturated
+    regions so that the LDS fix list and the exact float64 tiers run too.  Bit-identical to scipy."""
+    import build as emu_build
+    from scipy import ndimage
+
+    if "gaussian_pk.hip" not in emu_build.SOURCES:
+        pytest.skip("no clang++ host compiler: gaussian_pk.hip is not in the emulated library")
+    rng = np.random.default_rng(8)
+    base = rng.integers(0, 65535, (2, 96, 128)).astype(np.uint16)
+    base[0, 20:60, 30:100] = 40000          # flat: S = c * sum(w) = c +- 1e-12 -> the undecided tiers
+    base[1, :48, :] = 65535                 # saturated
+    base[1, 60:, 64:] = 0
+    smooth = (np.clip(ndimage.gaussian_filter(base.astype(float), 6), 0, 65535)).astype(np.uint16)
+    for frames in (base, smooth, (smooth.astype(np.int32) - 32768).astype(np.int16)):
+        for sigma in (1, 2, 3, 5):
+            radius = int(4.0 * sigma + 0.5)
+            x = np.arange(-radius, radius + 1)
+            wts = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+            wts = np.ascontiguousarray(wts / wts.sum())
+            out, tmp = np.empty_like(frames), np.empty_like(frames)
+            _ok(emu, emu.pl_gaussian2d(_p(frames), _p(out), _p(tmp), _DT[frames.dtype], 2, 96, 128, _p(wts), radius, None))
+            want = np.stack([ndimage.gaussian_filter(f, sigma) for f in frames])
+            np.testing.assert_array_equal(out, want, err_msg=f"{frames.dtype} sigma {sigma}")
+
+
 def test_emu_median3_packed_kernels(emu):
     from scipy import ndimage
 
