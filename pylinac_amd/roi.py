@@ -233,3 +233,109 @@ class RectangleROI:
     @property
     def max(self) -> float:
         return float(self._s()[4])
+
+
+# ------------------------------------------------------------------------------------------- contrast ROIs
+class LowContrastDiskROI(DiskROI):
+    """pylinac/core/roi.py:186-411: a disk ROI with contrast / CNR / visibility against a reference value."""
+
+    def __init__(self, array, radius: float, center, contrast_threshold=None, contrast_reference=None,
+                 cnr_threshold=None, contrast_method="Michelson", visibility_threshold: float = 0.1):
+        super().__init__(array, radius, center=center)
+        self.contrast_threshold = contrast_threshold
+        self.cnr_threshold = cnr_threshold
+        self.contrast_reference = contrast_reference
+        self.contrast_method = contrast_method
+        self.visibility_threshold = visibility_threshold
+
+    @classmethod
+    def from_phantom_center(cls, array, angle: float, roi_radius: float, dist_from_center: float, phantom_center,
+                            contrast_threshold=None, contrast_reference=None, cnr_threshold=None,
+                            contrast_method="Michelson", visibility_threshold=0.1):
+        base = DiskROI.from_phantom_center(array, angle, roi_radius, dist_from_center, phantom_center)
+        return cls(base._array, roi_radius, base.center, contrast_threshold, contrast_reference, cnr_threshold,
+                   contrast_method, visibility_threshold)
+
+    @property
+    def diameter(self) -> float:
+        return self.radius * 2
+
+    @property
+    def _contrast_array(self) -> np.ndarray:
+        return np.array((self.pixel_value, self.contrast_reference))
+
+    @property
+    def signal_to_noise(self) -> float:
+        return float(np.array(self.pixel_value) / self.std)
+
+    @property
+    def contrast(self) -> float:
+        from . import contrast as _c
+
+        return _c.contrast(self._contrast_array, self.contrast_method)
+
+    @property
+    def contrast_to_noise(self) -> float:
+        return float(np.array(self.contrast) / self.std)
+
+    @property
+    def michelson(self) -> float:
+        from . import contrast as _c
+
+        return _c.michelson(self._contrast_array)
+
+    @property
+    def weber(self) -> float:
+        from . import contrast as _c
+
+        return _c.weber(feature=self.pixel_value, background=self.contrast_reference)
+
+    @property
+    def rms(self) -> float:
+        from . import contrast as _c
+
+        return _c.rms(self._contrast_array)
+
+    @property
+    def visibility(self) -> float:
+        from . import contrast as _c
+
+        return _c.visibility(array=self._contrast_array, radius=self.radius, std=self.std, algorithm=self.contrast_method)
+
+    @property
+    def cnr_constant(self) -> float:
+        return self.contrast_to_noise * self.diameter
+
+    @property
+    def contrast_constant(self) -> float:
+        return self.contrast * self.diameter
+
+    @property
+    def passed(self) -> bool:
+        return self.contrast > self.contrast_threshold
+
+    @property
+    def passed_visibility(self) -> bool:
+        return self.visibility > self.visibility_threshold
+
+    @property
+    def passed_contrast_constant(self) -> bool:
+        return self.contrast_constant > self.contrast_threshold
+
+    @property
+    def passed_cnr_constant(self) -> bool:
+        return self.cnr_constant > self.cnr_threshold
+
+
+class HighContrastDiskROI(DiskROI):
+    """pylinac/core/roi.py:414-478: a disk ROI read through its ``max`` / ``min``."""
+
+    def __init__(self, array, radius: float, center, contrast_threshold: float):
+        super().__init__(array=array, radius=radius, center=center)
+        self.contrast_threshold = contrast_threshold
+
+    @classmethod
+    def from_phantom_center(cls, array, angle: float, roi_radius: float, dist_from_center: float, phantom_center,
+                            contrast_threshold: float):
+        base = DiskROI.from_phantom_center(array, angle, roi_radius, dist_from_center, phantom_center)
+        return cls(base._array, roi_radius, base.center, contrast_threshold)

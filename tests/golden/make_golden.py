@@ -846,6 +846,11 @@ def main():
     subprocess.run([PY39, os.path.join(HERE, "skimage_rect_py39.py"), os.path.join(HERE, "roi.npz"),
                     os.path.join(HERE, "rect.npz"), ROOT], check=True)
 
+    # ---- 21. contrast ROIs: the reference's own LowContrastDiskROI / HighContrastDiskROI + core.contrast (f3)
+    subprocess.run([PY39, os.path.join(HERE, "skimage_contrast_py39.py"), os.path.join(HERE, "roi.npz"),
+                    os.path.join(HERE, "contrast.npz"), ROOT], check=True)
+    # (hill.npz and starshot.npz have their own generators: make_hill_golden.py, make_starshot_golden.py)
+
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -233,3 +233,41 @@ def check_starshot(g, make, only=None, tol=1e-9):
         assert s.passed == bool(g[f"{name}.passed"]), name
         n += 1
     return n
+
+
+# ---------------------------------------------------------------------------------------------- contrast ROIs
+def check_contrast_rois(golden, dev):
+    """LowContrastDiskROI / HighContrastDiskROI and the pylinac.core.contrast formulas against the reference's own
+    classes (tests/golden/contrast.npz).  Median, min, max exact; std / derived ratios to 1e-12."""
+    from pylinac_amd import contrast as con
+    from pylinac_amd import roi
+
+    g, d = golden("contrast"), golden("roi")
+    arr = d["slice_i16"].astype(np.float64) + float(g["shift"])
+    frame = torch.from_numpy(arr).to(dev)
+    props = [str(p) for p in g["props"]]
+    for ci, (cx, cy, r, ref) in enumerate(g["cases"]):
+        for mi, m in enumerate(g["methods"]):
+            z = roi.LowContrastDiskROI(frame, radius=r, center=(cx, cy), contrast_threshold=0.01, contrast_reference=ref,
+                                       cnr_threshold=0.5, contrast_method=str(m), visibility_threshold=0.1)
+            got = np.array([float(getattr(z, p)) for p in props])
+            np.testing.assert_allclose(got, g["low"][ci, mi], rtol=1e-12, atol=0, err_msg=f"{ci} {m}")
+    fc = roi.LowContrastDiskROI.from_phantom_center(frame, angle=-33.0, roi_radius=6.5, dist_from_center=70.25,
+                                                    phantom_center=(250.3, 260.7), contrast_threshold=0.02,
+                                                    contrast_reference=1190.0, cnr_threshold=1.0)
+    got = [fc._xy[0], fc._xy[1], fc.pixel_value, fc.contrast, fc.visibility, float(fc.passed)]
+    np.testing.assert_allclose(got, g["low_from_center"], rtol=1e-12)
+    hc = roi.HighContrastDiskROI(frame, radius=9.0, center=(200.5, 310.25), contrast_threshold=0.5)
+    np.testing.assert_allclose([hc.max, hc.min, hc.pixel_value, hc.std], g["high"], rtol=1e-12)
+    v = g["fn_in"]
+    fn = [con.michelson(v), con.rms(v), con.weber(3.0, 2.0), con.ratio(3.0, 2.0), con.difference(3.0, 5.5),
+          con.contrast(np.array([3.0, 2.0]), "Weber"), con.contrast(v, con.Contrast.RMS),
+          con.visibility(np.array([3.0, 2.0]), 5.0, 0.7, "Michelson")]
+    assert np.array_equal(fn, g["fn"])
+    for bad in ("Weber", "Ratio", "Difference"):
+        with np.testing.assert_raises(ValueError):
+            con.contrast(v, bad)
+    with np.testing.assert_raises(ValueError):
+        con.contrast(v, "nope")
+    with np.testing.assert_raises(ValueError):
+        con.rms(np.array([0.5, 1.5]))

@@ -237,3 +237,9 @@ def test_emulated_starshot(golden, emulated):
     n = checks.check_starshot(golden("starshot"), lambda f, dpi, sid: starshot.Starshot(f, dpi=dpi, sid=sid),
                               only=("inverted", "float"))
     assert n == 2
+
+
+def test_emulated_contrast_rois(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_contrast_rois(golden, emulated)

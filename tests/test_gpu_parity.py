@@ -1482,6 +1482,14 @@ def test_starshot_vs_reference_golden(golden, dev):
         s.analyze(radius=0.1)
 
 
+def test_contrast_rois_vs_reference_golden(golden, dev):
+    """f3: LowContrastDiskROI / HighContrastDiskROI (device ROI statistics + pylinac.core.contrast formulas) against the
+    reference's own classes for the four two-element contrast algorithms."""
+    import next_row_checks as checks
+
+    checks.check_contrast_rois(golden, dev)
+
+
 def test_rectangle_roi_vs_reference_golden(golden, dev):
     """f3 (second half): pl_polygon_roi_stats / RectangleROI against the reference's own RectangleROI (rotated,
     unrotated, clipped) and scikit-image 0.18.3's draw.polygon pixel sets."""
