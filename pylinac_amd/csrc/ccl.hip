@@ -14,6 +14,16 @@
 // point to the SMALLER index, then paths are compressed.  The root of a component is therefore
 // its first pixel in raster order -- exactly the order skimage/scipy number labels in -- and
 // sequential numbering is a prefix count of roots.
+//
+// Run-based start (fewer atomics on large regions: the background of a Winston-Lutz frame is ONE component of a
+// million pixels): the init kernel links every foreground pixel straight to the first pixel of its horizontal run
+// inside its 64-lane chunk (ballot + count-leading-zeros, no atomics), so the merge kernel only unites
+//   * a chunk's first pixel with its left neighbour (runs that cross a chunk boundary),
+//   * the FIRST pixel of each overlap between a run and the run above it (pixel i skips the union with i-w when
+//     i-1 and i-w-1 are foreground too: i ~ i-1 ~ i-w-1 ~ i-w already),
+//   * 8-connectivity: the upper-left diagonal only when neither i-1 nor i-w is foreground, the upper-right one only
+//     when i-w is not (otherwise the row above connects them).
+// Every skipped union is implied by ones that other lanes perform in the same launch; roots stay the smallest index.
 #include "pl_common.h"
 
 namespace {
@@ -48,16 +58,28 @@ __device__ __forceinline__ void unite(int* L, int a, int b) {
   } while (!done);
 }
 
-// fg(i) = (mask[i] != 0) ^ invert
-__global__ void ccl_init_kernel(const uint8_t* __restrict__ mask, int invert, int64_t total, int64_t per_frame,
-                                int* __restrict__ L) {
+// fg(i) = (mask[i] != 0) ^ invert.  L[i] = first pixel of i's run within its 64-lane chunk (lanes = consecutive pixels)
+__global__ void __launch_bounds__(kThreads)
+ccl_init_kernel(const uint8_t* __restrict__ mask, int invert, int64_t total, int64_t per_frame, int w,
+                int* __restrict__ L) {
   const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (g >= total) return;
-  const bool fg = ((mask[g] != 0) ? 1 : 0) != invert;
-  L[g] = fg ? (int)(g % per_frame) : -1;
+  const bool in_range = g < total;
+  const int i = in_range ? (int)(g % per_frame) : 0;
+  const bool fg = in_range && (((mask[g] != 0) ? 1 : 0) != invert);
+  const int lane = threadIdx.x & 63;
+  const unsigned long long fgm = __ballot(fg);
+  // a run starts where the previous lane is background, or the pixel opens a row (i % w == 0 also covers a new frame)
+  const bool starts = fg && (lane == 0 || !((fgm >> (lane - 1)) & 1ull) || (i % w) == 0);
+  const unsigned long long sm = __ballot(starts);
+  if (!in_range) return;
+  if (!fg) { L[g] = -1; return; }
+  const unsigned long long upto = sm & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+  const int start_lane = 63 - __builtin_clzll(upto);      // upto != 0: the run containing this lane has a start
+  L[g] = i - (lane - start_lane);
 }
 
-__global__ void ccl_merge_kernel(int* __restrict__ Lall, int64_t total, int h, int w, int conn8) {
+__global__ void __launch_bounds__(kThreads)
+ccl_merge_kernel(int* __restrict__ Lall, int64_t total, int h, int w, int conn8) {
   const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (g >= total) return;
   const int64_t per_frame = (int64_t)h * w;
@@ -65,12 +87,16 @@ __global__ void ccl_merge_kernel(int* __restrict__ Lall, int64_t total, int h, i
   const int i = (int)(g % per_frame);
   if (L[i] < 0) return;
   const int r = i / w, c = i % w;
-  if (c > 0 && L[i - 1] >= 0) unite(L, i, i - 1);
+  const bool left = c > 0 && L[i - 1] >= 0;
+  // same mapping of lanes to pixels as ccl_init_kernel: lane 0 of a chunk is where a run may continue from the left
+  if (left && (threadIdx.x & 63) == 0) unite(L, i, i - 1);
   if (r > 0) {
-    if (L[i - w] >= 0) unite(L, i, i - w);
+    const bool up = L[i - w] >= 0;
+    const bool upleft = c > 0 && L[i - w - 1] >= 0;
+    if (up && !(left && upleft)) unite(L, i, i - w);
     if (conn8) {
-      if (c > 0 && L[i - w - 1] >= 0) unite(L, i, i - w - 1);
-      if (c + 1 < w && L[i - w + 1] >= 0) unite(L, i, i - w + 1);
+      if (upleft && !up && !left) unite(L, i, i - w - 1);
+      if (!up && c + 1 < w && L[i - w + 1] >= 0) unite(L, i, i - w + 1);
     }
   }
 }
@@ -212,7 +238,7 @@ __global__ void scaled_binary_kernel(const T* __restrict__ in, int64_t total, in
 int run_ccl(const uint8_t* mask, int invert, int64_t n, int h, int w, int conn, int* L, hipStream_t st) {
   const int64_t per_frame = (int64_t)h * w, total = n * per_frame;
   const unsigned blocks = (unsigned)pl_cdiv(total, kThreads);
-  hipLaunchKernelGGL(ccl_init_kernel, dim3(blocks), dim3(kThreads), 0, st, mask, invert, total, per_frame, L);
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(blocks), dim3(kThreads), 0, st, mask, invert, total, per_frame, w, L);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, h, w, conn == 8 ? 1 : 0);
   hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame);
   return pl_check_launch("ccl");

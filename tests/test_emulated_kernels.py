@@ -169,20 +169,76 @@ def test_emu_median3_packed_kernels(emu):
         np.testing.assert_array_equal(out, np.stack([ndimage.median_filter(f, size=3) for f in frames]))
 
 
+def _label_masks():
+    """random masks of several densities and shapes (frame sizes that are / are not multiples of the 64-lane chunk),
+    plus structured ones: solid, a frame with one hole, stripes, a checkerboard, staircases, a spiral"""
+    rng = np.random.default_rng(6)
+    out = []
+    for shape in ((2, 45, 61), (3, 16, 64), (2, 33, 130), (1, 70, 7), (2, 1, 200), (2, 9, 1)):
+        for dens in (0.15, 0.45, 0.6, 0.9):
+            out.append((rng.random(shape) < dens).astype(np.uint8))
+    h, w = 40, 150
+    solid = np.ones((1, h, w), np.uint8)
+    ring = solid.copy(); ring[0, 10:30, 20:120] = 0; ring[0, 15:25, 40:100] = 1
+    stripes_v = np.zeros((1, h, w), np.uint8); stripes_v[0, :, ::3] = 1
+    stripes_h = np.zeros((1, h, w), np.uint8); stripes_h[0, ::2, :] = 1
+    checker = (np.indices((h, w)).sum(0) % 2).astype(np.uint8)[None]
+    stairs = np.zeros((1, h, w), np.uint8)
+    for k in range(h):
+        stairs[0, k, max(0, 3 * k - 4):3 * k + 2] = 1
+    anti = stairs[:, :, ::-1].copy()
+    spiral = np.zeros((1, 41, 41), np.uint8)
+    r, c, dr, dc, n = 0, 0, 0, 1, 41
+    seg = [41, 40, 40, 38, 38, 36, 36, 34, 34, 32, 32, 30, 30, 28, 28, 26, 26, 24, 24, 22, 22]
+    for k, length in enumerate(seg):
+        for _ in range(length - (0 if k == 0 else 1)):
+            spiral[0, r, c] = 1
+            r, c = r + dr, c + dc
+        r, c = r - dr, c - dc
+        dr, dc = dc, -dr
+        r, c = r + dr, c + dc
+    out += [solid, ring, stripes_v, stripes_h, checker, stairs, anti, spiral, 1 - spiral, 1 - ring]
+    return out
+
+
 def test_emu_label_matches_scipy(emu):
+    """Run-based union-find labelling == scipy.ndimage.label numbering, 4- and 8-connected."""
     from scipy import ndimage
 
-    rng = np.random.default_rng(6)
-    mask = (rng.random((2, 45, 61)) > 0.55).astype(np.uint8)
-    for conn, structure in ((4, None), (8, np.ones((3, 3)))):
-        labels = np.empty(mask.shape, np.int32)
+    for mask in _label_masks():
+        n, h, w = mask.shape
+        for conn, structure in ((4, None), (8, np.ones((3, 3)))):
+            labels = np.empty(mask.shape, np.int32)
+            work = np.empty(mask.shape, np.int32)
+            count = np.empty(n, np.int32)
+            _ok(emu, emu.pl_label(_p(mask), n, h, w, conn, _p(labels), _p(work), _p(count), None))
+            for f in range(n):
+                want, nl = ndimage.label(mask[f], structure=structure)
+                assert count[f] == nl, (mask.shape, conn)
+                np.testing.assert_array_equal(labels[f], want, err_msg=f"{mask.shape} conn {conn}")
+
+
+def test_emu_fill_holes_and_clear_border(emu):
+    """The two other users of the union-find roots: binary_fill_holes (background labelling) and clear_border."""
+    from scipy import ndimage
+
+    for mask in _label_masks():
+        n, h, w = mask.shape
         work = np.empty(mask.shape, np.int32)
-        count = np.empty(2, np.int32)
-        _ok(emu, emu.pl_label(_p(mask), 2, 45, 61, conn, _p(labels), _p(work), _p(count), None))
-        for f in range(2):
-            want, nl = ndimage.label(mask[f], structure=structure)
-            assert count[f] == nl
-            np.testing.assert_array_equal(labels[f], want)
+        flags = np.empty(mask.shape, np.uint8)
+        for conn_bg, structure in ((4, None), (8, np.ones((3, 3)))):
+            out = np.empty_like(mask)
+            _ok(emu, emu.pl_fill_holes(_p(mask), _p(out), n, h, w, conn_bg, _p(work), _p(flags), None))
+            for f in range(n):
+                # scipy's `structure` is the connectivity of the hole-growing step, i.e. of the BACKGROUND
+                want = ndimage.binary_fill_holes(mask[f], structure=structure)
+                np.testing.assert_array_equal(out[f].astype(bool), want, err_msg=f"fill {mask.shape} {conn_bg}")
+        for buf in (0, 2):
+            out = np.empty_like(mask)
+            _ok(emu, emu.pl_clear_border(_p(mask), _p(out), n, h, w, buf, _p(work), _p(flags), None))
+            for f in range(n):
+                want = orc.clear_border_like_skimage(mask[f].astype(bool), buf)
+                np.testing.assert_array_equal(out[f].astype(bool), want, err_msg=f"clear {mask.shape} {buf}")
 
 
 # ---- host layer + kernels together on the emulated device (tests/emu_backend.py) ---------------------------------
