@@ -188,6 +188,34 @@ class PhantomRegion:
 
     area_bbox = bbox_area
 
+    def _moments(self):
+        """raw sums over the region's pixels in bbox-local (row, col) coordinates -> n, centroid, central second moments"""
+        rc = torch.nonzero(self.image).to(torch.float64)
+        n = rc.shape[0]
+        cen = rc.mean(dim=0)
+        d = rc - cen
+        mu20 = float((d[:, 0] * d[:, 0]).sum())        # rows
+        mu02 = float((d[:, 1] * d[:, 1]).sum())        # columns
+        mu11 = float((d[:, 0] * d[:, 1]).sum())
+        return n, (float(cen[0]), float(cen[1])), (mu20, mu02, mu11)
+
+    @property
+    def centroid(self) -> tuple:
+        """regionprops.centroid: (row, col) in image coordinates"""
+        _, (r, c), _ = self._moments()
+        return (r + self.bbox[0], c + self.bbox[1])
+
+    @property
+    def orientation(self) -> float:
+        """regionprops.orientation (scikit-image 0.18.3, used at planar_imaging.py:2348, 2498): the angle between the
+        row axis and the major axis of the region's inertia ellipse, from the normalised central second moments
+        (inertia tensor [[mu02, -mu11], [-mu11, mu20]] / n)."""
+        n, _, (mu20, mu02, mu11) = self._moments()
+        a, b, c = mu02 / n, -mu11 / n, mu20 / n
+        if a - c == 0:
+            return -math.pi / 4.0 if b < 0 else math.pi / 4.0
+        return 0.5 * math.atan2(-2 * b, c - a)
+
     @property
     def bbox_center_xy(self) -> tuple:
         """core/roi.py bbox_center: Point(x, y) of the bbox middle"""

@@ -59,6 +59,8 @@ def check_phantom_outline(golden, dev, names=None):
         assert region.label == big + 1 and region.bbox == tuple(int(v) for v in g[f"{n}.bbox"][big]), n
         assert region.bbox_area == size
         assert np.array_equal(region.image.cpu().numpy(), g[f"{n}.region_image"]), n
+        assert np.allclose(region.centroid, g[f"{n}.centroid"], rtol=0, atol=1e-9), n
+        assert abs(region.orientation - float(g[f"{n}.orientation"])) < 1e-9, (n, region.orientation)
         hs, _, di = canny.hough_line(region.image, theta=g[f"{n}.theta"])
         assert np.array_equal(hs.cpu().numpy().astype(np.uint64), g[f"{n}.hspace"]), n
         assert np.array_equal(di, g[f"{n}.dists"]), n
