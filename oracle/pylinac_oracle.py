@@ -888,8 +888,20 @@ def canny(image: np.ndarray, sigma=1.0, low_threshold=None, high_threshold=None,
     pylinac/planar_imaging.py:577-583.  Gaussian(mode='constant') normalised by the smoothed all-ones mask, Sobel,
     hypot, interior mask, four-sector interpolated non-maximum suppression, thresholds (absolute / np.percentile of the
     magnitude), hysteresis over 8-connected segments of the low mask."""
-    low_threshold = 0.1 if low_threshold is None else low_threshold
-    high_threshold = 0.2 if high_threshold is None else high_threshold
+    # integer images: skimage.filters.gaussian runs img_as_float first (util/dtype.py _convert: unsigned x * (1 / imax),
+    # signed (x + 0.5) * (2 / (imax - imin)), float64) and absolute thresholds are divided by dtype_max = imax
+    dtype_max = 1.0
+    if image.dtype.kind == "u":
+        dtype_max = float(np.iinfo(image.dtype).max)
+        image = np.multiply(image, 1.0 / dtype_max, dtype=np.float64)
+    elif image.dtype.kind == "i":
+        info = np.iinfo(image.dtype)
+        dtype_max = float(info.max)
+        image = np.add(image, 0.5, dtype=np.float64)
+        image *= 2 / (float(info.max) - info.min)
+    scale = 1.0 if use_quantiles else dtype_max
+    low_threshold = 0.1 if low_threshold is None else low_threshold / scale
+    high_threshold = 0.2 if high_threshold is None else high_threshold / scale
     g = lambda a: ndimage.gaussian_filter(a, sigma, mode="constant", cval=0, truncate=4.0)   # noqa: E731
     smoothed = g(image.astype(float)) / (g(np.ones(image.shape)) + np.finfo(float).eps)
     js, is_ = ndimage.sobel(smoothed, axis=1), ndimage.sobel(smoothed, axis=0)

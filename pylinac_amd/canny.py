@@ -2,7 +2,7 @@
 phantom finder calls it (pylinac/planar_imaging.py:574-588: ``feature.canny(image, sigma, low_threshold,
 high_threshold, use_quantiles=True)``; scikit-image 0.18.3 semantics, skimage/feature/_canny.py).
 
-Float64 images, ``mask=None``.  Every stage is a kernel: Gaussian smoothing with zero padding normalised by the
+Float64 and uint8 / uint16 / int16 images (the latter through skimage's ``img_as_float`` scaling), ``mask=None``.  Every stage is a kernel: Gaussian smoothing with zero padding normalised by the
 smoothed all-ones frame, the two Sobel gradients, hypot + interpolated non-maximum suppression, exact float64 order
 statistics for the quantile thresholds, and hysteresis by 8-connected labelling.
 """
@@ -15,37 +15,56 @@ from . import _lib, ops
 from ._lib import check
 
 
+# integer dtypes skimage's img_as_float rescales: (imin, imax)
+_IMG_AS_FLOAT = {torch.uint8: (0, 255), torch.uint16: (0, 65535), torch.int16: (-32768, 32767)}
+
+
 def canny(image, sigma: float = 1.0, low_threshold=None, high_threshold=None, mask=None,
           use_quantiles: bool = False, device=None) -> torch.Tensor:
     """-> uint8 edge map(s) with the shape of ``image`` ([H, W] or a batch [N, H, W])."""
     if mask is not None:
         raise NotImplementedError("canny(mask=...) is not built; pylinac calls it without a mask")
     t = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image))
-    if t.dtype != torch.float64:
-        raise TypeError("canny needs a float64 image (integer images are rescaled by skimage's img_as_float: not built)")
+    if t.dtype not in _IMG_AS_FLOAT and t.dtype != torch.float64:
+        raise TypeError("canny needs a float64, uint8, uint16 or int16 image")
     dev = t.device if t.is_cuda else (torch.device(device) if device is not None
                                       else torch.device("cuda", torch.cuda.current_device()))
     t = t.to(dev).contiguous()
-    batched = t.ndim == 3
     if t.ndim not in (2, 3):
         raise ValueError("The parameter `image` must be a 2-dimensional array")      # check_nD(image, 2)
+    if t.dtype in _IMG_AS_FLOAT:
+        # skimage.filters.gaussian converts integer images with img_as_float before smoothing (util/dtype.py _convert):
+        # unsigned: x * (1 / imax); signed: (x + 0.5) * (2 / (imax - imin)), in float64.  The division by 1 is the exact
+        # integer -> float64 conversion; the thresholds of non-quantile calls are divided by dtype_max = imax.
+        imin, imax = _IMG_AS_FLOAT[t.dtype]
+        frames = t if t.ndim == 3 else t[None]
+        f = ops.normalize(frames, 1.0)
+        if imin < 0:
+            f = ops.ground(f, value=0.5, mn=torch.zeros(f.shape[0], dtype=torch.float64, device=dev))
+            f = ops.scale(f, 2.0 / (float(imax) - float(imin)))
+        else:
+            f = ops.scale(f, 1.0 / imax)
+        t = f if t.ndim == 3 else f[0]
+        dtype_max = float(imax)
+    else:
+        dtype_max = 1.0                       # dtype_limits(float image, clip_negative=False)[1]
+    batched = t.ndim == 3
     x = t if batched else t[None]
     n, h, w = x.shape
-    # dtype_limits(float image, clip_negative=False)[1] == 1
     if low_threshold is None:
         low_threshold = 0.1
     elif use_quantiles:
         if not 0.0 <= low_threshold <= 1.0:
             raise ValueError("Quantile thresholds must be between 0 and 1.")
     else:
-        low_threshold = low_threshold / 1.0
+        low_threshold = low_threshold / dtype_max
     if high_threshold is None:
         high_threshold = 0.2
     elif use_quantiles:
         if not 0.0 <= high_threshold <= 1.0:
             raise ValueError("Quantile thresholds must be between 0 and 1.")
     else:
-        high_threshold = high_threshold / 1.0
+        high_threshold = high_threshold / dtype_max
     lib, st = _lib.load(), torch.cuda.current_stream(dev).cuda_stream
     g_img = ops.gaussian_filter_mode(x, sigma, mode="constant")
     g_one = ops.gaussian_filter_mode(torch.ones((1, h, w), dtype=torch.float64, device=dev), sigma, mode="constant")

@@ -849,6 +849,8 @@ def main():
     # ---- 21. contrast ROIs: the reference's own LowContrastDiskROI / HighContrastDiskROI + core.contrast (f3)
     subprocess.run([PY39, os.path.join(HERE, "skimage_contrast_py39.py"), os.path.join(HERE, "roi.npz"),
                     os.path.join(HERE, "contrast.npz"), ROOT], check=True)
+    # ---- 22. canny on integer images (scikit-image 0.18.3 itself)
+    subprocess.run([PY39, os.path.join(HERE, "skimage_canny_int_py39.py"), os.path.join(HERE, "canny_int.npz")], check=True)
     # (hill.npz and starshot.npz have their own generators: make_hill_golden.py, make_starshot_golden.py)
 
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)

@@ -273,3 +273,15 @@ def check_contrast_rois(golden, dev):
         con.contrast(v, "nope")
     with np.testing.assert_raises(ValueError):
         con.rms(np.array([0.5, 1.5]))
+
+
+def check_canny_integer_images(golden, dev):
+    """canny on uint8 / uint16 / int16 images (img_as_float scaling, dtype_max-scaled absolute thresholds) against
+    scikit-image 0.18.3's own feature.canny: identical edge maps."""
+    from pylinac_amd import canny
+
+    g = golden("canny_int")
+    for n in g["names"]:
+        kw = eval(str(g[f"{n}.kw"]), {"__builtins__": {}}, {"dict": dict})
+        got = canny.canny(torch.from_numpy(g[f"{n}.img"]).to(dev), **kw)
+        assert np.array_equal(got.cpu().numpy().astype(bool), g[f"{n}.edges"]), n

@@ -299,3 +299,9 @@ def test_emulated_contrast_rois(golden, emulated):
     import next_row_checks as checks
 
     checks.check_contrast_rois(golden, emulated)
+
+
+def test_emulated_canny_integer_images(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_canny_integer_images(golden, emulated)

@@ -1396,6 +1396,13 @@ def test_canny_vs_skimage_golden(golden, dev):
         pc.canny(img.astype(np.float32), device=dev)
 
 
+def test_canny_integer_images_vs_skimage_golden(golden, dev):
+    """canny on uint8 / uint16 / int16 images: identical edge maps to scikit-image 0.18.3 (img_as_float scaling)."""
+    import next_row_checks as checks
+
+    checks.check_canny_integer_images(golden, dev)
+
+
 def test_hough_line_vs_skimage_golden(golden, dev):
     """pl_hough_line against scikit-image 0.18.3's transform.hough_line: identical accumulators, angles and bins."""
     from pylinac_amd import canny as pc

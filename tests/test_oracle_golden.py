@@ -601,6 +601,15 @@ def test_canny_restatement_matches_skimage(golden):
         assert np.array_equal(o.canny(img, **kw), want), (k, kw)
 
 
+def test_canny_integer_images_restatement_matches_skimage(golden):
+    """oracle.canny on uint8 / uint16 / int16 images (img_as_float inside skimage.filters.gaussian, absolute thresholds
+    divided by dtype_max) against scikit-image 0.18.3's feature.canny: identical edge maps."""
+    g = golden("canny_int")
+    for n in g["names"]:
+        kw = eval(str(g[f"{n}.kw"]), {"__builtins__": {}}, {"dict": dict})
+        assert np.array_equal(o.canny(g[f"{n}.img"], **kw), g[f"{n}.edges"]), n
+
+
 def test_hough_line_restatement_matches_skimage(golden):
     """f2 (second half): oracle.hough_line against scikit-image 0.18.3's compiled transform.hough_line (default angles,
     pylinac's 40-50 degree band at 0.01 degree, a half-degree sweep): accumulator, angles and distance bins identical."""
