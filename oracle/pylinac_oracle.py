@@ -1891,3 +1891,22 @@ class StarshotRestated:
             phi = phi - 180 if phi > 90 else (phi + 180 if phi <= -90 else phi)
             self.angles.append(phi)
         self.passed = bool(self.wobble_radius_mm * 2 < self.tolerance)
+
+
+# --------------------------------------------------------------------------------------
+# "next" row f1, DICOM half: _rescale_dicom_values (pylinac/core/image.py:363-389).  PARITY UNPINNED: the rescale itself
+# is pydicom's pixels.apply_rescale (pydicom>=2.0,<3 per the reference's pyproject.toml; not installed here), restated
+# from its documented behaviour; nothing in this container can run it.
+# --------------------------------------------------------------------------------------
+
+def rescale_dicom_values(unscaled: np.ndarray, rescale_slope=None, rescale_intercept=None,
+                         pixel_intensity_relationship_sign=None, raw_pixels=False, invert_pixels=None) -> np.ndarray:
+    if raw_pixels:
+        return unscaled
+    scaled = unscaled
+    if rescale_slope is not None and rescale_intercept is not None:
+        scaled = unscaled.astype(np.float64) * float(rescale_slope)
+        scaled += float(rescale_intercept)
+    if invert_pixels or (invert_pixels is None and pixel_intensity_relationship_sign == -1):
+        scaled = scaled.max() - scaled + scaled.min()
+    return scaled

@@ -18,6 +18,29 @@ from . import ops
 MM_PER_INCH = 25.4
 
 
+def rescale_dicom_values(frames: torch.Tensor, rescale_slope=None, rescale_intercept=None,
+                         pixel_intensity_relationship_sign=None, raw_pixels: bool = False,
+                         invert_pixels: bool | None = None) -> torch.Tensor:
+    """``_rescale_dicom_values`` (pylinac/core/image.py:363-389) for a device batch [N, H, W] of stored pixel values,
+    with the three DICOM tags passed as numbers (None = tag absent).
+
+    ``pixels.apply_rescale`` is pydicom's (``pydicom>=2.0,<3`` in the reference's pyproject; absent from this
+    container): when both tags exist, ``arr.astype(float64) * RescaleSlope`` then ``+= RescaleIntercept``; otherwise
+    the array is returned as stored.  **Parity unpinned**: pydicom cannot be run here, so this restates its published
+    behaviour; the inversion that follows is the reference's own expression ``max - a + min`` per frame."""
+    x = ops._frames(frames)
+    if raw_pixels:
+        return x
+    if rescale_slope is not None and rescale_intercept is not None:
+        f = ops.normalize(x, 1.0) if x.dtype != torch.float64 else x          # exact conversion to float64
+        f = ops.scale(f, float(rescale_slope))
+        x = ops.ground(f, value=float(rescale_intercept),
+                       mn=torch.zeros(f.shape[0], dtype=torch.float64, device=f.device))     # (a - 0) + intercept
+    if invert_pixels or (invert_pixels is None and pixel_intensity_relationship_sign == -1):
+        x = ops.invert(x)                                                       # -a + max + min == max - a + min
+    return x
+
+
 class _MutatorMixin:
     """The reference's in-place API; subclasses provide ``array`` (numpy or device tensor)."""
 

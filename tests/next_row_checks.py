@@ -285,3 +285,20 @@ def check_canny_integer_images(golden, dev):
         kw = eval(str(g[f"{n}.kw"]), {"__builtins__": {}}, {"dict": dict})
         got = canny.canny(torch.from_numpy(g[f"{n}.img"]).to(dev), **kw)
         assert np.array_equal(got.cpu().numpy().astype(bool), g[f"{n}.edges"]), n
+
+
+def check_rescale_dicom_values(dev):
+    """image.rescale_dicom_values against the oracle restatement (PARITY UNPINNED: pydicom's apply_rescale cannot be run
+    here): uint16 / int16 stored values, CT-like and EPID-like tags, forced / tag-driven / suppressed inversion."""
+    from oracle import pylinac_oracle as o
+    from pylinac_amd import image
+
+    rng = np.random.default_rng(31)
+    for arr in (rng.integers(0, 65535, (2, 33, 47)).astype(np.uint16), rng.integers(-2000, 3000, (2, 20, 64)).astype(np.int16)):
+        for kw in (dict(rescale_slope=1.0, rescale_intercept=-1024.0), dict(rescale_slope=0.00036621, rescale_intercept=-3.7e-5,
+                                                                            pixel_intensity_relationship_sign=-1),
+                   dict(rescale_slope=2.5, rescale_intercept=10.0, pixel_intensity_relationship_sign=-1, invert_pixels=False),
+                   dict(invert_pixels=True), dict(), dict(rescale_slope=3.0, rescale_intercept=1.0, raw_pixels=True)):
+            got = image.rescale_dicom_values(torch.from_numpy(arr).to(dev), **kw).cpu().numpy()
+            want = np.stack([o.rescale_dicom_values(f, **kw) for f in arr])
+            assert got.dtype == want.dtype and np.array_equal(got, want), (arr.dtype, kw)

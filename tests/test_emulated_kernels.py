@@ -305,3 +305,9 @@ def test_emulated_canny_integer_images(golden, emulated):
     import next_row_checks as checks
 
     checks.check_canny_integer_images(golden, emulated)
+
+
+def test_emulated_rescale_dicom_values(emulated):
+    import next_row_checks as checks
+
+    checks.check_rescale_dicom_values(emulated)

@@ -1396,6 +1396,14 @@ def test_canny_vs_skimage_golden(golden, dev):
         pc.canny(img.astype(np.float32), device=dev)
 
 
+def test_rescale_dicom_values_vs_oracle(dev):
+    """f1 (DICOM half; parity UNPINNED -- pydicom is absent from the build container): device rescale / inversion against
+    the oracle's restatement of pydicom's apply_rescale + the reference's own inversion expression."""
+    import next_row_checks as checks
+
+    checks.check_rescale_dicom_values(dev)
+
+
 def test_canny_integer_images_vs_skimage_golden(golden, dev):
     """canny on uint8 / uint16 / int16 images: identical edge maps to scikit-image 0.18.3 (img_as_float scaling)."""
     import next_row_checks as checks
