@@ -23,7 +23,10 @@ For those two levels this file holds
       reference's own code (tests/golden/make_golden.py, tests/test_oracle_golden.py).
 
 Parity status: pinned (reference KATs of SURVEY.md section 8c + golden vectors generated
-by importing the reference through oracle/ref_loader.py).
+by importing the reference through oracle/ref_loader.py, and by scikit-image 0.18.3 itself for the
+skimage-level restatements), with ONE exception: ``rescale_dicom_values`` is PARITY UNPINNED -- its
+arithmetic is pydicom's ``pixels.apply_rescale`` (``pydicom>=2.0,<3``), which is not installed in
+the build container, so nothing here could run it.
 """
 from __future__ import annotations
 
