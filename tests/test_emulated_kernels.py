@@ -311,3 +311,79 @@ def test_emulated_rescale_dicom_values(emulated):
     import next_row_checks as checks
 
     checks.check_rescale_dicom_values(emulated)
+
+
+def test_emu_stencils_on_awkward_shapes(emu):
+    """Gaussian / median / Sobel on frames smaller than the stencil, one-row / one-column frames and odd widths (halos
+    that reflect more than once; the packed kernels' shape guards): scipy-exact for every shape."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(12)
+    shapes = [(1, 1), (1, 7), (7, 1), (2, 3), (3, 2), (5, 64), (64, 5), (9, 33), (17, 66), (33, 130), (40, 2)]
+    for h, w in shapes:
+        for dt, code in ((np.uint16, PL_U16), (np.float64, PL_F64), (np.int16, PL_I16)):
+            if dt == np.float64:
+                f = rng.normal(size=(2, h, w))
+            else:
+                info = np.iinfo(dt)
+                f = rng.integers(info.min, info.max, (2, h, w)).astype(dt)
+            for sigma in (1, 2, 5):
+                radius = int(4.0 * sigma + 0.5)
+                x = np.arange(-radius, radius + 1)
+                wts = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+                wts = np.ascontiguousarray(wts / wts.sum())
+                out, tmp = np.empty_like(f), np.empty_like(f)
+                _ok(emu, emu.pl_gaussian2d(_p(f), _p(out), _p(tmp), code, 2, h, w, _p(wts), radius, None))
+                want = np.stack([ndimage.gaussian_filter(a, sigma) for a in f])
+                np.testing.assert_array_equal(out, want, err_msg=f"gaussian {dt.__name__} {h}x{w} sigma {sigma}")
+            for size in (3, 5):
+                out = np.empty_like(f)
+                _ok(emu, emu.pl_median2d(_p(f), _p(out), code, 2, h, w, size, None))
+                want = np.stack([ndimage.median_filter(a, size=size) for a in f])
+                np.testing.assert_array_equal(out, want, err_msg=f"median {dt.__name__} {h}x{w} size {size}")
+            if dt == np.float64:
+                for axis in (0, 1):
+                    out = np.empty_like(f)
+                    _ok(emu, emu.pl_sobel(_p(f), _p(out), code, 2, h, w, axis, None))
+                    want = np.stack([ndimage.sobel(a, axis=axis) for a in f])
+                    np.testing.assert_array_equal(out, want, err_msg=f"sobel {h}x{w} axis {axis}")
+
+
+def test_emulated_find_peaks_sweep(emulated):
+    """pl_find_peaks through the host layer on short, flat, plateau-rich and noisy profiles with the argument
+    combinations the analyzers use: indices exact, properties to 1e-12 of scipy.signal.find_peaks (the oracle calls it
+    as the reference does).  Profiles whose peaks tie exactly on the sort key are skipped (np.argsort's tie order)."""
+    from pylinac_amd import profile
+
+    rng = np.random.default_rng(21)
+    profs = [np.array([0.0, 1, 0]), np.array([0.0, 1, 1, 0]), np.array([1.0, 1, 1, 1]), np.array([0.0, 2, 1, 2, 0, 3, 0]),
+             np.arange(9.0), np.array([0.0, 1, 2, 3, 4, 3, 2, 1, 0])]
+    for L in (5, 12, 63, 64, 65, 200, 1030):
+        for _ in range(3):
+            profs.append(np.round(rng.random(L) * 20) / 4)                       # plateaus and ties
+            x = np.linspace(0, 1, L)
+            profs.append(sum(np.exp(-0.5 * ((x - c) / 0.03) ** 2) * a for c, a in ((0.2, 1.0), (0.5, 0.7), (0.8, 1.3)))
+                         + rng.normal(0, 0.01, L))
+    combos = [dict(), dict(threshold=0.3, peak_separation=0.05), dict(threshold=0.5, peak_separation=3, max_number=2),
+              dict(fwxm_height=0.8, max_number=1), dict(threshold=0.1, required_prominence=0.2, peak_sort="peak_heights"),
+              dict(search_region=(0.2, 0.9), threshold=0.2), dict(min_width=2, peak_separation=0.02)]
+    checked = 0
+    for v in profs:
+        for kw in combos:
+            try:
+                widx, wprops = orc.find_peaks(v, **kw)
+            except (IndexError, ValueError) as exc:
+                with pytest.raises(type(exc)):
+                    profile.find_peaks(v, **kw)
+                continue
+            key = wprops[kw.get("peak_sort", "prominences")]
+            if len(np.unique(key)) != len(key) or len(np.unique(wprops["peak_heights"])) != len(key):
+                continue
+            idx, props = profile.find_peaks(v, **kw)
+            np.testing.assert_array_equal(idx, widx, err_msg=f"{len(v)} {kw}")
+            for k in ("peak_heights", "prominences", "left_ips", "right_ips", "widths", "width_heights"):
+                np.testing.assert_allclose(props[k], wprops[k], rtol=1e-12, atol=1e-12, err_msg=f"{k} {len(v)} {kw}")
+            for k in ("left_bases", "right_bases"):
+                np.testing.assert_array_equal(props[k], wprops[k], err_msg=f"{k} {len(v)} {kw}")
+            checked += 1
+    assert checked > 150
