@@ -174,13 +174,17 @@ def check_hill_and_penumbra(g, make_profile, tol=1e-9, only=None, spline_tol=Non
                 continue
             raise AssertionError(f"{tag}: the reference raised {g[tag + '.error']}")
         p = make_profile(values.copy(), _HILL_EDGES[edge], **kw)
-        t = spline_tol if (spline_tol and edge == "hill" and kw.get("interpolation") == "Spline") else tol
+        # Hill fits: MINPACK stops at a relative tolerance of 1.5e-8 and numpy's vectorised pow() is not bit-reproducible
+        # from run to run (SIMD body vs scalar remainder depends on buffer alignment), so even the reference against
+        # itself reproduces fitted parameters only to ~1e-8..1e-6 (ill-conditioned slope / plateau parameters): everything
+        # downstream of a fit is held to 1e-5 (the reference's own Hill tests use deltas of 0.01-0.1)
+        t = max(tol, spline_tol or 0.0, 1e-5) if edge == "hill" else tol
 
         def close(a, b, what, t=t):
             a, b = np.asarray(a, float), np.asarray(b, float)
             assert a.shape == b.shape and np.allclose(a, b, rtol=t, atol=t), (tag, what, a, b)
 
-        close(p.values, g[f"{tag}.values"], "values")
+        close(p.values, g[f"{tag}.values"], "values", t)
         if edge == "hill":
             inf = p.inflection_data()
             close([inf[k] for k in g["hill_keys"]], g[f"{tag}.infl"], "inflection")
