@@ -339,3 +339,26 @@ class HighContrastDiskROI(DiskROI):
                             contrast_threshold: float):
         base = DiskROI.from_phantom_center(array, angle, roi_radius, dist_from_center, phantom_center)
         return cls(base._array, roi_radius, base.center, contrast_threshold)
+
+
+class ThicknessROI(RectangleROI):
+    """pylinac/ct.py:300-313: the slice-thickness wire ramp of the CatPhan HU module -- Gaussian(1) of the unrotated
+    rectangle window, maximum along its short axis, FWHM of the resulting profile."""
+
+    @property
+    def long_profile(self):
+        from .profile import FWXMProfile
+
+        win = self.pixel_array.contiguous()
+        smooth = ops.gaussian_filter(win[None], 1)                         # image.load(pixel_array).filter(1, "gaussian")
+        axis = int(np.argmin(win.shape))
+        prof = ops.reduce_axis(smooth, axis, "max")[0].cpu().numpy().astype(_NP_OF[win.dtype])
+        return FWXMProfile(values=prof)
+
+    @property
+    def wire_fwhm(self) -> float:
+        return self.long_profile.field_width_px
+
+
+_NP_OF = {torch.uint8: np.uint8, torch.uint16: np.uint16, torch.int16: np.int16, torch.int32: np.int32,
+          torch.int64: np.int64, torch.float32: np.float32, torch.float64: np.float64}

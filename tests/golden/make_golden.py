@@ -851,6 +851,8 @@ def main():
                     os.path.join(HERE, "contrast.npz"), ROOT], check=True)
     # ---- 22. canny on integer images (scikit-image 0.18.3 itself)
     subprocess.run([PY39, os.path.join(HERE, "skimage_canny_int_py39.py"), os.path.join(HERE, "canny_int.npz")], check=True)
+    # ---- 23. ThicknessROI: the reference's own pylinac.ct.ThicknessROI on synthetic wire ramps
+    subprocess.run([PY39, os.path.join(HERE, "skimage_thickness_py39.py"), os.path.join(HERE, "thickness.npz"), ROOT], check=True)
     # (hill.npz and starshot.npz have their own generators: make_hill_golden.py, make_starshot_golden.py)
 
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)

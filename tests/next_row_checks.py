@@ -306,3 +306,20 @@ def check_rescale_dicom_values(dev):
             got = image.rescale_dicom_values(torch.from_numpy(arr).to(dev), **kw).cpu().numpy()
             want = np.stack([o.rescale_dicom_values(f, **kw) for f in arr])
             assert got.dtype == want.dtype and np.array_equal(got, want), (arr.dtype, kw)
+
+
+def check_thickness_roi(golden, dev):
+    """ThicknessROI.wire_fwhm / long_profile against the reference's own pylinac.ct.ThicknessROI (int16 and float64 slices,
+    wires along x and along y)."""
+    from pylinac_amd import roi
+
+    g = golden("thickness")
+    for k, (cx, cy, width, height) in enumerate(g["specs"]):
+        r = roi.ThicknessROI(torch.from_numpy(g[f"img{k}"]).to(dev), width=width, height=height, center=(cx, cy))
+        prof = r.long_profile
+        if g[f"img{k}"].dtype.kind == "i":      # integer windows: the truncating Gaussian is bit-exact
+            assert np.array_equal(np.asarray(prof.values, float), g[f"profile{k}"]), k
+        else:                                   # float windows: same taps, summation order may differ in the last ulp
+            assert np.allclose(np.asarray(prof.values, float), g[f"profile{k}"], rtol=1e-13, atol=0), k
+        want = g["results"][k]
+        assert abs(r.wire_fwhm - want[0]) <= 1e-9 * want[0] and len(prof.values) == int(want[1]), (k, r.wire_fwhm, want)

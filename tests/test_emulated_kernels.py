@@ -387,3 +387,9 @@ def test_emulated_find_peaks_sweep(emulated):
                 np.testing.assert_array_equal(props[k], wprops[k], err_msg=f"{k} {len(v)} {kw}")
             checked += 1
     assert checked > 150
+
+
+def test_emulated_thickness_roi(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_thickness_roi(golden, emulated)

@@ -1505,6 +1505,13 @@ def test_contrast_rois_vs_reference_golden(golden, dev):
     checks.check_contrast_rois(golden, dev)
 
 
+def test_thickness_roi_vs_reference_golden(golden, dev):
+    """f3: ThicknessROI (CatPhan slice-thickness ramps) against the reference's own pylinac.ct.ThicknessROI."""
+    import next_row_checks as checks
+
+    checks.check_thickness_roi(golden, dev)
+
+
 def test_rectangle_roi_vs_reference_golden(golden, dev):
     """f3 (second half): pl_polygon_roi_stats / RectangleROI against the reference's own RectangleROI (rotated,
     unrotated, clipped) and scikit-image 0.18.3's draw.polygon pixel sets."""
