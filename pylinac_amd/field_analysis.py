@@ -57,3 +57,53 @@ def symmetry_area(profile, in_field_ratio: float, **kwargs) -> float:
     area_left = np.sum(fv[: floor(n / 2)])
     area_right = np.sum(fv[ceil(n / 2):])
     return 100 * (area_left - area_right) / (area_left + area_right)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Strip profiles and centre search (pylinac/field_analysis.py:488-506, 1068-1117)
+# ---------------------------------------------------------------------------------------------------------------
+def _strip_edges(length: int, position: float, width: float) -> tuple:
+    """The reference's rounding of a strip of relative `width` about relative `position` along an axis of `length`."""
+    lo = max(int(round(length * position - length * width / 2)), 0)
+    hi = min(int(round(length * position + length * width / 2) + 1), length)
+    return lo, hi
+
+
+def horiz_values(frames, horiz_position: float, horiz_width: float):
+    """``FieldAnalysis._get_horiz_values`` (:1094-1117) for a device batch -> (float64 [N, W] profiles
+    ``np.mean(array[bottom:top, :], 0)``, bottom_edge, top_edge)."""
+    from . import ops
+
+    x = ops._frames(frames)
+    bottom, top = _strip_edges(x.shape[1], horiz_position, horiz_width)
+    return ops.reduce_axis(x[:, bottom:top, :].contiguous(), 0, "mean"), bottom, top
+
+
+def vert_values(frames, vert_position: float, vert_width: float):
+    """``FieldAnalysis._get_vert_values`` (:1068-1092) -> (float64 [N, H] ``np.mean(array[:, left:right], 1)``, left, right)."""
+    from . import ops
+
+    x = ops._frames(frames)
+    left, right = _strip_edges(x.shape[2], vert_position, vert_width)
+    return ops.reduce_axis(x[:, :, left:right].contiguous(), 1, "mean"), left, right
+
+
+def determine_center(frame, centering="Beam center") -> tuple:
+    """``FieldAnalysis._determine_center`` (:488-506) for one frame -> (vert_ratio, horiz_ratio): the row / column sums
+    (device reductions) through ``SingleProfile`` with its defaults."""
+    from . import ops
+    from .profile import Centering, SingleProfile, _enum
+
+    x = ops._frames(frame)
+    if x.shape[0] != 1:
+        raise ValueError("determine_center takes one frame")
+    vert_sum = ops.reduce_axis(x, 1, "sum")[0].cpu().numpy()
+    horiz_sum = ops.reduce_axis(x, 0, "sum")[0].cpu().numpy()
+    v_prof, h_prof = SingleProfile(vert_sum), SingleProfile(horiz_sum)
+    if _enum(centering, Centering) == Centering.GEOMETRIC_CENTER:
+        horiz_ratio = v_prof.geometric_center()["index (exact)"] / x.shape[1]
+        vert_ratio = h_prof.geometric_center()["index (exact)"] / x.shape[2]
+    else:
+        horiz_ratio = v_prof.beam_center()["index (exact)"] / x.shape[1]
+        vert_ratio = h_prof.beam_center()["index (exact)"] / x.shape[2]
+    return vert_ratio, horiz_ratio

@@ -323,3 +323,30 @@ def check_thickness_roi(golden, dev):
             assert np.allclose(np.asarray(prof.values, float), g[f"profile{k}"], rtol=1e-13, atol=0), k
         want = g["results"][k]
         assert abs(r.wire_fwhm - want[0]) <= 1e-9 * want[0] and len(prof.values) == int(want[1]), (k, r.wire_fwhm, want)
+
+
+def check_field_strips(golden, dev):
+    """Strip profiles and the centre search of FieldAnalysis against the reference's own methods
+    (tests/golden/field_strips.npz): edges identical, uint16 profiles identical, float64 profiles to 1e-12, centre
+    ratios to 1e-9."""
+    from pylinac_amd import field_analysis as fa
+
+    g = golden("field_strips")
+    for name in ("frames", "frames_f64"):
+        frames = torch.from_numpy(g[name]).to(dev)
+        for k, (pos, width) in enumerate(g["specs"]):
+            hv, b, t = fa.horiz_values(frames, pos, width)
+            vv, left, right = fa.vert_values(frames, pos, width)
+            for i in range(frames.shape[0]):
+                assert [b, t, left, right] == list(g[f"{name}.{i}.edges{k}"]), (name, k)
+                for got, key in ((hv[i], "h"), (vv[i], "v")):
+                    want = g[f"{name}.{i}.{key}{k}"]
+                    got = got.cpu().numpy()
+                    if name == "frames":
+                        assert np.array_equal(got, want), (name, i, key, k)
+                    else:
+                        assert np.allclose(got, want, rtol=1e-12, atol=0), (name, i, key, k)
+        for i in range(frames.shape[0]):
+            for cname, c in (("beam", "Beam center"), ("geo", "Geometric center")):
+                got = fa.determine_center(frames[i], c)
+                assert np.allclose(got, g[f"{name}.{i}.center_{cname}"], rtol=1e-9, atol=1e-12), (name, i, cname, got)

@@ -393,3 +393,9 @@ def test_emulated_thickness_roi(golden, emulated):
     import next_row_checks as checks
 
     checks.check_thickness_roi(golden, emulated)
+
+
+def test_emulated_field_strips(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_field_strips(golden, emulated)

@@ -1505,6 +1505,14 @@ def test_contrast_rois_vs_reference_golden(golden, dev):
     checks.check_contrast_rois(golden, dev)
 
 
+def test_field_strips_vs_reference_golden(golden, dev):
+    """a7: FieldAnalysis strip profiles (`np.mean(array[bottom:top, :], 0)` and the vertical twin, with the reference's
+    edge rounding / clipping) and its centre search (axis sums -> SingleProfile) against the reference's own methods."""
+    import next_row_checks as checks
+
+    checks.check_field_strips(golden, dev)
+
+
 def test_thickness_roi_vs_reference_golden(golden, dev):
     """f3: ThicknessROI (CatPhan slice-thickness ramps) against the reference's own pylinac.ct.ThicknessROI."""
     import next_row_checks as checks
