@@ -327,7 +327,11 @@ int pl_gamma1d(const double* d_ref, const double* d_ref_x, int n_ref, const doub
  * between profiles, 0 = shared by all), d_y float64 [n_profiles][length], d_xq float64 [n_query] (shared),
  * kind 0 = "linear" (scipy's slope form, bit-identical), 1 = "cubic" (the not-a-knot interpolating cubic
  * spline, ~1e-13 relative to scipy's B-spline evaluation; length >= 4).  d_work: 3*n_profiles*length doubles
- * for kind 1 (may be NULL for kind 0).  d_out float64 [n_profiles][n_query]. */
+ * for kind 1 (may be NULL for kind 0); after a kind-1 call its first n_profiles*length doubles hold the spline's
+ * second derivatives M[profile][i] at the knots (the piecewise cubic on [x_i, x_i+1], h = x_i+1 - x_i, is
+ * (M_i (x_i+1 - x)^3 + M_i+1 (x - x_i)^3) / (6 h) + (y_i / h - M_i h / 6)(x_i+1 - x) + (y_i+1 / h - M_i+1 h / 6)(x - x_i)),
+ * which host-side optimisers evaluate point by point (InflectionDerivativeProfile.field_edge_idx, profile.py:656-670).
+ * d_out float64 [n_profiles][n_query]. */
 int pl_interp1d(const double* d_x, int64_t x_stride, const double* d_y, int64_t n_profiles, int length,
                 const double* d_xq, int n_query, int kind, double* d_work, double* d_out, void* stream);
 /* np.gradient(y) (unit spacing, edge_order 1) per profile, as SingleProfile.inflection_data takes it of the

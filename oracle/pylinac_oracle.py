@@ -1913,3 +1913,60 @@ def rescale_dicom_values(unscaled: np.ndarray, rescale_slope=None, rescale_inter
     if invert_pixels or (invert_pixels is None and pixel_intensity_relationship_sign == -1):
         scaled = scaled.max() - scaled + scaled.min()
     return scaled
+
+
+# --------------------------------------------------------------------------------------
+# "next" row f4: the new-style edge profiles (pylinac/core/profile.py:612-740)
+# --------------------------------------------------------------------------------------
+
+class EdgeProfileRestated:
+    """ProfileBase (:195-344) + InflectionDerivativeProfile.field_edge_idx (:656-670) + HillProfile.field_edge_idx
+    (:708-728), calling the same scipy routines as the reference (gaussian_filter1d, interp1d cubic, minimize, curve_fit)."""
+
+    def __init__(self, values, x_values=None, ground_profile=False, normalization=None, edge_smoothing_ratio=0.003,
+                 hill_window_ratio=None):
+        values = np.asarray(values, dtype=float)
+        x_values = np.arange(len(values)) if x_values is None else np.asarray(x_values)
+        order = np.argsort(x_values)
+        self.x_values, self.values = x_values[order], values[order]
+        self.smooth, self.hill_window_ratio = edge_smoothing_ratio, hill_window_ratio
+        if ground_profile:
+            self.values = ground(self.values)
+        if normalization == "Max":
+            self.values = self.values / self.values.max()
+        elif normalization == "Beam center":
+            c = self.center_idx
+            self.values = self.values / float(np.interp(c, self.x_values, self.values))
+
+    def x_at_x_idx(self, idx):
+        return float(np.interp(idx, np.arange(len(self.x_values)), self.x_values))
+
+    def _inflection(self, side):
+        from scipy.interpolate import interp1d
+        from scipy.optimize import minimize
+
+        diff = np.gradient(ndimage.gaussian_filter1d(self.values, sigma=self.smooth * len(self.values)))
+        f_diff = interp1d(x=self.x_values, y=diff, kind="cubic")
+        if side == "left":
+            return minimize(lambda x: -f_diff(x), x0=self.x_at_x_idx(np.argmax(diff))).x[0]
+        return minimize(f_diff, x0=self.x_at_x_idx(np.argmin(diff))).x[0]
+
+    def field_edge_idx(self, side):
+        if self.hill_window_ratio is None:
+            return self._inflection(side)
+        li, ri = self._inflection("left"), self._inflection("right")
+        win = (ri - li) * self.hill_window_ratio
+        mid = li if side == "left" else ri
+        a = int(np.argmin(np.abs(self.x_values - (mid - win))))
+        b = int(np.argmin(np.abs(self.x_values - (mid + win))))
+        return hill_inflection(hill_fit(self.x_values[a:b + 1], self.values[a:b + 1]))
+
+    @property
+    def center_idx(self):
+        left, right = self.field_edge_idx("left"), self.field_edge_idx("right")
+        return abs(right - left) / 2 + left
+
+    @property
+    def field_width_px(self):
+        left, right = self.field_edge_idx("left"), self.field_edge_idx("right")
+        return max(right, left) - min(right, left)

@@ -652,6 +652,24 @@ def interp1d(x: torch.Tensor, y: torch.Tensor, xq: torch.Tensor, kind: str = "li
     return out if y.ndim == 2 else out[0]
 
 
+def cubic_spline_moments(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Second derivatives at the knots of the not-a-knot cubic spline through (x, y) -- what
+    ``interp1d(x, y, kind="cubic")`` interpolates with -- for ``x`` float64 [L] and ``y`` float64 [N, L] (or [L])
+    -> float64 [N, L].  The tridiagonal solves run on the device (``pl_interp1d``'s workspace, see the header)."""
+    yy = y if y.dim() == 2 else y.unsqueeze(0)
+    yy = yy.to(torch.float64).contiguous()
+    xx = x.to(device=yy.device, dtype=torch.float64).contiguous()
+    n, length = yy.shape
+    if xx.dim() != 1 or xx.numel() != length:
+        raise ValueError("x must be [L] (shared abscissae)")
+    work = torch.empty(3 * n * length, dtype=torch.float64, device=yy.device)
+    xq = xx[:1].clone()
+    out = torch.empty((n, 1), dtype=torch.float64, device=yy.device)
+    check(_lib.load().pl_interp1d(xx.data_ptr(), 0, yy.data_ptr(), n, length, xq.data_ptr(), 1, 1, work.data_ptr(),
+                                  out.data_ptr(), _stream()), "pl_interp1d")
+    return work[: n * length].view(n, length).clone()
+
+
 def gradient1d(y: torch.Tensor) -> torch.Tensor:
     """``np.gradient(y)`` (unit spacing) for [L] or [N, L] float64 profiles."""
     y2 = (y if y.ndim == 2 else y[None]).to(torch.float64).contiguous()

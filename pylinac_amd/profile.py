@@ -154,16 +154,15 @@ def _linear_at(xp: np.ndarray, fp: np.ndarray, x):
     return fp[i] + t * (fp[i + 1] - fp[i])
 
 
-class FWXMProfile:
-    """pylinac/core/profile.py:578-611 on ProfileBase (:195-344): a profile with one large signal
-    whose edges are the FWXM intersections of its most prominent peak."""
+class _ProfileBase:
+    """pylinac/core/profile.py:195-344 (``ProfileBase``): sorting by x, grounding / normalisation, index <-> position
+    look-ups (a k=1, s=0 ``UnivariateSpline`` is piecewise-linear interpolation), centre / width from the subclass's
+    ``field_edge_idx``."""
 
-    def __init__(self, values, x_values=None, ground: bool = False,
-                 normalization=Normalization.NONE, fwxm_height: float = 50):
+    def __init__(self, values, x_values=None, ground: bool = False, normalization=Normalization.NONE):
         values = np.asarray(values)
         if values.ndim > 1:
             raise ValueError(f"Array was multidimensional. Must pass 1D array; found {values.ndim}")
-        self.fwxm_height = fwxm_height
         if x_values is None:
             x_values = np.arange(len(values))
         x_values = np.asarray(x_values)
@@ -199,9 +198,48 @@ class FWXMProfile:
         r = _linear_at(np.arange(len(self.x_values), dtype=float), self.x_values.astype(float), x)
         return float(r) if r.size == 1 else r
 
+    def x_idx_at_x(self, x: float) -> int:
+        """profile.py:269-271: index of the x-value closest to ``x``"""
+        return int(np.argmin(np.abs(self.x_values - x)))
+
     def y_at_x(self, x):
         r = _linear_at(self.x_values.astype(float), np.asarray(self.values, dtype=float), x)
         return float(r) if r.size == 1 else r
+
+    def field_edge_idx(self, side: str) -> float:
+        raise NotImplementedError
+
+    @property
+    def center_idx(self) -> float:
+        left = self.field_edge_idx(LEFT)
+        right = self.field_edge_idx(RIGHT)
+        return abs(right - left) / 2 + left
+
+    @property
+    def geometric_center_idx(self) -> float:
+        """profile.py:329-332"""
+        return self.x_at_x_idx(au.geometric_center_idx(self.values))
+
+    @property
+    def cax_index(self) -> float:
+        """profile.py:334-337"""
+        return self.x_at_x_idx((len(self.x_values) - 1) / 2)
+
+    @property
+    def field_width_px(self) -> float:
+        left = self.field_edge_idx(LEFT)
+        right = self.field_edge_idx(RIGHT)
+        return max(right, left) - min(right, left)
+
+
+class FWXMProfile(_ProfileBase):
+    """pylinac/core/profile.py:578-611: a profile with one large signal whose edges are the FWXM intersections of its
+    most prominent peak."""
+
+    def __init__(self, values, x_values=None, ground: bool = False,
+                 normalization=Normalization.NONE, fwxm_height: float = 50):
+        self.fwxm_height = fwxm_height
+        super().__init__(values, x_values=x_values, ground=ground, normalization=normalization)
 
     def _edges(self):
         if "edges" not in self._cache:
@@ -214,17 +252,88 @@ class FWXMProfile:
         left, right = self._edges()
         return self.x_at_x_idx(left if side == LEFT else right)
 
-    @property
-    def center_idx(self) -> float:
-        left = self.field_edge_idx(LEFT)
-        right = self.field_edge_idx(RIGHT)
-        return abs(right - left) / 2 + left
 
-    @property
-    def field_width_px(self) -> float:
-        left = self.field_edge_idx(LEFT)
-        right = self.field_edge_idx(RIGHT)
-        return max(right, left) - min(right, left)
+class _CubicOnHost:
+    """The not-a-knot cubic spline ``interp1d(x, y, kind="cubic")`` interpolates with, evaluated point by point on the
+    host from second derivatives the device solved for (``ops.cubic_spline_moments``).  ``bounds_error=True`` like
+    scipy's default: a query outside the knots raises ValueError."""
+
+    def __init__(self, x: np.ndarray, y: np.ndarray, moments: np.ndarray):
+        self.x, self.y, self.m = np.asarray(x, float), np.asarray(y, float), np.asarray(moments, float)
+
+    def __call__(self, xq):
+        v = np.atleast_1d(np.asarray(xq, dtype=float))
+        if (v < self.x[0]).any():
+            raise ValueError("A value in x_new is below the interpolation range.")
+        if (v > self.x[-1]).any():
+            raise ValueError("A value in x_new is above the interpolation range.")
+        hi = np.clip(np.searchsorted(self.x, v, side="left"), 1, len(self.x) - 1)
+        lo = hi - 1
+        h = self.x[hi] - self.x[lo]
+        a, b = self.x[hi] - v, v - self.x[lo]
+        out = ((self.m[lo] * a ** 3 + self.m[hi] * b ** 3) / (6.0 * h) + (self.y[lo] / h - self.m[lo] * h / 6.0) * a
+               + (self.y[hi] / h - self.m[hi] * h / 6.0) * b)
+        return out if np.ndim(xq) else out.reshape(())
+
+
+class InflectionDerivativeProfile(_ProfileBase):
+    """pylinac/core/profile.py:612-680: field edges = the extrema of the derivative of the Gaussian-smoothed profile,
+    refined on its cubic interpolant.  Smoothing, gradient and the spline solve run on the device; the two
+    one-dimensional BFGS refinements are the reference's own ``scipy.optimize.minimize`` calls on the host (SURVEY.md
+    section 8 row f4)."""
+
+    def __init__(self, values, x_values=None, ground: bool = False, normalization=Normalization.NONE,
+                 edge_smoothing_ratio: float = 0.003):
+        self.edge_smoothing_ratio = edge_smoothing_ratio
+        super().__init__(values, x_values=x_values, ground=ground, normalization=normalization)
+
+    def _derivative(self):
+        if "diff" not in self._cache:
+            v = _to_device_profile(np.asarray(self.values, dtype=float))
+            sm = ops.gaussian_filter1d(v[None], self.edge_smoothing_ratio * len(self.values))[0]
+            d1 = ops.gradient1d(sm)
+            xs = torch.from_numpy(np.ascontiguousarray(self.x_values, dtype=np.float64)).to(d1.device)
+            m = ops.cubic_spline_moments(xs, d1)[0]
+            diff = d1.cpu().numpy()
+            self._cache["diff"] = (diff, _CubicOnHost(self.x_values, diff, m.cpu().numpy()))
+        return self._cache["diff"]
+
+    def _inflection_edge(self, side: str) -> float:
+        from scipy.optimize import minimize
+
+        key = "infl_" + side
+        if key not in self._cache:
+            diff, f_diff = self._derivative()
+            if side == LEFT:
+                initial_guess = self.x_at_x_idx(np.argmax(diff))
+                self._cache[key] = minimize(lambda x: -f_diff(x), x0=initial_guess).x[0]
+            else:
+                initial_guess = self.x_at_x_idx(np.argmin(diff))
+                self._cache[key] = minimize(f_diff, x0=initial_guess).x[0]
+        return self._cache[key]
+
+    def field_edge_idx(self, side: str) -> float:
+        """profile.py:656-670"""
+        return self._inflection_edge(side)
+
+
+class HillProfile(InflectionDerivativeProfile):
+    """pylinac/core/profile.py:682-740: a Hill function fitted to a window about each inflection edge."""
+
+    def __init__(self, values, x_values=None, ground: bool = False, normalization=Normalization.NONE,
+                 edge_smoothing_ratio: float = 0.003, hill_window_ratio: float = 0.1):
+        self.hill_window_ratio = hill_window_ratio
+        super().__init__(values, x_values=x_values, ground=ground, normalization=normalization,
+                         edge_smoothing_ratio=edge_smoothing_ratio)
+
+    def field_edge_idx(self, side: str) -> float:
+        """profile.py:708-728"""
+        left_infl, right_infl = self._inflection_edge(LEFT), self._inflection_edge(RIGHT)
+        window_size = (right_infl - left_infl) * self.hill_window_ratio
+        mid = left_infl if side == LEFT else right_infl
+        left_idx, right_idx = self.x_idx_at_x(mid - window_size), self.x_idx_at_x(mid + window_size)
+        fit = Hill.fit(x_data=self.x_values[left_idx:right_idx + 1], y_data=self.values[left_idx:right_idx + 1])
+        return fit.inflection_idx()["index (exact)"]
 
 
 class CircleProfile(MultiProfile):

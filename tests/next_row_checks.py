@@ -350,3 +350,46 @@ def check_field_strips(golden, dev):
             for cname, c in (("beam", "Beam center"), ("geo", "Geometric center")):
                 got = fa.determine_center(frames[i], c)
                 assert np.allclose(got, g[f"{name}.{i}.center_{cname}"], rtol=1e-9, atol=1e-12), (name, i, cname, got)
+
+
+# ---------------------------------------------------------------------------------------------- new-style edge profiles
+def edge_profile_cases(g):
+    """(tag, kind, values, kwargs) for tests/golden/edge_profiles.npz; kwargs in the reference's constructor names"""
+    for i in range(20):
+        x, y = g[f"fx{i}.x"], g[f"fx{i}.y"]
+        yield f"fx{i}.infl", "infl", y, dict(x_values=x)
+        yield f"fx{i}.infl_ground_max", "infl", y, dict(x_values=x, ground=True, normalization="Max", edge_smoothing_ratio=0.01)
+        yield f"fx{i}.hill", "hill", y, dict(x_values=x, hill_window_ratio=0.3)
+    yield "epid.infl", "infl", g["epid.y"], dict()
+    yield "epid.hill", "hill", g["epid.y"], dict()
+    yield "epid.hill_beam", "hill", g["epid.y"], dict(normalization="Beam center", hill_window_ratio=0.2)
+    for k in range(3):
+        yield f"fff{k}.infl", "infl", g[f"fff{k}.y"], dict(x_values=g[f"fff{k}.x"])
+        yield f"fff{k}.hill", "hill", g[f"fff{k}.y"], dict(x_values=g[f"fff{k}.x"], hill_window_ratio=0.15)
+
+
+def check_edge_profiles(g, make, only=None):
+    """`make(kind, values, **kw)` -> an object with field_edge_idx / center_idx / field_width_px (+ optionally
+    geometric_center_idx / cax_index).  Edges come out of BFGS on a cubic interpolant (gtol 1e-5) and, for "hill", a
+    curve_fit on top: held to 1e-5 of the profile's extent (these optimisers are not bit-reproducible run to run)."""
+    n = 0
+    for tag, kind, values, kw in edge_profile_cases(g):
+        if only is not None and not only(tag):
+            continue
+        if f"{tag}.error" in g:
+            try:
+                p = make(kind, values.copy(), **kw)
+                p.field_edge_idx("left"), p.field_edge_idx("right")
+            except (ValueError, IndexError, RuntimeError, TypeError):
+                continue
+            raise AssertionError(f"{tag}: the reference raised {g[tag + '.error']}")
+        p = make(kind, values.copy(), **kw)
+        want = g[tag]
+        x = kw.get("x_values")
+        extent = float(np.ptp(x)) if x is not None else float(len(values))
+        got = [p.field_edge_idx("left"), p.field_edge_idx("right"), p.center_idx, p.field_width_px]
+        assert np.allclose(got, want[:4], rtol=0, atol=1e-5 * extent), (tag, got, want[:4])
+        if hasattr(p, "cax_index"):
+            assert np.allclose([p.geometric_center_idx, p.cax_index], want[4:], rtol=0, atol=1e-9), tag
+        n += 1
+    return n

@@ -399,3 +399,21 @@ def test_emulated_field_strips(golden, emulated):
     import next_row_checks as checks
 
     checks.check_field_strips(golden, emulated)
+
+
+def test_emulated_edge_profiles(golden, emulated):
+    """InflectionDerivativeProfile / HillProfile on the emulated device (a subset; the full set runs with -m gpu)."""
+    import warnings
+
+    import next_row_checks as checks
+    from pylinac_amd import profile
+
+    def make(kind, values, **kw):
+        cls = profile.HillProfile if kind == "hill" else profile.InflectionDerivativeProfile
+        return cls(values, **kw)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        n = checks.check_edge_profiles(golden("edge_profiles"), make,
+                                       only=lambda t: t.startswith(("fx2.", "fx4.", "fx11.", "epid.", "fff1.")))
+    assert n >= 10

@@ -1505,6 +1505,25 @@ def test_contrast_rois_vs_reference_golden(golden, dev):
     checks.check_contrast_rois(golden, dev)
 
 
+def test_edge_profiles_vs_reference_golden(golden, dev):
+    """f4: InflectionDerivativeProfile / HillProfile (profile.py:612-740; device smoothing, gradient and spline solve,
+    host BFGS / curve_fit like the reference) against the reference's own classes on its 20 frozen profiles, an EPID
+    profile and FFF-style profiles: edges / centre / width to 1e-5 of the profile extent, geometric centre and CAX index
+    to 1e-9, and the two profiles the reference rejects."""
+    import warnings
+
+    import next_row_checks as checks
+    from pylinac_amd import profile
+
+    def make(kind, values, **kw):
+        cls = profile.HillProfile if kind == "hill" else profile.InflectionDerivativeProfile
+        return cls(values, **kw)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert checks.check_edge_profiles(golden("edge_profiles"), make) == 65
+
+
 def test_field_strips_vs_reference_golden(golden, dev):
     """a7: FieldAnalysis strip profiles (`np.mean(array[bottom:top, :], 0)` and the vertical twin, with the reference's
     edge rounding / clipping) and its centre search (axis sums -> SingleProfile) against the reference's own methods."""

@@ -450,6 +450,24 @@ def test_hill_edge_and_penumbra_restatement_matches_reference(golden):
         assert checks.check_hill_and_penumbra(golden("hill"), make, tol=1e-12) == 132
 
 
+def test_edge_profile_restatement_matches_reference(golden):
+    """f4: oracle.EdgeProfileRestated (InflectionDerivativeProfile / HillProfile) against the reference's own classes:
+    65 profiles + the two it rejects."""
+    import warnings
+
+    import next_row_checks as checks
+
+    def make(kind, values, **kw):
+        return o.EdgeProfileRestated(values, x_values=kw.get("x_values"), ground_profile=kw.get("ground", False),
+                                     normalization=kw.get("normalization"),
+                                     edge_smoothing_ratio=kw.get("edge_smoothing_ratio", 0.003),
+                                     hill_window_ratio=(kw.get("hill_window_ratio", 0.1) if kind == "hill" else None))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert checks.check_edge_profiles(golden("edge_profiles"), make) == 65
+
+
 def test_starshot_restatement_matches_reference(golden):
     """Starshot (north_star's third analyzer): oracle.StarshotRestated against the reference's own
     Starshot.analyze() on six synthetic star-shot frames (uint16 / float32, inverted, 3-6 spokes, peak instead of FWHM
