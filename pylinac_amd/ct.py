@@ -121,3 +121,67 @@ def phantom_roi_batch(slices: torch.Tensor, mm_per_pixel: float, catphan_radius_
             continue
         out[i] = [0, k + 1, filled[k], t[k, 5] / t[k, 0], t[k, 6] / t[k, 0], t[k, 1], t[k, 2], t[k, 3]]
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Volume-level localisation (pylinac/ct.py:2398-2508): the loop over every slice of BASELINE config #5
+# ----------------------------------------------------------------------------------------------------------
+def find_phantom_axis_volume(slices: torch.Tensor, mm_per_pixel: float, catphan_radius_mm: float = CATPHAN_RADIUS_MM,
+                             x_adjustment: float = 0, y_adjustment: float = 0, roi: np.ndarray | None = None):
+    """``CatPhanBase.find_phantom_axis`` (ct.py:2398-2446) for a resident volume [Z, H, W]: the phantom ROI of EVERY
+    slice in one batch, then the reference's outlier screen (``np.isclose`` to the median, atol 3, rtol 0.01) and the
+    two first-order fits of the centre against z.  -> (fit_zx coefficients, fit_zy coefficients, roi table)."""
+    if roi is None:
+        roi = phantom_roi_batch(slices, mm_per_pixel, catphan_radius_mm)
+    seen = roi[:, 0] == 0                                   # is_phantom_in_view()
+    zs = np.flatnonzero(seen)
+    if len(zs) == 0:
+        raise ValueError("The phantom was not found in any slice")
+    center_xs = roi[seen, 4] + x_adjustment
+    center_ys = roi[seen, 3] + y_adjustment
+    x_idxs = np.argwhere(np.isclose(np.median(center_xs), center_xs, atol=3, rtol=0.01))
+    y_idxs = np.argwhere(np.isclose(np.median(center_ys), center_ys, atol=3, rtol=0.01))
+    common = np.intersect1d(x_idxs, y_idxs)
+    fit_zx = np.polyfit(zs[common], center_xs[common], deg=1, rcond=0.00001)
+    fit_zy = np.polyfit(zs[common], center_ys[common], deg=1, rcond=0.00001)
+    return fit_zx, fit_zy, roi
+
+
+def find_origin_slice_volume(slices: torch.Tensor, mm_per_pixel: float, fit_zx, fit_zy, slice_thickness: float,
+                             localization_radius: float = 59, hu_origin_slice_variance: float = 400,
+                             catphan_radius_mm: float = CATPHAN_RADIUS_MM, roi: np.ndarray | None = None) -> int:
+    """``CatPhanBase.find_origin_slice`` (ct.py:2453-2508): for every second slice that shows the phantom, a collapsed
+    circle profile (5 radii, +-5 %) through the HU inserts about the fitted centre, and the percentile / median test for
+    "both very low and very high HU, little variation in between"; the median of the qualifying slices is the centre of
+    the HU module.  Profiles and their order statistics are one batch on the device."""
+    from .canny import _percentile_f64
+
+    x = ops._frames(slices)
+    n, h, w = x.shape
+    idx = np.arange(0, n, 2)
+    if roi is None:
+        roi = phantom_roi_batch(x, mm_per_pixel, catphan_radius_mm)
+    idx = idx[roi[idx, 0] == 0]
+    if len(idx) == 0:
+        raise ValueError("No slices were found that resembled the HU linearity module")
+    cx = np.polyval(fit_zx, idx)
+    cy = np.polyval(fit_zy, idx)
+    radius = localization_radius / mm_per_pixel
+    if (w < radius + cx).any() or (h < radius + cy).any():        # CircleProfile._ensure_array_size (profile.py:2394-2402)
+        raise ValueError("Array size not large enough to compute profile")
+    radii = np.linspace(radius * 0.95, radius * 1.05, 5)
+    sub = x[torch.from_numpy(idx).to(x.device)].contiguous()
+    prof = ops.circle_profile(sub, cx, cy, radii, np.pi * radii.max() * 2, 0, True, 5.0)       # [M, L] float64
+    p = prof[:, None, :].contiguous()                                                       # one "frame" per profile
+    low_end, high_end, p80, p20, median = (_percentile_f64(p, q).cpu().numpy() for q in (2, 98, 80, 20, 50))
+    variation_limit = max(100, slice_thickness * -100 + 300)
+    hit = ((low_end < median - hu_origin_slice_variance) & (high_end > median + hu_origin_slice_variance)
+           & ((p80 - p20) < variation_limit))
+    hu_slices = idx[hit]
+    if len(hu_slices) == 0:
+        raise ValueError("No slices were found that resembled the HU linearity module")
+    c = int(round(float(np.median(hu_slices))))
+    ln = len(hu_slices)
+    hu_slices = hu_slices[((c + ln / 2) >= hu_slices) & (hu_slices >= (c - ln / 2))]
+    center = int(round(float(np.median(hu_slices))))
+    return center if 0 <= center < n else None

@@ -853,6 +853,9 @@ def main():
     subprocess.run([PY39, os.path.join(HERE, "skimage_canny_int_py39.py"), os.path.join(HERE, "canny_int.npz")], check=True)
     # ---- 23. ThicknessROI: the reference's own pylinac.ct.ThicknessROI on synthetic wire ramps
     subprocess.run([PY39, os.path.join(HERE, "skimage_thickness_py39.py"), os.path.join(HERE, "thickness.npz"), ROOT], check=True)
+    # ---- 24. CatPhan volume localisation: the reference's own find_phantom_axis / find_origin_slice
+    subprocess.run([PY39, os.path.join(HERE, "skimage_catphan_volume_py39.py"), os.path.join(HERE, "catphan_volume.npz"), ROOT],
+                   check=True)
     # (hill.npz and starshot.npz have their own generators: make_hill_golden.py, make_starshot_golden.py)
 
     json.dump(meta, open(os.path.join(HERE, "META.json"), "w"), indent=1)

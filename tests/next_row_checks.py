@@ -393,3 +393,23 @@ def check_edge_profiles(g, make, only=None):
             assert np.allclose([p.geometric_center_idx, p.cax_index], want[4:], rtol=0, atol=1e-9), tag
         n += 1
     return n
+
+
+def check_catphan_volume(golden, dev, names=("a", "b")):
+    """Volume-level CatPhan localisation (config #5's loop over slices) against the reference's own
+    CatPhanBase.find_phantom_axis / find_origin_slice on synthetic volumes: which slices show the phantom, their ROI
+    centroids (1e-9), the two axis fits (1e-9), the origin slice."""
+    from pylinac_amd import ct
+
+    g = golden("catphan_volume")
+    for name in names:
+        vol = torch.from_numpy(g[f"{name}.volume"]).to(dev)
+        mmpp = float(g[f"{name}.mmpp"])
+        fit_zx, fit_zy, roi = ct.find_phantom_axis_volume(vol, mmpp)
+        assert np.array_equal(roi[:, 0] == 0, g[f"{name}.in_view"]), name
+        seen = g[f"{name}.in_view"]
+        assert np.allclose(roi[seen, 3:5], g[f"{name}.centroids"][seen], rtol=0, atol=1e-9), name
+        assert np.allclose(fit_zx, g[f"{name}.fit_zx"], rtol=1e-9, atol=1e-9), (name, fit_zx)
+        assert np.allclose(fit_zy, g[f"{name}.fit_zy"], rtol=1e-9, atol=1e-9), (name, fit_zy)
+        origin = ct.find_origin_slice_volume(vol, mmpp, fit_zx, fit_zy, slice_thickness=2.5, roi=roi)
+        assert origin == int(g[f"{name}.origin"]), (name, origin)

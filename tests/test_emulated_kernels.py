@@ -417,3 +417,9 @@ def test_emulated_edge_profiles(golden, emulated):
         n = checks.check_edge_profiles(golden("edge_profiles"), make,
                                        only=lambda t: t.startswith(("fx2.", "fx4.", "fx11.", "epid.", "fff1.")))
     assert n >= 10
+
+
+def test_emulated_catphan_volume(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_catphan_volume(golden, emulated, names=("b",))

@@ -1505,6 +1505,15 @@ def test_contrast_rois_vs_reference_golden(golden, dev):
     checks.check_contrast_rois(golden, dev)
 
 
+def test_catphan_volume_localisation_vs_reference_golden(golden, dev):
+    """Config #5's loop over slices: find_phantom_axis (phantom ROI of every slice -> outlier screen -> linear fits) and
+    find_origin_slice (collapsed circle profile through the HU inserts + percentile test on every second slice) against
+    the reference's own CatPhanBase methods on two synthetic tilted volumes."""
+    import next_row_checks as checks
+
+    checks.check_catphan_volume(golden, dev)
+
+
 def test_edge_profiles_vs_reference_golden(golden, dev):
     """f4: InflectionDerivativeProfile / HillProfile (profile.py:612-740; device smoothing, gradient and spline solve,
     host BFGS / curve_fit like the reference) against the reference's own classes on its 20 frozen profiles, an EPID
