@@ -185,3 +185,53 @@ def find_origin_slice_volume(slices: torch.Tensor, mm_per_pixel: float, fit_zx, 
     hu_slices = hu_slices[((c + ln / 2) >= hu_slices) & (hu_slices >= (c - ln / 2))]
     center = int(round(float(np.median(hu_slices))))
     return center if 0 <= center < n else None
+
+
+def find_phantom_roll_volume(slices: torch.Tensor, mm_per_pixel: float, origin_slice: int, fit_zx,
+                             air_bubble_radius_mm: float = 7, slice_offset: int = 0) -> float:
+    """``CatPhanBase.find_phantom_roll`` (ct.py:2517-2563): the regions of the HU slice (``get_regions`` without hole
+    filling) that look like the air bubbles -- ``filled_area`` within a factor 2 of the bubble disk and
+    ``eccentricity`` < 0.5 (regionprops semantics: holes filled inside the region's own bounding box with the full
+    structuring element; eccentricity from the eigenvalues of the region's inertia tensor) -- the two closest to the
+    phantom's x centre, and the angle of the line through them.  Labelling, region table and the per-candidate hole
+    filling run on the device; a handful of candidates are screened on the host."""
+    import math
+    import warnings
+
+    x = ops._frames(slices)
+    k = int(origin_slice) + int(slice_offset)
+    reg = get_regions_batch(x[k:k + 1], mm_per_pixel, fill_holes=False, clear_borders=True, max_labels=256)
+    if int(reg["overflow"][0]):
+        raise RuntimeError("more than 256 regions in the roll slice")
+    num = int(reg["num"][0])
+    stats = reg["stats"][0, :num].cpu().numpy()
+    labels = reg["labels"][0]
+    thresh = np.pi * ((air_bubble_radius_mm / mm_per_pixel) ** 2)
+    bubbles = []
+    for j in range(num):
+        area, r0, c0, r1, c1 = stats[j, 0], int(stats[j, 1]), int(stats[j, 2]), int(stats[j, 3]), int(stats[j, 4])
+        # filled_area lies between the region's area and its bounding-box area: skip what cannot qualify
+        if not (area < thresh * 2 and (r1 - r0) * (c1 - c0) > thresh / 2):
+            continue
+        crop = (labels[r0:r1, c0:c1] == j + 1).to(torch.uint8).contiguous()
+        filled_area = float(ops.fill_holes(crop[None], connectivity_bg=8)[0].sum())
+        if not thresh * 2 > filled_area > thresh / 2:
+            continue
+        rc = torch.nonzero(crop).to(torch.float64)
+        d = rc - rc.mean(dim=0)
+        n = rc.shape[0]
+        mu20, mu02, mu11 = float((d[:, 0] ** 2).sum()), float((d[:, 1] ** 2).sum()), float((d[:, 0] * d[:, 1]).sum())
+        eig = np.clip(np.linalg.eigvalsh(np.array([[mu02 / n, -mu11 / n], [-mu11 / n, mu20 / n]])), 0, None)
+        l1, l2 = sorted(eig, reverse=True)
+        ecc = 0.0 if l1 == 0 else math.sqrt(1 - l2 / l1)
+        if ecc < 0.5:
+            bubbles.append((stats[j, 5] / area, stats[j, 6] / area))          # centroid (row, col)
+    cx = float(np.polyval(fit_zx, k))
+    central = sorted(bubbles, key=lambda b: abs(b[1] - cx))[:2]
+    top_bottom = sorted(central, key=lambda b: b[0])
+    if len(top_bottom) < 2:
+        warnings.warn("Could not determine phantom roll. Setting roll to 0.", UserWarning)
+        return 0.0
+    y_dist = top_bottom[1][0] - top_bottom[0][0]
+    x_dist = top_bottom[1][1] - top_bottom[0][1]
+    return float(np.rad2deg(np.arctan2(y_dist, x_dist)) - 90)

@@ -53,13 +53,21 @@ for name, (n, size, seed, hu) in {"a": (24, 256, 3, (9, 10, 11, 12, 13)), "b": (
         metadata = meta
 
     dstack = Stack(stack)
-    cp = types.SimpleNamespace(dicom_stack=dstack, clear_borders=True, x_adjustment=0, y_adjustment=0,
+    dstack.slice_spacing = 2.5
+    cp = types.SimpleNamespace(roll_slice_offset=0, air_bubble_radius_mm=7, dicom_stack=dstack, clear_borders=True, x_adjustment=0, y_adjustment=0,
                                catphan_size=np.pi * 101 ** 2 / mmpp ** 2, mm_per_pixel=mmpp, clip_in_localization=False,
                                _phantom_center_func=None, num_images=n, localization_radius=59,
                                hu_origin_slice_variance=400, _is_within_image_extent=lambda k: 0 <= k < n)
     fit_zx, fit_zy = ct.CatPhanBase.find_phantom_axis(cp)
     cp._phantom_center_func = (fit_zx, fit_zy)
     origin = ct.CatPhanBase.find_origin_slice(cp)
+    cp.origin_slice = origin
+    cp._is_right_area = types.MethodType(ct.CatPhanBase._is_right_area, cp)
+    cp._is_right_eccentricity = types.MethodType(ct.CatPhanBase._is_right_eccentricity, cp)
+    out[f"{name}.roll"] = np.float64(ct.CatPhanBase.find_phantom_roll(cp))
+    s0 = ct.Slice(cp, origin, clear_borders=True)
+    _, regs, _ = ct.get_regions(s0)
+    out[f"{name}.roll_regions"] = np.array([[r.area, r.filled_area, r.eccentricity, r.centroid[0], r.centroid[1]] for r in regs], dtype=float)
     # per-slice intermediate values for diagnosis
     in_view, cen = [], []
     for idx, img in enumerate(dstack):
@@ -72,5 +80,5 @@ for name, (n, size, seed, hu) in {"a": (24, 256, 3, (9, 10, 11, 12, 13)), "b": (
     out[f"{name}.origin"] = np.int64(origin)
     out[f"{name}.in_view"] = np.array(in_view)
     out[f"{name}.centroids"] = np.array(cen, dtype=float)
-    print(name, fit_zx.coeffs, fit_zy.coeffs, origin, int(np.sum(in_view)))
+    print(name, fit_zx.coeffs, fit_zy.coeffs, origin, int(np.sum(in_view)), out[f"{name}.roll"], len(regs))
 np.savez_compressed(sys.argv[1], **out)

@@ -398,7 +398,7 @@ def check_edge_profiles(g, make, only=None):
 def check_catphan_volume(golden, dev, names=("a", "b")):
     """Volume-level CatPhan localisation (config #5's loop over slices) against the reference's own
     CatPhanBase.find_phantom_axis / find_origin_slice on synthetic volumes: which slices show the phantom, their ROI
-    centroids (1e-9), the two axis fits (1e-9), the origin slice."""
+    centroids (1e-9), the two axis fits (1e-9), the origin slice, the phantom roll from the air bubbles (1e-9 degrees)."""
     from pylinac_amd import ct
 
     g = golden("catphan_volume")
@@ -413,3 +413,5 @@ def check_catphan_volume(golden, dev, names=("a", "b")):
         assert np.allclose(fit_zy, g[f"{name}.fit_zy"], rtol=1e-9, atol=1e-9), (name, fit_zy)
         origin = ct.find_origin_slice_volume(vol, mmpp, fit_zx, fit_zy, slice_thickness=2.5, roi=roi)
         assert origin == int(g[f"{name}.origin"]), (name, origin)
+        roll = ct.find_phantom_roll_volume(vol, mmpp, origin, fit_zx)
+        assert abs(roll - float(g[f"{name}.roll"])) < 1e-9, (name, roll, float(g[f"{name}.roll"]))

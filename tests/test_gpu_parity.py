@@ -1508,7 +1508,8 @@ def test_contrast_rois_vs_reference_golden(golden, dev):
 def test_catphan_volume_localisation_vs_reference_golden(golden, dev):
     """Config #5's loop over slices: find_phantom_axis (phantom ROI of every slice -> outlier screen -> linear fits) and
     find_origin_slice (collapsed circle profile through the HU inserts + percentile test on every second slice) against
-    the reference's own CatPhanBase methods on two synthetic tilted volumes."""
+    the reference's own CatPhanBase methods on two synthetic tilted volumes; find_phantom_roll (air-bubble regions by
+    filled area and eccentricity) to 1e-9 degrees."""
     import next_row_checks as checks
 
     checks.check_catphan_volume(golden, dev)
