@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
+from . import contrast as _c
 from ._lib import check
 
 STAT_FIELDS = ("count", "mean", "std", "min", "max", "median")
@@ -270,8 +271,6 @@ class LowContrastDiskROI(DiskROI):
 
     @property
     def contrast(self) -> float:
-        from . import contrast as _c
-
         return _c.contrast(self._contrast_array, self.contrast_method)
 
     @property
@@ -280,26 +279,18 @@ class LowContrastDiskROI(DiskROI):
 
     @property
     def michelson(self) -> float:
-        from . import contrast as _c
-
         return _c.michelson(self._contrast_array)
 
     @property
     def weber(self) -> float:
-        from . import contrast as _c
-
         return _c.weber(feature=self.pixel_value, background=self.contrast_reference)
 
     @property
     def rms(self) -> float:
-        from . import contrast as _c
-
         return _c.rms(self._contrast_array)
 
     @property
     def visibility(self) -> float:
-        from . import contrast as _c
-
         return _c.visibility(array=self._contrast_array, radius=self.radius, std=self.std, algorithm=self.contrast_method)
 
     @property
