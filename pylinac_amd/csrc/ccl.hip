@@ -101,12 +101,19 @@ ccl_merge_kernel(int* __restrict__ Lall, int64_t total, int h, int w, int conn8)
   }
 }
 
-__global__ void ccl_compress_kernel(int* __restrict__ Lall, int64_t total, int64_t per_frame) {
+// Flatten the forest.  After the run-based merge a pixel points to the head of its run, run heads point along the row
+// and row heads point up a chain whose length depends on the order in which the hardware happened to run the unions
+// (up to the number of rows in flight).  Pass 1 (heads_only) lets only the run heads -- row starts, chunk starts and
+// pixels whose left neighbour is background: the nodes other pixels point to -- walk that chain; pass 2 then costs
+// every pixel at most two hops.  Without pass 1 a million background pixels would each walk the whole chain.
+__global__ void __launch_bounds__(kThreads)
+ccl_compress_kernel(int* __restrict__ Lall, int64_t total, int64_t per_frame, int w, int heads_only) {
   const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (g >= total) return;
   int* L = Lall + (g / per_frame) * per_frame;
   const int i = (int)(g % per_frame);
   if (L[i] < 0) return;
+  if (heads_only && !((i % w) == 0 || (threadIdx.x & 63) == 0 || L[i - 1] < 0)) return;
   L[i] = find_root(L, i);
 }
 
@@ -240,7 +247,8 @@ int run_ccl(const uint8_t* mask, int invert, int64_t n, int h, int w, int conn, 
   const unsigned blocks = (unsigned)pl_cdiv(total, kThreads);
   hipLaunchKernelGGL(ccl_init_kernel, dim3(blocks), dim3(kThreads), 0, st, mask, invert, total, per_frame, w, L);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, h, w, conn == 8 ? 1 : 0);
-  hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame);
+  hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame, w, 1);
+  hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame, w, 0);
   return pl_check_launch("ccl");
 }
 
