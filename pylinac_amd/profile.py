@@ -209,6 +209,44 @@ class _ProfileBase:
     def field_edge_idx(self, side: str) -> float:
         raise NotImplementedError
 
+    def field_x_values(self, in_field_ratio: float) -> np.ndarray:
+        """profile.py:308-321: the x-values inside the central ``in_field_ratio`` of the field, inclusive of the edges
+        (floor / ceil of the two bounds)."""
+        left = self.field_edge_idx(side=LEFT)
+        right = self.field_edge_idx(side=RIGHT)
+        width = self.field_width_px
+        f_left = left + (1 - in_field_ratio) / 2 * width
+        f_right = right - (1 - in_field_ratio) / 2 * width
+        lower_bound = math.floor(min((f_left, f_right)))
+        upper_bound = math.ceil(max((f_left, f_right)))
+        inner = np.nonzero((self.x_values >= lower_bound) & (self.x_values <= upper_bound))[0]
+        return self.x_values[inner]
+
+    def field_values(self, in_field_ratio: float = 0.8) -> np.ndarray:
+        """profile.py:345-352"""
+        return np.atleast_1d(self.y_at_x(self.field_x_values(in_field_ratio)))
+
+    def field_indices(self, in_field_ratio: float) -> tuple:
+        """profile.py:299-306 -> (left, right, width) in x-value units"""
+        xs = self.field_x_values(in_field_ratio)
+        left, right = xs[0], xs[-1]
+        return left, right, max(right, left) - min(right, left)
+
+    def resample_to(self, target_profile: "_ProfileBase"):
+        """profile.py:392-431: this profile's values linearly interpolated at the target's x-values (no
+        extrapolation), as a new profile of this class."""
+        target_x = np.asarray(target_profile.x_values, dtype=float)
+        self_x = np.asarray(self.x_values, dtype=float)
+        if target_x.min() < self_x.min() or target_x.max() > self_x.max():
+            raise ValueError(
+                "The target profile x-values are outside this profiles range. Extrapolation is not allowed. "
+                f"self x-values: {self_x.min()} to {self_x.max()}. target x-values: {target_x.min()} to {target_x.max()}. ")
+        xs = torch.from_numpy(np.ascontiguousarray(self_x))
+        dev = _to_device_profile(np.asarray(self.values, dtype=float))
+        target_y = ops.interp1d(xs.to(dev.device), dev, torch.from_numpy(np.ascontiguousarray(target_x)).to(dev.device),
+                                kind="linear").reshape(-1).cpu().numpy()
+        return type(self)(values=target_y, x_values=target_x)
+
     @property
     def center_idx(self) -> float:
         left = self.field_edge_idx(LEFT)

@@ -58,6 +58,17 @@ for k, (n, half, soft, peak) in enumerate([(300, 90, 6.0, 0.0), (520, 170, 9.0, 
     out[f"fff{k}.y"], out[f"fff{k}.x"] = y, x * 0.4
     record(f"fff{k}.infl", prof.InflectionDerivativeProfile, y, x_values=x * 0.4)
     record(f"fff{k}.hill", prof.HillProfile, y, x_values=x * 0.4, hill_window_ratio=0.15)
+# ProfileBase.field_x_values / field_values / field_indices / resample_to (profile.py:299-352, 392-431) through FWXMProfile
+for i in (0, 3, 7, 12, 19):
+    fx = fxm.PROFILE_REGRESSION_FIXTURES[i]
+    p = prof.FWXMProfile(np.asarray(fx.values, float), x_values=np.asarray(fx.x_values, float), fwxm_height=50)
+    for r in (1.0, 0.8, 0.5):
+        out[f"fx{i}.fwxm.field_x.{r}"] = np.asarray(p.field_x_values(r), float)
+        out[f"fx{i}.fwxm.field_v.{r}"] = np.asarray(p.field_values(r), float)
+        out[f"fx{i}.fwxm.field_idx.{r}"] = np.asarray(p.field_indices(r), float)
+    tx = np.linspace(np.min(fx.x_values) * 0.6, np.max(fx.x_values) * 0.7, 37)
+    q = p.resample_to(prof.FWXMProfile(np.ones(37), x_values=tx))
+    out[f"fx{i}.fwxm.resample_x"], out[f"fx{i}.fwxm.resample_y"] = np.asarray(q.x_values, float), np.asarray(q.values, float)
 np.savez_compressed(os.path.join(HERE, "edge_profiles.npz"), **out)
 errs = [k for k in out if k.endswith(".error")]
 print(len(out), "arrays;", len(errs), "errors", sorted({str(out[k]) for k in errs}), errs[:6])

@@ -418,3 +418,29 @@ def check_catphan_volume(golden, dev, names=("a", "b")):
         assert origin == int(g[f"{name}.origin"]), (name, origin)
         roll = ct.find_phantom_roll_volume(vol, mmpp, origin, fit_zx)
         assert abs(roll - float(g[f"{name}.roll"])) < 1e-9, (name, roll, float(g[f"{name}.roll"]))
+
+
+def check_profile_base_fields(g, dev=None):
+    """ProfileBase.field_x_values / field_values / field_indices / resample_to through FWXMProfile against the reference
+    (tests/golden/edge_profiles.npz) and the reference's literal known answers (tests_basic/core/test_profile.py:327-341:
+    5 and 3 field values of the 9-point triangle for in_field_ratio 1 and 0.5)."""
+    from pylinac_amd import profile
+
+    tri = profile.FWXMProfile(np.array([0, 1, 2, 3, 4, 3, 2, 1, 0], dtype=float), fwxm_height=50)
+    assert len(tri.field_values(in_field_ratio=1)) == 5 and len(tri.field_values(in_field_ratio=0.5)) == 3
+    for i in (0, 3, 7, 12, 19):
+        p = profile.FWXMProfile(g[f"fx{i}.y"], x_values=g[f"fx{i}.x"], fwxm_height=50)
+        for r in (1.0, 0.8, 0.5):
+            assert np.array_equal(p.field_x_values(r), g[f"fx{i}.fwxm.field_x.{r}"]), (i, r)
+            assert np.allclose(p.field_values(r), g[f"fx{i}.fwxm.field_v.{r}"], rtol=1e-12, atol=1e-12), (i, r)
+            assert np.allclose(p.field_indices(r), g[f"fx{i}.fwxm.field_idx.{r}"], rtol=0, atol=1e-12), (i, r)
+        tx = g[f"fx{i}.fwxm.resample_x"]
+        q = p.resample_to(profile.FWXMProfile(np.ones(len(tx)), x_values=tx))
+        assert isinstance(q, profile.FWXMProfile) and np.array_equal(q.x_values, tx)
+        assert np.allclose(q.values, g[f"fx{i}.fwxm.resample_y"], rtol=1e-12, atol=1e-12), i
+        try:
+            p.resample_to(profile.FWXMProfile(np.ones(5), x_values=np.linspace(tx[0] * 10, tx[-1] * 10, 5)))
+        except ValueError:
+            pass
+        else:
+            raise AssertionError("extrapolation must raise")

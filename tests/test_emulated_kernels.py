@@ -447,3 +447,9 @@ def test_emu_run_based_ccl_variant():
     r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), env={**os.environ, "PL_CCL_RUNS": "1"},
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "RUN_BASED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_emulated_profile_base_fields(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_profile_base_fields(golden("edge_profiles"))

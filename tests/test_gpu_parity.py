@@ -1515,6 +1515,14 @@ def test_catphan_volume_localisation_vs_reference_golden(golden, dev):
     checks.check_catphan_volume(golden, dev)
 
 
+def test_profile_base_fields_vs_reference_golden(golden, dev):
+    """ProfileBase.field_x_values / field_values / field_indices / resample_to (profile.py:299-352, 392-431) through
+    FWXMProfile: the reference's known answers and its own results on five frozen profiles."""
+    import next_row_checks as checks
+
+    checks.check_profile_base_fields(golden("edge_profiles"))
+
+
 def test_edge_profiles_vs_reference_golden(golden, dev):
     """f4: InflectionDerivativeProfile / HillProfile (profile.py:612-740; device smoothing, gradient and spline solve,
     host BFGS / curve_fit like the reference) against the reference's own classes on its 20 frozen profiles, an EPID
