@@ -374,6 +374,55 @@ class HillProfile(InflectionDerivativeProfile):
         return fit.inflection_idx()["index (exact)"]
 
 
+class PhysicalProfileMixin:
+    """pylinac/core/profile.py:742-775: profiles whose x-values are pixels of known size (``dpmm``) or already physical
+    positions (``dpmm=None``: the mean spacing is the implicit dots-per-mm)."""
+
+    def _init_physical(self, dpmm: float | None) -> None:
+        self.dpmm = dpmm
+        self.implicit_dpmm = np.mean(np.diff(self.x_values)) if dpmm is None else dpmm
+
+    @property
+    def physical_x_values(self) -> np.ndarray:
+        if self.dpmm is None:
+            return self.x_values
+        return self.x_values / self.dpmm + 0.5 / self.dpmm          # half-pixel offset
+
+    @property
+    def field_width_mm(self) -> float:
+        return self.field_width_px / self.implicit_dpmm
+
+
+class FWXMProfilePhysical(PhysicalProfileMixin, FWXMProfile):
+    """profile.py:1014-1043"""
+
+    def __init__(self, values, dpmm: float | None = None, x_values=None, ground: bool = False,
+                 normalization=Normalization.NONE, fwxm_height: float = 50):
+        FWXMProfile.__init__(self, values=values, x_values=x_values, ground=ground, normalization=normalization,
+                             fwxm_height=fwxm_height)
+        self._init_physical(dpmm)
+
+
+class InflectionDerivativeProfilePhysical(PhysicalProfileMixin, InflectionDerivativeProfile):
+    """profile.py:1046-1081"""
+
+    def __init__(self, values, dpmm: float | None = None, x_values=None, ground: bool = False,
+                 normalization=Normalization.NONE, edge_smoothing_ratio: float = 0.003):
+        InflectionDerivativeProfile.__init__(self, values=values, x_values=x_values, ground=ground,
+                                             normalization=normalization, edge_smoothing_ratio=edge_smoothing_ratio)
+        self._init_physical(dpmm)
+
+
+class HillProfilePhysical(PhysicalProfileMixin, HillProfile):
+    """profile.py:1084-1115"""
+
+    def __init__(self, values, dpmm: float | None = None, x_values=None, ground: bool = False,
+                 normalization=Normalization.NONE, edge_smoothing_ratio: float = 0.003, hill_window_ratio: float = 0.1):
+        HillProfile.__init__(self, values=values, x_values=x_values, ground=ground, normalization=normalization,
+                             edge_smoothing_ratio=edge_smoothing_ratio, hill_window_ratio=hill_window_ratio)
+        self._init_physical(dpmm)
+
+
 class CircleProfile(MultiProfile):
     """pylinac/core/profile.py:2179-2402: a profile sampled along a circle
     (``ndimage.map_coordinates(image, [y, x], order=0)``)."""

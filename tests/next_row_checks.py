@@ -428,6 +428,19 @@ def check_profile_base_fields(g, dev=None):
 
     tri = profile.FWXMProfile(np.array([0, 1, 2, 3, 4, 3, 2, 1, 0], dtype=float), fwxm_height=50)
     assert len(tri.field_values(in_field_ratio=1)) == 5 and len(tri.field_values(in_field_ratio=0.5)) == 3
+    # the physical variants: the reference's known answers (tests_basic/core/test_profile.py:476-482, 540-550, 576-581, 641-646)
+    long23 = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0], dtype=float)
+    sharp21 = np.array([0, 1, 1, 2, 5, 8, 9, 10, 10, 10, 10, 10, 10, 10, 9, 8, 5, 2, 1, 1, 0], dtype=float)
+    pf = profile.FWXMProfilePhysical(long23, fwxm_height=50, dpmm=2)
+    assert pf.field_width_mm == pf.field_width_px / 2
+    px = profile.FWXMProfilePhysical(long23, fwxm_height=50, dpmm=3).physical_x_values
+    assert abs(min(px) - 1 / 6) < 1e-12 and abs(max(px) - (23 / 3 - 1 / 6)) < 1e-12
+    pi_ = profile.InflectionDerivativeProfilePhysical(long23, dpmm=2)
+    assert pi_.field_width_mm == pi_.field_width_px / 2
+    ph = profile.HillProfilePhysical(sharp21, dpmm=2, hill_window_ratio=0.2)
+    assert ph.field_width_mm == ph.field_width_px / 2
+    nod = profile.FWXMProfilePhysical(long23, x_values=np.arange(23) * 0.25)
+    assert nod.implicit_dpmm == 0.25 and np.array_equal(nod.physical_x_values, nod.x_values)
     for i in (0, 3, 7, 12, 19):
         p = profile.FWXMProfile(g[f"fx{i}.y"], x_values=g[f"fx{i}.x"], fwxm_height=50)
         for r in (1.0, 0.8, 0.5):
