@@ -1970,3 +1970,40 @@ class EdgeProfileRestated:
     def field_width_px(self):
         left, right = self.field_edge_idx("left"), self.field_edge_idx("right")
         return max(right, left) - min(right, left)
+
+
+def zoom1d_cubic_nearest(values, factor: float) -> np.ndarray:
+    """scipy.ndimage.zoom(values, factor, order=3, mode="nearest", grid_mode=False) (scipy/ndimage/_interpolation.py zoom,
+    src/ni_splines.c) restated for 1-D float64 input, as ProfileBase.as_resampled calls it (pylinac/core/profile.py:
+    370-376): 12 edge samples of padding, cubic B-spline prefilter with mirror initialisation, four-tap evaluation at
+    i * (n - 1) / (m - 1) + 12 with clamped indices.  Pinned against scipy itself (tests/test_oracle_golden.py)."""
+    values = np.asarray(values, dtype=np.float64)
+    n = len(values)
+    m = int(round(n * factor))
+    npad = 12
+    c = np.pad(values, npad, mode="edge")
+    ln = len(c)
+    z = math.sqrt(3.0) - 2.0
+    c = c * ((1 - z) * (1 - 1 / z))
+    z_i, z_n_1 = z, math.pow(z, ln - 1)
+    c0 = c[0] + z_n_1 * c[ln - 1]
+    for i in range(1, ln - 1):
+        c0 += z_i * (c[i] + z_n_1 * c[ln - 1 - i])
+        z_i *= z
+    c[0] = c0 / (1 - z_n_1 * z_n_1)
+    for i in range(1, ln):
+        c[i] += z * c[i - 1]
+    c[ln - 1] = (z * c[ln - 2] + c[ln - 1]) * z / (z * z - 1)
+    for i in range(ln - 2, -1, -1):
+        c[i] = z * (c[i + 1] - c[i])
+    zoom = (n - 1) / (m - 1) if m > 1 else 1.0
+    out = np.empty(m)
+    for i in range(m):
+        cc = zoom * i + npad
+        fl = math.floor(cc)
+        y = cc - fl
+        zz = 1 - y
+        w = [zz * zz * zz / 6.0, (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0, (zz * zz * (zz - 2.0) * 3.0 + 4.0) / 6.0]
+        w.append(1.0 - w[0] - w[1] - w[2])
+        out[i] = sum(c[min(max(fl - 1 + k, 0), ln - 1)] * w[k] for k in range(4))
+    return out

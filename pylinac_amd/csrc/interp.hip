@@ -128,7 +128,78 @@ __global__ void gradient_kernel(const double* __restrict__ y, int L, int64_t tot
   out[i] = k == 0 ? p[1] - p[0] : (k == L - 1 ? p[L - 1] - p[L - 2] : (p[k + 1] - p[k - 1]) / 2.0);
 }
 
+// ---- scipy.ndimage.zoom(values, zoom, order=3, mode="nearest", grid_mode=False) of 1-D profiles --------------------
+// (ProfileBase.as_resampled, pylinac/core/profile.py:353-390).  scipy pads the input with 12 edge samples, runs the cubic
+// B-spline prefilter (pole sqrt(3) - 2, mirror initialisation) over the padded array and evaluates the four-tap spline
+// at i * (L - 1) / (S - 1) + 12 with clamped tap indices.  The prefilter is a sequential recursion: one lane per profile.
+constexpr int kZoomPad = 12;
+
+__global__ void zoom_prefilter_kernel(const double* __restrict__ y, int L, int64_t n_profiles, double* __restrict__ work) {
+  const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (p >= n_profiles) return;
+  const double* v = y + p * (int64_t)L;
+  const int n = L + 2 * kZoomPad;
+  double* c = work + p * (int64_t)n;
+  const double z = sqrt(3.0) - 2.0;
+  const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+  for (int i = 0; i < n; ++i) {
+    const int k = i - kZoomPad;
+    c[i] = v[k < 0 ? 0 : (k > L - 1 ? L - 1 : k)] * gain;
+  }
+  double z_i = z;
+  const double z_n_1 = pow(z, (double)(n - 1));
+  double c0 = c[0] + z_n_1 * c[n - 1];
+  for (int i = 1; i < n - 1; ++i) {
+    c0 += z_i * (c[i] + z_n_1 * c[n - 1 - i]);
+    z_i *= z;
+  }
+  c[0] = c0 / (1.0 - z_n_1 * z_n_1);
+  for (int i = 1; i < n; ++i) c[i] += z * c[i - 1];
+  c[n - 1] = (z * c[n - 2] + c[n - 1]) * z / (z * z - 1.0);
+  for (int i = n - 2; i >= 0; --i) c[i] = z * (c[i + 1] - c[i]);
+}
+
+__global__ void zoom_eval_kernel(const double* __restrict__ work, int L, int S, int64_t total, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i % S);
+  const int64_t p = i / S;
+  const int n = L + 2 * kZoomPad;
+  const double* c = work + p * (int64_t)n;
+  const double zoom = S > 1 ? (double)(L - 1) / (double)(S - 1) : 1.0;
+  const double cc = zoom * (double)q + (double)kZoomPad;
+  const double fl = floor(cc);
+  const double yv = cc - fl, zv = 1.0 - yv;
+  const double w1 = (yv * yv * (yv - 2.0) * 3.0 + 4.0) / 6.0;
+  const double w2 = (zv * zv * (zv - 2.0) * 3.0 + 4.0) / 6.0;
+  const double w0 = zv * zv * zv / 6.0;
+  const double w3 = 1.0 - w0 - w1 - w2;
+  const int start = (int)fl - 1;
+  auto at = [&](int k) { return c[k < 0 ? 0 : (k > n - 1 ? n - 1 : k)]; };
+  double t = 0.0;
+  t += at(start) * w0;
+  t += at(start + 1) * w1;
+  t += at(start + 2) * w2;
+  t += at(start + 3) * w3;
+  out[i] = t;
+}
+
 }  // namespace
+
+extern "C" int pl_zoom1d_cubic(const double* y, int64_t n_profiles, int length, int out_length, double* work,
+                               double* out, void* stream) {
+  PL_REQUIRE(y && work && out, "null pointer");
+  PL_REQUIRE(n_profiles >= 0 && length >= 2 && out_length >= 1, "bad shape");
+  if (n_profiles == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = n_profiles * (int64_t)out_length;
+  PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "batch too large for one launch");
+  hipLaunchKernelGGL(zoom_prefilter_kernel, dim3((unsigned)pl_cdiv(n_profiles, kThreads)), dim3(kThreads), 0, st, y,
+                     length, n_profiles, work);
+  hipLaunchKernelGGL(zoom_eval_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0, st, work, length,
+                     out_length, total, out);
+  return pl_check_launch("pl_zoom1d_cubic");
+}
 
 extern "C" int pl_gradient1d(const double* y, int64_t n_profiles, int length, double* out, void* stream) {
   PL_REQUIRE(y && out, "null pointer");

@@ -232,6 +232,32 @@ class _ProfileBase:
         left, right = xs[0], xs[-1]
         return left, right, max(right, left) - min(right, left)
 
+    def _resample_kwargs(self) -> dict:
+        """constructor arguments a resampled copy keeps (the subclasses' own parameters)"""
+        return {}
+
+    def as_resampled(self, interpolation_factor: float = 10, order: int = 3):
+        """profile.py:353-390: ``scipy.ndimage.zoom(values, interpolation_factor, order=3, mode="nearest",
+        grid_mode=False)`` on the device, x-values re-spaced over the same range, a new profile of this class."""
+        import warnings
+
+        if order != 3:
+            raise NotImplementedError("as_resampled is built for the cubic spline (order=3) the reference defaults to")
+        values = np.asarray(self.values)
+        arr_range = values.max() - values.min()
+        if values.dtype != float and arr_range < 100:
+            warnings.warn(f"Array range is small ({arr_range}) and is not a float. Interpolation may look step-like. "
+                          "Consider converting the array to a float before passing it to this method.", UserWarning)
+        new_y = ops.zoom1d_cubic(_to_device_profile(values.astype(np.float64)), interpolation_factor).cpu().numpy()
+        if values.dtype.kind in "iu":     # scipy writes into an array of the input dtype: round half away, clamp
+            info = np.iinfo(values.dtype)
+            new_y = np.clip(np.where(new_y > 0, new_y + 0.5, new_y - 0.5), info.min, info.max).astype(values.dtype)
+        elif values.dtype == np.float32:
+            new_y = new_y.astype(np.float32)
+        new_x = np.linspace(self.x_values.min(), self.x_values.max(), len(new_y))
+        return type(self)(values=new_y, x_values=new_x, ground=False, normalization=Normalization.NONE,
+                          **self._resample_kwargs())
+
     def resample_to(self, target_profile: "_ProfileBase"):
         """profile.py:392-431: this profile's values linearly interpolated at the target's x-values (no
         extrapolation), as a new profile of this class."""
@@ -279,6 +305,9 @@ class FWXMProfile(_ProfileBase):
         self.fwxm_height = fwxm_height
         super().__init__(values, x_values=x_values, ground=ground, normalization=normalization)
 
+    def _resample_kwargs(self) -> dict:
+        return dict(fwxm_height=self.fwxm_height)
+
     def _edges(self):
         if "edges" not in self._cache:
             _, props = find_peaks(self.values, fwxm_height=self.fwxm_height / 100, max_number=1)
@@ -325,6 +354,9 @@ class InflectionDerivativeProfile(_ProfileBase):
         self.edge_smoothing_ratio = edge_smoothing_ratio
         super().__init__(values, x_values=x_values, ground=ground, normalization=normalization)
 
+    def _resample_kwargs(self) -> dict:
+        return dict(edge_smoothing_ratio=self.edge_smoothing_ratio)
+
     def _derivative(self):
         if "diff" not in self._cache:
             v = _to_device_profile(np.asarray(self.values, dtype=float))
@@ -363,6 +395,9 @@ class HillProfile(InflectionDerivativeProfile):
         self.hill_window_ratio = hill_window_ratio
         super().__init__(values, x_values=x_values, ground=ground, normalization=normalization,
                          edge_smoothing_ratio=edge_smoothing_ratio)
+
+    def _resample_kwargs(self) -> dict:
+        return dict(edge_smoothing_ratio=self.edge_smoothing_ratio, hill_window_ratio=self.hill_window_ratio)
 
     def field_edge_idx(self, side: str) -> float:
         """profile.py:708-728"""

@@ -457,3 +457,35 @@ def check_profile_base_fields(g, dev=None):
             pass
         else:
             raise AssertionError("extrapolation must raise")
+
+
+def check_as_resampled(dev):
+    """ProfileBase.as_resampled against scipy.ndimage.zoom itself (order 3, mode nearest, grid_mode False; scipy is
+    present on the GPU box too) and the reference's known answers (tests_basic/core/test_profile.py:343-381, 483-500:
+    lengths, preserved x range, type, similar maxima; an interpolation factor of 0.5)."""
+    from scipy import ndimage
+
+    from pylinac_amd import ops, profile
+
+    rng = np.random.default_rng(3)
+    for n in (5, 12, 23, 24, 63, 200):
+        for f in (2, 10, 0.5, 3.3, 1.0, 7.25):
+            v = rng.normal(size=(3, n)) * 100
+            got = ops.zoom1d_cubic(torch.from_numpy(v).to(dev), f).cpu().numpy()
+            want = np.stack([ndimage.zoom(r, zoom=f, order=3, grid_mode=False, mode="nearest") for r in v])
+            assert got.shape == want.shape and np.allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max()), (n, f)
+    long23 = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0], dtype=float)
+    for cls, kw in ((profile.FWXMProfile, dict(fwxm_height=50)), (profile.InflectionDerivativeProfile, dict()),
+                    (profile.FWXMProfilePhysical, dict(fwxm_height=50, dpmm=2))):
+        p = cls(long23, **kw)
+        for factor, length in ((2, 46), (10, 230), (0.5, 12)):
+            if cls is profile.FWXMProfilePhysical:
+                continue                                  # the physical classes resample by resolution (not built)
+            r = p.as_resampled(interpolation_factor=factor)
+            assert len(r) == length and isinstance(r, cls) and r.x_values.max() == p.x_values.max()
+            assert abs(r.values.max() - p.values.max()) < 0.1
+            want = ndimage.zoom(long23, zoom=factor, order=3, grid_mode=False, mode="nearest")
+            assert np.allclose(r.values, want, rtol=1e-12, atol=1e-12)
+    ints = profile.FWXMProfile((long23 * 1000).astype(np.int32), fwxm_height=50).as_resampled(3)
+    want = ndimage.zoom((long23 * 1000).astype(np.int32), zoom=3, order=3, grid_mode=False, mode="nearest")
+    assert ints.values.dtype == want.dtype and np.array_equal(ints.values, want)

@@ -453,3 +453,9 @@ def test_emulated_profile_base_fields(golden, emulated):
     import next_row_checks as checks
 
     checks.check_profile_base_fields(golden("edge_profiles"))
+
+
+def test_emulated_as_resampled(emulated):
+    import next_row_checks as checks
+
+    checks.check_as_resampled(emulated)

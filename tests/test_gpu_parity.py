@@ -1515,6 +1515,15 @@ def test_catphan_volume_localisation_vs_reference_golden(golden, dev):
     checks.check_catphan_volume(golden, dev)
 
 
+def test_as_resampled_vs_scipy_zoom(dev):
+    """ProfileBase.as_resampled (pl_zoom1d_cubic) against scipy.ndimage.zoom(order=3, mode="nearest", grid_mode=False):
+    1e-12 on random profiles of six lengths x six factors, the reference's length / range / type known answers, and the
+    integer-dtype rounding."""
+    import next_row_checks as checks
+
+    checks.check_as_resampled(dev)
+
+
 def test_profile_base_fields_vs_reference_golden(golden, dev):
     """ProfileBase.field_x_values / field_values / field_indices / resample_to (profile.py:299-352, 392-431) through
     FWXMProfile: the reference's known answers and its own results on five frozen profiles."""

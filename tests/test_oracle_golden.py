@@ -468,6 +468,20 @@ def test_edge_profile_restatement_matches_reference(golden):
         assert checks.check_edge_profiles(golden("edge_profiles"), make) == 65
 
 
+def test_zoom_restatement_matches_scipy():
+    """oracle.zoom1d_cubic_nearest (the restated 12-sample padding + cubic prefilter + four-tap evaluation) against
+    scipy.ndimage.zoom itself: 1e-13."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(0)
+    for n in (5, 12, 23, 24, 63, 200):
+        for f in (2, 10, 0.5, 3.3, 1.0, 7.25):
+            v = rng.normal(size=n) * 100
+            want = ndimage.zoom(v, zoom=f, order=3, grid_mode=False, mode="nearest")
+            got = o.zoom1d_cubic_nearest(v, f)
+            assert got.shape == want.shape and np.allclose(got, want, rtol=1e-13, atol=1e-13 * np.abs(want).max()), (n, f)
+
+
 def test_starshot_restatement_matches_reference(golden):
     """Starshot (north_star's third analyzer): oracle.StarshotRestated against the reference's own
     Starshot.analyze() on six synthetic star-shot frames (uint16 / float32, inverted, 3-6 spokes, peak instead of FWHM
