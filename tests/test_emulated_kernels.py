@@ -459,3 +459,53 @@ def test_emulated_as_resampled(emulated):
     import next_row_checks as checks
 
     checks.check_as_resampled(emulated)
+
+
+def test_emulated_reductions_statistics_sweep(emulated):
+    """Axis reductions, min/max, Otsu, percentiles and circle profiles on small odd shapes and several dtypes against
+    numpy / the oracle (shapes the `-m gpu` parity tests do not visit)."""
+    import torch
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(33)
+    dev = emulated
+    for h, w in ((1, 1), (1, 9), (9, 1), (3, 65), (65, 3), (17, 31), (40, 128)):
+        for dt in (np.uint16, np.int16, np.float32, np.float64, np.uint8):
+            if np.issubdtype(dt, np.integer):
+                info = np.iinfo(dt)
+                f = rng.integers(info.min, info.max, (2, h, w)).astype(dt)
+            else:
+                f = (rng.normal(size=(2, h, w)) * 50).astype(dt)
+            t = torch.from_numpy(f).to(dev)
+            mn, mx = ops.minmax(t)
+            assert np.array_equal(mn.cpu().numpy(), f.reshape(2, -1).min(1)) and np.array_equal(mx.cpu().numpy(), f.reshape(2, -1).max(1))
+            for axis in (0, 1):
+                for op, fn in (("sum", np.sum), ("mean", np.mean), ("max", np.max), ("min", np.min)):
+                    got = ops.reduce_axis(t, axis, op).cpu().numpy()
+                    want = fn(f if dt == np.float32 else f.astype(np.float64), axis=axis + 1)
+                    if np.issubdtype(dt, np.integer) or op in ("max", "min"):
+                        assert np.array_equal(got, want), (dt, h, w, axis, op)
+                    elif dt == np.float32:      # numpy accumulates float32 sums in float32 (pairwise): a few ulps
+                        assert np.allclose(got, want, rtol=2e-6, atol=1e-4), (dt, h, w, axis, op)
+                    else:
+                        assert np.allclose(got, want, rtol=1e-12, atol=1e-12), (dt, h, w, axis, op)
+            if dt in (np.uint16, np.int16) and h * w >= 9:
+                thr = ops.threshold_otsu(t).cpu().numpy()
+                want = np.array([orc.threshold_otsu(a) for a in f])
+                assert np.array_equal(thr, want), (dt, h, w, thr, want)
+                qs = [0, 5, 37.5, 50, 99.9, 100]
+                got = ops.percentile(t, qs).cpu().numpy()
+                assert np.array_equal(got, np.stack([np.percentile(a, qs) for a in f])), (dt, h, w)
+    # circle profiles: centres near / outside the border, radii that leave the frame (out-of-bounds samples read 0)
+    img = rng.integers(0, 60000, (1, 37, 53)).astype(np.uint16)
+    t = torch.from_numpy(img).to(dev)
+    for cx, cy, r in ((26.2, 18.7, 9.5), (3.0, 4.0, 7.0), (50.5, 35.5, 11.0), (-4.0, 10.0, 8.0), (26.0, 18.0, 40.0)):
+        size = np.pi * r * 2
+        got = ops.circle_profile(t, cx, cy, [r], size)[0].cpu().numpy()
+        want = orc.circle_profile(img[0], (cx, cy), r).astype(np.float64)
+        assert np.array_equal(got, want), (cx, cy, r)
+        radii = np.linspace(r * 0.9, r * 1.1, 5)
+        got = ops.circle_profile(t, cx, cy, radii, np.pi * radii.max() * 2, 0, True, 5.0)[0].cpu().numpy()
+        want = orc.collapsed_circle_profile(img[0], (cx, cy), r, width_ratio=0.1, num_profiles=5)
+        assert np.allclose(got, want, rtol=1e-13, atol=1e-9), (cx, cy, r)
