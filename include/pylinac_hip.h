@@ -334,12 +334,14 @@ int pl_gamma1d(const double* d_ref, const double* d_ref_x, int n_ref, const doub
  * d_out float64 [n_profiles][n_query]. */
 int pl_interp1d(const double* d_x, int64_t x_stride, const double* d_y, int64_t n_profiles, int length,
                 const double* d_xq, int n_query, int kind, double* d_work, double* d_out, void* stream);
-/* scipy.ndimage.zoom(values, zoom, order=3, mode="nearest", grid_mode=False) of 1-D float64 profiles, as
- * ProfileBase.as_resampled calls it (pylinac/core/profile.py:353-390): 12-sample edge padding, cubic B-spline prefilter
- * (mirror initialisation), four-tap evaluation at i * (length - 1) / (out_length - 1).  out_length = round(length * zoom)
- * is the caller's.  d_work: n_profiles * (length + 24) doubles.  ~1e-14 relative to scipy (tests state 1e-12). */
-int pl_zoom1d_cubic(const double* d_y, int64_t n_profiles, int length, int out_length, double* d_work, double* d_out,
-                    void* stream);
+/* scipy.ndimage.zoom(values, zoom, order=3, mode="nearest", grid_mode) of 1-D float64 profiles, as
+ * ProfileBase.as_resampled (pylinac/core/profile.py:353-390, grid_mode 0) and PhysicalProfileMixin.as_resampled
+ * (:950-1011, grid_mode 1 by default) call it: 12-sample edge padding, cubic B-spline prefilter (mirror initialisation),
+ * four-tap evaluation at i * (length - 1) / (out_length - 1), or at (i + 1/2) * length / out_length - 1/2 in grid mode.
+ * out_length = round(length * zoom) is the caller's.  d_work: n_profiles * (length + 24) doubles.  ~1e-14 relative to
+ * scipy (tests state 1e-12). */
+int pl_zoom1d_cubic(const double* d_y, int64_t n_profiles, int length, int out_length, int grid_mode, double* d_work,
+                    double* d_out, void* stream);
 /* np.gradient(y) (unit spacing, edge_order 1) per profile, as SingleProfile.inflection_data takes it of the
  * smoothed profile (pylinac/core/profile.py:1643-1647).  float64 [n_profiles][length] -> same shape. */
 int pl_gradient1d(const double* d_y, int64_t n_profiles, int length, double* d_out, void* stream);

@@ -1972,7 +1972,7 @@ class EdgeProfileRestated:
         return max(right, left) - min(right, left)
 
 
-def zoom1d_cubic_nearest(values, factor: float) -> np.ndarray:
+def zoom1d_cubic_nearest(values, factor: float, grid_mode: bool = False) -> np.ndarray:
     """scipy.ndimage.zoom(values, factor, order=3, mode="nearest", grid_mode=False) (scipy/ndimage/_interpolation.py zoom,
     src/ni_splines.c) restated for 1-D float64 input, as ProfileBase.as_resampled calls it (pylinac/core/profile.py:
     370-376): 12 edge samples of padding, cubic B-spline prefilter with mirror initialisation, four-tap evaluation at
@@ -1996,10 +1996,14 @@ def zoom1d_cubic_nearest(values, factor: float) -> np.ndarray:
     c[ln - 1] = (z * c[ln - 2] + c[ln - 1]) * z / (z * z - 1)
     for i in range(ln - 2, -1, -1):
         c[i] = z * (c[i + 1] - c[i])
-    zoom = (n - 1) / (m - 1) if m > 1 else 1.0
+    if grid_mode:
+        zoom = n / m
+        shift = 0.5 * zoom - 0.5
+    else:
+        zoom, shift = ((n - 1) / (m - 1) if m > 1 else 1.0), 0.0
     out = np.empty(m)
     for i in range(m):
-        cc = zoom * i + npad
+        cc = zoom * i + shift + npad
         fl = math.floor(cc)
         y = cc - fl
         zz = 1 - y

@@ -128,8 +128,8 @@ __global__ void gradient_kernel(const double* __restrict__ y, int L, int64_t tot
   out[i] = k == 0 ? p[1] - p[0] : (k == L - 1 ? p[L - 1] - p[L - 2] : (p[k + 1] - p[k - 1]) / 2.0);
 }
 
-// ---- scipy.ndimage.zoom(values, zoom, order=3, mode="nearest", grid_mode=False) of 1-D profiles --------------------
-// (ProfileBase.as_resampled, pylinac/core/profile.py:353-390).  scipy pads the input with 12 edge samples, runs the cubic
+// ---- scipy.ndimage.zoom(values, zoom, order=3, mode="nearest", grid_mode) of 1-D profiles --------------------
+// (ProfileBase.as_resampled, pylinac/core/profile.py:353-390; PhysicalProfileMixin.as_resampled :950-1011 with grid_mode).  scipy pads the input with 12 edge samples, runs the cubic
 // B-spline prefilter (pole sqrt(3) - 2, mirror initialisation) over the padded array and evaluates the four-tap spline
 // at i * (L - 1) / (S - 1) + 12 with clamped tap indices.  The prefilter is a sequential recursion: one lane per profile.
 constexpr int kZoomPad = 12;
@@ -159,15 +159,18 @@ __global__ void zoom_prefilter_kernel(const double* __restrict__ y, int L, int64
   for (int i = n - 2; i >= 0; --i) c[i] = z * (c[i + 1] - c[i]);
 }
 
-__global__ void zoom_eval_kernel(const double* __restrict__ work, int L, int S, int64_t total, double* __restrict__ out) {
+__global__ void zoom_eval_kernel(const double* __restrict__ work, int L, int S, int grid_mode, int64_t total,
+                                 double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= total) return;
   const int q = (int)(i % S);
   const int64_t p = i / S;
   const int n = L + 2 * kZoomPad;
   const double* c = work + p * (int64_t)n;
-  const double zoom = S > 1 ? (double)(L - 1) / (double)(S - 1) : 1.0;
-  const double cc = zoom * (double)q + (double)kZoomPad;
+  // grid_mode: samples are cell centres (zoom = L / S, shift = zoom / 2 - 1 / 2); otherwise the end points coincide
+  const double zoom = grid_mode ? (double)L / (double)S : (S > 1 ? (double)(L - 1) / (double)(S - 1) : 1.0);
+  const double shift = grid_mode ? 0.5 * zoom - 0.5 : 0.0;
+  const double cc = zoom * (double)q + shift + (double)kZoomPad;
   const double fl = floor(cc);
   const double yv = cc - fl, zv = 1.0 - yv;
   const double w1 = (yv * yv * (yv - 2.0) * 3.0 + 4.0) / 6.0;
@@ -186,8 +189,8 @@ __global__ void zoom_eval_kernel(const double* __restrict__ work, int L, int S, 
 
 }  // namespace
 
-extern "C" int pl_zoom1d_cubic(const double* y, int64_t n_profiles, int length, int out_length, double* work,
-                               double* out, void* stream) {
+extern "C" int pl_zoom1d_cubic(const double* y, int64_t n_profiles, int length, int out_length, int grid_mode,
+                               double* work, double* out, void* stream) {
   PL_REQUIRE(y && work && out, "null pointer");
   PL_REQUIRE(n_profiles >= 0 && length >= 2 && out_length >= 1, "bad shape");
   if (n_profiles == 0) return PL_OK;
@@ -197,7 +200,7 @@ extern "C" int pl_zoom1d_cubic(const double* y, int64_t n_profiles, int length, 
   hipLaunchKernelGGL(zoom_prefilter_kernel, dim3((unsigned)pl_cdiv(n_profiles, kThreads)), dim3(kThreads), 0, st, y,
                      length, n_profiles, work);
   hipLaunchKernelGGL(zoom_eval_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0, st, work, length,
-                     out_length, total, out);
+                     out_length, grid_mode ? 1 : 0, total, out);
   return pl_check_launch("pl_zoom1d_cubic");
 }
 

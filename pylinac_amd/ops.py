@@ -670,9 +670,9 @@ def cubic_spline_moments(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return work[: n * length].view(n, length).clone()
 
 
-def zoom1d_cubic(y: torch.Tensor, zoom: float) -> torch.Tensor:
-    """``scipy.ndimage.zoom(profile, zoom, order=3, mode="nearest", grid_mode=False)`` for float64 profiles [N, L] (or
-    [L]) -> float64 [N, round(L * zoom)] (pylinac/core/profile.py:370-376)."""
+def zoom1d_cubic(y: torch.Tensor, zoom: float, grid_mode: bool = False) -> torch.Tensor:
+    """``scipy.ndimage.zoom(profile, zoom, order=3, mode="nearest", grid_mode=grid_mode)`` for float64 profiles [N, L]
+    (or [L]) -> float64 [N, round(L * zoom)] (pylinac/core/profile.py:370-376, 985-991)."""
     yy = y if y.dim() == 2 else y.unsqueeze(0)
     yy = yy.to(torch.float64).contiguous()
     n, length = yy.shape
@@ -681,7 +681,8 @@ def zoom1d_cubic(y: torch.Tensor, zoom: float) -> torch.Tensor:
         raise ValueError("zoom leaves no samples")
     work = torch.empty(n * (length + 24), dtype=torch.float64, device=yy.device)
     out = torch.empty((n, out_length), dtype=torch.float64, device=yy.device)
-    check(_lib.load().pl_zoom1d_cubic(yy.data_ptr(), n, length, out_length, work.data_ptr(), out.data_ptr(), _stream()),
+    check(_lib.load().pl_zoom1d_cubic(yy.data_ptr(), n, length, out_length, 1 if grid_mode else 0, work.data_ptr(),
+                                      out.data_ptr(), _stream()),
           "pl_zoom1d_cubic")
     return out if y.dim() == 2 else out[0]
 

@@ -427,6 +427,37 @@ class PhysicalProfileMixin:
     def field_width_mm(self) -> float:
         return self.field_width_px / self.implicit_dpmm
 
+    def as_simple_profile(self):
+        """profile.py:936-948: the non-physical class over the physical x-values"""
+        return type(self).__bases__[-1](values=self.values, x_values=self.physical_x_values)
+
+    def as_resampled(self, interpolation_resolution_mm: float = 0.1, order: int = 3, grid: bool = True):
+        """profile.py:950-1011: zoom by ``1 / (dpmm * resolution)`` (``grid_mode=grid``: every sample is a cell of
+        physical size), x-values widened by the half-cell offset, a new physical profile at ``1 / resolution`` dpmm."""
+        import warnings
+
+        if order != 3:
+            raise NotImplementedError("as_resampled is built for the cubic spline (order=3) the reference defaults to")
+        values = np.asarray(self.values)
+        arr_range = values.max() - values.min()
+        if values.dtype != float and arr_range < 100:
+            warnings.warn(f"Array range is small ({arr_range}) and is not a float. Interpolation may look step-like. "
+                          "Consider converting the array to a float before passing it to this method.", UserWarning)
+        factor = 1 / (self.dpmm * interpolation_resolution_mm)
+        new_y = ops.zoom1d_cubic(_to_device_profile(values.astype(np.float64)), factor, grid_mode=grid).cpu().numpy()
+        if values.dtype.kind in "iu":
+            info = np.iinfo(values.dtype)
+            new_y = np.clip(np.where(new_y > 0, new_y + 0.5, new_y - 0.5), info.min, info.max).astype(values.dtype)
+        elif values.dtype == np.float32:
+            new_y = new_y.astype(np.float32)
+        if grid:
+            offset = 0.5 - 1 / (2 * factor)
+            new_x = np.linspace(self.x_values.min() - offset, self.x_values.max() + offset, len(new_y))
+        else:
+            new_x = np.linspace(self.x_values.min(), self.x_values.max(), len(new_y))
+        return type(self)(values=new_y, x_values=new_x, dpmm=factor * self.dpmm, ground=False,
+                          normalization=Normalization.NONE, **self._resample_kwargs())
+
 
 class FWXMProfilePhysical(PhysicalProfileMixin, FWXMProfile):
     """profile.py:1014-1043"""

@@ -480,12 +480,34 @@ def check_as_resampled(dev):
         p = cls(long23, **kw)
         for factor, length in ((2, 46), (10, 230), (0.5, 12)):
             if cls is profile.FWXMProfilePhysical:
-                continue                                  # the physical classes resample by resolution (not built)
+                continue                                  # the physical classes resample by resolution (below)
             r = p.as_resampled(interpolation_factor=factor)
             assert len(r) == length and isinstance(r, cls) and r.x_values.max() == p.x_values.max()
             assert abs(r.values.max() - p.values.max()) < 0.1
             want = ndimage.zoom(long23, zoom=factor, order=3, grid_mode=False, mode="nearest")
             assert np.allclose(r.values, want, rtol=1e-12, atol=1e-12)
+    # grid mode + the physical variants: the reference's known answers (tests_basic/core/test_profile.py:483-538, 583-638)
+    v = rng.normal(size=(2, 41)) * 10
+    for f in (0.5, 2.0, 10.0, 3.7):
+        got = ops.zoom1d_cubic(torch.from_numpy(v).to(dev), f, grid_mode=True).cpu().numpy()
+        want = np.stack([ndimage.zoom(r, zoom=f, order=3, grid_mode=True, mode="nearest") for r in v])
+        assert got.shape == want.shape and np.allclose(got, want, rtol=1e-12, atol=1e-11), f
+    for cls, kw in ((profile.FWXMProfilePhysical, dict(fwxm_height=50)), (profile.InflectionDerivativeProfilePhysical, dict()),
+                    (profile.HillProfilePhysical, dict(hill_window_ratio=0.2))):
+        same = cls(long23, dpmm=2, **kw).as_resampled(interpolation_resolution_mm=0.5)
+        assert len(same) == 23 and isinstance(same, cls) and same.x_values.max() == 22
+        p1 = cls(long23, dpmm=1, **kw)
+        r10 = p1.as_resampled(interpolation_resolution_mm=0.1)
+        assert len(r10) == 230 and isinstance(r10, cls) and r10.x_values.max() == p1.x_values.max() + 0.45
+        assert r10.dpmm == 10 and abs(r10.x_values[0] + 0.45) < 0.01 and abs(r10.values.max() - 10) < 0.1
+        want = ndimage.zoom(long23, zoom=10, order=3, grid_mode=True, mode="nearest")
+        assert np.allclose(r10.values, want, rtol=1e-12, atol=1e-12)
+        # resampling a resampled profile again must not use grid mode (:620-638)
+        r100 = p1.as_resampled(interpolation_resolution_mm=0.01)
+        r100_2 = r10.as_resampled(interpolation_resolution_mm=0.01, grid=False)
+        assert len(r100.values) == len(r100_2.values)
+    simple = profile.FWXMProfilePhysical(long23, fwxm_height=50, dpmm=2).as_simple_profile()
+    assert type(simple) is profile.FWXMProfile and np.allclose(simple.x_values, np.arange(23) / 2 + 0.25)
     ints = profile.FWXMProfile((long23 * 1000).astype(np.int32), fwxm_height=50).as_resampled(3)
     want = ndimage.zoom((long23 * 1000).astype(np.int32), zoom=3, order=3, grid_mode=False, mode="nearest")
     assert ints.values.dtype == want.dtype and np.array_equal(ints.values, want)

@@ -477,9 +477,10 @@ def test_zoom_restatement_matches_scipy():
     for n in (5, 12, 23, 24, 63, 200):
         for f in (2, 10, 0.5, 3.3, 1.0, 7.25):
             v = rng.normal(size=n) * 100
-            want = ndimage.zoom(v, zoom=f, order=3, grid_mode=False, mode="nearest")
-            got = o.zoom1d_cubic_nearest(v, f)
-            assert got.shape == want.shape and np.allclose(got, want, rtol=1e-13, atol=1e-13 * np.abs(want).max()), (n, f)
+            for grid in (False, True):
+                want = ndimage.zoom(v, zoom=f, order=3, grid_mode=grid, mode="nearest")
+                got = o.zoom1d_cubic_nearest(v, f, grid)
+                assert got.shape == want.shape and np.allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max()), (n, f)
 
 
 def test_starshot_restatement_matches_reference(golden):
