@@ -206,6 +206,17 @@ class _ProfileBase:
         r = _linear_at(self.x_values.astype(float), np.asarray(self.values, dtype=float), x)
         return float(r) if r.size == 1 else r
 
+    def x_at_y(self, y, side: str):
+        """profile.py:279-292: the x-value where one flank of the profile reaches ``y`` (linear ``interp1d`` over the
+        samples left / right of the centre, sorted by value like scipy does for unsorted abscissae)."""
+        s_idx = self.x_idx_at_x(self.center_idx)
+        vals = np.asarray(self.values, dtype=float)
+        xs = np.asarray(self.x_values, dtype=float)
+        v, x = (vals[:s_idx], xs[:s_idx]) if side == LEFT else (vals[s_idx:], xs[s_idx:])
+        order = np.argsort(v, kind="mergesort")
+        r = np.asarray(_Linear1d(v[order], x[order], extrapolate=False)(y))
+        return float(r) if r.size == 1 else r
+
     def field_edge_idx(self, side: str) -> float:
         raise NotImplementedError
 

@@ -66,6 +66,10 @@ for i in (0, 3, 7, 12, 19):
         out[f"fx{i}.fwxm.field_x.{r}"] = np.asarray(p.field_x_values(r), float)
         out[f"fx{i}.fwxm.field_v.{r}"] = np.asarray(p.field_values(r), float)
         out[f"fx{i}.fwxm.field_idx.{r}"] = np.asarray(p.field_indices(r), float)
+    ys = np.array([0.2, 0.5, 0.8]) * (np.max(fx.values) - np.min(fx.values)) + np.min(fx.values)
+    out[f"fx{i}.fwxm.x_at_y_in"] = ys
+    out[f"fx{i}.fwxm.x_at_y_left"] = np.asarray(p.x_at_y(ys, "left"), float)
+    out[f"fx{i}.fwxm.x_at_y_right"] = np.asarray(p.x_at_y(ys, "right"), float)
     tx = np.linspace(np.min(fx.x_values) * 0.6, np.max(fx.x_values) * 0.7, 37)
     q = p.resample_to(prof.FWXMProfile(np.ones(37), x_values=tx))
     out[f"fx{i}.fwxm.resample_x"], out[f"fx{i}.fwxm.resample_y"] = np.asarray(q.x_values, float), np.asarray(q.values, float)

@@ -447,6 +447,10 @@ def check_profile_base_fields(g, dev=None):
             assert np.array_equal(p.field_x_values(r), g[f"fx{i}.fwxm.field_x.{r}"]), (i, r)
             assert np.allclose(p.field_values(r), g[f"fx{i}.fwxm.field_v.{r}"], rtol=1e-12, atol=1e-12), (i, r)
             assert np.allclose(p.field_indices(r), g[f"fx{i}.fwxm.field_idx.{r}"], rtol=0, atol=1e-12), (i, r)
+        ys = g[f"fx{i}.fwxm.x_at_y_in"]
+        assert np.allclose(p.x_at_y(ys, "left"), g[f"fx{i}.fwxm.x_at_y_left"], rtol=1e-12, atol=1e-12), i
+        assert np.allclose(p.x_at_y(ys, "right"), g[f"fx{i}.fwxm.x_at_y_right"], rtol=1e-12, atol=1e-12), i
+        assert isinstance(p.x_at_y(float(ys[1]), "left"), float)
         tx = g[f"fx{i}.fwxm.resample_x"]
         q = p.resample_to(profile.FWXMProfile(np.ones(len(tx)), x_values=tx))
         assert isinstance(q, profile.FWXMProfile) and np.array_equal(q.x_values, tx)
