@@ -509,3 +509,48 @@ def test_emulated_reductions_statistics_sweep(emulated):
         got = ops.circle_profile(t, cx, cy, radii, np.pi * radii.max() * 2, 0, True, 5.0)[0].cpu().numpy()
         want = orc.collapsed_circle_profile(img[0], (cx, cy), r, width_ratio=0.1, num_profiles=5)
         assert np.allclose(got, want, rtol=1e-13, atol=1e-9), (cx, cy, r)
+
+
+def test_emulated_bb_finder_random_windows(emulated):
+    """find_features_batch (label -> region table -> pl_features_level: flood fill, perimeter, hull, predicates, weighted
+    centroid, de-duplication) on randomly generated BB windows -- sizes, positions, blur, noise, a second BB, a rod --
+    against the oracle's restatement of the reference's find_features (itself pinned to the reference under scikit-image
+    0.18.3): same level, same count, centroids to 1e-10."""
+    import torch
+    from scipy import ndimage
+
+    from pylinac_amd import features as pf
+
+    rng = np.random.default_rng(77)
+    dpmm = 2.98
+    wins, specs = [], []
+    for k in range(10):
+        n = int(rng.integers(90, 150))
+        yy, xx = np.mgrid[0:n, 0:n].astype(float)
+        img = np.full((n, n), 0.2)
+        r_mm = 2.5 * rng.uniform(0.85, 1.15)
+        cy, cx = rng.uniform(n * 0.3, n * 0.7, 2)
+        img[np.hypot(yy - cy, xx - cx) < r_mm * dpmm] = 1.0
+        if k % 3 == 1:          # a second BB, well separated
+            cy2, cx2 = cy + rng.choice([-1, 1]) * 30, cx + rng.choice([-1, 1]) * 25
+            img[np.hypot(yy - cy2, xx - cx2) < 2.5 * dpmm] = 0.9
+        if k % 4 == 2:          # a thin rod attached to the BB
+            img[int(cy) - 1:int(cy) + 1, int(cx):min(n - 8, int(cx) + 40)] = 0.8
+        img = ndimage.gaussian_filter(img, rng.uniform(0.6, 1.6)) + rng.normal(0, 0.01, (n, n))
+        wins.append(img)
+        specs.append((2 if k % 3 == 1 else 1, 5.0))
+    checked = 0
+    for img, (maxn, minsep) in zip(wins, specs):
+        try:
+            ref_pts, ref_level = orc.find_features_restated(img, dpmm, 2.5, 0.5, max_number=maxn, min_separation_mm=minsep)
+        except ValueError:
+            ref_pts, ref_level = [], -1
+        res = pf.find_features_batch(torch.from_numpy(img[None]).to(emulated), dpmm, 2.5, 0.5, max_number=maxn,
+                                     min_separation_mm=minsep)
+        assert int(res["status"][0]) == 0
+        assert int(res["count"][0]) == len(ref_pts) and int(res["level"][0]) == ref_level, (len(ref_pts), ref_level)
+        if ref_pts:
+            got = res["xy"][0, : len(ref_pts)].cpu().numpy()
+            assert np.allclose(got, np.array(ref_pts), rtol=1e-10, atol=1e-10)
+            checked += 1
+    assert checked >= 6
