@@ -554,3 +554,30 @@ def test_emulated_bb_finder_random_windows(emulated):
             assert np.allclose(got, np.array(ref_pts), rtol=1e-10, atol=1e-10)
             checked += 1
     assert checked >= 6
+
+
+def test_emulated_picket_fence_random_frames(emulated):
+    """analyze_batch (scaled column mean, picket peaks, leaf x picket windows, FWXM positions) on random picket-fence
+    frames -- picket count, spacing, gap, pixel size, frame size, hidden rows -- against the oracle's per-image loop
+    (pinned to the reference's own PicketFence.analyze): same NaN pattern, identical positions."""
+    import torch
+
+    from pylinac_amd import picketfence as ppf
+    from tests.golden.make_golden import pf_frame
+
+    rng = np.random.default_rng(88)
+    for k in range(6):
+        pixel = float(rng.choice([0.78125, 0.6, 1.0]))
+        h, w = int(rng.integers(120, 200)), int(rng.integers(260, 420))
+        n_pickets = int(rng.integers(3, 8))
+        spacing = float(rng.uniform(18, 30))
+        frame = pf_frame(h + 8, w + 8, pixel, 4000 + k, n_pickets=n_pickets, spacing_mm=spacing,
+                         gap_mm=float(rng.uniform(1.5, 3.5)))[4:-4, 4:-4]
+        frame = np.ascontiguousarray(frame)
+        res = ppf.analyze_batch(torch.from_numpy(frame[None]).to(emulated), 1 / pixel)
+        ref = orc.pf_measure(orc.normalize(orc.ground(frame)), 1 / pixel)
+        P = len(ref["peak_idxs"])
+        assert int(res.picket_count[0]) == P, (k, P)
+        pos = res.position[0, :, :P].cpu().numpy()
+        assert np.array_equal(np.isnan(pos), np.isnan(ref["position"])), k
+        assert np.array_equal(pos[~np.isnan(pos)], ref["position"][~np.isnan(pos)]), k
