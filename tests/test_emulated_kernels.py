@@ -581,3 +581,46 @@ def test_emulated_picket_fence_random_frames(emulated):
         pos = res.position[0, :, :P].cpu().numpy()
         assert np.array_equal(np.isnan(pos), np.isnan(ref["position"])), k
         assert np.array_equal(pos[~np.isnan(pos)], ref["position"][~np.isnan(pos)]), k
+
+
+def test_emulated_wl_field_xim_gamma_random(emulated):
+    """Three more randomised audits on the emulated device: the WL field CAX (percentile threshold -> fill holes ->
+    centre of mass) on random field / BB geometries, XIM decoding of random images whose differences need 1-, 2- and
+    4-byte codes, and gamma_2d on random dose pairs -- all against the pinned restatements, exact."""
+    import torch
+
+    from pylinac_amd import gamma as pg
+    from pylinac_amd import winston_lutz, xim
+
+    rng = np.random.default_rng(99)
+    # ---- WL field CAX
+    frames = []
+    for k in range(5):
+        h, w = int(rng.integers(90, 160)), int(rng.integers(90, 160))
+        yy, xx = np.mgrid[0:h, 0:w]
+        cy, cx, half = rng.integers(35, h - 35), rng.integers(35, w - 35), int(rng.integers(10, 25))
+        img = np.where((abs(yy - cy) < half) & (abs(xx - cx) < half), 42000, 1500).astype(np.int64)
+        bb = ((yy - cy - rng.integers(-4, 5)) ** 2 + (xx - cx - rng.integers(-4, 5)) ** 2) < rng.integers(9, 40)
+        img[bb] = 11000
+        img = img + rng.integers(0, 300, img.shape)
+        frames.append(img.astype(np.uint16))
+    for f in frames:
+        got = winston_lutz.field_centroids_batch(torch.from_numpy(f[None]).to(emulated))[0].cpu().numpy()
+        want = orc.wl_field_centroid(f)
+        assert np.allclose(got, want, rtol=0, atol=1e-9), (got, want)
+    # ---- XIM
+    for k, (h, w, step) in enumerate(((23, 31, 90), (40, 17, 20000), (9, 64, 3000000))):
+        img = np.cumsum(rng.integers(-step, step, (h, w)), axis=1)
+        img = (img + rng.integers(-step, step, (h, 1))).astype(np.int32)
+        lut, stream = orc.xim_encode(img)
+        out = xim.decode_xim_pixels(lut, stream, w, h, 4, device=emulated).cpu().numpy()
+        assert np.array_equal(out, img), k
+    # ---- gamma_2d
+    for k in range(3):
+        ref = rng.uniform(0, 100, (20 + k, 24)) * (rng.random((20 + k, 24)) > 0.05)
+        ev = ref * rng.uniform(0.95, 1.05, ref.shape)
+        kw = dict(dose_to_agreement=float(rng.choice([1, 2, 3])), distance_to_agreement=int(rng.integers(1, 4)),
+                  gamma_cap_value=2, global_dose=bool(k % 2), dose_threshold=float(rng.choice([0, 5, 10])))
+        got = pg.gamma_2d(ref, ev, device=emulated, **kw).cpu().numpy()
+        want = orc.gamma_2d(ref, ev, **kw)
+        assert np.array_equal(got, want, equal_nan=True), kw
