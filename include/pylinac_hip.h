@@ -94,6 +94,9 @@ int pl_invert(const void* in, void* out, int dtype, int64_t n, int64_t count, co
 /* out = a * factor   (same dtype; the multiply inside stretch(), array_utils.py:168) */
 int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,
              void* stream);
+/* out = np.array(in, dtype=T) for float64 in: C conversion through a 64-bit integer then narrowing (negative values wrap
+ * into unsigned types), which convert_to_dtype's `relative * range - max - 1` depends on (array_utils.py:171-198). */
+int pl_cast_wrap(const double* in, void* out, int dtype, int64_t count, void* stream);
 
 /* ---- a3: BaseImage.threshold / as_binary (pylinac/core/image.py:785-815) ------------------------
  * kind 0 ('high'): out = a >= t ? a : 0 ; kind 1 ('low'): out = a <= t ? a : 0.

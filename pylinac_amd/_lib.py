@@ -98,6 +98,7 @@ SIGNATURES = {
     "pl_bakai_gamma": ([_p, _p, _p, _p, C.c_float, C.c_float, _l, _p, _p], C.c_int),
     "pl_gamma1d": ([_p, _p, _i, _p, _p, _i, _d, _d, _i, _d, _d, _d, _i, _d, _d, _p, _p, _p, _p, _p], C.c_int),
     "pl_gamma2d": ([_p, _p, _l, _i, _i, _d, _i, _p, _p, _p, _p, _i, _d, _d, _d, _p, _p, _p], C.c_int),
+    "pl_cast_wrap": ([_p, _p, _i, _l, _p], C.c_int),
     "pl_zoom1d_cubic": ([_p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_gradient1d": ([_p, _l, _i, _p, _p], C.c_int),
     "pl_interp1d": ([_p, _l, _p, _l, _i, _p, _i, _i, _p, _p, _p], C.c_int),

@@ -14,6 +14,8 @@ import torch
 from . import ops
 
 _NP_OK = (np.uint8, np.uint16, np.int16, np.int32, np.int64, np.float32, np.float64)
+_TORCH_OF = {np.uint8: torch.uint8, np.uint16: torch.uint16, np.int16: torch.int16, np.int32: torch.int32,
+             np.int64: torch.int64, np.float32: torch.float32, np.float64: torch.float64}
 
 
 def _device() -> torch.device:
@@ -128,6 +130,49 @@ def stretch(array, min: int = 0, max: int = 1):
     nrm = ops.normalize(g)
     scaled = ops.scale(nrm, float(max - min))
     return s.out(ops.ground(scaled, value=float(min)))
+
+
+def bit_invert(array):
+    """array_utils.py:80-89: ``np.invert`` = the datatype-specific complement (0 -> 255 for uint8, -1 for int8)."""
+    a = np.asarray(array)
+    array_not_empty(a)
+    if a.dtype.kind not in "iub":
+        raise ValueError(f"The datatype {a.dtype} could not be safely inverted. This usually means the array is a "
+                         "float-like datatype. Cast to an integer-like datatype first.")
+    info = np.iinfo(a.dtype) if a.dtype.kind in "iu" else None
+    s = _Staged(a)                        # dtypes without a kernel (int8, uint32, ...) are staged as int64
+    n = s.t.shape[0]
+    lo = torch.full((n,), float(info.min if info else 0), dtype=torch.float64, device=s.t.device)
+    hi = torch.full((n,), float(info.max if info else 1), dtype=torch.float64, device=s.t.device)
+    out = torch.empty_like(s.t)           # ~a == -a + max + min of the dtype (max + min == -1 for signed types)
+    from ._lib import check, load
+
+    check(load().pl_invert(s.t.data_ptr(), out.data_ptr(), ops._dt(s.t), n, s.t[0].numel(), lo.data_ptr(),
+                           hi.data_ptr(), ops._stream()), "pl_invert")
+    return s.out(out).astype(a.dtype)
+
+
+def convert_to_dtype(array, dtype):
+    """array_utils.py:171-198: rescale the VALUES to the same relative position in the new datatype's range (integer
+    input: ``a / old_max``; float input: stretched to 0..1), then ``relative * range - max - 1`` cast to ``dtype``
+    (the cast wraps negative values into unsigned types, which is what makes the formula land on ``relative * max``)."""
+    a = np.asarray(array)
+    array_not_empty(a)
+    new = np.dtype(dtype)
+    if a.dtype.kind == "f":
+        rel = _Staged(stretch(a, min=0, max=1)).t
+    else:
+        rel = ops.normalize(_Staged(a).t, float(np.iinfo(a.dtype).max))
+    info = np.iinfo(new) if new.kind in "iu" else np.finfo(new)
+    f = ops.scale(rel, float(info.max) - float(info.min))
+    zeros = torch.zeros(f.shape[0], dtype=torch.float64, device=f.device)
+    f = ops.ground(ops.ground(f, value=-float(info.max), mn=zeros), value=-1.0, mn=zeros)     # (x - max) - 1
+    kernel_dtype = new if new.type in _NP_OK else (np.dtype(np.int64) if new.kind in "iu" else np.dtype(np.float64))
+    out = torch.empty(f.shape, dtype=_TORCH_OF[kernel_dtype.type], device=f.device)
+    from ._lib import check, load
+
+    check(load().pl_cast_wrap(f.data_ptr(), out.data_ptr(), ops._dt(out), f.numel(), ops._stream()), "pl_cast_wrap")
+    return out.cpu().numpy().reshape(a.shape).astype(new)      # int8 / uint32 ...: exact narrowing of the int64 result
 
 
 def geometric_center_idx(array) -> float:

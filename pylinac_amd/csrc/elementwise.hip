@@ -6,6 +6,7 @@
 //   pl_normalize   array / val   (-> float64)               pylinac/core/array_utils.py:63-71
 //   pl_invert      -array + array.max() + array.min()       pylinac/core/array_utils.py:74-77
 //   pl_scale       array * scalar  (stretch)                pylinac/core/array_utils.py:168
+//   pl_cast_wrap   np.array(float64, dtype=T) incl. the wrap of negative values (convert_to_dtype :198)
 //   pl_threshold   np.where(a >= t, a, 0) / (a <= t)        pylinac/core/image.py:785-800
 //   pl_as_binary   np.where(a >= t, 1, 0)                   pylinac/core/image.py:802-815
 //
@@ -290,6 +291,28 @@ extern "C" int pl_invert(const void* in, void* out, int dtype, int64_t n, int64_
                        (T*)out, count, p.chunk, p.bpf, d_min, d_max);
   });
   return pl_check_launch("pl_invert");
+}
+
+// np.array(float64_values, dtype=T) as numpy does it on x86-64 (C conversion through a 64-bit integer, then narrowing:
+// negative values wrap into unsigned types).  convert_to_dtype (array_utils.py:171-198) relies on exactly that wrap:
+// `relative * range - max - 1` is negative for unsigned targets and lands on the right value modulo 2^bits.
+template <typename T>
+__global__ void cast_wrap_kernel(const double* __restrict__ in, T* __restrict__ out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  if (is_floating<T>::value) out[i] = (T)in[i];
+  else out[i] = (T)(long long)in[i];
+}
+
+extern "C" int pl_cast_wrap(const double* in, void* out, int dtype, int64_t count, void* stream) {
+  PL_REQUIRE(in && out, "null pointer");
+  PL_REQUIRE(count >= 0, "bad count");
+  if (count == 0) return PL_OK;
+  PL_REQUIRE(pl_cdiv(count, kThreads) <= 0x7fffffffLL, "batch too large for one launch");
+  PL_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL(cast_wrap_kernel<T>, dim3((unsigned)pl_cdiv(count, kThreads)), dim3(kThreads), 0,
+                                       (hipStream_t)stream, in, (T*)out, count));
+  return pl_check_launch("pl_cast_wrap");
 }
 
 extern "C" int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,

@@ -515,3 +515,39 @@ def check_as_resampled(dev):
     ints = profile.FWXMProfile((long23 * 1000).astype(np.int32), fwxm_height=50).as_resampled(3)
     want = ndimage.zoom((long23 * 1000).astype(np.int32), zoom=3, order=3, grid_mode=False, mode="nearest")
     assert ints.values.dtype == want.dtype and np.array_equal(ints.values, want)
+
+
+def check_bit_invert_and_convert_to_dtype():
+    """array_utils.bit_invert / convert_to_dtype: the reference's literal known answers
+    (tests_basic/core/test_array_utils.py:152-173, 215-243) and numpy's own expressions on random arrays."""
+    from pylinac_amd import array_utils as au
+
+    assert np.array_equal(au.bit_invert(np.array([0, 10], dtype=np.uint8)), [255, 245])
+    assert np.array_equal(au.bit_invert(np.array([0, 10], dtype=np.uint16)), [65535, 65525])
+    assert np.array_equal(au.bit_invert(np.array([0, 10], dtype=np.int8)), [-1, -11])
+    try:
+        au.bit_invert(np.array([0, 10], dtype=float))
+    except ValueError as exc:
+        assert "could not be safely" in str(exc)
+    else:
+        raise AssertionError("float input must raise")
+    c = au.convert_to_dtype(np.array([5, 6, 7], dtype=np.uint8), dtype=np.uint16)
+    assert np.array_equal(c, [1285, 1542, 1799]) and c.dtype == np.uint16
+    c = au.convert_to_dtype(np.array([0, 100, 1000, 10000, 65535], dtype=np.uint16), dtype=np.uint8)
+    assert np.array_equal(c, [0, 1, 4, 39, 255]) and c.dtype == np.uint8
+    c = au.convert_to_dtype(np.array([0, 255], dtype=np.uint8), dtype=np.int8)
+    assert np.array_equal(c, [-128, 127]) and c.dtype == np.int8
+    c = au.convert_to_dtype(np.array([0, 255.2], dtype=float), dtype=np.uint16)
+    assert np.array_equal(c, [0, 65535]) and c.dtype == np.uint16
+    rng = np.random.default_rng(2)
+    for dt in (np.uint8, np.uint16, np.int16, np.int32):
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, info.max, (13, 17)).astype(dt)
+        assert np.array_equal(au.bit_invert(a), np.invert(a)), dt
+    a16 = rng.integers(0, 65535, (9, 21)).astype(np.uint16)
+    for new in (np.uint8, np.int16, np.uint16):
+        ninfo = np.iinfo(new)
+        with np.errstate(all="ignore"):
+            want = np.array(a16.astype(float) / 65535 * (ninfo.max - ninfo.min) - ninfo.max - 1, dtype=new)
+        got = au.convert_to_dtype(a16, new)
+        assert got.dtype == want.dtype and np.array_equal(got, want), new

@@ -624,3 +624,9 @@ def test_emulated_wl_field_xim_gamma_random(emulated):
         got = pg.gamma_2d(ref, ev, device=emulated, **kw).cpu().numpy()
         want = orc.gamma_2d(ref, ev, **kw)
         assert np.array_equal(got, want, equal_nan=True), kw
+
+
+def test_emulated_bit_invert_and_convert_to_dtype(emulated):
+    import next_row_checks as checks
+
+    checks.check_bit_invert_and_convert_to_dtype()

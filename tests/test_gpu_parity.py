@@ -1628,3 +1628,10 @@ def test_as_resampled_vs_scipy_zoom(dev):
     import next_row_checks as checks
 
     checks.check_as_resampled(dev)
+
+
+def test_bit_invert_and_convert_to_dtype(dev):
+    """a5 companions (array_utils.py:80-89, 171-198): the reference's literal known answers and numpy's expressions."""
+    import next_row_checks as checks
+
+    checks.check_bit_invert_and_convert_to_dtype()
