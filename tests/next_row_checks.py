@@ -371,6 +371,21 @@ def edge_profile_cases(g):
         yield f"fff{k}.hill", "hill", g[f"fff{k}.y"], dict(x_values=g[f"fff{k}.x"], hill_window_ratio=0.15)
 
 
+def check_edge_profile_known_answers(make):
+    """The reference's literal known answers for the inflection / Hill profile classes
+    (tests_basic/core/test_profile.py:383-448; deltas 0.01 / 0.1 as there)."""
+    s21 = np.array([0, 1, 2, 4, 6, 8, 9, 10, 10, 10, 10, 10, 10, 10, 9, 8, 6, 4, 2, 1, 0], dtype=float)
+    s20 = np.array([0, 1, 2, 4, 6, 8, 9, 10, 10, 10, 10, 10, 10, 9, 8, 6, 4, 2, 1, 0], dtype=float)
+    sharp21 = np.array([0, 1, 1, 2, 5, 8, 9, 10, 10, 10, 10, 10, 10, 10, 9, 8, 5, 2, 1, 1, 0], dtype=float)
+    p = make("infl", s21)
+    assert abs(p.center_idx - 10) < 0.01 and abs(p.field_edge_idx("left") - 3.5) < 0.01
+    assert abs(p.field_edge_idx("right") - 16.5) < 0.01 and abs(p.field_width_px - 13) < 0.01
+    assert abs(make("infl", s20).center_idx - 9.5) < 0.01
+    h = make("hill", sharp21, hill_window_ratio=0.2)
+    assert abs(h.center_idx - 10) < 0.1 and abs(h.field_edge_idx("left") - 3.8) < 0.1
+    assert abs(h.field_edge_idx("right") - 15.9) < 0.1 and abs(h.field_width_px - 12) < 0.1
+
+
 def check_edge_profiles(g, make, only=None):
     """`make(kind, values, **kw)` -> an object with field_edge_idx / center_idx / field_width_px (+ optionally
     geometric_center_idx / cax_index).  Edges come out of BFGS on a cubic interpolant (gtol 1e-5) and, for "hill", a

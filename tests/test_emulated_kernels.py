@@ -415,6 +415,9 @@ def test_emulated_edge_profiles(golden, emulated):
         n = checks.check_edge_profiles(golden("edge_profiles"), make,
                                        only=lambda t: t.startswith(("fx2.", "fx4.", "fx11.", "epid.", "fff1.")))
     assert n >= 10
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        checks.check_edge_profile_known_answers(make)
 
 
 def test_emulated_catphan_volume(golden, emulated):

@@ -1601,6 +1601,7 @@ def test_edge_profiles_vs_reference_golden(golden, dev):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert checks.check_edge_profiles(golden("edge_profiles"), make) == 65
+        checks.check_edge_profile_known_answers(make)
 
 
 def test_catphan_volume_localisation_vs_reference_golden(golden, dev):

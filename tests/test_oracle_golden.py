@@ -466,6 +466,7 @@ def test_edge_profile_restatement_matches_reference(golden):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert checks.check_edge_profiles(golden("edge_profiles"), make) == 65
+        checks.check_edge_profile_known_answers(make)
 
 
 def test_zoom_restatement_matches_scipy():
