@@ -24,6 +24,10 @@ PL_CCL_RUNS=1 timeout 60 python scripts/time_configs.py $OUT/configs_ccl_runs.js
 echo "--- per-pixel union-find" | tee -a $OUT/summary.txt; cat $OUT/configs_ccl_px.jsonl | tee -a $OUT/summary.txt
 echo "--- run-based union-find" | tee -a $OUT/summary.txt; cat $OUT/configs_ccl_runs.jsonl | tee -a $OUT/summary.txt
 
+# 2b. orientation timings of the "next"-row paths
+timeout 120 python scripts/time_next_rows.py $OUT/next_rows.jsonl 3 > $OUT/next_rows.log 2>&1
+echo "--- next-row paths" | tee -a $OUT/summary.txt; cat $OUT/next_rows.jsonl | tee -a $OUT/summary.txt
+
 # 3. the bench line (default), and the float64 Gaussian for reference
 timeout 200 python bench.py 2>&1 | tail -1 > $OUT/bench.json
 PL_GAUSS_PK=0 timeout 120 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_f64_gauss.json
