@@ -44,6 +44,8 @@
 //
 // u16 -> f32 without cvt instructions: (x16 | 0x4B000000) is the float 2^23 + x16; one v_pk_add_f32 with
 // -(2^23 + m) yields x - m for two pixels (exact).  int16 is XOR-biased into the unsigned domain first.
+#include <stdlib.h>
+
 #include "pl_common.h"
 
 namespace {
@@ -180,8 +182,11 @@ __device__ __forceinline__ void push_fails(FixList& fl, unsigned failmask, unsig
 // Workgroup tile = 128 columns x kVRows rows (+ 2*RAD halo rows) staged ONCE through LDS as m-subtracted
 // float pairs; lane = column pair, wave w owns kVRows/4 rows in groups of 8 outputs.
 // m = per-column minimum over the whole staged tile (a valid lower bound for every window in it).
-template <typename T, int RAD, int kVRows, int NW>
-__global__ void __launch_bounds__(NW * PL_WAVE, (NW == 8 ? 2 : (kVRows == 64 ? 2 : 3)))
+// OCC = workgroups per CU the register allocation is bounded for: 3 (134 VGPRs, the configuration measured in round 1)
+// or 4 (128 VGPRs: one 8-byte value spilled and reloaded once per 8-row group; a fourth wave per SIMD to hide the LDS /
+// barrier latency that keeps the VALU only ~half busy).  4 is selected with PL_GAUSS_V_OCC=4 until it has been timed.
+template <typename T, int RAD, int kVRows, int NW, int OCC = 3>
+__global__ void __launch_bounds__(NW * PL_WAVE, (NW == 8 ? 2 : (kVRows == 64 ? 2 : OCC)))
 gauss_v_pk(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_tiles, int row_tiles,
            const double* __restrict__ wts) {
   constexpr int NOUT = 8, WIN = NOUT + 2 * RAD;
@@ -552,8 +557,16 @@ int launch_pk_t(const T* in, T* out, int64_t n, int h, int w, int axis, const do
     const int64_t blocks = n * col_tiles * row_tiles;
     if (blocks > 0x7fffffffLL) return -1;
     // measured alternatives: 64-row tiles with 4 waves 0.69 ms, 64-row tiles with 8 waves 0.78 ms (32 rows: 0.58)
-    hipLaunchKernelGGL((gauss_v_pk<T, RAD, kVRows, 4>), dim3((unsigned)blocks), dim3(kPkThreads), 0, st, in, out,
-                       h, w, col_tiles, row_tiles, wts);
+    static const bool occ4 = [] {
+      const char* e = getenv("PL_GAUSS_V_OCC");
+      return e && e[0] == '4';
+    }();
+    if (occ4)
+      hipLaunchKernelGGL((gauss_v_pk<T, RAD, kVRows, 4, 4>), dim3((unsigned)blocks), dim3(kPkThreads), 0, st, in, out,
+                         h, w, col_tiles, row_tiles, wts);
+    else
+      hipLaunchKernelGGL((gauss_v_pk<T, RAD, kVRows, 4>), dim3((unsigned)blocks), dim3(kPkThreads), 0, st, in, out,
+                         h, w, col_tiles, row_tiles, wts);
   } else {
     const int col_tiles = (int)pl_cdiv(w, PL_WAVE * 8);
     const int64_t rows_total = n * h;

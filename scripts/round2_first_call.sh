@@ -31,10 +31,14 @@ echo "--- next-row paths" | tee -a $OUT/summary.txt; cat $OUT/next_rows.jsonl | 
 # 3. the bench line (default), and the float64 Gaussian for reference
 timeout 200 python bench.py 2>&1 | tail -1 > $OUT/bench.json
 PL_GAUSS_PK=0 timeout 120 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_f64_gauss.json
+# axis-0 packed kernel bounded for 4 workgroups per CU (128 VGPRs): parity of the Gaussian tests, then the bench
+PL_GAUSS_V_OCC=4 timeout 120 python -m pytest tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider -k "gaussian or filters" > $OUT/pytest_occ4.log 2>&1
+echo "occ4 pytest rc=$?" | tee -a $OUT/summary.txt
+PL_GAUSS_V_OCC=4 timeout 120 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_v_occ4.json
 python - <<'PY' | tee -a $OUT/summary.txt
 import json, os
 out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "r2_first")
-for name in ("bench.json", "bench_f64_gauss.json"):
+for name in ("bench.json", "bench_f64_gauss.json", "bench_v_occ4.json"):
     try:
         d = json.load(open(os.path.join(out, name)))
         print(name, d["value"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["stage_ms"])
