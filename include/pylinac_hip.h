@@ -200,6 +200,13 @@ int pl_clear_border(const uint8_t* d_mask, uint8_t* d_out, int64_t n, int h, int
 int pl_region_stats(const int32_t* d_labels, const double* d_intensity, int64_t n, int h, int w,
                     int max_labels, unsigned long long* d_isum, double* d_wsum, double* d_stats,
                     int32_t* d_overflow, void* stream);
+/* pl_region_moments: exact raw moments per label, uint64 [n][max_labels][6] = m00, m10 (sum r), m01 (sum c),
+ *   m20, m02, m11 in image coordinates: what skimage 0.18.3's regionprops.moments_central / inertia_tensor /
+ *   orientation / eccentricity are formed from (measure/_regionprops.py:318-322, 394-420; called at
+ *   pylinac/planar_imaging.py:2348, pylinac/ct.py:2522-2563).  The host forms the central moments in exact
+ *   integer arithmetic, so symmetric regions decide `a - c == 0` exactly. */
+int pl_region_moments(const int32_t* d_labels, int64_t n, int h, int w, int max_labels,
+                      unsigned long long* d_mom, int32_t* d_overflow, void* stream);
 
 /* ---- a13: one threshold level of find_features (pylinac/metrics/utils.py:128-180 + features.py) ---
  * Inputs per window i: d_sample float64 [n][h][w] (the stretched sample), the 4-connected label image of

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pl_compare": ([_p, _i, _l, _l, _p, _i, _i, _p, _p], C.c_int),
     "pl_clear_border": ([_p, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_region_stats": ([_p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p], C.c_int),
+    "pl_region_moments": ([_p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_features_level": ([_p, _p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_fields_level": ([_p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_roi_stats": ([_p, _i, _l, _i, _i, _p, _i, _l, _i, _p, _p, _p], C.c_int),

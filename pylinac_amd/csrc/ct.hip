@@ -181,6 +181,56 @@ __global__ void region_finish_kernel(const unsigned long long* __restrict__ isum
   o[7] = wsum[g * 3 + 0]; o[8] = wsum[g * 3 + 1]; o[9] = wsum[g * 3 + 2];
 }
 
+// ---- exact raw second moments per label (regionprops.orientation / eccentricity / centroid) ------
+// m00, m10 = sum r, m01 = sum c, m20 = sum r*r, m02 = sum c*c, m11 = sum r*c in IMAGE coordinates, exact uint64.
+// The central moments are translation invariant and are formed from these on the host in exact integer
+// arithmetic (n*m20 - m10*m10, ...), so symmetric regions give mu20 == mu02 and mu11 == 0 exactly.
+// A wave usually sits inside one region: the lanes that share the first pending label are summed with
+// cross-lane butterflies and one lane issues the six atomics.
+__global__ void __launch_bounds__(kThreads)
+region_moments_kernel(const int32_t* __restrict__ labels, int64_t total, int h, int w, int max_labels,
+                      unsigned long long* __restrict__ mom, int32_t* __restrict__ overflow) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t per_frame = (int64_t)h * w;
+  int lab = 0;
+  int64_t frame = 0;
+  unsigned long long r = 0, c = 0;
+  if (g < total) {
+    lab = labels[g];
+    frame = g / per_frame;
+    const int i = (int)(g - frame * per_frame);
+    r = (unsigned long long)(i / w);
+    c = (unsigned long long)(i % w);
+    if (lab > max_labels) { overflow[frame] = 1; lab = 0; }
+    if (lab < 0) lab = 0;
+  }
+  // key = (frame, label): a wave can straddle two frames
+  long long key = lab > 0 ? frame * (long long)max_labels + (lab - 1) : -1;
+  unsigned long long pending = __ballot(key >= 0);
+  const int lane = threadIdx.x & 63;
+  while (pending) {
+    const int leader = __builtin_ctzll(pending);
+    const long long k = __shfl(key, leader, 64);
+    const bool mine = key == k;
+    const unsigned long long grp = __ballot(mine);
+    unsigned long long v[6];
+    v[0] = mine ? 1ull : 0ull;
+    v[1] = mine ? r : 0ull;
+    v[2] = mine ? c : 0ull;
+    v[3] = mine ? r * r : 0ull;
+    v[4] = mine ? c * c : 0ull;
+    v[5] = mine ? r * c : 0ull;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v[q] = pl_wave_reduce(v[q], [](unsigned long long a, unsigned long long b) { return a + b; });
+    if (lane == leader) {
+      unsigned long long* s = mom + k * 6;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) atomicAdd(&s[q], v[q]);
+    }
+    pending &= ~grp;
+  }
+}
+
 }  // namespace
 
 int pl_ccl_roots(const uint8_t* mask, int invert, int64_t n, int h, int w, int conn, int* L, hipStream_t st);
@@ -273,4 +323,17 @@ extern "C" int pl_region_stats(const int32_t* d_labels, const double* d_intensit
   hipLaunchKernelGGL(region_finish_kernel, dim3((unsigned)pl_cdiv(rows, kThreads)), dim3(kThreads), 0, st, d_isum,
                      d_wsum, rows, d_stats);
   return pl_check_launch("pl_region_stats");
+}
+
+extern "C" int pl_region_moments(const int32_t* d_labels, int64_t n, int h, int w, int max_labels,
+                                 unsigned long long* d_mom, int32_t* d_overflow, void* stream) {
+  PL_REQUIRE(d_labels && d_mom && d_overflow, "null pointer");
+  PL_REQUIRE(max_labels > 0, "max_labels must be positive");
+  PL_CT_TOTAL();
+  hipError_t e = hipMemsetAsync(d_overflow, 0, (size_t)n * sizeof(int32_t), st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_mom, 0, (size_t)n * max_labels * 6 * sizeof(unsigned long long), st);
+  if (e != hipSuccess) { pl_set_error("pl_region_moments: memset: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+  hipLaunchKernelGGL(region_moments_kernel, dim3(blocks), dim3(kThreads), 0, st, d_labels, total, h, w, max_labels,
+                     d_mom, d_overflow);
+  return pl_check_launch("pl_region_moments");
 }

@@ -25,7 +25,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, regionprops as _rp
 
 CATPHAN_RADIUS_MM = 101  # pylinac/ct.py: CatPhanBase.catphan_radius_mm
 
@@ -217,13 +217,8 @@ def find_phantom_roll_volume(slices: torch.Tensor, mm_per_pixel: float, origin_s
         filled_area = float(ops.fill_holes(crop[None], connectivity_bg=8)[0].sum())
         if not thresh * 2 > filled_area > thresh / 2:
             continue
-        rc = torch.nonzero(crop).to(torch.float64)
-        d = rc - rc.mean(dim=0)
-        n = rc.shape[0]
-        mu20, mu02, mu11 = float((d[:, 0] ** 2).sum()), float((d[:, 1] ** 2).sum()), float((d[:, 0] * d[:, 1]).sum())
-        eig = np.clip(np.linalg.eigvalsh(np.array([[mu02 / n, -mu11 / n], [-mu11 / n, mu20 / n]])), 0, None)
-        l1, l2 = sorted(eig, reverse=True)
-        ecc = 0.0 if l1 == 0 else math.sqrt(1 - l2 / l1)
+        mom, _ = ops.region_moments(crop.to(torch.int32)[None], 1)            # exact integer raw moments
+        ecc = _rp.eccentricity(tuple(int(v) for v in mom[0, 0].cpu().tolist()))
         if ecc < 0.5:
             bubbles.append((stats[j, 5] / area, stats[j, 6] / area))          # centroid (row, col)
     cx = float(np.polyval(fit_zx, k))

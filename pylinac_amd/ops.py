@@ -631,6 +631,18 @@ def region_stats(labels: torch.Tensor, intensity: torch.Tensor | None, max_label
     return stats, ovf
 
 
+def region_moments(labels: torch.Tensor, max_labels: int):
+    """Exact raw moments per label -> (int64 [N, max_labels, 6] = m00, m10 (sum r), m01 (sum c), m20, m02, m11 in image
+    coordinates, int32 overflow [N]).  See ``regionprops.inertia_from_raw_moments`` for what is formed from them."""
+    lab = labels if labels.ndim == 3 else labels[None]
+    n, h, w = lab.shape
+    mom = torch.empty((n, int(max_labels), 6), dtype=torch.int64, device=lab.device)
+    ovf = torch.empty(n, dtype=torch.int32, device=lab.device)
+    check(_lib.load().pl_region_moments(lab.contiguous().data_ptr(), n, h, w, int(max_labels), mom.data_ptr(),
+                                        ovf.data_ptr(), _stream()), "pl_region_moments")
+    return mom, ovf
+
+
 def interp1d(x: torch.Tensor, y: torch.Tensor, xq: torch.Tensor, kind: str = "linear") -> torch.Tensor:
     """``scipy.interpolate.interp1d(x, y, kind, bounds_error=False, fill_value="extrapolate")(xq)`` for a batch
     of profiles: ``x`` float64 [L] (shared) or [N, L], ``y`` float64 [N, L] (or [L]), ``xq`` float64 [S]

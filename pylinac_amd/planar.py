@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
-from . import _lib, canny as _canny, ops
+from . import _lib, canny as _canny, ops, regionprops as _rp
 from ._lib import check
 
 
@@ -181,6 +181,7 @@ class PhantomRegion:
     label: int
     bbox: tuple
     image: torch.Tensor            # bool [bbox rows, bbox cols] on the device: region.image
+    _raw: tuple = None
 
     @property
     def bbox_area(self) -> int:
@@ -188,33 +189,30 @@ class PhantomRegion:
 
     area_bbox = bbox_area
 
-    def _moments(self):
-        """raw sums over the region's pixels in bbox-local (row, col) coordinates -> n, centroid, central second moments"""
-        rc = torch.nonzero(self.image).to(torch.float64)
-        n = rc.shape[0]
-        cen = rc.mean(dim=0)
-        d = rc - cen
-        mu20 = float((d[:, 0] * d[:, 0]).sum())        # rows
-        mu02 = float((d[:, 1] * d[:, 1]).sum())        # columns
-        mu11 = float((d[:, 0] * d[:, 1]).sum())
-        return n, (float(cen[0]), float(cen[1])), (mu20, mu02, mu11)
+    def _raw_moments(self):
+        """exact integer raw moments (m00, m10, m01, m20, m02, m11) of the region in bbox-local (row, col) coordinates
+        (``pl_region_moments``); see ``regionprops.py`` for how scikit-image's quantities are formed from them"""
+        if getattr(self, "_raw", None) is None:
+            mom, _ = ops.region_moments(self.image.to(torch.int32).contiguous()[None], 1)
+            self._raw = tuple(int(v) for v in mom[0, 0].cpu().tolist())
+        return self._raw
 
     @property
     def centroid(self) -> tuple:
         """regionprops.centroid: (row, col) in image coordinates"""
-        _, (r, c), _ = self._moments()
+        r, c = _rp.centroid(self._raw_moments())
         return (r + self.bbox[0], c + self.bbox[1])
 
     @property
     def orientation(self) -> float:
         """regionprops.orientation (scikit-image 0.18.3, used at planar_imaging.py:2348, 2498): the angle between the
-        row axis and the major axis of the region's inertia ellipse, from the normalised central second moments
-        (inertia tensor [[mu02, -mu11], [-mu11, mu20]] / n)."""
-        n, _, (mu20, mu02, mu11) = self._moments()
-        a, b, c = mu02 / n, -mu11 / n, mu20 / n
-        if a - c == 0:
-            return -math.pi / 4.0 if b < 0 else math.pi / 4.0
-        return 0.5 * math.atan2(-2 * b, c - a)
+        row axis and the major axis of the region's inertia ellipse, from the inertia tensor
+        [[mu02, -mu11], [-mu11, mu20]] / n built from exact integer moments."""
+        return _rp.orientation(self._raw_moments())
+
+    @property
+    def eccentricity(self) -> float:
+        return _rp.eccentricity(self._raw_moments())
 
     @property
     def bbox_center_xy(self) -> tuple:

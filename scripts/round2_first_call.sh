@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 
 # 1. the whole parity suite (includes the tests that never ran on hardware in round 1: the tail of test_gpu_parity.py)
-timeout 300 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
+timeout 420 python -m pytest tests -q -m gpu -p no:cacheprovider -rf > $OUT/pytest_gpu.log 2>&1
 echo "pytest rc=$?" | tee -a $OUT/summary.txt
 tail -3 $OUT/pytest_gpu.log | tee -a $OUT/summary.txt
 
@@ -27,6 +27,11 @@ echo "--- run-based union-find" | tee -a $OUT/summary.txt; cat $OUT/configs_ccl_
 # 2b. orientation timings of the "next"-row paths
 timeout 120 python scripts/time_next_rows.py $OUT/next_rows.jsonl 3 > $OUT/next_rows.log 2>&1
 echo "--- next-row paths" | tee -a $OUT/summary.txt; cat $OUT/next_rows.jsonl | tee -a $OUT/summary.txt
+
+# 2c. single-rank RCCL: init -> all_gather_into_tensor -> barrier inside the bench step
+PL_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 200 \
+  python bench.py --no-cpu-baseline > $OUT/bench_force_dist.log 2>&1
+echo "force-dist rc=$?" | tee -a $OUT/summary.txt; tail -1 $OUT/bench_force_dist.log | cut -c1-300 | tee -a $OUT/summary.txt
 
 # 3. the bench line (default), and the float64 Gaussian for reference
 timeout 200 python bench.py 2>&1 | tail -1 > $OUT/bench.json

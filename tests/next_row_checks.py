@@ -66,6 +66,63 @@ def check_phantom_outline(golden, dev, names=None):
         assert np.array_equal(di, g[f"{n}.dists"]), n
 
 
+# regions whose second moments are symmetric (a - c == 0 analytically) AND whose scikit-image value came out of the
+# general atan2 branch because np.dot's rounding left a - c = 1e-15: scikit-image's special-case branch has the opposite
+# sign convention to the limit of its general branch (b < 0 -> -pi/4 vs atan2(-2b, 0+) / 2 = +pi/4), so on such regions the
+# reference's sign is BLAS-rounding noise.  This build takes the special-case branch there (exact a - c == 0).
+REGIONPROPS_SIGN_IS_NOISE = ("blob_sym",)
+
+
+def raw_moments_numpy(labels, label=1):
+    r, c = np.nonzero(labels == label)
+    r, c = r.astype(object), c.astype(object)
+    return (len(r), int(r.sum()), int(c.sum()), int((r * r).sum()), int((c * c).sum()), int((r * c).sum()))
+
+
+def check_regionprops_formulas(g, raw_of):
+    """centroid / orientation / eccentricity / inertia tensor formed from exact raw moments against scikit-image 0.18.3's
+    regionprops (tests/golden/regionprops.npz); ``raw_of(labels) -> (m00, m10, m01, m20, m02, m11)``."""
+    from pylinac_amd import regionprops as rp
+
+    for n in g["names"]:
+        raw = raw_of(g[f"{n}.labels"])
+        assert raw == raw_moments_numpy(g[f"{n}.labels"]), n
+        assert np.allclose(rp.centroid(raw), g[f"{n}.centroid"], rtol=0, atol=1e-12), n
+        assert np.allclose(rp.inertia_tensor(raw), g[f"{n}.inertia_tensor"], rtol=1e-12, atol=1e-12), n
+        # sqrt(1 - l2/l1) near 0 amplifies the eigenvalues' rounding: absolute 1e-6 there, 1e-12 elsewhere
+        assert abs(rp.eccentricity(raw) - float(g[f"{n}.eccentricity"])) < 1e-6, n
+        want = float(g[f"{n}.orientation"])
+        if n in REGIONPROPS_SIGN_IS_NOISE:
+            assert abs(abs(rp.orientation(raw)) - np.pi / 4) < 1e-12 and abs(abs(want) - np.pi / 4) < 1e-12, n
+        else:
+            assert abs(rp.orientation(raw) - want) < 1e-12, (n, rp.orientation(raw), want)
+
+
+def check_region_moments_kernel(golden, dev):
+    """pl_region_moments on the golden label images (one label each) + a multi-label, multi-frame batch against numpy"""
+    from pylinac_amd import ops
+
+    g = golden("regionprops")
+
+    def raw_of(labels):
+        mom, ovf = ops.region_moments(torch.from_numpy(labels).to(dev), 1)
+        assert int(ovf.max()) == 0
+        return tuple(int(v) for v in mom[0, 0].cpu().tolist())
+
+    check_regionprops_formulas(g, raw_of)
+    rng = np.random.default_rng(3)
+    lab = rng.integers(0, 6, (3, 37, 131)).astype(np.int32)        # rows shorter than / straddling a 64-lane wave
+    lab[1] = 4                                                      # a frame that is one region
+    mom, ovf = ops.region_moments(torch.from_numpy(lab).to(dev), 5)
+    mom = mom.cpu().numpy()
+    assert int(ovf.max()) == 0
+    for f in range(3):
+        for k in range(1, 6):
+            assert tuple(int(v) for v in mom[f, k - 1]) == raw_moments_numpy(lab[f], k), (f, k)
+    _, ovf = ops.region_moments(torch.from_numpy(lab).to(dev), 3)
+    assert ovf.cpu().tolist() == [1, 1, 1]
+
+
 def check_rectangle_roi(golden, dev):
     """RectangleROI / polygon statistics against the reference's own RectangleROI and raw skimage.draw.polygon pixel
     lists (tests/golden/rect.npz): counts, min, max, median exact; mean / std to 1e-12 (summation order)."""

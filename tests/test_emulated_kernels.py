@@ -264,6 +264,13 @@ def test_emulated_phantom_outline(golden, emulated):
     checks.check_phantom_outline(golden, emulated, names=["sq0"])
 
 
+def test_emulated_region_moments(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_region_moments_kernel(golden, emulated)
+    checks.check_phantom_outline(golden, emulated, names=["sq45"])      # the symmetric region of round 1's failure
+
+
 def test_emulated_rectangle_roi(golden, emulated):
     import next_row_checks as checks
 

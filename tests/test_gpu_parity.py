@@ -1419,6 +1419,14 @@ def test_hough_line_peaks_vs_skimage_golden(golden, dev):
     checks.check_hough_line_peaks(golden, dev)
 
 
+def test_region_moments_vs_skimage_regionprops_golden(golden, dev):
+    """f2 / a16: exact integer raw moments per label (pl_region_moments) and scikit-image 0.18.3's centroid /
+    inertia_tensor / orientation / eccentricity formed from them, on 19 regions including axis-swap-symmetric ones."""
+    import next_row_checks as checks
+
+    checks.check_region_moments_kernel(golden, dev)
+
+
 def test_phantom_outline_vs_skimage_golden(golden, dev):
     """f2 (second half): canny -> label -> bbox table -> phantom_ski_region -> region.image -> hough_line on three
     synthetic phantom frames against scikit-image's own canny / label / regionprops / hough_line."""

@@ -100,3 +100,10 @@ def test_hann_window_restatement_is_scipys():
     for m in (1, 2, 3, 6, 8, 97, 256, 1001):
         assert np.array_equal(mtf.hann(m), windows.hann(m)), m
     assert np.array_equal(mtf.boxcar(5), windows.boxcar(5))
+
+
+def test_regionprops_formulas_vs_skimage_golden(golden):
+    """regionprops.py (exact integer central moments + scikit-image 0.18.3's expressions) against scikit-image itself"""
+    import next_row_checks as checks
+
+    checks.check_regionprops_formulas(golden("regionprops"), checks.raw_moments_numpy)
