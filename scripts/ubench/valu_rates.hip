@@ -24,7 +24,6 @@ __global__ void __launch_bounds__(256) k(unsigned* out, unsigned seed, unsigned 
         if (OP == 3) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "s"(w));
         if (OP == 4) asm volatile("v_perm_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(x), "s"(w));
         if (OP == 5) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "v"(x));
-        if (OP == 8) asm volatile("v_dot2_u32_u16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(x), "s"(w));
         if (OP == 9) asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "s"(w));
         if (OP == 10) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]));
         if (OP == 11) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(a[i]) : "v"(x));
@@ -78,7 +77,6 @@ void run(const char* name, int per_rep) {
 
 int main() {
   run<0>("v_dot2_u32_u16 (v,s)", 8);
-  run<8>("v_dot2_u32_u16 op_sel swap", 8);
   run<9>("v_dot2_i32_i16", 8);
   run<1>("v_fma_f32", 8);
   run<6>("v_pk_fma_f32 (per instr)", 4);
