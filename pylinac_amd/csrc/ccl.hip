@@ -24,8 +24,6 @@
 //   * 8-connectivity: the upper-left diagonal only when neither i-1 nor i-w is foreground, the upper-right one only
 //     when i-w is not (otherwise the row above connects them).
 // Every skipped union is implied by ones that other lanes perform in the same launch; roots stay the smallest index.
-#include <stdlib.h>
-
 #include "pl_common.h"
 
 namespace {
@@ -60,47 +58,9 @@ __device__ __forceinline__ void unite(int* L, int a, int b) {
   } while (!done);
 }
 
-// ---- per-pixel variant (the one measured in round 1: every foreground pixel starts as its own root and is united with
-// its visited neighbours).  Default until the run-based variant below has been timed on the GPU; PL_CCL_RUNS=1 selects
-// the run-based one.  Both produce the same roots.
-// fg(i) = (mask[i] != 0) ^ invert
-__global__ void ccl_init_px_kernel(const uint8_t* __restrict__ mask, int invert, int64_t total, int64_t per_frame,
-                                int* __restrict__ L) {
-  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (g >= total) return;
-  const bool fg = ((mask[g] != 0) ? 1 : 0) != invert;
-  L[g] = fg ? (int)(g % per_frame) : -1;
-}
-
-__global__ void ccl_merge_px_kernel(int* __restrict__ Lall, int64_t total, int h, int w, int conn8) {
-  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (g >= total) return;
-  const int64_t per_frame = (int64_t)h * w;
-  int* L = Lall + (g / per_frame) * per_frame;
-  const int i = (int)(g % per_frame);
-  if (L[i] < 0) return;
-  const int r = i / w, c = i % w;
-  if (c > 0 && L[i - 1] >= 0) unite(L, i, i - 1);
-  if (r > 0) {
-    if (L[i - w] >= 0) unite(L, i, i - w);
-    if (conn8) {
-      if (c > 0 && L[i - w - 1] >= 0) unite(L, i, i - w - 1);
-      if (c + 1 < w && L[i - w + 1] >= 0) unite(L, i, i - w + 1);
-    }
-  }
-}
-
-__global__ void ccl_compress_px_kernel(int* __restrict__ Lall, int64_t total, int64_t per_frame) {
-  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (g >= total) return;
-  int* L = Lall + (g / per_frame) * per_frame;
-  const int i = (int)(g % per_frame);
-  if (L[i] < 0) return;
-  L[i] = find_root(L, i);
-}
-
-
-// ---- run-based variant ------------------------------------------------------------------------------------------------
+// Measured on MI355X (profiles/r02a_first_call_summary.txt, config #4: 512 x 1024^2 frames, fill-holes of a field mask
+// whose background is one component of a million pixels): per-pixel start (one or two atomic unions per pixel, round 1)
+// 133.5 ms, run-based start 20.3 ms.  The per-pixel variant is gone.
 // fg(i) = (mask[i] != 0) ^ invert.  L[i] = first pixel of i's run within its 64-lane chunk (lanes = consecutive pixels)
 __global__ void __launch_bounds__(kThreads)
 ccl_init_kernel(const uint8_t* __restrict__ mask, int invert, int64_t total, int64_t per_frame, int w,
@@ -285,28 +245,13 @@ __global__ void scaled_binary_kernel(const T* __restrict__ in, int64_t total, in
   out[g] = (grounded / div[f] >= thr[f]) ? 1 : 0;
 }
 
-// The run-based start is parity-checked (emulator + GPU tests run both) but not yet timed on the hardware: off by default.
-bool use_run_based_ccl() {
-  static const bool on = [] {
-    const char* e = getenv("PL_CCL_RUNS");
-    return e && e[0] == '1';
-  }();
-  return on;
-}
-
 int run_ccl(const uint8_t* mask, int invert, int64_t n, int h, int w, int conn, int* L, hipStream_t st) {
   const int64_t per_frame = (int64_t)h * w, total = n * per_frame;
   const unsigned blocks = (unsigned)pl_cdiv(total, kThreads);
-  if (use_run_based_ccl()) {
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(blocks), dim3(kThreads), 0, st, mask, invert, total, per_frame, w, L);
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, h, w, conn == 8 ? 1 : 0);
-    hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame, w, 1);
-    hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame, w, 0);
-  } else {
-    hipLaunchKernelGGL(ccl_init_px_kernel, dim3(blocks), dim3(kThreads), 0, st, mask, invert, total, per_frame, L);
-    hipLaunchKernelGGL(ccl_merge_px_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, h, w, conn == 8 ? 1 : 0);
-    hipLaunchKernelGGL(ccl_compress_px_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame);
-  }
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(blocks), dim3(kThreads), 0, st, mask, invert, total, per_frame, w, L);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, h, w, conn == 8 ? 1 : 0);
+  hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame, w, 1);
+  hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks), dim3(kThreads), 0, st, L, total, per_frame, w, 0);
   return pl_check_launch("ccl");
 }
 

@@ -443,22 +443,6 @@ def test_emu_fill_holes_and_clear_border(emu):
     _check_fill_holes_and_clear_border(emu)
 
 
-def test_emu_run_based_ccl_variant():
-    """PL_CCL_RUNS=1 (run-based union-find start, off by default until it has been timed on the GPU): the same label /
-    fill_holes / clear_border checks in a subprocess, because the switch is read once per process."""
-    import os
-    import subprocess
-
-    code = ("import sys; sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/hipemu')\n"
-            "import test_emulated_kernels as t\n"
-            "from emu_backend import load_emulated_library\n"
-            "lib = load_emulated_library()\n"
-            "t._check_label(lib); t._check_fill_holes_and_clear_border(lib); print('RUN_BASED_OK')\n")
-    r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), env={**os.environ, "PL_CCL_RUNS": "1"},
-                       capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "RUN_BASED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_emulated_profile_base_fields(golden, emulated):
     import next_row_checks as checks
 
