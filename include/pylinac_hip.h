@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_ABI_VERSION 1
+#define PL_ABI_VERSION 2
 
 typedef enum pl_status {
   PL_OK = 0,
@@ -58,20 +58,16 @@ int pl_device_available(void);
 /* ---- a2: ndimage.gaussian_filter (pylinac/core/array_utils.py:133) ------------------------------
  * One correlate1d pass along `axis` (0 = rows/vertical, 1 = columns/horizontal) of every frame,
  * mode='reflect', scipy's symmetric summation order in float64, result cast into `dtype`
- * (truncation toward zero for integer dtypes).  d_weights = 2*radius+1 float64 taps on the device
- * (scipy's _gaussian_kernel1d; the host layer computes them).  in != out. */
+ * (truncation toward zero for integer dtypes).  The 2*radius+1 float64 taps (scipy's _gaussian_kernel1d; the
+ * host layer computes them) are passed TWICE: d_weights on the device (read by the float64 kernels) and
+ * h_weights in host memory (the packed kernels for 16-bit frames receive them as kernel arguments).
+ * h_weights may be NULL: the library then fetches the taps from d_weights when it needs them, which
+ * SYNCHRONISES the stream -- pass both on a hot path.  in != out. */
 int pl_gaussian1d(const void* in, void* out, int dtype, int64_t n, int h, int w, int axis,
-                  const double* d_weights, int radius, void* stream);
+                  const double* d_weights, const double* h_weights, int radius, void* stream);
 /* axis 0 into tmp, then axis 1 into out: ndimage.gaussian_filter on a 2-D frame. */
 int pl_gaussian2d(const void* in, void* out, void* tmp, int dtype, int64_t n, int h, int w,
-                  const double* d_weights, int radius, void* stream);
-
-/* Pipeline fusion of Image.filter(sigma,"gaussian")'s axis-1 pass with Image.filter(3,"median")
- * (pylinac/core/image.py:695-712 twice; the PF noise filter, pylinac/picketfence.py:226):
- * out = median3x3(gauss_axis1(in)); the intermediate never leaves LDS.  tmp is only touched by the
- * unfused fallback (unsupported dtype / radius / very wide frames). */
-int pl_gauss_h_median3(const void* in, void* out, void* tmp, int dtype, int64_t n, int h, int w,
-                       const double* d_weights, int radius, void* stream);
+                  const double* d_weights, const double* h_weights, int radius, void* stream);
 
 /* ---- a1: ndimage.median_filter(size=s) (pylinac/core/array_utils.py:131) ------------------------
  * s x s window (h > 1) or length-s window (h == 1), mode='reflect', origin 0, rank (s*s)/2. */

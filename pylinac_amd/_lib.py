@@ -51,9 +51,8 @@ SIGNATURES = {
     "pl_status_string": ([_i], C.c_char_p),
     "pl_last_error": ([], C.c_char_p),
     "pl_device_available": ([], C.c_int),
-    "pl_gaussian1d": ([_p, _p, _i, _l, _i, _i, _i, _p, _i, _p], C.c_int),
-    "pl_gaussian2d": ([_p, _p, _p, _i, _l, _i, _i, _p, _i, _p], C.c_int),
-    "pl_gauss_h_median3": ([_p, _p, _p, _i, _l, _i, _i, _p, _i, _p], C.c_int),
+    "pl_gaussian1d": ([_p, _p, _i, _l, _i, _i, _i, _p, _p, _i, _p], C.c_int),
+    "pl_gaussian2d": ([_p, _p, _p, _i, _l, _i, _i, _p, _p, _i, _p], C.c_int),
     "pl_median2d": ([_p, _p, _i, _l, _i, _i, _i, _p], C.c_int),
     "pl_minmax": ([_p, _i, _l, _l, _p, _p, _p], C.c_int),
     "pl_ground": ([_p, _p, _i, _l, _l, _p, _d, _p], C.c_int),
@@ -150,7 +149,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.pl_abi_version() != 1:
+    if lib.pl_abi_version() != 2:
         raise PylinacHipError(f"ABI version mismatch: library reports {lib.pl_abi_version()}")
     _lib = lib
     return lib

@@ -88,6 +88,20 @@ __device__ __forceinline__ unsigned char pl_from_double<unsigned char>(double v)
   return (unsigned char)(unsigned int)v;
 }
 
+// Buffer addressing (MUBUF): base in a 4-SGPR resource, a wave-uniform byte offset in an SGPR, the lane's byte offset in
+// ONE VGPR -- strided row walks cost no per-access VALU address arithmetic.  Bounds checking is not relied upon
+// (num_records covers the whole 32-bit offset range); callers keep every offset inside their allocation.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pl_make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ unsigned pl_buffer_load_u32(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uniform_off) {
+  return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)uniform_off, 0);
+}
+__device__ __forceinline__ void pl_buffer_store_u32(unsigned v, __amdgpu_buffer_rsrc_t r, unsigned lane_off,
+                                                    unsigned uniform_off) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)lane_off, (int)uniform_off, 0);
+}
+
 // wave-level reductions (64 lanes, xor butterflies -> every lane holds the result)
 template <typename T, typename F>
 __device__ __forceinline__ T pl_wave_reduce(T v, F f) {

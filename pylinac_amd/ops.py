@@ -78,12 +78,14 @@ def gaussian_weights(sigma: float, truncate: float = 4.0) -> tuple[np.ndarray, i
 _weights_cache: dict = {}
 
 
-def _device_weights(sigma: float, device) -> tuple[torch.Tensor, int]:
+def _device_weights(sigma: float, device) -> tuple[torch.Tensor, np.ndarray, int]:
+    """(taps on the device, the same taps in host memory, radius): the C ABI takes both copies (pylinac_hip.h)"""
     key = (float(sigma), str(device))
     hit = _weights_cache.get(key)
     if hit is None:
         w, lw = gaussian_weights(sigma)
-        hit = (torch.from_numpy(w).to(device), lw)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        hit = (torch.from_numpy(w).to(device), w, lw)
         _weights_cache[key] = hit
     return hit
 
@@ -92,12 +94,12 @@ def gaussian_filter(frames: torch.Tensor, sigma: float, out=None, tmp=None) -> t
     """``ndimage.gaussian_filter(frame, sigma)`` per frame (pylinac/core/array_utils.py:133)."""
     x = _frames(frames)
     n, h, w = x.shape
-    wts, lw = _device_weights(sigma, x.device)
+    wts, hw, lw = _device_weights(sigma, x.device)
     out = torch.empty_like(x) if out is None else out
     tmp = torch.empty_like(x) if tmp is None else tmp
     check(
         _lib.load().pl_gaussian2d(x.data_ptr(), out.data_ptr(), tmp.data_ptr(), _dt(x), n, h, w,
-                                  wts.data_ptr(), lw, _stream()),
+                                  wts.data_ptr(), hw.ctypes.data, lw, _stream()),
         "pl_gaussian2d",
     )
     return out
@@ -112,11 +114,11 @@ def gaussian_filter1d(x: torch.Tensor, sigma: float, axis: int = -1) -> torch.Te
         f = _frames(x)
         ax = axis
     n, h, w = f.shape
-    wts, lw = _device_weights(sigma, f.device)
+    wts, hw, lw = _device_weights(sigma, f.device)
     out = torch.empty_like(f)
     check(
-        _lib.load().pl_gaussian1d(f.data_ptr(), out.data_ptr(), _dt(f), n, h, w, ax, wts.data_ptr(), lw,
-                                  _stream()),
+        _lib.load().pl_gaussian1d(f.data_ptr(), out.data_ptr(), _dt(f), n, h, w, ax, wts.data_ptr(), hw.ctypes.data,
+                                  lw, _stream()),
         "pl_gaussian1d",
     )
     return out.reshape(x.shape)
@@ -546,7 +548,7 @@ def gaussian_filter_mode(frames: torch.Tensor, sigma: float, mode: str = "neares
     """``ndimage.gaussian_filter(frame, sigma, mode=...)``; ``skimage.filters.gaussian`` uses 'nearest'."""
     x = _frames(frames)
     n, h, w = x.shape
-    wts, lw = _device_weights(sigma, x.device)
+    wts, _, lw = _device_weights(sigma, x.device)
     out, tmp = torch.empty_like(x), torch.empty_like(x)
     check(_lib.load().pl_gaussian2d_mode(x.data_ptr(), out.data_ptr(), tmp.data_ptr(), _dt(x), n, h, w,
                                          wts.data_ptr(), lw, {"reflect": 0, "nearest": 1, "constant": 2}[mode], _stream()),

@@ -25,7 +25,7 @@ from ._lib import check
 RECORD_FIELDS = ("otsu_threshold", "n_peaks", "peak_idx", "peak_height", "prominence",
                  "left_edge", "right_edge", "center", "width")
 
-STAGES = ("gauss_v", "gauss_h_median3", "hist16", "otsu", "threshold_colsum", "colsum_to_mean",
+STAGES = ("gauss_v", "gauss_h", "median3", "hist16", "otsu", "threshold_colsum", "colsum_to_mean",
           "find_peaks", "fwxm_record")
 
 
@@ -51,13 +51,6 @@ class EpidPipeline:
     sigma: float = 5
     median_size: int = 3
     fwxm_height: float = 50
-    # fuse the Gaussian's axis-1 pass with the 3x3 median: one HBM round trip less, but measured
-    # slower than the two specialised kernels on MI355X (VALU-issue-bound either way) -> opt-in
-    fused: bool = False
-    # software pipelining over frame chunks: the two Gaussian passes (FP64-issue-bound) of chunk i+1 run
-    # on a second HIP stream while the median/histogram/threshold/profile stages (memory-bound) of chunk i
-    # run on the first.  1 = a single stream, whole batch per launch.
-    chunks: int = 1
     timings: dict = field(default_factory=dict)
 
     def __post_init__(self):
@@ -82,13 +75,9 @@ class EpidPipeline:
             props=torch.empty((n, 6, 1), dtype=torch.float64, device=dev),
             status=torch.empty(n, dtype=torch.int32, device=dev),
         )
-        self.wts, self.radius = ops._device_weights(self.sigma, dev)
+        self.wts, self.host_wts, self.radius = ops._device_weights(self.sigma, dev)
         self.prm = ops.make_peak_params(w, fwxm_height=self.fwxm_height / 100, max_number=1)
         self.lib = _lib.load()
-        if self.chunks < 1 or self.n % self.chunks:
-            raise ValueError("chunks must divide the batch")
-        if self.chunks > 1:
-            self._filter_stream = torch.cuda.Stream(device=dev)
 
     def run(self, frames: torch.Tensor, events: dict | None = None) -> EpidResult:
         """One pass over a resident batch.  ``events``: optional {stage: [(start, stop), ...]} sink;
@@ -116,7 +105,7 @@ class EpidPipeline:
 
         fb = h * w * 2                                   # bytes per uint16 frame
         xp, ap, bp, op = x.data_ptr(), self.buf_a.data_ptr(), self.buf_b.data_ptr(), self.out.data_ptr()
-        wts, pk = self.wts.data_ptr(), self.peaks
+        wts, hwts, pk = self.wts.data_ptr(), self.host_wts.ctypes.data, self.peaks
         hist, thr, vmin, vmax = (t.data_ptr() for t in (self.hist, self.thr, self.vmin, self.vmax))
         colsum, profile, fwxm = self.colsum.data_ptr(), self.profile.data_ptr(), self.fwxm.data_ptr()
         cnt, idx, lb, rb, props, status = (t.data_ptr() for t in (pk.count, pk.idx, pk.left_bases,
@@ -125,22 +114,16 @@ class EpidPipeline:
         def filters(lo, m, stream):
             """Image.filter(sigma, "gaussian"): axis 0 then axis 1, frames [lo, lo+m)."""
             st, o = stream.cuda_stream, lo * fb
-            stage("gauss_v", lambda: lib.pl_gaussian1d(xp + o, ap + o, U16, m, h, w, 0, wts, self.radius, st), stream)
-            if self.fused and self.median_size == 3:
-                stage("gauss_h_median3", lambda: lib.pl_gauss_h_median3(ap + o, bp + o, op + o, U16, m, h, w, wts,
-                                                                        self.radius, st), stream)
-            else:
-                stage("gauss_h", lambda: lib.pl_gaussian1d(ap + o, bp + o, U16, m, h, w, 1, wts, self.radius, st),
-                      stream)
+            stage("gauss_v", lambda: lib.pl_gaussian1d(xp + o, ap + o, U16, m, h, w, 0, wts, hwts, self.radius, st),
+                  stream)
+            stage("gauss_h", lambda: lib.pl_gaussian1d(ap + o, bp + o, U16, m, h, w, 1, wts, hwts, self.radius, st),
+                  stream)
 
         def rest(lo, m, stream):
             """median -> Otsu -> threshold -> column profile -> FWXM record, frames [lo, lo+m)."""
             st, o = stream.cuda_stream, lo * fb
-            if self.fused and self.median_size == 3:
-                med = bp + o
-            else:
-                stage("median3", lambda: lib.pl_median2d(bp + o, ap + o, U16, m, h, w, self.median_size, st), stream)
-                med = ap + o
+            stage("median3", lambda: lib.pl_median2d(bp + o, ap + o, U16, m, h, w, self.median_size, st), stream)
+            med = ap + o
             stage("hist16", lambda: lib.pl_hist16(med, U16, m, h * w, hist + lo * 65536 * 4, st), stream)
             stage("otsu", lambda: lib.pl_otsu_from_hist(hist + lo * 65536 * 4, U16, m, thr + lo * 4, vmin + lo * 4,
                                                         vmax + lo * 4, st), stream)
@@ -154,17 +137,6 @@ class EpidPipeline:
             stage("fwxm_record", lambda: lib.pl_fwxm_record(cnt + lo * 4, idx + lo * 4, props + lo * 48, 1, m,
                                                             fwxm + lo * 64, st), stream)
 
-        if self.chunks == 1:
-            filters(0, self.n, main)
-            rest(0, self.n, main)
-        else:
-            m = self.n // self.chunks
-            fs = self._filter_stream
-            fs.wait_stream(main)                      # frames (and the previous step's readers) are ready
-            for c in range(self.chunks):
-                filters(c * m, m, fs)
-                done = torch.cuda.Event()
-                done.record(fs)
-                main.wait_event(done)
-                rest(c * m, m, main)
+        filters(0, self.n, main)
+        rest(0, self.n, main)
         return EpidResult(self.out, self.profile, self.thr, self.fwxm, self.peaks.status)

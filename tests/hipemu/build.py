@@ -20,7 +20,7 @@ BUILD = HERE / "_build"
 LIB = BUILD / "libpylinac_emu.so"
 
 # the ROCm toolchain's clang++ as a plain x86 host compiler: it understands the clang vector extensions
-# (ext_vector_type, __builtin_elementwise_*) that gaussian_pk.hip is written in; g++ does for everything else
+# (ext_vector_type, __builtin_elementwise_*) that gaussian_rw.hip is written in; g++ does for everything else
 _CLANG = pathlib.Path("/opt/rocm/lib/llvm/bin/clang++")
 CXX = str(_CLANG) if _CLANG.exists() else "g++"
 
@@ -28,7 +28,7 @@ SOURCES = ["runtime.hip", "interp.hip", "gamma.hip", "roi.hip", "canny.hip", "el
            "edge.hip", "circle.hip", "spectral.hip", "xim.hip", "planar.hip", "ccl.hip", "ct.hip", "features.hip", "peaks.hip",
            "hist_otsu.hip", "picketfence.hip", "median.hip", "gaussian.hip"]
 if CXX != "g++":
-    SOURCES.append("gaussian_pk.hip")
+    SOURCES.append("gaussian_rw.hip")
 
 _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([\w\s]+?)\s+(\w+)\[\];")
 
@@ -61,7 +61,7 @@ def build(sources=None, verbose: bool = False) -> pathlib.Path:
         cpps.append(str(out))
     cmd = [CXX, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
            "-Wno-attributes", "-Wno-unknown-pragmas", f"-I{HERE}", f"-I{BUILD}", f"-I{CSRC}", *cpps, str(HERE / "hipemu.cpp"),
-           *([] if "gaussian_pk.hip" in sources else [str(HERE / "emu_stubs.cpp")]),
+           *([] if "gaussian_rw.hip" in sources else [str(HERE / "emu_stubs.cpp")]),
            "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))

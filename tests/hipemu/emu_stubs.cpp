@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- entry points of csrc files the emulator build leaves out.
-// gaussian_pk.hip is gfx950-specific (packed-float32 VALU builtins, clang vector types): in the emulated library the
-// launcher reports "not covered" (-1), which is the documented signal for gaussian.hip to use its float64 kernels.
+// gaussian_rw.hip is written with clang vector types: when only g++ is available as the host compiler the emulated
+// library reports "not covered", which is the documented signal for gaussian.hip to use its float64 kernels.
 #include "hip/hip_runtime.h"
 
-int pl_gauss_pk_launch(const void*, void*, int, int64_t, int, int, int, const double*, int, hipStream_t) { return -1; }
+int pl_gauss_rw_covers(const void*, const void*, int, int, int, int) { return 0; }
+int pl_gauss_rw_launch(const void*, void*, int, int64_t, int, int, int, const double*, int, hipStream_t) { return -1; }

@@ -108,6 +108,7 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind
 template <typename F>
 inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 
 // ---- barriers and wave intrinsics ------------------------------------------------------------------------
 inline void __syncthreads() { hipemu::block_barrier(); }
@@ -115,6 +116,22 @@ inline int __syncthreads_or(int p) { return hipemu::block_barrier_or(p); }
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::shfl_from(0, 0))
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_fract(x) ((x) - floor(x))
+#define __builtin_amdgcn_fractf(x) ((x) - floorf(x))
+// MUBUF raw buffer access: resource = base pointer, offsets are plain byte offsets
+struct hipemu_rsrc { char* base; };
+#define __amdgpu_buffer_rsrc_t hipemu_rsrc
+inline hipemu_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return hipemu_rsrc{(char*)p}; }
+inline unsigned __builtin_amdgcn_raw_buffer_load_b32(hipemu_rsrc r, int voff, int soff, int) {
+  unsigned v;
+  memcpy(&v, r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, 4);
+  return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, hipemu_rsrc r, int voff, int soff, int) {
+  memcpy(r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, &v, 4);
+}
+// v_alignbit_b32: low 32 bits of ({hi, lo} >> (s & 31))
+#define __builtin_amdgcn_alignbit(hi, lo, s) \
+  ((unsigned)(((((unsigned long long)(unsigned)(hi)) << 32) | (unsigned)(lo)) >> ((s) & 31)))
 // v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {src1 (bytes 0-3), src0 (bytes 4-7)}; 0x0c -> 0x00
 inline unsigned hipemu_perm(unsigned src0, unsigned src1, unsigned sel) {
   const unsigned long long pool = ((unsigned long long)src0 << 32) | src1;

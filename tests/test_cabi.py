@@ -52,19 +52,19 @@ def test_library_contains_gfx950_code_object():
 
 
 def test_status_strings_and_version(lib):
-    assert lib.pl_abi_version() == 1
+    assert lib.pl_abi_version() == 2
     assert lib.pl_status_string(0) == b"ok"
     assert b"invalid" in lib.pl_status_string(1)
 
 
 def test_argument_validation_without_launch(lib):
     """Invalid arguments are rejected with PL_ERR_INVALID_ARG before any HIP call."""
-    assert lib.pl_gaussian1d(None, None, 0, 1, 4, 4, 0, None, 1, None) == 1
+    assert lib.pl_gaussian1d(None, None, 0, 1, 4, 4, 0, None, None, 1, None) == 1
     assert b"pl_gaussian1d" in lib.pl_last_error()
     buf = (C.c_uint16 * 16)()
     w = (C.c_double * 3)()
     p = C.cast(buf, C.c_void_p)
-    assert lib.pl_gaussian1d(p, p, 0, 1, 4, 4, 0, C.cast(w, C.c_void_p), 1, None) == 1  # in-place refused
+    assert lib.pl_gaussian1d(p, p, 0, 1, 4, 4, 0, C.cast(w, C.c_void_p), None, 1, None) == 1  # in-place refused
     assert lib.pl_median2d(p, p, 0, 1, 4, 4, 3, None) == 1
     assert lib.pl_hist16(p, 3, 1, 16, p, None) == 1  # float dtype refused
     assert lib.pl_reduce_axis(p, 0, 1, 4, 4, 2, 0, p, None) == 1  # bad axis

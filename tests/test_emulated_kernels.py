@@ -126,20 +126,20 @@ def test_emu_gaussian_f64_kernels_match_scipy(emu):
         wts = np.ascontiguousarray(wts / wts.sum())
         out = np.empty_like(frames)
         tmp = np.empty_like(frames)
-        _ok(emu, emu.pl_gaussian2d(_p(frames), _p(out), _p(tmp), PL_U16, 2, 70, 96, _p(wts), radius, None))
+        _ok(emu, emu.pl_gaussian2d(_p(frames), _p(out), _p(tmp), PL_U16, 2, 70, 96, _p(wts), _p(wts), radius, None))
         want = np.stack([ndimage.gaussian_filter(f, sigma) for f in frames])
         np.testing.assert_array_equal(out, want)
 
 
 def test_emu_gaussian_packed_f32_decision_kernels(emu):
-    """gaussian_pk.hip (the bench's default Gaussian for 16-bit frames) under the emulator (needs the ROCm clang++ as
+    """gaussian_rw.hip (the bench's default Gaussian for 16-bit frames) under the emulator (needs the ROCm clang++ as
     host compiler: clang vector types): radii 4 / 8 / 12 / 20, uint16 and int16, frames with flat and saturated
     regions so that the LDS fix list and the exact float64 tiers run too.  Bit-identical to scipy."""
     import build as emu_build
     from scipy import ndimage
 
-    if "gaussian_pk.hip" not in emu_build.SOURCES:
-        pytest.skip("no clang++ host compiler: gaussian_pk.hip is not in the emulated library")
+    if "gaussian_rw.hip" not in emu_build.SOURCES:
+        pytest.skip("no clang++ host compiler: gaussian_rw.hip is not in the emulated library")
     rng = np.random.default_rng(8)
     base = rng.integers(0, 65535, (2, 96, 128)).astype(np.uint16)
     base[0, 20:60, 30:100] = 40000          # flat: S = c * sum(w) = c +- 1e-12 -> the undecided tiers
@@ -153,9 +153,42 @@ def test_emu_gaussian_packed_f32_decision_kernels(emu):
             wts = np.exp(-0.5 / (sigma * sigma) * x ** 2)
             wts = np.ascontiguousarray(wts / wts.sum())
             out, tmp = np.empty_like(frames), np.empty_like(frames)
-            _ok(emu, emu.pl_gaussian2d(_p(frames), _p(out), _p(tmp), _DT[frames.dtype], 2, 96, 128, _p(wts), radius, None))
+            _ok(emu, emu.pl_gaussian2d(_p(frames), _p(out), _p(tmp), _DT[frames.dtype], 2, 96, 128, _p(wts), _p(wts), radius, None))
             want = np.stack([ndimage.gaussian_filter(f, sigma) for f in frames])
             np.testing.assert_array_equal(out, want, err_msg=f"{frames.dtype} sigma {sigma}")
+
+
+def test_emu_gaussian_register_window_kernels(emu):
+    """gaussian_rw.hip (register-window kernels: lane-local minimum, wave-owned windows, raw LDS copy for the
+    fix-ups): partial row tiles, two column tiles with a partial second one on axis 1 (right halo inside inactive lanes'
+    positions), an odd number of rows, frames shorter than the halo (multiple reflections), zero / flat / saturated regions
+    (list overflow -> whole-tile recompute), int16.  Bit-identical to scipy."""
+    import build as emu_build
+    from scipy import ndimage
+
+    if "gaussian_rw.hip" not in emu_build.SOURCES:
+        pytest.skip("no clang++ host compiler: gaussian_rw.hip is not in the emulated library")
+    rng = np.random.default_rng(18)
+    cases = []
+    for shape in ((2, 150, 144), (1, 37, 1040), (3, 33, 16), (1, 9, 32)):
+        smooth = ndimage.gaussian_filter(rng.integers(0, 65535, shape).astype(float), (0, 5, 5))
+        a = np.clip(smooth + rng.normal(0, 300, shape), 0, 65535).astype(np.uint16)
+        a[0, : shape[1] // 3, : shape[2] // 2] = 0
+        a[-1, shape[1] // 2:, shape[2] // 2:] = 41234
+        cases.append(a)
+    cases.append((cases[0].astype(np.int32) - 31000).astype(np.int16))
+    cases.append(np.full((1, 70, 128), 65535, dtype=np.uint16))
+    for frames in cases:
+        n, h, w = frames.shape
+        for sigma in ((5,) if w > 1000 else (1, 2, 3, 5)):
+            radius = int(4.0 * sigma + 0.5)
+            x = np.arange(-radius, radius + 1)
+            wts = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+            wts = np.ascontiguousarray(wts / wts.sum())
+            out, tmp = np.empty_like(frames), np.empty_like(frames)
+            _ok(emu, emu.pl_gaussian2d(_p(frames), _p(out), _p(tmp), _DT[frames.dtype], n, h, w, _p(wts), _p(wts), radius, None))
+            want = np.stack([ndimage.gaussian_filter(f, sigma) for f in frames])
+            np.testing.assert_array_equal(out, want, err_msg=f"{frames.shape} {frames.dtype} sigma {sigma}")
 
 
 def test_emu_median3_packed_kernels(emu):
@@ -338,7 +371,7 @@ def test_emu_stencils_on_awkward_shapes(emu):
                 wts = np.exp(-0.5 / (sigma * sigma) * x ** 2)
                 wts = np.ascontiguousarray(wts / wts.sum())
                 out, tmp = np.empty_like(f), np.empty_like(f)
-                _ok(emu, emu.pl_gaussian2d(_p(f), _p(out), _p(tmp), code, 2, h, w, _p(wts), radius, None))
+                _ok(emu, emu.pl_gaussian2d(_p(f), _p(out), _p(tmp), code, 2, h, w, _p(wts), _p(wts), radius, None))
                 want = np.stack([ndimage.gaussian_filter(a, sigma) for a in f])
                 np.testing.assert_array_equal(out, want, err_msg=f"gaussian {dt.__name__} {h}x{w} sigma {sigma}")
             for size in (3, 5):
