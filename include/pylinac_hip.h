@@ -111,6 +111,13 @@ int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_h
  * one bin per integer in [min,max], float64 class statistics, first argmax.  Outputs int32[n]. */
 int pl_otsu_from_hist(const uint32_t* d_hist, int dtype, int64_t n, int32_t* d_thr,
                       int32_t* d_min, int32_t* d_max, void* stream);
+/* The same threshold straight from the 16-bit frames.  Frames whose values fit a window of 38 912 consecutive bins
+ * are read ONCE (+ a 1/16 row sample that places the window): histogram in 152 KiB of LDS, Otsu scan on the LDS bins,
+ * no table in HBM.  d_lo / d_hi: optional per-frame bounds (int32[n], d_lo <= values <= d_hi) that place the window
+ * instead of the sample; both NULL otherwise.  Frames that do not fit go through pl_hist16 + pl_otsu_from_hist inside
+ * the same call (d_hist uint32[n][65536] workspace is touched only for those; d_flag int32[n] scratch says which). */
+int pl_otsu16(const void* in, int dtype, int64_t n, int64_t count, const int32_t* d_lo, const int32_t* d_hi,
+              int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist, void* stream);
 /* exact order statistics: out[i][k] = value with 0-based rank d_ranks[k] in frame i
  * (np.percentile call sites: pylinac/core/image.py:899-926, picketfence.py:229-238). */
 int pl_order_stats_from_hist(const uint32_t* d_hist, int dtype, int64_t n, const int64_t* d_ranks,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pl_as_binary": ([_p, _p, _i, _l, _l, _p, _i, _p], C.c_int),
     "pl_hist16": ([_p, _i, _l, _l, _p, _p], C.c_int),
     "pl_otsu_from_hist": ([_p, _i, _l, _p, _p, _p, _p], C.c_int),
+    "pl_otsu16": ([_p, _i, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_order_stats_from_hist": ([_p, _i, _l, _p, _i, _p, _p], C.c_int),
     "pl_reduce_axis": ([_p, _i, _l, _i, _i, _i, _i, _p, _p], C.c_int),
     "pl_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),

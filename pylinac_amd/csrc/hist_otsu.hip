@@ -32,7 +32,7 @@ constexpr int kHistThreads = 1024;
 template <int PARTS, bool RUNS>
 __global__ void __launch_bounds__(kHistThreads)
 hist16_kernel(const unsigned short* __restrict__ in, int64_t n, int64_t count, unsigned flip,
-              uint32_t* __restrict__ hist) {
+              uint32_t* __restrict__ hist, const int32_t* __restrict__ only /* NULL, or per-frame: run when != 0 */) {
   constexpr int kBins = 65536 / PARTS;
   constexpr int kShift = PARTS == 4 ? 14 : 15;
   extern __shared__ unsigned bins[];  // kBins
@@ -41,6 +41,7 @@ hist16_kernel(const unsigned short* __restrict__ in, int64_t n, int64_t count, u
   const int64_t frame = (int64_t)(blockIdx.x / (8 * PARTS)) * 8 + (within & 7);
   const unsigned part = within >> 3;
   if (frame >= n) return;
+  if (only && !only[frame]) return;
   for (int i = threadIdx.x; i < kBins; i += kHistThreads) bins[i] = 0;
   __syncthreads();
 
@@ -95,7 +96,8 @@ hist16_kernel(const unsigned short* __restrict__ in, int64_t n, int64_t count, u
 }
 
 template <int PARTS, bool RUNS>
-int launch_hist16(const unsigned short* in, int64_t n, int64_t count, unsigned flip, uint32_t* hist, hipStream_t st) {
+int launch_hist16(const unsigned short* in, int64_t n, int64_t count, unsigned flip, uint32_t* hist, hipStream_t st,
+                  const int32_t* only = nullptr) {
   const size_t lds = (size_t)(65536 / PARTS) * sizeof(unsigned);
   static bool attr = false;
   if (!attr) {
@@ -109,7 +111,7 @@ int launch_hist16(const unsigned short* in, int64_t n, int64_t count, unsigned f
   const int64_t blocks = pl_cdiv(n, 8) * 8 * PARTS;
   if (blocks > 0x7fffffffLL) return -1;
   hipLaunchKernelGGL((hist16_kernel<PARTS, RUNS>), dim3((unsigned)blocks), dim3(kHistThreads), lds, st, in, n, count,
-                     flip, hist);
+                     flip, hist, only);
   return 0;
 }
 
@@ -141,12 +143,13 @@ __device__ __forceinline__ Pair block_exclusive_scan(Pair v, Pair* total, Pair* 
 
 __global__ void __launch_bounds__(kHistThreads)
 otsu_kernel(const uint32_t* __restrict__ hist, int bias, int32_t* __restrict__ thr,
-            int32_t* __restrict__ vmin, int32_t* __restrict__ vmax) {
+            int32_t* __restrict__ vmin, int32_t* __restrict__ vmax, const int32_t* __restrict__ only) {
   __shared__ Pair wave_tot[kHistThreads / 64];
   __shared__ int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64];
   __shared__ double s_var[kHistThreads / 64];
   __shared__ int s_idx[kHistThreads / 64];
   const int64_t frame = blockIdx.x;
+  if (only && !only[frame]) return;
   const uint32_t* hh = hist + frame * 65536;
   const int b0 = threadIdx.x * 64;
   const uint4* p = reinterpret_cast<const uint4*>(hh + b0);
@@ -213,6 +216,169 @@ otsu_kernel(const uint32_t* __restrict__ hist, int bias, int32_t* __restrict__ t
   }
 }
 
+// ---- single-pass Otsu: histogram in LDS + class statistics, one workgroup per frame -------------------------------------
+// A 152 KiB LDS window holds 38 912 consecutive bins.  Where the frame's values fit such a window the frame is read ONCE
+// (plus a 1/16 row sample), every pixel is one LDS atomic, and the Otsu scan runs on the LDS bins -- no 256 KiB table per
+// frame in HBM, no second reader, no second launch (256 x 1024^2: hist16 0.158 ms + otsu 0.064 ms before).
+// Window placement: the caller's bounds (lo_hint <= every value <= hi_hint) when given, else the extrema of every 16th
+// row, centred in the window (filtered frames are smooth: the sample misses the true extrema by a few counts, the
+// slack on either side is hundreds to thousands).  A pixel outside the window, or a range wider than the window,
+// sets flag[frame] = 1: the frame is then left to the two-kernel path, launched right behind and gated per frame by that flag.
+constexpr int kWinBins = 38912;   // 152 KiB
+
+__global__ void __launch_bounds__(kHistThreads)
+otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, unsigned flip, int bias,
+                     const int32_t* __restrict__ lo_hint, const int32_t* __restrict__ hi_hint, int32_t* __restrict__ thr,
+                     int32_t* __restrict__ vmin, int32_t* __restrict__ vmax, int32_t* __restrict__ flag) {
+  extern __shared__ unsigned bins[];  // kWinBins
+  __shared__ Pair wave_tot[kHistThreads / 64];
+  __shared__ int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64];
+  __shared__ double s_var[kHistThreads / 64];
+  __shared__ int s_idx[kHistThreads / 64];
+  const int64_t frame = blockIdx.x;
+  const unsigned short* src = in + frame * count;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int klo, khi;   // window = keys [klo, khi] (biased domain)
+  if (lo_hint) {
+    klo = lo_hint[frame] + bias;
+    khi = hi_hint[frame] + bias;
+  } else {
+    // extrema of a 1/16 sample: blocks of 1024 pixels (128 x 16 bytes), every 16th block
+    int mn = 1 << 30, mx = -1;
+    auto see = [&](unsigned key) {
+      const int k = (int)(key ^ flip);
+      mn = k < mn ? k : mn;
+      mx = k > mx ? k : mx;
+    };
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && count >= 8) {
+      const int64_t nvec = count / 8;
+      const uint4* vsrc = reinterpret_cast<const uint4*>(src);
+      for (int64_t blk = threadIdx.x >> 7; blk * 2048 < nvec; blk += kHistThreads >> 7) {
+        const int64_t idx = blk * 2048 + (threadIdx.x & 127);
+        if (idx < nvec) {
+          const uint4 q = vsrc[idx];
+          const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { see(wds[k] & 0xffffu); see(wds[k] >> 16); }
+        }
+      }
+    } else {
+      for (int64_t i = threadIdx.x; i < count; i += 16LL * kHistThreads) see(src[i]);
+    }
+    mn = pl_wave_reduce(mn, [](int a, int b) { return a < b ? a : b; });
+    mx = pl_wave_reduce(mx, [](int a, int b) { return a > b ? a : b; });
+    if (lane == 0) { s_lo[wv] = mn; s_hi[wv] = mx; }
+    __syncthreads();
+    for (int k = 0; k < kHistThreads / 64; ++k) { mn = s_lo[k] < mn ? s_lo[k] : mn; mx = s_hi[k] > mx ? s_hi[k] : mx; }
+    __syncthreads();
+    if (mx < mn) { mn = 0; mx = 0; }
+    const int slack = kWinBins - (mx - mn + 1);
+    klo = mn - (slack > 0 ? slack / 2 : 0);
+    if (klo < 0) klo = 0;
+    khi = klo + kWinBins - 1;
+    if (khi > 65535) { khi = 65535; klo = khi - kWinBins + 1; }
+    if (slack < 0) khi = klo + kWinBins;   // too wide: fails the range test below
+  }
+  const int range = khi - klo + 1;
+  if (range > kWinBins || range <= 0 || klo < 0 || khi > 65535) {
+    if (threadIdx.x == 0) flag[frame] = 1;
+    return;
+  }
+  for (int i = threadIdx.x; i < range; i += kHistThreads) bins[i] = 0;
+  __syncthreads();
+
+  int outside = 0;
+  auto tally = [&](unsigned key) {
+    const unsigned b = (key ^ flip) - (unsigned)klo;
+    if (b < (unsigned)range) atomicAdd(&bins[b], 1u);
+    else outside = 1;
+  };
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const int64_t nvec = count / 8;
+    const uint4* vsrc = reinterpret_cast<const uint4*>(src);
+    auto tally4 = [&](uint4 q) {
+      const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        tally(wds[k] & 0xffffu);
+        tally(wds[k] >> 16);
+      }
+    };
+    int64_t v = threadIdx.x;
+    constexpr int U = 4;  // independent 16-byte loads in flight per lane
+    for (; v + (int64_t)(U - 1) * kHistThreads < nvec; v += (int64_t)U * kHistThreads) {
+      uint4 q[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) q[k] = vsrc[v + (int64_t)k * kHistThreads];
+#pragma unroll
+      for (int k = 0; k < U; ++k) tally4(q[k]);
+    }
+    for (; v < nvec; v += kHistThreads) tally4(vsrc[v]);
+    for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally(src[i]);
+  } else {
+    for (int64_t i = threadIdx.x; i < count; i += kHistThreads) tally(src[i]);
+  }
+  if (__syncthreads_or(outside)) {   // a pixel fell outside the window (or outside the caller's bounds): two-kernel path
+    if (threadIdx.x == 0) flag[frame] = 1;
+    return;
+  }
+  if (threadIdx.x == 0) flag[frame] = 0;
+
+  // ---- Otsu on the window: lane t owns window bins [t*per, t*per + per); same integer prefix sums, float64 expression
+  // and first-index arg-max as otsu_kernel
+  const int per = (range + kHistThreads - 1) / kHistThreads;
+  const int b0 = threadIdx.x * per;
+  const int b1 = b0 + per < range ? b0 + per : range;
+  Pair mine = {0, 0};
+  int lo = 1 << 30, hi = -1;
+  for (int b = b0; b < b1; ++b) {
+    const unsigned c = bins[b];
+    mine.c += c;
+    mine.s += (long long)c * (long long)(b + klo - bias);
+    if (c) { if (lo == (1 << 30)) lo = b; hi = b; }
+  }
+  lo = pl_wave_reduce(lo, [](int a, int b) { return a < b ? a : b; });
+  hi = pl_wave_reduce(hi, [](int a, int b) { return a > b ? a : b; });
+  if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
+  Pair total;
+  Pair ex = block_exclusive_scan(mine, &total, wave_tot);  // contains __syncthreads
+  for (int k = 0; k < kHistThreads / 64; ++k) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; }
+
+  double best = -1.0;
+  int best_k = 1 << 30;
+  unsigned long long w1 = ex.c;
+  long long s1 = ex.s;
+  for (int b = b0; b < b1; ++b) {
+    const unsigned c = bins[b];
+    w1 += c;
+    s1 += (long long)c * (long long)(b + klo - bias);
+    if (b >= lo && b < hi) {
+      const double dw1 = (double)w1, dw2 = (double)(total.c - w1);
+      const double m1 = (double)s1 / dw1;
+      const double m2 = (double)(total.s - s1) / dw2;
+      const double d = m1 - m2;
+      const double var = (dw1 * dw2) * (d * d);
+      if (var > best) { best = var; best_k = b; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(best, o, 64);
+    int ok = __shfl_xor(best_k, o, 64);
+    if (ov > best || (ov == best && ok < best_k)) { best = ov; best_k = ok; }
+  }
+  if (lane == 0) { s_var[wv] = best; s_idx[wv] = best_k; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kHistThreads / 64; ++k)
+      if (s_var[k] > best || (s_var[k] == best && s_idx[k] < best_k)) { best = s_var[k]; best_k = s_idx[k]; }
+    // constant image: skimage returns that value (thresholding.py: np.all(image == first_pixel))
+    thr[frame] = (lo == hi) ? (lo + klo - bias) : (best_k + klo - bias);
+    if (vmin) vmin[frame] = lo + klo - bias;
+    if (vmax) vmax[frame] = hi + klo - bias;
+  }
+}
+
 __global__ void __launch_bounds__(kHistThreads)
 order_stats_kernel(const uint32_t* __restrict__ hist, int bias, const int64_t* __restrict__ ranks,
                    int nranks, int32_t* __restrict__ out) {
@@ -266,7 +432,7 @@ extern "C" int pl_otsu_from_hist(const uint32_t* d_hist, int dtype, int64_t n, i
   PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL, "bad batch");
   if (n == 0) return PL_OK;
   hipLaunchKernelGGL(otsu_kernel, dim3((unsigned)n), dim3(kHistThreads), 0, (hipStream_t)stream, d_hist,
-                     dtype == PL_I16 ? 32768 : 0, d_thr, d_min, d_max);
+                     dtype == PL_I16 ? 32768 : 0, d_thr, d_min, d_max, (const int32_t*)nullptr);
   return pl_check_launch("pl_otsu_from_hist");
 }
 
@@ -280,4 +446,40 @@ extern "C" int pl_order_stats_from_hist(const uint32_t* d_hist, int dtype, int64
   hipLaunchKernelGGL(order_stats_kernel, dim3((unsigned)n), dim3(kHistThreads), 0, (hipStream_t)stream,
                      d_hist, dtype == PL_I16 ? 32768 : 0, d_ranks, nranks, d_out);
   return pl_check_launch("pl_order_stats_from_hist");
+}
+
+/* skimage.filters.threshold_otsu straight from the 16-bit frames (pylinac/ct.py:3323, 3338; acr.py:1409).  d_lo / d_hi:
+ * optional per-frame bounds (int32[n], d_lo <= values <= d_hi), both NULL = the kernel places its window from a row
+ * sample.  d_thr / d_min / d_max as pl_otsu_from_hist; d_flag int32[n] scratch; d_hist uint32[n][65536] workspace,
+ * touched only for frames that do not fit the 38 912-bin LDS window. */
+extern "C" int pl_otsu16(const void* in, int dtype, int64_t n, int64_t count, const int32_t* d_lo, const int32_t* d_hi,
+                         int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist,
+                         void* stream) {
+  PL_REQUIRE(in && d_thr && d_flag && d_hist, "null pointer");
+  PL_REQUIRE((d_lo == nullptr) == (d_hi == nullptr), "give both bounds or neither");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL / 8 && count > 0, "bad shape");
+  PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned flip = dtype == PL_I16 ? 0x8000u : 0u;
+  const int bias = dtype == PL_I16 ? 32768 : 0;
+  const size_t lds = (size_t)kWinBins * sizeof(unsigned);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)otsu16_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      pl_set_error("pl_otsu16: LDS attribute: %s", hipGetErrorString(hipGetLastError()));
+      return PL_ERR_HIP;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL(otsu16_window_kernel, dim3((unsigned)n), dim3(kHistThreads), lds, st, (const unsigned short*)in,
+                     count, flip, bias, d_lo, d_hi, d_thr, d_min, d_max, d_flag);
+  // frames too wide for the window: the two-kernel path, every workgroup gated by d_flag
+  int rc = launch_hist16<2, false>((const unsigned short*)in, n, count, flip, d_hist, st, d_flag);
+  if (rc != 0) rc = launch_hist16<4, false>((const unsigned short*)in, n, count, flip, d_hist, st, d_flag);
+  PL_REQUIRE(rc == 0, "launch configuration rejected");
+  hipLaunchKernelGGL(otsu_kernel, dim3((unsigned)n), dim3(kHistThreads), 0, st, d_hist, bias, d_thr, d_min, d_max,
+                     (const int32_t*)d_flag);
+  return pl_check_launch("pl_otsu16");
 }

@@ -249,10 +249,27 @@ def otsu_from_hist(hist: torch.Tensor, dtype: torch.dtype):
     return thr, mn, mx
 
 
+def otsu16(frames: torch.Tensor, lo: torch.Tensor | None = None, hi: torch.Tensor | None = None,
+           hist: torch.Tensor | None = None):
+    """``skimage.filters.threshold_otsu`` per 16-bit frame -> (threshold, min, max) int32 [N]: one read of the frame with
+    the histogram in an LDS window where its values span <= 38 912 bins, the two-kernel path otherwise (``pl_otsu16``).
+    ``lo`` / ``hi``: optional per-frame bounds (int32 [N], ``lo <= values <= hi``) that place the window."""
+    x = _frames(frames)
+    if x.dtype not in (torch.uint16, torch.int16):
+        raise TypeError("otsu16 needs uint16 or int16 frames")
+    n, dev = x.shape[0], x.device
+    thr = torch.empty(n, dtype=torch.int32, device=dev)
+    mn, mx, flag = torch.empty_like(thr), torch.empty_like(thr), torch.empty_like(thr)
+    hist = torch.empty((n, 65536), dtype=torch.int32, device=dev) if hist is None else hist
+    check(_lib.load().pl_otsu16(x.data_ptr(), _dt(x), n, x[0].numel(), None if lo is None else lo.data_ptr(),
+                                None if hi is None else hi.data_ptr(), thr.data_ptr(),
+                                mn.data_ptr(), mx.data_ptr(), flag.data_ptr(), hist.data_ptr(), _stream()), "pl_otsu16")
+    return thr, mn, mx
+
+
 def threshold_otsu(frames: torch.Tensor) -> torch.Tensor:
     """``skimage.filters.threshold_otsu`` per integer frame -> int32 [N]."""
-    x = _frames(frames)
-    return otsu_from_hist(histogram16(x), x.dtype)[0]
+    return otsu16(frames)[0]
 
 
 def _percentile_plan(cnt: int, q):

@@ -25,8 +25,7 @@ from ._lib import check
 RECORD_FIELDS = ("otsu_threshold", "n_peaks", "peak_idx", "peak_height", "prominence",
                  "left_edge", "right_edge", "center", "width")
 
-STAGES = ("gauss_v", "gauss_h", "median3", "hist16", "otsu", "threshold_colsum", "colsum_to_mean",
-          "find_peaks", "fwxm_record")
+STAGES = ("gauss_v", "gauss_h", "median3", "otsu16", "threshold_colsum", "colsum_to_mean", "find_peaks", "fwxm_record")
 
 
 @dataclass
@@ -64,6 +63,7 @@ class EpidPipeline:
         self.thr = torch.empty(n, dtype=torch.int32, device=dev)
         self.vmin = torch.empty(n, dtype=torch.int32, device=dev)
         self.vmax = torch.empty(n, dtype=torch.int32, device=dev)
+        self.flag = torch.empty(n, dtype=torch.int32, device=dev)
         self.colsum = torch.empty((n, w), dtype=torch.int64, device=dev)
         self.profile = torch.empty((n, w), dtype=torch.float64, device=dev)
         self.fwxm = torch.empty((n, 8), dtype=torch.float64, device=dev)
@@ -107,6 +107,7 @@ class EpidPipeline:
         xp, ap, bp, op = x.data_ptr(), self.buf_a.data_ptr(), self.buf_b.data_ptr(), self.out.data_ptr()
         wts, hwts, pk = self.wts.data_ptr(), self.host_wts.ctypes.data, self.peaks
         hist, thr, vmin, vmax = (t.data_ptr() for t in (self.hist, self.thr, self.vmin, self.vmax))
+        flag = self.flag.data_ptr()
         colsum, profile, fwxm = self.colsum.data_ptr(), self.profile.data_ptr(), self.fwxm.data_ptr()
         cnt, idx, lb, rb, props, status = (t.data_ptr() for t in (pk.count, pk.idx, pk.left_bases,
                                                                    pk.right_bases, pk.props, pk.status))
@@ -124,9 +125,9 @@ class EpidPipeline:
             st, o = stream.cuda_stream, lo * fb
             stage("median3", lambda: lib.pl_median2d(bp + o, ap + o, U16, m, h, w, self.median_size, st), stream)
             med = ap + o
-            stage("hist16", lambda: lib.pl_hist16(med, U16, m, h * w, hist + lo * 65536 * 4, st), stream)
-            stage("otsu", lambda: lib.pl_otsu_from_hist(hist + lo * 65536 * 4, U16, m, thr + lo * 4, vmin + lo * 4,
-                                                        vmax + lo * 4, st), stream)
+            stage("otsu16", lambda: lib.pl_otsu16(med, U16, m, h * w, None, None, thr + lo * 4,
+                                                  vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
+                                                  hist + lo * 65536 * 4, st), stream)
             stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(med, op + o, m, h, w, thr + lo * 4,
                                                                           colsum + lo * w * 8, st), stream)
             stage("colsum_to_mean", lambda: lib.pl_colsum_to_mean(colsum + lo * w * 8, m, w, h,

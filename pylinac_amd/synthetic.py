@@ -49,3 +49,43 @@ def epid_open_field_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 10
             img.view(-1)[pos] = val
         out[i] = _to_u16(img)
     return out
+
+
+def wl_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 3000, pixel_mm: float = 0.336,
+              field_mm: float = 20.0, bb_mm: float = 5.0, bb_alpha: float = -0.8, blur_mm: float = 1.5,
+              max_offset_mm: float = 1.0, return_truth: bool = False):
+    """Config #4: n Winston-Lutz frames h x w uint16 on the HOST (numpy), frame i from
+    ``np.random.default_rng(seed0 + i)``.  Closed-form restatement of the reference's generator recipe
+    (``generate_winstonlutz`` with ``PerfectFieldLayer`` 20 x 20 mm, ``PerfectBBLayer`` 5 mm ``alpha=-0.8`` at a random
+    sub-pixel offset of at most 1 mm, ``GaussianFilterLayer(1.5 mm)``; pylinac/core/image_generator/utils.py:139-263,
+    layers.py:80-134, 187-243, 365-393; the ``SyntheticWLMixin`` recipe, tests_basic/test_winstonlutz.py:1244-1300):
+    zeros -> field rectangle = 65535 (polygon fill: pixel centres inside the half-integer bounds) -> BB disk adds
+    int(65535 * alpha) with clipping (``draw.disk``: strict ellipse inequality) -> ``skimage.filters.gaussian`` =
+    ``ndimage.gaussian_filter(float image, sigma, mode="nearest", truncate=4)`` -> truncation to uint16.
+    The blur only touches the neighbourhood of the field, so it is evaluated on a centred crop."""
+    import numpy as np
+    from scipy import ndimage
+
+    out = np.zeros((n, h, w), dtype=np.uint16)
+    truth = np.zeros((n, 4), dtype=np.float64)          # field x, field y, bb x, bb y (generator's nominal centres)
+    sigma = blur_mm / pixel_mm
+    half = int(round(field_mm / pixel_mm)) // 2 + int(4 * sigma + 0.5) + int(max_offset_mm / pixel_mm) + 8
+    ext = int(round(field_mm / pixel_mm))
+    ext += ext % 2                                       # even_round
+    rad = bb_mm / 2 / pixel_mm
+    for i in range(n):
+        rng = np.random.default_rng(seed0 + i)
+        f_off = rng.uniform(-1.0, 1.0, 2)                # field centre jitter (pixels)
+        b_off = rng.uniform(-max_offset_mm, max_offset_mm, 2) / pixel_mm
+        fcy, fcx = h / 2 - 0.5 + f_off[0], w / 2 - 0.5 + f_off[1]
+        bcy, bcx = h / 2 - 0.5 + b_off[0], w / 2 - 0.5 + b_off[1]
+        r0, c0 = h // 2 - half, w // 2 - half
+        yy, xx = np.mgrid[r0:r0 + 2 * half, c0:c0 + 2 * half].astype(np.float64)
+        img = np.zeros((2 * half, 2 * half), dtype=np.float64)
+        img[(yy >= fcy - ext / 2) & (yy <= fcy + ext / 2) & (xx >= fcx - ext / 2) & (xx <= fcx + ext / 2)] = 65535.0
+        disk = ((yy - bcy) / rad) ** 2 + ((xx - bcx) / rad) ** 2 < 1
+        img[disk] = np.clip(img[disk] + float(int(65535 * bb_alpha)), 0, 65535)
+        img = ndimage.gaussian_filter(img, sigma, mode="nearest", truncate=4.0)
+        out[i, r0:r0 + 2 * half, c0:c0 + 2 * half] = img.astype(np.uint16)
+        truth[i] = (fcx, fcy, bcx, bcy)
+    return (out, truth) if return_truth else out

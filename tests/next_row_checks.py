@@ -123,6 +123,45 @@ def check_region_moments_kernel(golden, dev):
     assert ovf.cpu().tolist() == [1, 1, 1]
 
 
+def check_otsu16(golden, dev, big=True):
+    """pl_otsu16 (single-pass LDS-window Otsu; window placed by a row sample or by the caller's bounds; gated two-kernel
+    path for frames that do not fit) against the golden skimage 0.18.3 thresholds and the oracle's restatement."""
+    from oracle import pylinac_oracle as o
+    from pylinac_amd import ops
+
+    g = golden("otsu")
+    for k in ["u16_field", "u16_random", "i16", "const", "two_level"]:
+        a = g[f"{k}.in"]
+        t = torch.from_numpy(a).to(dev)
+        x = t if t.ndim == 3 else t[None]
+        flat = x.cpu().numpy().reshape(x.shape[0], -1).astype(np.int64)
+        lo, hi = flat.min(1), flat.max(1)
+        thr, mn, mx = ops.otsu16(x)
+        assert np.array_equal(thr.cpu().numpy(), np.atleast_1d(g[f"{k}.otsu"])), k
+        assert np.array_equal(mn.cpu().numpy(), lo) and np.array_equal(mx.cpu().numpy(), hi), k
+        # caller's (enclosing) bounds give the same answer
+        info = np.iinfo(a.dtype)
+        tlo = torch.from_numpy(np.clip(lo - 7, info.min, info.max).astype(np.int32)).to(dev)
+        thi = torch.from_numpy(np.clip(hi + 11, info.min, info.max).astype(np.int32)).to(dev)
+        thr2, mn2, mx2 = ops.otsu16(x, tlo, thi)
+        assert np.array_equal(thr2.cpu().numpy(), thr.cpu().numpy()) and np.array_equal(mn2.cpu().numpy(), lo) and \
+            np.array_equal(mx2.cpu().numpy(), hi), k
+    rng = np.random.default_rng(91)
+    shapes = [(3, 40, 64), (2, 33, 50), (1, 21, 37)] + ([(3, 160, 1024)] if big else [])
+    for shape in shapes:
+        for dt in (np.uint16, np.int16):
+            a = (rng.integers(2000, 2400, shape) + (np.arange(shape[2]) > shape[2] // 2) * 9000).astype(np.int64)
+            a[-1] = rng.integers(0, 65536, shape[1:])            # last frame: full range -> two-kernel path
+            if shape[0] > 2:                                      # a frame whose extrema sit in ONE unsampled pixel each
+                a[1, shape[1] - 1, 3] = 60000
+                a[1, 1, 5] = 17
+            a = (a - (32768 if dt == np.int16 else 0)).astype(dt)
+            thr, tmin, tmax = ops.otsu16(torch.from_numpy(a).to(dev))
+            assert np.array_equal(thr.cpu().numpy(), np.array([o.threshold_otsu(f) for f in a])), (shape, dt)
+            assert np.array_equal(tmin.cpu().numpy(), a.reshape(shape[0], -1).min(1)), (shape, dt)
+            assert np.array_equal(tmax.cpu().numpy(), a.reshape(shape[0], -1).max(1)), (shape, dt)
+
+
 def check_rectangle_roi(golden, dev):
     """RectangleROI / polygon statistics against the reference's own RectangleROI and raw skimage.draw.polygon pixel
     lists (tests/golden/rect.npz): counts, min, max, median exact; mean / std to 1e-12 (summation order)."""

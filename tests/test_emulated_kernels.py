@@ -304,6 +304,12 @@ def test_emulated_region_moments(golden, emulated):
     checks.check_phantom_outline(golden, emulated, names=["sq45"])      # the symmetric region of round 1's failure
 
 
+def test_emulated_otsu16(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_otsu16(golden, emulated, big=False)
+
+
 def test_emulated_rectangle_roi(golden, emulated):
     import next_row_checks as checks
 

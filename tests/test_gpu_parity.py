@@ -146,6 +146,14 @@ def test_otsu_vs_skimage_golden(golden, dev):
         assert np.array_equal(got, g[f"{k}.otsu"]), k
 
 
+def test_otsu16_single_pass(golden, dev):
+    """a4 (fast path): pl_otsu16 (LDS-window histogram + Otsu in one read of the frame; frames that do not fit the window
+    -- full-range noise, outliers the row sample missed -- take the gated two-kernel path inside the same call)."""
+    import next_row_checks as checks
+
+    checks.check_otsu16(golden, dev)
+
+
 PROFILES = ["simple9", "simple8", "long23", "long22", "skewed19", "sigmoid21", "sawtooth", "walk600", "pickets",
             "noisy_field"]
 
