@@ -10,10 +10,11 @@ from __future__ import annotations
 
 import math
 
-import torch
+
+def _to_u16(x):
+    import torch
 
 
-def _to_u16(x: torch.Tensor) -> torch.Tensor:
     x = x.round().clamp_(0, 65535).to(torch.int32)
     return (x & 0xFFFF).to(torch.int16).view(torch.uint16)
 
@@ -22,10 +23,12 @@ def epid_open_field_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 10
                            device="cpu", pixel_mm: float = 0.336, field_mm: float = 200.0,
                            background: float = 2000.0, plateau: float = 40000.0,
                            blur_mm: float = 2.0, noise_frac: float = 0.01,
-                           bad_pixels: int = 8) -> torch.Tensor:
+                           bad_pixels: int = 8):
     """Config #2: n frames h x w uint16; frame i uses seed ``seed0 + i``: background 2 000, a
     20 cm square field (plateau 40 000, 3 % Gaussian horn dip sigma 32 mm, 2 mm Gaussian
     penumbra), 1 % Gaussian noise, ``bad_pixels`` dead/hot pixels (0 / 65535)."""
+    import torch
+
     device = torch.device(device)
     ys = torch.arange(h, dtype=torch.float32, device=device)
     xs = torch.arange(w, dtype=torch.float32, device=device)

@@ -162,6 +162,25 @@ def check_otsu16(golden, dev, big=True):
             assert np.array_equal(tmax.cpu().numpy(), a.reshape(shape[0], -1).max(1)), (shape, dt)
 
 
+def check_wl_analyze_batch(golden, dev, frames=None):
+    """winston_lutz.analyze_batch against the reference's own per-image sequence (check_inversion_by_histogram ->
+    _clean_edges -> ground -> normalize -> find_field_centroids -> find_bb_centroids, driven under scikit-image 0.18.3;
+    tests/golden/skimage_wl_py39.py): config #4 recipe frames incl. an inverted one, one whose edges get cropped
+    twice and an off-centre one.  Field CAX exact (integer sums / count), BB weighted centroid 1e-9."""
+    from pylinac_amd import winston_lutz as wl
+
+    g = golden("wl")
+    sel = list(range(len(g["frames"]))) if frames is None else list(frames)
+    fr = torch.from_numpy(g["frames"][sel]).to(dev)
+    res = wl.analyze_batch(fr, 1 / float(g["pixel_mm"]), float(g["bb_mm"]))
+    want = g["record"][sel]
+    assert np.array_equal(res["status"], np.zeros(len(sel), dtype=np.int32))
+    assert np.array_equal(res["inverted"], g["inverted"][sel])
+    assert np.array_equal(res["crop"] * 2, g["frames"].shape[1] - g["shape_after_clean"][sel][:, 0])
+    assert np.array_equal(res["record"][:, :2], want[:, :2]), np.abs(res["record"][:, :2] - want[:, :2]).max()
+    assert np.allclose(res["record"][:, 2:], want[:, 2:4], rtol=0, atol=1e-9), np.abs(res["record"][:, 2:] - want[:, 2:4]).max()
+
+
 def check_rectangle_roi(golden, dev):
     """RectangleROI / polygon statistics against the reference's own RectangleROI and raw skimage.draw.polygon pixel
     lists (tests/golden/rect.npz): counts, min, max, median exact; mean / std to 1e-12 (summation order)."""

@@ -822,6 +822,13 @@ def test_find_features_batch_vs_reference_golden(golden, dev):
         o.find_features_restated(flat[0], dpmm, 2.5, 0.5)
 
 
+def test_wl_analyze_batch_vs_reference_golden(golden, dev):
+    """config #4 / north_star n1: the composed per-image Winston-Lutz path against the reference's own sequence."""
+    import next_row_checks as checks
+
+    checks.check_wl_analyze_batch(golden, dev)
+
+
 def test_wl_bb_centroids_batch_vs_oracle(dev):
     """WLBaseImage.find_bb_centroids (pylinac/winston_lutz.py:788-806) on synthetic WL frames: window
     crop (floor/ceil), frame-level ground/normalize, invert, sweep -- against the oracle composition."""
