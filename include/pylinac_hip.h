@@ -227,6 +227,16 @@ int pl_features_level(const double* d_sample, const int32_t* d_labels, const int
                       double radius_mm, double tol_mm, double min_sep_px, int max_number, int level,
                       int32_t* d_done, int32_t* d_count, double* d_xy, int32_t* d_level, int32_t* d_status,
                       void* stream);
+/* The WHOLE threshold sweep of find_features (BB mode; pylinac/metrics/utils.py:120-181) for n windows of h x w float64
+ * samples already stretched to [0, 1], one workgroup per window with the window resident in LDS (level map, row runs,
+ * union-find over run ids, per-candidate crop analysis).  h_cutoffs: HOST memory, nlevels <= 64 increasing values
+ * (imin + step, imin + 2 step, ... accumulated like the reference).  The sweep stops at the first level that completes
+ * max_number features.  Outputs as pl_features_level; d_status: 0 ok, 2 / 4 as there, 3 = a candidate's bbox exceeds
+ * 64 pixels, 5 = a level has more than 4096 row runs -- for 3 and 5 the caller uses the level-by-level entry points.
+ * Windows up to 160 x 160. */
+int pl_features_sweep(const double* d_sample, int64_t n, int h, int w, double dpmm, double radius_mm, double tol_mm,
+                      double min_sep_px, int max_number, const double* h_cutoffs, int nlevels, int32_t* d_count,
+                      double* d_xy, int32_t* d_level, int32_t* d_status, void* stream);
 
 /* ---- a13 (fields): one threshold level of GlobalSizedFieldLocator.calculate (pylinac/metrics/image.py:817-897)
  * Inputs per frame: the 8-connected label image of `sample > cutoff` (pl_label), its label count and region

@@ -1,0 +1,442 @@
+// BB / disk finder: the WHOLE threshold sweep of pylinac's find_features for one window in one workgroup
+// (BASELINE config #4's per-image BB search).
+//
+// Replaces pylinac/metrics/utils.py:120-181 (after `sample = stretch(sample, 0, 1)`):
+//   while cutoff <= imax and len(total_features) < max_number:
+//       labels  = measure.label(sample > cutoff, connectivity=1);  segmentation.clear_border(labels)
+//       regions = measure.regionprops(labels, intensity_image=sample)  ->  the five predicates of
+//       pylinac/metrics/features.py (is_right_size_bb, is_round, is_right_circumference, is_symmetric, is_solid)
+//       new points = Point(weighted_centroid[1], weighted_centroid[0]), de-duplicated by min_separation
+//       cutoff += step
+// as called through SizedDiskLocator (pylinac/metrics/image.py:564-612) by WLBaseImage.find_bb_centroids
+// (pylinac/winston_lutz.py:788-806).
+//
+// Round 1 ran every level as nine launches over the batch (compare, five labelling kernels on a global label plane,
+// three region-table kernels, the candidate kernel) with a host poll every eight levels: 145 us per 134 x 134 window.
+// Here a workgroup keeps its window in LDS for the whole sweep:
+//   * level map  L(p) = #{k : sample(p) > cutoff_k}  (exact float64 comparisons, once); mask_k(p) = L(p) > k because the
+//     cutoffs increase;
+//   * per level: row runs of the mask (one lane per row), run ids in raster order, 4-connected merge of vertically
+//     overlapping runs with a union-find over RUN ids in LDS (links point to the smaller id, so a component's root is its
+//     first run in raster order = scikit-image's label order), per-root area / bbox, candidate roots by the cheap
+//     necessary conditions, then the same per-candidate crop analysis as features.hip (8-connected hole fill,
+//     perimeter codes, exact convex area, weighted centroid from the float64 samples);
+//   * the loop ends at the first level that completes max_number features, like the reference.
+// Results are identical to features.hip's level-by-level path (tests run both on the same windows).
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kSwThreads = 256;
+constexpr int kSwMaxSide = 160;          // window side limit (coordinates are packed in 8 bits)
+constexpr int kSwMaxRuns = 4096;         // row runs of one level
+constexpr int kSwMaxCrop = 64;           // candidate bbox side limit for the crop analysis
+constexpr int kSwMaxHullPts = 8 * kSwMaxCrop;
+constexpr int kSwMaxOut = 8;
+constexpr int kSwMaxLevels = 64;
+
+struct SweepParams {
+  double dpmm, radius_mm, tol_mm, min_sep_px;
+  int max_number;
+  int nlevels;
+  double cut[kSwMaxLevels];
+};
+
+__device__ __forceinline__ long long sw_cross2(int ax, int ay, int bx, int by, int cx, int cy) {
+  return (long long)(bx - ax) * (cy - ay) - (long long)(by - ay) * (cx - ax);
+}
+
+__device__ __forceinline__ unsigned sw_find(const unsigned* parent, unsigned i) {
+  unsigned p = parent[i];
+  while (p != i) {
+    i = p;
+    p = parent[i];
+  }
+  return i;
+}
+
+__device__ __forceinline__ void sw_unite(unsigned* parent, unsigned a, unsigned b) {
+  bool done;
+  do {
+    a = sw_find(parent, a);
+    b = sw_find(parent, b);
+    if (a < b) {
+      const unsigned old = atomicMin(&parent[b], a);
+      done = (old == b);
+      b = old;
+    } else if (b < a) {
+      const unsigned old = atomicMin(&parent[a], b);
+      done = (old == a);
+      a = old;
+    } else {
+      done = true;
+    }
+  } while (!done);
+}
+
+__global__ void __launch_bounds__(kSwThreads)
+bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepParams prm,
+                int32_t* __restrict__ out_count, double* __restrict__ out_xy, int32_t* __restrict__ out_level,
+                int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // ---- dynamic LDS carve-up
+  const int npx = h * w;
+  unsigned* run_info = reinterpret_cast<unsigned*>(smem);                 // start | end << 8 | row << 16
+  unsigned* parent = run_info + kSwMaxRuns;
+  int* t_area = reinterpret_cast<int*>(parent + kSwMaxRuns);
+  int* t_r1 = t_area + kSwMaxRuns;
+  int* t_c0 = t_r1 + kSwMaxRuns;
+  int* t_c1 = t_c0 + kSwMaxRuns;
+  int* s_hx = t_c1 + kSwMaxRuns;
+  int* s_hy = s_hx + kSwMaxHullPts;
+  int* s_hull_x = s_hy + kSwMaxHullPts;
+  int* s_hull_y = s_hull_x + kSwMaxHullPts + 1;
+  unsigned char* m = reinterpret_cast<unsigned char*>(s_hull_y + kSwMaxHullPts + 1);   // crop mask
+  unsigned char* reach = m + kSwMaxCrop * kSwMaxCrop;
+  unsigned char* bord = reach + kSwMaxCrop * kSwMaxCrop;
+  unsigned char* L = bord + kSwMaxCrop * kSwMaxCrop;                      // level map [npx]
+  __shared__ int row_cnt[kSwMaxSide + 1];                                  // runs per row, then exclusive prefix
+  __shared__ int s_cand[32];
+  __shared__ int s_ncand, s_nh, s_inside, s_nruns;
+  __shared__ int s_cnt[4];
+  __shared__ double s_red[3][kSwThreads / PL_WAVE];
+  __shared__ double s_xy[kSwMaxOut][2];
+  __shared__ int s_nout, s_first_level, s_status;
+
+  const int64_t img = blockIdx.x;
+  const double* smp = sample + img * (int64_t)npx;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const double dp2 = prm.dpmm * prm.dpmm;
+  const double pi = 3.141592653589793;
+  const double larger = pi * ((prm.radius_mm + prm.tol_mm) * (prm.radius_mm + prm.tol_mm));
+  double smaller = pi * ((prm.radius_mm - prm.tol_mm) * (prm.radius_mm - prm.tol_mm));
+  if (!(smaller > 2.0)) smaller = 2.0;                      // max((pi*(r-t)**2, 2))
+  if (tid == 0) { s_nout = 0; s_first_level = -1; s_status = 0; }
+
+  // ---- level map: L(p) = number of cutoffs below the sample (binary search, exact float64 comparisons)
+  for (int e = tid; e < npx; e += kSwThreads) {
+    const double v = smp[e];
+    int lo = 0, hi = prm.nlevels;                           // invariant: v > cut[k] for k < lo, !(v > cut[k]) for k >= hi
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (v > prm.cut[mid]) lo = mid + 1; else hi = mid;
+    }
+    L[e] = (unsigned char)lo;
+  }
+  __syncthreads();
+
+  for (int level = 0; level < prm.nlevels; ++level) {
+    // ---- A. runs per row (lane = row)
+    int my_runs = 0;
+    if (tid < h) {
+      const unsigned char* row = L + tid * w;
+      bool in = false;
+      for (int c = 0; c < w; ++c) {
+        const bool fg = row[c] > level;
+        my_runs += (fg && !in) ? 1 : 0;
+        in = fg;
+      }
+    }
+    if (tid <= kSwMaxSide) row_cnt[tid] = (tid < h) ? my_runs : 0;
+    __syncthreads();
+    // ---- B. exclusive prefix over rows (h <= 160: one lane walks it; the other phases dominate)
+    if (tid == 0) {
+      int acc = 0;
+      for (int r = 0; r <= h; ++r) { const int c = row_cnt[r]; row_cnt[r] = acc; acc += c; }
+      s_nruns = row_cnt[h];
+      s_ncand = 0;
+    }
+    __syncthreads();
+    const int nruns = s_nruns;
+    if (nruns > kSwMaxRuns) {                                // salt-and-pepper level: more runs than the table holds
+      if (tid == 0) s_status = 5;
+      break;
+    }
+    if (nruns == 0) continue;                                // uniform on every lane: nothing at this level
+    // ---- C. write the runs, initialise the forest and the per-root accumulators
+    if (tid < h) {
+      const unsigned char* row = L + tid * w;
+      int id = row_cnt[tid];
+      int start = -1;
+      for (int c = 0; c <= w; ++c) {
+        const bool fg = c < w && row[c] > level;
+        if (fg && start < 0) start = c;
+        if (!fg && start >= 0) {
+          run_info[id] = (unsigned)start | ((unsigned)(c - 1) << 8) | ((unsigned)tid << 16);
+          parent[id] = (unsigned)id;
+          t_area[id] = 0; t_r1[id] = 0; t_c0[id] = 255; t_c1[id] = 0;
+          ++id;
+          start = -1;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- D. 4-connected merge: runs of row r against runs of row r-1 (both sorted by column)
+    if (tid >= 1 && tid < h) {
+      int a = row_cnt[tid], a_end = row_cnt[tid + 1];
+      int b = row_cnt[tid - 1];
+      const int b_end = row_cnt[tid];
+      while (a < a_end && b < b_end) {
+        const unsigned ia = run_info[a], ib = run_info[b];
+        const int sa = ia & 255, ea = (ia >> 8) & 255, sb = ib & 255, eb = (ib >> 8) & 255;
+        if (sa <= eb && sb <= ea) sw_unite(parent, (unsigned)a, (unsigned)b);
+        if (ea < eb) ++a; else ++b;
+      }
+    }
+    __syncthreads();
+    // ---- E. flatten, F. per-root area / bbox
+    for (int id = tid; id < nruns; id += kSwThreads) parent[id] = sw_find(parent, (unsigned)id);
+    __syncthreads();
+    for (int id = tid; id < nruns; id += kSwThreads) {
+      const unsigned info = run_info[id];
+      const int s = info & 255, e = (info >> 8) & 255, r = (int)(info >> 16);
+      const unsigned root = parent[id];
+      atomicAdd(&t_area[root], e - s + 1);
+      atomicMax(&t_r1[root], r);
+      atomicMin(&t_c0[root], s);
+      atomicMax(&t_c1[root], e);
+    }
+    __syncthreads();
+    // ---- G. candidate roots: necessary conditions from (area, bbox) only (same as features.hip)
+    for (int id = tid; id < nruns; id += kSwThreads) {
+      if (parent[id] != (unsigned)id) continue;
+      const double area = (double)t_area[id];
+      const int r0 = (int)(run_info[id] >> 16), c0 = t_c0[id], r1 = t_r1[id] + 1, c1 = t_c1[id] + 1;   // half-open
+      const double bbox_area = (double)(r1 - r0) * (double)(c1 - c0);
+      if (r0 == 0 || c0 == 0 || r1 == h || c1 == w) continue;          // clear_border
+      if (!(area / dp2 < larger)) continue;                            // filled_area >= area
+      if (!(bbox_area / dp2 > smaller)) continue;                      // filled_area <= bbox_area
+      const double y = (double)(r1 - r0), x = (double)(c1 - c0);       // is_symmetric (features.py:7-14)
+      const double hi = (y * 1.05 > y + 3) ? y * 1.05 : y + 3, lo = (y * 0.95 < y - 3) ? y * 0.95 : y - 3;
+      if (x > hi || x < lo) continue;
+      if (!(area / bbox_area < pi / 4 * 1.2)) continue;                // is_round upper bound needs filled >= area
+      const int slot = atomicAdd(&s_ncand, 1);
+      if (slot < 32) s_cand[slot] = id;
+    }
+    __syncthreads();
+    int ncand = s_ncand;
+    if (ncand > 32) { ncand = 32; if (tid == 0) s_status = 2; }
+    if (tid == 0)                                             // label order = raster order of the first pixel = root id order
+      for (int a = 1; a < ncand; ++a) { int v = s_cand[a], b = a - 1; while (b >= 0 && s_cand[b] > v) { s_cand[b + 1] = s_cand[b]; --b; } s_cand[b + 1] = v; }
+    __syncthreads();
+
+    for (int ci = 0; ci < ncand; ++ci) {
+      const int k = s_cand[ci];
+      const int r0 = (int)(run_info[k] >> 16), c0 = t_c0[k], r1 = t_r1[k] + 1, c1 = t_c1[k] + 1;
+      const int ch = r1 - r0, cw = c1 - c0;
+      const double area = (double)t_area[k];
+      if (ch > kSwMaxCrop || cw > kSwMaxCrop) { if (tid == 0) s_status = 3; continue; }
+      const int cpx = ch * cw;
+      // region mask of the crop from the runs of its rows
+      for (int e = tid; e < cpx; e += kSwThreads) m[e] = 0;
+      __syncthreads();
+      for (int rr = tid; rr < ch; rr += kSwThreads) {
+        for (int id = row_cnt[r0 + rr]; id < row_cnt[r0 + rr + 1]; ++id) {
+          if (parent[id] != (unsigned)k) continue;
+          const unsigned info = run_info[id];
+          const int s = info & 255, e = (info >> 8) & 255;
+          for (int c = s; c <= e; ++c) m[rr * cw + (c - c0)] = 1;
+        }
+      }
+      __syncthreads();
+      // ---- filled_area: non-region pixels reachable (8-conn) from the crop border are NOT holes
+      for (int e = tid; e < cpx; e += kSwThreads) {
+        const int r = e / cw, c = e % cw;
+        const bool edge = (r == 0 || c == 0 || r == ch - 1 || c == cw - 1);
+        reach[e] = (!m[e] && edge) ? 1 : 0;
+        bool b = false;
+        if (m[e]) b = (r == 0 || !m[e - cw]) || (r == ch - 1 || !m[e + cw]) || (c == 0 || !m[e - 1]) || (c == cw - 1 || !m[e + 1]);
+        bord[e] = b ? 1 : 0;
+      }
+      __syncthreads();
+      for (;;) {
+        int changed = 0;
+        for (int e = tid; e < cpx; e += kSwThreads) {
+          if (m[e] || reach[e]) continue;
+          const int r = e / cw, c = e % cw;
+          bool hit = false;
+          for (int dr = -1; dr <= 1 && !hit; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+              const int rr = r + dr, cc = c + dc;
+              if ((dr | dc) == 0 || rr < 0 || cc < 0 || rr >= ch || cc >= cw) continue;
+              if (reach[rr * cw + cc]) { hit = true; break; }
+            }
+          if (hit) { reach[e] = 1; changed = 1; }
+        }
+        if (!__syncthreads_or(changed)) break;
+      }
+      if (tid < 4) s_cnt[tid] = 0;
+      __syncthreads();
+      // ---- holes, perimeter codes, weighted moments
+      int holes = 0, n1 = 0, n2 = 0, n3 = 0;
+      double w0 = 0.0, wr = 0.0, wc = 0.0;
+      for (int e = tid; e < cpx; e += kSwThreads) {
+        const int r = e / cw, c = e % cw;
+        if (!m[e] && !reach[e]) ++holes;
+        if (bord[e]) {
+          auto B = [&](int rr, int cc) { return (rr < 0 || cc < 0 || rr >= ch || cc >= cw) ? 0 : (int)bord[rr * cw + cc]; };
+          const int code = 1 + 2 * (B(r - 1, c) + B(r + 1, c) + B(r, c - 1) + B(r, c + 1)) +
+                           10 * (B(r - 1, c - 1) + B(r - 1, c + 1) + B(r + 1, c - 1) + B(r + 1, c + 1));
+          if (code == 5 || code == 7 || code == 15 || code == 17 || code == 25 || code == 27) ++n1;
+          else if (code == 21 || code == 33) ++n2;
+          else if (code == 13 || code == 23) ++n3;
+        }
+        if (m[e]) {
+          const double v = smp[(int64_t)(r0 + r) * w + c0 + c];
+          w0 += v; wr += v * (double)r; wc += v * (double)c;
+        }
+      }
+      auto addi = [](int a, int b) { return a + b; };
+      auto addd = [](double a, double b) { return a + b; };
+      holes = pl_wave_reduce(holes, addi); n1 = pl_wave_reduce(n1, addi); n2 = pl_wave_reduce(n2, addi); n3 = pl_wave_reduce(n3, addi);
+      w0 = pl_wave_reduce(w0, addd); wr = pl_wave_reduce(wr, addd); wc = pl_wave_reduce(wc, addd);
+      if (lane == 0) {
+        atomicAdd(&s_cnt[0], holes); atomicAdd(&s_cnt[1], n1); atomicAdd(&s_cnt[2], n2); atomicAdd(&s_cnt[3], n3);
+        s_red[0][wv] = w0; s_red[1][wv] = wr; s_red[2][wv] = wc;
+      }
+      // ---- convex hull candidates: mid-edge points of the row-extreme pixels
+      for (int r = tid; r < ch; r += kSwThreads) {
+        int cl = -1, cr = -1;
+        for (int c = 0; c < cw; ++c) if (m[r * cw + c]) { if (cl < 0) cl = c; cr = c; }
+        int* px = s_hx + r * 8; int* py = s_hy + r * 8;
+        for (int q = 0; q < 8; ++q) { px[q] = 0x7fffffff; py[q] = 0; }
+        if (cl >= 0) {
+          const int xs[2] = {cl, cr};
+          for (int q = 0; q < 2; ++q) {
+            const int X = 2 * r, Y = 2 * xs[q];
+            px[4 * q + 0] = X;     py[4 * q + 0] = Y - 1;
+            px[4 * q + 1] = X;     py[4 * q + 1] = Y + 1;
+            px[4 * q + 2] = X - 1; py[4 * q + 2] = Y;
+            px[4 * q + 3] = X + 1; py[4 * q + 3] = Y;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const int np = ch * 8;
+        for (int a = 1; a < np; ++a) {
+          const int vx = s_hx[a], vy = s_hy[a];
+          int b = a - 1;
+          while (b >= 0 && (s_hx[b] > vx || (s_hx[b] == vx && s_hy[b] > vy))) { s_hx[b + 1] = s_hx[b]; s_hy[b + 1] = s_hy[b]; --b; }
+          s_hx[b + 1] = vx; s_hy[b + 1] = vy;
+        }
+        int n = 0;
+        while (n < np && s_hx[n] != 0x7fffffff) ++n;
+        int u = 0;
+        for (int a = 0; a < n; ++a) if (a == 0 || s_hx[a] != s_hx[a - 1] || s_hy[a] != s_hy[a - 1]) { s_hx[u] = s_hx[a]; s_hy[u] = s_hy[a]; ++u; }
+        n = u;
+        int kk = 0;
+        for (int a = 0; a < n; ++a) {           // lower chain
+          while (kk >= 2 && sw_cross2(s_hull_x[kk - 2], s_hull_y[kk - 2], s_hull_x[kk - 1], s_hull_y[kk - 1], s_hx[a], s_hy[a]) <= 0) --kk;
+          s_hull_x[kk] = s_hx[a]; s_hull_y[kk] = s_hy[a]; ++kk;
+        }
+        const int lower = kk + 1;
+        for (int a = n - 2; a >= 0; --a) {      // upper chain
+          while (kk >= lower && sw_cross2(s_hull_x[kk - 2], s_hull_y[kk - 2], s_hull_x[kk - 1], s_hull_y[kk - 1], s_hx[a], s_hy[a]) <= 0) --kk;
+          s_hull_x[kk] = s_hx[a]; s_hull_y[kk] = s_hy[a]; ++kk;
+        }
+        s_nh = kk - 1;                          // last point == first point
+        s_inside = 0;
+      }
+      __syncthreads();
+      const int nh = s_nh;
+      int inside = 0;
+      for (int e = tid; e < cpx; e += kSwThreads) {
+        const int X = 2 * (e / cw), Y = 2 * (e % cw);
+        bool in = true;
+        for (int a = 0; a < nh && in; ++a) {
+          const int b = (a + 1 == nh) ? 0 : a + 1;
+          in = sw_cross2(s_hull_x[a], s_hull_y[a], s_hull_x[b], s_hull_y[b], X, Y) >= 0;
+        }
+        inside += in ? 1 : 0;
+      }
+      inside = pl_wave_reduce(inside, addi);
+      if (lane == 0) atomicAdd(&s_inside, inside);
+      __syncthreads();
+      // ---- predicates (pylinac/metrics/features.py) and output
+      if (tid == 0) {
+        const double filled = area + (double)s_cnt[0];
+        const double perim = ((double)s_cnt[1] * 1.0 + (double)s_cnt[2] * 1.4142135623730951) +
+                             (double)s_cnt[3] * ((1 + 1.4142135623730951) / 2);
+        const double per_mm = perim / prm.dpmm;
+        const double bbox_area = (double)ch * (double)cw;
+        bool ok = true;
+        const double bb_area = filled / dp2;
+        ok = ok && (smaller < bb_area && bb_area < larger);                            // is_right_size_bb
+        const double ratio = filled / bbox_area;
+        ok = ok && (pi / 4 * 1.2 > ratio && ratio > pi / 4 * 0.8);                     // is_round
+        ok = ok && (2 * pi * (prm.radius_mm + prm.tol_mm) > per_mm && per_mm > 2 * pi * (prm.radius_mm - prm.tol_mm));
+        ok = ok && (area / (double)s_inside > 0.9);                                    // is_solid
+        if (ok) {
+          double m0 = 0.0, mr = 0.0, mc = 0.0;
+          for (int q = 0; q < kSwThreads / PL_WAVE; ++q) { m0 += s_red[0][q]; mr += s_red[1][q]; mc += s_red[2][q]; }
+          const double py = mr / m0 + (double)r0, px = mc / m0 + (double)c0;
+          // de-duplicate against every point accepted so far, INCLUDING this level's (metrics/utils.py:28-36:
+          // `combined_points` aliases `original_points`, so the list being iterated grows)
+          bool keep = true;
+          for (int q = 0; q < s_nout; ++q) {
+            const double dx = px - s_xy[q][0], dy = py - s_xy[q][1];
+            if (sqrt(dx * dx + dy * dy) < prm.min_sep_px) { keep = false; break; }
+          }
+          if (keep) {
+            if (s_nout < kSwMaxOut) {
+              s_xy[s_nout][0] = px; s_xy[s_nout][1] = py;
+              ++s_nout;
+              if (s_first_level < 0) s_first_level = level;
+            } else {
+              s_status = 4;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (s_nout >= prm.max_number) break;                     // while ... len(total_features) < max_number
+  }
+  __syncthreads();
+  if (tid == 0) {
+    out_count[img] = s_nout;
+    out_level[img] = s_first_level;
+    status[img] = s_status;
+    for (int q = 0; q < kSwMaxOut; ++q) {
+      out_xy[(img * kSwMaxOut + q) * 2] = q < s_nout ? s_xy[q][0] : 0.0;
+      out_xy[(img * kSwMaxOut + q) * 2 + 1] = q < s_nout ? s_xy[q][1] : 0.0;
+    }
+  }
+}
+
+}  // namespace
+
+/* The whole find_features threshold sweep (BB mode) for n windows of h x w float64 samples (already stretched to
+ * [0, 1]): d_cutoffs (HOST memory, nlevels <= 64 increasing values: imin + step, imin + 2 step, ... as the reference
+ * accumulates them).  Outputs as pl_features_level: d_count int32[n], d_xy float64[n][8][2] (x, y) window coordinates,
+ * d_level int32[n] (first level that produced a feature, -1 none), d_status int32[n]: 0 ok, 2 more than 32 candidate
+ * regions at a level, 3 a candidate's bbox exceeds 64 pixels, 4 more than 8 features, 5 a level has more than 4096 row runs
+ * (the caller then uses the level-by-level path).  Windows up to 160 x 160. */
+extern "C" int pl_features_sweep(const double* d_sample, int64_t n, int h, int w, double dpmm, double radius_mm,
+                                 double tol_mm, double min_sep_px, int max_number, const double* h_cutoffs, int nlevels,
+                                 int32_t* d_count, double* d_xy, int32_t* d_level, int32_t* d_status, void* stream) {
+  PL_REQUIRE(d_sample && h_cutoffs && d_count && d_xy && d_level && d_status, "null pointer");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && h > 0 && w > 0 && h <= kSwMaxSide && w <= kSwMaxSide, "bad shape");
+  PL_REQUIRE(nlevels > 0 && nlevels <= kSwMaxLevels && max_number > 0, "bad arguments");
+  PL_REQUIRE(dpmm > 0 && radius_mm > 0, "bad physical parameters");
+  if (n == 0) return PL_OK;
+  SweepParams prm;
+  prm.dpmm = dpmm; prm.radius_mm = radius_mm; prm.tol_mm = tol_mm; prm.min_sep_px = min_sep_px;
+  prm.max_number = max_number;
+  prm.nlevels = nlevels;
+  for (int k = 0; k < kSwMaxLevels; ++k) prm.cut[k] = k < nlevels ? h_cutoffs[k] : 0.0;
+  for (int k = 1; k < nlevels; ++k) PL_REQUIRE(h_cutoffs[k] > h_cutoffs[k - 1], "cutoffs must increase");
+  const size_t lds = (size_t)kSwMaxRuns * 6 * 4 + ((size_t)2 * kSwMaxHullPts + 2 * (kSwMaxHullPts + 1)) * 4 +
+                     (size_t)3 * kSwMaxCrop * kSwMaxCrop + (size_t)h * w;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)bb_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { pl_set_error("pl_features_sweep: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(bb_sweep_kernel, dim3((unsigned)n), dim3(kSwThreads), lds, (hipStream_t)stream, d_sample, h, w, prm,
+                     d_count, d_xy, d_level, d_status);
+  return pl_check_launch("pl_features_sweep");
+}

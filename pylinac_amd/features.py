@@ -37,18 +37,51 @@ def sweep_cutoffs() -> list[float]:
     return out
 
 
+SWEEP_MAX_SIDE = 160      # pl_features_sweep keeps a window of at most 160 x 160 samples in LDS
+
+
 def find_features_batch(samples: torch.Tensor, dpmm: float, radius_mm: float, radius_tolerance_mm: float,
                         max_number: int = 1, min_separation_mm: float = 5, max_labels: int = 4096,
-                        poll_every: int = 8):
+                        poll_every: int = 8, level_by_level: bool = False):
     """-> dict(xy float64 [N,8,2] (x, y) window coordinates, count int32 [N], level int32 [N],
     status int32 [N]).  ``count < min_number`` is the reference's ValueError("Couldn't find the minimum
-    number of disks"); the batch reports it per window instead of raising."""
+    number of disks"); the batch reports it per window instead of raising.
+
+    Windows up to 160 x 160 run the whole sweep in one launch (``pl_features_sweep``: one workgroup per window, the
+    window resident in LDS); larger windows, and windows the sweep kernel hands back (status 3 / 5: a candidate or a
+    level too large for its tables), take the level-by-level path (``level_by_level=True`` forces it)."""
     s = ops._frames(samples)
     if s.dtype != torch.float64:
         raise TypeError("find_features_batch needs float64 samples")
     n, h, w = s.shape
     dev = s.device
     s = stretch_device(s)
+    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    if not level_by_level and h <= SWEEP_MAX_SIDE and w <= SWEEP_MAX_SIDE and n > 0:
+        cuts = np.ascontiguousarray(sweep_cutoffs(), dtype=np.float64)
+        count = torch.empty(n, dtype=torch.int32, device=dev)
+        level = torch.empty(n, dtype=torch.int32, device=dev)
+        status = torch.empty(n, dtype=torch.int32, device=dev)
+        xy = torch.empty((n, 8, 2), dtype=torch.float64, device=dev)
+        check(lib.pl_features_sweep(s.data_ptr(), n, h, w, float(dpmm), float(radius_mm), float(radius_tolerance_mm),
+                                    float(min_separation_mm * dpmm), int(max_number), cuts.ctypes.data, len(cuts),
+                                    count.data_ptr(), xy.data_ptr(), level.data_ptr(), status.data_ptr(), st),
+              "pl_features_sweep")
+        redo = torch.nonzero((status == 3) | (status == 5)).flatten()
+        if redo.numel():                                        # tables too small for these windows: the general path
+            sub = _find_features_levels(s[redo].contiguous(), dpmm, radius_mm, radius_tolerance_mm, max_number,
+                                        min_separation_mm, max_labels, poll_every)
+            xy[redo], count[redo], level[redo], status[redo] = sub["xy"], sub["count"], sub["level"], sub["status"]
+        return dict(xy=xy, count=count, level=level, status=status)
+    return _find_features_levels(s, dpmm, radius_mm, radius_tolerance_mm, max_number, min_separation_mm, max_labels,
+                                 poll_every)
+
+
+def _find_features_levels(s: torch.Tensor, dpmm: float, radius_mm: float, radius_tolerance_mm: float, max_number: int,
+                          min_separation_mm: float, max_labels: int, poll_every: int):
+    """the level-by-level sweep over stretched samples ``s`` (compare -> label -> region table -> pl_features_level)"""
+    n, h, w = s.shape
+    dev = s.device
     lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
     done = torch.zeros(n, dtype=torch.int32, device=dev)
     count = torch.zeros(n, dtype=torch.int32, device=dev)

@@ -592,6 +592,11 @@ def test_emulated_bb_finder_random_windows(emulated):
             got = res["xy"][0, : len(ref_pts)].cpu().numpy()
             assert np.allclose(got, np.array(ref_pts), rtol=1e-10, atol=1e-10)
             checked += 1
+        # the level-by-level path (the fallback of the one-launch sweep) gives the same answer
+        lv = pf.find_features_batch(torch.from_numpy(img[None]).to(emulated), dpmm, 2.5, 0.5, max_number=maxn,
+                                    min_separation_mm=minsep, level_by_level=True)
+        assert int(lv["count"][0]) == int(res["count"][0]) and int(lv["level"][0]) == int(res["level"][0])
+        assert np.array_equal(lv["xy"][0, : len(ref_pts)].cpu().numpy(), res["xy"][0, : len(ref_pts)].cpu().numpy())
     assert checked >= 6
 
 

@@ -818,6 +818,11 @@ def test_find_features_batch_vs_reference_golden(golden, dev):
     flat = 0.5 + rng.normal(0, 0.01, (1, 134, 134))
     r2 = pf.find_features_batch(T(flat, dev), dpmm, 2.5, 0.5)
     assert int(r2["count"][0]) == 0 and int(r2["level"][0]) == -1
+    # the one-launch sweep and the level-by-level path agree bit for bit
+    a = pf.find_features_batch(T(wins[:4], dev), dpmm, 2.5, 0.5)
+    b = pf.find_features_batch(T(wins[:4], dev), dpmm, 2.5, 0.5, level_by_level=True)
+    for key in ("xy", "count", "level", "status"):
+        assert torch.equal(a[key], b[key]), key
     with pytest.raises(ValueError):
         o.find_features_restated(flat[0], dpmm, 2.5, 0.5)
 
