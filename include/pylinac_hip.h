@@ -173,6 +173,14 @@ int pl_binary_centroid(const uint8_t* d_mask, int64_t n, int h, int w, unsigned 
                        double* d_out, void* stream);
 int pl_scaled_binary(const void* in, int dtype, int64_t n, int64_t count, const double* d_sub,
                      const double* d_div, const double* d_thr, uint8_t* d_out, void* stream);
+/* ndimage.center_of_mass(ndimage.binary_fill_holes(((a - sub) / div) >= thr)) per frame (pylinac/winston_lutz.py:775-779)
+ * WITHOUT materialising the mask or a label plane: one streaming pass reduces the foreground's count, coordinate sums
+ * and bounding box, then one workgroup per frame flood-fills the background of the box (grown by one pixel) in LDS and
+ * adds the holes.  d_out float64[n][3] = (row, col, filled pixel count); d_acc uint64[n][8] scratch; d_status int32[n]:
+ * 0 done, 1 = the bounding box exceeds the 384 x 384 LDS window: use pl_scaled_binary -> pl_fill_holes ->
+ * pl_binary_centroid for that frame. */
+int pl_field_cax(const void* in, int dtype, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                 const double* d_thr, unsigned long long* d_acc, double* d_out, int32_t* d_status, void* stream);
 
 /* ---- a16: CatPhan slice localisation (pylinac/ct.py:381-425, 3315-3348) --------------------------
  * pl_scharr: skimage.filters.scharr(float image) -> float64 edge magnitude.

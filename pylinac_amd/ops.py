@@ -538,6 +538,28 @@ def binary_centroid(mask: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def field_cax(frames: torch.Tensor, sub, div, thr) -> torch.Tensor:
+    """``center_of_mass(binary_fill_holes(((a - sub) / div) >= thr))`` per frame -> float64 [N,3] = (row, col, count):
+    the fused window path (``pl_field_cax``), the general mask -> fill -> centroid path for frames whose foreground
+    bounding box does not fit the LDS window."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    dev = x.device
+    a = [_per_frame(v, n, dev)[0].expand(n).contiguous() if _per_frame(v, n, dev)[1] == 0 else _per_frame(v, n, dev)[0]
+         for v in (sub, div, thr)]
+    acc = torch.empty((n, 8), dtype=torch.int64, device=dev)
+    out = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    check(_lib.load().pl_field_cax(x.data_ptr(), _dt(x), n, h, w, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                   acc.data_ptr(), out.data_ptr(), status.data_ptr(), _stream()), "pl_field_cax")
+    redo = torch.nonzero(status).flatten()
+    if redo.numel():
+        sel = x.view(torch.int16)[redo].view(torch.uint16) if x.dtype == torch.uint16 else x[redo]
+        binary = scaled_binary(sel, a[0][redo], a[1][redo], a[2][redo])
+        out[redo] = binary_centroid(fill_holes(binary, connectivity_bg=4))
+    return out
+
+
 def scaled_binary(frames: torch.Tensor, sub, div, thr) -> torch.Tensor:
     """``((a - sub) / div) >= thr`` in float64 per frame -> uint8 mask."""
     x = _frames(frames)

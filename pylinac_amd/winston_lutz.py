@@ -47,9 +47,7 @@ def field_centroids_batch(frames: torch.Tensor, hist: torch.Tensor | None = None
     b = (st[:, 4:6] - vmin[:, None]) / gmax[:, None]
     p = ops.lerp_like_numpy(a, b, t[None, :])                  # [N,2] = (p5, p99.9) of the f64 frame
     thr = (p[:, 1] - p[:, 0]) / 2 + p[:, 0]
-    binary = ops.scaled_binary(x, vmin, gmax, thr)
-    filled = ops.fill_holes(binary, connectivity_bg=4)
-    cen = ops.binary_centroid(filled)                          # row, col, count
+    cen = ops.field_cax(x, vmin, gmax, thr)                    # threshold -> fill holes -> centre of mass: row, col, count
     return torch.stack([cen[:, 1], cen[:, 0], cen[:, 2]], dim=1)
 
 

@@ -41,18 +41,16 @@ def timed(name, n, fn, note):
     print(json.dumps(line), flush=True)
 
 
-# ---- config #4 (per GPU share): Winston-Lutz field CAX, 1024^2 uint16
-h = w = int(1024 * min(scale, 1.0)) if scale < 1 else 1024
+# ---- config #4 (per GPU share): Winston-Lutz per-image analysis, 1024^2 uint16, SURVEY 8d recipe (seed 3000 + i)
+from pylinac_amd.synthetic import wl_frames  # noqa: E402
+
 n4 = max(int(512 * scale), 2)
-yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
-cy, cx, half = h // 2 - 12, w // 2 + 8, max(h // 34, 6)
-field = ((yy - cy).abs() < half) & ((xx - cx).abs() < half)
-bb = ((yy - cy - 3) ** 2 + (xx - cx + 3) ** 2) < max(half // 4, 2) ** 2
-base = torch.where(bb, 12000, torch.where(field, 42000, 1500)).to(torch.int32)
-base = (base + ((yy * 7 + xx * 13) % 5).to(torch.int32) * (base > 2000).to(torch.int32)).to(torch.int16).view(torch.uint16)
-frames4 = roll_batch(base, torch.randint(-h // 6, h // 6, (n4, 2), generator=g))
-timed("#4 WL field CAX (percentile threshold, fill holes, centre of mass)", n4,
-      lambda: winston_lutz.field_centroids_batch(frames4), f"{h}x{w} uint16")
+frames4 = torch.from_numpy(wl_frames(n4)).to(dev)
+timed("#4 WL analyze_batch (inversion check, clean edges, field CAX, BB sweep)", n4,
+      lambda: winston_lutz.analyze_batch(frames4, 1 / 0.336, 5.0), "1024x1024 uint16")
+timed("#4a WL field CAX only", n4, lambda: winston_lutz.field_centroids_batch(frames4), "1024x1024 uint16")
+from pylinac_amd import features  # noqa: E402
+timed("#4b WL BB sweep only", n4, lambda: features.bb_centroids_batch(frames4, 1 / 0.336, 5.0), "1024x1024 uint16")
 del frames4
 
 # ---- config #5: CatPhan phantom ROI per slice, 512^2 int16

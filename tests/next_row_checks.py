@@ -181,6 +181,48 @@ def check_wl_analyze_batch(golden, dev, frames=None):
     assert np.allclose(res["record"][:, 2:], want[:, 2:4], rtol=0, atol=1e-9), np.abs(res["record"][:, 2:] - want[:, 2:4]).max()
 
 
+def check_field_cax(dev):
+    """ops.field_cax (pl_field_cax: one streaming reduction + an LDS window flood fill) against scipy's
+    binary_fill_holes + center_of_mass on masks with holes, nested holes, shapes touching the frame border (a hole that
+    is open to the border is not a hole), several blobs, an empty mask, and a foreground too large for the LDS window
+    (general path).  Exact: integer sums / count."""
+    from scipy import ndimage
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(12)
+    frames = []
+    h, w = 96, 130
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.zeros((h, w), bool); a[30:60, 40:90] = True; a[40:50, 55:70] = False; a[43:47, 60:64] = True   # hole with an island
+    frames.append(a)
+    b = np.zeros((h, w), bool); b[0:40, 0:50] = True; b[10:20, 0:12] = False; b[25:30, 20:30] = False      # open to the border / closed
+    frames.append(b)
+    c = (np.hypot(yy - 50, xx - 60) < 30) & ~(np.hypot(yy - 50, xx - 60) < 12); c |= np.hypot(yy - 80, xx - 115) < 9
+    frames.append(c)
+    frames.append(np.zeros((h, w), bool))                                                                  # empty
+    d = rng.random((h, w)) < 0.55; frames.append(d)                                                        # noise: many holes
+    e = np.ones((h, w), bool); e[1:-1, 1:-1] = False; e[40:50, 40:50] = True; frames.append(e)             # a ring along the border
+    f = np.zeros((h, w), bool); f[:, 64] = True; f[48, :] = True; frames.append(f)                         # a cross: no holes
+    m = np.stack(frames)
+    x = torch.from_numpy((m * 1000 + 7).astype(np.uint16)).to(dev)
+    got = ops.field_cax(x, 7.0, 1000.0, 0.5).cpu().numpy()
+    for k, fm in enumerate(m):
+        filled = ndimage.binary_fill_holes(fm)
+        if not filled.any():
+            assert np.isnan(got[k, 0]) and np.isnan(got[k, 1]) and got[k, 2] == 0, k
+            continue
+        want = ndimage.center_of_mass(filled)
+        assert got[k, 2] == filled.sum(), (k, got[k, 2], filled.sum())
+        assert np.array_equal(got[k, :2], np.array(want)), (k, got[k], want)
+    big = np.zeros((2, 420, 440), bool); big[:, 10:410, 15:430] = True; big[0, 100:200, 100:300] = False; big[1, 0:50, 200:210] = False
+    xb = torch.from_numpy((big * 500).astype(np.uint16)).to(dev)
+    gb = ops.field_cax(xb, 0.0, 500.0, 0.5).cpu().numpy()
+    for k in range(2):
+        filled = ndimage.binary_fill_holes(big[k])
+        assert gb[k, 2] == filled.sum() and np.array_equal(gb[k, :2], np.array(ndimage.center_of_mass(filled))), k
+
+
 def check_rectangle_roi(golden, dev):
     """RectangleROI / polygon statistics against the reference's own RectangleROI and raw skimage.draw.polygon pixel
     lists (tests/golden/rect.npz): counts, min, max, median exact; mean / std to 1e-12 (summation order)."""

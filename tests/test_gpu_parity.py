@@ -827,6 +827,13 @@ def test_find_features_batch_vs_reference_golden(golden, dev):
         o.find_features_restated(flat[0], dpmm, 2.5, 0.5)
 
 
+def test_field_cax_fused_vs_scipy(dev):
+    """a14: pl_field_cax (threshold -> fill holes -> centre of mass without a mask or label plane) against scipy."""
+    import next_row_checks as checks
+
+    checks.check_field_cax(dev)
+
+
 def test_wl_analyze_batch_vs_reference_golden(golden, dev):
     """config #4 / north_star n1: the composed per-image Winston-Lutz path against the reference's own sequence."""
     import next_row_checks as checks
