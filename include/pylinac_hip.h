@@ -181,6 +181,10 @@ int pl_scaled_binary(const void* in, int dtype, int64_t n, int64_t count, const 
  * pl_binary_centroid for that frame. */
 int pl_field_cax(const void* in, int dtype, int64_t n, int h, int w, const double* d_sub, const double* d_div,
                  const double* d_thr, unsigned long long* d_acc, double* d_out, int32_t* d_status, void* stream);
+/* min / max over the four `window`-pixel-wide edge strips of every 16-bit frame (int32[n] each): the edge test of
+ * WLBaseImage._clean_edges (pylinac/winston_lutz.py:1109-1133). */
+int pl_edge_minmax(const void* in, int dtype, int64_t n, int h, int w, int window, int32_t* d_min, int32_t* d_max,
+                   void* stream);
 
 /* ---- a16: CatPhan slice localisation (pylinac/ct.py:381-425, 3315-3348) --------------------------
  * pl_scharr: skimage.filters.scharr(float image) -> float64 edge magnitude.
@@ -218,6 +222,17 @@ int pl_region_stats(const int32_t* d_labels, const double* d_intensity, int64_t 
  *   integer arithmetic, so symmetric regions decide `a - c == 0` exactly. */
 int pl_region_moments(const int32_t* d_labels, int64_t n, int h, int w, int max_labels,
                       unsigned long long* d_mom, int32_t* d_overflow, void* stream);
+/* np.linspace(lo_i, hi_i, nbins + 1) per frame -> d_edges float64 [n][nbins + 1]: the bin edges np.histogram builds for
+ * `bins = nbins` over the range of the selected pixels (feeds pl_hist_uniform without a host round trip). */
+int pl_linspace_edges(const double* d_lo, const double* d_hi, int nbins, int64_t n, double* d_edges, void* stream);
+/* skimage 0.18.3 threshold_otsu from a 256-bin float histogram (counts uint32 [n][256], edges float64 [n][257]):
+ * d_thr[i] = otsu_i * scale (pylinac/ct.py:3338-3340 uses 0.8), d_raw[i] = otsu_i (optional, may be NULL). */
+int pl_otsu_from_counts(const uint32_t* d_counts, const double* d_edges, int nbins, int64_t n, double scale,
+                        double* d_thr, double* d_raw, void* stream);
+/* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count]: mode 0 = np.max (d_out has
+ * the input dtype), mode 1 = np.mean (d_out float64).  The window s-k .. s+k is clamped to the stack. */
+int pl_combine_slices(const void* in, void* d_out, int dtype, int64_t n, int64_t count, int plusminus, int mode,
+                      void* stream);
 
 /* ---- a13: one threshold level of find_features (pylinac/metrics/utils.py:128-180 + features.py) ---
  * Inputs per window i: d_sample float64 [n][h][w] (the stretched sample), the 4-connected label image of
@@ -426,6 +441,13 @@ int pl_find_peaks_var(const double* d_x, int64_t n, int len, const int32_t* d_le
                       const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,
                       int32_t* d_left_base, int32_t* d_right_base, double* d_props, int32_t* d_status,
                       void* stream);
+/* pl_find_peaks_var with per-profile search regions: d_regions int32[n][2] = [lo, hi) of profile i (NULL = the region of
+ * `params`): CTP528CP504.mtf searches the valleys between the outermost peaks of each line-pair region
+ * (pylinac/ct.py:1526-1533). */
+int pl_find_peaks_regions(const double* d_x, int64_t n, int len, const int32_t* d_lens, int64_t stride,
+                          const pl_peak_params* params, const int32_t* d_regions, int cap, int32_t* d_count,
+                          int32_t* d_idx, int32_t* d_left_base, int32_t* d_right_base, double* d_props,
+                          int32_t* d_status, void* stream);
 
 /* ---- BASELINE config #3: PicketFence.analyze per-image measurement, UP_DOWN pickets ------------
  * (pylinac/picketfence.py:745-803, 847-912, 1605-1628) on uint16 frames whose float64 image would be

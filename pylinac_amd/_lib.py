@@ -74,6 +74,7 @@ SIGNATURES = {
     "pl_binary_centroid": ([_p, _l, _i, _i, _p, _p, _p], C.c_int),
     "pl_scaled_binary": ([_p, _i, _l, _l, _p, _p, _p, _p, _p], C.c_int),
     "pl_field_cax": ([_p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p], C.c_int),
+    "pl_edge_minmax": ([_p, _i, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_scharr": ([_p, _p, _i, _l, _i, _i, _p], C.c_int),
     "pl_gaussian2d_mode": ([_p, _p, _p, _i, _l, _i, _i, _p, _i, _i, _p], C.c_int),
     "pl_minmax_masked": ([_p, _p, _l, _l, _p, _p, _p], C.c_int),
@@ -83,6 +84,9 @@ SIGNATURES = {
     "pl_clear_border": ([_p, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_region_stats": ([_p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p], C.c_int),
     "pl_region_moments": ([_p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
+    "pl_linspace_edges": ([_p, _p, _i, _l, _p, _p], C.c_int),
+    "pl_otsu_from_counts": ([_p, _p, _i, _l, _d, _p, _p, _p], C.c_int),
+    "pl_combine_slices": ([_p, _p, _i, _l, _l, _i, _i, _p], C.c_int),
     "pl_features_level": ([_p, _p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_features_sweep": ([_p, _l, _i, _i, _d, _d, _d, _d, _i, _p, _i, _p, _p, _p, _p, _p], C.c_int),
     "pl_fields_level": ([_p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
@@ -112,6 +116,10 @@ SIGNATURES = {
     "pl_colsum_to_mean": ([_p, _l, _i, _i, _p, _p], C.c_int),
     "pl_find_peaks_var": (
         [_p, _l, _i, _p, _l, C.POINTER(PeakParams), _i, _p, _p, _p, _p, _p, _p, _p],
+        C.c_int,
+    ),
+    "pl_find_peaks_regions": (
+        [_p, _l, _i, _p, _l, C.POINTER(PeakParams), _p, _i, _p, _p, _p, _p, _p, _p, _p],
         C.c_int,
     ),
     "pl_scaled_colmean": ([_p, _l, _i, _i, _p, _p, _p, _p], C.c_int),

@@ -342,6 +342,22 @@ namespace {
 
 constexpr int kCaxMaxWindow = 147456;   // 384 x 384 bytes of LDS for the window mask
 
+// ((double)a - s) / d >= t is monotone in a (d > 0): for 16-bit frames the smallest integer that passes is found by
+// bisection with the SAME float64 expression, and every pixel is then one integer comparison instead of a float64
+// division.  Returns 65536 (unsigned) / 32768 (signed) when no value passes.  d <= 0 or NaN: callers keep the float test.
+template <typename T>
+__device__ __forceinline__ int cax_int_threshold(double s, double d, double t) {
+  constexpr int kLo = (T)-1 < (T)0 ? -32768 : 0, kHi = (T)-1 < (T)0 ? 32767 : 65535;
+  auto pass = [&](int a) { return ((double)a - s) / d >= t; };
+  if (!pass(kHi)) return kHi + 1;
+  int lo = kLo, hi = kHi;               // invariant: pass(hi)
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (pass(mid)) hi = mid; else lo = mid + 1;
+  }
+  return hi;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 cax_reduce_kernel(const T* __restrict__ in, int h, int w, int bpf, const double* __restrict__ sub,
@@ -355,9 +371,18 @@ cax_reduce_kernel(const T* __restrict__ in, int h, int w, int bpf, const double*
   unsigned long long cnt = 0, sr = 0, sc = 0;
   unsigned rmin = 0xffffffffu, rmax = 0, cmin = 0xffffffffu, cmax = 0;
   const int64_t lo = (int64_t)chunk * 65536, hi = (lo + 65536 < per_frame) ? lo + 65536 : per_frame;
+  const bool use_int = sizeof(T) == 2 && d > 0.0;
+  int ithr = 0;
+  if constexpr (sizeof(T) == 2) { if (use_int) ithr = cax_int_threshold<T>(s, d, t); }
   for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-    const double grounded = (double)f[i] - s;   // exact for integer dtypes (array - array.min())
-    if (grounded / d >= t) {
+    bool fg;
+    if (use_int) {
+      fg = (int)f[i] >= ithr;
+    } else {
+      const double grounded = (double)f[i] - s;   // exact for integer dtypes (array - array.min())
+      fg = grounded / d >= t;
+    }
+    if (fg) {
       const unsigned r = (unsigned)(i / w), c = (unsigned)(i % w);
       ++cnt; sr += r; sc += c;
       rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax;
@@ -410,10 +435,13 @@ cax_window_kernel(const T* __restrict__ in, int h, int w, const double* __restri
   const T* f = in + frame * (int64_t)h * w;
   const double s = sub[frame], d = div[frame], t = thr[frame];
   if (threadIdx.x < 3) s_add[threadIdx.x] = 0;
+  const bool use_int = sizeof(T) == 2 && d > 0.0;
+  int ithr = 0;
+  if constexpr (sizeof(T) == 2) { if (use_int) ithr = cax_int_threshold<T>(s, d, t); }
   for (int e = threadIdx.x; e < npx; e += kThreads) {
     const int r = e / ww, c = e % ww;
-    const double grounded = (double)f[(int64_t)(r0 + r) * w + c0 + c] - s;
-    const bool fg = grounded / d >= t;
+    const T px = f[(int64_t)(r0 + r) * w + c0 + c];
+    const bool fg = use_int ? ((int)px >= ithr) : (((double)px - s) / d >= t);
     const bool edge = r == 0 || c == 0 || r == wh - 1 || c == ww - 1;
     win[e] = fg ? 1 : (edge ? 2 : 0);
   }
@@ -479,4 +507,55 @@ extern "C" int pl_field_cax(const void* in, int dtype, int64_t n, int h, int w, 
                        d_sub, d_div, d_thr, d_acc, d_out, d_status);
   });
   return pl_check_launch("pl_field_cax");
+}
+
+// ---- WLBaseImage._clean_edges' edge test (pylinac/winston_lutz.py:1109-1133): min / max over the four window_size-wide
+// edge strips of every frame.  One workgroup per frame.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+edge_minmax_kernel(const T* __restrict__ in, int h, int w, int ws, int32_t* __restrict__ emin, int32_t* __restrict__ emax) {
+  __shared__ int s_mn[kThreads / 64], s_mx[kThreads / 64];
+  const T* f = in + (int64_t)blockIdx.x * h * w;
+  int mn = 0x7fffffff, mx = -0x7fffffff - 1;
+  auto see = [&](int v) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; };
+  const int band = ws < h ? ws : h;
+  for (int e = threadIdx.x; e < band * w; e += kThreads) {          // top and bottom strips
+    see((int)f[e]);
+    see((int)f[(int64_t)(h - band) * w + e]);
+  }
+  const int cb = ws < w ? ws : w;
+  for (int e = threadIdx.x; e < h * cb; e += kThreads) {            // left and right strips
+    const int r = e / cb, c = e % cb;
+    see((int)f[(int64_t)r * w + c]);
+    see((int)f[(int64_t)r * w + (w - cb) + c]);
+  }
+  mn = pl_wave_reduce(mn, [](int a, int b) { return a < b ? a : b; });
+  mx = pl_wave_reduce(mx, [](int a, int b) { return a > b ? a : b; });
+  if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kThreads / 64; ++k) { mn = s_mn[k] < mn ? s_mn[k] : mn; mx = s_mx[k] > mx ? s_mx[k] : mx; }
+    emin[blockIdx.x] = mn;
+    emax[blockIdx.x] = mx;
+  }
+}
+}  // namespace
+
+/* min / max over the four `window`-pixel-wide edge strips of every 16-bit frame (int32[n] each): the edge test of
+ * WLBaseImage._clean_edges (pylinac/winston_lutz.py:1109-1133). */
+extern "C" int pl_edge_minmax(const void* in, int dtype, int64_t n, int h, int w, int window, int32_t* d_min,
+                              int32_t* d_max, void* stream) {
+  PL_REQUIRE(in && d_min && d_max, "null pointer");
+  PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
+  PL_REQUIRE(window > 0, "window must be positive");
+  PL_CCL_CHECK_SHAPE();
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PL_U16)
+    hipLaunchKernelGGL(edge_minmax_kernel<unsigned short>, dim3((unsigned)n), dim3(kThreads), 0, st,
+                       (const unsigned short*)in, h, w, window, d_min, d_max);
+  else
+    hipLaunchKernelGGL(edge_minmax_kernel<short>, dim3((unsigned)n), dim3(kThreads), 0, st, (const short*)in, h, w,
+                       window, d_min, d_max);
+  return pl_check_launch("pl_edge_minmax");
 }

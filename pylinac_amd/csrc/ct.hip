@@ -137,30 +137,64 @@ __global__ void region_init_kernel(unsigned long long* __restrict__ isum, double
   wsum[g * 3 + 0] = 0.0; wsum[g * 3 + 1] = 0.0; wsum[g * 3 + 2] = 0.0;
 }
 
+// Lanes of a wave that carry the same (frame, label) are reduced across the wave first and ONE lane issues the atomics:
+// a CatPhan slice is a single filled disk of 125 000 pixels, and round 1's one-atomic-set-per-pixel version spent 140 ms
+// per 200 slices serialising on that label's ten accumulators (profiles/r02d_*): 93 % of the slice localisation.
 __global__ void __launch_bounds__(kThreads)
 region_accum_kernel(const int32_t* __restrict__ labels, const double* __restrict__ intensity, int64_t total,
                     int h, int w, int max_labels, unsigned long long* __restrict__ isum,
                     double* __restrict__ wsum, int32_t* __restrict__ overflow) {
   const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (g >= total) return;
-  const int lab = labels[g];
-  if (lab <= 0) return;
   const int64_t per_frame = (int64_t)h * w;
-  const int64_t frame = g / per_frame;
-  if (lab > max_labels) { overflow[frame] = 1; return; }
-  const int i = (int)(g % per_frame);
-  const unsigned long long r = (unsigned long long)(i / w), c = (unsigned long long)(i % w);
-  unsigned long long* s = isum + (frame * max_labels + (lab - 1)) * 7;
-  atomicAdd(&s[0], 1ull);
-  atomicMin(&s[1], r); atomicMin(&s[2], c);
-  atomicMax(&s[3], r); atomicMax(&s[4], c);
-  atomicAdd(&s[5], r); atomicAdd(&s[6], c);
-  if (intensity) {
-    const double v = intensity[g];
-    double* ws = wsum + (frame * max_labels + (lab - 1)) * 3;
-    atomicAdd(&ws[0], v);
-    atomicAdd(&ws[1], v * (double)r);
-    atomicAdd(&ws[2], v * (double)c);
+  int lab = 0;
+  int64_t frame = 0;
+  unsigned long long r = 0, c = 0;
+  double v = 0.0;
+  if (g < total) {
+    lab = labels[g];
+    frame = g / per_frame;
+    const int i = (int)(g - frame * per_frame);
+    r = (unsigned long long)(i / w);
+    c = (unsigned long long)(i % w);
+    if (lab > max_labels) { overflow[frame] = 1; lab = 0; }
+    if (lab < 0) lab = 0;
+    if (lab > 0 && intensity) v = intensity[g];
+  }
+  const long long key = lab > 0 ? frame * (long long)max_labels + (lab - 1) : -1;
+  unsigned long long pending = __ballot(key >= 0);
+  const int lane = threadIdx.x & 63;
+  auto addu = [](unsigned long long a, unsigned long long b) { return a + b; };
+  auto minu = [](unsigned long long a, unsigned long long b) { return a < b ? a : b; };
+  auto maxu = [](unsigned long long a, unsigned long long b) { return a > b ? a : b; };
+  while (pending) {
+    const int leader = __builtin_ctzll(pending);
+    const long long k = __shfl(key, leader, 64);
+    const bool mine = key == k;
+    const unsigned long long grp = __ballot(mine);
+    const unsigned long long cnt = pl_wave_reduce(mine ? 1ull : 0ull, addu);
+    const unsigned long long rmin = pl_wave_reduce(mine ? r : ~0ull, minu), cmin = pl_wave_reduce(mine ? c : ~0ull, minu);
+    const unsigned long long rmax = pl_wave_reduce(mine ? r : 0ull, maxu), cmax = pl_wave_reduce(mine ? c : 0ull, maxu);
+    const unsigned long long sr = pl_wave_reduce(mine ? r : 0ull, addu), sc = pl_wave_reduce(mine ? c : 0ull, addu);
+    if (lane == leader) {
+      unsigned long long* s = isum + k * 7;
+      atomicAdd(&s[0], cnt);
+      atomicMin(&s[1], rmin); atomicMin(&s[2], cmin);
+      atomicMax(&s[3], rmax); atomicMax(&s[4], cmax);
+      atomicAdd(&s[5], sr); atomicAdd(&s[6], sc);
+    }
+    if (intensity) {
+      // the weighted sums keep float64 atomics: their summation order was never defined (compared at 1e-9, see above);
+      // the wave's partial sums are formed in a fixed butterfly order, only the order of the waves' atomics varies
+      auto addd = [](double a, double b) { return a + b; };
+      const double w0 = pl_wave_reduce(mine ? v : 0.0, addd);
+      const double w1 = pl_wave_reduce(mine ? v * (double)r : 0.0, addd);
+      const double w2 = pl_wave_reduce(mine ? v * (double)c : 0.0, addd);
+      if (lane == leader) {
+        double* ws = wsum + k * 3;
+        atomicAdd(&ws[0], w0); atomicAdd(&ws[1], w1); atomicAdd(&ws[2], w2);
+      }
+    }
+    pending &= ~grp;
   }
 }
 
@@ -228,6 +262,94 @@ region_moments_kernel(const int32_t* __restrict__ labels, int64_t total, int h, 
       for (int q = 0; q < 6; ++q) atomicAdd(&s[q], v[q]);
     }
     pending &= ~grp;
+  }
+}
+
+// ---- float-image Otsu without the host: np.linspace edges, skimage's class statistics ------------------------------------
+// np.linspace(lo, hi, nbins + 1) (numpy/core/function_base.py): step = (hi - lo) / nbins; y = arange * step + lo (two
+// roundings: -ffp-contract=off keeps them apart); the last edge is set to hi.  step == 0 takes numpy's other branch
+// (y = arange / div * delta + lo): every edge equals lo.
+__global__ void linspace_edges_kernel(const double* __restrict__ lo, const double* __restrict__ hi, int nbins, int64_t n,
+                                      double* __restrict__ edges /* [n][nbins+1] */) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= n * (nbins + 1)) return;
+  const int64_t f = g / (nbins + 1);
+  const int i = (int)(g % (nbins + 1));
+  const double a = lo[f], b = hi[f];
+  const double delta = b - a;
+  const double step = delta / (double)nbins;
+  double y = step == 0.0 ? ((double)i / (double)nbins) * delta + a : (double)i * step + a;
+  if (i == nbins) y = b;
+  edges[g] = y;
+}
+
+// skimage 0.18.3 threshold_otsu on a ready 256-bin histogram (filters/thresholding.py): centres = (e[:-1] + e[1:]) / 2,
+// weight1 = cumsum(counts), weight2 = cumsum(counts[::-1])[::-1], mean1 = cumsum(counts * centres) / weight1,
+// mean2 = (cumsum((counts * centres)[::-1]) / weight2[::-1])[::-1], variance12 = weight1[:-1] * weight2[1:] *
+// (mean1[:-1] - mean2[1:]) ** 2, first arg-max.  np.cumsum is a sequential float64 loop: one lane per frame repeats it.
+// lo == hi (constant selection): the threshold is that value.  out = threshold * scale (the reference uses 0.8).
+__global__ void otsu_counts_kernel(const uint32_t* __restrict__ counts, const double* __restrict__ edges, int nbins,
+                                   int64_t n, double scale, double* __restrict__ thr, double* __restrict__ raw) {
+  const int64_t f = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (f >= n) return;
+  const uint32_t* c = counts + f * nbins;
+  const double* e = edges + f * (nbins + 1);
+  double otsu;
+  if (e[0] == e[nbins]) {
+    otsu = e[0];
+  } else {
+    // suffix sums first (cumsum over the reversed arrays), kept per bin in registers is too much: two passes over
+    // 256 bins, recomputing the reversed cumulative sums on the fly from the totals is NOT the same rounding, so
+    // store them in a small local array (256 doubles x 2 per lane: scratch, 4 KB -- one lane per frame, n is small)
+    double w2[256], m2[256];
+    double aw = 0.0, am = 0.0;
+    for (int i = nbins - 1; i >= 0; --i) {
+      const double ci = (double)c[i];
+      const double centre = (e[i] + e[i + 1]) / 2.0;
+      aw = aw + ci;
+      am = am + ci * centre;
+      w2[i] = aw;
+      m2[i] = am / aw;
+    }
+    double w1 = 0.0, s1 = 0.0, best = 0.0;
+    int best_i = 0;
+    bool first = true;
+    for (int i = 0; i < nbins - 1; ++i) {
+      const double ci = (double)c[i];
+      const double centre = (e[i] + e[i + 1]) / 2.0;
+      w1 = w1 + ci;
+      s1 = s1 + ci * centre;
+      const double mean1 = s1 / w1;
+      const double d = mean1 - m2[i + 1];
+      const double var = (w1 * w2[i + 1]) * (d * d);
+      // np.argmax: first maximum; a NaN (empty leading class) is treated as the maximum by numpy
+      if (first || var > best || (var != var && best == best)) { best = var; best_i = i; first = false; }
+    }
+    otsu = (e[best_i] + e[best_i + 1]) / 2.0;
+  }
+  if (raw) raw[f] = otsu;
+  thr[f] = otsu * scale;
+}
+
+// np.max / np.mean over slices s-k .. s+k of a stack (combine_surrounding_slices, pylinac/ct.py:3351-3386): mode 0 max
+// (dtype kept), mode 1 mean (float64, numpy's pairwise-free sequential sum over the 2k+1 slices).  Slices whose window
+// leaves the stack are marked invalid by the caller; here the window is clamped so every output is defined.
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+combine_slices_kernel(const T* __restrict__ in, int64_t n, int64_t per_frame, int k, int mode, T* __restrict__ out_max,
+                      double* __restrict__ out_mean) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= n * per_frame) return;
+  const int64_t s = g / per_frame, p = g % per_frame;
+  const int64_t a = s - k < 0 ? 0 : s - k, b = s + k > n - 1 ? n - 1 : s + k;
+  if (mode == 0) {
+    T m = in[a * per_frame + p];
+    for (int64_t q = a + 1; q <= b; ++q) { const T v = in[q * per_frame + p]; m = v > m ? v : m; }
+    out_max[g] = m;
+  } else {
+    double acc = 0.0;
+    for (int64_t q = a; q <= b; ++q) acc += (double)in[q * per_frame + p];
+    out_mean[g] = acc / (double)(b - a + 1);
   }
 }
 
@@ -336,4 +458,45 @@ extern "C" int pl_region_moments(const int32_t* d_labels, int64_t n, int h, int 
   hipLaunchKernelGGL(region_moments_kernel, dim3(blocks), dim3(kThreads), 0, st, d_labels, total, h, w, max_labels,
                      d_mom, d_overflow);
   return pl_check_launch("pl_region_moments");
+}
+
+/* np.linspace(lo_i, hi_i, nbins + 1) per frame -> d_edges float64 [n][nbins + 1] (the bin edges np.histogram builds for
+ * `bins = nbins` over the range of the selected pixels; feeds pl_hist_uniform) */
+extern "C" int pl_linspace_edges(const double* d_lo, const double* d_hi, int nbins, int64_t n, double* d_edges,
+                                 void* stream) {
+  PL_REQUIRE(d_lo && d_hi && d_edges, "null pointer");
+  PL_REQUIRE(n >= 0 && nbins > 0 && nbins <= 8192, "bad arguments");
+  if (n == 0) return PL_OK;
+  const int64_t total = n * (nbins + 1);
+  hipLaunchKernelGGL(linspace_edges_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0,
+                     (hipStream_t)stream, d_lo, d_hi, nbins, n, d_edges);
+  return pl_check_launch("pl_linspace_edges");
+}
+
+/* skimage 0.18.3 threshold_otsu from a 256-bin float histogram (counts uint32 [n][256], edges float64 [n][257]) ->
+ * d_thr[i] = otsu_i * scale, d_raw[i] = otsu_i (optional).  pylinac/ct.py:3338-3340 uses scale 0.8. */
+extern "C" int pl_otsu_from_counts(const uint32_t* d_counts, const double* d_edges, int nbins, int64_t n, double scale,
+                                   double* d_thr, double* d_raw, void* stream) {
+  PL_REQUIRE(d_counts && d_edges && d_thr, "null pointer");
+  PL_REQUIRE(n >= 0 && nbins == 256, "256 bins (skimage's default for float images)");
+  if (n == 0) return PL_OK;
+  hipLaunchKernelGGL(otsu_counts_kernel, dim3((unsigned)pl_cdiv(n, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                     d_counts, d_edges, nbins, n, scale, d_thr, d_raw);
+  return pl_check_launch("pl_otsu_from_counts");
+}
+
+/* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count]: mode 0 = np.max (d_out has
+ * the input dtype), mode 1 = np.mean (d_out float64).  The window s-k .. s+k is clamped to the stack. */
+extern "C" int pl_combine_slices(const void* in, void* d_out, int dtype, int64_t n, int64_t count, int plusminus, int mode,
+                                 void* stream) {
+  PL_REQUIRE(in && d_out && in != d_out, "null or aliased pointers");
+  PL_REQUIRE(n >= 0 && count > 0 && plusminus >= 0 && (mode == 0 || mode == 1), "bad arguments");
+  if (n == 0) return PL_OK;
+  const int64_t total = n * count;
+  PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "too large");
+  PL_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL(combine_slices_kernel<T>, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0,
+                                       (hipStream_t)stream, (const T*)in, n, count, plusminus, mode, (T*)d_out,
+                                       (double*)d_out));
+  return pl_check_launch("pl_combine_slices");
 }

@@ -131,7 +131,8 @@ __device__ __forceinline__ void prominence_side(const double* xs, int pk, int m,
 // between an LDS and a global pointer degrades every access to a slow FLAT load).
 template <bool STAGE>
 __global__ void __launch_bounds__(kThreads)
-find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __restrict__ lens, int64_t stride,
+find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __restrict__ lens,
+                  const int32_t* __restrict__ regions, int64_t stride,
                   pl_peak_params prm, int cap, int maxc, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
                   int32_t* __restrict__ d_lb, int32_t* __restrict__ d_rb, double* __restrict__ d_props,
                   int32_t* __restrict__ d_status) {
@@ -143,8 +144,10 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
   const int64_t prof = blockIdx.x;
   const int len = lens ? lens[prof] : len_all;   // ragged batches: per-profile length
   const double* xfull = x + prof * stride;
-  int lo = prm.region_lo < 0 ? 0 : prm.region_lo;
-  int hi = prm.region_hi > len ? len : prm.region_hi;
+  // search region: the batch's, or this profile's own [lo, hi) (python slice semantics resolved by the caller)
+  const int rlo = regions ? regions[2 * prof] : prm.region_lo, rhi = regions ? regions[2 * prof + 1] : prm.region_hi;
+  int lo = rlo < 0 ? 0 : rlo;
+  int hi = rhi > len ? len : rhi;
   if (hi < lo) hi = lo;
   const int m = hi - lo;
 
@@ -393,6 +396,10 @@ extern "C" int pl_find_peaks_var(const double* d_x, int64_t n, int len, const in
                                  const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,
                                  int32_t* d_left_base, int32_t* d_right_base, double* d_props,
                                  int32_t* d_status, void* stream);
+extern "C" int pl_find_peaks_regions(const double* d_x, int64_t n, int len, const int32_t* d_lens, int64_t stride,
+                                     const pl_peak_params* params, const int32_t* d_regions, int cap, int32_t* d_count,
+                                     int32_t* d_idx, int32_t* d_left_base, int32_t* d_right_base, double* d_props,
+                                     int32_t* d_status, void* stream);
 
 extern "C" int pl_find_peaks(const double* d_x, int64_t n, int len, int64_t stride,
                              const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,
@@ -408,6 +415,17 @@ extern "C" int pl_find_peaks_var(const double* d_x, int64_t n, int len, const in
                                  const pl_peak_params* params, int cap, int32_t* d_count, int32_t* d_idx,
                                  int32_t* d_left_base, int32_t* d_right_base, double* d_props,
                                  int32_t* d_status, void* stream) {
+  return pl_find_peaks_regions(d_x, n, len, d_lens, stride, params, nullptr, cap, d_count, d_idx, d_left_base,
+                               d_right_base, d_props, d_status, stream);
+}
+
+// per-profile search regions: d_regions int32[n][2] = [lo, hi) of profile i (NULL: the region of `params`).  The
+// reference's per-image loops search each profile where ITS peaks were (CTP528CP504.mtf: valleys between the outermost
+// peaks of a line-pair region, pylinac/ct.py:1526-1533).
+extern "C" int pl_find_peaks_regions(const double* d_x, int64_t n, int len, const int32_t* d_lens, int64_t stride,
+                                     const pl_peak_params* params, const int32_t* d_regions, int cap, int32_t* d_count,
+                                     int32_t* d_idx, int32_t* d_left_base, int32_t* d_right_base, double* d_props,
+                                     int32_t* d_status, void* stream) {
   PL_REQUIRE(d_x && params && d_count && d_idx && d_left_base && d_right_base && d_props && d_status,
              "null pointer");
   PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && len > 0 && stride >= len && cap > 0, "bad shape");
@@ -416,6 +434,7 @@ extern "C" int pl_find_peaks_var(const double* d_x, int64_t n, int len, const in
   int lo = params->region_lo < 0 ? 0 : params->region_lo;
   int hi = params->region_hi > len ? len : params->region_hi;
   int m = hi > lo ? hi - lo : 0;
+  if (d_regions) m = len;                      // per-profile regions: size the tables for the longest possible one
   int maxc = m / 2 + 1;
   if (maxc > kMaxCand) maxc = kMaxCand;
   const int stage_x = (m <= kStageMax) ? 1 : 0;
@@ -432,11 +451,11 @@ extern "C" int pl_find_peaks_var(const double* d_x, int64_t n, int len, const in
   }
   if (stage_x)
     hipLaunchKernelGGL(find_peaks_kernel<true>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
-                       len, d_lens, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base, d_props,
-                       d_status);
+                       len, d_lens, d_regions, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base,
+                       d_props, d_status);
   else
     hipLaunchKernelGGL(find_peaks_kernel<false>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
-                       len, d_lens, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base, d_props,
-                       d_status);
+                       len, d_lens, d_regions, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base,
+                       d_props, d_status);
   return pl_check_launch("pl_find_peaks");
 }

@@ -48,35 +48,30 @@ def disk_mask(center_rc, radius: float, shape) -> np.ndarray:
     return m
 
 
-def otsu_from_counts(counts: np.ndarray, centers: np.ndarray) -> float:
-    """skimage 0.18.3 ``threshold_otsu`` on a ready histogram (filters/thresholding.py)."""
-    counts = counts.astype(float)
-    weight1 = np.cumsum(counts)
-    weight2 = np.cumsum(counts[::-1])[::-1]
-    mean1 = np.cumsum(counts * centers) / weight1
-    mean2 = (np.cumsum((counts * centers)[::-1]) / weight2[::-1])[::-1]
-    variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:]) ** 2
-    return centers[np.argmax(variance12)]
+_DISK_CACHE: dict = {}
+
+
+def _disk_on_device(h: int, w: int, mm_per_pixel: float, dev) -> torch.Tensor:
+    key = (h, w, float(mm_per_pixel), str(dev))
+    if key not in _DISK_CACHE:
+        cy, cx = h / 2 - 0.5, w / 2 - 0.5                                  # BaseImage.center, image.py:527-533
+        _DISK_CACHE[key] = torch.from_numpy(disk_mask((cy, cx), 110 / mm_per_pixel, (h, w))).to(dev)
+    return _DISK_CACHE[key]
 
 
 def get_regions_batch(slices: torch.Tensor, mm_per_pixel: float, fill_holes: bool = True,
-                      clear_borders: bool = True, max_labels: int = 64):
+                      clear_borders: bool = True, max_labels: int = 64, raw_edges: torch.Tensor | None = None):
     """-> dict(edges f64 [N,H,W], bw u8, labels i32, num i32 [N], stats f64 [N,max_labels,10],
-    overflow i32 [N], otsu f64 [N])."""
+    overflow i32 [N], otsu f64 [N] (device)).  Nothing returns to the host: the 256-bin Otsu of the disk-masked edge
+    image (np.linspace edges, np.histogram binning, skimage's class statistics) runs in kernels too.
+    ``raw_edges``: ``ops.scharr(slices)`` when the caller already has it."""
     x = ops._frames(slices)
     n, h, w = x.shape
     dev = x.device
-    edges = ops.gaussian_filter_mode(ops.scharr(x), 1, "nearest")
-    cy, cx = h / 2 - 0.5, w / 2 - 0.5                                  # BaseImage.center, image.py:527-533
-    disk = torch.from_numpy(disk_mask((cy, cx), 110 / mm_per_pixel, (h, w))).to(dev)
+    edges = ops.gaussian_filter_mode(ops.scharr(x) if raw_edges is None else raw_edges, 1, "nearest")
+    disk = _disk_on_device(h, w, mm_per_pixel, dev)
     # np.histogram(edges[disk], 256): the range is the min/max of the SELECTED pixels
-    mn, mx = ops.minmax_masked(edges, disk)
-    lo, hi = mn.cpu().numpy(), mx.cpu().numpy()
-    e = np.stack([np.linspace(a, b, 257) for a, b in zip(lo, hi)])
-    counts = ops.hist_uniform(edges, torch.from_numpy(e).to(dev), disk).cpu().numpy()
-    otsu = np.array([a if a == b else otsu_from_counts(c, (ee[:-1] + ee[1:]) / 2.0)
-                     for a, b, c, ee in zip(lo, hi, counts, e)])
-    thr = torch.from_numpy(otsu * 0.8).to(dev)
+    thr, otsu = ops.otsu_float_masked(edges, disk, scale=0.8)
     bw = ops.compare(edges, thr, ">")
     if clear_borders:
         bw = ops.clear_border(bw, min(int(max(h, w) / 100), 3))
@@ -97,29 +92,32 @@ def phantom_roi_batch(slices: torch.Tensor, mm_per_pixel: float, catphan_radius_
     x = ops._frames(slices)
     n = x.shape[0]
     catphan_size = np.pi * catphan_radius_mm**2 / mm_per_pixel**2        # ct.py:2581-2584
-    raw_max = ops.minmax(ops.scharr(x))[1].cpu().numpy()                 # ct.py:392: np.max(edges) < 0.1
-    reg = get_regions_batch(x, mm_per_pixel, fill_holes=True, clear_borders=True, max_labels=max_labels)
+    raw = ops.scharr(x)                                                  # computed once: the edge test and get_regions
+    raw_max_t = ops.minmax(raw)[1]                                       # ct.py:392: np.max(edges) < 0.1
+    reg = get_regions_batch(x, mm_per_pixel, fill_holes=True, clear_borders=True, max_labels=max_labels, raw_edges=raw)
+    raw_max = raw_max_t.cpu().numpy()
     stats = reg["stats"].cpu().numpy()
-    num = reg["num"].cpu().numpy()
+    num = np.minimum(reg["num"].cpu().numpy(), max_labels)
     ovf = reg["overflow"].cpu().numpy()
+    # the selection (sorted(regionprops, key=|filled_area - catphan_size|)[0] and the size test), vectorised over slices
+    valid = np.arange(max_labels)[None, :] < num[:, None]
+    filled = stats[:, :, 0]                                 # == filled_area after binary_fill_holes
+    dist = np.where(valid, np.abs(filled - catphan_size), np.inf)
+    k = np.argmin(dist, axis=1)                             # first minimum = the stable sort's first element
+    rows = np.arange(n)
+    t = stats[rows, k]
+    fk = t[:, 0]
+    status = np.zeros(n)
+    status[(catphan_size * 1.3 < fk) | (fk < catphan_size / 1.3)] = 3
+    status[ovf != 0] = 4
+    status[num < 1] = 2
+    status[raw_max < 0.1] = 1
     out = np.full((n, 8), np.nan)
-    for i in range(n):
-        if raw_max[i] < 0.1:
-            out[i, 0] = 1
-            continue
-        if num[i] < 1:
-            out[i, 0] = 2
-            continue
-        if ovf[i]:
-            out[i, 0] = 4
-            continue
-        t = stats[i, : num[i]]
-        filled = t[:, 0]                                   # == filled_area after binary_fill_holes
-        k = int(np.argsort(np.abs(filled - catphan_size), kind="stable")[0])
-        if catphan_size * 1.3 < filled[k] or filled[k] < catphan_size / 1.3:
-            out[i, 0] = 3
-            continue
-        out[i] = [0, k + 1, filled[k], t[k, 5] / t[k, 0], t[k, 6] / t[k, 0], t[k, 1], t[k, 2], t[k, 3]]
+    out[:, 0] = status
+    ok = status == 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        good = np.stack([np.zeros(n), k + 1.0, fk, t[:, 5] / t[:, 0], t[:, 6] / t[:, 0], t[:, 1], t[:, 2], t[:, 3]], axis=1)
+    out[ok] = good[ok]
     return out
 
 

@@ -103,7 +103,8 @@ def _find_features_levels(s: torch.Tensor, dpmm: float, radius_mm: float, radius
 
 
 def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float, low_density: bool = False,
-                       bb_tolerance_mm: float | None = None):
+                       bb_tolerance_mm: float | None = None, vmin: torch.Tensor | None = None,
+                       vmax: torch.Tensor | None = None):
     """``WLBaseImage.find_bb_centroids`` (pylinac/winston_lutz.py:788-806) for uint16 frames:
     SizedDiskLocator.from_center_physical(expected (0, 0) mm, window (40 + d) mm, radius d/2,
     invert = not low_density) on the ground()/normalize()d frame.  Returns the find_features result
@@ -120,7 +121,8 @@ def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float,
     right = math.ceil(ex + win / 2)
     top = max(math.floor(ey - win / 2), 0)
     bottom = math.ceil(ey + win / 2)
-    vmin, vmax = ops.minmax(x)                          # frame-level ground()/normalize()
+    if vmin is None or vmax is None:
+        vmin, vmax = ops.minmax(x)                      # frame-level ground()/normalize()
     crop = x.view(torch.int16)[:, top:bottom, left:right].contiguous().view(torch.uint16)
     q = ops.normalize(ops.ground(crop, mn=vmin), vmax - vmin)        # float64 (a - min) / (max - min)
     sample = ops.invert(q) if not low_density else q

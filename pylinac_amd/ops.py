@@ -402,9 +402,10 @@ def make_peak_params(length: int, threshold=-np.inf, peak_separation=0, max_numb
 
 
 def find_peaks_batch(profiles: torch.Tensor, cap: int | None = None, lens: torch.Tensor | None = None,
-                     **kwargs) -> PeakBatch:
+                     regions: torch.Tensor | None = None, **kwargs) -> PeakBatch:
     """``pylinac.core.profile.find_peaks`` for every row of ``profiles`` [N, L] (float64).
-    ``lens`` (int32 [N]) makes the batch ragged: row i holds ``lens[i] <= L`` samples."""
+    ``lens`` (int32 [N]) makes the batch ragged: row i holds ``lens[i] <= L`` samples.
+    ``regions`` (int32 [N, 2]): per-profile search region ``values[lo:hi]`` (indices; overrides ``search_region``)."""
     x = profiles
     if x.dim() == 1:
         x = x.unsqueeze(0)
@@ -418,9 +419,14 @@ def find_peaks_batch(profiles: torch.Tensor, cap: int | None = None, lens: torch
         raise ValueError("Array must not be empty")
     prm = make_peak_params(length, **kwargs)
     if cap is None:
-        cap = prm.max_number if prm.max_number > 0 else max((prm.region_hi - prm.region_lo) // 2 + 1, 1)
+        span = length if regions is not None else prm.region_hi - prm.region_lo
+        cap = prm.max_number if prm.max_number > 0 else max(span // 2 + 1, 1)
         cap = max(cap, 1)
     dev = x.device
+    if regions is not None:
+        regions = regions.to(device=dev, dtype=torch.int32).contiguous()
+        if tuple(regions.shape) != (n, 2):
+            raise ValueError("regions must be [N, 2]")
     res = PeakBatch(
         count=torch.empty(n, dtype=torch.int32, device=dev),
         idx=torch.empty((n, cap), dtype=torch.int32, device=dev),
@@ -430,11 +436,12 @@ def find_peaks_batch(profiles: torch.Tensor, cap: int | None = None, lens: torch
         status=torch.empty(n, dtype=torch.int32, device=dev),
     )
     check(
-        _lib.load().pl_find_peaks_var(x.data_ptr(), n, length, 0 if lens is None else lens.data_ptr(), x.stride(0),
-                                      C.byref(prm), cap, res.count.data_ptr(), res.idx.data_ptr(),
-                                      res.left_bases.data_ptr(), res.right_bases.data_ptr(), res.props.data_ptr(),
-                                      res.status.data_ptr(), _stream()),
-        "pl_find_peaks_var",
+        _lib.load().pl_find_peaks_regions(x.data_ptr(), n, length, 0 if lens is None else lens.data_ptr(), x.stride(0),
+                                          C.byref(prm), 0 if regions is None else regions.data_ptr(), cap,
+                                          res.count.data_ptr(), res.idx.data_ptr(), res.left_bases.data_ptr(),
+                                          res.right_bases.data_ptr(), res.props.data_ptr(), res.status.data_ptr(),
+                                          _stream()),
+        "pl_find_peaks_regions",
     )
     return res
 
@@ -560,6 +567,17 @@ def field_cax(frames: torch.Tensor, sub, div, thr) -> torch.Tensor:
     return out
 
 
+def edge_minmax(frames: torch.Tensor, window: int = 2):
+    """min / max over the four ``window``-wide edge strips of every 16-bit frame -> (int32 [N], int32 [N])."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    mn = torch.empty(n, dtype=torch.int32, device=x.device)
+    mx = torch.empty_like(mn)
+    check(_lib.load().pl_edge_minmax(x.data_ptr(), _dt(x), n, h, w, int(window), mn.data_ptr(), mx.data_ptr(), _stream()),
+          "pl_edge_minmax")
+    return mn, mx
+
+
 def scaled_binary(frames: torch.Tensor, sub, div, thr) -> torch.Tensor:
     """``((a - sub) / div) >= thr`` in float64 per frame -> uint8 mask."""
     x = _frames(frames)
@@ -639,6 +657,41 @@ def hist_uniform(frames: torch.Tensor, edges: torch.Tensor, mask: torch.Tensor |
     out = torch.empty((n, nb), dtype=torch.int32, device=x.device)
     check(_lib.load().pl_hist_uniform(x.data_ptr(), 0 if mask is None else mask.data_ptr(), n, x[0].numel(),
                                       edges.contiguous().data_ptr(), nb, out.data_ptr(), _stream()), "pl_hist_uniform")
+    return out
+
+
+def otsu_float_masked(frames: torch.Tensor, mask: torch.Tensor | None, scale: float = 1.0):
+    """``skimage.filters.threshold_otsu(frame[mask])`` for float64 frames (256 bins over the min .. max of the selected
+    pixels; pylinac/ct.py:3323, 3338-3340) entirely on the device -> (threshold * scale, threshold) float64 [N]."""
+    x = _frames(frames)
+    if x.dtype != torch.float64:
+        raise TypeError("otsu_float_masked needs float64 frames")
+    n = x.shape[0]
+    dev = x.device
+    lib, st = _lib.load(), _stream()
+    if mask is None:
+        lo, hi = minmax(x)
+    else:
+        lo, hi = minmax_masked(x, mask)
+    edges = torch.empty((n, 257), dtype=torch.float64, device=dev)
+    check(lib.pl_linspace_edges(lo.data_ptr(), hi.data_ptr(), 256, n, edges.data_ptr(), st), "pl_linspace_edges")
+    counts = hist_uniform(x, edges, mask)
+    thr = torch.empty(n, dtype=torch.float64, device=dev)
+    raw = torch.empty(n, dtype=torch.float64, device=dev)
+    check(lib.pl_otsu_from_counts(counts.data_ptr(), edges.data_ptr(), 256, n, float(scale), thr.data_ptr(), raw.data_ptr(),
+                                  st), "pl_otsu_from_counts")
+    return thr, raw
+
+
+def combine_slices(stack: torch.Tensor, plusminus: int, mode: str = "max") -> torch.Tensor:
+    """``combine_surrounding_slices`` (pylinac/ct.py:3351-3386) for every slice of ``stack`` [S, H, W]: "max" keeps the
+    dtype, "mean" gives float64; the window is clamped to the stack."""
+    x = _frames(stack)
+    if mode not in ("max", "mean"):
+        raise ValueError("mode must be 'max' or 'mean'")
+    out = torch.empty_like(x) if mode == "max" else torch.empty(x.shape, dtype=torch.float64, device=x.device)
+    check(_lib.load().pl_combine_slices(x.data_ptr(), out.data_ptr(), _dt(x), x.shape[0], x[0].numel(), int(plusminus),
+                                        0 if mode == "max" else 1, _stream()), "pl_combine_slices")
     return out
 
 

@@ -67,7 +67,16 @@ def wl_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 3000, pixel_mm:
     ``ndimage.gaussian_filter(float image, sigma, mode="nearest", truncate=4)`` -> truncation to uint16.
     The blur only touches the neighbourhood of the field, so it is evaluated on a centred crop."""
     import numpy as np
-    from scipy import ndimage
+
+    def blur(img, sigma):
+        """ndimage.gaussian_filter(img, sigma, mode="nearest", truncate=4): scipy's kernel formula, one pass per axis"""
+        lw = int(4.0 * sigma + 0.5)
+        k = np.exp(-0.5 / (sigma * sigma) * np.arange(-lw, lw + 1) ** 2)
+        k /= k.sum()
+        for axis in (0, 1):
+            p = np.pad(img, [(lw, lw) if a == axis else (0, 0) for a in (0, 1)], mode="edge")
+            img = sum(k[j] * np.take(p, range(j, j + img.shape[axis]), axis=axis) for j in range(2 * lw + 1))
+        return img
 
     out = np.zeros((n, h, w), dtype=np.uint16)
     truth = np.zeros((n, 4), dtype=np.float64)          # field x, field y, bb x, bb y (generator's nominal centres)
@@ -88,7 +97,7 @@ def wl_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 3000, pixel_mm:
         img[(yy >= fcy - ext / 2) & (yy <= fcy + ext / 2) & (xx >= fcx - ext / 2) & (xx <= fcx + ext / 2)] = 65535.0
         disk = ((yy - bcy) / rad) ** 2 + ((xx - bcx) / rad) ** 2 < 1
         img[disk] = np.clip(img[disk] + float(int(65535 * bb_alpha)), 0, 65535)
-        img = ndimage.gaussian_filter(img, sigma, mode="nearest", truncate=4.0)
+        img = blur(img, sigma)
         out[i, r0:r0 + 2 * half, c0:c0 + 2 * half] = img.astype(np.uint16)
         truth[i] = (fcx, fcy, bcx, bcy)
     return (out, truth) if return_truth else out

@@ -26,40 +26,60 @@ import torch
 from . import ops
 
 
-def field_centroids_batch(frames: torch.Tensor, hist: torch.Tensor | None = None) -> torch.Tensor:
-    """-> float64 [N, 3] = (x, y, filled_pixel_count) of the field centroid of every frame.  ``hist``: the frames'
-    exact histogram (``ops.histogram16``) when the caller already has it."""
+_FIELD_Q = (5.0, 99.9)          # find_field_centroids, winston_lutz.py:775
+_INVERSION_Q = (0.01, 50.0, 99.99)   # analyze, winston_lutz.py:709
+_EDGE_Q = (5.0, 99.5)            # _clean_edges, winston_lutz.py:1117
+
+
+class _FrameStats:
+    """Every order statistic the per-image sequence asks for, from ONE exact histogram per frame and ONE selection
+    launch: min, max and the two neighbours of each percentile's virtual index; ``np.percentile``'s interpolation
+    (``_lerp``) is evaluated on the host table."""
+
+    def __init__(self, x: torch.Tensor, hist: torch.Tensor | None = None, qs=_FIELD_Q + _INVERSION_Q + _EDGE_Q):
+        self.cnt = x[0].numel()
+        self.qs = tuple(qs)
+        _, lo, hi, frac = ops._percentile_plan(self.cnt, list(self.qs))
+        self.frac = frac
+        ranks = np.concatenate([[0, self.cnt - 1], lo, hi])
+        hist = ops.histogram16(x) if hist is None else hist
+        st = ops.order_stats(x, ranks, hist=hist).cpu().numpy().astype(np.float64)
+        self.vmin, self.vmax = st[:, 0], st[:, 1]
+        k = len(self.qs)
+        self.lo, self.hi = st[:, 2:2 + k], st[:, 2 + k:2 + 2 * k]
+
+    def percentiles(self, qs, transform=None) -> np.ndarray:
+        """np.percentile(f(frame), qs) for a monotone elementwise ``transform`` f applied to the order statistics
+        (identity when None) -> float64 [N, len(qs)]"""
+        idx = [self.qs.index(q) for q in qs]
+        a, b = self.lo[:, idx], self.hi[:, idx]
+        if transform is not None:
+            a, b = transform(a), transform(b)
+        t = self.frac[idx][None, :]
+        d = b - a
+        return np.where(t >= 0.5, b - d * (1 - t), a + d * t)
+
+
+def _field_threshold(stats: _FrameStats):
+    """ground() / normalize() then ``(p99.9 - p5) / 2 + p5`` of the float64 frame (winston_lutz.py:711-712, 775-776):
+    the order statistics pushed through the same float64 operations -> (vmin, gmax, thr) float64 [N] on the host"""
+    vmin, gmax = stats.vmin, stats.vmax - stats.vmin            # max of the grounded frame
+    p = stats.percentiles(_FIELD_Q, transform=lambda v: (v - vmin[:, None]) / gmax[:, None])
+    return vmin, gmax, (p[:, 1] - p[:, 0]) / 2 + p[:, 0]
+
+
+def field_centroids_batch(frames: torch.Tensor, stats: _FrameStats | None = None) -> torch.Tensor:
+    """-> float64 [N, 3] = (x, y, filled_pixel_count) of the field centroid of every frame.  ``stats``: the frames'
+    order statistics when the caller already has them."""
     x = ops._frames(frames)
     if x.dtype != torch.uint16:
         # int16: the reference's ground() (`array - array.min()`, array_utils.py:102) wraps around in
         # int16 for any frame whose range exceeds 32767, i.e. its own result is an overflow artefact
         raise TypeError("field_centroids_batch needs uint16 frames")
-    cnt = x[0].numel()
-    hist = ops.histogram16(x) if hist is None else hist
-    qs, lo, hi, frac = ops._percentile_plan(cnt, [5, 99.9])
-
-    ranks = np.concatenate([[0, cnt - 1], lo, hi])           # min, max, p-lo ranks, p-hi ranks
-    st = ops.order_stats(x, ranks, hist=hist).to(torch.float64)
-    vmin, vmax = st[:, 0], st[:, 1]
-    gmax = vmax - vmin                                         # max of the grounded frame
-    t = torch.as_tensor(frac, dtype=torch.float64, device=x.device)
-    a = (st[:, 2:4] - vmin[:, None]) / gmax[:, None]           # normalised lower order statistics
-    b = (st[:, 4:6] - vmin[:, None]) / gmax[:, None]
-    p = ops.lerp_like_numpy(a, b, t[None, :])                  # [N,2] = (p5, p99.9) of the f64 frame
-    thr = (p[:, 1] - p[:, 0]) / 2 + p[:, 0]
+    stats = _FrameStats(x, qs=_FIELD_Q) if stats is None else stats
+    vmin, gmax, thr = (torch.from_numpy(np.ascontiguousarray(v)).to(x.device) for v in _field_threshold(stats))
     cen = ops.field_cax(x, vmin, gmax, thr)                    # threshold -> fill holes -> centre of mass: row, col, count
     return torch.stack([cen[:, 1], cen[:, 0], cen[:, 2]], dim=1)
-
-
-
-def _percentiles_from_hist(x: torch.Tensor, hist: torch.Tensor, q) -> np.ndarray:
-    """np.percentile(frame, q) per frame from the exact histogram -> float64 [N, len(q)] on the host"""
-    cnt = x[0].numel()
-    qs, lo, hi, frac = ops._percentile_plan(cnt, q)
-    st = ops.order_stats(x, np.concatenate([lo, hi]), hist=hist).cpu().numpy().astype(np.float64)
-    a, b = st[:, : len(qs)], st[:, len(qs):]
-    d = b - a
-    return np.where((frac >= 0.5)[None, :], b - d * (1 - frac), a + d * frac)
 
 
 def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0, low_density: bool = False,
@@ -77,41 +97,37 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0
     frame, like the reference's points; status int32 [N]: 0 ok, 1 = no BB found (the reference raises ValueError);
     inverted bool [N]; crop int32 [N] = pixels ``_clean_edges`` removed from every side).
 
-    One exact histogram per frame serves every percentile the sequence asks for; the decisions (three comparisons per
-    frame) are taken on the host from a [N, 5] table, inversion is applied on the device to the frames that need it.
-    A frame whose edges need cleaning changes shape: it is finished on its own (same kernels, batch of one)."""
+    One exact histogram and one selection launch per batch serve every percentile the sequence asks for; the decisions
+    (three comparisons per frame) are taken on the host from that table, inversion is applied on the device to the
+    frames that need it.  A frame whose edges need cleaning changes shape: it is finished on its own (same kernels,
+    batch of one)."""
     from . import decisions, features
-    from .roi import rectangle_stats_batch
 
     x = ops._frames(frames)
     if x.dtype != torch.uint16:
         raise TypeError("analyze_batch needs uint16 frames")
     n, h, w = x.shape
     dev = x.device
-    hist = ops.histogram16(x)
+    stats = _FrameStats(x)
     # ---- inversion (|p50 - p0.01| > |p50 - p99.99|): invert -a + max + min, in the frame's dtype
-    p = _percentiles_from_hist(x, hist, [0.01, 50, 99.99])
+    p = stats.percentiles(_INVERSION_Q)
     inverted = np.abs(p[:, 1] - p[:, 0]) > np.abs(p[:, 1] - p[:, 2])
     if inverted.any():
         idx = torch.from_numpy(np.nonzero(inverted)[0]).to(dev)
         x = x.clone()
         xi = x.view(torch.int16)                       # torch has no indexed copies for uint16: same bits as int16
-        sub = ops.invert(xi[idx].view(torch.uint16))
-        xi[idx] = sub.view(torch.int16)
-        hist[idx] = ops.histogram16(sub)
+        xi[idx] = ops.invert(xi[idx].view(torch.uint16)).view(torch.int16)
+        stats = _FrameStats(x)                         # the inverted frames' order statistics (a rare branch)
     # ---- edge cleaning decision on the whole batch; frames that need cropping leave the batch
     crop = np.zeros(n, dtype=np.int32)
     record = np.full((n, 4), np.nan, dtype=np.float64)
     status = np.zeros(n, dtype=np.int32)
     keep = np.ones(n, dtype=bool)
     if clean_edges:
-        pe = _percentiles_from_hist(x, hist, [5, 99.5])
-        ws = 2
-        strips = np.array([[0, ws, 0, w], [0, h, 0, ws], [h - ws, h, 0, w], [0, h, w - ws, w]], dtype=np.float64)
-        s = rectangle_stats_batch(x, strips)[0].cpu().numpy()                # [N, 4, fields]: 3 = min, 4 = max
-        edge_min, edge_max = s[:, :, 3].min(axis=1), s[:, :, 4].max(axis=1)
+        pe = stats.percentiles(_EDGE_Q)
+        emin, emax = (t.cpu().numpy().astype(np.float64) for t in ops.edge_minmax(x, 2))
         rng = pe[:, 1] - pe[:, 0]
-        noisy = (edge_min < pe[:, 0] - rng / 10) | (edge_max > pe[:, 1] + rng / 10)
+        noisy = (emin < pe[:, 0] - rng / 10) | (emax > pe[:, 1] + rng / 10)
         for i in np.nonzero(noisy)[0]:
             cleaned = decisions.clean_edges(x[i])                              # the reference's loop, one frame
             crop[i] = (h - cleaned.shape[0]) // 2
@@ -119,10 +135,14 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0
             record[i], status[i] = one["record"][0], one["status"][0]
             keep[i] = False
     if keep.any():
-        sel = x if keep.all() else x.view(torch.int16)[torch.from_numpy(np.nonzero(keep)[0]).to(dev)].view(torch.uint16)
-        hsel = hist if keep.all() else hist[torch.from_numpy(np.nonzero(keep)[0]).to(dev)]
-        fld = field_centroids_batch(sel, hist=hsel).cpu().numpy()
-        bb = features.bb_centroids_batch(sel, dpmm, bb_diameter_mm, low_density=low_density)
+        if keep.all():
+            sel, sst = x, stats
+        else:
+            sel = x.view(torch.int16)[torch.from_numpy(np.nonzero(keep)[0]).to(dev)].view(torch.uint16)
+            sst = _FrameStats(sel)
+        fld = field_centroids_batch(sel, stats=sst).cpu().numpy()
+        bb = features.bb_centroids_batch(sel, dpmm, bb_diameter_mm, low_density=low_density,
+                                         vmin=torch.from_numpy(sst.vmin).to(dev), vmax=torch.from_numpy(sst.vmax).to(dev))
         bxy = bb["xy"][:, 0, :].cpu().numpy()
         cnt = bb["count"].cpu().numpy()
         rec = np.concatenate([fld[:, :2], np.where(cnt[:, None] > 0, bxy, np.nan)], axis=1)

@@ -160,6 +160,20 @@ def check_otsu16(golden, dev, big=True):
             assert np.array_equal(thr.cpu().numpy(), np.array([o.threshold_otsu(f) for f in a])), (shape, dt)
             assert np.array_equal(tmin.cpu().numpy(), a.reshape(shape[0], -1).min(1)), (shape, dt)
             assert np.array_equal(tmax.cpu().numpy(), a.reshape(shape[0], -1).max(1)), (shape, dt)
+    # flat frames (one value per whole wave: the single-atomic path of both histogram kernels), ragged sizes so that the
+    # last vectors are handled by partial waves, a few outliers in otherwise constant data
+    for shape in ((2, 63, 72), (1, 200, 1024), (1, 37, 50)) if big else ((2, 63, 72), (1, 37, 50)):
+        a = np.zeros(shape, dtype=np.uint16)
+        a[0, shape[1] // 2:, :] = 31000
+        a[0, 3, 5] = 7
+        a[-1, -1, -1] = 40000
+        t = torch.from_numpy(a).to(dev)
+        h = ops.histogram16(t).cpu().numpy().astype(np.int64)
+        assert np.array_equal(h, np.stack([np.bincount(f.ravel(), minlength=65536) for f in a])), shape
+        thr, tmin, tmax = ops.otsu16(t)
+        assert np.array_equal(thr.cpu().numpy(), np.array([o.threshold_otsu(f) for f in a])), shape
+        assert np.array_equal(tmin.cpu().numpy(), a.reshape(shape[0], -1).min(1)) and \
+            np.array_equal(tmax.cpu().numpy(), a.reshape(shape[0], -1).max(1)), shape
 
 
 def check_wl_analyze_batch(golden, dev, frames=None):

@@ -641,7 +641,7 @@ def test_catphan_stages_vs_skimage_golden(golden, dev):
     assert np.array_equal(gs[0].cpu().numpy(), g["0.gauss"])
     reg = ct.get_regions_batch(t, mm)
     n = len(sl)
-    assert np.array_equal(reg["otsu"], [float(g[f"{i}.otsu"]) for i in range(n)])
+    assert np.array_equal(reg["otsu"].cpu().numpy(), [float(g[f"{i}.otsu"]) for i in range(n)])   # device float Otsu
     assert np.array_equal(reg["bw"].cpu().numpy(), np.stack([g[f"{i}.filled"] for i in range(n)]))
     assert np.array_equal(reg["labels"].cpu().numpy(), np.stack([g[f"{i}.labels"] for i in range(n)]))
     stats = reg["stats"].cpu().numpy()
@@ -656,7 +656,7 @@ def test_catphan_stages_vs_skimage_golden(golden, dev):
         assert np.allclose(s[:, 8] / s[:, 7], p[:, 8], rtol=1e-9, atol=0)
         assert np.allclose(s[:, 9] / s[:, 7], p[:, 9], rtol=1e-9, atol=0)
     # intermediate masks: '>' threshold and clear_border
-    thr = torch.from_numpy(reg["otsu"] * 0.8).to(dev)
+    thr = torch.from_numpy(reg["otsu"].cpu().numpy() * 0.8).to(dev)
     bw = ops.compare(reg["edges"], thr, ">")
     assert np.array_equal(bw.cpu().numpy(), np.stack([g[f"{i}.bw"] for i in range(n)]))
     cl = ops.clear_border(bw, min(int(max(sl.shape[1:]) / 100), 3))
