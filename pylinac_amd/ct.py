@@ -228,3 +228,105 @@ def find_phantom_roll_volume(slices: torch.Tensor, mm_per_pixel: float, origin_s
     y_dist = top_bottom[1][0] - top_bottom[0][0]
     x_dist = top_bottom[1][1] - top_bottom[0][1]
     return float(np.rad2deg(np.arctan2(y_dist, x_dist)) - 90)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# CTP528 spatial resolution per slice (pylinac/ct.py:1398-1580): BASELINE config #5's per-slice record
+# ----------------------------------------------------------------------------------------------------------
+# line-pair regions of the CatPhan 504 / 604 (pylinac/ct.py:1417-1503): start, end (fractions of the circle profile),
+# number of peaks, number of valleys, peak spacing (fraction), lp/mm
+CTP528_REGIONS = (
+    (0, 0.107, 2, 1, 0.021, 0.1), (0.107, 0.173, 3, 2, 0.01, 0.2), (0.173, 0.236, 4, 3, 0.006, 0.3),
+    (0.236, 0.286, 4, 3, 0.00557, 0.4), (0.286, 0.335, 4, 3, 0.004777, 0.5), (0.335, 0.387, 5, 4, 0.00398, 0.6),
+    (0.387, 0.434, 5, 4, 0.00358, 0.7), (0.434, 0.479, 5, 4, 0.0027866, 0.8),
+)
+
+
+def ctp528_profiles_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx, fit_zy, slices=None, roll_deg: float = 0.0,
+                          radius2linepairs_mm: float = 47, scaling_factor: float = 1.0, roi_size_factor: float = 1.0,
+                          start_angle: float = np.pi, ccw: bool = True, slices_plusminus: int = 3):
+    """``CTP528CP504.circle_profile`` (pylinac/ct.py:1559-1580) for the chosen slices of a resident volume [S, H, W]:
+    ``combine_surrounding_slices(+-3, "max")`` (module attributes ``combine_method = "max"``, ``num_slices = 3``,
+    ct.py:1415-1416), a CollapsedCircleProfile of 20 radii within +-4 % of the line-pair radius at 2x sampling about the
+    phantom centre ``(fit_zx(z), fit_zy(z))``, ``filter(0.001, "gaussian")``, ``ground()``.
+    -> (float64 [M, L] profiles on the device, the slice indices)."""
+    from .array_utils import resolve_filter_size
+
+    x = ops._frames(volume)
+    n, h, w = x.shape
+    idx = np.arange(n) if slices is None else np.asarray(slices, dtype=np.int64)
+    combined = ops.combine_slices(x, slices_plusminus, "max")
+    sub = combined if slices is None else combined[torch.from_numpy(idx).to(x.device)].contiguous()
+    cx, cy = np.polyval(fit_zx, idx), np.polyval(fit_zy, idx)                 # Slice.phan_center, ct.py:434-439
+    radius = radius2linepairs_mm * scaling_factor / mm_per_pixel               # ct.py:1546-1549
+    if (w < radius + cx).any() or (h < radius + cy).any():                     # CircleProfile._ensure_array_size
+        raise ValueError("Array size not large enough to compute profile")
+    width_ratio, num_profiles, sampling_ratio = 0.04 * roi_size_factor, 20, 2
+    radii = np.linspace(radius * (1 - width_ratio), radius * (1 + width_ratio), num_profiles)   # profile.py:2448-2452
+    size = np.pi * radii.max() * 2 * sampling_ratio
+    prof = ops.circle_profile(sub, cx, cy, radii, size, start_angle + np.deg2rad(roll_deg), ccw, float(num_profiles))
+    sigma = resolve_filter_size(prof.shape[1], 0.001)                          # array_utils.filter: int(round(len * size))
+    prof = ops.gaussian_filter1d(prof, sigma, axis=-1)
+    mn, _ = ops.minmax(prof[:, None, :])
+    prof = ops.ground(prof[:, None, :].contiguous(), mn=mn)[:, 0, :].contiguous()
+    return prof, idx
+
+
+def ctp528_mtf_batch(profiles: torch.Tensor, regions=CTP528_REGIONS):
+    """``CTP528CP504.mtf`` (pylinac/ct.py:1511-1544) for a batch of circle profiles [M, L]: per line-pair region the
+    ``num peaks`` most prominent peaks (``find_peaks``, threshold 0.3, the region as search window), the valleys between
+    the outermost of them (``find_valleys`` = peaks of the negated profile, per-profile search window), their means,
+    Michelson contrast, normalised to region 1.  A slice stops at the first region with the wrong number of peaks, like
+    the reference's ``break``.  -> dict(rmtf float64 [M, 8] (NaN beyond the regions found; all NaN = the reference's
+    "Did not find any spatial resolution pairs"), nregions int [M], maxs / mins float64 [M, 8])."""
+    p = profiles.contiguous()
+    m, length = p.shape
+    neg = ops.scale(p[:, None, :].contiguous(), -1.0)[:, 0, :].contiguous()
+    maxs = np.full((m, len(regions)), np.nan)
+    mins = np.full((m, len(regions)), np.nan)
+    alive = np.ones(m, dtype=bool)
+    nreg = np.zeros(m, dtype=np.int64)
+    for k, (start, end, npk, nval, spacing, _) in enumerate(regions):
+        if not alive.any():
+            break
+        pk = ops.find_peaks_batch(p, cap=npk, threshold=0.3, peak_separation=spacing, max_number=npk,
+                                  search_region=(start, end))
+        cnt = pk.count.cpu().numpy()
+        idx = pk.idx.cpu().numpy()
+        heights = pk.props[:, 0, :].cpu().numpy()                      # peak_heights
+        ok = alive & (cnt == npk)
+        alive = ok
+        if not ok.any():
+            break
+        lo = np.where(ok, idx[:, :npk].min(axis=1), 0)
+        hi = np.where(ok, idx[:, :npk].max(axis=1), 0)
+        reg = torch.from_numpy(np.stack([lo, hi], axis=1).astype(np.int32))
+        vl = ops.find_peaks_batch(neg, cap=max(nval, 1), regions=reg, threshold=0.3, peak_separation=spacing,
+                                  max_number=nval)
+        vcnt = vl.count.cpu().numpy()
+        vidx = vl.idx.cpu().numpy()
+        pv = p.cpu().numpy() if k == 0 else pv                          # values[valley_idxs]: the profile itself
+        for i in np.nonzero(ok)[0]:
+            maxs[i, k] = heights[i, :npk].mean()
+            mins[i, k] = pv[i, vidx[i, : vcnt[i]]].mean() if vcnt[i] else np.nan      # np.mean of an empty selection
+        nreg[ok] = k + 1
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mtf = (maxs - mins) / (maxs + mins)                             # michelson: (max - min) / (max + min)
+        rmtf = mtf / mtf[:, :1]
+    return dict(rmtf=rmtf, nregions=nreg, maxs=maxs, mins=mins)
+
+
+def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=None, slices=None, roll_deg: float = 0.0,
+                 **kw):
+    """Config #5's per-slice record for a resident CatPhan volume [S, H, W]: phantom ROI of every
+    slice -> the reference's axis fits -> circle profile and relative MTF of every requested slice.
+    -> dict(center float64 [M, 2] = (x, y) fitted phantom centre, profiles float64 [M, L] (device), rmtf float64 [M, 8],
+    nregions, maxs, mins, slices, roi = the per-slice phantom ROI table)."""
+    roi = None
+    if fit_zx is None or fit_zy is None:
+        fit_zx, fit_zy, roi = find_phantom_axis_volume(volume, mm_per_pixel)
+    prof, idx = ctp528_profiles_batch(volume, mm_per_pixel, fit_zx, fit_zy, slices=slices, roll_deg=roll_deg, **kw)
+    out = ctp528_mtf_batch(prof)
+    out.update(center=np.stack([np.polyval(fit_zx, idx), np.polyval(fit_zy, idx)], axis=1), profiles=prof, slices=idx,
+               roi=roi, fit_zx=np.asarray(fit_zx), fit_zy=np.asarray(fit_zy))
+    return out

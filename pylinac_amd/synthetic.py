@@ -101,3 +101,54 @@ def wl_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 3000, pixel_mm:
         out[i, r0:r0 + 2 * half, c0:c0 + 2 * half] = img.astype(np.uint16)
         truth[i] = (fcx, fcy, bcx, bcy)
     return (out, truth) if return_truth else out
+
+
+# CTP528 line-pair regions (pylinac/ct.py:1417-1503): start / end as fractions of the circle profile, bars, gap (cm)
+_CTP528_REGIONS = ((0.0, 0.107, 2, 0.5), (0.107, 0.173, 3, 0.25), (0.173, 0.236, 4, 0.167), (0.236, 0.286, 4, 0.125),
+                   (0.286, 0.335, 4, 0.1), (0.335, 0.387, 5, 0.083), (0.387, 0.434, 5, 0.071), (0.434, 0.479, 5, 0.063))
+
+
+def catphan_volume(seed: int = 4000, n_slices: int = 80, size: int = 512, mm_per_pixel: float = 0.5,
+                   noise_hu: float = 8.0, return_truth: bool = False):
+    """Config #5: one analytic CatPhan-504-like volume [n_slices, size, size] int16 on the HOST
+    from ``np.random.default_rng(seed)``: air (-1000 HU) around a 200 mm cylinder (90 HU) whose centre drifts linearly
+    with z (a slightly tilted phantom); a HU module (eight inserts on the 58.4 mm circle incl. two air bubbles) around
+    z = 0.3 n; a spatial-resolution module around z = 0.55 n with the eight CTP528 line-pair groups (0.1 ... 0.8 lp/mm,
+    bar = gap widths of pylinac/ct.py:1417-1503) as 1000 HU bars on the 47 mm circle, each group centred in its
+    region of the reference's circle profile (start angle pi, counter-clockwise); a couch bar below; Gaussian noise."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:size, 0:size].astype(np.float64)
+    c0 = size / 2 - 0.5 + rng.uniform(-4, 4, 2)                    # (row, col) centre at z = 0
+    tilt = rng.uniform(-0.06, 0.06, 2)                             # pixels per slice
+    hu_c, res_c = int(round(0.3 * n_slices)), int(round(0.55 * n_slices))
+    hu_half, res_half = max(n_slices // 16, 2), max(n_slices // 14, 3)
+    out = np.empty((n_slices, size, size), dtype=np.int16)
+    circ_mm = 2 * np.pi * 47.0
+    for z in range(n_slices):
+        cy, cx = c0[0] + tilt[0] * z, c0[1] + tilt[1] * z
+        dy, dx = (y - cy) * mm_per_pixel, (x - cx) * mm_per_pixel
+        r = np.hypot(dy, dx)
+        img = np.full((size, size), -1000.0)
+        img[r < 100.0] = 90.0
+        if abs(z - hu_c) <= hu_half:
+            for k, hu in enumerate((-1000, 340, -200, 950, -100, 120, -1000, 990)):
+                a = k * np.pi / 4 + np.pi / 2                       # air bubbles at the top and the bottom
+                img[np.hypot(dy - 58.4 * np.sin(a), dx - 58.4 * np.cos(a)) < 6.0] = hu
+        if abs(z - res_c) <= res_half:
+            # position along the reference's circle profile: sample i sits at angle pi + 2 pi (1 - i / L) (ccw reversal)
+            frac = np.mod(1.0 - (np.arctan2(dy, dx) - np.pi) / (2 * np.pi), 1.0)
+            ring = np.abs(r - 47.0) < 4.0
+            for lo, hi, bars, gap_cm in _CTP528_REGIONS:
+                width = gap_cm * 10.0 / circ_mm                       # bar (= gap) width as a fraction of the circle
+                start = (lo + hi) / 2 - (2 * bars - 1) * width / 2
+                for b in range(bars):
+                    s = start + 2 * b * width
+                    img[ring & (frac >= s) & (frac < s + width)] = 1000.0
+        img[int(size * 0.955):int(size * 0.975), int(size * 0.15):int(size * 0.85)] = 200.0     # couch
+        img += rng.normal(0, noise_hu, img.shape)
+        out[z] = np.clip(np.round(img), -1024, 3000).astype(np.int16)
+    if return_truth:
+        return out, dict(center0=c0, tilt=tilt, hu_slice=hu_c, resolution_slice=res_c)
+    return out

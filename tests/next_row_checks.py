@@ -237,6 +237,34 @@ def check_field_cax(dev):
         assert gb[k, 2] == filled.sum() and np.array_equal(gb[k, :2], np.array(ndimage.center_of_mass(filled))), k
 
 
+def check_ctp528_batch(golden, dev, whole=True):
+    """ct.ctp528_batch (combine +-3 slices by max -> collapsed circle profile -> 1-D Gaussian -> ground -> per-region
+    peaks / valleys -> relative MTF) against the reference's OWN CTP528CP504.circle_profile / .mtf per slice on a
+    synthetic CatPhan volume (tests/golden/skimage_ctp528_py39.py), incl. the phantom-axis fits from the reference's
+    find_phantom_axis.  Profiles 1e-9, rMTF 1e-9, same number of regions."""
+    from pylinac_amd import ct
+
+    g = golden("ctp528")
+    vol = torch.from_numpy(g["volume"]).to(dev)
+    mmpp = float(g["mmpp"])
+    sl = g["slices"]
+    prof, idx = ct.ctp528_profiles_batch(vol, mmpp, g["fit_zx"], g["fit_zy"], slices=sl)
+    assert np.array_equal(idx, sl)
+    assert np.allclose(prof.cpu().numpy(), g["profiles"], rtol=0, atol=1e-9)
+    res = ct.ctp528_mtf_batch(prof)
+    assert np.array_equal(res["nregions"], g["nregions"])
+    for key in ("rmtf", "maxs", "mins"):
+        assert np.allclose(res[key], g[key], rtol=1e-9, atol=1e-9, equal_nan=True), key
+    # a profile without line pairs: the reference raises "Did not find any spatial resolution pairs" -> all NaN, 0 regions
+    flat = torch.zeros((1, prof.shape[1]), dtype=torch.float64, device=prof.device)
+    r0 = ct.ctp528_mtf_batch(flat)
+    assert int(r0["nregions"][0]) == 0 and np.isnan(r0["rmtf"]).all()
+    if whole:   # the composed entry: axis fits from the device's own phantom ROIs, every slice of the volume
+        full = ct.ctp528_batch(vol, mmpp)
+        assert np.allclose(full["fit_zx"], g["fit_zx"], rtol=1e-9, atol=1e-9) and np.allclose(full["fit_zy"], g["fit_zy"], rtol=1e-9, atol=1e-9)
+        assert np.allclose(full["rmtf"][sl], g["rmtf"], rtol=1e-7, atol=1e-7, equal_nan=True)
+
+
 def check_rectangle_roi(golden, dev):
     """RectangleROI / polygon statistics against the reference's own RectangleROI and raw skimage.draw.polygon pixel
     lists (tests/golden/rect.npz): counts, min, max, median exact; mean / std to 1e-12 (summation order)."""

@@ -310,6 +310,12 @@ def test_emulated_otsu16(golden, emulated):
     checks.check_otsu16(golden, emulated, big=False)
 
 
+def test_emulated_ctp528_batch(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_ctp528_batch(golden, emulated, whole=False)
+
+
 def test_emulated_field_cax(emulated):
     import next_row_checks as checks
 

@@ -827,6 +827,13 @@ def test_find_features_batch_vs_reference_golden(golden, dev):
         o.find_features_restated(flat[0], dpmm, 2.5, 0.5)
 
 
+def test_ctp528_batch_vs_reference_golden(golden, dev):
+    """config #5: the per-slice spatial-resolution record against the reference's own CTP528CP504 on a synthetic volume."""
+    import next_row_checks as checks
+
+    checks.check_ctp528_batch(golden, dev)
+
+
 def test_field_cax_fused_vs_scipy(dev):
     """a14: pl_field_cax (threshold -> fill holes -> centre of mass without a mask or label plane) against scipy."""
     import next_row_checks as checks
