@@ -9,8 +9,14 @@
 A "step" is one pass of the hot path (Gaussian(5) -> median(3) -> Otsu -> threshold -> column
 profile -> FWXM peak) over one batch of 256 synthetic 1024x1024 uint16 frames PER GPU
 (BASELINE.json configs[1]); frames are resident in HBM before the timed region.  N > 1 shards
-independent frames (weak scaling, no data-path collective) and ends each step with the one
-all-gather of the per-image scalar records.  Rank 0 prints ONE JSON line.
+independent frames (weak scaling by default, `--scaling strong` splits the 256 frames over the ranks;
+no data-path collective) and ends each step with the one all-gather of the per-image scalar records.
+Rank 0 prints ONE JSON line.
+
+At N = 1 the line also carries `configs`: BASELINE configs #3 (picket fence), #4 (Winston-Lutz) and #5
+(CatPhan CTP528) on their SURVEY 8d seeded generators, each with its own fraction of the HBM-read
+roofline and its own CPU baseline, and `cpu_baseline` (single thread + one worker per host core) for the
+headline workload.
 """
 from __future__ import annotations
 
@@ -20,13 +26,16 @@ import os
 import sys
 import time
 
-import torch
+# torch is imported inside the functions: the CPU baseline's spawn-context worker processes re-import this module as
+# __mp_main__ and must stay light (numpy / scipy only)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0          # measured float4 copy (same guide): the ceiling a streaming kernel can reach
 ALG_BYTES_PER_FRAME = 4_194_304  # read u16 frame + write u16 frame
+ALG_BYTES = {"#3": 1_572_864, "#4": 2_097_152, "#5": 524_288}   # read-once roofline per frame / slice
 
 
 def parse():
@@ -34,37 +43,121 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (weak) / in total (strong)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--cpu-frames", type=int, default=96,
                     help="bounded CPU-baseline sample (frames through the oracle on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs #3-#5")
     return ap.parse_args()
 
 
-def cpu_baseline(frames_host, n_sample):
-    """The oracle (numpy glue over the same scipy routines the reference calls) on host cores."""
-    from oracle import pylinac_oracle as oracle
+def timed_passes(fn, iters=3):
+    import torch
 
-    n_sample = min(n_sample, frames_host.shape[0])
-    oracle.epid_pipeline_frame(frames_host[0])  # warm-up (imports, page faults)
+    fn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(n_sample):
-        oracle.epid_pipeline_frame(frames_host[i])
-    dt = time.perf_counter() - t0
-    return {
-        "value": round(n_sample / dt, 3),
-        "unit": "images/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{n_sample} of the same synthetic 1024x1024 uint16 frames through oracle/pylinac_oracle.py "
-                  f"(scipy.ndimage gaussian+median, Otsu, threshold, np.mean, scipy.signal.find_peaks), "
-                  f"single thread, {dt:.1f} s; host has {os.cpu_count()} cores",
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def bench_configs(dev):
+    """BASELINE configs #3 / #4 / #5 on one GPU, inputs resident in HBM, SURVEY 8d seeded generators."""
+    import torch
+
+    from pylinac_amd import ct, picketfence, winston_lutz
+    from pylinac_amd.synthetic import catphan_volume, pf_frames, wl_frames
+
+    out = {}
+
+    def entry(key, workload, units, unit, dt, inputs):
+        rate = units / dt
+        gbs = rate * ALG_BYTES[key] / 1e9
+        out[key] = {"workload": workload, "units": units, "unit": unit, "ms_per_pass": round(dt * 1e3, 3),
+                    "value": round(rate, 1), "algorithmic_GBs": round(gbs, 2),
+                    "frac": round(gbs / HBM_PEAK_GBS, 5), "frac_of_measured_copy": round(gbs / HBM_COPY_GBS, 5),
+                    "inputs": inputs}
+
+    n3 = 512
+    f3 = pf_frames(n3, device=dev)
+    dt = timed_passes(lambda: picketfence.analyze_batch(f3, 1 / 0.390625, num_pickets=10))
+    entry("#3", "PicketFence: 512 x (768 x 1024) uint16, column mean -> picket peaks -> 60-leaf x 10-picket windows -> "
+                "FWXM positions", n3, "frames/s", dt, "synthetic.pf_frames seed 2000+i")
+    del f3
+    n4 = 512
+    f4 = torch.from_numpy(wl_frames(n4)).to(dev)
+    dt = timed_passes(lambda: winston_lutz.analyze_batch(f4, 1 / 0.336, 5.0))
+    entry("#4", "Winston-Lutz: 512 x 1024^2 uint16, inversion check -> clean edges -> field CAX (percentile threshold, "
+                "fill holes, centre of mass) -> BB threshold sweep + weighted centroid", n4, "frames/s", dt,
+          "synthetic.wl_frames seed 3000+i (generate_winstonlutz recipe)")
+    del f4
+    vols = [torch.from_numpy(catphan_volume(4000 + v)).to(dev) for v in range(4)]
+    dt = timed_passes(lambda: [ct.ctp528_batch(v, 0.5) for v in vols])
+    entry("#5", "CatPhan-504: 4 volumes x 80 x 512^2 int16 (a bounded sample of the 200-volume job), per slice: phantom "
+                "ROI (scharr, gaussian, Otsu, clear_border, fill, label, regionprops) -> axis fits -> +-3-slice max -> "
+                "collapsed circle profile -> 8-region peak/valley rMTF", 4 * 80, "slices/s", dt,
+          "synthetic.catphan_volume seed 4000+v")
+    return out, vols
+
+
+def cpu_baselines(frames_host, args, with_configs):
+    """single-thread + pool-of-cores oracle timings (bounded samples) -> (headline cpu_baseline, per-config baselines)"""
+    from oracle import cpu_baseline as cb
+    from pylinac_amd.synthetic import pf_frames
+
+    cores = os.cpu_count() or 1
+    model = cb.cpu_model()
+    n_sample = min(args.cpu_frames, frames_host.shape[0])
+    cb.single_thread("epid", frames_host[:1])                     # warm-up (imports, page faults)
+    rate, units, dt = cb.single_thread("epid", frames_host[:n_sample])
+    per_cfg = {}
+    tasks = [("epid", frames_host[i % frames_host.shape[0]][None]) for i in range(cores)]
+    singles = {}
+    if with_configs:
+        pf = pf_frames(8).numpy()
+        singles["#3"] = cb.single_thread("pf", pf[:4])
+        singles["#4"] = cb.single_thread("wl", *cb._make_inputs("wl", 3000, 8))
+        singles["#5"] = cb.single_thread("ct", *cb._make_inputs("ct", 4000, 8))
+        tasks += [("pf", pf[i % 8][None]) for i in range(cores)]
+        tasks += [("wl", ("gen", 3000 + i, 2)) for i in range(cores)]
+        tasks += [("ct", ("gen", 4000 + i, 2)) for i in range(cores)]
+    try:
+        pool = cb.pool_throughput(tasks, cores)
+    except Exception as exc:   # a baseline must not take the bench line down
+        pool = {}
+        print(f"[bench] pool baseline failed: {exc!r}", file=sys.stderr)
+    head = {
+        "value": round(rate, 3), "unit": "images/s", "cores": 1, "kind": "port",
+        "sample": f"{units} of the same synthetic 1024x1024 uint16 frames through oracle/pylinac_oracle.py "
+                  f"(scipy.ndimage gaussian+median, Otsu, threshold, np.mean, scipy.signal.find_peaks), single thread, "
+                  f"{dt:.1f} s",
+        "cpu_model": model, "host_cores": cores,
     }
+    if "epid" in pool:
+        head["pool"] = {"value": round(pool["epid"][0], 2), "cores": cores, "units": pool["epid"][1],
+                        "wall_s": round(pool["epid"][2], 2),
+                        "how": "multiprocessing spawn pool, one worker per host core, one frame each"}
+    names = {"#3": ("pf", "frames/s"), "#4": ("wl", "frames/s"), "#5": ("ct", "slices/s")}
+    for key, (kind, unit) in names.items():
+        if key not in singles:
+            continue
+        r, u, d = singles[key]
+        per_cfg[key] = {"value": round(r, 3), "unit": unit, "cores": 1, "kind": "port",
+                        "sample": f"{u} units through the oracle's restatement of the reference's per-image sequence, {d:.1f} s"}
+        if kind in pool:
+            per_cfg[key]["pool"] = {"value": round(pool[kind][0], 2), "cores": cores, "units": pool[kind][1],
+                                    "wall_s": round(pool[kind][2], 2)}
+    return head, per_cfg
 
 
 def main():
+    import torch
+
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,15 +179,20 @@ def main():
     from pylinac_amd.pipeline import EpidPipeline
     from pylinac_amd.synthetic import epid_open_field_frames
 
-    n, h, w = args.frames, args.height, args.width
-    # weak scaling: every rank owns `n` frames; global frame index = rank*n + i -> seed 1000 + index
-    frames = epid_open_field_frames(n, h, w, seed0=1000 + rank * n, device=dev)
+    h, w = args.height, args.width
+    if args.scaling == "strong":
+        lo, hi = pdist.shard_range(args.frames, rank, world)     # contiguous block split of the fixed frame set
+        n, first, n_total = hi - lo, lo, args.frames
+    else:
+        n, first, n_total = args.frames, rank * args.frames, args.frames * world
+    # global frame index -> seed 1000 + index
+    frames = epid_open_field_frames(n, h, w, seed0=1000 + first, device=dev)
     pipe = EpidPipeline(n, h, w, dev)
 
     def step(events=None):
         res = pipe.run(frames, events)
         rec = res.record()
-        return pdist.all_gather_records(rec, n * world) if dist is not None else rec
+        return pdist.all_gather_records(rec, n_total) if dist is not None else rec
 
     for _ in range(args.warmup):
         step()
@@ -130,7 +228,7 @@ def main():
             traffic = None
 
     if rank == 0:
-        total_frames = n * world * args.steps
+        total_frames = n_total * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         value = total_frames / elapsed
         line = {
@@ -142,14 +240,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: 256 synthetic 1024x1024 uint16 EPID frames per GPU: "
                             "Gaussian(5)+median(3)+Otsu threshold on MI355X, then column-mean profile + FWXM peak",
-                "frames_per_gpu": n, "height": h, "width": w,
+                "frames_per_gpu": n, "frames_total": n_total, "height": h, "width": w,
                 "parallelism": f"{world} x independent frame shards + 1 all-gather of [N,9] f64 records",
             },
             "roofline": {
@@ -159,17 +257,30 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
                 "traffic": traffic,
-                "note": "dominant kernel reads+writes one u16 frame (4 MiB/frame algorithmic; PMC traffic "
-                        "matches); it is VALU-issue-bound, not HBM-bound: scipy-exact float64 accumulation "
-                        "decided in packed float32 (~47-52 VALU instr/px at sigma=5; float64 kernels 61/px) "
-                        "(DESIGN.md section 5)",
+                "note": "dominant kernel reads+writes one u16 frame (4 MiB/frame algorithmic; PMC traffic matches); it is "
+                        "VALU-issue-bound, not HBM-bound: scipy-exact float64 accumulation decided in packed float32 on a "
+                        "wave-owned register window (37.8 VALU instructions per 64 pixels at sigma=5, VALU ~83 % busy; "
+                        "DESIGN.md section 5)",
                 "pipeline_frac": round(value / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(frames[: args.cpu_frames].cpu().numpy(), args.cpu_frames)
+        if world == 1:
+            with_configs = not args.no_configs
+            if with_configs:
+                del pipe
+                torch.cuda.empty_cache()
+                cfg, keep = bench_configs(dev)
+                line["configs"] = cfg
+                del keep
+            if not args.no_cpu_baseline:
+                head, per_cfg = cpu_baselines(frames[: max(args.cpu_frames, 1)].cpu().numpy(), args, with_configs)
+                line["cpu_baseline"] = head
+                for key, val in per_cfg.items():
+                    if key in line.get("configs", {}):
+                        line["configs"][key]["cpu_baseline"] = val
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

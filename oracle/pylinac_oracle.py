@@ -2011,3 +2011,74 @@ def zoom1d_cubic_nearest(values, factor: float, grid_mode: bool = False) -> np.n
         w.append(1.0 - w[0] - w[1] - w[2])
         out[i] = sum(c[min(max(fl - 1 + k, 0), ln - 1)] * w[k] for k in range(4))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# config #4  Winston-Lutz per-image sequence  (pylinac/winston_lutz.py:709-725, 764-806, 1109-1133;
+#            pylinac/metrics/image.py:564-612).  CPU baseline of bench.py and restatement pinned to the
+#            reference's own sequence (tests/golden/wl.npz, tests/test_oracle_golden.py).
+# --------------------------------------------------------------------------------------
+def wl_analyze_frame(frame: np.ndarray, dpmm: float, bb_diameter_mm: float = 5.0, low_density: bool = False):
+    """check_inversion_by_histogram((0.01, 50, 99.99)) -> _clean_edges -> ground -> normalize -> find_field_centroids ->
+    find_bb_centroids.  -> (field_x, field_y, bb_x, bb_y, inverted, crop) in the cleaned frame's coordinates."""
+    a = np.asarray(frame)
+    p_low, p_mid, p_high = (np.percentile(a, q) for q in (0.01, 50, 99.99))           # image.py:899-926
+    inverted = bool(abs(p_mid - p_low) > abs(p_mid - p_high))
+    if inverted:
+        a = invert(a)
+    h0 = a.shape[0]
+    a = clean_edges(a)
+    crop = (h0 - a.shape[0]) // 2
+    fx, fy, _ = wl_field_centroid(a)
+    arr = normalize(ground(a))                                                        # winston_lutz.py:711-712
+    tol = float(np.interp(bb_diameter_mm, (1.5, 30), (2, 4)))                         # _calculate_bb_tolerance
+    win = (40 + bb_diameter_mm) * dpmm
+    ex, ey = a.shape[1] / 2, a.shape[0] / 2                                           # from_center_physical, (0, 0) mm
+    left, right = max(math.floor(ex - win / 2), 0), math.ceil(ex + win / 2)
+    top, bottom = max(math.floor(ey - win / 2), 0), math.ceil(ey + win / 2)
+    sample = arr[top:bottom, left:right]
+    if not low_density:
+        sample = invert(sample)
+    try:
+        pts, _ = find_features_restated(sample, dpmm, bb_diameter_mm / 2, tol)
+        bx, by = pts[0][0] + left, pts[0][1] + top
+    except ValueError:
+        bx = by = np.nan
+    return fx, fy, bx, by, inverted, crop
+
+
+# --------------------------------------------------------------------------------------
+# config #5  CTP528 per slice  (pylinac/ct.py:1511-1580, 3351-3386)
+# --------------------------------------------------------------------------------------
+CTP528_REGIONS = (
+    (0, 0.107, 2, 1, 0.021, 0.1), (0.107, 0.173, 3, 2, 0.01, 0.2), (0.173, 0.236, 4, 3, 0.006, 0.3),
+    (0.236, 0.286, 4, 3, 0.00557, 0.4), (0.286, 0.335, 4, 3, 0.004777, 0.5), (0.335, 0.387, 5, 4, 0.00398, 0.6),
+    (0.387, 0.434, 5, 4, 0.00358, 0.7), (0.434, 0.479, 5, 4, 0.0027866, 0.8),
+)
+
+
+def ctp528_slice(volume: np.ndarray, s: int, center_xy, mm_per_pixel: float, roll_deg: float = 0.0):
+    """combine_surrounding_slices(+-3, "max") -> CollapsedCircleProfile(20 radii, +-4 %, 2x sampling, start pi, ccw) ->
+    filter(0.001, "gaussian") -> ground -> per region find_peaks / find_valleys -> relative MTF.
+    -> (profile float64 [L], rmtf float64 [8] NaN beyond the regions found)."""
+    n = len(volume)
+    arr = np.max(np.dstack([volume[q] for q in range(max(s - 3, 0), min(s + 3, n - 1) + 1)]), 2)
+    radius = 47 / mm_per_pixel
+    prof = collapsed_circle_profile(arr, center_xy, radius, start_angle=np.pi + np.deg2rad(roll_deg), ccw=True,
+                                    sampling_ratio=2, width_ratio=0.04, num_profiles=20)
+    prof = filter(prof, 0.001, "gaussian")
+    prof = ground(prof)
+    maxs, mins = [], []
+    for start, end, npk, nval, spacing, _ in CTP528_REGIONS:
+        idx, vals = multiprofile_find_peaks(prof, min_distance=spacing, max_number=npk, search_region=(start, end))
+        if len(vals) != npk:
+            break
+        maxs.append(vals.mean())
+        _, vvals = multiprofile_find_valleys(prof, min_distance=spacing, max_number=nval,
+                                             search_region=(min(idx), max(idx)))
+        mins.append(vvals.mean())
+    rmtf = np.full(len(CTP528_REGIONS), np.nan)
+    if maxs:
+        mtf = [(a - b) / (a + b) for a, b in zip(maxs, mins)]
+        rmtf[: len(mtf)] = np.array(mtf) / mtf[0]
+    return prof, rmtf

@@ -152,3 +152,31 @@ def catphan_volume(seed: int = 4000, n_slices: int = 80, size: int = 512, mm_per
     if return_truth:
         return out, dict(center0=c0, tilt=tilt, hu_slice=hu_c, resolution_slice=res_c)
     return out
+
+
+def pf_frames(n: int, h: int = 768, w: int = 1024, seed0: int = 2000, device="cpu", pixel_mm: float = 0.390625,
+              pickets: int = 10, picket_spacing_mm: float = 15.0, gap_mm: float = 2.0, blur_mm: float = 2.0,
+              offset_sigma_mm: float = 0.2, background: float = 2000.0, peak: float = 50000.0,
+              noise_frac: float = 0.001):
+    """Config #3: n picket-fence frames h x w uint16 (AS1000 geometry, SID 1000), UP_DOWN pickets:
+    ``pickets`` strips of ``gap_mm`` every ``picket_spacing_mm`` with a per-picket offset N(0, 0.2 mm), blurred by a 2 mm
+    Gaussian (closed form: the difference of two error functions -- ``FilteredFieldLayer`` strips + ``GaussianFilterLayer``
+    of the reference's ``generate_picketfence``, pylinac/core/image_generator/utils.py:78-136), + N(0, 0.001 * 65535)
+    noise (``RandomNoiseLayer``), frame i from seed ``seed0 + i``."""
+    import torch
+
+    device = torch.device(device)
+    xs = (torch.arange(w, dtype=torch.float64, device=device) - (w / 2 - 0.5)) * pixel_mm
+    out = torch.empty((n, h, w), dtype=torch.uint16, device=device)
+    s = blur_mm * math.sqrt(2.0)
+    for i in range(n):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed0 + i)
+        off = torch.randn(pickets, generator=g, device=device, dtype=torch.float64) * offset_sigma_mm
+        centres = (torch.arange(pickets, dtype=torch.float64, device=device) - (pickets - 1) / 2) * picket_spacing_mm + off
+        prof = (0.5 * (torch.erf((xs[None, :] - centres[:, None] + gap_mm / 2) / s)
+                       - torch.erf((xs[None, :] - centres[:, None] - gap_mm / 2) / s))).sum(dim=0)
+        img = background + peak * prof[None, :].expand(h, w)
+        img = img + torch.randn((h, w), generator=g, device=device, dtype=torch.float64) * (noise_frac * 65535.0)
+        out[i] = _to_u16(img)
+    return out

@@ -735,3 +735,24 @@ def test_bakai_gamma_restatement_matches_reference(golden):
                             threshold=kw.get("threshold", 0.1), ground_images=kw.get("ground", True),
                             normalize_images=kw.get("normalize", True))
         assert np.array_equal(got, want, equal_nan=True), name
+
+
+def test_oracle_wl_sequence_vs_reference_golden(golden):
+    """oracle.wl_analyze_frame (the CPU baseline of config #4) against the reference's own per-image sequence
+    (tests/golden/skimage_wl_py39.py): inversion, edge cleaning, field CAX, BB centroid."""
+    g = golden("wl")
+    for k, f in enumerate(g["frames"]):
+        fx, fy, bx, by, inv, crop = o.wl_analyze_frame(f, 1 / float(g["pixel_mm"]), float(g["bb_mm"]))
+        assert (fx, fy) == tuple(g["record"][k, :2]), k
+        assert np.allclose([bx, by], g["record"][k, 2:4], rtol=0, atol=1e-9), k
+        assert inv == bool(g["inverted"][k]) and 2 * crop == g["frames"].shape[1] - g["shape_after_clean"][k, 0], k
+
+
+def test_oracle_ctp528_slice_vs_reference_golden(golden):
+    """oracle.ctp528_slice (the CPU baseline of config #5) against the reference's own CTP528CP504.circle_profile / .mtf."""
+    g = golden("ctp528")
+    for j, s in enumerate(g["slices"]):
+        c = (np.polyval(g["fit_zx"], s), np.polyval(g["fit_zy"], s))
+        prof, rmtf = o.ctp528_slice(g["volume"], int(s), c, float(g["mmpp"]))
+        assert np.allclose(prof, g["profiles"][j], rtol=0, atol=1e-9), s
+        assert np.allclose(rmtf, g["rmtf"][j], rtol=1e-9, atol=1e-9, equal_nan=True), s
