@@ -96,8 +96,8 @@ def bench_configs(dev):
                 "fill holes, centre of mass) -> BB threshold sweep + weighted centroid", n4, "frames/s", dt,
           "synthetic.wl_frames seed 3000+i (generate_winstonlutz recipe)")
     del f4
-    vols = [torch.from_numpy(catphan_volume(4000 + v)).to(dev) for v in range(4)]
-    dt = timed_passes(lambda: [ct.ctp528_batch(v, 0.5) for v in vols])
+    vols = torch.stack([torch.from_numpy(catphan_volume(4000 + v)) for v in range(4)]).to(dev)   # [V, 80, 512, 512]
+    dt = timed_passes(lambda: ct.ctp528_batch(vols, 0.5))
     entry("#5", "CatPhan-504: 4 volumes x 80 x 512^2 int16 (a bounded sample of the 200-volume job), per slice: phantom "
                 "ROI (scharr, gaussian, Otsu, clear_border, fill, label, regionprops) -> axis fits -> +-3-slice max -> "
                 "collapsed circle profile -> 8-region peak/valley rMTF", 4 * 80, "slices/s", dt,
@@ -116,16 +116,18 @@ def cpu_baselines(frames_host, args, with_configs):
     cb.single_thread("epid", frames_host[:1])                     # warm-up (imports, page faults)
     rate, units, dt = cb.single_thread("epid", frames_host[:n_sample])
     per_cfg = {}
-    tasks = [("epid", frames_host[i % frames_host.shape[0]][None]) for i in range(cores)]
+    tasks = {"epid": [("epid", frames_host[i % frames_host.shape[0]][None]) for i in range(cores)]}
     singles = {}
     if with_configs:
         pf = pf_frames(8).numpy()
-        singles["#3"] = cb.single_thread("pf", pf[:4])
-        singles["#4"] = cb.single_thread("wl", *cb._make_inputs("wl", 3000, 8))
-        singles["#5"] = cb.single_thread("ct", *cb._make_inputs("ct", 4000, 8))
-        tasks += [("pf", pf[i % 8][None]) for i in range(cores)]
-        tasks += [("wl", ("gen", 3000 + i, 2)) for i in range(cores)]
-        tasks += [("ct", ("gen", 4000 + i, 2)) for i in range(cores)]
+        wl_in, ct_in = cb._make_inputs("wl", 3000, 9), cb._make_inputs("ct", 4000, 9)
+        cb.single_thread("pf", pf[:1]), cb.single_thread("wl", wl_in[0][:1]), cb.single_thread("ct", ct_in[0], ct_in[1][:1])  # warm-up
+        singles["#3"] = cb.single_thread("pf", pf[1:])
+        singles["#4"] = cb.single_thread("wl", wl_in[0][1:])
+        singles["#5"] = cb.single_thread("ct", ct_in[0], ct_in[1][1:])
+        tasks["pf"] = [("pf", pf[i % 8][None]) for i in range(cores)]
+        tasks["wl"] = [("wl", ("gen", 3000 + i, 2)) for i in range(cores)]
+        tasks["ct"] = [("ct", ("gen", 4000 + i, 2)) for i in range(cores)]
     try:
         pool = cb.pool_throughput(tasks, cores)
     except Exception as exc:   # a baseline must not take the bench line down
@@ -141,7 +143,8 @@ def cpu_baselines(frames_host, args, with_configs):
     if "epid" in pool:
         head["pool"] = {"value": round(pool["epid"][0], 2), "cores": cores, "units": pool["epid"][1],
                         "wall_s": round(pool["epid"][2], 2),
-                        "how": "multiprocessing spawn pool, one worker per host core, one frame each"}
+                        "how": "multiprocessing spawn pool, one worker per host core (os.cpu_count()), one frame each, "
+                               "wall clock from the first worker's start to the last worker's end"}
     names = {"#3": ("pf", "frames/s"), "#4": ("wl", "frames/s"), "#5": ("ct", "slices/s")}
     for key, (kind, unit) in names.items():
         if key not in singles:

@@ -229,10 +229,11 @@ int pl_linspace_edges(const double* d_lo, const double* d_hi, int nbins, int64_t
  * d_thr[i] = otsu_i * scale (pylinac/ct.py:3338-3340 uses 0.8), d_raw[i] = otsu_i (optional, may be NULL). */
 int pl_otsu_from_counts(const uint32_t* d_counts, const double* d_edges, int nbins, int64_t n, double scale,
                         double* d_thr, double* d_raw, void* stream);
-/* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count]: mode 0 = np.max (d_out has
- * the input dtype), mode 1 = np.mean (d_out float64).  The window s-k .. s+k is clamped to the stack. */
+/* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count] made of whole volumes of
+ * slices_per_volume slices: mode 0 = np.max (d_out has the input dtype), mode 1 = np.mean (d_out float64).  The window
+ * s-k .. s+k is clamped to the slice's own volume. */
 int pl_combine_slices(const void* in, void* d_out, int dtype, int64_t n, int64_t count, int plusminus, int mode,
-                      void* stream);
+                      int64_t slices_per_volume, void* stream);
 
 /* ---- a13: one threshold level of find_features (pylinac/metrics/utils.py:128-180 + features.py) ---
  * Inputs per window i: d_sample float64 [n][h][w] (the stretched sample), the 4-connected label image of

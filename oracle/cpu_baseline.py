@@ -99,20 +99,26 @@ def single_thread(kind: str, *args):
     return units / dt, units, dt
 
 
-def pool_throughput(tasks, cores: int | None = None, timeout_s: float = 240.0):
-    """Run ``tasks`` (one per worker) on a spawn-context pool -> {kind: (units per second, units, wall seconds)}; the
-    wall clock of a kind runs from its first task's start (after input preparation) to its last task's end.
-    Raises ``multiprocessing.TimeoutError`` after ``timeout_s`` (a bench must never hang on its baseline)."""
+def _warm(_):
+    from oracle import pylinac_oracle  # noqa: F401  (numpy / scipy imports, page faults)
+    return os.getpid()
+
+
+def pool_throughput(tasks_by_kind: dict, cores: int | None = None, timeout_s: float = 240.0):
+    """``tasks_by_kind`` = {kind: [task, ...]} (one task per worker).  A spawn-context pool of ``cores`` workers is
+    warmed up (every worker imports the oracle), then each kind runs on its own: its wall clock goes from its first
+    task's start (after input preparation) to its last task's end -> {kind: (units per second, units, wall seconds)}.
+    Raises ``multiprocessing.TimeoutError`` after ``timeout_s`` per kind (a bench must never hang on its baseline)."""
     import multiprocessing as mp
 
     cores = cores or os.cpu_count() or 1
     ctx = mp.get_context("spawn")               # the parent holds a HIP context: never fork it
-    with ctx.Pool(cores) as pool:
-        results = pool.map_async(run_task, tasks, chunksize=1).get(timeout=timeout_s)
     out = {}
-    for kind in {r[0] for r in results}:
-        rs = [r for r in results if r[0] == kind]
-        units = sum(r[1] for r in rs)
-        wall = max(r[3] for r in rs) - min(r[2] for r in rs)
-        out[kind] = (units / wall, units, wall)
+    with ctx.Pool(cores) as pool:
+        pool.map_async(_warm, range(4 * cores), chunksize=1).get(timeout=timeout_s)
+        for kind, tasks in tasks_by_kind.items():
+            rs = pool.map_async(run_task, tasks, chunksize=1).get(timeout=timeout_s)
+            units = sum(r[1] for r in rs)
+            wall = max(r[3] for r in rs) - min(r[2] for r in rs)
+            out[kind] = (units / wall, units, wall)
     return out

@@ -86,7 +86,7 @@ SIGNATURES = {
     "pl_region_moments": ([_p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_linspace_edges": ([_p, _p, _i, _l, _p, _p], C.c_int),
     "pl_otsu_from_counts": ([_p, _p, _i, _l, _d, _p, _p, _p], C.c_int),
-    "pl_combine_slices": ([_p, _p, _i, _l, _l, _i, _i, _p], C.c_int),
+    "pl_combine_slices": ([_p, _p, _i, _l, _l, _i, _i, _l, _p], C.c_int),
     "pl_features_level": ([_p, _p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_features_sweep": ([_p, _l, _i, _i, _d, _d, _d, _d, _i, _p, _i, _p, _p, _p, _p, _p], C.c_int),
     "pl_fields_level": ([_p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),

@@ -336,12 +336,13 @@ __global__ void otsu_counts_kernel(const uint32_t* __restrict__ counts, const do
 // leaves the stack are marked invalid by the caller; here the window is clamped so every output is defined.
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
-combine_slices_kernel(const T* __restrict__ in, int64_t n, int64_t per_frame, int k, int mode, T* __restrict__ out_max,
-                      double* __restrict__ out_mean) {
+combine_slices_kernel(const T* __restrict__ in, int64_t n, int64_t per_frame, int k, int mode, int64_t per_volume,
+                      T* __restrict__ out_max, double* __restrict__ out_mean) {
   const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (g >= n * per_frame) return;
   const int64_t s = g / per_frame, p = g % per_frame;
-  const int64_t a = s - k < 0 ? 0 : s - k, b = s + k > n - 1 ? n - 1 : s + k;
+  const int64_t v0 = (s / per_volume) * per_volume, v1 = v0 + per_volume - 1;   // the slice's own volume
+  const int64_t a = s - k < v0 ? v0 : s - k, b = s + k > v1 ? v1 : s + k;
   if (mode == 0) {
     T m = in[a * per_frame + p];
     for (int64_t q = a + 1; q <= b; ++q) { const T v = in[q * per_frame + p]; m = v > m ? v : m; }
@@ -485,18 +486,20 @@ extern "C" int pl_otsu_from_counts(const uint32_t* d_counts, const double* d_edg
   return pl_check_launch("pl_otsu_from_counts");
 }
 
-/* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count]: mode 0 = np.max (d_out has
- * the input dtype), mode 1 = np.mean (d_out float64).  The window s-k .. s+k is clamped to the stack. */
+/* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count] of whole volumes of
+ * slices_per_volume slices: mode 0 = np.max (d_out has the input dtype), mode 1 = np.mean (d_out float64).  The window
+ * s-k .. s+k is clamped to the slice's own volume. */
 extern "C" int pl_combine_slices(const void* in, void* d_out, int dtype, int64_t n, int64_t count, int plusminus, int mode,
-                                 void* stream) {
+                                 int64_t slices_per_volume, void* stream) {
   PL_REQUIRE(in && d_out && in != d_out, "null or aliased pointers");
   PL_REQUIRE(n >= 0 && count > 0 && plusminus >= 0 && (mode == 0 || mode == 1), "bad arguments");
+  PL_REQUIRE(slices_per_volume > 0 && n % slices_per_volume == 0, "n must be a whole number of volumes");
   if (n == 0) return PL_OK;
   const int64_t total = n * count;
   PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "too large");
   PL_DISPATCH_DTYPE(dtype, T,
                     hipLaunchKernelGGL(combine_slices_kernel<T>, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0,
-                                       (hipStream_t)stream, (const T*)in, n, count, plusminus, mode, (T*)d_out,
-                                       (double*)d_out));
+                                       (hipStream_t)stream, (const T*)in, n, count, plusminus, mode, slices_per_volume,
+                                       (T*)d_out, (double*)d_out));
   return pl_check_launch("pl_combine_slices");
 }

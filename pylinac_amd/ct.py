@@ -244,20 +244,27 @@ CTP528_REGIONS = (
 
 def ctp528_profiles_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx, fit_zy, slices=None, roll_deg: float = 0.0,
                           radius2linepairs_mm: float = 47, scaling_factor: float = 1.0, roi_size_factor: float = 1.0,
-                          start_angle: float = np.pi, ccw: bool = True, slices_plusminus: int = 3):
-    """``CTP528CP504.circle_profile`` (pylinac/ct.py:1559-1580) for the chosen slices of a resident volume [S, H, W]:
-    ``combine_surrounding_slices(+-3, "max")`` (module attributes ``combine_method = "max"``, ``num_slices = 3``,
-    ct.py:1415-1416), a CollapsedCircleProfile of 20 radii within +-4 % of the line-pair radius at 2x sampling about the
-    phantom centre ``(fit_zx(z), fit_zy(z))``, ``filter(0.001, "gaussian")``, ``ground()``.
-    -> (float64 [M, L] profiles on the device, the slice indices)."""
+                          start_angle: float = np.pi, ccw: bool = True, slices_plusminus: int = 3,
+                          slices_per_volume: int | None = None):
+    """``CTP528CP504.circle_profile`` (pylinac/ct.py:1559-1580) for the chosen slices of resident volumes: a stack
+    [S, H, W] of one volume, or of several volumes of ``slices_per_volume`` slices each (``fit_zx`` / ``fit_zy`` are then
+    [V, 2] coefficient tables and ``slices`` indexes the stack).  ``combine_surrounding_slices(+-3, "max")`` (module
+    attributes ``combine_method = "max"``, ``num_slices = 3``, ct.py:1415-1416) inside each slice's own volume, a
+    CollapsedCircleProfile of 20 radii within +-4 % of the line-pair radius at 2x sampling about the phantom centre
+    ``(fit_zx(z), fit_zy(z))``, ``filter(0.001, "gaussian")``, ``ground()``.
+    -> (float64 [M, L] profiles on the device, the slice indices into the stack)."""
     from .array_utils import resolve_filter_size
 
     x = ops._frames(volume)
     n, h, w = x.shape
+    spv = int(slices_per_volume or n)
     idx = np.arange(n) if slices is None else np.asarray(slices, dtype=np.int64)
-    combined = ops.combine_slices(x, slices_plusminus, "max")
+    combined = ops.combine_slices(x, slices_plusminus, "max", spv)
     sub = combined if slices is None else combined[torch.from_numpy(idx).to(x.device)].contiguous()
-    cx, cy = np.polyval(fit_zx, idx), np.polyval(fit_zy, idx)                 # Slice.phan_center, ct.py:434-439
+    fzx, fzy = np.atleast_2d(np.asarray(fit_zx, dtype=np.float64)), np.atleast_2d(np.asarray(fit_zy, dtype=np.float64))
+    v, z = idx // spv, idx % spv                                               # volume and slice number inside it
+    cx = fzx[v, 0] * z + fzx[v, 1]                                             # np.poly1d(fit)(z), ct.py:434-439
+    cy = fzy[v, 0] * z + fzy[v, 1]
     radius = radius2linepairs_mm * scaling_factor / mm_per_pixel               # ct.py:1546-1549
     if (w < radius + cx).any() or (h < radius + cy).any():                     # CircleProfile._ensure_array_size
         raise ValueError("Array size not large enough to compute profile")
@@ -318,15 +325,25 @@ def ctp528_mtf_batch(profiles: torch.Tensor, regions=CTP528_REGIONS):
 
 def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=None, slices=None, roll_deg: float = 0.0,
                  **kw):
-    """Config #5's per-slice record for a resident CatPhan volume [S, H, W]: phantom ROI of every
-    slice -> the reference's axis fits -> circle profile and relative MTF of every requested slice.
-    -> dict(center float64 [M, 2] = (x, y) fitted phantom centre, profiles float64 [M, L] (device), rmtf float64 [M, 8],
-    nregions, maxs, mins, slices, roi = the per-slice phantom ROI table)."""
+    """Config #5's per-slice record for resident CatPhan volumes: one volume [S, H, W] or several
+    [V, S, H, W] in ONE batch (the phantom ROI of every slice, then per volume the reference's axis fits, then the circle
+    profile and relative MTF of every requested slice; volumes never mix: the +-3-slice window and the fits stay inside a
+    volume).  -> dict(center float64 [M, 2] = (x, y) fitted phantom centre, profiles float64 [M, L] (device),
+    rmtf float64 [M, 8], nregions, maxs, mins, slices (indices into the flattened stack), roi = the per-slice phantom
+    ROI table, fit_zx / fit_zy [V, 2])."""
+    x = volume if volume.dim() == 4 else volume[None]
+    nv, spv = x.shape[0], x.shape[1]
+    flat = x.reshape(nv * spv, x.shape[2], x.shape[3])
     roi = None
     if fit_zx is None or fit_zy is None:
-        fit_zx, fit_zy, roi = find_phantom_axis_volume(volume, mm_per_pixel)
-    prof, idx = ctp528_profiles_batch(volume, mm_per_pixel, fit_zx, fit_zy, slices=slices, roll_deg=roll_deg, **kw)
+        roi = phantom_roi_batch(flat, mm_per_pixel)
+        fits = [find_phantom_axis_volume(None, mm_per_pixel, roi=roi[v * spv:(v + 1) * spv]) for v in range(nv)]
+        fit_zx, fit_zy = np.stack([f[0] for f in fits]), np.stack([f[1] for f in fits])
+    prof, idx = ctp528_profiles_batch(flat, mm_per_pixel, fit_zx, fit_zy, slices=slices, roll_deg=roll_deg,
+                                      slices_per_volume=spv, **kw)
     out = ctp528_mtf_batch(prof)
-    out.update(center=np.stack([np.polyval(fit_zx, idx), np.polyval(fit_zy, idx)], axis=1), profiles=prof, slices=idx,
-               roi=roi, fit_zx=np.asarray(fit_zx), fit_zy=np.asarray(fit_zy))
+    fzx, fzy = np.atleast_2d(np.asarray(fit_zx, dtype=np.float64)), np.atleast_2d(np.asarray(fit_zy, dtype=np.float64))
+    v, z = idx // spv, idx % spv
+    out.update(center=np.stack([fzx[v, 0] * z + fzx[v, 1], fzy[v, 0] * z + fzy[v, 1]], axis=1), profiles=prof, slices=idx,
+               roi=roi, fit_zx=fzx if volume.dim() == 4 else fzx[0], fit_zy=fzy if volume.dim() == 4 else fzy[0])
     return out

@@ -45,3 +45,37 @@ def all_gather_records(local: torch.Tensor, n_total: int | None = None) -> torch
     if all(c == m for c in counts):
         return out
     return torch.cat([out[r * m : r * m + c] for r, c in enumerate(counts)], dim=0)
+
+
+# ---- sharded drivers: every analyzer's per-image record through the same single all-gather --------------------------
+def _rank_world() -> tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def sharded_records(n_total: int, local_fn) -> torch.Tensor:
+    """Split units ``0 .. n_total-1`` into contiguous blocks over the ranks, let ``local_fn(start, stop)`` produce this
+    rank's record tensor ``[stop - start, ...]`` (float64, on the device it computed on), and all-gather the blocks into
+    ``[n_total, ...]`` on every rank (rank order == unit order).  Units are EPID frames / WL frames / PF frames -- or
+    whole CatPhan volumes (``records_per_unit`` rows each, see ``sharded_volume_records``): SURVEY.md section 8e."""
+    rank, world = _rank_world()
+    a, b = shard_range(n_total, rank, world)
+    local = local_fn(a, b)
+    if local.shape[0] != b - a:
+        raise ValueError("local_fn must return one record per unit of its shard")
+    return all_gather_records(local.contiguous(), n_total)
+
+
+def sharded_volume_records(n_volumes: int, slices_per_volume: int, local_fn) -> torch.Tensor:
+    """CatPhan: split BY VOLUME so that the +-3-slice ``combine_surrounding_slices`` and the per-volume axis fits stay
+    local (pylinac/ct.py:3351-3386, 2398-2446).  ``local_fn(v0, v1)`` returns ``[(v1 - v0) * slices_per_volume, K]``
+    per-slice records of volumes v0 .. v1-1 -> ``[n_volumes * slices_per_volume, K]`` on every rank."""
+    rank, world = _rank_world()
+    a, b = shard_range(n_volumes, rank, world)
+    local = local_fn(a, b)
+    if local.shape[0] != (b - a) * slices_per_volume:
+        raise ValueError("local_fn must return slices_per_volume records per volume of its shard")
+    k = local.shape[1:]
+    out = all_gather_records(local.reshape(b - a, slices_per_volume, *k).contiguous(), n_volumes)
+    return out.reshape(n_volumes * slices_per_volume, *k)

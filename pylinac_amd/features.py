@@ -123,6 +123,7 @@ def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float,
     bottom = math.ceil(ey + win / 2)
     if vmin is None or vmax is None:
         vmin, vmax = ops.minmax(x)                      # frame-level ground()/normalize()
+    vmin, vmax = vmin.to(torch.float64).contiguous(), vmax.to(torch.float64).contiguous()
     crop = x.view(torch.int16)[:, top:bottom, left:right].contiguous().view(torch.uint16)
     q = ops.normalize(ops.ground(crop, mn=vmin), vmax - vmin)        # float64 (a - min) / (max - min)
     sample = ops.invert(q) if not low_density else q

@@ -156,6 +156,7 @@ def ground(frames: torch.Tensor, value: float = 0.0, mn=None) -> torch.Tensor:
     n = x.shape[0]
     if mn is None:
         mn, _ = minmax(x)
+    mn = _per_frame(mn, n, x.device)[0].expand(n).contiguous()     # raw pointer below: dense float64 [N]
     out = torch.empty_like(x)
     check(_lib.load().pl_ground(x.data_ptr(), out.data_ptr(), _dt(x), n, x[0].numel(), mn.data_ptr(),
                                 float(value), _stream()), "pl_ground")
@@ -683,15 +684,17 @@ def otsu_float_masked(frames: torch.Tensor, mask: torch.Tensor | None, scale: fl
     return thr, raw
 
 
-def combine_slices(stack: torch.Tensor, plusminus: int, mode: str = "max") -> torch.Tensor:
+def combine_slices(stack: torch.Tensor, plusminus: int, mode: str = "max", slices_per_volume: int | None = None) -> torch.Tensor:
     """``combine_surrounding_slices`` (pylinac/ct.py:3351-3386) for every slice of ``stack`` [S, H, W]: "max" keeps the
-    dtype, "mean" gives float64; the window is clamped to the stack."""
+    dtype, "mean" gives float64; the window is clamped to the slice's own volume (``slices_per_volume`` consecutive
+    slices; default: the whole stack is one volume)."""
     x = _frames(stack)
     if mode not in ("max", "mean"):
         raise ValueError("mode must be 'max' or 'mean'")
     out = torch.empty_like(x) if mode == "max" else torch.empty(x.shape, dtype=torch.float64, device=x.device)
     check(_lib.load().pl_combine_slices(x.data_ptr(), out.data_ptr(), _dt(x), x.shape[0], x[0].numel(), int(plusminus),
-                                        0 if mode == "max" else 1, _stream()), "pl_combine_slices")
+                                        0 if mode == "max" else 1, int(slices_per_volume or x.shape[0]), _stream()),
+          "pl_combine_slices")
     return out
 
 

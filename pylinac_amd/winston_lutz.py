@@ -44,9 +44,10 @@ class _FrameStats:
         ranks = np.concatenate([[0, self.cnt - 1], lo, hi])
         hist = ops.histogram16(x) if hist is None else hist
         st = ops.order_stats(x, ranks, hist=hist).cpu().numpy().astype(np.float64)
-        self.vmin, self.vmax = st[:, 0], st[:, 1]
+        # contiguous copies: these columns travel to the device through raw pointers
+        self.vmin, self.vmax = np.ascontiguousarray(st[:, 0]), np.ascontiguousarray(st[:, 1])
         k = len(self.qs)
-        self.lo, self.hi = st[:, 2:2 + k], st[:, 2 + k:2 + 2 * k]
+        self.lo, self.hi = np.ascontiguousarray(st[:, 2:2 + k]), np.ascontiguousarray(st[:, 2 + k:2 + 2 * k])
 
     def percentiles(self, qs, transform=None) -> np.ndarray:
         """np.percentile(f(frame), qs) for a monotone elementwise ``transform`` f applied to the order statistics

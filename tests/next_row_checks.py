@@ -193,6 +193,11 @@ def check_wl_analyze_batch(golden, dev, frames=None):
     assert np.array_equal(res["crop"] * 2, g["frames"].shape[1] - g["shape_after_clean"][sel][:, 0])
     assert np.array_equal(res["record"][:, :2], want[:, :2]), np.abs(res["record"][:, :2] - want[:, :2]).max()
     assert np.allclose(res["record"][:, 2:], want[:, 2:4], rtol=0, atol=1e-9), np.abs(res["record"][:, 2:] - want[:, 2:4]).max()
+    if frames is None:
+        # a batch that keeps every frame AND holds an inverted one (no edge-cleaned frame: the whole-batch branch)
+        sub = [0, 1, 6, 9]
+        r2 = wl.analyze_batch(torch.from_numpy(g["frames"][sub]).to(dev), 1 / float(g["pixel_mm"]), float(g["bb_mm"]))
+        assert np.array_equal(r2["record"], res["record"][sub]) and np.array_equal(r2["inverted"], g["inverted"][sub])
 
 
 def check_field_cax(dev):
@@ -263,6 +268,14 @@ def check_ctp528_batch(golden, dev, whole=True):
         full = ct.ctp528_batch(vol, mmpp)
         assert np.allclose(full["fit_zx"], g["fit_zx"], rtol=1e-9, atol=1e-9) and np.allclose(full["fit_zy"], g["fit_zy"], rtol=1e-9, atol=1e-9)
         assert np.allclose(full["rmtf"][sl], g["rmtf"], rtol=1e-7, atol=1e-7, equal_nan=True)
+        # several volumes in one batch never mix: [volume, volume shifted by 5 px] == the two single-volume results
+        v2 = torch.roll(vol, shifts=(5, -3), dims=(1, 2))
+        both = ct.ctp528_batch(torch.stack([vol, v2]), mmpp)
+        one = ct.ctp528_batch(v2, mmpp)
+        s_ = len(vol)
+        assert np.array_equal(both["rmtf"][:s_], full["rmtf"], equal_nan=True) and np.array_equal(both["rmtf"][s_:], one["rmtf"], equal_nan=True)
+        assert np.array_equal(both["fit_zx"][0], full["fit_zx"]) and np.array_equal(both["fit_zx"][1], one["fit_zx"])
+        assert torch.equal(both["profiles"][s_:], one["profiles"])
 
 
 def check_rectangle_roi(golden, dev):
