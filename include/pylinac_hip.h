@@ -86,6 +86,9 @@ int pl_normalize(const void* in, double* out, int dtype, int64_t n, int64_t coun
 /* out = -a + d_max[i] + d_min[i]       (same dtype)   array_utils.py:77 */
 int pl_invert(const void* in, void* out, int dtype, int64_t n, int64_t count, const double* d_min,
               const double* d_max, void* stream);
+/* np.invert(array) for integer frames (pylinac/core/array_utils.py:80-89): out = ~in in the array's own type
+ * (PL_U8 / PL_U16 / PL_I16 / PL_I32 / PL_I64; wider unsigned types travel as their same-width signed bits). */
+int pl_bit_invert(const void* in, void* out, int dtype, int64_t total, void* stream);
 
 /* out = a * factor   (same dtype; the multiply inside stretch(), array_utils.py:168) */
 int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,

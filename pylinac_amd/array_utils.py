@@ -34,6 +34,11 @@ def array_not_empty(array) -> None:
         raise ValueError("Array must not be empty")
 
 
+_NP_OF_TORCH = {torch.uint8: np.dtype(np.uint8), torch.uint16: np.dtype(np.uint16), torch.int16: np.dtype(np.int16),
+                torch.int32: np.dtype(np.int32), torch.int64: np.dtype(np.int64), torch.float32: np.dtype(np.float32),
+                torch.float64: np.dtype(np.float64)}
+
+
 class _Staged:
     """numpy <-> device staging: 1-D -> [1,1,L], 2-D -> [1,H,W]; tensors pass through."""
 
@@ -102,16 +107,30 @@ def normalize(array, value=None):
     return s.out(ops.normalize(s.t, value))
 
 
+def _refuse_inexact_64bit(array, what: str) -> None:
+    """min / max travel as float64 scalars: 64-bit integers beyond 2^53 would lose their low bits there."""
+    if not isinstance(array, torch.Tensor):
+        a = np.asarray(array)
+        if a.dtype in (np.int64, np.uint64) and a.size and (int(a.max()) > 2**53 or int(a.min()) < -(2**53)):
+            raise TypeError(f"{what}: 64-bit integer values beyond 2**53 are not supported exactly on this backend")
+
+
 def invert(array):
     """array_utils.py:74-77."""
+    _refuse_inexact_64bit(array, "invert")
     s = _Staged(array)
     return s.out(ops.invert(s.t))
 
 
 def ground(array, value: float = 0):
-    """array_utils.py:92-102."""
+    """array_utils.py:92-102: ``array - array.min() + value``; a non-integral ``value`` promotes an integer array to
+    float64 (numpy's promotion of ``int_array + python_float``)."""
+    _refuse_inexact_64bit(array, "ground")
     s = _Staged(array)
-    return s.out(ops.ground(s.t, value))
+    t = s.t
+    if not t.dtype.is_floating_point and float(value) != int(value):
+        t = ops.normalize(t, 1.0)                                        # exact conversion to float64
+    return s.out(ops.ground(t, value))
 
 
 def stretch(array, min: int = 0, max: int = 1):
@@ -119,7 +138,7 @@ def stretch(array, min: int = 0, max: int = 1):
     if max <= min:
         raise ValueError(f"Max must be larger than min. Passed max of {max} was <= {min}")
     a = array if isinstance(array, torch.Tensor) else np.asarray(array)
-    info_dtype = a.cpu().numpy().dtype if isinstance(a, torch.Tensor) else a.dtype
+    info_dtype = _NP_OF_TORCH[a.dtype] if isinstance(a, torch.Tensor) else a.dtype     # no device-to-host copy for a dtype
     info = np.iinfo(info_dtype) if info_dtype.kind in "iu" else np.finfo(info_dtype)
     if max > info.max:
         raise ValueError(f"Max of {max} was larger than the allowed datatype maximum of {info.max}")
@@ -133,23 +152,24 @@ def stretch(array, min: int = 0, max: int = 1):
 
 
 def bit_invert(array):
-    """array_utils.py:80-89: ``np.invert`` = the datatype-specific complement (0 -> 255 for uint8, -1 for int8)."""
+    """array_utils.py:80-89: ``np.invert`` = the datatype-specific complement (0 -> 255 for uint8, -1 for int8).  The
+    complement is taken bitwise on the device (``pl_bit_invert``); 64-bit types keep every bit (uint64 travels as the
+    int64 with the same bits, narrower unstaged types as int64 values whose low bits are the answer)."""
     a = np.asarray(array)
     array_not_empty(a)
     if a.dtype.kind not in "iub":
         raise ValueError(f"The datatype {a.dtype} could not be safely inverted. This usually means the array is a "
                          "float-like datatype. Cast to an integer-like datatype first.")
-    info = np.iinfo(a.dtype) if a.dtype.kind in "iu" else None
-    s = _Staged(a)                        # dtypes without a kernel (int8, uint32, ...) are staged as int64
-    n = s.t.shape[0]
-    lo = torch.full((n,), float(info.min if info else 0), dtype=torch.float64, device=s.t.device)
-    hi = torch.full((n,), float(info.max if info else 1), dtype=torch.float64, device=s.t.device)
-    out = torch.empty_like(s.t)           # ~a == -a + max + min of the dtype (max + min == -1 for signed types)
+    if a.dtype == np.bool_:
+        return np.logical_not(a)                     # np.invert on bool is logical not: no arithmetic to offload
     from ._lib import check, load
 
-    check(load().pl_invert(s.t.data_ptr(), out.data_ptr(), ops._dt(s.t), n, s.t[0].numel(), lo.data_ptr(),
-                           hi.data_ptr(), ops._stream()), "pl_invert")
-    return s.out(out).astype(a.dtype)
+    src = a.view(np.int64) if a.dtype == np.uint64 else a
+    s = _Staged(src)
+    out = torch.empty_like(s.t)
+    check(load().pl_bit_invert(s.t.data_ptr(), out.data_ptr(), ops._dt(s.t), s.t.numel(), ops._stream()), "pl_bit_invert")
+    res = s.out(out)
+    return res.view(np.uint64) if a.dtype == np.uint64 else res.astype(a.dtype)
 
 
 def convert_to_dtype(array, dtype):

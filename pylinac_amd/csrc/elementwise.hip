@@ -181,6 +181,16 @@ invert_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int6
   });
 }
 
+// np.invert on an integer array: the bitwise complement in the array's own type (array_utils.py:80-89).  No float64
+// scalars are involved, so 64-bit values keep every bit (round 1 routed this through -a + max + min with the type's
+// extrema as doubles: 2^63 is not an int64).
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+bit_invert_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < total) out[i] = (T)~in[i];
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 scale_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int64_t chunk, int bpf,
@@ -352,4 +362,22 @@ extern "C" int pl_as_binary(const void* in, uint8_t* out, int dtype, int64_t n, 
                        out, count, p.chunk, p.bpf, d_thr, thr_stride);
   });
   return pl_check_launch("pl_as_binary");
+}
+
+/* np.invert(array) for integer frames (pylinac/core/array_utils.py:80-89): out = ~in in the array's own type. */
+extern "C" int pl_bit_invert(const void* in, void* out, int dtype, int64_t total, void* stream) {
+  PL_REQUIRE(in && out, "null pointer");
+  PL_REQUIRE(total >= 0 && pl_cdiv(total, kThreads) <= 0x7fffffffLL, "bad size");
+  if (total == 0) return PL_OK;
+  const unsigned blocks = (unsigned)pl_cdiv(total, kThreads);
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case PL_U8: hipLaunchKernelGGL(bit_invert_kernel<unsigned char>, dim3(blocks), dim3(kThreads), 0, st, (const unsigned char*)in, (unsigned char*)out, total); break;
+    case PL_U16: hipLaunchKernelGGL(bit_invert_kernel<unsigned short>, dim3(blocks), dim3(kThreads), 0, st, (const unsigned short*)in, (unsigned short*)out, total); break;
+    case PL_I16: hipLaunchKernelGGL(bit_invert_kernel<short>, dim3(blocks), dim3(kThreads), 0, st, (const short*)in, (short*)out, total); break;
+    case PL_I32: hipLaunchKernelGGL(bit_invert_kernel<int>, dim3(blocks), dim3(kThreads), 0, st, (const int*)in, (int*)out, total); break;
+    case PL_I64: hipLaunchKernelGGL(bit_invert_kernel<long long>, dim3(blocks), dim3(kThreads), 0, st, (const long long*)in, (long long*)out, total); break;
+    default: pl_set_error("pl_bit_invert: integer dtypes only"); return PL_ERR_UNSUPPORTED;
+  }
+  return pl_check_launch("pl_bit_invert");
 }

@@ -41,6 +41,16 @@ def rescale_dicom_values(frames: torch.Tensor, rescale_slope=None, rescale_inter
     return x
 
 
+def _uniquify(seq, value: str) -> str:
+    """``pylinac.core.utilities.uniquify`` (utilities.py:368-377): ``value``, else ``value-1``, ``value-2`` ..."""
+    if value not in seq:
+        return value
+    n = 1
+    while f"{value}-{n}" in seq:
+        n += 1
+    return f"{value}-{n}"
+
+
 class _MutatorMixin:
     """The reference's in-place API; subclasses provide ``array`` (numpy or device tensor)."""
 
@@ -168,6 +178,51 @@ class ArrayImage(_MutatorMixin):
 
     def roll(self, direction: str = "x", amount: int = 1) -> None:
         self.array = np.roll(self.array, amount, axis=1 if direction == "x" else 0)
+
+    @property
+    def center(self):
+        """image.py:526-533: the centre of the array as a point (x, y); even lengths give the mid-point between the two
+        central indices."""
+        from .profile import Point
+
+        return Point(x=(self.shape[1] / 2) - 0.5, y=(self.shape[0] / 2) - 0.5)
+
+    def as_type(self, dtype) -> np.ndarray:
+        return self.array.astype(dtype)
+
+    def bit_invert(self) -> None:
+        """image.py:759-761."""
+        self.array = au.bit_invert(self.array)
+
+    def check_inversion(self, box_size: int = 20, position=(0.0, 0.0)) -> None:
+        """image.py:868-897: invert when the mean of the four corner boxes exceeds the mean of the image (box statistics
+        and the frame sum on the device, ``decisions.corners_inverted``)."""
+        from . import decisions
+
+        s = au._Staged(self.array)
+        if bool(decisions.corners_inverted(s.t, box_size=box_size, position=position)[0]):
+            self.invert()
+
+    def compute(self, metrics):
+        """image.py:1022-1054, the reference's one extension point: ``metric.inject_image(self)``,
+        ``metric.context_calculate()`` (which hashes ``self.array.tobytes()`` before and after ``calculate()`` and raises
+        RuntimeError when a metric modified the image, metrics/image.py:61-71), results stored under a unique name in
+        ``metric_values`` and the metric objects in ``metrics``.  Accepts any object with the ``MetricBase`` protocol
+        (``inject_image``, ``context_calculate``, ``name``) -- the reference's own metric classes included."""
+        metric_data = {}
+        if not isinstance(metrics, (list, tuple)):
+            metrics = [metrics]
+        key = None
+        for metric in metrics:
+            metric.inject_image(self)
+            value = metric.context_calculate()
+            self.metrics.append(metric)
+            key = _uniquify(list(metric_data.keys()) + list(self.metric_values.keys()), metric.name)
+            metric_data[key] = value
+        self.metric_values |= metric_data
+        if len(metrics) == 1:
+            return metric_data[key]
+        return metric_data
 
     def check_inversion_by_histogram(self, percentiles=(5, 50, 95)) -> bool:
         """image.py:899-926: invert when |p_mid - p_low| > |p_mid - p_high|.  For 16-bit frames the

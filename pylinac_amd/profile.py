@@ -74,7 +74,16 @@ def find_peaks(
     Known, documented divergence: where several peaks tie EXACTLY on the sort key (or on height
     inside the ``distance`` filter) the reference's order comes from ``np.argsort``'s default
     introsort and is implementation-defined; this backend uses the stable order."""
+    if max_number is not None and max_number < 0:
+        # the reference slices `[::-1][:max_number]`: a negative count would DROP that many of the smallest peaks
+        raise ValueError("max_number must be None or >= 0")
     x = _to_device_profile(values)
+    if max_number == 0:                                  # `[::-1][:0]`: no peaks (profile.py:2616-2623)
+        res = ops.find_peaks_batch(x, threshold=threshold, peak_separation=peak_separation, max_number=None,
+                                   fwxm_height=fwxm_height, min_width=min_width, search_region=search_region,
+                                   peak_sort=peak_sort, required_prominence=required_prominence)
+        idx, props = res.to_host(0)
+        return idx[:0], {k: v[:0] for k, v in props.items()}
     res = ops.find_peaks_batch(
         x, threshold=threshold, peak_separation=peak_separation, max_number=max_number,
         fwxm_height=fwxm_height, min_width=min_width, search_region=search_region,

@@ -767,10 +767,37 @@ def check_bit_invert_and_convert_to_dtype():
     c = au.convert_to_dtype(np.array([0, 255.2], dtype=float), dtype=np.uint16)
     assert np.array_equal(c, [0, 65535]) and c.dtype == np.uint16
     rng = np.random.default_rng(2)
-    for dt in (np.uint8, np.uint16, np.int16, np.int32):
+    for dt in (np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.int64, np.uint64):
         info = np.iinfo(dt)
-        a = rng.integers(info.min, info.max, (13, 17)).astype(dt)
-        assert np.array_equal(au.bit_invert(a), np.invert(a)), dt
+        a = rng.integers(info.min, info.max, (13, 17), dtype=dt, endpoint=True)
+        a.ravel()[:4] = [info.min, info.max, info.max - 1, info.min + 1]      # the extremes (ADVICE: 64-bit, 2^63)
+        got = au.bit_invert(a)
+        assert got.dtype == a.dtype and np.array_equal(got, np.invert(a)), dt
+    assert np.array_equal(au.bit_invert(np.array([True, False])), [False, True])
+    # 64-bit invert()/ground(): values beyond 2^53 cannot pass through the float64 extrema -> refused, not wrong
+    big = np.array([2**60, 5, 7], dtype=np.int64)
+    for fn in (au.invert, au.ground):
+        try:
+            fn(big)
+        except TypeError:
+            pass
+        else:
+            raise AssertionError("values beyond 2**53 must be refused")
+    assert np.array_equal(au.invert(np.array([1, 5, 9], dtype=np.int64)), [9, 5, 1])
+    # ground() with a non-integral value promotes an integer array to float64, like numpy
+    g16 = au.ground(np.array([3, 5, 9], dtype=np.uint16), 0.5)
+    assert g16.dtype == np.float64 and np.array_equal(g16, [0.5, 2.5, 6.5])
+    assert au.ground(np.array([3, 5, 9], dtype=np.uint16), 2).dtype == np.uint16
+    # find_peaks(max_number=0) is the reference's `[::-1][:0]`: nothing; a negative count is refused
+    from pylinac_amd import profile as pr
+    idx, props = pr.find_peaks(np.array([0, 1, 0, 2, 0, 3, 0], dtype=float), max_number=0)
+    assert len(idx) == 0 and all(len(v) == 0 for v in props.values())
+    try:
+        pr.find_peaks(np.array([0, 1, 0], dtype=float), max_number=-1)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("negative max_number must raise")
     a16 = rng.integers(0, 65535, (9, 21)).astype(np.uint16)
     for new in (np.uint8, np.int16, np.uint16):
         ninfo = np.iinfo(new)

@@ -1,0 +1,132 @@
+"""CPU (build container only: needs /root/reference): the REFERENCE'S OWN analyzer code executed on the shim.
+
+INTEGRATION.md's claim is that pylinac's analyzers keep working when the array-level primitives they call are rebound to
+``pylinac_amd``.  Here the reference is imported read-only through ``oracle/ref_loader.py`` and
+
+  * ``PicketFence.analyze()`` (pylinac/picketfence.py:636-845) runs UNCHANGED with its image an ``pylinac_amd`` ArrayImage
+    and its ``MultiProfile`` / ``FWXMProfilePhysical`` rebound to the shim's classes,
+  * ``WLBaseImage._clean_edges`` / ``find_field_centroids`` (pylinac/winston_lutz.py:764-780, 1109-1133) run UNCHANGED as
+    methods of a shim image,
+  * ``BaseImage.compute()`` semantics hold for the reference's own ``MetricBase`` subclasses on a shim image,
+
+with the kernels of the emulated library underneath (tests/emu_backend.py).  Results must equal the unpatched run.
+"""
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import ref_loader  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not ref_loader.reference_available(), reason="needs /root/reference (build container)")
+
+
+def _pf_frame(h, w, pixel, seed):
+    from pylinac_amd.synthetic import pf_frames
+
+    return pf_frames(1, h, w, seed0=seed, pixel_mm=pixel, pickets=7, picket_spacing_mm=30.0, gap_mm=3.0,
+                     blur_mm=2.0)[0].numpy()
+
+
+def _run_reference_pf(pfm, image_cls, raw, dpmm):
+    class PFImg(image_cls):                  # what PFDicomImage adds to the array image (picketfence.py:204-260)
+        _central_axis = None
+
+        def adjust_for_sag(self, sag, orientation):
+            pass
+
+    im = PFImg(raw.copy(), dpi=dpmm * 25.4, sid=1000)
+    im.crop(pixels=int(round(3 * im.dpmm)))             # picketfence.py:214-215
+    im.ground()
+    im.normalize()                                       # picketfence.py:322-323
+    pf = pfm.PicketFence(None)                           # skips image loading (picketfence.py:315)
+    pf.image = im
+    pf.analyze(orientation="Up-Down")                    # the reference's own analyze()
+    meas = np.array([[m.leaf_num, m.picket_num, m.position[0], m._approximate_idx] for m in pf.mlc_meas])
+    return meas, float(pf.max_error), float(pf.abs_median_error)
+
+
+def test_reference_picketfence_analyze_runs_unchanged_on_the_shim():
+    from emu_backend import emulated_device
+
+    pfm, image = ref_loader.ref("picketfence"), ref_loader.ref("core.image")
+    raw = _pf_frame(400, 520, 0.78125, 2000)
+    want = _run_reference_pf(pfm, image.ArrayImage, raw, 1 / 0.78125)
+    with emulated_device():
+        from pylinac_amd import image as shim_image, profile as shim_profile
+
+        with mock.patch.object(pfm, "MultiProfile", shim_profile.MultiProfile), \
+                mock.patch.object(pfm, "FWXMProfilePhysical", shim_profile.FWXMProfilePhysical):
+            got = _run_reference_pf(pfm, shim_image.ArrayImage, raw, 1 / 0.78125)
+    assert want[0].shape == got[0].shape and want[0].shape[0] > 50
+    assert np.array_equal(want[0][:, :2], got[0][:, :2]) and np.array_equal(want[0][:, 3], got[0][:, 3])
+    assert np.allclose(want[0][:, 2], got[0][:, 2], rtol=0, atol=1e-9)
+    assert abs(want[1] - got[1]) < 1e-9 and abs(want[2] - got[2]) < 1e-9
+
+
+def test_reference_winston_lutz_methods_run_unchanged_on_a_shim_image():
+    from emu_backend import emulated_device
+
+    wl, image = ref_loader.ref("winston_lutz"), ref_loader.ref("core.image")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "wl.npz"))
+
+    def run(image_cls, frame):
+        class W(image_cls):
+            pass
+
+        W._clean_edges = wl.WLBaseImage._clean_edges                        # the reference's own functions
+        W.find_field_centroids = wl.WLBaseImage.find_field_centroids
+        img = W(frame.copy(), dpi=25.4 / 0.336)
+        inverted = img.check_inversion_by_histogram(percentiles=(0.01, 50, 99.99))
+        img._clean_edges()
+        img.ground()
+        img.normalize()
+        p = img.find_field_centroids(is_open_field=False)[0]
+        return inverted, img.array.shape, (p.x, p.y)
+
+    for k in (0, 6, 7):          # plain, inverted polarity, edges cropped twice
+        want = run(image.ArrayImage, g["frames"][k])
+        with emulated_device():
+            from pylinac_amd import image as shim_image
+
+            got = run(shim_image.ArrayImage, g["frames"][k])
+        assert want == got, k
+        assert want[2] == tuple(g["record"][k, :2]), k      # and both equal the golden of the full reference run
+
+
+def test_compute_contract_with_the_references_own_metric_base():
+    from emu_backend import emulated_device
+
+    mi = ref_loader.ref("metrics.image")
+
+    class MeanOfCentralBox(mi.MetricBase):
+        name = "central mean"
+
+        def calculate(self):
+            a = self.image.array
+            h, w = a.shape
+            return float(a[h // 2 - 2:h // 2 + 2, w // 2 - 2:w // 2 + 2].mean())
+
+    class Vandal(mi.MetricBase):
+        name = "vandal"
+
+        def calculate(self):
+            self.image.array[0, 0] += 1
+            return 0
+
+    with emulated_device():
+        from pylinac_amd import image as shim_image
+
+        img = shim_image.ArrayImage(np.arange(100, dtype=np.float64).reshape(10, 10))
+        assert img.compute(MeanOfCentralBox()) == np.arange(100.0).reshape(10, 10)[3:7, 3:7].mean()
+        both = img.compute([MeanOfCentralBox(), MeanOfCentralBox()])
+        assert list(both) == ["central mean-1", "central mean-2"] and len(img.metrics) == 3
+        assert set(img.metric_values) == {"central mean", "central mean-1", "central mean-2"}
+        with pytest.raises(RuntimeError, match="modified an image"):
+            img.compute(Vandal())
+        assert img.center.x == 4.5 and img.center.y == 4.5
