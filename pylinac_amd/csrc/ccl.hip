@@ -374,6 +374,41 @@ cax_reduce_kernel(const T* __restrict__ in, int h, int w, int bpf, const double*
   const bool use_int = sizeof(T) == 2 && d > 0.0;
   int ithr = 0;
   if constexpr (sizeof(T) == 2) { if (use_int) ithr = cax_int_threshold<T>(s, d, t); }
+  if (sizeof(T) == 2 && use_int && (w & 7) == 0 && (reinterpret_cast<uintptr_t>(f) & 15) == 0) {
+    // eight pixels of one row per 16-byte load; the row / column of the vector is divided out once, not per pixel
+    const uint4* vf = reinterpret_cast<const uint4*>(f);
+    for (int64_t v = lo / 8 + threadIdx.x; v < hi / 8; v += kThreads) {
+      const uint4 q = vf[v];
+      const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+      const int64_t i = v * 8;
+      const unsigned r = (unsigned)(i / w), c0 = (unsigned)(i % w);
+      unsigned m = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int a0 = (int)(T)(wd[k] & 0xffffu), a1 = (int)(T)(wd[k] >> 16);
+        m |= (a0 >= ithr ? 1u : 0u) << (2 * k);
+        m |= (a1 >= ithr ? 1u : 0u) << (2 * k + 1);
+      }
+      if (m) {
+        const unsigned n = (unsigned)__popc(m);
+        unsigned csum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) csum += ((m >> k) & 1u) * (c0 + (unsigned)k);
+        cnt += n; sr += (unsigned long long)r * n; sc += csum;
+        rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax;
+        const unsigned cl = c0 + (unsigned)__builtin_ctz(m), ch = c0 + 31u - (unsigned)__builtin_clz(m);
+        cmin = cl < cmin ? cl : cmin; cmax = ch > cmax ? ch : cmax;
+      }
+    }
+    for (int64_t i = (hi / 8) * 8 + threadIdx.x; i < hi; i += kThreads) {   // tail of a chunk that is not a multiple of 8
+      if ((int)f[i] >= ithr) {
+        const unsigned r = (unsigned)(i / w), c = (unsigned)(i % w);
+        ++cnt; sr += r; sc += c;
+        rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax;
+        cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
+      }
+    }
+  } else
   for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
     bool fg;
     if (use_int) {

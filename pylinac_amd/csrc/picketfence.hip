@@ -144,33 +144,56 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   vmax = pl_wave_reduce(vmax, [](int a, int b) { return a > b ? a : b; });
   const bool above = (((double)vmax - s) / d) > height_threshold * pk_val[frame * cap + pi];
 
-  // np.std(window, axis=1): lane r handles row r serially with numpy's summation order
-  for (int r = lane; r < nrows; r += PL_WAVE) {
-    const double mean = pairwise_sum_block(ncols, [&](int c) { return q(r, c); }) / (double)ncols;
-    const double ss = pairwise_sum_block(ncols, [&](int c) { const double x = q(r, c) - mean; return x * x; });
-    s_std[wv][r] = sqrt(ss / (double)ncols);
+  // np.std(window, axis=1) with numpy's pairwise summation order (one block of ncols <= 128 values: eight running sums
+  // r[j] over elements j, j+8, ..., combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 tail).  EIGHT lanes
+  // share a row: lane j of the group owns chain r[j], the tree is three xor-shuffles (float addition commutes, so both
+  // partners hold the same sum), one lane adds the tail.  Same operations in the same order as one lane doing it all,
+  // at an eighth of the float64 divisions per lane (round 1: one lane per row, 12 of 64 lanes busy).
+  {
+    const int j = lane & 7, gr = lane >> 3;                 // chain index, row inside the pass of 8 rows
+    const int nmain = ncols - (ncols % 8);
+    for (int row0 = 0; row0 < nrows; row0 += 8) {           // wave-uniform trip count
+      const int r = row0 + gr;
+      const bool act = r < nrows;
+      const int rr = act ? r : 0;
+      auto block_sum = [&](auto at) -> double {            // every lane of the wave executes the shuffles
+        double res;
+        if (ncols < 8) {
+          res = 0.0;
+          if (j == 0) for (int i = 0; i < ncols; ++i) res = res + at(i);
+        } else {
+          double acc = at(j);
+          for (int i = 8; i < nmain; i += 8) acc = acc + at(i + j);
+          acc = acc + __shfl_xor(acc, 1, 64);
+          acc = acc + __shfl_xor(acc, 2, 64);
+          acc = acc + __shfl_xor(acc, 4, 64);
+          res = acc;
+          if (j == 0) for (int i = nmain; i < ncols; ++i) res = res + at(i);
+        }
+        return __shfl(res, lane & ~7, 64);                  // the group's lane 0 holds the total
+      };
+      const double mean = block_sum([&](int c) { return q(rr, c); }) / (double)ncols;
+      const double ss = block_sum([&](int c) { const double x = q(rr, c) - mean; return x * x; });
+      if (act && j == 0) s_std[wv][r] = sqrt(ss / (double)ncols);
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  // max(std) < edge_threshold * np.median(std): evaluated redundantly by every lane (nrows <= 64)
-  double smax = s_std[wv][0];
-  for (int r = 1; r < nrows; ++r) smax = s_std[wv][r] > smax ? s_std[wv][r] : smax;
-  double med;
+  // max(std) < edge_threshold * np.median(std): lane a ranks std[a] (nrows <= 48 <= 64 lanes)
+  double smax, med;
   {
-    // rank selection without a private array: the k-th smallest is the element with exactly k
-    // smaller-or-(equal and earlier) elements
-    const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
-    double v_lo = 0.0, v_hi = 0.0;
-    for (int a = 0; a < nrows; ++a) {
-      const double va = s_std[wv][a];
-      int rank = 0;
-      for (int b = 0; b < nrows; ++b) {
-        const double vb = s_std[wv][b];
-        rank += (vb < va || (vb == va && b < a)) ? 1 : 0;
-      }
-      if (rank == k_lo) v_lo = va;
-      if (rank == k_hi) v_hi = va;
+    const bool act = lane < nrows;
+    const double va = act ? s_std[wv][lane] : 0.0;
+    smax = pl_wave_reduce(act ? va : -1.0, [](double x, double y) { return x > y ? x : y; });   // std >= 0
+    int rank = 0;
+    for (int b2 = 0; b2 < nrows; ++b2) {
+      const double vb = s_std[wv][b2];
+      rank += (vb < va || (vb == va && b2 < lane)) ? 1 : 0;
     }
+    const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
+    const unsigned long long m_lo = __ballot(act && rank == k_lo), m_hi = __ballot(act && rank == k_hi);
+    const double v_lo = __shfl(va, __builtin_ctzll(m_lo | (1ull << 63)), 64);
+    const double v_hi = __shfl(va, __builtin_ctzll(m_hi | (1ull << 63)), 64);
     med = (nrows & 1) ? v_hi : (v_lo + v_hi) / 2.0;
   }
   const bool not_edge = smax < edge_threshold * med;

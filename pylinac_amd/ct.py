@@ -22,6 +22,8 @@ against scikit-image on the golden slices.
 """
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -289,34 +291,43 @@ def ctp528_mtf_batch(profiles: torch.Tensor, regions=CTP528_REGIONS):
     p = profiles.contiguous()
     m, length = p.shape
     neg = ops.scale(p[:, None, :].contiguous(), -1.0)[:, 0, :].contiguous()
+    # every search is launched before anything returns to the host: the valley window of a profile is the span of ITS
+    # peaks, taken on the device from the peak indices (rows whose peak count is wrong are discarded below, whatever
+    # window their unset indices produced)
+    launched = []
+    for start, end, npk, nval, spacing, _ in regions:
+        pk = ops.find_peaks_batch(p, cap=npk, threshold=0.3, peak_separation=spacing, max_number=npk,
+                                  search_region=(start, end))
+        idx = pk.idx[:, :npk]
+        reg = torch.stack([idx.amin(dim=1), idx.amax(dim=1)], dim=1).to(torch.int32)
+        vl = ops.find_peaks_batch(neg, cap=max(nval, 1), regions=reg, threshold=0.3, peak_separation=spacing,
+                                  max_number=nval)
+        launched.append((pk.count, pk.props[:, 0, :], vl.count, vl.idx))
+    cnts = torch.stack([t[0] for t in launched], dim=1).cpu().numpy()                     # [M, R]
+    vcnts = torch.stack([t[2] for t in launched], dim=1).cpu().numpy()
+    heights = [t[1].cpu().numpy() for t in launched]                                      # peak_heights, [M, npk] each
+    vidxs = [t[3].cpu().numpy() for t in launched]
+    pv = p.cpu().numpy()                                                                  # values[valley_idxs]
     maxs = np.full((m, len(regions)), np.nan)
     mins = np.full((m, len(regions)), np.nan)
     alive = np.ones(m, dtype=bool)
     nreg = np.zeros(m, dtype=np.int64)
+    rows = np.arange(m)
     for k, (start, end, npk, nval, spacing, _) in enumerate(regions):
+        alive = alive & (cnts[:, k] == npk)                              # the reference's `break` at the first miss
         if not alive.any():
             break
-        pk = ops.find_peaks_batch(p, cap=npk, threshold=0.3, peak_separation=spacing, max_number=npk,
-                                  search_region=(start, end))
-        cnt = pk.count.cpu().numpy()
-        idx = pk.idx.cpu().numpy()
-        heights = pk.props[:, 0, :].cpu().numpy()                      # peak_heights
-        ok = alive & (cnt == npk)
-        alive = ok
-        if not ok.any():
-            break
-        lo = np.where(ok, idx[:, :npk].min(axis=1), 0)
-        hi = np.where(ok, idx[:, :npk].max(axis=1), 0)
-        reg = torch.from_numpy(np.stack([lo, hi], axis=1).astype(np.int32))
-        vl = ops.find_peaks_batch(neg, cap=max(nval, 1), regions=reg, threshold=0.3, peak_separation=spacing,
-                                  max_number=nval)
-        vcnt = vl.count.cpu().numpy()
-        vidx = vl.idx.cpu().numpy()
-        pv = p.cpu().numpy() if k == 0 else pv                          # values[valley_idxs]: the profile itself
-        for i in np.nonzero(ok)[0]:
-            maxs[i, k] = heights[i, :npk].mean()
-            mins[i, k] = pv[i, vidx[i, : vcnt[i]]].mean() if vcnt[i] else np.nan      # np.mean of an empty selection
-        nreg[ok] = k + 1
+        maxs[alive, k] = heights[k][alive, :npk].mean(axis=1)
+        vi, vc = vidxs[k], vcnts[:, k]
+        vals = pv[rows[:, None], np.clip(vi, 0, length - 1)]
+        vals = np.where(np.arange(vi.shape[1])[None, :] < vc[:, None], vals, np.nan)
+        with np.errstate(invalid="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            vmean = np.nansum(vals, axis=1) / np.maximum(vc, 1)
+        vmean = np.where(vc > 0, vmean, np.nan)                        # np.mean of an empty selection
+        # np.mean sums sequentially for short arrays: nansum over <= 4 entries is the same left-to-right sum
+        mins[alive, k] = vmean[alive]
+        nreg[alive] = k + 1
     with np.errstate(invalid="ignore", divide="ignore"):
         mtf = (maxs - mins) / (maxs + mins)                             # michelson: (max - min) / (max + min)
         rmtf = mtf / mtf[:, :1]
