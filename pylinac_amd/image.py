@@ -26,8 +26,10 @@ def rescale_dicom_values(frames: torch.Tensor, rescale_slope=None, rescale_inter
 
     ``pixels.apply_rescale`` is pydicom's (``pydicom>=2.0,<3`` in the reference's pyproject; absent from this
     container): when both tags exist, ``arr.astype(float64) * RescaleSlope`` then ``+= RescaleIntercept``; otherwise
-    the array is returned as stored.  **Parity unpinned**: pydicom cannot be run here, so this restates its published
-    behaviour; the inversion that follows is the reference's own expression ``max - a + min`` per frame."""
+    the array is returned as stored.  pydicom cannot be run here; the pin is the set of identities the reference's own
+    tests state for this function (tests_basic/core/test_image.py:131-200: raw / no-tag pass-through, ``RescaleSlope *
+    pixel_array + RescaleIntercept``, the three inversion cases), checked in tests/next_row_checks.py; the inversion that
+    follows is the reference's own expression ``max - a + min`` per frame."""
     x = ops._frames(frames)
     if raw_pixels:
         return x

@@ -507,8 +507,9 @@ def check_canny_integer_images(golden, dev):
 
 
 def check_rescale_dicom_values(dev):
-    """image.rescale_dicom_values against the oracle restatement (PARITY UNPINNED: pydicom's apply_rescale cannot be run
-    here): uint16 / int16 stored values, CT-like and EPID-like tags, forced / tag-driven / suppressed inversion."""
+    """image.rescale_dicom_values against the oracle restatement (pydicom's apply_rescale cannot be run here) and, as the
+    pin, against the identities the reference's own tests state for it: uint16 / int16 stored values, CT-like and EPID-like
+    tags, forced / tag-driven / suppressed inversion."""
     from oracle import pylinac_oracle as o
     from pylinac_amd import image
 
@@ -521,6 +522,28 @@ def check_rescale_dicom_values(dev):
             got = image.rescale_dicom_values(torch.from_numpy(arr).to(dev), **kw).cpu().numpy()
             want = np.stack([o.rescale_dicom_values(f, **kw) for f in arr])
             assert got.dtype == want.dtype and np.array_equal(got, want), (arr.dtype, kw)
+    # ---- the identities the reference's OWN tests state (tests_basic/core/test_image.py:131-200), as known answers:
+    # raw_pixels=True and "no tags" leave the array alone (:131-147); with both tags the result is
+    # RescaleSlope * pixel_array + RescaleIntercept (:160-170); with PixelIntensityRelationshipSign = +1 the automatic
+    # choice equals the forced NON-inversion and differs from the forced inversion, with -1 it equals the forced
+    # inversion (:172-200); the inversion is `max - a + min` (image.py:384-388).
+    a = rng.integers(0, 4096, (1, 9, 11)).astype(np.uint16)
+    t = torch.from_numpy(a).to(dev)
+    same = lambda x, y: np.array_equal(x.cpu().numpy(), y)
+    assert same(image.rescale_dicom_values(t, rescale_slope=2.0, rescale_intercept=5.0, raw_pixels=True), a)
+    assert same(image.rescale_dicom_values(t), a)
+    assert same(image.rescale_dicom_values(t, rescale_slope=1.5, rescale_intercept=-1000.0), 1.5 * a + -1000.0)
+    ones = np.ones((1, 3, 3)); ones[0, 0, 0] = 100                       # the reference's own 3x3 case
+    to = torch.from_numpy(ones).to(dev)
+    for sign, auto_equals_forced_inversion in ((1, False), (-1, True)):
+        kw = dict(rescale_slope=1, rescale_intercept=-1000, pixel_intensity_relationship_sign=sign)
+        forced = image.rescale_dicom_values(to, invert_pixels=True, **kw).cpu().numpy()
+        plain = image.rescale_dicom_values(to, invert_pixels=False, **kw).cpu().numpy()
+        auto = image.rescale_dicom_values(to, invert_pixels=None, **kw).cpu().numpy()
+        scaled = 1 * ones + -1000
+        assert np.array_equal(plain, scaled) and np.array_equal(forced, scaled.max() - scaled + scaled.min())
+        assert np.array_equal(auto, forced if auto_equals_forced_inversion else plain)
+        assert not np.array_equal(forced, plain)
 
 
 def check_thickness_roi(golden, dev):

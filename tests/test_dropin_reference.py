@@ -130,3 +130,40 @@ def test_compute_contract_with_the_references_own_metric_base():
         with pytest.raises(RuntimeError, match="modified an image"):
             img.compute(Vandal())
         assert img.center.x == 4.5 and img.center.y == 4.5
+
+
+def test_find_peaks_exact_ties_vs_the_reference():
+    """Where peaks tie EXACTLY on the sort key the reference's top-``max_number`` choice comes from ``np.argsort``'s
+    default sort (pylinac/core/profile.py:2616-2618) -- on this numpy an AVX-dispatched, unstable sort even for a handful
+    of elements -- while this backend keeps the stable order.  Enumerated here: profiles whose peaks tie on height and
+    prominence, 2 .. 40 peaks, every cut.  The divergence is bounded: both keep the same multiset of key values, both
+    keep EVERY peak whose key is strictly above the value at the cut, and only members of the one group tied at the cut
+    may be exchanged.  Without ties at the cut the results are identical."""
+    from emu_backend import emulated_device
+
+    prof = ref_loader.ref("core.profile")
+    rng = np.random.default_rng(8)
+    differing = total = 0
+    for npk in (2, 3, 5, 8, 12, 16, 17, 24, 40):
+        heights = rng.choice([1.0, 2.0, 3.0], size=npk)            # many exact ties
+        x = np.zeros(4 * npk + 1)
+        x[2::4][:npk] = heights
+        for key in ("prominences", "peak_heights"):
+            for k in sorted({1, 2, npk // 2, npk - 1, npk}):
+                if k < 1:
+                    continue
+                ri, rp = prof.find_peaks(x, max_number=k, peak_sort=key)
+                with emulated_device():
+                    from pylinac_amd import profile as shim
+
+                    gi, gp = shim.find_peaks(x, max_number=k, peak_sort=key)
+                total += 1
+                assert len(gi) == len(ri) == k
+                assert np.array_equal(np.sort(rp[key]), np.sort(gp[key])), (npk, key, k)   # same key values kept
+                cut = np.sort(rp[key])[0]
+                assert set(ri[rp[key] > cut]) == set(gi[gp[key] > cut]), (npk, key, k)     # everything above the cut
+                n_tied_at_cut = int(np.sum(heights == cut))
+                if np.sum(rp[key] == cut) == n_tied_at_cut:          # the whole tied group fits: no choice to make
+                    assert np.array_equal(ri, gi), (npk, key, k)
+                differing += int(not np.array_equal(ri, gi))
+    print(f"exact-tie cases where the stable order departs from numpy's argsort: {differing} of {total}")
