@@ -90,6 +90,13 @@ int pl_invert(const void* in, void* out, int dtype, int64_t n, int64_t count, co
  * (PL_U8 / PL_U16 / PL_I16 / PL_I32 / PL_I64; wider unsigned types travel as their same-width signed bits). */
 int pl_bit_invert(const void* in, void* out, int dtype, int64_t total, void* stream);
 
+/* BaseImage.rotate (pylinac/core/image.py:780-783) = skimage.transform.rotate(array, angle, mode="edge"): order-1 warp
+ * (order 0 = nearest neighbour with C round(), skimage's default for bool images, no clipping) with the row-major 2x3 inverse map h_matrix (host memory, 6 doubles: c = m0*col + m1*row + m2, r = m3*col + m4*row + m5),
+ * edge-clamped neighbours, result clipped to [d_min[i], d_max[i]].  PL_F32 / PL_F64 frames (the host converts integers the
+ * way skimage.img_as_float does); in != out. */
+int pl_warp_affine(const void* in, void* out, int dtype, int64_t n, int64_t h, int64_t w, int order, const double* h_matrix,
+                   const double* d_min, const double* d_max, void* stream);
+
 /* out = a * factor   (same dtype; the multiply inside stretch(), array_utils.py:168) */
 int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,
              void* stream);

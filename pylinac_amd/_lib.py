@@ -59,6 +59,7 @@ SIGNATURES = {
     "pl_normalize": ([_p, _p, _i, _l, _l, _p, _p], C.c_int),
     "pl_invert": ([_p, _p, _i, _l, _l, _p, _p, _p], C.c_int),
     "pl_bit_invert": ([_p, _p, _i, _l, _p], C.c_int),
+    "pl_warp_affine": ([_p, _p, _i, _l, _l, _l, _i, _p, _p, _p, _p], C.c_int),
     "pl_scale": ([_p, _p, _i, _l, _l, _d, _p], C.c_int),
     "pl_threshold": ([_p, _p, _i, _l, _l, _p, _i, _i, _p], C.c_int),
     "pl_as_binary": ([_p, _p, _i, _l, _l, _p, _i, _p], C.c_int),

@@ -53,6 +53,45 @@ def _uniquify(seq, value: str) -> str:
     return f"{value}-{n}"
 
 
+
+def rotate_array(array, angle: float, resize: bool = False, center=None, order=None, mode: str = "edge", cval=0,
+                 clip: bool = True, preserve_range: bool = False):
+    """``skimage.transform.rotate`` for 2-D arrays (numpy in / numpy out) or device frames ``[N,H,W]`` (tensor out), see
+    ``ArrayImage.rotate``.  The warp itself is ``pl_warp_affine``."""
+    from . import ops
+
+    if resize or mode != "edge" or order not in (None, 0, 1):
+        raise NotImplementedError("rotate: only order 0 / 1, mode='edge', resize=False (what BaseImage.rotate's callers use)")
+    s = au._Staged(array)
+    if s.ndim == 1:
+        raise ValueError("rotate needs a 2-D image")
+    t = s.t
+    kind = np.dtype(np.asarray(array).dtype if not s.is_tensor else au._NP_OF_TORCH[t.dtype])
+    if kind == np.uint64:
+        raise TypeError("rotate: uint64 images are not supported")
+    if order is None:
+        order = 0 if kind.kind == "b" else 1           # skimage's _validate_interpolation_order
+    if kind.kind == "b":
+        x = t.to(torch.float64)
+    elif kind.kind in "ui" and not preserve_range:
+        info = np.iinfo(kind)
+        x = t.to(torch.float64)
+        x = x * (1.0 / info.max) if kind.kind == "u" else (x + 0.5) * (2 / (info.max - info.min))
+    elif kind.kind in "ui":
+        x = t.to(torch.float64)
+    elif kind == np.float32 or kind == np.float64:
+        x = t
+    else:
+        raise TypeError(f"rotate: unsupported dtype {kind}")
+    x = x.contiguous()
+    frames = x if x.dim() == 3 else x.unsqueeze(0)
+    rows, cols = frames.shape[-2:]
+    m = ops.rotation_matrix(rows, cols, angle, center)
+    inf = float("inf")
+    out = ops.warp_affine(frames, m, order=order) if clip else ops.warp_affine(frames, m, -inf, inf, order=order)
+    return s.out(out.reshape(x.shape))
+
+
 class _MutatorMixin:
     """The reference's in-place API; subclasses provide ``array`` (numpy or device tensor)."""
 
@@ -180,6 +219,14 @@ class ArrayImage(_MutatorMixin):
 
     def roll(self, direction: str = "x", amount: int = 1) -> None:
         self.array = np.roll(self.array, amount, axis=1 if direction == "x" else 0)
+
+    def rotate(self, angle: float, mode: str = "edge", *args, **kwargs) -> None:
+        """image.py:780-783: counter-clockwise rotation by ``angle`` degrees, ``skimage.transform.rotate(array, angle,
+        mode=mode, ...)``: integer arrays are first rescaled the way ``img_as_float`` does (unsigned: ``a * (1 / imax)``;
+        signed: ``(a + 0.5) * (2 / (imax - imin))``; so a rotated uint16 image is float64 in 0..1, as in the reference),
+        then warped bilinearly (bool arrays: nearest neighbour, skimage's default order for them) about ``(cols, rows) / 2 - 0.5`` with edge replication and clipped to the input's range.
+        Only what the reference's own callers use is offered (order 1, mode "edge", no resize); anything else raises."""
+        self.array = rotate_array(self.array, angle, mode=mode, *args, **kwargs)
 
     @property
     def center(self):

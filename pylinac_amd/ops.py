@@ -802,3 +802,51 @@ def gradient1d(y: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(y2)
     check(_lib.load().pl_gradient1d(y2.data_ptr(), y2.shape[0], y2.shape[1], out.data_ptr(), _stream()), "pl_gradient1d")
     return out if y.ndim == 2 else out[0]
+
+
+# ---- BaseImage.rotate (pylinac/core/image.py:780-783 -> skimage.transform.rotate) -----------------------------------
+def rotation_matrix(rows: int, cols: int, angle: float, center=None):
+    """The 3x3 inverse map skimage.transform.rotate hands to warp(): translate the centre to the origin, rotate by
+    ``angle`` degrees, translate back -- built with the same numpy expressions (SimilarityTransform parameter matrices,
+    ``tform3 + tform2 + tform1`` == ``T1 @ (R @ T3)``, last row forced to (0, 0, 1))."""
+    import math
+
+    import numpy as np
+
+    center = np.array((cols, rows)) / 2.0 - 0.5 if center is None else np.asarray(center)
+
+    def similarity(rotation=0.0, translation=(0, 0)):
+        m = np.array([[math.cos(rotation), -math.sin(rotation), 0], [math.sin(rotation), math.cos(rotation), 0], [0, 0, 1]])
+        m[0:2, 0:2] *= 1
+        m[0:2, 2] = translation
+        return m
+
+    t1 = similarity(translation=center)
+    t2 = similarity(rotation=np.deg2rad(angle))
+    t3 = similarity(translation=-center)
+    m = t1 @ (t2 @ t3)
+    m[2] = (0, 0, 1)
+    return m
+
+
+def warp_affine(frames: torch.Tensor, matrix, lo=None, hi=None, order: int = 1) -> torch.Tensor:
+    """Order-1 (bilinear; ``order=0``: nearest neighbour, never clipped) 'edge' warp of float32 / float64 frames through the affine inverse map ``matrix`` (3x3 or 2x3, output
+    (row, col) -> input (r, c)); the result is clipped to ``[lo, hi]`` per frame (default: each frame's own min / max,
+    which is warp()'s clip=True)."""
+    import numpy as np
+
+    x = _frames(frames)
+    if x.dtype not in (torch.float32, torch.float64):
+        raise TypeError("warp_affine needs float32 or float64 frames")
+    n, h, w = x.shape
+    if order == 0:
+        lo, hi = 0.0, 0.0
+    elif lo is None or hi is None:
+        lo, hi = minmax(x)
+    lo = _per_frame(lo, n, x.device)[0].expand(n).contiguous()
+    hi = _per_frame(hi, n, x.device)[0].expand(n).contiguous()
+    m = np.ascontiguousarray(np.asarray(matrix, dtype=np.float64)[:2, :3])
+    out = torch.empty_like(x)
+    check(_lib.load().pl_warp_affine(x.data_ptr(), out.data_ptr(), _dt(x), n, h, w, int(order), m.ctypes.data, lo.data_ptr(),
+                                     hi.data_ptr(), _stream()), "pl_warp_affine")
+    return out

@@ -828,3 +828,60 @@ def check_bit_invert_and_convert_to_dtype():
             want = np.array(a16.astype(float) / 65535 * (ninfo.max - ninfo.min) - ninfo.max - 1, dtype=new)
         got = au.convert_to_dtype(a16, new)
         assert got.dtype == want.dtype and np.array_equal(got, want), new
+
+
+def check_rotate(golden, dev):
+    """BaseImage.rotate (pylinac/core/image.py:780-783) == skimage.transform.rotate(array, angle, mode="edge") of
+    scikit-image 0.18.3 (tests/golden/rotate.npz, generated by tests/golden/skimage_rotate_py39.py).  Three statements:
+    (1) the kernel on skimage's own captured inverse map and skimage's float conversion is BIT-EXACT; (2) the host builds
+    that map to within 2 ulp of its largest entry (the 3x3 products run through whichever BLAS numpy links); (3) the public
+    ``ArrayImage.rotate`` therefore agrees to 1e-12 of the value range, and exactly for the right angles' dtype / shape."""
+    import torch
+
+    from pylinac_amd import image as im
+    from pylinac_amd import ops
+
+    g = golden("rotate")
+    angles = g["angles"]
+    for name in g["names"]:
+        name = str(name)
+        a = g[name + ".in"]
+        k = 0
+        while f"{name}.{k}.out" in g:
+            want, m = g[f"{name}.{k}.out"], g[f"{name}.{k}.m"]
+            # (1) same conversion, same map -> same bits
+            if a.dtype.kind == "u":
+                x = np.multiply(a, 1.0 / np.iinfo(a.dtype).max, dtype=np.float64)
+            elif a.dtype.kind == "i":
+                x = np.add(a, 0.5, dtype=np.float64)
+                x *= 2 / (int(np.iinfo(a.dtype).max) - int(np.iinfo(a.dtype).min))
+            else:
+                x = a.astype(np.float64) if a.dtype.kind == "b" else a
+            got = ops.warp_affine(torch.from_numpy(np.ascontiguousarray(x)).to(dev), m, order=0 if a.dtype.kind == "b" else 1)[0].cpu().numpy()
+            assert got.dtype == want.dtype and got.shape == want.shape, (name, k)
+            assert np.array_equal(got, want), (name, k, float(np.abs(got - want).max()))
+            # (2) the host's map
+            mine = ops.rotation_matrix(a.shape[0], a.shape[1], float(angles[k]))
+            assert np.abs(mine - m).max() <= 2 * np.spacing(np.abs(m).max()), (name, k)
+            # (3) the public method
+            img = im.ArrayImage(a.copy())
+            img.rotate(float(angles[k]))
+            assert img.array.dtype == want.dtype and img.array.shape == want.shape
+            span = float(want.max() - want.min()) or 1.0
+            assert np.abs(img.array - want).max() <= 1e-12 * span, (name, k, float(np.abs(img.array - want).max()))
+            k += 1
+    # contract: what is not offered fails loudly; clip=False leaves the interpolated values alone
+    a = g["f64.in"]
+    for kw in (dict(resize=True), dict(order=3), dict(mode="constant")):
+        try:
+            im.rotate_array(a, 10.0, **kw)
+        except NotImplementedError:
+            pass
+        else:
+            raise AssertionError(kw)
+    assert np.array_equal(im.rotate_array(a, 33.3, clip=False), im.rotate_array(a, 33.3))     # bilinear stays in range
+    # batched device frames: every frame is rotated like the single image
+    t = torch.from_numpy(np.stack([a, a[::-1].copy(), a * 2])).to(dev)
+    r = im.rotate_array(t, -12.5)
+    for i in range(3):
+        assert np.array_equal(r[i].cpu().numpy(), im.rotate_array(t[i].cpu().numpy(), -12.5))

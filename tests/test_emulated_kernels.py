@@ -686,3 +686,9 @@ def test_emulated_bit_invert_and_convert_to_dtype(emulated):
     import next_row_checks as checks
 
     checks.check_bit_invert_and_convert_to_dtype()
+
+
+def test_emulated_rotate(emulated, golden):
+    import next_row_checks as checks
+
+    checks.check_rotate(golden, emulated)

@@ -1630,3 +1630,10 @@ def test_bit_invert_and_convert_to_dtype(dev):
     import next_row_checks as checks
 
     checks.check_bit_invert_and_convert_to_dtype()
+
+
+def test_rotate_matches_skimage(dev, golden):
+    """BaseImage.rotate (image.py:780-783): bit-exact on skimage 0.18.3's own inverse map, 1e-12 through the public method."""
+    import next_row_checks as checks
+
+    checks.check_rotate(golden, dev)
