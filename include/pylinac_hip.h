@@ -333,7 +333,8 @@ int pl_canny_hysteresis(const unsigned char* d_local_max, const double* d_magnit
  * doubles between frames, 0 = the same ROIs for every frame): kind 0 disk = (cx, cy, radius, unused) with
  * skimage.draw.disk membership; kind 1 rectangle = (r0, r1, c0, c1) half-open.  d_out float64
  * [n][rois_per_frame][6] = count, mean, std (population), min, max, median (np.median).  d_status int32
- * [n][rois_per_frame]: 0 ok, 1 ROI box leaves the frame, 2 more than 16384 pixels, 3 empty. */
+ * [n][rois_per_frame]: 0 ok, 1 a selected pixel lies outside the frame (rectangles: the window leaves it), 2 the ROI box
+ * exceeds 2^28 pixels, 3 empty.  ROIs of up to 16384 pixels are reduced from an LDS copy, larger ones by streaming passes. */
 int pl_roi_stats(const void* d_frames, int dtype, int64_t n, int h, int w, const double* d_rois,
                  int rois_per_frame, int64_t roi_frame_stride, int kind, double* d_out, int32_t* d_status,
                  void* stream);

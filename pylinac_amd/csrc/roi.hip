@@ -17,7 +17,8 @@
 //                 mean of the two middle values for an even count)
 //
 // One workgroup per (frame, ROI): the ROI values are gathered into LDS as float64 (<= 16 384 pixels), reduced,
-// and the median is found by bisection on an order-preserving 64-bit key.
+// and the median is found by bisection on an order-preserving 64-bit key.  Larger ROIs take the same passes straight
+// from the frame (membership re-evaluated, pixels re-read per pass): slower per ROI, no size limit below 2^28 box pixels.
 #include "pl_common.h"
 
 namespace {
@@ -104,50 +105,60 @@ roi_stats_kernel(const T* __restrict__ frames, int h, int w, const double* __res
       return;
     }
   }
-  if (threadIdx.x == 0) s_n = 0;
+  __shared__ int s_outside;
+  if (threadIdx.x == 0) { s_n = 0; s_outside = 0; }
   __syncthreads();
-  const bool inside_frame = r_lo >= 0 && c_lo >= 0 && r_lo + nr <= h && c_lo + nc <= w && nr > 0 && nc > 0;
-  if (!inside_frame || (int64_t)nr * nc > 4 * kMaxPix) {   // the reference would wrap or raise: reported, not guessed
-    if (threadIdx.x == 0) { status[item] = inside_frame ? 2 : 1; for (int q = 0; q < 6; ++q) o[q] = __longlong_as_double(0x7ff8000000000000LL); }
-    return;
-  }
-  // ---- gather in raster order (ordered compaction, one box row chunk at a time) ----------------------------
-  const int total = nr * nc;
-  for (int base = 0; base < total; base += kThreads) {
-    const int e = base + threadIdx.x;
-    bool in = false;
-    double v = 0;
-    if (e < total) {
-      const int ri = e / nc, ci = e % nc;
-      if (kind == 0) {
-        const double a = ((double)ri - r_org) / rad, b = ((double)ci - c_org) / rad;
-        in = (a * a + b * b) < 1.0;
-      } else if (kind == 1) {
-        in = true;
-      } else {
-        in = in_polygon(roi, nv, (double)(c_lo + ci), (double)(r_lo + ri));
-      }
-      if (in) v = (double)f[(int64_t)(r_lo + ri) * w + (c_lo + ci)];
+  auto fail = [&](int code) {
+    if (threadIdx.x == 0) { status[item] = code; for (int q = 0; q < 6; ++q) o[q] = __longlong_as_double(0x7ff8000000000000LL); }
+  };
+  const int64_t total64 = (int64_t)nr * nc;
+  if (nr <= 0 || nc <= 0) { fail(kind == 1 ? 1 : 3); return; }
+  if (total64 > (1LL << 28)) { fail(2); return; }     // a box of more than 2^28 pixels is not an ROI
+  if (kind == 1 && !(r_lo >= 0 && c_lo >= 0 && r_lo + nr <= h && c_lo + nc <= w)) { fail(1); return; }
+  const int total = (int)total64;
+  // membership + value of box element e; a selected pixel that lies outside the frame is what makes the reference wrap
+  // or raise (decided from the pixels actually selected, not from the box: a disk whose box row -1 selects nothing is fine)
+  auto member = [&](int e, double& v) -> bool {
+    const int ri = e / nc, ci = e % nc;
+    bool in;
+    if (kind == 0) {
+      const double a = ((double)ri - r_org) / rad, b = ((double)ci - c_org) / rad;
+      in = (a * a + b * b) < 1.0;
+    } else if (kind == 1) {
+      in = true;
+    } else {
+      in = in_polygon(roi, nv, (double)(c_lo + ci), (double)(r_lo + ri));
     }
-    const unsigned long long bal = __ballot(in);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ int s_wcnt[kThreads / PL_WAVE];
-    if (lane == 0) s_wcnt[wv] = __popcll(bal);
-    __syncthreads();
-    int off = s_n;
-    for (int q = 0; q < wv; ++q) off += s_wcnt[q];
-    const int dst = off + __popcll(bal & ((1ull << lane) - 1ull));
-    if (in && dst < kMaxPix) vals[dst] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < kThreads / PL_WAVE; ++q) t += s_wcnt[q]; s_n += t; }
-    __syncthreads();
+    if (!in) return false;
+    const int r = r_lo + ri, c = c_lo + ci;
+    if (r < 0 || c < 0 || r >= h || c >= w) { s_outside = 1; return false; }
+    v = (double)f[(int64_t)r * w + c];
+    return true;
+  };
+  // ---- small ROIs: gather in raster order into LDS (ordered compaction, one box row chunk at a time); ROIs whose box or
+  //      pixel count exceeds the LDS buffer are STREAMED instead: every pass re-evaluates the membership and re-reads the
+  //      pixels (ACR large uniformity disks, large rectangles) --------------------------------------------------------------
+  bool streaming = total > 4 * kMaxPix;
+  if (!streaming) {
+    for (int base = 0; base < total; base += kThreads) {
+      const int e = base + threadIdx.x;
+      double v = 0;
+      const bool in = e < total && member(e, v);
+      const unsigned long long bal = __ballot(in);
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      __shared__ int s_wcnt[kThreads / PL_WAVE];
+      if (lane == 0) s_wcnt[wv] = __popcll(bal);
+      __syncthreads();
+      int off = s_n;
+      for (int q = 0; q < wv; ++q) off += s_wcnt[q];
+      const int dst = off + __popcll(bal & ((1ull << lane) - 1ull));
+      if (in && dst < kMaxPix) vals[dst] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < kThreads / PL_WAVE; ++q) t += s_wcnt[q]; s_n += t; }
+      __syncthreads();
+    }
+    streaming = s_n > kMaxPix;
   }
-  const int n = s_n;
-  if (n == 0 || n > kMaxPix) {
-    if (threadIdx.x == 0) { status[item] = n == 0 ? 3 : 2; for (int q = 0; q < 6; ++q) o[q] = __longlong_as_double(0x7ff8000000000000LL); }
-    return;
-  }
-  // ---- sum / min / max, then the two-pass variance -------------------------------------------------------------
   auto block_reduce = [&](double v, int slot, auto op) {
     v = pl_wave_reduce(v, op);
     if ((threadIdx.x & 63) == 0) s_red[slot][threadIdx.x >> 6] = v;
@@ -157,22 +168,39 @@ roi_stats_kernel(const T* __restrict__ frames, int h, int w, const double* __res
     __syncthreads();
     return t;
   };
-  double sum = 0, mn = vals[0], mx = vals[0];
-  for (int i = threadIdx.x; i < n; i += kThreads) {
-    const double v = vals[i];
+  int n = s_n;
+  if (streaming) {
+    double c = 0;
+    for (int e = threadIdx.x; e < total; e += kThreads) { double v; c += member(e, v) ? 1.0 : 0.0; }
+    n = (int)block_reduce(c, 0, [](double a, double b) { return a + b; });
+  }
+  __syncthreads();
+  if (s_outside) { fail(1); return; }
+  if (n == 0) { fail(3); return; }
+  auto for_each = [&](auto fn) {
+    if (!streaming) {
+      for (int i = threadIdx.x; i < n; i += kThreads) fn(vals[i]);
+    } else {
+      for (int e = threadIdx.x; e < total; e += kThreads) { double v; if (member(e, v)) fn(v); }
+    }
+  };
+  // ---- sum / min / max, then the two-pass variance -------------------------------------------------------------
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  double sum = 0, mn = inf, mx = -inf;
+  for_each([&](double v) {
     sum += v;
     mn = v < mn ? v : mn;
     mx = v > mx ? v : mx;
-  }
+  });
   sum = block_reduce(sum, 0, [](double a, double b) { return a + b; });
   mn = block_reduce(mn, 1, [](double a, double b) { return a < b ? a : b; });
   mx = block_reduce(mx, 2, [](double a, double b) { return a > b ? a : b; });
   const double mean = sum / (double)n;
   double ss = 0;
-  for (int i = threadIdx.x; i < n; i += kThreads) {
-    const double d = vals[i] - mean;
+  for_each([&](double v) {
+    const double d = v - mean;
     ss += d * d;
-  }
+  });
   ss = block_reduce(ss, 3, [](double a, double b) { return a + b; });
   // ---- median: smallest key with #{<= key} >= rank + 1, for the two middle ranks -----------------------------------
   auto kth = [&](int rank) {
@@ -180,7 +208,7 @@ roi_stats_kernel(const T* __restrict__ frames, int h, int w, const double* __res
     while (lo < hi) {
       const unsigned long long mid = lo + ((hi - lo) >> 1);
       unsigned long long c = 0;
-      for (int i = threadIdx.x; i < n; i += kThreads) c += key_of(vals[i]) <= mid ? 1 : 0;
+      for_each([&](double v) { c += key_of(v) <= mid ? 1 : 0; });
       c = pl_wave_reduce(c, [](unsigned long long a, unsigned long long b) { return a + b; });
       if (threadIdx.x == 0) s_cnt = 0;
       __syncthreads();

@@ -80,7 +80,7 @@ class DiskROI:
             if st == 1:   # the reference indexes without a shape: negative indices wrap, large ones raise
                 raise IndexError("disk ROI leaves the image")
             if st:
-                raise ValueError("disk ROI is empty or larger than 16384 pixels")
+                raise ValueError("disk ROI is empty" if st == 3 else "disk ROI box exceeds 2**28 pixels")
             self._cache = out[0, 0].cpu().numpy()
         return self._cache
 
@@ -204,7 +204,7 @@ class RectangleROI:
             out, status = polygon_roi_stats_batch(self._array[None], _pixels_flat_polygon(self.vertices)[None])
             st = int(status[0, 0])
             if st == 2:
-                raise ValueError("rectangle ROI is larger than 16384 pixels")
+                raise ValueError("rectangle ROI box exceeds 2**28 pixels")
             self._cache = out[0, 0].cpu().numpy()        # status 3 (no pixels): NaNs, like np.mean of an empty array
         return self._cache
 

@@ -885,3 +885,48 @@ def check_rotate(golden, dev):
     r = im.rotate_array(t, -12.5)
     for i in range(3):
         assert np.array_equal(r[i].cpu().numpy(), im.rotate_array(t[i].cpu().numpy(), -12.5))
+
+
+def check_large_rois(dev):
+    """ROIs beyond the LDS buffer (DiskROI of radius > ~72 px such as the ACR large uniformity ROI, large
+    rectangles) go through the streaming path: same statistics as numpy on the same pixel set.  And the out-of-frame
+    decision comes from the pixels a disk actually selects: a disk whose box reaches row -1 without selecting anything
+    there (cy - r == -1: the boundary is excluded) is inside, as in the reference (pylinac/core/roi.py:134-138)."""
+    from oracle import pylinac_oracle as o
+    from pylinac_amd import roi
+
+    rng = np.random.default_rng(8)
+    arr = (rng.normal(1000, 50, (400, 460)) + np.add.outer(np.arange(400), np.arange(460)) * 0.5)
+    frames = {"f64": arr, "i16": arr.astype(np.int16), "u16": arr.astype(np.uint16)}
+    disks = np.array([[230.3, 200.7, 120.0], [100.0, 90.0, 72.5], [300.5, 250.5, 149.0], [50.0, 11.0, 12.0],
+                      [11.0, 60.0, 12.0], [200.0, 200.0, 5.0]])
+    for name, a in frames.items():
+        out, st = roi.disk_roi_stats_batch(torch.from_numpy(a).to(dev)[None], disks[:, :2], disks[:, 2])
+        assert int(st.abs().sum()) == 0, (name, st)
+        got = out[0].cpu().numpy()
+        want = np.array([o.disk_roi_stats(a, cx, cy, r) for cx, cy, r in disks])
+        assert want[0, 0] > 16384 and want[2, 0] > 4 * 16384       # beyond the LDS buffer / beyond the gather box limit
+        assert np.array_equal(got[:, [0, 3, 4, 5]], want[:, [0, 3, 4, 5]]), name
+        assert np.allclose(got[:, 1:3], want[:, 1:3], rtol=1e-12, atol=0), name
+    # one pixel further and the disk selects row / column -1: reported like before
+    _, st = roi.disk_roi_stats_batch(torch.from_numpy(arr).to(dev)[None], [[50.0, 10.5], [10.5, 60.0]], 12.0)
+    assert st.cpu().numpy().tolist() == [[1, 1]]
+    d = roi.DiskROI(frames["i16"], radius=120.0, center=(230.3, 200.7))
+    w = o.disk_roi_stats(frames["i16"], 230.3, 200.7, 120.0)
+    assert (d.pixel_value, d.min, d.max) == (w[5], w[3], w[4]) and abs(d.mean - w[1]) < 1e-9 and abs(d.std - w[2]) < 1e-9
+    # large windows and a large rotated rectangle
+    boxes = np.array([[0, 400, 0, 460], [10, 390, 20, 300], [100, 228, 100, 229]], dtype=float)
+    outr, st = roi.rectangle_stats_batch(torch.from_numpy(arr).to(dev)[None], boxes)
+    assert int(st.abs().sum()) == 0
+    for k, (r0, r1, c0, c1) in enumerate(boxes.astype(int)):
+        v = arr[r0:r1, c0:c1]
+        got = outr[0, k].cpu().numpy()
+        assert got[0] == v.size and got[3] == v.min() and got[4] == v.max() and got[5] == np.median(v)
+        assert abs(got[1] - v.mean()) <= 1e-12 * abs(v.mean()) and abs(got[2] - v.std()) <= 1e-12 * v.std()
+    big = roi.RectangleROI(frames["i16"], width=300, height=180, center=(230, 200), rotation=30)
+    small_sum = roi.RectangleROI(frames["i16"], width=300, height=180, center=(230, 200), rotation=0)
+    v = frames["i16"][110:290, 80:380]                      # rotation 0: pixels_flat's -1 corners make it == pixel_array
+    assert small_sum._s()[0] == v.size and small_sum.min == v.min() and small_sum.max == v.max()
+    assert abs(small_sum.mean - v.mean()) < 1e-9 and abs(small_sum.std - v.std()) < 1e-9
+    n_big = big._s()[0]
+    assert abs(n_big - 300 * 180) < 0.02 * 300 * 180 and big.min >= frames["i16"].min() and big.max <= frames["i16"].max()

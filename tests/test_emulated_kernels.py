@@ -692,3 +692,9 @@ def test_emulated_rotate(emulated, golden):
     import next_row_checks as checks
 
     checks.check_rotate(golden, emulated)
+
+
+def test_emulated_large_rois(emulated):
+    import next_row_checks as checks
+
+    checks.check_large_rois(emulated)

@@ -1637,3 +1637,10 @@ def test_rotate_matches_skimage(dev, golden):
     import next_row_checks as checks
 
     checks.check_rotate(golden, dev)
+
+
+def test_large_rois_stream(dev):
+    """f3: ROIs beyond the 16384-pixel LDS buffer (streaming passes) and the pixel-based out-of-frame decision."""
+    import next_row_checks as checks
+
+    checks.check_large_rois(dev)
