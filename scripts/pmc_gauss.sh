@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC view of the Gaussian kernels (packed-f32 decision path and, with PL_GAUSS_F64=1, the float64 path).
+# PMC view of the Gaussian kernels that serve 16-bit frames (register-window packed-f32 decision path).
 # SQ counters only, two passes; every rocprofv3 call is wrapped in `timeout`.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_gauss
 rm -rf $OUT; mkdir -p $OUT
