@@ -1,0 +1,466 @@
+// Exact-integer matrix-core kernels for the scipy-exact Gaussian on 16-bit images.
+//
+// Replaces: scipy.ndimage.gaussian_filter on uint16 / int16 frames as called at
+// pylinac/core/array_utils.py:133 (BaseImage.filter(kind="gaussian"), pylinac/core/image.py:695-712).
+//
+// Contract (gaussian.hip header): out = trunc(S), S = scipy's float64 tap sequence along one axis.  The register-window
+// kernels (gaussian_rw.hip) decide trunc(S) with a packed-float32 chain and are VALU-issue bound at ~0.35 of the HBM
+// roofline.  Here the 41-tap sum itself moves to the matrix cores, in EXACT integer arithmetic:
+//
+//   taps     w_k = wq_k * 2^-Q + e_k,  wq_k = round(w_k * 2^Q) written in four balanced base-256 digits d0..d3 (int8),
+//            Q chosen on the host so that the largest tap fills the four digits (Q = 34 at sigma = 5)
+//   samples  biased value x in [0, 65535] (int16 input: x = v + 32768);  x - 32896 = 256 * hi + lo with
+//            hi = x_hi - 128, lo = x_lo - 128: BOTH digits are the raw bytes with the top bit flipped, both int8
+//   T        = sum_k wq_k * (x_k - 32896) = sum over digit pairs 256^(a+b) * sum_k d_a[k] * digit_b[x_k]:
+//            eight v_mfma_i32_16x16x64_i8 per 16 x 16 output tile (Toeplitz band of one weight digit x one sample
+//            digit plane, K = the 64-sample window that holds the 16 + 2*RAD <= 64 inputs of 16 outputs), int32
+//            accumulation: exact, order-free
+//   S        = 2^-Q * (T + 32896 * sum wq_k) + E,  |E| <= 65535 * sum |e_k|  (7.8e-5 at sigma = 5)
+//
+// so floor(S) is known exactly unless frac(S) lies within delta = |E|-bound + float32 recombination slack (~1e-4) of an
+// integer; those pixels (~0.02 %, plus constant / saturated neighbourhoods where S sits 1e-11 from an integer) are listed
+// and recomputed with scipy's float64 sequence from the raw bytes still in LDS (rw_exact, as in gaussian_rw.hip).
+//
+// Recombination per output (VALU): the five int32 accumulators (digit-pair scales 0, 8, 16, 24, 32 bits) are merged as
+//   U = a3 + (a4 << 8) + C_hi               int32, scale 2^24: integer part floor(U / 2^(Q-24)) taken with a shift
+//   L = a0 + 2^8 a1 + 2^16 a2 + C_lo        float32, |L| * 2^-Q < 8: absolute error < 2e-6
+// C = 32896 * sum wq_k is folded into the accumulator initial values (the MFMA's C operand).
+//
+// Operand layout: v_mfma_i32_16x16x64_i8 pairs byte s of lane (m, g) of A with byte s of lane (n, g) of B (m, n = lane & 15,
+// g = lane >> 4) and leaves D[m = 4 * (lane >> 4) + reg][n = lane & 15] (scripts/ubench/mfma_i8.hip checks this on the
+// device); because A and B use the SAME slot -> k map, any consistent assignment of window positions to slots is correct:
+// slot (g, s) <-> window position k = 16 g + s.
+//
+// Axis 1: a wave owns 16 rows x 256 columns; it splits the raw rows (+ 24 halo columns each side, reflected at the frame
+// edge) into two byte planes in a wave-private LDS strip (one ds_read_b128 per plane then feeds a tile's 16 rows x 64
+// window bytes); no workgroup barrier.  Axis 0: a workgroup owns 64 columns x 256 rows; its four waves write the planes
+// TRANSPOSED ([column][row] bytes) so that the same 16-byte reads deliver 16 consecutive ROWS of one column; one barrier.
+// Results leave as 8-byte stores (4 consecutive columns of one row per lane); a row's 32-byte segments of neighbouring
+// tiles complete full lines in L2.
+#include <type_traits>
+
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kMmThreads = 256;
+constexpr int kMmWaves = kMmThreads / PL_WAVE;
+constexpr int kMmHalo = 24;                 // window start = first output - 24: 16-byte aligned, covers RAD <= 24
+constexpr int kMmMaxRad = 24;
+constexpr int kMmListCap = 128;             // undecided outputs a wave / workgroup lists before everybody recomputes
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// Everything a pass needs, computed on the host (mm_make_params) and passed by value.
+struct MmParams {
+  // band[d][c][.]: the zero-padded band sequence E_d[p] = digit_d[|p - 39|] (|p - 39| <= RAD, else 0) of weight digit d,
+  // shifted left by c bytes, so that a lane whose Toeplitz row starts at p0 = 16 g - i + 15 reads its 16 bytes as four
+  // ALIGNED dwords band[d][p0 & 3][(p0 >> 2) .. + 3]
+  unsigned band[4][4][24];
+  float two_mq;      // 2^-Q
+  float two_m8q;     // 2^(8 - Q)
+  float two_m16q;    // 2^(16 - Q)
+  float two_msh;     // 2^-(Q - 24)
+  int sh;            // Q - 24
+  int c_hi;          // (32896 * sum wq) >> 24        -> initial value of the scale-24 accumulator
+  int c_lo;          // (32896 * sum wq) & (2^24 - 1) -> initial value of the scale-0 accumulator
+  float lim;         // 0.5 - delta
+  int radius;
+  double wd[kMmMaxRad + 1];  // float64 taps (offset j) for the exact path, zero beyond radius
+};
+
+bool mm_make_params(const double* h_wts /* 2*R+1 taps, centre at R */, int R, MmParams& p) {
+  if (R < 1 || R > kMmMaxRad) return false;
+  double wmax = 0.0, W = 0.0;
+  for (int k = 0; k <= 2 * R; ++k) {
+    if (!(h_wts[k] >= 0.0)) return false;          // floor == trunc needs S >= 0 in the biased domain
+    wmax = h_wts[k] > wmax ? h_wts[k] : wmax;
+    W += h_wts[k];
+  }
+  if (!(wmax > 0.0) || !(W < 4.0)) return false;
+  int Q = 24;
+  while (Q < 36 && __builtin_ldexp(wmax, Q + 1) < 2.0e9) ++Q;
+  if (__builtin_ldexp(wmax, Q) >= 2.0e9) return false;
+  long long wq[2 * kMmMaxRad + 1];
+  long long WQ = 0;
+  double eq = 0.0;
+  signed char dig[4][kMmMaxRad + 1];
+  for (int k = 0; k <= 2 * R; ++k) {
+    wq[k] = (long long)__builtin_llround(__builtin_ldexp(h_wts[k], Q));
+    WQ += wq[k];
+    eq += __builtin_fabs(h_wts[k] - __builtin_ldexp((double)wq[k], -Q));
+  }
+  for (int j = 0; j <= R; ++j) {
+    if (wq[R - j] != wq[R + j]) return false;      // the band is built from one half: taps must be symmetric
+    long long v = wq[R - j];
+    for (int d = 0; d < 4; ++d) {
+      const long long lo = ((v + 128) & 255) - 128;
+      dig[d][j] = (signed char)lo;
+      v = (v - lo) >> 8;
+    }
+    if (v != 0) return false;
+  }
+  for (int d = 0; d < 4; ++d)
+    for (int c = 0; c < 4; ++c) {
+      unsigned char bytes[96];
+      for (int x = 0; x < 96; ++x) {
+        const int pidx = x + c - 39;               // E[x + c], centre at 39
+        const int dist = pidx < 0 ? -pidx : pidx;
+        bytes[x] = (x + c <= 78 + 16 && dist <= R) ? (unsigned char)dig[d][dist] : 0;
+      }
+      for (int q = 0; q < 24; ++q)
+        p.band[d][c][q] = (unsigned)bytes[4 * q] | ((unsigned)bytes[4 * q + 1] << 8) | ((unsigned)bytes[4 * q + 2] << 16) |
+                          ((unsigned)bytes[4 * q + 3] << 24);
+    }
+  const long long C = 32896LL * WQ;
+  p.c_hi = (int)(C >> 24);
+  p.c_lo = (int)(C & 0xffffffLL);
+  if ((C >> 24) > 0x3fffffffLL) return false;
+  p.sh = Q - 24;
+  p.two_mq = (float)__builtin_ldexp(1.0, -Q);
+  p.two_m8q = (float)__builtin_ldexp(1.0, 8 - Q);
+  p.two_m16q = (float)__builtin_ldexp(1.0, 16 - Q);
+  p.two_msh = (float)__builtin_ldexp(1.0, -(Q - 24));
+  // |S_real - 2^-Q (T + C)| <= 65535 * sum|e_k|; float32 recombination < 8e-6; scipy's own rounding and the int16 bias
+  // 32768 * (W - 1) are ~1e-11
+  const double delta = 65535.0 * eq * (1.0 + 1e-9) + 8e-6 + 65536.0 * __builtin_fabs(W - 1.0) + 1e-9;
+  if (!(delta < 0.25)) return false;
+  p.lim = (float)(0.5 - delta);
+  p.radius = R;
+  for (int j = 0; j <= kMmMaxRad; ++j) p.wd[j] = j <= R ? h_wts[R - j] : 0.0;
+  return true;
+}
+
+// the lane's Toeplitz operand of weight digit d: bytes s = 0..15 <-> window position k = 16 g + s, value
+// digit_d[|k - i - 24|] for the lane's index i = lane & 15 inside the 16-output tile
+__device__ __forceinline__ v4i mm_band_operand(const MmParams& P, int d, int lane) {
+  const int p0 = 16 * (lane >> 4) - (lane & 15) + 15;
+  const unsigned* src = &P.band[d][p0 & 3][p0 >> 2];
+  return v4i{(int)src[0], (int)src[1], (int)src[2], (int)src[3]};
+}
+
+// scipy's value for one output from the two byte planes: lo(k), hi(k) = the plane bytes at window offset k - RAD
+template <typename F>
+__device__ __forceinline__ double mm_exact(F raw /* k in [-R, R] -> actual value as double */, const MmParams& P) {
+  const int R = P.radius;
+  double a = raw(0) * P.wd[0];
+  for (int j = R; j >= 1; --j) a = __builtin_fma(raw(-j) + raw(j), P.wd[j], a);
+  const double off = __builtin_fabs(__builtin_amdgcn_fract(__builtin_fabs(a)) - 0.5);
+  if (off > 0.5 - 4e-9) {
+    a = raw(0) * P.wd[0];
+    for (int j = R; j >= 1; --j) a = a + (raw(-j) + raw(j)) * P.wd[j];
+  }
+  return a;
+}
+
+struct MmAcc { v4i a0, a1, a2, a3, a4; };
+
+// the eight MFMAs of one tile: img_lo / img_hi = the 16 x 64 sample digit planes (as A when IMG_IS_A), w[d] = Toeplitz
+template <bool IMG_IS_A>
+__device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[4], const MmParams& P) {
+  auto mm = [&](v4i img, v4i band, v4i c) {
+    return IMG_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(img, band, c, 0, 0, 0)
+                    : __builtin_amdgcn_mfma_i32_16x16x64_i8(band, img, c, 0, 0, 0);
+  };
+  MmAcc r;
+  const v4i z = {0, 0, 0, 0};
+  r.a0 = mm(img_lo, w[0], v4i{P.c_lo, P.c_lo, P.c_lo, P.c_lo});
+  r.a1 = mm(img_lo, w[1], z);
+  r.a2 = mm(img_lo, w[2], z);
+  r.a3 = mm(img_lo, w[3], v4i{P.c_hi, P.c_hi, P.c_hi, P.c_hi});
+  r.a4 = mm(img_hi, w[3], z);
+  r.a1 = mm(img_hi, w[0], r.a1);
+  r.a2 = mm(img_hi, w[1], r.a2);
+  r.a3 = mm(img_hi, w[2], r.a3);
+  return r;
+}
+
+// one output from its five accumulator values: floor(S) in the biased domain (0 .. 65535) and the fail bit
+__device__ __forceinline__ unsigned mm_decide(int a0, int a1, int a2, int a3, int a4, const MmParams& P, unsigned& fail) {
+  const int U = a3 + (a4 << 8);
+  const int hi = U >> P.sh;
+  const float lo = (float)(U & ((1 << P.sh) - 1));
+  float t = lo * P.two_msh;
+  t = __builtin_fmaf((float)a0, P.two_mq, t);
+  t = __builtin_fmaf((float)a1, P.two_m8q, t);
+  t = __builtin_fmaf((float)a2, P.two_m16q, t);
+  const float fr = __builtin_amdgcn_fractf(t);
+  const float fl = t - fr;                                   // floor(t), exact
+  fail = __builtin_amdgcn_alignbit(fail, __float_as_uint(P.lim - __builtin_fabsf(fr - 0.5f)), 31);
+  return (unsigned)(hi + (int)fl);
+}
+
+// four outputs of a lane (regs 0..3 = consecutive columns) -> two dwords of packed 16-bit results in the image's own
+// domain; the four fail bits are shifted into `fail` (reg 0 first)
+template <bool SIGNED>
+__device__ __forceinline__ uint2 mm_finish(const MmAcc& r, const MmParams& P, unsigned& fail) {
+  unsigned v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = mm_decide(r.a0[q], r.a1[q], r.a2[q], r.a3[q], r.a4[q], P, fail);
+    if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;   // C truncation rounds negative S toward zero
+  }
+  return uint2{__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
+}
+
+// 16 raw pixels (8 dwords) -> their 16 low-digit bytes and 16 high-digit bytes
+template <bool SIGNED>
+__device__ __forceinline__ void mm_split16(const uint4 a, const uint4 b, uint4& lo, uint4& hi) {
+  constexpr unsigned kHiFlip = SIGNED ? 0u : 0x80808080u;    // int16: the signed high byte already is x_hi - 128
+  lo = uint4{__builtin_amdgcn_perm(a.y, a.x, 0x06040200u) ^ 0x80808080u, __builtin_amdgcn_perm(a.w, a.z, 0x06040200u) ^ 0x80808080u,
+             __builtin_amdgcn_perm(b.y, b.x, 0x06040200u) ^ 0x80808080u, __builtin_amdgcn_perm(b.w, b.z, 0x06040200u) ^ 0x80808080u};
+  hi = uint4{__builtin_amdgcn_perm(a.y, a.x, 0x07050301u) ^ kHiFlip, __builtin_amdgcn_perm(a.w, a.z, 0x07050301u) ^ kHiFlip,
+             __builtin_amdgcn_perm(b.y, b.x, 0x07050301u) ^ kHiFlip, __builtin_amdgcn_perm(b.w, b.z, 0x07050301u) ^ kHiFlip};
+}
+
+// the actual sample value from its two plane bytes
+template <bool SIGNED>
+__device__ __forceinline__ double mm_value(unsigned char lo, unsigned char hi) {
+  const int x = ((int)(signed char)hi + 128) * 256 + ((int)(signed char)lo + 128);   // biased value 0 .. 65535
+  return (double)(x - (SIGNED ? 32768 : 0));
+}
+
+// ---------------------------------------------------------------------- axis 1 (horizontal) pass
+constexpr int kHSeg = 256;                       // output columns per wave
+constexpr int kHPitch = kHSeg + 2 * kMmHalo;     // bytes per plane row (304: 16-byte multiple, 76 dwords: conflict-free b128)
+constexpr int kHTiles = kHSeg / 16;
+
+template <typename T>
+__global__ void __launch_bounds__(kMmThreads)
+gauss_h_mm(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, int w, int col_tiles, const MmParams P) {
+  constexpr bool kSigned = (T)-1 < (T)0;
+  __shared__ __attribute__((aligned(16))) unsigned char s_lo[kMmWaves][16 * kHPitch];
+  __shared__ __attribute__((aligned(16))) unsigned char s_hi[kMmWaves][16 * kHPitch];
+  __shared__ unsigned s_cnt[kMmWaves];
+  __shared__ unsigned s_item[kMmWaves][kMmListCap];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (PL_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / PL_WAVE);
+  const unsigned lid = pl_xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = lid % col_tiles;
+  const int64_t r0 = ((int64_t)(lid / col_tiles) * kMmWaves + wave) * 16;   // first of the wave's 16 rows (frame*h + r)
+  if (r0 >= rows_total) return;                    // wave-uniform; no workgroup barrier below
+  const int c0 = ct * kHSeg;
+  unsigned char* plo = s_lo[wave];
+  unsigned char* phi = s_hi[wave];
+  const int j = lane & 15, g = lane >> 4;
+  if (lane == 0) s_cnt[wave] = 0;
+
+  // ---- split the 16 rows x 304 columns into the two byte planes: lane = (row j, 16-column chunk g + 4 * it)
+  {
+    const int64_t row = r0 + j < rows_total ? r0 + j : rows_total - 1;     // rows beyond the end repeat the last one
+    const T* src = in + row * (size_t)w;
+#pragma unroll 1
+    for (int it = 0; it < 5; ++it) {
+      const int chunk = g + 4 * it;
+      if (chunk >= kHPitch / 16) break;
+      const int col = c0 - kMmHalo + 16 * chunk;
+      uint4 a, b;
+      if (col >= 0 && col + 16 <= w) {
+        a = *reinterpret_cast<const uint4*>(src + col);
+        b = *reinterpret_cast<const uint4*>(src + col + 8);
+      } else {
+        unsigned short v[16];
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) v[q] = (unsigned short)src[pl_reflect(col + q, w)];
+        a = uint4{v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16)};
+        b = uint4{v[8] | ((unsigned)v[9] << 16), v[10] | ((unsigned)v[11] << 16), v[12] | ((unsigned)v[13] << 16), v[14] | ((unsigned)v[15] << 16)};
+      }
+      uint4 lo, hi;
+      mm_split16<kSigned>(a, b, lo, hi);
+      *reinterpret_cast<uint4*>(plo + j * kHPitch + 16 * chunk) = lo;
+      *reinterpret_cast<uint4*>(phi + j * kHPitch + 16 * chunk) = hi;
+    }
+  }
+  v4i band[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) band[d] = mm_band_operand(P, d, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  // ---- tiles: Toeplitz (M = output column) x image (N = row): lane (j, g) ends with columns 4 g .. 4 g + 3 of row j
+  const int64_t orow = r0 + j;
+  T* dst = out + orow * (size_t)w + c0 + 4 * g;
+  const bool row_ok = orow < rows_total;
+  const int ntiles = (w - c0) / 16 < kHTiles ? (w - c0) / 16 : kHTiles;
+  unsigned anyfail = 0;
+#pragma unroll 2
+  for (int t = 0; t < ntiles; ++t) {
+    const uint4 qlo = *reinterpret_cast<const uint4*>(plo + j * kHPitch + 16 * (t + g));
+    const uint4 qhi = *reinterpret_cast<const uint4*>(phi + j * kHPitch + 16 * (t + g));
+    const MmAcc r = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w},
+                                   v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+    unsigned fail = 0;
+    const uint2 res = mm_finish<kSigned>(r, P, fail);
+    if (row_ok) *reinterpret_cast<uint2*>(dst + 16 * t) = res;
+    fail &= row_ok ? 15u : 0u;
+    if (fail) {                                   // rare: list (tile, lane, 4 fail bits)
+      const unsigned i = atomicAdd(&s_cnt[wave], 1u);
+      if (i < (unsigned)kMmListCap) s_item[wave][i] = ((unsigned)t << 10) | ((unsigned)lane << 4) | fail;
+      anyfail = 1;
+    }
+  }
+  (void)anyfail;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const unsigned cnt = s_cnt[wave];
+  if (cnt == 0) return;
+  // ---- undecided outputs: scipy's float64 sequence from the plane bytes of the wave's own strip
+  auto fix_one = [&](int t, int l, int q) {       // tile t, lane l, register q (fail bit 3 - q)
+    const int jj = l & 15, col = 16 * t + 4 * (l >> 4) + q;           // strip-relative output column
+    if (r0 + jj >= rows_total || c0 + col >= w) return;
+    const unsigned char* lo = plo + jj * kHPitch + col + kMmHalo;
+    const unsigned char* hi = phi + jj * kHPitch + col + kMmHalo;
+    const double acc = mm_exact([&](int k) { return mm_value<kSigned>(lo[k], hi[k]); }, P);
+    out[(r0 + jj) * (size_t)w + c0 + col] = pl_from_double<T>(acc);
+  };
+  if (cnt <= (unsigned)kMmListCap) {
+    for (unsigned e = lane; e < cnt * 4; e += PL_WAVE) {
+      const unsigned code = s_item[wave][e >> 2];
+      const int q = (int)(e & 3u);
+      if (code & (8u >> q)) fix_one((int)(code >> 10), (int)((code >> 4) & 63u), q);
+    }
+  } else {
+    for (int t = 0; t < ntiles; ++t)
+      for (int q = 0; q < 4; ++q) fix_one(t, lane, q);
+  }
+}
+
+// ------------------------------------------------------------------------ axis 0 (vertical) pass
+constexpr int kVCols = 64;                       // columns per workgroup (lane = column while the planes are filled)
+constexpr int kVRows = 256;                      // output rows per workgroup (64 per wave)
+constexpr int kVPitch = kVRows + 2 * kMmHalo;    // bytes per plane COLUMN (304)
+
+template <typename T>
+__global__ void __launch_bounds__(kMmThreads)
+gauss_v_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_tiles, int row_tiles, const MmParams P) {
+  constexpr bool kSigned = (T)-1 < (T)0;
+  __shared__ __attribute__((aligned(16))) unsigned char s_lo[kVCols * kVPitch];   // [column][row]
+  __shared__ __attribute__((aligned(16))) unsigned char s_hi[kVCols * kVPitch];
+  __shared__ unsigned s_cnt;
+  __shared__ unsigned s_item[kMmListCap];
+
+  unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = id % col_tiles;
+  id /= col_tiles;
+  const int rt = id % row_tiles;
+  const size_t frame = id / row_tiles;
+  const int tid = threadIdx.x;
+  const int lane = tid & (PL_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / PL_WAVE);
+  const int c0 = ct * kVCols, r0 = rt * kVRows;
+  const T* f = in + frame * (size_t)h * w;
+  T* o = out + frame * (size_t)h * w;
+  if (tid == 0) s_cnt = 0;
+
+  // ---- planes, transposed: every wave takes 76 of the 304 window rows, four rows per step; lane = column
+  {
+    const int c = c0 + lane < w ? c0 + lane : w - 1;
+    constexpr unsigned kHiFlip = kSigned ? 0u : 0x80808080u;
+    constexpr int kShare = kVPitch / kMmWaves;     // 76
+#pragma unroll 1
+    for (int s = 0; s < kShare; s += 4) {
+      const int p = wave * kShare + s;             // plane row of the first of the four
+      unsigned x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[q] = (unsigned short)f[(size_t)pl_reflect(r0 - kMmHalo + p + q, h) * w + c];
+      const unsigned t0 = __builtin_amdgcn_perm(x[1], x[0], 0x05010400u);   // {x0.b0, x1.b0, x0.b1, x1.b1}
+      const unsigned t1 = __builtin_amdgcn_perm(x[3], x[2], 0x05010400u);
+      *reinterpret_cast<unsigned*>(s_lo + lane * kVPitch + p) = __builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u;
+      *reinterpret_cast<unsigned*>(s_hi + lane * kVPitch + p) = __builtin_amdgcn_perm(t1, t0, 0x07060302u) ^ kHiFlip;
+    }
+  }
+  v4i band[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) band[d] = mm_band_operand(P, d, lane);
+  __syncthreads();
+
+  // ---- tiles: image (M = column) x Toeplitz (N = output row): lane (j, g) ends with columns 4 g .. 4 g + 3 of row j
+  const int j = lane & 15, g = lane >> 4;
+  const int ncb = (w - c0) / 16 < kVCols / 16 ? (w - c0) / 16 : kVCols / 16;
+#pragma unroll 1
+  for (int tr = 0; tr < 4; ++tr) {
+    const int lrow = wave * 64 + 16 * tr;          // first output row of the tile inside the workgroup
+    if (r0 + lrow >= h) break;
+    const bool row_ok = r0 + lrow + j < h;
+    T* dst = o + (size_t)(r0 + lrow + j) * w + c0 + 4 * g;
+#pragma unroll 2
+    for (int cb = 0; cb < ncb; ++cb) {
+      const uint4 qlo = *reinterpret_cast<const uint4*>(s_lo + (16 * cb + j) * kVPitch + lrow + 16 * g);
+      const uint4 qhi = *reinterpret_cast<const uint4*>(s_hi + (16 * cb + j) * kVPitch + lrow + 16 * g);
+      const MmAcc r = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w},
+                                    v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+      unsigned fail = 0;
+      const uint2 res = mm_finish<kSigned>(r, P, fail);
+      if (row_ok) *reinterpret_cast<uint2*>(dst + 16 * cb) = res;
+      fail &= row_ok ? 15u : 0u;
+      if (fail) {
+        const unsigned i = atomicAdd(&s_cnt, 1u);
+        if (i < (unsigned)kMmListCap) s_item[i] = ((unsigned)(wave * 16 + tr * 4 + cb) << 10) | ((unsigned)lane << 4) | fail;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned cnt = s_cnt;
+  if (cnt == 0) return;
+  auto fix_one = [&](int tile, int l, int q) {     // tile = wave * 16 + tr * 4 + cb
+    const int lrow = (tile >> 4) * 64 + ((tile >> 2) & 3) * 16 + (l & 15);
+    const int lcol = (tile & 3) * 16 + 4 * (l >> 4) + q;
+    if (r0 + lrow >= h || c0 + lcol >= w) return;
+    const unsigned char* lo = s_lo + lcol * kVPitch + lrow + kMmHalo;
+    const unsigned char* hi = s_hi + lcol * kVPitch + lrow + kMmHalo;
+    const double acc = mm_exact([&](int k) { return mm_value<kSigned>(lo[k], hi[k]); }, P);
+    o[(size_t)(r0 + lrow) * w + c0 + lcol] = pl_from_double<T>(acc);
+  };
+  if (cnt <= (unsigned)kMmListCap) {
+    for (unsigned e = tid; e < cnt * 4; e += kMmThreads) {
+      const unsigned code = s_item[e >> 2];
+      const int q = (int)(e & 3u);
+      if (code & (8u >> q)) fix_one((int)(code >> 10), (int)((code >> 4) & 63u), q);
+    }
+  } else {
+    for (int tile = wave * 16; tile < wave * 16 + 16; ++tile)
+      for (int q = 0; q < 4; ++q) fix_one(tile, lane, q);
+  }
+}
+
+template <typename T>
+int launch_mm_t(const T* in, T* out, int64_t n, int h, int w, int axis, const MmParams& P, hipStream_t st) {
+  if (axis == 0) {
+    const int col_tiles = (int)pl_cdiv(w, kVCols);
+    const int row_tiles = (int)pl_cdiv(h, kVRows);
+    const int64_t blocks = n * col_tiles * row_tiles;
+    if (blocks > 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL(gauss_v_mm<T>, dim3((unsigned)blocks), dim3(kMmThreads), 0, st, in, out, h, w, col_tiles, row_tiles, P);
+  } else {
+    const int col_tiles = (int)pl_cdiv(w, kHSeg);
+    const int64_t rows_total = n * h;
+    const int64_t blocks = pl_cdiv(pl_cdiv(rows_total, 16), kMmWaves) * col_tiles;
+    if (blocks > 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL(gauss_h_mm<T>, dim3((unsigned)blocks), dim3(kMmThreads), 0, st, in, out, rows_total, w, col_tiles, P);
+  }
+  return 0;
+}
+
+}  // namespace
+
+// 1 when pl_gauss_mm_launch covers this call's shape (the taps are checked at launch; the caller needs them in HOST memory)
+int pl_gauss_mm_covers(const void* in, const void* out, int h, int w, int axis, int radius) {
+  if (radius < 1 || radius > kMmMaxRad || h < 1) return 0;
+  if (w % 16) return 0;
+  if (axis == 0) return !((reinterpret_cast<uintptr_t>(in) & 1) || (reinterpret_cast<uintptr_t>(out) & 7));
+  return !((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 7));
+}
+
+// 0 = launched; -1 = shape / alignment / taps not covered (caller uses the other kernels).  wts: HOST memory.
+int pl_gauss_mm_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, int axis, const double* wts,
+                       int radius, hipStream_t st) {
+  if (!pl_gauss_mm_covers(in, out, h, w, axis, radius)) return -1;
+  MmParams P;
+  if (!mm_make_params(wts, radius, P)) return -1;
+  return is_signed ? launch_mm_t<short>((const short*)in, (short*)out, n, h, w, axis, P, st)
+                   : launch_mm_t<unsigned short>((const unsigned short*)in, (unsigned short*)out, n, h, w, axis, P, st);
+}

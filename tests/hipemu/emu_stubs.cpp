@@ -5,3 +5,5 @@
 
 int pl_gauss_rw_covers(const void*, const void*, int, int, int, int) { return 0; }
 int pl_gauss_rw_launch(const void*, void*, int, int64_t, int, int, int, const double*, int, hipStream_t) { return -1; }
+int pl_gauss_mm_covers(const void*, const void*, int, int, int, int) { return 0; }
+int pl_gauss_mm_launch(const void*, void*, int, int64_t, int, int, int, const double*, int, hipStream_t) { return -1; }

@@ -117,6 +117,35 @@ inline int __syncthreads_or(int p) { return hipemu::block_barrier_or(p); }
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_fract(x) ((x) - floor(x))
 #define __builtin_amdgcn_fractf(x) ((x) - floorf(x))
+// v_mfma_i32_16x16x64_i8: byte s of lane (m, g) of A meets byte s of lane (n, g) of B (m, n = lane & 15, g = lane >> 4);
+// D[m = 4 * (lane >> 4) + reg][n = lane & 15] (the layout scripts/ubench/mfma_i8.hip checks on the device).  All 64 lanes
+// must take part (the kernels call it wave-uniformly).
+typedef int hipemu_v4i __attribute__((ext_vector_type(4)));
+inline hipemu_v4i hipemu_mfma_i32_16x16x64_i8(hipemu_v4i a, hipemu_v4i b, hipemu_v4i c) {
+  uint64_t all[4][64], act;
+  uint64_t mine[4];
+  memcpy(&mine[0], &a, 16);
+  memcpy(&mine[2], &b, 16);
+  for (int q = 0; q < 4; ++q) hipemu::wave_exchange(mine[q], all[q], &act);
+  const int lane = hipemu::lane_id();
+  const int n = lane & 15;
+  hipemu_v4i d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int m = 4 * (lane >> 4) + r;
+    int acc = 0;
+    for (int g = 0; g < 4; ++g) {
+      signed char ab[16], bb[16];
+      uint64_t t[2] = {all[0][m + 16 * g], all[1][m + 16 * g]};
+      memcpy(ab, t, 16);
+      uint64_t u[2] = {all[2][n + 16 * g], all[3][n + 16 * g]};
+      memcpy(bb, u, 16);
+      for (int s = 0; s < 16; ++s) acc += (int)ab[s] * (int)bb[s];
+    }
+    d[r] = c[r] + acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, x, y, z) hipemu_mfma_i32_16x16x64_i8((a), (b), (c))
 // MUBUF raw buffer access: resource = base pointer, offsets are plain byte offsets
 struct hipemu_rsrc { char* base; };
 #define __amdgpu_buffer_rsrc_t hipemu_rsrc
