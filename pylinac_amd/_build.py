@@ -32,6 +32,11 @@ HIPCC_FLAGS = [
 ]
 
 
+# per-file additions: the matrix-core Gaussian keeps its accumulators in VGPRs (gfx950's register file is unified; the
+# default AGPR form costs one v_accvgpr_read per accumulator value the integer recombination touches)
+EXTRA_FLAGS = {"gaussian_mm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -60,7 +65,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         obj = BUILD / (src.stem + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([cc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)])
+            jobs.append([cc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)])
 
     def run(cmd):
         if verbose:

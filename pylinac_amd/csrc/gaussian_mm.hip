@@ -7,24 +7,27 @@
 // kernels (gaussian_rw.hip) decide trunc(S) with a packed-float32 chain and are VALU-issue bound at ~0.35 of the HBM
 // roofline.  Here the 41-tap sum itself moves to the matrix cores, in EXACT integer arithmetic:
 //
-//   taps     w_k = wq_k * 2^-Q + e_k,  wq_k = round(w_k * 2^Q) written in four balanced base-256 digits d0..d3 (int8),
-//            Q chosen on the host so that the largest tap fills the four digits (Q = 34 at sigma = 5)
+//   taps     w_k = wq_k * 2^-Q + e_k,  wq_k = round(w_k * 2^Q) written in FIVE balanced base-256 digits d0..d4 (int8),
+//            Q chosen on the host so that the largest tap fills the five digits (Q = 42 at sigma = 5)
 //   samples  biased value x in [0, 65535] (int16 input: x = v + 32768);  x - 32896 = 256 * hi + lo with
 //            hi = x_hi - 128, lo = x_lo - 128: BOTH digits are the raw bytes with the top bit flipped, both int8
 //   T        = sum_k wq_k * (x_k - 32896) = sum over digit pairs 256^(a+b) * sum_k d_a[k] * digit_b[x_k]:
-//            eight v_mfma_i32_16x16x64_i8 per 16 x 16 output tile (Toeplitz band of one weight digit x one sample
+//            ten v_mfma_i32_16x16x64_i8 per 16 x 16 output tile (Toeplitz band of one weight digit x one sample
 //            digit plane, K = the 64-sample window that holds the 16 + 2*RAD <= 64 inputs of 16 outputs), int32
-//            accumulation: exact, order-free
-//   S        = 2^-Q * (T + 32896 * sum wq_k) + E,  |E| <= 65535 * sum |e_k|  (7.8e-5 at sigma = 5)
+//            accumulation: exact, order-free; six accumulators a0..a5 (digit-pair scales 0, 8, .., 40 bits)
+//   S        = 2^-Q * (T + 32896 * sum wq_k) + E,  |E| <= 65535 * sum |e_k|  (3e-7 at sigma = 5)
 //
-// so floor(S) is known exactly unless frac(S) lies within delta = |E|-bound + float32 recombination slack (~1e-4) of an
-// integer; those pixels (~0.02 %, plus constant / saturated neighbourhoods where S sits 1e-11 from an integer) are listed
-// and recomputed with scipy's float64 sequence from the raw bytes still in LDS (rw_exact, as in gaussian_rw.hip).
+// so floor(S) is known exactly unless frac(S) lies within delta = the |E| bound of an integer; those pixels (~1e-5, plus
+// constant / saturated neighbourhoods where S sits 1e-11 from an integer) are listed and recomputed with scipy's float64
+// sequence from the raw bytes still in LDS.
 //
-// Recombination per output (VALU): the five int32 accumulators (digit-pair scales 0, 8, 16, 24, 32 bits) are merged as
-//   U = a3 + (a4 << 8) + C_hi               int32, scale 2^24: integer part floor(U / 2^(Q-24)) taken with a shift
-//   L = a0 + 2^8 a1 + 2^16 a2 + C_lo        float32, |L| * 2^-Q < 8: absolute error < 2e-6
-// C = 32896 * sum wq_k is folded into the accumulator initial values (the MFMA's C operand).
+// Recombination per output is INTEGER ONLY (12 shift / add / and operations, no conversions), exact by the identity
+// floor((floor(x / a) + n) / b) = floor((x + a n) / (a b)):   with C = 32896 * sum wq_k folded into the accumulators' initial
+// values (the MFMA's C operand),
+//   U  = a4 + 2^8 a5                                  scale 2^32;  U = Uh * 2^(Q-32) + Ur
+//   R  = (a2 + ((a0 + 2^8 a1) >> 16)) >> 8            = floor((a0 + 2^8 a1 + 2^16 a2) / 2^24)
+//   F  = 2^8 Ur + a3 + R                              = floor((T + C - Uh 2^Q) / 2^24)
+//   floor(S) = Uh + (F >> (Q - 24));   frac(S) * 2^(Q-24) lies in [f, f + 1) with f = F & (2^(Q-24) - 1)
 //
 // Operand layout: v_mfma_i32_16x16x64_i8 pairs byte s of lane (m, g) of A with byte s of lane (n, g) of B (m, n = lane & 15,
 // g = lane >> 4) and leaves D[m = 4 * (lane >> 4) + reg][n = lane & 15] (scripts/ubench/mfma_i8.hip checks this on the
@@ -52,19 +55,20 @@ constexpr int kMmListCap = 128;             // undecided outputs a wave / workgr
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 // Everything a pass needs, computed on the host (mm_make_params) and passed by value.
+constexpr int kMmDigits = 5;
+
 struct MmParams {
   // band[d][c][.]: the zero-padded band sequence E_d[p] = digit_d[|p - 39|] (|p - 39| <= RAD, else 0) of weight digit d,
   // shifted left by c bytes, so that a lane whose Toeplitz row starts at p0 = 16 g - i + 15 reads its 16 bytes as four
   // ALIGNED dwords band[d][p0 & 3][(p0 >> 2) .. + 3]
-  unsigned band[4][4][24];
-  float two_mq;      // 2^-Q
-  float two_m8q;     // 2^(8 - Q)
-  float two_m16q;    // 2^(16 - Q)
-  float two_msh;     // 2^-(Q - 24)
-  int sh;            // Q - 24
-  int c_hi;          // (32896 * sum wq) >> 24        -> initial value of the scale-24 accumulator
-  int c_lo;          // (32896 * sum wq) & (2^24 - 1) -> initial value of the scale-0 accumulator
-  float lim;         // 0.5 - delta
+  unsigned band[kMmDigits][4][24];
+  int sh;            // Q - 32: U = Uh * 2^sh + Ur
+  int fb;            // Q - 24: fraction bits of F
+  int c0;            // C & (2^24 - 1)        -> initial value of a0
+  int c3;            // (C >> 24) & 255       -> initial value of a3
+  int c4;            // C >> 32               -> initial value of a4        (C = 32896 * sum wq)
+  unsigned m;        // ceil(delta * 2^fb): f in [m, 2^fb - m - 1] is decided
+  unsigned lim;      // 2^fb - 2 m - 1
   int radius;
   double wd[kMmMaxRad + 1];  // float64 taps (offset j) for the exact path, zero beyond radius
 };
@@ -77,14 +81,14 @@ bool mm_make_params(const double* h_wts /* 2*R+1 taps, centre at R */, int R, Mm
     wmax = h_wts[k] > wmax ? h_wts[k] : wmax;
     W += h_wts[k];
   }
-  if (!(wmax > 0.0) || !(W < 4.0)) return false;
-  int Q = 24;
-  while (Q < 36 && __builtin_ldexp(wmax, Q + 1) < 2.0e9) ++Q;
-  if (__builtin_ldexp(wmax, Q) >= 2.0e9) return false;
+  if (!(wmax > 0.0) || !(W < 2.0)) return false;
+  int Q = 32;
+  while (Q < 46 && __builtin_ldexp(wmax, Q + 1) < 5.0e11) ++Q;   // five balanced digits hold |wq| < 127 * 2^32
+  if (__builtin_ldexp(wmax, Q) >= 5.0e11) return false;
   long long wq[2 * kMmMaxRad + 1];
   long long WQ = 0;
   double eq = 0.0;
-  signed char dig[4][kMmMaxRad + 1];
+  signed char dig[kMmDigits][kMmMaxRad + 1];
   for (int k = 0; k <= 2 * R; ++k) {
     wq[k] = (long long)__builtin_llround(__builtin_ldexp(h_wts[k], Q));
     WQ += wq[k];
@@ -93,39 +97,37 @@ bool mm_make_params(const double* h_wts /* 2*R+1 taps, centre at R */, int R, Mm
   for (int j = 0; j <= R; ++j) {
     if (wq[R - j] != wq[R + j]) return false;      // the band is built from one half: taps must be symmetric
     long long v = wq[R - j];
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < kMmDigits; ++d) {
       const long long lo = ((v + 128) & 255) - 128;
       dig[d][j] = (signed char)lo;
       v = (v - lo) >> 8;
     }
     if (v != 0) return false;
   }
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < kMmDigits; ++d)
     for (int c = 0; c < 4; ++c) {
       unsigned char bytes[96];
       for (int x = 0; x < 96; ++x) {
         const int pidx = x + c - 39;               // E[x + c], centre at 39
         const int dist = pidx < 0 ? -pidx : pidx;
-        bytes[x] = (x + c <= 78 + 16 && dist <= R) ? (unsigned char)dig[d][dist] : 0;
+        bytes[x] = dist <= R ? (unsigned char)dig[d][dist] : 0;
       }
       for (int q = 0; q < 24; ++q)
         p.band[d][c][q] = (unsigned)bytes[4 * q] | ((unsigned)bytes[4 * q + 1] << 8) | ((unsigned)bytes[4 * q + 2] << 16) |
                           ((unsigned)bytes[4 * q + 3] << 24);
     }
-  const long long C = 32896LL * WQ;
-  p.c_hi = (int)(C >> 24);
-  p.c_lo = (int)(C & 0xffffffLL);
-  if ((C >> 24) > 0x3fffffffLL) return false;
-  p.sh = Q - 24;
-  p.two_mq = (float)__builtin_ldexp(1.0, -Q);
-  p.two_m8q = (float)__builtin_ldexp(1.0, 8 - Q);
-  p.two_m16q = (float)__builtin_ldexp(1.0, 16 - Q);
-  p.two_msh = (float)__builtin_ldexp(1.0, -(Q - 24));
-  // |S_real - 2^-Q (T + C)| <= 65535 * sum|e_k|; float32 recombination < 8e-6; scipy's own rounding and the int16 bias
-  // 32768 * (W - 1) are ~1e-11
-  const double delta = 65535.0 * eq * (1.0 + 1e-9) + 8e-6 + 65536.0 * __builtin_fabs(W - 1.0) + 1e-9;
-  if (!(delta < 0.25)) return false;
-  p.lim = (float)(0.5 - delta);
+  const long long C = 32896LL * WQ;                // < 2^16 * 2^47
+  p.c0 = (int)(C & 0xffffffLL);
+  p.c3 = (int)((C >> 24) & 0xffLL);
+  p.c4 = (int)(C >> 32);
+  p.sh = Q - 32;
+  p.fb = Q - 24;
+  // |S_real - 2^-Q (T + C)| <= 65535 * sum|e_k|; scipy's own rounding and the int16 bias 32768 * (W - 1) are ~1e-11
+  const double delta = 65535.0 * eq * (1.0 + 1e-9) + 65536.0 * __builtin_fabs(W - 1.0) + 1e-9;
+  const double md = __builtin_ceil(__builtin_ldexp(delta, p.fb)) + 1.0;
+  if (!(md < __builtin_ldexp(0.25, p.fb))) return false;
+  p.m = (unsigned)md;
+  p.lim = (1u << p.fb) - 2u * p.m - 1u;
   p.radius = R;
   for (int j = 0; j <= kMmMaxRad; ++j) p.wd[j] = j <= R ? h_wts[R - j] : 0.0;
   return true;
@@ -153,53 +155,56 @@ __device__ __forceinline__ double mm_exact(F raw /* k in [-R, R] -> actual value
   return a;
 }
 
-struct MmAcc { v4i a0, a1, a2, a3, a4; };
+struct MmAcc { v4i a0, a1, a2, a3, a4, a5; };
 
-// the eight MFMAs of one tile: img_lo / img_hi = the 16 x 64 sample digit planes (as A when IMG_IS_A), w[d] = Toeplitz
+// the ten MFMAs of one tile: img_lo / img_hi = the 16 x 64 sample digit planes (as A when IMG_IS_A), w[d] = Toeplitz
 template <bool IMG_IS_A>
-__device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[4], const MmParams& P) {
+__device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[kMmDigits], const MmParams& P) {
   auto mm = [&](v4i img, v4i band, v4i c) {
     return IMG_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(img, band, c, 0, 0, 0)
                     : __builtin_amdgcn_mfma_i32_16x16x64_i8(band, img, c, 0, 0, 0);
   };
   MmAcc r;
   const v4i z = {0, 0, 0, 0};
-  r.a0 = mm(img_lo, w[0], v4i{P.c_lo, P.c_lo, P.c_lo, P.c_lo});
+  r.a0 = mm(img_lo, w[0], v4i{P.c0, P.c0, P.c0, P.c0});
   r.a1 = mm(img_lo, w[1], z);
   r.a2 = mm(img_lo, w[2], z);
-  r.a3 = mm(img_lo, w[3], v4i{P.c_hi, P.c_hi, P.c_hi, P.c_hi});
-  r.a4 = mm(img_hi, w[3], z);
+  r.a3 = mm(img_lo, w[3], v4i{P.c3, P.c3, P.c3, P.c3});
+  r.a4 = mm(img_lo, w[4], v4i{P.c4, P.c4, P.c4, P.c4});
+  r.a5 = mm(img_hi, w[4], z);
   r.a1 = mm(img_hi, w[0], r.a1);
   r.a2 = mm(img_hi, w[1], r.a2);
   r.a3 = mm(img_hi, w[2], r.a3);
+  r.a4 = mm(img_hi, w[3], r.a4);
   return r;
 }
 
-// one output from its five accumulator values: floor(S) in the biased domain (0 .. 65535) and the fail bit
-__device__ __forceinline__ unsigned mm_decide(int a0, int a1, int a2, int a3, int a4, const MmParams& P, unsigned& fail) {
-  const int U = a3 + (a4 << 8);
-  const int hi = U >> P.sh;
-  const float lo = (float)(U & ((1 << P.sh) - 1));
-  float t = lo * P.two_msh;
-  t = __builtin_fmaf((float)a0, P.two_mq, t);
-  t = __builtin_fmaf((float)a1, P.two_m8q, t);
-  t = __builtin_fmaf((float)a2, P.two_m16q, t);
-  const float fr = __builtin_amdgcn_fractf(t);
-  const float fl = t - fr;                                   // floor(t), exact
-  fail = __builtin_amdgcn_alignbit(fail, __float_as_uint(P.lim - __builtin_fabsf(fr - 0.5f)), 31);
-  return (unsigned)(hi + (int)fl);
+// one output from its six accumulator values: floor(S) in the biased domain (0 .. 65535); g = f - m (unsigned), the
+// output is decided iff g <= P.lim
+__device__ __forceinline__ unsigned mm_decide(int a0, int a1, int a2, int a3, int a4, int a5, const MmParams& P, unsigned& g) {
+  const int s = (a1 << 8) + a0;
+  const int R = (a2 + (s >> 16)) >> 8;
+  const int U = (a5 << 8) + a4;
+  const int F = ((U & ((1 << P.sh) - 1)) << 8) + a3 + R;
+  g = (unsigned)(F & ((1 << P.fb) - 1)) - P.m;
+  return (unsigned)((U >> P.sh) + (F >> P.fb));
 }
 
 // four outputs of a lane (regs 0..3 = consecutive columns) -> two dwords of packed 16-bit results in the image's own
-// domain; the four fail bits are shifted into `fail` (reg 0 first)
+// domain; fail: bit 3 - q set when output q is undecided
 template <bool SIGNED>
 __device__ __forceinline__ uint2 mm_finish(const MmAcc& r, const MmParams& P, unsigned& fail) {
-  unsigned v[4];
+  unsigned v[4], g[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    v[q] = mm_decide(r.a0[q], r.a1[q], r.a2[q], r.a3[q], r.a4[q], P, fail);
+    v[q] = mm_decide(r.a0[q], r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], P, g[q]);
     if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;   // C truncation rounds negative S toward zero
   }
+  unsigned gm = g[0] > g[1] ? g[0] : g[1];
+  gm = gm > g[2] ? gm : g[2];
+  gm = gm > g[3] ? gm : g[3];
+  fail = 0;
+  if (gm > P.lim) fail = (g[0] > P.lim ? 8u : 0u) | (g[1] > P.lim ? 4u : 0u) | (g[2] > P.lim ? 2u : 0u) | (g[3] > P.lim ? 1u : 0u);
   return uint2{__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
 }
 
@@ -273,9 +278,9 @@ gauss_h_mm(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, in
       *reinterpret_cast<uint4*>(phi + j * kHPitch + 16 * chunk) = hi;
     }
   }
-  v4i band[4];
+  v4i band[kMmDigits];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) band[d] = mm_band_operand(P, d, lane);
+  for (int d = 0; d < kMmDigits; ++d) band[d] = mm_band_operand(P, d, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -373,9 +378,9 @@ gauss_v_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_
       *reinterpret_cast<unsigned*>(s_hi + lane * kVPitch + p) = __builtin_amdgcn_perm(t1, t0, 0x07060302u) ^ kHiFlip;
     }
   }
-  v4i band[4];
+  v4i band[kMmDigits];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) band[d] = mm_band_operand(P, d, lane);
+  for (int d = 0; d < kMmDigits; ++d) band[d] = mm_band_operand(P, d, lane);
   __syncthreads();
 
   // ---- tiles: image (M = column) x Toeplitz (N = output row): lane (j, g) ends with columns 4 g .. 4 g + 3 of row j
