@@ -262,10 +262,10 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
                 "traffic": traffic,
-                "note": "dominant kernel reads+writes one u16 frame (4 MiB/frame algorithmic; PMC traffic matches); it is "
-                        "VALU-issue-bound, not HBM-bound: scipy-exact float64 accumulation decided in packed float32 on a "
-                        "wave-owned register window (37.8 VALU instructions per 64 pixels at sigma=5, VALU ~83 % busy; "
-                        "DESIGN.md section 5)",
+                "note": "dominant kernel reads+writes one u16 frame (4 MiB/frame algorithmic); gauss2d = both Gaussian axes "
+                        "in one launch, exact integer arithmetic on the matrix cores (v_mfma_i32_16x16x64_i8 over byte digit "
+                        "planes), axis-0 plane kept in LDS; bound by MFMA + integer recombination issue, not by HBM "
+                        "(DESIGN.md section 5)",
                 "pipeline_frac": round(value / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             },

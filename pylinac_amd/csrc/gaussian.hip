@@ -283,6 +283,10 @@ int pl_gauss_rw_launch(const void* in, void* out, int is_signed, int64_t n, int 
 int pl_gauss_mm_covers(const void* in, const void* out, int h, int w, int axis, int radius);
 int pl_gauss_mm_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, int axis,
                        const double* h_wts, int radius, hipStream_t st);
+// both axes in one kernel (the axis-0 result stays in LDS); same protocol
+int pl_gauss_mm2d_covers(const void* in, const void* out, int h, int w, int radius);
+int pl_gauss_mm2d_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, const double* h_wts, int radius,
+                         hipStream_t st);
 
 namespace {
 // 16-bit frames, reflect mode, radius 4 / 8 / 12 / 20, even width (axis 0) or width % 16 == 0 (axis 1): the register-
@@ -368,6 +372,20 @@ extern "C" int pl_gaussian2d_mode(const void* in, void* out, void* tmp, int dtyp
 extern "C" int pl_gaussian2d(const void* in, void* out, void* tmp, int dtype, int64_t n, int h, int w,
                              const double* d_weights, const double* h_weights, int radius, void* stream) {
   PL_REQUIRE(tmp && tmp != in && tmp != out, "tmp must be a distinct buffer");
+  if ((dtype == PL_U16 || dtype == PL_I16) && in && out && d_weights && in != out && n > 0 && h > 0 && w > 0 &&
+      pl_gauss_mm2d_covers(in, out, h, w, radius)) {
+    hipStream_t st = (hipStream_t)stream;
+    double fetched[49];
+    if (!h_weights) {  // no host copy of the taps: fetch them (synchronises the stream)
+      if (hipMemcpyAsync(fetched, d_weights, (size_t)(2 * radius + 1) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess) {
+        pl_set_error("pl_gaussian2d: fetching the taps failed: %s", hipGetErrorString(hipGetLastError()));
+        return PL_ERR_HIP;
+      }
+      h_weights = fetched;
+    }
+    if (pl_gauss_mm2d_launch(in, out, dtype == PL_I16, n, h, w, h_weights, radius, st) == 0) return pl_check_launch("pl_gaussian2d");
+  }
   int rc = pl_gaussian1d(in, tmp, dtype, n, h, w, 0, d_weights, h_weights, radius, stream);
   if (rc != PL_OK) return rc;
   return pl_gaussian1d(tmp, out, dtype, n, h, w, 1, d_weights, h_weights, radius, stream);

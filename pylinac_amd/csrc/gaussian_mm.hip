@@ -17,17 +17,19 @@
 //            accumulation: exact, order-free; six accumulators a0..a5 (digit-pair scales 0, 8, .., 40 bits)
 //   S        = 2^-Q * (T + 32896 * sum wq_k) + E,  |E| <= 65535 * sum |e_k|  (3e-7 at sigma = 5)
 //
-// so floor(S) is known exactly unless frac(S) lies within delta = the |E| bound of an integer; those pixels (~1e-5, plus
+// so floor(S) is known exactly unless frac(S) lies within delta = the |E| bound of an integer; those pixels (~1e-6, plus
 // constant / saturated neighbourhoods where S sits 1e-11 from an integer) are listed and recomputed with scipy's float64
 // sequence from the raw bytes still in LDS.
 //
-// Recombination per output is INTEGER ONLY (12 shift / add / and operations, no conversions), exact by the identity
+// Recombination per output is INTEGER ONLY (a dozen shift / add / and operations, no conversions), exact by the identity
 // floor((floor(x / a) + n) / b) = floor((x + a n) / (a b)):   with C = 32896 * sum wq_k folded into the accumulators' initial
 // values (the MFMA's C operand),
 //   U  = a4 + 2^8 a5                                  scale 2^32;  U = Uh * 2^(Q-32) + Ur
-//   R  = (a2 + ((a0 + 2^8 a1) >> 16)) >> 8            = floor((a0 + 2^8 a1 + 2^16 a2) / 2^24)
-//   F  = 2^8 Ur + a3 + R                              = floor((T + C - Uh 2^Q) / 2^24)
-//   floor(S) = Uh + (F >> (Q - 24));   frac(S) * 2^(Q-24) lies in [f, f + 1) with f = F & (2^(Q-24) - 1)
+//   t  = a2 + ((a0 + 2^8 a1) >> 16)                   = floor((a0 + 2^8 a1 + 2^16 a2) / 2^16)
+//   F  = 2^16 Ur + 2^8 a3 + t                         = floor((T + C - Uh 2^Q) / 2^16)
+//   floor(S) = Uh + (F >> (Q - 16));   frac(S) * 2^(Q-16) lies in [f, f + 1) with f = F & (2^(Q-16) - 1)
+// The fraction is resolved to 2^-(Q-16) (1.5e-8 at sigma = 5), well below the tap-rounding bound delta, so an output is
+// undecided only when frac(S) really lies within ~delta of an integer (~1e-6 of the pixels).
 //
 // Operand layout: v_mfma_i32_16x16x64_i8 pairs byte s of lane (m, g) of A with byte s of lane (n, g) of B (m, n = lane & 15,
 // g = lane >> 4) and leaves D[m = 4 * (lane >> 4) + reg][n = lane & 15] (scripts/ubench/mfma_i8.hip checks this on the
@@ -63,7 +65,7 @@ struct MmParams {
   // ALIGNED dwords band[d][p0 & 3][(p0 >> 2) .. + 3]
   unsigned band[kMmDigits][4][24];
   int sh;            // Q - 32: U = Uh * 2^sh + Ur
-  int fb;            // Q - 24: fraction bits of F
+  int fb;            // Q - 16: fraction bits of F
   int c0;            // C & (2^24 - 1)        -> initial value of a0
   int c3;            // (C >> 24) & 255       -> initial value of a3
   int c4;            // C >> 32               -> initial value of a4        (C = 32896 * sum wq)
@@ -121,7 +123,7 @@ bool mm_make_params(const double* h_wts /* 2*R+1 taps, centre at R */, int R, Mm
   p.c3 = (int)((C >> 24) & 0xffLL);
   p.c4 = (int)(C >> 32);
   p.sh = Q - 32;
-  p.fb = Q - 24;
+  p.fb = Q - 16;
   // |S_real - 2^-Q (T + C)| <= 65535 * sum|e_k|; scipy's own rounding and the int16 bias 32768 * (W - 1) are ~1e-11
   const double delta = 65535.0 * eq * (1.0 + 1e-9) + 65536.0 * __builtin_fabs(W - 1.0) + 1e-9;
   const double md = __builtin_ceil(__builtin_ldexp(delta, p.fb)) + 1.0;
@@ -183,9 +185,9 @@ __device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[
 // output is decided iff g <= P.lim
 __device__ __forceinline__ unsigned mm_decide(int a0, int a1, int a2, int a3, int a4, int a5, const MmParams& P, unsigned& g) {
   const int s = (a1 << 8) + a0;
-  const int R = (a2 + (s >> 16)) >> 8;
+  const int t = a2 + (s >> 16);
   const int U = (a5 << 8) + a4;
-  const int F = ((U & ((1 << P.sh) - 1)) << 8) + a3 + R;
+  const int F = ((U & ((1 << P.sh) - 1)) << 16) + (a3 << 8) + t;
   g = (unsigned)(F & ((1 << P.fb) - 1)) - P.m;
   return (unsigned)((U >> P.sh) + (F >> P.fb));
 }
@@ -432,6 +434,288 @@ gauss_v_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_
   }
 }
 
+// ------------------------------------------------------------------ both axes in ONE kernel: the marching strip
+// scipy.ndimage.gaussian_filter on a 16-bit frame is axis 0 into the 16-bit output, then axis 1 on THAT (truncated) plane.
+// A workgroup owns a strip of 256 output columns (+ 24 halo columns each side) and marches down a segment of rows, 16
+// output rows per step:
+//   - five row-group slots of the INPUT digit planes live in LDS ([slot][column cell: 16 rows x 1 column = 16 bytes]); four
+//     are under the axis-0 MFMAs of the step while the fifth receives the row group the NEXT step needs (buffer loads
+//     issued before the step's MFMAs, split into planes and written after them);
+//   - the axis-0 tiles (19 per step: 304 window columns) leave their truncated 16-bit results as digit planes in a
+//     double-buffered 16-row x 304-column LDS plane ([row][column bytes]) -- the intermediate frame never goes to HBM;
+//   - one workgroup barrier per step; then the axis-1 tiles (16 per step) read that plane and store the output rows.
+// HBM traffic: the frame read once (x 304/256 for the column halo, + 48 rows per segment), written once -- half of the
+// two-pass form.  The tile loops are straight-line code: the MFMAs of tile i + 1 are issued before the integer
+// recombination of tile i, no branch in between (border reflection by arithmetic, stores beyond the segment dropped by
+// the buffer's bounds check, tiles beyond a partial strip recompute tile 0).  Undecided outputs (~1e-6 of the pixels, and
+// whole tiles of constant input, which take one wave-uniform evaluation) are recomputed after the loop with scipy's
+// float64 sequence from the plane bytes and overwrite what the loop stored.
+constexpr int kFCols = 256;                       // output columns per strip
+constexpr int kFWin = kFCols + 2 * kMmHalo;       // 304 window columns
+constexpr int kFSlots = 5;                        // row-group slots
+constexpr int kFPlane = kFWin * 16;               // bytes of one plane of one row group (= one 16-row axis-0 result plane)
+constexpr int kFQuadPitch = (kFWin / 4) * 16;     // byte distance between the cells of columns c and c + 1 (same c >> 2)
+constexpr int kFInLo = 0;                         // LDS map
+constexpr int kFInHi = kFInLo + kFSlots * kFPlane;
+constexpr int kFVLo = kFInHi + kFSlots * kFPlane;
+constexpr int kFVHi = kFVLo + 2 * kFPlane;
+constexpr int kFLds = kFVHi + 2 * kFPlane;        // 68096 bytes: two workgroups per CU
+
+// byte offset of column c's cell inside a row-group plane: cells ordered [c & 3][c >> 2] -- the four columns a lane
+// splits land 76 cells apart (ds_write_b32: 64 lanes -> 64 banks) and the 16 columns of a tile read conflict-free b128s
+__device__ __forceinline__ int f_cell(int c) { return kFQuadPitch * (c & 3) + 16 * (c >> 2); }
+
+struct FQuad { uint2 r[4]; };                     // 4 rows x 4 columns of raw 16-bit samples
+
+// element q (0..3) of a lane's packed four results
+__device__ __forceinline__ void mm_set(uint2& res, int q, unsigned v16) {
+  unsigned d = q < 2 ? res.x : res.y;
+  d = (q & 1) ? (d & 0x0000ffffu) | (v16 << 16) : (d & 0xffff0000u) | v16;
+  if (q < 2) res.x = d; else res.y = d;
+}
+
+// true when the lane's two 16-byte operands are one repeated byte each AND every lane of the wave holds the same two bytes
+__device__ __forceinline__ bool mm_wave_flat(const uint4& lo, const uint4& hi) {
+  const unsigned l0 = lo.x, h0 = hi.x;
+  const unsigned lf = __builtin_amdgcn_readfirstlane(l0), hf = __builtin_amdgcn_readfirstlane(h0);   // every lane takes part
+  const unsigned d = (lo.y ^ l0) | (lo.z ^ l0) | (lo.w ^ l0) | (hi.y ^ h0) | (hi.z ^ h0) | (hi.w ^ h0) |
+                     (__builtin_amdgcn_alignbit(l0, l0, 8) ^ l0) | (__builtin_amdgcn_alignbit(h0, h0, 8) ^ h0) | (lf ^ l0) | (hf ^ h0);
+  return __ballot(d != 0u) == 0ull;
+}
+
+// four outputs of a lane, branch-free: packed results and ONE flag (some output of the four is undecided)
+template <bool SIGNED>
+__device__ __forceinline__ uint2 mm_finish_flag(const MmAcc& r, const MmParams& P, bool& bad) {
+  unsigned v[4], g[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = mm_decide(r.a0[q], r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], P, g[q]);
+    if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;
+  }
+  unsigned gm = g[0] > g[1] ? g[0] : g[1];
+  gm = gm > g[2] ? gm : g[2];
+  gm = gm > g[3] ? gm : g[3];
+  bad = gm > P.lim;
+  return uint2{__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kMmThreads)
+gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int strips, int segs, int seg_rows, const MmParams P) {
+  constexpr bool kSigned = (T)-1 < (T)0;
+  constexpr unsigned kHiFlip = kSigned ? 0u : 0x80808080u;     // int16: the signed high byte already is x_hi - 128
+  __shared__ __attribute__((aligned(16))) unsigned char s_mem[kFLds];
+
+  unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = id % strips;
+  id /= strips;
+  const int rt = id % segs;
+  const size_t frame = id / segs;
+  const int tid = threadIdx.x;
+  const int lane = tid & (PL_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / PL_WAVE);
+  const int j = lane & 15, g = lane >> 4;
+  const int c0 = ct * kFCols, r_begin = rt * seg_rows;
+  const int r_end = r_begin + seg_rows < h ? r_begin + seg_rows : h;
+  const int nsteps = (r_end - r_begin + 15) / 16;
+  if (nsteps <= 0) return;
+  const T* f = in + frame * (size_t)h * w;
+  const int wcols = w - c0 < kFCols ? w - c0 : kFCols;      // output columns of this strip (a multiple of 16)
+  const int nvt = wcols / 16 + 3;                            // axis-0 tiles the axis-1 windows reach
+  const int nht = wcols / 16;
+  const __amdgpu_buffer_rsrc_t src = pl_make_rsrc(f);
+  // the segment's output rows as a bounded buffer: a store whose offset lies beyond it is dropped
+  const __amdgpu_buffer_rsrc_t dstb = pl_make_rsrc_bounded(out + (frame * (size_t)h + r_begin) * w, (unsigned)(r_end - r_begin) * (unsigned)w * 2u);
+
+  // ---- who loads what: wave v splits column quads 16 v .. 16 v + 15 (lane & 15) x row quad (lane >> 4) of every row
+  // group; wave 3, which has one axis-0 tile less, also takes the twelve quads 64 .. 75.  A quad lies wholly inside or
+  // wholly outside the frame (w % 4 == 0); outside, the MIRRORED quad is loaded and its four columns land in reverse.
+  const int rq = g;
+  struct QuadPlace { unsigned colb; int d0, dstep; bool on; };
+  auto place = [&](int cqx, bool on) {
+    const int col0 = c0 - kMmHalo + 4 * cqx;
+    const bool mir = col0 < 0 || col0 >= w;
+    const int mc = col0 < 0 ? -col0 - 4 : (col0 >= w ? 2 * w - 4 - col0 : col0);
+    QuadPlace q;
+    q.colb = 2u * (unsigned)mc;
+    q.d0 = 16 * cqx + 4 * rq + (mir ? 3 * kFQuadPitch : 0);
+    q.dstep = mir ? -kFQuadPitch : kFQuadPitch;
+    q.on = on && 4 * cqx < 16 * nvt;
+    return q;
+  };
+  const QuadPlace qa = place(16 * wave + j, true), qb = place(64 + j, wave == 3 && j < 12);
+  const unsigned wb = 2u * (unsigned)w;
+  auto load_quad = [&](const QuadPlace& q, int k, FQuad& x) {
+    if (!q.on) return;
+    const int rbase = r_begin - kMmHalo + 16 * k + 4 * rq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int r = rbase + i;
+      r ^= r >> 31;                                          // -r - 1 below the frame
+      const int r2 = 2 * h - 1 - r;
+      r = r < r2 ? r : r2;                                   // 2 h - 1 - r above it (one reflection: h >= 64)
+      x.r[i] = pl_buffer_load_u64(src, (unsigned)r * wb + q.colb, 0);
+    }
+  };
+  auto store_quad = [&](const QuadPlace& q, int k, const FQuad& x) {
+    if (!q.on) return;
+    unsigned char* base = s_mem + kFInLo + (k % kFSlots) * kFPlane + q.d0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const unsigned a0 = half ? x.r[0].y : x.r[0].x, a1 = half ? x.r[1].y : x.r[1].x;
+      const unsigned a2 = half ? x.r[2].y : x.r[2].x, a3 = half ? x.r[3].y : x.r[3].x;
+      const unsigned e0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u);   // even element: {lo r0, lo r1, hi r0, hi r1}
+      const unsigned e1 = __builtin_amdgcn_perm(a3, a2, 0x05010400u);
+      const unsigned o0 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);   // odd element
+      const unsigned o1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+      unsigned char* pe = base + (2 * half) * q.dstep;
+      unsigned char* po = base + (2 * half + 1) * q.dstep;
+      *reinterpret_cast<unsigned*>(pe) = __builtin_amdgcn_perm(e1, e0, 0x05040100u) ^ 0x80808080u;
+      *reinterpret_cast<unsigned*>(pe + (kFInHi - kFInLo)) = __builtin_amdgcn_perm(e1, e0, 0x07060302u) ^ kHiFlip;
+      *reinterpret_cast<unsigned*>(po) = __builtin_amdgcn_perm(o1, o0, 0x05040100u) ^ 0x80808080u;
+      *reinterpret_cast<unsigned*>(po + (kFInHi - kFInLo)) = __builtin_amdgcn_perm(o1, o0, 0x07060302u) ^ kHiFlip;
+    }
+  };
+  {
+    FQuad a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { load_quad(qa, k, a[k]); load_quad(qb, k, b[k]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { store_quad(qa, k, a[k]); store_quad(qb, k, b[k]); }
+  }
+  v4i band[kMmDigits];
+#pragma unroll
+  for (int d = 0; d < kMmDigits; ++d) band[d] = mm_band_operand(P, d, lane);
+  __syncthreads();
+
+  const int lane_cell = f_cell(j);                 // cell of column 16 t + j, less the tile's 64 t bytes
+  int slot_g = g;                                  // slot of row group s + g
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    FQuad na, nb;
+    if (more) { load_quad(qa, s + 4, na); load_quad(qb, s + 4, nb); }
+    const int vb = (s & 1) * kFPlane;
+    const int lrow = 16 * s + j;                   // the lane's output row inside the segment, both passes
+    const bool row_ok = r_begin + lrow < r_end;
+
+    // ---- axis 0: image (M = column 16 t + m) x Toeplitz (N = output row): lane (j, g) gets columns 16 t + 4 g .. + 3 of row j
+    {
+      const unsigned char* ain = s_mem + kFInLo + slot_g * kFPlane + lane_cell;
+      unsigned char* vout = s_mem + kFVLo + vb + j * kFWin + 4 * g;
+      auto tile_of = [&](int i) { const int t = wave + 4 * i; return t < nvt ? t : 0; };
+      auto run = [&](auto NT) {
+        constexpr int N = decltype(NT)::value;
+        unsigned badbits = 0;
+        uint4 qlo = *reinterpret_cast<const uint4*>(ain + 64 * tile_of(0));
+        uint4 qhi = *reinterpret_cast<const uint4*>(ain + 64 * tile_of(0) + (kFInHi - kFInLo));
+        MmAcc acc = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          MmAcc nxt;
+          if (i + 1 < N) {
+            qlo = *reinterpret_cast<const uint4*>(ain + 64 * tile_of(i + 1));
+            qhi = *reinterpret_cast<const uint4*>(ain + 64 * tile_of(i + 1) + (kFInHi - kFInLo));
+            nxt = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+          }
+          bool bad;
+          const uint2 res = mm_finish_flag<kSigned>(acc, P, bad);
+          badbits |= (bad && row_ok) ? (1u << i) : 0u;
+          unsigned char* vd = vout + 16 * tile_of(i);
+          *reinterpret_cast<unsigned*>(vd) = __builtin_amdgcn_perm(res.y, res.x, 0x06040200u) ^ 0x80808080u;
+          *reinterpret_cast<unsigned*>(vd + (kFVHi - kFVLo)) = __builtin_amdgcn_perm(res.y, res.x, 0x07050301u) ^ kHiFlip;
+          if (i + 1 < N) acc = nxt;
+        }
+        if (__ballot(badbits != 0u) == 0ull) return;
+        // ---- undecided outputs of the wave's tiles (rare): scipy's float64 sequence from the input plane bytes
+        auto sample = [&](int x, int p) {          // window column x, plane row p (0 .. 63) of this step
+          const int a = ((s + (p >> 4)) % kFSlots) * kFPlane + f_cell(x) + (p & 15);
+          return mm_value<kSigned>(s_mem[kFInLo + a], s_mem[kFInHi + a]);
+        };
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+          if (__ballot((badbits >> i) & 1u) == 0ull) continue;
+          const int t = tile_of(i);
+          unsigned char* vd = vout + 16 * t;
+          const uint4 flo = *reinterpret_cast<const uint4*>(ain + 64 * t);
+          const uint4 fhi = *reinterpret_cast<const uint4*>(ain + 64 * t + (kFInHi - kFInLo));
+          if (mm_wave_flat(flo, fhi)) {            // constant input under the whole tile: one value for every output
+            const double c = sample(16 * t, 0);
+            const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int) { return c; }, P));
+            *reinterpret_cast<unsigned*>(vd) = (0x01010101u * (v & 255u)) ^ 0x80808080u;
+            *reinterpret_cast<unsigned*>(vd + (kFVHi - kFVLo)) = (0x01010101u * (v >> 8)) ^ kHiFlip;
+          } else if ((badbits >> i) & 1u) {
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+              const int x = 16 * t + 4 * g + q;
+              const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(x, kMmHalo + j + k); }, P));
+              vd[q] = (unsigned char)((v & 255u) ^ 0x80u);
+              vd[q + (kFVHi - kFVLo)] = (unsigned char)((v >> 8) ^ (kHiFlip & 0x80u));
+            }
+          }
+        }
+      };
+      if (wave == 3) run(std::integral_constant<int, 4>{}); else run(std::integral_constant<int, 5>{});
+    }
+    if (more) { store_quad(qa, s + 4, na); store_quad(qb, s + 4, nb); }
+    __syncthreads();
+
+    // ---- axis 1: Toeplitz (M = output column) x image (N = row j): lane (j, g) gets columns 16 t + 4 g .. + 3 of row j
+    {
+      const unsigned char* bin = s_mem + kFVLo + vb + j * kFWin + 16 * g;
+      // byte offset of the lane's first column inside the segment's output rows; rows beyond the segment: dropped
+      const unsigned doff = row_ok ? ((unsigned)lrow * (unsigned)w + (unsigned)(c0 + 4 * g)) * 2u : 0x80000000u;
+      auto tile_of = [&](int i) { const int t = 4 * wave + i; return t < nht ? t : 0; };
+      constexpr int N = 4;
+      unsigned badbits = 0;
+      uint4 qlo = *reinterpret_cast<const uint4*>(bin + 16 * tile_of(0));
+      uint4 qhi = *reinterpret_cast<const uint4*>(bin + 16 * tile_of(0) + (kFVHi - kFVLo));
+      MmAcc acc = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        MmAcc nxt;
+        if (i + 1 < N) {
+          qlo = *reinterpret_cast<const uint4*>(bin + 16 * tile_of(i + 1));
+          qhi = *reinterpret_cast<const uint4*>(bin + 16 * tile_of(i + 1) + (kFVHi - kFVLo));
+          nxt = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+        }
+        bool bad;
+        const uint2 res = mm_finish_flag<kSigned>(acc, P, bad);
+        badbits |= (bad && row_ok) ? (1u << i) : 0u;
+        pl_buffer_store_u64(res, dstb, doff + 32u * (unsigned)tile_of(i), 0);
+        if (i + 1 < N) acc = nxt;
+      }
+      if (__ballot(badbits != 0u) != 0ull) {
+        auto sample = [&](int row, int x) {        // row of the step, window column x
+          const int a = vb + row * kFWin + x;
+          return mm_value<kSigned>(s_mem[kFVLo + a], s_mem[kFVHi + a]);
+        };
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+          if (__ballot((badbits >> i) & 1u) == 0ull) continue;
+          const int t = tile_of(i);
+          const uint4 flo = *reinterpret_cast<const uint4*>(bin + 16 * t);
+          const uint4 fhi = *reinterpret_cast<const uint4*>(bin + 16 * t + (kFVHi - kFVLo));
+          if (mm_wave_flat(flo, fhi)) {
+            const double c = sample(0, 16 * t);
+            const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int) { return c; }, P));
+            pl_buffer_store_u64(uint2{v | (v << 16), v | (v << 16)}, dstb, doff + 32u * (unsigned)t, 0);
+          } else if ((badbits >> i) & 1u) {
+            uint2 res{0u, 0u};
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+              const int x = kMmHalo + 16 * t + 4 * g + q;
+              mm_set(res, q, (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(j, x + k); }, P)));
+            }
+            pl_buffer_store_u64(res, dstb, doff + 32u * (unsigned)t, 0);
+          }
+        }
+      }
+    }
+    slot_g = slot_g == kFSlots - 1 ? 0 : slot_g + 1;
+  }
+}
+
 template <typename T>
 int launch_mm_t(const T* in, T* out, int64_t n, int h, int w, int axis, const MmParams& P, hipStream_t st) {
   if (axis == 0) {
@@ -450,7 +734,42 @@ int launch_mm_t(const T* in, T* out, int64_t n, int h, int w, int axis, const Mm
   return 0;
 }
 
+template <typename T>
+int launch_mm2d_t(const T* in, T* out, int64_t n, int h, int w, const MmParams& P, hipStream_t st) {
+  const int strips = (int)pl_cdiv(w, kFCols);
+  // row segments: enough workgroups to fill the chip several times over, at least 128 rows each (every segment re-reads
+  // 48 halo rows and pays the four-group prologue)
+  int64_t segs = pl_cdiv(2048, n * strips);
+  const int64_t max_segs = h / 128 > 1 ? h / 128 : 1;
+  segs = segs < 1 ? 1 : (segs > max_segs ? max_segs : segs);
+  const int seg_rows = (int)(pl_cdiv(pl_cdiv(h, segs), 16) * 16);
+  segs = pl_cdiv(h, seg_rows);
+  const int64_t blocks = n * strips * segs;
+  if (blocks > 0x7fffffffLL) return -1;
+  hipLaunchKernelGGL(gauss2d_mm<T>, dim3((unsigned)blocks), dim3(kMmThreads), 0, st, in, out, h, w, strips, (int)segs,
+                     seg_rows, P);
+  return 0;
+}
+
 }  // namespace
+
+// 1 when pl_gauss_mm2d_launch covers this call's shape: both axes in one kernel (16-bit frames, reflect borders)
+int pl_gauss_mm2d_covers(const void* in, const void* out, int h, int w, int radius) {
+  // h, w >= 64: every row / column the 24-wide halos reach is at most ONE reflection away (the kernel reflects by
+  // arithmetic); frames below 2 GiB: 32-bit buffer offsets, 0x80000000 + tile offset stays out of range
+  if (radius < 1 || radius > kMmMaxRad || h < 64 || w < 64 || (w % 16) || (int64_t)h * w * 2 >= 0x7fff0000LL) return 0;
+  return !((reinterpret_cast<uintptr_t>(in) & 7) || (reinterpret_cast<uintptr_t>(out) & 7));
+}
+
+// 0 = launched; -1 = shape / alignment / taps not covered (the caller runs the two passes).  wts: HOST memory.
+int pl_gauss_mm2d_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, const double* wts, int radius,
+                         hipStream_t st) {
+  if (!pl_gauss_mm2d_covers(in, out, h, w, radius)) return -1;
+  MmParams P;
+  if (!mm_make_params(wts, radius, P)) return -1;
+  return is_signed ? launch_mm2d_t<short>((const short*)in, (short*)out, n, h, w, P, st)
+                   : launch_mm2d_t<unsigned short>((const unsigned short*)in, (unsigned short*)out, n, h, w, P, st);
+}
 
 // 1 when pl_gauss_mm_launch covers this call's shape (the taps are checked at launch; the caller needs them in HOST memory)
 int pl_gauss_mm_covers(const void* in, const void* out, int h, int w, int axis, int radius) {

@@ -102,6 +102,20 @@ __device__ __forceinline__ void pl_buffer_store_u32(unsigned v, __amdgpu_buffer_
   __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)lane_off, (int)uniform_off, 0);
 }
 
+// 8-byte forms, and a BOUNDED resource: an access whose lane offset lies at or beyond `bytes` is dropped by the hardware's
+// range check (stores vanish, loads return 0) -- predication without a branch
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pl_make_rsrc_bounded(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint2 pl_buffer_load_u64(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uniform_off) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)uniform_off, 0);
+  return uint2{(unsigned)v[0], (unsigned)v[1]};
+}
+__device__ __forceinline__ void pl_buffer_store_u64(uint2 v, __amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uniform_off) {
+  typedef unsigned pl_v2u __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(pl_v2u{v.x, v.y}, r, (int)lane_off, (int)uniform_off, 0);
+}
+
 // wave-level reductions (64 lanes, xor butterflies -> every lane holds the result)
 template <typename T, typename F>
 __device__ __forceinline__ T pl_wave_reduce(T v, F f) {

@@ -25,7 +25,7 @@ from ._lib import check
 RECORD_FIELDS = ("otsu_threshold", "n_peaks", "peak_idx", "peak_height", "prominence",
                  "left_edge", "right_edge", "center", "width")
 
-STAGES = ("gauss_v", "gauss_h", "median3", "otsu16", "threshold_colsum", "colsum_to_mean", "find_peaks", "fwxm_record")
+STAGES = ("gauss2d", "median3", "otsu16", "threshold_colsum", "colsum_to_mean", "find_peaks", "fwxm_record")
 
 
 @dataclass
@@ -113,11 +113,10 @@ class EpidPipeline:
                                                                    pk.right_bases, pk.props, pk.status))
 
         def filters(lo, m, stream):
-            """Image.filter(sigma, "gaussian"): axis 0 then axis 1, frames [lo, lo+m)."""
+            """Image.filter(sigma, "gaussian"): axis 0 then axis 1 in ONE launch (the axis-0 plane stays in LDS), frames
+            [lo, lo+m); buf_a is the two-pass fallback's scratch."""
             st, o = stream.cuda_stream, lo * fb
-            stage("gauss_v", lambda: lib.pl_gaussian1d(xp + o, ap + o, U16, m, h, w, 0, wts, hwts, self.radius, st),
-                  stream)
-            stage("gauss_h", lambda: lib.pl_gaussian1d(ap + o, bp + o, U16, m, h, w, 1, wts, hwts, self.radius, st),
+            stage("gauss2d", lambda: lib.pl_gaussian2d(xp + o, bp + o, ap + o, U16, m, h, w, wts, hwts, self.radius, st),
                   stream)
 
         def rest(lo, m, stream):

@@ -4,7 +4,6 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/mm
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 120 scripts/ubench/mfma_i8 2>&1 | tee $OUT/mfma_i8.txt
 timeout 600 python -m pytest tests -q -m gpu -p no:cacheprovider -rf -k "gaussian or filters or pipeline or smoke or epid" > $OUT/pytest.log 2>&1
 echo "pytest rc=$? $(tail -1 $OUT/pytest.log)" | tee -a $OUT/summary.txt
 grep -E "^FAILED|^ERROR" $OUT/pytest.log | head -20 | tee -a $OUT/summary.txt

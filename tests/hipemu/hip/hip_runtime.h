@@ -146,17 +146,28 @@ inline hipemu_v4i hipemu_mfma_i32_16x16x64_i8(hipemu_v4i a, hipemu_v4i b, hipemu
   return d;
 }
 #define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, x, y, z) hipemu_mfma_i32_16x16x64_i8((a), (b), (c))
-// MUBUF raw buffer access: resource = base pointer, offsets are plain byte offsets
-struct hipemu_rsrc { char* base; };
+// MUBUF raw buffer access: resource = base pointer + num_records; offsets are plain byte offsets; an access whose lane
+// offset reaches num_records is dropped (loads return 0), as the hardware's range check does for raw buffers
+struct hipemu_rsrc { char* base; unsigned num; };
 #define __amdgpu_buffer_rsrc_t hipemu_rsrc
-inline hipemu_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return hipemu_rsrc{(char*)p}; }
+inline hipemu_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num, int) { return hipemu_rsrc{(char*)p, (unsigned)num}; }
+inline bool hipemu_in_range(hipemu_rsrc r, int voff, unsigned size) { return (unsigned long long)(unsigned)voff + size <= (unsigned long long)r.num; }
 inline unsigned __builtin_amdgcn_raw_buffer_load_b32(hipemu_rsrc r, int voff, int soff, int) {
-  unsigned v;
-  memcpy(&v, r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, 4);
+  unsigned v = 0;
+  if (hipemu_in_range(r, voff, 4)) memcpy(&v, r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, 4);
   return v;
 }
 inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, hipemu_rsrc r, int voff, int soff, int) {
-  memcpy(r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, &v, 4);
+  if (hipemu_in_range(r, voff, 4)) memcpy(r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, &v, 4);
+}
+typedef unsigned hipemu_v2u __attribute__((ext_vector_type(2)));
+inline hipemu_v2u __builtin_amdgcn_raw_buffer_load_b64(hipemu_rsrc r, int voff, int soff, int) {
+  hipemu_v2u v = {0u, 0u};
+  if (hipemu_in_range(r, voff, 8)) memcpy(&v, r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, 8);
+  return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_v2u v, hipemu_rsrc r, int voff, int soff, int) {
+  if (hipemu_in_range(r, voff, 8)) memcpy(r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, &v, 8);
 }
 // v_alignbit_b32: low 32 bits of ({hi, lo} >> (s & 31))
 #define __builtin_amdgcn_alignbit(hi, lo, s) \
