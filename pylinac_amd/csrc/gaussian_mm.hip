@@ -12,24 +12,27 @@
 //   samples  biased value x in [0, 65535] (int16 input: x = v + 32768);  x - 32896 = 256 * hi + lo with
 //            hi = x_hi - 128, lo = x_lo - 128: BOTH digits are the raw bytes with the top bit flipped, both int8
 //   T        = sum_k wq_k * (x_k - 32896) = sum over digit pairs 256^(a+b) * sum_k d_a[k] * digit_b[x_k]:
-//            ten v_mfma_i32_16x16x64_i8 per 16 x 16 output tile (Toeplitz band of one weight digit x one sample
+//            NINE v_mfma_i32_16x16x64_i8 per 16 x 16 output tile (Toeplitz band of one weight digit x one sample
 //            digit plane, K = the 64-sample window that holds the 16 + 2*RAD <= 64 inputs of 16 outputs), int32
-//            accumulation: exact, order-free; six accumulators a0..a5 (digit-pair scales 0, 8, .., 40 bits)
-//   S        = 2^-Q * (T + 32896 * sum wq_k) + E,  |E| <= 65535 * sum |e_k|  (3e-7 at sigma = 5)
+//            accumulation: exact, order-free; five accumulators a1..a5 (digit-pair scales 8, 16, .., 40 bits).  The tenth
+//            product (low sample digit x lowest weight digit, scale 0) is worth at most 1.5e-7 of a grey level: it is
+//            left out and its bound is part of delta
+//   S        = 2^-Q * (T + 32896 * sum wq_k) + E,  |E| <= 65535 * sum |e_k| + the dropped product  (4.5e-7 at sigma = 5)
 //
 // so floor(S) is known exactly unless frac(S) lies within delta = the |E| bound of an integer; those pixels (~1e-6, plus
-// constant / saturated neighbourhoods where S sits 1e-11 from an integer) are listed and recomputed with scipy's float64
-// sequence from the raw bytes still in LDS.
+// constant / saturated neighbourhoods where S sits 1e-11 from an integer) are recomputed with scipy's float64 sequence
+// from the plane bytes still in LDS.
 //
-// Recombination per output is INTEGER ONLY (a dozen shift / add / and operations, no conversions), exact by the identity
-// floor((floor(x / a) + n) / b) = floor((x + a n) / (a b)):   with C = 32896 * sum wq_k folded into the accumulators' initial
-// values (the MFMA's C operand),
+// Recombination per output is INTEGER ONLY (ten shift / add / and operations, no conversions), exact by the identity
+// floor((floor(x / a) + n) / b) = floor((x + a n) / (a b)).   With C' = 32896 * sum wq_k + M folded into the accumulators'
+// initial values (the MFMA's C operand; M = m 2^16 >= delta 2^Q + 2^16 shifts the undecided band [-delta, delta] around
+// every integer to [0, 2 m) of the fraction field),
 //   U  = a4 + 2^8 a5                                  scale 2^32;  U = Uh * 2^(Q-32) + Ur
-//   t  = a2 + ((a0 + 2^8 a1) >> 16)                   = floor((a0 + 2^8 a1 + 2^16 a2) / 2^16)
-//   F  = 2^16 Ur + 2^8 a3 + t                         = floor((T + C - Uh 2^Q) / 2^16)
-//   floor(S) = Uh + (F >> (Q - 16));   frac(S) * 2^(Q-16) lies in [f, f + 1) with f = F & (2^(Q-16) - 1)
-// The fraction is resolved to 2^-(Q-16) (1.5e-8 at sigma = 5), well below the tap-rounding bound delta, so an output is
-// undecided only when frac(S) really lies within ~delta of an integer (~1e-6 of the pixels).
+//   t  = a2 + (a1 >> 8)                               = floor((2^8 a1 + 2^16 a2) / 2^16)
+//   F  = 2^16 Ur + 2^8 a3 + t                         = floor((T + C' - Uh 2^Q) / 2^16)
+//   f  = F & (2^(Q-16) - 1);   decided iff f >= 2 m, and then floor(S) = Uh + (F >> (Q - 16))
+// The fraction is resolved to 2^-(Q-16) (1.5e-8 at sigma = 5), well below delta, so an output is undecided only when
+// frac(S) really lies within ~delta of an integer.
 //
 // Operand layout: v_mfma_i32_16x16x64_i8 pairs byte s of lane (m, g) of A with byte s of lane (n, g) of B (m, n = lane & 15,
 // g = lane >> 4) and leaves D[m = 4 * (lane >> 4) + reg][n = lane & 15] (scripts/ubench/mfma_i8.hip checks this on the
@@ -45,6 +48,13 @@
 #include <type_traits>
 
 #include "pl_common.h"
+
+// Timing-attribution switches for scripts/ubench/g2d_variants.hip ONLY (results become wrong): bit 0 drops the MFMAs,
+// bit 1 the integer recombination, bit 2 the global loads, bit 3 the per-step barrier, bit 4 the global stores, bit 5 the plane
+// split + LDS writes of the input, bit 6 the LDS writes of the axis-0 plane, bit 7 the LDS operand reads.
+#ifndef PL_G2D_VARIANT
+#define PL_G2D_VARIANT 0
+#endif
 
 namespace {
 
@@ -66,11 +76,10 @@ struct MmParams {
   unsigned band[kMmDigits][4][24];
   int sh;            // Q - 32: U = Uh * 2^sh + Ur
   int fb;            // Q - 16: fraction bits of F
-  int c0;            // C & (2^24 - 1)        -> initial value of a0
-  int c3;            // (C >> 24) & 255       -> initial value of a3
-  int c4;            // C >> 32               -> initial value of a4        (C = 32896 * sum wq)
-  unsigned m;        // ceil(delta * 2^fb): f in [m, 2^fb - m - 1] is decided
-  unsigned lim;      // 2^fb - 2 m - 1
+  int c1;            // (C' & (2^24 - 1)) >> 8 -> initial value of a1   (C' = 32896 * sum wq + M, M = m * 2^16)
+  int c3;            // (C' >> 24) & 255       -> initial value of a3
+  int c4;            // C' >> 32               -> initial value of a4
+  unsigned lim;      // 2 m: an output is decided iff its fraction field f = F & (2^fb - 1) is >= lim
   int radius;
   double wd[kMmMaxRad + 1];  // float64 taps (offset j) for the exact path, zero beyond radius
 };
@@ -118,18 +127,21 @@ bool mm_make_params(const double* h_wts /* 2*R+1 taps, centre at R */, int R, Mm
         p.band[d][c][q] = (unsigned)bytes[4 * q] | ((unsigned)bytes[4 * q + 1] << 8) | ((unsigned)bytes[4 * q + 2] << 16) |
                           ((unsigned)bytes[4 * q + 3] << 24);
     }
-  const long long C = 32896LL * WQ;                // < 2^16 * 2^47
-  p.c0 = (int)(C & 0xffffffLL);
-  p.c3 = (int)((C >> 24) & 0xffLL);
-  p.c4 = (int)(C >> 32);
   p.sh = Q - 32;
   p.fb = Q - 16;
-  // |S_real - 2^-Q (T + C)| <= 65535 * sum|e_k|; scipy's own rounding and the int16 bias 32768 * (W - 1) are ~1e-11
-  const double delta = 65535.0 * eq * (1.0 + 1e-9) + 65536.0 * __builtin_fabs(W - 1.0) + 1e-9;
-  const double md = __builtin_ceil(__builtin_ldexp(delta, p.fb)) + 1.0;
-  if (!(md < __builtin_ldexp(0.25, p.fb))) return false;
-  p.m = (unsigned)md;
-  p.lim = (1u << p.fb) - 2u * p.m - 1u;
+  // |S_real - 2^-Q (T + C)| <= 65535 * sum|e_k|; scipy's own rounding and the int16 bias 32768 * (W - 1) are ~1e-11; the
+  // product of the two LOWEST digit planes is not computed (|sum| <= (2R+1) * 128 * 128) and the low byte of C is dropped
+  const double delta = 65535.0 * eq * (1.0 + 1e-9) + 65536.0 * __builtin_fabs(W - 1.0) + 1e-9 +
+                       __builtin_ldexp((double)(2 * R + 1) * 16384.0 + 256.0, -Q);
+  const double md = __builtin_ceil(__builtin_ldexp(delta, p.fb)) + 1.0;      // + 1: F is a floor
+  if (!(md < __builtin_ldexp(0.125, p.fb))) return false;
+  // M = m * 2^16 rides on the accumulators' constants: frac(S) + m 2^-fb is what F's fraction field holds, so "within
+  // delta of an integer" is the single test f < 2 m, and f >= 2 m leaves floor(T' / 2^Q) = floor(S)
+  const long long C = 32896LL * WQ + ((long long)md << 16);                  // < 2^16 * 2^47
+  p.c1 = (int)((C & 0xffffffLL) >> 8);
+  p.c3 = (int)((C >> 24) & 0xffLL);
+  p.c4 = (int)(C >> 32);
+  p.lim = 2u * (unsigned)md;
   p.radius = R;
   for (int j = 0; j <= kMmMaxRad; ++j) p.wd[j] = j <= R ? h_wts[R - j] : 0.0;
   return true;
@@ -157,19 +169,20 @@ __device__ __forceinline__ double mm_exact(F raw /* k in [-R, R] -> actual value
   return a;
 }
 
-struct MmAcc { v4i a0, a1, a2, a3, a4, a5; };
+struct MmAcc { v4i a1, a2, a3, a4, a5; };
 
-// the ten MFMAs of one tile: img_lo / img_hi = the 16 x 64 sample digit planes (as A when IMG_IS_A), w[d] = Toeplitz
+// the nine MFMAs of one tile: img_lo / img_hi = the 16 x 64 sample digit planes (as A when IMG_IS_A), w[d] = Toeplitz
+// (low sample digit x lowest weight digit is below the decision's resolution: left out, its bound is part of delta)
 template <bool IMG_IS_A>
 __device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[kMmDigits], const MmParams& P) {
-  auto mm = [&](v4i img, v4i band, v4i c) {
+  auto mm = [&](v4i img, v4i band, v4i c) -> v4i {
+    if (PL_G2D_VARIANT & 1) return img + band + c;
     return IMG_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(img, band, c, 0, 0, 0)
                     : __builtin_amdgcn_mfma_i32_16x16x64_i8(band, img, c, 0, 0, 0);
   };
   MmAcc r;
   const v4i z = {0, 0, 0, 0};
-  r.a0 = mm(img_lo, w[0], v4i{P.c0, P.c0, P.c0, P.c0});
-  r.a1 = mm(img_lo, w[1], z);
+  r.a1 = mm(img_lo, w[1], v4i{P.c1, P.c1, P.c1, P.c1});
   r.a2 = mm(img_lo, w[2], z);
   r.a3 = mm(img_lo, w[3], v4i{P.c3, P.c3, P.c3, P.c3});
   r.a4 = mm(img_lo, w[4], v4i{P.c4, P.c4, P.c4, P.c4});
@@ -181,14 +194,13 @@ __device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[
   return r;
 }
 
-// one output from its six accumulator values: floor(S) in the biased domain (0 .. 65535); g = f - m (unsigned), the
-// output is decided iff g <= P.lim
-__device__ __forceinline__ unsigned mm_decide(int a0, int a1, int a2, int a3, int a4, int a5, const MmParams& P, unsigned& g) {
-  const int s = (a1 << 8) + a0;
-  const int t = a2 + (s >> 16);
+// one output from its five accumulator values: floor(S) in the biased domain (0 .. 65535) and the fraction field f; the
+// output is decided iff f >= P.lim
+__device__ __forceinline__ unsigned mm_decide(int a1, int a2, int a3, int a4, int a5, const MmParams& P, unsigned& f) {
+  const int t = a2 + (a1 >> 8);
   const int U = (a5 << 8) + a4;
   const int F = ((U & ((1 << P.sh) - 1)) << 16) + (a3 << 8) + t;
-  g = (unsigned)(F & ((1 << P.fb) - 1)) - P.m;
+  f = (unsigned)(F & ((1 << P.fb) - 1));
   return (unsigned)((U >> P.sh) + (F >> P.fb));
 }
 
@@ -199,14 +211,14 @@ __device__ __forceinline__ uint2 mm_finish(const MmAcc& r, const MmParams& P, un
   unsigned v[4], g[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    v[q] = mm_decide(r.a0[q], r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], P, g[q]);
+    v[q] = mm_decide(r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], P, g[q]);
     if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;   // C truncation rounds negative S toward zero
   }
-  unsigned gm = g[0] > g[1] ? g[0] : g[1];
-  gm = gm > g[2] ? gm : g[2];
-  gm = gm > g[3] ? gm : g[3];
+  unsigned gm = g[0] < g[1] ? g[0] : g[1];
+  gm = gm < g[2] ? gm : g[2];
+  gm = gm < g[3] ? gm : g[3];
   fail = 0;
-  if (gm > P.lim) fail = (g[0] > P.lim ? 8u : 0u) | (g[1] > P.lim ? 4u : 0u) | (g[2] > P.lim ? 2u : 0u) | (g[3] > P.lim ? 1u : 0u);
+  if (gm < P.lim) fail = (g[0] < P.lim ? 8u : 0u) | (g[1] < P.lim ? 4u : 0u) | (g[2] < P.lim ? 2u : 0u) | (g[3] < P.lim ? 1u : 0u);
   return uint2{__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
 }
 
@@ -452,20 +464,36 @@ gauss_v_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_
 // float64 sequence from the plane bytes and overwrite what the loop stored.
 constexpr int kFCols = 256;                       // output columns per strip
 constexpr int kFWin = kFCols + 2 * kMmHalo;       // 304 window columns
-constexpr int kFSlots = 5;                        // row-group slots
+#ifndef PL_G2D_SLOTS
+#define PL_G2D_SLOTS 4
+#endif
+// 5 slots: the incoming row group has a slot of its own and the axis-0 plane is double-buffered: ONE barrier per step,
+// 68 KB, two workgroups per CU.  4 slots: the incoming group replaces the oldest one after the step's axis-0 tiles and the
+// axis-0 plane is single: TWO barriers per step, 48.6 KB, three workgroups per CU.
+constexpr int kFSlots = PL_G2D_SLOTS;             // row-group slots
+constexpr int kFVBufs = kFSlots == 5 ? 2 : 1;     // axis-0 result planes
 constexpr int kFPlane = kFWin * 16;               // bytes of one plane of one row group (= one 16-row axis-0 result plane)
 constexpr int kFQuadPitch = (kFWin / 4) * 16;     // byte distance between the cells of columns c and c + 1 (same c >> 2)
 constexpr int kFInLo = 0;                         // LDS map
 constexpr int kFInHi = kFInLo + kFSlots * kFPlane;
 constexpr int kFVLo = kFInHi + kFSlots * kFPlane;
-constexpr int kFVHi = kFVLo + 2 * kFPlane;
-constexpr int kFLds = kFVHi + 2 * kFPlane;        // 68096 bytes: two workgroups per CU
+constexpr int kFVHi = kFVLo + kFVBufs * kFPlane;
+constexpr int kFLds = kFVHi + kFVBufs * kFPlane;  // 68096 / 48640 bytes
 
 // byte offset of column c's cell inside a row-group plane: cells ordered [c & 3][c >> 2] -- the four columns a lane
 // splits land 76 cells apart (ds_write_b32: 64 lanes -> 64 banks) and the 16 columns of a tile read conflict-free b128s
 __device__ __forceinline__ int f_cell(int c) { return kFQuadPitch * (c & 3) + 16 * (c >> 2); }
 
 struct FQuad { uint2 r[4]; };                     // 4 rows x 4 columns of raw 16-bit samples
+
+// a tile operand: 16 bytes of one plane
+__device__ __forceinline__ uint4 f_ldsq(const unsigned char* p) {
+  if (PL_G2D_VARIANT & 128) {
+    const unsigned a = (unsigned)(uintptr_t)p;
+    return uint4{a, a * 3u, a * 5u, a * 7u};
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
 
 // element q (0..3) of a lane's packed four results
 __device__ __forceinline__ void mm_set(uint2& res, int q, unsigned v16) {
@@ -486,16 +514,21 @@ __device__ __forceinline__ bool mm_wave_flat(const uint4& lo, const uint4& hi) {
 // four outputs of a lane, branch-free: packed results and ONE flag (some output of the four is undecided)
 template <bool SIGNED>
 __device__ __forceinline__ uint2 mm_finish_flag(const MmAcc& r, const MmParams& P, bool& bad) {
+  if (PL_G2D_VARIANT & 2) {
+    bad = false;
+    const v4i t = r.a1 ^ r.a2 ^ r.a3 ^ r.a4 ^ r.a5;
+    return uint2{(unsigned)(t[0] ^ t[1]), (unsigned)(t[2] ^ t[3])};
+  }
   unsigned v[4], g[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    v[q] = mm_decide(r.a0[q], r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], P, g[q]);
+    v[q] = mm_decide(r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], P, g[q]);
     if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;
   }
-  unsigned gm = g[0] > g[1] ? g[0] : g[1];
-  gm = gm > g[2] ? gm : g[2];
-  gm = gm > g[3] ? gm : g[3];
-  bad = gm > P.lim;
+  unsigned gm = g[0] < g[1] ? g[0] : g[1];
+  gm = gm < g[2] ? gm : g[2];
+  gm = gm < g[3] ? gm : g[3];
+  bad = gm < P.lim;
   return uint2{__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
 }
 
@@ -523,7 +556,9 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
   const int wcols = w - c0 < kFCols ? w - c0 : kFCols;      // output columns of this strip (a multiple of 16)
   const int nvt = wcols / 16 + 3;                            // axis-0 tiles the axis-1 windows reach
   const int nht = wcols / 16;
-  const __amdgpu_buffer_rsrc_t src = pl_make_rsrc(f);
+  // bounded: the look-ahead loads of the last steps may reflect to a negative row when h < 71; those never reach a
+  // tile that is stored, and out of range they read 0 instead of faulting
+  const __amdgpu_buffer_rsrc_t src = pl_make_rsrc_bounded(f, (unsigned)h * (unsigned)w * 2u);
   // the segment's output rows as a bounded buffer: a store whose offset lies beyond it is dropped
   const __amdgpu_buffer_rsrc_t dstb = pl_make_rsrc_bounded(out + (frame * (size_t)h + r_begin) * w, (unsigned)(r_end - r_begin) * (unsigned)w * 2u);
 
@@ -554,11 +589,12 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       r ^= r >> 31;                                          // -r - 1 below the frame
       const int r2 = 2 * h - 1 - r;
       r = r < r2 ? r : r2;                                   // 2 h - 1 - r above it (one reflection: h >= 64)
-      x.r[i] = pl_buffer_load_u64(src, (unsigned)r * wb + q.colb, 0);
+      x.r[i] = (PL_G2D_VARIANT & 4) ? uint2{(unsigned)r * wb, q.colb} : pl_buffer_load_u64(src, (unsigned)r * wb + q.colb, 0);
     }
   };
   auto store_quad = [&](const QuadPlace& q, int k, const FQuad& x) {
     if (!q.on) return;
+    if ((PL_G2D_VARIANT & 32) && x.r[0].x != 0x12345u) return;
     unsigned char* base = s_mem + kFInLo + (k % kFSlots) * kFPlane + q.d0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -576,10 +612,15 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       *reinterpret_cast<unsigned*>(po + (kFInHi - kFInLo)) = __builtin_amdgcn_perm(o1, o0, 0x07060302u) ^ kHiFlip;
     }
   };
+  // row groups 0 .. 3 go to LDS now; group 4 (and from then on always the group TWO steps ahead) waits in registers:
+  // two row groups per lane are in flight while a step computes
+  FQuad xa, xb, ya, yb;
   {
     FQuad a[4], b[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { load_quad(qa, k, a[k]); load_quad(qb, k, b[k]); }
+    load_quad(qa, 4, xa);
+    load_quad(qb, 4, xb);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { store_quad(qa, k, a[k]); store_quad(qb, k, b[k]); }
   }
@@ -590,12 +631,11 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
 
   const int lane_cell = f_cell(j);                 // cell of column 16 t + j, less the tile's 64 t bytes
   int slot_g = g;                                  // slot of row group s + g
-#pragma unroll 1
-  for (int s = 0; s < nsteps; ++s) {
-    const bool more = s + 1 < nsteps;
-    FQuad na, nb;
-    if (more) { load_quad(qa, s + 4, na); load_quad(qb, s + 4, nb); }
-    const int vb = (s & 1) * kFPlane;
+  // one step: loads of group s + 5 into (la, lb); axis 0; group s + 4 from (sa, sb) into its slot; barrier; axis 1
+  auto step = [&](int s, FQuad& la, FQuad& lb, const FQuad& sa, const FQuad& sb) {
+    load_quad(qa, s + 5, la);
+    load_quad(qb, s + 5, lb);
+    const int vb = kFVBufs == 2 ? (s & 1) * kFPlane : 0;
     const int lrow = 16 * s + j;                   // the lane's output row inside the segment, both passes
     const bool row_ok = r_begin + lrow < r_end;
 
@@ -607,23 +647,25 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       auto run = [&](auto NT) {
         constexpr int N = decltype(NT)::value;
         unsigned badbits = 0;
-        uint4 qlo = *reinterpret_cast<const uint4*>(ain + 64 * tile_of(0));
-        uint4 qhi = *reinterpret_cast<const uint4*>(ain + 64 * tile_of(0) + (kFInHi - kFInLo));
+        uint4 qlo = f_ldsq(ain + 64 * tile_of(0));
+        uint4 qhi = f_ldsq(ain + 64 * tile_of(0) + (kFInHi - kFInLo));
         MmAcc acc = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           MmAcc nxt;
           if (i + 1 < N) {
-            qlo = *reinterpret_cast<const uint4*>(ain + 64 * tile_of(i + 1));
-            qhi = *reinterpret_cast<const uint4*>(ain + 64 * tile_of(i + 1) + (kFInHi - kFInLo));
+            qlo = f_ldsq(ain + 64 * tile_of(i + 1));
+            qhi = f_ldsq(ain + 64 * tile_of(i + 1) + (kFInHi - kFInLo));
             nxt = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
           }
           bool bad;
           const uint2 res = mm_finish_flag<kSigned>(acc, P, bad);
           badbits |= (bad && row_ok) ? (1u << i) : 0u;
           unsigned char* vd = vout + 16 * tile_of(i);
-          *reinterpret_cast<unsigned*>(vd) = __builtin_amdgcn_perm(res.y, res.x, 0x06040200u) ^ 0x80808080u;
-          *reinterpret_cast<unsigned*>(vd + (kFVHi - kFVLo)) = __builtin_amdgcn_perm(res.y, res.x, 0x07050301u) ^ kHiFlip;
+          if (!(PL_G2D_VARIANT & 64) || res.x == 0x12345u) {
+            *reinterpret_cast<unsigned*>(vd) = __builtin_amdgcn_perm(res.y, res.x, 0x06040200u) ^ 0x80808080u;
+            *reinterpret_cast<unsigned*>(vd + (kFVHi - kFVLo)) = __builtin_amdgcn_perm(res.y, res.x, 0x07050301u) ^ kHiFlip;
+          }
           if (i + 1 < N) acc = nxt;
         }
         if (__ballot(badbits != 0u) == 0ull) return;
@@ -657,8 +699,15 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       };
       if (wave == 3) run(std::integral_constant<int, 4>{}); else run(std::integral_constant<int, 5>{});
     }
-    if (more) { store_quad(qa, s + 4, na); store_quad(qb, s + 4, nb); }
-    __syncthreads();
+    if (kFSlots == 5) {
+      store_quad(qa, s + 4, sa);
+      store_quad(qb, s + 4, sb);
+    }
+    if (!(PL_G2D_VARIANT & 8)) __syncthreads();
+    if (kFSlots == 4) {                            // group s is done with: its slot takes group s + 4
+      store_quad(qa, s + 4, sa);
+      store_quad(qb, s + 4, sb);
+    }
 
     // ---- axis 1: Toeplitz (M = output column) x image (N = row j): lane (j, g) gets columns 16 t + 4 g .. + 3 of row j
     {
@@ -668,21 +717,21 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       auto tile_of = [&](int i) { const int t = 4 * wave + i; return t < nht ? t : 0; };
       constexpr int N = 4;
       unsigned badbits = 0;
-      uint4 qlo = *reinterpret_cast<const uint4*>(bin + 16 * tile_of(0));
-      uint4 qhi = *reinterpret_cast<const uint4*>(bin + 16 * tile_of(0) + (kFVHi - kFVLo));
+      uint4 qlo = f_ldsq(bin + 16 * tile_of(0));
+      uint4 qhi = f_ldsq(bin + 16 * tile_of(0) + (kFVHi - kFVLo));
       MmAcc acc = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         MmAcc nxt;
         if (i + 1 < N) {
-          qlo = *reinterpret_cast<const uint4*>(bin + 16 * tile_of(i + 1));
-          qhi = *reinterpret_cast<const uint4*>(bin + 16 * tile_of(i + 1) + (kFVHi - kFVLo));
+          qlo = f_ldsq(bin + 16 * tile_of(i + 1));
+          qhi = f_ldsq(bin + 16 * tile_of(i + 1) + (kFVHi - kFVLo));
           nxt = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
         }
         bool bad;
         const uint2 res = mm_finish_flag<kSigned>(acc, P, bad);
         badbits |= (bad && row_ok) ? (1u << i) : 0u;
-        pl_buffer_store_u64(res, dstb, doff + 32u * (unsigned)tile_of(i), 0);
+        if (!(PL_G2D_VARIANT & 16) || res.x == 0x12345u) pl_buffer_store_u64(res, dstb, doff + 32u * (unsigned)tile_of(i), 0);
         if (i + 1 < N) acc = nxt;
       }
       if (__ballot(badbits != 0u) != 0ull) {
@@ -713,6 +762,12 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       }
     }
     slot_g = slot_g == kFSlots - 1 ? 0 : slot_g + 1;
+    if (kFSlots == 4 && !(PL_G2D_VARIANT & 8)) __syncthreads();   // axis-0 plane read, incoming group in place
+  };
+#pragma unroll 1
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, ya, yb, xa, xb);
+    if (s + 1 < nsteps) step(s + 1, xa, xb, ya, yb);
   }
 }
 
