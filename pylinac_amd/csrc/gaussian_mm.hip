@@ -68,18 +68,16 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 // Everything a pass needs, computed on the host (mm_make_params) and passed by value.
 constexpr int kMmDigits = 5;
+constexpr int kMmQ = 40;                      // taps are quantised to 2^-40
 
 struct MmParams {
   // band[d][c][.]: the zero-padded band sequence E_d[p] = digit_d[|p - 39|] (|p - 39| <= RAD, else 0) of weight digit d,
   // shifted left by c bytes, so that a lane whose Toeplitz row starts at p0 = 16 g - i + 15 reads its 16 bytes as four
   // ALIGNED dwords band[d][p0 & 3][(p0 >> 2) .. + 3]
   unsigned band[kMmDigits][4][24];
-  int sh;            // Q - 32: U = Uh * 2^sh + Ur
-  int fb;            // Q - 16: fraction bits of F
-  int c1;            // (C' & (2^24 - 1)) >> 8 -> initial value of a1   (C' = 32896 * sum wq + M, M = m * 2^16)
+  int c1;            // (C' & (2^24 - 1)) >> 8 -> initial value of a1   (C' = 32896 * sum wq + M, M = 2^23)
   int c3;            // (C' >> 24) & 255       -> initial value of a3
   int c4;            // C' >> 32               -> initial value of a4
-  unsigned lim;      // 2 m: an output is decided iff its fraction field f = F & (2^fb - 1) is >= lim
   int radius;
   double wd[kMmMaxRad + 1];  // float64 taps (offset j) for the exact path, zero beyond radius
 };
@@ -93,8 +91,9 @@ bool mm_make_params(const double* h_wts /* 2*R+1 taps, centre at R */, int R, Mm
     W += h_wts[k];
   }
   if (!(wmax > 0.0) || !(W < 2.0)) return false;
-  int Q = 32;
-  while (Q < 46 && __builtin_ldexp(wmax, Q + 1) < 5.0e11) ++Q;   // five balanced digits hold |wq| < 127 * 2^32
+  // Q is FIXED at 40: the integer part of S then IS the top accumulator level and the decision reads whole bytes of the
+  // levels below (mm_decide).  Five balanced digits hold |wq| < 127 * 2^32: taps up to 0.49 (sigma >= 0.82).
+  constexpr int Q = kMmQ;
   if (__builtin_ldexp(wmax, Q) >= 5.0e11) return false;
   long long wq[2 * kMmMaxRad + 1];
   long long WQ = 0;
@@ -127,21 +126,19 @@ bool mm_make_params(const double* h_wts /* 2*R+1 taps, centre at R */, int R, Mm
         p.band[d][c][q] = (unsigned)bytes[4 * q] | ((unsigned)bytes[4 * q + 1] << 8) | ((unsigned)bytes[4 * q + 2] << 16) |
                           ((unsigned)bytes[4 * q + 3] << 24);
     }
-  p.sh = Q - 32;
-  p.fb = Q - 16;
-  // |S_real - 2^-Q (T + C)| <= 65535 * sum|e_k|; scipy's own rounding and the int16 bias 32768 * (W - 1) are ~1e-11; the
-  // product of the two LOWEST digit planes is not computed (|sum| <= (2R+1) * 128 * 128) and the low byte of C is dropped
-  const double delta = 65535.0 * eq * (1.0 + 1e-9) + 65536.0 * __builtin_fabs(W - 1.0) + 1e-9 +
-                       __builtin_ldexp((double)(2 * R + 1) * 16384.0 + 256.0, -Q);
-  const double md = __builtin_ceil(__builtin_ldexp(delta, p.fb)) + 1.0;      // + 1: F is a floor
-  if (!(md < __builtin_ldexp(0.125, p.fb))) return false;
-  // M = m * 2^16 rides on the accumulators' constants: frac(S) + m 2^-fb is what F's fraction field holds, so "within
-  // delta of an integer" is the single test f < 2 m, and f >= 2 m leaves floor(T' / 2^Q) = floor(S)
-  const long long C = 32896LL * WQ + ((long long)md << 16);                  // < 2^16 * 2^47
+  // D bounds |2^Q S_real - (T + C)| in units of T: tap rounding 65535 * sum|e_k| 2^Q; scipy's own rounding and the int16
+  // bias 32768 (W - 1), ~1e-11 of a grey level; the product of the two LOWEST digit planes, which is not computed
+  // (|sum| <= (2R+1) * 128 * 128); the low byte of C, dropped.
+  const double D = __builtin_ldexp(65535.0 * eq * (1.0 + 1e-9) + 65536.0 * __builtin_fabs(W - 1.0) + 1e-9, Q) +
+                   (double)(2 * R + 1) * 16384.0 + 256.0;
+  // M = 2^23 rides on the accumulators' constants: T' = T + C + M.  If T' mod 2^Q >= 2 M, then floor(T' / 2^Q) =
+  // floor(S) whatever the error within +-D <= M; "T' mod 2^Q < 2^24" is "bits 24 .. 39 of T' are all zero"
+  constexpr long long M = 1LL << 23;
+  if (!(D < (double)M)) return false;
+  const long long C = 32896LL * WQ + M;                                      // < 2^16 * 2^41
   p.c1 = (int)((C & 0xffffffLL) >> 8);
   p.c3 = (int)((C >> 24) & 0xffLL);
   p.c4 = (int)(C >> 32);
-  p.lim = 2u * (unsigned)md;
   p.radius = R;
   for (int j = 0; j <= kMmMaxRad; ++j) p.wd[j] = j <= R ? h_wts[R - j] : 0.0;
   return true;
@@ -173,19 +170,24 @@ struct MmAcc { v4i a1, a2, a3, a4, a5; };
 
 // the nine MFMAs of one tile: img_lo / img_hi = the 16 x 64 sample digit planes (as A when IMG_IS_A), w[d] = Toeplitz
 // (low sample digit x lowest weight digit is below the decision's resolution: left out, its bound is part of delta)
+struct MmConst { v4i c1, c3, c4; };            // the accumulators' initial values, one register quad each
+__device__ __forceinline__ MmConst mm_const(const MmParams& P) {
+  return MmConst{v4i{P.c1, P.c1, P.c1, P.c1}, v4i{P.c3, P.c3, P.c3, P.c3}, v4i{P.c4, P.c4, P.c4, P.c4}};
+}
+
 template <bool IMG_IS_A>
-__device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[kMmDigits], const MmParams& P) {
+__device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[kMmDigits], const MmConst& K) {
   auto mm = [&](v4i img, v4i band, v4i c) -> v4i {
-    if (PL_G2D_VARIANT & 1) return img + band + c;
+    if (PL_G2D_VARIANT & 1) return img;            // no instruction at all
     return IMG_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(img, band, c, 0, 0, 0)
                     : __builtin_amdgcn_mfma_i32_16x16x64_i8(band, img, c, 0, 0, 0);
   };
   MmAcc r;
   const v4i z = {0, 0, 0, 0};
-  r.a1 = mm(img_lo, w[1], v4i{P.c1, P.c1, P.c1, P.c1});
+  r.a1 = mm(img_lo, w[1], K.c1);
   r.a2 = mm(img_lo, w[2], z);
-  r.a3 = mm(img_lo, w[3], v4i{P.c3, P.c3, P.c3, P.c3});
-  r.a4 = mm(img_lo, w[4], v4i{P.c4, P.c4, P.c4, P.c4});
+  r.a3 = mm(img_lo, w[3], K.c3);
+  r.a4 = mm(img_lo, w[4], K.c4);
   r.a5 = mm(img_hi, w[4], z);
   r.a1 = mm(img_hi, w[0], r.a1);
   r.a2 = mm(img_hi, w[1], r.a2);
@@ -193,32 +195,39 @@ __device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[
   r.a4 = mm(img_hi, w[3], r.a4);
   return r;
 }
+template <bool IMG_IS_A>
+__device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[kMmDigits], const MmParams& P) {
+  return mm_tile<IMG_IS_A>(img_lo, img_hi, w, mm_const(P));
+}
 
-// one output from its five accumulator values: floor(S) in the biased domain (0 .. 65535) and the fraction field f; the
-// output is decided iff f >= P.lim
-__device__ __forceinline__ unsigned mm_decide(int a1, int a2, int a3, int a4, int a5, const MmParams& P, unsigned& f) {
-  const int t = a2 + (a1 >> 8);
-  const int U = (a5 << 8) + a4;
-  const int F = ((U & ((1 << P.sh) - 1)) << 16) + (a3 << 8) + t;
-  f = (unsigned)(F & ((1 << P.fb) - 1));
-  return (unsigned)((U >> P.sh) + (F >> P.fb));
+// one output from its five accumulator values: floor(S) in the biased domain (0 .. 65535) and z = bits 24 .. 39 of T' folded
+// into a byte: the output is decided iff z != 0.  A carry cascade of arithmetic right shifts and adds (full-rate VALU
+// opcodes only; floor(floor(x / a) / b) = floor(x / (a b)) keeps every level exact):
+//   t_k = a_k + (t_{k-1} >> 8) = floor((2^8 a1 + .. + 2^(8k) a_k) / 2^(8k));   bits 8k .. 8k+7 of T' = t_k & 255
+__device__ __forceinline__ unsigned mm_decide(int a1, int a2, int a3, int a4, int a5, unsigned& z) {
+  const int t2 = a2 + (a1 >> 8);
+  const int t3 = a3 + (t2 >> 8);
+  const int t4 = a4 + (t3 >> 8);
+  const int t5 = a5 + (t4 >> 8);
+  z = (unsigned)((t3 | t4) & 255);
+  return (unsigned)t5;
 }
 
 // four outputs of a lane (regs 0..3 = consecutive columns) -> two dwords of packed 16-bit results in the image's own
 // domain; fail: bit 3 - q set when output q is undecided
 template <bool SIGNED>
-__device__ __forceinline__ uint2 mm_finish(const MmAcc& r, const MmParams& P, unsigned& fail) {
-  unsigned v[4], g[4];
+__device__ __forceinline__ uint2 mm_finish(const MmAcc& r, const MmParams&, unsigned& fail) {
+  unsigned v[4], z[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    v[q] = mm_decide(r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], P, g[q]);
+    v[q] = mm_decide(r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], z[q]);
     if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;   // C truncation rounds negative S toward zero
   }
-  unsigned gm = g[0] < g[1] ? g[0] : g[1];
-  gm = gm < g[2] ? gm : g[2];
-  gm = gm < g[3] ? gm : g[3];
+  unsigned zm = z[0] < z[1] ? z[0] : z[1];
+  zm = zm < z[2] ? zm : z[2];
+  zm = zm < z[3] ? zm : z[3];
   fail = 0;
-  if (gm < P.lim) fail = (g[0] < P.lim ? 8u : 0u) | (g[1] < P.lim ? 4u : 0u) | (g[2] < P.lim ? 2u : 0u) | (g[3] < P.lim ? 1u : 0u);
+  if (zm == 0u) fail = (z[0] == 0u ? 8u : 0u) | (z[1] == 0u ? 4u : 0u) | (z[2] == 0u ? 2u : 0u) | (z[3] == 0u ? 1u : 0u);
   return uint2{__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
 }
 
@@ -513,27 +522,26 @@ __device__ __forceinline__ bool mm_wave_flat(const uint4& lo, const uint4& hi) {
 
 // four outputs of a lane, branch-free: packed results and ONE flag (some output of the four is undecided)
 template <bool SIGNED>
-__device__ __forceinline__ uint2 mm_finish_flag(const MmAcc& r, const MmParams& P, bool& bad) {
+__device__ __forceinline__ uint2 mm_finish_flag(const MmAcc& r, bool& bad) {
   if (PL_G2D_VARIANT & 2) {
     bad = false;
-    const v4i t = r.a1 ^ r.a2 ^ r.a3 ^ r.a4 ^ r.a5;
-    return uint2{(unsigned)(t[0] ^ t[1]), (unsigned)(t[2] ^ t[3])};
+    return uint2{(unsigned)(r.a1[0] ^ r.a5[1]), (unsigned)(r.a3[2] ^ r.a4[3])};
   }
-  unsigned v[4], g[4];
+  unsigned v[4], z[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    v[q] = mm_decide(r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], P, g[q]);
+    v[q] = mm_decide(r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], z[q]);
     if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;
   }
-  unsigned gm = g[0] < g[1] ? g[0] : g[1];
-  gm = gm < g[2] ? gm : g[2];
-  gm = gm < g[3] ? gm : g[3];
-  bad = gm < P.lim;
+  unsigned zm = z[0] < z[1] ? z[0] : z[1];
+  zm = zm < z[2] ? zm : z[2];
+  zm = zm < z[3] ? zm : z[3];
+  bad = zm == 0u;
   return uint2{__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
 }
 
 template <typename T>
-__global__ void __launch_bounds__(kMmThreads)
+__global__ void __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 48.6 KB of LDS: three workgroups per CU
 gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int strips, int segs, int seg_rows, const MmParams P) {
   constexpr bool kSigned = (T)-1 < (T)0;
   constexpr unsigned kHiFlip = kSigned ? 0u : 0x80808080u;     // int16: the signed high byte already is x_hi - 128
@@ -589,7 +597,7 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       r ^= r >> 31;                                          // -r - 1 below the frame
       const int r2 = 2 * h - 1 - r;
       r = r < r2 ? r : r2;                                   // 2 h - 1 - r above it (one reflection: h >= 64)
-      x.r[i] = (PL_G2D_VARIANT & 4) ? uint2{(unsigned)r * wb, q.colb} : pl_buffer_load_u64(src, (unsigned)r * wb + q.colb, 0);
+      x.r[i] = (PL_G2D_VARIANT & 4) ? uint2{((unsigned)r * wb + q.colb) * 2654435761u, ((unsigned)r * wb + q.colb) * 40503u + 12345u} : pl_buffer_load_u64(src, (unsigned)r * wb + q.colb, 0);
     }
   };
   auto store_quad = [&](const QuadPlace& q, int k, const FQuad& x) {
@@ -627,6 +635,15 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
   v4i band[kMmDigits];
 #pragma unroll
   for (int d = 0; d < kMmDigits; ++d) band[d] = mm_band_operand(P, d, lane);
+  // the band operands are vector loads: retire them HERE -- left pending into the loop, the compiler's wait-count pass puts
+  // vmcnt(0) in front of the first MFMAs of every step, which also waits for the step's own look-ahead loads
+  __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0), expcnt / lgkmcnt untouched
+  // the accumulators' initial values live in twelve VGPRs for the whole march (the compiler would otherwise rebuild the
+  // three quads from SGPRs in front of every tile: six v_mov_b64 per tile)
+  MmConst K = mm_const(P);
+#ifndef PL_HIPEMU
+  asm volatile("" : "+v"(K.c1), "+v"(K.c3), "+v"(K.c4));
+#endif
   __syncthreads();
 
   const int lane_cell = f_cell(j);                 // cell of column 16 t + j, less the tile's 64 t bytes
@@ -649,17 +666,17 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
         unsigned badbits = 0;
         uint4 qlo = f_ldsq(ain + 64 * tile_of(0));
         uint4 qhi = f_ldsq(ain + 64 * tile_of(0) + (kFInHi - kFInLo));
-        MmAcc acc = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+        MmAcc acc = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, K);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           MmAcc nxt;
           if (i + 1 < N) {
             qlo = f_ldsq(ain + 64 * tile_of(i + 1));
             qhi = f_ldsq(ain + 64 * tile_of(i + 1) + (kFInHi - kFInLo));
-            nxt = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+            nxt = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, K);
           }
           bool bad;
-          const uint2 res = mm_finish_flag<kSigned>(acc, P, bad);
+          const uint2 res = mm_finish_flag<kSigned>(acc, bad);
           badbits |= (bad && row_ok) ? (1u << i) : 0u;
           unsigned char* vd = vout + 16 * tile_of(i);
           if (!(PL_G2D_VARIANT & 64) || res.x == 0x12345u) {
@@ -686,13 +703,19 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
             const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int) { return c; }, P));
             *reinterpret_cast<unsigned*>(vd) = (0x01010101u * (v & 255u)) ^ 0x80808080u;
             *reinterpret_cast<unsigned*>(vd + (kFVHi - kFVLo)) = (0x01010101u * (v >> 8)) ^ kHiFlip;
-          } else if ((badbits >> i) & 1u) {
+          } else {                                 // the tile once more (every lane): WHICH outputs are undecided
+            const MmAcc ra = mm_tile<true>(v4i{(int)flo.x, (int)flo.y, (int)flo.z, (int)flo.w}, v4i{(int)fhi.x, (int)fhi.y, (int)fhi.z, (int)fhi.w}, band, K);
+            if ((badbits >> i) & 1u) {
 #pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-              const int x = 16 * t + 4 * g + q;
-              const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(x, kMmHalo + j + k); }, P));
-              vd[q] = (unsigned char)((v & 255u) ^ 0x80u);
-              vd[q + (kFVHi - kFVLo)] = (unsigned char)((v >> 8) ^ (kHiFlip & 0x80u));
+              for (int q = 0; q < 4; ++q) {
+                unsigned z;
+                mm_decide(ra.a1[q], ra.a2[q], ra.a3[q], ra.a4[q], ra.a5[q], z);
+                if (z != 0u) continue;
+                const int x = 16 * t + 4 * g + q;
+                const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(x, kMmHalo + j + k); }, P));
+                vd[q] = (unsigned char)((v & 255u) ^ 0x80u);
+                vd[q + (kFVHi - kFVLo)] = (unsigned char)((v >> 8) ^ (kHiFlip & 0x80u));
+              }
             }
           }
         }
@@ -714,24 +737,39 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       const unsigned char* bin = s_mem + kFVLo + vb + j * kFWin + 16 * g;
       // byte offset of the lane's first column inside the segment's output rows; rows beyond the segment: dropped
       const unsigned doff = row_ok ? ((unsigned)lrow * (unsigned)w + (unsigned)(c0 + 4 * g)) * 2u : 0x80000000u;
+      // after the pair exchange below lane (g1 = g >> 1, g0 = g & 1) holds columns 8 g1 .. 8 g1 + 7 of tile 2 k + g0
+      const unsigned doff16 = row_ok ? ((unsigned)lrow * (unsigned)w + (unsigned)(c0 + 8 * (g >> 1))) * 2u : 0x80000000u;
+      uint2 keep{0u, 0u};
       auto tile_of = [&](int i) { const int t = 4 * wave + i; return t < nht ? t : 0; };
       constexpr int N = 4;
       unsigned badbits = 0;
       uint4 qlo = f_ldsq(bin + 16 * tile_of(0));
       uint4 qhi = f_ldsq(bin + 16 * tile_of(0) + (kFVHi - kFVLo));
-      MmAcc acc = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+      MmAcc acc = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, K);
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         MmAcc nxt;
         if (i + 1 < N) {
           qlo = f_ldsq(bin + 16 * tile_of(i + 1));
           qhi = f_ldsq(bin + 16 * tile_of(i + 1) + (kFVHi - kFVLo));
-          nxt = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
+          nxt = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, K);
         }
         bool bad;
-        const uint2 res = mm_finish_flag<kSigned>(acc, P, bad);
+        const uint2 res = mm_finish_flag<kSigned>(acc, bad);
         badbits |= (bad && row_ok) ? (1u << i) : 0u;
-        if (!(PL_G2D_VARIANT & 16) || res.x == 0x12345u) pl_buffer_store_u64(res, dstb, doff + 32u * (unsigned)tile_of(i), 0);
+        // the MFMA leaves a lane with 4 columns (8 bytes) of a row: stored tile by tile, a row would receive 32-byte
+        // pieces.  Tiles 2 k and 2 k + 1 trade halves across lane rows (v_permlane16_swap: row 1 of the first operand <->
+        // row 0 of the second, row 3 <-> row 2), after which a lane holds 8 consecutive columns of ONE tile and the four
+        // lanes of a row store 64 contiguous bytes
+        if ((i & 1) == 0) {
+          keep = res;
+        } else {
+          const auto sx = __builtin_amdgcn_permlane16_swap(keep.x, res.x, false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(keep.y, res.y, false, false);
+          const unsigned tsel = (g & 1) ? (unsigned)tile_of(i) : (unsigned)tile_of(i - 1);
+          if (!(PL_G2D_VARIANT & 16) || res.x == 0x12345u)
+            pl_buffer_store_u128(uint4{(unsigned)sx[0], (unsigned)sy[0], (unsigned)sx[1], (unsigned)sy[1]}, dstb, doff16 + 32u * tsel, 0);
+        }
         if (i + 1 < N) acc = nxt;
       }
       if (__ballot(badbits != 0u) != 0ull) {
@@ -749,14 +787,21 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
             const double c = sample(0, 16 * t);
             const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int) { return c; }, P));
             pl_buffer_store_u64(uint2{v | (v << 16), v | (v << 16)}, dstb, doff + 32u * (unsigned)t, 0);
-          } else if ((badbits >> i) & 1u) {
-            uint2 res{0u, 0u};
+          } else {
+            const MmAcc ra = mm_tile<false>(v4i{(int)flo.x, (int)flo.y, (int)flo.z, (int)flo.w}, v4i{(int)fhi.x, (int)fhi.y, (int)fhi.z, (int)fhi.w}, band, K);
+            if ((badbits >> i) & 1u) {
+              bool dummy;
+              uint2 res = mm_finish_flag<kSigned>(ra, dummy);
 #pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-              const int x = kMmHalo + 16 * t + 4 * g + q;
-              mm_set(res, q, (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(j, x + k); }, P)));
+              for (int q = 0; q < 4; ++q) {
+                unsigned z;
+                mm_decide(ra.a1[q], ra.a2[q], ra.a3[q], ra.a4[q], ra.a5[q], z);
+                if (z != 0u) continue;
+                const int x = kMmHalo + 16 * t + 4 * g + q;
+                mm_set(res, q, (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(j, x + k); }, P)));
+              }
+              pl_buffer_store_u64(res, dstb, doff + 32u * (unsigned)t, 0);
             }
-            pl_buffer_store_u64(res, dstb, doff + 32u * (unsigned)t, 0);
           }
         }
       }
@@ -813,7 +858,7 @@ int pl_gauss_mm2d_covers(const void* in, const void* out, int h, int w, int radi
   // h, w >= 64: every row / column the 24-wide halos reach is at most ONE reflection away (the kernel reflects by
   // arithmetic); frames below 2 GiB: 32-bit buffer offsets, 0x80000000 + tile offset stays out of range
   if (radius < 1 || radius > kMmMaxRad || h < 64 || w < 64 || (w % 16) || (int64_t)h * w * 2 >= 0x7fff0000LL) return 0;
-  return !((reinterpret_cast<uintptr_t>(in) & 7) || (reinterpret_cast<uintptr_t>(out) & 7));
+  return !((reinterpret_cast<uintptr_t>(in) & 7) || (reinterpret_cast<uintptr_t>(out) & 15));
 }
 
 // 0 = launched; -1 = shape / alignment / taps not covered (the caller runs the two passes).  wts: HOST memory.

@@ -116,6 +116,11 @@ __device__ __forceinline__ void pl_buffer_store_u64(uint2 v, __amdgpu_buffer_rsr
   __builtin_amdgcn_raw_buffer_store_b64(pl_v2u{v.x, v.y}, r, (int)lane_off, (int)uniform_off, 0);
 }
 
+__device__ __forceinline__ void pl_buffer_store_u128(uint4 v, __amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uniform_off) {
+  typedef unsigned pl_v4u __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(pl_v4u{v.x, v.y, v.z, v.w}, r, (int)lane_off, (int)uniform_off, 0);
+}
+
 // wave-level reductions (64 lanes, xor butterflies -> every lane holds the result)
 template <typename T, typename F>
 __device__ __forceinline__ T pl_wave_reduce(T v, F f) {

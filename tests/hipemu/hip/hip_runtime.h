@@ -115,6 +115,7 @@ inline void __syncthreads() { hipemu::block_barrier(); }
 inline int __syncthreads_or(int p) { return hipemu::block_barrier_or(p); }
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::shfl_from(0, 0))
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_fract(x) ((x) - floor(x))
 #define __builtin_amdgcn_fractf(x) ((x) - floorf(x))
 // v_mfma_i32_16x16x64_i8: byte s of lane (m, g) of A meets byte s of lane (n, g) of B (m, n = lane & 15, g = lane >> 4);
@@ -169,6 +170,23 @@ inline hipemu_v2u __builtin_amdgcn_raw_buffer_load_b64(hipemu_rsrc r, int voff, 
 inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_v2u v, hipemu_rsrc r, int voff, int soff, int) {
   if (hipemu_in_range(r, voff, 8)) memcpy(r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, &v, 8);
 }
+typedef unsigned hipemu_v4u __attribute__((ext_vector_type(4)));
+inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_v4u v, hipemu_rsrc r, int voff, int soff, int) {
+  if (hipemu_in_range(r, voff, 16)) memcpy(r.base + (size_t)(unsigned)voff + (size_t)(unsigned)soff, &v, 16);
+}
+// v_permlane16_swap_b32 (gfx950): rows of 16 lanes; row 1 of the first operand <-> row 0 of the second, row 3 <-> row 2.
+// Returns {new first, new second}.  Every lane of the wave must take part.
+inline hipemu_v2u hipemu_permlane16_swap(unsigned a, unsigned b) {
+  uint64_t all[64], act;
+  hipemu::wave_exchange(((uint64_t)b << 32) | a, all, &act);
+  const int lane = hipemu::lane_id();
+  const int row = lane >> 4;
+  hipemu_v2u r = {a, b};
+  if (row & 1) r[0] = (unsigned)(all[lane - 16] >> 32);        // first.row(odd) <- second.row(even)
+  else r[1] = (unsigned)(all[lane + 16] & 0xffffffffull);       // second.row(even) <- first.row(odd)
+  return r;
+}
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) hipemu_permlane16_swap((a), (b))
 // v_alignbit_b32: low 32 bits of ({hi, lo} >> (s & 31))
 #define __builtin_amdgcn_alignbit(hi, lo, s) \
   ((unsigned)(((((unsigned long long)(unsigned)(hi)) << 32) | (unsigned)(lo)) >> ((s) & 31)))
