@@ -541,7 +541,7 @@ __device__ __forceinline__ uint2 mm_finish_flag(const MmAcc& r, bool& bad) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 48.6 KB of LDS: three workgroups per CU
+__global__ void __launch_bounds__(kMmThreads) PL_WAVES_PER_EU(3, 3)   // 48.6 KB of LDS: three workgroups per CU
 gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int strips, int segs, int seg_rows, const MmParams P) {
   constexpr bool kSigned = (T)-1 < (T)0;
   constexpr unsigned kHiFlip = kSigned ? 0u : 0x80808080u;     // int16: the signed high byte already is x_hi - 128
@@ -837,11 +837,18 @@ int launch_mm_t(const T* in, T* out, int64_t n, int h, int w, int axis, const Mm
 template <typename T>
 int launch_mm2d_t(const T* in, T* out, int64_t n, int h, int w, const MmParams& P, hipStream_t st) {
   const int strips = (int)pl_cdiv(w, kFCols);
-  // row segments: enough workgroups to fill the chip several times over, at least 128 rows each (every segment re-reads
-  // 48 halo rows and pays the four-group prologue)
-  int64_t segs = pl_cdiv(2048, n * strips);
+  // row segments: the chip holds 256 CUs x 3 workgroups (48.6 KB of LDS each) at a time; a workgroup's cost is its steps
+  // plus about three steps' worth of prologue (four row groups, 48 halo rows).  Take the segment count that minimises
+  // rounds x (steps + 3), segments of at least 128 rows -- 256 x 1024 x 1024: 3 segments, 3072 workgroups, four full rounds
+  const int64_t resident = 256 * 3;
   const int64_t max_segs = h / 128 > 1 ? h / 128 : 1;
-  segs = segs < 1 ? 1 : (segs > max_segs ? max_segs : segs);
+  int64_t segs = 1, best = -1;
+  for (int64_t cand = 1; cand <= max_segs; ++cand) {
+    const int64_t rows = pl_cdiv(pl_cdiv(h, cand), 16) * 16;
+    const int64_t wgs = n * strips * pl_cdiv(h, rows);
+    const int64_t cost = pl_cdiv(wgs, resident) * (rows / 16 + 3);
+    if (best < 0 || cost < best) { best = cost; segs = cand; }
+  }
   const int seg_rows = (int)(pl_cdiv(pl_cdiv(h, segs), 16) * 16);
   segs = pl_cdiv(h, seg_rows);
   const int64_t blocks = n * strips * segs;
