@@ -541,7 +541,7 @@ __device__ __forceinline__ uint2 mm_finish_flag(const MmAcc& r, bool& bad) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(kMmThreads) PL_WAVES_PER_EU(3, 3)   // 48.6 KB of LDS: three workgroups per CU
+__global__ void __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 48.6 KB of LDS: three workgroups per CU
 gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int strips, int segs, int seg_rows, const MmParams P) {
   constexpr bool kSigned = (T)-1 < (T)0;
   constexpr unsigned kHiFlip = kSigned ? 0u : 0x80808080u;     // int16: the signed high byte already is x_hi - 128
@@ -641,9 +641,7 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
   // the accumulators' initial values live in twelve VGPRs for the whole march (the compiler would otherwise rebuild the
   // three quads from SGPRs in front of every tile: six v_mov_b64 per tile)
   MmConst K = mm_const(P);
-#ifndef PL_HIPEMU
   asm volatile("" : "+v"(K.c1), "+v"(K.c3), "+v"(K.c4));
-#endif
   __syncthreads();
 
   const int lane_cell = f_cell(j);                 // cell of column 16 t + j, less the tile's 64 t bytes

@@ -6,12 +6,6 @@
 #include "../../include/pylinac_hip.h"
 
 #define PL_WAVE 64
-// occupancy target of a kernel (register budget): the CPU emulator of tests/hipemu has no such attribute
-#ifdef PL_HIPEMU
-#define PL_WAVES_PER_EU(lo, hi)
-#else
-#define PL_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
-#endif
 
 // ---- host side -------------------------------------------------------------------------------
 void pl_set_error(const char* fmt, ...);

@@ -35,11 +35,15 @@ _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)
 
 _WAITCNT = re.compile(r'asm\s+volatile\s*\(\s*"s_waitcnt[^;]*;')
 _MED3 = re.compile(r'asm\("v_med3_[ui]32[^;]*;')
+_PIN = re.compile(r'asm\s+volatile\s*\(\s*""[^;]*;')                      # empty asm: a register-allocation hint
+_OCC = re.compile(r'__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)')   # occupancy target of a kernel
 
 
 def _rewrite(text: str) -> str:
     # gfx950 inline assembly: waits are meaningless here; v_med3 (operands a, b, c -> r) is spelled out
     text = _WAITCNT.sub(";", text)
+    text = _PIN.sub(";", text)
+    text = _OCC.sub("", text)
     text = _MED3.sub("r = std::max(std::min(a, b), std::min(std::max(a, b), c));", text)
     # `extern __shared__ T name[];`  ->  a pointer to the emulator's dynamic-LDS buffer
     return _DYN.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(hipemu::dyn_lds());", text)
