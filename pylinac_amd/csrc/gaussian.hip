@@ -279,10 +279,7 @@ int pl_gauss_rw_covers(const void* in, const void* out, int h, int w, int axis, 
 int pl_gauss_rw_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, int axis,
                        const double* h_wts, int radius, hipStream_t st);
 
-// gaussian_mm.hip: exact-integer matrix-core kernels for 16-bit images (any radius <= 24, width % 16 == 0); same protocol.
-int pl_gauss_mm_covers(const void* in, const void* out, int h, int w, int axis, int radius);
-int pl_gauss_mm_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, int axis,
-                       const double* h_wts, int radius, hipStream_t st);
+// gaussian_mm.hip: exact-integer matrix-core kernel for 16-bit frames, radius <= 24, width % 16 == 0, at least 64 x 64:
 // both axes in one kernel (the axis-0 result stays in LDS); same protocol
 int pl_gauss_mm2d_covers(const void* in, const void* out, int h, int w, int radius);
 int pl_gauss_mm2d_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, const double* h_wts, int radius,
@@ -297,8 +294,7 @@ template <typename T>
 int gaussian1d_t(const T* in, T* out, int64_t n, int h, int w, int axis, const double* wts, const double* h_wts,
                  int radius, hipStream_t st, int mode = 0) {
   int rc = -1;
-  const bool mm = sizeof(T) == 2 && mode == 0 && pl_gauss_mm_covers(in, out, h, w, axis, radius);
-  if (mm || (sizeof(T) == 2 && mode == 0 && pl_gauss_rw_covers(in, out, h, w, axis, radius))) {
+  if (sizeof(T) == 2 && mode == 0 && pl_gauss_rw_covers(in, out, h, w, axis, radius)) {
     double fetched[49];
     if (!h_wts) {  // convenience path: the caller gave no host copy of the taps -> fetch them (synchronises the stream)
       if (hipMemcpyAsync(fetched, wts, (size_t)(2 * radius + 1) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -308,9 +304,7 @@ int gaussian1d_t(const T* in, T* out, int64_t n, int h, int w, int axis, const d
       }
       h_wts = fetched;
     }
-    if (mm) rc = pl_gauss_mm_launch(in, out, (T)-1 < (T)0, n, h, w, axis, h_wts, radius, st);
-    if (rc != 0 && pl_gauss_rw_covers(in, out, h, w, axis, radius))
-      rc = pl_gauss_rw_launch(in, out, (T)-1 < (T)0, n, h, w, axis, h_wts, radius, st);
+    rc = pl_gauss_rw_launch(in, out, (T)-1 < (T)0, n, h, w, axis, h_wts, radius, st);
     if (rc == 0) return pl_check_launch("pl_gaussian1d");
   }
   // specialised instances: radius = int(4*sigma+0.5) for sigma 1, 2, 3, 5

@@ -1,50 +1,41 @@
-// Exact-integer matrix-core kernels for the scipy-exact Gaussian on 16-bit images.
+// Exact-integer matrix-core kernel for the scipy-exact Gaussian on 16-bit frames.
 //
 // Replaces: scipy.ndimage.gaussian_filter on uint16 / int16 frames as called at
 // pylinac/core/array_utils.py:133 (BaseImage.filter(kind="gaussian"), pylinac/core/image.py:695-712).
 //
-// Contract (gaussian.hip header): out = trunc(S), S = scipy's float64 tap sequence along one axis.  The register-window
-// kernels (gaussian_rw.hip) decide trunc(S) with a packed-float32 chain and are VALU-issue bound at ~0.35 of the HBM
-// roofline.  Here the 41-tap sum itself moves to the matrix cores, in EXACT integer arithmetic:
+// Contract (gaussian.hip header): per axis out = trunc(S), S = scipy's float64 tap sequence; axis 0 first, into the 16-bit
+// plane, then axis 1 on THAT plane.  The register-window kernels (gaussian_rw.hip, one axis per launch) decide trunc(S)
+// with a packed-float32 chain on the VALU.  Here the 41-tap sums move to the matrix cores, in EXACT integer arithmetic,
+// and both axes run in ONE launch (gauss2d_mm below):
 //
-//   taps     w_k = wq_k * 2^-Q + e_k,  wq_k = round(w_k * 2^Q) written in FIVE balanced base-256 digits d0..d4 (int8),
-//            Q chosen on the host so that the largest tap fills the five digits (Q = 42 at sigma = 5)
+//   taps     w_k = wq_k * 2^-40 + e_k,  wq_k = round(w_k * 2^40) written in FIVE balanced base-256 digits d0..d4 (int8)
 //   samples  biased value x in [0, 65535] (int16 input: x = v + 32768);  x - 32896 = 256 * hi + lo with
 //            hi = x_hi - 128, lo = x_lo - 128: BOTH digits are the raw bytes with the top bit flipped, both int8
 //   T        = sum_k wq_k * (x_k - 32896) = sum over digit pairs 256^(a+b) * sum_k d_a[k] * digit_b[x_k]:
 //            NINE v_mfma_i32_16x16x64_i8 per 16 x 16 output tile (Toeplitz band of one weight digit x one sample
 //            digit plane, K = the 64-sample window that holds the 16 + 2*RAD <= 64 inputs of 16 outputs), int32
 //            accumulation: exact, order-free; five accumulators a1..a5 (digit-pair scales 8, 16, .., 40 bits).  The tenth
-//            product (low sample digit x lowest weight digit, scale 0) is worth at most 1.5e-7 of a grey level: it is
-//            left out and its bound is part of delta
-//   S        = 2^-Q * (T + 32896 * sum wq_k) + E,  |E| <= 65535 * sum |e_k| + the dropped product  (4.5e-7 at sigma = 5)
+//            product (low sample digit x lowest weight digit, scale 0) is worth at most 6e-7 of a grey level: it is left
+//            out and its bound is part of D
+//   S        = 2^-40 * (T + 32896 * sum wq_k) + E,  |E| 2^40 <= D = 65535 * sum |e_k| 2^40 + the dropped product
+//            (D = 1.4e6 at sigma = 5, i.e. 1.3e-6 of a grey level)
 //
-// so floor(S) is known exactly unless frac(S) lies within delta = the |E| bound of an integer; those pixels (~1e-6, plus
-// constant / saturated neighbourhoods where S sits 1e-11 from an integer) are recomputed with scipy's float64 sequence
-// from the plane bytes still in LDS.
-//
-// Recombination per output is INTEGER ONLY (ten shift / add / and operations, no conversions), exact by the identity
-// floor((floor(x / a) + n) / b) = floor((x + a n) / (a b)).   With C' = 32896 * sum wq_k + M folded into the accumulators'
-// initial values (the MFMA's C operand; M = m 2^16 >= delta 2^Q + 2^16 shifts the undecided band [-delta, delta] around
-// every integer to [0, 2 m) of the fraction field),
-//   U  = a4 + 2^8 a5                                  scale 2^32;  U = Uh * 2^(Q-32) + Ur
-//   t  = a2 + (a1 >> 8)                               = floor((2^8 a1 + 2^16 a2) / 2^16)
-//   F  = 2^16 Ur + 2^8 a3 + t                         = floor((T + C' - Uh 2^Q) / 2^16)
-//   f  = F & (2^(Q-16) - 1);   decided iff f >= 2 m, and then floor(S) = Uh + (F >> (Q - 16))
-// The fraction is resolved to 2^-(Q-16) (1.5e-8 at sigma = 5), well below delta, so an output is undecided only when
-// frac(S) really lies within ~delta of an integer.
+// Decision.  With C' = 32896 * sum wq_k + M (M = 2^23 >= D) folded into the accumulators' initial values (the MFMA's C
+// operand), T' = T + C' and a carry cascade of arithmetic right shifts and adds -- full-rate VALU opcodes only, exact by
+// floor(floor(x / a) / b) = floor(x / (a b)):
+//   t_k = a_k + (t_{k-1} >> 8) = floor((2^8 a1 + .. + 2^(8k) a_k) / 2^(8k)),     bits 8k .. 8k+7 of T' = t_k & 255
+//   floor(S) = t_5 whenever T' mod 2^40 >= 2 M, i.e. whenever bits 24 .. 39 of T' are not all zero: z = (t3 | t4) & 255 != 0
+// z = 0 (1.5e-5 of the outputs, plus constant / saturated neighbourhoods where S sits 1e-11 from an integer) means
+// "undecided": recomputed with scipy's float64 sequence from the plane bytes still in LDS.
 //
 // Operand layout: v_mfma_i32_16x16x64_i8 pairs byte s of lane (m, g) of A with byte s of lane (n, g) of B (m, n = lane & 15,
 // g = lane >> 4) and leaves D[m = 4 * (lane >> 4) + reg][n = lane & 15] (scripts/ubench/mfma_i8.hip checks this on the
 // device); because A and B use the SAME slot -> k map, any consistent assignment of window positions to slots is correct:
 // slot (g, s) <-> window position k = 16 g + s.
 //
-// Axis 1: a wave owns 16 rows x 256 columns; it splits the raw rows (+ 24 halo columns each side, reflected at the frame
-// edge) into two byte planes in a wave-private LDS strip (one ds_read_b128 per plane then feeds a tile's 16 rows x 64
-// window bytes); no workgroup barrier.  Axis 0: a workgroup owns 64 columns x 256 rows; its four waves write the planes
-// TRANSPOSED ([column][row] bytes) so that the same 16-byte reads deliver 16 consecutive ROWS of one column; one barrier.
-// Results leave as 8-byte stores (4 consecutive columns of one row per lane); a row's 32-byte segments of neighbouring
-// tiles complete full lines in L2.
+// Cost model (scripts/ubench/mfma_valu_overlap.hip, mfma_valu_mix.hip on the MI355X): on one SIMD the i8 MFMA (17 cycles)
+// and the VALU (2.4 cycles for full-rate, 4.2 for half-rate opcodes) do NOT overlap -- their times add.  A tile costs
+// 9 MFMA + ~44 VALU, which is what bounds this kernel (not HBM): see DESIGN.md section 5.
 #include <type_traits>
 
 #include "pl_common.h"
@@ -62,7 +53,6 @@ constexpr int kMmThreads = 256;
 constexpr int kMmWaves = kMmThreads / PL_WAVE;
 constexpr int kMmHalo = 24;                 // window start = first output - 24: 16-byte aligned, covers RAD <= 24
 constexpr int kMmMaxRad = 24;
-constexpr int kMmListCap = 128;             // undecided outputs a wave / workgroup lists before everybody recomputes
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -213,246 +203,11 @@ __device__ __forceinline__ unsigned mm_decide(int a1, int a2, int a3, int a4, in
   return (unsigned)t5;
 }
 
-// four outputs of a lane (regs 0..3 = consecutive columns) -> two dwords of packed 16-bit results in the image's own
-// domain; fail: bit 3 - q set when output q is undecided
-template <bool SIGNED>
-__device__ __forceinline__ uint2 mm_finish(const MmAcc& r, const MmParams&, unsigned& fail) {
-  unsigned v[4], z[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    v[q] = mm_decide(r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], z[q]);
-    if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;   // C truncation rounds negative S toward zero
-  }
-  unsigned zm = z[0] < z[1] ? z[0] : z[1];
-  zm = zm < z[2] ? zm : z[2];
-  zm = zm < z[3] ? zm : z[3];
-  fail = 0;
-  if (zm == 0u) fail = (z[0] == 0u ? 8u : 0u) | (z[1] == 0u ? 4u : 0u) | (z[2] == 0u ? 2u : 0u) | (z[3] == 0u ? 1u : 0u);
-  return uint2{__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
-}
-
-// 16 raw pixels (8 dwords) -> their 16 low-digit bytes and 16 high-digit bytes
-template <bool SIGNED>
-__device__ __forceinline__ void mm_split16(const uint4 a, const uint4 b, uint4& lo, uint4& hi) {
-  constexpr unsigned kHiFlip = SIGNED ? 0u : 0x80808080u;    // int16: the signed high byte already is x_hi - 128
-  lo = uint4{__builtin_amdgcn_perm(a.y, a.x, 0x06040200u) ^ 0x80808080u, __builtin_amdgcn_perm(a.w, a.z, 0x06040200u) ^ 0x80808080u,
-             __builtin_amdgcn_perm(b.y, b.x, 0x06040200u) ^ 0x80808080u, __builtin_amdgcn_perm(b.w, b.z, 0x06040200u) ^ 0x80808080u};
-  hi = uint4{__builtin_amdgcn_perm(a.y, a.x, 0x07050301u) ^ kHiFlip, __builtin_amdgcn_perm(a.w, a.z, 0x07050301u) ^ kHiFlip,
-             __builtin_amdgcn_perm(b.y, b.x, 0x07050301u) ^ kHiFlip, __builtin_amdgcn_perm(b.w, b.z, 0x07050301u) ^ kHiFlip};
-}
-
 // the actual sample value from its two plane bytes
 template <bool SIGNED>
 __device__ __forceinline__ double mm_value(unsigned char lo, unsigned char hi) {
   const int x = ((int)(signed char)hi + 128) * 256 + ((int)(signed char)lo + 128);   // biased value 0 .. 65535
   return (double)(x - (SIGNED ? 32768 : 0));
-}
-
-// ---------------------------------------------------------------------- axis 1 (horizontal) pass
-constexpr int kHSeg = 256;                       // output columns per wave
-constexpr int kHPitch = kHSeg + 2 * kMmHalo;     // bytes per plane row (304: 16-byte multiple, 76 dwords: conflict-free b128)
-constexpr int kHTiles = kHSeg / 16;
-
-template <typename T>
-__global__ void __launch_bounds__(kMmThreads)
-gauss_h_mm(const T* __restrict__ in, T* __restrict__ out, int64_t rows_total, int w, int col_tiles, const MmParams P) {
-  constexpr bool kSigned = (T)-1 < (T)0;
-  __shared__ __attribute__((aligned(16))) unsigned char s_lo[kMmWaves][16 * kHPitch];
-  __shared__ __attribute__((aligned(16))) unsigned char s_hi[kMmWaves][16 * kHPitch];
-  __shared__ unsigned s_cnt[kMmWaves];
-  __shared__ unsigned s_item[kMmWaves][kMmListCap];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & (PL_WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid / PL_WAVE);
-  const unsigned lid = pl_xcd_remap(blockIdx.x, gridDim.x);
-  const int ct = lid % col_tiles;
-  const int64_t r0 = ((int64_t)(lid / col_tiles) * kMmWaves + wave) * 16;   // first of the wave's 16 rows (frame*h + r)
-  if (r0 >= rows_total) return;                    // wave-uniform; no workgroup barrier below
-  const int c0 = ct * kHSeg;
-  unsigned char* plo = s_lo[wave];
-  unsigned char* phi = s_hi[wave];
-  const int j = lane & 15, g = lane >> 4;
-  if (lane == 0) s_cnt[wave] = 0;
-
-  // ---- split the 16 rows x 304 columns into the two byte planes: lane = (row j, 16-column chunk g + 4 * it)
-  {
-    const int64_t row = r0 + j < rows_total ? r0 + j : rows_total - 1;     // rows beyond the end repeat the last one
-    const T* src = in + row * (size_t)w;
-#pragma unroll 1
-    for (int it = 0; it < 5; ++it) {
-      const int chunk = g + 4 * it;
-      if (chunk >= kHPitch / 16) break;
-      const int col = c0 - kMmHalo + 16 * chunk;
-      uint4 a, b;
-      if (col >= 0 && col + 16 <= w) {
-        a = *reinterpret_cast<const uint4*>(src + col);
-        b = *reinterpret_cast<const uint4*>(src + col + 8);
-      } else {
-        unsigned short v[16];
-#pragma unroll 1
-        for (int q = 0; q < 16; ++q) v[q] = (unsigned short)src[pl_reflect(col + q, w)];
-        a = uint4{v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16)};
-        b = uint4{v[8] | ((unsigned)v[9] << 16), v[10] | ((unsigned)v[11] << 16), v[12] | ((unsigned)v[13] << 16), v[14] | ((unsigned)v[15] << 16)};
-      }
-      uint4 lo, hi;
-      mm_split16<kSigned>(a, b, lo, hi);
-      *reinterpret_cast<uint4*>(plo + j * kHPitch + 16 * chunk) = lo;
-      *reinterpret_cast<uint4*>(phi + j * kHPitch + 16 * chunk) = hi;
-    }
-  }
-  v4i band[kMmDigits];
-#pragma unroll
-  for (int d = 0; d < kMmDigits; ++d) band[d] = mm_band_operand(P, d, lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-  // ---- tiles: Toeplitz (M = output column) x image (N = row): lane (j, g) ends with columns 4 g .. 4 g + 3 of row j
-  const int64_t orow = r0 + j;
-  T* dst = out + orow * (size_t)w + c0 + 4 * g;
-  const bool row_ok = orow < rows_total;
-  const int ntiles = (w - c0) / 16 < kHTiles ? (w - c0) / 16 : kHTiles;
-  unsigned anyfail = 0;
-#pragma unroll 2
-  for (int t = 0; t < ntiles; ++t) {
-    const uint4 qlo = *reinterpret_cast<const uint4*>(plo + j * kHPitch + 16 * (t + g));
-    const uint4 qhi = *reinterpret_cast<const uint4*>(phi + j * kHPitch + 16 * (t + g));
-    const MmAcc r = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w},
-                                   v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
-    unsigned fail = 0;
-    const uint2 res = mm_finish<kSigned>(r, P, fail);
-    if (row_ok) *reinterpret_cast<uint2*>(dst + 16 * t) = res;
-    fail &= row_ok ? 15u : 0u;
-    if (fail) {                                   // rare: list (tile, lane, 4 fail bits)
-      const unsigned i = atomicAdd(&s_cnt[wave], 1u);
-      if (i < (unsigned)kMmListCap) s_item[wave][i] = ((unsigned)t << 10) | ((unsigned)lane << 4) | fail;
-      anyfail = 1;
-    }
-  }
-  (void)anyfail;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const unsigned cnt = s_cnt[wave];
-  if (cnt == 0) return;
-  // ---- undecided outputs: scipy's float64 sequence from the plane bytes of the wave's own strip
-  auto fix_one = [&](int t, int l, int q) {       // tile t, lane l, register q (fail bit 3 - q)
-    const int jj = l & 15, col = 16 * t + 4 * (l >> 4) + q;           // strip-relative output column
-    if (r0 + jj >= rows_total || c0 + col >= w) return;
-    const unsigned char* lo = plo + jj * kHPitch + col + kMmHalo;
-    const unsigned char* hi = phi + jj * kHPitch + col + kMmHalo;
-    const double acc = mm_exact([&](int k) { return mm_value<kSigned>(lo[k], hi[k]); }, P);
-    out[(r0 + jj) * (size_t)w + c0 + col] = pl_from_double<T>(acc);
-  };
-  if (cnt <= (unsigned)kMmListCap) {
-    for (unsigned e = lane; e < cnt * 4; e += PL_WAVE) {
-      const unsigned code = s_item[wave][e >> 2];
-      const int q = (int)(e & 3u);
-      if (code & (8u >> q)) fix_one((int)(code >> 10), (int)((code >> 4) & 63u), q);
-    }
-  } else {
-    for (int t = 0; t < ntiles; ++t)
-      for (int q = 0; q < 4; ++q) fix_one(t, lane, q);
-  }
-}
-
-// ------------------------------------------------------------------------ axis 0 (vertical) pass
-constexpr int kVCols = 64;                       // columns per workgroup (lane = column while the planes are filled)
-constexpr int kVRows = 256;                      // output rows per workgroup (64 per wave)
-constexpr int kVPitch = kVRows + 2 * kMmHalo;    // bytes per plane COLUMN (304)
-
-template <typename T>
-__global__ void __launch_bounds__(kMmThreads)
-gauss_v_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_tiles, int row_tiles, const MmParams P) {
-  constexpr bool kSigned = (T)-1 < (T)0;
-  __shared__ __attribute__((aligned(16))) unsigned char s_lo[kVCols * kVPitch];   // [column][row]
-  __shared__ __attribute__((aligned(16))) unsigned char s_hi[kVCols * kVPitch];
-  __shared__ unsigned s_cnt;
-  __shared__ unsigned s_item[kMmListCap];
-
-  unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
-  const int ct = id % col_tiles;
-  id /= col_tiles;
-  const int rt = id % row_tiles;
-  const size_t frame = id / row_tiles;
-  const int tid = threadIdx.x;
-  const int lane = tid & (PL_WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid / PL_WAVE);
-  const int c0 = ct * kVCols, r0 = rt * kVRows;
-  const T* f = in + frame * (size_t)h * w;
-  T* o = out + frame * (size_t)h * w;
-  if (tid == 0) s_cnt = 0;
-
-  // ---- planes, transposed: every wave takes 76 of the 304 window rows, four rows per step; lane = column
-  {
-    const int c = c0 + lane < w ? c0 + lane : w - 1;
-    constexpr unsigned kHiFlip = kSigned ? 0u : 0x80808080u;
-    constexpr int kShare = kVPitch / kMmWaves;     // 76
-#pragma unroll 1
-    for (int s = 0; s < kShare; s += 4) {
-      const int p = wave * kShare + s;             // plane row of the first of the four
-      unsigned x[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) x[q] = (unsigned short)f[(size_t)pl_reflect(r0 - kMmHalo + p + q, h) * w + c];
-      const unsigned t0 = __builtin_amdgcn_perm(x[1], x[0], 0x05010400u);   // {x0.b0, x1.b0, x0.b1, x1.b1}
-      const unsigned t1 = __builtin_amdgcn_perm(x[3], x[2], 0x05010400u);
-      *reinterpret_cast<unsigned*>(s_lo + lane * kVPitch + p) = __builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u;
-      *reinterpret_cast<unsigned*>(s_hi + lane * kVPitch + p) = __builtin_amdgcn_perm(t1, t0, 0x07060302u) ^ kHiFlip;
-    }
-  }
-  v4i band[kMmDigits];
-#pragma unroll
-  for (int d = 0; d < kMmDigits; ++d) band[d] = mm_band_operand(P, d, lane);
-  __syncthreads();
-
-  // ---- tiles: image (M = column) x Toeplitz (N = output row): lane (j, g) ends with columns 4 g .. 4 g + 3 of row j
-  const int j = lane & 15, g = lane >> 4;
-  const int ncb = (w - c0) / 16 < kVCols / 16 ? (w - c0) / 16 : kVCols / 16;
-#pragma unroll 1
-  for (int tr = 0; tr < 4; ++tr) {
-    const int lrow = wave * 64 + 16 * tr;          // first output row of the tile inside the workgroup
-    if (r0 + lrow >= h) break;
-    const bool row_ok = r0 + lrow + j < h;
-    T* dst = o + (size_t)(r0 + lrow + j) * w + c0 + 4 * g;
-#pragma unroll 2
-    for (int cb = 0; cb < ncb; ++cb) {
-      const uint4 qlo = *reinterpret_cast<const uint4*>(s_lo + (16 * cb + j) * kVPitch + lrow + 16 * g);
-      const uint4 qhi = *reinterpret_cast<const uint4*>(s_hi + (16 * cb + j) * kVPitch + lrow + 16 * g);
-      const MmAcc r = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w},
-                                    v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, P);
-      unsigned fail = 0;
-      const uint2 res = mm_finish<kSigned>(r, P, fail);
-      if (row_ok) *reinterpret_cast<uint2*>(dst + 16 * cb) = res;
-      fail &= row_ok ? 15u : 0u;
-      if (fail) {
-        const unsigned i = atomicAdd(&s_cnt, 1u);
-        if (i < (unsigned)kMmListCap) s_item[i] = ((unsigned)(wave * 16 + tr * 4 + cb) << 10) | ((unsigned)lane << 4) | fail;
-      }
-    }
-  }
-  __syncthreads();
-  const unsigned cnt = s_cnt;
-  if (cnt == 0) return;
-  auto fix_one = [&](int tile, int l, int q) {     // tile = wave * 16 + tr * 4 + cb
-    const int lrow = (tile >> 4) * 64 + ((tile >> 2) & 3) * 16 + (l & 15);
-    const int lcol = (tile & 3) * 16 + 4 * (l >> 4) + q;
-    if (r0 + lrow >= h || c0 + lcol >= w) return;
-    const unsigned char* lo = s_lo + lcol * kVPitch + lrow + kMmHalo;
-    const unsigned char* hi = s_hi + lcol * kVPitch + lrow + kMmHalo;
-    const double acc = mm_exact([&](int k) { return mm_value<kSigned>(lo[k], hi[k]); }, P);
-    o[(size_t)(r0 + lrow) * w + c0 + lcol] = pl_from_double<T>(acc);
-  };
-  if (cnt <= (unsigned)kMmListCap) {
-    for (unsigned e = tid; e < cnt * 4; e += kMmThreads) {
-      const unsigned code = s_item[e >> 2];
-      const int q = (int)(e & 3u);
-      if (code & (8u >> q)) fix_one((int)(code >> 10), (int)((code >> 4) & 63u), q);
-    }
-  } else {
-    for (int tile = wave * 16; tile < wave * 16 + 16; ++tile)
-      for (int q = 0; q < 4; ++q) fix_one(tile, lane, q);
-  }
 }
 
 // ------------------------------------------------------------------ both axes in ONE kernel: the marching strip
@@ -815,24 +570,6 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
 }
 
 template <typename T>
-int launch_mm_t(const T* in, T* out, int64_t n, int h, int w, int axis, const MmParams& P, hipStream_t st) {
-  if (axis == 0) {
-    const int col_tiles = (int)pl_cdiv(w, kVCols);
-    const int row_tiles = (int)pl_cdiv(h, kVRows);
-    const int64_t blocks = n * col_tiles * row_tiles;
-    if (blocks > 0x7fffffffLL) return -1;
-    hipLaunchKernelGGL(gauss_v_mm<T>, dim3((unsigned)blocks), dim3(kMmThreads), 0, st, in, out, h, w, col_tiles, row_tiles, P);
-  } else {
-    const int col_tiles = (int)pl_cdiv(w, kHSeg);
-    const int64_t rows_total = n * h;
-    const int64_t blocks = pl_cdiv(pl_cdiv(rows_total, 16), kMmWaves) * col_tiles;
-    if (blocks > 0x7fffffffLL) return -1;
-    hipLaunchKernelGGL(gauss_h_mm<T>, dim3((unsigned)blocks), dim3(kMmThreads), 0, st, in, out, rows_total, w, col_tiles, P);
-  }
-  return 0;
-}
-
-template <typename T>
 int launch_mm2d_t(const T* in, T* out, int64_t n, int h, int w, const MmParams& P, hipStream_t st) {
   const int strips = (int)pl_cdiv(w, kFCols);
   // row segments: the chip holds 256 CUs x 3 workgroups (48.6 KB of LDS each) at a time; a workgroup's cost is its steps
@@ -874,22 +611,4 @@ int pl_gauss_mm2d_launch(const void* in, void* out, int is_signed, int64_t n, in
   if (!mm_make_params(wts, radius, P)) return -1;
   return is_signed ? launch_mm2d_t<short>((const short*)in, (short*)out, n, h, w, P, st)
                    : launch_mm2d_t<unsigned short>((const unsigned short*)in, (unsigned short*)out, n, h, w, P, st);
-}
-
-// 1 when pl_gauss_mm_launch covers this call's shape (the taps are checked at launch; the caller needs them in HOST memory)
-int pl_gauss_mm_covers(const void* in, const void* out, int h, int w, int axis, int radius) {
-  if (radius < 1 || radius > kMmMaxRad || h < 1) return 0;
-  if (w % 16) return 0;
-  if (axis == 0) return !((reinterpret_cast<uintptr_t>(in) & 1) || (reinterpret_cast<uintptr_t>(out) & 7));
-  return !((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 7));
-}
-
-// 0 = launched; -1 = shape / alignment / taps not covered (caller uses the other kernels).  wts: HOST memory.
-int pl_gauss_mm_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, int axis, const double* wts,
-                       int radius, hipStream_t st) {
-  if (!pl_gauss_mm_covers(in, out, h, w, axis, radius)) return -1;
-  MmParams P;
-  if (!mm_make_params(wts, radius, P)) return -1;
-  return is_signed ? launch_mm_t<short>((const short*)in, (short*)out, n, h, w, axis, P, st)
-                   : launch_mm_t<unsigned short>((const unsigned short*)in, (unsigned short*)out, n, h, w, axis, P, st);
 }

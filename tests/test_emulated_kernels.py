@@ -191,6 +191,39 @@ def test_emu_gaussian_register_window_kernels(emu):
             np.testing.assert_array_equal(out, want, err_msg=f"{frames.shape} {frames.dtype} sigma {sigma}")
 
 
+def test_emu_gaussian_marching_strip_kernel(emu):
+    """gaussian_mm.hip, gauss2d_mm (both axes in one launch: marching strip, integer MFMA digit planes, carry-cascade
+    decision, pair exchange for the stores): two strips with a partial second one, two row segments, mirrored border quads
+    on both sides, zero / constant / saturated blocks (whole-tile constant path and per-output recompute), int16, all
+    sigmas.  Bit-identical to scipy.  (Frames below 64 x 64 take the single-axis kernels: covered by the tests above.)"""
+    import build as emu_build
+    from scipy import ndimage
+
+    if "gaussian_mm.hip" not in emu_build.SOURCES:
+        pytest.skip("no clang++ host compiler: gaussian_mm.hip is not in the emulated library")
+    rng = np.random.default_rng(31)
+    cases = []
+    for shape in ((2, 150, 144), (1, 300, 272), (1, 70, 1040)):
+        smooth = ndimage.gaussian_filter(rng.integers(0, 65535, shape).astype(float), (0, 5, 5))
+        a = np.clip(smooth + rng.normal(0, 300, shape), 0, 65535).astype(np.uint16)
+        a[0, : shape[1] // 3, : shape[2] // 2] = 0
+        a[-1, shape[1] // 2:, shape[2] // 2:] = 41234
+        cases.append(a)
+    cases.append((cases[0].astype(np.int32) - 31000).astype(np.int16))
+    cases.append(np.full((1, 70, 128), 65535, dtype=np.uint16))
+    for frames in cases:
+        n, h, w = frames.shape
+        for sigma in ((5,) if w > 1000 else (1, 2, 3, 5)):
+            radius = int(4.0 * sigma + 0.5)
+            x = np.arange(-radius, radius + 1)
+            wts = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+            wts = np.ascontiguousarray(wts / wts.sum())
+            out, tmp = np.full_like(frames, 12345), np.empty_like(frames)
+            _ok(emu, emu.pl_gaussian2d(_p(frames), _p(out), _p(tmp), _DT[frames.dtype], n, h, w, _p(wts), _p(wts), radius, None))
+            want = np.stack([ndimage.gaussian_filter(f, sigma) for f in frames])
+            np.testing.assert_array_equal(out, want, err_msg=f"{frames.shape} {frames.dtype} sigma {sigma}")
+
+
 def test_emu_median3_packed_kernels(emu):
     from scipy import ndimage
 

@@ -921,6 +921,52 @@ def test_gaussian_default_kernels_on_epid_and_ragged_frames(dev):
     _check_gaussian_cases(dev)
 
 
+def test_gaussian_marching_strip_kernel_vs_scipy(dev):
+    """gauss2d_mm (both axes in one launch, exact integer arithmetic on the matrix cores): frames of at least 64 x 64 with
+    width % 16 == 0 take it.  Several strips with a partial last one, several row segments, mirrored border quads, EPID-like
+    content, zero / constant / saturated blocks (whole-tile constant path), full-range noise, int16, every sigma the
+    analyzers use plus radius 24; 1024 x 1024 frames against scipy itself."""
+    from scipy import ndimage
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(2024)
+    cases = []
+    for shape in ((2, 300, 528), (1, 64, 64), (3, 130, 1040), (1, 1024, 1024)):
+        smooth = ndimage.gaussian_filter(rng.integers(0, 65535, shape).astype(float), (0, 6, 6))
+        a = np.clip(20000 + 6.0 * (smooth - 32767) + rng.normal(0, 250, shape), 0, 65535).astype(np.uint16)
+        a[0, : shape[1] // 3, : shape[2] // 2] = 0
+        a[-1, shape[1] // 2:, shape[2] // 2:] = 41234
+        a[0, shape[1] // 2:, : shape[2] // 4] = 65535
+        cases.append(a)
+    cases.append(rng.integers(0, 65536, (2, 200, 272), dtype=np.uint16))
+    cases.append((cases[0].astype(np.int32) - 31000).astype(np.int16))
+    cases.append(np.full((1, 96, 256), 65535, dtype=np.uint16))
+    for a in cases:
+        for sigma in ((5,) if a.shape[1] >= 1024 else (1, 2, 3, 5, 6)):
+            ref = np.stack([ndimage.gaussian_filter(f, sigma) for f in a])
+            got = ops.gaussian_filter(T(a, dev), sigma).cpu().numpy()
+            assert np.array_equal(got, ref), (a.shape, a.dtype, sigma, int((got != ref).sum()))
+
+
+def test_gaussian_marching_strip_equals_two_pass_kernels_full_size(dev):
+    """At BASELINE size (64 frames of 1024 x 1024) without the oracle: the one-launch kernel (pl_gaussian2d) and the two
+    single-axis launches (pl_gaussian1d twice: a different kernel family with a different decision rule) agree bit for
+    bit on EPID frames -- 67 M outputs, where a decision bound that is too tight by one part in a million would show."""
+    from pylinac_amd import _lib, ops
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    fr = epid_open_field_frames(64, 1024, 1024, device=dev)
+    one = ops.gaussian_filter(fr, 5)
+    wts, hw, rad = ops._device_weights(5, dev)
+    lib = _lib.load()
+    tmp, two = torch.empty_like(fr), torch.empty_like(fr)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.pl_gaussian1d(fr.data_ptr(), tmp.data_ptr(), _lib.PL_U16, 64, 1024, 1024, 0, wts.data_ptr(), hw.ctypes.data, rad, st) == 0
+    assert lib.pl_gaussian1d(tmp.data_ptr(), two.data_ptr(), _lib.PL_U16, 64, 1024, 1024, 1, wts.data_ptr(), hw.ctypes.data, rad, st) == 0
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+
+
 def test_gaussian_without_host_taps_fetches_them(dev):
     """pl_gaussian2d with h_weights = NULL: the library fetches the taps from the device copy (synchronising
     convenience path) and produces the same frames."""
