@@ -266,6 +266,11 @@ def main():
                         "in one launch, exact integer arithmetic on the matrix cores (v_mfma_i32_16x16x64_i8 over byte digit "
                         "planes), axis-0 plane kept in LDS; bound by MFMA + integer recombination issue, not by HBM "
                         "(DESIGN.md section 5)",
+                # the same launch priced as matrix-core work (gauss2d only): 35 tiles of 16 x 16 outputs per 16 x 256
+                # block, nine v_mfma_i32_16x16x64_i8 (32768 int8 ops) each, against the ~5 POP/s dense int8 peak
+                "mfma_view": ({"tiles": n * (h // 16) * (w // 256) * 35, "tops": round(n * (h // 16) * (w // 256) * 35 * 9 * 32768 / dom_s / 1e12, 1),
+                               "peak_tops": 5000.0, "frac": round(n * (h // 16) * (w // 256) * 35 * 9 * 32768 / dom_s / 1e12 / 5000.0, 4)}
+                              if dominant == "gauss2d" and h % 16 == 0 and w % 256 == 0 else None),
                 "pipeline_frac": round(value / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             },
