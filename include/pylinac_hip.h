@@ -128,6 +128,14 @@ int pl_otsu_from_hist(const uint32_t* d_hist, int dtype, int64_t n, int32_t* d_t
  * the same call (d_hist uint32[n][65536] workspace is touched only for those; d_flag int32[n] scratch says which). */
 int pl_otsu16(const void* in, int dtype, int64_t n, int64_t count, const int32_t* d_lo, const int32_t* d_hi,
               int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist, void* stream);
+/* pl_otsu16 of the 3x3 MEDIAN of each h x w frame (Image.filter(3, "median") followed by the Otsu threshold,
+ * pylinac/core/image.py:695-712 -> array_utils.py:131, then skimage.filters.threshold_otsu as at pylinac/ct.py:3323)
+ * WITHOUT writing the median plane: the one-pass kernel computes the medians on the fly.  Needs h > 1, w % 8 == 0, 16-byte
+ * aligned frames.  scratch (n*h*w elements of dtype) receives the median plane of ONLY those frames that do not fit the
+ * one-pass window (d_flag[i] = 1) -- they go through pl_median2d's kernel, pl_hist16 and pl_otsu_from_hist inside this call. */
+int pl_median3_otsu16(const void* in, void* scratch, int dtype, int64_t n, int h, int w, const int32_t* d_lo,
+                      const int32_t* d_hi, int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag,
+                      uint32_t* d_hist, void* stream);
 /* exact order statistics: out[i][k] = value with 0-based rank d_ranks[k] in frame i
  * (np.percentile call sites: pylinac/core/image.py:899-926, picketfence.py:229-238). */
 int pl_order_stats_from_hist(const uint32_t* d_hist, int dtype, int64_t n, const int64_t* d_ranks,
@@ -143,6 +151,11 @@ int pl_reduce_axis(const void* in, int dtype, int64_t n, int h, int w, int axis,
  * image.py:797-800 and picketfence.py:747-750).  d_colsum: uint64 [n][w], zeroed inside. */
 int pl_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_t n, int h, int w,
                             const int32_t* d_thr, unsigned long long* d_colsum, void* stream);
+/* the same with out = threshold(median3(in)): Image.filter(3, "median") (image.py:695-712), Image.threshold (:785-800)
+ * and the axis-0 column sums (picketfence.py:747-750) in ONE pass over the unfiltered frame; the median plane is never
+ * written.  Needs h > 1, w % 8 == 0, 16-byte aligned frames. */
+int pl_median3_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_t n, int h, int w,
+                                    const int32_t* d_thr, unsigned long long* d_colsum, void* stream);
 
 /* d_out[n][w] = d_colsum[n][w] / h in float64: the np.mean(axis=0) profile of an integer frame. */
 int pl_colsum_to_mean(const unsigned long long* d_colsum, int64_t n, int w, int h, double* d_out,

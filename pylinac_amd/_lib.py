@@ -66,9 +66,11 @@ SIGNATURES = {
     "pl_hist16": ([_p, _i, _l, _l, _p, _p], C.c_int),
     "pl_otsu_from_hist": ([_p, _i, _l, _p, _p, _p, _p], C.c_int),
     "pl_otsu16": ([_p, _i, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
+    "pl_median3_otsu16": ([_p, _p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_order_stats_from_hist": ([_p, _i, _l, _p, _i, _p, _p], C.c_int),
     "pl_reduce_axis": ([_p, _i, _l, _i, _i, _i, _i, _p, _p], C.c_int),
     "pl_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
+    "pl_median3_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
     "pl_circle_profile": ([_p, _i, _l, _i, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p], C.c_int),
     "pl_sobel": ([_p, _p, _i, _l, _i, _i, _i, _p], C.c_int),
     "pl_label": ([_p, _l, _i, _i, _i, _p, _p, _p, _p], C.c_int),

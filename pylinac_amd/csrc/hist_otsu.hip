@@ -22,6 +22,7 @@
 // cumsum because every partial sum is an integer < 2^53), then the float64 variance expression in
 // skimage's operation order and a (value, first-index) arg-max reduction.
 #include "pl_common.h"
+#include "median3_rows.h"
 
 namespace {
 
@@ -243,8 +244,12 @@ otsu_kernel(const uint32_t* __restrict__ hist, int bias, int32_t* __restrict__ t
 // sets flag[frame] = 1: the frame is then left to the two-kernel path, launched right behind and gated per frame by that flag.
 constexpr int kWinBins = 38912;   // 152 KiB
 
+// MED3: the histogram is that of the 3x3 MEDIAN of the frame (h x w, geometry of pl_median3_rows_covers), computed on the
+// fly by pl_median3_rows -- the median plane is never written (the window is still placed from a sample of the raw frame: a
+// median lies between the extrema of its window).  T = short / unsigned short decides how the median compares.
+template <typename T, bool MED3>
 __global__ void __launch_bounds__(kHistThreads)
-otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, unsigned flip, int bias,
+otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h, int w, unsigned flip, int bias,
                      const int32_t* __restrict__ lo_hint, const int32_t* __restrict__ hi_hint, int32_t* __restrict__ thr,
                      int32_t* __restrict__ vmin, int32_t* __restrict__ vmax, int32_t* __restrict__ flag) {
   extern __shared__ unsigned bins[];  // kWinBins
@@ -310,7 +315,40 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, unsig
     if (b < (unsigned)range) atomicAdd(&bins[b], 1u);
     else outside = 1;
   };
-  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+  if (MED3) {
+    // every wave walks (column block of 512, row group of 16) items; all 64 lanes take part in the median's cross-lane moves,
+    // lanes beyond the frame's width tally nothing
+    const int col_waves = (w / 8 + PL_WAVE - 1) / PL_WAVE, row_groups = (h + 15) / 16;
+    for (int item = wv; item < col_waves * row_groups; item += kHistThreads / 64) {
+      const int c0 = ((item % col_waves) * PL_WAVE + lane) * 8;
+      const bool on = c0 < w;
+      pl_median3_rows<T, 16>(reinterpret_cast<const T*>(src), h, w, c0, lane, (item / col_waves) * 16,
+                             [&](int, const unsigned (&pk)[4]) {
+        const unsigned first = pk[0] & 0xffffu;
+        const unsigned splat = first | (first << 16);
+        const bool lane_flat = pk[0] == splat && pk[1] == splat && pk[2] == splat && pk[3] == splat;
+        const unsigned long long act = __ballot(on);
+        if (act == 0ull) return;
+        const unsigned wave_first = (unsigned)__builtin_amdgcn_readlane((int)splat, __builtin_ctzll(act));
+        if (__ballot(on && !(lane_flat && splat == wave_first)) == 0ull) {   // one value in the whole wave: one atomic
+          const unsigned b = ((wave_first & 0xffffu) ^ flip) - (unsigned)klo;
+          if (b < (unsigned)range) {
+            if (lane == __builtin_ctzll(act)) atomicAdd(&bins[b], 8u * (unsigned)__popcll(act));
+          } else {
+            outside = 1;
+          }
+          return;
+        }
+        if (on) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            tally(pk[k] & 0xffffu);
+            tally(pk[k] >> 16);
+          }
+        }
+      });
+    }
+  } else if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const int64_t nvec = count / 8;
     const uint4* vsrc = reinterpret_cast<const uint4*>(src);
     auto tally4 = [&](uint4 q) {
@@ -484,6 +522,50 @@ extern "C" int pl_order_stats_from_hist(const uint32_t* d_hist, int dtype, int64
  * optional per-frame bounds (int32[n], d_lo <= values <= d_hi), both NULL = the kernel places its window from a row
  * sample.  d_thr / d_min / d_max as pl_otsu_from_hist; d_flag int32[n] scratch; d_hist uint32[n][65536] workspace,
  * touched only for frames that do not fit the 38 912-bin LDS window. */
+// median.hip: 3x3 median of the frames whose gate flag is non-zero (0 = launched)
+int pl_median3_gated(const void* in, void* out, int is_signed, int64_t n, int h, int w, const int32_t* d_gate, hipStream_t st);
+
+namespace {
+template <typename T, bool MED3>
+int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t count, int h, int w, const int32_t* d_lo,
+                  const int32_t* d_hi, int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist,
+                  hipStream_t st, const char* who) {
+  const unsigned flip = dtype == PL_I16 ? 0x8000u : 0u;
+  const int bias = dtype == PL_I16 ? 32768 : 0;
+  const size_t lds = (size_t)kWinBins * sizeof(unsigned);
+  static bool attr = false;                        // one flag per instantiation
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)otsu16_window_kernel<T, MED3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      pl_set_error("%s: LDS attribute: %s", who, hipGetErrorString(hipGetLastError()));
+      return PL_ERR_HIP;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL((otsu16_window_kernel<T, MED3>), dim3((unsigned)n), dim3(kHistThreads), lds, st, (const unsigned short*)in,
+                     count, h, w, flip, bias, d_lo, d_hi, d_thr, d_min, d_max, d_flag);
+  // frames too wide for the window: the two-kernel path, every workgroup gated by d_flag -- on the median plane, which is
+  // materialised for exactly those frames when the one-pass kernel computed its medians on the fly
+  const unsigned short* plane = (const unsigned short*)in;
+  if (MED3) {
+    if (pl_median3_gated(in, scratch, dtype == PL_I16, n, h, w, d_flag, st) != 0) {
+      pl_set_error("%s: gated median launch rejected", who);
+      return PL_ERR_INVALID_ARG;
+    }
+    plane = (const unsigned short*)scratch;
+  }
+  int rc = launch_hist16<2, false>(plane, n, count, flip, d_hist, st, d_flag);
+  if (rc != 0) rc = launch_hist16<4, false>(plane, n, count, flip, d_hist, st, d_flag);
+  if (rc != 0) {
+    pl_set_error("%s: launch configuration rejected", who);
+    return PL_ERR_INVALID_ARG;
+  }
+  hipLaunchKernelGGL(otsu_kernel, dim3((unsigned)n), dim3(kHistThreads), 0, st, d_hist, bias, d_thr, d_min, d_max,
+                     (const int32_t*)d_flag);
+  return pl_check_launch(who);
+}
+}  // namespace
+
 extern "C" int pl_otsu16(const void* in, int dtype, int64_t n, int64_t count, const int32_t* d_lo, const int32_t* d_hi,
                          int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist,
                          void* stream) {
@@ -492,26 +574,25 @@ extern "C" int pl_otsu16(const void* in, int dtype, int64_t n, int64_t count, co
   PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL / 8 && count > 0, "bad shape");
   PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
   if (n == 0) return PL_OK;
-  hipStream_t st = (hipStream_t)stream;
-  const unsigned flip = dtype == PL_I16 ? 0x8000u : 0u;
-  const int bias = dtype == PL_I16 ? 32768 : 0;
-  const size_t lds = (size_t)kWinBins * sizeof(unsigned);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)otsu16_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess) {
-      pl_set_error("pl_otsu16: LDS attribute: %s", hipGetErrorString(hipGetLastError()));
-      return PL_ERR_HIP;
-    }
-    attr = true;
-  }
-  hipLaunchKernelGGL(otsu16_window_kernel, dim3((unsigned)n), dim3(kHistThreads), lds, st, (const unsigned short*)in,
-                     count, flip, bias, d_lo, d_hi, d_thr, d_min, d_max, d_flag);
-  // frames too wide for the window: the two-kernel path, every workgroup gated by d_flag
-  int rc = launch_hist16<2, false>((const unsigned short*)in, n, count, flip, d_hist, st, d_flag);
-  if (rc != 0) rc = launch_hist16<4, false>((const unsigned short*)in, n, count, flip, d_hist, st, d_flag);
-  PL_REQUIRE(rc == 0, "launch configuration rejected");
-  hipLaunchKernelGGL(otsu_kernel, dim3((unsigned)n), dim3(kHistThreads), 0, st, d_hist, bias, d_thr, d_min, d_max,
-                     (const int32_t*)d_flag);
-  return pl_check_launch("pl_otsu16");
+  return otsu16_launch<unsigned short, false>(in, nullptr, dtype, n, count, 0, 0, d_lo, d_hi, d_thr, d_min, d_max, d_flag, d_hist,
+                                              (hipStream_t)stream, "pl_otsu16");
+}
+
+extern "C" int pl_median3_otsu16(const void* in, void* scratch, int dtype, int64_t n, int h, int w, const int32_t* d_lo,
+                                 const int32_t* d_hi, int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag,
+                                 uint32_t* d_hist, void* stream) {
+  PL_REQUIRE(in && scratch && d_thr && d_flag && d_hist, "null pointer");
+  PL_REQUIRE(in != scratch, "scratch must be a distinct buffer");
+  PL_REQUIRE((d_lo == nullptr) == (d_hi == nullptr), "give both bounds or neither");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL / 8 && h > 0 && w > 0, "bad shape");
+  PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
+  PL_REQUIRE(pl_median3_rows_covers(in, h, w) && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0,
+             "needs h > 1, width % 8 == 0 and 16-byte aligned frames (run pl_median2d + pl_otsu16 otherwise)");
+  if (n == 0) return PL_OK;
+  const int64_t count = (int64_t)h * w;
+  return dtype == PL_I16
+             ? otsu16_launch<short, true>(in, scratch, dtype, n, count, h, w, d_lo, d_hi, d_thr, d_min, d_max, d_flag, d_hist,
+                                          (hipStream_t)stream, "pl_median3_otsu16")
+             : otsu16_launch<unsigned short, true>(in, scratch, dtype, n, count, h, w, d_lo, d_hi, d_thr, d_min, d_max, d_flag,
+                                                   d_hist, (hipStream_t)stream, "pl_median3_otsu16");
 }

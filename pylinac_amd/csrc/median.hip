@@ -14,6 +14,7 @@
 // coalesce into the same 128-byte lines.
 // General s: rank selection by bisection on an order-preserving integer key over an LDS tile.
 #include "pl_common.h"
+#include "median3_rows.h"
 
 namespace {
 
@@ -171,15 +172,13 @@ median3_pair_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
   }
 }
 
-// 3x3 median, 16-bit, EIGHT columns per lane (one 16-byte load and one 16-byte store per row): the column to the
-// left / right of the lane's block comes from the neighbouring lane (one cross-lane move each); only the first and
-// last lane of a wave fetch theirs from memory.  Same arithmetic as the pair kernel (sorted horizontal triples,
-// median of nine = med3(max3(lows), med3(mids), min3(highs))); 0.5 vector-memory instructions per pixel instead of 2.
+// 3x3 median, 16-bit, EIGHT columns per lane (one 16-byte load and one 16-byte store per row): pl_median3_rows
+// (median3_rows.h) does the arithmetic; 0.5 vector-memory instructions per pixel.  gate: optional per-frame flags; a frame
+// whose flag is 0 is skipped (the fused pipeline materialises the median plane only for frames its one-pass Otsu cannot hold).
 template <typename T, int ROWS>
 __global__ void __launch_bounds__(kThreads)
 median3_oct_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_waves, int row_groups,
-                   int64_t n_waves) {
-  static_assert(sizeof(T) == 2, "packed kernel is for 16-bit dtypes");
+                   int64_t n_waves, const int32_t* __restrict__ gate) {
   const int lane = threadIdx.x & (PL_WAVE - 1);
   const int64_t gw = (int64_t)pl_xcd_remap(blockIdx.x, gridDim.x) * (kThreads / PL_WAVE) + threadIdx.x / PL_WAVE;
   if (gw >= n_waves) return;
@@ -187,60 +186,14 @@ median3_oct_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w, 
   const int64_t t = gw / col_waves;
   const int rg = (int)(t % row_groups);
   const size_t frame = (size_t)(t / row_groups);
+  if (gate && gate[frame] == 0) return;            // wave-uniform
   const int c0 = (cw * PL_WAVE + lane) * 8;        // first of the lane's 8 columns
   const bool active = c0 < w;                      // w % 8 == 0: all 8 inside or none
-  const int r0 = rg * ROWS;
   const T* f = in + frame * (size_t)h * w;
   T* o = out + frame * (size_t)h * w;
-  const unsigned offc = (unsigned)(active ? c0 : 0) * 2u;
-  const bool first = c0 == 0, last = c0 + 8 >= w;
-  const bool edge_l = lane == 0 && !first, edge_r = lane == PL_WAVE - 1 && !last;
-
-  int lo[3][8], mi[3][8], hi[3][8];
-  auto load_row = [&](int r, int slot) {
-    const char* row = reinterpret_cast<const char*>(f + (size_t)pl_reflect(r, h) * w);  // wave-uniform
-    const uint4 q = *reinterpret_cast<const uint4*>(row + offc);
-    const unsigned wd[4] = {q.x, q.y, q.z, q.w};
-    int v[10];   // columns c0-1 .. c0+8
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      v[1 + 2 * k] = (int)(T)(wd[k] & 0xffffu);
-      v[2 + 2 * k] = (int)(T)(wd[k] >> 16);
-    }
-    int left = __shfl_up(v[8], 1, PL_WAVE), right = __shfl_down(v[1], 1, PL_WAVE);
-    if (edge_l) left = (int)*reinterpret_cast<const T*>(row + offc - 2);
-    if (edge_r) right = (int)*reinterpret_cast<const T*>(row + offc + 16);
-    v[0] = first ? v[1] : left;     // reflect: column -1 -> column 0
-    v[9] = last ? v[8] : right;     // column w -> column w-1
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int a = v[j], b = v[j + 1], c = v[j + 2];
-      lo[slot][j] = min(min(a, b), c);
-      hi[slot][j] = max(max(a, b), c);
-      mi[slot][j] = pl_smed3(a, b, c);
-    }
-  };
-  load_row(r0 - 1, 0);
-  load_row(r0, 1);
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    const int r = r0 + i;
-    if (r >= h) break;
-    load_row(r + 1, (i + 2) % 3);
-    unsigned pk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int m[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int j = 2 * k + e;
-        m[e] = pl_smed3(max(max(lo[0][j], lo[1][j]), lo[2][j]), pl_smed3(mi[0][j], mi[1][j], mi[2][j]),
-                        min(min(hi[0][j], hi[1][j]), hi[2][j]));
-      }
-      pk[k] = ((unsigned)m[0] & 0xffffu) | ((unsigned)m[1] << 16);
-    }
-    if (active) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(o + (size_t)r * w) + offc) = uint4{pk[0], pk[1], pk[2], pk[3]};
-  }
+  pl_median3_rows<T, ROWS>(f, h, w, c0, lane, rg * ROWS, [&](int r, const unsigned (&pk)[4]) {
+    if (active) *reinterpret_cast<uint4*>(o + (size_t)r * w + c0) = uint4{pk[0], pk[1], pk[2], pk[3]};
+  });
 }
 
 // --------------------------------------------------------------------- general size (LDS tile)
@@ -286,7 +239,7 @@ median_general_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int 
 }
 
 template <typename T>
-int median_t(const T* in, T* out, int64_t n, int h, int w, int size, hipStream_t st) {
+int median_t(const T* in, T* out, int64_t n, int h, int w, int size, hipStream_t st, const int32_t* gate = nullptr) {
   if (size == 1) {
     hipError_t e = hipMemcpyAsync(out, in, (size_t)n * h * w * sizeof(T), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { pl_set_error("pl_median2d: copy failed: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
@@ -301,7 +254,7 @@ int median_t(const T* in, T* out, int64_t n, int h, int w, int size, hipStream_t
       const int64_t blocks = pl_cdiv(n_waves, kThreads / PL_WAVE);
       if (blocks > 0x7fffffffLL) { pl_set_error("pl_median2d: batch too large"); return PL_ERR_INVALID_ARG; }
       hipLaunchKernelGGL((median3_oct_kernel<T, ROWS>), dim3((unsigned)blocks), dim3(kThreads), 0, st, in, out, h, w,
-                         col_waves, row_groups, n_waves);
+                         col_waves, row_groups, n_waves, gate);
       return pl_check_launch("pl_median2d");
     }
     if (size == 3 && h > 1 && w >= 4 && (w & 1) == 0 && ((reinterpret_cast<uintptr_t>(in) & 3) == 0) &&
@@ -352,4 +305,12 @@ extern "C" int pl_median2d(const void* in, void* out, int dtype, int64_t n, int 
   hipStream_t st = (hipStream_t)stream;
   PL_DISPATCH_DTYPE(dtype, T, return median_t<T>((const T*)in, (T*)out, n, h, w, size, st));
   return PL_OK;
+}
+
+// 3x3 median of the frames whose gate flag is non-zero only (16-bit, geometry of pl_median3_rows_covers): the fused
+// median + Otsu path's way of materialising the median plane for the frames its LDS window cannot hold.  0 = launched.
+int pl_median3_gated(const void* in, void* out, int is_signed, int64_t n, int h, int w, const int32_t* d_gate, hipStream_t st) {
+  if (!pl_median3_rows_covers(in, h, w) || (reinterpret_cast<uintptr_t>(out) & 15)) return -1;
+  return is_signed ? median_t<short>((const short*)in, (short*)out, n, h, w, 3, st, d_gate)
+                   : median_t<unsigned short>((const unsigned short*)in, (unsigned short*)out, n, h, w, 3, st, d_gate);
 }

@@ -1,0 +1,86 @@
+// Streaming 3x3 median of a 16-bit frame (scipy.ndimage.median_filter(size=3), mode='reflect':
+// pylinac/core/array_utils.py:131), shared by the median kernel itself and by the kernels that CONSUME medians without ever
+// writing the median plane (Otsu histogram, threshold + column sums: pipeline fusion of pylinac/core/image.py:695-712 with
+// :785-800 and pylinac/picketfence.py:747-750).
+//
+// A lane owns EIGHT consecutive columns (one 16-byte load per row) and slides down ROWS rows; the column to the left / right
+// of its block comes from the neighbouring lane (one cross-lane move each; only the first and last lane of a wave fetch theirs
+// from memory).  Each new row contributes SORTED horizontal triples (min3 / med3 / max3), kept in registers for three rows;
+// median of nine = med3(max3(lows), med3(mids), min3(highs)).  EVERY lane of the wave must call this (cross-lane moves); a
+// lane whose block lies beyond the frame (c0 >= w) computes on a clamped address and its values are meaningless.
+// Needs w % 8 == 0, 16-byte aligned rows, h > 1.
+#pragma once
+// (included after pl_common.h by every user)
+
+// consume(r, pk): pk[k] = medians of columns c0 + 2k (low half) and c0 + 2k + 1 (high half) of row r, raw 16-bit patterns.
+// AHEAD rows are in flight as raw 16-byte loads before their turn (the consumers that run few waves per CU -- one workgroup
+// per frame for the Otsu histogram -- would otherwise pay the full memory latency once per row).
+template <typename T, int ROWS, int AHEAD = 4, typename F>
+__device__ __forceinline__ void pl_median3_rows(const T* __restrict__ f, int h, int w, int c0, int lane, int r0, F&& consume) {
+  static_assert(sizeof(T) == 2, "16-bit dtypes");
+  const bool active = c0 < w;
+  const unsigned offc = (unsigned)(active ? c0 : 0) * 2u;
+  const bool first = c0 == 0, last = c0 + 8 >= w;
+  const bool edge_l = lane == 0 && !first, edge_r = lane == PL_WAVE - 1 && !last && active;
+  struct Raw { uint4 q; int el, er; };
+  auto fetch = [&](int r) {                         // row r0 - 1 + k of the walk
+    const char* row = reinterpret_cast<const char*>(f + (size_t)pl_reflect(r, h) * w);  // wave-uniform
+    Raw x;
+    x.q = *reinterpret_cast<const uint4*>(row + offc);
+    x.el = edge_l ? (int)*reinterpret_cast<const T*>(row + offc - 2) : 0;
+    x.er = edge_r ? (int)*reinterpret_cast<const T*>(row + offc + 16) : 0;
+    return x;
+  };
+  int lo[3][8], mi[3][8], hi[3][8];
+  auto digest = [&](const Raw& x, int slot) {
+    const unsigned wd[4] = {x.q.x, x.q.y, x.q.z, x.q.w};
+    int v[10];   // columns c0-1 .. c0+8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[1 + 2 * k] = (int)(T)(wd[k] & 0xffffu);
+      v[2 + 2 * k] = (int)(T)(wd[k] >> 16);
+    }
+    int left = pl_wave_from_prev(v[8]), right = pl_wave_from_next(v[1]);
+    if (edge_l) left = x.el;
+    if (edge_r) right = x.er;
+    v[0] = first ? v[1] : left;     // reflect: column -1 -> column 0
+    v[9] = last ? v[8] : right;     // column w -> column w-1
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int a = v[j], b = v[j + 1], c = v[j + 2];
+      lo[slot][j] = min(min(a, b), c);
+      hi[slot][j] = max(max(a, b), c);
+      mi[slot][j] = pl_smed3(a, b, c);
+    }
+  };
+  Raw ring[AHEAD];
+#pragma unroll
+  for (int k = 0; k < AHEAD; ++k) ring[k] = fetch(r0 - 1 + k);
+#pragma unroll
+  for (int k = 0; k < ROWS + 2; ++k) {              // walk row k = frame row r0 - 1 + k
+    const Raw cur = ring[k % AHEAD];
+    if (k + AHEAD < ROWS + 2) ring[k % AHEAD] = fetch(r0 - 1 + k + AHEAD);
+    digest(cur, k % 3);
+    if (k < 2) continue;
+    const int r = r0 + k - 2;
+    if (r >= h) continue;                           // wave-uniform
+    unsigned pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int m[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * q + e;
+        m[e] = pl_smed3(max(max(lo[0][j], lo[1][j]), lo[2][j]), pl_smed3(mi[0][j], mi[1][j], mi[2][j]),
+                        min(min(hi[0][j], hi[1][j]), hi[2][j]));
+      }
+      pk[q] = ((unsigned)m[0] & 0xffffu) | ((unsigned)m[1] << 16);
+    }
+    consume(r, pk);
+  }
+}
+
+// 1 when pl_median3_rows serves this frame geometry
+static inline bool pl_median3_rows_covers(const void* in, int h, int w) {
+  return h > 1 && w >= 8 && (w & 7) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (((size_t)h * w) & 7) == 0;
+}

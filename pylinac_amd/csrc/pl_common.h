@@ -121,6 +121,12 @@ __device__ __forceinline__ void pl_buffer_store_u128(uint4 v, __amdgpu_buffer_rs
   __builtin_amdgcn_raw_buffer_store_b128(pl_v4u{v.x, v.y, v.z, v.w}, r, (int)lane_off, (int)uniform_off, 0);
 }
 
+// neighbour exchange inside a wave on the VALU's data-parallel path (DPP wave_shr:1 / wave_shl:1), NOT through the LDS
+// crossbar (__shfl_up / __shfl_down compile to ds_bpermute_b32, which queues behind a kernel's own LDS atomics).
+// pl_wave_from_prev: lane i receives lane i - 1's value (lane 0 keeps `v`); pl_wave_from_next: lane i receives lane i + 1's.
+__device__ __forceinline__ int pl_wave_from_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int pl_wave_from_next(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+
 // wave-level reductions (64 lanes, xor butterflies -> every lane holds the result)
 template <typename T, typename F>
 __device__ __forceinline__ T pl_wave_reduce(T v, F f) {

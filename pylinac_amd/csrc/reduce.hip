@@ -14,6 +14,7 @@
 // accesses (4 independent loads in flight per lane), per-lane uint32 partial sums over a 128-row
 // band, one uint64 atomic per column/band.
 #include "pl_common.h"
+#include "median3_rows.h"
 
 namespace {
 
@@ -146,6 +147,52 @@ threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* _
   }
 }
 
+// The same with the 3x3 MEDIAN of the frame as the thresholded quantity, computed on the fly (pl_median3_rows): the median
+// plane is never written.  One workgroup = 8 waves = one block of 512 columns x one band of 128 rows; wave v walks row group v
+// (16 rows) of the band; the eight waves' column sums meet in LDS and leave as one 64-bit atomic per column.
+constexpr int kMtWaves = kBandRows / 16;           // 8
+__global__ void __launch_bounds__(kMtWaves * PL_WAVE)
+median3_threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, int h, int w, int bands,
+                                int col_groups, const int32_t* __restrict__ thr, unsigned long long* __restrict__ colsum) {
+  __shared__ unsigned s_cs[PL_WAVE * 8];
+  unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
+  const int cg = id % col_groups;
+  id /= col_groups;
+  const int band = id % bands;
+  const size_t frame = id / bands;
+  const int t = thr[frame];
+  const int lane = threadIdx.x & (PL_WAVE - 1), wave = threadIdx.x / PL_WAVE;
+  const int c0 = (cg * PL_WAVE + lane) * 8;
+  const bool on = c0 < w;
+  const int rg = band * kBandRows + 16 * wave;     // the wave's first row; rows beyond the frame produce nothing
+  const unsigned short* f = in + frame * (size_t)h * w;
+  unsigned short* o = out + frame * (size_t)h * w;
+  for (int i = threadIdx.x; i < PL_WAVE * 8; i += kMtWaves * PL_WAVE) s_cs[i] = 0;
+  __syncthreads();
+  unsigned s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rg < h) {                                     // wave-uniform
+    pl_median3_rows<unsigned short, 16>(f, h, w, c0, lane, rg, [&](int r, const unsigned (&pk)[4]) {
+      if (!on) return;
+      unsigned q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned a = pk[k] & 0xffffu, b = pk[k] >> 16;
+        const unsigned va = ((int)a >= t) ? a : 0u, vb = ((int)b >= t) ? b : 0u;
+        s[2 * k] += va;
+        s[2 * k + 1] += vb;
+        q[k] = va | (vb << 16);
+      }
+      *reinterpret_cast<uint4*>(o + (size_t)r * w + c0) = uint4{q[0], q[1], q[2], q[3]};
+    });
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&s_cs[lane * 8 + k], s[k]);     // 16 rows x 65535 < 2^32 per wave, 8 waves < 2^32
+  }
+  __syncthreads();
+  unsigned long long* cs = colsum + frame * (size_t)w + (size_t)cg * PL_WAVE * 8;
+  for (int i = threadIdx.x; i < PL_WAVE * 8; i += kMtWaves * PL_WAVE)
+    if (cg * PL_WAVE * 8 + i < w) atomicAdd(cs + i, (unsigned long long)s_cs[i]);
+}
+
 __global__ void colsum_to_mean_kernel(const unsigned long long* __restrict__ cs, int64_t total, int h,
                                       double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,4 +251,21 @@ extern "C" int pl_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_
   hipLaunchKernelGGL(threshold_colsum_kernel, dim3((unsigned)(n * bands)), dim3(kTcThreads), 0, st, in, out,
                      h, w, bands, d_thr, d_colsum);
   return pl_check_launch("pl_threshold_colsum_u16");
+}
+
+extern "C" int pl_median3_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_t n, int h, int w,
+                                               const int32_t* d_thr, unsigned long long* d_colsum, void* stream) {
+  PL_REQUIRE(in && out && d_thr && d_colsum && in != out, "null or aliased pointers");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");
+  PL_REQUIRE(pl_median3_rows_covers(in, h, w) && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+             "needs h > 1, width % 8 == 0 and 16-byte aligned frames (run pl_median2d + pl_threshold_colsum_u16 otherwise)");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_colsum, 0, (size_t)n * w * sizeof(unsigned long long), st);
+  if (e != hipSuccess) { pl_set_error("pl_median3_threshold_colsum_u16: memset: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+  const int bands = (int)pl_cdiv(h, kBandRows), col_groups = (int)pl_cdiv(w / 8, PL_WAVE);
+  PL_REQUIRE(n * bands * col_groups <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(median3_threshold_colsum_kernel, dim3((unsigned)(n * bands * col_groups)), dim3(kMtWaves * PL_WAVE), 0, st, in, out,
+                     h, w, bands, col_groups, d_thr, d_colsum);
+  return pl_check_launch("pl_median3_threshold_colsum_u16");
 }

@@ -268,6 +268,40 @@ def otsu16(frames: torch.Tensor, lo: torch.Tensor | None = None, hi: torch.Tenso
     return thr, mn, mx
 
 
+def median3_otsu16(frames: torch.Tensor, hist: torch.Tensor | None = None, scratch: torch.Tensor | None = None):
+    """:func:`otsu16` of ``median_filter(frame, size=3)`` without writing the median plane (``pl_median3_otsu16``: the one-pass
+    Otsu kernel computes the medians on the fly) -> (threshold, min, max, flag) int32 [N]; ``flag[i] = 1`` marks the frames that
+    did not fit the one-pass window: their median plane is in ``scratch`` and they went through the two-kernel path.
+    Frames need width % 8 == 0 and more than one row."""
+    x = _frames(frames)
+    if x.dtype not in (torch.uint16, torch.int16):
+        raise TypeError("median3_otsu16 needs uint16 or int16 frames")
+    n, h, w = x.shape
+    dev = x.device
+    thr = torch.empty(n, dtype=torch.int32, device=dev)
+    mn, mx, flag = torch.empty_like(thr), torch.empty_like(thr), torch.empty_like(thr)
+    hist = torch.empty((n, 65536), dtype=torch.int32, device=dev) if hist is None else hist
+    scratch = torch.empty_like(x) if scratch is None else scratch
+    check(_lib.load().pl_median3_otsu16(x.data_ptr(), scratch.data_ptr(), _dt(x), n, h, w, None, None, thr.data_ptr(),
+                                        mn.data_ptr(), mx.data_ptr(), flag.data_ptr(), hist.data_ptr(), _stream()),
+          "pl_median3_otsu16")
+    return thr, mn, mx, flag
+
+
+def median3_threshold_colsum_u16(frames: torch.Tensor, thr_i32: torch.Tensor, out=None, colsum=None):
+    """``threshold(median_filter(frame, 3), thr)`` and its axis-0 column sums in one pass over the unfiltered frame
+    (``pl_median3_threshold_colsum_u16``) -> (thresholded uint16 frames, int64 [N, W] column sums)."""
+    x = _frames(frames)
+    if x.dtype != torch.uint16:
+        raise TypeError("median3_threshold_colsum_u16 needs uint16 frames")
+    n, h, w = x.shape
+    out = torch.empty_like(x) if out is None else out
+    colsum = torch.empty((n, w), dtype=torch.int64, device=x.device) if colsum is None else colsum
+    check(_lib.load().pl_median3_threshold_colsum_u16(x.data_ptr(), out.data_ptr(), n, h, w, thr_i32.data_ptr(),
+                                                      colsum.data_ptr(), _stream()), "pl_median3_threshold_colsum_u16")
+    return out, colsum
+
+
 def threshold_otsu(frames: torch.Tensor) -> torch.Tensor:
     """``skimage.filters.threshold_otsu`` per integer frame -> int32 [N]."""
     return otsu16(frames)[0]

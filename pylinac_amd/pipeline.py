@@ -25,7 +25,7 @@ from ._lib import check
 RECORD_FIELDS = ("otsu_threshold", "n_peaks", "peak_idx", "peak_height", "prominence",
                  "left_edge", "right_edge", "center", "width")
 
-STAGES = ("gauss2d", "median3", "otsu16", "threshold_colsum", "colsum_to_mean", "find_peaks", "fwxm_record")
+STAGES = ("gauss2d", "median3_otsu16", "median3_threshold_colsum", "colsum_to_mean", "find_peaks", "fwxm_record")
 
 
 @dataclass
@@ -112,6 +112,9 @@ class EpidPipeline:
         cnt, idx, lb, rb, props, status = (t.data_ptr() for t in (pk.count, pk.idx, pk.left_bases,
                                                                    pk.right_bases, pk.props, pk.status))
 
+        # 3x3 median on frames of width % 8 == 0 (torch allocations are 256-byte aligned): consumed on the fly
+        fused_median = self.median_size == 3 and h > 1 and w % 8 == 0 and (h * w) % 8 == 0
+
         def filters(lo, m, stream):
             """Image.filter(sigma, "gaussian"): axis 0 then axis 1 in ONE launch (the axis-0 plane stays in LDS), frames
             [lo, lo+m); buf_a is the two-pass fallback's scratch."""
@@ -122,13 +125,23 @@ class EpidPipeline:
         def rest(lo, m, stream):
             """median -> Otsu -> threshold -> column profile -> FWXM record, frames [lo, lo+m)."""
             st, o = stream.cuda_stream, lo * fb
-            stage("median3", lambda: lib.pl_median2d(bp + o, ap + o, U16, m, h, w, self.median_size, st), stream)
-            med = ap + o
-            stage("otsu16", lambda: lib.pl_otsu16(med, U16, m, h * w, None, None, thr + lo * 4,
-                                                  vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
-                                                  hist + lo * 65536 * 4, st), stream)
-            stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(med, op + o, m, h, w, thr + lo * 4,
-                                                                          colsum + lo * w * 8, st), stream)
+            if fused_median:
+                # Image.filter(3, "median") is never materialised: the Otsu histogram and the threshold + column sums each
+                # compute the 3x3 medians of the Gaussian plane on the fly (two reads of that plane instead of median write +
+                # two reads of the median plane); buf_a is scratch for frames the one-pass Otsu window cannot hold
+                stage("median3_otsu16", lambda: lib.pl_median3_otsu16(bp + o, ap + o, U16, m, h, w, None, None, thr + lo * 4,
+                                                                      vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
+                                                                      hist + lo * 65536 * 4, st), stream)
+                stage("median3_threshold_colsum", lambda: lib.pl_median3_threshold_colsum_u16(
+                    bp + o, op + o, m, h, w, thr + lo * 4, colsum + lo * w * 8, st), stream)
+            else:
+                stage("median3", lambda: lib.pl_median2d(bp + o, ap + o, U16, m, h, w, self.median_size, st), stream)
+                med = ap + o
+                stage("otsu16", lambda: lib.pl_otsu16(med, U16, m, h * w, None, None, thr + lo * 4,
+                                                      vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
+                                                      hist + lo * 65536 * 4, st), stream)
+                stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(med, op + o, m, h, w, thr + lo * 4,
+                                                                              colsum + lo * w * 8, st), stream)
             stage("colsum_to_mean", lambda: lib.pl_colsum_to_mean(colsum + lo * w * 8, m, w, h,
                                                                   profile + lo * w * 8, st), stream)
             stage("find_peaks", lambda: lib.pl_find_peaks(

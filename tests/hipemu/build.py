@@ -52,7 +52,7 @@ def _rewrite(text: str) -> str:
 def build(sources=None, verbose: bool = False) -> pathlib.Path:
     sources = [s for s in (sources or SOURCES) if (CSRC / s).exists()]
     BUILD.mkdir(exist_ok=True)
-    inputs = [CSRC / s for s in sources] + [HERE / "hipemu.cpp", HERE / "emu_stubs.cpp", HERE / "hip" / "hip_runtime.h", CSRC / "pl_common.h",
+    inputs = [CSRC / s for s in sources] + list(CSRC.glob("*.h")) + [HERE / "hipemu.cpp", HERE / "emu_stubs.cpp", HERE / "hip" / "hip_runtime.h",
                                             ROOT / "include" / "pylinac_hip.h", pathlib.Path(__file__)]
     if LIB.exists() and all(LIB.stat().st_mtime >= p.stat().st_mtime for p in inputs):
         return LIB

@@ -215,6 +215,16 @@ inline T readfirstlane(T v) {
   return from_bits<T>(all[__builtin_ctzll(act)]);
 }
 }  // namespace hipemu
+// DPP wave_shr:1 (0x138: lane i <- lane i - 1) / wave_shl:1 (0x130: lane i <- lane i + 1); a lane without a source keeps `old`
+inline int hipemu_update_dpp(int old, int src, int ctrl) {
+  uint64_t all[64], act;
+  hipemu::wave_exchange(hipemu::to_bits(src), all, &act);
+  const int from = hipemu::lane_id() + (ctrl == 0x138 ? -1 : ctrl == 0x130 ? 1 : 64);
+  if (from < 0 || from > 63 || !((act >> from) & 1ull)) return old;
+  return hipemu::from_bits<int>(all[from]);
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl))
+#define __builtin_amdgcn_readlane(v, l) (hipemu::shfl_from((v), (l)))
 template <typename T>
 inline T __shfl(T v, int src, int width = 64) { (void)width; return hipemu::shfl_from(v, src); }
 template <typename T>

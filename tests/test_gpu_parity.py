@@ -921,6 +921,39 @@ def test_gaussian_default_kernels_on_epid_and_ragged_frames(dev):
     _check_gaussian_cases(dev)
 
 
+def test_median_consumed_on_the_fly_vs_scipy_and_oracle(dev):
+    """pl_median3_otsu16 / pl_median3_threshold_colsum_u16 (the EPID pipeline's stages after the Gaussian: the 3x3 median is
+    computed inside the Otsu histogram kernel and again inside the threshold + column-sum kernel, the median plane is never
+    written) against scipy's median_filter + the oracle's Otsu + numpy: EPID-like frames, a frame with full-range noise (does
+    not fit the one-pass window: flagged, goes through the materialised plane), a constant frame, widths that leave the last
+    wave partly idle, a height that is not a multiple of 16, int16."""
+    from scipy import ndimage
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(77)
+    for shape in ((3, 200, 264), (2, 37, 1040), (4, 130, 64), (1, 16, 8)):
+        for dt in (np.uint16, np.int16):
+            a = (rng.integers(2000, 2600, shape) + (np.arange(shape[2]) > shape[2] // 2) * 9000).astype(np.int64)
+            a[-1] = rng.integers(0, 65536, shape[1:])                # full range: two-kernel path on the scratch plane
+            if shape[0] > 2:
+                a[1] = 12345                                          # constant frame
+            a = (a - (32768 if dt == np.int16 else 0)).astype(dt)
+            t = torch.from_numpy(a).to(dev)
+            med = np.stack([ndimage.median_filter(f, size=3) for f in a])
+            thr, mn, mx, flag = ops.median3_otsu16(t)
+            assert np.array_equal(thr.cpu().numpy(), np.array([o.threshold_otsu(f) for f in med])), (shape, dt)
+            assert np.array_equal(mn.cpu().numpy(), med.reshape(shape[0], -1).min(1)), (shape, dt)
+            assert np.array_equal(mx.cpu().numpy(), med.reshape(shape[0], -1).max(1)), (shape, dt)
+            assert int(flag[-1]) == 1 or shape[1] * shape[2] < 1000, (shape, dt, flag.cpu().tolist())
+            if dt == np.uint16:
+                cut = torch.from_numpy(np.array([int(np.percentile(f, 40)) for f in med], dtype=np.int32)).to(dev)
+                out, cs = ops.median3_threshold_colsum_u16(t, cut)
+                want = np.where(med.astype(np.int64) >= cut.cpu().numpy()[:, None, None], med, 0).astype(np.uint16)
+                assert np.array_equal(out.cpu().numpy(), want), shape
+                assert np.array_equal(cs.cpu().numpy(), want.astype(np.int64).sum(1)), shape
+
+
 def test_gaussian_marching_strip_kernel_vs_scipy(dev):
     """gauss2d_mm (both axes in one launch, exact integer arithmetic on the matrix cores): frames of at least 64 x 64 with
     width % 16 == 0 take it.  Several strips with a partial last one, several row segments, mirrored border quads, EPID-like
