@@ -316,13 +316,14 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     else outside = 1;
   };
   if (MED3) {
-    // every wave walks (column block of 512, row group of 16) items; all 64 lanes take part in the median's cross-lane moves,
+    // every wave walks (column block of 512, row group of 32) items; all 64 lanes take part in the median's cross-lane moves,
     // lanes beyond the frame's width tally nothing
-    const int col_waves = (w / 8 + PL_WAVE - 1) / PL_WAVE, row_groups = (h + 15) / 16;
+    constexpr int kRows = 32;                        // rows per item: two halo rows are re-read per item
+    const int col_waves = (w / 8 + PL_WAVE - 1) / PL_WAVE, row_groups = (h + kRows - 1) / kRows;
     for (int item = wv; item < col_waves * row_groups; item += kHistThreads / 64) {
       const int c0 = ((item % col_waves) * PL_WAVE + lane) * 8;
       const bool on = c0 < w;
-      pl_median3_rows<T, 16>(reinterpret_cast<const T*>(src), h, w, c0, lane, (item / col_waves) * 16,
+      pl_median3_rows<T, kRows>(reinterpret_cast<const T*>(src), h, w, c0, lane, (item / col_waves) * kRows,
                              [&](int, const unsigned (&pk)[4]) {
         const unsigned first = pk[0] & 0xffffu;
         const unsigned splat = first | (first << 16);

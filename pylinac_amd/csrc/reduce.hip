@@ -148,9 +148,10 @@ threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* _
 }
 
 // The same with the 3x3 MEDIAN of the frame as the thresholded quantity, computed on the fly (pl_median3_rows): the median
-// plane is never written.  One workgroup = 8 waves = one block of 512 columns x one band of 128 rows; wave v walks row group v
-// (16 rows) of the band; the eight waves' column sums meet in LDS and leave as one 64-bit atomic per column.
-constexpr int kMtWaves = kBandRows / 16;           // 8
+// plane is never written.  One workgroup = 4 waves = one block of 512 columns x one band of 128 rows; wave v walks row group v
+// (32 rows) of the band; the four waves' column sums meet in LDS and leave as one 64-bit atomic per column.
+constexpr int kMtRows = 32;                        // rows per wave: two halo rows are re-read per wave
+constexpr int kMtWaves = kBandRows / kMtRows;      // 4
 __global__ void __launch_bounds__(kMtWaves * PL_WAVE)
 median3_threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, int h, int w, int bands,
                                 int col_groups, const int32_t* __restrict__ thr, unsigned long long* __restrict__ colsum) {
@@ -164,14 +165,14 @@ median3_threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned 
   const int lane = threadIdx.x & (PL_WAVE - 1), wave = threadIdx.x / PL_WAVE;
   const int c0 = (cg * PL_WAVE + lane) * 8;
   const bool on = c0 < w;
-  const int rg = band * kBandRows + 16 * wave;     // the wave's first row; rows beyond the frame produce nothing
+  const int rg = band * kBandRows + kMtRows * wave;     // the wave's first row; rows beyond the frame produce nothing
   const unsigned short* f = in + frame * (size_t)h * w;
   unsigned short* o = out + frame * (size_t)h * w;
   for (int i = threadIdx.x; i < PL_WAVE * 8; i += kMtWaves * PL_WAVE) s_cs[i] = 0;
   __syncthreads();
   unsigned s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rg < h) {                                     // wave-uniform
-    pl_median3_rows<unsigned short, 16>(f, h, w, c0, lane, rg, [&](int r, const unsigned (&pk)[4]) {
+    pl_median3_rows<unsigned short, kMtRows>(f, h, w, c0, lane, rg, [&](int r, const unsigned (&pk)[4]) {
       if (!on) return;
       unsigned q[4];
 #pragma unroll
@@ -185,7 +186,7 @@ median3_threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned 
       *reinterpret_cast<uint4*>(o + (size_t)r * w + c0) = uint4{q[0], q[1], q[2], q[3]};
     });
 #pragma unroll
-    for (int k = 0; k < 8; ++k) atomicAdd(&s_cs[lane * 8 + k], s[k]);     // 16 rows x 65535 < 2^32 per wave, 8 waves < 2^32
+    for (int k = 0; k < 8; ++k) atomicAdd(&s_cs[lane * 8 + k], s[k]);     // 32 rows x 65535 per wave, 4 waves: < 2^32
   }
   __syncthreads();
   unsigned long long* cs = colsum + frame * (size_t)w + (size_t)cg * PL_WAVE * 8;
