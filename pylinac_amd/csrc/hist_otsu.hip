@@ -24,6 +24,11 @@
 #include "pl_common.h"
 #include "median3_rows.h"
 
+// rows the fused median + Otsu kernel keeps in flight per lane (1024 threads: 128 VGPRs)
+#ifndef PL_OTSU_AHEAD
+#define PL_OTSU_AHEAD 2
+#endif
+
 namespace {
 
 constexpr int kHistThreads = 1024;
@@ -252,7 +257,7 @@ __global__ void __launch_bounds__(kHistThreads)
 otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h, int w, unsigned flip, int bias,
                      const int32_t* __restrict__ lo_hint, const int32_t* __restrict__ hi_hint, int32_t* __restrict__ thr,
                      int32_t* __restrict__ vmin, int32_t* __restrict__ vmax, int32_t* __restrict__ flag) {
-  extern __shared__ unsigned bins[];  // kWinBins
+  extern __shared__ unsigned bins[];  // kWinBins + 1
   __shared__ Pair wave_tot[kHistThreads / 64];
   __shared__ int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64];
   __shared__ double s_var[kHistThreads / 64];
@@ -319,19 +324,20 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     // every wave walks (column block of 512, row group of 32) items; all 64 lanes take part in the median's cross-lane moves,
     // lanes beyond the frame's width tally nothing
     constexpr int kRows = 32;                        // rows per item: two halo rows are re-read per item
+    unsigned bmax = 0;                               // largest window index seen by this lane (lanes beyond the width: none)
     const int col_waves = (w / 8 + PL_WAVE - 1) / PL_WAVE, row_groups = (h + kRows - 1) / kRows;
     for (int item = wv; item < col_waves * row_groups; item += kHistThreads / 64) {
       const int c0 = ((item % col_waves) * PL_WAVE + lane) * 8;
       const bool on = c0 < w;
-      pl_median3_rows<T, kRows>(reinterpret_cast<const T*>(src), h, w, c0, lane, (item / col_waves) * kRows,
+      pl_median3_rows<T, kRows, PL_OTSU_AHEAD>(reinterpret_cast<const T*>(src), h, w, c0, lane, (item / col_waves) * kRows,
                              [&](int, const unsigned (&pk)[4]) {
         const unsigned first = pk[0] & 0xffffu;
         const unsigned splat = first | (first << 16);
-        const bool lane_flat = pk[0] == splat && pk[1] == splat && pk[2] == splat && pk[3] == splat;
+        const unsigned spread = (pk[0] ^ splat) | (pk[1] ^ splat) | (pk[2] ^ splat) | (pk[3] ^ splat);
         const unsigned long long act = __ballot(on);
         if (act == 0ull) return;
         const unsigned wave_first = (unsigned)__builtin_amdgcn_readlane((int)splat, __builtin_ctzll(act));
-        if (__ballot(on && !(lane_flat && splat == wave_first)) == 0ull) {   // one value in the whole wave: one atomic
+        if (__ballot(on && (spread | (splat ^ wave_first)) != 0u) == 0ull) {   // one value in the whole wave: one atomic
           const unsigned b = ((wave_first & 0xffffu) ^ flip) - (unsigned)klo;
           if (b < (unsigned)range) {
             if (lane == __builtin_ctzll(act)) atomicAdd(&bins[b], 8u * (unsigned)__popcll(act));
@@ -340,15 +346,21 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
           }
           return;
         }
-        if (on) {
+        // branch-free tally: a value outside the window lands in the spare bin at index `range` and raises bmax
+        const unsigned cap = on ? (unsigned)range : 0u;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            tally(pk[k] & 0xffffu);
-            tally(pk[k] >> 16);
+        for (int k = 0; k < 4; ++k) {
+          const unsigned b0 = ((pk[k] & 0xffffu) ^ flip) - (unsigned)klo, b1 = ((pk[k] >> 16) ^ flip) - (unsigned)klo;
+          if (on) {
+            bmax = b0 > bmax ? b0 : bmax;
+            bmax = b1 > bmax ? b1 : bmax;
+            atomicAdd(&bins[b0 < cap ? b0 : cap], 1u);
+            atomicAdd(&bins[b1 < cap ? b1 : cap], 1u);
           }
         }
       });
     }
+    if (bmax >= (unsigned)range) outside = 1;
   } else if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const int64_t nvec = count / 8;
     const uint4* vsrc = reinterpret_cast<const uint4*>(src);
@@ -533,7 +545,7 @@ int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t c
                   hipStream_t st, const char* who) {
   const unsigned flip = dtype == PL_I16 ? 0x8000u : 0u;
   const int bias = dtype == PL_I16 ? 32768 : 0;
-  const size_t lds = (size_t)kWinBins * sizeof(unsigned);
+  const size_t lds = (size_t)(kWinBins + 1) * sizeof(unsigned);   // + the spare bin of the branch-free tally
   static bool attr = false;                        // one flag per instantiation
   if (!attr) {
     if (hipFuncSetAttribute((const void*)otsu16_window_kernel<T, MED3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

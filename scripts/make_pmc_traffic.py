@@ -4,7 +4,7 @@ doubled: MI355X_MICROARCH.md, HBM / rocprofv3 section).  usage: make_pmc_traffic
 import json
 import sys
 
-STAGE_OF = {"gauss2d_mm": "gauss2d", "gauss_v_rw": "gauss_v", "gauss_h_rw": "gauss_h", "median3_oct_kernel": "median3", "otsu16_window_kernel": "otsu16",
+STAGE_OF = {"gauss2d_mm": "gauss2d", "gauss_v_rw": "gauss_v", "gauss_h_rw": "gauss_h", "median3_threshold_colsum_kernel": "median3_threshold_colsum", "median3_oct_kernel": "median3", "otsu16_window_kernel": "median3_otsu16",
             "threshold_colsum_kernel": "threshold_colsum", "find_peaks_kernel": "find_peaks"}
 summary = json.load(open(sys.argv[1]))
 tag = sys.argv[2]
