@@ -279,7 +279,7 @@ int pl_gauss_rw_covers(const void* in, const void* out, int h, int w, int axis, 
 int pl_gauss_rw_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, int axis,
                        const double* h_wts, int radius, hipStream_t st);
 
-// gaussian_mm.hip: exact-integer matrix-core kernel for 16-bit frames, radius <= 24, width % 16 == 0, at least 64 x 64:
+// gaussian_mm.hip: exact-integer matrix-core kernel for 16-bit frames, radius <= 24, even width, at least 64 x 64:
 // both axes in one kernel (the axis-0 result stays in LDS); same protocol
 int pl_gauss_mm2d_covers(const void* in, const void* out, int h, int w, int radius);
 int pl_gauss_mm2d_launch(const void* in, void* out, int is_signed, int64_t n, int h, int w, const double* h_wts, int radius,

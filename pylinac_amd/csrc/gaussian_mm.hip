@@ -316,9 +316,10 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
   const int nsteps = (r_end - r_begin + 15) / 16;
   if (nsteps <= 0) return;
   const T* f = in + frame * (size_t)h * w;
-  const int wcols = w - c0 < kFCols ? w - c0 : kFCols;      // output columns of this strip (a multiple of 16)
-  const int nvt = wcols / 16 + 3;                            // axis-0 tiles the axis-1 windows reach
-  const int nht = wcols / 16;
+  const int wcols = w - c0 < kFCols ? w - c0 : kFCols;      // output columns of this strip (even; the last strip's may be ragged)
+  const int nht = (wcols + 15) / 16;                         // axis-1 tiles (the last one may reach beyond the frame)
+  const int nvt = nht + 3;                                   // axis-0 tiles the axis-1 windows reach
+  const bool ragged = (wcols & 15) != 0;                     // the last tile's stores are cut at the frame's edge
   // bounded: the look-ahead loads of the last steps may reflect to a negative row when h < 71; those never reach a
   // tile that is stored, and out of range they read 0 instead of faulting
   const __amdgpu_buffer_rsrc_t src = pl_make_rsrc_bounded(f, (unsigned)h * (unsigned)w * 2u);
@@ -326,15 +327,17 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
   const __amdgpu_buffer_rsrc_t dstb = pl_make_rsrc_bounded(out + (frame * (size_t)h + r_begin) * w, (unsigned)(r_end - r_begin) * (unsigned)w * 2u);
 
   // ---- who loads what: wave v splits column quads 16 v .. 16 v + 15 (lane & 15) x row quad (lane >> 4) of every row
-  // group; wave 3, which has one axis-0 tile less, also takes the twelve quads 64 .. 75.  A quad lies wholly inside or
-  // wholly outside the frame (w % 4 == 0); outside, the MIRRORED quad is loaded and its four columns land in reverse.
+  // group; wave 3, which has one axis-0 tile less, also takes the twelve quads 64 .. 75.  A quad lies wholly inside the
+  // frame, wholly outside it (the MIRRORED quad is loaded and its four columns land in reverse) or -- when w % 4 == 2 --
+  // across the right edge: columns w - 2, w - 1 and their reflections w - 1, w - 2 (one dword and its halves swapped).
   const int rq = g;
-  struct QuadPlace { unsigned colb; int d0, dstep; bool on; };
+  struct QuadPlace { unsigned colb; int d0, dstep; bool on, across; };
   auto place = [&](int cqx, bool on) {
     const int col0 = c0 - kMmHalo + 4 * cqx;
     const bool mir = col0 < 0 || col0 >= w;
     const int mc = col0 < 0 ? -col0 - 4 : (col0 >= w ? 2 * w - 4 - col0 : col0);
     QuadPlace q;
+    q.across = col0 < w && col0 + 4 > w;
     q.colb = 2u * (unsigned)mc;
     q.d0 = 16 * cqx + 4 * rq + (mir ? 3 * kFQuadPitch : 0);
     q.dstep = mir ? -kFQuadPitch : kFQuadPitch;
@@ -352,7 +355,12 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       r ^= r >> 31;                                          // -r - 1 below the frame
       const int r2 = 2 * h - 1 - r;
       r = r < r2 ? r : r2;                                   // 2 h - 1 - r above it (one reflection: h >= 64)
-      x.r[i] = (PL_G2D_VARIANT & 4) ? uint2{((unsigned)r * wb + q.colb) * 2654435761u, ((unsigned)r * wb + q.colb) * 40503u + 12345u} : pl_buffer_load_u64(src, (unsigned)r * wb + q.colb, 0);
+      if (q.across) {
+        const unsigned d = pl_buffer_load_u32(src, (unsigned)r * wb + q.colb, 0);
+        x.r[i] = uint2{d, __builtin_amdgcn_alignbit(d, d, 16)};
+      } else {
+        x.r[i] = (PL_G2D_VARIANT & 4) ? uint2{((unsigned)r * wb + q.colb) * 2654435761u, ((unsigned)r * wb + q.colb) * 40503u + 12345u} : pl_buffer_load_u64(src, (unsigned)r * wb + q.colb, 0);
+      }
     }
   };
   auto store_quad = [&](const QuadPlace& q, int k, const FQuad& x) {
@@ -493,6 +501,12 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       // after the pair exchange below lane (g1 = g >> 1, g0 = g & 1) holds columns 8 g1 .. 8 g1 + 7 of tile 2 k + g0
       const unsigned doff16 = row_ok ? ((unsigned)lrow * (unsigned)w + (unsigned)(c0 + 8 * (g >> 1))) * 2u : 0x80000000u;
       uint2 keep{0u, 0u};
+      // a ragged strip's stores, dword by dword: column pairs at or beyond the frame's right edge go out of range (dropped)
+      auto store_cut = [&](unsigned off, int x0, unsigned d0, unsigned d1, unsigned d2, unsigned d3) {
+        const unsigned d[4] = {d0, d1, d2, d3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pl_buffer_store_u32(d[k], dstb, x0 + 2 * k < wcols ? off + 4u * (unsigned)k : 0x80000000u, 0);
+      };
       auto tile_of = [&](int i) { const int t = 4 * wave + i; return t < nht ? t : 0; };
       constexpr int N = 4;
       unsigned badbits = 0;
@@ -520,12 +534,20 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
           const auto sx = __builtin_amdgcn_permlane16_swap(keep.x, res.x, false, false);
           const auto sy = __builtin_amdgcn_permlane16_swap(keep.y, res.y, false, false);
           const unsigned tsel = (g & 1) ? (unsigned)tile_of(i) : (unsigned)tile_of(i - 1);
-          if (!(PL_G2D_VARIANT & 16) || res.x == 0x12345u)
-            pl_buffer_store_u128(uint4{(unsigned)sx[0], (unsigned)sy[0], (unsigned)sx[1], (unsigned)sy[1]}, dstb, doff16 + 32u * tsel, 0);
+          const uint4 piece{(unsigned)sx[0], (unsigned)sy[0], (unsigned)sx[1], (unsigned)sy[1]};
+          if (!ragged) {
+            if (!(PL_G2D_VARIANT & 16) || res.x == 0x12345u) pl_buffer_store_u128(piece, dstb, doff16 + 32u * tsel, 0);
+          } else {
+            store_cut(doff16 + 32u * tsel, 16 * (int)tsel + 8 * (g >> 1), piece.x, piece.y, piece.z, piece.w);
+          }
         }
         if (i + 1 < N) acc = nxt;
       }
       if (__ballot(badbits != 0u) != 0ull) {
+        auto store_cut2 = [&](unsigned off, int x0, unsigned d0, unsigned d1) {   // 4 columns from x0, cut at the edge
+          pl_buffer_store_u32(d0, dstb, x0 < wcols ? off : 0x80000000u, 0);
+          pl_buffer_store_u32(d1, dstb, x0 + 2 < wcols ? off + 4u : 0x80000000u, 0);
+        };
         auto sample = [&](int row, int x) {        // row of the step, window column x
           const int a = vb + row * kFWin + x;
           return mm_value<kSigned>(s_mem[kFVLo + a], s_mem[kFVHi + a]);
@@ -539,7 +561,7 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
           if (mm_wave_flat(flo, fhi)) {
             const double c = sample(0, 16 * t);
             const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int) { return c; }, P));
-            pl_buffer_store_u64(uint2{v | (v << 16), v | (v << 16)}, dstb, doff + 32u * (unsigned)t, 0);
+            store_cut2(doff + 32u * (unsigned)t, 16 * t + 4 * g, v | (v << 16), v | (v << 16));
           } else {
             const MmAcc ra = mm_tile<false>(v4i{(int)flo.x, (int)flo.y, (int)flo.z, (int)flo.w}, v4i{(int)fhi.x, (int)fhi.y, (int)fhi.z, (int)fhi.w}, band, K);
             if ((badbits >> i) & 1u) {
@@ -553,7 +575,7 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
                 const int x = kMmHalo + 16 * t + 4 * g + q;
                 mm_set(res, q, (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(j, x + k); }, P)));
               }
-              pl_buffer_store_u64(res, dstb, doff + 32u * (unsigned)t, 0);
+              store_cut2(doff + 32u * (unsigned)t, 16 * t + 4 * g, res.x, res.y);
             }
           }
         }
@@ -599,8 +621,10 @@ int launch_mm2d_t(const T* in, T* out, int64_t n, int h, int w, const MmParams& 
 int pl_gauss_mm2d_covers(const void* in, const void* out, int h, int w, int radius) {
   // h, w >= 64: every row / column the 24-wide halos reach is at most ONE reflection away (the kernel reflects by
   // arithmetic); frames below 2 GiB: 32-bit buffer offsets, 0x80000000 + tile offset stays out of range
-  if (radius < 1 || radius > kMmMaxRad || h < 64 || w < 64 || (w % 16) || (int64_t)h * w * 2 >= 0x7fff0000LL) return 0;
-  return !((reinterpret_cast<uintptr_t>(in) & 7) || (reinterpret_cast<uintptr_t>(out) & 15));
+  // even widths: dword accesses (rows start on 4-byte boundaries; a strip whose width is not a multiple of 16 takes the
+  // dword-by-dword stores)
+  if (radius < 1 || radius > kMmMaxRad || h < 64 || w < 64 || (w & 1) || (int64_t)h * w * 2 >= 0x7fff0000LL) return 0;
+  return !((reinterpret_cast<uintptr_t>(in) & 3) || (reinterpret_cast<uintptr_t>(out) & 3));
 }
 
 // 0 = launched; -1 = shape / alignment / taps not covered (the caller runs the two passes).  wts: HOST memory.

@@ -193,8 +193,8 @@ def test_emu_gaussian_register_window_kernels(emu):
 
 def test_emu_gaussian_marching_strip_kernel(emu):
     """gaussian_mm.hip, gauss2d_mm (both axes in one launch: marching strip, integer MFMA digit planes, carry-cascade
-    decision, pair exchange for the stores): two strips with a partial second one, two row segments, mirrored border quads
-    on both sides, zero / constant / saturated blocks (whole-tile constant path and per-output recompute), int16, all
+    decision, pair exchange for the stores): two strips with a partial second one (also ragged widths, 66 / 1046 with a quad
+    across the right edge, 300), two row segments, mirrored border quads on both sides, zero / constant / saturated blocks (whole-tile constant path and per-output recompute), int16, all
     sigmas.  Bit-identical to scipy.  (Frames below 64 x 64 take the single-axis kernels: covered by the tests above.)"""
     import build as emu_build
     from scipy import ndimage
@@ -203,7 +203,7 @@ def test_emu_gaussian_marching_strip_kernel(emu):
         pytest.skip("no clang++ host compiler: gaussian_mm.hip is not in the emulated library")
     rng = np.random.default_rng(31)
     cases = []
-    for shape in ((2, 150, 144), (1, 300, 272), (1, 70, 1040)):
+    for shape in ((2, 150, 144), (1, 300, 272), (1, 70, 1040), (2, 70, 66), (1, 80, 1046), (1, 90, 300)):
         smooth = ndimage.gaussian_filter(rng.integers(0, 65535, shape).astype(float), (0, 5, 5))
         a = np.clip(smooth + rng.normal(0, 300, shape), 0, 65535).astype(np.uint16)
         a[0, : shape[1] // 3, : shape[2] // 2] = 0

@@ -955,8 +955,9 @@ def test_median_consumed_on_the_fly_vs_scipy_and_oracle(dev):
 
 
 def test_gaussian_marching_strip_kernel_vs_scipy(dev):
-    """gauss2d_mm (both axes in one launch, exact integer arithmetic on the matrix cores): frames of at least 64 x 64 with
-    width % 16 == 0 take it.  Several strips with a partial last one, several row segments, mirrored border quads, EPID-like
+    """gauss2d_mm (both axes in one launch, exact integer arithmetic on the matrix cores): frames of at least 64 x 64 with an
+    even width take it.  Several strips with a partial last one (also ragged: width % 16 != 0, and with a column quad across
+    the right edge: width % 4 == 2, e.g. the aS1200's 1190), several row segments, mirrored border quads, EPID-like
     content, zero / constant / saturated blocks (whole-tile constant path), full-range noise, int16, every sigma the
     analyzers use plus radius 24; 1024 x 1024 frames against scipy itself."""
     from scipy import ndimage
@@ -965,7 +966,7 @@ def test_gaussian_marching_strip_kernel_vs_scipy(dev):
 
     rng = np.random.default_rng(2024)
     cases = []
-    for shape in ((2, 300, 528), (1, 64, 64), (3, 130, 1040), (1, 1024, 1024)):
+    for shape in ((2, 300, 528), (1, 64, 64), (3, 130, 1040), (1, 1024, 1024), (2, 150, 1190), (2, 70, 66), (1, 200, 300)):
         smooth = ndimage.gaussian_filter(rng.integers(0, 65535, shape).astype(float), (0, 6, 6))
         a = np.clip(20000 + 6.0 * (smooth - 32767) + rng.normal(0, 250, shape), 0, 65535).astype(np.uint16)
         a[0, : shape[1] // 3, : shape[2] // 2] = 0
