@@ -277,10 +277,34 @@ region_accum8_kernel(const int32_t* __restrict__ labels, const double* __restric
     for (int j = 0; j < 8; ++j) { w0 += val[j]; w2 += val[j] * (double)(c0 + j); }
     reduce_groups(key, 8ull, c0, c0 + 7, 8 * c0 + 28, w0, w2);
   } else {
-#pragma unroll 1
-    for (int j = 0; j < 8; ++j) {
-      const long long key = lab[j] > 0 ? frame * (long long)max_labels + (lab[j] - 1) : -1;
-      reduce_groups(key, 1ull, c0 + j, c0 + j, c0 + j, val[j], val[j] * (double)(c0 + j));
+    // some lane holds more than one label (region borders: two lanes of a row through a disk).  Rounds: every lane folds,
+    // in registers, the pixels that carry the label of its first pixel not yet handled, and the wave reduces those folds;
+    // lanes of one label are done after the first round, a border lane after one round per label it holds -- two rounds
+    // for almost every wave, where presenting the pixels one position at a time took eight
+    unsigned todo = 0xffu;                           // bit j: pixel j not yet accumulated (label 0 = background: never)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) todo &= lab[j] > 0 ? 0xffu : ~(1u << j);
+    while (__ballot(todo != 0u) != 0ull) {           // wave-uniform
+      const int jf = todo ? __builtin_ctz(todo) : 0;
+      int cur = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cur = (todo && j == jf) ? lab[j] : cur;
+      unsigned long long cnt = 0, cmin = ~0ull, cmax = 0, sc = 0;
+      double w0 = 0.0, w2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool take = ((todo >> j) & 1u) && lab[j] == cur;
+        const unsigned long long c = c0 + j;
+        cnt += take ? 1ull : 0ull;
+        cmin = take && c < cmin ? c : cmin;
+        cmax = take && c > cmax ? c : cmax;
+        sc += take ? c : 0ull;
+        w0 += take ? val[j] : 0.0;
+        w2 += take ? val[j] * (double)c : 0.0;
+        todo &= take ? ~(1u << j) : 0xffu;
+      }
+      const long long key = cnt ? frame * (long long)max_labels + (cur - 1) : -1;
+      reduce_groups(key, cnt, cmin, cmax, sc, w0, w2);
     }
   }
 }
