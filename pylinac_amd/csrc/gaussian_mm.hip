@@ -20,11 +20,12 @@
 //   S        = 2^-40 * (T + 32896 * sum wq_k) + E,  |E| 2^40 <= D = 65535 * sum |e_k| 2^40 + the dropped product
 //            (D = 1.4e6 at sigma = 5, i.e. 1.3e-6 of a grey level)
 //
-// Decision.  With C' = 32896 * sum wq_k + M (M = 2^23 >= D) folded into the accumulators' initial values (the MFMA's C
-// operand), T' = T + C' and a carry cascade of arithmetic right shifts and adds -- full-rate VALU opcodes only, exact by
-// floor(floor(x / a) / b) = floor(x / (a b)):
+// Decision.  With C' = 32896 * sum wq_k + M (M = 2^23 >= D) folded into the chain's constants, T' = T + C' and a carry
+// cascade over the five digit-pair levels, exact by floor(floor(x / a) / b) = floor(x / (a b)):
 //   t_k = a_k + (t_{k-1} >> 8) = floor((2^8 a1 + .. + 2^(8k) a_k) / 2^(8k)),     bits 8k .. 8k+7 of T' = t_k & 255
 //   floor(S) = t_5 whenever T' mod 2^40 >= 2 M, i.e. whenever bits 24 .. 39 of T' are not all zero: z = (t3 | t4) & 255 != 0
+// The additions of the cascade are the MFMAs' own: level k's first MFMA takes (t_{k-1} >> 8) as its C operand (mm_tile).
+// Per output the VALU does four arithmetic right shifts, one add and the byte test -- full-rate opcodes only.
 // z = 0 (1.5e-5 of the outputs, plus constant / saturated neighbourhoods where S sits 1e-11 from an integer) means
 // "undecided": recomputed with scipy's float64 sequence from the plane bytes still in LDS.
 //
@@ -35,7 +36,7 @@
 //
 // Cost model (scripts/ubench/mfma_valu_overlap.hip, mfma_valu_mix.hip on the MI355X): on one SIMD the i8 MFMA (17 cycles)
 // and the VALU (2.4 cycles for full-rate, 4.2 for half-rate opcodes) do NOT overlap -- their times add.  A tile costs
-// 9 MFMA + ~44 VALU, which is what bounds this kernel (not HBM): see DESIGN.md section 5.
+// 9 MFMA + ~40 VALU, which is what bounds this kernel (not HBM): see DESIGN.md section 5.
 #include <type_traits>
 
 #include "pl_common.h"
@@ -65,9 +66,8 @@ struct MmParams {
   // shifted left by c bytes, so that a lane whose Toeplitz row starts at p0 = 16 g - i + 15 reads its 16 bytes as four
   // ALIGNED dwords band[d][p0 & 3][(p0 >> 2) .. + 3]
   unsigned band[kMmDigits][4][24];
-  int c1;            // (C' & (2^24 - 1)) >> 8 -> initial value of a1   (C' = 32896 * sum wq + M, M = 2^23)
-  int c3;            // (C' >> 24) & 255       -> initial value of a3
-  int c4;            // C' >> 32               -> initial value of a4
+  int c1;            // (C' mod 2^32) >> 8     -> initial value of level 1   (C' = 32896 * sum wq + M, M = 2^23)
+  int c4;            // C' >> 32               -> added where level 4 starts
   int radius;
   double wd[kMmMaxRad + 1];  // float64 taps (offset j) for the exact path, zero beyond radius
 };
@@ -82,7 +82,7 @@ bool mm_make_params(const double* h_wts /* 2*R+1 taps, centre at R */, int R, Mm
   }
   if (!(wmax > 0.0) || !(W < 2.0)) return false;
   // Q is FIXED at 40: the integer part of S then IS the top accumulator level and the decision reads whole bytes of the
-  // levels below (mm_decide).  Five balanced digits hold |wq| < 127 * 2^32: taps up to 0.49 (sigma >= 0.82).
+  // levels below (mm_tile).  Five balanced digits hold |wq| < 127 * 2^32: taps up to 0.49 (sigma >= 0.82).
   constexpr int Q = kMmQ;
   if (__builtin_ldexp(wmax, Q) >= 5.0e11) return false;
   long long wq[2 * kMmMaxRad + 1];
@@ -126,8 +126,7 @@ bool mm_make_params(const double* h_wts /* 2*R+1 taps, centre at R */, int R, Mm
   constexpr long long M = 1LL << 23;
   if (!(D < (double)M)) return false;
   const long long C = 32896LL * WQ + M;                                      // < 2^16 * 2^41
-  p.c1 = (int)((C & 0xffffffLL) >> 8);
-  p.c3 = (int)((C >> 24) & 0xffLL);
+  p.c1 = (int)((C & 0xffffffffLL) >> 8);
   p.c4 = (int)(C >> 32);
   p.radius = R;
   for (int j = 0; j <= kMmMaxRad; ++j) p.wd[j] = j <= R ? h_wts[R - j] : 0.0;
@@ -156,51 +155,41 @@ __device__ __forceinline__ double mm_exact(F raw /* k in [-R, R] -> actual value
   return a;
 }
 
-struct MmAcc { v4i a1, a2, a3, a4, a5; };
+// One tile's result: v = floor(S) per output in the biased domain (0 .. 65535); z = bits 24 .. 39 of T' folded into a
+// byte: the output is decided iff z != 0.
+struct MmAcc { v4i v, z; };
 
-// the nine MFMAs of one tile: img_lo / img_hi = the 16 x 64 sample digit planes (as A when IMG_IS_A), w[d] = Toeplitz
-// (low sample digit x lowest weight digit is below the decision's resolution: left out, its bound is part of delta)
-struct MmConst { v4i c1, c3, c4; };            // the accumulators' initial values, one register quad each
+struct MmConst { v4i c1, c4; };                // level 1's initial value, level 4's added constant: one register quad each
 __device__ __forceinline__ MmConst mm_const(const MmParams& P) {
-  return MmConst{v4i{P.c1, P.c1, P.c1, P.c1}, v4i{P.c3, P.c3, P.c3, P.c3}, v4i{P.c4, P.c4, P.c4, P.c4}};
+  return MmConst{v4i{P.c1, P.c1, P.c1, P.c1}, v4i{P.c4, P.c4, P.c4, P.c4}};
 }
 
+// The nine MFMAs of one tile as a CARRY CHAIN: img_lo / img_hi = the 16 x 64 sample digit planes (as A when IMG_IS_A),
+// w[d] = Toeplitz band of weight digit d.  Level k (digit-pair scale 2^(8k)) starts from the level below shifted right by
+// eight -- the shifted value IS the MFMA's C operand, so the additions of the cascade
+//   t_k = a_k + (t_{k-1} >> 8) = floor((2^8 a1 + .. + 2^(8k) a_k) / 2^(8k)),     bits 8k .. 8k+7 of T' = t_k & 255
+// cost nothing: per output the VALU does four arithmetic shifts, one add (the part of the constant that does not fit
+// level 1's 32 bits) and the byte test.  floor(floor(x / a) / b) = floor(x / (a b)) keeps every level exact.  The low
+// sample digit x lowest weight digit product (scale 0) is below the decision's resolution: left out, its bound is in D.
 template <bool IMG_IS_A>
 __device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[kMmDigits], const MmConst& K) {
   auto mm = [&](v4i img, v4i band, v4i c) -> v4i {
-    if (PL_G2D_VARIANT & 1) return img;            // no instruction at all
+    if (PL_G2D_VARIANT & 1) return img + c;        // no matrix instruction
     return IMG_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(img, band, c, 0, 0, 0)
                     : __builtin_amdgcn_mfma_i32_16x16x64_i8(band, img, c, 0, 0, 0);
   };
+  v4i t = mm(img_lo, w[1], K.c1);                  // level 1
+  t = mm(img_hi, w[0], t);
+  t = mm(img_lo, w[2], t >> 8);                    // level 2
+  t = mm(img_hi, w[1], t);
+  v4i t3 = mm(img_lo, w[3], t >> 8);               // level 3
+  t3 = mm(img_hi, w[2], t3);
+  v4i t4 = mm(img_lo, w[4], (t3 >> 8) + K.c4);     // level 4
+  t4 = mm(img_hi, w[3], t4);
   MmAcc r;
-  const v4i z = {0, 0, 0, 0};
-  r.a1 = mm(img_lo, w[1], K.c1);
-  r.a2 = mm(img_lo, w[2], z);
-  r.a3 = mm(img_lo, w[3], K.c3);
-  r.a4 = mm(img_lo, w[4], K.c4);
-  r.a5 = mm(img_hi, w[4], z);
-  r.a1 = mm(img_hi, w[0], r.a1);
-  r.a2 = mm(img_hi, w[1], r.a2);
-  r.a3 = mm(img_hi, w[2], r.a3);
-  r.a4 = mm(img_hi, w[3], r.a4);
+  r.v = mm(img_hi, w[4], t4 >> 8);                 // level 5 = floor(T' / 2^40)
+  r.z = (t3 | t4) & 255;
   return r;
-}
-template <bool IMG_IS_A>
-__device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[kMmDigits], const MmParams& P) {
-  return mm_tile<IMG_IS_A>(img_lo, img_hi, w, mm_const(P));
-}
-
-// one output from its five accumulator values: floor(S) in the biased domain (0 .. 65535) and z = bits 24 .. 39 of T' folded
-// into a byte: the output is decided iff z != 0.  A carry cascade of arithmetic right shifts and adds (full-rate VALU
-// opcodes only; floor(floor(x / a) / b) = floor(x / (a b)) keeps every level exact):
-//   t_k = a_k + (t_{k-1} >> 8) = floor((2^8 a1 + .. + 2^(8k) a_k) / 2^(8k));   bits 8k .. 8k+7 of T' = t_k & 255
-__device__ __forceinline__ unsigned mm_decide(int a1, int a2, int a3, int a4, int a5, unsigned& z) {
-  const int t2 = a2 + (a1 >> 8);
-  const int t3 = a3 + (t2 >> 8);
-  const int t4 = a4 + (t3 >> 8);
-  const int t5 = a5 + (t4 >> 8);
-  z = (unsigned)((t3 | t4) & 255);
-  return (unsigned)t5;
 }
 
 // the actual sample value from its two plane bytes
@@ -280,13 +269,14 @@ template <bool SIGNED>
 __device__ __forceinline__ uint2 mm_finish_flag(const MmAcc& r, bool& bad) {
   if (PL_G2D_VARIANT & 2) {
     bad = false;
-    return uint2{(unsigned)(r.a1[0] ^ r.a5[1]), (unsigned)(r.a3[2] ^ r.a4[3])};
+    return uint2{(unsigned)(r.v[0] ^ r.z[1]), (unsigned)(r.v[2] ^ r.z[3])};
   }
   unsigned v[4], z[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    v[q] = mm_decide(r.a1[q], r.a2[q], r.a3[q], r.a4[q], r.a5[q], z[q]);
-    if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;
+    v[q] = (unsigned)r.v[q];
+    z[q] = (unsigned)r.z[q];
+    if (SIGNED) v[q] = (v[q] + (v[q] < 32768u ? 1u : 0u)) ^ 0x8000u;   // C truncation rounds negative S toward zero
   }
   unsigned zm = z[0] < z[1] ? z[0] : z[1];
   zm = zm < z[2] ? zm : z[2];
@@ -401,10 +391,10 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
   // the band operands are vector loads: retire them HERE -- left pending into the loop, the compiler's wait-count pass puts
   // vmcnt(0) in front of the first MFMAs of every step, which also waits for the step's own look-ahead loads
   __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0), expcnt / lgkmcnt untouched
-  // the accumulators' initial values live in twelve VGPRs for the whole march (the compiler would otherwise rebuild the
-  // three quads from SGPRs in front of every tile: six v_mov_b64 per tile)
+  // the chain's two constants live in eight VGPRs for the whole march (the compiler would otherwise rebuild the quads from
+  // SGPRs in front of every tile)
   MmConst K = mm_const(P);
-  asm volatile("" : "+v"(K.c1), "+v"(K.c3), "+v"(K.c4));
+  asm volatile("" : "+v"(K.c1), "+v"(K.c4));
   __syncthreads();
 
   const int lane_cell = f_cell(j);                 // cell of column 16 t + j, less the tile's 64 t bytes
@@ -469,9 +459,7 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
             if ((badbits >> i) & 1u) {
 #pragma unroll 1
               for (int q = 0; q < 4; ++q) {
-                unsigned z;
-                mm_decide(ra.a1[q], ra.a2[q], ra.a3[q], ra.a4[q], ra.a5[q], z);
-                if (z != 0u) continue;
+                if (ra.z[q] != 0) continue;
                 const int x = 16 * t + 4 * g + q;
                 const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(x, kMmHalo + j + k); }, P));
                 vd[q] = (unsigned char)((v & 255u) ^ 0x80u);
@@ -569,9 +557,7 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
               uint2 res = mm_finish_flag<kSigned>(ra, dummy);
 #pragma unroll 1
               for (int q = 0; q < 4; ++q) {
-                unsigned z;
-                mm_decide(ra.a1[q], ra.a2[q], ra.a3[q], ra.a4[q], ra.a5[q], z);
-                if (z != 0u) continue;
+                if (ra.z[q] != 0) continue;
                 const int x = kMmHalo + 16 * t + 4 * g + q;
                 mm_set(res, q, (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(j, x + k); }, P)));
               }
