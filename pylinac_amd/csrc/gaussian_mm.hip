@@ -192,6 +192,40 @@ __device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[
   return r;
 }
 
+// NT tiles in lock step, level by level: the MFMA of tile i at level k is followed by the other tiles' MFMAs of that level
+// before anything depends on it -- a single tile's chain would stall on the matrix pipe's latency after every level.
+template <bool IMG_IS_A, int NT>
+__device__ __forceinline__ void mm_tiles(const v4i (&lo)[NT], const v4i (&hi)[NT], const v4i (&w)[kMmDigits], const MmConst& K,
+                                         MmAcc (&r)[NT]) {
+  auto mm = [&](v4i img, v4i band, v4i c) -> v4i {
+    if (PL_G2D_VARIANT & 1) return img + c;        // no matrix instruction
+    return IMG_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(img, band, c, 0, 0, 0)
+                    : __builtin_amdgcn_mfma_i32_16x16x64_i8(band, img, c, 0, 0, 0);
+  };
+  v4i t[NT], t3[NT], t4[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) t[i] = mm(lo[i], w[1], K.c1);                  // level 1
+#pragma unroll
+  for (int i = 0; i < NT; ++i) t[i] = mm(hi[i], w[0], t[i]);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) t[i] = mm(lo[i], w[2], t[i] >> 8);             // level 2
+#pragma unroll
+  for (int i = 0; i < NT; ++i) t[i] = mm(hi[i], w[1], t[i]);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) t3[i] = mm(lo[i], w[3], t[i] >> 8);            // level 3
+#pragma unroll
+  for (int i = 0; i < NT; ++i) t3[i] = mm(hi[i], w[2], t3[i]);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) t4[i] = mm(lo[i], w[4], (t3[i] >> 8) + K.c4);  // level 4
+#pragma unroll
+  for (int i = 0; i < NT; ++i) t4[i] = mm(hi[i], w[3], t4[i]);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    r[i].v = mm(hi[i], w[4], t4[i] >> 8);                                      // level 5 = floor(T' / 2^40)
+    r[i].z = (t3[i] | t4[i]) & 255;
+  }
+}
+
 // the actual sample value from its two plane bytes
 template <bool SIGNED>
 __device__ __forceinline__ double mm_value(unsigned char lo, unsigned char hi) {
@@ -415,27 +449,33 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       auto run = [&](auto NT) {
         constexpr int N = decltype(NT)::value;
         unsigned badbits = 0;
-        uint4 qlo = f_ldsq(ain + 64 * tile_of(0));
-        uint4 qhi = f_ldsq(ain + 64 * tile_of(0) + (kFInHi - kFInLo));
-        MmAcc acc = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, K);
+        // the wave's tiles in two lock-step groups (3 + 2 or 2 + 2: register budget of three waves per SIMD)
+        auto group = [&](auto I0, auto NG) {
+          constexpr int i0 = decltype(I0)::value, ng = decltype(NG)::value;
+          v4i lo[ng], hi[ng];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          MmAcc nxt;
-          if (i + 1 < N) {
-            qlo = f_ldsq(ain + 64 * tile_of(i + 1));
-            qhi = f_ldsq(ain + 64 * tile_of(i + 1) + (kFInHi - kFInLo));
-            nxt = mm_tile<true>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, K);
+          for (int i = 0; i < ng; ++i) {
+            const uint4 qlo = f_ldsq(ain + 64 * tile_of(i0 + i));
+            const uint4 qhi = f_ldsq(ain + 64 * tile_of(i0 + i) + (kFInHi - kFInLo));
+            lo[i] = v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w};
+            hi[i] = v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
           }
-          bool bad;
-          const uint2 res = mm_finish_flag<kSigned>(acc, bad);
-          badbits |= (bad && row_ok) ? (1u << i) : 0u;
-          unsigned char* vd = vout + 16 * tile_of(i);
-          if (!(PL_G2D_VARIANT & 64) || res.x == 0x12345u) {
-            *reinterpret_cast<unsigned*>(vd) = __builtin_amdgcn_perm(res.y, res.x, 0x06040200u) ^ 0x80808080u;
-            *reinterpret_cast<unsigned*>(vd + (kFVHi - kFVLo)) = __builtin_amdgcn_perm(res.y, res.x, 0x07050301u) ^ kHiFlip;
+          MmAcc acc[ng];
+          mm_tiles<true, ng>(lo, hi, band, K, acc);
+#pragma unroll
+          for (int i = 0; i < ng; ++i) {
+            bool bad;
+            const uint2 res = mm_finish_flag<kSigned>(acc[i], bad);
+            badbits |= (bad && row_ok) ? (1u << (i0 + i)) : 0u;
+            unsigned char* vd = vout + 16 * tile_of(i0 + i);
+            if (!(PL_G2D_VARIANT & 64) || res.x == 0x12345u) {
+              *reinterpret_cast<unsigned*>(vd) = __builtin_amdgcn_perm(res.y, res.x, 0x06040200u) ^ 0x80808080u;
+              *reinterpret_cast<unsigned*>(vd + (kFVHi - kFVLo)) = __builtin_amdgcn_perm(res.y, res.x, 0x07050301u) ^ kHiFlip;
+            }
           }
-          if (i + 1 < N) acc = nxt;
-        }
+        };
+        group(std::integral_constant<int, 0>{}, std::integral_constant<int, N - 2>{});
+        group(std::integral_constant<int, N - 2>{}, std::integral_constant<int, 2>{});
         if (__ballot(badbits != 0u) == 0ull) return;
         // ---- undecided outputs of the wave's tiles (rare): scipy's float64 sequence from the input plane bytes
         auto sample = [&](int x, int p) {          // window column x, plane row p (0 .. 63) of this step
@@ -488,7 +528,6 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       const unsigned doff = row_ok ? ((unsigned)lrow * (unsigned)w + (unsigned)(c0 + 4 * g)) * 2u : 0x80000000u;
       // after the pair exchange below lane (g1 = g >> 1, g0 = g & 1) holds columns 8 g1 .. 8 g1 + 7 of tile 2 k + g0
       const unsigned doff16 = row_ok ? ((unsigned)lrow * (unsigned)w + (unsigned)(c0 + 8 * (g >> 1))) * 2u : 0x80000000u;
-      uint2 keep{0u, 0u};
       // a ragged strip's stores, dword by dword: column pairs at or beyond the frame's right edge go out of range (dropped)
       auto store_cut = [&](unsigned off, int x0, unsigned d0, unsigned d1, unsigned d2, unsigned d3) {
         const unsigned d[4] = {d0, d1, d2, d3};
@@ -498,39 +537,39 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       auto tile_of = [&](int i) { const int t = 4 * wave + i; return t < nht ? t : 0; };
       constexpr int N = 4;
       unsigned badbits = 0;
-      uint4 qlo = f_ldsq(bin + 16 * tile_of(0));
-      uint4 qhi = f_ldsq(bin + 16 * tile_of(0) + (kFVHi - kFVLo));
-      MmAcc acc = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, K);
+      // the MFMA leaves a lane with 4 columns (8 bytes) of a row: stored tile by tile, a row would receive 32-byte pieces.
+      // Tiles 2 k and 2 k + 1 trade halves across lane rows (v_permlane16_swap: row 1 of the first operand <-> row 0 of the
+      // second, row 3 <-> row 2), after which a lane holds 8 consecutive columns of ONE tile and the four lanes of a row
+      // store 64 contiguous bytes.  RAGGED (the strip's width is not a multiple of 16) is a compile-time choice of the whole
+      // pass: a branch inside it would split the straight-line code the tiles' MFMAs are scheduled across.
+      auto hpass = [&](auto RAGGED) {
+        v4i lo[N], hi[N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        MmAcc nxt;
-        if (i + 1 < N) {
-          qlo = f_ldsq(bin + 16 * tile_of(i + 1));
-          qhi = f_ldsq(bin + 16 * tile_of(i + 1) + (kFVHi - kFVLo));
-          nxt = mm_tile<false>(v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w}, v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w}, band, K);
+        for (int i = 0; i < N; ++i) {
+          const uint4 qlo = f_ldsq(bin + 16 * tile_of(i));
+          const uint4 qhi = f_ldsq(bin + 16 * tile_of(i) + (kFVHi - kFVLo));
+          lo[i] = v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w};
+          hi[i] = v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
         }
-        bool bad;
-        const uint2 res = mm_finish_flag<kSigned>(acc, bad);
-        badbits |= (bad && row_ok) ? (1u << i) : 0u;
-        // the MFMA leaves a lane with 4 columns (8 bytes) of a row: stored tile by tile, a row would receive 32-byte
-        // pieces.  Tiles 2 k and 2 k + 1 trade halves across lane rows (v_permlane16_swap: row 1 of the first operand <->
-        // row 0 of the second, row 3 <-> row 2), after which a lane holds 8 consecutive columns of ONE tile and the four
-        // lanes of a row store 64 contiguous bytes
-        if ((i & 1) == 0) {
-          keep = res;
-        } else {
-          const auto sx = __builtin_amdgcn_permlane16_swap(keep.x, res.x, false, false);
-          const auto sy = __builtin_amdgcn_permlane16_swap(keep.y, res.y, false, false);
-          const unsigned tsel = (g & 1) ? (unsigned)tile_of(i) : (unsigned)tile_of(i - 1);
+        MmAcc acc[N];
+        mm_tiles<false, N>(lo, hi, band, K, acc);
+#pragma unroll
+        for (int i = 0; i < N; i += 2) {
+          bool bad0, bad1;
+          const uint2 r0 = mm_finish_flag<kSigned>(acc[i], bad0), r1 = mm_finish_flag<kSigned>(acc[i + 1], bad1);
+          badbits |= ((bad0 && row_ok) ? (1u << i) : 0u) | ((bad1 && row_ok) ? (2u << i) : 0u);
+          const auto sx = __builtin_amdgcn_permlane16_swap(r0.x, r1.x, false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(r0.y, r1.y, false, false);
+          const unsigned tsel = (g & 1) ? (unsigned)tile_of(i + 1) : (unsigned)tile_of(i);
           const uint4 piece{(unsigned)sx[0], (unsigned)sy[0], (unsigned)sx[1], (unsigned)sy[1]};
-          if (!ragged) {
-            if (!(PL_G2D_VARIANT & 16) || res.x == 0x12345u) pl_buffer_store_u128(piece, dstb, doff16 + 32u * tsel, 0);
+          if (!decltype(RAGGED)::value) {
+            if (!(PL_G2D_VARIANT & 16) || r1.x == 0x12345u) pl_buffer_store_u128(piece, dstb, doff16 + 32u * tsel, 0);
           } else {
             store_cut(doff16 + 32u * tsel, 16 * (int)tsel + 8 * (g >> 1), piece.x, piece.y, piece.z, piece.w);
           }
         }
-        if (i + 1 < N) acc = nxt;
-      }
+      };
+      if (ragged) hpass(std::true_type{}); else hpass(std::false_type{});
       if (__ballot(badbits != 0u) != 0ull) {
         auto store_cut2 = [&](unsigned off, int x0, unsigned d0, unsigned d1) {   // 4 columns from x0, cut at the edge
           pl_buffer_store_u32(d0, dstb, x0 < wcols ? off : 0x80000000u, 0);
