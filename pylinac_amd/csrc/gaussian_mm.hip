@@ -174,7 +174,7 @@ __device__ __forceinline__ MmConst mm_const(const MmParams& P) {
 template <bool IMG_IS_A>
 __device__ __forceinline__ MmAcc mm_tile(v4i img_lo, v4i img_hi, const v4i (&w)[kMmDigits], const MmConst& K) {
   auto mm = [&](v4i img, v4i band, v4i c) -> v4i {
-    if (PL_G2D_VARIANT & 1) return img + c;        // no matrix instruction
+    if (PL_G2D_VARIANT & 1) return c;              // no matrix instruction
     return IMG_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(img, band, c, 0, 0, 0)
                     : __builtin_amdgcn_mfma_i32_16x16x64_i8(band, img, c, 0, 0, 0);
   };
@@ -198,7 +198,7 @@ template <bool IMG_IS_A, int NT>
 __device__ __forceinline__ void mm_tiles(const v4i (&lo)[NT], const v4i (&hi)[NT], const v4i (&w)[kMmDigits], const MmConst& K,
                                          MmAcc (&r)[NT]) {
   auto mm = [&](v4i img, v4i band, v4i c) -> v4i {
-    if (PL_G2D_VARIANT & 1) return img + c;        // no matrix instruction
+    if (PL_G2D_VARIANT & 1) return c;              // no matrix instruction
     return IMG_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(img, band, c, 0, 0, 0)
                     : __builtin_amdgcn_mfma_i32_16x16x64_i8(band, img, c, 0, 0, 0);
   };
@@ -237,35 +237,32 @@ __device__ __forceinline__ double mm_value(unsigned char lo, unsigned char hi) {
 // scipy.ndimage.gaussian_filter on a 16-bit frame is axis 0 into the 16-bit output, then axis 1 on THAT (truncated) plane.
 // A workgroup owns a strip of 256 output columns (+ 24 halo columns each side) and marches down a segment of rows, 16
 // output rows per step:
-//   - five row-group slots of the INPUT digit planes live in LDS ([slot][column cell: 16 rows x 1 column = 16 bytes]); four
-//     are under the axis-0 MFMAs of the step while the fifth receives the row group the NEXT step needs (buffer loads
-//     issued before the step's MFMAs, split into planes and written after them);
-//   - the axis-0 tiles (19 per step: 304 window columns) leave their truncated 16-bit results as digit planes in a
-//     double-buffered 16-row x 304-column LDS plane ([row][column bytes]) -- the intermediate frame never goes to HBM;
-//   - one workgroup barrier per step; then the axis-1 tiles (16 per step) read that plane and store the output rows.
+//   - four row-group slots of the INPUT digit planes live in LDS ([slot][column cell: 16 rows x 1 column = 16 bytes]): the
+//     64 window rows of the step's axis-0 tiles.  The row group two steps ahead is in flight as buffer loads (issued before
+//     the step's MFMAs), the one the next step needs waits in registers;
+//   - the axis-0 tiles (19 per step: 304 window columns) leave their truncated 16-bit results as digit planes in a 16-row x
+//     304-column LDS plane ([row][column bytes]) -- the intermediate frame never goes to HBM;
+//   - barrier; the waiting row group is split into planes and replaces the oldest slot; the axis-1 tiles (16 per step) read
+//     the plane and store the output rows; barrier.
 // HBM traffic: the frame read once (x 304/256 for the column halo, + 48 rows per segment), written once -- half of the
-// two-pass form.  The tile loops are straight-line code: the MFMAs of tile i + 1 are issued before the integer
-// recombination of tile i, no branch in between (border reflection by arithmetic, stores beyond the segment dropped by
-// the buffer's bounds check, tiles beyond a partial strip recompute tile 0).  Undecided outputs (~1e-6 of the pixels, and
-// whole tiles of constant input, which take one wave-uniform evaluation) are recomputed after the loop with scipy's
-// float64 sequence from the plane bytes and overwrite what the loop stored.
+// two-pass form.  The tile code is straight-line: a wave's tiles run their level chains in lock step (mm_tiles), no branch
+// in between (border reflection by arithmetic, stores beyond the segment dropped by the buffer's bounds check, tiles beyond
+// a partial strip recompute tile 0, ragged-strip stores chosen per pass).  Undecided outputs (1.5e-5 of the pixels, and
+// whole tiles of constant input, which take one wave-uniform evaluation) are recomputed after the pass with scipy's
+// float64 sequence from the plane bytes and overwrite what the pass stored.
 constexpr int kFCols = 256;                       // output columns per strip
 constexpr int kFWin = kFCols + 2 * kMmHalo;       // 304 window columns
-#ifndef PL_G2D_SLOTS
-#define PL_G2D_SLOTS 4
-#endif
-// 5 slots: the incoming row group has a slot of its own and the axis-0 plane is double-buffered: ONE barrier per step,
-// 68 KB, two workgroups per CU.  4 slots: the incoming group replaces the oldest one after the step's axis-0 tiles and the
-// axis-0 plane is single: TWO barriers per step, 48.6 KB, three workgroups per CU.
-constexpr int kFSlots = PL_G2D_SLOTS;             // row-group slots
-constexpr int kFVBufs = kFSlots == 5 ? 2 : 1;     // axis-0 result planes
+// Four row-group slots: the incoming group replaces the oldest one after the step's axis-0 tiles; one axis-0 result plane;
+// TWO barriers per step; 48.6 KB, three workgroups per CU.  (Five slots + a double-buffered result plane need one barrier
+// but 68 KB -- two workgroups per CU: measured 3-5 % slower and removed.)
+constexpr int kFSlots = 4;                        // row-group slots
 constexpr int kFPlane = kFWin * 16;               // bytes of one plane of one row group (= one 16-row axis-0 result plane)
 constexpr int kFQuadPitch = (kFWin / 4) * 16;     // byte distance between the cells of columns c and c + 1 (same c >> 2)
 constexpr int kFInLo = 0;                         // LDS map
 constexpr int kFInHi = kFInLo + kFSlots * kFPlane;
 constexpr int kFVLo = kFInHi + kFSlots * kFPlane;
-constexpr int kFVHi = kFVLo + kFVBufs * kFPlane;
-constexpr int kFLds = kFVHi + kFVBufs * kFPlane;  // 68096 / 48640 bytes
+constexpr int kFVHi = kFVLo + kFPlane;
+constexpr int kFLds = kFVHi + kFPlane;            // 48640 bytes
 
 // byte offset of column c's cell inside a row-group plane: cells ordered [c & 3][c >> 2] -- the four columns a lane
 // splits land 76 cells apart (ds_write_b32: 64 lanes -> 64 banks) and the 16 columns of a tile read conflict-free b128s
@@ -437,7 +434,7 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
   auto step = [&](int s, FQuad& la, FQuad& lb, const FQuad& sa, const FQuad& sb) {
     load_quad(qa, s + 5, la);
     load_quad(qb, s + 5, lb);
-    const int vb = kFVBufs == 2 ? (s & 1) * kFPlane : 0;
+    const int vb = 0;                              // the single axis-0 result plane
     const int lrow = 16 * s + j;                   // the lane's output row inside the segment, both passes
     const bool row_ok = r_begin + lrow < r_end;
 
@@ -511,15 +508,9 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       };
       if (wave == 3) run(std::integral_constant<int, 4>{}); else run(std::integral_constant<int, 5>{});
     }
-    if (kFSlots == 5) {
-      store_quad(qa, s + 4, sa);
-      store_quad(qb, s + 4, sb);
-    }
     if (!(PL_G2D_VARIANT & 8)) __syncthreads();
-    if (kFSlots == 4) {                            // group s is done with: its slot takes group s + 4
-      store_quad(qa, s + 4, sa);
-      store_quad(qb, s + 4, sb);
-    }
+    store_quad(qa, s + 4, sa);                     // group s is done with: its slot takes group s + 4
+    store_quad(qb, s + 4, sb);
 
     // ---- axis 1: Toeplitz (M = output column) x image (N = row j): lane (j, g) gets columns 16 t + 4 g .. + 3 of row j
     {
@@ -607,7 +598,7 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       }
     }
     slot_g = slot_g == kFSlots - 1 ? 0 : slot_g + 1;
-    if (kFSlots == 4 && !(PL_G2D_VARIANT & 8)) __syncthreads();   // axis-0 plane read, incoming group in place
+    if (!(PL_G2D_VARIANT & 8)) __syncthreads();    // axis-0 plane read, incoming group in place
   };
 #pragma unroll 1
   for (int s = 0; s < nsteps; s += 2) {
