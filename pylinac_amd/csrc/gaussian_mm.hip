@@ -238,11 +238,11 @@ __device__ __forceinline__ double mm_value(unsigned char lo, unsigned char hi) {
 // A workgroup owns a strip of 256 output columns (+ 24 halo columns each side) and marches down a segment of rows, 16
 // output rows per step:
 //   - four row-group slots of the INPUT digit planes live in LDS ([slot][column cell: 16 rows x 1 column = 16 bytes]): the
-//     64 window rows of the step's axis-0 tiles.  The row group two steps ahead is in flight as buffer loads (issued before
-//     the step's MFMAs), the one the next step needs waits in registers;
+//     64 window rows of the step's axis-0 tiles.  The row group the next step needs is in flight as buffer loads, issued
+//     before the step's MFMAs;
 //   - the axis-0 tiles (19 per step: 304 window columns) leave their truncated 16-bit results as digit planes in a 16-row x
 //     304-column LDS plane ([row][column bytes]) -- the intermediate frame never goes to HBM;
-//   - barrier; the waiting row group is split into planes and replaces the oldest slot; the axis-1 tiles (16 per step) read
+//   - barrier; the loaded row group is split into planes and replaces the oldest slot; the axis-1 tiles (16 per step) read
 //     the plane and store the output rows; barrier.
 // HBM traffic: the frame read once (x 304/256 for the column halo, + 48 rows per segment), written once -- half of the
 // two-pass form.  The tile code is straight-line: a wave's tiles run their level chains in lock step (mm_tiles), no branch
@@ -404,15 +404,12 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       *reinterpret_cast<unsigned*>(po + (kFInHi - kFInLo)) = __builtin_amdgcn_perm(o1, o0, 0x07060302u) ^ kHiFlip;
     }
   };
-  // row groups 0 .. 3 go to LDS now; group 4 (and from then on always the group TWO steps ahead) waits in registers:
-  // two row groups per lane are in flight while a step computes
-  FQuad xa, xb, ya, yb;
+  // row groups 0 .. 3 go to LDS now; from then on every step loads the row group the NEXT step needs before its axis-0
+  // tiles and writes it into the freed slot after them (a second group in flight was measured: no gain)
   {
     FQuad a[4], b[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { load_quad(qa, k, a[k]); load_quad(qb, k, b[k]); }
-    load_quad(qa, 4, xa);
-    load_quad(qb, 4, xb);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { store_quad(qa, k, a[k]); store_quad(qb, k, b[k]); }
   }
@@ -430,10 +427,11 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
 
   const int lane_cell = f_cell(j);                 // cell of column 16 t + j, less the tile's 64 t bytes
   int slot_g = g;                                  // slot of row group s + g
-  // one step: loads of group s + 5 into (la, lb); axis 0; group s + 4 from (sa, sb) into its slot; barrier; axis 1
-  auto step = [&](int s, FQuad& la, FQuad& lb, const FQuad& sa, const FQuad& sb) {
-    load_quad(qa, s + 5, la);
-    load_quad(qb, s + 5, lb);
+  // one step: loads of group s + 4; axis 0; barrier; group s + 4 into the slot of group s; axis 1; barrier
+  auto step = [&](int s) {
+    FQuad la, lb;
+    load_quad(qa, s + 4, la);
+    load_quad(qb, s + 4, lb);
     const int vb = 0;                              // the single axis-0 result plane
     const int lrow = 16 * s + j;                   // the lane's output row inside the segment, both passes
     const bool row_ok = r_begin + lrow < r_end;
@@ -509,8 +507,8 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       if (wave == 3) run(std::integral_constant<int, 4>{}); else run(std::integral_constant<int, 5>{});
     }
     if (!(PL_G2D_VARIANT & 8)) __syncthreads();
-    store_quad(qa, s + 4, sa);                     // group s is done with: its slot takes group s + 4
-    store_quad(qb, s + 4, sb);
+    store_quad(qa, s + 4, la);                     // group s is done with: its slot takes group s + 4
+    store_quad(qb, s + 4, lb);
 
     // ---- axis 1: Toeplitz (M = output column) x image (N = row j): lane (j, g) gets columns 16 t + 4 g .. + 3 of row j
     {
@@ -601,10 +599,7 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
     if (!(PL_G2D_VARIANT & 8)) __syncthreads();    // axis-0 plane read, incoming group in place
   };
 #pragma unroll 1
-  for (int s = 0; s < nsteps; s += 2) {
-    step(s, ya, yb, xa, xb);
-    if (s + 1 < nsteps) step(s + 1, xa, xb, ya, yb);
-  }
+  for (int s = 0; s < nsteps; ++s) step(s);
 }
 
 template <typename T>
