@@ -954,6 +954,32 @@ def test_median_consumed_on_the_fly_vs_scipy_and_oracle(dev):
                 assert np.array_equal(cs.cpu().numpy(), want.astype(np.int64).sum(1)), shape
 
 
+def test_pipeline_fused_stages_equal_separate_ops_at_baseline_size(dev):
+    """BASELINE configs[1] size (256 frames of 1024 x 1024): the pipeline's fused stages (both Gaussian axes in one launch;
+    3x3 median consumed on the fly by the Otsu histogram and by the threshold + column sums) against the composition of
+    the separate entry points (pl_gaussian1d twice, pl_median2d, pl_otsu16, pl_threshold_colsum_u16) -- different kernels
+    for every stage, 268 M pixels, bit for bit."""
+    from pylinac_amd import _lib, ops
+    from pylinac_amd.pipeline import EpidPipeline
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    n, h, w = 256, 1024, 1024
+    fr = epid_open_field_frames(n, h, w, seed0=7000, device=dev)
+    res = EpidPipeline(n, h, w, dev).run(fr)
+    wts, hw, rad = ops._device_weights(5, dev)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    tmp, g = torch.empty_like(fr), torch.empty_like(fr)
+    assert lib.pl_gaussian1d(fr.data_ptr(), tmp.data_ptr(), _lib.PL_U16, n, h, w, 0, wts.data_ptr(), hw.ctypes.data, rad, st) == 0
+    assert lib.pl_gaussian1d(tmp.data_ptr(), g.data_ptr(), _lib.PL_U16, n, h, w, 1, wts.data_ptr(), hw.ctypes.data, rad, st) == 0
+    med = ops.median_filter(g, 3)
+    thr, _, _ = ops.otsu16(med)
+    out, cs = ops.threshold_colsum_u16(med, thr)
+    assert torch.equal(res.threshold, thr)
+    assert torch.equal(res.frames.view(torch.int16), out.view(torch.int16))
+    assert torch.equal(res.profile, cs.to(torch.float64) / h)
+
+
 def test_gaussian_marching_strip_kernel_vs_scipy(dev):
     """gauss2d_mm (both axes in one launch, exact integer arithmetic on the matrix cores): frames of at least 64 x 64 with an
     even width take it.  Several strips with a partial last one (also ragged: width % 16 != 0, and with a column quad across
