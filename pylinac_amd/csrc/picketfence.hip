@@ -129,9 +129,19 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   }
   const unsigned short* f = in + frame * (size_t)h * w;
   unsigned short* sw = s_win[wv];
-  for (int e = lane; e < nrows * ncols; e += PL_WAVE) {
-    const int r = e / ncols, c = e % ncols;
-    sw[r * ncols + c] = f[(size_t)(top + r) * w + left + c];
+  // the window into LDS, its maximum on the way (element e = lane, lane + 64, ..: row / column advance by carry, no division)
+  int vmax = 0;
+  {
+    int r = lane / ncols, c = lane - r * ncols;
+    const int dr = PL_WAVE / ncols, dc = PL_WAVE - dr * ncols;
+    for (int e = lane; e < nrows * ncols; e += PL_WAVE) {
+      const unsigned short v = f[(size_t)(top + r) * w + left + c];
+      sw[e] = v;
+      vmax = max(vmax, (int)v);
+      r += dr;
+      c += dc;
+      if (c >= ncols) { c -= ncols; ++r; }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
@@ -139,8 +149,6 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   auto q = [&](int r, int c) { return ((double)sw[r * ncols + c] - s) / d; };
 
   // np.max(window) > height_threshold * picket_peak_val   (q is monotone in the integer pixel)
-  int vmax = 0;
-  for (int e = lane; e < nrows * ncols; e += PL_WAVE) vmax = max(vmax, (int)sw[e]);
   vmax = pl_wave_reduce(vmax, [](int a, int b) { return a > b ? a : b; });
   const bool above = (((double)vmax - s) / d) > height_threshold * pk_val[frame * cap + pi];
 
@@ -204,15 +212,29 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   for (int c = lane; c < ncols; c += PL_WAVE) {
     const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
     int v_lo = 0, v_hi = 0;
-    for (int a = 0; a < nrows; ++a) {
-      const int va = sw[a * ncols + c];
-      int rank = 0;
-      for (int b = 0; b < nrows; ++b) {
-        const int vb = sw[b * ncols + c];
-        rank += (vb < va || (vb == va && b < a)) ? 1 : 0;
+    if (nrows <= 16) {                               // wave-uniform; the usual leaf height: the column lives in registers
+      int col[16];
+#pragma unroll
+      for (int a = 0; a < 16; ++a) col[a] = a < nrows ? (int)sw[a * ncols + c] : 0x7fffffff;   // padding ranks last
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        int rank = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) rank += (b < a ? col[b] <= col[a] : col[b] < col[a]) ? 1 : 0;   // ties: lower index first
+        if (a < nrows && rank == k_lo) v_lo = col[a];
+        if (a < nrows && rank == k_hi) v_hi = col[a];
       }
-      if (rank == k_lo) v_lo = va;
-      if (rank == k_hi) v_hi = va;
+    } else {
+      for (int a = 0; a < nrows; ++a) {
+        const int va = sw[a * ncols + c];
+        int rank = 0;
+        for (int b = 0; b < nrows; ++b) {
+          const int vb = sw[b * ncols + c];
+          rank += (vb < va || (vb == va && b < a)) ? 1 : 0;
+        }
+        if (rank == k_lo) v_lo = va;
+        if (rank == k_hi) v_hi = va;
+      }
     }
     const double qh = ((double)v_hi - s) / d;
     pv[c] = (nrows & 1) ? qh : ((((double)v_lo - s) / d) + qh) / 2.0;
