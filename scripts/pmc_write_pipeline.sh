@@ -30,5 +30,16 @@ for f in glob.glob("gpurun_out/pmc_pipe/**/*counter_collection.csv", recursive=T
             acc[n][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for n, d in sorted(acc.items()):
     print(n, {k: round(sum(v) / len(v), 1) for k, v in d.items()}, "(KiB per launch; FETCH counts 64 B per 128-B request: double it)")
+import json
+stage_of = {"gauss2d_mm": "gauss2d", "otsu16_window_kernel": "median3_otsu16", "median3_threshold_colsum_kernel": "median3_threshold_colsum",
+            "find_peaks_kernel": "find_peaks"}
+out = {"_comment": "HBM bytes per launch (256 frames 1024x1024 u16) = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
+                   "passes over a minimal driver of the pipeline (scripts/pmc_write_pipeline.sh; FETCH doubled per MI355X_MICROARCH.md section HBM)"}
+for n, d in acc.items():
+    for key, stage in stage_of.items():
+        if n.startswith(key) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+            out[stage] = int(round((2 * f + w) * 1024))
+json.dump(out, open("gpurun_out/pmc_pipe/pmc_traffic.json", "w"), indent=1)
 PY
 find $OUT -name "*.csv" -size +1M -delete

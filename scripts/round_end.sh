@@ -24,6 +24,8 @@ bash scripts/profile_bench.sh $TAG > $OUT/profile_bench.log 2>&1
 cp gpurun_out/prof_$TAG/summary.txt $OUT/rocprofv3_summary.txt
 cp gpurun_out/prof_$TAG/summary.json $OUT/rocprofv3_summary.json
 grep '"metric"' gpurun_out/prof_$TAG/bench_trace.log | tail -1 > $OUT/bench_line_under_rocprof.json
-python scripts/make_pmc_traffic.py $OUT/rocprofv3_summary.json $TAG $OUT/pmc_traffic.json | tee -a $OUT/summary.txt
+bash scripts/pmc_write_pipeline.sh > $OUT/pmc_pipeline_traffic.txt 2>&1
+cp gpurun_out/pmc_pipe/pmc_traffic.json $OUT/pmc_traffic.json
+cat $OUT/pmc_traffic.json | tee -a $OUT/summary.txt
 bash scripts/pmc_gauss.sh 2>&1 | grep -v "^[EW]2026" > $OUT/pmc_gauss.txt
 tail -20 $OUT/pmc_gauss.txt | tee -a $OUT/summary.txt
