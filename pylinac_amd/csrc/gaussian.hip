@@ -227,7 +227,15 @@ gauss_generic(const T* __restrict__ in, T* __restrict__ out, int64_t total, int 
   const int r = (int)(t % h);
   const T* f = in + (t / h) * (size_t)h * w;
   double acc;
-  if (axis == 0) {
+  if (axis == 0 && r - rad >= 0 && r + rad < h) {           // interior: no border arithmetic per tap
+    const T* p = f + (size_t)r * w + c;
+    acc = (double)p[0] * wts[rad];
+    for (int j = rad; j >= 1; --j) acc = acc + ((double)p[-(ptrdiff_t)j * w] + (double)p[(ptrdiff_t)j * w]) * wts[rad - j];
+  } else if (axis == 1 && c - rad >= 0 && c + rad < w) {
+    const T* p = f + (size_t)r * w + c;
+    acc = (double)p[0] * wts[rad];
+    for (int j = rad; j >= 1; --j) acc = acc + ((double)p[-j] + (double)p[j]) * wts[rad - j];
+  } else if (axis == 0) {
     acc = (double)f[(size_t)r * w + c] * wts[rad];
     for (int j = rad; j >= 1; --j) {
       const int ia = border(r - j, h), ib = border(r + j, h);
