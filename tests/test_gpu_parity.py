@@ -6,6 +6,7 @@ Bars: bit-exact for integer frames / thresholds / indices; float results compare
 np.array_equal where the reference's operation order is defined, otherwise rtol 1e-12
 (north_star asks 1e-5)."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -1750,3 +1751,37 @@ def test_large_rois_stream(dev):
     import next_row_checks as checks
 
     checks.check_large_rois(dev)
+
+
+def test_bench_line_contract(dev):
+    """bench.py prints ONE JSON line with the driver's keys: metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+    higher_is_better / scaling / vs_baseline / dtype / data / config.workload, the roofline object of the dominant kernel
+    (bound, achieved, peak, unit, frac, traffic) and the cpu_baseline object (value, unit, cores, kind, sample).  A short run
+    on small frames (the default size is what the driver times)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "8", "--height", "256", "--width", "256",
+                        "--steps", "3", "--warmup", "1", "--no-configs", "--cpu-frames", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "images/s" and d["value"] > 0 and d["ms_per_step"] > 0 and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0
+
