@@ -452,6 +452,25 @@ def test_epid_pipeline_vs_oracle_small(dev):
     assert np.allclose(got, rec, rtol=1e-12, atol=0, equal_nan=True)
 
 
+def test_epid_pipeline_widths_off_the_fused_paths(dev):
+    """Widths the fused stages do not all cover: 270 (even, not a multiple of 8: matrix-core Gaussian with a ragged strip and a
+    quad across the edge, then the three separate median / Otsu / threshold launches) and 135 (odd: two-pass float64
+    Gaussian as well) give the oracle's frames, profiles and records like any other width."""
+    from pylinac_amd.pipeline import EpidPipeline
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    for w in (270, 135):
+        n, h = 3, 100
+        fr = epid_open_field_frames(n, h, w, seed0=77, device=dev, field_mm=20.0)
+        res = EpidPipeline(n, h, w, dev).run(fr)
+        out, prof, rec = o.epid_pipeline(fr.cpu().numpy())
+        assert np.array_equal(res.frames.cpu().numpy(), out), w
+        assert np.array_equal(res.profile.cpu().numpy(), prof), w
+        got = res.record().cpu().numpy()
+        assert np.array_equal(got[:, :3], rec[:, :3]), w
+        assert np.allclose(got, rec, rtol=1e-12, atol=0, equal_nan=True), w
+
+
 def test_full_size_frames_vs_oracle_and_properties(dev):
     """BASELINE config #2 size (1024x1024): 2 frames against the oracle end-to-end, then
     size-independent properties on a 24-frame batch: idempotence of thresholding, permutation
