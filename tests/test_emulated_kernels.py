@@ -224,6 +224,40 @@ def test_emu_gaussian_marching_strip_kernel(emu):
             np.testing.assert_array_equal(out, want, err_msg=f"{frames.shape} {frames.dtype} sigma {sigma}")
 
 
+def test_emu_median_consumed_on_the_fly(emu):
+    """pl_median3_otsu16 / pl_median3_threshold_colsum_u16 (median3_rows.h inside the Otsu window kernel and inside the
+    threshold + column-sum kernel: the median plane is never written): tiny and ragged geometries (2 rows, one 8-column
+    block, widths that leave the last wave partly idle, heights off the 16 / 32 row groups), a full-range frame that does not
+    fit the one-pass window (flagged: gated median into scratch + two-kernel histogram), int16."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(5)
+    for shape in ((1, 2, 8), (2, 3, 16), (1, 5, 520), (2, 33, 24), (1, 40, 1032), (3, 17, 64)):
+        for dt, code in ((np.uint16, PL_U16), (np.int16, PL_I16)):
+            n, h, w = shape
+            a = (rng.integers(1000, 1400, shape) + (np.arange(w) > w // 2) * 5000).astype(np.int64)
+            a[-1] = rng.integers(0, 65536, (h, w))
+            a = (a - (32768 if dt == np.int16 else 0)).astype(dt)
+            med = np.stack([ndimage.median_filter(f, size=3) for f in a])
+            thr, mn, mx, flag = (np.zeros(n, np.int32) for _ in range(4))
+            hist, scratch = np.zeros((n, 65536), np.uint32), np.zeros_like(a)
+            _ok(emu, emu.pl_median3_otsu16(_p(a), _p(scratch), code, n, h, w, None, None, _p(thr), _p(mn), _p(mx), _p(flag),
+                                           _p(hist), None))
+            np.testing.assert_array_equal(thr, [orc.threshold_otsu(f) for f in med], err_msg=f"{shape} {dt.__name__}")
+            np.testing.assert_array_equal(mn, med.reshape(n, -1).min(1))
+            np.testing.assert_array_equal(mx, med.reshape(n, -1).max(1))
+            if h * w >= 1000:
+                assert flag[-1] == 1, (shape, flag)                        # the full-range frame went the two-kernel way
+                np.testing.assert_array_equal(scratch[-1], med[-1])        # ... on its materialised median plane
+            if dt == np.uint16:
+                cut = np.array([int(np.percentile(f, 40)) for f in med], np.int32)
+                out, cs = np.zeros_like(a), np.zeros((n, w), np.uint64)
+                _ok(emu, emu.pl_median3_threshold_colsum_u16(_p(a), _p(out), n, h, w, _p(cut), _p(cs), None))
+                want = np.where(med.astype(np.int64) >= cut[:, None, None], med, 0).astype(np.uint16)
+                np.testing.assert_array_equal(out, want, err_msg=str(shape))
+                np.testing.assert_array_equal(cs.astype(np.int64), want.astype(np.int64).sum(1))
+
+
 def test_emu_median3_packed_kernels(emu):
     from scipy import ndimage
 
