@@ -224,6 +224,34 @@ def test_emu_gaussian_marching_strip_kernel(emu):
             np.testing.assert_array_equal(out, want, err_msg=f"{frames.shape} {frames.dtype} sigma {sigma}")
 
 
+def test_emu_gaussian_matrix_core_extreme_values(emu):
+    """gauss2d_mm where the digit planes and the accumulators are at their extremes: full-range int16 noise, frames of only
+    -32768 / 32767 and of only 0 / 65535 (every digit +-128 / 127), a saturated block on a saturated background; sigmas on
+    both sides of the tap limit (0.9 .. 6: radius 4 .. 24, non-integer sigma included).  Bit-identical to scipy."""
+    import build as emu_build
+    from scipy import ndimage
+
+    if "gaussian_mm.hip" not in emu_build.SOURCES:
+        pytest.skip("no clang++ host compiler: gaussian_mm.hip is not in the emulated library")
+    rng = np.random.default_rng(3)
+    block = np.full((1, 64, 64), -32768, np.int16)
+    block[0, 20:40, 10:50] = 32767
+    cases = [rng.integers(-32768, 32768, (2, 96, 144)).astype(np.int16),
+             np.where(rng.random((2, 80, 128)) < 0.5, -32768, 32767).astype(np.int16),
+             np.where(rng.random((1, 70, 160)) < 0.5, 0, 65535).astype(np.uint16), block]
+    for frames in cases:
+        n, h, w = frames.shape
+        for sigma in (0.9, 2, 3.3, 6):
+            radius = int(4.0 * sigma + 0.5)
+            x = np.arange(-radius, radius + 1)
+            wts = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+            wts = np.ascontiguousarray(wts / wts.sum())
+            out, tmp = np.empty_like(frames), np.empty_like(frames)
+            _ok(emu, emu.pl_gaussian2d(_p(frames), _p(out), _p(tmp), _DT[frames.dtype], n, h, w, _p(wts), _p(wts), radius, None))
+            want = np.stack([ndimage.gaussian_filter(f, sigma) for f in frames])
+            np.testing.assert_array_equal(out, want, err_msg=f"{frames.shape} {frames.dtype} sigma {sigma}")
+
+
 def test_emu_median_consumed_on_the_fly(emu):
     """pl_median3_otsu16 / pl_median3_threshold_colsum_u16 (median3_rows.h inside the Otsu window kernel and inside the
     threshold + column-sum kernel: the median plane is never written): tiny and ragged geometries (2 rows, one 8-column
