@@ -47,10 +47,11 @@ def parse():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--cpu-frames", type=int, default=96,
-                    help="bounded CPU-baseline sample (frames through the oracle on one core)")
+    ap.add_argument("--cpu-frames", type=int, default=24,
+                    help="bounded CPU-baseline sample (frames through the oracle on one core, per repeat: 3 warm-up + 5 timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs #3-#5")
+    ap.add_argument("--no-parity", action="store_true", help="skip the headline parity sample against the oracle")
     return ap.parse_args()
 
 
@@ -61,13 +62,83 @@ def timed_passes(fn, iters=3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        fn()
+        out = fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters
+    return (time.perf_counter() - t0) / iters, out
 
 
-def bench_configs(dev):
-    """BASELINE configs #3 / #4 / #5 on one GPU, inputs resident in HBM, SURVEY 8d seeded generators."""
+# ------------------------------------------------------------------------------------------------ parity samples
+# After a configuration's timed passes a few of the units it just produced are compared with the CPU oracle's sequence
+# (oracle/ = the checker, never the thing measured): `"parity_sample": {"units": k, "ok": true}` in the line.  Bars as
+# in tests/test_gpu_bench_size.py: integer results / indices / picket positions exact, BB centroids 1e-9, profiles 1e-9.
+def parity_epid(res, frames, k=4):
+    import numpy as np
+
+    from oracle import pylinac_oracle as o
+
+    idx = np.linspace(0, frames.shape[0] - 1, k).astype(int)
+    ref_out, ref_prof, ref_rec = o.epid_pipeline(frames[idx].cpu().numpy())
+    rec = res.record()[idx].cpu().numpy()
+    ok = (np.array_equal(res.frames[idx].cpu().numpy(), ref_out) and np.array_equal(res.profile[idx].cpu().numpy(), ref_prof)
+          and np.array_equal(rec[:, :3], ref_rec[:, :3]) and np.allclose(rec, ref_rec, rtol=1e-12, atol=0, equal_nan=True))
+    return {"units": int(k), "ok": bool(ok), "against": "oracle.epid_pipeline (scipy gaussian_filter + median_filter, "
+            "Otsu, threshold, np.mean, scipy find_peaks): frames, profiles, records"}
+
+
+def parity_pf(res, frames, dpmm, k=2):
+    import numpy as np
+
+    from oracle import pylinac_oracle as o
+
+    ok = True
+    for i in np.linspace(0, frames.shape[0] - 1, k).astype(int):
+        raw = frames[i].cpu().numpy()
+        ref = o.pf_measure(o.normalize(o.ground(raw)), dpmm, num_pickets=10)
+        P = len(ref["peak_idxs"])
+        pos = res.position[i, :, :P].cpu().numpy()
+        ok &= int(res.picket_count[i]) == P and np.array_equal(res.picket_idx[i, :P].cpu().numpy(), ref["peak_idxs"])
+        ok &= float(res.spacing[i]) == ref["spacing"] and np.array_equal(np.isnan(pos), np.isnan(ref["position"]))
+        ok &= np.array_equal(pos[~np.isnan(pos)], ref["position"][~np.isnan(pos)])
+    return {"units": int(k), "ok": bool(ok), "against": "oracle.pf_measure: picket indices, spacing, every leaf x picket position"}
+
+
+def parity_wl(res, frames, dpmm, k=2):
+    import numpy as np
+
+    from oracle import pylinac_oracle as o
+
+    ok = True
+    for i in np.linspace(0, frames.shape[0] - 1, k).astype(int):
+        fx, fy, bx, by, inv, crop = o.wl_analyze_frame(frames[i].cpu().numpy(), dpmm, 5.0)
+        r = res["record"][i]
+        ok &= (fx, fy) == (r[0], r[1]) and inv == bool(res["inverted"][i]) and crop == int(res["crop"][i])
+        ok &= abs(bx - r[2]) < 1e-9 and abs(by - r[3]) < 1e-9 and int(res["status"][i]) == 0
+    return {"units": int(k), "ok": bool(ok), "against": "oracle.wl_analyze_frame: field CAX exact, BB centroid 1e-9, inversion, crop"}
+
+
+def parity_ct(res, vols, mmpp, k=3):
+    import numpy as np
+
+    from oracle import pylinac_oracle as o
+
+    spv = vols.shape[1]
+    v = vols.shape[0] - 1                                        # the last volume of the batch
+    vol = vols[v].cpu().numpy()
+    prof = res["profiles"]
+    ok = True
+    for s in np.linspace(3, spv - 4, k).astype(int):
+        m = v * spv + int(s)
+        p, rmtf = o.ctp528_slice(vol, int(s), tuple(res["center"][m]), mmpp)
+        ok &= np.allclose(prof[m].cpu().numpy(), p, rtol=0, atol=1e-9)
+        ok &= np.allclose(res["rmtf"][m], rmtf, rtol=1e-9, atol=1e-9, equal_nan=True)
+    return {"units": int(k), "ok": bool(ok), "against": "oracle.ctp528_slice about the device's fitted centre: circle profile 1e-9, rMTF 1e-9"}
+
+
+def bench_configs(dev, world=8):
+    """BASELINE configs #3 / #4 / #5 on one GPU at the per-GPU share BASELINE states (512 frames; 10 000 / 8 = 1 250
+    frames; 200 / 8 = 25 volumes), inputs resident in HBM, SURVEY 8d seeded generators; #4n = #4 with the reference's
+    dark-current layer (RandomNoiseLayer(0.001)) on every frame."""
+    import numpy as np
     import torch
 
     from pylinac_amd import ct, picketfence, winston_lutz
@@ -75,56 +146,82 @@ def bench_configs(dev):
 
     out = {}
 
-    def entry(key, workload, units, unit, dt, inputs):
+    def entry(key, workload, units, unit, dt, inputs, parity):
         rate = units / dt
-        gbs = rate * ALG_BYTES[key] / 1e9
+        gbs = rate * ALG_BYTES[key[:2]] / 1e9
         out[key] = {"workload": workload, "units": units, "unit": unit, "ms_per_pass": round(dt * 1e3, 3),
                     "value": round(rate, 1), "algorithmic_GBs": round(gbs, 2),
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "frac_of_measured_copy": round(gbs / HBM_COPY_GBS, 5),
-                    "inputs": inputs}
+                    "inputs": inputs, "parity_sample": parity}
 
     n3 = 512
     f3 = pf_frames(n3, device=dev)
-    dt = timed_passes(lambda: picketfence.analyze_batch(f3, 1 / 0.390625, num_pickets=10))
+    dt, r3 = timed_passes(lambda: picketfence.analyze_batch(f3, 1 / 0.390625, num_pickets=10))
     entry("#3", "PicketFence: 512 x (768 x 1024) uint16, column mean -> picket peaks -> 60-leaf x 10-picket windows -> "
-                "FWXM positions", n3, "frames/s", dt, "synthetic.pf_frames seed 2000+i")
-    del f3
-    n4 = 512
-    f4 = torch.from_numpy(wl_frames(n4)).to(dev)
-    dt = timed_passes(lambda: winston_lutz.analyze_batch(f4, 1 / 0.336, 5.0))
-    entry("#4", "Winston-Lutz: 512 x 1024^2 uint16, inversion check -> clean edges -> field CAX (percentile threshold, "
-                "fill holes, centre of mass) -> BB threshold sweep + weighted centroid", n4, "frames/s", dt,
-          "synthetic.wl_frames seed 3000+i (generate_winstonlutz recipe)")
-    del f4
-    vols = torch.stack([torch.from_numpy(catphan_volume(4000 + v)) for v in range(4)]).to(dev)   # [V, 80, 512, 512]
-    dt = timed_passes(lambda: ct.ctp528_batch(vols, 0.5))
-    entry("#5", "CatPhan-504: 4 volumes x 80 x 512^2 int16 (a bounded sample of the 200-volume job), per slice: phantom "
+                "FWXM positions", n3, "frames/s", dt, "synthetic.pf_frames seed 2000+i", parity_pf(r3, f3, 1 / 0.390625))
+    del f3, r3
+    n4 = 10000 // world
+    host4 = wl_frames(n4)
+    f4 = torch.from_numpy(host4).to(dev)
+    dt, r4 = timed_passes(lambda: winston_lutz.analyze_batch(f4, 1 / 0.336, 5.0))
+    wl_text = (f"Winston-Lutz: {n4} (= 10 000 / {world}, one GPU's shard) x 1024^2 uint16, inversion check -> clean edges -> "
+               "field CAX (percentile threshold, fill holes, centre of mass) -> BB threshold sweep + weighted centroid")
+    entry("#4", wl_text, n4, "frames/s", dt, "synthetic.wl_frames seed 3000+i (generate_winstonlutz recipe, noise-free)",
+          parity_wl(r4, f4, 1 / 0.336))
+    del r4
+    # the same frames under the reference's dark-current layer: N(0, 0.001 * 65535) per pixel through clip_add
+    # (RandomNoiseLayer, pylinac/core/image_generator/layers.py:396-407), seeded, generated on the device
+    g = torch.Generator(device=dev)
+    g.manual_seed(3000)
+    f4n = torch.empty_like(f4)
+    for lo in range(0, n4, 125):
+        blk = f4[lo:lo + 125].to(torch.float32)
+        blk += torch.randn(blk.shape, generator=g, device=dev) * (0.001 * 65535.0)
+        # clip_add: clip to the dtype's range, then numpy's truncating cast (same bits through int16: torch copies uint16 that way)
+        f4n.view(torch.int16)[lo:lo + 125] = blk.clamp_(0, 65535).to(torch.int32).bitwise_and_(0xFFFF).to(torch.int16)
+    del f4, blk
+    dt, r4n = timed_passes(lambda: winston_lutz.analyze_batch(f4n, 1 / 0.336, 5.0))
+    entry("#4n", wl_text + "; every frame with RandomNoiseLayer(sigma = 0.001) dark-current noise", n4, "frames/s", dt,
+          "synthetic.wl_frames seed 3000+i + N(0, 65.5) per pixel (torch generator seed 3000 on the device), clipped",
+          parity_wl(r4n, f4n, 1 / 0.336))
+    del f4n, r4n
+    nv = 200 // world
+    vols = torch.stack([torch.from_numpy(catphan_volume(4000 + v)) for v in range(nv)]).to(dev)   # [V, 80, 512, 512]
+    dt, r5 = timed_passes(lambda: ct.ctp528_batch(vols, 0.5))
+    entry("#5", f"CatPhan-504: {nv} volumes (= 200 / {world}, one GPU's shard) x 80 x 512^2 int16, per slice: phantom "
                 "ROI (scharr, gaussian, Otsu, clear_border, fill, label, regionprops) -> axis fits -> +-3-slice max -> "
-                "collapsed circle profile -> 8-region peak/valley rMTF", 4 * 80, "slices/s", dt,
-          "synthetic.catphan_volume seed 4000+v")
+                "collapsed circle profile -> 8-region peak/valley rMTF", nv * 80, "slices/s", dt,
+          "synthetic.catphan_volume seed 4000+v", parity_ct(r5, vols, 0.5))
     return out, vols
 
 
+def _median_rate(fn, warmup=3, repeats=5):
+    """3 warm-up + 5 timed repeats, median -> (units per second, units per repeat, median seconds)"""
+    for _ in range(warmup):
+        fn()
+    rs = sorted((fn() for _ in range(repeats)), key=lambda r: r[2])
+    return rs[len(rs) // 2]
+
+
 def cpu_baselines(frames_host, args, with_configs):
-    """single-thread + pool-of-cores oracle timings (bounded samples) -> (headline cpu_baseline, per-config baselines)"""
+    """single-thread (3 warm-up + 5 repeats, median) + pool-of-cores oracle timings on bounded samples
+    -> (headline cpu_baseline, per-config baselines)"""
     from oracle import cpu_baseline as cb
     from pylinac_amd.synthetic import pf_frames
 
     cores = os.cpu_count() or 1
     model = cb.cpu_model()
     n_sample = min(args.cpu_frames, frames_host.shape[0])
-    cb.single_thread("epid", frames_host[:1])                     # warm-up (imports, page faults)
-    rate, units, dt = cb.single_thread("epid", frames_host[:n_sample])
+    rate, units, dt = _median_rate(lambda: cb.single_thread("epid", frames_host[:n_sample]))
     per_cfg = {}
     tasks = {"epid": [("epid", frames_host[i % frames_host.shape[0]][None]) for i in range(cores)]}
     singles = {}
     if with_configs:
         pf = pf_frames(8).numpy()
-        wl_in, ct_in = cb._make_inputs("wl", 3000, 9), cb._make_inputs("ct", 4000, 9)
-        cb.single_thread("pf", pf[:1]), cb.single_thread("wl", wl_in[0][:1]), cb.single_thread("ct", ct_in[0], ct_in[1][:1])  # warm-up
-        singles["#3"] = cb.single_thread("pf", pf[1:])
-        singles["#4"] = cb.single_thread("wl", wl_in[0][1:])
-        singles["#5"] = cb.single_thread("ct", ct_in[0], ct_in[1][1:])
+        wl_in, ct_in = cb._make_inputs("wl", 3000, 8), cb._make_inputs("ct", 4000, 8)
+        singles["#3"] = _median_rate(lambda: cb.single_thread("pf", pf))
+        singles["#4"] = _median_rate(lambda: cb.single_thread("wl", wl_in[0]))
+        singles["#5"] = _median_rate(lambda: cb.single_thread("ct", ct_in[0], ct_in[1]))
         tasks["pf"] = [("pf", pf[i % 8][None]) for i in range(cores)]
         tasks["wl"] = [("wl", ("gen", 3000 + i, 2)) for i in range(cores)]
         tasks["ct"] = [("ct", ("gen", 4000 + i, 2)) for i in range(cores)]
@@ -133,11 +230,18 @@ def cpu_baselines(frames_host, args, with_configs):
     except Exception as exc:   # a baseline must not take the bench line down
         pool = {}
         print(f"[bench] pool baseline failed: {exc!r}", file=sys.stderr)
+    ref = {}
+    rpath = os.path.join(ROOT, "profiles", "cpu_reference.json")
+    if os.path.exists(rpath):
+        try:
+            ref = json.load(open(rpath))
+        except Exception:
+            ref = {}
     head = {
         "value": round(rate, 3), "unit": "images/s", "cores": 1, "kind": "port",
         "sample": f"{units} of the same synthetic 1024x1024 uint16 frames through oracle/pylinac_oracle.py "
                   f"(scipy.ndimage gaussian+median, Otsu, threshold, np.mean, scipy.signal.find_peaks), single thread, "
-                  f"{dt:.1f} s",
+                  f"3 warm-up + 5 repeats, median repeat {dt:.2f} s",
         "cpu_model": model, "host_cores": cores,
     }
     if "epid" in pool:
@@ -145,16 +249,26 @@ def cpu_baselines(frames_host, args, with_configs):
                         "wall_s": round(pool["epid"][2], 2),
                         "how": "multiprocessing spawn pool, one worker per host core (os.cpu_count()), one frame each, "
                                "wall clock from the first worker's start to the last worker's end"}
+    if "#2" in ref:
+        head["reference_kind"] = ref["#2"]          # the reference's own modules, timed in the build container (committed)
     names = {"#3": ("pf", "frames/s"), "#4": ("wl", "frames/s"), "#5": ("ct", "slices/s")}
     for key, (kind, unit) in names.items():
         if key not in singles:
             continue
         r, u, d = singles[key]
         per_cfg[key] = {"value": round(r, 3), "unit": unit, "cores": 1, "kind": "port",
-                        "sample": f"{u} units through the oracle's restatement of the reference's per-image sequence, {d:.1f} s"}
+                        "sample": f"{u} units through the oracle's restatement of the reference's per-image sequence, "
+                                  f"3 warm-up + 5 repeats, median repeat {d:.2f} s"}
         if kind in pool:
             per_cfg[key]["pool"] = {"value": round(pool[kind][0], 2), "cores": cores, "units": pool[kind][1],
                                     "wall_s": round(pool[kind][2], 2)}
+        if key in ref:
+            per_cfg[key]["reference_kind"] = ref[key]
+    if "#1" in ref:
+        head["config_1_reference"] = ref["#1"]
+    if "#4n" in ref and with_configs:
+        per_cfg["#4n"] = dict(ref["#4n"], sample="the reference's own WLBaseImage sequence on 4 noisy frames, timed in the build "
+                                                 "container (profiles/r03_cpu_reference.json); no live port timing for this variant")
     return head, per_cfg
 
 
@@ -276,6 +390,9 @@ def main():
             },
         }
         if world == 1:
+            # a sample of what the timed steps produced, against the CPU oracle (outside the timed region)
+            if not args.no_parity:
+                line["parity_sample"] = parity_epid(pipe.run(frames), frames)
             with_configs = not args.no_configs
             if with_configs:
                 del pipe

@@ -56,7 +56,7 @@ def epid_open_field_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 10
 
 def wl_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 3000, pixel_mm: float = 0.336,
               field_mm: float = 20.0, bb_mm: float = 5.0, bb_alpha: float = -0.8, blur_mm: float = 1.5,
-              max_offset_mm: float = 1.0, return_truth: bool = False):
+              max_offset_mm: float = 1.0, return_truth: bool = False, noise_sigma: float = 0.0):
     """Config #4: n Winston-Lutz frames h x w uint16 on the HOST (numpy), frame i from
     ``np.random.default_rng(seed0 + i)``.  Closed-form restatement of the reference's generator recipe
     (``generate_winstonlutz`` with ``PerfectFieldLayer`` 20 x 20 mm, ``PerfectBBLayer`` 5 mm ``alpha=-0.8`` at a random
@@ -65,7 +65,10 @@ def wl_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 3000, pixel_mm:
     zeros -> field rectangle = 65535 (polygon fill: pixel centres inside the half-integer bounds) -> BB disk adds
     int(65535 * alpha) with clipping (``draw.disk``: strict ellipse inequality) -> ``skimage.filters.gaussian`` =
     ``ndimage.gaussian_filter(float image, sigma, mode="nearest", truncate=4)`` -> truncation to uint16.
-    The blur only touches the neighbourhood of the field, so it is evaluated on a centred crop."""
+    The blur only touches the neighbourhood of the field, so it is evaluated on a centred crop.
+    ``noise_sigma`` > 0 adds the reference's dark-current layer on top (``RandomNoiseLayer(sigma)``, layers.py:396-407:
+    N(0, sigma * 65535) over the whole frame through ``clip_add``), drawn from the frame's own seeded generator AFTER the
+    offsets, so the noise-free and the noisy variant of a seed share their geometry."""
     import numpy as np
 
     def blur(img, sigma):
@@ -99,6 +102,9 @@ def wl_frames(n: int, h: int = 1024, w: int = 1024, seed0: int = 3000, pixel_mm:
         img[disk] = np.clip(img[disk] + float(int(65535 * bb_alpha)), 0, 65535)
         img = blur(img, sigma)
         out[i, r0:r0 + 2 * half, c0:c0 + 2 * half] = img.astype(np.uint16)
+        if noise_sigma > 0:
+            noise = rng.normal(0.0, noise_sigma * 65535.0, size=(h, w))
+            out[i] = np.clip(out[i].astype(float) + noise, 0, 65535).astype(np.uint16)     # clip_add (layers.py:12-18)
         truth[i] = (fcx, fcy, bcx, bcy)
     return (out, truth) if return_truth else out
 

@@ -1,0 +1,126 @@
+"""GPU (-m gpu): parity AT THE SIZES bench.py TIMES (BASELINE configs #2 - #5).
+
+Every batch below is regenerated from its seed by pylinac_amd/synthetic.py (numpy / torch-CPU generators: identical on the
+build container and on the GPU box) and the device result is compared with
+  (i)  tests/golden/bench_size.npz = what the REFERENCE'S OWN PicketFence.analyze() / WLBaseImage sequence / CTP528CP504
+       returned on exactly these inputs (tests/golden/make_bench_size_golden.py), and
+  (ii) the CPU oracle's sequence -- the one oracle/cpu_baseline.py times -- run here on the same arrays.
+Reference loops: pylinac/picketfence.py:636-845, pylinac/winston_lutz.py:668-806, pylinac/ct.py:1511-1580.
+Bars: integer results / indices / positions the reference computes in a defined order: exact; BB weighted centroids 1e-9
+absolute (north_star: 1e-5 relative); circle profiles and rMTF 1e-9.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pylinac_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _checksum(a):
+    return int(a.astype(np.uint64).sum()) if a.dtype.kind == "u" else int(a.astype(np.int64).sum())
+
+
+# ---------------------------------------------------------------------------------------------- config #2 (headline)
+def test_headline_pipeline_64_frames_vs_scipy_oracle(dev):
+    """64 of the 256 bench frames (1024 x 1024 uint16, the bench's own GPU generator and seeds 1000 ..) through
+    EpidPipeline against the oracle's scipy sequence: thresholded frames, Otsu thresholds, profiles, peak records."""
+    from pylinac_amd.pipeline import EpidPipeline
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    n, h, w = 64, 1024, 1024
+    frames = epid_open_field_frames(n, h, w, seed0=1000, device=dev)
+    res = EpidPipeline(n, h, w, dev).run(frames)
+    torch.cuda.synchronize()
+    got_frames, got_prof, got_rec = res.frames.cpu().numpy(), res.profile.cpu().numpy(), res.record().cpu().numpy()
+    host = frames.cpu().numpy()
+    for lo in range(0, n, 16):
+        ref_out, ref_prof, ref_rec = o.epid_pipeline(host[lo:lo + 16])
+        assert np.array_equal(got_frames[lo:lo + 16], ref_out), lo
+        assert np.array_equal(got_prof[lo:lo + 16], ref_prof), lo
+        assert np.array_equal(got_rec[lo:lo + 16, :3], ref_rec[:, :3]), lo
+        assert np.allclose(got_rec[lo:lo + 16], ref_rec, rtol=1e-12, atol=0, equal_nan=True), lo
+
+
+# ---------------------------------------------------------------------------------------------- config #3
+def test_picket_fence_768x1024_vs_reference_analyze_and_oracle(golden, dev):
+    from pylinac_amd import picketfence as ppf
+    from pylinac_amd.synthetic import pf_frames
+
+    g = golden("bench_size")
+    pixel = float(g["pf.pixel_mm"])
+    dpmm = 1 / pixel
+    frames = pf_frames(4, 768, 1024, seed0=2000, device="cpu", pixel_mm=pixel).numpy()
+    res = ppf.analyze_batch(T(frames, dev), dpmm, num_pickets=10)
+    st = res.status.cpu().numpy()
+    for k, raw in enumerate(frames):
+        assert _checksum(raw) == int(g[f"pf.{k}.checksum"]), "the generator's frames changed: regenerate the golden"
+        ref = o.pf_measure(o.normalize(o.ground(raw)), dpmm, num_pickets=10)
+        P = len(ref["peak_idxs"])
+        assert P == 10 and int(res.picket_count[k]) == P
+        assert np.array_equal(res.picket_idx[k, :P].cpu().numpy(), ref["peak_idxs"])
+        assert float(res.spacing[k]) == ref["spacing"] == float(g[f"pf.{k}.spacing"])
+        assert res.leaf_nums == [n for n, _, _ in ref["leaves"]]
+        pos = res.position[k, :, :P].cpu().numpy()
+        assert np.array_equal(np.isnan(pos), np.isnan(ref["position"]))
+        assert np.array_equal(pos[~np.isnan(pos)], ref["position"][~np.isnan(pos)])
+        idx = {n: i for i, n in enumerate(res.leaf_nums)}
+        meas = g[f"pf.{k}.meas"]                                 # what the reference itself measured and kept
+        assert len(meas) >= 0.9 * len(res.leaf_nums) * P
+        for leaf, picket, p, _ in meas:
+            assert pos[idx[int(leaf)], int(picket)] == p
+        assert (st[k][:, P:] == 1).all() and set(np.unique(st[k][:, :P])) <= {0, 2}
+
+
+# ---------------------------------------------------------------------------------------------- config #4
+@pytest.mark.parametrize("tag,sigma", [("wl", 0.0), ("wln", 0.001)])
+def test_winston_lutz_1024_vs_reference_sequence_and_oracle(golden, dev, tag, sigma):
+    """noise-free frames (the SURVEY recipe) and the RandomNoiseLayer(0.001) dark-current variant"""
+    from pylinac_amd import winston_lutz as wl
+    from pylinac_amd.synthetic import wl_frames
+
+    g = golden("bench_size")
+    frames = wl_frames(6, 1024, 1024, seed0=3000, noise_sigma=sigma)
+    assert np.array_equal(np.array([_checksum(f) for f in frames], dtype=np.uint64), g[f"{tag}.checksum"])
+    res = wl.analyze_batch(T(frames, dev), 1 / 0.336, 5.0)
+    want = g[f"{tag}.record"]
+    assert (want[:, 4] == 1).all()
+    assert np.array_equal(res["status"], np.zeros(len(frames), dtype=np.int32))
+    assert np.array_equal(res["inverted"], g[f"{tag}.inverted"])
+    assert np.array_equal(res["crop"] * 2, 1024 - g[f"{tag}.shape_after_clean"][:, 0])
+    assert np.array_equal(res["record"][:, :2], want[:, :2])
+    assert np.allclose(res["record"][:, 2:], want[:, 2:4], rtol=0, atol=1e-9), np.abs(res["record"][:, 2:] - want[:, 2:4]).max()
+    for k in (0, 3):                                             # the oracle's sequence (what cpu_baseline times)
+        fx, fy, bx, by, inv, crop = o.wl_analyze_frame(frames[k], 1 / 0.336, 5.0)
+        assert (fx, fy) == tuple(res["record"][k, :2]) and inv == bool(res["inverted"][k]) and crop == int(res["crop"][k])
+        assert abs(bx - res["record"][k, 2]) < 1e-9 and abs(by - res["record"][k, 3]) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------- config #5
+def test_ctp528_80x512x512_volume_vs_reference_and_oracle(golden, dev):
+    from pylinac_amd import ct
+    from pylinac_amd.synthetic import catphan_volume
+
+    g = golden("bench_size")
+    vol = catphan_volume(4000)
+    assert vol.shape == (80, 512, 512) and _checksum(vol) == int(g["ct.checksum"])
+    full = ct.ctp528_batch(T(vol, dev), 0.5)
+    assert np.allclose(full["fit_zx"], g["ct.fit_zx"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(full["fit_zy"], g["ct.fit_zy"], rtol=1e-9, atol=1e-9)
+    sl = g["ct.slices"]
+    assert np.array_equal(full["nregions"][sl], g["ct.nregions"])
+    for key in ("rmtf", "maxs", "mins"):
+        assert np.allclose(full[key][sl], g[f"ct.{key}"], rtol=1e-7, atol=1e-7, equal_nan=True), key
+    rows = g["ct.profile_rows"]
+    prof = full["profiles"].cpu().numpy()
+    assert np.allclose(prof[sl[rows]], g["ct.profiles"], rtol=0, atol=1e-9)
+    # the oracle's per-slice sequence about the same fitted centres
+    for s in (10, 44, 70):
+        p, rmtf = o.ctp528_slice(vol, s, tuple(full["center"][s]), 0.5)
+        assert np.allclose(prof[s], p, rtol=0, atol=1e-9)
+        assert np.allclose(full["rmtf"][s], rmtf, rtol=1e-9, atol=1e-9, equal_nan=True)

@@ -1803,4 +1803,5 @@ def test_bench_line_contract(dev):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0
+    assert d["parity_sample"]["ok"] is True and d["parity_sample"]["units"] >= 1
 
