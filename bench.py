@@ -77,9 +77,10 @@ def parity_epid(res, frames, k=4):
     from oracle import pylinac_oracle as o
 
     idx = np.linspace(0, frames.shape[0] - 1, k).astype(int)
-    ref_out, ref_prof, ref_rec = o.epid_pipeline(frames[idx].cpu().numpy())
-    rec = res.record()[idx].cpu().numpy()
-    ok = (np.array_equal(res.frames[idx].cpu().numpy(), ref_out) and np.array_equal(res.profile[idx].cpu().numpy(), ref_prof)
+    pick = lambda t: np.stack([t[int(i)].cpu().numpy() for i in idx])      # (torch has no indexed gather for uint16)
+    ref_out, ref_prof, ref_rec = o.epid_pipeline(pick(frames))
+    rec = pick(res.record())
+    ok = (np.array_equal(pick(res.frames), ref_out) and np.array_equal(pick(res.profile), ref_prof)
           and np.array_equal(rec[:, :3], ref_rec[:, :3]) and np.allclose(rec, ref_rec, rtol=1e-12, atol=0, equal_nan=True))
     return {"units": int(k), "ok": bool(ok), "against": "oracle.epid_pipeline (scipy gaussian_filter + median_filter, "
             "Otsu, threshold, np.mean, scipy find_peaks): frames, profiles, records"}

@@ -61,8 +61,9 @@ int pl_device_available(void);
  * (truncation toward zero for integer dtypes).  The 2*radius+1 float64 taps (scipy's _gaussian_kernel1d; the
  * host layer computes them) are passed TWICE: d_weights on the device (read by the float64 kernels) and
  * h_weights in host memory (the packed kernels for 16-bit frames receive them as kernel arguments).
- * h_weights may be NULL: the library then fetches the taps from d_weights when it needs them, which
- * SYNCHRONISES the stream -- pass both on a hot path.  in != out. */
+ * h_weights may be NULL: the calls then run the float64 kernels on d_weights (same frames, slower; no
+ * device-to-host fetch, no stream synchronisation, legal under stream capture) -- pass both on a hot
+ * path.  The caller guarantees that the two copies hold the same taps.  in != out. */
 int pl_gaussian1d(const void* in, void* out, int dtype, int64_t n, int h, int w, int axis,
                   const double* d_weights, const double* h_weights, int radius, void* stream);
 /* axis 0 into tmp, then axis 1 into out: ndimage.gaussian_filter on a 2-D frame. */

@@ -522,7 +522,7 @@ extern "C" int pl_field_cax(const void* in, int dtype, int64_t n, int h, int w, 
   hipStream_t st = (hipStream_t)stream;
   const int bpf = (int)pl_cdiv((int64_t)h * w, 65536);
   PL_REQUIRE(n * bpf <= 0x7fffffffLL, "batch too large");
-  static bool attr = false;
+  static std::atomic<bool> attr{false};
   hipLaunchKernelGGL(cax_init_kernel, dim3((unsigned)pl_cdiv(n, kThreads)), dim3(kThreads), 0, st, d_acc, n);
   PL_DISPATCH_DTYPE(dtype, T, {
     if (!attr) {

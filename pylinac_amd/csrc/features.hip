@@ -349,7 +349,7 @@ extern "C" int pl_features_level(const double* d_sample, const int32_t* d_labels
   if (n == 0) return PL_OK;
   FeatureParams prm{dpmm, radius_mm, tol_mm, min_sep_px, max_number, 0};
   const size_t lds = (size_t)3 * kMaxCrop * kMaxCrop;
-  static bool attr = false;
+  static std::atomic<bool> attr{false};
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)features_level_kernel<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -373,7 +373,7 @@ extern "C" int pl_fields_level(const int32_t* d_labels, const int32_t* d_nlabels
   if (n == 0) return PL_OK;
   FeatureParams prm{dpmm, field_width_mm, field_tol_mm, field_height_mm, max_number, buffer_size + 1};
   const size_t lds = (size_t)3 * kMaxCrop * kMaxCrop;
-  static bool attr = false;
+  static std::atomic<bool> attr{false};
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)features_level_kernel<true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

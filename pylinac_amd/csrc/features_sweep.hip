@@ -430,7 +430,7 @@ extern "C" int pl_features_sweep(const double* d_sample, int64_t n, int h, int w
   for (int k = 1; k < nlevels; ++k) PL_REQUIRE(h_cutoffs[k] > h_cutoffs[k - 1], "cutoffs must increase");
   const size_t lds = (size_t)kSwMaxRuns * 6 * 4 + ((size_t)2 * kSwMaxHullPts + 2 * (kSwMaxHullPts + 1)) * 4 +
                      (size_t)3 * kSwMaxCrop * kSwMaxCrop + (size_t)h * w;
-  static size_t attr_lds = 0;
+  static std::atomic<size_t> attr_lds{0};
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute((const void*)bb_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { pl_set_error("pl_features_sweep: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }

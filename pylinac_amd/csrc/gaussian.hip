@@ -302,16 +302,10 @@ template <typename T>
 int gaussian1d_t(const T* in, T* out, int64_t n, int h, int w, int axis, const double* wts, const double* h_wts,
                  int radius, hipStream_t st, int mode = 0) {
   int rc = -1;
-  if (sizeof(T) == 2 && mode == 0 && pl_gauss_rw_covers(in, out, h, w, axis, radius)) {
-    double fetched[49];
-    if (!h_wts) {  // convenience path: the caller gave no host copy of the taps -> fetch them (synchronises the stream)
-      if (hipMemcpyAsync(fetched, wts, (size_t)(2 * radius + 1) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess) {
-        pl_set_error("pl_gaussian1d: fetching the taps failed: %s", hipGetErrorString(hipGetLastError()));
-        return PL_ERR_HIP;
-      }
-      h_wts = fetched;
-    }
+  // the register-window kernels take the taps as kernel arguments: they need the HOST copy.  Without one (h_wts == NULL)
+  // nothing is fetched back -- no hidden stream synchronisation, legal under stream capture -- and the float64 kernels
+  // below, which read the device copy, produce the same frames
+  if (sizeof(T) == 2 && mode == 0 && h_wts && pl_gauss_rw_covers(in, out, h, w, axis, radius)) {
     rc = pl_gauss_rw_launch(in, out, (T)-1 < (T)0, n, h, w, axis, h_wts, radius, st);
     if (rc == 0) return pl_check_launch("pl_gaussian1d");
   }
@@ -374,18 +368,11 @@ extern "C" int pl_gaussian2d_mode(const void* in, void* out, void* tmp, int dtyp
 extern "C" int pl_gaussian2d(const void* in, void* out, void* tmp, int dtype, int64_t n, int h, int w,
                              const double* d_weights, const double* h_weights, int radius, void* stream) {
   PL_REQUIRE(tmp && tmp != in && tmp != out, "tmp must be a distinct buffer");
-  if ((dtype == PL_U16 || dtype == PL_I16) && in && out && d_weights && in != out && n > 0 && h > 0 && w > 0 &&
+  // both axes in one launch on the matrix cores: needs the host copy of the taps (kernel arguments); without it the two
+  // passes below run (float64 kernels on the device copy) -- never a device-to-host fetch inside a launch path
+  if ((dtype == PL_U16 || dtype == PL_I16) && in && out && d_weights && h_weights && in != out && n > 0 && h > 0 && w > 0 &&
       pl_gauss_mm2d_covers(in, out, h, w, radius)) {
     hipStream_t st = (hipStream_t)stream;
-    double fetched[49];
-    if (!h_weights) {  // no host copy of the taps: fetch them (synchronises the stream)
-      if (hipMemcpyAsync(fetched, d_weights, (size_t)(2 * radius + 1) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess) {
-        pl_set_error("pl_gaussian2d: fetching the taps failed: %s", hipGetErrorString(hipGetLastError()));
-        return PL_ERR_HIP;
-      }
-      h_weights = fetched;
-    }
     if (pl_gauss_mm2d_launch(in, out, dtype == PL_I16, n, h, w, h_weights, radius, st) == 0) return pl_check_launch("pl_gaussian2d");
   }
   int rc = pl_gaussian1d(in, tmp, dtype, n, h, w, 0, d_weights, h_weights, radius, stream);

@@ -560,6 +560,9 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       };
       if (ragged) hpass(std::true_type{}); else hpass(std::false_type{});
       if (__ballot(badbits != 0u) != 0ull) {
+        // the fix-up stores below overwrite addresses the pass has just stored from OTHER lanes of this wave (after the
+        // permlane16_swap re-layout): retire those first -- same-address ordering across lanes is not a guarantee
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0)
         auto store_cut2 = [&](unsigned off, int x0, unsigned d0, unsigned d1) {   // 4 columns from x0, cut at the edge
           pl_buffer_store_u32(d0, dstb, x0 < wcols ? off : 0x80000000u, 0);
           pl_buffer_store_u32(d1, dstb, x0 + 2 < wcols ? off + 4u : 0x80000000u, 0);
@@ -605,10 +608,10 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
 template <typename T>
 int launch_mm2d_t(const T* in, T* out, int64_t n, int h, int w, const MmParams& P, hipStream_t st) {
   const int strips = (int)pl_cdiv(w, kFCols);
-  // row segments: the chip holds 256 CUs x 3 workgroups (48.6 KB of LDS each) at a time; a workgroup's cost is its steps
+  // row segments: the chip holds its CUs (256) x 3 workgroups (48.6 KB of LDS each) at a time; a workgroup's cost is its steps
   // plus about three steps' worth of prologue (four row groups, 48 halo rows).  Take the segment count that minimises
   // rounds x (steps + 3), segments of at least 128 rows -- 256 x 1024 x 1024: 3 segments, 3072 workgroups, four full rounds
-  const int64_t resident = 256 * 3;
+  const int64_t resident = (int64_t)pl_cu_count() * 3;
   const int64_t max_segs = h / 128 > 1 ? h / 128 : 1;
   int64_t segs = 1, best = -1;
   for (int64_t cand = 1; cand <= max_segs; ++cand) {

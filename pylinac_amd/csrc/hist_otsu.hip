@@ -122,7 +122,7 @@ template <int PARTS, bool RUNS>
 int launch_hist16(const unsigned short* in, int64_t n, int64_t count, unsigned flip, uint32_t* hist, hipStream_t st,
                   const int32_t* only = nullptr) {
   const size_t lds = (size_t)(65536 / PARTS) * sizeof(unsigned);
-  static bool attr = false;
+  static std::atomic<bool> attr{false};
   if (!attr) {
     if (hipFuncSetAttribute((const void*)hist16_kernel<PARTS, RUNS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
@@ -546,7 +546,7 @@ int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t c
   const unsigned flip = dtype == PL_I16 ? 0x8000u : 0u;
   const int bias = dtype == PL_I16 ? 32768 : 0;
   const size_t lds = (size_t)(kWinBins + 1) * sizeof(unsigned);   // + the spare bin of the branch-free tally
-  static bool attr = false;                        // one flag per instantiation
+  static std::atomic<bool> attr{false};                        // one flag per instantiation
   if (!attr) {
     if (hipFuncSetAttribute((const void*)otsu16_window_kernel<T, MED3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {

@@ -439,7 +439,7 @@ extern "C" int pl_find_peaks_regions(const double* d_x, int64_t n, int len, cons
   if (maxc > kMaxCand) maxc = kMaxCand;
   const int stage_x = (m <= kStageMax) ? 1 : 0;
   size_t lds = (size_t)maxc * (8 + 8 + 4 * 4) + 8 + (stage_x ? (size_t)m * 8 : 0);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)find_peaks_kernel<true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

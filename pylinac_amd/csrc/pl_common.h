@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/pylinac_hip.h"
 
 #define PL_WAVE 64
@@ -20,6 +22,11 @@ int pl_check_launch(const char* what);
   } while (0)
 
 static inline int64_t pl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// compute units of the current device (queried once per device; 256 on an MI355X): grid-shaping heuristics only
+int pl_cu_count();
+// The "opt in to more than 64 KB of dynamic LDS" flags next to the launches are std::atomic: hipFuncSetAttribute is
+// idempotent, so two host threads racing through a first call both set it and both store `true` -- no data race.
 
 // ---- device side -----------------------------------------------------------------------------
 // scipy 'reflect' (half-sample symmetric:  d c b a | a b c d | d c b a), valid for any distance.

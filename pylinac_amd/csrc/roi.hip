@@ -248,7 +248,7 @@ extern "C" int pl_roi_stats(const void* frames, int dtype, int64_t n, int h, int
   const size_t lds = (size_t)kMaxPix * sizeof(double);
   hipStream_t st = (hipStream_t)stream;
   PL_DISPATCH_DTYPE(dtype, T, {
-    static bool attr = false;
+    static std::atomic<bool> attr{false};
     if (!attr) {
       hipError_t e = hipFuncSetAttribute((const void*)roi_stats_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds);
@@ -275,7 +275,7 @@ extern "C" int pl_polygon_roi_stats(const void* frames, int dtype, int64_t n, in
   const size_t lds = (size_t)kMaxPix * sizeof(double);
   hipStream_t st = (hipStream_t)stream;
   PL_DISPATCH_DTYPE(dtype, T, {
-    static bool attr = false;
+    static std::atomic<bool> attr{false};
     if (!attr) {
       hipError_t e = hipFuncSetAttribute((const void*)roi_stats_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds);

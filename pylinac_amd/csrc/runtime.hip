@@ -22,6 +22,20 @@ int pl_check_launch(const char* what) {
   return PL_OK;
 }
 
+int pl_cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+  int c = cached[dev].load(std::memory_order_relaxed);
+  if (c > 0) return c;
+  if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) {
+    (void)hipGetLastError();
+    c = 256;
+  }
+  cached[dev].store(c, std::memory_order_relaxed);
+  return c;
+}
+
 extern "C" int pl_abi_version(void) { return PL_ABI_VERSION; }
 
 extern "C" const char* pl_last_error(void) { return g_err; }

@@ -638,6 +638,8 @@ def scharr(frames: torch.Tensor) -> torch.Tensor:
 
 def gaussian_filter_mode(frames: torch.Tensor, sigma: float, mode: str = "nearest") -> torch.Tensor:
     """``ndimage.gaussian_filter(frame, sigma, mode=...)``; ``skimage.filters.gaussian`` uses 'nearest'."""
+    if mode == "reflect":
+        return gaussian_filter(frames, sigma)       # the default entry hands the library the cached host taps as well
     x = _frames(frames)
     n, h, w = x.shape
     wts, _, lw = _device_weights(sigma, x.device)

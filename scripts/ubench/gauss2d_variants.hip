@@ -11,15 +11,20 @@
 
 void pl_set_error(const char*, ...) {}
 int pl_check_launch(const char*) { return 0; }
+int pl_cu_count() { return 256; }
 
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 256, h = 1024, w = 1024, R = 20;
+  const int epid = argc > 2 ? atoi(argv[2]) : 0;   // 1: EPID-like frames (background 2000, 595-pixel plateau 40000, +-400 noise)
   const size_t px = (size_t)n * h * w;
   std::vector<unsigned short> host(px);
   unsigned s = 12345u;
   for (size_t i = 0; i < px; ++i) {
     s = s * 1664525u + 1013904223u;
-    host[i] = (unsigned short)(20000 + ((i / w) % h) * 10 + (s >> 22));      // ramp + noise
+    const size_t y = (i / w) % h, x = i % w;
+    const bool in_field = y > 214 && y < 810 && x > 214 && x < 810;
+    host[i] = epid ? (unsigned short)((in_field ? 39600 : 1600) + (s >> 22) * 800 / 1024)
+                   : (unsigned short)(20000 + y * 10 + (s >> 22));             // ramp + noise
   }
   double wts[2 * 20 + 1], sum = 0;
   for (int k = -R; k <= R; ++k) sum += (wts[k + R] = std::exp(-0.5 / 25.0 * k * k));
@@ -40,6 +45,7 @@ int main(int argc, char** argv) {
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
-  printf("variant %3d: %.4f ms per launch of %d frames (%s)\n", PL_G2D_VARIANT, ms / iters, n, hipGetErrorString(hipGetLastError()));
+  printf("variant %3d: %.4f ms per launch of %d frames, %s data (%s)\n", PL_G2D_VARIANT, ms / iters, n, epid ? "EPID-like" : "ramp+noise",
+         hipGetErrorString(hipGetLastError()));
   return 0;
 }

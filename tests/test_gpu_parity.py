@@ -1047,9 +1047,9 @@ def test_gaussian_marching_strip_equals_two_pass_kernels_full_size(dev):
     assert torch.equal(one.view(torch.int16), two.view(torch.int16))
 
 
-def test_gaussian_without_host_taps_fetches_them(dev):
-    """pl_gaussian2d with h_weights = NULL: the library fetches the taps from the device copy (synchronising
-    convenience path) and produces the same frames."""
+def test_gaussian_without_host_taps_runs_the_float64_kernels(dev):
+    """pl_gaussian2d with h_weights = NULL: no device-to-host fetch, no stream synchronisation -- the float64
+    kernels read the device copy of the taps and produce the same frames."""
     from pylinac_amd import _lib, ops
 
     rng = np.random.default_rng(77)
