@@ -34,24 +34,23 @@
 // device); because A and B use the SAME slot -> k map, any consistent assignment of window positions to slots is correct:
 // slot (g, s) <-> window position k = 16 g + s.
 //
-// Cost model (scripts/ubench/mfma_valu_overlap.hip, mfma_valu_mix.hip on the MI355X): on one SIMD the i8 MFMA (17 cycles)
-// and the VALU (2.4 cycles for full-rate, 4.2 for half-rate opcodes) do NOT overlap -- their times add.  A tile costs
-// 9 MFMA + ~40 VALU, which is what bounds this kernel (not HBM): see DESIGN.md section 5.
+// Cost model (scripts/ubench/mfma_valu_settle.hip on the MI355X, profiles/r03a_ubench_mfma_valu_settle.txt): on one SIMD the
+// i8 MFMA (16 cycles, SQ_VALU_MFMA_BUSY_CYCLES = 16 x SQ_INSTS_MFMA) and the VALU (2.3 - 2.4 cycles per full-rate opcode from two
+// or more waves) do NOT overlap -- interleaved in one wave, blocked, or on partner waves, their times add.  A tile costs
+// 9 MFMA + ~37 VALU (50 with the plane split and addressing), which is what bounds this kernel (not HBM): DESIGN.md section 5.
 #include <type_traits>
 
 #include "pl_common.h"
 
 // Timing-attribution switches for scripts/ubench/g2d_variants.hip ONLY (results become wrong): bit 0 drops the MFMAs,
 // bit 1 the integer recombination, bit 2 the global loads, bit 3 the per-step barrier, bit 4 the global stores, bit 5 the plane
-// split + LDS writes of the input, bit 6 the LDS writes of the axis-0 plane, bit 7 the LDS operand reads.
+// split + LDS writes of the input, bit 6 the LDS writes of the axis-0 plane, bit 7 the LDS operand reads, bit 8 the two level-1 MFMAs and every fix-up.
 #ifndef PL_G2D_VARIANT
 #define PL_G2D_VARIANT 0
 #endif
 
 namespace {
 
-constexpr int kMmThreads = 256;
-constexpr int kMmWaves = kMmThreads / PL_WAVE;
 constexpr int kMmHalo = 24;                 // window start = first output - 24: 16-byte aligned, covers RAD <= 24
 constexpr int kMmMaxRad = 24;
 
@@ -203,10 +202,15 @@ __device__ __forceinline__ void mm_tiles(const v4i (&lo)[NT], const v4i (&hi)[NT
                     : __builtin_amdgcn_mfma_i32_16x16x64_i8(band, img, c, 0, 0, 0);
   };
   v4i t[NT], t3[NT], t4[NT];
+  if (PL_G2D_VARIANT & 256) {                      // stopwatch only: what would a 7-MFMA tile (no level 1) cost?
+#pragma unroll
+    for (int i = 0; i < NT; ++i) t[i] = K.c1 + lo[i];
+  } else {
 #pragma unroll
   for (int i = 0; i < NT; ++i) t[i] = mm(lo[i], w[1], K.c1);                  // level 1
 #pragma unroll
   for (int i = 0; i < NT; ++i) t[i] = mm(hi[i], w[0], t[i]);
+  }
 #pragma unroll
   for (int i = 0; i < NT; ++i) t[i] = mm(lo[i], w[2], t[i] >> 8);             // level 2
 #pragma unroll
@@ -237,13 +241,11 @@ __device__ __forceinline__ double mm_value(unsigned char lo, unsigned char hi) {
 // scipy.ndimage.gaussian_filter on a 16-bit frame is axis 0 into the 16-bit output, then axis 1 on THAT (truncated) plane.
 // A workgroup owns a strip of 256 output columns (+ 24 halo columns each side) and marches down a segment of rows, 16
 // output rows per step:
-//   - four row-group slots of the INPUT digit planes live in LDS ([slot][column cell: 16 rows x 1 column = 16 bytes]): the
-//     64 window rows of the step's axis-0 tiles.  The row group the next step needs is in flight as buffer loads, issued
-//     before the step's MFMAs;
-//   - the axis-0 tiles (19 per step: 304 window columns) leave their truncated 16-bit results as digit planes in a 16-row x
-//     304-column LDS plane ([row][column bytes]) -- the intermediate frame never goes to HBM;
-//   - barrier; the loaded row group is split into planes and replaces the oldest slot; the axis-1 tiles (16 per step) read
-//     the plane and store the output rows; barrier.
+//   - a ring of row-group slots of the INPUT digit planes lives in LDS ([slot][column cell: 16 rows x 1 column = 16 bytes]):
+//     the 64 window rows of the step's axis-0 tiles.  The row group a later step needs is in flight as buffer loads;
+//   - the axis-0 tiles (19 per step: 304 window columns) leave their truncated 16-bit results as digit planes in LDS -- the
+//     intermediate frame never goes to HBM;
+//   - barrier; the axis-1 tiles (16 per step) read that plane and store the output rows.
 // HBM traffic: the frame read once (x 304/256 for the column halo, + 48 rows per segment), written once -- half of the
 // two-pass form.  The tile code is straight-line: a wave's tiles run their level chains in lock step (mm_tiles), no branch
 // in between (border reflection by arithmetic, stores beyond the segment dropped by the buffer's bounds check, tiles beyond
@@ -252,17 +254,8 @@ __device__ __forceinline__ double mm_value(unsigned char lo, unsigned char hi) {
 // float64 sequence from the plane bytes and overwrite what the pass stored.
 constexpr int kFCols = 256;                       // output columns per strip
 constexpr int kFWin = kFCols + 2 * kMmHalo;       // 304 window columns
-// Four row-group slots: the incoming group replaces the oldest one after the step's axis-0 tiles; one axis-0 result plane;
-// TWO barriers per step; 48.6 KB, three workgroups per CU.  (Five slots + a double-buffered result plane need one barrier
-// but 68 KB -- two workgroups per CU: measured 3-5 % slower and removed.)
-constexpr int kFSlots = 4;                        // row-group slots
 constexpr int kFPlane = kFWin * 16;               // bytes of one plane of one row group (= one 16-row axis-0 result plane)
 constexpr int kFQuadPitch = (kFWin / 4) * 16;     // byte distance between the cells of columns c and c + 1 (same c >> 2)
-constexpr int kFInLo = 0;                         // LDS map
-constexpr int kFInHi = kFInLo + kFSlots * kFPlane;
-constexpr int kFVLo = kFInHi + kFSlots * kFPlane;
-constexpr int kFVHi = kFVLo + kFPlane;
-constexpr int kFLds = kFVHi + kFPlane;            // 48640 bytes
 
 // byte offset of column c's cell inside a row-group plane: cells ordered [c & 3][c >> 2] -- the four columns a lane
 // splits land 76 cells apart (ds_write_b32: 64 lanes -> 64 banks) and the 16 columns of a tile read conflict-free b128s
@@ -298,6 +291,11 @@ __device__ __forceinline__ bool mm_wave_flat(const uint4& lo, const uint4& hi) {
 // four outputs of a lane, branch-free: packed results and ONE flag (some output of the four is undecided)
 template <bool SIGNED>
 __device__ __forceinline__ uint2 mm_finish_flag(const MmAcc& r, bool& bad) {
+  if (PL_G2D_VARIANT & 256) {                      // 7-MFMA stopwatch: results are garbage, nothing is undecided
+    bad = false;
+    return uint2{__builtin_amdgcn_perm((unsigned)r.v[1], (unsigned)r.v[0], 0x05040100u) ^ (unsigned)r.z[0],
+                 __builtin_amdgcn_perm((unsigned)r.v[3], (unsigned)r.v[2], 0x05040100u) ^ (unsigned)r.z[3]};
+  }
   if (PL_G2D_VARIANT & 2) {
     bad = false;
     return uint2{(unsigned)(r.v[0] ^ r.z[1]), (unsigned)(r.v[2] ^ r.z[3])};
@@ -316,12 +314,52 @@ __device__ __forceinline__ uint2 mm_finish_flag(const MmAcc& r, bool& bad) {
   return uint2{__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
 }
 
+// ------------------------------------------------------------------ eight waves, ONE barrier per step
+// Round 2's kernel kept three 4-wave workgroups on a CU, a four-slot ring and one result plane: two barriers per step, and
+// per-lane branches around its look-ahead loads that made the compiler wait for every load on the spot.  Here a workgroup
+// has eight waves (two workgroups per CU: FOUR waves per SIMD), the input ring has FIVE row-group slots and the axis-0 result
+// plane is double-buffered, so that one barrier per step is enough:
+//     step s:  A0(s): axis-0 tiles read groups s .. s + 3, results -> plane V[s & 1]
+//              W: the group loaded during step s - 1 (group s + 4) goes into slot (s + 4) % 5 -- the slot of group s - 1, dead
+//                 since barrier s - 1;   loads of group s + 5 are issued and stay in flight for a whole step
+//              barrier s
+//              A1(s): axis-1 tiles read V[s & 1], store the output rows
+//     A0(s + 1) writes the OTHER plane while slower waves still read V[s & 1]; A0(s + 2) reuses V[s & 1] after barrier s + 1,
+//     which every wave reaches only after its A1(s).  W(s + 4) precedes barrier s and is read from A0(s + 1) on.
+// The axis-0 plane is tile-major ([tile][row][16 columns], 256 bytes per tile and byte plane): both its ds_write_b32 (64 lanes
+// -> 64 consecutive dwords) and the axis-1 ds_read_b128 (lane (j, g) -> tile t + g, row j: 1 KiB contiguous per wave) are
+// conflict-free (the row-major plane of the 4-wave kernel, pitch 304, reads 2-way conflicted).
+// Work split: the 304 x 16 samples of a row group are 76 column quads x 4 row quads = 304 lane tasks: waves 0 .. 3 take
+// column quads 16 v + (lane & 15), wave 4 the twelve quads 64 .. 75; the 19 axis-0 tiles go two each to waves 0 .. 4 and three
+// each to waves 5 .. 7 (which load nothing); the 16 axis-1 tiles go pairwise (2 v, 2 v + 1: the permlane16_swap partners).
+// One segment per strip where the frame allows: 256 x 1024 x 1024 -> 1024 workgroups = exactly two rounds of the 512
+// resident ones, 64 steps after a four-group prologue (the 4-wave kernel: 3072 workgroups, four rounds, 22 steps each).
+// Phase stopwatch for scripts/ubench/gauss2d_variants.hip ONLY (-DPL_G2D_TIMING): per wave, s_memtime totals of the four
+// phases of a step (W + load issue, axis 0, barrier wait, axis 1) -> g2d_dbg[workgroup][wave][4].
+#ifndef PL_G2D_TIMING
+#define PL_G2D_TIMING 0
+#endif
+#if PL_G2D_TIMING
+__device__ unsigned long long g2d_dbg[4096 * 8 * 4];
+#define PL_G2D_STAMP(k) do { const long long t_ = clock64(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define PL_G2D_STAMP(k) do { } while (0)
+#endif
+constexpr int kGThreads = 512;
+constexpr int kGWaves = kGThreads / PL_WAVE;
+constexpr int kGSlots = 5;
+constexpr int kGInLo = 0;
+constexpr int kGInHi = kGInLo + kGSlots * kFPlane;
+constexpr int kGVLo = kGInHi + kGSlots * kFPlane;     // two buffers
+constexpr int kGVHi = kGVLo + 2 * kFPlane;            // two buffers
+constexpr int kGLds = kGVHi + 2 * kFPlane;            // 68096 bytes: two workgroups per CU
+
 template <typename T>
-__global__ void __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 48.6 KB of LDS: three workgroups per CU
+__global__ void __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int strips, int segs, int seg_rows, const MmParams P) {
   constexpr bool kSigned = (T)-1 < (T)0;
   constexpr unsigned kHiFlip = kSigned ? 0u : 0x80808080u;     // int16: the signed high byte already is x_hi - 128
-  __shared__ __attribute__((aligned(16))) unsigned char s_mem[kFLds];
+  __shared__ __attribute__((aligned(16))) unsigned char s_mem[kGLds];
 
   unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
   const int ct = id % strips;
@@ -341,34 +379,28 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
   const int nht = (wcols + 15) / 16;                         // axis-1 tiles (the last one may reach beyond the frame)
   const int nvt = nht + 3;                                   // axis-0 tiles the axis-1 windows reach
   const bool ragged = (wcols & 15) != 0;                     // the last tile's stores are cut at the frame's edge
-  // bounded: the look-ahead loads of the last steps may reflect to a negative row when h < 71; those never reach a
-  // tile that is stored, and out of range they read 0 instead of faulting
   const __amdgpu_buffer_rsrc_t src = pl_make_rsrc_bounded(f, (unsigned)h * (unsigned)w * 2u);
-  // the segment's output rows as a bounded buffer: a store whose offset lies beyond it is dropped
   const __amdgpu_buffer_rsrc_t dstb = pl_make_rsrc_bounded(out + (frame * (size_t)h + r_begin) * w, (unsigned)(r_end - r_begin) * (unsigned)w * 2u);
 
-  // ---- who loads what: wave v splits column quads 16 v .. 16 v + 15 (lane & 15) x row quad (lane >> 4) of every row
-  // group; wave 3, which has one axis-0 tile less, also takes the twelve quads 64 .. 75.  A quad lies wholly inside the
-  // frame, wholly outside it (the MIRRORED quad is loaded and its four columns land in reverse) or -- when w % 4 == 2 --
-  // across the right edge: columns w - 2, w - 1 and their reflections w - 1, w - 2 (one dword and its halves swapped).
+  // ---- loader lanes: one column quad (4 columns) x row quad (4 rows) per lane.  A quad lies wholly inside the frame, wholly
+  // outside it (the MIRRORED quad is loaded and its four columns land in reverse) or -- when w % 4 == 2 -- across the right edge
   const int rq = g;
-  struct QuadPlace { unsigned colb; int d0, dstep; bool on, across; };
-  auto place = [&](int cqx, bool on) {
-    const int col0 = c0 - kMmHalo + 4 * cqx;
-    const bool mir = col0 < 0 || col0 >= w;
-    const int mc = col0 < 0 ? -col0 - 4 : (col0 >= w ? 2 * w - 4 - col0 : col0);
-    QuadPlace q;
-    q.across = col0 < w && col0 + 4 > w;
-    q.colb = 2u * (unsigned)mc;
-    q.d0 = 16 * cqx + 4 * rq + (mir ? 3 * kFQuadPitch : 0);
-    q.dstep = mir ? -kFQuadPitch : kFQuadPitch;
-    q.on = on && 4 * cqx < 16 * nvt;
-    return q;
-  };
-  const QuadPlace qa = place(16 * wave + j, true), qb = place(64 + j, wave == 3 && j < 12);
+  const int cqx = wave < 4 ? 16 * wave + j : 64 + j;
+  const bool loader = (wave < 4 || (wave == 4 && j < 12)) && 4 * cqx < 16 * nvt;
+  const int col0 = c0 - kMmHalo + 4 * cqx;
+  const bool mir = col0 < 0 || col0 >= w;
+  const int mc = col0 < 0 ? -col0 - 4 : (col0 >= w ? 2 * w - 4 - col0 : col0);
+  const bool across = col0 < w && col0 + 4 > w;
+  const unsigned colb = 2u * (unsigned)mc;
+  const unsigned colb_ld = across ? colb - 4u : colb;
+  const int qd0 = 16 * cqx + 4 * rq + (mir ? 3 * kFQuadPitch : 0);
+  const int qdstep = mir ? -kFQuadPitch : kFQuadPitch;
   const unsigned wb = 2u * (unsigned)w;
-  auto load_quad = [&](const QuadPlace& q, int k, FQuad& x) {
-    if (!q.on) return;
+  // Loads are UNCONDITIONAL and branch-free (a per-lane branch around a load makes the compiler wait for it on the spot --
+  // vmcnt(0) after every load, four serialised round trips per row group instead of one group in flight for a whole step).
+  // A quad ACROSS the right edge (w % 4 == 2: columns w - 2, w - 1 and their reflections) loads columns w - 4 .. w - 1 -- eight
+  // bytes inside the frame -- and store_quad builds {w - 2, w - 1, w - 1, w - 2} from the upper half.
+  auto load_quad = [&](int k, FQuad& x) {
     const int rbase = r_begin - kMmHalo + 16 * k + 4 * rq;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -376,18 +408,22 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       r ^= r >> 31;                                          // -r - 1 below the frame
       const int r2 = 2 * h - 1 - r;
       r = r < r2 ? r : r2;                                   // 2 h - 1 - r above it (one reflection: h >= 64)
-      if (q.across) {
-        const unsigned d = pl_buffer_load_u32(src, (unsigned)r * wb + q.colb, 0);
-        x.r[i] = uint2{d, __builtin_amdgcn_alignbit(d, d, 16)};
-      } else {
-        x.r[i] = (PL_G2D_VARIANT & 4) ? uint2{((unsigned)r * wb + q.colb) * 2654435761u, ((unsigned)r * wb + q.colb) * 40503u + 12345u} : pl_buffer_load_u64(src, (unsigned)r * wb + q.colb, 0);
-      }
+      x.r[i] = pl_buffer_load_u64(src, loader ? (unsigned)r * wb + colb_ld : 0x80000000u, 0);   // idle lanes: out of range, no traffic
     }
   };
-  auto store_quad = [&](const QuadPlace& q, int k, const FQuad& x) {
-    if (!q.on) return;
-    if ((PL_G2D_VARIANT & 32) && x.r[0].x != 0x12345u) return;
-    unsigned char* base = s_mem + kFInLo + (k % kFSlots) * kFPlane + q.d0;
+  const bool any_across = (w & 3) == 2;            // kernel-uniform: only then can a quad lie across the right edge
+  auto store_quad = [&](int slot, const FQuad& xin) {
+    if (!loader) return;
+    FQuad x = xin;
+    if (any_across) {                              // columns w - 2, w - 1, then their reflections w - 1, w - 2
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned up = xin.r[i].y;
+        x.r[i].x = across ? up : xin.r[i].x;
+        x.r[i].y = across ? __builtin_amdgcn_alignbit(up, up, 16) : up;
+      }
+    }
+    unsigned char* base = s_mem + kGInLo + slot * kFPlane + qd0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const unsigned a0 = half ? x.r[0].y : x.r[0].x, a1 = half ? x.r[1].y : x.r[1].x;
@@ -396,99 +432,90 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
       const unsigned e1 = __builtin_amdgcn_perm(a3, a2, 0x05010400u);
       const unsigned o0 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);   // odd element
       const unsigned o1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
-      unsigned char* pe = base + (2 * half) * q.dstep;
-      unsigned char* po = base + (2 * half + 1) * q.dstep;
+      unsigned char* pe = base + (2 * half) * qdstep;
+      unsigned char* po = base + (2 * half + 1) * qdstep;
       *reinterpret_cast<unsigned*>(pe) = __builtin_amdgcn_perm(e1, e0, 0x05040100u) ^ 0x80808080u;
-      *reinterpret_cast<unsigned*>(pe + (kFInHi - kFInLo)) = __builtin_amdgcn_perm(e1, e0, 0x07060302u) ^ kHiFlip;
+      *reinterpret_cast<unsigned*>(pe + (kGInHi - kGInLo)) = __builtin_amdgcn_perm(e1, e0, 0x07060302u) ^ kHiFlip;
       *reinterpret_cast<unsigned*>(po) = __builtin_amdgcn_perm(o1, o0, 0x05040100u) ^ 0x80808080u;
-      *reinterpret_cast<unsigned*>(po + (kFInHi - kFInLo)) = __builtin_amdgcn_perm(o1, o0, 0x07060302u) ^ kHiFlip;
+      *reinterpret_cast<unsigned*>(po + (kGInHi - kGInLo)) = __builtin_amdgcn_perm(o1, o0, 0x07060302u) ^ kHiFlip;
     }
   };
-  // row groups 0 .. 3 go to LDS now; from then on every step loads the row group the NEXT step needs before its axis-0
-  // tiles and writes it into the freed slot after them (a second group in flight was measured: no gain)
-  {
-    FQuad a[4], b[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { load_quad(qa, k, a[k]); load_quad(qb, k, b[k]); }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { store_quad(qa, k, a[k]); store_quad(qb, k, b[k]); }
-  }
+  // the band operands are vector loads: retire them before anything else is in flight (left pending into the loop, the
+  // compiler's wait-count pass would put vmcnt(0) in front of the first MFMAs of every step)
   v4i band[kMmDigits];
 #pragma unroll
   for (int d = 0; d < kMmDigits; ++d) band[d] = mm_band_operand(P, d, lane);
-  // the band operands are vector loads: retire them HERE -- left pending into the loop, the compiler's wait-count pass puts
-  // vmcnt(0) in front of the first MFMAs of every step, which also waits for the step's own look-ahead loads
   __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0), expcnt / lgkmcnt untouched
-  // the chain's two constants live in eight VGPRs for the whole march (the compiler would otherwise rebuild the quads from
-  // SGPRs in front of every tile)
   MmConst K = mm_const(P);
   asm volatile("" : "+v"(K.c1), "+v"(K.c4));
+  // row groups 0 .. 3 go to LDS now, group 4 stays in flight: step s writes group s + 4 and loads group s + 5
+  FQuad nxt;
+  {
+    FQuad a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_quad(k, a[k]);
+    load_quad(4, nxt);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_quad(k, a[k]);
+  }
   __syncthreads();
 
   const int lane_cell = f_cell(j);                 // cell of column 16 t + j, less the tile's 64 t bytes
   int slot_g = g;                                  // slot of row group s + g
-  // one step: loads of group s + 4; axis 0; barrier; group s + 4 into the slot of group s; axis 1; barrier
+  int wslot = 4;                                   // slot that receives group s + 4
+#if PL_G2D_TIMING
+  long long tacc[4] = {0, 0, 0, 0}, tlast = clock64();
+#endif
   auto step = [&](int s) {
-    FQuad la, lb;
-    load_quad(qa, s + 4, la);
-    load_quad(qb, s + 4, lb);
-    const int vb = 0;                              // the single axis-0 result plane
+    const int vb = (s & 1) * kFPlane;              // this step's axis-0 result plane
     const int lrow = 16 * s + j;                   // the lane's output row inside the segment, both passes
     const bool row_ok = r_begin + lrow < r_end;
 
     // ---- axis 0: image (M = column 16 t + m) x Toeplitz (N = output row): lane (j, g) gets columns 16 t + 4 g .. + 3 of row j
     {
-      const unsigned char* ain = s_mem + kFInLo + slot_g * kFPlane + lane_cell;
-      unsigned char* vout = s_mem + kFVLo + vb + j * kFWin + 4 * g;
-      auto tile_of = [&](int i) { const int t = wave + 4 * i; return t < nvt ? t : 0; };
-      auto run = [&](auto NT) {
+      const unsigned char* ain = s_mem + kGInLo + slot_g * kFPlane + lane_cell;
+      unsigned char* vout = s_mem + kGVLo + vb + 16 * j + 4 * g;     // tile-major plane: + 256 t
+      auto run = [&](auto NT, int t0, int tstep) {
         constexpr int N = decltype(NT)::value;
+        auto tile_of = [&](int i) { const int t = t0 + tstep * i; return t < nvt ? t : 0; };
         unsigned badbits = 0;
-        // the wave's tiles in two lock-step groups (3 + 2 or 2 + 2: register budget of three waves per SIMD)
-        auto group = [&](auto I0, auto NG) {
-          constexpr int i0 = decltype(I0)::value, ng = decltype(NG)::value;
-          v4i lo[ng], hi[ng];
+        v4i lo[N], hi[N];
 #pragma unroll
-          for (int i = 0; i < ng; ++i) {
-            const uint4 qlo = f_ldsq(ain + 64 * tile_of(i0 + i));
-            const uint4 qhi = f_ldsq(ain + 64 * tile_of(i0 + i) + (kFInHi - kFInLo));
-            lo[i] = v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w};
-            hi[i] = v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
-          }
-          MmAcc acc[ng];
-          mm_tiles<true, ng>(lo, hi, band, K, acc);
+        for (int i = 0; i < N; ++i) {
+          const uint4 qlo = f_ldsq(ain + 64 * tile_of(i));
+          const uint4 qhi = f_ldsq(ain + 64 * tile_of(i) + (kGInHi - kGInLo));
+          lo[i] = v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w};
+          hi[i] = v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
+        }
+        MmAcc acc[N];
+        mm_tiles<true, N>(lo, hi, band, K, acc);
 #pragma unroll
-          for (int i = 0; i < ng; ++i) {
-            bool bad;
-            const uint2 res = mm_finish_flag<kSigned>(acc[i], bad);
-            badbits |= (bad && row_ok) ? (1u << (i0 + i)) : 0u;
-            unsigned char* vd = vout + 16 * tile_of(i0 + i);
-            if (!(PL_G2D_VARIANT & 64) || res.x == 0x12345u) {
-              *reinterpret_cast<unsigned*>(vd) = __builtin_amdgcn_perm(res.y, res.x, 0x06040200u) ^ 0x80808080u;
-              *reinterpret_cast<unsigned*>(vd + (kFVHi - kFVLo)) = __builtin_amdgcn_perm(res.y, res.x, 0x07050301u) ^ kHiFlip;
-            }
-          }
-        };
-        group(std::integral_constant<int, 0>{}, std::integral_constant<int, N - 2>{});
-        group(std::integral_constant<int, N - 2>{}, std::integral_constant<int, 2>{});
+        for (int i = 0; i < N; ++i) {
+          bool bad;
+          const uint2 res = mm_finish_flag<kSigned>(acc[i], bad);
+          badbits |= (bad && row_ok) ? (1u << i) : 0u;
+          unsigned char* vd = vout + 256 * tile_of(i);
+          *reinterpret_cast<unsigned*>(vd) = __builtin_amdgcn_perm(res.y, res.x, 0x06040200u) ^ 0x80808080u;
+          *reinterpret_cast<unsigned*>(vd + (kGVHi - kGVLo)) = __builtin_amdgcn_perm(res.y, res.x, 0x07050301u) ^ kHiFlip;
+        }
         if (__ballot(badbits != 0u) == 0ull) return;
         // ---- undecided outputs of the wave's tiles (rare): scipy's float64 sequence from the input plane bytes
         auto sample = [&](int x, int p) {          // window column x, plane row p (0 .. 63) of this step
-          const int a = ((s + (p >> 4)) % kFSlots) * kFPlane + f_cell(x) + (p & 15);
-          return mm_value<kSigned>(s_mem[kFInLo + a], s_mem[kFInHi + a]);
+          const int a = ((s + (p >> 4)) % kGSlots) * kFPlane + f_cell(x) + (p & 15);
+          return mm_value<kSigned>(s_mem[kGInLo + a], s_mem[kGInHi + a]);
         };
 #pragma unroll 1
         for (int i = 0; i < N; ++i) {
           if (__ballot((badbits >> i) & 1u) == 0ull) continue;
           const int t = tile_of(i);
-          unsigned char* vd = vout + 16 * t;
+          unsigned char* vd = vout + 256 * t;
           const uint4 flo = *reinterpret_cast<const uint4*>(ain + 64 * t);
-          const uint4 fhi = *reinterpret_cast<const uint4*>(ain + 64 * t + (kFInHi - kFInLo));
+          const uint4 fhi = *reinterpret_cast<const uint4*>(ain + 64 * t + (kGInHi - kGInLo));
           if (mm_wave_flat(flo, fhi)) {            // constant input under the whole tile: one value for every output
             const double c = sample(16 * t, 0);
             const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int) { return c; }, P));
             *reinterpret_cast<unsigned*>(vd) = (0x01010101u * (v & 255u)) ^ 0x80808080u;
-            *reinterpret_cast<unsigned*>(vd + (kFVHi - kFVLo)) = (0x01010101u * (v >> 8)) ^ kHiFlip;
+            *reinterpret_cast<unsigned*>(vd + (kGVHi - kGVLo)) = (0x01010101u * (v >> 8)) ^ kHiFlip;
           } else {                                 // the tile once more (every lane): WHICH outputs are undecided
             const MmAcc ra = mm_tile<true>(v4i{(int)flo.x, (int)flo.y, (int)flo.z, (int)flo.w}, v4i{(int)fhi.x, (int)fhi.y, (int)fhi.z, (int)fhi.w}, band, K);
             if ((badbits >> i) & 1u) {
@@ -498,85 +525,79 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
                 const int x = 16 * t + 4 * g + q;
                 const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int k) { return sample(x, kMmHalo + j + k); }, P));
                 vd[q] = (unsigned char)((v & 255u) ^ 0x80u);
-                vd[q + (kFVHi - kFVLo)] = (unsigned char)((v >> 8) ^ (kHiFlip & 0x80u));
+                vd[q + (kGVHi - kGVLo)] = (unsigned char)((v >> 8) ^ (kHiFlip & 0x80u));
               }
             }
           }
         }
       };
-      if (wave == 3) run(std::integral_constant<int, 4>{}); else run(std::integral_constant<int, 5>{});
+      // tiles 0 .. 9: waves 0 .. 4 (w, w + 5); tiles 10 .. 18: waves 5 .. 7 (10 + (w - 5), + 3, + 6)
+      if (wave < 5) run(std::integral_constant<int, 2>{}, wave, 5); else run(std::integral_constant<int, 3>{}, 5 + wave, 3);
     }
-    if (!(PL_G2D_VARIANT & 8)) __syncthreads();
-    store_quad(qa, s + 4, la);                     // group s is done with: its slot takes group s + 4
-    store_quad(qb, s + 4, lb);
+    PL_G2D_STAMP(1);
+    // W after the axis-0 tiles: the group loaded during the previous step (s + 4) has had a whole step to arrive, and the
+    // output stores of the previous axis-1 pass, which the in-order vmcnt makes this wait for as well, an axis-0 pass
+    store_quad(wslot, nxt);
+    load_quad(s + 5, nxt);
+    PL_G2D_STAMP(0);
+    __syncthreads();
+    PL_G2D_STAMP(2);
 
     // ---- axis 1: Toeplitz (M = output column) x image (N = row j): lane (j, g) gets columns 16 t + 4 g .. + 3 of row j
     {
-      const unsigned char* bin = s_mem + kFVLo + vb + j * kFWin + 16 * g;
-      // byte offset of the lane's first column inside the segment's output rows; rows beyond the segment: dropped
+      const unsigned char* bin = s_mem + kGVLo + vb + 16 * j + 256 * g;      // tile t + g, row j
       const unsigned doff = row_ok ? ((unsigned)lrow * (unsigned)w + (unsigned)(c0 + 4 * g)) * 2u : 0x80000000u;
-      // after the pair exchange below lane (g1 = g >> 1, g0 = g & 1) holds columns 8 g1 .. 8 g1 + 7 of tile 2 k + g0
       const unsigned doff16 = row_ok ? ((unsigned)lrow * (unsigned)w + (unsigned)(c0 + 8 * (g >> 1))) * 2u : 0x80000000u;
-      // a ragged strip's stores, dword by dword: column pairs at or beyond the frame's right edge go out of range (dropped)
       auto store_cut = [&](unsigned off, int x0, unsigned d0, unsigned d1, unsigned d2, unsigned d3) {
         const unsigned d[4] = {d0, d1, d2, d3};
 #pragma unroll
         for (int k = 0; k < 4; ++k) pl_buffer_store_u32(d[k], dstb, x0 + 2 * k < wcols ? off + 4u * (unsigned)k : 0x80000000u, 0);
       };
-      auto tile_of = [&](int i) { const int t = 4 * wave + i; return t < nht ? t : 0; };
-      constexpr int N = 4;
+      auto tile_of = [&](int i) { const int t = 2 * wave + i; return t < nht ? t : 0; };
+      constexpr int N = 2;
       unsigned badbits = 0;
-      // the MFMA leaves a lane with 4 columns (8 bytes) of a row: stored tile by tile, a row would receive 32-byte pieces.
-      // Tiles 2 k and 2 k + 1 trade halves across lane rows (v_permlane16_swap: row 1 of the first operand <-> row 0 of the
-      // second, row 3 <-> row 2), after which a lane holds 8 consecutive columns of ONE tile and the four lanes of a row
-      // store 64 contiguous bytes.  RAGGED (the strip's width is not a multiple of 16) is a compile-time choice of the whole
-      // pass: a branch inside it would split the straight-line code the tiles' MFMAs are scheduled across.
       auto hpass = [&](auto RAGGED) {
         v4i lo[N], hi[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-          const uint4 qlo = f_ldsq(bin + 16 * tile_of(i));
-          const uint4 qhi = f_ldsq(bin + 16 * tile_of(i) + (kFVHi - kFVLo));
+          const uint4 qlo = f_ldsq(bin + 256 * tile_of(i));
+          const uint4 qhi = f_ldsq(bin + 256 * tile_of(i) + (kGVHi - kGVLo));
           lo[i] = v4i{(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w};
           hi[i] = v4i{(int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
         }
         MmAcc acc[N];
         mm_tiles<false, N>(lo, hi, band, K, acc);
-#pragma unroll
-        for (int i = 0; i < N; i += 2) {
-          bool bad0, bad1;
-          const uint2 r0 = mm_finish_flag<kSigned>(acc[i], bad0), r1 = mm_finish_flag<kSigned>(acc[i + 1], bad1);
-          badbits |= ((bad0 && row_ok) ? (1u << i) : 0u) | ((bad1 && row_ok) ? (2u << i) : 0u);
-          const auto sx = __builtin_amdgcn_permlane16_swap(r0.x, r1.x, false, false);
-          const auto sy = __builtin_amdgcn_permlane16_swap(r0.y, r1.y, false, false);
-          const unsigned tsel = (g & 1) ? (unsigned)tile_of(i + 1) : (unsigned)tile_of(i);
-          const uint4 piece{(unsigned)sx[0], (unsigned)sy[0], (unsigned)sx[1], (unsigned)sy[1]};
-          if (!decltype(RAGGED)::value) {
-            if (!(PL_G2D_VARIANT & 16) || r1.x == 0x12345u) pl_buffer_store_u128(piece, dstb, doff16 + 32u * tsel, 0);
-          } else {
-            store_cut(doff16 + 32u * tsel, 16 * (int)tsel + 8 * (g >> 1), piece.x, piece.y, piece.z, piece.w);
-          }
+        bool bad0, bad1;
+        const uint2 r0 = mm_finish_flag<kSigned>(acc[0], bad0), r1 = mm_finish_flag<kSigned>(acc[1], bad1);
+        badbits |= ((bad0 && row_ok) ? 1u : 0u) | ((bad1 && row_ok) ? 2u : 0u);
+        const auto sx = __builtin_amdgcn_permlane16_swap(r0.x, r1.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(r0.y, r1.y, false, false);
+        const unsigned tsel = (g & 1) ? (unsigned)tile_of(1) : (unsigned)tile_of(0);
+        const uint4 piece{(unsigned)sx[0], (unsigned)sy[0], (unsigned)sx[1], (unsigned)sy[1]};
+        if (!decltype(RAGGED)::value) {
+          pl_buffer_store_u128(piece, dstb, doff16 + 32u * tsel, 0);
+        } else {
+          store_cut(doff16 + 32u * tsel, 16 * (int)tsel + 8 * (g >> 1), piece.x, piece.y, piece.z, piece.w);
         }
       };
       if (ragged) hpass(std::true_type{}); else hpass(std::false_type{});
       if (__ballot(badbits != 0u) != 0ull) {
-        // the fix-up stores below overwrite addresses the pass has just stored from OTHER lanes of this wave (after the
-        // permlane16_swap re-layout): retire those first -- same-address ordering across lanes is not a guarantee
-        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0)
+        // the fix-up stores overwrite addresses the pass has just stored from OTHER lanes of this wave: retire those first
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0) (also retires the look-ahead loads: rare path)
         auto store_cut2 = [&](unsigned off, int x0, unsigned d0, unsigned d1) {   // 4 columns from x0, cut at the edge
           pl_buffer_store_u32(d0, dstb, x0 < wcols ? off : 0x80000000u, 0);
           pl_buffer_store_u32(d1, dstb, x0 + 2 < wcols ? off + 4u : 0x80000000u, 0);
         };
         auto sample = [&](int row, int x) {        // row of the step, window column x
-          const int a = vb + row * kFWin + x;
-          return mm_value<kSigned>(s_mem[kFVLo + a], s_mem[kFVHi + a]);
+          const int a = vb + 256 * (x >> 4) + 16 * row + (x & 15);
+          return mm_value<kSigned>(s_mem[kGVLo + a], s_mem[kGVHi + a]);
         };
 #pragma unroll 1
         for (int i = 0; i < N; ++i) {
           if (__ballot((badbits >> i) & 1u) == 0ull) continue;
           const int t = tile_of(i);
-          const uint4 flo = *reinterpret_cast<const uint4*>(bin + 16 * t);
-          const uint4 fhi = *reinterpret_cast<const uint4*>(bin + 16 * t + (kFVHi - kFVLo));
+          const uint4 flo = *reinterpret_cast<const uint4*>(bin + 256 * t);
+          const uint4 fhi = *reinterpret_cast<const uint4*>(bin + 256 * t + (kGVHi - kGVLo));
           if (mm_wave_flat(flo, fhi)) {
             const double c = sample(0, 16 * t);
             const unsigned v = (unsigned short)pl_from_double<T>(mm_exact([&](int) { return c; }, P));
@@ -598,20 +619,26 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
         }
       }
     }
-    slot_g = slot_g == kFSlots - 1 ? 0 : slot_g + 1;
-    if (!(PL_G2D_VARIANT & 8)) __syncthreads();    // axis-0 plane read, incoming group in place
+    slot_g = slot_g == kGSlots - 1 ? 0 : slot_g + 1;
+    wslot = wslot == kGSlots - 1 ? 0 : wslot + 1;
+    PL_G2D_STAMP(3);
   };
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) step(s);
+#if PL_G2D_TIMING
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int k = 0; k < 4; ++k) g2d_dbg[(blockIdx.x * 8 + wave) * 4 + k] = (unsigned long long)tacc[k];
+#endif
 }
 
+
+// Row segments: a workgroup's cost is its steps plus about three steps' worth of prologue (four row groups, 48 halo rows);
+// take the segment count that minimises rounds x (steps + 3) over the resident workgroups, segments of at least 128 rows.
+// 256 x 1024 x 1024 with the 8-wave kernel (2 per CU): one segment, 1024 workgroups, two full rounds of 64 + 3 steps.
 template <typename T>
 int launch_mm2d_t(const T* in, T* out, int64_t n, int h, int w, const MmParams& P, hipStream_t st) {
   const int strips = (int)pl_cdiv(w, kFCols);
-  // row segments: the chip holds its CUs (256) x 3 workgroups (48.6 KB of LDS each) at a time; a workgroup's cost is its steps
-  // plus about three steps' worth of prologue (four row groups, 48 halo rows).  Take the segment count that minimises
-  // rounds x (steps + 3), segments of at least 128 rows -- 256 x 1024 x 1024: 3 segments, 3072 workgroups, four full rounds
-  const int64_t resident = (int64_t)pl_cu_count() * 3;
+  const int64_t resident = (int64_t)pl_cu_count() * 2;
   const int64_t max_segs = h / 128 > 1 ? h / 128 : 1;
   int64_t segs = 1, best = -1;
   for (int64_t cand = 1; cand <= max_segs; ++cand) {
@@ -624,8 +651,7 @@ int launch_mm2d_t(const T* in, T* out, int64_t n, int h, int w, const MmParams& 
   segs = pl_cdiv(h, seg_rows);
   const int64_t blocks = n * strips * segs;
   if (blocks > 0x7fffffffLL) return -1;
-  hipLaunchKernelGGL(gauss2d_mm<T>, dim3((unsigned)blocks), dim3(kMmThreads), 0, st, in, out, h, w, strips, (int)segs,
-                     seg_rows, P);
+  hipLaunchKernelGGL(gauss2d_mm<T>, dim3((unsigned)blocks), dim3(kGThreads), 0, st, in, out, h, w, strips, (int)segs, seg_rows, P);
   return 0;
 }
 

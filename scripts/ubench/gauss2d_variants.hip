@@ -4,6 +4,8 @@
 //   scripts/build_g2d_variants.sh 0 3 7 ...   ->  scripts/ubench/g2d_v<bits>
 #include "../../pylinac_amd/csrc/gaussian_mm.hip"
 
+#include <time.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -38,13 +40,54 @@ int main(int argc, char** argv) {
   hipEventCreate(&e1);
   for (int it = 0; it < 3; ++it) pl_gauss_mm2d_launch(din, dout, 0, n, h, w, wts, R, 0);
   hipDeviceSynchronize();
-  const int iters = 10;
+  const int iters = argc > 3 ? atoi(argv[3]) : 10;
   hipEventRecord(e0);
   for (int it = 0; it < iters; ++it) pl_gauss_mm2d_launch(din, dout, 0, n, h, w, wts, R, 0);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
+  if (argc > 4) {   // DVFS ramp: after `idle_ms` of idleness, time consecutive groups of 5 launches
+    const int idle_ms = atoi(argv[4]);
+    hipDeviceSynchronize();
+    struct timespec ts = {idle_ms / 1000, (idle_ms % 1000) * 1000000L};
+    nanosleep(&ts, nullptr);
+    std::vector<hipEvent_t> ev(61);
+    for (auto& e : ev) hipEventCreate(&e);
+    hipEventRecord(ev[0]);
+    for (int g = 0; g < 60; ++g) {
+      for (int it = 0; it < 5; ++it) pl_gauss_mm2d_launch(din, dout, 0, n, h, w, wts, R, 0);
+      hipEventRecord(ev[g + 1]);
+    }
+    hipEventSynchronize(ev[60]);
+    printf("ramp after %d ms idle (ms per launch, groups of 5):", idle_ms);
+    for (int g = 0; g < 60; ++g) {
+      float t;
+      hipEventElapsedTime(&t, ev[g], ev[g + 1]);
+      printf(" %.3f", t / 5);
+    }
+    printf("\n");
+  }
+#if PL_G2D_TIMING
+  {
+    std::vector<unsigned long long> dbg(4096 * 8 * 4);
+    hipMemcpyFromSymbol(dbg.data(), HIP_SYMBOL(g2d_dbg), dbg.size() * 8);
+    const int wgs = n * 4 < 4096 ? n * 4 : 4096;
+    const char* names[4] = {"W+load-issue", "axis0", "barrier", "axis1"};
+    for (int wv = 0; wv < 8; ++wv) {
+      printf("  wave %d:", wv);
+      double tot = 0;
+      for (int k = 0; k < 4; ++k) {
+        double a = 0;
+        for (int b = 0; b < wgs; ++b) a += (double)dbg[(b * 8 + wv) * 4 + k];
+        a /= wgs * 64.0;                                       // per step (64 steps per workgroup at 1024 rows)
+        tot += a;
+        printf("  %s %7.0f", names[k], a);
+      }
+      printf("   = %7.0f memtime ticks per step\n", tot);
+    }
+  }
+#endif
   printf("variant %3d: %.4f ms per launch of %d frames, %s data (%s)\n", PL_G2D_VARIANT, ms / iters, n, epid ? "EPID-like" : "ramp+noise",
          hipGetErrorString(hipGetLastError()));
   return 0;

@@ -125,7 +125,9 @@ __global__ void __launch_bounds__(1024) loop(const v4i* src, int* dst, long long
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const int only_waves = argc > 1 ? atoi(argv[1]) : 0;     // run only this many waves per SIMD
+  const int mult = argc > 2 ? atoi(argv[2]) : 1;           // iteration multiplier (sustained-power runs)
   v4i* src;
   int* dst;
   long long* clk;
@@ -136,7 +138,7 @@ int main() {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  const int iters = 9999;
+  const int iters = 9999 * mult;
   std::vector<long long> h(2 * 256 * 16);
   for (int rnd = 0; rnd < 2; ++rnd) {
     std::vector<unsigned char> bytes(128 * 16);
@@ -165,6 +167,7 @@ int main() {
              name, waves, ms * 1e6 / tiles, cyc / tiles, wall, ms * 1e3, cyc / (ms * 1e6));
     };
     for (int wv = 1; wv <= 4; ++wv) {
+      if (only_waves && wv != only_waves) continue;
       run(loop<kM>, wv, "M  9 MFMA", 2);
       run(loop<kV>, wv, "V  44 VALU full-rate", 2);
       run(loop<kI>, wv, "I  interleaved in one wave", 2);
