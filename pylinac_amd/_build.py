@@ -65,7 +65,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         obj = BUILD / (src.stem + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([cc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)])
+            jobs.append([cc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src.name, []), *os.environ.get("PL_EXTRA_HIPCC_FLAGS", "").split(),
+                         "-c", str(src), "-o", str(obj)])
 
     def run(cmd):
         if verbose:

@@ -247,6 +247,9 @@ otsu_kernel(const uint32_t* __restrict__ hist, int bias, int32_t* __restrict__ t
 // row, centred in the window (filtered frames are smooth: the sample misses the true extrema by a few counts, the
 // slack on either side is hundreds to thousands).  A pixel outside the window, or a range wider than the window,
 // sets flag[frame] = 1: the frame is then left to the two-kernel path, launched right behind and gated per frame by that flag.
+#ifndef PL_OTSU_VARIANT
+#define PL_OTSU_VARIANT 0
+#endif
 constexpr int kWinBins = 38912;   // 152 KiB
 
 // MED3: the histogram is that of the 3x3 MEDIAN of the frame (h x w, geometry of pl_median3_rows_covers), computed on the
@@ -311,7 +314,7 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     if (threadIdx.x == 0) flag[frame] = 1;
     return;
   }
-  for (int i = threadIdx.x; i < range; i += kHistThreads) bins[i] = 0;
+  for (int i = threadIdx.x; i <= range; i += kHistThreads) bins[i] = 0;      // + the spare bin at index `range`
   __syncthreads();
 
   int outside = 0;
@@ -324,7 +327,10 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     // every wave walks (column block of 512, row group of 32) items; all 64 lanes take part in the median's cross-lane moves,
     // lanes beyond the frame's width tally nothing
     constexpr int kRows = 32;                        // rows per item: two halo rows are re-read per item
-    unsigned bmax = 0;                               // largest window index seen by this lane (lanes beyond the width: none)
+    const unsigned klo4 = 4u * (unsigned)klo;
+#if PL_OTSU_VARIANT & 1
+    unsigned dummy = 0;
+#endif
     const int col_waves = (w / 8 + PL_WAVE - 1) / PL_WAVE, row_groups = (h + kRows - 1) / kRows;
     for (int item = wv; item < col_waves * row_groups; item += kHistThreads / 64) {
       const int c0 = ((item % col_waves) * PL_WAVE + lane) * 8;
@@ -346,21 +352,27 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
           }
           return;
         }
-        // branch-free tally: a value outside the window lands in the spare bin at index `range` and raises bmax
-        const unsigned cap = on ? (unsigned)range : 0u;
+        // branch-free tally: a value outside the window lands in the spare bin at index `range` (checked after the pass).
+        // Per pixel: extract + scale (x 4: the byte offset of the bin), subtract the window's base, clamp, one LDS atomic
+        const unsigned cap4 = on ? 4u * (unsigned)range : 0u;
+        unsigned char* const base = reinterpret_cast<unsigned char*>(bins);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const unsigned b0 = ((pk[k] & 0xffffu) ^ flip) - (unsigned)klo, b1 = ((pk[k] >> 16) ^ flip) - (unsigned)klo;
+          const unsigned b0 = (((pk[k] & 0xffffu) ^ flip) << 2) - klo4, b1 = (((pk[k] >> 16) ^ flip) << 2) - klo4;
           if (on) {
-            bmax = b0 > bmax ? b0 : bmax;
-            bmax = b1 > bmax ? b1 : bmax;
-            atomicAdd(&bins[b0 < cap ? b0 : cap], 1u);
-            atomicAdd(&bins[b1 < cap ? b1 : cap], 1u);
+#if PL_OTSU_VARIANT & 1    // stopwatch only: everything but the LDS atomics
+            dummy += (b0 < cap4 ? b0 : cap4) ^ (b1 < cap4 ? b1 : cap4);
+#else
+            atomicAdd(reinterpret_cast<unsigned*>(base + (b0 < cap4 ? b0 : cap4)), 1u);
+            atomicAdd(reinterpret_cast<unsigned*>(base + (b1 < cap4 ? b1 : cap4)), 1u);
+#endif
           }
         }
       });
     }
-    if (bmax >= (unsigned)range) outside = 1;
+#if PL_OTSU_VARIANT & 1
+    if (dummy == 0x12345678u) bins[0] = 1;
+#endif
   } else if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const int64_t nvec = count / 8;
     const uint4* vsrc = reinterpret_cast<const uint4*>(src);
@@ -400,6 +412,10 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally(src[i]);
   } else {
     for (int64_t i = threadIdx.x; i < count; i += kHistThreads) tally(src[i]);
+  }
+  if (MED3) {                        // the branch-free tally counts out-of-window pixels in the spare bin
+    __syncthreads();
+    if (bins[range] != 0u) outside = 1;
   }
   if (__syncthreads_or(outside)) {   // a pixel fell outside the window (or outside the caller's bounds): two-kernel path
     if (threadIdx.x == 0) flag[frame] = 1;
