@@ -209,6 +209,17 @@ int pl_field_cax(const void* in, int dtype, int64_t n, int h, int w, const doubl
  * WLBaseImage._clean_edges (pylinac/winston_lutz.py:1109-1133). */
 int pl_edge_minmax(const void* in, int dtype, int64_t n, int h, int w, int window, int32_t* d_min, int32_t* d_max,
                    void* stream);
+/* The scalar decisions WLBaseImage.analyze takes per image, from the frame's exact order statistics, WITHOUT a host round
+ * trip: check_inversion_by_histogram((0.01, 50, 99.99)) (pylinac/core/image.py:899-926), the edge test of _clean_edges
+ * (pylinac/winston_lutz.py:1109-1133: percentiles 5 / 99.5 against the edge strips' extrema), and ground() / normalize() +
+ * the field threshold (p99.9 - p5) / 2 + p5 of find_field_centroids (pylinac/winston_lutz.py:711-712, 775-776), all in numpy's
+ * float64 operation order (np.percentile's _lerp).  d_stats int32[n][16] = min, max, the LOWER order-statistic neighbour of
+ * the percentiles (5, 99.9, 0.01, 50, 99.99, 5, 99.5), then their UPPER neighbours; h_frac[7] (host) = the interpolation
+ * weights of those percentiles (the fractional part of q / 100 * (count - 1)).  Outputs (device): d_inverted / d_noisy
+ * int32[n], d_vmin / d_vmax / d_gmax (= max - min) / d_thr float64[n]. */
+int pl_wl_decisions(const int32_t* d_stats, const int32_t* d_edge_min, const int32_t* d_edge_max, int64_t n,
+                    const double* h_frac, int32_t* d_inverted, int32_t* d_noisy, double* d_vmin, double* d_vmax,
+                    double* d_gmax, double* d_thr, void* stream);
 
 /* ---- a16: CatPhan slice localisation (pylinac/ct.py:381-425, 3315-3348) --------------------------
  * pl_scharr: skimage.filters.scharr(float image) -> float64 edge magnitude.

@@ -79,6 +79,7 @@ SIGNATURES = {
     "pl_scaled_binary": ([_p, _i, _l, _l, _p, _p, _p, _p, _p], C.c_int),
     "pl_field_cax": ([_p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_edge_minmax": ([_p, _i, _l, _i, _i, _i, _p, _p, _p], C.c_int),
+    "pl_wl_decisions": ([_p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_scharr": ([_p, _p, _i, _l, _i, _i, _p], C.c_int),
     "pl_gaussian2d_mode": ([_p, _p, _p, _i, _l, _i, _i, _p, _i, _i, _p], C.c_int),
     "pl_minmax_masked": ([_p, _p, _l, _l, _p, _p, _p], C.c_int),

@@ -594,3 +594,55 @@ extern "C" int pl_edge_minmax(const void* in, int dtype, int64_t n, int h, int w
                        window, d_min, d_max);
   return pl_check_launch("pl_edge_minmax");
 }
+
+
+// ---- the per-frame scalar decisions of WLBaseImage.analyze on the device -----------------------------------------------
+namespace {
+struct WlFrac { double t[7]; };
+
+// numpy's _lerp (np.percentile, method "linear"): a + (b - a) t, and b - (b - a)(1 - t) where t >= 0.5
+__device__ __forceinline__ double wl_lerp(double a, double b, double t) {
+  const double d = b - a;
+  return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+}
+
+__global__ void wl_decisions_kernel(const int32_t* __restrict__ stats, const int32_t* __restrict__ emin, const int32_t* __restrict__ emax,
+                                    int64_t n, WlFrac f, int32_t* __restrict__ inverted, int32_t* __restrict__ noisy,
+                                    double* __restrict__ vmin, double* __restrict__ vmax, double* __restrict__ gmax, double* __restrict__ thr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t* s = stats + i * 16;               // min, max, lower neighbours of the 7 percentiles, upper neighbours
+  const double mn = (double)s[0], mx = (double)s[1];
+  auto pct = [&](int q) { return wl_lerp((double)s[2 + q], (double)s[9 + q], f.t[q]); };
+  // image.py:899-926 check_inversion_by_histogram((0.01, 50, 99.99)): invert when the median sits nearer the top
+  const double p_lo = pct(2), p_mid = pct(3), p_hi = pct(4);
+  inverted[i] = __builtin_fabs(p_mid - p_lo) > __builtin_fabs(p_mid - p_hi) ? 1 : 0;
+  // winston_lutz.py:1109-1133 _clean_edges: an edge strip more than 10 % of the (p5 .. p99.5) range outside it
+  const double e0 = pct(5), e1 = pct(6), rng = e1 - e0;
+  noisy[i] = ((double)emin[i] < e0 - rng / 10.0) || ((double)emax[i] > e1 + rng / 10.0) ? 1 : 0;
+  // winston_lutz.py:711-712, 775-776: ground() / normalize(), then (p99.9 - p5) / 2 + p5 of the float64 frame: the order
+  // statistics pushed through the same float64 operations
+  const double g = mx - mn;
+  const double a0 = ((double)s[2] - mn) / g, b0 = ((double)s[9] - mn) / g;
+  const double a1 = ((double)s[3] - mn) / g, b1 = ((double)s[10] - mn) / g;
+  const double p0 = wl_lerp(a0, b0, f.t[0]), p1 = wl_lerp(a1, b1, f.t[1]);
+  vmin[i] = mn;
+  vmax[i] = mx;
+  gmax[i] = g;
+  thr[i] = (p1 - p0) / 2.0 + p0;
+}
+}  // namespace
+
+extern "C" int pl_wl_decisions(const int32_t* d_stats, const int32_t* d_edge_min, const int32_t* d_edge_max, int64_t n,
+                               const double* h_frac, int32_t* d_inverted, int32_t* d_noisy, double* d_vmin, double* d_vmax,
+                               double* d_gmax, double* d_thr, void* stream) {
+  PL_REQUIRE(d_stats && d_edge_min && d_edge_max && h_frac && d_inverted && d_noisy && d_vmin && d_vmax && d_gmax && d_thr,
+             "null pointer");
+  PL_REQUIRE(n >= 0, "bad shape");
+  if (n == 0) return PL_OK;
+  WlFrac f;
+  for (int k = 0; k < 7; ++k) f.t[k] = h_frac[k];
+  hipLaunchKernelGGL(wl_decisions_kernel, dim3((unsigned)pl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, d_stats,
+                     d_edge_min, d_edge_max, n, f, d_inverted, d_noisy, d_vmin, d_vmax, d_gmax, d_thr);
+  return pl_check_launch("pl_wl_decisions");
+}

@@ -42,14 +42,15 @@ SWEEP_MAX_SIDE = 160      # pl_features_sweep keeps a window of at most 160 x 16
 
 def find_features_batch(samples: torch.Tensor, dpmm: float, radius_mm: float, radius_tolerance_mm: float,
                         max_number: int = 1, min_separation_mm: float = 5, max_labels: int = 4096,
-                        poll_every: int = 8, level_by_level: bool = False):
+                        poll_every: int = 8, level_by_level: bool = False, defer: bool = False):
     """-> dict(xy float64 [N,8,2] (x, y) window coordinates, count int32 [N], level int32 [N],
     status int32 [N]).  ``count < min_number`` is the reference's ValueError("Couldn't find the minimum
     number of disks"); the batch reports it per window instead of raising.
 
     Windows up to 160 x 160 run the whole sweep in one launch (``pl_features_sweep``: one workgroup per window, the
     window resident in LDS); larger windows, and windows the sweep kernel hands back (status 3 / 5: a candidate or a
-    level too large for its tables), take the level-by-level path (``level_by_level=True`` forces it)."""
+    level too large for its tables), take the level-by-level path (``level_by_level=True`` forces it).  ``defer=True``
+    leaves windows with status 3 / 5 to the caller (no host synchronisation here)."""
     s = ops._frames(samples)
     if s.dtype != torch.float64:
         raise TypeError("find_features_batch needs float64 samples")
@@ -67,6 +68,8 @@ def find_features_batch(samples: torch.Tensor, dpmm: float, radius_mm: float, ra
                                     float(min_separation_mm * dpmm), int(max_number), cuts.ctypes.data, len(cuts),
                                     count.data_ptr(), xy.data_ptr(), level.data_ptr(), status.data_ptr(), st),
               "pl_features_sweep")
+        if defer:
+            return dict(xy=xy, count=count, level=level, status=status)
         redo = torch.nonzero((status == 3) | (status == 5)).flatten()
         if redo.numel():                                        # tables too small for these windows: the general path
             sub = _find_features_levels(s[redo].contiguous(), dpmm, radius_mm, radius_tolerance_mm, max_number,
@@ -104,7 +107,7 @@ def _find_features_levels(s: torch.Tensor, dpmm: float, radius_mm: float, radius
 
 def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float, low_density: bool = False,
                        bb_tolerance_mm: float | None = None, vmin: torch.Tensor | None = None,
-                       vmax: torch.Tensor | None = None):
+                       vmax: torch.Tensor | None = None, defer: bool = False):
     """``WLBaseImage.find_bb_centroids`` (pylinac/winston_lutz.py:788-806) for uint16 frames:
     SizedDiskLocator.from_center_physical(expected (0, 0) mm, window (40 + d) mm, radius d/2,
     invert = not low_density) on the ground()/normalize()d frame.  Returns the find_features result
@@ -127,8 +130,9 @@ def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float,
     crop = x.view(torch.int16)[:, top:bottom, left:right].contiguous().view(torch.uint16)
     q = ops.normalize(ops.ground(crop, mn=vmin), vmax - vmin)        # float64 (a - min) / (max - min)
     sample = ops.invert(q) if not low_density else q
-    res = find_features_batch(sample, dpmm, bb_diameter_mm / 2, bb_tolerance_mm)
-    res["xy"] = res["xy"] + torch.tensor([left, top], dtype=torch.float64, device=x.device)
+    res = find_features_batch(sample, dpmm, bb_diameter_mm / 2, bb_tolerance_mm, defer=defer)
+    res["xy"][..., 0] += float(left)                     # (scalar adds: no host-to-device copy, no synchronisation)
+    res["xy"][..., 1] += float(top)
     res["window"] = (top, bottom, left, right)
     return res
 

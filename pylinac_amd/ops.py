@@ -318,12 +318,26 @@ def _percentile_plan(cnt: int, q):
     return qs, lo, hi, virt - lo
 
 
+_RANK_CACHE: dict = {}
+
+
+def _device_ranks(ranks, device) -> torch.Tensor:
+    """the rank list on the device, cached: a blocking host-to-device copy would synchronise the stream on every call"""
+    key = (tuple(int(r) for r in np.asarray(ranks).ravel()), str(device))
+    t = _RANK_CACHE.get(key)
+    if t is None:
+        if len(_RANK_CACHE) > 64:
+            _RANK_CACHE.clear()
+        t = _RANK_CACHE[key] = torch.as_tensor(np.asarray(ranks, dtype=np.int64)).to(device)
+    return t
+
+
 def order_stats(frames: torch.Tensor, ranks, hist=None) -> torch.Tensor:
     """Exact order statistics (0-based ranks) of every 16-bit frame -> int32 [N, len(ranks)] on the
     device (no host synchronisation)."""
     x = _frames(frames)
     n = x.shape[0]
-    r = torch.as_tensor(np.asarray(ranks, dtype=np.int64)).to(x.device)
+    r = _device_ranks(ranks, x.device)
     out = torch.empty((n, r.numel()), dtype=torch.int32, device=x.device)
     hist = histogram16(x) if hist is None else hist
     check(_lib.load().pl_order_stats_from_hist(hist.data_ptr(), _dt(x), n, r.data_ptr(), r.numel(),
@@ -580,10 +594,11 @@ def binary_centroid(mask: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def field_cax(frames: torch.Tensor, sub, div, thr) -> torch.Tensor:
+def field_cax(frames: torch.Tensor, sub, div, thr, defer: bool = False):
     """``center_of_mass(binary_fill_holes(((a - sub) / div) >= thr))`` per frame -> float64 [N,3] = (row, col, count):
     the fused window path (``pl_field_cax``), the general mask -> fill -> centroid path for frames whose foreground
-    bounding box does not fit the LDS window."""
+    bounding box does not fit the LDS window.  ``defer=True`` returns ``(out, status)`` without looking at the status on
+    the host (no synchronisation): the caller redoes the frames whose status is non-zero."""
     x = _frames(frames)
     n, h, w = x.shape
     dev = x.device
@@ -594,11 +609,31 @@ def field_cax(frames: torch.Tensor, sub, div, thr) -> torch.Tensor:
     status = torch.empty(n, dtype=torch.int32, device=dev)
     check(_lib.load().pl_field_cax(x.data_ptr(), _dt(x), n, h, w, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
                                    acc.data_ptr(), out.data_ptr(), status.data_ptr(), _stream()), "pl_field_cax")
+    if defer:
+        return out, status
     redo = torch.nonzero(status).flatten()
     if redo.numel():
         sel = x.view(torch.int16)[redo].view(torch.uint16) if x.dtype == torch.uint16 else x[redo]
         binary = scaled_binary(sel, a[0][redo], a[1][redo], a[2][redo])
         out[redo] = binary_centroid(fill_holes(binary, connectivity_bg=4))
+    return out
+
+
+def wl_decisions(stats: torch.Tensor, edge_min: torch.Tensor, edge_max: torch.Tensor, frac) -> dict:
+    """``pl_wl_decisions``: the inversion check, the edge test and the field threshold of ``WLBaseImage.analyze`` from the
+    order statistics table ``stats`` int32 [N,16] (min, max, lower / upper neighbours of the percentiles 5, 99.9, 0.01, 50,
+    99.99, 5, 99.5), on the device -> dict(inverted, noisy int32 [N]; vmin, vmax, gmax, thr float64 [N])."""
+    n, dev = stats.shape[0], stats.device
+    frac = np.ascontiguousarray(frac, dtype=np.float64)
+    if stats.shape[1] != 16 or frac.size != 7:
+        raise ValueError("stats must be [N,16] and frac must hold 7 weights")
+    i32 = lambda: torch.empty(n, dtype=torch.int32, device=dev)
+    f64 = lambda: torch.empty(n, dtype=torch.float64, device=dev)
+    out = dict(inverted=i32(), noisy=i32(), vmin=f64(), vmax=f64(), gmax=f64(), thr=f64())
+    check(_lib.load().pl_wl_decisions(stats.contiguous().data_ptr(), edge_min.data_ptr(), edge_max.data_ptr(), n, frac.ctypes.data,
+                                      out["inverted"].data_ptr(), out["noisy"].data_ptr(), out["vmin"].data_ptr(),
+                                      out["vmax"].data_ptr(), out["gmax"].data_ptr(), out["thr"].data_ptr(), _stream()),
+          "pl_wl_decisions")
     return out
 
 

@@ -98,6 +98,66 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0
     frame, like the reference's points; status int32 [N]: 0 ok, 1 = no BB found (the reference raises ValueError);
     inverted bool [N]; crop int32 [N] = pixels ``_clean_edges`` removed from every side).
 
+    Round 3: ONE host synchronisation per batch.  Every frame first runs the sequence as if it were neither inverted nor
+    in need of edge cleaning -- one exact histogram + one selection launch serve every percentile, ``pl_wl_decisions`` takes
+    the three scalar decisions on the device, the field CAX and the BB sweep read their thresholds from device arrays --
+    and a single table (records, flags, kernel status words) comes back.  The frames whose flags say otherwise (inverted
+    polarity, dirty edges, a field or BB window too large for a kernel's LDS tables) are then finished by the
+    host-driven sequence ``_analyze_batch_host`` (the round-2 path), exactly as before."""
+    from . import features
+
+    x = ops._frames(frames)
+    if x.dtype != torch.uint16:
+        raise TypeError("analyze_batch needs uint16 frames")
+    n, h, w = x.shape
+    if n == 0:
+        return dict(record=np.zeros((0, 4)), status=np.zeros(0, np.int32), inverted=np.zeros(0, bool), crop=np.zeros(0, np.int32))
+    cnt = h * w
+    qs = _FIELD_Q + _INVERSION_Q + _EDGE_Q
+    _, lo, hi, frac = ops._percentile_plan(cnt, list(qs))
+    hist = ops.histogram16(x)
+    st = ops.order_stats(x, np.concatenate([[0, cnt - 1], lo, hi]), hist=hist)          # int32 [N, 16], on the device
+    del hist
+    emin, emax = ops.edge_minmax(x, 2)
+    dec = ops.wl_decisions(st, emin, emax, frac)
+    cen, cax_status = ops.field_cax(x, dec["vmin"], dec["gmax"], dec["thr"], defer=True)   # (row, col, count)
+    bb = features.bb_centroids_batch(x, dpmm, bb_diameter_mm, low_density=low_density, vmin=dec["vmin"], vmax=dec["vmax"],
+                                     defer=True)
+    f64 = lambda t: t.to(torch.float64)
+    table = torch.stack([cen[:, 1], cen[:, 0], bb["xy"][:, 0, 0], bb["xy"][:, 0, 1], f64(bb["count"]), f64(bb["status"]),
+                         f64(cax_status), f64(dec["inverted"]), f64(dec["noisy"])], dim=1).cpu().numpy()   # the one sync
+    cntb = table[:, 4]
+    record = np.concatenate([table[:, :2], np.where(cntb[:, None] > 0, table[:, 2:4], np.nan)], axis=1)
+    status = (cntb == 0).astype(np.int32)
+    inverted = table[:, 7] != 0
+    crop = np.zeros(n, dtype=np.int32)
+    redo = inverted | (table[:, 6] != 0) | (table[:, 5] == 3) | (table[:, 5] == 5)
+    if clean_edges:
+        redo |= table[:, 8] != 0
+    if redo.any():
+        idx = np.nonzero(redo)[0]
+        sub = x.view(torch.int16)[torch.from_numpy(idx).to(x.device)].view(torch.uint16)
+        r = _analyze_batch_host(sub, dpmm, bb_diameter_mm, low_density, clean_edges)
+        record[idx], status[idx], inverted[idx], crop[idx] = r["record"], r["status"], r["inverted"], r["crop"]
+    return dict(record=record, status=status, inverted=inverted, crop=crop)
+
+
+def _analyze_batch_host(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0, low_density: bool = False,
+                        clean_edges: bool = True):
+    """The host-driven form of ``analyze_batch`` (round 2): every decision is taken on the host from the order-statistics
+    table, which costs a handful of synchronisations per call.  ``analyze_batch`` hands it the frames that leave the common
+    path (inverted polarity, dirty edges, oversized windows).  Same sequence:
+
+        check_inversion_by_histogram((0.01, 50, 99.99))   image.py:899-926
+        _clean_edges()                                     winston_lutz.py:1109-1133
+        ground(); normalize()                              winston_lutz.py:711-712
+        find_field_centroids(is_open_field=False)          winston_lutz.py:764-780
+        find_bb_centroids(bb_diameter_mm, low_density)     winston_lutz.py:788-806
+
+    -> dict(record float64 [N, 4] = (field_x, field_y, bb_x, bb_y) in the coordinates of the (possibly edge-cleaned)
+    frame, like the reference's points; status int32 [N]: 0 ok, 1 = no BB found (the reference raises ValueError);
+    inverted bool [N]; crop int32 [N] = pixels ``_clean_edges`` removed from every side).
+
     One exact histogram and one selection launch per batch serve every percentile the sequence asks for; the decisions
     (three comparisons per frame) are taken on the host from that table, inversion is applied on the device to the
     frames that need it.  A frame whose edges need cleaning changes shape: it is finished on its own (same kernels,
@@ -132,7 +192,7 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0
         for i in np.nonzero(noisy)[0]:
             cleaned = decisions.clean_edges(x[i])                              # the reference's loop, one frame
             crop[i] = (h - cleaned.shape[0]) // 2
-            one = analyze_batch(cleaned[None], dpmm, bb_diameter_mm, low_density, clean_edges=False)
+            one = _analyze_batch_host(cleaned[None], dpmm, bb_diameter_mm, low_density, clean_edges=False)
             record[i], status[i] = one["record"][0], one["status"][0]
             keep[i] = False
     if keep.any():

@@ -12,7 +12,12 @@ dev = torch.device("cuda:0")
 if which == "wl":
     from pylinac_amd import winston_lutz
     from pylinac_amd.synthetic import wl_frames
-    fr = torch.from_numpy(wl_frames(256)).to(dev)
+    fr = torch.from_numpy(wl_frames(512)).to(dev)
+    fn = lambda: winston_lutz.analyze_batch(fr, 1 / 0.336, 5.0)
+elif which == "wln":
+    from pylinac_amd import winston_lutz
+    from pylinac_amd.synthetic import wl_frames
+    fr = torch.from_numpy(wl_frames(256, noise_sigma=0.001)).to(dev)
     fn = lambda: winston_lutz.analyze_batch(fr, 1 / 0.336, 5.0)
 elif which == "pf":
     from pylinac_amd import picketfence
@@ -22,7 +27,7 @@ elif which == "pf":
 elif which == "ctp":
     from pylinac_amd import ct
     from pylinac_amd.synthetic import catphan_volume
-    vols = torch.stack([torch.from_numpy(catphan_volume(4000 + v)) for v in range(2)]).to(dev)
+    vols = torch.stack([torch.from_numpy(catphan_volume(4000 + v)) for v in range(4)]).to(dev)
     fn = lambda: ct.ctp528_batch(vols, 0.5)
 else:
     from pylinac_amd import ct
@@ -42,7 +47,7 @@ for _ in range(3): fn()
 torch.cuda.synchronize()
 print(which, "ms per pass", (time.perf_counter() - t0) / 3 * 1e3, flush=True)
 PY
-for which in wl pf ctp; do
+for which in ${@:-wl wln pf ctp}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$which -o p -- python /tmp/run_cfg.py $which > $OUT/$which.log 2>&1
   grep "ms per pass" $OUT/$which.log
   python - "$OUT/$which" <<'PY'
