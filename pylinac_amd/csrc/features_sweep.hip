@@ -102,6 +102,7 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
   __shared__ double s_red[3][kSwThreads / PL_WAVE];
   __shared__ double s_xy[kSwMaxOut][2];
   __shared__ int s_nout, s_first_level, s_status;
+  __shared__ unsigned long long s_used;
 
   const int64_t img = blockIdx.x;
   const double* smp = sample + img * (int64_t)npx;
@@ -112,7 +113,9 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
   const double larger = pi * ((prm.radius_mm + prm.tol_mm) * (prm.radius_mm + prm.tol_mm));
   double smaller = pi * ((prm.radius_mm - prm.tol_mm) * (prm.radius_mm - prm.tol_mm));
   if (!(smaller > 2.0)) smaller = 2.0;                      // max((pi*(r-t)**2, 2))
-  if (tid == 0) { s_nout = 0; s_first_level = -1; s_status = 0; }
+  if (tid == 0) { s_nout = 0; s_first_level = -1; s_status = 0; s_used = 0ull; }
+  __syncthreads();
+  unsigned long long used = 0ull;
 
   // ---- level map: L(p) = number of cutoffs below the sample (binary search, exact float64 comparisons)
   for (int e = tid; e < npx; e += kSwThreads) {
@@ -123,10 +126,18 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
       if (v > prm.cut[mid]) lo = mid + 1; else hi = mid;
     }
     L[e] = (unsigned char)lo;
+    used |= 1ull << lo;
   }
+  // which values the level map takes: mask_k = {L > k} differs from mask_(k-1) only when some pixel has L == k, and an
+  // unchanged mask yields the same regions -- rejected again, or duplicates of what the earlier level accepted -- so the
+  // reference's loop body is a no-op for that level and it is skipped
+  used = pl_wave_reduce(used, [](unsigned long long a, unsigned long long b) { return a | b; });
+  if (lane == 0) atomicOr(&s_used, used);
   __syncthreads();
+  const unsigned long long level_used = s_used;
 
   for (int level = 0; level < prm.nlevels; ++level) {
+    if (level > 0 && !((level_used >> level) & 1ull)) continue;
     // ---- A. runs per row (lane = row)
     int my_runs = 0;
     if (tid < h) {
@@ -138,14 +149,21 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
         in = fg;
       }
     }
-    if (tid <= kSwMaxSide) row_cnt[tid] = (tid < h) ? my_runs : 0;
-    __syncthreads();
-    // ---- B. exclusive prefix over rows (h <= 160: one lane walks it; the other phases dominate)
-    if (tid == 0) {
-      int acc = 0;
-      for (int r = 0; r <= h; ++r) { const int c = row_cnt[r]; row_cnt[r] = acc; acc += c; }
-      s_nruns = row_cnt[h];
-      s_ncand = 0;
+    // ---- B. exclusive prefix over rows (h <= 160 < 256 lanes): wave scans + the three wave totals
+    {
+      int inc = my_runs;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+      }
+      if (lane == 63 && wv < 4) s_cnt[wv] = inc;
+      __syncthreads();
+      int base = 0;
+      for (int k = 0; k < 4; ++k) base += (k < wv) ? s_cnt[k] : 0;
+      if (tid <= kSwMaxSide) row_cnt[tid] = base + inc - my_runs;     // rows >= h hold the total (my_runs = 0 there)
+      if (tid == 0) s_ncand = 0;
+      if (tid == h) s_nruns = base + inc - my_runs;
     }
     __syncthreads();
     const int nruns = s_nruns;
