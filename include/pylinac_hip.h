@@ -266,7 +266,9 @@ int pl_otsu_from_counts(const uint32_t* d_counts, const double* d_edges, int nbi
                         double* d_thr, double* d_raw, void* stream);
 /* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count] made of whole volumes of
  * slices_per_volume slices: mode 0 = np.max (d_out has the input dtype), mode 1 = np.mean (d_out float64).  The window
- * s-k .. s+k is clamped to the slice's own volume. */
+ * z-k .. z+k indexes the slice's own volume the way the reference indexes its Python list: a negative index wraps around
+ * to the end of the volume; an index beyond the last slice raises IndexError in the reference -- such slices reuse the last
+ * slice here and the caller reports them as invalid. */
 int pl_combine_slices(const void* in, void* d_out, int dtype, int64_t n, int64_t count, int plusminus, int mode,
                       int64_t slices_per_volume, void* stream);
 

@@ -2061,8 +2061,9 @@ def ctp528_slice(volume: np.ndarray, s: int, center_xy, mm_per_pixel: float, rol
     """combine_surrounding_slices(+-3, "max") -> CollapsedCircleProfile(20 radii, +-4 %, 2x sampling, start pi, ccw) ->
     filter(0.001, "gaussian") -> ground -> per region find_peaks / find_valleys -> relative MTF.
     -> (profile float64 [L], rmtf float64 [8] NaN beyond the regions found)."""
-    n = len(volume)
-    arr = np.max(np.dstack([volume[q] for q in range(max(s - 3, 0), min(s + 3, n - 1) + 1)]), 2)
+    # combine_surrounding_slices (pylinac/ct.py:3375-3385): dicomstack[q] for q in range(s - 3, s + 4) -- a negative q wraps
+    # to the end of the stack, q >= len raises IndexError, exactly like indexing the volume array here
+    arr = np.max(np.dstack([volume[q] for q in range(s - 3, s + 4)]), 2)
     radius = 47 / mm_per_pixel
     prof = collapsed_circle_profile(arr, center_xy, radius, start_angle=np.pi + np.deg2rad(roll_deg), ccw=True,
                                     sampling_ratio=2, width_ratio=0.04, num_profiles=20)

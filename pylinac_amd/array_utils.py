@@ -123,13 +123,20 @@ def invert(array):
 
 
 def ground(array, value: float = 0):
-    """array_utils.py:92-102: ``array - array.min() + value``; a non-integral ``value`` promotes an integer array to
-    float64 (numpy's promotion of ``int_array + python_float``)."""
+    """array_utils.py:92-102: ``array - array.min() + value``.  numpy's promotion of ``int_array + value``: a Python
+    ``float`` (any, 0.0 and 1.0 included -- also inf / nan) or a numpy floating scalar turns an integer array into a float
+    array (float64 for Python floats and float64 scalars), a Python ``int`` keeps the array's dtype."""
     _refuse_inexact_64bit(array, "ground")
     s = _Staged(array)
     t = s.t
-    if not t.dtype.is_floating_point and float(value) != int(value):
+    if not t.dtype.is_floating_point and isinstance(value, (float, np.floating)):
         t = ops.normalize(t, 1.0)                                        # exact conversion to float64
+        out = s.out(ops.ground(t, float(value)))
+        if isinstance(value, np.floating) and not isinstance(out, torch.Tensor):
+            want = np.result_type(np.asarray(array).dtype, value)        # e.g. uint8 + float32 scalar -> float32
+            if want != out.dtype:
+                out = out.astype(want)
+        return out
     return s.out(ops.ground(t, value))
 
 

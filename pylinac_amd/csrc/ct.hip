@@ -452,16 +452,26 @@ combine_slices_kernel(const T* __restrict__ in, int64_t n, int64_t per_frame, in
   const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (g >= n * per_frame) return;
   const int64_t s = g / per_frame, p = g % per_frame;
-  const int64_t v0 = (s / per_volume) * per_volume, v1 = v0 + per_volume - 1;   // the slice's own volume
-  const int64_t a = s - k < v0 ? v0 : s - k, b = s + k > v1 ? v1 : s + k;
+  // The reference indexes dicomstack[s] for s in range(z - k, z + k + 1) (pylinac/ct.py:3375-3378): a NEGATIVE index wraps to
+  // the end of the stack (Python list indexing); an index beyond the last slice raises IndexError -- those slices are
+  // reported as invalid by the host layer (ct.ctp528_profiles_batch), here they reuse the last slice so that nothing is
+  // read out of bounds.  Elements are visited in the reference's order (np.dstack order: z - k first).
+  const int64_t v0 = (s / per_volume) * per_volume, z = s - v0;                    // the slice's own volume
+  auto src = [&](int d) {
+    int64_t q = z + d;
+    if (q < 0) q += per_volume;
+    if (q < 0) q = 0;                                                              // k > slices per volume: clamp
+    if (q >= per_volume) q = per_volume - 1;
+    return in[(v0 + q) * per_frame + p];
+  };
   if (mode == 0) {
-    T m = in[a * per_frame + p];
-    for (int64_t q = a + 1; q <= b; ++q) { const T v = in[q * per_frame + p]; m = v > m ? v : m; }
+    T m = src(-k);
+    for (int d = -k + 1; d <= k; ++d) { const T v = src(d); m = v > m ? v : m; }
     out_max[g] = m;
   } else {
     double acc = 0.0;
-    for (int64_t q = a; q <= b; ++q) acc += (double)in[q * per_frame + p];
-    out_mean[g] = acc / (double)(b - a + 1);
+    for (int d = -k; d <= k; ++d) acc += (double)src(d);
+    out_mean[g] = acc / (double)(2 * k + 1);
   }
 }
 

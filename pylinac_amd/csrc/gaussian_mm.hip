@@ -466,6 +466,13 @@ gauss2d_mm(const T* __restrict__ in, T* __restrict__ out, int h, int w, int stri
 #if PL_G2D_TIMING
   long long tacc[4] = {0, 0, 0, 0}, tlast = clock64();
 #endif
+#ifdef PL_G2D_EXP
+  // experiments (stopwatch builds only): de-phase the workgroups that share a CU
+  if (PL_G2D_EXP & 4) { if ((blockIdx.x >> 8) & 1) { __builtin_amdgcn_s_sleep(50); } }
+  if (PL_G2D_EXP & 8) { if (blockIdx.x & 1) { __builtin_amdgcn_s_sleep(50); } }
+  if (PL_G2D_EXP & 16) { if ((blockIdx.x >> 3) & 1) { __builtin_amdgcn_s_sleep(50); } }
+  if (PL_G2D_EXP & 32) { if ((blockIdx.x >> 9) & 1) { __builtin_amdgcn_s_sleep(50); } }
+#endif
   auto step = [&](int s) {
     const int vb = (s & 1) * kFPlane;              // this step's axis-0 result plane
     const int lrow = 16 * s + j;                   // the lane's output row inside the segment, both passes

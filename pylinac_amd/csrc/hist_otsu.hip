@@ -38,16 +38,25 @@ constexpr int kHistThreads = 1024;
 template <int PARTS, bool RUNS>
 __global__ void __launch_bounds__(kHistThreads)
 hist16_kernel(const unsigned short* __restrict__ in, int64_t n, int64_t count, unsigned flip,
-              uint32_t* __restrict__ hist, const int32_t* __restrict__ only /* NULL, or per-frame: run when != 0 */) {
+              uint32_t* __restrict__ hist, const int32_t* __restrict__ only /* NULL, or per-frame: run when != 0 */,
+              unsigned virtual_blocks) {
   constexpr int kBins = 65536 / PARTS;
   constexpr int kShift = PARTS == 4 ? 14 : 15;
   extern __shared__ unsigned bins[];  // kBins
-  // 8 frames x PARTS parts per group; the parts of one frame share blockIdx % 8 (same XCD)
-  const unsigned within = blockIdx.x % (8 * PARTS);
-  const int64_t frame = (int64_t)(blockIdx.x / (8 * PARTS)) * 8 + (within & 7);
+  // gated launches are persistent (see median3_oct_kernel): leave at once when no frame is flagged
+  if (only) {
+    int any = 0;
+    for (int64_t i = threadIdx.x; i < n; i += kHistThreads) any |= only[i];
+    if (!__syncthreads_or(any)) return;
+  }
+  for (unsigned vb = blockIdx.x; vb < virtual_blocks; vb += gridDim.x) {
+  // 8 frames x PARTS parts per group; the parts of one frame share block % 8 (same XCD)
+  const unsigned within = vb % (8 * PARTS);
+  const int64_t frame = (int64_t)(vb / (8 * PARTS)) * 8 + (within & 7);
   const unsigned part = within >> 3;
-  if (frame >= n) return;
-  if (only && !only[frame]) return;
+  if (frame >= n) continue;
+  if (only && !only[frame]) continue;
+  __syncthreads();                                   // the previous virtual block's copy-out is done with the bins
   for (int i = threadIdx.x; i < kBins; i += kHistThreads) bins[i] = 0;
   __syncthreads();
 
@@ -116,6 +125,7 @@ hist16_kernel(const unsigned short* __restrict__ in, int64_t n, int64_t count, u
   __syncthreads();
   uint32_t* dst = hist + frame * 65536 + (size_t)part * kBins;
   for (int i = threadIdx.x; i < kBins; i += kHistThreads) dst[i] = bins[i];
+  }
 }
 
 template <int PARTS, bool RUNS>
@@ -133,8 +143,9 @@ int launch_hist16(const unsigned short* in, int64_t n, int64_t count, unsigned f
   }
   const int64_t blocks = pl_cdiv(n, 8) * 8 * PARTS;
   if (blocks > 0x7fffffffLL) return -1;
-  hipLaunchKernelGGL((hist16_kernel<PARTS, RUNS>), dim3((unsigned)blocks), dim3(kHistThreads), lds, st, in, n, count,
-                     flip, hist, only);
+  const unsigned grid = only ? (unsigned)(blocks < 256 ? blocks : 256) : (unsigned)blocks;
+  hipLaunchKernelGGL((hist16_kernel<PARTS, RUNS>), dim3(grid), dim3(kHistThreads), lds, st, in, n, count,
+                     flip, hist, only, (unsigned)blocks);
   return 0;
 }
 

@@ -175,25 +175,35 @@ median3_pair_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
 // 3x3 median, 16-bit, EIGHT columns per lane (one 16-byte load and one 16-byte store per row): pl_median3_rows
 // (median3_rows.h) does the arithmetic; 0.5 vector-memory instructions per pixel.  gate: optional per-frame flags; a frame
 // whose flag is 0 is skipped (the fused pipeline materialises the median plane only for frames its one-pass Otsu cannot hold).
+// Gated launches (the Otsu fallback of the EPID pipeline) are PERSISTENT: a small fixed grid whose workgroups first look at
+// the whole gate array -- nothing flagged (the common case): every workgroup leaves after one 1 KB read, which costs ~2 us
+// of launch instead of the ~8 us an early-exiting full grid takes to dispatch -- and otherwise loop over the virtual blocks.
 template <typename T, int ROWS>
 __global__ void __launch_bounds__(kThreads)
 median3_oct_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w, int col_waves, int row_groups,
-                   int64_t n_waves, const int32_t* __restrict__ gate) {
+                   int64_t n_waves, const int32_t* __restrict__ gate, int64_t n_frames, unsigned virtual_blocks) {
   const int lane = threadIdx.x & (PL_WAVE - 1);
-  const int64_t gw = (int64_t)pl_xcd_remap(blockIdx.x, gridDim.x) * (kThreads / PL_WAVE) + threadIdx.x / PL_WAVE;
-  if (gw >= n_waves) return;
-  const int cw = (int)(gw % col_waves);
-  const int64_t t = gw / col_waves;
-  const int rg = (int)(t % row_groups);
-  const size_t frame = (size_t)(t / row_groups);
-  if (gate && gate[frame] == 0) return;            // wave-uniform
-  const int c0 = (cw * PL_WAVE + lane) * 8;        // first of the lane's 8 columns
-  const bool active = c0 < w;                      // w % 8 == 0: all 8 inside or none
-  const T* f = in + frame * (size_t)h * w;
-  T* o = out + frame * (size_t)h * w;
-  pl_median3_rows<T, ROWS>(f, h, w, c0, lane, rg * ROWS, [&](int r, const unsigned (&pk)[4]) {
-    if (active) *reinterpret_cast<uint4*>(o + (size_t)r * w + c0) = uint4{pk[0], pk[1], pk[2], pk[3]};
-  });
+  if (gate) {
+    int any = 0;
+    for (int64_t i = threadIdx.x; i < n_frames; i += kThreads) any |= gate[i];
+    if (!__syncthreads_or(any)) return;
+  }
+  for (unsigned vb = blockIdx.x; vb < virtual_blocks; vb += gridDim.x) {
+    const int64_t gw = (int64_t)pl_xcd_remap(vb, virtual_blocks) * (kThreads / PL_WAVE) + threadIdx.x / PL_WAVE;
+    if (gw >= n_waves) continue;
+    const int cw = (int)(gw % col_waves);
+    const int64_t t = gw / col_waves;
+    const int rg = (int)(t % row_groups);
+    const size_t frame = (size_t)(t / row_groups);
+    if (gate && gate[frame] == 0) continue;          // wave-uniform
+    const int c0 = (cw * PL_WAVE + lane) * 8;        // first of the lane's 8 columns
+    const bool active = c0 < w;                      // w % 8 == 0: all 8 inside or none
+    const T* f = in + frame * (size_t)h * w;
+    T* o = out + frame * (size_t)h * w;
+    pl_median3_rows<T, ROWS>(f, h, w, c0, lane, rg * ROWS, [&](int r, const unsigned (&pk)[4]) {
+      if (active) *reinterpret_cast<uint4*>(o + (size_t)r * w + c0) = uint4{pk[0], pk[1], pk[2], pk[3]};
+    });
+  }
 }
 
 // --------------------------------------------------------------------- general size (LDS tile)
@@ -253,8 +263,9 @@ int median_t(const T* in, T* out, int64_t n, int h, int w, int size, hipStream_t
       const int64_t n_waves = n * col_waves * row_groups;
       const int64_t blocks = pl_cdiv(n_waves, kThreads / PL_WAVE);
       if (blocks > 0x7fffffffLL) { pl_set_error("pl_median2d: batch too large"); return PL_ERR_INVALID_ARG; }
-      hipLaunchKernelGGL((median3_oct_kernel<T, ROWS>), dim3((unsigned)blocks), dim3(kThreads), 0, st, in, out, h, w,
-                         col_waves, row_groups, n_waves, gate);
+      const unsigned grid = gate ? (unsigned)(blocks < 512 ? blocks : 512) : (unsigned)blocks;
+      hipLaunchKernelGGL((median3_oct_kernel<T, ROWS>), dim3(grid), dim3(kThreads), 0, st, in, out, h, w,
+                         col_waves, row_groups, n_waves, gate, n, (unsigned)blocks);
       return pl_check_launch("pl_median2d");
     }
     if (size == 3 && h > 1 && w >= 4 && (w & 1) == 0 && ((reinterpret_cast<uintptr_t>(in) & 3) == 0) &&

@@ -278,6 +278,12 @@ def ctp528_profiles_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx, fit
     prof = ops.gaussian_filter1d(prof, sigma, axis=-1)
     mn, _ = ops.minmax(prof[:, None, :])
     prof = ops.ground(prof[:, None, :].contiguous(), mn=mn)[:, 0, :].contiguous()
+    # combine_surrounding_slices indexes dicomstack[z - k .. z + k] (ct.py:3375-3378): negative indices wrap around to the end
+    # of the stack (reproduced by pl_combine_slices), indices past the last slice raise IndexError in the reference -- those
+    # slices get a NaN profile here (-> no regions, NaN rMTF downstream)
+    beyond = torch.from_numpy(z + slices_plusminus >= spv).to(prof.device)
+    if bool((z + slices_plusminus >= spv).any()):
+        prof = torch.where(beyond[:, None], torch.full_like(prof, float("nan")), prof)
     return prof, idx
 
 

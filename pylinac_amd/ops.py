@@ -757,8 +757,9 @@ def otsu_float_masked(frames: torch.Tensor, mask: torch.Tensor | None, scale: fl
 
 def combine_slices(stack: torch.Tensor, plusminus: int, mode: str = "max", slices_per_volume: int | None = None) -> torch.Tensor:
     """``combine_surrounding_slices`` (pylinac/ct.py:3351-3386) for every slice of ``stack`` [S, H, W]: "max" keeps the
-    dtype, "mean" gives float64; the window is clamped to the slice's own volume (``slices_per_volume`` consecutive
-    slices; default: the whole stack is one volume)."""
+    dtype, "mean" gives float64; the window z - k .. z + k indexes the slice's own volume (``slices_per_volume``
+    consecutive slices; default: the whole stack is one volume) like the reference's Python list: negative indices wrap
+    around, slices whose window passes the end of the volume (IndexError in the reference) are for the caller to discard."""
     x = _frames(stack)
     if mode not in ("max", "mean"):
         raise ValueError("mode must be 'max' or 'mean'")

@@ -25,7 +25,8 @@ int main(int argc, char** argv) {
     s = s * 1664525u + 1013904223u;
     const size_t y = (i / w) % h, x = i % w;
     const bool in_field = y > 214 && y < 810 && x > 214 && x < 810;
-    host[i] = epid ? (unsigned short)((in_field ? 39600 : 1600) + (s >> 22) * 800 / 1024)
+    host[i] = epid == 2 ? (unsigned short)(1000 + ((s >> 22) & 3))          // low-toggle data: the power-cap probe
+            : epid ? (unsigned short)((in_field ? 39600 : 1600) + (s >> 22) * 800 / 1024)
                    : (unsigned short)(20000 + y * 10 + (s >> 22));             // ramp + noise
   }
   double wts[2 * 20 + 1], sum = 0;
@@ -88,7 +89,7 @@ int main(int argc, char** argv) {
     }
   }
 #endif
-  printf("variant %3d: %.4f ms per launch of %d frames, %s data (%s)\n", PL_G2D_VARIANT, ms / iters, n, epid ? "EPID-like" : "ramp+noise",
+  printf("variant %3d: %.4f ms per launch of %d frames, %s data (%s)\n", PL_G2D_VARIANT, ms / iters, n, epid == 2 ? "low-toggle (1000 + 2 random bits)" : epid ? "EPID-like" : "ramp+noise",
          hipGetErrorString(hipGetLastError()));
   return 0;
 }

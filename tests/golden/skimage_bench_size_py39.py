@@ -69,7 +69,15 @@ elif kind == "ct":
                                _phantom_center_func=None, num_images=n)
     fit_zx, fit_zy = ct.CatPhanBase.find_phantom_axis(cp)
     out["fit_zx"], out["fit_zy"] = np.asarray(fit_zx.coeffs, float), np.asarray(fit_zy.coeffs, float)
-    slices = list(range(3, n - 3))
+    # slices 0 .. 2: combine_surrounding_slices indexes dicomstack[-3 .. -1] there, which WRAPS to the end of the stack;
+    # slices n - 3 .. n - 1 raise IndexError in the reference (checked below) and have no golden rows
+    slices = list(range(0, n - 3))
+    for s in range(n - 3, n):
+        try:
+            ct.combine_surrounding_slices(dstack, s, slices_plusminus=3, mode="max")
+            raise SystemExit("the reference combined a window that passes the end of the stack")
+        except IndexError:
+            pass
     profiles, rmtf, nregions, maxs_all, mins_all = [], [], [], [], []
     for s in slices:
         m = object.__new__(ct.CTP528CP504)

@@ -119,6 +119,10 @@ def test_ctp528_80x512x512_volume_vs_reference_and_oracle(golden, dev):
     rows = g["ct.profile_rows"]
     prof = full["profiles"].cpu().numpy()
     assert np.allclose(prof[sl[rows]], g["ct.profiles"], rtol=0, atol=1e-9)
+    # the ends of the stack: slices 0 .. 2 combine with the LAST slices (Python's negative indices; part of `sl`), the last
+    # three slices raise IndexError in the reference: NaN profile, no regions, NaN rMTF here
+    assert sl[0] == 0 and sl[-1] == 76
+    assert np.isnan(prof[77:]).all() and (full["nregions"][77:] == 0).all() and np.isnan(full["rmtf"][77:]).all()
     # the oracle's per-slice sequence about the same fitted centres
     for s in (10, 44, 70):
         p, rmtf = o.ctp528_slice(vol, s, tuple(full["center"][s]), 0.5)

@@ -1772,6 +1772,20 @@ def test_large_rois_stream(dev):
     checks.check_large_rois(dev)
 
 
+def test_ground_promotes_like_numpy(dev):
+    """array_utils.ground (pylinac/core/array_utils.py:92-102 = ``array - array.min() + value``): numpy's result dtype for
+    every kind of ``value`` (a Python float 0.0 / 1.0 promotes an integer array too; inf / nan do not raise)."""
+    from pylinac_amd import array_utils as au
+
+    a = np.array([[5, 9, 7], [6, 5, 8]], dtype=np.uint16)
+    for value in (0, 3, 0.0, 1.0, 2.5, np.float64(1.0), np.float32(1.5), float("inf")):
+        want = a - a.min() + value
+        got = au.ground(a, value)
+        assert got.dtype == want.dtype and np.array_equal(got, want), (value, got.dtype, want.dtype)
+    f = np.array([1.5, -2.0, 4.0])
+    assert np.array_equal(au.ground(f, 1), f - f.min() + 1)
+
+
 def test_bench_line_contract(dev):
     """bench.py prints ONE JSON line with the driver's keys: metric / value / unit / n_gpus / steps / warmup / ms_per_step /
     higher_is_better / scaling / vs_baseline / dtype / data / config.workload, the roofline object of the dominant kernel
