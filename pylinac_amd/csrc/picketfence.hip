@@ -129,18 +129,34 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   }
   const unsigned short* f = in + frame * (size_t)h * w;
   unsigned short* sw = s_win[wv];
-  // the window into LDS, its maximum on the way (element e = lane, lane + 64, ..: row / column advance by carry, no division)
+  // the window into LDS, its maximum on the way (element e = lane, lane + 64, ..: row / column advance by carry, no division).
+  // EIGHT loads are issued before the first of them is consumed: one load per trip made the wave pay the full memory
+  // latency for every 64 pixels (eight dependent round trips for a 12 x 38 window)
   int vmax = 0;
   {
     int r = lane / ncols, c = lane - r * ncols;
     const int dr = PL_WAVE / ncols, dc = PL_WAVE - dr * ncols;
-    for (int e = lane; e < nrows * ncols; e += PL_WAVE) {
-      const unsigned short v = f[(size_t)(top + r) * w + left + c];
-      sw[e] = v;
-      vmax = max(vmax, (int)v);
-      r += dr;
-      c += dc;
-      if (c >= ncols) { c -= ncols; ++r; }
+    const int total = nrows * ncols;
+    for (int e0 = lane; e0 < total + lane; e0 += 8 * PL_WAVE) {      // wave-uniform trip count
+      unsigned short v[8];
+      int rr = r, cc = c;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool in_win = e0 + k * PL_WAVE < total;
+        v[k] = in_win ? f[(size_t)(top + rr) * w + left + cc] : (unsigned short)0;
+        rr += dr;
+        cc += dc;
+        if (cc >= ncols) { cc -= ncols; ++rr; }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (e0 + k * PL_WAVE < total) {
+          sw[e0 + k * PL_WAVE] = v[k];
+          vmax = max(vmax, (int)v[k]);
+        }
+      }
+      r = rr;
+      c = cc;
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -207,9 +223,14 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   const bool not_edge = smax < edge_threshold * med;
   if (!(above && not_edge)) status = 2;
 
-  // np.median(window, axis=0): lane c (and c+64) selects the middle order statistic(s) of its column
-  double* pv = pout;
-  for (int c = lane; c < ncols; c += PL_WAVE) {
+  // np.median(window, axis=0): lane c (and c+64) selects the middle order statistic(s) of its column; the profile stays in
+  // registers (ncols <= 128: two columns per lane) through ground() and normalize() and is stored once -- round 2 wrote it
+  // to global memory and read it back three times, each a full store -> load round trip
+  double pvr[2] = {0.0, 0.0};
+#pragma unroll
+  for (int slot = 0; slot < 2; ++slot) {
+    const int c = lane + slot * PL_WAVE;
+    if (c >= ncols) continue;
     const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
     int v_lo = 0, v_hi = 0;
     if (nrows <= 16) {                               // wave-uniform; the usual leaf height: the column lives in registers
@@ -237,18 +258,20 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
       }
     }
     const double qh = ((double)v_hi - s) / d;
-    pv[c] = (nrows & 1) ? qh : ((((double)v_lo - s) / d) + qh) / 2.0;
+    pvr[slot] = (nrows & 1) ? qh : ((((double)v_lo - s) / d) + qh) / 2.0;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
   // ground (values - min) then normalize (/ max of the grounded profile)
+  const bool has0 = lane < ncols, has1 = lane + PL_WAVE < ncols;
   double mn = __longlong_as_double(0x7ff0000000000000LL);
-  for (int c = lane; c < ncols; c += PL_WAVE) mn = pv[c] < mn ? pv[c] : mn;
+  if (has0) mn = pvr[0] < mn ? pvr[0] : mn;
+  if (has1) mn = pvr[1] < mn ? pvr[1] : mn;
   mn = pl_wave_reduce(mn, [](double a, double b) { return a < b ? a : b; });
   double mx = __longlong_as_double((long long)0xfff0000000000000ULL);
-  for (int c = lane; c < ncols; c += PL_WAVE) { const double g = pv[c] - mn; mx = g > mx ? g : mx; }
+  if (has0) { const double g = pvr[0] - mn; mx = g > mx ? g : mx; }
+  if (has1) { const double g = pvr[1] - mn; mx = g > mx ? g : mx; }
   mx = pl_wave_reduce(mx, [](double a, double b) { return a > b ? a : b; });
-  for (int c = lane; c < ncols; c += PL_WAVE) pv[c] = (pv[c] - mn) / mx;
+  if (has0) pout[lane] = (pvr[0] - mn) / mx;
+  if (has1) pout[lane + PL_WAVE] = (pvr[1] - mn) / mx;
   if (lane == 0) { status_out[win] = status; len_out[win] = ncols; offset_out[win] = off; }
 }
 
