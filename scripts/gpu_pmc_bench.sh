@@ -8,7 +8,7 @@ SETS=("GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_A
 i=0
 for set in "${SETS[@]}"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python bench.py --no-cpu-baseline --no-configs --no-parity --steps 4 --warmup 2 > $OUT/p$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python bench.py --no-cpu-baseline --no-configs --no-parity --steps 4 --warmup 2 --sustained-steps 0 > $OUT/p$i.log 2>&1
 done
 python3 - $OUT <<'PY'
 import csv, glob, collections, sys, re

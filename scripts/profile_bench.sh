@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs > $OUT/bench_trace.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-parity --sustained-steps 0 > $OUT/bench_trace.log 2>&1
 find $OUT -type f -exec ls -la {} \;
 # keep the per-dispatch traces small: the summaries are what gets committed
 python scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
