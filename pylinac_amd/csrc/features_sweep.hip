@@ -25,6 +25,17 @@
 // Results are identical to features.hip's level-by-level path (tests run both on the same windows).
 #include "pl_common.h"
 
+// Phase stopwatch (-DPL_SWEEP_TIMING, development builds only): per-workgroup s_memtime totals of the level loop's phases.
+#ifndef PL_SWEEP_TIMING
+#define PL_SWEEP_TIMING 0
+#endif
+#if PL_SWEEP_TIMING
+__device__ unsigned long long pl_sweep_dbg[8];
+#define SW_STAMP(k) do { if (tid == 0) { const long long t_ = clock64(); tacc[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define SW_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kSwThreads = 256;
@@ -136,8 +147,12 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
   __syncthreads();
   const unsigned long long level_used = s_used;
 
+#if PL_SWEEP_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
   for (int level = 0; level < prm.nlevels; ++level) {
     if (level > 0 && !((level_used >> level) & 1ull)) continue;
+    SW_STAMP(7);
     // ---- A. runs per row (lane = row)
     int my_runs = 0;
     if (tid < h) {
@@ -233,6 +248,7 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
       if (slot < 32) s_cand[slot] = id;
     }
     __syncthreads();
+    SW_STAMP(0);                                              // runs, merge, flatten, region table, candidate screen
     int ncand = s_ncand;
     if (ncand > 32) { ncand = 32; if (tid == 0) s_status = 2; }
     if (tid == 0)                                             // label order = raster order of the first pixel = root id order
@@ -258,6 +274,7 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
         }
       }
       __syncthreads();
+      SW_STAMP(1);                                            // crop mask
       // ---- filled_area: non-region pixels reachable (8-conn) from the crop border are NOT holes
       for (int e = tid; e < cpx; e += kSwThreads) {
         const int r = e / cw, c = e % cw;
@@ -284,6 +301,7 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
         }
         if (!__syncthreads_or(changed)) break;
       }
+      SW_STAMP(2);                                            // flood fill
       if (tid < 4) s_cnt[tid] = 0;
       __syncthreads();
       // ---- holes, perimeter codes, weighted moments
@@ -313,7 +331,72 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
         atomicAdd(&s_cnt[0], holes); atomicAdd(&s_cnt[1], n1); atomicAdd(&s_cnt[2], n2); atomicAdd(&s_cnt[3], n3);
         s_red[0][wv] = w0; s_red[1][wv] = wr; s_red[2][wv] = wc;
       }
-      // ---- convex hull candidates: mid-edge points of the row-extreme pixels
+      SW_STAMP(3);                                            // holes, perimeter, moments
+      // ---- convex hull of the pixels' mid-edge points (the "diamond" hull skimage's convex_hull_image builds).
+      // Only the row-extreme pixels matter, and of their points only, for every doubled abscissa X = 2 r - 1 .. 2 r + 1, the
+      // lowest and the highest ordinate: X even (= 2 r): 2 cl - 1 and 2 cr + 1; X odd (between rows r and r + 1): min of the two
+      // rows' 2 cl, max of their 2 cr.  That is at most 2 (2 ch + 1) points ALREADY SORTED by X.  Round 2 sorted eight points per
+      // row by insertion and ran Andrew's chains on ONE lane: 73 % of this kernel's time (phase stopwatch, -DPL_SWEEP_TIMING).
+      // Now one wave prunes each chain in parallel: a point whose turn (previous alive, itself, next alive) is not strictly
+      // counter-clockwise lies on or inside the chord of two other points and is no hull vertex -- all such points go at once,
+      // until none is left: the same strictly convex polygon as the sequential chains, a handful of rounds.
+      const int nx = 2 * ch + 1;
+      if (nx <= 63) {                                       // wave-uniform: the usual BB blob (ch <= 31 rows)
+        for (int r = tid; r < ch; r += kSwThreads) {
+          int cl = -1, cr = -1;
+          for (int c = 0; c < cw; ++c) if (m[r * cw + c]) { if (cl < 0) cl = c; cr = c; }
+          s_hx[r] = cl; s_hy[r] = cr;                       // (a connected region has a pixel in every row of its bbox)
+        }
+        __syncthreads();
+        if (wv == 0) {
+          const int big = 0x3fffffff;
+          int ymin = big, ymax = -big;
+          if (lane < nx) {
+            if (lane & 1) {                                 // X = lane - 1 even = 2 r
+              const int r = (lane - 1) >> 1;
+              if (s_hx[r] >= 0) { ymin = 2 * s_hx[r] - 1; ymax = 2 * s_hy[r] + 1; }
+            } else {                                        // X odd: between rows r and r + 1
+              const int r = (lane >> 1) - 1;
+              if (r >= 0 && s_hx[r] >= 0) { ymin = 2 * s_hx[r]; ymax = 2 * s_hy[r]; }
+              if (r + 1 < ch && s_hx[r + 1] >= 0) {
+                ymin = ymin < 2 * s_hx[r + 1] ? ymin : 2 * s_hx[r + 1];
+                ymax = ymax > 2 * s_hy[r + 1] ? ymax : 2 * s_hy[r + 1];
+              }
+            }
+          }
+          // chain q = 0: lower (X ascending, lowest ordinates, then the last abscissa's highest); q = 1: upper (X descending,
+          // highest ordinates, then the first abscissa's lowest): nx + 1 points each
+          int nh = 0;
+#pragma unroll 1
+          for (int q = 0; q < 2; ++q) {
+            const int src = q == 0 ? (lane < nx ? lane : nx - 1) : (lane < nx ? nx - 1 - lane : 0);
+            const int ylo = __shfl(ymin, src, 64), yhi = __shfl(ymax, src, 64);
+            const int X = src - 1;
+            const int Y = q == 0 ? (lane < nx ? ylo : yhi) : (lane < nx ? yhi : ylo);
+            const int npts = nx + 1;
+            unsigned long long alive = npts >= 64 ? ~0ull : (1ull << npts) - 1ull;
+            for (;;) {
+              const unsigned long long below = alive & ((1ull << lane) - 1ull);
+              const unsigned long long above = lane >= 63 ? 0ull : (alive & ~((2ull << lane) - 1ull));
+              const int pi = below ? 63 - __builtin_clzll(below) : 0, ni = above ? __builtin_ctzll(above) : 0;
+              const int xp = __shfl(X, pi, 64), yp = __shfl(Y, pi, 64), xn = __shfl(X, ni, 64), yn = __shfl(Y, ni, 64);
+              const bool interior = ((alive >> lane) & 1ull) && below && above;
+              const unsigned long long gone = __ballot(interior && sw_cross2(xp, yp, X, Y, xn, yn) <= 0);
+              if (!gone) break;
+              alive &= ~gone;
+            }
+            // the chain's vertices without its last point (= the first point of the other chain)
+            const unsigned long long keep = alive & ~(1ull << (npts - 1));
+            if ((keep >> lane) & 1ull) {
+              const int at = nh + __popcll(keep & ((1ull << lane) - 1ull));
+              s_hull_x[at] = X; s_hull_y[at] = Y;
+            }
+            nh += __popcll(keep);
+          }
+          if (lane == 0) { s_nh = nh; s_inside = 0; }
+        }
+      } else {
+      // tall crops: the sequential form (eight points per row, sorted, Andrew's chains on one lane)
       for (int r = tid; r < ch; r += kSwThreads) {
         int cl = -1, cr = -1;
         for (int c = 0; c < cw; ++c) if (m[r * cw + c]) { if (cl < 0) cl = c; cr = c; }
@@ -357,7 +440,9 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
         s_nh = kk - 1;                          // last point == first point
         s_inside = 0;
       }
+      }
       __syncthreads();
+      SW_STAMP(4);                                            // hull
       const int nh = s_nh;
       int inside = 0;
       for (int e = tid; e < cpx; e += kSwThreads) {
@@ -372,6 +457,7 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
       inside = pl_wave_reduce(inside, addi);
       if (lane == 0) atomicAdd(&s_inside, inside);
       __syncthreads();
+      SW_STAMP(5);                                            // pixels inside the hull
       // ---- predicates (pylinac/metrics/features.py) and output
       if (tid == 0) {
         const double filled = area + (double)s_cnt[0];
@@ -413,6 +499,9 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
     if (s_nout >= prm.max_number) break;                     // while ... len(total_features) < max_number
   }
   __syncthreads();
+#if PL_SWEEP_TIMING
+  if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&pl_sweep_dbg[k], (unsigned long long)tacc[k]);
+#endif
   if (tid == 0) {
     out_count[img] = s_nout;
     out_level[img] = s_first_level;
@@ -458,3 +547,9 @@ extern "C" int pl_features_sweep(const double* d_sample, int64_t n, int h, int w
                      d_count, d_xy, d_level, d_status);
   return pl_check_launch("pl_features_sweep");
 }
+
+#if PL_SWEEP_TIMING
+extern "C" int pl_debug_sweep_timing(unsigned long long* h_out) {
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(pl_sweep_dbg), sizeof(pl_sweep_dbg)) == hipSuccess ? 0 : 1;
+}
+#endif
