@@ -298,6 +298,17 @@ int pl_features_level(const double* d_sample, const int32_t* d_labels, const int
 int pl_features_sweep(const double* d_sample, int64_t n, int h, int w, double dpmm, double radius_mm, double tol_mm,
                       double min_sep_px, int max_number, const double* h_cutoffs, int nlevels, int32_t* d_count,
                       double* d_xy, int32_t* d_level, int32_t* d_status, void* stream);
+/* The same sweep straight from uint16 FRAMES: the window [top, top + h) x [left, left + w) of every frame, whose sample
+ * SizedDiskRegion.calculate builds as stretch(invert((a - frame min) / (frame max - frame min))) (pylinac/winston_lutz.py:
+ * 711-712, 788-806; pylinac/metrics/image.py:564-612; pylinac/metrics/utils.py:112-118).  Every map of that chain is monotone,
+ * so the workgroup evaluates it per pixel from the window's integer extrema with the float64 operations of pl_ground /
+ * pl_normalize / pl_invert / pl_scale in their order: bit-identical samples without nine float64 passes over the windows.
+ * d_vmin / d_vmax float64[n]: the FRAME's min / max (ground() / normalize() act on the whole image); invert = 0 for
+ * low-density BBs. */
+int pl_features_sweep_u16(const uint16_t* d_frames, int64_t n, int frame_h, int frame_w, int top, int left, int h, int w,
+                          const double* d_vmin, const double* d_vmax, int invert, double dpmm, double radius_mm, double tol_mm,
+                          double min_sep_px, int max_number, const double* h_cutoffs, int nlevels, int32_t* d_count,
+                          double* d_xy, int32_t* d_level, int32_t* d_status, void* stream);
 
 /* ---- a13 (fields): one threshold level of GlobalSizedFieldLocator.calculate (pylinac/metrics/image.py:817-897)
  * Inputs per frame: the 8-connected label image of `sample > cutoff` (pl_label), its label count and region

@@ -94,6 +94,8 @@ SIGNATURES = {
     "pl_combine_slices": ([_p, _p, _i, _l, _l, _i, _i, _l, _p], C.c_int),
     "pl_features_level": ([_p, _p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_features_sweep": ([_p, _l, _i, _i, _d, _d, _d, _d, _i, _p, _i, _p, _p, _p, _p, _p], C.c_int),
+    "pl_features_sweep_u16": ([_p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _i, _d, _d, _d, _d, _i, _p, _i, _p, _p, _p, _p, _p],
+                              C.c_int),
     "pl_fields_level": ([_p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_roi_stats": ([_p, _i, _l, _i, _i, _p, _i, _l, _i, _p, _p, _p], C.c_int),
     "pl_polygon_roi_stats": ([_p, _i, _l, _i, _i, _p, _i, _i, _l, _p, _p, _p], C.c_int),

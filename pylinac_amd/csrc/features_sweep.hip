@@ -85,8 +85,25 @@ __device__ __forceinline__ void sw_unite(unsigned* parent, unsigned a, unsigned 
   } while (!done);
 }
 
+// Where the window's samples come from: `sample` (float64 windows, already stretched), or -- f16 != nullptr -- straight from the
+// uint16 frames: the sample of SizedDiskRegion.calculate / find_features (pylinac/metrics/image.py:564-612,
+// pylinac/metrics/utils.py:112-118) is a chain of MONOTONE float64 maps of the integer pixel,
+//   q = (a - frame min) / (frame max - frame min)          BaseImage.ground() / normalize(), winston_lutz.py:711-712
+//   s = (-q + max q) + min q   over the window (invert)     metrics/image.py:600-607  (low-density BBs: s = q)
+//   stretch(s, 0, 1) = ground(normalize(ground(s)) * 1)     metrics/utils.py:118, array_utils.py:141-168
+// so every extremum the chain needs is the image of the window's integer minimum / maximum under the same float
+// operations, and the workgroup evaluates the chain per pixel with exactly the operations of the separate kernels
+// (pl_ground, pl_normalize, pl_invert, pl_scale): no float64 window ever goes through HBM (round 2: nine passes over it).
+struct SweepSrc {
+  const unsigned short* f16;
+  int fh, fw, top, left;
+  const double* vmin;
+  const double* vmax;
+  int invert;
+};
+
 __global__ void __launch_bounds__(kSwThreads)
-bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepParams prm,
+bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, int w, const SweepParams prm,
                 int32_t* __restrict__ out_count, double* __restrict__ out_xy, int32_t* __restrict__ out_level,
                 int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -116,9 +133,42 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
   __shared__ unsigned long long s_used;
 
   const int64_t img = blockIdx.x;
-  const double* smp = sample + img * (int64_t)npx;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
+  const double* smp = src.f16 ? nullptr : sample + img * (int64_t)npx;
+  // ---- the uint16 source: window extrema, then the constants of the chain (every lane computes the same scalars)
+  const unsigned short* f16 = src.f16 ? src.f16 + img * (int64_t)src.fh * src.fw + (int64_t)src.top * src.fw + src.left : nullptr;
+  double c_vmin = 0.0, c_gm = 1.0, c_qmin = 0.0, c_qmax = 0.0, c_smin = 0.0, c_mg = 1.0, c_mn2 = 0.0;
+  if (f16) {
+    int amin = 65535, amax = 0;
+    for (int e = tid; e < npx; e += kSwThreads) {
+      const int r = e / w, a = (int)f16[(int64_t)r * src.fw + (e - r * w)];
+      amin = a < amin ? a : amin;
+      amax = a > amax ? a : amax;
+    }
+    amin = pl_wave_reduce(amin, [](int a, int b) { return a < b ? a : b; });
+    amax = pl_wave_reduce(amax, [](int a, int b) { return a > b ? a : b; });
+    if (lane == 0) { s_cnt[wv] = amin; s_cand[wv] = amax; }
+    __syncthreads();
+    for (int k = 0; k < kSwThreads / PL_WAVE; ++k) { amin = s_cnt[k] < amin ? s_cnt[k] : amin; amax = s_cand[k] > amax ? s_cand[k] : amax; }
+    __syncthreads();
+    c_vmin = src.vmin[img];
+    c_gm = src.vmax[img] - c_vmin;                             // ops.normalize(ops.ground(crop, mn=vmin), vmax - vmin)
+    c_qmin = ((double)amin - c_vmin) / c_gm;
+    c_qmax = ((double)amax - c_vmin) / c_gm;
+    const double s_lo = src.invert ? (-c_qmax + c_qmax) + c_qmin : c_qmin;   // the chain's image of the window's extrema
+    const double s_hi = src.invert ? (-c_qmin + c_qmax) + c_qmin : c_qmax;
+    c_smin = s_lo;
+    c_mg = (s_hi - s_lo) + 0.0;                                // max of ground(s)
+    c_mn2 = (((s_lo - s_lo) + 0.0) / c_mg) * 1.0;              // min of normalize(ground(s)) * 1
+  }
+  auto value_at = [&](int r, int c) -> double {                // the stretched sample of window pixel (r, c)
+    if (!f16) return smp[r * w + c];
+    const double q = ((double)f16[(int64_t)r * src.fw + c] - c_vmin) / c_gm;
+    const double sv = src.invert ? (-q + c_qmax) + c_qmin : q;
+    const double g = (sv - c_smin) + 0.0;
+    return (((g / c_mg) * 1.0) - c_mn2) + 0.0;
+  };
   const double dp2 = prm.dpmm * prm.dpmm;
   const double pi = 3.141592653589793;
   const double larger = pi * ((prm.radius_mm + prm.tol_mm) * (prm.radius_mm + prm.tol_mm));
@@ -129,15 +179,21 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
   unsigned long long used = 0ull;
 
   // ---- level map: L(p) = number of cutoffs below the sample (binary search, exact float64 comparisons)
-  for (int e = tid; e < npx; e += kSwThreads) {
-    const double v = smp[e];
-    int lo = 0, hi = prm.nlevels;                           // invariant: v > cut[k] for k < lo, !(v > cut[k]) for k >= hi
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (v > prm.cut[mid]) lo = mid + 1; else hi = mid;
+  // rows are padded to a multiple of four bytes (the row scans below read dwords); padding = level 0 = never foreground
+  const int pitch = (w + 3) & ~3;
+  for (int e = tid; e < h * pitch; e += kSwThreads) {
+    const int r = e / pitch, c = e - r * pitch;
+    int lo = 0;
+    if (c < w) {
+      const double v = value_at(r, c);
+      int hi = prm.nlevels;                                 // invariant: v > cut[k] for k < lo, !(v > cut[k]) for k >= hi
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v > prm.cut[mid]) lo = mid + 1; else hi = mid;
+      }
+      used |= 1ull << lo;
     }
     L[e] = (unsigned char)lo;
-    used |= 1ull << lo;
   }
   // which values the level map takes: mask_k = {L > k} differs from mask_(k-1) only when some pixel has L == k, and an
   // unchanged mask yields the same regions -- rejected again, or duplicates of what the earlier level accepted -- so the
@@ -153,16 +209,35 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
   for (int level = 0; level < prm.nlevels; ++level) {
     if (level > 0 && !((level_used >> level) & 1ull)) continue;
     SW_STAMP(7);
-    // ---- A. runs per row (lane = row)
+    // ---- A. the row's foreground as a 160-bit mask (lane = row): four level-map bytes per LDS read, "byte > level" for all
+    // four at once (bytes <= 64: adding 127 - level sets bit 7 exactly where the byte exceeds the level), the four flags
+    // gathered into a nibble.  Runs start where a set bit follows a clear one: popcount.  (Round 2 walked the row byte by
+    // byte here and once more in C: 71 % of the kernel after the hull was fixed.)
+    unsigned long long fm[3] = {0ull, 0ull, 0ull}, st[3], en[3];
     int my_runs = 0;
     if (tid < h) {
-      const unsigned char* row = L + tid * w;
-      bool in = false;
-      for (int c = 0; c < w; ++c) {
-        const bool fg = row[c] > level;
-        my_runs += (fg && !in) ? 1 : 0;
-        in = fg;
+      const unsigned* row32 = reinterpret_cast<const unsigned*>(L + tid * pitch);
+      const unsigned add = (unsigned)(127 - level) * 0x01010101u;
+#pragma unroll
+      for (int wi = 0; wi < 3; ++wi) {
+        unsigned long long acc = 0ull;
+#pragma unroll 4
+        for (int d = 0; d < 16; ++d) {
+          const int dd = 16 * wi + d;
+          if (4 * dd >= pitch) break;
+          const unsigned y = ((row32[dd] + add) >> 7) & 0x01010101u;
+          const unsigned nib = (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xfu;
+          acc |= (unsigned long long)nib << (4 * d);
+        }
+        fm[wi] = acc;
       }
+      st[0] = fm[0] & ~(fm[0] << 1);
+      st[1] = fm[1] & ~((fm[1] << 1) | (fm[0] >> 63));
+      st[2] = fm[2] & ~((fm[2] << 1) | (fm[1] >> 63));
+      en[0] = fm[0] & ~((fm[0] >> 1) | (fm[1] << 63));
+      en[1] = fm[1] & ~((fm[1] >> 1) | (fm[2] << 63));
+      en[2] = fm[2] & ~(fm[2] >> 1);
+      my_runs = __popcll(st[0]) + __popcll(st[1]) + __popcll(st[2]);
     }
     // ---- B. exclusive prefix over rows (h <= 160 < 256 lanes): wave scans + the three wave totals
     {
@@ -187,20 +262,24 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
       break;
     }
     if (nruns == 0) continue;                                // uniform on every lane: nothing at this level
-    // ---- C. write the runs, initialise the forest and the per-root accumulators
+    // ---- C. write the runs (k-th start bit pairs with the k-th end bit), initialise the forest and the per-root accumulators
     if (tid < h) {
-      const unsigned char* row = L + tid * w;
       int id = row_cnt[tid];
-      int start = -1;
-      for (int c = 0; c <= w; ++c) {
-        const bool fg = c < w && row[c] > level;
-        if (fg && start < 0) start = c;
-        if (!fg && start >= 0) {
-          run_info[id] = (unsigned)start | ((unsigned)(c - 1) << 8) | ((unsigned)tid << 16);
+      int ew = 0;
+      unsigned long long ecur = en[0];
+#pragma unroll
+      for (int wi = 0; wi < 3; ++wi) {
+        unsigned long long scur = st[wi];
+        while (scur) {
+          const int start = 64 * wi + __builtin_ctzll(scur);
+          scur &= scur - 1ull;
+          while (!ecur) { ++ew; ecur = ew == 1 ? en[1] : en[2]; }
+          const int end = 64 * ew + __builtin_ctzll(ecur);
+          ecur &= ecur - 1ull;
+          run_info[id] = (unsigned)start | ((unsigned)end << 8) | ((unsigned)tid << 16);
           parent[id] = (unsigned)id;
           t_area[id] = 0; t_r1[id] = 0; t_c0[id] = 255; t_c1[id] = 0;
           ++id;
-          start = -1;
         }
       }
     }
@@ -319,7 +398,7 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
           else if (code == 13 || code == 23) ++n3;
         }
         if (m[e]) {
-          const double v = smp[(int64_t)(r0 + r) * w + c0 + c];
+          const double v = value_at(r0 + r, c0 + c);
           w0 += v; wr += v * (double)r; wc += v * (double)c;
         }
       }
@@ -521,6 +600,31 @@ bb_sweep_kernel(const double* __restrict__ sample, int h, int w, const SweepPara
  * d_level int32[n] (first level that produced a feature, -1 none), d_status int32[n]: 0 ok, 2 more than 32 candidate
  * regions at a level, 3 a candidate's bbox exceeds 64 pixels, 4 more than 8 features, 5 a level has more than 4096 row runs
  * (the caller then uses the level-by-level path).  Windows up to 160 x 160. */
+namespace {
+int sweep_launch(const double* d_sample, const SweepSrc& src, int64_t n, int h, int w, double dpmm, double radius_mm, double tol_mm,
+                 double min_sep_px, int max_number, const double* h_cutoffs, int nlevels, int32_t* d_count, double* d_xy,
+                 int32_t* d_level, int32_t* d_status, void* stream, const char* who) {
+  SweepParams prm;
+  prm.dpmm = dpmm; prm.radius_mm = radius_mm; prm.tol_mm = tol_mm; prm.min_sep_px = min_sep_px;
+  prm.max_number = max_number;
+  prm.nlevels = nlevels;
+  for (int k = 0; k < kSwMaxLevels; ++k) prm.cut[k] = k < nlevels ? h_cutoffs[k] : 0.0;
+  for (int k = 1; k < nlevels; ++k)
+    if (!(h_cutoffs[k] > h_cutoffs[k - 1])) { pl_set_error("%s: cutoffs must increase", who); return PL_ERR_INVALID_ARG; }
+  const size_t lds = (size_t)kSwMaxRuns * 6 * 4 + ((size_t)2 * kSwMaxHullPts + 2 * (kSwMaxHullPts + 1)) * 4 +
+                     (size_t)3 * kSwMaxCrop * kSwMaxCrop + (size_t)h * ((w + 3) & ~3);
+  static std::atomic<size_t> attr_lds{0};
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)bb_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { pl_set_error("%s: LDS attribute: %s", who, hipGetErrorString(e)); return PL_ERR_HIP; }
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(bb_sweep_kernel, dim3((unsigned)n), dim3(kSwThreads), lds, (hipStream_t)stream, d_sample, src, h, w, prm,
+                     d_count, d_xy, d_level, d_status);
+  return pl_check_launch(who);
+}
+}  // namespace
+
 extern "C" int pl_features_sweep(const double* d_sample, int64_t n, int h, int w, double dpmm, double radius_mm,
                                  double tol_mm, double min_sep_px, int max_number, const double* h_cutoffs, int nlevels,
                                  int32_t* d_count, double* d_xy, int32_t* d_level, int32_t* d_status, void* stream) {
@@ -529,23 +633,26 @@ extern "C" int pl_features_sweep(const double* d_sample, int64_t n, int h, int w
   PL_REQUIRE(nlevels > 0 && nlevels <= kSwMaxLevels && max_number > 0, "bad arguments");
   PL_REQUIRE(dpmm > 0 && radius_mm > 0, "bad physical parameters");
   if (n == 0) return PL_OK;
-  SweepParams prm;
-  prm.dpmm = dpmm; prm.radius_mm = radius_mm; prm.tol_mm = tol_mm; prm.min_sep_px = min_sep_px;
-  prm.max_number = max_number;
-  prm.nlevels = nlevels;
-  for (int k = 0; k < kSwMaxLevels; ++k) prm.cut[k] = k < nlevels ? h_cutoffs[k] : 0.0;
-  for (int k = 1; k < nlevels; ++k) PL_REQUIRE(h_cutoffs[k] > h_cutoffs[k - 1], "cutoffs must increase");
-  const size_t lds = (size_t)kSwMaxRuns * 6 * 4 + ((size_t)2 * kSwMaxHullPts + 2 * (kSwMaxHullPts + 1)) * 4 +
-                     (size_t)3 * kSwMaxCrop * kSwMaxCrop + (size_t)h * w;
-  static std::atomic<size_t> attr_lds{0};
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)bb_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { pl_set_error("pl_features_sweep: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
-    attr_lds = lds;
-  }
-  hipLaunchKernelGGL(bb_sweep_kernel, dim3((unsigned)n), dim3(kSwThreads), lds, (hipStream_t)stream, d_sample, h, w, prm,
-                     d_count, d_xy, d_level, d_status);
-  return pl_check_launch("pl_features_sweep");
+  const SweepSrc src{nullptr, 0, 0, 0, 0, nullptr, nullptr, 0};
+  return sweep_launch(d_sample, src, n, h, w, dpmm, radius_mm, tol_mm, min_sep_px, max_number, h_cutoffs, nlevels, d_count,
+                      d_xy, d_level, d_status, stream, "pl_features_sweep");
+}
+
+extern "C" int pl_features_sweep_u16(const uint16_t* d_frames, int64_t n, int frame_h, int frame_w, int top, int left, int h,
+                                     int w, const double* d_vmin, const double* d_vmax, int invert, double dpmm,
+                                     double radius_mm, double tol_mm, double min_sep_px, int max_number,
+                                     const double* h_cutoffs, int nlevels, int32_t* d_count, double* d_xy, int32_t* d_level,
+                                     int32_t* d_status, void* stream) {
+  PL_REQUIRE(d_frames && d_vmin && d_vmax && h_cutoffs && d_count && d_xy && d_level && d_status, "null pointer");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && h > 0 && w > 0 && h <= kSwMaxSide && w <= kSwMaxSide, "bad shape");
+  PL_REQUIRE(frame_h > 0 && frame_w > 0 && top >= 0 && left >= 0 && top + h <= frame_h && left + w <= frame_w,
+             "the window must lie inside the frame");
+  PL_REQUIRE(nlevels > 0 && nlevels <= kSwMaxLevels && max_number > 0, "bad arguments");
+  PL_REQUIRE(dpmm > 0 && radius_mm > 0, "bad physical parameters");
+  if (n == 0) return PL_OK;
+  const SweepSrc src{d_frames, frame_h, frame_w, top, left, d_vmin, d_vmax, invert ? 1 : 0};
+  return sweep_launch(nullptr, src, n, h, w, dpmm, radius_mm, tol_mm, min_sep_px, max_number, h_cutoffs, nlevels, d_count,
+                      d_xy, d_level, d_status, stream, "pl_features_sweep_u16");
 }
 
 #if PL_SWEEP_TIMING

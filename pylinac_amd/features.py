@@ -127,14 +127,46 @@ def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float,
     if vmin is None or vmax is None:
         vmin, vmax = ops.minmax(x)                      # frame-level ground()/normalize()
     vmin, vmax = vmin.to(torch.float64).contiguous(), vmax.to(torch.float64).contiguous()
-    crop = x.view(torch.int16)[:, top:bottom, left:right].contiguous().view(torch.uint16)
-    q = ops.normalize(ops.ground(crop, mn=vmin), vmax - vmin)        # float64 (a - min) / (max - min)
-    sample = ops.invert(q) if not low_density else q
-    res = find_features_batch(sample, dpmm, bb_diameter_mm / 2, bb_tolerance_mm, defer=defer)
+    bottom, right = min(bottom, h), min(right, w)       # numpy slicing clips at the frame's edge
+    wh, ww = bottom - top, right - left
+    if wh <= SWEEP_MAX_SIDE and ww <= SWEEP_MAX_SIDE and n > 0:
+        # the window straight from the uint16 frames: pl_features_sweep_u16 evaluates ground / normalize / invert / stretch
+        # per pixel inside the sweep's workgroup (bit-identical to the separate kernels below; no float64 window in HBM)
+        dev = x.device
+        cuts = np.ascontiguousarray(sweep_cutoffs(), dtype=np.float64)
+        count = torch.empty(n, dtype=torch.int32, device=dev)
+        level = torch.empty(n, dtype=torch.int32, device=dev)
+        status = torch.empty(n, dtype=torch.int32, device=dev)
+        xy = torch.empty((n, 8, 2), dtype=torch.float64, device=dev)
+        check(_lib.load().pl_features_sweep_u16(x.data_ptr(), n, h, w, top, left, wh, ww, vmin.data_ptr(), vmax.data_ptr(),
+                                                0 if low_density else 1, float(dpmm), float(bb_diameter_mm / 2),
+                                                float(bb_tolerance_mm), float(5 * dpmm), 1, cuts.ctypes.data, len(cuts),
+                                                count.data_ptr(), xy.data_ptr(), level.data_ptr(), status.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), "pl_features_sweep_u16")
+        res = dict(xy=xy, count=count, level=level, status=status)
+        if not defer:
+            redo = torch.nonzero((status == 3) | (status == 5)).flatten()
+            if redo.numel():                                    # tables too small for these windows: the general path
+                sub = _bb_sample(x.view(torch.int16)[redo].view(torch.uint16), top, bottom, left, right, vmin[redo], vmax[redo],
+                                 low_density)
+                r2 = find_features_batch(sub, dpmm, bb_diameter_mm / 2, bb_tolerance_mm, level_by_level=True)
+                for key in ("xy", "count", "level", "status"):
+                    res[key][redo] = r2[key]
+    else:
+        sample = _bb_sample(x, top, bottom, left, right, vmin, vmax, low_density)
+        res = find_features_batch(sample, dpmm, bb_diameter_mm / 2, bb_tolerance_mm, defer=defer)
     res["xy"][..., 0] += float(left)                     # (scalar adds: no host-to-device copy, no synchronisation)
     res["xy"][..., 1] += float(top)
     res["window"] = (top, bottom, left, right)
     return res
+
+
+def _bb_sample(x: torch.Tensor, top: int, bottom: int, left: int, right: int, vmin: torch.Tensor, vmax: torch.Tensor,
+               low_density: bool) -> torch.Tensor:
+    """the float64 sample of the BB window as separate kernels: crop, frame-level ground / normalize, invert"""
+    crop = x.view(torch.int16)[:, top:bottom, left:right].contiguous().view(torch.uint16)
+    q = ops.normalize(ops.ground(crop, mn=vmin), vmax - vmin)        # float64 (a - min) / (max - min)
+    return ops.invert(q) if not low_density else q
 
 
 def field_cutoffs(imin: float, imax: float) -> list[float]:
