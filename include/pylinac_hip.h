@@ -172,6 +172,16 @@ int pl_circle_profile(const void* img, int dtype, int64_t n, int h, int w, const
                       const double* d_cx, const double* d_cy, double divisor, double* d_out,
                       void* stream);
 
+/* The same profile of combine_surrounding_slices(z +- plusminus, "max") (pylinac/ct.py:3351-3386, sampled at ct.py:1561-1580)
+ * without building the combined slices: d_stack [n_stack][h][w] holds whole volumes of slices_per_volume slices, profile i
+ * belongs to slice d_slice_index[i] (int64 [m]; NULL = slice i, m == n_stack), every tap is the maximum over the slice's
+ * neighbours inside its own volume with pl_combine_slices' indexing (negative indices wrap, indices past the end reuse
+ * the last slice).  Integer slices; d_radii [m][nr], d_cx / d_cy [m], d_out [m][nsamp]. */
+int pl_circle_profile_combined(const void* stack, int dtype, int64_t n_stack, int h, int w, const int64_t* d_slice_index,
+                               int64_t m, int64_t slices_per_volume, int plusminus, const double* d_cos,
+                               const double* d_sin, int nsamp, const double* d_radii, int nr, const double* d_cx,
+                               const double* d_cy, double divisor, double* d_out, void* stream);
+
 /* ---- a15: ndimage.sobel(image, axis) (pylinac/core/image.py:1006-1007): [-1,0,1] along `axis`
  * then [1,2,1] along the other axis, mode='reflect', each pass cast into the image dtype. */
 int pl_sobel(const void* in, void* out, int dtype, int64_t n, int h, int w, int axis, void* stream);
@@ -264,6 +274,28 @@ int pl_linspace_edges(const double* d_lo, const double* d_hi, int nbins, int64_t
  * d_thr[i] = otsu_i * scale (pylinac/ct.py:3338-3340 uses 0.8), d_raw[i] = otsu_i (optional, may be NULL). */
 int pl_otsu_from_counts(const uint32_t* d_counts, const double* d_edges, int nbins, int64_t n, double scale,
                         double* d_thr, double* d_raw, void* stream);
+/* The edge-image half of the slice localisation in one pass (csrc/edge_field.hip; pylinac/ct.py:391-392, 3327-3338):
+ * d_out float64 [n][h][w] = ndimage.gaussian_filter(skimage.filters.scharr(frame.astype(float)), mode='nearest') with the
+ * taps d_weights (device float64 [2 * radius + 1], radius 1..8), bit-identical to pl_scharr + pl_gaussian2d_mode(mode 1);
+ * d_rawmax[i] = max of the Scharr magnitude itself (the "no edges" test), d_min / d_max[i] = extrema of d_out over the
+ * pixels selected by d_mask (uint8 [h][w] shared by all frames; NULL = every pixel).  int16 / uint16 frames. */
+int pl_scharr_gaussian(const void* in, int dtype, int64_t n, int h, int w, const double* d_weights, int radius,
+                       const uint8_t* d_mask, double* d_out, double* d_rawmax, double* d_min, double* d_max, void* stream);
+/* The labelling half of get_regions (pylinac/ct.py:3340-3347) for every frame in ONE launch, a workgroup per frame with the
+ * mask as a bit plane in LDS and components as sets of row runs (csrc/slice_regions.hip):
+ *   bw = in > d_thr[i]  (dtype PL_F64; NaN compares false)   or   bw = in != 0  (dtype PL_U8, d_thr NULL);
+ *   clear_border_ext > 0: skimage.segmentation.clear_border(bw, buffer_size = clear_border_ext - 1) (8-connected);
+ *   fill_holes != 0: scipy.ndimage.binary_fill_holes(bw) (default structure: 4-connected background);
+ *   measure.label(bw) (8-connected, scikit-image's raster-order numbering) and per label k < max_labels
+ *   d_table float64 [n][max_labels][7] = area, bbox r0, c0, r1, c1 (half-open), sum of rows, sum of columns (exact
+ *   integers); d_count int32[n] = number of labels (may exceed max_labels: the table then holds the first max_labels);
+ *   d_status int32[n]: 0, or 1 = more row runs than the LDS list holds -- repeat that frame with pl_compare /
+ *   pl_clear_border / pl_fill_holes / pl_label / pl_region_stats.  d_out_mask (optional uint8 [n][h][w]) receives the
+ *   final mask.  pl_mask_regions_fits(h, w, max_labels) != 0 says whether the shape fits the LDS form at all. */
+int pl_mask_regions_fits(int h, int w, int max_labels);
+int pl_mask_regions(const void* in, int dtype, const double* d_thr, int64_t n, int h, int w, int clear_border_ext,
+                    int fill_holes, int max_labels, double* d_table, int32_t* d_count, int32_t* d_status,
+                    uint8_t* d_out_mask, void* stream);
 /* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count] made of whole volumes of
  * slices_per_volume slices: mode 0 = np.max (d_out has the input dtype), mode 1 = np.mean (d_out float64).  The window
  * z-k .. z+k indexes the slice's own volume the way the reference indexes its Python list: a negative index wraps around

@@ -72,6 +72,7 @@ SIGNATURES = {
     "pl_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
     "pl_median3_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
     "pl_circle_profile": ([_p, _i, _l, _i, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p], C.c_int),
+    "pl_circle_profile_combined": ([_p, _i, _l, _i, _i, _p, _l, _l, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p], C.c_int),
     "pl_sobel": ([_p, _p, _i, _l, _i, _i, _i, _p], C.c_int),
     "pl_label": ([_p, _l, _i, _i, _i, _p, _p, _p, _p], C.c_int),
     "pl_fill_holes": ([_p, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
@@ -91,6 +92,9 @@ SIGNATURES = {
     "pl_region_moments": ([_p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_linspace_edges": ([_p, _p, _i, _l, _p, _p], C.c_int),
     "pl_otsu_from_counts": ([_p, _p, _i, _l, _d, _p, _p, _p], C.c_int),
+    "pl_scharr_gaussian": ([_p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p], C.c_int),
+    "pl_mask_regions_fits": ([_i, _i, _i], C.c_int),
+    "pl_mask_regions": ([_p, _i, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p], C.c_int),
     "pl_combine_slices": ([_p, _p, _i, _l, _l, _i, _i, _l, _p], C.c_int),
     "pl_features_level": ([_p, _p, _p, _p, _i, _l, _i, _i, _d, _d, _d, _d, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_features_sweep": ([_p, _l, _i, _i, _d, _d, _d, _d, _i, _p, _i, _p, _p, _p, _p, _p], C.c_int),

@@ -45,7 +45,74 @@ circle_profile_kernel(const T* __restrict__ img, int h, int w, const double* __r
   out[frame * (size_t)nsamp + s] = (divisor == 1.0) ? acc : acc / divisor;
 }
 
+// The same sampling on combine_surrounding_slices(slice +- k, "max") (pylinac/ct.py:3351-3386, called from
+// CTP528CP504's circle profile, ct.py:1561-1580) WITHOUT building the combined slices: the maximum over the 2k + 1
+// neighbouring slices is taken per tap (a ring of 20 radii touches ~2 % of a slice; the full combination moved every pixel
+// of 7 slices).  np.max over exact integers commutes with the nearest-neighbour gather, so the samples are identical.
+// Slice z of a volume reads z - k .. z + k of ITS volume the way the reference indexes its list (pl_combine_slices: a
+// negative index wraps to the end of the volume, an index past the end -- IndexError in the reference -- reuses the last
+// slice and the caller discards the profile).
+template <typename T>
+__global__ void __launch_bounds__(256)
+circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const int64_t* __restrict__ slice_index,
+                               int64_t per_volume, int k_pm, const double* __restrict__ cosv,
+                               const double* __restrict__ sinv, int nsamp, const double* __restrict__ radii, int nr,
+                               const double* __restrict__ cx, const double* __restrict__ cy, double divisor,
+                               double* __restrict__ out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  const size_t frame = blockIdx.y;
+  if (s >= nsamp) return;
+  const int64_t g = slice_index ? slice_index[frame] : (int64_t)frame;
+  const int64_t v0 = (g / per_volume) * per_volume, z = g - v0;
+  const size_t per_frame = (size_t)h * w;
+  const double c = cosv[s], sn = sinv[s];
+  const double x0 = cx[frame], y0 = cy[frame];
+  double acc = 0.0;
+  for (int k = 0; k < nr; ++k) {
+    const double r = radii[frame * nr + k];
+    const double x = c * r + x0;
+    const double y = sn * r + y0;
+    double v = 0.0;
+    if (x >= 0.0 && x <= (double)(w - 1) && y >= 0.0 && y <= (double)(h - 1)) {
+      const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
+      const size_t p = (size_t)yi * w + xi;
+      T m = 0;
+      for (int d = -k_pm; d <= k_pm; ++d) {
+        int64_t q = z + d;
+        if (q < 0) q += per_volume;
+        if (q < 0) q = 0;
+        if (q >= per_volume) q = per_volume - 1;
+        const T e = stack[(size_t)(v0 + q) * per_frame + p];
+        m = (d == -k_pm || e > m) ? e : m;
+      }
+      v = (double)m;
+    }
+    acc = acc + v;
+  }
+  out[frame * (size_t)nsamp + s] = (divisor == 1.0) ? acc : acc / divisor;
+}
+
 }  // namespace
+
+extern "C" int pl_circle_profile_combined(const void* stack, int dtype, int64_t n_stack, int h, int w,
+                                          const int64_t* d_slice_index, int64_t m, int64_t slices_per_volume, int plusminus,
+                                          const double* d_cos, const double* d_sin, int nsamp, const double* d_radii, int nr,
+                                          const double* d_cx, const double* d_cy, double divisor, double* d_out,
+                                          void* stream) {
+  PL_REQUIRE(stack && d_cos && d_sin && d_radii && d_cx && d_cy && d_out, "null pointer");
+  PL_REQUIRE(m >= 0 && m <= 65535 && h > 0 && w > 0 && nsamp > 0 && nr > 0 && plusminus >= 0, "bad shape");
+  PL_REQUIRE(slices_per_volume > 0 && n_stack > 0 && n_stack % slices_per_volume == 0, "the stack must hold whole volumes");
+  PL_REQUIRE(d_slice_index || m == n_stack, "without a slice index every slice of the stack is sampled");
+  PL_REQUIRE(divisor != 0.0, "zero divisor");
+  PL_REQUIRE(dtype == PL_I16 || dtype == PL_U16 || dtype == PL_I32 || dtype == PL_U8, "integer slices");
+  if (m == 0) return PL_OK;
+  dim3 grid((unsigned)pl_cdiv(nsamp, 256), (unsigned)m);
+  PL_DISPATCH_DTYPE(dtype, T,
+                    hipLaunchKernelGGL(circle_profile_combined_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)stack, h, w, d_slice_index, slices_per_volume, plusminus, d_cos, d_sin,
+                                       nsamp, d_radii, nr, d_cx, d_cy, divisor, d_out));
+  return pl_check_launch("pl_circle_profile_combined");
+}
 
 extern "C" int pl_circle_profile(const void* img, int dtype, int64_t n, int h, int w, const double* d_cos,
                                  const double* d_sin, int nsamp, const double* d_radii, int nr,

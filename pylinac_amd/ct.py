@@ -92,15 +92,35 @@ def phantom_roi_batch(slices: torch.Tensor, mm_per_pixel: float, catphan_radius_
     filled_area, centroid_r, centroid_c, bbox_r0, bbox_c0, bbox_r1 -- the reference raises ValueError
     for status 1-3; the batch reports per-slice codes instead."""
     x = ops._frames(slices)
-    n = x.shape[0]
+    n, h, w = x.shape
     catphan_size = np.pi * catphan_radius_mm**2 / mm_per_pixel**2        # ct.py:2581-2584
-    raw = ops.scharr(x)                                                  # computed once: the edge test and get_regions
-    raw_max_t = ops.minmax(raw)[1]                                       # ct.py:392: np.max(edges) < 0.1
-    reg = get_regions_batch(x, mm_per_pixel, fill_holes=True, clear_borders=True, max_labels=max_labels, raw_edges=raw)
-    raw_max = raw_max_t.cpu().numpy()
-    stats = reg["stats"].cpu().numpy()
-    num = np.minimum(reg["num"].cpu().numpy(), max_labels)
-    ovf = reg["overflow"].cpu().numpy()
+    if x.dtype in (torch.int16, torch.uint16) and ops.mask_regions_fits(h, w, max_labels):
+        # three launches per batch: edge image + its extrema, the disk histogram's Otsu threshold, and the whole
+        # clear_border -> fill_holes -> label -> regionprops chain of a slice inside one workgroup
+        disk = _disk_on_device(h, w, mm_per_pixel, x.device)
+        edges, raw_max_t, lo, hi = ops.scharr_gaussian(x, 1, disk)
+        thr, _ = ops.otsu_float_masked(edges, disk, scale=0.8, lohi=(lo, hi))
+        table, count, st = ops.mask_regions(edges, thr, min(int(max(h, w) / 100), 3) + 1, True, max_labels)
+        raw_max = raw_max_t.cpu().numpy()
+        stats = table.cpu().numpy()
+        cnt = count.cpu().numpy()
+        ovf = (cnt > max_labels).astype(np.int32)
+        num = np.minimum(cnt, max_labels)
+        redo = np.flatnonzero(st.cpu().numpy() != 0)          # slices with more row runs than the LDS list holds
+        if len(redo):
+            sub = x[torch.from_numpy(redo).to(x.device)].contiguous()
+            reg = get_regions_batch(sub, mm_per_pixel, fill_holes=True, clear_borders=True, max_labels=max_labels)
+            stats[redo] = reg["stats"].cpu().numpy()[:, :, :7]
+            num[redo] = np.minimum(reg["num"].cpu().numpy(), max_labels)
+            ovf[redo] = reg["overflow"].cpu().numpy()
+    else:
+        raw = ops.scharr(x)                                              # computed once: the edge test and get_regions
+        raw_max_t = ops.minmax(raw)[1]                                   # ct.py:392: np.max(edges) < 0.1
+        reg = get_regions_batch(x, mm_per_pixel, fill_holes=True, clear_borders=True, max_labels=max_labels, raw_edges=raw)
+        raw_max = raw_max_t.cpu().numpy()
+        stats = reg["stats"].cpu().numpy()
+        num = np.minimum(reg["num"].cpu().numpy(), max_labels)
+        ovf = reg["overflow"].cpu().numpy()
     # the selection (sorted(regionprops, key=|filled_area - catphan_size|)[0] and the size test), vectorised over slices
     valid = np.arange(max_labels)[None, :] < num[:, None]
     filled = stats[:, :, 0]                                 # == filled_area after binary_fill_holes
@@ -145,6 +165,65 @@ def find_phantom_axis_volume(slices: torch.Tensor, mm_per_pixel: float, catphan_
     fit_zx = np.polyfit(zs[common], center_xs[common], deg=1, rcond=0.00001)
     fit_zy = np.polyfit(zs[common], center_ys[common], deg=1, rcond=0.00001)
     return fit_zx, fit_zy, roi
+
+
+def _polyfit1_stack(xs: np.ndarray, ys: np.ndarray):
+    """``np.polyfit(x_g, y_g, deg=1, rcond=0.00001)`` for G data sets of the same length at once, bit-identical to G separate
+    calls: polyfit's own steps (Vandermonde columns scaled to unit norm, LAPACK ``gelsd``, rescaling;
+    numpy/lib/_polynomial_impl.py) with the solver's stacked form -- the gufunc behind ``np.linalg.lstsq`` solves every
+    leading-dimension item on its own with a single right-hand side, exactly like a separate call.  -> [G, 2] or None when
+    that gufunc is not there (the caller then loops)."""
+    try:
+        from numpy.linalg import _umath_linalg as _ul
+
+        gufunc = _ul.lstsq
+    except (ImportError, AttributeError):
+        return None
+    lhs = np.stack([xs, np.ones_like(xs)], axis=2).astype(np.float64)          # np.vander(x, 2)
+    scale = np.sqrt((lhs * lhs).sum(axis=1))
+    lhs = lhs / scale[:, None, :]
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore", under="ignore"):
+        c, _, rank, _ = gufunc(lhs, ys[:, :, None].astype(np.float64), 0.00001, signature="ddd->ddid")
+    if (rank != 2).any():
+        return None
+    return c[:, :, 0] / scale
+
+
+def find_phantom_axes_batch(roi: np.ndarray, n_volumes: int, x_adjustment: float = 0, y_adjustment: float = 0):
+    """``find_phantom_axis_volume`` for the ROI table of ``n_volumes`` equally long volumes -> (fit_zx [V, 2], fit_zy [V, 2]).
+    When every slice of every volume shows the phantom (the usual case) the medians, the outlier screen and the two
+    first-order fits of all volumes are taken together; the fits stay bit-identical to ``np.polyfit`` per volume
+    (``_polyfit1_stack``).  Anything else goes volume by volume."""
+    spv = roi.shape[0] // n_volumes
+    r = roi.reshape(n_volumes, spv, roi.shape[1])
+
+    def loop():
+        fits = [find_phantom_axis_volume(None, 0.0, roi=r[v], x_adjustment=x_adjustment, y_adjustment=y_adjustment)
+                for v in range(n_volumes)]
+        return np.stack([f[0] for f in fits]), np.stack([f[1] for f in fits])
+
+    if not (r[:, :, 0] == 0).all():
+        return loop()
+    cxs, cys = r[:, :, 4] + x_adjustment, r[:, :, 3] + y_adjustment
+    okx = np.isclose(np.median(cxs, axis=1)[:, None], cxs, atol=3, rtol=0.01)
+    oky = np.isclose(np.median(cys, axis=1)[:, None], cys, atol=3, rtol=0.01)
+    common = okx & oky
+    cnt = common.sum(axis=1)
+    if cnt.min() < 2:
+        return loop()
+    fzx = np.empty((n_volumes, 2))
+    fzy = np.empty((n_volumes, 2))
+    zs = np.arange(spv, dtype=np.float64)
+    for m in np.unique(cnt):                                   # volumes with the same number of kept slices together
+        g = np.flatnonzero(cnt == m)
+        sel = common[g]
+        xs = np.broadcast_to(zs, sel.shape)[sel].reshape(len(g), m)
+        cx = _polyfit1_stack(xs, cxs[g][sel].reshape(len(g), m))
+        cy = _polyfit1_stack(xs, cys[g][sel].reshape(len(g), m))
+        if cx is None or cy is None:
+            return loop()
+        fzx[g], fzy[g] = cx, cy
+    return fzx, fzy
 
 
 def find_origin_slice_volume(slices: torch.Tensor, mm_per_pixel: float, fit_zx, fit_zy, slice_thickness: float,
@@ -261,8 +340,6 @@ def ctp528_profiles_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx, fit
     n, h, w = x.shape
     spv = int(slices_per_volume or n)
     idx = np.arange(n) if slices is None else np.asarray(slices, dtype=np.int64)
-    combined = ops.combine_slices(x, slices_plusminus, "max", spv)
-    sub = combined if slices is None else combined[torch.from_numpy(idx).to(x.device)].contiguous()
     fzx, fzy = np.atleast_2d(np.asarray(fit_zx, dtype=np.float64)), np.atleast_2d(np.asarray(fit_zy, dtype=np.float64))
     v, z = idx // spv, idx % spv                                               # volume and slice number inside it
     cx = fzx[v, 0] * z + fzx[v, 1]                                             # np.poly1d(fit)(z), ct.py:434-439
@@ -273,7 +350,14 @@ def ctp528_profiles_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx, fit
     width_ratio, num_profiles, sampling_ratio = 0.04 * roi_size_factor, 20, 2
     radii = np.linspace(radius * (1 - width_ratio), radius * (1 + width_ratio), num_profiles)   # profile.py:2448-2452
     size = np.pi * radii.max() * 2 * sampling_ratio
-    prof = ops.circle_profile(sub, cx, cy, radii, size, start_angle + np.deg2rad(roll_deg), ccw, float(num_profiles))
+    if x.dtype in (torch.int16, torch.uint16, torch.int32, torch.uint8) and len(idx) <= 65535:
+        # the +-3-slice maximum is taken per tap of the ring: the combined slices are never built
+        prof = ops.circle_profile(x, cx, cy, radii, size, start_angle + np.deg2rad(roll_deg), ccw, float(num_profiles),
+                                  combine=(idx, spv, slices_plusminus))
+    else:
+        combined = ops.combine_slices(x, slices_plusminus, "max", spv)
+        sub = combined if slices is None else combined[torch.from_numpy(idx).to(x.device)].contiguous()
+        prof = ops.circle_profile(sub, cx, cy, radii, size, start_angle + np.deg2rad(roll_deg), ccw, float(num_profiles))
     sigma = resolve_filter_size(prof.shape[1], 0.001)                          # array_utils.filter: int(round(len * size))
     prof = ops.gaussian_filter1d(prof, sigma, axis=-1)
     mn, _ = ops.minmax(prof[:, None, :])
@@ -308,12 +392,20 @@ def ctp528_mtf_batch(profiles: torch.Tensor, regions=CTP528_REGIONS):
         reg = torch.stack([idx.amin(dim=1), idx.amax(dim=1)], dim=1).to(torch.int32)
         vl = ops.find_peaks_batch(neg, cap=max(nval, 1), regions=reg, threshold=0.3, peak_separation=spacing,
                                   max_number=nval)
-        launched.append((pk.count, pk.props[:, 0, :], vl.count, vl.idx))
-    cnts = torch.stack([t[0] for t in launched], dim=1).cpu().numpy()                     # [M, R]
-    vcnts = torch.stack([t[2] for t in launched], dim=1).cpu().numpy()
-    heights = [t[1].cpu().numpy() for t in launched]                                      # peak_heights, [M, npk] each
-    vidxs = [t[3].cpu().numpy() for t in launched]
-    pv = p.cpu().numpy()                                                                  # values[valley_idxs]
+        # values[valley_idxs], gathered where the profiles live (the profiles themselves stay on the device)
+        vvals = torch.gather(p, 1, vl.idx.clamp(0, length - 1).to(torch.int64))
+        launched.append((pk.count, pk.props[:, 0, :], vl.count, vvals))
+    # ONE transfer for the whole batch: counts, peak heights and valley values of the eight regions side by side
+    cols = ([t[0].to(torch.float64)[:, None] for t in launched] + [t[2].to(torch.float64)[:, None] for t in launched]
+            + [t[1] for t in launched] + [t[3] for t in launched])
+    widths = [c.shape[1] for c in cols]
+    packed = torch.cat(cols, dim=1).cpu().numpy()
+    parts = np.split(packed, np.cumsum(widths)[:-1], axis=1)
+    nr = len(launched)
+    cnts = np.concatenate(parts[:nr], axis=1).astype(np.int64)                            # [M, R]
+    vcnts = np.concatenate(parts[nr:2 * nr], axis=1).astype(np.int64)
+    heights = parts[2 * nr:3 * nr]                                                        # peak_heights, [M, npk] each
+    vvalues = parts[3 * nr:]
     maxs = np.full((m, len(regions)), np.nan)
     mins = np.full((m, len(regions)), np.nan)
     alive = np.ones(m, dtype=bool)
@@ -324,9 +416,8 @@ def ctp528_mtf_batch(profiles: torch.Tensor, regions=CTP528_REGIONS):
         if not alive.any():
             break
         maxs[alive, k] = heights[k][alive, :npk].mean(axis=1)
-        vi, vc = vidxs[k], vcnts[:, k]
-        vals = pv[rows[:, None], np.clip(vi, 0, length - 1)]
-        vals = np.where(np.arange(vi.shape[1])[None, :] < vc[:, None], vals, np.nan)
+        vals, vc = vvalues[k], vcnts[:, k]
+        vals = np.where(np.arange(vals.shape[1])[None, :] < vc[:, None], vals, np.nan)
         with np.errstate(invalid="ignore"), warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
             vmean = np.nansum(vals, axis=1) / np.maximum(vc, 1)
@@ -354,8 +445,7 @@ def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=
     roi = None
     if fit_zx is None or fit_zy is None:
         roi = phantom_roi_batch(flat, mm_per_pixel)
-        fits = [find_phantom_axis_volume(None, mm_per_pixel, roi=roi[v * spv:(v + 1) * spv]) for v in range(nv)]
-        fit_zx, fit_zy = np.stack([f[0] for f in fits]), np.stack([f[1] for f in fits])
+        fit_zx, fit_zy = find_phantom_axes_batch(roi, nv)
     prof, idx = ctp528_profiles_batch(flat, mm_per_pixel, fit_zx, fit_zy, slices=slices, roll_deg=roll_deg,
                                       slices_per_volume=spv, **kw)
     out = ctp528_mtf_batch(prof)

@@ -516,14 +516,24 @@ def circle_radians(size: float, start_angle: float = 0, ccw: bool = True) -> np.
 
 
 def circle_profile(frames: torch.Tensor, cx, cy, radii, size: float, start_angle: float = 0,
-                   ccw: bool = True, divisor: float = 1.0) -> torch.Tensor:
+                   ccw: bool = True, divisor: float = 1.0, combine=None) -> torch.Tensor:
     """``ndimage.map_coordinates(order=0)`` along circles, summed over ``radii`` and divided by
     ``divisor`` (pylinac/core/profile.py:2279-2283, 2473-2483).  ``cx, cy``: scalar or [N];
-    ``radii``: [nr] or [N, nr]; ``size`` = pi * r_max * 2 * sampling_ratio.  -> float64 [N, nsamp]."""
+    ``radii``: [nr] or [N, nr]; ``size`` = pi * r_max * 2 * sampling_ratio.  -> float64 [N, nsamp].
+    ``combine=(slice_index, slices_per_volume, plusminus)``: ``frames`` is a stack of whole volumes and profile i is taken
+    on ``combine_surrounding_slices(slice_index[i] +- plusminus, "max")`` of its own volume (pylinac/ct.py:3351-3386) --
+    the maximum is formed per tap, the combined slices are never built; N is then ``len(slice_index)``."""
     x = _frames(frames)
-    n, h, w = x.shape
-    rads = circle_radians(size, start_angle, ccw)
+    n_stack, h, w = x.shape
     dev = x.device
+    if combine is not None:
+        sidx, spv, pm = combine
+        sidx = np.ascontiguousarray(sidx, dtype=np.int64)
+        n = len(sidx)
+        d_sidx = torch.from_numpy(sidx).to(dev)
+    else:
+        n = n_stack
+    rads = circle_radians(size, start_angle, ccw)
     d_cos = torch.from_numpy(np.cos(rads)).to(dev)
     d_sin = torch.from_numpy(np.sin(rads)).to(dev)
     r = torch.as_tensor(np.asarray(radii, dtype=np.float64))
@@ -533,6 +543,12 @@ def circle_profile(frames: torch.Tensor, cx, cy, radii, size: float, start_angle
     cxs = torch.as_tensor(np.broadcast_to(np.asarray(cx, dtype=np.float64), (n,)).copy()).to(dev)
     cys = torch.as_tensor(np.broadcast_to(np.asarray(cy, dtype=np.float64), (n,)).copy()).to(dev)
     out = torch.empty((n, len(rads)), dtype=torch.float64, device=dev)
+    if combine is not None:
+        check(_lib.load().pl_circle_profile_combined(x.data_ptr(), _dt(x), n_stack, h, w, d_sidx.data_ptr(), n, int(spv),
+                                                     int(pm), d_cos.data_ptr(), d_sin.data_ptr(), len(rads), r.data_ptr(),
+                                                     r.shape[1], cxs.data_ptr(), cys.data_ptr(), float(divisor),
+                                                     out.data_ptr(), _stream()), "pl_circle_profile_combined")
+        return out
     check(_lib.load().pl_circle_profile(x.data_ptr(), _dt(x), n, h, w, d_cos.data_ptr(), d_sin.data_ptr(),
                                         len(rads), r.data_ptr(), r.shape[1], cxs.data_ptr(), cys.data_ptr(),
                                         float(divisor), out.data_ptr(), _stream()), "pl_circle_profile")
@@ -732,16 +748,37 @@ def hist_uniform(frames: torch.Tensor, edges: torch.Tensor, mask: torch.Tensor |
     return out
 
 
-def otsu_float_masked(frames: torch.Tensor, mask: torch.Tensor | None, scale: float = 1.0):
+def scharr_gaussian(frames: torch.Tensor, sigma: float, mask: torch.Tensor | None = None):
+    """``skimage.filters.gaussian(skimage.filters.scharr(frame.astype(float)), sigma)`` (mode 'nearest') in one pass over
+    int16 / uint16 frames (``pl_scharr_gaussian``; pylinac/ct.py:391, 3327-3328) -> (edges float64 [N,H,W], the maximum of
+    the raw Scharr magnitude [N], min and max [N] of ``edges[mask]`` for a frame-shared uint8 mask)."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    dev = x.device
+    wts, _, lw = _device_weights(sigma, dev)
+    out = torch.empty((n, h, w), dtype=torch.float64, device=dev)
+    rawmax = torch.empty(n, dtype=torch.float64, device=dev)
+    lo = torch.empty(n, dtype=torch.float64, device=dev)
+    hi = torch.empty(n, dtype=torch.float64, device=dev)
+    check(_lib.load().pl_scharr_gaussian(x.data_ptr(), _dt(x), n, h, w, wts.data_ptr(), lw,
+                                         0 if mask is None else mask.contiguous().data_ptr(), out.data_ptr(),
+                                         rawmax.data_ptr(), lo.data_ptr(), hi.data_ptr(), _stream()), "pl_scharr_gaussian")
+    return out, rawmax, lo, hi
+
+
+def otsu_float_masked(frames: torch.Tensor, mask: torch.Tensor | None, scale: float = 1.0, lohi=None):
     """``skimage.filters.threshold_otsu(frame[mask])`` for float64 frames (256 bins over the min .. max of the selected
-    pixels; pylinac/ct.py:3323, 3338-3340) entirely on the device -> (threshold * scale, threshold) float64 [N]."""
+    pixels; pylinac/ct.py:3323, 3338-3340) entirely on the device -> (threshold * scale, threshold) float64 [N].
+    ``lohi``: the selection's (min, max) when the caller already has them."""
     x = _frames(frames)
     if x.dtype != torch.float64:
         raise TypeError("otsu_float_masked needs float64 frames")
     n = x.shape[0]
     dev = x.device
     lib, st = _lib.load(), _stream()
-    if mask is None:
+    if lohi is not None:
+        lo, hi = lohi
+    elif mask is None:
         lo, hi = minmax(x)
     else:
         lo, hi = minmax_masked(x, mask)
@@ -798,6 +835,50 @@ def region_stats(labels: torch.Tensor, intensity: torch.Tensor | None, max_label
                                       n, h, w, int(max_labels), isum.data_ptr(), wsum.data_ptr(), stats.data_ptr(),
                                       ovf.data_ptr(), _stream()), "pl_region_stats")
     return stats, ovf
+
+
+MASK_REGION_FIELDS = REGION_FIELDS[:7]
+
+
+def mask_regions_fits(h: int, w: int, max_labels: int) -> bool:
+    """Whether ``mask_regions`` can hold an h x w frame (bit plane + run list in LDS) and a table of ``max_labels`` rows."""
+    return bool(_lib.load().pl_mask_regions_fits(int(h), int(w), int(max_labels)))
+
+
+def mask_regions(frames: torch.Tensor, thr=None, clear_border_ext: int = 0, fill_holes: bool = False, max_labels: int = 64,
+                 return_mask: bool = False):
+    """``regionprops(label(binary_fill_holes(clear_border(frame > thr))))`` of every frame in one launch
+    (``pl_mask_regions``: a workgroup per frame, bit plane and row runs in LDS).  ``frames`` float64 with per-frame ``thr``
+    (device float64 [N]) or a uint8 / bool mask with ``thr=None``; ``clear_border_ext`` = ``buffer_size + 1`` or 0 for no
+    clearing.  -> (float64 [N, max_labels, 7] in ``MASK_REGION_FIELDS`` order, int32 count [N], int32 status [N]
+    (1 = too many row runs: use the separate entry points for that frame)[, uint8 final mask])."""
+    x = _frames(frames) if frames.dtype != torch.bool else _mask(frames)
+    n, h, w = x.shape
+    dev = x.device
+    if x.dtype == torch.float64:
+        if thr is None:
+            raise ValueError("float64 frames need thresholds")
+        t = thr.to(torch.float64).reshape(-1)
+        if t.numel() == 1 and n != 1:
+            t = t.expand(n)
+        t = t.contiguous()
+        if t.numel() != n:
+            raise ValueError("one threshold per frame")
+        tp = t.data_ptr()
+    elif x.dtype == torch.uint8:
+        if thr is not None:
+            raise ValueError("a mask takes no threshold")
+        tp = 0
+    else:
+        raise TypeError("mask_regions needs float64 frames or uint8 masks")
+    table = torch.empty((n, int(max_labels), 7), dtype=torch.float64, device=dev)
+    count = torch.empty(n, dtype=torch.int32, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    om = torch.empty((n, h, w), dtype=torch.uint8, device=dev) if return_mask else None
+    check(_lib.load().pl_mask_regions(x.data_ptr(), _dt(x), tp, n, h, w, int(clear_border_ext), int(bool(fill_holes)),
+                                      int(max_labels), table.data_ptr(), count.data_ptr(), status.data_ptr(),
+                                      0 if om is None else om.data_ptr(), _stream()), "pl_mask_regions")
+    return (table, count, status, om) if return_mask else (table, count, status)
 
 
 def region_moments(labels: torch.Tensor, max_labels: int):

@@ -932,3 +932,148 @@ def check_large_rois(dev):
     assert abs(small_sum.mean - v.mean()) < 1e-9 and abs(small_sum.std - v.std()) < 1e-9
     n_big = big._s()[0]
     assert abs(n_big - 300 * 180) < 0.02 * 300 * 180 and big.min >= frames["i16"].min() and big.max <= frames["i16"].max()
+
+
+# ---- round 3: the fused CatPhan localisation kernels (slice_regions.hip, edge_field.hip, circle.hip) -------------------
+def _regions_reference(bw, ext, fill, max_labels):
+    """clear_border -> binary_fill_holes -> label(8-connected) -> raw regionprops sums with scipy (scikit-image's label /
+    clear_border number and select components the same way; ndimage.label numbers in raster order of the first pixel)."""
+    from scipy import ndimage
+
+    bw = bw.astype(bool).copy()
+    s8 = np.ones((3, 3))
+    if ext > 0:
+        lab, _ = ndimage.label(bw, s8)
+        band = np.zeros_like(bw)
+        band[:ext] = band[-ext:] = True
+        band[:, :ext] = band[:, -ext:] = True
+        bw[np.isin(lab, np.unique(lab[band & bw])) & bw] = False
+    if fill:
+        bw = ndimage.binary_fill_holes(bw)
+    lab, n = ndimage.label(bw, s8)
+    tab = np.zeros((max_labels, 7))
+    for k in range(1, min(n, max_labels) + 1):
+        rr, cc = np.nonzero(lab == k)
+        tab[k - 1] = [len(rr), rr.min(), cc.min(), rr.max() + 1, cc.max() + 1, rr.sum(), cc.sum()]
+    return tab, n, bw.astype(np.uint8)
+
+
+def check_mask_regions(dev, shapes=((64, 64), (70, 130), (33, 65), (17, 5), (96, 192), (1, 1), (40, 64)), seed=1):
+    """pl_mask_regions against scipy on random speckle, smooth blobs, full and empty masks: final mask, label count and the
+    region table are exact; a frame with more runs than the LDS list holds must say so (status 1) and nothing else may."""
+    import torch
+    from scipy import ndimage
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(seed)
+    checked = overflowed = 0
+    for h, w in shapes:
+        speckle = rng.random((2, h, w)) < rng.choice([0.3, 0.5, 0.7])
+        blobs = ndimage.gaussian_filter(rng.random((3, h, w)), (0, 2, 2)) > 0.5
+        arr = np.concatenate([speckle, blobs, np.ones((1, h, w), bool), np.zeros((1, h, w), bool)]).astype(np.uint8)
+        for ext, fill in ((0, False), (1, False), (3, True), (0, True), (4, True)):
+            if 2 * ext > min(h, w):
+                continue
+            tab, cnt, st, om = ops.mask_regions(torch.from_numpy(arr).to(dev), None, ext, fill, 64, return_mask=True)
+            tab, cnt, st, om = tab.cpu().numpy(), cnt.cpu().numpy(), st.cpu().numpy(), om.cpu().numpy()
+            for i in range(arr.shape[0]):
+                if st[i]:
+                    runs = int((np.diff(np.pad(arr[i].astype(np.int8), ((0, 0), (1, 1))), axis=1) == 1).sum())
+                    assert st[i] == 1 and 2 * runs + h > 3072, (h, w, i, runs)      # only genuinely crowded frames
+                    overflowed += 1
+                    continue
+                rt, rn, rbw = _regions_reference(arr[i], ext, fill, 64)
+                assert cnt[i] == rn, (h, w, ext, fill, i, cnt[i], rn)
+                assert np.array_equal(om[i], rbw), (h, w, ext, fill, i)
+                assert np.array_equal(tab[i], rt), (h, w, ext, fill, i)
+                checked += 1
+    # float64 frames with per-frame thresholds (strictly greater; NaN is background)
+    e = rng.random((2, 50, 70))
+    e[0, 3, 3] = np.nan
+    thr = np.array([0.5, 0.7])
+    tab, cnt, st = ops.mask_regions(torch.from_numpy(e).to(dev), torch.from_numpy(thr).to(dev), 2, True, 64)
+    for i in range(2):
+        with np.errstate(invalid="ignore"):
+            rt, rn, _ = _regions_reference(e[i] > thr[i], 2, True, 64)
+        assert int(cnt[i]) == rn and np.array_equal(tab[i].cpu().numpy(), rt)
+    return checked, overflowed
+
+
+def check_scharr_gaussian(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.uint16), (2, 32, 64, np.int16), (1, 5, 7, np.int16),
+                                       (1, 100, 9, np.uint16), (1, 64, 200, np.int16)), sigmas=(1, 0.5, 2)):
+    """pl_scharr_gaussian == pl_scharr -> pl_gaussian2d_mode('nearest') -> pl_minmax / pl_minmax_masked, bit for bit (those
+    are pinned to scikit-image 0.18.3 / scipy by the golden tests), on shapes that are not multiples of the 32 x 64 tile."""
+    import torch
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(3)
+    for n, h, w, dt in shapes:
+        a = rng.integers(-1000 if dt == np.int16 else 0, 3000, (n, h, w)).astype(dt)
+        a[:, h // 4:h // 2, w // 4:w // 2] += 500
+        m = (rng.random((h, w)) < 0.6).astype(np.uint8)
+        m[0, 0] = 1
+        x, mt = torch.from_numpy(a).to(dev), torch.from_numpy(m).to(dev)
+        raw = ops.scharr(x)
+        for sigma in sigmas:
+            e2 = ops.gaussian_filter_mode(raw, sigma, "nearest")
+            e, rm, lo, hi = ops.scharr_gaussian(x, sigma, mt)
+            assert torch.equal(e, e2), (n, h, w, sigma)
+            assert torch.equal(rm, ops.minmax(raw)[1])
+            lo2, hi2 = ops.minmax_masked(e2, mt)
+            assert torch.equal(lo, lo2) and torch.equal(hi, hi2)
+            _, _, lo, hi = ops.scharr_gaussian(x, sigma, None)
+            lo2, hi2 = ops.minmax(e2)
+            assert torch.equal(lo, lo2) and torch.equal(hi, hi2)
+
+
+def check_circle_profile_combined(dev, n_volumes=2, spv=9, h=96, w=112):
+    """The per-tap maximum over the +-k slices == the profile of pl_combine_slices' planes: every slice of two volumes
+    (wrapping first slices, clamped last ones included), a subset through the slice index, k = 0 .. 3."""
+    import torch
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(11)
+    vol = torch.from_numpy(rng.integers(-1000, 3000, (n_volumes * spv, h, w)).astype(np.int16)).to(dev)
+    n = n_volumes * spv
+    cx = w / 2 + rng.uniform(-3, 3, n)
+    cy = h / 2 + rng.uniform(-3, 3, n)
+    radii = np.linspace(30.0, 34.0, 5)
+    size = np.pi * radii.max() * 2 * 2
+    for k in (0, 1, 3):
+        combined = ops.combine_slices(vol, k, "max", spv)
+        want = ops.circle_profile(combined, cx, cy, radii, size, np.pi, True, 5.0)
+        got = ops.circle_profile(vol, cx, cy, radii, size, np.pi, True, 5.0, combine=(np.arange(n), spv, k))
+        assert torch.equal(got, want), k
+        sub = np.array([0, spv - 1, spv, n - 1, 4])
+        got = ops.circle_profile(vol, cx[sub], cy[sub], radii, size, np.pi, True, 5.0, combine=(sub, spv, k))
+        assert torch.equal(got, want[torch.from_numpy(sub).to(dev)]), k
+
+
+def check_phantom_roi_fused_vs_separate(dev, slices=(0, 24, 44, 79)):
+    """ct.phantom_roi_batch (fused: pl_scharr_gaussian, pl_otsu_from_counts, pl_mask_regions) == the same table built from
+    the separate entry points (get_regions_batch: the golden-pinned round-1/2 path) on synthetic CatPhan slices."""
+    import torch
+
+    from pylinac_amd import ct, ops
+    from pylinac_amd.synthetic import catphan_volume
+
+    vol = catphan_volume(seed=4000, n_slices=80)
+    x = torch.from_numpy(np.ascontiguousarray(vol[list(slices)])).to(dev)
+    assert ops.mask_regions_fits(512, 512, 64)
+    new = ct.phantom_roi_batch(x, 0.5)
+    reg = ct.get_regions_batch(x, 0.5, True, True, 64)
+    disk = ct._disk_on_device(512, 512, 0.5, x.device)
+    edges, _, lo, hi = ops.scharr_gaussian(x, 1, disk)
+    assert torch.equal(edges, reg["edges"])
+    thr, otsu = ops.otsu_float_masked(edges, disk, scale=0.8, lohi=(lo, hi))
+    assert torch.equal(otsu, reg["otsu"])
+    tab, cnt, st, om = ops.mask_regions(edges, thr, 4, True, 64, return_mask=True)
+    assert not st.any() and torch.equal(cnt, reg["num"]) and torch.equal(om, reg["bw"])
+    for i in range(len(slices)):
+        k = int(cnt[i])
+        assert torch.equal(tab[i, :k], reg["stats"][i, :k, :7]), i
+    assert (new[:, 0] == 0).all() and np.all(np.abs(new[:, 3:5] - 255.5) < 8)
+    return new

@@ -793,3 +793,29 @@ def test_emulated_large_rois(emulated):
     import next_row_checks as checks
 
     checks.check_large_rois(emulated)
+
+
+def test_emulated_mask_regions_vs_scipy(emulated):
+    """slice_regions.hip: bit-plane / row-run labelling of clear_border -> fill_holes -> label -> regionprops in one workgroup."""
+    import next_row_checks as checks
+
+    checked, overflowed = checks.check_mask_regions(emulated)
+    assert checked >= 150
+
+
+def test_emulated_scharr_gaussian_bit_identical(emulated):
+    import next_row_checks as checks
+
+    checks.check_scharr_gaussian(emulated)
+
+
+def test_emulated_circle_profile_combined(emulated):
+    import next_row_checks as checks
+
+    checks.check_circle_profile_combined(emulated)
+
+
+def test_emulated_phantom_roi_fused_vs_separate(emulated):
+    import next_row_checks as checks
+
+    checks.check_phantom_roi_fused_vs_separate(emulated, slices=(24, 44))

@@ -1819,3 +1819,37 @@ def test_bench_line_contract(dev):
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0
     assert d["parity_sample"]["ok"] is True and d["parity_sample"]["units"] >= 1
 
+
+
+@pytest.mark.gpu
+def test_mask_regions_vs_scipy(dev):
+    """pl_mask_regions (one workgroup per frame: bit plane + row runs in LDS) against scipy's clear_border / fill_holes /
+    label / regionprops sums, incl. a crowded 512 x 512 frame that must report status 1."""
+    import next_row_checks as checks
+
+    checked, _ = checks.check_mask_regions(dev, shapes=((64, 64), (70, 130), (33, 65), (17, 5), (96, 192), (1, 1), (40, 64),
+                                                        (300, 300), (512, 512)))
+    assert checked > 250
+
+
+@pytest.mark.gpu
+def test_scharr_gaussian_bit_identical(dev):
+    import next_row_checks as checks
+
+    checks.check_scharr_gaussian(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.uint16), (2, 32, 64, np.int16),
+                                              (1, 5, 7, np.int16), (1, 100, 9, np.uint16), (3, 512, 512, np.int16)))
+
+
+@pytest.mark.gpu
+def test_circle_profile_combined(dev):
+    import next_row_checks as checks
+
+    checks.check_circle_profile_combined(dev)
+    checks.check_circle_profile_combined(dev, n_volumes=3, spv=20, h=256, w=256)
+
+
+@pytest.mark.gpu
+def test_phantom_roi_fused_vs_separate(dev):
+    import next_row_checks as checks
+
+    checks.check_phantom_roi_fused_vs_separate(dev, slices=tuple(range(0, 80, 4)))

@@ -107,3 +107,26 @@ def test_regionprops_formulas_vs_skimage_golden(golden):
     import next_row_checks as checks
 
     checks.check_regionprops_formulas(golden("regionprops"), checks.raw_moments_numpy)
+
+
+def test_batched_phantom_axis_fits_are_polyfit_per_volume():
+    """ct.find_phantom_axes_batch (stacked gelsd through the gufunc behind np.linalg.lstsq) == np.polyfit volume by volume,
+    bit for bit, with outlier slices, unequal kept-slice counts and volumes that send it to the per-volume loop."""
+    import numpy as np
+
+    from pylinac_amd import ct
+
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        nv, spv = 7, 40
+        roi = np.zeros((nv * spv, 8))
+        roi[:, 3] = 255 + rng.normal(0, 0.3, nv * spv) + np.tile(np.arange(spv) * 0.03, nv)
+        roi[:, 4] = 256 + rng.normal(0, 0.3, nv * spv)
+        k = rng.integers(0, nv * spv, 15)
+        roi[k, 3] += rng.choice([-9, 9], 15)
+        if trial % 3 == 0:
+            roi[rng.integers(0, nv * spv, 3), 0] = 3          # a slice without the phantom: per-volume path
+        fzx, fzy = ct.find_phantom_axes_batch(roi, nv)
+        for v in range(nv):
+            zx, zy, _ = ct.find_phantom_axis_volume(None, 0.5, roi=roi[v * spv:(v + 1) * spv])
+            assert np.array_equal(fzx[v], zx) and np.array_equal(fzy[v], zy)
