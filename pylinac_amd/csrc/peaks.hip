@@ -27,24 +27,43 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kStageMax = 4096;   // profiles up to this length are staged in LDS
 constexpr int kMaxCand = 4096;    // candidate peaks kept per profile
+constexpr int kShortMax = 128;    // search regions up to this length: one wave per profile
 
 struct Scan { int wave[kThreads / PL_WAVE]; };
 
-__device__ __forceinline__ int block_flag_scan(int flag, int* total, Scan* s) {
-  const unsigned long long b = __ballot(flag);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int pre = __popcll(b & ((1ull << lane) - 1ull));
-  if (lane == 0) s->wave[wv] = __popcll(b);
-  __syncthreads();
-  int base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < kThreads / PL_WAVE; ++k) {
-    if (k < wv) base += s->wave[k];
-    tot += s->wave[k];
+// NT lanes work on one profile: 256 (a whole workgroup; the barrier is the workgroup's) or 64 (one wave of a
+// four-profile workgroup: the wave is in lock step, the "barrier" only orders its LDS traffic for the compiler)
+template <int NT>
+__device__ __forceinline__ void group_sync() {
+  if constexpr (NT == PL_WAVE) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
   }
-  __syncthreads();
-  *total = tot;
-  return base + pre;
+}
+
+template <int NT>
+__device__ __forceinline__ int block_flag_scan(int flag, int* total, Scan* s, int tid) {
+  const unsigned long long b = __ballot(flag);
+  const int lane = tid & 63, wv = tid >> 6;
+  const int pre = __popcll(b & ((1ull << lane) - 1ull));
+  if constexpr (NT == PL_WAVE) {
+    *total = __popcll(b);
+    return pre;
+  } else {
+    if (lane == 0) s->wave[wv] = __popcll(b);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NT / PL_WAVE; ++k) {
+      if (k < wv) base += s->wave[k];
+      tot += s->wave[k];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + pre;
+  }
 }
 
 struct Widths { double width, height, lip, rip; };
@@ -129,19 +148,25 @@ __device__ __forceinline__ void prominence_side(const double* xs, int pk, int m,
 // STAGE = true: the (trimmed) profile lives in LDS and every walk below is a ds_read; keeping the two
 // cases in separate instantiations lets the compiler know the address space (a runtime select
 // between an LDS and a global pointer degrades every access to a slow FLAT load).
-template <bool STAGE>
+template <bool STAGE, int NT>
 __global__ void __launch_bounds__(kThreads)
-find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __restrict__ lens,
+find_peaks_kernel(const double* __restrict__ x, int64_t nprof, int slot_bytes, int len_all, const int32_t* __restrict__ lens,
                   const int32_t* __restrict__ regions, int64_t stride,
                   pl_peak_params prm, int cap, int maxc, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
                   int32_t* __restrict__ d_lb, int32_t* __restrict__ d_rb, double* __restrict__ d_props,
                   int32_t* __restrict__ d_status) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ Scan scan;
-  __shared__ double s_red[2 * (kThreads / PL_WAVE)];
-  __shared__ int s_cnt;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  __shared__ Scan scan_a[kThreads / NT];
+  __shared__ double s_red_a[kThreads / NT][2 * (kThreads / PL_WAVE)];
+  __shared__ int s_cnt_a[kThreads / NT];
+  const int slot = threadIdx.x / NT, tid = threadIdx.x % NT;
+  unsigned char* smem = smem_all + (size_t)slot * slot_bytes;
+  Scan& scan = scan_a[slot];
+  double* s_red = s_red_a[slot];
+  int& s_cnt = s_cnt_a[slot];
 
-  const int64_t prof = blockIdx.x;
+  const int64_t prof = (int64_t)blockIdx.x * (kThreads / NT) + slot;
+  if (prof >= nprof) return;                     // NT == 64: a whole wave leaves; NT == 256: never taken
   const int len = lens ? lens[prof] : len_all;   // ragged batches: per-profile length
   const double* xfull = x + prof * stride;
   // search region: the batch's, or this profile's own [lo, hi) (python slice semantics resolved by the caller)
@@ -161,23 +186,23 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
   double* s_x = reinterpret_cast<double*>(s_keep + maxc + (maxc & 1));
 
   if (len <= 0) {   // empty profile (e.g. a window that was rejected upstream)
-    if (threadIdx.x == 0) { d_count[prof] = 0; d_status[prof] = 0; }
+    if (tid == 0) { d_count[prof] = 0; d_status[prof] = 0; }
     return;
   }
   // ---- A: height threshold -------------------------------------------------------------------
   double height = prm.threshold;
   if (prm.threshold_is_ratio) {
     double mn = xfull[0], mx = xfull[0];
-    for (int i = threadIdx.x; i < len; i += kThreads) {
+    for (int i = tid; i < len; i += NT) {
       double v = xfull[i];
       mn = v < mn ? v : mn;
       mx = v > mx ? v : mx;
     }
     mn = pl_wave_reduce(mn, [](double a, double b) { return a < b ? a : b; });
     mx = pl_wave_reduce(mx, [](double a, double b) { return a > b ? a : b; });
-    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = mn; s_red[4 + (threadIdx.x >> 6)] = mx; }
-    __syncthreads();
-    for (int k = 0; k < kThreads / PL_WAVE; ++k) {
+    if ((tid & 63) == 0) { s_red[tid >> 6] = mn; s_red[4 + (tid >> 6)] = mx; }
+    group_sync<NT>();
+    for (int k = 0; k < NT / PL_WAVE; ++k) {
       mn = s_red[k] < mn ? s_red[k] : mn;
       mx = s_red[4 + k] > mx ? s_red[4 + k] : mx;
     }
@@ -186,18 +211,18 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
 
   const double* xs;
   if constexpr (STAGE) {
-    for (int i = threadIdx.x; i < m; i += kThreads) s_x[i] = xfull[lo + i];
+    for (int i = tid; i < m; i += NT) s_x[i] = xfull[lo + i];
     xs = s_x;
   } else {
     xs = xfull + lo;
   }
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
+  if (tid == 0) s_cnt = 0;
+  group_sync<NT>();
 
   // ---- B: local maxima + height filter, ordered compaction -----------------------------------
   int overflow = 0;
-  for (int base = 0; base < m; base += kThreads) {
-    const int i = base + threadIdx.x;
+  for (int base = 0; base < m; base += NT) {
+    const int i = base + tid;
     int flag = 0, mid = 0;
     if (i >= 1 && i < m - 1 && xs[i - 1] < xs[i]) {
       int a = i + 1;
@@ -208,23 +233,23 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
       }
     }
     int tot;
-    const int off = block_flag_scan(flag, &tot, &scan);
+    const int off = block_flag_scan<NT>(flag, &tot, &scan, tid);
     const int cur = s_cnt;
     if (flag) {
       if (cur + off < maxc) s_idx[cur + off] = mid; else overflow = 1;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) s_cnt = cur + tot;
-    __syncthreads();
+    group_sync<NT>();
+    if (tid == 0) s_cnt = cur + tot;
+    group_sync<NT>();
   }
   int P = s_cnt;
   if (P > maxc) { P = maxc; overflow = 1; }
-  overflow = __syncthreads_or(overflow);
+  overflow = (NT == PL_WAVE ? (__ballot(overflow) != 0ull ? 1 : 0) : __syncthreads_or(overflow));
 
   // ---- C: distance filter --------------------------------------------------------------------
   if (prm.distance > 1 && P > 1) {
     int* s_order = s_lb;  // scratch: bases are not computed yet
-    for (int j = threadIdx.x; j < P; j += kThreads) {
+    for (int j = tid; j < P; j += NT) {
       const double hj = xs[s_idx[j]];
       int r = 0;
       for (int k = 0; k < P; ++k) {
@@ -234,8 +259,8 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
       s_order[r] = j;
       s_keep[j] = 1;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    group_sync<NT>();
+    if (tid == 0) {
       const int d = prm.distance;
       for (int i = P - 1; i >= 0; --i) {
         const int j = s_order[i];
@@ -246,28 +271,28 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
         while (k < P && s_idx[k] - s_idx[j] < d) { s_keep[k] = 0; ++k; }
       }
     }
-    __syncthreads();
+    group_sync<NT>();
     int* s_tmp = s_rb;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    for (int base = 0; base < P; base += kThreads) {
-      const int j = base + threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+    group_sync<NT>();
+    for (int base = 0; base < P; base += NT) {
+      const int j = base + tid;
       const int flag = (j < P) ? s_keep[j] : 0;
       int tot;
-      const int off = block_flag_scan(flag, &tot, &scan);
+      const int off = block_flag_scan<NT>(flag, &tot, &scan, tid);
       const int cur = s_cnt;
       if (flag) s_tmp[cur + off] = s_idx[j];
-      __syncthreads();
-      if (threadIdx.x == 0) s_cnt = cur + tot;
-      __syncthreads();
+      group_sync<NT>();
+      if (tid == 0) s_cnt = cur + tot;
+      group_sync<NT>();
     }
     P = s_cnt;
-    for (int j = threadIdx.x; j < P; j += kThreads) s_idx[j] = s_tmp[j];
-    __syncthreads();
+    for (int j = tid; j < P; j += NT) s_idx[j] = s_tmp[j];
+    group_sync<NT>();
   }
 
   // ---- D/E/F: prominences, bases, widths, filters (one wave per peak, see the walk helpers) -------
-  for (int p = threadIdx.x / PL_WAVE; p < P; p += kThreads / PL_WAVE) {
+  for (int p = tid / PL_WAVE; p < P; p += NT / PL_WAVE) {
     const int pk = s_idx[p];
     const double xp = xs[pk];
     double left_min, right_min;
@@ -278,7 +303,7 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
     int keep = (!prm.has_prominence || prom >= prm.prominence_min) ? 1 : 0;
     const Widths wd = peak_width(xs, pk, lb, rb, prom, prm.rel_height);
     keep = keep && (wd.width >= prm.width_min);
-    if ((threadIdx.x & (PL_WAVE - 1)) == 0) {
+    if ((tid & (PL_WAVE - 1)) == 0) {
       s_prom[p] = prom;
       s_width[p] = wd.width;
       s_lb[p] = lb;
@@ -286,13 +311,13 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
       s_keep[p] = keep;
     }
   }
-  __syncthreads();
+  group_sync<NT>();
 
   // ---- G: keep the max_number largest by key (np.argsort(kind=stable)[::-1][:max_number]) ------
   if (prm.max_number > 0) {
     // s_keep is read-only during the ranking; a peak to drop is tagged by complementing its
     // (non-negative) right base, then untagged after the barrier.
-    for (int p = threadIdx.x; p < P; p += kThreads) {
+    for (int p = tid; p < P; p += NT) {
       if (!s_keep[p]) continue;
       const double kp = prm.sort_key == PL_SORT_PROMINENCES ? s_prom[p]
                         : prm.sort_key == PL_SORT_PEAK_HEIGHTS ? xs[s_idx[p]] : s_width[p];
@@ -305,36 +330,36 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
       }
       if (ahead >= prm.max_number) s_rb[p] = ~s_rb[p];
     }
-    __syncthreads();
-    for (int p = threadIdx.x; p < P; p += kThreads)
+    group_sync<NT>();
+    for (int p = tid; p < P; p += NT)
       if (s_rb[p] < 0) { s_rb[p] = ~s_rb[p]; s_keep[p] = 0; }
-    __syncthreads();
+    group_sync<NT>();
   }
 
   // ---- H: ordered output: destinations by an ordered scan, then one wave per kept peak ---------------
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
-  for (int base = 0; base < P; base += kThreads) {
-    const int p = base + threadIdx.x;
+  if (tid == 0) s_cnt = 0;
+  group_sync<NT>();
+  for (int base = 0; base < P; base += NT) {
+    const int p = base + tid;
     const int flag = (p < P) ? s_keep[p] : 0;
     int tot;
-    const int off = block_flag_scan(flag, &tot, &scan);
+    const int off = block_flag_scan<NT>(flag, &tot, &scan, tid);
     const int cur = s_cnt;
     if (p < P) s_keep[p] = flag ? (cur + off + 1) : 0;   // destination + 1
-    __syncthreads();
-    if (threadIdx.x == 0) s_cnt = cur + tot;
-    __syncthreads();
+    group_sync<NT>();
+    if (tid == 0) s_cnt = cur + tot;
+    group_sync<NT>();
   }
   int32_t* o_idx = d_idx + prof * cap;
   int32_t* o_lb = d_lb + prof * cap;
   int32_t* o_rb = d_rb + prof * cap;
   double* o_p = d_props + prof * 6 * (int64_t)cap;
-  for (int p = threadIdx.x / PL_WAVE; p < P; p += kThreads / PL_WAVE) {
+  for (int p = tid / PL_WAVE; p < P; p += NT / PL_WAVE) {
     const int dst = s_keep[p] - 1;
     if (dst < 0 || dst >= cap) continue;                 // wave-uniform
     const int pk = s_idx[p];
     const Widths wd = peak_width(xs, pk, s_lb[p], s_rb[p], s_prom[p], prm.rel_height);
-    if ((threadIdx.x & (PL_WAVE - 1)) == 0) {
+    if ((tid & (PL_WAVE - 1)) == 0) {
       o_idx[dst] = pk + lo;  // only the indices are shifted (pylinac/core/profile.py:2613)
       o_lb[dst] = s_lb[p];
       o_rb[dst] = s_rb[p];
@@ -346,7 +371,7 @@ find_peaks_kernel(const double* __restrict__ x, int len_all, const int32_t* __re
       o_p[5 * cap + dst] = wd.rip;
     }
   }
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     const int total = s_cnt;
     d_count[prof] = total < cap ? total : cap;
     d_status[prof] = overflow ? 2 : (total > cap ? 1 : 0);
@@ -439,23 +464,30 @@ extern "C" int pl_find_peaks_regions(const double* d_x, int64_t n, int len, cons
   if (maxc > kMaxCand) maxc = kMaxCand;
   const int stage_x = (m <= kStageMax) ? 1 : 0;
   size_t lds = (size_t)maxc * (8 + 8 + 4 * 4) + 8 + (stage_x ? (size_t)m * 8 : 0);
+  lds = (lds + 15) & ~(size_t)15;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)find_peaks_kernel<true>,
+    hipError_t e = hipFuncSetAttribute((const void*)find_peaks_kernel<true, kThreads>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)find_peaks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      e = hipFuncSetAttribute((const void*)find_peaks_kernel<false, kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               150 * 1024);
     if (e != hipSuccess) { pl_set_error("pl_find_peaks: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
     attr_set = true;
   }
-  if (stage_x)
-    hipLaunchKernelGGL(find_peaks_kernel<true>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
-                       len, d_lens, d_regions, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base,
-                       d_props, d_status);
+  if (stage_x && m <= kShortMax)
+    // short profiles (picket-fence windows, 38 samples each, half a million per batch): one WAVE per profile, four
+    // profiles per workgroup, no workgroup barrier anywhere
+    hipLaunchKernelGGL((find_peaks_kernel<true, PL_WAVE>), dim3((unsigned)pl_cdiv(n, kThreads / PL_WAVE)), dim3(kThreads),
+                       lds * (kThreads / PL_WAVE), (hipStream_t)stream, d_x, n, (int)lds, len, d_lens, d_regions, stride,
+                       *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base, d_props, d_status);
+  else if (stage_x)
+    hipLaunchKernelGGL((find_peaks_kernel<true, kThreads>), dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
+                       n, (int)lds, len, d_lens, d_regions, stride, *params, cap, maxc, d_count, d_idx, d_left_base,
+                       d_right_base, d_props, d_status);
   else
-    hipLaunchKernelGGL(find_peaks_kernel<false>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
-                       len, d_lens, d_regions, stride, *params, cap, maxc, d_count, d_idx, d_left_base, d_right_base,
-                       d_props, d_status);
+    hipLaunchKernelGGL((find_peaks_kernel<false, kThreads>), dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_x,
+                       n, (int)lds, len, d_lens, d_regions, stride, *params, cap, maxc, d_count, d_idx, d_left_base,
+                       d_right_base, d_props, d_status);
   return pl_check_launch("pl_find_peaks");
 }

@@ -33,10 +33,52 @@ scaled_colmean_kernel(const unsigned short* __restrict__ in, int h, int w, int c
   const int c = ct * kThreads + threadIdx.x;
   if (c >= w) return;
   const unsigned short* p = in + frame * (size_t)h * w + c;
-  const double s = sub[frame], d = div[frame];
+  const PlQuot k = pl_quot_make(sub[frame], div[frame]);
   double acc = 0.0;
-  for (int r = 0; r < h; ++r) acc = acc + ((double)p[(size_t)r * w] - s) / d;   // numpy adds row by row
+  for (int r = 0; r < h; ++r) acc = acc + pl_quot(k, (double)p[(size_t)r * w]);   // numpy adds row by row
   out[frame * w + c] = acc / (double)h;
+}
+
+// width % 4 == 0: a lane owns FOUR adjacent columns (one 8-byte load per row: 512 B per wave and row instead of 128) and
+// keeps sixteen rows of loads in flight; the four sums are independent chains, each still row by row like numpy's.
+// Round 1-3's one-column lanes reached 1 TB/s (a dependent float64 division per row and 128-byte wave loads).
+__global__ void __launch_bounds__(kThreads)
+scaled_colmean4_kernel(const unsigned short* __restrict__ in, int h, int w, int64_t total_quads,
+                       const double* __restrict__ sub, const double* __restrict__ div, double* __restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= total_quads) return;
+  const int qpr = w >> 2;
+  const size_t frame = (size_t)(g / qpr);
+  const int c = (int)(g % qpr) * 4;
+  const unsigned short* p = in + frame * (size_t)h * w + c;
+  const PlQuot k = pl_quot_make(sub[frame], div[frame]);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  constexpr int U = 16;
+  int r = 0;
+  for (; r + U <= h; r += U) {
+    uint2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const uint2*>(p + (size_t)(r + u) * w);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a0 = a0 + pl_quot(k, (double)(v[u].x & 0xffffu));
+      a1 = a1 + pl_quot(k, (double)(v[u].x >> 16));
+      a2 = a2 + pl_quot(k, (double)(v[u].y & 0xffffu));
+      a3 = a3 + pl_quot(k, (double)(v[u].y >> 16));
+    }
+  }
+  for (; r < h; ++r) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p + (size_t)r * w);
+    a0 = a0 + pl_quot(k, (double)(v.x & 0xffffu));
+    a1 = a1 + pl_quot(k, (double)(v.x >> 16));
+    a2 = a2 + pl_quot(k, (double)(v.y & 0xffffu));
+    a3 = a3 + pl_quot(k, (double)(v.y >> 16));
+  }
+  double* o = out + frame * (size_t)w + c;
+  o[0] = a0 / (double)h;
+  o[1] = a1 / (double)h;
+  o[2] = a2 / (double)h;
+  o[3] = a3 / (double)h;
 }
 
 __global__ void pf_pickets_kernel(const int32_t* __restrict__ count, const double* __restrict__ props, int cap,
@@ -161,12 +203,12 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  const double s = sub[frame], d = div[frame];
-  auto q = [&](int r, int c) { return ((double)sw[r * ncols + c] - s) / d; };
+  const PlQuot kq = pl_quot_make(sub[frame], div[frame]);
+  auto q = [&](int r, int c) { return pl_quot(kq, (double)sw[r * ncols + c]); };
 
   // np.max(window) > height_threshold * picket_peak_val   (q is monotone in the integer pixel)
   vmax = pl_wave_reduce(vmax, [](int a, int b) { return a > b ? a : b; });
-  const bool above = (((double)vmax - s) / d) > height_threshold * pk_val[frame * cap + pi];
+  const bool above = pl_quot(kq, (double)vmax) > height_threshold * pk_val[frame * cap + pi];
 
   // np.std(window, axis=1) with numpy's pairwise summation order (one block of ncols <= 128 values: eight running sums
   // r[j] over elements j, j+8, ..., combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 tail).  EIGHT lanes
@@ -257,8 +299,8 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
         if (rank == k_hi) v_hi = va;
       }
     }
-    const double qh = ((double)v_hi - s) / d;
-    pvr[slot] = (nrows & 1) ? qh : ((((double)v_lo - s) / d) + qh) / 2.0;
+    const double qh = pl_quot(kq, (double)v_hi);
+    pvr[slot] = (nrows & 1) ? qh : (pl_quot(kq, (double)v_lo) + qh) / 2.0;
   }
   // ground (values - min) then normalize (/ max of the grounded profile)
   const bool has0 = lane < ncols, has1 = lane + PL_WAVE < ncols;
@@ -292,6 +334,12 @@ extern "C" int pl_scaled_colmean(const uint16_t* in, int64_t n, int h, int w, co
   if (n == 0) return PL_OK;
   const int col_tiles = (int)pl_cdiv(w, kThreads);
   PL_REQUIRE(n * col_tiles <= 0x7fffffffLL, "batch too large");
+  if ((w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 7) == 0) {
+    const int64_t quads = n * (int64_t)(w >> 2);
+    hipLaunchKernelGGL(scaled_colmean4_kernel, dim3((unsigned)pl_cdiv(quads, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       in, h, w, quads, d_sub, d_div, d_out);
+    return pl_check_launch("pl_scaled_colmean");
+  }
   hipLaunchKernelGGL(scaled_colmean_kernel, dim3((unsigned)(n * col_tiles)), dim3(kThreads), 0, (hipStream_t)stream,
                      in, h, w, col_tiles, d_sub, d_div, d_out);
   return pl_check_launch("pl_scaled_colmean");

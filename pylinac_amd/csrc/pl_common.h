@@ -134,6 +134,35 @@ __device__ __forceinline__ void pl_buffer_store_u128(uint4 v, __amdgpu_buffer_rs
 __device__ __forceinline__ int pl_wave_from_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int pl_wave_from_next(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
 
+// q = (a - s) / d, the float64 quotient every picket-fence kernel evaluates per pixel (ground() / normalize() folded in:
+// s = the frame's minimum, d = max - min).  A float64 division is ~12 instructions, several of them quarter rate; when s and
+// d are integers of the uint16 range (d >= 1) the correctly rounded quotient is three full-rate operations:
+//   q0 = x * r;  rem = fma(-q0, d, x);  q = fma(rem, r, q0)      with r = RN(1 / d), x = a - s (exact)
+// (Markstein's correction step).  That this equals RN(x / d) for EVERY integer |x| <= 65535 and d in [1, 65535] is checked
+// exhaustively (4.3e9 pairs, tests/fma_quotient_check.c, run by the CPU suite).  Anything else divides.
+struct PlQuot {
+  double s, d, r;
+  bool fast;
+};
+__device__ __forceinline__ PlQuot pl_quot_make(double s, double d) {
+  PlQuot k;
+  k.s = s;
+  k.d = d;
+  k.fast = d >= 1.0 && d <= 65535.0 && d == floor(d) && s >= 0.0 && s <= 65535.0 && s == floor(s);
+  k.r = k.fast ? 1.0 / d : 0.0;
+  return k;
+}
+// `a` must be an integer of the uint16 range when k.fast (the callers pass pixels of uint16 frames)
+__device__ __forceinline__ double pl_quot(const PlQuot& k, double a) {
+  const double x = a - k.s;
+  if (k.fast) {
+    const double q0 = x * k.r;
+    const double rem = fma(-q0, k.d, x);
+    return fma(rem, k.r, q0);
+  }
+  return x / k.d;
+}
+
 // wave-level reductions (64 lanes, xor butterflies -> every lane holds the result)
 template <typename T, typename F>
 __device__ __forceinline__ T pl_wave_reduce(T v, F f) {

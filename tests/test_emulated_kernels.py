@@ -521,6 +521,12 @@ def test_emulated_find_peaks_sweep(emulated):
             x = np.linspace(0, 1, L)
             profs.append(sum(np.exp(-0.5 * ((x - c) / 0.03) ** 2) * a for c, a in ((0.2, 1.0), (0.5, 0.7), (0.8, 1.3)))
                          + rng.normal(0, 0.01, L))
+    rng2 = np.random.default_rng(22)          # either side of the one-wave-per-profile limit (128 samples), no exact ties
+    for L in (127, 128, 129):
+        x = np.linspace(0, 1, L)
+        profs.append(rng2.random(L))
+        profs.append(sum(np.exp(-0.5 * ((x - c) / 0.03) ** 2) * a for c, a in ((0.2, 1.0), (0.5, 0.7), (0.8, 1.3)))
+                     + rng2.normal(0, 0.01, L))
     combos = [dict(), dict(threshold=0.3, peak_separation=0.05), dict(threshold=0.5, peak_separation=3, max_number=2),
               dict(fwxm_height=0.8, max_number=1), dict(threshold=0.1, required_prominence=0.2, peak_sort="peak_heights"),
               dict(search_region=(0.2, 0.9), threshold=0.2), dict(min_width=2, peak_separation=0.02)]

@@ -130,3 +130,16 @@ def test_batched_phantom_axis_fits_are_polyfit_per_volume():
         for v in range(nv):
             zx, zy, _ = ct.find_phantom_axis_volume(None, 0.5, roi=roi[v * spv:(v + 1) * spv])
             assert np.array_equal(fzx[v], zx) and np.array_equal(fzy[v], zy)
+
+
+def test_fma_quotient_identity_exhaustive(tmp_path):
+    """The three-operation quotient of pl_quot (csrc/pl_common.h) == float64 division for all 65536 x 65535 integer pairs
+    the picket-fence kernels can meet (tests/fma_quotient_check.c, gcc; a few seconds on 8 cores)."""
+    import subprocess
+    from pathlib import Path
+
+    src = Path(__file__).resolve().parent / "fma_quotient_check.c"
+    exe = tmp_path / "fma_quotient_check"
+    subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout + r.stderr
