@@ -134,6 +134,37 @@ __device__ __forceinline__ double pairwise_sum_block(int n, F at) {
   return res;
 }
 
+// Middle order statistics of a window column (n <= N rows, pitch `pitch` in LDS) by Batcher's odd-even merge sort on N
+// registers: lo = sorted[N/2 - 1], hi = sorted[N/2] of the column padded with floor((N - n) / 2) values of -1 in front and
+// INT_MAX behind.  For even n these are the two middle values, for odd n `lo` is THE median.
+template <int N>
+__device__ __forceinline__ void pf_column_median(const unsigned short* col, int pitch, int n, int& lo, int& hi) {
+  int v[N];
+  const int pad_lo = (N - n) >> 1;
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    const int r = a - pad_lo;                        // wave-uniform; the read itself is unconditional (clamped row)
+    const int rc = r < 0 ? 0 : (r < n ? r : n - 1);
+    const int x = (int)col[rc * pitch];
+    v[a] = r < 0 ? -1 : (r < n ? x : 0x7fffffff);
+  }
+#pragma unroll
+  for (int p = 1; p < N; p <<= 1)
+#pragma unroll
+    for (int k = p; k >= 1; k >>= 1)
+#pragma unroll
+      for (int j = k % p; j + k < N; j += 2 * k)
+#pragma unroll
+        for (int i = 0; i < k; ++i)
+          if (i + j + k < N && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+            const int x = v[i + j], y = v[i + j + k];
+            v[i + j] = x < y ? x : y;
+            v[i + j + k] = x < y ? y : x;
+          }
+  lo = v[N / 2 - 1];
+  hi = v[N / 2];
+}
+
 __global__ void __launch_bounds__(kThreads)
 pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const double* __restrict__ sub,
                   const double* __restrict__ div, const int32_t* __restrict__ pk_count,
@@ -144,25 +175,28 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
                   double* __restrict__ offset_out, int32_t* __restrict__ status_out, int64_t total_windows) {
   __shared__ unsigned short s_win[kThreads / PL_WAVE][kMaxRows * kMaxCols];
   __shared__ double s_std[kThreads / PL_WAVE][kMaxRows];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t win = (int64_t)blockIdx.x * (kThreads / PL_WAVE) + wv;
-  if (win >= total_windows) return;
-  const int pi = (int)(win % cap);
-  const int li = (int)((win / cap) % nleaves);
-  const int64_t frame = win / ((int64_t)cap * nleaves);
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // window index in 32 bits (the launcher refuses more: the profiles of 2^31 windows would be 2 TB), wave-uniform: scalar
+  const unsigned win = blockIdx.x * (unsigned)(kThreads / PL_WAVE) + (unsigned)wv;
+  if ((int64_t)win >= total_windows) return;
+  const int pi = (int)(win % (unsigned)cap);
+  const int li = (int)((win / (unsigned)cap) % (unsigned)nleaves);
+  const int64_t frame = win / ((unsigned)cap * (unsigned)nleaves);
   int status = 0;   // 0 valid, 1 no such picket, 2 failed _is_mlc_peak_in_window, 3 window too large / empty
-  double* pout = prof_out + win * lmax;
+  double* pout = prof_out + (size_t)win * lmax;
   if (pi >= pk_count[frame]) {
     if (lane == 0) { status_out[win] = 1; len_out[win] = 0; offset_out[win] = 0.0; }
     return;
   }
   const double approx = (double)pk_idx[frame * cap + pi];
   const double sp = spacing[frame];
-  const int top = leaf_top[li], bottom = leaf_bottom[li];
+  const int top = __builtin_amdgcn_readfirstlane(leaf_top[li]), bottom = __builtin_amdgcn_readfirstlane(leaf_bottom[li]);
   int left = (int)(approx - sp / 2);            // python int(): truncation toward zero
   if (left < 0) left = 0;
   int right = (int)(approx + sp / 2);
   if (right > w) right = w;
+  left = __builtin_amdgcn_readfirstlane(left);     // the window geometry is the wave's: keep it in scalar registers
+  right = __builtin_amdgcn_readfirstlane(right);
   const int nrows = bottom - top, ncols = right - left;
   const double off = (approx - sp / 2 > 0.0) ? (approx - sp / 2) : 0.0;   // max(approx_idx - spacing/2, 0)
   if (nrows <= 0 || ncols <= 2 || nrows > kMaxRows || ncols > kMaxCols || !(sp == sp)) {
@@ -275,18 +309,14 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
     if (c >= ncols) continue;
     const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
     int v_lo = 0, v_hi = 0;
-    if (nrows <= 16) {                               // wave-uniform; the usual leaf height: the column lives in registers
-      int col[16];
-#pragma unroll
-      for (int a = 0; a < 16; ++a) col[a] = a < nrows ? (int)sw[a * ncols + c] : 0x7fffffff;   // padding ranks last
-#pragma unroll
-      for (int a = 0; a < 16; ++a) {
-        int rank = 0;
-#pragma unroll
-        for (int b = 0; b < 16; ++b) rank += (b < a ? col[b] <= col[a] : col[b] < col[a]) ? 1 : 0;   // ties: lower index first
-        if (a < nrows && rank == k_lo) v_lo = col[a];
-        if (a < nrows && rank == k_hi) v_hi = col[a];
-      }
+    if (nrows <= 32) {                               // wave-uniform; every leaf of the Millennium / HD / Agility banks at EPID scale
+      // A sorting network on the column in registers.  The column is padded to N values with floor((N - n) / 2) values below
+      // every pixel and the rest above: the middle order statistics then sit at the FIXED positions N/2 - 1 and N/2 (n even)
+      // or N/2 - 1 alone (n odd), so the compiler drops every compare-exchange the two outputs do not depend on.  Rounds 1-3
+      // ranked by counting (n^2 LDS reads beyond 16 rows: 20 us for a 26-row leaf).
+      if (nrows <= 16) pf_column_median<16>(sw + c, ncols, nrows, v_lo, v_hi);
+      else pf_column_median<32>(sw + c, ncols, nrows, v_lo, v_hi);
+      if (nrows & 1) v_hi = v_lo;
     } else {
       for (int a = 0; a < nrows; ++a) {
         const int va = sw[a * ncols + c];
@@ -366,7 +396,7 @@ extern "C" int pl_pf_windows(const uint16_t* in, int64_t n, int h, int w, const 
   if (n == 0) return PL_OK;
   const int64_t total = n * (int64_t)nleaves * cap;
   const int64_t blocks = pl_cdiv(total, kThreads / PL_WAVE);
-  PL_REQUIRE(blocks <= 0x7fffffffLL, "batch too large");
+  PL_REQUIRE(total <= 0x7fffffffLL, "batch too large");
   hipLaunchKernelGGL(pf_windows_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, in, h, w,
                      d_sub, d_div, d_pk_count, d_pk_idx, d_pk_val, cap, d_spacing, d_leaf_top, d_leaf_bottom, nleaves,
                      height_threshold, edge_threshold, lmax, d_prof, d_len, d_offset, d_status, total);

@@ -738,6 +738,19 @@ def test_emulated_picket_fence_random_frames(emulated):
         pos = res.position[0, :, :P].cpu().numpy()
         assert np.array_equal(np.isnan(pos), np.isnan(ref["position"])), k
         assert np.array_equal(pos[~np.isnan(pos)], ref["position"][~np.isnan(pos)]), k
+    # leaf heights either side of the column-median networks: MLCi leaves (10 mm) at 0.4 mm -> 25 rows (32-value network),
+    # at 0.26 mm -> 38 rows (beyond the networks: rank counting), Millennium at 0.8 mm -> 6 / 12 rows (16-value network)
+    for k, (pixel, mlc, h, w) in enumerate([(0.4, "MLCI", 150, 300), (0.26, "MLCI", 160, 360), (0.8, "MILLENNIUM", 130, 280)]):
+        frame = pf_frame(h + 8, w + 8, pixel, 4100 + k, n_pickets=4, spacing_mm=w * pixel / 6, gap_mm=3.0)[4:-4, 4:-4]
+        frame = np.ascontiguousarray(frame)
+        res = ppf.analyze_batch(torch.from_numpy(frame[None]).to(emulated), 1 / pixel, mlc=mlc)
+        ref = orc.pf_measure(orc.normalize(orc.ground(frame)), 1 / pixel, mlc=mlc)
+        P = len(ref["peak_idxs"])
+        assert int(res.picket_count[0]) == P and P >= 3, (k, P)
+        pos = res.position[0, :, :P].cpu().numpy()
+        assert np.isfinite(pos).sum() >= P, k
+        assert np.array_equal(np.isnan(pos), np.isnan(ref["position"])), k
+        assert np.array_equal(pos[~np.isnan(pos)], ref["position"][~np.isnan(pos)]), k
 
 
 def test_emulated_wl_field_xim_gamma_random(emulated):
