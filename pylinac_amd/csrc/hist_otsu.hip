@@ -262,6 +262,14 @@ otsu_kernel(const uint32_t* __restrict__ hist, int bias, int32_t* __restrict__ t
 #define PL_OTSU_VARIANT 0
 #endif
 constexpr int kWinBins = 38912;   // 152 KiB
+struct OtsuScratch {
+  Pair wave_tot[kHistThreads / 64];
+  double s_var[kHistThreads / 64];
+  int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64], s_idx[kHistThreads / 64];
+  int any;
+};
+constexpr int kOtsuScratchAt = ((kWinBins + 1) * 4 + 15) & ~15;
+constexpr size_t kOtsuLds = kOtsuScratchAt + sizeof(OtsuScratch);
 
 // MED3: the histogram is that of the 3x3 MEDIAN of the frame (h x w, geometry of pl_median3_rows_covers), computed on the
 // fly by pl_median3_rows -- the median plane is never written (the window is still placed from a sample of the raw frame: a
@@ -271,11 +279,15 @@ __global__ void __launch_bounds__(kHistThreads)
 otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h, int w, unsigned flip, int bias,
                      const int32_t* __restrict__ lo_hint, const int32_t* __restrict__ hi_hint, int32_t* __restrict__ thr,
                      int32_t* __restrict__ vmin, int32_t* __restrict__ vmax, int32_t* __restrict__ flag) {
-  extern __shared__ unsigned bins[];  // kWinBins + 1
-  __shared__ Pair wave_tot[kHistThreads / 64];
-  __shared__ int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64];
-  __shared__ double s_var[kHistThreads / 64];
-  __shared__ int s_idx[kHistThreads / 64];
+  // ALL of the kernel's LDS is the dynamic block: the bins start at LDS address 0, so a bin's byte offset IS its address
+  // (with static arrays in front the compiler spent one add per pixel on the base), the reduction scratch sits behind them
+  extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // kWinBins + 1, then OtsuScratch
+  OtsuScratch& scr = *reinterpret_cast<OtsuScratch*>(reinterpret_cast<unsigned char*>(bins) + kOtsuScratchAt);
+  Pair* const wave_tot = scr.wave_tot;
+  int* const s_lo = scr.s_lo;
+  int* const s_hi = scr.s_hi;
+  double* const s_var = scr.s_var;
+  int* const s_idx = scr.s_idx;
   const int64_t frame = blockIdx.x;
   const unsigned short* src = in + frame * count;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -321,11 +333,13 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     if (slack < 0) khi = klo + kWinBins;   // too wide: fails the range test below
   }
   const int range = khi - klo + 1;
-  if (range > kWinBins || range <= 0 || klo < 0 || khi > 65535) {
+  // (MED3 addresses the bins by absolute LDS address: they must start the workgroup's LDS -- else the two-kernel path)
+  if (range > kWinBins || range <= 0 || klo < 0 || khi > 65535 || (MED3 && pl_lds_base(bins) != 0u)) {
     if (threadIdx.x == 0) flag[frame] = 1;
     return;
   }
   for (int i = threadIdx.x; i <= range; i += kHistThreads) bins[i] = 0;      // + the spare bin at index `range`
+  if (threadIdx.x == 0) scr.any = 0;
   __syncthreads();
 
   int outside = 0;
@@ -338,46 +352,50 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     // every wave walks (column block of 512, row group of 32) items; all 64 lanes take part in the median's cross-lane moves,
     // lanes beyond the frame's width tally nothing
     constexpr int kRows = 32;                        // rows per item: two halo rows are re-read per item
-    const unsigned klo4 = 4u * (unsigned)klo;
+    constexpr int kSBias = ((T)-1 < (T)0) ? 32768 : 0;          // median (sign-extended for int16) -> key of the biased domain
+    const unsigned kbase4 = 4u * (unsigned)(kSBias - klo);
 #if PL_OTSU_VARIANT & 1
     unsigned dummy = 0;
 #endif
     const int col_waves = (w / 8 + PL_WAVE - 1) / PL_WAVE, row_groups = (h + kRows - 1) / kRows;
-    for (int item = wv; item < col_waves * row_groups; item += kHistThreads / 64) {
+    for (int item = __builtin_amdgcn_readfirstlane(wv); item < col_waves * row_groups; item += kHistThreads / 64) {   // scalar
       const int c0 = ((item % col_waves) * PL_WAVE + lane) * 8;
       const bool on = c0 < w;
+      // per item: which lanes hold columns of the frame (all of them unless w / 8 is not a multiple of 64)
+      const unsigned long long act = __ballot(on);
+      if (act == 0ull) continue;
+      const int first_on = __builtin_ctzll(act);
+      const unsigned cap4 = on ? 4u * (unsigned)range : 0u;      // lanes beyond the frame add 0 to bin 0
+      const unsigned inc = on ? 1u : 0u;
       pl_median3_rows<T, kRows, PL_OTSU_AHEAD>(reinterpret_cast<const T*>(src), h, w, c0, lane, (item / col_waves) * kRows,
-                             [&](int, const unsigned (&pk)[4]) {
-        const unsigned first = pk[0] & 0xffffu;
-        const unsigned splat = first | (first << 16);
-        const unsigned spread = (pk[0] ^ splat) | (pk[1] ^ splat) | (pk[2] ^ splat) | (pk[3] ^ splat);
-        const unsigned long long act = __ballot(on);
-        if (act == 0ull) return;
-        const unsigned wave_first = (unsigned)__builtin_amdgcn_readlane((int)splat, __builtin_ctzll(act));
-        if (__ballot(on && (spread | (splat ^ wave_first)) != 0u) == 0ull) {   // one value in the whole wave: one atomic
-          const unsigned b = ((wave_first & 0xffffu) ^ flip) - (unsigned)klo;
+                             [&](int, const int (&m)[8]) {
+        // one value in the whole wave (saturated / constant neighbourhoods): ONE atomic of 8 x the lane count -- 512 atomics
+        // on one address would serialise
+        unsigned spread = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) spread |= (unsigned)(m[k] ^ m[0]);
+        const int wave_first = __builtin_amdgcn_readlane(m[0], first_on);
+        if (__ballot(on && (spread | (unsigned)(m[0] ^ wave_first)) != 0u) == 0ull) {
+          const unsigned b = (unsigned)(wave_first + kSBias - klo);
           if (b < (unsigned)range) {
-            if (lane == __builtin_ctzll(act)) atomicAdd(&bins[b], 8u * (unsigned)__popcll(act));
+            if (lane == first_on) atomicAdd(&bins[b], 8u * (unsigned)__popcll(act));
           } else {
             outside = 1;
           }
           return;
         }
         // branch-free tally: a value outside the window lands in the spare bin at index `range` (checked after the pass).
-        // Per pixel: extract + scale (x 4: the byte offset of the bin), subtract the window's base, clamp, one LDS atomic
-        const unsigned cap4 = on ? 4u * (unsigned)range : 0u;
-        unsigned char* const base = reinterpret_cast<unsigned char*>(bins);
+        // Per pixel: scale (x 4: the byte offset of the bin IS its LDS address) and subtract the window's base in one
+        // instruction, clamp, one LDS atomic
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned b0 = (((pk[k] & 0xffffu) ^ flip) << 2) - klo4, b1 = (((pk[k] >> 16) ^ flip) << 2) - klo4;
-          if (on) {
+        for (int k = 0; k < 8; ++k) {
+          const unsigned b4 = ((unsigned)m[k] << 2) + kbase4;
+          const unsigned a4 = b4 < cap4 ? b4 : cap4;
 #if PL_OTSU_VARIANT & 1    // stopwatch only: everything but the LDS atomics
-            dummy += (b0 < cap4 ? b0 : cap4) ^ (b1 < cap4 ? b1 : cap4);
+          dummy += a4;
 #else
-            atomicAdd(reinterpret_cast<unsigned*>(base + (b0 < cap4 ? b0 : cap4)), 1u);
-            atomicAdd(reinterpret_cast<unsigned*>(base + (b1 < cap4 ? b1 : cap4)), 1u);
+          pl_lds_add_abs(a4, inc);
 #endif
-          }
         }
       });
     }
@@ -424,11 +442,11 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
   } else {
     for (int64_t i = threadIdx.x; i < count; i += kHistThreads) tally(src[i]);
   }
-  if (MED3) {                        // the branch-free tally counts out-of-window pixels in the spare bin
-    __syncthreads();
-    if (bins[range] != 0u) outside = 1;
-  }
-  if (__syncthreads_or(outside)) {   // a pixel fell outside the window (or outside the caller's bounds): two-kernel path
+  // a pixel fell outside the window (or outside the caller's bounds): two-kernel path.  (__syncthreads_or would bring 256
+  // bytes of static LDS in front of the bins.)  The branch-free tally counts out-of-window pixels in the spare bin.
+  if (outside) scr.any = 1;
+  __syncthreads();
+  if (scr.any != 0 || (MED3 && bins[range] != 0u)) {   // the same for every thread
     if (threadIdx.x == 0) flag[frame] = 1;
     return;
   }
@@ -572,7 +590,7 @@ int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t c
                   hipStream_t st, const char* who) {
   const unsigned flip = dtype == PL_I16 ? 0x8000u : 0u;
   const int bias = dtype == PL_I16 ? 32768 : 0;
-  const size_t lds = (size_t)(kWinBins + 1) * sizeof(unsigned);   // + the spare bin of the branch-free tally
+  const size_t lds = kOtsuLds;                                  // bins + the spare bin of the branch-free tally + scratch
   static std::atomic<bool> attr{false};                        // one flag per instantiation
   if (!attr) {
     if (hipFuncSetAttribute((const void*)otsu16_window_kernel<T, MED3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

@@ -200,8 +200,10 @@ median3_oct_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w, 
     const bool active = c0 < w;                      // w % 8 == 0: all 8 inside or none
     const T* f = in + frame * (size_t)h * w;
     T* o = out + frame * (size_t)h * w;
-    pl_median3_rows<T, ROWS>(f, h, w, c0, lane, rg * ROWS, [&](int r, const unsigned (&pk)[4]) {
-      if (active) *reinterpret_cast<uint4*>(o + (size_t)r * w + c0) = uint4{pk[0], pk[1], pk[2], pk[3]};
+    pl_median3_rows<T, ROWS>(f, h, w, c0, lane, rg * ROWS, [&](int r, const int (&m)[8]) {
+      if (active)
+        *reinterpret_cast<uint4*>(o + (size_t)r * w + c0) =
+            uint4{pl_pack16(m[0], m[1]), pl_pack16(m[2], m[3]), pl_pack16(m[4], m[5]), pl_pack16(m[6], m[7])};
     });
   }
 }

@@ -5,30 +5,39 @@
 //
 // A lane owns EIGHT consecutive columns (one 16-byte load per row) and slides down ROWS rows; the column to the left / right
 // of its block comes from the neighbouring lane (one cross-lane move each; only the first and last lane of a wave fetch theirs
-// from memory).  Each new row contributes SORTED horizontal triples (min3 / med3 / max3), kept in registers for three rows;
+// from memory, with one masked load).  Each new row contributes SORTED horizontal triples (min3 / med3 / max3), kept in registers for three rows;
 // median of nine = med3(max3(lows), med3(mids), min3(highs)).  EVERY lane of the wave must call this (cross-lane moves); a
 // lane whose block lies beyond the frame (c0 >= w) computes on a clamped address and its values are meaningless.
 // Needs w % 8 == 0, 16-byte aligned rows, h > 1.
 #pragma once
 // (included after pl_common.h by every user)
 
-// consume(r, pk): pk[k] = medians of columns c0 + 2k (low half) and c0 + 2k + 1 (high half) of row r, raw 16-bit patterns.
+// consume(r, m): m[j] = median of column c0 + j of row r (the value itself: sign-extended for int16 frames).
 // AHEAD rows are in flight as raw 16-byte loads before their turn (the consumers that run few waves per CU -- one workgroup
 // per frame for the Otsu histogram -- would otherwise pay the full memory latency once per row).
+// `r0` (first output row) must be the same in every lane of the wave: it is moved to a scalar register here, so the row
+// walk -- reflection at the frame's first / last row and the row pointers -- is scalar arithmetic (rounds 1-3 did a general
+// reflect with its integer division, and a 64-bit multiply, per lane and row: ~45 of the 180 vector instructions per row).
 template <typename T, int ROWS, int AHEAD = 4, typename F>
-__device__ __forceinline__ void pl_median3_rows(const T* __restrict__ f, int h, int w, int c0, int lane, int r0, F&& consume) {
+__device__ __forceinline__ void pl_median3_rows(const T* __restrict__ f, int h, int w, int c0, int lane, int r0_lane, F&& consume) {
   static_assert(sizeof(T) == 2, "16-bit dtypes");
+  const int r0 = __builtin_amdgcn_readfirstlane(r0_lane);
   const bool active = c0 < w;
   const unsigned offc = (unsigned)(active ? c0 : 0) * 2u;
   const bool first = c0 == 0, last = c0 + 8 >= w;
+  // the column left of lane 0's block / right of lane 63's comes from memory: ONE masked 2-byte load per row serves both
   const bool edge_l = lane == 0 && !first, edge_r = lane == PL_WAVE - 1 && !last && active;
-  struct Raw { uint4 q; int el, er; };
-  auto fetch = [&](int r) {                         // row r0 - 1 + k of the walk
-    const char* row = reinterpret_cast<const char*>(f + (size_t)pl_reflect(r, h) * w);  // wave-uniform
+  const bool edge = edge_l || edge_r;
+  const unsigned offe = edge_l ? offc - 2u : offc + 16u;
+  struct Raw { uint4 q; int e; };
+  auto fetch = [&](int r) {                         // row r of the walk; only rows -1 and h are ever reflected INTO a result,
+    const int rm = 2 * h - 1 - r;                   // rows beyond (digested, never consumed) just need a valid address
+    int rr = r < rm ? r : rm;
+    rr = rr > 0 ? rr : 0;
+    const char* row = reinterpret_cast<const char*>(f) + (size_t)rr * (size_t)w * 2u;   // scalar
     Raw x;
     x.q = *reinterpret_cast<const uint4*>(row + offc);
-    x.el = edge_l ? (int)*reinterpret_cast<const T*>(row + offc - 2) : 0;
-    x.er = edge_r ? (int)*reinterpret_cast<const T*>(row + offc + 16) : 0;
+    x.e = edge ? (int)*reinterpret_cast<const T*>(row + offe) : 0;
     return x;
   };
   int lo[3][8], mi[3][8], hi[3][8];
@@ -40,9 +49,9 @@ __device__ __forceinline__ void pl_median3_rows(const T* __restrict__ f, int h, 
       v[1 + 2 * k] = (int)(T)(wd[k] & 0xffffu);
       v[2 + 2 * k] = (int)(T)(wd[k] >> 16);
     }
-    int left = pl_wave_from_prev(v[8]), right = pl_wave_from_next(v[1]);
-    if (edge_l) left = x.el;
-    if (edge_r) right = x.er;
+    // lane 0 / lane 63 have no neighbour in the wave: the DPP move leaves them `old` = the value loaded for them
+    const int left = __builtin_amdgcn_update_dpp(x.e, v[8], 0x138, 0xf, 0xf, false);    // wave_shr:1
+    const int right = __builtin_amdgcn_update_dpp(x.e, v[1], 0x130, 0xf, 0xf, false);   // wave_shl:1
     v[0] = first ? v[1] : left;     // reflect: column -1 -> column 0
     v[9] = last ? v[8] : right;     // column w -> column w-1
 #pragma unroll
@@ -64,21 +73,17 @@ __device__ __forceinline__ void pl_median3_rows(const T* __restrict__ f, int h, 
     if (k < 2) continue;
     const int r = r0 + k - 2;
     if (r >= h) continue;                           // wave-uniform
-    unsigned pk[4];
+    int m[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int m[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int j = 2 * q + e;
-        m[e] = pl_smed3(max(max(lo[0][j], lo[1][j]), lo[2][j]), pl_smed3(mi[0][j], mi[1][j], mi[2][j]),
-                        min(min(hi[0][j], hi[1][j]), hi[2][j]));
-      }
-      pk[q] = ((unsigned)m[0] & 0xffffu) | ((unsigned)m[1] << 16);
-    }
-    consume(r, pk);
+    for (int j = 0; j < 8; ++j)
+      m[j] = pl_smed3(max(max(lo[0][j], lo[1][j]), lo[2][j]), pl_smed3(mi[0][j], mi[1][j], mi[2][j]),
+                      min(min(hi[0][j], hi[1][j]), hi[2][j]));
+    consume(r, m);
   }
 }
+
+// the 16-bit patterns of two values in one dword (low half = a)
+__device__ __forceinline__ unsigned pl_pack16(int a, int b) { return ((unsigned)a & 0xffffu) | ((unsigned)b << 16); }
 
 // 1 when pl_median3_rows serves this frame geometry
 static inline bool pl_median3_rows_covers(const void* in, int h, int w) {

@@ -172,18 +172,16 @@ median3_threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned 
   __syncthreads();
   unsigned s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rg < h) {                                     // wave-uniform
-    pl_median3_rows<unsigned short, kMtRows>(f, h, w, c0, lane, rg, [&](int r, const unsigned (&pk)[4]) {
+    pl_median3_rows<unsigned short, kMtRows>(f, h, w, c0, lane, rg, [&](int r, const int (&m)[8]) {
       if (!on) return;
-      unsigned q[4];
+      unsigned v[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned a = pk[k] & 0xffffu, b = pk[k] >> 16;
-        const unsigned va = ((int)a >= t) ? a : 0u, vb = ((int)b >= t) ? b : 0u;
-        s[2 * k] += va;
-        s[2 * k + 1] += vb;
-        q[k] = va | (vb << 16);
+      for (int k = 0; k < 8; ++k) {
+        v[k] = m[k] >= t ? (unsigned)m[k] : 0u;
+        s[k] += v[k];
       }
-      *reinterpret_cast<uint4*>(o + (size_t)r * w + c0) = uint4{q[0], q[1], q[2], q[3]};
+      *reinterpret_cast<uint4*>(o + (size_t)r * w + c0) =
+          uint4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
     });
 #pragma unroll
     for (int k = 0; k < 8; ++k) atomicAdd(&s_cs[lane * 8 + k], s[k]);     // 32 rows x 65535 per wave, 4 waves: < 2^32

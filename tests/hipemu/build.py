@@ -36,6 +36,9 @@ _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)
 _WAITCNT = re.compile(r'asm\s+volatile\s*\(\s*"s_waitcnt[^;]*;')
 _MED3 = re.compile(r'asm\("v_med3_[ui]32[^;]*;')
 _PIN = re.compile(r'asm\s+volatile\s*\(\s*""[^;]*;')                      # empty asm: a register-allocation hint
+_LDSABS = re.compile(r'__hip_atomic_fetch_add\(\(pl_lds_u32\*\)byte_addr[^;]*;')   # absolute LDS address -> offset into the emulator's block
+_LDSBASE = re.compile(r'return \(unsigned\)reinterpret_cast<uintptr_t>\(lds_ptr\);')
+_LDSTYPE = re.compile(r'typedef __attribute__\(\(address_space\(3\)\)\) unsigned pl_lds_u32;')
 _OCC = re.compile(r'__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)')   # occupancy target of a kernel
 
 
@@ -44,6 +47,9 @@ def _rewrite(text: str) -> str:
     text = _WAITCNT.sub(";", text)
     text = _PIN.sub(";", text)
     text = _OCC.sub("", text)
+    text = _LDSABS.sub("atomicAdd(reinterpret_cast<unsigned*>(static_cast<unsigned char*>(hipemu::dyn_lds()) + byte_addr), v);", text)
+    text = _LDSBASE.sub("return (unsigned)(static_cast<const unsigned char*>(lds_ptr) - static_cast<const unsigned char*>(hipemu::dyn_lds()));", text)
+    text = _LDSTYPE.sub("", text)
     text = _MED3.sub("r = std::max(std::min(a, b), std::min(std::max(a, b), c));", text)
     # `extern __shared__ T name[];`  ->  a pointer to the emulator's dynamic-LDS buffer
     return _DYN.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(hipemu::dyn_lds());", text)

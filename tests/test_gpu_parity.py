@@ -1827,9 +1827,10 @@ def test_mask_regions_vs_scipy(dev):
     label / regionprops sums, incl. a crowded 512 x 512 frame that must report status 1."""
     import next_row_checks as checks
 
-    checked, _ = checks.check_mask_regions(dev, shapes=((64, 64), (70, 130), (33, 65), (17, 5), (96, 192), (1, 1), (40, 64),
-                                                        (300, 300), (512, 512)))
-    assert checked > 250
+    checked, overflowed = checks.check_mask_regions(dev, shapes=((64, 64), (70, 130), (33, 65), (17, 5), (96, 192), (1, 1), (40, 64),
+                                                                 (300, 300), (512, 512)))
+    # 9 shapes x 7 masks x up to 5 settings; the speckle masks of the two large shapes overflow the run list (status 1)
+    assert checked >= 200 and overflowed >= 10 and checked + overflowed >= 260, (checked, overflowed)
 
 
 @pytest.mark.gpu
