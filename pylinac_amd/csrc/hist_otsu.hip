@@ -532,6 +532,172 @@ order_stats_kernel(const uint32_t* __restrict__ hist, int bias, const int64_t* _
   }
 }
 
+
+// ---- exact 65 536-bin histogram in ONE read of the frame: two LDS windows + global atomics for the rest -----------------
+// hist16_kernel keeps half (or a quarter) of the bins in LDS and reads the frame once per part.  Radiographs are bimodal --
+// an unexposed background and an exposed field, few pixels in between -- so here ONE workgroup per frame holds TWO windows
+// of 19 456 consecutive bins (2 x 76 KiB), placed at the two ends of the value range seen in a 1/16 row sample (one
+// contiguous 38 912-bin window when the range is that narrow); a pixel that falls into neither goes to the frame's table
+// in HBM with a global atomic (exact whatever the sample missed; only slower when many pixels do).  A wave that holds a
+// single value adds its whole count with one atomic (hist16_kernel's flat test); beyond that every wave PEELS a hot value:
+// lanes whose pixel equals the wave's current guess L count it in a register instead of the LDS atomic unit -- the clipped
+// dark noise of a real detector puts half of the background on one value, 30-way same-address serialisation per atomic
+// instruction (the noisy Winston-Lutz frames: 0.90 ms per 256 frames with hist16_kernel<2> against 0.47 without noise).
+// The guess is replaced by the first lane's pixel whenever it attracted less than 1/16 of the last 64 pixels per lane.
+constexpr int kTwBins = 19456;                               // bins per window
+struct TwScratch { int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64]; };
+constexpr int kTwScratchAt = (2 * kTwBins + 1 + PL_WAVE + 3) / 4 * 16;   // two windows, the spare bin, one dummy bin per lane
+constexpr size_t kTwLds = kTwScratchAt + sizeof(TwScratch);
+
+__global__ void __launch_bounds__(kHistThreads)
+hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, unsigned flip, uint32_t* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // 2 * kTwBins, then TwScratch
+  TwScratch& scr = *reinterpret_cast<TwScratch*>(reinterpret_cast<unsigned char*>(bins) + kTwScratchAt);
+  const int64_t frame = blockIdx.x;
+  const unsigned short* src = in + frame * count;
+  uint32_t* row = hist + frame * 65536;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && count >= 8;
+  const int64_t nvec = vec ? count / 8 : 0;
+  const uint4* vsrc = reinterpret_cast<const uint4*>(src);
+
+  for (int i = threadIdx.x; i < 2 * kTwBins; i += kHistThreads) bins[i] = 0;
+  // extrema of a 1/16 sample (blocks of 1024 pixels, every 16th block), as otsu16_window_kernel
+  int mn = 1 << 30, mx = -1;
+  auto see = [&](unsigned key) {
+    const int k = (int)(key ^ flip);
+    mn = k < mn ? k : mn;
+    mx = k > mx ? k : mx;
+  };
+  if (vec) {
+    for (int64_t blk = threadIdx.x >> 7; blk * 2048 < nvec; blk += kHistThreads >> 7) {
+      const int64_t idx = blk * 2048 + (threadIdx.x & 127);
+      if (idx < nvec) {
+        const uint4 q = vsrc[idx];
+        const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { see(wds[k] & 0xffffu); see(wds[k] >> 16); }
+      }
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < count; i += 16LL * kHistThreads) see(src[i]);
+  }
+  mn = pl_wave_reduce(mn, [](int a, int b) { return a < b ? a : b; });
+  mx = pl_wave_reduce(mx, [](int a, int b) { return a > b ? a : b; });
+  if (lane == 0) { scr.s_lo[wv] = mn; scr.s_hi[wv] = mx; }
+  __syncthreads();
+  for (int k = 0; k < kHistThreads / 64; ++k) { mn = scr.s_lo[k] < mn ? scr.s_lo[k] : mn; mx = scr.s_hi[k] > mx ? scr.s_hi[k] : mx; }
+  if (mx < mn) { mn = 0; mx = 0; }
+  // window bases (biased key domain): contiguous [w0, w0 + 2 W) around a narrow range, else one window at each end
+  int w0, w1;
+  if (mx - mn + 1 <= 2 * kTwBins) {
+    w0 = mn - (2 * kTwBins - (mx - mn + 1)) / 2;
+    w0 = w0 < 0 ? 0 : (w0 > 65536 - 2 * kTwBins ? 65536 - 2 * kTwBins : w0);
+    w1 = w0 + kTwBins;
+  } else {
+    w0 = mn - 256 < 0 ? 0 : mn - 256;                // the sample misses the true extrema by a little
+    w1 = mx + 256 > 65535 ? 65536 - kTwBins : mx + 257 - kTwBins;
+    if (w1 < w0 + kTwBins) w1 = w0 + kTwBins;        // (cannot happen for a range wider than two windows; keeps them disjoint)
+  }
+  const unsigned uw0 = (unsigned)w0, uw1 = (unsigned)w1;
+  // the table's bins OUTSIDE the windows start as zeros (they only ever see the global atomics below; the windows' bins are
+  // stored whole at the end): quads of four bins, a quad that lies entirely inside a window is skipped
+  for (int i = threadIdx.x; i < 65536 / 4; i += kHistThreads) {
+    const unsigned b = 4u * (unsigned)i;
+    const bool inside = (b - uw0 < (unsigned)kTwBins && b + 3u - uw0 < (unsigned)kTwBins) ||
+                        (b - uw1 < (unsigned)kTwBins && b + 3u - uw1 < (unsigned)kTwBins);
+    if (!inside) reinterpret_cast<uint4*>(row)[i] = uint4{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();                                   // the zeroed table is in place before any global atomic
+
+  unsigned hot = 0;                                  // this lane's pixels that equalled the wave's guess since the last flush
+  unsigned guess = 0xffffffffu;                      // wave-uniform key (biased domain), none yet
+  auto add_key = [&](unsigned key, unsigned n) {     // n pixels of one key, from one lane (the rare paths)
+    const unsigned b0 = key - uw0, b1 = key - uw1;
+    if (b0 < (unsigned)kTwBins) atomicAdd(&bins[b0], n);
+    else if (b1 < (unsigned)kTwBins) atomicAdd(&bins[kTwBins + b1], n);
+    else atomicAdd(row + key, n);
+  };
+  auto flush = [&]() {                               // the wave's count of its guess -> one atomic
+    const unsigned tot = pl_wave_reduce(hot, [](unsigned a, unsigned b) { return a + b; });
+    if (tot != 0u && lane == 0) add_key(guess, tot);
+    hot = 0;
+    return tot;
+  };
+  // Branch-free per pixel: ONE LDS atomic at an absolute LDS byte address -- the pixel's bin in window 0 or 1, a spare bin for
+  // pixels outside both (those are re-walked with global atomics when a vector has any), a per-lane dummy bin for pixels that
+  // equal the wave's guess (an add of 0 to the guess's bin would still queue on that address).  Twelve vector instructions.
+  const unsigned base = pl_lds_base(bins);
+  const unsigned k0 = base - 4u * uw0, k1 = base + 4u * (unsigned)kTwBins - 4u * uw1;
+  const unsigned spare_addr = base + 4u * (unsigned)(2 * kTwBins), dummy_addr = spare_addr + 4u + 4u * (unsigned)lane;
+  auto tally = [&](unsigned raw, unsigned long long& outside) {
+    const unsigned key = raw ^ flip;
+    const bool in0 = key - uw0 < (unsigned)kTwBins, in1 = key - uw1 < (unsigned)kTwBins, is_hot = key == guess;
+    unsigned addr = in0 ? (key << 2) + k0 : (in1 ? (key << 2) + k1 : spare_addr);
+    addr = is_hot ? dummy_addr : addr;
+    hot += is_hot ? 1u : 0u;
+    pl_lds_add_abs(addr, 1u);
+    outside |= __ballot(!(in0 || in1 || is_hot));
+  };
+  auto tally4 = [&](uint4 q) {
+    // a wave that holds ONE value in this vector adds its whole count with one atomic (see hist16_kernel)
+    const unsigned first = q.x & 0xffffu;
+    const unsigned splat = first | (first << 16);
+    const bool lane_flat = q.x == splat && q.y == splat && q.z == splat && q.w == splat;
+    const unsigned wave_first = __builtin_amdgcn_readfirstlane(splat);
+    const unsigned long long active = __ballot(1);                  // taken by ALL active lanes, before any lane-only branch
+    if (__ballot(!(lane_flat && splat == wave_first)) == 0) {       // wave-uniform branch
+      if ((threadIdx.x & 63) == __builtin_ctzll(active)) add_key((wave_first & 0xffffu) ^ flip, 8u * (unsigned)__popcll(active));
+      return;
+    }
+    const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+    unsigned long long outside = 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tally(wds[k] & 0xffffu, outside);
+      tally(wds[k] >> 16, outside);
+    }
+    if (outside != 0ull) {                                          // wave-uniform, rare: the pixels between the windows
+#pragma unroll 1
+      for (int k = 0; k < 8; ++k) {
+        const unsigned key = ((k & 1) ? wds[k >> 1] >> 16 : wds[k >> 1] & 0xffffu) ^ flip;
+        if (key - uw0 >= (unsigned)kTwBins && key - uw1 >= (unsigned)kTwBins && key != guess) atomicAdd(row + key, 1u);
+      }
+    }
+  };
+  auto tally1 = [&](unsigned raw) {                                 // tail pixels of a frame whose size is not a multiple of 8
+    const unsigned key = raw ^ flip;
+    if (key == guess) ++hot; else add_key(key, 1u);
+  };
+  int64_t v = threadIdx.x;
+  constexpr int U = 8;  // independent 16-byte loads in flight per lane (one workgroup per CU: 128 KiB in flight)
+  // the trip count is the WAVE's (its last lane decides): the wave-level steps inside never run under divergence
+  for (; v - lane + (PL_WAVE - 1) + (int64_t)(U - 1) * kHistThreads < nvec; v += (int64_t)U * kHistThreads) {
+    uint4 q[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) q[k] = vsrc[v + (int64_t)k * kHistThreads];
+#pragma unroll
+    for (int k = 0; k < U; ++k) tally4(q[k]);
+    // 64 pixels per lane later: keep a guess that attracted >= 1/16 of them, else try the first lane's latest pixel
+    const unsigned got = flush();
+    if (got < 256u) guess = __builtin_amdgcn_readfirstlane((q[U - 1].w >> 16) ^ flip);
+  }
+  for (; v < nvec; v += kHistThreads) {              // fewer than 8192 vectors are left: no wave-level steps under divergence
+    const uint4 q = vsrc[v];
+    const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { tally1(wds[k] & 0xffffu); tally1(wds[k] >> 16); }
+  }
+  for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally1(src[i]);
+  flush();
+  __syncthreads();
+  // the windows go out with plain stores: no global atomic ever touched a bin inside a window
+  for (int i = threadIdx.x; i < kTwBins; i += kHistThreads) {
+    row[w0 + i] = bins[i];
+    row[w1 + i] = bins[kTwBins + i];
+  }
+}
+
 }  // namespace
 
 extern "C" int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist,
@@ -544,9 +710,22 @@ extern "C" int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, ui
   const unsigned flip = dtype == PL_I16 ? 0x8000u : 0u;
   hipStream_t st = (hipStream_t)stream;
   const unsigned short* src = (const unsigned short*)in;
-  // measured on MI355X, 256 x 1024^2: 2 parts / one LDS atomic per pixel 0.16 ms; 2 parts / run-merged 0.22;
+  // (multi-part kernels) measured on MI355X, 256 x 1024^2: 2 parts / one LDS atomic per pixel 0.16 ms; 2 parts / run-merged 0.22;
   // 4 parts / per pixel 0.26; 4 parts / run-merged 0.31 (the kernel is VALU-bound: instructions per pixel
   // times the number of parts that look at it)
+  // frames of at least a quarter of a megapixel: ONE read by one workgroup per frame (two LDS windows + global atomics for the
+  // pixels in between); smaller frames, or no 152 KiB of LDS: the multi-part kernels
+  static std::atomic<int> two_window{0};             // 0 untried, 1 available, -1 refused
+  if (two_window == 0) {
+    const bool ok = hipFuncSetAttribute((const void*)hist16_two_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kTwLds) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    two_window = ok ? 1 : -1;
+  }
+  if (two_window == 1 && count >= 262144) {
+    hipLaunchKernelGGL(hist16_two_window_kernel, dim3((unsigned)n), dim3(kHistThreads), kTwLds, st, src, count, flip, d_hist);
+    return pl_check_launch("pl_hist16");
+  }
   int rc = launch_hist16<2, false>(src, n, count, flip, d_hist, st);
   if (rc != 0) rc = launch_hist16<4, false>(src, n, count, flip, d_hist, st);   // 64 KiB LDS needs no opt-in
   PL_REQUIRE(rc == 0, "launch configuration rejected");

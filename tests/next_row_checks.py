@@ -1077,3 +1077,38 @@ def check_phantom_roi_fused_vs_separate(dev, slices=(0, 24, 44, 79)):
         assert torch.equal(tab[i, :k], reg["stats"][i, :k, :7]), i
     assert (new[:, 0] == 0).all() and np.all(np.abs(new[:, 3:5] - 255.5) < 8)
     return new
+
+
+def check_histogram16_one_read(dev, sizes=((512, 512), (513, 520), (600, 437), (505, 523))):
+    """pl_hist16 on frames of at least 2^18 pixels (the single-read two-window kernel) against np.bincount: bimodal frames
+    whose range exceeds the two LDS windows (pixels in between take the global-atomic path), a clipped noisy background (the
+    hot-value peel), narrow ranges (one contiguous window), constants, int16, a size that is not a multiple of 8."""
+    import torch
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(61)
+    n_checked = 0
+    for h, w in sizes:
+        yy, xx = np.mgrid[:h, :w]
+        field = ((abs(yy - h / 2) < h / 5) & (abs(xx - w / 2) < w / 4)).astype(np.float64)
+        from scipy import ndimage
+        soft = ndimage.gaussian_filter(field, 6)
+        frames = [
+            np.clip(soft * 60000 + rng.normal(0, 65, (h, w)), 0, 65535),                 # clipped dark noise + field + penumbra
+            np.clip(soft * 52000 + 9000 + rng.normal(0, 40, (h, w)), 0, 65535),          # offset background: no single hot value
+            np.clip(20000 + rng.normal(0, 300, (h, w)), 0, 65535),                       # narrow range: one contiguous window
+            rng.integers(0, 65536, (h, w)).astype(np.float64),                            # everything everywhere
+            np.full((h, w), 777.0), np.zeros((h, w)), np.full((h, w), 65535.0),
+            np.where(rng.random((h, w)) < 0.5, 3.0, 65000.0),                            # two values
+        ]
+        a = np.stack(frames).astype(np.uint16)
+        a[1, 0, 0] = 0                       # extremes the 1/16 row sample does not see
+        a[1, h - 1, w - 1] = 65535
+        for arr in (a, (a.astype(np.int32) - 32768).astype(np.int16)):
+            got = ops.histogram16(torch.from_numpy(arr).to(dev)).cpu().numpy().view(np.uint32)
+            for i in range(arr.shape[0]):
+                want = np.bincount(arr[i].astype(np.int64).ravel() + (32768 if arr.dtype == np.int16 else 0), minlength=65536)
+                assert np.array_equal(got[i], want), (h, w, arr.dtype, i, np.flatnonzero(got[i] != want)[:5])
+                n_checked += 1
+    return n_checked

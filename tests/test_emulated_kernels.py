@@ -838,3 +838,10 @@ def test_emulated_phantom_roi_fused_vs_separate(emulated):
     import next_row_checks as checks
 
     checks.check_phantom_roi_fused_vs_separate(emulated, slices=(24, 44))
+
+
+def test_emulated_histogram16_one_read(emulated):
+    """The single-read two-window histogram (frames of >= 2^18 pixels) == np.bincount on the emulated device."""
+    import next_row_checks as checks
+
+    assert checks.check_histogram16_one_read(emulated, sizes=((512, 512), (513, 520))) == 32

@@ -1854,3 +1854,12 @@ def test_phantom_roi_fused_vs_separate(dev):
     import next_row_checks as checks
 
     checks.check_phantom_roi_fused_vs_separate(dev, slices=tuple(range(0, 80, 4)))
+
+
+@pytest.mark.gpu
+def test_histogram16_one_read_vs_bincount(dev):
+    """pl_hist16's single-read kernel (two LDS windows, hot-value peel, global atomics between the windows) == np.bincount:
+    bimodal / clipped-noise / narrow / uniform-random / constant frames, uint16 and int16, sizes off the 8-pixel vectors."""
+    import next_row_checks as checks
+
+    assert checks.check_histogram16_one_read(dev) == 64
