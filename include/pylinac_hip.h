@@ -158,6 +158,13 @@ int pl_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_t n, int h,
 int pl_median3_threshold_colsum_u16(const uint16_t* in, uint16_t* out, int64_t n, int h, int w,
                                     const int32_t* d_thr, unsigned long long* d_colsum, void* stream);
 
+/* pl_median3_threshold_colsum_u16 with the column sums left as per-band partial sums d_parts uint32[n][bands][w], bands =
+ * ceil(h / pl_colparts_band_rows()): plain stores -- no table to zero, no atomics.  pl_colparts_profile_fwxm (below, with
+ * pl_fwxm_record) adds the bands up.  The EPID pipeline's third stage. */
+int pl_median3_threshold_colparts_u16(const uint16_t* in, uint16_t* out, int64_t n, int h, int w,
+                                      const int32_t* d_thr, uint32_t* d_parts, void* stream);
+int pl_colparts_band_rows(void);
+
 /* d_out[n][w] = d_colsum[n][w] / h in float64: the np.mean(axis=0) profile of an integer frame. */
 int pl_colsum_to_mean(const unsigned long long* d_colsum, int64_t n, int w, int h, double* d_out,
                       void* stream);
@@ -560,6 +567,13 @@ int pl_pf_positions(const int32_t* d_status, const double* d_fwxm, const double*
  * (NaN-filled when a profile has no peak; the reference raises IndexError there). */
 int pl_fwxm_record(const int32_t* d_count, const int32_t* d_idx, const double* d_props, int cap,
                    int64_t n, double* d_out, void* stream);
+
+/* The tail of the EPID pipeline in one launch (one workgroup per frame): d_profile[n][w] = (sum over bands of
+ * d_parts[n][bands][w]) / h  = np.mean(frame, 0) (pylinac/picketfence.py:747-750), pl_find_peaks on it with `params`
+ * (outputs as pl_find_peaks), then pl_fwxm_record's row d_fwxm[n][8] (pylinac/core/profile.py:602-611, 322-344). */
+int pl_colparts_profile_fwxm(const uint32_t* d_parts, int64_t n, int bands, int w, int h, const pl_peak_params* params,
+                             int cap, double* d_profile, int32_t* d_count, int32_t* d_idx, int32_t* d_left_base,
+                             int32_t* d_right_base, double* d_props, int32_t* d_status, double* d_fwxm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,9 @@ SIGNATURES = {
     "pl_reduce_axis": ([_p, _i, _l, _i, _i, _i, _i, _p, _p], C.c_int),
     "pl_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
     "pl_median3_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
+    "pl_median3_threshold_colparts_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
+    "pl_colparts_band_rows": ([], C.c_int),
+    "pl_colparts_profile_fwxm": ([_p, _l, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_circle_profile": ([_p, _i, _l, _i, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p], C.c_int),
     "pl_circle_profile_combined": ([_p, _i, _l, _i, _i, _p, _l, _l, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p], C.c_int),
     "pl_sobel": ([_p, _p, _i, _l, _i, _i, _i, _p], C.c_int),

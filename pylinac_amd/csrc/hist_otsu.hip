@@ -221,7 +221,9 @@ otsu_kernel(const uint32_t* __restrict__ hist, int bias, int32_t* __restrict__ t
       const int b = b0 + 4 * k4 + j;
       w1 += c[j];
       s1 += (long long)c[j] * (long long)(b - bias);
-      if (b >= lo && b < hi) {
+      // an empty bin leaves both classes as they were: its variance equals the previous non-empty bin's (>= lo, evaluated) and
+      // can never be strictly greater -- skipped, with its two float64 divisions
+      if (c[j] != 0u && b >= lo && b < hi) {
         const double dw1 = (double)w1, dw2 = (double)(total.c - w1);
         const double m1 = (double)s1 / dw1;
         const double m2 = (double)(total.s - s1) / dw2;
@@ -480,7 +482,7 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     const unsigned c = bins[b];
     w1 += c;
     s1 += (long long)c * (long long)(b + klo - bias);
-    if (b >= lo && b < hi) {
+    if (c != 0u && b >= lo && b < hi) {           // empty bins: see otsu_kernel
       const double dw1 = (double)w1, dw2 = (double)(total.c - w1);
       const double m1 = (double)s1 / dw1;
       const double m2 = (double)(total.s - s1) / dw2;

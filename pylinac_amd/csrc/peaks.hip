@@ -145,32 +145,25 @@ __device__ __forceinline__ void prominence_side(const double* xs, int pk, int m,
   out_base = pk + DIR * step;
 }
 
-// STAGE = true: the (trimmed) profile lives in LDS and every walk below is a ds_read; keeping the two
-// cases in separate instantiations lets the compiler know the address space (a runtime select
-// between an LDS and a global pointer degrades every access to a slow FLAT load).
-template <bool STAGE, int NT>
-__global__ void __launch_bounds__(kThreads)
-find_peaks_kernel(const double* __restrict__ x, int64_t nprof, int slot_bytes, int len_all, const int32_t* __restrict__ lens,
-                  const int32_t* __restrict__ regions, int64_t stride,
-                  pl_peak_params prm, int cap, int maxc, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
-                  int32_t* __restrict__ d_lb, int32_t* __restrict__ d_rb, double* __restrict__ d_props,
-                  int32_t* __restrict__ d_status) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-  __shared__ Scan scan_a[kThreads / NT];
-  __shared__ double s_red_a[kThreads / NT][2 * (kThreads / PL_WAVE)];
-  __shared__ int s_cnt_a[kThreads / NT];
-  const int slot = threadIdx.x / NT, tid = threadIdx.x % NT;
-  unsigned char* smem = smem_all + (size_t)slot * slot_bytes;
-  Scan& scan = scan_a[slot];
-  double* s_red = s_red_a[slot];
-  int& s_cnt = s_cnt_a[slot];
+struct PeakLds {                                   // the LDS of one profile's search
+  unsigned char* smem;                             // dynamic block: candidate tables (+ the staged profile)
+  Scan* scan;
+  double* s_red;                                   // 2 x (kThreads / PL_WAVE)
+  int* s_cnt;
+};
 
-  const int64_t prof = (int64_t)blockIdx.x * (kThreads / NT) + slot;
-  if (prof >= nprof) return;                     // NT == 64: a whole wave leaves; NT == 256: never taken
-  const int len = lens ? lens[prof] : len_all;   // ragged batches: per-profile length
-  const double* xfull = x + prof * stride;
-  // search region: the batch's, or this profile's own [lo, hi) (python slice semantics resolved by the caller)
-  const int rlo = regions ? regions[2 * prof] : prm.region_lo, rhi = regions ? regions[2 * prof + 1] : prm.region_hi;
+// One profile, NT lanes (tid = 0 .. NT-1): `xfull` has `len` samples, the search region is [rlo, rhi) clipped to it; results go
+// to the profile's own output rows (o_count / o_status one element, o_idx / o_lb / o_rb `cap`, o_p 6 x cap).  Every lane of the
+// group calls it; all of them return together.
+template <bool STAGE, int NT>
+__device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xfull, int len, int rlo, int rhi, const pl_peak_params& prm,
+                                                   int cap, int maxc, const PeakLds L, int tid, int32_t* __restrict__ o_count,
+                                                   int32_t* __restrict__ o_idx, int32_t* __restrict__ o_lb, int32_t* __restrict__ o_rb,
+                                                   double* __restrict__ o_p, int32_t* __restrict__ o_status) {
+  unsigned char* smem = L.smem;
+  Scan& scan = *L.scan;
+  double* s_red = L.s_red;
+  int& s_cnt = *L.s_cnt;
   int lo = rlo < 0 ? 0 : rlo;
   int hi = rhi > len ? len : rhi;
   if (hi < lo) hi = lo;
@@ -186,7 +179,7 @@ find_peaks_kernel(const double* __restrict__ x, int64_t nprof, int slot_bytes, i
   double* s_x = reinterpret_cast<double*>(s_keep + maxc + (maxc & 1));
 
   if (len <= 0) {   // empty profile (e.g. a window that was rejected upstream)
-    if (tid == 0) { d_count[prof] = 0; d_status[prof] = 0; }
+    if (tid == 0) { *o_count = 0; *o_status = 0; }
     return;
   }
   // ---- A: height threshold -------------------------------------------------------------------
@@ -350,10 +343,6 @@ find_peaks_kernel(const double* __restrict__ x, int64_t nprof, int slot_bytes, i
     if (tid == 0) s_cnt = cur + tot;
     group_sync<NT>();
   }
-  int32_t* o_idx = d_idx + prof * cap;
-  int32_t* o_lb = d_lb + prof * cap;
-  int32_t* o_rb = d_rb + prof * cap;
-  double* o_p = d_props + prof * 6 * (int64_t)cap;
   for (int p = tid / PL_WAVE; p < P; p += NT / PL_WAVE) {
     const int dst = s_keep[p] - 1;
     if (dst < 0 || dst >= cap) continue;                 // wave-uniform
@@ -373,36 +362,95 @@ find_peaks_kernel(const double* __restrict__ x, int64_t nprof, int slot_bytes, i
   }
   if (tid == 0) {
     const int total = s_cnt;
-    d_count[prof] = total < cap ? total : cap;
-    d_status[prof] = overflow ? 2 : (total > cap ? 1 : 0);
+    *o_count = total < cap ? total : cap;
+    *o_status = overflow ? 2 : (total > cap ? 1 : 0);
   }
+}
+
+// STAGE = true: the (trimmed) profile lives in LDS and every walk is a ds_read; keeping the two
+// cases in separate instantiations lets the compiler know the address space (a runtime select
+// between an LDS and a global pointer degrades every access to a slow FLAT load).
+template <bool STAGE, int NT>
+__global__ void __launch_bounds__(kThreads)
+find_peaks_kernel(const double* __restrict__ x, int64_t nprof, int slot_bytes, int len_all, const int32_t* __restrict__ lens,
+                  const int32_t* __restrict__ regions, int64_t stride,
+                  pl_peak_params prm, int cap, int maxc, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
+                  int32_t* __restrict__ d_lb, int32_t* __restrict__ d_rb, double* __restrict__ d_props,
+                  int32_t* __restrict__ d_status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  __shared__ Scan scan_a[kThreads / NT];
+  __shared__ double s_red_a[kThreads / NT][2 * (kThreads / PL_WAVE)];
+  __shared__ int s_cnt_a[kThreads / NT];
+  const int slot = threadIdx.x / NT, tid = threadIdx.x % NT;
+  const PeakLds L{smem_all + (size_t)slot * slot_bytes, &scan_a[slot], s_red_a[slot], &s_cnt_a[slot]};
+  const int64_t prof = (int64_t)blockIdx.x * (kThreads / NT) + slot;
+  if (prof >= nprof) return;                     // NT == 64: a whole wave leaves; NT == 256: never taken
+  const int len = lens ? lens[prof] : len_all;   // ragged batches: per-profile length
+  // search region: the batch's, or this profile's own [lo, hi) (python slice semantics resolved by the caller)
+  const int rlo = regions ? regions[2 * prof] : prm.region_lo, rhi = regions ? regions[2 * prof + 1] : prm.region_hi;
+  find_peaks_profile<STAGE, NT>(x + prof * stride, len, rlo, rhi, prm, cap, maxc, L, tid, d_count + prof, d_idx + prof * cap,
+                                d_lb + prof * cap, d_rb + prof * cap, d_props + prof * 6 * (int64_t)cap, d_status + prof);
 }
 
 // FWXMProfile.field_edge_idx / center_idx / field_width_px from the single most prominent peak
 // (pylinac/core/profile.py:602-611, 322-327, 339-344): record = {n_peaks, peak_idx, height,
 // prominence, left, right, |r-l|/2+l, max(r,l)-min(r,l)}; NaN when the profile has no peak.
-__global__ void fwxm_record_kernel(const int32_t* __restrict__ count, const int32_t* __restrict__ idx,
-                                   const double* __restrict__ props, int cap, int64_t n,
-                                   double* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double* o = out + i * 8;
+__device__ __forceinline__ void fwxm_record_one(int c, const int32_t* __restrict__ idx, const double* __restrict__ p, int cap,
+                                                double* __restrict__ o) {
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
-  const int c = count[i];
   o[0] = (double)c;
   if (c <= 0) {
     for (int k = 1; k < 8; ++k) o[k] = nan;
     return;
   }
-  const double* p = props + i * 6 * (int64_t)cap;
   const double l = p[4 * cap], r = p[5 * cap];
-  o[1] = (double)idx[i * cap];
+  o[1] = (double)idx[0];
   o[2] = p[0];
   o[3] = p[1 * cap];
   o[4] = l;
   o[5] = r;
   o[6] = fabs(r - l) / 2 + l;
   o[7] = (r > l ? r : l) - (r < l ? r : l);
+}
+
+__global__ void fwxm_record_kernel(const int32_t* __restrict__ count, const int32_t* __restrict__ idx,
+                                   const double* __restrict__ props, int cap, int64_t n,
+                                   double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fwxm_record_one(count[i], idx + i * cap, props + i * 6 * (int64_t)cap, cap, out + i * 8);
+}
+
+// The tail of the EPID pipeline in ONE launch, one workgroup per frame: per-band column sums of the thresholded frame ->
+// np.mean(frame, 0) (pylinac/picketfence.py:747-750: float64 sum of integers / count) -> find_peaks on that profile ->
+// the FWXM record.  Three launches (pl_colsum_to_mean, pl_find_peaks, pl_fwxm_record: 4 + 25 + 4 us of kernels and the gaps
+// between them) and the column-sum memset + 64-bit atomics in front of them become one.
+template <bool STAGE>
+__global__ void __launch_bounds__(kThreads)
+colparts_profile_fwxm_kernel(const uint32_t* __restrict__ parts, int bands, int w, int h, pl_peak_params prm, int cap, int maxc,
+                             double* __restrict__ profile, int32_t* __restrict__ d_count, int32_t* __restrict__ d_idx,
+                             int32_t* __restrict__ d_lb, int32_t* __restrict__ d_rb, double* __restrict__ d_props,
+                             int32_t* __restrict__ d_status, double* __restrict__ fwxm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  __shared__ Scan scan;
+  __shared__ double s_red[2 * (kThreads / PL_WAVE)];
+  __shared__ int s_cnt;
+  const int64_t frame = blockIdx.x;
+  const int tid = threadIdx.x;
+  const uint32_t* pf = parts + frame * (int64_t)bands * w;
+  double* prof = profile + frame * (int64_t)w;
+  for (int i = tid; i < w; i += kThreads) {
+    unsigned long long cs = 0;
+    for (int b = 0; b < bands; ++b) cs += pf[(size_t)b * w + i];
+    prof[i] = (double)cs / (double)h;               // np.mean of integers: float64 sum / count
+  }
+  __syncthreads();                                  // the profile row (global memory) is this workgroup's own
+  const PeakLds L{smem_all, &scan, s_red, &s_cnt};
+  find_peaks_profile<STAGE, kThreads>(prof, w, prm.region_lo, prm.region_hi, prm, cap, maxc, L, tid, d_count + frame,
+                                      d_idx + frame * cap, d_lb + frame * cap, d_rb + frame * cap,
+                                      d_props + frame * 6 * (int64_t)cap, d_status + frame);
+  __syncthreads();
+  if (tid == 0) fwxm_record_one(d_count[frame], d_idx + frame * cap, d_props + frame * 6 * (int64_t)cap, cap, fwxm + frame * 8);
 }
 
 }  // namespace
@@ -490,4 +538,39 @@ extern "C" int pl_find_peaks_regions(const double* d_x, int64_t n, int len, cons
                        n, (int)lds, len, d_lens, d_regions, stride, *params, cap, maxc, d_count, d_idx, d_left_base,
                        d_right_base, d_props, d_status);
   return pl_check_launch("pl_find_peaks");
+}
+
+// per-band column sums (pl_median3_threshold_colparts_u16) -> mean profile, its peaks, the FWXM record: see the kernel
+extern "C" int pl_colparts_profile_fwxm(const uint32_t* d_parts, int64_t n, int bands, int w, int h, const pl_peak_params* params,
+                                        int cap, double* d_profile, int32_t* d_count, int32_t* d_idx, int32_t* d_left_base,
+                                        int32_t* d_right_base, double* d_props, int32_t* d_status, double* d_fwxm, void* stream) {
+  PL_REQUIRE(d_parts && params && d_profile && d_count && d_idx && d_left_base && d_right_base && d_props && d_status && d_fwxm,
+             "null pointer");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && bands > 0 && w > 0 && h > 0 && cap > 0, "bad shape");
+  PL_REQUIRE(params->distance >= 1, "distance must be >= 1");
+  if (n == 0) return PL_OK;
+  const int lo = params->region_lo < 0 ? 0 : params->region_lo;
+  const int hi = params->region_hi > w ? w : params->region_hi;
+  const int m = hi > lo ? hi - lo : 0;
+  int maxc = m / 2 + 1;
+  if (maxc > kMaxCand) maxc = kMaxCand;
+  const bool stage_x = m <= kStageMax;
+  size_t lds = (size_t)maxc * (8 + 8 + 4 * 4) + 8 + (stage_x ? (size_t)m * 8 : 0);
+  lds = (lds + 15) & ~(size_t)15;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)colparts_profile_fwxm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       150 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)colparts_profile_fwxm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) { pl_set_error("pl_colparts_profile_fwxm: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+    attr_set = true;
+  }
+  if (stage_x)
+    hipLaunchKernelGGL(colparts_profile_fwxm_kernel<true>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_parts, bands,
+                       w, h, *params, cap, maxc, d_profile, d_count, d_idx, d_left_base, d_right_base, d_props, d_status, d_fwxm);
+  else
+    hipLaunchKernelGGL(colparts_profile_fwxm_kernel<false>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_parts, bands,
+                       w, h, *params, cap, maxc, d_profile, d_count, d_idx, d_left_base, d_right_base, d_props, d_status, d_fwxm);
+  return pl_check_launch("pl_colparts_profile_fwxm");
 }

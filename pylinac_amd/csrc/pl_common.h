@@ -168,7 +168,7 @@ __device__ __forceinline__ double pl_quot(const PlQuot& k, double a) {
 // base is a link-time symbol the compiler cannot fold).  pl_lds_base() is what a kernel checks before relying on it.
 typedef __attribute__((address_space(3))) unsigned pl_lds_u32;
 __device__ __forceinline__ void pl_lds_add_abs(unsigned byte_addr, unsigned v) {
-  __hip_atomic_fetch_add((pl_lds_u32*)byte_addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add((pl_lds_u32*)(uintptr_t)byte_addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ unsigned pl_lds_base(const void* lds_ptr) { return (unsigned)reinterpret_cast<uintptr_t>(lds_ptr); }
 

@@ -152,9 +152,13 @@ threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* _
 // (32 rows) of the band; the four waves' column sums meet in LDS and leave as one 64-bit atomic per column.
 constexpr int kMtRows = 32;                        // rows per wave: two halo rows are re-read per wave
 constexpr int kMtWaves = kBandRows / kMtRows;      // 4
+// PARTS: the band's column sums are STORED as uint32 parts[frame][band][column] (128 rows x 65535 < 2^32) instead of added to
+// colsum[frame][column] with 64-bit atomics -- no zeroed table, no atomics; pl_colparts_profile_fwxm adds the bands up.
+template <bool PARTS>
 __global__ void __launch_bounds__(kMtWaves * PL_WAVE)
 median3_threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, int h, int w, int bands,
-                                int col_groups, const int32_t* __restrict__ thr, unsigned long long* __restrict__ colsum) {
+                                int col_groups, const int32_t* __restrict__ thr, unsigned long long* __restrict__ colsum,
+                                uint32_t* __restrict__ parts) {
   __shared__ unsigned s_cs[PL_WAVE * 8];
   unsigned id = pl_xcd_remap(blockIdx.x, gridDim.x);
   const int cg = id % col_groups;
@@ -187,9 +191,15 @@ median3_threshold_colsum_kernel(const unsigned short* __restrict__ in, unsigned 
     for (int k = 0; k < 8; ++k) atomicAdd(&s_cs[lane * 8 + k], s[k]);     // 32 rows x 65535 per wave, 4 waves: < 2^32
   }
   __syncthreads();
-  unsigned long long* cs = colsum + frame * (size_t)w + (size_t)cg * PL_WAVE * 8;
-  for (int i = threadIdx.x; i < PL_WAVE * 8; i += kMtWaves * PL_WAVE)
-    if (cg * PL_WAVE * 8 + i < w) atomicAdd(cs + i, (unsigned long long)s_cs[i]);
+  if (PARTS) {
+    uint32_t* ps = parts + (frame * (size_t)bands + band) * (size_t)w + (size_t)cg * PL_WAVE * 8;
+    for (int i = threadIdx.x; i < PL_WAVE * 8; i += kMtWaves * PL_WAVE)
+      if (cg * PL_WAVE * 8 + i < w) ps[i] = s_cs[i];
+  } else {
+    unsigned long long* cs = colsum + frame * (size_t)w + (size_t)cg * PL_WAVE * 8;
+    for (int i = threadIdx.x; i < PL_WAVE * 8; i += kMtWaves * PL_WAVE)
+      if (cg * PL_WAVE * 8 + i < w) atomicAdd(cs + i, (unsigned long long)s_cs[i]);
+  }
 }
 
 __global__ void colsum_to_mean_kernel(const unsigned long long* __restrict__ cs, int64_t total, int h,
@@ -264,7 +274,26 @@ extern "C" int pl_median3_threshold_colsum_u16(const uint16_t* in, uint16_t* out
   if (e != hipSuccess) { pl_set_error("pl_median3_threshold_colsum_u16: memset: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
   const int bands = (int)pl_cdiv(h, kBandRows), col_groups = (int)pl_cdiv(w / 8, PL_WAVE);
   PL_REQUIRE(n * bands * col_groups <= 0x7fffffffLL, "batch too large");
-  hipLaunchKernelGGL(median3_threshold_colsum_kernel, dim3((unsigned)(n * bands * col_groups)), dim3(kMtWaves * PL_WAVE), 0, st, in, out,
-                     h, w, bands, col_groups, d_thr, d_colsum);
+  hipLaunchKernelGGL(median3_threshold_colsum_kernel<false>, dim3((unsigned)(n * bands * col_groups)), dim3(kMtWaves * PL_WAVE), 0, st,
+                     in, out, h, w, bands, col_groups, d_thr, d_colsum, (uint32_t*)nullptr);
   return pl_check_launch("pl_median3_threshold_colsum_u16");
+}
+
+// rows per band of pl_median3_threshold_colparts_u16's partial sums: bands = ceil(h / pl_colparts_band_rows())
+extern "C" int pl_colparts_band_rows(void) { return kBandRows; }
+
+// The same pass with the column sums left as per-band partial sums d_parts uint32[n][bands][w] (plain stores: nothing to zero,
+// no atomics); pl_colparts_profile_fwxm (peaks.hip) turns them into the mean profile and its FWXM record.
+extern "C" int pl_median3_threshold_colparts_u16(const uint16_t* in, uint16_t* out, int64_t n, int h, int w,
+                                                 const int32_t* d_thr, uint32_t* d_parts, void* stream) {
+  PL_REQUIRE(in && out && d_thr && d_parts && in != out, "null or aliased pointers");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");
+  PL_REQUIRE(pl_median3_rows_covers(in, h, w) && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+             "needs h > 1, width % 8 == 0 and 16-byte aligned frames (run pl_median2d + pl_threshold_colsum_u16 otherwise)");
+  if (n == 0) return PL_OK;
+  const int bands = (int)pl_cdiv(h, kBandRows), col_groups = (int)pl_cdiv(w / 8, PL_WAVE);
+  PL_REQUIRE(n * bands * col_groups <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(median3_threshold_colsum_kernel<true>, dim3((unsigned)(n * bands * col_groups)), dim3(kMtWaves * PL_WAVE), 0,
+                     (hipStream_t)stream, in, out, h, w, bands, col_groups, d_thr, (unsigned long long*)nullptr, d_parts);
+  return pl_check_launch("pl_median3_threshold_colparts_u16");
 }

@@ -25,7 +25,8 @@ from ._lib import check
 RECORD_FIELDS = ("otsu_threshold", "n_peaks", "peak_idx", "peak_height", "prominence",
                  "left_edge", "right_edge", "center", "width")
 
-STAGES = ("gauss2d", "median3_otsu16", "median3_threshold_colsum", "colsum_to_mean", "find_peaks", "fwxm_record")
+# stages of the fused path (3x3 median on frames of width % 8 == 0); other geometries run the separate entry points
+STAGES = ("gauss2d", "median3_otsu16", "median3_threshold_colsum", "profile_fwxm")
 
 
 @dataclass
@@ -50,6 +51,7 @@ class EpidPipeline:
     sigma: float = 5
     median_size: int = 3
     fwxm_height: float = 50
+    fused_tail: bool = True        # per-band column sums + ONE launch for profile -> peaks -> record (False: round 1-3's five launches)
     timings: dict = field(default_factory=dict)
 
     def __post_init__(self):
@@ -65,6 +67,9 @@ class EpidPipeline:
         self.vmax = torch.empty(n, dtype=torch.int32, device=dev)
         self.flag = torch.empty(n, dtype=torch.int32, device=dev)
         self.colsum = torch.empty((n, w), dtype=torch.int64, device=dev)
+        self.lib = _lib.load()
+        self.bands = -(-h // self.lib.pl_colparts_band_rows())
+        self.parts = torch.empty((n, self.bands, w), dtype=torch.int32, device=dev)   # uint32 per-band column sums
         self.profile = torch.empty((n, w), dtype=torch.float64, device=dev)
         self.fwxm = torch.empty((n, 8), dtype=torch.float64, device=dev)
         self.peaks = ops.PeakBatch(
@@ -77,7 +82,6 @@ class EpidPipeline:
         )
         self.wts, self.host_wts, self.radius = ops._device_weights(self.sigma, dev)
         self.prm = ops.make_peak_params(w, fwxm_height=self.fwxm_height / 100, max_number=1)
-        self.lib = _lib.load()
 
     def run(self, frames: torch.Tensor, events: dict | None = None) -> EpidResult:
         """One pass over a resident batch.  ``events``: optional {stage: [(start, stop), ...]} sink;
@@ -125,6 +129,16 @@ class EpidPipeline:
         def rest(lo, m, stream):
             """median -> Otsu -> threshold -> column profile -> FWXM record, frames [lo, lo+m)."""
             st, o = stream.cuda_stream, lo * fb
+
+            def separate_tail():
+                stage("colsum_to_mean", lambda: lib.pl_colsum_to_mean(colsum + lo * w * 8, m, w, h,
+                                                                      profile + lo * w * 8, st), stream)
+                stage("find_peaks", lambda: lib.pl_find_peaks(
+                    profile + lo * w * 8, m, w, w, C.byref(self.prm), 1, cnt + lo * 4, idx + lo * 4, lb + lo * 4,
+                    rb + lo * 4, props + lo * 48, status + lo * 4, st), stream)
+                stage("fwxm_record", lambda: lib.pl_fwxm_record(cnt + lo * 4, idx + lo * 4, props + lo * 48, 1, m,
+                                                                fwxm + lo * 64, st), stream)
+
             if fused_median:
                 # Image.filter(3, "median") is never materialised: the Otsu histogram and the threshold + column sums each
                 # compute the 3x3 medians of the Gaussian plane on the fly (two reads of that plane instead of median write +
@@ -132,23 +146,27 @@ class EpidPipeline:
                 stage("median3_otsu16", lambda: lib.pl_median3_otsu16(bp + o, ap + o, U16, m, h, w, None, None, thr + lo * 4,
                                                                       vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
                                                                       hist + lo * 65536 * 4, st), stream)
-                stage("median3_threshold_colsum", lambda: lib.pl_median3_threshold_colsum_u16(
-                    bp + o, op + o, m, h, w, thr + lo * 4, colsum + lo * w * 8, st), stream)
-            else:
-                stage("median3", lambda: lib.pl_median2d(bp + o, ap + o, U16, m, h, w, self.median_size, st), stream)
-                med = ap + o
-                stage("otsu16", lambda: lib.pl_otsu16(med, U16, m, h * w, None, None, thr + lo * 4,
-                                                      vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
-                                                      hist + lo * 65536 * 4, st), stream)
-                stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(med, op + o, m, h, w, thr + lo * 4,
-                                                                              colsum + lo * w * 8, st), stream)
-            stage("colsum_to_mean", lambda: lib.pl_colsum_to_mean(colsum + lo * w * 8, m, w, h,
-                                                                  profile + lo * w * 8, st), stream)
-            stage("find_peaks", lambda: lib.pl_find_peaks(
-                profile + lo * w * 8, m, w, w, C.byref(self.prm), 1, cnt + lo * 4, idx + lo * 4, lb + lo * 4,
-                rb + lo * 4, props + lo * 48, status + lo * 4, st), stream)
-            stage("fwxm_record", lambda: lib.pl_fwxm_record(cnt + lo * 4, idx + lo * 4, props + lo * 48, 1, m,
-                                                            fwxm + lo * 64, st), stream)
+                if not self.fused_tail:
+                    stage("median3_threshold_colsum", lambda: lib.pl_median3_threshold_colsum_u16(
+                        bp + o, op + o, m, h, w, thr + lo * 4, colsum + lo * w * 8, st), stream)
+                    separate_tail()
+                    return
+                # threshold + per-band column sums (plain stores), then ONE launch for mean profile -> peaks -> FWXM record
+                parts = self.parts.data_ptr() + lo * self.bands * w * 4
+                stage("median3_threshold_colsum", lambda: lib.pl_median3_threshold_colparts_u16(
+                    bp + o, op + o, m, h, w, thr + lo * 4, parts, st), stream)
+                stage("profile_fwxm", lambda: lib.pl_colparts_profile_fwxm(
+                    parts, m, self.bands, w, h, C.byref(self.prm), 1, profile + lo * w * 8, cnt + lo * 4, idx + lo * 4,
+                    lb + lo * 4, rb + lo * 4, props + lo * 48, status + lo * 4, fwxm + lo * 64, st), stream)
+                return
+            stage("median3", lambda: lib.pl_median2d(bp + o, ap + o, U16, m, h, w, self.median_size, st), stream)
+            med = ap + o
+            stage("otsu16", lambda: lib.pl_otsu16(med, U16, m, h * w, None, None, thr + lo * 4,
+                                                  vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
+                                                  hist + lo * 65536 * 4, st), stream)
+            stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(med, op + o, m, h, w, thr + lo * 4,
+                                                                          colsum + lo * w * 8, st), stream)
+            separate_tail()
 
         filters(0, self.n, main)
         rest(0, self.n, main)

@@ -36,7 +36,7 @@ _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)
 _WAITCNT = re.compile(r'asm\s+volatile\s*\(\s*"s_waitcnt[^;]*;')
 _MED3 = re.compile(r'asm\("v_med3_[ui]32[^;]*;')
 _PIN = re.compile(r'asm\s+volatile\s*\(\s*""[^;]*;')                      # empty asm: a register-allocation hint
-_LDSABS = re.compile(r'__hip_atomic_fetch_add\(\(pl_lds_u32\*\)byte_addr[^;]*;')   # absolute LDS address -> offset into the emulator's block
+_LDSABS = re.compile(r'__hip_atomic_fetch_add\(\(pl_lds_u32\*\)\(uintptr_t\)byte_addr[^;]*;')   # absolute LDS address -> offset into the emulator's block
 _LDSBASE = re.compile(r'return \(unsigned\)reinterpret_cast<uintptr_t>\(lds_ptr\);')
 _LDSTYPE = re.compile(r'typedef __attribute__\(\(address_space\(3\)\)\) unsigned pl_lds_u32;')
 _OCC = re.compile(r'__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)')   # occupancy target of a kernel

@@ -1112,3 +1112,55 @@ def check_histogram16_one_read(dev, sizes=((512, 512), (513, 520), (600, 437), (
                 assert np.array_equal(got[i], want), (h, w, arr.dtype, i, np.flatnonzero(got[i] != want)[:5])
                 n_checked += 1
     return n_checked
+
+
+def check_fused_tail_vs_separate(dev, shapes=((3, 200, 520), (2, 128, 64), (2, 130, 1032), (1, 2, 8))):
+    """pl_median3_threshold_colparts_u16 + pl_colparts_profile_fwxm (the EPID pipeline's third stage and its one-launch tail)
+    == pl_median3_threshold_colsum_u16 -> pl_colsum_to_mean -> pl_find_peaks -> pl_fwxm_record, bit for bit, on heights that
+    leave a partial band and widths that leave a partial column group."""
+    import ctypes as C
+
+    import torch
+
+    from pylinac_amd import _lib, ops
+    from pylinac_amd._lib import check
+
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    st = torch.cuda.current_stream().cuda_stream
+    for n, h, w in shapes:
+        yy, xx = np.mgrid[:h, :w]
+        base = 20000 * np.exp(-0.5 * ((xx - w * 0.55) / (w * 0.18)) ** 2) + 3000
+        fr = np.clip(base[None] + rng.normal(0, 400, (n, h, w)), 0, 65535).astype(np.uint16)
+        x = torch.from_numpy(fr).to(dev)
+        thr = torch.from_numpy(np.array([9000, 0, 70000][:n] if n <= 3 else [9000] * n, dtype=np.int32)).to(dev)
+        prm = ops.make_peak_params(w, fwxm_height=0.5, max_number=1)
+
+        def outputs():
+            return dict(out=torch.empty_like(x), prof=torch.empty((n, w), dtype=torch.float64, device=dev),
+                        cnt=torch.empty(n, dtype=torch.int32, device=dev), idx=torch.empty((n, 1), dtype=torch.int32, device=dev),
+                        lb=torch.empty((n, 1), dtype=torch.int32, device=dev), rb=torch.empty((n, 1), dtype=torch.int32, device=dev),
+                        props=torch.empty((n, 6, 1), dtype=torch.float64, device=dev),
+                        status=torch.empty(n, dtype=torch.int32, device=dev), fwxm=torch.empty((n, 8), dtype=torch.float64, device=dev))
+
+        a, b = outputs(), outputs()
+        colsum = torch.empty((n, w), dtype=torch.int64, device=dev)
+        check(lib.pl_median3_threshold_colsum_u16(x.data_ptr(), a["out"].data_ptr(), n, h, w, thr.data_ptr(), colsum.data_ptr(), st), "colsum")
+        check(lib.pl_colsum_to_mean(colsum.data_ptr(), n, w, h, a["prof"].data_ptr(), st), "mean")
+        check(lib.pl_find_peaks(a["prof"].data_ptr(), n, w, w, C.byref(prm), 1, a["cnt"].data_ptr(), a["idx"].data_ptr(), a["lb"].data_ptr(),
+                                a["rb"].data_ptr(), a["props"].data_ptr(), a["status"].data_ptr(), st), "peaks")
+        check(lib.pl_fwxm_record(a["cnt"].data_ptr(), a["idx"].data_ptr(), a["props"].data_ptr(), 1, n, a["fwxm"].data_ptr(), st), "fwxm")
+        bands = -(-h // lib.pl_colparts_band_rows())
+        parts = torch.full((n, bands, w), -1, dtype=torch.int32, device=dev)       # every element must be overwritten
+        check(lib.pl_median3_threshold_colparts_u16(x.data_ptr(), b["out"].data_ptr(), n, h, w, thr.data_ptr(), parts.data_ptr(), st), "colparts")
+        check(lib.pl_colparts_profile_fwxm(parts.data_ptr(), n, bands, w, h, C.byref(prm), 1, b["prof"].data_ptr(), b["cnt"].data_ptr(),
+                                           b["idx"].data_ptr(), b["lb"].data_ptr(), b["rb"].data_ptr(), b["props"].data_ptr(),
+                                           b["status"].data_ptr(), b["fwxm"].data_ptr(), st), "tail")
+        assert np.array_equal(parts.cpu().numpy().view(np.uint32).astype(np.int64).sum(1), colsum.cpu().numpy()), (n, h, w)
+        for k in ("out", "prof", "cnt", "status", "fwxm"):
+            assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=k == "fwxm"), (n, h, w, k)
+        c = a["cnt"].cpu().numpy()
+        for k in ("idx", "lb", "rb"):
+            assert np.array_equal(a[k].cpu().numpy()[c > 0], b[k].cpu().numpy()[c > 0]), (n, h, w, k)
+        assert np.array_equal(a["props"].cpu().numpy()[c > 0], b["props"].cpu().numpy()[c > 0]), (n, h, w)
+    return len(shapes)

@@ -845,3 +845,10 @@ def test_emulated_histogram16_one_read(emulated):
     import next_row_checks as checks
 
     assert checks.check_histogram16_one_read(emulated, sizes=((512, 512), (513, 520))) == 32
+
+
+def test_emulated_fused_tail_vs_separate(emulated):
+    """The pipeline's per-band column sums + one-launch tail == the separate colsum / mean / find_peaks / fwxm_record launches."""
+    import next_row_checks as checks
+
+    assert checks.check_fused_tail_vs_separate(emulated) == 4

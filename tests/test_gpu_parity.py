@@ -1863,3 +1863,12 @@ def test_histogram16_one_read_vs_bincount(dev):
     import next_row_checks as checks
 
     assert checks.check_histogram16_one_read(dev) == 64
+
+
+@pytest.mark.gpu
+def test_fused_tail_vs_separate(dev):
+    """pl_median3_threshold_colparts_u16 + pl_colparts_profile_fwxm == the four separate launches they replace, bit for bit
+    (partial bands, partial column groups, a frame wholly below / above its threshold), plus one 1024 x 1024 batch."""
+    import next_row_checks as checks
+
+    assert checks.check_fused_tail_vs_separate(dev, shapes=((3, 200, 520), (2, 128, 64), (2, 130, 1032), (1, 2, 8), (3, 1024, 1024))) == 5
