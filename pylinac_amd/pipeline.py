@@ -25,8 +25,8 @@ from ._lib import check
 RECORD_FIELDS = ("otsu_threshold", "n_peaks", "peak_idx", "peak_height", "prominence",
                  "left_edge", "right_edge", "center", "width")
 
-# stages of the fused path (3x3 median on frames of width % 8 == 0); other geometries run the separate entry points
-STAGES = ("gauss2d", "median3_otsu16", "median3_threshold_colsum", "profile_fwxm")
+# stages of the default path (3x3 median on frames of width % 8 == 0); other geometries run the separate entry points
+STAGES = ("gauss2d", "median3_otsu16", "median3_threshold_colsum", "colsum_to_mean", "find_peaks", "fwxm_record")
 
 
 @dataclass
@@ -51,7 +51,10 @@ class EpidPipeline:
     sigma: float = 5
     median_size: int = 3
     fwxm_height: float = 50
-    fused_tail: bool = True        # per-band column sums + ONE launch for profile -> peaks -> record (False: round 1-3's five launches)
+    # True: per-band column sums + ONE launch for profile -> peaks -> record (pl_colparts_profile_fwxm) instead of memset +
+    # 64-bit atomics + three small launches.  Same results; measured on 256 x 1024^2 (scripts/time_epid_tail.py): 0.7675 ms
+    # per step against 0.760 -- back-to-back launches on one stream cost next to nothing, so the default stays False
+    fused_tail: bool = False
     timings: dict = field(default_factory=dict)
 
     def __post_init__(self):
