@@ -767,8 +767,17 @@ def test_ctp528_style_peak_valley_mtf(dev):
                                             search_region=(min(i), max(i)))
         mins.append(vv.mean())
     assert got.maximums == maxs and got.minimums == mins
-    ref = pmtf.MTF([s["lp/mm"] for s in settings.values()], maxs, mins)
-    assert got.norm_mtfs == ref.norm_mtfs and got.relative_resolution(50) == ref.relative_resolution(50)
+    # rMTF restated here from the reference's formulas (pylinac/core/mtf.py:62-72 Michelson contrast per region, normalised to
+    # the first region; :91-96 relative_resolution = scipy interp1d of spacing over rMTF) -- not through pylinac_amd.mtf
+    from scipy.interpolate import interp1d
+
+    lps = [s["lp/mm"] for s in settings.values()]
+    mtfs = {lp: (np.nanmax(np.array((mx, mn))) - np.nanmin(np.array((mx, mn)))) / (np.nanmax(np.array((mx, mn))) + np.nanmin(np.array((mx, mn))))
+            for lp, mx, mn in zip(lps, maxs, mins)}
+    norm = {k: v / mtfs[lps[0]] for k, v in sorted(mtfs.items())}
+    assert got.norm_mtfs == norm
+    want50 = float(interp1d(list(norm.values()), list(norm.keys()), fill_value="extrapolate")(0.5))
+    assert got.relative_resolution(50) == want50
 
 
 # --------------------------------------------------------------- picket fence (BASELINE config #3)
