@@ -155,8 +155,10 @@ struct PeakLds {                                   // the LDS of one profile's s
 // One profile, NT lanes (tid = 0 .. NT-1): `xfull` has `len` samples, the search region is [rlo, rhi) clipped to it; results go
 // to the profile's own output rows (o_count / o_status one element, o_idx / o_lb / o_rb `cap`, o_p 6 x cap).  Every lane of the
 // group calls it; all of them return together.
+// (`prm` BY VALUE: with a reference to the kernel's by-value parameter struct the gfx950 build ranked peak_sort="widths"
+// wrongly -- tests/test_gpu_parity.py::test_find_peaks_vs_oracle_random caught it on the device, the CPU emulator did not.)
 template <bool STAGE, int NT>
-__device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xfull, int len, int rlo, int rhi, const pl_peak_params& prm,
+__device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xfull, int len, int rlo, int rhi, const pl_peak_params prm,
                                                    int cap, int maxc, const PeakLds L, int tid, int32_t* __restrict__ o_count,
                                                    int32_t* __restrict__ o_idx, int32_t* __restrict__ o_lb, int32_t* __restrict__ o_rb,
                                                    double* __restrict__ o_p, int32_t* __restrict__ o_status) {
