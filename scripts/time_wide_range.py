@@ -12,9 +12,12 @@ from pylinac_amd.synthetic import epid_open_field_frames
 
 dev = torch.device("cuda:0")
 fr = epid_open_field_frames(256, 1024, 1024, device=dev)
-lo, hi = int(fr.to(torch.int32).min()), int(fr.to(torch.int32).max())
-wide = ((fr.to(torch.float32) - lo) * (65000.0 / (hi - lo))).round().clamp(0, 65535).to(torch.int32).to(torch.uint16)
-for name, x in (("synthetic (range %d)" % (hi - lo), fr), ("stretched to 0..65000", wide)):
+# the raw frames already span 0..65535 (noise tails); what matters is the range of the FILTERED frame: map the 1 % / 99 %
+# quantiles of frame 0 (background level, field plateau) to 500 / 65000
+q = torch.quantile(fr[0].to(torch.float32).flatten()[::16], torch.tensor([0.01, 0.99], device=dev))
+lo, hi = float(q[0]), float(q[1])
+wide = ((fr.to(torch.float32) - lo) * (64500.0 / (hi - lo)) + 500.0).round().clamp(0, 65535).to(torch.int32).to(torch.uint16)
+for name, x in (("synthetic (plateau - background = %d)" % (hi - lo), fr), ("plateau - background stretched to 64500", wide)):
     pipe = EpidPipeline(256, 1024, 1024, dev)
     for _ in range(3):
         res = pipe.run(x)
