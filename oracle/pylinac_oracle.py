@@ -24,9 +24,11 @@ For those two levels this file holds
 
 Parity status: pinned (reference KATs of SURVEY.md section 8c + golden vectors generated
 by importing the reference through oracle/ref_loader.py, and by scikit-image 0.18.3 itself for the
-skimage-level restatements), with ONE exception: ``rescale_dicom_values`` is PARITY UNPINNED -- its
-arithmetic is pydicom's ``pixels.apply_rescale`` (``pydicom>=2.0,<3``), which is not installed in
-the build container, so nothing here could run it.
+skimage-level restatements).  ``rescale_dicom_values`` restates a THIRD-PARTY algorithm, pydicom's
+``pixels.apply_rescale`` (``pydicom>=2.0,<3``, the reference's pyproject.toml:40; not installed in the
+build container, so nothing here could run it): it is pinned on the known answers of the reference's
+own tests for ``_rescale_dicom_values`` (tests_basic/core/test_image.py:131-229), not on vectors
+produced by pydicom.
 """
 from __future__ import annotations
 
@@ -1897,9 +1899,10 @@ class StarshotRestated:
 
 
 # --------------------------------------------------------------------------------------
-# "next" row f1, DICOM half: _rescale_dicom_values (pylinac/core/image.py:363-389).  PARITY UNPINNED: the rescale itself
-# is pydicom's pixels.apply_rescale (pydicom>=2.0,<3 per the reference's pyproject.toml; not installed here), restated
-# from its documented behaviour; nothing in this container can run it.
+# "next" row f1, DICOM half: _rescale_dicom_values (pylinac/core/image.py:363-389).  The rescale itself is pydicom's
+# pixels.apply_rescale (third party: pydicom>=2.0,<3 per the reference's pyproject.toml:40; not installed here), restated from
+# its documented behaviour and pinned on the known answers of the reference's own tests (tests_basic/core/test_image.py:131-229:
+# pass-through cases, slope * array + intercept, the inversion cases, no overflow when inverting); no pydicom-produced vector.
 # --------------------------------------------------------------------------------------
 
 def rescale_dicom_values(unscaled: np.ndarray, rescale_slope=None, rescale_intercept=None,

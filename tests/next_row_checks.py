@@ -510,8 +510,8 @@ def check_canny_integer_images(golden, dev):
 
 def check_rescale_dicom_values(dev):
     """image.rescale_dicom_values against the oracle restatement (pydicom's apply_rescale cannot be run here) and, as the
-    pin, against the identities the reference's own tests state for it: uint16 / int16 stored values, CT-like and EPID-like
-    tags, forced / tag-driven / suppressed inversion."""
+    pin, against the known answers of the reference's own tests for it (tests_basic/core/test_image.py:131-229): uint16 / int16
+    stored values, CT-like and EPID-like tags, forced / tag-driven / suppressed inversion, no overflow when inverting."""
     from oracle import pylinac_oracle as o
     from pylinac_amd import image
 
@@ -546,6 +546,19 @@ def check_rescale_dicom_values(dev):
         assert np.array_equal(plain, scaled) and np.array_equal(forced, scaled.max() - scaled + scaled.min())
         assert np.array_equal(auto, forced if auto_equals_forced_inversion else plain)
         assert not np.array_equal(forced, plain)
+    # test_no_overflow_when_inverting (tests_basic/core/test_image.py:210-229): arrays whose min + max exceed their dtype's range
+    # come back swapped, in their own dtype (the reference's parameters; its int8 case is a dtype no DICOM pixel format and no
+    # entry point of this library has: refused loudly)
+    for arr in (np.array([200, 250], dtype=np.uint8), np.array([60_000, 60_000], dtype=np.uint16),
+                np.array([2**31 - 100, 2**31 - 1], dtype=np.int32)):
+        inv = image.rescale_dicom_values(torch.from_numpy(arr.reshape(1, 1, 2)).to(dev), invert_pixels=True, raw_pixels=False)
+        inv = inv.cpu().numpy().ravel()
+        assert inv.dtype == arr.dtype and inv[0] == arr[1] and inv[1] == arr[0], (arr.dtype, inv)
+    try:
+        image.rescale_dicom_values(torch.from_numpy(np.array([120, 127], dtype=np.int8).reshape(1, 1, 2)).to(dev), invert_pixels=True)
+        raise AssertionError("int8 frames must be refused")
+    except TypeError:
+        pass
 
 
 def check_thickness_roi(golden, dev):
