@@ -384,6 +384,14 @@ int pl_canny_normalise(const double* d_g_img, const double* d_g_ones, int64_t n,
                        void* stream);
 int pl_canny_nms(const double* d_isobel, const double* d_jsobel, int64_t n, int h, int w, double* d_magnitude,
                  unsigned char* d_local_max, void* stream);
+/* canny(mask=...) (skimage/feature/_canny.py, smooth_with_function_and_mask + the eroded mask): pl_canny_mask_prepare writes
+ * the image with 0 outside the mask and the mask as float64 (both are then smoothed; pl_canny_normalise divides them per frame);
+ * pl_canny_nms_masked is pl_canny_nms restricted to binary_erosion(mask, 3 x 3 ones, border_value=0).  d_mask: uint8, non-zero =
+ * inside; mask_per_frame = 1: [n][h][w], 0: one [h][w] plane for the batch. */
+int pl_canny_mask_prepare(const double* d_img, const unsigned char* d_mask, int mask_per_frame, int64_t n, int64_t per_frame,
+                          double* d_masked, double* d_mask_f, void* stream);
+int pl_canny_nms_masked(const double* d_isobel, const double* d_jsobel, int64_t n, int h, int w, const unsigned char* d_mask,
+                        int mask_per_frame, double* d_magnitude, unsigned char* d_local_max, void* stream);
 int pl_order_stats_f64(const double* d_values, int64_t n, int64_t count, const int64_t* d_ranks, int n_ranks,
                        double* d_out, void* stream);
 /* skimage.transform.hough_line(image, theta) accumulator (pylinac/planar_imaging.py:3158): d_image uint8 [h][w]

@@ -108,6 +108,8 @@ SIGNATURES = {
     "pl_polygon_roi_stats": ([_p, _i, _l, _i, _i, _p, _i, _i, _l, _p, _p, _p], C.c_int),
     "pl_canny_normalise": ([_p, _p, _l, _l, _p, _p], C.c_int),
     "pl_canny_nms": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),
+    "pl_canny_mask_prepare": ([_p, _p, _i, _l, _l, _p, _p, _p], C.c_int),
+    "pl_canny_nms_masked": ([_p, _p, _l, _i, _i, _p, _i, _p, _p, _p], C.c_int),
     "pl_order_stats_f64": ([_p, _l, _l, _p, _i, _p, _p], C.c_int),
     "pl_hough_line": ([_p, _i, _i, _p, _p, _i, _p, _p], C.c_int),
     "pl_max_filter1d": ([_p, _p, _i, _l, _i, _i, _i, _i, _p], C.c_int),

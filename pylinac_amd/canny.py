@@ -2,7 +2,7 @@
 phantom finder calls it (pylinac/planar_imaging.py:574-588: ``feature.canny(image, sigma, low_threshold,
 high_threshold, use_quantiles=True)``; scikit-image 0.18.3 semantics, skimage/feature/_canny.py).
 
-Float64 and uint8 / uint16 / int16 images (the latter through skimage's ``img_as_float`` scaling), ``mask=None``.  Every stage is a kernel: Gaussian smoothing with zero padding normalised by the
+Float64 and uint8 / uint16 / int16 images (the latter through skimage's ``img_as_float`` scaling), with or without ``mask``.  Every stage is a kernel: Gaussian smoothing with zero padding normalised by the
 smoothed all-ones frame, the two Sobel gradients, hypot + interpolated non-maximum suppression, exact float64 order
 statistics for the quantile thresholds, and hysteresis by 8-connected labelling.
 """
@@ -22,8 +22,6 @@ _IMG_AS_FLOAT = {torch.uint8: (0, 255), torch.uint16: (0, 65535), torch.int16: (
 def canny(image, sigma: float = 1.0, low_threshold=None, high_threshold=None, mask=None,
           use_quantiles: bool = False, device=None) -> torch.Tensor:
     """-> uint8 edge map(s) with the shape of ``image`` ([H, W] or a batch [N, H, W])."""
-    if mask is not None:
-        raise NotImplementedError("canny(mask=...) is not built; pylinac calls it without a mask")
     t = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image))
     if t.dtype not in _IMG_AS_FLOAT and t.dtype != torch.float64:
         raise TypeError("canny needs a float64, uint8, uint16 or int16 image")
@@ -66,17 +64,38 @@ def canny(image, sigma: float = 1.0, low_threshold=None, high_threshold=None, ma
     else:
         high_threshold = high_threshold / dtype_max
     lib, st = _lib.load(), torch.cuda.current_stream(dev).cuda_stream
-    g_img = ops.gaussian_filter_mode(x, sigma, mode="constant")
-    g_one = ops.gaussian_filter_mode(torch.ones((1, h, w), dtype=torch.float64, device=dev), sigma, mode="constant")
     smoothed = torch.empty_like(x)
-    check(lib.pl_canny_normalise(g_img.data_ptr(), g_one.data_ptr(), n, h * w, smoothed.data_ptr(), st),
-          "pl_canny_normalise")
+    mk = None
+    if mask is None:
+        g_img = ops.gaussian_filter_mode(x, sigma, mode="constant")
+        g_one = ops.gaussian_filter_mode(torch.ones((1, h, w), dtype=torch.float64, device=dev), sigma, mode="constant")
+        check(lib.pl_canny_normalise(g_img.data_ptr(), g_one.data_ptr(), n, h * w, smoothed.data_ptr(), st),
+              "pl_canny_normalise")
+    else:
+        # smooth_with_function_and_mask (_canny.py): G(image with 0 outside the mask) / (G(mask) + eps), per frame; the mask
+        # is one [H, W] plane for every frame or one per frame
+        mk = mask if isinstance(mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mask))
+        mk = (mk.to(dev) != 0).to(torch.uint8).contiguous()
+        if tuple(mk.shape) not in ((h, w), (n, h, w)):
+            raise ValueError("mask must have the shape of the image")
+        per_frame = 1 if mk.ndim == 3 else 0
+        masked, mask_f = torch.empty_like(x), torch.empty_like(x)
+        check(lib.pl_canny_mask_prepare(x.data_ptr(), mk.data_ptr(), per_frame, n, h * w, masked.data_ptr(), mask_f.data_ptr(), st),
+              "pl_canny_mask_prepare")
+        g_img = ops.gaussian_filter_mode(masked, sigma, mode="constant")
+        g_msk = ops.gaussian_filter_mode(mask_f, sigma, mode="constant")
+        check(lib.pl_canny_normalise(g_img.data_ptr(), g_msk.data_ptr(), 1, n * h * w, smoothed.data_ptr(), st),
+              "pl_canny_normalise")
     jsobel = ops.sobel(smoothed, 1)
     isobel = ops.sobel(smoothed, 0)
     mag = torch.empty_like(x)
     local_max = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
-    check(lib.pl_canny_nms(isobel.data_ptr(), jsobel.data_ptr(), n, h, w, mag.data_ptr(), local_max.data_ptr(), st),
-          "pl_canny_nms")
+    if mk is None:
+        check(lib.pl_canny_nms(isobel.data_ptr(), jsobel.data_ptr(), n, h, w, mag.data_ptr(), local_max.data_ptr(), st),
+              "pl_canny_nms")
+    else:
+        check(lib.pl_canny_nms_masked(isobel.data_ptr(), jsobel.data_ptr(), n, h, w, mk.data_ptr(), 1 if mk.ndim == 3 else 0,
+                                      mag.data_ptr(), local_max.data_ptr(), st), "pl_canny_nms_masked")
     if use_quantiles:
         thr = torch.stack([_percentile_f64(mag, 100.0 * low_threshold), _percentile_f64(mag, 100.0 * high_threshold)],
                           dim=1).contiguous()

@@ -35,8 +35,23 @@ __global__ void canny_magnitude_kernel(const double* __restrict__ isob, const do
   mag[i] = hypot(isob[i], jsob[i]);
 }
 
+// masked_image = image where the mask is set, 0 elsewhere; mask_f = the mask as float64 (smooth_with_function_and_mask,
+// skimage/feature/_canny.py: both go through the same Gaussian).  The mask is one plane for the batch or one per frame.
+__global__ void canny_mask_prepare_kernel(const double* __restrict__ img, const unsigned char* __restrict__ mask, int64_t per_frame,
+                                          int64_t mask_stride, int64_t total, double* __restrict__ masked, double* __restrict__ mask_f) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const bool on = mask[(i / per_frame) * mask_stride + i % per_frame] != 0;
+  masked[i] = on ? img[i] : 0.0;
+  mask_f[i] = on ? 1.0 : 0.0;
+}
+
+// mask: NULL (every pixel counts: the eroded mask is the frame's interior) or uint8, one plane per frame (stride per_frame) or
+// one for the batch (stride 0): eroded_mask = binary_erosion(mask, 3 x 3 ones, border_value=0) -- the pixel and its eight
+// neighbours are all inside the frame and all set
 __global__ void canny_nms_kernel(const double* __restrict__ isob, const double* __restrict__ jsob,
                                  const double* __restrict__ mag, int h, int w, int64_t total,
+                                 const unsigned char* __restrict__ mask, int64_t mask_stride,
                                  unsigned char* __restrict__ local_max) {
   const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= total) return;
@@ -44,7 +59,15 @@ __global__ void canny_nms_kernel(const double* __restrict__ isob, const double* 
   const int r = (int)((i / w) % h);
   unsigned char res = 0;
   const double m = mag[i];
-  if (r > 0 && c > 0 && r < h - 1 && c < w - 1 && m > 0.0) {
+  bool inside = r > 0 && c > 0 && r < h - 1 && c < w - 1;
+  if (inside && mask) {
+    const unsigned char* mk = mask + (i / ((int64_t)h * w)) * mask_stride + (int64_t)r * w + c;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+      for (int dc = -1; dc <= 1; ++dc) inside = inside && mk[(int64_t)dr * w + dc] != 0;
+  }
+  if (inside && m > 0.0) {
     const double is = isob[i], js = jsob[i];
     const double ai = fabs(is), aj = fabs(js);
     auto M = [&](int dr, int dc) { return mag[i + (int64_t)dr * w + dc]; };
@@ -190,8 +213,28 @@ extern "C" int pl_canny_normalise(const double* d_g_img, const double* d_g_ones,
   return pl_check_launch("pl_canny_normalise");
 }
 
+extern "C" int pl_canny_nms_masked(const double* d_isobel, const double* d_jsobel, int64_t n, int h, int w, const unsigned char* d_mask,
+                                   int mask_per_frame, double* d_magnitude, unsigned char* d_local_max, void* stream);
+
 extern "C" int pl_canny_nms(const double* d_isobel, const double* d_jsobel, int64_t n, int h, int w, double* d_magnitude,
                             unsigned char* d_local_max, void* stream) {
+  return pl_canny_nms_masked(d_isobel, d_jsobel, n, h, w, nullptr, 0, d_magnitude, d_local_max, stream);
+}
+
+extern "C" int pl_canny_mask_prepare(const double* d_img, const unsigned char* d_mask, int mask_per_frame, int64_t n, int64_t per_frame,
+                                     double* d_masked, double* d_mask_f, void* stream) {
+  PL_REQUIRE(d_img && d_mask && d_masked && d_mask_f, "null pointer");
+  PL_REQUIRE(n >= 0 && per_frame > 0, "bad shape");
+  const int64_t total = n * per_frame;
+  if (total == 0) return PL_OK;
+  PL_REQUIRE(pl_cdiv(total, kThreads) <= 0x7fffffffLL, "batch too large for one launch");
+  hipLaunchKernelGGL(canny_mask_prepare_kernel, dim3((unsigned)pl_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, d_img,
+                     d_mask, per_frame, mask_per_frame ? per_frame : (int64_t)0, total, d_masked, d_mask_f);
+  return pl_check_launch("pl_canny_mask_prepare");
+}
+
+extern "C" int pl_canny_nms_masked(const double* d_isobel, const double* d_jsobel, int64_t n, int h, int w, const unsigned char* d_mask,
+                                   int mask_per_frame, double* d_magnitude, unsigned char* d_local_max, void* stream) {
   PL_REQUIRE(d_isobel && d_jsobel && d_magnitude && d_local_max, "null pointer");
   PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");
   const int64_t total = n * (int64_t)h * w;
@@ -200,8 +243,8 @@ extern "C" int pl_canny_nms(const double* d_isobel, const double* d_jsobel, int6
   const unsigned blocks = (unsigned)pl_cdiv(total, kThreads);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(canny_magnitude_kernel, dim3(blocks), dim3(kThreads), 0, st, d_isobel, d_jsobel, total, d_magnitude);
-  hipLaunchKernelGGL(canny_nms_kernel, dim3(blocks), dim3(kThreads), 0, st, d_isobel, d_jsobel, d_magnitude, h, w, total,
-                     d_local_max);
+  hipLaunchKernelGGL(canny_nms_kernel, dim3(blocks), dim3(kThreads), 0, st, d_isobel, d_jsobel, d_magnitude, h, w, total, d_mask,
+                     mask_per_frame ? (int64_t)h * w : (int64_t)0, d_local_max);
   return pl_check_launch("pl_canny_nms");
 }
 

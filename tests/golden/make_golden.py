@@ -851,6 +851,7 @@ def main():
                     os.path.join(HERE, "contrast.npz"), ROOT], check=True)
     # ---- 22. canny on integer images (scikit-image 0.18.3 itself)
     subprocess.run([PY39, os.path.join(HERE, "skimage_canny_int_py39.py"), os.path.join(HERE, "canny_int.npz")], check=True)
+    subprocess.run([PY39, os.path.join(HERE, "skimage_canny_mask_py39.py"), os.path.join(HERE, "canny_mask.npz")], check=True)
     # ---- 23. ThicknessROI: the reference's own pylinac.ct.ThicknessROI on synthetic wire ramps
     subprocess.run([PY39, os.path.join(HERE, "skimage_thickness_py39.py"), os.path.join(HERE, "thickness.npz"), ROOT], check=True)
     # ---- 24. CatPhan volume localisation: the reference's own find_phantom_axis / find_origin_slice

@@ -508,6 +508,28 @@ def check_canny_integer_images(golden, dev):
         assert np.array_equal(got.cpu().numpy().astype(bool), g[f"{n}.edges"]), n
 
 
+def check_canny_masked(golden, dev):
+    """canny(mask=...) against scikit-image 0.18.3's own feature.canny (tests/golden/skimage_canny_mask_py39.py): disk, half-plane,
+    speckle and border masks, float64 and uint16 images, an all-false mask; plus the batched form with one mask per frame."""
+    from pylinac_amd import canny
+
+    g = golden("canny_mask")
+    for n in g["names"]:
+        kw = eval(str(g[f"{n}.kw"]), {"__builtins__": {}}, {"dict": dict})
+        got = canny.canny(torch.from_numpy(g[f"{n}.img"]).to(dev), mask=g[f"{n}.mask"], **kw)
+        assert np.array_equal(got.cpu().numpy().astype(bool), g[f"{n}.edges"]), n
+    # two frames of one shape, each with its own mask, in ONE call == the two single calls
+    a, b = "f64_half", "f64_half"
+    img = np.stack([g["f64_half.img"], g["f64_half.img"][::-1].copy()])
+    msk = np.stack([g["f64_half.mask"], g["f64_half.mask"][:, ::-1].copy()])
+    kw = eval(str(g["f64_half.kw"]), {"__builtins__": {}}, {"dict": dict})
+    both = canny.canny(torch.from_numpy(img).to(dev), mask=msk, **kw).cpu().numpy()
+    for k in range(2):
+        one = canny.canny(torch.from_numpy(img[k]).to(dev), mask=msk[k], **kw).cpu().numpy()
+        assert np.array_equal(both[k], one), k
+    assert np.array_equal(both[0].astype(bool), g["f64_half.edges"])
+
+
 def check_rescale_dicom_values(dev):
     """image.rescale_dicom_values against the oracle restatement (pydicom's apply_rescale cannot be run here) and, as the
     pin, against the known answers of the reference's own tests for it (tests_basic/core/test_image.py:131-229): uint16 / int16

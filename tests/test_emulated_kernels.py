@@ -852,3 +852,9 @@ def test_emulated_fused_tail_vs_separate(emulated):
     import next_row_checks as checks
 
     assert checks.check_fused_tail_vs_separate(emulated) == 4
+
+
+def test_emulated_canny_masked(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_canny_masked(golden, emulated)

@@ -1881,3 +1881,11 @@ def test_fused_tail_vs_separate(dev):
     import next_row_checks as checks
 
     assert checks.check_fused_tail_vs_separate(dev, shapes=((3, 200, 520), (2, 128, 64), (2, 130, 1032), (1, 2, 8), (3, 1024, 1024))) == 5
+
+
+@pytest.mark.gpu
+def test_canny_masked_vs_skimage_golden(golden, dev):
+    """canny(mask=...) == scikit-image 0.18.3's feature.canny with the same mask (golden from the helper interpreter)."""
+    import next_row_checks as checks
+
+    checks.check_canny_masked(golden, dev)
