@@ -309,13 +309,24 @@ def main():
     frames = epid_open_field_frames(n, h, w, seed0=1000 + first, device=dev)
     pipe = EpidPipeline(n, h, w, dev)
 
+    pending = []          # work handles of the record gathers in flight (N > 1): the gather of step k overlaps step k + 1
+
     def step(events=None):
         res = pipe.run(frames, events)
         rec = res.record()
-        return pdist.all_gather_records(rec, n_total) if dist is not None else rec
+        if dist is None:
+            return rec
+        while len(pending) >= 2:          # at most two gathers in flight: their output buffers stay bounded
+            pending.pop(0).wait()
+        return pdist.all_gather_records(rec, n_total, pending)
+
+    def drain():
+        while pending:
+            pending.pop(0).wait()         # every gathered record table is complete before the clock stops
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -324,6 +335,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(events)
+    drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -401,10 +413,12 @@ def main():
             # this object reports the same step after the governor has settled -- the rate of a production loop.
             for _ in range(max(args.sustained_steps // 3, 1)):
                 step()
+            drain()
             torch.cuda.synchronize()
             ts = time.perf_counter()
             for _ in range(args.sustained_steps):
                 step()
+            drain()
             torch.cuda.synchronize()
             sdt = (time.perf_counter() - ts) / args.sustained_steps
             line["sustained"] = {"steps": args.sustained_steps, "settle_steps": max(args.sustained_steps // 3, 1),

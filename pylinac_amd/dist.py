@@ -20,21 +20,32 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def all_gather_records(local: torch.Tensor, n_total: int | None = None) -> torch.Tensor:
+def all_gather_records(local: torch.Tensor, n_total: int | None = None, pending: list | None = None) -> torch.Tensor:
     """Gather per-image records ``[n_local, K]`` from every rank into ``[n_total, K]`` (rank
     order == frame order for ``shard_range`` shards).  Uneven shards are padded to the largest
-    shard for the single ``all_gather_into_tensor`` and trimmed afterwards."""
+    shard for the single ``all_gather_into_tensor`` and trimmed afterwards.
+
+    Even shards (``n_total`` divisible by the world size: the bench's weak-scaling case) cost ONE collective and nothing else --
+    no size exchange, no host-to-device copy of a length (a ``torch.tensor([...], device=...)`` per call is a blocking copy: it
+    stopped the host from running ahead of the device, 60 us per step on one rank).  ``pending``: when a list is given and the
+    shards are even, the collective is issued with ``async_op=True`` and its work handle appended; the returned tensor is
+    complete once that handle's ``wait()`` has been called (or the device synchronised) -- the gather of step k then overlaps
+    the kernels of step k + 1 (RCCL runs on its own stream)."""
     if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size()
     k = local.shape[1:]
+    if n_total is not None and n_total % world == 0 and local.shape[0] == n_total // world:
+        out = torch.empty((n_total, *k), dtype=local.dtype, device=local.device)
+        if pending is not None:
+            pending.append(dist.all_gather_into_tensor(out, local.contiguous(), async_op=True))
+        else:
+            dist.all_gather_into_tensor(out, local.contiguous())
+        return out
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    if n_total is not None and n_total % world == 0:
-        counts = [n_total // world] * world
-    else:
-        sizes = [torch.zeros_like(n_local) for _ in range(world)]
-        dist.all_gather(sizes, n_local)
-        counts = [int(s.item()) for s in sizes]
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    counts = [int(s.item()) for s in sizes]
     m = max(counts)
     padded = local
     if local.shape[0] != m:

@@ -29,6 +29,16 @@ def _worker(rank, world, port, n_total, q):
         # the "record" of frame i is [i, 2i, ..., 9i]: stands in for the per-image scalars
         local = torch.arange(a, b, dtype=torch.float64)[:, None] * torch.arange(1, 10, dtype=torch.float64)[None, :]
         full = pdist.all_gather_records(local, n_total)
+        # the pipelined form bench.py uses for N > 1: three "steps" whose gathers are in flight together, completed by wait()
+        pending, outs = [], []
+        for step in range(3):
+            outs.append(pdist.all_gather_records(local + step, n_total, pending))
+        for w in pending:
+            w.wait()
+        for step, o in enumerate(outs):
+            want = torch.arange(n_total, dtype=torch.float64)[:, None] * torch.arange(1, 10, dtype=torch.float64)[None, :] + step
+            assert torch.equal(o, want), (rank, step)
+        assert len(pending) == (3 if n_total % world == 0 else 0)      # uneven shards take the blocking path
         q.put((rank, full.numpy()))
     finally:
         dist.destroy_process_group()
