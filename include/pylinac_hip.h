@@ -566,6 +566,13 @@ int pl_pf_windows(const uint16_t* in, int64_t n, int h, int w, const double* d_s
                   const double* d_spacing, const int32_t* d_leaf_top, const int32_t* d_leaf_bottom, int nleaves,
                   double height_threshold, double edge_threshold, int lmax, double* d_prof, int32_t* d_len,
                   double* d_offset, int32_t* d_status, void* stream);
+/* pl_pf_windows with the caller's bound on the window height (max_rows = the tallest bottom - top of the leaf table, 1..48):
+ * the kernel's LDS per wave follows it, which is what decides how many waves hide each other's latency. */
+int pl_pf_windows_rows(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                       const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap,
+                       const double* d_spacing, const int32_t* d_leaf_top, const int32_t* d_leaf_bottom, int nleaves,
+                       int max_rows, double height_threshold, double edge_threshold, int lmax, double* d_prof, int32_t* d_len,
+                       double* d_offset, int32_t* d_status, void* stream);
 int pl_pf_positions(const int32_t* d_status, const double* d_fwxm, const double* d_offset, int64_t m,
                     double* d_pos, void* stream);
 

@@ -142,6 +142,8 @@ SIGNATURES = {
     "pl_pf_pickets": ([_p, _p, _i, _p, _i, _l, _p, _p, _p, _p], C.c_int),
     "pl_pf_windows": ([_p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _d, _d, _i, _p, _p, _p, _p, _p],
                       C.c_int),
+    "pl_pf_windows_rows": ([_p, _l, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _d, _d, _i, _p, _p, _p, _p, _p],
+                      C.c_int),
     "pl_pf_positions": ([_p, _p, _p, _l, _p, _p], C.c_int),
     "pl_fwxm_record": ([_p, _p, _p, _i, _l, _p, _p], C.c_int),
     "pl_find_peaks": (

@@ -172,9 +172,14 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
                   const double* __restrict__ spacing, const int32_t* __restrict__ leaf_top,
                   const int32_t* __restrict__ leaf_bottom, int nleaves, double height_threshold,
                   double edge_threshold, int lmax, double* __restrict__ prof_out, int32_t* __restrict__ len_out,
-                  double* __restrict__ offset_out, int32_t* __restrict__ status_out, int64_t total_windows) {
-  __shared__ unsigned short s_win[kThreads / PL_WAVE][kMaxRows * kMaxCols];
-  __shared__ double s_std[kThreads / PL_WAVE][kMaxRows];
+                  double* __restrict__ offset_out, int32_t* __restrict__ status_out, int64_t total_windows, int rows_cap) {
+  // dynamic LDS: per wave `rows_cap` x 128 window pixels, then `rows_cap` row deviations.  rows_cap is the tallest leaf window
+  // the CALLER will ask for (the leaf geometry is host knowledge): the fixed 48-row capacity of rounds 1-3 kept three
+  // workgroups on a CU where a 26-row bank leaves room for five -- the kernel is one long dependent chain per wave and
+  // lives on the number of waves that hide it
+  extern __shared__ __attribute__((aligned(16))) unsigned char pf_lds[];
+  double* const s_std_all = reinterpret_cast<double*>(pf_lds);
+  unsigned short* const s_win_all = reinterpret_cast<unsigned short*>(pf_lds + (size_t)(kThreads / PL_WAVE) * rows_cap * sizeof(double));
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // window index in 32 bits (the launcher refuses more: the profiles of 2^31 windows would be 2 TB), wave-uniform: scalar
   const unsigned win = blockIdx.x * (unsigned)(kThreads / PL_WAVE) + (unsigned)wv;
@@ -199,12 +204,13 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   right = __builtin_amdgcn_readfirstlane(right);
   const int nrows = bottom - top, ncols = right - left;
   const double off = (approx - sp / 2 > 0.0) ? (approx - sp / 2) : 0.0;   // max(approx_idx - spacing/2, 0)
-  if (nrows <= 0 || ncols <= 2 || nrows > kMaxRows || ncols > kMaxCols || !(sp == sp)) {
+  if (nrows <= 0 || ncols <= 2 || nrows > rows_cap || ncols > kMaxCols || !(sp == sp)) {
     if (lane == 0) { status_out[win] = 3; len_out[win] = 0; offset_out[win] = off; }
     return;
   }
   const unsigned short* f = in + frame * (size_t)h * w;
-  unsigned short* sw = s_win[wv];
+  unsigned short* sw = s_win_all + (size_t)wv * rows_cap * kMaxCols;
+  double* const s_std_w = s_std_all + (size_t)wv * rows_cap;
   // the window into LDS, its maximum on the way (element e = lane, lane + 64, ..: row / column advance by carry, no division).
   // EIGHT loads are issued before the first of them is consumed: one load per trip made the wave pay the full memory
   // latency for every 64 pixels (eight dependent round trips for a 12 x 38 window)
@@ -274,7 +280,7 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
       };
       const double mean = block_sum([&](int c) { return q(rr, c); }) / (double)ncols;
       const double ss = block_sum([&](int c) { const double x = q(rr, c) - mean; return x * x; });
-      if (act && j == 0) s_std[wv][r] = sqrt(ss / (double)ncols);
+      if (act && j == 0) s_std_w[r] = sqrt(ss / (double)ncols);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -283,11 +289,11 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   double smax, med;
   {
     const bool act = lane < nrows;
-    const double va = act ? s_std[wv][lane] : 0.0;
+    const double va = act ? s_std_w[lane] : 0.0;
     smax = pl_wave_reduce(act ? va : -1.0, [](double x, double y) { return x > y ? x : y; });   // std >= 0
     int rank = 0;
     for (int b2 = 0; b2 < nrows; ++b2) {
-      const double vb = s_std[wv][b2];
+      const double vb = s_std_w[b2];
       rank += (vb < va || (vb == va && b2 < lane)) ? 1 : 0;
     }
     const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
@@ -385,11 +391,28 @@ extern "C" int pl_pf_pickets(const int32_t* d_count, const double* d_props, int 
   return pl_check_launch("pl_pf_pickets");
 }
 
+extern "C" int pl_pf_windows_rows(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                                  const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap,
+                                  const double* d_spacing, const int32_t* d_leaf_top, const int32_t* d_leaf_bottom,
+                                  int nleaves, int max_rows, double height_threshold, double edge_threshold, int lmax,
+                                  double* d_prof, int32_t* d_len, double* d_offset, int32_t* d_status, void* stream);
+
 extern "C" int pl_pf_windows(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
                              const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap,
                              const double* d_spacing, const int32_t* d_leaf_top, const int32_t* d_leaf_bottom,
                              int nleaves, double height_threshold, double edge_threshold, int lmax,
                              double* d_prof, int32_t* d_len, double* d_offset, int32_t* d_status, void* stream) {
+  return pl_pf_windows_rows(in, n, h, w, d_sub, d_div, d_pk_count, d_pk_idx, d_pk_val, cap, d_spacing, d_leaf_top, d_leaf_bottom,
+                            nleaves, kMaxRows, height_threshold, edge_threshold, lmax, d_prof, d_len, d_offset, d_status, stream);
+}
+
+// max_rows: the tallest leaf window (bottom - top) of the call, 1 .. 48 -- windows taller than that get status 3
+extern "C" int pl_pf_windows_rows(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                                  const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap,
+                                  const double* d_spacing, const int32_t* d_leaf_top, const int32_t* d_leaf_bottom,
+                                  int nleaves, int max_rows, double height_threshold, double edge_threshold, int lmax,
+                                  double* d_prof, int32_t* d_len, double* d_offset, int32_t* d_status, void* stream) {
+  PL_REQUIRE(max_rows >= 1 && max_rows <= kMaxRows, "max_rows 1..48");
   PL_REQUIRE(in && d_sub && d_div && d_pk_count && d_pk_idx && d_pk_val && d_spacing && d_leaf_top && d_leaf_bottom &&
                  d_prof && d_len && d_offset && d_status, "null pointer");
   PL_REQUIRE(n >= 0 && h > 0 && w > 0 && cap > 0 && nleaves > 0 && lmax >= kMaxCols, "bad shape (lmax >= 128)");
@@ -397,9 +420,11 @@ extern "C" int pl_pf_windows(const uint16_t* in, int64_t n, int h, int w, const 
   const int64_t total = n * (int64_t)nleaves * cap;
   const int64_t blocks = pl_cdiv(total, kThreads / PL_WAVE);
   PL_REQUIRE(total <= 0x7fffffffLL, "batch too large");
-  hipLaunchKernelGGL(pf_windows_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, in, h, w,
+  const int rows_cap = (max_rows + 1) & ~1;          // even: the window planes stay 4-byte aligned behind the row deviations
+  const size_t lds = (size_t)(kThreads / PL_WAVE) * rows_cap * (sizeof(double) + (size_t)kMaxCols * sizeof(unsigned short));
+  hipLaunchKernelGGL(pf_windows_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, in, h, w,
                      d_sub, d_div, d_pk_count, d_pk_idx, d_pk_val, cap, d_spacing, d_leaf_top, d_leaf_bottom, nleaves,
-                     height_threshold, edge_threshold, lmax, d_prof, d_len, d_offset, d_status, total);
+                     height_threshold, edge_threshold, lmax, d_prof, d_len, d_offset, d_status, total, rows_cap);
   return pl_check_launch("pl_pf_windows");
 }
 

@@ -107,11 +107,12 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, mlc: str = "MILLENNIUM", nu
     lens = torch.empty(m, dtype=torch.int32, device=dev)
     offset = torch.empty(m, dtype=torch.float64, device=dev)
     status = torch.empty(m, dtype=torch.int32, device=dev)
-    check(lib.pl_pf_windows(x.data_ptr(), n, h, w, vmin.data_ptr(), gmax.data_ptr(), peaks.count.data_ptr(),
+    max_rows = min(max(max(b - t for t, b in zip(tops, bottoms)), 1), 48)      # taller windows: status 3, as before
+    check(lib.pl_pf_windows_rows(x.data_ptr(), n, h, w, vmin.data_ptr(), gmax.data_ptr(), peaks.count.data_ptr(),
                             pk_idx.data_ptr(), pk_val.data_ptr(), cap, spacing.data_ptr(), d_top.data_ptr(),
-                            d_bot.data_ptr(), nl, float(height_threshold), float(edge_threshold), lmax,
+                            d_bot.data_ptr(), nl, max_rows, float(height_threshold), float(edge_threshold), lmax,
                             prof.data_ptr(), lens.data_ptr(), offset.data_ptr(), status.data_ptr(), st),
-          "pl_pf_windows")
+          "pl_pf_windows_rows")
     wpk = ops.find_peaks_batch(prof, cap=1, lens=lens, fwxm_height=fwxm / 100, max_number=1)   # FWXMProfile edges
     rec = ops.fwxm_record(wpk)
     pos = torch.empty(m, dtype=torch.float64, device=dev)
