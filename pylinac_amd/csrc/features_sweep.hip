@@ -40,7 +40,8 @@ namespace {
 
 constexpr int kSwThreads = 256;
 constexpr int kSwMaxSide = 160;          // window side limit (coordinates are packed in 8 bits)
-constexpr int kSwMaxRuns = 4096;         // row runs of one level
+constexpr int kSwMaxRuns = 4096;         // row runs of one level: the large table (second pass)
+constexpr int kSwFirstRuns = 1536;       // ... the first pass's table: 74 KB of LDS per workgroup, two workgroups per CU
 constexpr int kSwMaxCrop = 64;           // candidate bbox side limit for the crop analysis
 constexpr int kSwMaxHullPts = 8 * kSwMaxCrop;
 constexpr int kSwMaxOut = 8;
@@ -105,17 +106,22 @@ struct SweepSrc {
 __global__ void __launch_bounds__(kSwThreads)
 bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, int w, const SweepParams prm,
                 int32_t* __restrict__ out_count, double* __restrict__ out_xy, int32_t* __restrict__ out_level,
-                int32_t* __restrict__ status) {
+                int32_t* __restrict__ status, int max_runs, int redo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // Two passes share this kernel.  The first runs every frame with a table of kSwFirstRuns row runs: 74 KB of LDS, TWO
+  // workgroups per CU (the 4096-run table of rounds 1-3 left ONE: four waves on a CU for a kernel that is all latency).  A
+  // level with more runs (speckle) ends the frame with status 5; the second pass (redo != 0) takes exactly those frames again
+  // with the large table -- a workgroup whose frame is not marked leaves at once.
+  if (redo && status[blockIdx.x] != 5) return;
   // ---- dynamic LDS carve-up
   const int npx = h * w;
   unsigned* run_info = reinterpret_cast<unsigned*>(smem);                 // start | end << 8 | row << 16
-  unsigned* parent = run_info + kSwMaxRuns;
-  int* t_area = reinterpret_cast<int*>(parent + kSwMaxRuns);
-  int* t_r1 = t_area + kSwMaxRuns;
-  int* t_c0 = t_r1 + kSwMaxRuns;
-  int* t_c1 = t_c0 + kSwMaxRuns;
-  int* s_hx = t_c1 + kSwMaxRuns;
+  unsigned* parent = run_info + max_runs;
+  int* t_area = reinterpret_cast<int*>(parent + max_runs);
+  int* t_r1 = t_area + max_runs;
+  int* t_c0 = t_r1 + max_runs;
+  int* t_c1 = t_c0 + max_runs;
+  int* s_hx = t_c1 + max_runs;
   int* s_hy = s_hx + kSwMaxHullPts;
   int* s_hull_x = s_hy + kSwMaxHullPts;
   int* s_hull_y = s_hull_x + kSwMaxHullPts + 1;
@@ -126,7 +132,7 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
   __shared__ int row_cnt[kSwMaxSide + 1];                                  // runs per row, then exclusive prefix
   __shared__ int s_cand[32];
   __shared__ int s_ncand, s_nh, s_inside, s_nruns;
-  __shared__ int s_cnt[4];
+  __shared__ int s_cnt[kSwThreads / PL_WAVE > 4 ? kSwThreads / PL_WAVE : 4];
   __shared__ double s_red[3][kSwThreads / PL_WAVE];
   __shared__ double s_xy[kSwMaxOut][2];
   __shared__ int s_nout, s_first_level, s_status;
@@ -257,7 +263,7 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
     }
     __syncthreads();
     const int nruns = s_nruns;
-    if (nruns > kSwMaxRuns) {                                // salt-and-pepper level: more runs than the table holds
+    if (nruns > max_runs) {                                  // salt-and-pepper level: more runs than the table holds
       if (tid == 0) s_status = 5;
       break;
     }
@@ -611,16 +617,21 @@ int sweep_launch(const double* d_sample, const SweepSrc& src, int64_t n, int h, 
   for (int k = 0; k < kSwMaxLevels; ++k) prm.cut[k] = k < nlevels ? h_cutoffs[k] : 0.0;
   for (int k = 1; k < nlevels; ++k)
     if (!(h_cutoffs[k] > h_cutoffs[k - 1])) { pl_set_error("%s: cutoffs must increase", who); return PL_ERR_INVALID_ARG; }
-  const size_t lds = (size_t)kSwMaxRuns * 6 * 4 + ((size_t)2 * kSwMaxHullPts + 2 * (kSwMaxHullPts + 1)) * 4 +
-                     (size_t)3 * kSwMaxCrop * kSwMaxCrop + (size_t)h * ((w + 3) & ~3);
+  const size_t fixed = ((size_t)2 * kSwMaxHullPts + 2 * (kSwMaxHullPts + 1)) * 4 + (size_t)3 * kSwMaxCrop * kSwMaxCrop +
+                       (size_t)h * ((w + 3) & ~3);
+  const size_t lds = (size_t)kSwMaxRuns * 6 * 4 + fixed, lds_first = (size_t)kSwFirstRuns * 6 * 4 + fixed;
   static std::atomic<size_t> attr_lds{0};
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute((const void*)bb_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { pl_set_error("%s: LDS attribute: %s", who, hipGetErrorString(e)); return PL_ERR_HIP; }
     attr_lds = lds;
   }
+  // measured on 512 Winston-Lutz frames (scripts/time_wl_variants.py, analyze_batch per pass): this pair 0.956 ms clean / 1.157 ms
+  // noisy; one pass with the large table 1.080 / 1.319; 512 threads per workgroup instead of 256: 0.985 / 1.21
+  hipLaunchKernelGGL(bb_sweep_kernel, dim3((unsigned)n), dim3(kSwThreads), lds_first, (hipStream_t)stream, d_sample, src, h, w, prm,
+                     d_count, d_xy, d_level, d_status, kSwFirstRuns, 0);
   hipLaunchKernelGGL(bb_sweep_kernel, dim3((unsigned)n), dim3(kSwThreads), lds, (hipStream_t)stream, d_sample, src, h, w, prm,
-                     d_count, d_xy, d_level, d_status);
+                     d_count, d_xy, d_level, d_status, kSwMaxRuns, 1);
   return pl_check_launch(who);
 }
 }  // namespace
