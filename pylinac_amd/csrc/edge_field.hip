@@ -4,7 +4,7 @@
 //   edges = skimage.filters.gaussian(raw, sigma)  (mode 'nearest') ct.py:3328 (ndimage.gaussian_filter underneath)
 //   edges[disk].min(), .max()                                      the histogram range of threshold_otsu, ct.py:3334-3338
 // Rounds 1-3 ran this as scharr -> gaussian axis 0 -> gaussian axis 1 -> minmax -> minmax_masked: five launches and
-// 2 MiB of float64 per 512 x 512 slice written three times and read four times.  Here a workgroup owns a 32 x 64 output
+// 2 MiB of float64 per 512 x 512 slice written three times and read four times.  Here a workgroup owns a 24 x 64 output
 // tile: the raw samples with a (radius + 1) halo go to LDS once (clamped coordinates: for the one pixel beyond the frame
 // that scharr's 'reflect' border needs, reflection and clamping coincide), the Scharr magnitude is evaluated on the tile
 // plus the Gaussian's halo -- at CLAMPED frame coordinates, which is exactly what mode 'nearest' feeds the filter --,
@@ -17,7 +17,9 @@
 namespace {
 
 constexpr int kEfThreads = 256;
-constexpr int kTH = 32, kTW = 64;
+// 24 x 64 tiles: 37 KB of LDS and (radius 4) 97 registers leave FOUR workgroups on a CU; the 32-row tile of the first version
+// (48 KB, 129 registers) left three, and the kernel waits more than it computes
+constexpr int kTH = 24, kTW = 64;
 
 __device__ __forceinline__ void ef_atomic_min(double* addr, double v) {
   unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
@@ -48,7 +50,7 @@ __global__ void ef_init_kernel(double* __restrict__ rawmax, double* __restrict__
 }
 
 template <typename T, int RAD>
-__global__ void __launch_bounds__(kEfThreads)
+__global__ void __launch_bounds__(kEfThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 edge_field_kernel(const T* __restrict__ in, int h, int w, int tiles_r, int tiles_c, const double* __restrict__ wts,
                   const uint8_t* __restrict__ mask, double* __restrict__ out, double* __restrict__ rawmax,
                   double* __restrict__ mn, double* __restrict__ mx) {
