@@ -11,6 +11,9 @@
 // Needs w % 8 == 0, 16-byte aligned rows, h > 1.
 #pragma once
 // (included after pl_common.h by every user)
+#ifndef PL_MEDIAN_ROLL
+#define PL_MEDIAN_ROLL 1
+#endif
 
 // consume(r, m): m[j] = median of column c0 + j of row r (the value itself: sign-extended for int16 frames).
 // AHEAD rows are in flight as raw 16-byte loads before their turn (the consumers that run few waves per CU -- one workgroup
@@ -62,24 +65,58 @@ __device__ __forceinline__ void pl_median3_rows(const T* __restrict__ f, int h, 
       mi[slot][j] = pl_smed3(a, b, c);
     }
   };
-  Raw ring[AHEAD];
-#pragma unroll
-  for (int k = 0; k < AHEAD; ++k) ring[k] = fetch(r0 - 1 + k);
-#pragma unroll
-  for (int k = 0; k < ROWS + 2; ++k) {              // walk row k = frame row r0 - 1 + k
-    const Raw cur = ring[k % AHEAD];
-    if (k + AHEAD < ROWS + 2) ring[k % AHEAD] = fetch(r0 - 1 + k + AHEAD);
-    digest(cur, k % 3);
-    if (k < 2) continue;
+  auto emit = [&](int k) {                          // the output row of walk step k (>= 2)
     const int r = r0 + k - 2;
-    if (r >= h) continue;                           // wave-uniform
+    if (r >= h) return;                             // wave-uniform
     int m[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       m[j] = pl_smed3(max(max(lo[0][j], lo[1][j]), lo[2][j]), pl_smed3(mi[0][j], mi[1][j], mi[2][j]),
                       min(min(hi[0][j], hi[1][j]), hi[2][j]));
     consume(r, m);
+  };
+  Raw ring[AHEAD];
+#pragma unroll
+  for (int k = 0; k < AHEAD; ++k) ring[k] = fetch(r0 - 1 + k);
+#if PL_MEDIAN_ROLL
+  // Rolled walk (the default; -DPL_MEDIAN_ROLL=0 builds the straight-line one): the body below is kChunk rows -- a multiple of 3
+  // (the sorted-triple slots) and of AHEAD (the load ring), so every slot index in it is a compile-time constant -- inside a real
+  // loop; the ROWS % kChunk rows that remain follow unrolled.  The straight-line form of 34 rows is 40 KB of code per
+  // instantiation, and that is what made the two median stages box-dependent: on the evidence boxes where they ran 1.3x slower
+  // (0.227 / 0.253 ms against 0.173 / 0.191) the rolled form runs at the fast boxes' rate (0.174 / 0.202: A/B of two library
+  // builds on one such box) -- an instruction-cache effect, not the memory system as first assumed.
+  constexpr int kChunk = (AHEAD % 3 == 0) ? AHEAD : 3 * AHEAD;
+  auto step = [&](int k, int ring_slot, int tri_slot) {      // k may be a run-time value; the two slots are constants
+    const Raw cur = ring[ring_slot];
+    ring[ring_slot] = fetch(r0 - 1 + k + AHEAD);    // rows past the walk are clamped to a valid address and never consumed
+    digest(cur, tri_slot);
+  };
+  step(0, 0 % AHEAD, 0);
+  step(1, 1 % AHEAD, 1);
+  constexpr int kMain = (ROWS / kChunk) * kChunk;
+#pragma unroll 1
+  for (int kb = 2; kb < 2 + kMain; kb += kChunk) {
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+      step(kb + j, (2 + j) % AHEAD, (2 + j) % 3);   // kb - 2 is a multiple of kChunk: (kb + j) % AHEAD == (2 + j) % AHEAD, same mod 3
+      emit(kb + j);
+    }
   }
+#pragma unroll
+  for (int k = 2 + kMain; k < ROWS + 2; ++k) {
+    step(k, k % AHEAD, k % 3);
+    emit(k);
+  }
+#else
+#pragma unroll
+  for (int k = 0; k < ROWS + 2; ++k) {              // walk row k = frame row r0 - 1 + k
+    const Raw cur = ring[k % AHEAD];
+    if (k + AHEAD < ROWS + 2) ring[k % AHEAD] = fetch(r0 - 1 + k + AHEAD);
+    digest(cur, k % 3);
+    if (k < 2) continue;
+    emit(k);
+  }
+#endif
 }
 
 // the 16-bit patterns of two values in one dword (low half = a)
