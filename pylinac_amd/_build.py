@@ -34,7 +34,9 @@ HIPCC_FLAGS = [
 
 # per-file additions: the matrix-core Gaussian keeps its accumulators in VGPRs (gfx950's register file is unified; the
 # default AGPR form costs one v_accvgpr_read per accumulator value the integer recombination touches)
-EXTRA_FLAGS = {"gaussian_mm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"gaussian_mm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # edge_field asks for four waves per SIMD; its radius >= 6 instantiations settle for three and say so
+               "edge_field.hip": ["-Wno-pass-failed"]}
 
 
 def hipcc() -> str:
