@@ -107,7 +107,7 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, mlc: str = "MILLENNIUM", nu
     lens = torch.empty(m, dtype=torch.int32, device=dev)
     offset = torch.empty(m, dtype=torch.float64, device=dev)
     status = torch.empty(m, dtype=torch.int32, device=dev)
-    max_rows = min(max(max(b - t for t, b in zip(tops, bottoms)), 1), 48)      # taller windows: status 3, as before
+    max_rows = min(max([b - t for t, b in zip(tops, bottoms)] + [1]), 48)      # taller windows: status 3, as before
     check(lib.pl_pf_windows_rows(x.data_ptr(), n, h, w, vmin.data_ptr(), gmax.data_ptr(), peaks.count.data_ptr(),
                             pk_idx.data_ptr(), pk_val.data_ptr(), cap, spacing.data_ptr(), d_top.data_ptr(),
                             d_bot.data_ptr(), nl, max_rows, float(height_threshold), float(edge_threshold), lmax,
