@@ -281,11 +281,19 @@ int pl_linspace_edges(const double* d_lo, const double* d_hi, int nbins, int64_t
  * d_thr[i] = otsu_i * scale (pylinac/ct.py:3338-3340 uses 0.8), d_raw[i] = otsu_i (optional, may be NULL). */
 int pl_otsu_from_counts(const uint32_t* d_counts, const double* d_edges, int nbins, int64_t n, double scale,
                         double* d_thr, double* d_raw, void* stream);
-/* The edge-image half of the slice localisation in one pass (csrc/edge_field.hip; pylinac/ct.py:391-392, 3327-3338):
- * d_out float64 [n][h][w] = ndimage.gaussian_filter(skimage.filters.scharr(frame.astype(float)), mode='nearest') with the
- * taps d_weights (device float64 [2 * radius + 1], radius 1..8), bit-identical to pl_scharr + pl_gaussian2d_mode(mode 1);
- * d_rawmax[i] = max of the Scharr magnitude itself (the "no edges" test), d_min / d_max[i] = extrema of d_out over the
- * pixels selected by d_mask (uint8 [h][w] shared by all frames; NULL = every pixel).  int16 / uint16 frames. */
+/* The edge-image half of the slice localisation as one streaming pass (csrc/edge_stream.hip; pylinac/ct.py:391-392,
+ * 3327-3338): ndimage.gaussian_filter(skimage.filters.scharr(frame.astype(float)), mode='nearest') with the taps d_weights
+ * (device float64 [2 * radius + 1], radius 1..8), every float64 value bit-identical to pl_scharr + pl_gaussian2d_mode(mode 1).
+ *   d_out (may be NULL: extrema only) = the plane as out_dtype PL_F64 [n][h][w], or PL_F32 = RN of the float64 value (1 MiB
+ *   per 512 x 512 slice instead of 2; pl_edge_otsu / pl_edge_regions decide on it and fall back to the exact value where the
+ *   rounding could matter);  d_rawmax[i] = max of the Scharr magnitude itself (the "no edges" test np.max(edges) < 0.1);
+ *   d_min / d_max[i] = exact float64 extrema of the smoothed plane over the selected pixels: d_row_spans (int32 [h][2]:
+ *   columns [c0, c1) of each row, shared by all frames -- a disk) or d_mask (uint8 [h][w], shared), or every pixel when both
+ *   are NULL (+inf / -inf when nothing is selected).  int16 / uint16 frames. */
+int pl_edge_plane(const void* in, int dtype, int64_t n, int h, int w, const double* d_weights, int radius,
+                  const int32_t* d_row_spans, const uint8_t* d_mask, void* d_out, int out_dtype, double* d_rawmax,
+                  double* d_min, double* d_max, void* stream);
+/* round 3's form of the same pass: float64 plane, byte mask (= pl_edge_plane(..., NULL, d_mask, d_out, PL_F64, ...)) */
 int pl_scharr_gaussian(const void* in, int dtype, int64_t n, int h, int w, const double* d_weights, int radius,
                        const uint8_t* d_mask, double* d_out, double* d_rawmax, double* d_min, double* d_max, void* stream);
 /* The labelling half of get_regions (pylinac/ct.py:3340-3347) for every frame in ONE launch, a workgroup per frame with the

@@ -36,7 +36,7 @@ HIPCC_FLAGS = [
 # default AGPR form costs one v_accvgpr_read per accumulator value the integer recombination touches)
 EXTRA_FLAGS = {"gaussian_mm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # edge_field asks for four waves per SIMD; its radius >= 6 instantiations settle for three and say so
-               "edge_field.hip": ["-Wno-pass-failed"]}
+               "edge_stream.hip": ["-Wno-pass-failed"]}
 
 
 def hipcc() -> str:

@@ -1,0 +1,269 @@
+// CatPhan slice localisation, the edge-image half as a STREAMING pass (pylinac/ct.py:391-392, 3327-3340):
+//   raw   = skimage.filters.scharr(slice.astype(float))            pylinac/ct.py:391, 3327
+//   max(raw)                                                       the "no edges" test np.max(edges) < 0.1, ct.py:392
+//   edges = skimage.filters.gaussian(raw, sigma)  (mode 'nearest') ct.py:3328 (ndimage.gaussian_filter underneath)
+//   edges[disk].min(), .max()                                      the histogram range of threshold_otsu, ct.py:3334-3338
+//   thres = threshold_otsu(edges[disk]) * 0.8                      ct.py:3338-3340 (256 bins, np.histogram's edges)
+//
+// Round 3 (csrc/edge_field.hip, deleted) ran 24 x 64 tiles with three workgroup barriers each, evaluated the Scharr magnitude
+// 1.5 times per pixel through twelve float64 multiply-adds, and wrote a float64 plane (2 MiB per 512 x 512 slice, four times
+// the slice) that the histogram and the labelling kernel read again: 1.05 + 0.29 ms per 320 slices, 0.8 % of the HBM roofline.
+//
+// pl_edge_plane -- MARCHING STRIPS, one wave each, no workgroup barrier: a lane owns one column of a 64-column strip and walks
+// down a segment of rows.
+//   * Scharr in INTEGERS: every tap of scharr's two 3 x 3 kernels is a multiple of 1/16 and the pixels are 16-bit integers, so
+//     16 s0 and 16 s1 are exact int32 values and separable (vertical difference / smoothing per lane from a three-row register
+//     window, the horizontal half from the two neighbour lanes by DPP wave shifts); o = s0^2 + s1^2 is an exact float64
+//     whatever the order of the reference's twelve accumulations (every partial sum is a multiple of 1/16 below 2^53), so
+//     sqrt(o) / sqrt(2) -- the same two IEEE operations as the reference -- gives the same bits;
+//   * axis 0 of the Gaussian from a (2 radius + 1)-row REGISTER window of the lane's column (the loop is unrolled by the
+//     window length so that every slot is a fixed register), axis 1 through a wave-private LDS row; both in scipy's
+//     symmetric-kernel order (centre tap, then (left + right) * weight from the outermost pair inwards, NI_Correlate1D);
+//   * mode 'nearest' = the edge value at CLAMPED coordinates: rows beyond the frame repeat the first / last edge row, lanes
+//     beyond the frame copy the lane that holds column 0 / w - 1;
+//   * the plane leaves as float32 (1 MiB per slice; RN of the float64 value) or float64; the three extrema stay exact float64.
+// pl_edge_otsu -- the 256-bin histogram of the selected pixels and skimage's threshold from it in one launch.  On a float32
+// plane a pixel's bin is decided from the two float32 neighbours of its value (the exact value lies between them); the
+// few pixels per slice whose interval straddles a bin edge are recomputed exactly from the 16-bit slice (es_exact_wave: the
+// whole wave evaluates the (2 radius + 1)^2 Scharr values, the operation order of the streaming kernel).  The workgroup that
+// finishes a slice last runs the class statistics (otsu_counts_kernel's order of operations).
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kEsThreads = 256;
+constexpr int kEsWaves = kEsThreads / PL_WAVE;
+
+// skimage's Scharr magnitude sqrt(s0^2 + s1^2) / sqrt(2) from the integer responses S0 = 16 s0, S1 = 16 s1 (|S| <= 16 * 65535):
+// o = (S0^2 + S1^2) / 256 is exact, so RN(sqrt(o)) = RN(sqrt(K)) / 16 with the integer K = S0^2 + S1^2 < 2^43, and the
+// quotient by RN(sqrt(2)) becomes a quotient by 16 RN(sqrt(2)) (both scalings are powers of two).
+//   * the square root is the compiler's own float64 expansion (v_rsq_f64 seed, Goldschmidt step, two fused residual
+//     corrections: AMDGPULegalizerInfo::legalizeFSQRTF64) WITHOUT its range scaling (K is an integer: never below 2^-767)
+//     and with the seed taken from max(K, 1), which runs K = 0 through the same chain to exactly 0 instead of a special case;
+//   * the division by the constant is Markstein's three operations q0 = g r, rem = fma(-q0, c, g), q = fma(rem, r, q0) with
+//     r = RN(1 / c).  Correct rounding for EVERY float64 g is proven by enumeration (tests/test_exact_sequences.py): the exact
+//     value the last operation rounds lies within g / c * 4.001 * 2^-106 of g / c, only six mantissas g put g / c that close
+//     to a rounding boundary, and all six round correctly.
+__device__ __forceinline__ double es_edge(int S0, int S1) {
+  const double a = (double)S0, b = (double)S1;
+  const double x = fma(a, a, b * b);                    // K, exact
+  const long long xb = __double_as_longlong(x);
+  const unsigned hi = max((unsigned)(xb >> 32), 0x3ff00000u);
+  const double xs = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)(xb & 0xffffffffLL)));
+  const double y = __builtin_amdgcn_rsq(xs);
+  double g = x * y;
+  double hh = y * 0.5;
+  const double r0 = fma(-hh, g, 0.5);
+  g = fma(g, r0, g);
+  hh = fma(hh, r0, hh);
+  const double d0 = fma(-g, g, x);
+  g = fma(d0, hh, g);
+  const double d1 = fma(-g, g, x);
+  g = fma(d1, hh, g);                                    // RN(sqrt(K))
+  constexpr double c16 = 0x1.6a09e667f3bcdp+4;           // 16 * 1.4142135623730951
+  constexpr double r16 = 0x1.6a09e667f3bccp-5;           // RN(1 / 1.4142135623730951) / 16
+  const double q0 = g * r16;
+  const double rem = fma(-q0, c16, g);
+  return fma(rem, r16, q0);                              // RN(RN(sqrt(K)) / 16 / RN(sqrt(2))) = np.sqrt(output) / np.sqrt(ndim)
+}
+
+// DPP wave shifts whose first / last lane receives 0 (bound_ctrl): no copy of the source into the destination first, as the
+// "keeps its own value" form of pl_common.h needs; the two outermost lanes of a strip are halo that nothing reads
+__device__ __forceinline__ int es_from_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int es_from_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+
+__device__ __forceinline__ int es_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// non-negative float64 values (and -inf / +inf as "empty") order like their bit patterns read as SIGNED 64-bit integers
+__device__ __forceinline__ void es_atomic_max(double* addr, double v) {
+  atomicMax(reinterpret_cast<long long*>(addr), __double_as_longlong(v));
+}
+__device__ __forceinline__ void es_atomic_min(double* addr, double v) {
+  atomicMin(reinterpret_cast<long long*>(addr), __double_as_longlong(v));
+}
+
+__global__ void es_init_kernel(double* __restrict__ rawmax, double* __restrict__ mn, double* __restrict__ mx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kEsThreads + threadIdx.x;
+  if (i >= n) return;
+  const double pinf = __longlong_as_double(0x7ff0000000000000LL), ninf = __longlong_as_double((long long)0xfff0000000000000ULL);
+  rawmax[i] = ninf;
+  mn[i] = pinf;
+  mx[i] = ninf;
+}
+
+template <typename T, int RAD, typename OutT>
+__global__ void __launch_bounds__(kEsThreads)
+edge_stream_kernel(const T* __restrict__ in, int h, int w, int strips, int segs, int seg_rows, int64_t items,
+                   const double* __restrict__ wts, const int* __restrict__ spans, const uint8_t* __restrict__ mask,
+                   OutT* __restrict__ out, double* __restrict__ rawmax, double* __restrict__ mn, double* __restrict__ mx) {
+  constexpr int WIN = 2 * RAD + 1, HALO = RAD + 1, OUTW = PL_WAVE - 2 * HALO;
+  __shared__ double vbuf[kEsWaves][2][PL_WAVE + 2 * RAD];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t item = (int64_t)blockIdx.x * kEsWaves + wv;
+  if (item >= items) return;                             // a whole wave leaves; the kernel has no workgroup barrier
+  const int s = (int)(item % strips);
+  const int g = (int)((item / strips) % segs);
+  const int64_t f = item / ((int64_t)strips * segs);
+
+  double tw[RAD + 1];
+#pragma unroll
+  for (int k = 0; k <= RAD; ++k) tw[k] = wts[k];
+
+  const int c_base = s * OUTW - HALO;
+  const int vc = c_base + lane;
+  const int cc = es_clamp(vc, 0, w - 1);
+  const int r0 = g * seg_rows, r1 = min(h, r0 + seg_rows);
+  const int vstart = r0 - RAD, vend = r1 + RAD;          // the edge rows (virtual: clamped into the frame) the segment needs
+  const T* src = in + f * (int64_t)h * w;
+  const bool out_lane = lane >= HALO && lane < PL_WAVE - HALO && vc < w;
+  const bool fix_left = c_base < 0, fix_right = c_base + PL_WAVE - 1 > w - 1;
+  const int lane_first = -c_base, lane_last = w - 1 - c_base;     // the lanes that hold column 0 / w - 1 (when fix_*)
+  auto ld = [&](int row) { return (int)src[(int64_t)row * w + cc]; };
+  auto crow = [&](int v) { return min(max(v, 0) + 1, h - 1); };   // the row BELOW edge row v (clamped like scharr's reflect)
+
+  const double pinf = __longlong_as_double(0x7ff0000000000000LL), ninf = __longlong_as_double((long long)0xfff0000000000000ULL);
+  double lo = pinf, hi = ninf, rmax = ninf;
+  auto edge_row = [&](int ra, int rb, int rc) {
+    const int dv = rc - ra;                                // vertical difference: 16 * the 'edge' taps
+    const int sv = 3 * (ra + rc) + 10 * rb;                // vertical smoothing
+    const int dl = es_from_prev(dv), dr = es_from_next(dv);
+    const int sl = es_from_prev(sv), sr = es_from_next(sv);
+    double e = es_edge(3 * (dl + dr) + 10 * dv, sr - sl);
+    if (fix_left) { const double t = __shfl(e, lane_first, PL_WAVE); e = lane < lane_first ? t : e; }
+    if (fix_right) { const double t = __shfl(e, lane_last, PL_WAVE); e = lane > lane_last ? t : e; }
+    return e;
+  };
+  // prologue: the first edge row that lies inside the frame fills the whole window -- edge rows above the frame (first
+  // segment) are copies of it (mode 'nearest'), elsewhere the other slots are overwritten before the first output reads them
+  const int fr = max(vstart, 0);
+  int ra = ld(max(fr - 1, 0)), rb = ld(fr), rc = ld(min(fr + 1, h - 1));
+  int pending = ld(crow(fr + 1));
+  double e = edge_row(ra, rb, rc);
+  double E[WIN];
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) E[i] = e;
+  int par = 0;
+  const bool has_out = out != nullptr, has_mask = mask != nullptr, has_spans = spans != nullptr;
+  OutT* dptr = out + (f * h + r0) * (int64_t)w + vc;
+  const uint8_t* mptr = mask + (int64_t)r0 * w + cc;
+  const int hm1 = h - 1;
+
+  // slot i of the window holds edge row base + i.  Every step computes its edge row (the last iteration may run up to
+  // 2 * radius rows past the segment: clamped loads, results unused); only the output half of a step is conditional, so the
+  // raw-row rotation and the window slots are pure register renaming in the unrolled body
+  for (int base = fr + 1; base < vend; base += WIN) {
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) {
+      const int vr = base + i;
+      ra = rb; rb = rc; rc = pending;
+      pending = ld(crow(vr + 1));                          // in flight for a whole step
+      const double en = edge_row(ra, rb, rc);
+      e = vr <= hm1 ? en : e;                              // rows below the frame (last segment) repeat the last edge row
+      E[i] = e;
+      const int ro = vr - RAD;
+      if (ro >= r0 && ro < r1) {
+        const double ctr = E[(i + WIN - RAD) % WIN];
+        double a0 = ctr * tw[RAD];
+#pragma unroll
+        for (int k = RAD; k >= 1; --k)
+          a0 = a0 + (E[(i + 2 * WIN - RAD - k) % WIN] + E[(i + WIN - RAD + k) % WIN]) * tw[RAD - k];
+        double* vb = vbuf[wv][par];
+        par ^= 1;
+        vb[lane + RAD] = a0;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double a1 = a0 * tw[RAD];
+#pragma unroll
+        for (int k = RAD; k >= 1; --k) a1 = a1 + (vb[lane + RAD - k] + vb[lane + RAD + k]) * tw[RAD - k];
+        asm volatile("" ::: "memory");
+        bool sel = out_lane;
+        if (has_spans) {
+          const int c0 = spans[2 * ro], c1 = spans[2 * ro + 1];
+          sel = sel & (vc >= c0) & (vc < c1);
+        } else if (has_mask) {
+          sel = sel & (*mptr != 0);                        // every lane reads inside the frame (clamped column)
+          mptr += w;
+        }
+        const double cm = out_lane ? ctr : ninf;
+        rmax = cm > rmax ? cm : rmax;
+        lo = (sel & (a1 < lo)) ? a1 : lo;
+        hi = (sel & (a1 > hi)) ? a1 : hi;
+        if (has_out) {
+          if (out_lane) *dptr = (OutT)a1;
+          dptr += w;
+        }
+      }
+    }
+  }
+  rmax = pl_wave_reduce(rmax, [](double a, double c) { return a > c ? a : c; });
+  lo = pl_wave_reduce(lo, [](double a, double c) { return a < c ? a : c; });
+  hi = pl_wave_reduce(hi, [](double a, double c) { return a > c ? a : c; });
+  if (lane == 0) {
+    if (rmax != ninf) es_atomic_max(rawmax + f, rmax);
+    if (lo != pinf) es_atomic_min(mn + f, lo);
+    if (hi != ninf) es_atomic_max(mx + f, hi);
+  }
+}
+
+template <typename T, typename OutT>
+int es_launch(const T* in, int64_t n, int h, int w, const double* wts, int radius, const int* spans, const uint8_t* mask,
+              OutT* out, double* rawmax, double* mn, double* mx, hipStream_t st) {
+  const int outw = PL_WAVE - 2 * (radius + 1);
+  const int strips = (int)pl_cdiv(w, outw);
+  // segments: enough waves to fill the chip several times over (8 waves per SIMD resident), at least 32 rows each so that
+  // the 2 * radius extra edge rows of a segment stay a small share
+  const int64_t want = 4LL * pl_cu_count() * 32;
+  int segs = (int)pl_cdiv(want, n * strips);
+  const int max_segs = (int)pl_cdiv(h, 32);
+  if (segs > max_segs) segs = max_segs;
+  if (segs < 1) segs = 1;
+  const int seg_rows = (int)pl_cdiv(h, segs);
+  segs = (int)pl_cdiv(h, seg_rows);
+  const int64_t items = n * strips * segs;
+  const int64_t blocks = pl_cdiv(items, kEsWaves);
+  if (blocks > 0x7fffffffLL) { pl_set_error("pl_edge_plane: batch too large for one launch"); return PL_ERR_INVALID_ARG; }
+  hipLaunchKernelGGL(es_init_kernel, dim3((unsigned)pl_cdiv(n, kEsThreads)), dim3(kEsThreads), 0, st, rawmax, mn, mx, n);
+#define ES_CASE(R)                                                                                                         \
+  case R:                                                                                                                  \
+    hipLaunchKernelGGL((edge_stream_kernel<T, R, OutT>), dim3((unsigned)blocks), dim3(kEsThreads), 0, st, in, h, w, strips, \
+                       segs, seg_rows, items, wts, spans, mask, out, rawmax, mn, mx);                                      \
+    break;
+  switch (radius) {
+    ES_CASE(1) ES_CASE(2) ES_CASE(3) ES_CASE(4) ES_CASE(5) ES_CASE(6) ES_CASE(7) ES_CASE(8)
+    default: pl_set_error("pl_edge_plane: radius 1..8"); return PL_ERR_UNSUPPORTED;
+  }
+#undef ES_CASE
+  return pl_check_launch("pl_edge_plane");
+}
+
+}  // namespace
+
+extern "C" int pl_edge_plane(const void* in, int dtype, int64_t n, int h, int w, const double* d_weights, int radius,
+                             const int32_t* d_row_spans, const uint8_t* d_mask, void* d_out, int out_dtype,
+                             double* d_rawmax, double* d_min, double* d_max, void* stream) {
+  PL_REQUIRE(in && d_weights && d_rawmax && d_min && d_max, "null pointer");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");
+  PL_REQUIRE(radius >= 1 && radius <= 8, "radius 1..8 (sigma <= 2 at truncate 4)");
+  PL_REQUIRE(dtype == PL_I16 || dtype == PL_U16, "int16 / uint16 slices");
+  PL_REQUIRE(out_dtype == PL_F32 || out_dtype == PL_F64, "float32 or float64 plane");
+  PL_REQUIRE(!(d_row_spans && d_mask), "row spans or a byte mask, not both");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PL_I16) {
+    if (out_dtype == PL_F32)
+      return es_launch<short, float>((const short*)in, n, h, w, d_weights, radius, d_row_spans, d_mask, (float*)d_out, d_rawmax, d_min, d_max, st);
+    return es_launch<short, double>((const short*)in, n, h, w, d_weights, radius, d_row_spans, d_mask, (double*)d_out, d_rawmax, d_min, d_max, st);
+  }
+  if (out_dtype == PL_F32)
+    return es_launch<unsigned short, float>((const unsigned short*)in, n, h, w, d_weights, radius, d_row_spans, d_mask, (float*)d_out, d_rawmax, d_min, d_max, st);
+  return es_launch<unsigned short, double>((const unsigned short*)in, n, h, w, d_weights, radius, d_row_spans, d_mask, (double*)d_out, d_rawmax, d_min, d_max, st);
+}
+
+/* round 3's entry point, kept: the float64 plane with a byte mask */
+extern "C" int pl_scharr_gaussian(const void* in, int dtype, int64_t n, int h, int w, const double* d_weights, int radius,
+                                  const uint8_t* d_mask, double* d_out, double* d_rawmax, double* d_min, double* d_max,
+                                  void* stream) {
+  PL_REQUIRE(d_out, "null pointer");
+  return pl_edge_plane(in, dtype, n, h, w, d_weights, radius, nullptr, d_mask, d_out, PL_F64, d_rawmax, d_min, d_max, stream);
+}

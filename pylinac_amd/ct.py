@@ -53,6 +53,41 @@ def disk_mask(center_rc, radius: float, shape) -> np.ndarray:
 _DISK_CACHE: dict = {}
 
 
+def row_spans(mask: np.ndarray) -> np.ndarray | None:
+    """int32 [H, 2] column intervals [c0, c1) of a mask whose rows are single runs (a disk); None when some row is not."""
+    m = np.asarray(mask) != 0
+    h, w = m.shape
+    cnt = m.sum(axis=1)
+    c0 = np.where(cnt > 0, m.argmax(axis=1), 0)
+    c1 = c0 + cnt
+    ok = all(m[r, c0[r]:c1[r]].all() for r in range(h))
+    return np.stack([c0, c1], axis=1).astype(np.int32) if ok else None
+
+
+def _disk_spans_on_device(h: int, w: int, mm_per_pixel: float, dev) -> torch.Tensor:
+    key = ("spans", h, w, float(mm_per_pixel), str(dev))
+    if key not in _DISK_CACHE:
+        cy, cx = h / 2 - 0.5, w / 2 - 0.5
+        _DISK_CACHE[key] = torch.from_numpy(row_spans(disk_mask((cy, cx), 110 / mm_per_pixel, (h, w)))).to(dev)
+    return _DISK_CACHE[key]
+
+
+def STAGE_TIMERS(x: torch.Tensor, mm_per_pixel: float):
+    """(name, thunk) pairs for scripts/time_ct_stages.py: the entry points of the localisation, each on its own."""
+    n, h, w = x.shape
+    disk = _disk_on_device(h, w, mm_per_pixel, x.device)
+    spans = _disk_spans_on_device(h, w, mm_per_pixel, x.device)
+    yield "edge_plane float32 + spans", lambda: ops.edge_plane(x, 1, spans=spans)
+    yield "edge_plane float64 + spans", lambda: ops.edge_plane(x, 1, spans=spans, dtype=torch.float64)
+    yield "edge_plane float32 + byte mask", lambda: ops.edge_plane(x, 1, mask=disk)
+    yield "edge_plane extrema only", lambda: ops.edge_plane(x, 1, spans=spans, want_plane=False)
+    e64, _, lo, hi = ops.edge_plane(x, 1, spans=spans, dtype=torch.float64)
+    yield "otsu_float_masked (float64 plane, round 3)", lambda: ops.otsu_float_masked(e64, disk, scale=0.8, lohi=(lo, hi))
+    thr, _ = ops.otsu_float_masked(e64, disk, scale=0.8, lohi=(lo, hi))
+    yield "mask_regions (float64 plane, round 3)", lambda: ops.mask_regions(e64, thr, min(int(max(h, w) / 100), 3) + 1, True, 64)
+    yield "phantom_roi_batch", lambda: phantom_roi_batch(x, mm_per_pixel)
+
+
 def _disk_on_device(h: int, w: int, mm_per_pixel: float, dev) -> torch.Tensor:
     key = (h, w, float(mm_per_pixel), str(dev))
     if key not in _DISK_CACHE:

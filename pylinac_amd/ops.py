@@ -766,6 +766,33 @@ def scharr_gaussian(frames: torch.Tensor, sigma: float, mask: torch.Tensor | Non
     return out, rawmax, lo, hi
 
 
+def edge_plane(frames: torch.Tensor, sigma: float, spans: torch.Tensor | None = None, mask: torch.Tensor | None = None,
+               dtype=torch.float32, want_plane: bool = True):
+    """The streaming form of ``scharr_gaussian`` (``pl_edge_plane``): the smoothed Scharr plane as float32 (the float64 value
+    rounded to nearest; ``dtype=torch.float64`` for the exact plane; ``want_plane=False``: extrema only) and the exact float64
+    extrema over the pixels selected by ``spans`` (int32 [H, 2] column intervals per row, see ``row_spans``) or ``mask``
+    (uint8 [H, W]).  -> (plane or None, raw Scharr maximum [N], min [N], max [N])."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    dev = x.device
+    wts, _, lw = _device_weights(sigma, dev)
+    if dtype not in (torch.float32, torch.float64):
+        raise TypeError("edge_plane writes float32 or float64")
+    out = torch.empty((n, h, w), dtype=dtype, device=dev) if want_plane else None
+    rawmax = torch.empty(n, dtype=torch.float64, device=dev)
+    lo = torch.empty(n, dtype=torch.float64, device=dev)
+    hi = torch.empty(n, dtype=torch.float64, device=dev)
+    if spans is not None:
+        spans = spans.to(torch.int32).contiguous()
+        if tuple(spans.shape) != (h, 2):
+            raise ValueError("spans must be [H, 2]")
+    check(_lib.load().pl_edge_plane(x.data_ptr(), _dt(x), n, h, w, wts.data_ptr(), lw,
+                                    0 if spans is None else spans.data_ptr(), 0 if mask is None else mask.contiguous().data_ptr(),
+                                    0 if out is None else out.data_ptr(), _lib.PL_F32 if dtype == torch.float32 else _lib.PL_F64,
+                                    rawmax.data_ptr(), lo.data_ptr(), hi.data_ptr(), _stream()), "pl_edge_plane")
+    return out, rawmax, lo, hi
+
+
 def otsu_float_masked(frames: torch.Tensor, mask: torch.Tensor | None, scale: float = 1.0, lohi=None):
     """``skimage.filters.threshold_otsu(frame[mask])`` for float64 frames (256 bins over the min .. max of the selected
     pixels; pylinac/ct.py:3323, 3338-3340) entirely on the device -> (threshold * scale, threshold) float64 [N].

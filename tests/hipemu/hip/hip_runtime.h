@@ -120,6 +120,7 @@ inline int __syncthreads_or(int p) { return hipemu::block_barrier_or(p); }
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_fract(x) ((x) - floor(x))
+#define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))   /* v_rsq_f64: a seed; the kernels refine it */
 #define __builtin_amdgcn_fractf(x) ((x) - floorf(x))
 // v_mfma_i32_16x16x64_i8: byte s of lane (m, g) of A meets byte s of lane (n, g) of B (m, n = lane & 15, g = lane >> 4);
 // D[m = 4 * (lane >> 4) + reg][n = lane & 15] (the layout scripts/ubench/mfma_i8.hip checks on the device).  All 64 lanes

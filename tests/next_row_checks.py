@@ -1061,6 +1061,20 @@ def check_scharr_gaussian(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.ui
             _, _, lo, hi = ops.scharr_gaussian(x, sigma, None)
             lo2, hi2 = ops.minmax(e2)
             assert torch.equal(lo, lo2) and torch.equal(hi, hi2)
+            # the streaming entry point itself: float32 plane = RN of the float64 one, row spans = the same selection as a
+            # byte mask whose rows are single runs, extrema-only call
+            c0 = rng.integers(0, w, h)
+            c1 = np.minimum(c0 + rng.integers(0, w, h), w)
+            ms = np.zeros((h, w), np.uint8)
+            for r in range(h):
+                ms[r, c0[r]:c1[r]] = 1
+            spans = torch.from_numpy(np.stack([c0, c1], 1).astype(np.int32)).to(dev)
+            p32, rm3, lo3, hi3 = ops.edge_plane(x, sigma, spans=spans)
+            assert p32.dtype == torch.float32 and torch.equal(p32, e2.to(torch.float32)) and torch.equal(rm3, rm)
+            _, _, lo4, hi4 = ops.scharr_gaussian(x, sigma, torch.from_numpy(ms).to(dev))
+            assert torch.equal(lo3, lo4) and torch.equal(hi3, hi4)
+            none, rm5, lo5, hi5 = ops.edge_plane(x, sigma, spans=spans, want_plane=False)
+            assert none is None and torch.equal(rm5, rm) and torch.equal(lo5, lo4) and torch.equal(hi5, hi4)
 
 
 def check_circle_profile_combined(dev, n_volumes=2, spv=9, h=96, w=112):
