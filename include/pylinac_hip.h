@@ -293,6 +293,16 @@ int pl_otsu_from_counts(const uint32_t* d_counts, const double* d_edges, int nbi
 int pl_edge_plane(const void* in, int dtype, int64_t n, int h, int w, const double* d_weights, int radius,
                   const int32_t* d_row_spans, const uint8_t* d_mask, void* d_out, int out_dtype, double* d_rawmax,
                   double* d_min, double* d_max, void* stream);
+/* skimage.filters.threshold_otsu(edges[selection]) for the plane pl_edge_plane wrote (pylinac/ct.py:3334-3340), one launch:
+ * np.histogram's 256 bins over [d_min[i], d_max[i]] (np.linspace edges, numpy's edge-corrected binning) and skimage 0.18.3's
+ * class statistics -> d_thr[i] = otsu_i * scale (0.8 in the reference), d_raw_otsu[i] = otsu_i (optional).  d_min / d_max
+ * must be the EXACT extrema of the selection (pl_edge_plane's).  On a PL_F32 plane a pixel whose float32 neighbours fall into
+ * different bins is recomputed exactly from the slices in_raw (dtype PL_I16 / PL_U16) with the taps d_weights; a PL_F64
+ * plane needs neither (in_raw may be NULL).  d_work: uint32 [n][258] scratch (zeroed here; afterwards [i][0..255] = the
+ * histogram, [i][257] = how many pixels were recomputed exactly).  Empty selection -> NaN, constant selection -> that value. */
+int pl_edge_otsu(const void* d_plane, int plane_dtype, const void* in_raw, int dtype, int64_t n, int h, int w,
+                 const double* d_weights, int radius, const int32_t* d_row_spans, const uint8_t* d_mask, const double* d_min,
+                 const double* d_max, double scale, uint32_t* d_work, double* d_thr, double* d_raw_otsu, void* stream);
 /* round 3's form of the same pass: float64 plane, byte mask (= pl_edge_plane(..., NULL, d_mask, d_out, PL_F64, ...)) */
 int pl_scharr_gaussian(const void* in, int dtype, int64_t n, int h, int w, const double* d_weights, int radius,
                        const uint8_t* d_mask, double* d_out, double* d_rawmax, double* d_min, double* d_max, void* stream);
@@ -311,6 +321,17 @@ int pl_mask_regions_fits(int h, int w, int max_labels);
 int pl_mask_regions(const void* in, int dtype, const double* d_thr, int64_t n, int h, int w, int clear_border_ext,
                     int fill_holes, int max_labels, double* d_table, int32_t* d_count, int32_t* d_status,
                     uint8_t* d_out_mask, void* stream);
+/* pl_mask_regions on the float32 plane of pl_edge_plane (bw = plane > d_thr[i], decided on the float32 value where its two
+ * float32 neighbours agree and recomputed exactly from the slices in_raw / taps d_weights otherwise), and -- when d_roi is
+ * given -- Slice.phantom_roi's choice (pylinac/ct.py:381-425) in the same launch: d_roi float64 [n][8] = status, label,
+ * filled_area, centroid row, centroid col, bbox r0, c0, r1 of the region whose area is closest to catphan_size (first on
+ * ties) -- status 0 ok, 1 no edges (d_rawmax[i] < 0.1), 2 no region, 3 not within a factor 1.3 of catphan_size, 4 more than
+ * max_labels regions, 5 run list overflow (d_status[i] = 1: repeat the slice on the general path); columns 1-7 are NaN unless
+ * status is 0.  d_table may be NULL. */
+int pl_edge_regions(const float* d_plane, const void* in_raw, int dtype, const double* d_weights, int radius,
+                    const double* d_thr, int64_t n, int h, int w, int clear_border_ext, int fill_holes, int max_labels,
+                    double* d_table, int32_t* d_count, int32_t* d_status, uint8_t* d_out_mask, double catphan_size,
+                    const double* d_rawmax, double* d_roi, void* stream);
 /* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count] made of whole volumes of
  * slices_per_volume slices: mode 0 = np.max (d_out has the input dtype), mode 1 = np.mean (d_out float64).  The window
  * z-k .. z+k indexes the slice's own volume the way the reference indexes its Python list: a negative index wraps around
@@ -553,6 +574,17 @@ int pl_find_peaks_regions(const double* d_x, int64_t n, int len, const int32_t* 
                           const pl_peak_params* params, const int32_t* d_regions, int cap, int32_t* d_count,
                           int32_t* d_idx, int32_t* d_left_base, int32_t* d_right_base, double* d_props,
                           int32_t* d_status, void* stream);
+
+/* CTP528CP504.mtf's searches (pylinac/ct.py:1511-1544) for every (profile, line-pair region) pair in one launch: per region
+ * k < nregions (<= 16) find_peaks with peak_params[k] (host array; its search region and max_number = the expected number
+ * of peaks, 1..cap_p) and, when exactly max_number peaks were found, find_valleys = find_peaks of the negated profile with
+ * valley_params[k] inside [first peak index, last peak index) (valley_params' own region is ignored).
+ *   d_pk_count int32 [n][nregions], d_pk_height float64 [n][nregions][cap_p] (peak_heights in index order, NaN beyond count),
+ *   d_vl_count int32 [n][nregions] (0 when the peak count was wrong), d_vl_value float64 [n][nregions][cap_v] (the profile's
+ *   values at the valley indices, NaN beyond count).  Capacities 1..8, regions of at most 1024 samples. */
+int pl_peak_valley_regions(const double* d_x, int64_t n, int len, int64_t stride, const pl_peak_params* peak_params,
+                           const pl_peak_params* valley_params, int nregions, int cap_p, int cap_v, int32_t* d_pk_count,
+                           double* d_pk_height, int32_t* d_vl_count, double* d_vl_value, void* stream);
 
 /* ---- BASELINE config #3: PicketFence.analyze per-image measurement, UP_DOWN pickets ------------
  * (pylinac/picketfence.py:745-803, 847-912, 1605-1628) on uint16 frames whose float64 image would be

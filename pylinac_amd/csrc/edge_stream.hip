@@ -28,51 +28,17 @@
 // whole wave evaluates the (2 radius + 1)^2 Scharr values, the operation order of the streaming kernel).  The workgroup that
 // finishes a slice last runs the class statistics (otsu_counts_kernel's order of operations).
 #include "pl_common.h"
+#include "edge_exact.h"
 
 namespace {
 
 constexpr int kEsThreads = 256;
 constexpr int kEsWaves = kEsThreads / PL_WAVE;
 
-// skimage's Scharr magnitude sqrt(s0^2 + s1^2) / sqrt(2) from the integer responses S0 = 16 s0, S1 = 16 s1 (|S| <= 16 * 65535):
-// o = (S0^2 + S1^2) / 256 is exact, so RN(sqrt(o)) = RN(sqrt(K)) / 16 with the integer K = S0^2 + S1^2 < 2^43, and the
-// quotient by RN(sqrt(2)) becomes a quotient by 16 RN(sqrt(2)) (both scalings are powers of two).
-//   * the square root is the compiler's own float64 expansion (v_rsq_f64 seed, Goldschmidt step, two fused residual
-//     corrections: AMDGPULegalizerInfo::legalizeFSQRTF64) WITHOUT its range scaling (K is an integer: never below 2^-767)
-//     and with the seed taken from max(K, 1), which runs K = 0 through the same chain to exactly 0 instead of a special case;
-//   * the division by the constant is Markstein's three operations q0 = g r, rem = fma(-q0, c, g), q = fma(rem, r, q0) with
-//     r = RN(1 / c).  Correct rounding for EVERY float64 g is proven by enumeration (tests/test_exact_sequences.py): the exact
-//     value the last operation rounds lies within g / c * 4.001 * 2^-106 of g / c, only six mantissas g put g / c that close
-//     to a rounding boundary, and all six round correctly.
-__device__ __forceinline__ double es_edge(int S0, int S1) {
-  const double a = (double)S0, b = (double)S1;
-  const double x = fma(a, a, b * b);                    // K, exact
-  const long long xb = __double_as_longlong(x);
-  const unsigned hi = max((unsigned)(xb >> 32), 0x3ff00000u);
-  const double xs = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)(xb & 0xffffffffLL)));
-  const double y = __builtin_amdgcn_rsq(xs);
-  double g = x * y;
-  double hh = y * 0.5;
-  const double r0 = fma(-hh, g, 0.5);
-  g = fma(g, r0, g);
-  hh = fma(hh, r0, hh);
-  const double d0 = fma(-g, g, x);
-  g = fma(d0, hh, g);
-  const double d1 = fma(-g, g, x);
-  g = fma(d1, hh, g);                                    // RN(sqrt(K))
-  constexpr double c16 = 0x1.6a09e667f3bcdp+4;           // 16 * 1.4142135623730951
-  constexpr double r16 = 0x1.6a09e667f3bccp-5;           // RN(1 / 1.4142135623730951) / 16
-  const double q0 = g * r16;
-  const double rem = fma(-q0, c16, g);
-  return fma(rem, r16, q0);                              // RN(RN(sqrt(K)) / 16 / RN(sqrt(2))) = np.sqrt(output) / np.sqrt(ndim)
-}
-
 // DPP wave shifts whose first / last lane receives 0 (bound_ctrl): no copy of the source into the destination first, as the
 // "keeps its own value" form of pl_common.h needs; the two outermost lanes of a strip are halo that nothing reads
 __device__ __forceinline__ int es_from_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
 __device__ __forceinline__ int es_from_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
-
-__device__ __forceinline__ int es_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // non-negative float64 values (and -inf / +inf as "empty") order like their bit patterns read as SIGNED 64-bit integers
 __device__ __forceinline__ void es_atomic_max(double* addr, double v) {
@@ -237,6 +203,148 @@ int es_launch(const T* in, int64_t n, int h, int w, const double* wts, int radiu
   return pl_check_launch("pl_edge_plane");
 }
 
+// np.histogram(values, 256) + skimage.filters.threshold_otsu's class statistics (pylinac/ct.py:3334-3340), one launch:
+// grid (parts, n); each workgroup bins a band of rows of its slice into an LDS histogram, adds it to the slice's counts in
+// global memory, and the workgroup that arrives last runs the threshold (otsu_counts_kernel's operations).
+template <typename PlaneT, typename T>
+__global__ void __launch_bounds__(kEsThreads)
+edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, int h, int w, const double* __restrict__ wts, int rad,
+                 const int* __restrict__ spans, const uint8_t* __restrict__ mask, const double* __restrict__ lo_all,
+                 const double* __restrict__ hi_all, double scale, uint32_t* __restrict__ work /* [n][258], zeroed */,
+                 double* __restrict__ thr, double* __restrict__ otsu_raw) {
+  constexpr int NB = 256;
+  __shared__ double s_edge[NB + 1];
+  __shared__ unsigned s_hist[kEsWaves][NB];
+  __shared__ double s_scratch[kEsWaves][kEsScratch];
+  __shared__ double s_c[NB], s_p[NB], s_w1[NB], s_s1[NB], s_w2[NB], s_m2[NB], s_var[NB];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t f = blockIdx.y;
+  const int parts = gridDim.x, part = blockIdx.x;
+  const double first = lo_all[f], last = hi_all[f];
+  uint32_t* counts = work + f * (NB + 2);     // 256 bins, the arrival ticket, the number of exact evaluations
+  // np.linspace(first, last, 257) (linspace_edges_kernel)
+  {
+    const double delta = last - first;
+    const double step = delta / (double)NB;
+    s_edge[tid] = step == 0.0 ? ((double)tid / (double)NB) * delta + first : (double)tid * step + first;
+    if (tid == 0) s_edge[NB] = last;
+    for (int k = 0; k < kEsWaves; ++k) s_hist[k][tid] = 0;
+  }
+  __syncthreads();
+  const bool usable = first < last;                       // an empty or constant selection has no histogram to take
+  if (usable) {
+    const double inv = (double)NB / (last - first);
+    unsigned* hist = s_hist[wv];
+    const int rows_per = (h + parts - 1) / parts;
+    const int rb = part * rows_per, re = min(h, rb + rows_per);
+    const PlaneT* pl = plane + f * (int64_t)h * w;
+    const T* src = raw ? raw + f * (int64_t)h * w : nullptr;
+    for (int r = rb + wv; r < re; r += kEsWaves) {
+      int c0 = 0, c1 = w;
+      if (spans) { c0 = spans[2 * r]; c1 = spans[2 * r + 1]; }
+      for (int cb = c0; cb < c1; cb += PL_WAVE) {
+        const int c = cb + lane;
+        bool valid = c < c1;
+        if (valid && mask) valid = mask[(int64_t)r * w + c] != 0;
+        int bin = -1;
+        bool exact_needed = false;
+        if (valid) {
+          const PlaneT pv = pl[(int64_t)r * w + c];
+          double vlo, vhi;
+          if constexpr (sizeof(PlaneT) == 4) es_f32_bracket(pv, vlo, vhi);
+          else { vlo = (double)pv; vhi = vlo; }
+          if (vlo >= first && vhi <= last) {
+            int idx = (int)((vlo - first) * inv);
+            idx = idx < 0 ? 0 : (idx > NB - 1 ? NB - 1 : idx);
+            while (idx > 0 && vlo < s_edge[idx]) --idx;
+            while (idx < NB - 1 && vlo >= s_edge[idx + 1]) ++idx;
+            if (idx == NB - 1 || vhi < s_edge[idx + 1]) bin = idx;      // the whole bracket lies in one bin
+            else exact_needed = true;
+          } else if constexpr (sizeof(PlaneT) == 4) {
+            exact_needed = vhi >= first && vlo <= last;    // the bracket straddles an end of the range
+          }
+        }
+        if constexpr (sizeof(PlaneT) == 4) {
+          unsigned long long todo = __ballot(exact_needed);
+          while (todo) {                                   // wave-uniform
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const double v = es_exact_wave(src, h, w, r, cb + l, wts, rad, s_scratch[wv]);
+            if (lane == l) atomicAdd(&counts[NB + 1], 1u);
+            if (lane == l && v >= first && v <= last) {    // np.histogram drops values outside the range
+              int idx = (int)((v - first) * inv);
+              idx = idx < 0 ? 0 : (idx > NB - 1 ? NB - 1 : idx);
+              while (idx > 0 && v < s_edge[idx]) --idx;
+              while (idx < NB - 1 && v >= s_edge[idx + 1]) ++idx;
+              bin = idx;
+            }
+          }
+        }
+        // lanes that share the first lane's bin are counted by one atomic (smooth planes: most of a wave)
+        const unsigned long long have = __ballot(bin >= 0);
+        if (have) {
+          const int b0 = __shfl(bin, __builtin_ctzll(have), PL_WAVE);
+          const unsigned long long same = __ballot(bin == b0);
+          if (lane == __builtin_ctzll(have)) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+          else if (bin >= 0 && bin != b0) atomicAdd(&hist[bin], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (usable) {
+    unsigned v = 0;
+    for (int k = 0; k < kEsWaves; ++k) v += s_hist[k][tid];
+    if (v) atomicAdd(&counts[tid], v);
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&counts[NB], 1u) == (unsigned)(parts - 1);
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // ---- skimage 0.18.3 threshold_otsu on the finished counts (see otsu_counts_kernel in ct.hip for the order of operations)
+  const int i = tid;
+  const double ci = (double)atomicAdd(&counts[i], 0u);   // read at the device's coherence point
+  const double centre = (s_edge[i] + s_edge[i + 1]) / 2.0;
+  s_c[i] = ci;
+  s_p[i] = ci * centre;
+  __syncthreads();
+  if (i == 0) {
+    double w1 = 0.0, s1 = 0.0;
+    for (int k = 0; k < NB; ++k) { w1 = w1 + s_c[k]; s1 = s1 + s_p[k]; s_w1[k] = w1; s_s1[k] = s1; }
+  } else if (i == PL_WAVE) {
+    double aw = 0.0, am = 0.0;
+    for (int k = NB - 1; k >= 0; --k) { aw = aw + s_c[k]; am = am + s_p[k]; s_w2[k] = aw; s_m2[k] = am; }
+  }
+  __syncthreads();
+  if (i < NB - 1) {
+    const double mean1 = s_s1[i] / s_w1[i];
+    const double mean2 = s_m2[i + 1] / s_w2[i + 1];
+    const double d = mean1 - mean2;
+    s_var[i] = (s_w1[i] * s_w2[i + 1]) * (d * d);
+  }
+  __syncthreads();
+  if (i == 0) {
+    double otsu;
+    if (!(first < last)) {
+      otsu = first == last ? first : __longlong_as_double(0x7ff8000000000000LL);
+    } else {
+      double best = s_var[0];
+      int best_i = 0;
+      for (int k = 1; k < NB - 1; ++k) {
+        const double var = s_var[k];
+        if (var > best || (var != var && best == best)) { best = var; best_i = k; }
+      }
+      otsu = (s_edge[best_i] + s_edge[best_i + 1]) / 2.0;
+    }
+    if (otsu_raw) otsu_raw[f] = otsu;
+    thr[f] = otsu * scale;
+  }
+}
+
 }  // namespace
 
 extern "C" int pl_edge_plane(const void* in, int dtype, int64_t n, int h, int w, const double* d_weights, int radius,
@@ -266,4 +374,38 @@ extern "C" int pl_scharr_gaussian(const void* in, int dtype, int64_t n, int h, i
                                   void* stream) {
   PL_REQUIRE(d_out, "null pointer");
   return pl_edge_plane(in, dtype, n, h, w, d_weights, radius, nullptr, d_mask, d_out, PL_F64, d_rawmax, d_min, d_max, stream);
+}
+
+/* np.histogram(plane[selection], 256) over [d_min, d_max] + skimage's threshold_otsu on it, per frame, one launch */
+extern "C" int pl_edge_otsu(const void* d_plane, int plane_dtype, const void* in_raw, int dtype, int64_t n, int h, int w,
+                            const double* d_weights, int radius, const int32_t* d_row_spans, const uint8_t* d_mask,
+                            const double* d_min, const double* d_max, double scale, uint32_t* d_work, double* d_thr,
+                            double* d_raw_otsu, void* stream) {
+  PL_REQUIRE(d_plane && d_min && d_max && d_work && d_thr, "null pointer");
+  PL_REQUIRE(n >= 0 && n <= 65535 && h > 0 && w > 0, "bad shape");
+  PL_REQUIRE(plane_dtype == PL_F32 || plane_dtype == PL_F64, "float32 or float64 plane");
+  PL_REQUIRE(plane_dtype == PL_F64 || (in_raw && d_weights && radius >= 1 && radius <= 8 && (dtype == PL_I16 || dtype == PL_U16)),
+             "a float32 plane needs the int16 / uint16 slices and the taps it was made from");
+  PL_REQUIRE(!(d_row_spans && d_mask), "row spans or a byte mask, not both");
+  if (n == 0) return PL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_work, 0, (size_t)n * 258 * sizeof(uint32_t), st);
+  if (e != hipSuccess) { pl_set_error("pl_edge_otsu: memset: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+  // bands: enough workgroups to fill the chip at small batches, at least 32 rows each
+  int parts = (int)pl_cdiv(2LL * pl_cu_count(), n);
+  const int max_parts = (int)pl_cdiv(h, 32);
+  if (parts > max_parts) parts = max_parts;
+  if (parts < 1) parts = 1;
+  const dim3 grid((unsigned)parts, (unsigned)n);
+#define EO_LAUNCH(P, T)                                                                                                     \
+  hipLaunchKernelGGL((edge_otsu_kernel<P, T>), grid, dim3(kEsThreads), 0, st, (const P*)d_plane, (const T*)in_raw, h, w,    \
+                     d_weights, radius, d_row_spans, d_mask, d_min, d_max, scale, d_work, d_thr, d_raw_otsu)
+  if (plane_dtype == PL_F32) {
+    if (dtype == PL_I16) EO_LAUNCH(float, short);
+    else EO_LAUNCH(float, unsigned short);
+  } else {
+    EO_LAUNCH(double, short);
+  }
+#undef EO_LAUNCH
+  return pl_check_launch("pl_edge_otsu");
 }

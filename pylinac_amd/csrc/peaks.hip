@@ -161,7 +161,9 @@ template <bool STAGE, int NT>
 __device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xfull, int len, int rlo, int rhi, const pl_peak_params prm,
                                                    int cap, int maxc, const PeakLds L, int tid, int32_t* __restrict__ o_count,
                                                    int32_t* __restrict__ o_idx, int32_t* __restrict__ o_lb, int32_t* __restrict__ o_rb,
-                                                   double* __restrict__ o_p, int32_t* __restrict__ o_status) {
+                                                   double* __restrict__ o_p, int32_t* __restrict__ o_status, const double sign = 1.0) {
+  // `sign` = -1: the search runs on the NEGATED profile (find_valleys, pylinac/core/profile.py: peaks of -values); staged
+  // profiles only (the negation happens while the region is copied to LDS; x * 1.0 and x * -1.0 are exact)
   unsigned char* smem = L.smem;
   Scan& scan = *L.scan;
   double* s_red = L.s_red;
@@ -187,9 +189,9 @@ __device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xf
   // ---- A: height threshold -------------------------------------------------------------------
   double height = prm.threshold;
   if (prm.threshold_is_ratio) {
-    double mn = xfull[0], mx = xfull[0];
+    double mn = sign * xfull[0], mx = mn;
     for (int i = tid; i < len; i += NT) {
-      double v = xfull[i];
+      double v = sign * xfull[i];
       mn = v < mn ? v : mn;
       mx = v > mx ? v : mx;
     }
@@ -206,7 +208,7 @@ __device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xf
 
   const double* xs;
   if constexpr (STAGE) {
-    for (int i = tid; i < m; i += NT) s_x[i] = xfull[lo + i];
+    for (int i = tid; i < m; i += NT) s_x[i] = sign * xfull[lo + i];
     xs = s_x;
   } else {
     xs = xfull + lo;
@@ -455,6 +457,56 @@ colparts_profile_fwxm_kernel(const uint32_t* __restrict__ parts, int bands, int 
   if (tid == 0) fwxm_record_one(d_count[frame], d_idx + frame * cap, d_props + frame * 6 * (int64_t)cap, cap, fwxm + frame * 8);
 }
 
+// CTP528CP504.mtf's searches (pylinac/ct.py:1511-1544) for every (profile, line-pair region) pair in ONE launch, a wave per
+// pair: the `max_number` most prominent peaks inside the region, and -- when exactly that many were found -- the valleys
+// (peaks of the negated profile) between the outermost two of them.  Rounds 1-3 issued sixteen pl_find_peaks_regions
+// launches plus the torch glue between them per batch.
+constexpr int kPvMaxRegions = 16, kPvCap = 8;
+struct PvRegions {
+  pl_peak_params pk[kPvMaxRegions], vl[kPvMaxRegions];
+  int n;
+};
+
+__global__ void __launch_bounds__(kThreads)
+peak_valley_kernel(const double* __restrict__ x, int64_t nprof, int64_t stride, int len, PvRegions R, int slot_bytes, int maxc,
+                   int cap_p, int cap_v, int32_t* __restrict__ d_pk_count, double* __restrict__ d_pk_height,
+                   int32_t* __restrict__ d_vl_count, double* __restrict__ d_vl_value) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  constexpr int NW = kThreads / PL_WAVE;
+  __shared__ Scan scan_a[NW];
+  __shared__ double s_red_a[NW][2 * NW];
+  __shared__ int s_cnt_a[NW];
+  __shared__ int32_t o_cnt[NW], o_st[NW], o_idx[NW][kPvCap], o_lb[NW][kPvCap], o_rb[NW][kPvCap];
+  __shared__ double o_p[NW][6 * kPvCap];
+  const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / PL_WAVE)), tid = threadIdx.x % PL_WAVE;
+  const int64_t unit = (int64_t)blockIdx.x * NW + slot;
+  if (unit >= nprof * R.n) return;                     // a whole wave leaves
+  const int64_t prof = unit / R.n;
+  const int k = (int)(unit - prof * R.n);
+  const PeakLds L{smem_all + (size_t)slot * slot_bytes, &scan_a[slot], s_red_a[slot], &s_cnt_a[slot]};
+  const double* xp = x + prof * stride;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  const pl_peak_params pk = R.pk[k];
+  find_peaks_profile<true, PL_WAVE>(xp, len, pk.region_lo, pk.region_hi, pk, cap_p, maxc, L, tid, &o_cnt[slot], o_idx[slot],
+                                    o_lb[slot], o_rb[slot], o_p[slot], &o_st[slot]);
+  group_sync<PL_WAVE>();
+  const int cnt = o_cnt[slot];
+  const int lo = cnt > 0 ? o_idx[slot][0] : 0, hi = cnt > 0 ? o_idx[slot][cnt - 1] : 0;   // peaks leave in index order
+  if (tid == 0) d_pk_count[unit] = cnt;
+  if (tid < cap_p) d_pk_height[unit * cap_p + tid] = tid < cnt ? o_p[slot][tid] : nan;
+  group_sync<PL_WAVE>();
+  int vcnt = 0;
+  if (cnt == pk.max_number && cnt > 0) {               // wave-uniform
+    const pl_peak_params vl = R.vl[k];
+    find_peaks_profile<true, PL_WAVE>(xp, len, lo, hi, vl, cap_v, maxc, L, tid, &o_cnt[slot], o_idx[slot], o_lb[slot], o_rb[slot],
+                                      o_p[slot], &o_st[slot], -1.0);
+    group_sync<PL_WAVE>();
+    vcnt = o_cnt[slot];
+  }
+  if (tid == 0) d_vl_count[unit] = vcnt;
+  if (tid < cap_v) d_vl_value[unit * cap_v + tid] = tid < vcnt ? xp[o_idx[slot][tid]] : nan;   // values[valley_idxs]
+}
+
 }  // namespace
 
 extern "C" int pl_fwxm_record(const int32_t* d_count, const int32_t* d_idx, const double* d_props,
@@ -575,4 +627,43 @@ extern "C" int pl_colparts_profile_fwxm(const uint32_t* d_parts, int64_t n, int 
     hipLaunchKernelGGL(colparts_profile_fwxm_kernel<false>, dim3((unsigned)n), dim3(kThreads), lds, (hipStream_t)stream, d_parts, bands,
                        w, h, *params, cap, maxc, d_profile, d_count, d_idx, d_left_base, d_right_base, d_props, d_status, d_fwxm);
   return pl_check_launch("pl_colparts_profile_fwxm");
+}
+
+/* CTP528CP504.mtf's peak and valley searches for every (profile, region) pair in one launch: see peak_valley_kernel */
+extern "C" int pl_peak_valley_regions(const double* d_x, int64_t n, int len, int64_t stride, const pl_peak_params* peak_params,
+                                      const pl_peak_params* valley_params, int nregions, int cap_p, int cap_v,
+                                      int32_t* d_pk_count, double* d_pk_height, int32_t* d_vl_count, double* d_vl_value,
+                                      void* stream) {
+  PL_REQUIRE(d_x && peak_params && valley_params && d_pk_count && d_pk_height && d_vl_count && d_vl_value, "null pointer");
+  PL_REQUIRE(n >= 0 && len > 0 && stride >= len, "bad shape");
+  PL_REQUIRE(nregions >= 1 && nregions <= kPvMaxRegions && cap_p >= 1 && cap_p <= kPvCap && cap_v >= 1 && cap_v <= kPvCap,
+             "1..16 regions, capacities 1..8");
+  PL_REQUIRE(n * nregions <= 0x7fffffffLL, "batch too large");
+  if (n == 0) return PL_OK;
+  PvRegions R;
+  R.n = nregions;
+  int m = 0;
+  for (int k = 0; k < nregions; ++k) {
+    R.pk[k] = peak_params[k];
+    R.vl[k] = valley_params[k];
+    PL_REQUIRE(R.pk[k].distance >= 1 && R.vl[k].distance >= 1, "distance must be >= 1");
+    PL_REQUIRE(R.pk[k].max_number >= 1 && R.pk[k].max_number <= cap_p, "a peak count of 1..cap_p per region");
+    const int lo = R.pk[k].region_lo < 0 ? 0 : R.pk[k].region_lo, hi = R.pk[k].region_hi > len ? len : R.pk[k].region_hi;
+    if (hi - lo > m) m = hi - lo;
+  }
+  PL_REQUIRE(m <= 1024, "search regions of at most 1024 samples (a wave per region)");
+  const int maxc = m / 2 + 1;
+  size_t lds = (size_t)maxc * (8 + 8 + 4 * 4) + 8 + (size_t)m * 8;
+  lds = (lds + 15) & ~(size_t)15;
+  const int64_t units = n * nregions;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)peak_valley_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) { pl_set_error("pl_peak_valley_regions: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(peak_valley_kernel, dim3((unsigned)pl_cdiv(units, kThreads / PL_WAVE)), dim3(kThreads),
+                     lds * (kThreads / PL_WAVE), (hipStream_t)stream, d_x, n, stride, len, R, (int)lds, maxc, cap_p, cap_v,
+                     d_pk_count, d_pk_height, d_vl_count, d_vl_value);
+  return pl_check_launch("pl_peak_valley_regions");
 }

@@ -19,6 +19,7 @@
 //     scikit-image's label) and adds each run's length, row and column sums and extent to its label's row of the table.
 // A slice with more runs than the LDS list holds reports status 1 and the host layer repeats it on the general path.
 #include "pl_common.h"
+#include "edge_exact.h"
 
 namespace {
 
@@ -161,6 +162,12 @@ __device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, 
   return nruns;
 }
 
+__host__ __device__ inline size_t sr_lds_bytes(int h, int w) {
+  const int ww = (w + 63) >> 6;
+  return (size_t)h * ww * 8 + (size_t)kSrMaxRuns * 4 + (size_t)(h + 1 + ((h + 1) & 1)) * 4 + (size_t)kSrMaxRuns * 2 * 4;
+}
+__host__ __device__ inline size_t es_scratch_doubles(int rad) { return (size_t)(2 * rad + 1) * (2 * rad + 1) + (2 * rad + 1); }
+
 // set (value = true) or clear the bits of run `id` in the plane
 __device__ __forceinline__ void sr_paint(const SrLds& L, int ww, int id, bool value) {
   const int r = L.run_r[id], s = L.run_s[id], e = L.run_e[id];
@@ -171,11 +178,23 @@ __device__ __forceinline__ void sr_paint(const SrLds& L, int ww, int id, bool va
   }
 }
 
+// what the float32 form needs beside the plane: the slices and taps the plane was made from (pixels whose float32 neighbours
+// lie on both sides of the threshold are recomputed exactly), and the phantom-ROI selection of Slice.phantom_roi
+struct SrEdgeArgs {
+  const void* raw;            // int16 / uint16 slices [n][h][w]
+  int raw_is_signed;
+  const double* wts;          // device float64 [2 rad + 1]
+  int rad;
+  double catphan_size;        // > 0 with roi
+  const double* rawmax;       // [n] max of the raw Scharr magnitude (the "no edges" test)
+  double* roi;                // [n][8] or NULL
+};
+
 template <typename T>
 __global__ void __launch_bounds__(kSrThreads)
 mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, int h, int w, int clear_ext, int fill,
-                    int max_labels, double* __restrict__ table /* [n][max_labels][7] */, int32_t* __restrict__ count,
-                    int32_t* __restrict__ status, uint8_t* __restrict__ out_mask /* optional [n][h][w] */) {
+                    int max_labels, double* __restrict__ table /* [n][max_labels][7] or NULL */, int32_t* __restrict__ count,
+                    int32_t* __restrict__ status, uint8_t* __restrict__ out_mask /* optional [n][h][w] */, SrEdgeArgs ea) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ww = (w + 63) >> 6;
   SrLds L;
@@ -192,7 +211,8 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
   __shared__ u64 t_sr[kSrMaxLabels], t_sc[kSrMaxLabels];
 
   const int64_t f = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T* src = in + f * (int64_t)h * w;
   const double t = thr ? thr[f] : 0.0;
   // ---- the bit plane: a wave turns 64 consecutive pixels of a row into one word
@@ -201,9 +221,33 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
     const int r = q / ww, j = q - r * ww;
     const int c = j * 64 + lane;
     bool fg = false;
-    if (c < w) {
-      const T v = src[(int64_t)r * w + c];
-      fg = thr ? ((double)v > t) : (v != (T)0);
+    if constexpr (sizeof(T) == 4) {
+      // float32 plane: the float64 value it was rounded from lies between the value's two float32 neighbours
+      bool undecided = false;
+      if (c < w) {
+        double vlo, vhi;
+        es_f32_bracket(src[(int64_t)r * w + c], vlo, vhi);
+        fg = vlo > t;
+        undecided = !fg && vhi > t;
+      }
+      unsigned long long todo = __ballot(undecided);
+      if (todo) {                                          // a handful of pixels per thousand slices
+        double* scratch = reinterpret_cast<double*>(smem + sr_lds_bytes(h, w)) + (size_t)wv * es_scratch_doubles(ea.rad);
+        while (todo) {
+          const int l = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const int64_t off = f * (int64_t)h * w;
+          const double v = ea.raw_is_signed
+                               ? es_exact_wave(static_cast<const short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch)
+                               : es_exact_wave(static_cast<const unsigned short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch);
+          if (lane == l) fg = v > t;
+        }
+      }
+    } else {
+      if (c < w) {
+        const T v = src[(int64_t)r * w + c];
+        fg = thr ? ((double)v > t) : (v != (T)0);
+      }
     }
     const u64 m = __ballot(fg);
     if (lane == 0) L.plane[q] = m;
@@ -281,20 +325,53 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
     }
   }
   // ---- results
-  double* tab = table + f * (int64_t)max_labels * 7;
-  for (int k = tid; k < max_labels; k += kSrThreads) {
-    const bool have = st == 0 && k < nlab;
-    tab[k * 7 + 0] = have ? (double)t_area[k] : 0.0;
-    tab[k * 7 + 1] = have ? (double)t_r0[k] : 0.0;
-    tab[k * 7 + 2] = have ? (double)t_c0[k] : 0.0;
-    tab[k * 7 + 3] = have ? (double)(t_r1[k] + 1) : 0.0;      // half-open like regionprops' bbox
-    tab[k * 7 + 4] = have ? (double)(t_c1[k] + 1) : 0.0;
-    tab[k * 7 + 5] = have ? (double)t_sr[k] : 0.0;
-    tab[k * 7 + 6] = have ? (double)t_sc[k] : 0.0;
+  if (table) {
+    double* tab = table + f * (int64_t)max_labels * 7;
+    for (int k = tid; k < max_labels; k += kSrThreads) {
+      const bool have = st == 0 && k < nlab;
+      tab[k * 7 + 0] = have ? (double)t_area[k] : 0.0;
+      tab[k * 7 + 1] = have ? (double)t_r0[k] : 0.0;
+      tab[k * 7 + 2] = have ? (double)t_c0[k] : 0.0;
+      tab[k * 7 + 3] = have ? (double)(t_r1[k] + 1) : 0.0;      // half-open like regionprops' bbox
+      tab[k * 7 + 4] = have ? (double)(t_c1[k] + 1) : 0.0;
+      tab[k * 7 + 5] = have ? (double)t_sr[k] : 0.0;
+      tab[k * 7 + 6] = have ? (double)t_sc[k] : 0.0;
+    }
   }
   if (tid == 0) {
     count[f] = st == 0 ? nlab : 0;
     status[f] = st;
+    if (ea.roi) {
+      // Slice.phantom_roi (pylinac/ct.py:381-425): the region whose filled area (= area after binary_fill_holes) is closest
+      // to the phantom's, first one on ties (sorted() is stable), must lie within a factor 1.3 of it.  status: 0 ok,
+      // 1 no edges (np.max(edges) < 0.1), 2 no region, 3 wrong size, 4 more labels than the table holds, 5 = this kernel's
+      // run list overflowed (the caller repeats the slice on the general path)
+      double* o = ea.roi + f * 8;
+      const double nan = __longlong_as_double(0x7ff8000000000000LL);
+      const int num = nlab < max_labels ? nlab : max_labels;
+      int best = 0;
+      double best_d = __longlong_as_double(0x7ff0000000000000LL), fk = 0.0;
+      for (int k = 0; k < num; ++k) {
+        const double d = fabs((double)t_area[k] - ea.catphan_size);
+        if (d < best_d) { best_d = d; best = k; }
+      }
+      if (num > 0) fk = (double)t_area[best];
+      int code = 0;
+      if (num > 0 && (ea.catphan_size * 1.3 < fk || fk < ea.catphan_size / 1.3)) code = 3;
+      if (nlab > max_labels) code = 4;
+      if (num < 1) code = 2;
+      if (ea.rawmax[f] < 0.1) code = 1;
+      if (st != 0) code = 5;
+      o[0] = (double)code;
+      const bool ok = code == 0;
+      o[1] = ok ? (double)(best + 1) : nan;
+      o[2] = ok ? fk : nan;
+      o[3] = ok ? (double)t_sr[best] / fk : nan;
+      o[4] = ok ? (double)t_sc[best] / fk : nan;
+      o[5] = ok ? (double)t_r0[best] : nan;
+      o[6] = ok ? (double)t_c0[best] : nan;
+      o[7] = ok ? (double)(t_r1[best] + 1) : nan;
+    }
   }
   if (out_mask && st == 0) {
     uint8_t* om = out_mask + f * (int64_t)h * w;
@@ -304,11 +381,6 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
       if (c < w) om[(int64_t)r * w + c] = (uint8_t)((L.plane[q] >> lane) & 1ull);
     }
   }
-}
-
-size_t sr_lds_bytes(int h, int w) {
-  const int ww = (w + 63) >> 6;
-  return (size_t)h * ww * 8 + (size_t)kSrMaxRuns * 4 + (size_t)(h + 1 + ((h + 1) & 1)) * 4 + (size_t)kSrMaxRuns * 2 * 4;
 }
 
 }  // namespace
@@ -337,7 +409,7 @@ extern "C" int pl_mask_regions(const void* in, int dtype, const double* d_thr, i
       attr = lds;
     }
     hipLaunchKernelGGL(mask_regions_kernel<double>, dim3((unsigned)n), dim3(kSrThreads), lds, st, (const double*)in, d_thr, h, w,
-                       clear_border_ext, fill_holes, max_labels, d_table, d_count, d_status, d_out_mask);
+                       clear_border_ext, fill_holes, max_labels, d_table, d_count, d_status, d_out_mask, SrEdgeArgs{});
   } else {
     static std::atomic<size_t> attr{0};
     if (lds > attr) {
@@ -346,7 +418,33 @@ extern "C" int pl_mask_regions(const void* in, int dtype, const double* d_thr, i
       attr = lds;
     }
     hipLaunchKernelGGL(mask_regions_kernel<uint8_t>, dim3((unsigned)n), dim3(kSrThreads), lds, st, (const uint8_t*)in, nullptr, h, w,
-                       clear_border_ext, fill_holes, max_labels, d_table, d_count, d_status, d_out_mask);
+                       clear_border_ext, fill_holes, max_labels, d_table, d_count, d_status, d_out_mask, SrEdgeArgs{});
   }
   return pl_check_launch("pl_mask_regions");
+}
+
+/* pl_mask_regions on the float32 plane of pl_edge_plane, with the phantom ROI chosen in the same launch */
+extern "C" int pl_edge_regions(const float* d_plane, const void* in_raw, int dtype, const double* d_weights, int radius,
+                               const double* d_thr, int64_t n, int h, int w, int clear_border_ext, int fill_holes, int max_labels,
+                               double* d_table, int32_t* d_count, int32_t* d_status, uint8_t* d_out_mask, double catphan_size,
+                               const double* d_rawmax, double* d_roi, void* stream) {
+  PL_REQUIRE(d_plane && in_raw && d_weights && d_thr && d_count && d_status, "null pointer");
+  PL_REQUIRE(dtype == PL_I16 || dtype == PL_U16, "int16 / uint16 slices");
+  PL_REQUIRE(radius >= 1 && radius <= 8, "radius 1..8");
+  PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL && clear_border_ext >= 0, "bad arguments");
+  PL_REQUIRE(!d_roi || (d_rawmax && catphan_size > 0), "the ROI selection needs the phantom size and the raw edge maxima");
+  PL_REQUIRE(pl_mask_regions_fits(h, w, max_labels), "frame or label table too large for the LDS form (pl_mask_regions_fits)");
+  if (n == 0) return PL_OK;
+  const size_t lds = sr_lds_bytes(h, w) + (kSrThreads / PL_WAVE) * es_scratch_doubles(radius) * sizeof(double);
+  PL_REQUIRE(lds <= 160 * 1024, "frame too large for the LDS form");
+  static std::atomic<size_t> attr{0};
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)mask_regions_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { pl_set_error("pl_edge_regions: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+    attr = lds;
+  }
+  SrEdgeArgs ea{in_raw, dtype == PL_I16, d_weights, radius, catphan_size, d_rawmax, d_roi};
+  hipLaunchKernelGGL(mask_regions_kernel<float>, dim3((unsigned)n), dim3(kSrThreads), lds, (hipStream_t)stream, d_plane, d_thr, h, w,
+                     clear_border_ext, fill_holes, max_labels, d_table, d_count, d_status, d_out_mask, ea);
+  return pl_check_launch("pl_edge_regions");
 }

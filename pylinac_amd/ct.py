@@ -85,6 +85,12 @@ def STAGE_TIMERS(x: torch.Tensor, mm_per_pixel: float):
     yield "otsu_float_masked (float64 plane, round 3)", lambda: ops.otsu_float_masked(e64, disk, scale=0.8, lohi=(lo, hi))
     thr, _ = ops.otsu_float_masked(e64, disk, scale=0.8, lohi=(lo, hi))
     yield "mask_regions (float64 plane, round 3)", lambda: ops.mask_regions(e64, thr, min(int(max(h, w) / 100), 3) + 1, True, 64)
+    p32, rawmax, lo, hi = ops.edge_plane(x, 1, spans=spans)
+    yield "edge_otsu (float32 plane, one launch)", lambda: ops.edge_otsu(p32, lo, hi, frames=x, sigma=1, spans=spans, scale=0.8)
+    yield "edge_otsu (float64 plane, one launch)", lambda: ops.edge_otsu(e64, lo, hi, spans=spans, scale=0.8)
+    yield "edge_regions (float32 plane + ROI choice)", lambda: ops.edge_regions(
+        p32, x, 1, thr, min(int(max(h, w) / 100), 3) + 1, True, 64, catphan_size=np.pi * 101**2 / mm_per_pixel**2, rawmax=rawmax,
+        want_table=False)
     yield "phantom_roi_batch", lambda: phantom_roi_batch(x, mm_per_pixel)
 
 
@@ -119,44 +125,12 @@ def get_regions_batch(slices: torch.Tensor, mm_per_pixel: float, fill_holes: boo
     return dict(edges=edges, bw=bw, labels=labels, num=num, stats=stats, overflow=ovf, otsu=otsu)
 
 
-def phantom_roi_batch(slices: torch.Tensor, mm_per_pixel: float, catphan_radius_mm: float = CATPHAN_RADIUS_MM,
-                      max_labels: int = 64) -> np.ndarray:
-    """``Slice.phantom_roi`` for every slice -> float64 [N, 8]:
-    status, label, filled_area, centroid_row, centroid_col, bbox(r0, c0, r1, c1)[first 3 shown]...
-    columns: status (0 ok, 1 no edges, 2 no ROI, 3 wrong size, 4 label overflow), label,
-    filled_area, centroid_r, centroid_c, bbox_r0, bbox_c0, bbox_r1 -- the reference raises ValueError
-    for status 1-3; the batch reports per-slice codes instead."""
-    x = ops._frames(slices)
-    n, h, w = x.shape
-    catphan_size = np.pi * catphan_radius_mm**2 / mm_per_pixel**2        # ct.py:2581-2584
-    if x.dtype in (torch.int16, torch.uint16) and ops.mask_regions_fits(h, w, max_labels):
-        # three launches per batch: edge image + its extrema, the disk histogram's Otsu threshold, and the whole
-        # clear_border -> fill_holes -> label -> regionprops chain of a slice inside one workgroup
-        disk = _disk_on_device(h, w, mm_per_pixel, x.device)
-        edges, raw_max_t, lo, hi = ops.scharr_gaussian(x, 1, disk)
-        thr, _ = ops.otsu_float_masked(edges, disk, scale=0.8, lohi=(lo, hi))
-        table, count, st = ops.mask_regions(edges, thr, min(int(max(h, w) / 100), 3) + 1, True, max_labels)
-        raw_max = raw_max_t.cpu().numpy()
-        stats = table.cpu().numpy()
-        cnt = count.cpu().numpy()
-        ovf = (cnt > max_labels).astype(np.int32)
-        num = np.minimum(cnt, max_labels)
-        redo = np.flatnonzero(st.cpu().numpy() != 0)          # slices with more row runs than the LDS list holds
-        if len(redo):
-            sub = x[torch.from_numpy(redo).to(x.device)].contiguous()
-            reg = get_regions_batch(sub, mm_per_pixel, fill_holes=True, clear_borders=True, max_labels=max_labels)
-            stats[redo] = reg["stats"].cpu().numpy()[:, :, :7]
-            num[redo] = np.minimum(reg["num"].cpu().numpy(), max_labels)
-            ovf[redo] = reg["overflow"].cpu().numpy()
-    else:
-        raw = ops.scharr(x)                                              # computed once: the edge test and get_regions
-        raw_max_t = ops.minmax(raw)[1]                                   # ct.py:392: np.max(edges) < 0.1
-        reg = get_regions_batch(x, mm_per_pixel, fill_holes=True, clear_borders=True, max_labels=max_labels, raw_edges=raw)
-        raw_max = raw_max_t.cpu().numpy()
-        stats = reg["stats"].cpu().numpy()
-        num = np.minimum(reg["num"].cpu().numpy(), max_labels)
-        ovf = reg["overflow"].cpu().numpy()
-    # the selection (sorted(regionprops, key=|filled_area - catphan_size|)[0] and the size test), vectorised over slices
+def _select_phantom_roi(stats: np.ndarray, num: np.ndarray, ovf: np.ndarray, raw_max: np.ndarray, catphan_size: float,
+                        max_labels: int) -> np.ndarray:
+    """The choice of ``Slice.phantom_roi`` (``sorted(regionprops, key=|filled_area - catphan_size|)[0]`` and the size test,
+    ct.py:398-409) from region tables on the host, vectorised over slices: the general path's half of ``phantom_roi_batch``
+    (the fused path makes the same choice inside ``pl_edge_regions``)."""
+    n = stats.shape[0]
     valid = np.arange(max_labels)[None, :] < num[:, None]
     filled = stats[:, :, 0]                                 # == filled_area after binary_fill_holes
     dist = np.where(valid, np.abs(filled - catphan_size), np.inf)
@@ -175,6 +149,43 @@ def phantom_roi_batch(slices: torch.Tensor, mm_per_pixel: float, catphan_radius_
     with np.errstate(invalid="ignore", divide="ignore"):
         good = np.stack([np.zeros(n), k + 1.0, fk, t[:, 5] / t[:, 0], t[:, 6] / t[:, 0], t[:, 1], t[:, 2], t[:, 3]], axis=1)
     out[ok] = good[ok]
+    return out
+
+
+def _phantom_roi_general(x: torch.Tensor, mm_per_pixel: float, catphan_size: float, max_labels: int) -> np.ndarray:
+    raw = ops.scharr(x)                                              # computed once: the edge test and get_regions
+    raw_max_t = ops.minmax(raw)[1]                                   # ct.py:392: np.max(edges) < 0.1
+    reg = get_regions_batch(x, mm_per_pixel, fill_holes=True, clear_borders=True, max_labels=max_labels, raw_edges=raw)
+    return _select_phantom_roi(reg["stats"].cpu().numpy(), np.minimum(reg["num"].cpu().numpy(), max_labels),
+                               reg["overflow"].cpu().numpy(), raw_max_t.cpu().numpy(), catphan_size, max_labels)
+
+
+def phantom_roi_batch(slices: torch.Tensor, mm_per_pixel: float, catphan_radius_mm: float = CATPHAN_RADIUS_MM,
+                      max_labels: int = 64) -> np.ndarray:
+    """``Slice.phantom_roi`` for every slice -> float64 [N, 8]:
+    columns: status (0 ok, 1 no edges, 2 no ROI, 3 wrong size, 4 label overflow), label,
+    filled_area, centroid_r, centroid_c, bbox_r0, bbox_c0, bbox_r1 -- the reference raises ValueError
+    for status 1-3; the batch reports per-slice codes instead.
+
+    int16 / uint16 slices take THREE launches and ONE transfer of 64 bytes per slice: ``pl_edge_plane`` (smoothed Scharr
+    plane as float32 + its exact extrema on the 110 mm disk), ``pl_edge_otsu`` (the disk histogram and its Otsu threshold)
+    and ``pl_edge_regions`` (threshold, clear_border, fill_holes, label, regionprops and the choice of the phantom region,
+    one workgroup per slice)."""
+    x = ops._frames(slices)
+    n, h, w = x.shape
+    catphan_size = np.pi * catphan_radius_mm**2 / mm_per_pixel**2        # ct.py:2581-2584
+    if not (x.dtype in (torch.int16, torch.uint16) and ops.mask_regions_fits(h, w, max_labels)):
+        return _phantom_roi_general(x, mm_per_pixel, catphan_size, max_labels)
+    spans = _disk_spans_on_device(h, w, mm_per_pixel, x.device)
+    plane, raw_max, lo, hi = ops.edge_plane(x, 1, spans=spans)
+    thr, _ = ops.edge_otsu(plane, lo, hi, frames=x, sigma=1, spans=spans, scale=0.8)
+    reg = ops.edge_regions(plane, x, 1, thr, min(int(max(h, w) / 100), 3) + 1, True, max_labels, catphan_size=catphan_size,
+                           rawmax=raw_max, want_table=False)
+    out = reg["roi"].cpu().numpy()                                       # the one synchronisation of the localisation
+    redo = np.flatnonzero(out[:, 0] == 5)                                # slices with more row runs than the LDS list holds
+    if len(redo):
+        sub = x[torch.from_numpy(redo).to(x.device)].contiguous()
+        out[redo] = _phantom_roi_general(sub, mm_per_pixel, catphan_size, max_labels)
     return out
 
 
@@ -415,32 +426,19 @@ def ctp528_mtf_batch(profiles: torch.Tensor, regions=CTP528_REGIONS):
     "Did not find any spatial resolution pairs"), nregions int [M], maxs / mins float64 [M, 8])."""
     p = profiles.contiguous()
     m, length = p.shape
-    neg = ops.scale(p[:, None, :].contiguous(), -1.0)[:, 0, :].contiguous()
-    # every search is launched before anything returns to the host: the valley window of a profile is the span of ITS
-    # peaks, taken on the device from the peak indices (rows whose peak count is wrong are discarded below, whatever
-    # window their unset indices produced)
-    launched = []
-    for start, end, npk, nval, spacing, _ in regions:
-        pk = ops.find_peaks_batch(p, cap=npk, threshold=0.3, peak_separation=spacing, max_number=npk,
-                                  search_region=(start, end))
-        idx = pk.idx[:, :npk]
-        reg = torch.stack([idx.amin(dim=1), idx.amax(dim=1)], dim=1).to(torch.int32)
-        vl = ops.find_peaks_batch(neg, cap=max(nval, 1), regions=reg, threshold=0.3, peak_separation=spacing,
-                                  max_number=nval)
-        # values[valley_idxs], gathered where the profiles live (the profiles themselves stay on the device)
-        vvals = torch.gather(p, 1, vl.idx.clamp(0, length - 1).to(torch.int64))
-        launched.append((pk.count, pk.props[:, 0, :], vl.count, vvals))
-    # ONE transfer for the whole batch: counts, peak heights and valley values of the eight regions side by side
-    cols = ([t[0].to(torch.float64)[:, None] for t in launched] + [t[2].to(torch.float64)[:, None] for t in launched]
-            + [t[1] for t in launched] + [t[3] for t in launched])
-    widths = [c.shape[1] for c in cols]
-    packed = torch.cat(cols, dim=1).cpu().numpy()
-    parts = np.split(packed, np.cumsum(widths)[:-1], axis=1)
-    nr = len(launched)
-    cnts = np.concatenate(parts[:nr], axis=1).astype(np.int64)                            # [M, R]
-    vcnts = np.concatenate(parts[nr:2 * nr], axis=1).astype(np.int64)
-    heights = parts[2 * nr:3 * nr]                                                        # peak_heights, [M, npk] each
-    vvalues = parts[3 * nr:]
+    # ONE launch for the sixteen searches of a profile (a wave per (profile, region) pair: the peaks, then the valleys inside
+    # the span of THAT profile's peaks) and ONE transfer: counts, peak heights and valley values of the eight regions
+    pc, ph, vc, vv = ops.peak_valley_regions(
+        p, [dict(threshold=0.3, peak_separation=sp, max_number=npk, search_region=(st, en)) for st, en, npk, _, sp, _ in regions],
+        [dict(threshold=0.3, peak_separation=sp, max_number=nval) for _, _, _, nval, sp, _ in regions])
+    nr = len(regions)
+    packed = torch.cat([pc.to(torch.float64), vc.to(torch.float64), ph.reshape(m, -1), vv.reshape(m, -1)], dim=1).cpu().numpy()
+    cnts = packed[:, :nr].astype(np.int64)                                                # [M, R]
+    vcnts = packed[:, nr:2 * nr].astype(np.int64)
+    hts = packed[:, 2 * nr:2 * nr + nr * ph.shape[2]].reshape(m, nr, ph.shape[2])
+    vls = packed[:, 2 * nr + nr * ph.shape[2]:].reshape(m, nr, vv.shape[2])
+    heights = [hts[:, k, :] for k in range(nr)]                                           # peak_heights, [M, cap] each
+    vvalues = [vls[:, k, :] for k in range(nr)]
     maxs = np.full((m, len(regions)), np.nan)
     mins = np.full((m, len(regions)), np.nan)
     alive = np.ones(m, dtype=bool)

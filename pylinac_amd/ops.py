@@ -495,6 +495,36 @@ def find_peaks_batch(profiles: torch.Tensor, cap: int | None = None, lens: torch
     return res
 
 
+def peak_valley_regions(profiles: torch.Tensor, peak_kwargs: list, valley_kwargs: list):
+    """``find_peaks`` and, between the outermost peaks found, ``find_valleys`` for every (profile, region) pair in one launch
+    (``pl_peak_valley_regions``; CTP528CP504.mtf, pylinac/ct.py:1511-1544).  ``peak_kwargs[k]`` / ``valley_kwargs[k]``: the
+    keyword arguments of ``find_peaks_batch`` for region k (``max_number`` required; the valleys' search region is set per
+    profile by the peaks).  -> (peak counts int32 [N, R], peak heights float64 [N, R, cap_p], valley counts int32 [N, R],
+    profile values at the valleys float64 [N, R, cap_v]); NaN beyond a count."""
+    x = profiles
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    if not x.is_cuda:
+        raise ValueError("profiles must live on the GPU")
+    x = x.to(torch.float64).contiguous()
+    n, length = x.shape
+    r = len(peak_kwargs)
+    if r != len(valley_kwargs) or not 1 <= r <= 16:
+        raise ValueError("1..16 regions, one valley parameter set per peak parameter set")
+    pk = (_lib.PeakParams * r)(*[make_peak_params(length, **kw) for kw in peak_kwargs])
+    vl = (_lib.PeakParams * r)(*[make_peak_params(length, **kw) for kw in valley_kwargs])
+    cap_p = max(max(p.max_number for p in pk), 1)
+    cap_v = max(max(p.max_number for p in vl), 1)
+    dev = x.device
+    pc = torch.empty((n, r), dtype=torch.int32, device=dev)
+    ph = torch.empty((n, r, cap_p), dtype=torch.float64, device=dev)
+    vc = torch.empty((n, r), dtype=torch.int32, device=dev)
+    vv = torch.empty((n, r, cap_v), dtype=torch.float64, device=dev)
+    check(_lib.load().pl_peak_valley_regions(x.data_ptr(), n, length, x.stride(0), pk, vl, r, cap_p, cap_v, pc.data_ptr(),
+                                             ph.data_ptr(), vc.data_ptr(), vv.data_ptr(), _stream()), "pl_peak_valley_regions")
+    return pc, ph, vc, vv
+
+
 def fwxm_record(res: PeakBatch, out=None) -> torch.Tensor:
     """FWXMProfile edges / centre / width from a ``max_number=1`` peak batch -> float64 [N, 8]."""
     n = res.count.shape[0]
@@ -793,6 +823,39 @@ def edge_plane(frames: torch.Tensor, sigma: float, spans: torch.Tensor | None = 
     return out, rawmax, lo, hi
 
 
+def edge_otsu(plane: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, frames: torch.Tensor | None = None, sigma: float = 1.0,
+              spans: torch.Tensor | None = None, mask: torch.Tensor | None = None, scale: float = 1.0, return_work: bool = False):
+    """``threshold_otsu(plane[selection]) * scale`` for the plane of ``edge_plane`` in one launch (``pl_edge_otsu``;
+    pylinac/ct.py:3334-3340).  ``lo`` / ``hi``: the selection's exact extrema (``edge_plane``'s); a float32 plane also needs the
+    ``frames`` and ``sigma`` it was made from.  -> (threshold * scale, threshold) float64 [N][, int32 [N, 258]: the histogram,
+    an internal counter, the number of pixels recomputed exactly]."""
+    p = _frames(plane)
+    n, h, w = p.shape
+    dev = p.device
+    if p.dtype == torch.float32:
+        if frames is None:
+            raise ValueError("a float32 plane needs the frames it was made from")
+        x = _frames(frames)
+        if tuple(x.shape) != (n, h, w):
+            raise ValueError("frames and plane differ in shape")
+        wts, _, lw = _device_weights(sigma, dev)
+        raw_ptr, raw_dt, wp = x.data_ptr(), _dt(x), wts.data_ptr()
+    elif p.dtype == torch.float64:
+        raw_ptr, raw_dt, wp, lw = 0, _lib.PL_I16, 0, 0
+    else:
+        raise TypeError("edge_otsu needs a float32 or float64 plane")
+    if spans is not None:
+        spans = spans.to(torch.int32).contiguous()
+    work = torch.empty((n, 258), dtype=torch.int32, device=dev)
+    thr = torch.empty(n, dtype=torch.float64, device=dev)
+    raw = torch.empty(n, dtype=torch.float64, device=dev)
+    check(_lib.load().pl_edge_otsu(p.data_ptr(), _dt(p), raw_ptr, raw_dt, n, h, w, wp, lw,
+                                   0 if spans is None else spans.data_ptr(), 0 if mask is None else mask.contiguous().data_ptr(),
+                                   lo.contiguous().data_ptr(), hi.contiguous().data_ptr(), float(scale), work.data_ptr(),
+                                   thr.data_ptr(), raw.data_ptr(), _stream()), "pl_edge_otsu")
+    return (thr, raw, work) if return_work else (thr, raw)
+
+
 def otsu_float_masked(frames: torch.Tensor, mask: torch.Tensor | None, scale: float = 1.0, lohi=None):
     """``skimage.filters.threshold_otsu(frame[mask])`` for float64 frames (256 bins over the min .. max of the selected
     pixels; pylinac/ct.py:3323, 3338-3340) entirely on the device -> (threshold * scale, threshold) float64 [N].
@@ -906,6 +969,41 @@ def mask_regions(frames: torch.Tensor, thr=None, clear_border_ext: int = 0, fill
                                       int(max_labels), table.data_ptr(), count.data_ptr(), status.data_ptr(),
                                       0 if om is None else om.data_ptr(), _stream()), "pl_mask_regions")
     return (table, count, status, om) if return_mask else (table, count, status)
+
+
+def edge_regions(plane: torch.Tensor, frames: torch.Tensor, sigma: float, thr: torch.Tensor, clear_border_ext: int = 0,
+                 fill_holes: bool = False, max_labels: int = 64, catphan_size: float | None = None,
+                 rawmax: torch.Tensor | None = None, want_table: bool = True, return_mask: bool = False):
+    """``mask_regions`` on the float32 plane of ``edge_plane`` (``pl_edge_regions``): pixels the float32 value cannot decide
+    against the threshold are recomputed exactly from ``frames``.  With ``catphan_size`` and ``rawmax`` the phantom ROI of
+    ``Slice.phantom_roi`` (pylinac/ct.py:381-425) is chosen in the same launch.
+    -> dict(table float64 [N, max_labels, 7] or None, count, status int32 [N], roi float64 [N, 8] or None, mask or None)."""
+    p = _frames(plane)
+    x = _frames(frames)
+    if p.dtype != torch.float32:
+        raise TypeError("edge_regions needs the float32 plane of edge_plane")
+    n, h, w = p.shape
+    if tuple(x.shape) != (n, h, w):
+        raise ValueError("frames and plane differ in shape")
+    dev = p.device
+    wts, _, lw = _device_weights(sigma, dev)
+    t = thr.to(torch.float64).reshape(-1).contiguous()
+    if t.numel() != n:
+        raise ValueError("one threshold per frame")
+    table = torch.empty((n, int(max_labels), 7), dtype=torch.float64, device=dev) if want_table else None
+    count = torch.empty(n, dtype=torch.int32, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    roi = torch.empty((n, 8), dtype=torch.float64, device=dev) if catphan_size is not None else None
+    if roi is not None and rawmax is None:
+        raise ValueError("the ROI selection needs rawmax")
+    om = torch.empty((n, h, w), dtype=torch.uint8, device=dev) if return_mask else None
+    check(_lib.load().pl_edge_regions(p.data_ptr(), x.data_ptr(), _dt(x), wts.data_ptr(), lw, t.data_ptr(), n, h, w,
+                                      int(clear_border_ext), int(bool(fill_holes)), int(max_labels),
+                                      0 if table is None else table.data_ptr(), count.data_ptr(), status.data_ptr(),
+                                      0 if om is None else om.data_ptr(), float(catphan_size or 0.0),
+                                      0 if rawmax is None else rawmax.contiguous().data_ptr(),
+                                      0 if roi is None else roi.data_ptr(), _stream()), "pl_edge_regions")
+    return dict(table=table, count=count, status=status, roi=roi, mask=om)
 
 
 def region_moments(labels: torch.Tensor, max_labels: int):

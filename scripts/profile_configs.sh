@@ -24,6 +24,11 @@ elif which == "pf":
     from pylinac_amd.synthetic import pf_frames
     fr = pf_frames(256, device=dev)
     fn = lambda: picketfence.analyze_batch(fr, 1 / 0.390625, num_pickets=10)
+elif which == "ctp25":                      # config #5 at the bench's size: 25 volumes = one GPU's share of 200
+    from pylinac_amd import ct
+    from pylinac_amd.synthetic import catphan_volume
+    vols = torch.stack([torch.from_numpy(catphan_volume(4000 + v)) for v in range(25)]).to(dev)
+    fn = lambda: ct.ctp528_batch(vols, 0.5)
 elif which == "ctp":
     from pylinac_amd import ct
     from pylinac_amd.synthetic import catphan_volume

@@ -115,6 +115,7 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 
 // ---- barriers and wave intrinsics ------------------------------------------------------------------------
 inline void __syncthreads() { hipemu::block_barrier(); }
+inline void __threadfence() {}   // one OS thread: every store is visible at once
 inline int __syncthreads_or(int p) { return hipemu::block_barrier_or(p); }
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::shfl_from(0, 0))
 #define __builtin_amdgcn_fence(...) ((void)0)

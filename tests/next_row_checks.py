@@ -1077,6 +1077,64 @@ def check_scharr_gaussian(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.ui
             assert none is None and torch.equal(rm5, rm) and torch.equal(lo5, lo4) and torch.equal(hi5, hi4)
 
 
+def check_edge_otsu(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.uint16), (1, 100, 9, np.uint16), (2, 64, 200, np.int16)),
+                    sigmas=(1, 2)):
+    """pl_edge_otsu (one launch; float32 plane with exact recomputation of the undecided pixels, and float64 plane) ==
+    pl_linspace_edges -> pl_hist_uniform -> pl_otsu_from_counts on the float64 plane (the golden-pinned round 1-3 path), on
+    row-span and byte-mask selections, constant and empty selections included.  -> how many pixels took the exact path is not
+    observable from outside; the float32 case is additionally forced through it by a plane whose values sit ON bin edges."""
+    import torch
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(17)
+    n_exact = 0
+    for n, h, w, dt in shapes:
+        a = rng.integers(-1000 if dt == np.int16 else 0, 3000, (n, h, w)).astype(dt)
+        a[:, h // 4:h // 2, w // 4:w // 2] += 700
+        a[0, : h // 8] = 5                                        # a flat band: edge value exactly 0 there
+        x = torch.from_numpy(a).to(dev)
+        c0 = rng.integers(0, w // 2, h)
+        c1 = np.minimum(c0 + rng.integers(1, w, h), w)
+        ms = np.zeros((h, w), np.uint8)
+        for r in range(h):
+            ms[r, c0[r]:c1[r]] = 1
+        spans = torch.from_numpy(np.stack([c0, c1], 1).astype(np.int32)).to(dev)
+        mt = torch.from_numpy(ms).to(dev)
+        for sigma in sigmas:
+            e64, _, lo, hi = ops.edge_plane(x, sigma, spans=spans, dtype=torch.float64)
+            want_thr, want_raw = ops.otsu_float_masked(e64, mt, scale=0.8, lohi=(lo, hi))
+            p32 = e64.to(torch.float32)
+            for plane, kw in ((p32, dict(frames=x, sigma=sigma)), (e64, {})):
+                for sel in (dict(spans=spans), dict(mask=mt)):
+                    thr, raw = ops.edge_otsu(plane, lo, hi, scale=0.8, **kw, **sel)
+                    assert torch.equal(raw, want_raw) and torch.equal(thr, want_thr), (n, h, w, sigma, plane.dtype, list(sel))
+            # a NARROW range (np.histogram drops what lies outside): the bins shrink to a few float32 steps, so the float32
+            # plane cannot decide most pixels inside and the exact recomputation carries the histogram
+            sel_vals = e64[0][mt.bool()]
+            mid = sel_vals.sort().values[sel_vals.numel() // 2]
+            nlo = (mid * (1 - 3e-5)).reshape(1).expand(n).contiguous()
+            nhi = (mid * (1 + 3e-5)).reshape(1).expand(n).contiguous()
+            want_thr, want_raw = ops.otsu_float_masked(e64, mt, scale=0.8, lohi=(nlo, nhi))
+            thr, raw, work = ops.edge_otsu(p32, nlo, nhi, frames=x, sigma=sigma, spans=spans, scale=0.8, return_work=True)
+            assert torch.equal(raw, want_raw) and torch.equal(thr, want_thr)
+            lin = torch.empty((n, 257), dtype=torch.float64, device=e64.device)
+            from pylinac_amd import _lib
+            ops.check(_lib.load().pl_linspace_edges(nlo.data_ptr(), nhi.data_ptr(), 256, n, lin.data_ptr(), ops._stream()), "edges")
+            assert torch.equal(work[:, :256], ops.hist_uniform(e64, lin, mt))
+            n_exact += int(work[:, 257].sum())
+    assert n_exact > 0, "the exact path was never taken"
+    # constant selection -> the value; empty selection -> NaN (float64 plane: no recomputation possible or needed)
+    flat = torch.full((1, 40, 70), 3.25, dtype=torch.float64, device=dev)
+    sp = torch.from_numpy(np.tile(np.array([[5, 60]], np.int32), (40, 1))).to(dev)
+    v = torch.tensor([3.25], dtype=torch.float64, device=dev)
+    thr, raw = ops.edge_otsu(flat, v, v, spans=sp, scale=0.8)
+    assert float(raw[0]) == 3.25 and float(thr[0]) == 3.25 * 0.8
+    inf = torch.tensor([float("inf")], dtype=torch.float64, device=dev)
+    thr, raw = ops.edge_otsu(flat, inf, -inf, spans=sp, scale=0.8)
+    assert np.isnan(float(raw[0]))
+
+
 def check_circle_profile_combined(dev, n_volumes=2, spv=9, h=96, w=112):
     """The per-tap maximum over the +-k slices == the profile of pl_combine_slices' planes: every slice of two volumes
     (wrapping first slices, clamped last ones included), a subset through the slice index, k = 0 .. 3."""
@@ -1102,8 +1160,9 @@ def check_circle_profile_combined(dev, n_volumes=2, spv=9, h=96, w=112):
 
 
 def check_phantom_roi_fused_vs_separate(dev, slices=(0, 24, 44, 79)):
-    """ct.phantom_roi_batch (fused: pl_scharr_gaussian, pl_otsu_from_counts, pl_mask_regions) == the same table built from
-    the separate entry points (get_regions_batch: the golden-pinned round-1/2 path) on synthetic CatPhan slices."""
+    """ct.phantom_roi_batch (three launches: pl_edge_plane float32, pl_edge_otsu, pl_edge_regions with the ROI chosen on the
+    device) == the same table built from the separate entry points (get_regions_batch + the host selection: the golden-pinned
+    round-1/2 path) on synthetic CatPhan slices; every intermediate is compared too."""
     import torch
 
     from pylinac_amd import ct, ops
@@ -1111,20 +1170,46 @@ def check_phantom_roi_fused_vs_separate(dev, slices=(0, 24, 44, 79)):
 
     vol = catphan_volume(seed=4000, n_slices=80)
     x = torch.from_numpy(np.ascontiguousarray(vol[list(slices)])).to(dev)
+    n = len(slices)
     assert ops.mask_regions_fits(512, 512, 64)
     new = ct.phantom_roi_batch(x, 0.5)
     reg = ct.get_regions_batch(x, 0.5, True, True, 64)
     disk = ct._disk_on_device(512, 512, 0.5, x.device)
-    edges, _, lo, hi = ops.scharr_gaussian(x, 1, disk)
-    assert torch.equal(edges, reg["edges"])
-    thr, otsu = ops.otsu_float_masked(edges, disk, scale=0.8, lohi=(lo, hi))
+    spans = ct._disk_spans_on_device(512, 512, 0.5, x.device)
+    assert np.array_equal(ct.row_spans(disk.cpu().numpy()), spans.cpu().numpy())
+    p32, rawmax, lo, hi = ops.edge_plane(x, 1, spans=spans)
+    assert torch.equal(p32, reg["edges"].to(torch.float32))
+    lo2, hi2 = ops.minmax_masked(reg["edges"], disk)
+    assert torch.equal(lo, lo2) and torch.equal(hi, hi2) and torch.equal(rawmax, ops.minmax(ops.scharr(x))[1])
+    thr, otsu = ops.edge_otsu(p32, lo, hi, frames=x, sigma=1, spans=spans, scale=0.8)
     assert torch.equal(otsu, reg["otsu"])
-    tab, cnt, st, om = ops.mask_regions(edges, thr, 4, True, 64, return_mask=True)
-    assert not st.any() and torch.equal(cnt, reg["num"]) and torch.equal(om, reg["bw"])
-    for i in range(len(slices)):
-        k = int(cnt[i])
-        assert torch.equal(tab[i, :k], reg["stats"][i, :k, :7]), i
+    catphan_size = np.pi * 101**2 / 0.5**2
+    r = ops.edge_regions(p32, x, 1, thr, 4, True, 64, catphan_size=catphan_size, rawmax=rawmax, return_mask=True)
+    assert not r["status"].any() and torch.equal(r["count"], reg["num"]) and torch.equal(r["mask"], reg["bw"])
+    for i in range(n):
+        k = int(r["count"][i])
+        assert torch.equal(r["table"][i, :k], reg["stats"][i, :k, :7]), i
+    want = ct._select_phantom_roi(reg["stats"].cpu().numpy(), np.minimum(reg["num"].cpu().numpy(), 64),
+                                  reg["overflow"].cpu().numpy(), rawmax.cpu().numpy(), catphan_size, 64)
+    assert np.array_equal(r["roi"].cpu().numpy(), want, equal_nan=True) and np.array_equal(new, want, equal_nan=True)
     assert (new[:, 0] == 0).all() and np.all(np.abs(new[:, 3:5] - 255.5) < 8)
+    # the other status codes of the on-device choice: wrong size (3), no edges (1), label table too small (4), no region (2)
+    for size, rmx, ml, code in ((catphan_size * 2, rawmax, 64, 3), (catphan_size, torch.zeros_like(rawmax), 64, 1),
+                                (catphan_size, rawmax, 1, None)):
+        q = ops.edge_regions(p32, x, 1, thr, 4, True, ml, catphan_size=size, rawmax=rmx)
+        w2 = ct._select_phantom_roi(q["table"].cpu().numpy(), np.minimum(q["count"].cpu().numpy(), ml),
+                                    (q["count"].cpu().numpy() > ml).astype(np.int32), rmx.cpu().numpy(), size, ml)
+        assert np.array_equal(q["roi"].cpu().numpy(), w2, equal_nan=True)
+        if code is not None:
+            assert (w2[:, 0] == code).all()
+    q = ops.edge_regions(p32, x, 1, torch.full_like(hi, float("inf")), 4, True, 64, catphan_size=catphan_size, rawmax=rawmax)
+    assert (q["roi"][:, 0] == 2).all()
+    # thresholds placed ON plane values: the float32 bracket of those pixels straddles the threshold, so they are decided by
+    # the exact recomputation; the mask must equal the float64 comparison
+    e64 = reg["edges"]
+    tt = e64.reshape(n, -1).sort(dim=1).values[:, -500].contiguous()     # high: a mask of few runs
+    q = ops.edge_regions(p32, x, 1, tt, 0, False, 64, return_mask=True, want_table=False)
+    assert not q["status"].any() and torch.equal(q["mask"], (e64 > tt[:, None, None]).to(torch.uint8))
     return new
 
 

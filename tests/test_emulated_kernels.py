@@ -828,6 +828,12 @@ def test_emulated_scharr_gaussian_bit_identical(emulated):
     checks.check_scharr_gaussian(emulated)
 
 
+def test_emulated_edge_otsu_one_launch(emulated):
+    import next_row_checks as checks
+
+    checks.check_edge_otsu(emulated, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.uint16)), sigmas=(1,))
+
+
 def test_emulated_circle_profile_combined(emulated):
     import next_row_checks as checks
 

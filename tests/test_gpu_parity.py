@@ -1851,6 +1851,14 @@ def test_scharr_gaussian_bit_identical(dev):
 
 
 @pytest.mark.gpu
+def test_edge_otsu_one_launch(dev):
+    import next_row_checks as checks
+
+    checks.check_edge_otsu(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.uint16), (1, 100, 9, np.uint16),
+                                        (2, 64, 200, np.int16), (3, 512, 512, np.int16)))
+
+
+@pytest.mark.gpu
 def test_circle_profile_combined(dev):
     import next_row_checks as checks
 
