@@ -52,7 +52,9 @@ circle_profile_kernel(const T* __restrict__ img, int h, int w, const double* __r
 // Slice z of a volume reads z - k .. z + k of ITS volume the way the reference indexes its list (pl_combine_slices: a
 // negative index wraps to the end of the volume, an index past the end -- IndexError in the reference -- reuses the last
 // slice and the caller discards the profile).
-template <typename T>
+// KPM >= 0: the 2 KPM + 1 slices are compile-time, so the gathers of a tap (and of two consecutive radii) are issued together;
+// rounds 1-3 ran one runtime loop whose 140 dependent two-byte gathers per sample each waited out a memory round trip.
+template <typename T, int KPM>
 __global__ void __launch_bounds__(256)
 circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const int64_t* __restrict__ slice_index,
                                int64_t per_volume, int k_pm, const double* __restrict__ cosv,
@@ -67,27 +69,67 @@ circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const 
   const size_t per_frame = (size_t)h * w;
   const double c = cosv[s], sn = sinv[s];
   const double x0 = cx[frame], y0 = cy[frame];
+  auto slice_of = [&](int d) {                               // the reference's list index z + d inside the slice's own volume
+    int64_t q = z + d;
+    if (q < 0) q += per_volume;
+    if (q < 0) q = 0;
+    if (q >= per_volume) q = per_volume - 1;
+    return stack + (size_t)(v0 + q) * per_frame;
+  };
   double acc = 0.0;
-  for (int k = 0; k < nr; ++k) {
-    const double r = radii[frame * nr + k];
-    const double x = c * r + x0;
-    const double y = sn * r + y0;
-    double v = 0.0;
-    if (x >= 0.0 && x <= (double)(w - 1) && y >= 0.0 && y <= (double)(h - 1)) {
+  if constexpr (KPM >= 0) {
+    constexpr int NS = 2 * KPM + 1;
+    const T* base[NS];
+#pragma unroll
+    for (int d = 0; d < NS; ++d) base[d] = slice_of(d - KPM);
+    const double* rad = radii + frame * nr;
+    auto tap = [&](double r, unsigned& off) {                // -> inside?, offset of the nearest pixel
+      const double x = c * r + x0;
+      const double y = sn * r + y0;
+      const bool in = x >= 0.0 && x <= (double)(w - 1) && y >= 0.0 && y <= (double)(h - 1);
       const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
-      const size_t p = (size_t)yi * w + xi;
-      T m = 0;
-      for (int d = -k_pm; d <= k_pm; ++d) {
-        int64_t q = z + d;
-        if (q < 0) q += per_volume;
-        if (q < 0) q = 0;
-        if (q >= per_volume) q = per_volume - 1;
-        const T e = stack[(size_t)(v0 + q) * per_frame + p];
-        m = (d == -k_pm || e > m) ? e : m;
-      }
-      v = (double)m;
+      off = in ? (unsigned)yi * (unsigned)w + (unsigned)xi : 0u;
+      return in;
+    };
+    int k = 0;
+    for (; k + 2 <= nr; k += 2) {
+      unsigned o0, o1;
+      const bool in0 = tap(rad[k], o0), in1 = tap(rad[k + 1], o1);
+      T e0[NS], e1[NS];
+#pragma unroll
+      for (int d = 0; d < NS; ++d) { e0[d] = base[d][o0]; e1[d] = base[d][o1]; }
+      T m0 = e0[0], m1 = e1[0];
+#pragma unroll
+      for (int d = 1; d < NS; ++d) { m0 = e0[d] > m0 ? e0[d] : m0; m1 = e1[d] > m1 ? e1[d] : m1; }
+      acc = acc + (in0 ? (double)m0 : 0.0);
+      acc = acc + (in1 ? (double)m1 : 0.0);
     }
-    acc = acc + v;
+    for (; k < nr; ++k) {
+      unsigned o0;
+      const bool in0 = tap(rad[k], o0);
+      T m0 = base[0][o0];
+#pragma unroll
+      for (int d = 1; d < NS; ++d) { const T e = base[d][o0]; m0 = e > m0 ? e : m0; }
+      acc = acc + (in0 ? (double)m0 : 0.0);
+    }
+  } else {
+    for (int k = 0; k < nr; ++k) {
+      const double r = radii[frame * nr + k];
+      const double x = c * r + x0;
+      const double y = sn * r + y0;
+      double v = 0.0;
+      if (x >= 0.0 && x <= (double)(w - 1) && y >= 0.0 && y <= (double)(h - 1)) {
+        const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
+        const size_t p = (size_t)yi * w + xi;
+        T m = 0;
+        for (int d = -k_pm; d <= k_pm; ++d) {
+          const T e = slice_of(d)[p];
+          m = (d == -k_pm || e > m) ? e : m;
+        }
+        v = (double)m;
+      }
+      acc = acc + v;
+    }
   }
   out[frame * (size_t)nsamp + s] = (divisor == 1.0) ? acc : acc / divisor;
 }
@@ -107,10 +149,20 @@ extern "C" int pl_circle_profile_combined(const void* stack, int dtype, int64_t 
   PL_REQUIRE(dtype == PL_I16 || dtype == PL_U16 || dtype == PL_I32 || dtype == PL_U8, "integer slices");
   if (m == 0) return PL_OK;
   dim3 grid((unsigned)pl_cdiv(nsamp, 256), (unsigned)m);
-  PL_DISPATCH_DTYPE(dtype, T,
-                    hipLaunchKernelGGL(circle_profile_combined_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
-                                       (const T*)stack, h, w, d_slice_index, slices_per_volume, plusminus, d_cos, d_sin,
-                                       nsamp, d_radii, nr, d_cx, d_cy, divisor, d_out));
+  PL_REQUIRE((int64_t)h * w <= 0xffffffffLL, "frame too large");
+#define CPC_LAUNCH(K)                                                                                                       \
+  hipLaunchKernelGGL((circle_profile_combined_kernel<T, K>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)stack, h, w, \
+                     d_slice_index, slices_per_volume, plusminus, d_cos, d_sin, nsamp, d_radii, nr, d_cx, d_cy, divisor, d_out)
+  PL_DISPATCH_DTYPE(dtype, T, {
+    switch (plusminus) {
+      case 0: CPC_LAUNCH(0); break;
+      case 1: CPC_LAUNCH(1); break;
+      case 2: CPC_LAUNCH(2); break;
+      case 3: CPC_LAUNCH(3); break;
+      default: CPC_LAUNCH(-1); break;
+    }
+  });
+#undef CPC_LAUNCH
   return pl_check_launch("pl_circle_profile_combined");
 }
 

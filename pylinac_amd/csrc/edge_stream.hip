@@ -214,7 +214,8 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
                  double* __restrict__ thr, double* __restrict__ otsu_raw) {
   constexpr int NB = 256;
   __shared__ double s_edge[NB + 1];
-  __shared__ unsigned s_hist[kEsWaves][NB];
+  constexpr int kCopies = 8, kStride = NB + 1;
+  __shared__ unsigned s_hist[kCopies * kStride];
   __shared__ double s_scratch[kEsWaves][kEsScratch];
   __shared__ double s_c[NB], s_p[NB], s_w1[NB], s_s1[NB], s_w2[NB], s_m2[NB], s_var[NB];
   __shared__ int s_last;
@@ -230,65 +231,77 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
     const double step = delta / (double)NB;
     s_edge[tid] = step == 0.0 ? ((double)tid / (double)NB) * delta + first : (double)tid * step + first;
     if (tid == 0) s_edge[NB] = last;
-    for (int k = 0; k < kEsWaves; ++k) s_hist[k][tid] = 0;
+    for (int k = tid; k < kCopies * kStride; k += kEsThreads) s_hist[k] = 0;
   }
   __syncthreads();
   const bool usable = first < last;                       // an empty or constant selection has no histogram to take
   if (usable) {
     const double inv = (double)NB / (last - first);
-    unsigned* hist = s_hist[wv];
+    // the lanes of a wave spread their counts over kCopies copies of the table (smooth planes put most of a wave into one or
+    // two bins: a same-address LDS atomic serialises); copy c sits kStride words further, i.e. in the next bank
+    unsigned* hist = s_hist + (lane & (kCopies - 1)) * kStride;
     const int rows_per = (h + parts - 1) / parts;
     const int rb = part * rows_per, re = min(h, rb + rows_per);
     const PlaneT* pl = plane + f * (int64_t)h * w;
     const T* src = raw ? raw + f * (int64_t)h * w : nullptr;
+    constexpr int U = 4;                                   // loads in flight per lane
     for (int r = rb + wv; r < re; r += kEsWaves) {
       int c0 = 0, c1 = w;
       if (spans) { c0 = spans[2 * r]; c1 = spans[2 * r + 1]; }
-      for (int cb = c0; cb < c1; cb += PL_WAVE) {
-        const int c = cb + lane;
-        bool valid = c < c1;
-        if (valid && mask) valid = mask[(int64_t)r * w + c] != 0;
-        int bin = -1;
-        bool exact_needed = false;
-        if (valid) {
-          const PlaneT pv = pl[(int64_t)r * w + c];
-          double vlo, vhi;
-          if constexpr (sizeof(PlaneT) == 4) es_f32_bracket(pv, vlo, vhi);
-          else { vlo = (double)pv; vhi = vlo; }
-          if (vlo >= first && vhi <= last) {
-            int idx = (int)((vlo - first) * inv);
-            idx = idx < 0 ? 0 : (idx > NB - 1 ? NB - 1 : idx);
-            while (idx > 0 && vlo < s_edge[idx]) --idx;
-            while (idx < NB - 1 && vlo >= s_edge[idx + 1]) ++idx;
-            if (idx == NB - 1 || vhi < s_edge[idx + 1]) bin = idx;      // the whole bracket lies in one bin
-            else exact_needed = true;
-          } else if constexpr (sizeof(PlaneT) == 4) {
-            exact_needed = vhi >= first && vlo <= last;    // the bracket straddles an end of the range
-          }
+      const PlaneT* prow = pl + (int64_t)r * w;
+      const uint8_t* mrow = mask ? mask + (int64_t)r * w : nullptr;
+      for (int cb = c0; cb < c1; cb += U * PL_WAVE) {
+        PlaneT pv[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = cb + u * PL_WAVE + lane;
+          valid[u] = c < c1;
+          const int cl = valid[u] ? c : c1 - 1;            // every lane loads inside the row
+          pv[u] = prow[cl];
+          if (mrow) valid[u] = valid[u] & (mrow[cl] != 0);
         }
-        if constexpr (sizeof(PlaneT) == 4) {
-          unsigned long long todo = __ballot(exact_needed);
-          while (todo) {                                   // wave-uniform
-            const int l = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const double v = es_exact_wave(src, h, w, r, cb + l, wts, rad, s_scratch[wv]);
-            if (lane == l) atomicAdd(&counts[NB + 1], 1u);
-            if (lane == l && v >= first && v <= last) {    // np.histogram drops values outside the range
-              int idx = (int)((v - first) * inv);
-              idx = idx < 0 ? 0 : (idx > NB - 1 ? NB - 1 : idx);
-              while (idx > 0 && v < s_edge[idx]) --idx;
-              while (idx < NB - 1 && v >= s_edge[idx + 1]) ++idx;
-              bin = idx;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          double vlo, vhi;
+          if constexpr (sizeof(PlaneT) == 4) es_f32_bracket(pv[u], vlo, vhi);
+          else { vlo = (double)pv[u]; vhi = vlo; }
+          // the bin of vlo as estimated, and whether the whole bracket provably lies in it
+          int idx = (int)((vlo - first) * inv);
+          idx = idx < 0 ? 0 : (idx > NB - 1 ? NB - 1 : idx);
+          const double e0 = s_edge[idx], e1 = s_edge[idx + 1];
+          const bool fast = valid[u] & (vlo >= e0) & ((vhi < e1) | ((idx == NB - 1) & (vhi <= last)));
+          int bin = fast ? idx : -1;
+          if (__ballot(valid[u] & !fast)) {                // rare: an estimate off by one, a bracket across an edge
+            bool exact_needed = false;
+            if (valid[u] && !fast) {
+              if (vlo >= first && vhi <= last) {
+                while (idx > 0 && vlo < s_edge[idx]) --idx;
+                while (idx < NB - 1 && vlo >= s_edge[idx + 1]) ++idx;
+                if (idx == NB - 1 || vhi < s_edge[idx + 1]) bin = idx;
+                else exact_needed = true;
+              } else if constexpr (sizeof(PlaneT) == 4) {
+                exact_needed = vhi >= first && vlo <= last;  // the bracket straddles an end of the range
+              }                                              // (a float64 value outside the range is dropped, like np.histogram)
+            }
+            if constexpr (sizeof(PlaneT) == 4) {
+              unsigned long long todo = __ballot(exact_needed);
+              while (todo) {                                 // wave-uniform
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const double v = es_exact_wave(src, h, w, r, cb + u * PL_WAVE + l, wts, rad, s_scratch[wv]);
+                if (lane == l) atomicAdd(&counts[NB + 1], 1u);
+                if (lane == l && v >= first && v <= last) {
+                  int k = (int)((v - first) * inv);
+                  k = k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k);
+                  while (k > 0 && v < s_edge[k]) --k;
+                  while (k < NB - 1 && v >= s_edge[k + 1]) ++k;
+                  bin = k;
+                }
+              }
             }
           }
-        }
-        // lanes that share the first lane's bin are counted by one atomic (smooth planes: most of a wave)
-        const unsigned long long have = __ballot(bin >= 0);
-        if (have) {
-          const int b0 = __shfl(bin, __builtin_ctzll(have), PL_WAVE);
-          const unsigned long long same = __ballot(bin == b0);
-          if (lane == __builtin_ctzll(have)) atomicAdd(&hist[b0], (unsigned)__popcll(same));
-          else if (bin >= 0 && bin != b0) atomicAdd(&hist[bin], 1u);
+          if (bin >= 0) atomicAdd(&hist[bin], 1u);
         }
       }
     }
@@ -296,7 +309,7 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
   __syncthreads();
   if (usable) {
     unsigned v = 0;
-    for (int k = 0; k < kEsWaves; ++k) v += s_hist[k][tid];
+    for (int k = 0; k < kCopies; ++k) v += s_hist[k * kStride + tid];
     if (v) atomicAdd(&counts[tid], v);
   }
   __threadfence();

@@ -137,26 +137,66 @@ __device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, 
     }
   }
   __syncthreads();
-  // unions with the row above
+  // ---- components over the runs.  Rounds 1-3 united every run with every overlapping run of the row above through an
+  // atomic union-find whose links point to the smaller id: a tall component (the phantom's outline is 450 rows of one or two
+  // runs) became a 450-deep chain that every find walked link by link, three labellings per slice.  Now:
+  //   1. every run points at the FIRST run of the row above that it overlaps (no atomics): a forest, each tree reaching up;
+  //   2. pointer jumping flattens the forest in log2(depth) sweeps (a racing read sees an ancestor either way);
+  //   3. only runs that overlap MORE than one run above -- where two branches meet -- go through the atomic union, now
+  //      between roots; 4. one more flattening.  The root of a component is still its first run in raster order: that run
+  //      has nothing above it, so it is a forest root, and unions keep the smaller id.
   const int reach = conn8 ? 1 : 0;
   for (int id = tid; id < nruns; id += kSrThreads) {
     const int r = L.run_r[id];
-    if (r == 0) continue;
-    const int s = (int)L.run_s[id] - reach, e = (int)L.run_e[id] + reach;
-    int lo = L.row_off[r - 1];
+    unsigned first_above = (unsigned)id;
+    bool more = false;
+    if (r > 0) {
+      const int s = (int)L.run_s[id] - reach, e = (int)L.run_e[id] + reach;
+      int lo = L.row_off[r - 1];
+      const int end = L.row_off[r];
+      int hi = end;
+      while (lo < hi) {                       // first run of the row above whose end is >= s
+        const int mid = (lo + hi) >> 1;
+        if ((int)L.run_e[mid] < s) lo = mid + 1; else hi = mid;
+      }
+      if (lo < end && (int)L.run_s[lo] <= e) {
+        first_above = (unsigned)lo;
+        more = lo + 1 < end && (int)L.run_s[lo + 1] <= e;
+      }
+    }
+    L.parent[id] = first_above;
+    L.aux[id] = more ? 1 : 0;
+  }
+  __syncthreads();
+  for (;;) {
+    int changed = 0;
+    for (int id = tid; id < nruns; id += kSrThreads) {
+      const unsigned p = L.parent[id];
+      const unsigned pp = L.parent[p];
+      if (pp != p) { L.parent[id] = pp; changed = 1; }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+  for (int id = tid; id < nruns; id += kSrThreads) {
+    if (!L.aux[id]) continue;
+    const int r = L.run_r[id];
+    const int e = (int)L.run_e[id] + reach;
     const int end = L.row_off[r];
-    int hi = end;
-    while (lo < hi) {                       // first run of the row above whose end is >= s
+    // the runs after the first overlapping one: L.parent[id] no longer names it, so find it again
+    const int s = (int)L.run_s[id] - reach;
+    int lo = L.row_off[r - 1], hi = end;
+    while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if ((int)L.run_e[mid] < s) lo = mid + 1; else hi = mid;
     }
-    for (int k = lo; k < end && (int)L.run_s[k] <= e; ++k) sr_unite(L.parent, (unsigned)id, (unsigned)k);
+    for (int k = lo + 1; k < end && (int)L.run_s[k] <= e; ++k) sr_unite(L.parent, (unsigned)id, (unsigned)k);
   }
   __syncthreads();
   for (int id = tid; id < nruns; id += kSrThreads) {
     const unsigned root = sr_find(L.parent, (unsigned)id);
     // writing a root's own entry never changes it; other entries only ever move closer to the root
     L.parent[id] = root;
+    L.aux[id] = 0;
   }
   __syncthreads();
   return nruns;
@@ -215,42 +255,52 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T* src = in + f * (int64_t)h * w;
   const double t = thr ? thr[f] : 0.0;
-  // ---- the bit plane: a wave turns 64 consecutive pixels of a row into one word
+  // ---- the bit plane: a wave turns 64 consecutive pixels of a row into one word; eight words' loads are in flight per wave
+  // (one load per word and iteration left every wave waiting out a full memory round trip per 256 bytes)
   const int nwords = h * ww;
-  for (int q = wv; q < nwords; q += kSrThreads / PL_WAVE) {
-    const int r = q / ww, j = q - r * ww;
-    const int c = j * 64 + lane;
-    bool fg = false;
-    if constexpr (sizeof(T) == 4) {
-      // float32 plane: the float64 value it was rounded from lies between the value's two float32 neighbours
-      bool undecided = false;
-      if (c < w) {
-        double vlo, vhi;
-        es_f32_bracket(src[(int64_t)r * w + c], vlo, vhi);
-        fg = vlo > t;
-        undecided = !fg && vhi > t;
-      }
-      unsigned long long todo = __ballot(undecided);
-      if (todo) {                                          // a handful of pixels per thousand slices
-        double* scratch = reinterpret_cast<double*>(smem + sr_lds_bytes(h, w)) + (size_t)wv * es_scratch_doubles(ea.rad);
-        while (todo) {
-          const int l = __builtin_ctzll(todo);
-          todo &= todo - 1;
-          const int64_t off = f * (int64_t)h * w;
-          const double v = ea.raw_is_signed
-                               ? es_exact_wave(static_cast<const short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch)
-                               : es_exact_wave(static_cast<const unsigned short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch);
-          if (lane == l) fg = v > t;
-        }
-      }
-    } else {
-      if (c < w) {
-        const T v = src[(int64_t)r * w + c];
-        fg = thr ? ((double)v > t) : (v != (T)0);
-      }
+  constexpr int U = 8;
+  for (int q0 = wv * U; q0 < nwords; q0 += (kSrThreads / PL_WAVE) * U) {
+    T v[U];
+    bool inside[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = min(q0 + u, nwords - 1);
+      const int r = q / ww, j = q - r * ww;
+      const int c = j * 64 + lane;
+      inside[u] = (q0 + u < nwords) & (c < w);
+      v[u] = src[(int64_t)r * w + (c < w ? c : w - 1)];
     }
-    const u64 m = __ballot(fg);
-    if (lane == 0) L.plane[q] = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + u;
+      if (q >= nwords) break;                              // wave-uniform
+      bool fg = false;
+      if constexpr (sizeof(T) == 4) {
+        // float32 plane: the float64 value it was rounded from lies between the value's two float32 neighbours
+        double vlo, vhi;
+        es_f32_bracket(v[u], vlo, vhi);
+        fg = inside[u] & (vlo > t);
+        unsigned long long todo = __ballot(inside[u] & !(vlo > t) & (vhi > t));
+        if (todo) {                                        // a handful of pixels per thousand slices
+          // scratch of the exact recomputation: the run tables, which nothing uses before the labelling starts
+          double* scratch = reinterpret_cast<double*>(L.parent) + (size_t)wv * es_scratch_doubles(ea.rad);
+          const int r = q / ww, j = q - r * ww;
+          while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int64_t off = f * (int64_t)h * w;
+            const double ev = ea.raw_is_signed
+                                  ? es_exact_wave(static_cast<const short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch)
+                                  : es_exact_wave(static_cast<const unsigned short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch);
+            if (lane == l) fg = ev > t;
+          }
+        }
+      } else {
+        fg = inside[u] & (thr ? ((double)v[u] > t) : (v[u] != (T)0));
+      }
+      const u64 m = __ballot(fg);
+      if (lane == 0) L.plane[q] = m;
+    }
   }
   __syncthreads();
   int st = 0;
@@ -435,8 +485,9 @@ extern "C" int pl_edge_regions(const float* d_plane, const void* in_raw, int dty
   PL_REQUIRE(!d_roi || (d_rawmax && catphan_size > 0), "the ROI selection needs the phantom size and the raw edge maxima");
   PL_REQUIRE(pl_mask_regions_fits(h, w, max_labels), "frame or label table too large for the LDS form (pl_mask_regions_fits)");
   if (n == 0) return PL_OK;
-  const size_t lds = sr_lds_bytes(h, w) + (kSrThreads / PL_WAVE) * es_scratch_doubles(radius) * sizeof(double);
-  PL_REQUIRE(lds <= 160 * 1024, "frame too large for the LDS form");
+  const size_t lds = sr_lds_bytes(h, w);
+  static_assert((kSrThreads / PL_WAVE) * ((2 * 8 + 1) * (2 * 8 + 1) + 2 * 8 + 1) * sizeof(double) <= (size_t)kSrMaxRuns * 12,
+                "the exact recomputation's scratch (radius 8, every wave) must fit the run tables it borrows");
   static std::atomic<size_t> attr{0};
   if (lds > attr) {
     hipError_t e = hipFuncSetAttribute((const void*)mask_regions_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
