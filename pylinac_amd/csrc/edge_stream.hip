@@ -63,7 +63,7 @@ edge_stream_kernel(const T* __restrict__ in, int h, int w, int strips, int segs,
                    const double* __restrict__ wts, const int* __restrict__ spans, const uint8_t* __restrict__ mask,
                    OutT* __restrict__ out, double* __restrict__ rawmax, double* __restrict__ mn, double* __restrict__ mx) {
   constexpr int WIN = 2 * RAD + 1, HALO = RAD + 1, OUTW = PL_WAVE - 2 * HALO;
-  __shared__ double vbuf[kEsWaves][2][PL_WAVE + 2 * RAD];
+  __shared__ double vbuf[kEsWaves][PL_WAVE + 2 * RAD];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t item = (int64_t)blockIdx.x * kEsWaves + wv;
@@ -85,8 +85,6 @@ edge_stream_kernel(const T* __restrict__ in, int h, int w, int strips, int segs,
   const bool out_lane = lane >= HALO && lane < PL_WAVE - HALO && vc < w;
   const bool fix_left = c_base < 0, fix_right = c_base + PL_WAVE - 1 > w - 1;
   const int lane_first = -c_base, lane_last = w - 1 - c_base;     // the lanes that hold column 0 / w - 1 (when fix_*)
-  auto ld = [&](int row) { return (int)src[(int64_t)row * w + cc]; };
-  auto crow = [&](int v) { return min(max(v, 0) + 1, h - 1); };   // the row BELOW edge row v (clamped like scharr's reflect)
 
   const double pinf = __longlong_as_double(0x7ff0000000000000LL), ninf = __longlong_as_double((long long)0xfff0000000000000ULL);
   double lo = pinf, hi = ninf, rmax = ninf;
@@ -103,17 +101,25 @@ edge_stream_kernel(const T* __restrict__ in, int h, int w, int strips, int segs,
   // prologue: the first edge row that lies inside the frame fills the whole window -- edge rows above the frame (first
   // segment) are copies of it (mode 'nearest'), elsewhere the other slots are overwritten before the first output reads them
   const int fr = max(vstart, 0);
-  int ra = ld(max(fr - 1, 0)), rb = ld(fr), rc = ld(min(fr + 1, h - 1));
-  int pending = ld(crow(fr + 1));
+  const int hm1 = h - 1;
+  // raw rows are addressed by a 32-bit element offset that walks down with the march and stops at the last row (the clamp
+  // scharr's border handling amounts to): two scalar instructions per step instead of a 64-bit multiply
+  const unsigned last_row = (unsigned)hm1 * (unsigned)w;
+  auto ldo = [&](unsigned row_off) { return (int)src[row_off + (unsigned)cc]; };
+  int ra = ldo((unsigned)max(fr - 1, 0) * (unsigned)w), rb = ldo((unsigned)fr * (unsigned)w);
+  unsigned noff = min((unsigned)(fr + 1) * (unsigned)w, last_row);       // the row below edge row fr
+  int rc = ldo(noff);
+  noff = min(noff + (unsigned)w, last_row);
+  int pending = ldo(noff);                                               // the row below edge row fr + 1
   double e = edge_row(ra, rb, rc);
   double E[WIN];
 #pragma unroll
   for (int i = 0; i < WIN; ++i) E[i] = e;
-  int par = 0;
   const bool has_out = out != nullptr, has_mask = mask != nullptr, has_spans = spans != nullptr;
-  OutT* dptr = out + (f * h + r0) * (int64_t)w + vc;
-  const uint8_t* mptr = mask + (int64_t)r0 * w + cc;
-  const int hm1 = h - 1;
+  OutT* orow = has_out ? out + (f * h + r0) * (int64_t)w : nullptr;   // wave-uniform: the lane's column is the store's vector offset
+  const uint8_t* mrow = has_mask ? mask + (int64_t)r0 * w : nullptr;
+  const PL_CONSTANT_AS int* srow = pl_constant_ptr(has_spans ? spans + 2 * r0 : nullptr);    // scalar loads
+  double* vb = vbuf[wv];
 
   // slot i of the window holds edge row base + i.  Every step computes its edge row (the last iteration may run up to
   // 2 * radius rows past the segment: clamped loads, results unused); only the output half of a step is conditional, so the
@@ -123,10 +129,12 @@ edge_stream_kernel(const T* __restrict__ in, int h, int w, int strips, int segs,
     for (int i = 0; i < WIN; ++i) {
       const int vr = base + i;
       ra = rb; rb = rc; rc = pending;
-      pending = ld(crow(vr + 1));                          // in flight for a whole step
+      noff = min(noff + (unsigned)w, last_row);
+      pending = ldo(noff);                                 // in flight for a whole step
       const double en = edge_row(ra, rb, rc);
-      e = vr <= hm1 ? en : e;                              // rows below the frame (last segment) repeat the last edge row
-      E[i] = e;
+      // rows below the frame (last segment only) repeat the last edge row: a register copy on the rare side of a branch
+      if (vr <= hm1) E[i] = en;
+      else E[i] = E[(i + WIN - 1) % WIN];
       const int ro = vr - RAD;
       if (ro >= r0 && ro < r1) {
         const double ctr = E[(i + WIN - RAD) % WIN];
@@ -134,30 +142,28 @@ edge_stream_kernel(const T* __restrict__ in, int h, int w, int strips, int segs,
 #pragma unroll
         for (int k = RAD; k >= 1; --k)
           a0 = a0 + (E[(i + 2 * WIN - RAD - k) % WIN] + E[(i + WIN - RAD + k) % WIN]) * tw[RAD - k];
-        double* vb = vbuf[wv][par];
-        par ^= 1;
         vb[lane + RAD] = a0;
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+        es_wave_sync();
         double a1 = a0 * tw[RAD];
 #pragma unroll
         for (int k = RAD; k >= 1; --k) a1 = a1 + (vb[lane + RAD - k] + vb[lane + RAD + k]) * tw[RAD - k];
-        asm volatile("" ::: "memory");
+        es_wave_sync();                                    // (orders the next step's write behind these reads)
         bool sel = out_lane;
         if (has_spans) {
-          const int c0 = spans[2 * ro], c1 = spans[2 * ro + 1];
-          sel = sel & (vc >= c0) & (vc < c1);
+          sel = sel & (vc >= srow[0]) & (vc < srow[1]);
+          srow += 2;
         } else if (has_mask) {
-          sel = sel & (*mptr != 0);                        // every lane reads inside the frame (clamped column)
-          mptr += w;
+          sel = sel & (mrow[cc] != 0);                     // every lane reads inside the frame (clamped column)
+          mrow += w;
         }
-        const double cm = out_lane ? ctr : ninf;
-        rmax = cm > rmax ? cm : rmax;
-        lo = (sel & (a1 < lo)) ? a1 : lo;
-        hi = (sel & (a1 > hi)) ? a1 : hi;
+        if (out_lane) rmax = ctr > rmax ? ctr : rmax;
+        if (sel) {
+          lo = a1 < lo ? a1 : lo;
+          hi = a1 > hi ? a1 : hi;
+        }
         if (has_out) {
-          if (out_lane) *dptr = (OutT)a1;
-          dptr += w;
+          if (out_lane) orow[vc] = (OutT)a1;
+          orow += w;
         }
       }
     }
@@ -213,11 +219,16 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
                  const double* __restrict__ hi_all, double scale, uint32_t* __restrict__ work /* [n][258], zeroed */,
                  double* __restrict__ thr, double* __restrict__ otsu_raw) {
   constexpr int NB = 256;
-  __shared__ double s_edge[NB + 1];
   constexpr int kCopies = 8, kStride = NB + 1;
-  __shared__ unsigned s_hist[kCopies * kStride];
-  __shared__ double s_scratch[kEsWaves][kEsScratch];
-  __shared__ double s_c[NB], s_p[NB], s_w1[NB], s_s1[NB], s_w2[NB], s_m2[NB], s_var[NB];
+  __shared__ double s_edge[NB + 1];
+  // two lives of one block (20 KB with the edges: eight workgroups per CU -- the loop below waits on memory, waves hide it):
+  // the histogram copies and the exact recomputation's scratch while the band is binned, the class statistics afterwards
+  constexpr int kPhase1 = kEsWaves * kEsScratch + (kCopies * kStride + 1) / 2, kPhase2 = 7 * NB;
+  __shared__ double s_block[kPhase1 > kPhase2 ? kPhase1 : kPhase2];
+  double(*s_scratch)[kEsScratch] = reinterpret_cast<double(*)[kEsScratch]>(s_block);
+  unsigned* s_hist = reinterpret_cast<unsigned*>(s_block + kEsWaves * kEsScratch);
+  double *s_c = s_block, *s_p = s_c + NB, *s_w1 = s_p + NB, *s_s1 = s_w1 + NB, *s_w2 = s_s1 + NB, *s_m2 = s_w2 + NB,
+         *s_var = s_m2 + NB;
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -247,7 +258,7 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
     constexpr int U = 4;                                   // loads in flight per lane
     for (int r = rb + wv; r < re; r += kEsWaves) {
       int c0 = 0, c1 = w;
-      if (spans) { c0 = spans[2 * r]; c1 = spans[2 * r + 1]; }
+      if (spans) { c0 = pl_constant_ptr(spans)[2 * r]; c1 = pl_constant_ptr(spans)[2 * r + 1]; }
       const PlaneT* prow = pl + (int64_t)r * w;
       const uint8_t* mrow = mask ? mask + (int64_t)r * w : nullptr;
       for (int cb = c0; cb < c1; cb += U * PL_WAVE) {
@@ -364,7 +375,7 @@ extern "C" int pl_edge_plane(const void* in, int dtype, int64_t n, int h, int w,
                              const int32_t* d_row_spans, const uint8_t* d_mask, void* d_out, int out_dtype,
                              double* d_rawmax, double* d_min, double* d_max, void* stream) {
   PL_REQUIRE(in && d_weights && d_rawmax && d_min && d_max, "null pointer");
-  PL_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0 && (int64_t)h * w < 0x7fffffffLL, "bad shape");
   PL_REQUIRE(radius >= 1 && radius <= 8, "radius 1..8 (sigma <= 2 at truncate 4)");
   PL_REQUIRE(dtype == PL_I16 || dtype == PL_U16, "int16 / uint16 slices");
   PL_REQUIRE(out_dtype == PL_F32 || out_dtype == PL_F64, "float32 or float64 plane");

@@ -172,6 +172,15 @@ __device__ __forceinline__ void pl_lds_add_abs(unsigned byte_addr, unsigned v) {
 }
 __device__ __forceinline__ unsigned pl_lds_base(const void* lds_ptr) { return (unsigned)reinterpret_cast<uintptr_t>(lds_ptr); }
 
+// A pointer into memory the kernel never writes, read at wave-uniform addresses: through the CONSTANT address space the
+// compiler uses scalar loads (s_load: no vector memory instruction, no place in the in-order vmcnt queue).  A plain
+// `const T* __restrict__` read inside a loop that also stores came out as a vector load followed by s_waitcnt vmcnt(0).
+#define PL_CONSTANT_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const PL_CONSTANT_AS T* pl_constant_ptr(const T* p) {
+  return (const PL_CONSTANT_AS T*)p;
+}
+
 // wave-level reductions (64 lanes, xor butterflies -> every lane holds the result)
 template <typename T, typename F>
 __device__ __forceinline__ T pl_wave_reduce(T v, F f) {

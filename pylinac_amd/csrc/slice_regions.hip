@@ -255,10 +255,10 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T* src = in + f * (int64_t)h * w;
   const double t = thr ? thr[f] : 0.0;
-  // ---- the bit plane: a wave turns 64 consecutive pixels of a row into one word; eight words' loads are in flight per wave
+  // ---- the bit plane: a wave turns 64 consecutive pixels of a row into one word; sixteen words' loads are in flight per wave
   // (one load per word and iteration left every wave waiting out a full memory round trip per 256 bytes)
   const int nwords = h * ww;
-  constexpr int U = 8;
+  constexpr int U = 16;
   for (int q0 = wv * U; q0 < nwords; q0 += (kSrThreads / PL_WAVE) * U) {
     T v[U];
     bool inside[U];

@@ -39,6 +39,7 @@ _PIN = re.compile(r'asm\s+volatile\s*\(\s*""[^;]*;')                      # empt
 _LDSABS = re.compile(r'__hip_atomic_fetch_add\(\(pl_lds_u32\*\)\(uintptr_t\)byte_addr[^;]*;')   # absolute LDS address -> offset into the emulator's block
 _LDSBASE = re.compile(r'return \(unsigned\)reinterpret_cast<uintptr_t>\(lds_ptr\);')
 _LDSTYPE = re.compile(r'typedef __attribute__\(\(address_space\(3\)\)\) unsigned pl_lds_u32;')
+_CONSTAS = re.compile(r'#define PL_CONSTANT_AS __attribute__\(\(address_space\(4\)\)\)')   # scalar-load hint: plain pointer here
 _OCC = re.compile(r'__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)')   # occupancy target of a kernel
 
 
@@ -47,6 +48,7 @@ def _rewrite(text: str) -> str:
     text = _WAITCNT.sub(";", text)
     text = _PIN.sub(";", text)
     text = _OCC.sub("", text)
+    text = _CONSTAS.sub("#define PL_CONSTANT_AS", text)
     text = _LDSABS.sub("atomicAdd(reinterpret_cast<unsigned*>(static_cast<unsigned char*>(hipemu::dyn_lds()) + byte_addr), v);", text)
     text = _LDSBASE.sub("return (unsigned)(static_cast<const unsigned char*>(lds_ptr) - static_cast<const unsigned char*>(hipemu::dyn_lds()));", text)
     text = _LDSTYPE.sub("", text)
