@@ -255,37 +255,60 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
     const int rb = part * rows_per, re = min(h, rb + rows_per);
     const PlaneT* pl = plane + f * (int64_t)h * w;
     const T* src = raw ? raw + f * (int64_t)h * w : nullptr;
-    constexpr int U = 4;                                   // loads in flight per lane
-    for (int r = rb + wv; r < re; r += kEsWaves) {
-      int c0 = 0, c1 = w;
-      if (spans) { c0 = pl_constant_ptr(spans)[2 * r]; c1 = pl_constant_ptr(spans)[2 * r + 1]; }
-      const PlaneT* prow = pl + (int64_t)r * w;
-      const uint8_t* mrow = mask ? mask + (int64_t)r * w : nullptr;
-      for (int cb = c0; cb < c1; cb += U * PL_WAVE) {
-        PlaneT pv[U];
-        bool valid[U];
+    // A chunk = up to 512 pixels of one row (8 loads per lane); the NEXT chunk's loads are issued before this one is binned:
+    // the kernel is a stream of 4-byte loads whose rate is bytes in flight / memory latency (measured: with 4 loads per
+    // wave in flight 2.2 TB/s, and neither the LDS atomics nor the edge reads nor the waves per SIMD moved it)
+    constexpr int U = 8;
+    struct Chunk { int r, cb, c1; };
+    const PL_CONSTANT_AS int* cspans = pl_constant_ptr(spans);
+    auto row_span = [&](int r, int& c0, int& c1) {
+      c0 = 0; c1 = w;
+      if (spans) { c0 = cspans[2 * r]; c1 = cspans[2 * r + 1]; }
+    };
+    auto first_chunk = [&](int r) {                        // the first non-empty chunk at or after row r (r >= re: none)
+      Chunk ck{r, 0, 0};
+      while (ck.r < re) {
+        int c0;
+        row_span(ck.r, c0, ck.c1);
+        ck.cb = c0;
+        if (c0 < ck.c1) break;
+        ck.r += kEsWaves;
+      }
+      return ck;
+    };
+    auto next_chunk = [&](Chunk ck) {
+      ck.cb += U * PL_WAVE;
+      if (ck.cb < ck.c1) return ck;
+      return first_chunk(ck.r + kEsWaves);
+    };
+    auto load_chunk = [&](const Chunk& ck, PlaneT (&pv)[U], unsigned& vmask) {
+      vmask = 0;
+      if (ck.r >= re) return;                              // wave-uniform
+      const PlaneT* prow = pl + (int64_t)ck.r * w;
+      const uint8_t* mrow = mask ? mask + (int64_t)ck.r * w : nullptr;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int c = cb + u * PL_WAVE + lane;
-          valid[u] = c < c1;
-          const int cl = valid[u] ? c : c1 - 1;            // every lane loads inside the row
-          pv[u] = prow[cl];
-          if (mrow) valid[u] = valid[u] & (mrow[cl] != 0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < U; ++u) {
+        const int c = ck.cb + u * PL_WAVE + lane;
+        bool v = c < ck.c1;
+        const int cl = v ? c : ck.c1 - 1;                  // every lane loads inside the row
+        pv[u] = prow[cl];
+        if (mrow) v = v & (mrow[cl] != 0);
+        vmask |= v ? (1u << u) : 0u;
+      }
+    };
+    auto bin_pixel = [&](int r, int c0u, PlaneT pvu, bool vld) {
           double vlo, vhi;
-          if constexpr (sizeof(PlaneT) == 4) es_f32_bracket(pv[u], vlo, vhi);
-          else { vlo = (double)pv[u]; vhi = vlo; }
+          if constexpr (sizeof(PlaneT) == 4) es_f32_bracket(pvu, vlo, vhi);
+          else { vlo = (double)pvu; vhi = vlo; }
           // the bin of vlo as estimated, and whether the whole bracket provably lies in it
           int idx = (int)((vlo - first) * inv);
           idx = idx < 0 ? 0 : (idx > NB - 1 ? NB - 1 : idx);
           const double e0 = s_edge[idx], e1 = s_edge[idx + 1];
-          const bool fast = valid[u] & (vlo >= e0) & ((vhi < e1) | ((idx == NB - 1) & (vhi <= last)));
+          const bool fast = vld & (vlo >= e0) & ((vhi < e1) | ((idx == NB - 1) & (vhi <= last)));
           int bin = fast ? idx : -1;
-          if (__ballot(valid[u] & !fast)) {                // rare: an estimate off by one, a bracket across an edge
+          if (__ballot(vld & !fast)) {                // rare: an estimate off by one, a bracket across an edge
             bool exact_needed = false;
-            if (valid[u] && !fast) {
+            if (vld && !fast) {
               if (vlo >= first && vhi <= last) {
                 while (idx > 0 && vlo < s_edge[idx]) --idx;
                 while (idx < NB - 1 && vlo >= s_edge[idx + 1]) ++idx;
@@ -300,7 +323,7 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
               while (todo) {                                 // wave-uniform
                 const int l = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                const double v = es_exact_wave(src, h, w, r, cb + u * PL_WAVE + l, wts, rad, s_scratch[wv]);
+                const double v = es_exact_wave(src, h, w, r, c0u + l, wts, rad, s_scratch[wv]);
                 if (lane == l) atomicAdd(&counts[NB + 1], 1u);
                 if (lane == l && v >= first && v <= last) {
                   int k = (int)((v - first) * inv);
@@ -313,55 +336,138 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
             }
           }
           if (bin >= 0) atomicAdd(&hist[bin], 1u);
-        }
+    };
+    auto bin_chunk = [&](const Chunk& ck, const PlaneT (&pv)[U], unsigned vmask) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ck.cb + u * PL_WAVE >= ck.c1) break;           // wave-uniform
+        bin_pixel(ck.r, ck.cb + u * PL_WAVE, pv[u], (vmask >> u) & 1u);
       }
+    };
+    PlaneT pa[U], pb[U];
+    unsigned ma, mb;
+    Chunk ca = first_chunk(rb + wv);
+    load_chunk(ca, pa, ma);
+    while (ca.r < re) {
+      const Chunk cb2 = next_chunk(ca);
+      load_chunk(cb2, pb, mb);
+      bin_chunk(ca, pa, ma);
+      if (cb2.r >= re) break;
+      ca = next_chunk(cb2);
+      load_chunk(ca, pa, ma);
+      bin_chunk(cb2, pb, mb);
     }
   }
   __syncthreads();
-  if (usable) {
-    unsigned v = 0;
-    for (int k = 0; k < kCopies; ++k) v += s_hist[k * kStride + tid];
-    if (v) atomicAdd(&counts[tid], v);
+  unsigned own = 0;                                        // this workgroup's count of bin `tid`
+  if (usable)
+    for (int k = 0; k < kCopies; ++k) own += s_hist[k * kStride + tid];
+  if (parts == 1) {
+    // the workgroup IS its slice: no merge through global atomics, no arrival ticket, and above all no device-scope fences
+    // (each one writes the L2 back; with a fence pair in all 2 000 workgroups they were a quarter of the kernel)
+    counts[tid] = own;
+    __syncthreads();                                       // the block is about to change lives
+  } else {
+    // Several workgroups per slice (small batches).  Every access to `counts` is a device-scope atomic, performed at the
+    // device's coherence point, so ordering is all that is needed: the merging atomics RETURN (the wave waits for them
+    // because the barrier below consumes the value), then one lane takes the arrival ticket, and the last workgroup reads
+    // the sums back with atomics too -- no __threadfence (an L2 write-back each on this chip)
+    unsigned old = 0;
+    if (own) old = atomicAdd(&counts[tid], own);
+    const int never = __syncthreads_or(old == 0xffffffffu);   // (a count cannot reach 2^32 - 1: h * w < 2^31)
+    if (tid == 0) s_last = atomicAdd(&counts[NB], never ? 0u : 1u) == (unsigned)(parts - 1);
+    __syncthreads();
+    if (!s_last) return;
+    own = atomicAdd(&counts[tid], 0u);
   }
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) s_last = atomicAdd(&counts[NB], 1u) == (unsigned)(parts - 1);
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  // ---- skimage 0.18.3 threshold_otsu on the finished counts (see otsu_counts_kernel in ct.hip for the order of operations)
+  // ---- skimage 0.18.3 threshold_otsu on the finished counts (otsu_counts_kernel in ct.hip states the reference's order of
+  // operations).  Round 3's form -- one lane walking two 256-step chains through LDS, then a 254-step arg-max -- cost 36 us
+  // per workgroup, a quarter of this kernel when every workgroup is its slice's last.  Here:
+  //   * weight1 / weight2 (cumulative COUNTS) are integer prefix sums: exact in any order, so they are parallel scans;
+  //   * the two cumulative sums of counts * centres must keep numpy's left-to-right float64 order: wave 0 runs the forward
+  //     chain, wave 1 the reversed one, each from registers (v_readlane feeds the next term, no LDS round trip per step);
+  //   * np.argmax (first maximum; a NaN wins and the first NaN wins) is a ballot over the 255 variances.
   const int i = tid;
-  const double ci = (double)atomicAdd(&counts[i], 0u);   // read at the device's coherence point
+  const unsigned cu = own;
+  const double ci = (double)cu;
   const double centre = (s_edge[i] + s_edge[i + 1]) / 2.0;
-  s_c[i] = ci;
+  unsigned* s_cu = reinterpret_cast<unsigned*>(s_var);     // the variances come later
+  s_cu[i] = cu;
   s_p[i] = ci * centre;
   __syncthreads();
-  if (i == 0) {
-    double w1 = 0.0, s1 = 0.0;
-    for (int k = 0; k < NB; ++k) { w1 = w1 + s_c[k]; s1 = s1 + s_p[k]; s_w1[k] = w1; s_s1[k] = s1; }
-  } else if (i == PL_WAVE) {
-    double aw = 0.0, am = 0.0;
-    for (int k = NB - 1; k >= 0; --k) { aw = aw + s_c[k]; am = am + s_p[k]; s_w2[k] = aw; s_m2[k] = am; }
+  if (wv < 2) {
+    const bool fwd = wv == 0;
+    // bin held by this lane in block b: forward b * 64 + lane, backward 255 - (b * 64 + lane)
+    double term[4], mine[4];
+    unsigned cnt[4];
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) {
+      const int k = fwd ? bq * 64 + lane : NB - 1 - (bq * 64 + lane);
+      term[bq] = s_p[k];
+      cnt[bq] = s_cu[k];
+    }
+    double run = 0.0;
+    unsigned carry = 0;
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) {
+      for (int l = 0; l < PL_WAVE; ++l) {
+        run = run + pl_readlane_f64(term[bq], l);          // every lane keeps the same `run`
+        if (lane == l) mine[bq] = run;
+      }
+      unsigned c = cnt[bq];                                // inclusive scan of the counts inside the block
+#pragma unroll
+      for (int o = 1; o < PL_WAVE; o <<= 1) {
+        const unsigned t = __shfl_up(c, o, PL_WAVE);
+        if (lane >= o) c += t;
+      }
+      c += carry;
+      carry = __shfl(c, PL_WAVE - 1, PL_WAVE);
+      const int k = fwd ? bq * 64 + lane : NB - 1 - (bq * 64 + lane);
+      if (fwd) { s_w1[k] = (double)c; s_s1[k] = mine[bq]; }
+      else { s_w2[k] = (double)c; s_m2[k] = mine[bq]; }
+    }
   }
   __syncthreads();
+  double var = 0.0;
   if (i < NB - 1) {
     const double mean1 = s_s1[i] / s_w1[i];
     const double mean2 = s_m2[i + 1] / s_w2[i + 1];
     const double d = mean1 - mean2;
-    s_var[i] = (s_w1[i] * s_w2[i + 1]) * (d * d);
+    var = (s_w1[i] * s_w2[i + 1]) * (d * d);
   }
+  __syncthreads();                                         // s_cu (aliased by s_var) is no longer read
+  const bool live = i < NB - 1;
+  const bool isnan_ = live && var != var;
+  // per wave: first NaN lane, the maximum, then the first lane holding the workgroup's maximum
+  const unsigned long long nanb = __ballot(isnan_);
+  double wmax = live && !isnan_ ? var : __longlong_as_double((long long)0xfff0000000000000ULL);
+  wmax = pl_wave_reduce(wmax, [](double a, double c) { return a > c ? a : c; });
+  if (lane == 0) { s_var[wv] = wmax; reinterpret_cast<int*>(s_var + 8)[wv] = nanb ? wv * 64 + (int)__builtin_ctzll(nanb) : NB; }
+  __syncthreads();
+  double gmax = s_var[0];
+  int first_nan = reinterpret_cast<int*>(s_var + 8)[0];
+  for (int k = 1; k < kEsWaves; ++k) {
+    gmax = s_var[k] > gmax ? s_var[k] : gmax;
+    const int fn = reinterpret_cast<int*>(s_var + 8)[k];
+    first_nan = fn < first_nan ? fn : first_nan;
+  }
+  const unsigned long long eqb = __ballot(live && !isnan_ && var == gmax);
+  __syncthreads();
+  if (lane == 0) reinterpret_cast<int*>(s_var + 8)[wv] = eqb ? wv * 64 + (int)__builtin_ctzll(eqb) : NB;
   __syncthreads();
   if (i == 0) {
     double otsu;
     if (!(first < last)) {
       otsu = first == last ? first : __longlong_as_double(0x7ff8000000000000LL);
     } else {
-      double best = s_var[0];
-      int best_i = 0;
-      for (int k = 1; k < NB - 1; ++k) {
-        const double var = s_var[k];
-        if (var > best || (var != var && best == best)) { best = var; best_i = k; }
+      int best_i = first_nan;
+      if (best_i >= NB) {
+        for (int k = 0; k < kEsWaves; ++k) {
+          const int q = reinterpret_cast<int*>(s_var + 8)[k];
+          best_i = q < best_i ? q : best_i;
+        }
       }
+      if (best_i >= NB) best_i = 0;                        // (cannot happen: some variance equals the maximum)
       otsu = (s_edge[best_i] + s_edge[best_i + 1]) / 2.0;
     }
     if (otsu_raw) otsu_raw[f] = otsu;

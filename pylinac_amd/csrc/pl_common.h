@@ -181,6 +181,14 @@ __device__ __forceinline__ const PL_CONSTANT_AS T* pl_constant_ptr(const T* p) {
   return (const PL_CONSTANT_AS T*)p;
 }
 
+// the float64 of lane `l` (wave-uniform) in every lane, on the scalar path (two v_readlane_b32; __shfl would go through the
+// LDS crossbar)
+__device__ __forceinline__ double pl_readlane_f64(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+
 // wave-level reductions (64 lanes, xor butterflies -> every lane holds the result)
 template <typename T, typename F>
 __device__ __forceinline__ T pl_wave_reduce(T v, F f) {
