@@ -52,8 +52,15 @@ circle_profile_kernel(const T* __restrict__ img, int h, int w, const double* __r
 // Slice z of a volume reads z - k .. z + k of ITS volume the way the reference indexes its list (pl_combine_slices: a
 // negative index wraps to the end of the volume, an index past the end -- IndexError in the reference -- reuses the last
 // slice and the caller discards the profile).
-// KPM >= 0: the 2 KPM + 1 slices are compile-time, so the gathers of a tap (and of two consecutive radii) are issued together;
-// rounds 1-3 ran one runtime loop whose 140 dependent two-byte gathers per sample each waited out a memory round trip.
+// Lanes: EIGHT consecutive samples x EIGHT radii per wave (a lane takes radii rl, rl + 8, rl + 16 ...): the taps of one
+// wave-wide gather then lie in a patch of about 4 x 3 pixels -- one to four cache lines -- where a wave of 64 consecutive
+// samples of one radius spread over up to 32 rows (the kernel was bound by the address path: 47 cycles per gather
+// instruction, SQ_WAIT_INST_ANY 85 %).  The taps are integers, so the sum over the radii is exact in ANY order: each lane
+// adds its own radii, a three-step butterfly adds the eight lanes of a sample -- the same float64 as the reference's
+// sequential `profile += ...`.  KPM >= 0: the 2 KPM + 1 slices are compile-time, so a tap's gathers are issued together
+// (rounds 1-3: one runtime loop of 140 dependent gathers per sample).
+constexpr int kCpRadLanes = 8, kCpSamples = 256 / kCpRadLanes;
+
 template <typename T, int KPM>
 __global__ void __launch_bounds__(256)
 circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const int64_t* __restrict__ slice_index,
@@ -61,9 +68,11 @@ circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const 
                                const double* __restrict__ sinv, int nsamp, const double* __restrict__ radii, int nr,
                                const double* __restrict__ cx, const double* __restrict__ cy, double divisor,
                                double* __restrict__ out) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int rl = threadIdx.x & (kCpRadLanes - 1);
+  const int s_raw = blockIdx.x * kCpSamples + (threadIdx.x / kCpRadLanes);
+  const bool live = s_raw < nsamp;
+  const int s = live ? s_raw : nsamp - 1;                    // every lane stays for the butterfly
   const size_t frame = blockIdx.y;
-  if (s >= nsamp) return;
   const int64_t g = slice_index ? slice_index[frame] : (int64_t)frame;
   const int64_t v0 = (g / per_volume) * per_volume, z = g - v0;
   const size_t per_frame = (size_t)h * w;
@@ -76,62 +85,47 @@ circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const 
     if (q >= per_volume) q = per_volume - 1;
     return stack + (size_t)(v0 + q) * per_frame;
   };
-  double acc = 0.0;
+  const double* rad = radii + frame * nr;
+  auto tap = [&](double r, unsigned& off) {                  // -> inside?, offset of the nearest pixel
+    const double x = c * r + x0;
+    const double y = sn * r + y0;
+    const bool in = x >= 0.0 && x <= (double)(w - 1) && y >= 0.0 && y <= (double)(h - 1);
+    const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
+    off = in ? (unsigned)yi * (unsigned)w + (unsigned)xi : 0u;
+    return in;
+  };
+  double acc = 0.0;                                          // integers: exact whatever the order
   if constexpr (KPM >= 0) {
     constexpr int NS = 2 * KPM + 1;
     const T* base[NS];
 #pragma unroll
     for (int d = 0; d < NS; ++d) base[d] = slice_of(d - KPM);
-    const double* rad = radii + frame * nr;
-    auto tap = [&](double r, unsigned& off) {                // -> inside?, offset of the nearest pixel
-      const double x = c * r + x0;
-      const double y = sn * r + y0;
-      const bool in = x >= 0.0 && x <= (double)(w - 1) && y >= 0.0 && y <= (double)(h - 1);
-      const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
-      off = in ? (unsigned)yi * (unsigned)w + (unsigned)xi : 0u;
-      return in;
-    };
-    int k = 0;
-    for (; k + 2 <= nr; k += 2) {
-      unsigned o0, o1;
-      const bool in0 = tap(rad[k], o0), in1 = tap(rad[k + 1], o1);
-      T e0[NS], e1[NS];
-#pragma unroll
-      for (int d = 0; d < NS; ++d) { e0[d] = base[d][o0]; e1[d] = base[d][o1]; }
-      T m0 = e0[0], m1 = e1[0];
-#pragma unroll
-      for (int d = 1; d < NS; ++d) { m0 = e0[d] > m0 ? e0[d] : m0; m1 = e1[d] > m1 ? e1[d] : m1; }
-      acc = acc + (in0 ? (double)m0 : 0.0);
-      acc = acc + (in1 ? (double)m1 : 0.0);
-    }
-    for (; k < nr; ++k) {
+    for (int k = rl; k < nr; k += kCpRadLanes) {
       unsigned o0;
       const bool in0 = tap(rad[k], o0);
-      T m0 = base[0][o0];
+      T e0[NS];
 #pragma unroll
-      for (int d = 1; d < NS; ++d) { const T e = base[d][o0]; m0 = e > m0 ? e : m0; }
+      for (int d = 0; d < NS; ++d) e0[d] = base[d][o0];
+      T m0 = e0[0];
+#pragma unroll
+      for (int d = 1; d < NS; ++d) m0 = e0[d] > m0 ? e0[d] : m0;
       acc = acc + (in0 ? (double)m0 : 0.0);
     }
   } else {
-    for (int k = 0; k < nr; ++k) {
-      const double r = radii[frame * nr + k];
-      const double x = c * r + x0;
-      const double y = sn * r + y0;
-      double v = 0.0;
-      if (x >= 0.0 && x <= (double)(w - 1) && y >= 0.0 && y <= (double)(h - 1)) {
-        const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
-        const size_t p = (size_t)yi * w + xi;
-        T m = 0;
-        for (int d = -k_pm; d <= k_pm; ++d) {
-          const T e = slice_of(d)[p];
-          m = (d == -k_pm || e > m) ? e : m;
-        }
-        v = (double)m;
+    for (int k = rl; k < nr; k += kCpRadLanes) {
+      unsigned o0;
+      const bool in0 = tap(rad[k], o0);
+      T m = slice_of(-k_pm)[o0];
+      for (int d = -k_pm + 1; d <= k_pm; ++d) {
+        const T e = slice_of(d)[o0];
+        m = e > m ? e : m;
       }
-      acc = acc + v;
+      acc = acc + (in0 ? (double)m : 0.0);
     }
   }
-  out[frame * (size_t)nsamp + s] = (divisor == 1.0) ? acc : acc / divisor;
+#pragma unroll
+  for (int o = 1; o < kCpRadLanes; o <<= 1) acc = acc + __shfl_xor(acc, o, 64);
+  if (live && rl == 0) out[frame * (size_t)nsamp + s] = (divisor == 1.0) ? acc : acc / divisor;
 }
 
 }  // namespace
@@ -148,7 +142,7 @@ extern "C" int pl_circle_profile_combined(const void* stack, int dtype, int64_t 
   PL_REQUIRE(divisor != 0.0, "zero divisor");
   PL_REQUIRE(dtype == PL_I16 || dtype == PL_U16 || dtype == PL_I32 || dtype == PL_U8, "integer slices");
   if (m == 0) return PL_OK;
-  dim3 grid((unsigned)pl_cdiv(nsamp, 256), (unsigned)m);
+  dim3 grid((unsigned)pl_cdiv(nsamp, kCpSamples), (unsigned)m);
   PL_REQUIRE((int64_t)h * w <= 0xffffffffLL, "frame too large");
 #define CPC_LAUNCH(K)                                                                                                       \
   hipLaunchKernelGGL((circle_profile_combined_kernel<T, K>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)stack, h, w, \

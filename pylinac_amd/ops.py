@@ -536,6 +536,22 @@ def fwxm_record(res: PeakBatch, out=None) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------- circle profiles, Sobel
+_circle_cache: dict = {}
+
+
+def _circle_tables(size: float, start_angle: float, ccw: bool, dev):
+    """cos / sin of ``circle_radians`` on the device, cached per ring geometry (numpy's libm values: see csrc/circle.hip)."""
+    key = (float(size), float(start_angle), bool(ccw), str(dev))
+    hit = _circle_cache.get(key)
+    if hit is None:
+        rads = circle_radians(size, start_angle, ccw)
+        both = torch.from_numpy(np.stack([np.cos(rads), np.sin(rads)])).to(dev)
+        if len(_circle_cache) > 64:
+            _circle_cache.clear()
+        hit = _circle_cache[key] = (both[0], both[1], len(rads))
+    return hit
+
+
 def circle_radians(size: float, start_angle: float = 0, ccw: bool = True) -> np.ndarray:
     """``CircleProfile._radians`` (pylinac/core/profile.py:2244-2252)."""
     interval = (2 * np.pi) / size
@@ -560,27 +576,35 @@ def circle_profile(frames: torch.Tensor, cx, cy, radii, size: float, start_angle
         sidx, spv, pm = combine
         sidx = np.ascontiguousarray(sidx, dtype=np.int64)
         n = len(sidx)
-        d_sidx = torch.from_numpy(sidx).to(dev)
     else:
+        sidx = None
         n = n_stack
-    rads = circle_radians(size, start_angle, ccw)
-    d_cos = torch.from_numpy(np.cos(rads)).to(dev)
-    d_sin = torch.from_numpy(np.sin(rads)).to(dev)
-    r = torch.as_tensor(np.asarray(radii, dtype=np.float64))
-    if r.dim() == 1:
-        r = r[None, :].expand(n, -1)
-    r = r.contiguous().to(dev)
-    cxs = torch.as_tensor(np.broadcast_to(np.asarray(cx, dtype=np.float64), (n,)).copy()).to(dev)
-    cys = torch.as_tensor(np.broadcast_to(np.asarray(cy, dtype=np.float64), (n,)).copy()).to(dev)
-    out = torch.empty((n, len(rads)), dtype=torch.float64, device=dev)
+    d_cos, d_sin, nsamp = _circle_tables(size, start_angle, ccw, dev)
+    # ONE host-to-device copy for the per-profile arguments (slice index, radii, centres): five separate pageable copies
+    # were five synchronisations per call
+    r = np.asarray(radii, dtype=np.float64)
+    if r.ndim == 1:
+        r = np.broadcast_to(r[None, :], (n, r.shape[0]))
+    nr = r.shape[1]
+    pack = np.empty(n * (nr + 3), dtype=np.float64)
+    pack[:n].view(np.int64)[:] = sidx if sidx is not None else 0
+    pack[n:n + n * nr] = r.reshape(-1)
+    pack[n + n * nr:2 * n + n * nr] = np.broadcast_to(np.asarray(cx, dtype=np.float64), (n,))
+    pack[2 * n + n * nr:] = np.broadcast_to(np.asarray(cy, dtype=np.float64), (n,))
+    d_pack = torch.from_numpy(pack).to(dev)
+    d_sidx = d_pack[:n].view(torch.int64)
+    r = d_pack[n:n + n * nr].view(n, nr)
+    cxs = d_pack[n + n * nr:2 * n + n * nr]
+    cys = d_pack[2 * n + n * nr:]
+    out = torch.empty((n, nsamp), dtype=torch.float64, device=dev)
     if combine is not None:
         check(_lib.load().pl_circle_profile_combined(x.data_ptr(), _dt(x), n_stack, h, w, d_sidx.data_ptr(), n, int(spv),
-                                                     int(pm), d_cos.data_ptr(), d_sin.data_ptr(), len(rads), r.data_ptr(),
+                                                     int(pm), d_cos.data_ptr(), d_sin.data_ptr(), nsamp, r.data_ptr(),
                                                      r.shape[1], cxs.data_ptr(), cys.data_ptr(), float(divisor),
                                                      out.data_ptr(), _stream()), "pl_circle_profile_combined")
         return out
     check(_lib.load().pl_circle_profile(x.data_ptr(), _dt(x), n, h, w, d_cos.data_ptr(), d_sin.data_ptr(),
-                                        len(rads), r.data_ptr(), r.shape[1], cxs.data_ptr(), cys.data_ptr(),
+                                        nsamp, r.data_ptr(), r.shape[1], cxs.data_ptr(), cys.data_ptr(),
                                         float(divisor), out.data_ptr(), _stream()), "pl_circle_profile")
     return out
 
