@@ -581,10 +581,12 @@ int pl_find_peaks_regions(const double* d_x, int64_t n, int len, const int32_t* 
  * valley_params[k] inside [first peak index, last peak index) (valley_params' own region is ignored).
  *   d_pk_count int32 [n][nregions], d_pk_height float64 [n][nregions][cap_p] (peak_heights in index order, NaN beyond count),
  *   d_vl_count int32 [n][nregions] (0 when the peak count was wrong), d_vl_value float64 [n][nregions][cap_v] (the profile's
- *   values at the valley indices, NaN beyond count).  Capacities 1..8, regions of at most 1024 samples. */
+ *   values at the valley indices, NaN beyond count); d_means (optional) float64 [n][nregions][2] = np.mean of the peak
+ *   heights (NaN unless exactly max_number peaks were found) and of the valley values (NaN when there are none): the
+ *   max_values.mean() / min_values.mean() of ct.py:1530, 1536.  Capacities 1..8, regions of at most 1024 samples. */
 int pl_peak_valley_regions(const double* d_x, int64_t n, int len, int64_t stride, const pl_peak_params* peak_params,
                            const pl_peak_params* valley_params, int nregions, int cap_p, int cap_v, int32_t* d_pk_count,
-                           double* d_pk_height, int32_t* d_vl_count, double* d_vl_value, void* stream);
+                           double* d_pk_height, int32_t* d_vl_count, double* d_vl_value, double* d_means, void* stream);
 
 /* ---- BASELINE config #3: PicketFence.analyze per-image measurement, UP_DOWN pickets ------------
  * (pylinac/picketfence.py:745-803, 847-912, 1605-1628) on uint16 frames whose float64 image would be

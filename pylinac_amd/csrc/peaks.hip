@@ -470,7 +470,7 @@ struct PvRegions {
 __global__ void __launch_bounds__(kThreads)
 peak_valley_kernel(const double* __restrict__ x, int64_t nprof, int64_t stride, int len, PvRegions R, int slot_bytes, int maxc,
                    int cap_p, int cap_v, int32_t* __restrict__ d_pk_count, double* __restrict__ d_pk_height,
-                   int32_t* __restrict__ d_vl_count, double* __restrict__ d_vl_value) {
+                   int32_t* __restrict__ d_vl_count, double* __restrict__ d_vl_value, double* __restrict__ d_means) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   constexpr int NW = kThreads / PL_WAVE;
   __shared__ Scan scan_a[NW];
@@ -493,7 +493,8 @@ peak_valley_kernel(const double* __restrict__ x, int64_t nprof, int64_t stride, 
   const int cnt = o_cnt[slot];
   const int lo = cnt > 0 ? o_idx[slot][0] : 0, hi = cnt > 0 ? o_idx[slot][cnt - 1] : 0;   // peaks leave in index order
   if (tid == 0) d_pk_count[unit] = cnt;
-  if (tid < cap_p) d_pk_height[unit * cap_p + tid] = tid < cnt ? o_p[slot][tid] : nan;
+  const double hv = tid < cnt && tid < cap_p ? o_p[slot][tid] : nan;      // the peak heights stay in registers for the mean
+  if (tid < cap_p) d_pk_height[unit * cap_p + tid] = hv;
   group_sync<PL_WAVE>();
   int vcnt = 0;
   if (cnt == pk.max_number && cnt > 0) {               // wave-uniform
@@ -505,6 +506,26 @@ peak_valley_kernel(const double* __restrict__ x, int64_t nprof, int64_t stride, 
   }
   if (tid == 0) d_vl_count[unit] = vcnt;
   if (tid < cap_v) d_vl_value[unit * cap_v + tid] = tid < vcnt ? xp[o_idx[slot][tid]] : nan;   // values[valley_idxs]
+  if (d_means) {                                          // wave-uniform
+    // max_values.mean() / min_values.mean() (pylinac/ct.py:1530, 1536): np.mean of fewer than eight values is the plain
+    // left-to-right float64 sum divided by the count; an empty selection gives NaN.  The peak mean is only meaningful when
+    // the region held exactly max_number peaks -- the caller's `break` test -- and is NaN otherwise.
+    double pm = nan, vm = nan;
+    if (cnt == pk.max_number && cnt > 0) {
+      double sum = __shfl(hv, 0, PL_WAVE);
+      for (int j = 1; j < cnt; ++j) sum = sum + __shfl(hv, j, PL_WAVE);
+      pm = sum / (double)cnt;
+      if (vcnt > 0) {
+        double vs = xp[o_idx[slot][0]];
+        for (int j = 1; j < vcnt; ++j) vs = vs + xp[o_idx[slot][j]];
+        vm = vs / (double)vcnt;
+      }
+    }
+    if (tid == 0) {
+      d_means[unit * 2] = pm;
+      d_means[unit * 2 + 1] = vm;
+    }
+  }
 }
 
 }  // namespace
@@ -633,7 +654,7 @@ extern "C" int pl_colparts_profile_fwxm(const uint32_t* d_parts, int64_t n, int 
 extern "C" int pl_peak_valley_regions(const double* d_x, int64_t n, int len, int64_t stride, const pl_peak_params* peak_params,
                                       const pl_peak_params* valley_params, int nregions, int cap_p, int cap_v,
                                       int32_t* d_pk_count, double* d_pk_height, int32_t* d_vl_count, double* d_vl_value,
-                                      void* stream) {
+                                      double* d_means, void* stream) {
   PL_REQUIRE(d_x && peak_params && valley_params && d_pk_count && d_pk_height && d_vl_count && d_vl_value, "null pointer");
   PL_REQUIRE(n >= 0 && len > 0 && stride >= len, "bad shape");
   PL_REQUIRE(nregions >= 1 && nregions <= kPvMaxRegions && cap_p >= 1 && cap_p <= kPvCap && cap_v >= 1 && cap_v <= kPvCap,
@@ -664,6 +685,6 @@ extern "C" int pl_peak_valley_regions(const double* d_x, int64_t n, int len, int
   }
   hipLaunchKernelGGL(peak_valley_kernel, dim3((unsigned)pl_cdiv(units, kThreads / PL_WAVE)), dim3(kThreads),
                      lds * (kThreads / PL_WAVE), (hipStream_t)stream, d_x, n, stride, len, R, (int)lds, maxc, cap_p, cap_v,
-                     d_pk_count, d_pk_height, d_vl_count, d_vl_value);
+                     d_pk_count, d_pk_height, d_vl_count, d_vl_value, d_means);
   return pl_check_launch("pl_peak_valley_regions");
 }

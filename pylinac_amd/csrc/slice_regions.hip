@@ -255,10 +255,16 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T* src = in + f * (int64_t)h * w;
   const double t = thr ? thr[f] : 0.0;
-  // ---- the bit plane: a wave turns 64 consecutive pixels of a row into one word; sixteen words' loads are in flight per wave
-  // (one load per word and iteration left every wave waiting out a full memory round trip per 256 bytes)
+  // ---- the bit plane: a wave turns 64 consecutive pixels of a row into one word; thirty-two words' loads are in flight per
+  // wave (one load per word and iteration left every wave waiting out a full memory round trip per 256 bytes; the build is
+  // a stream whose rate is bytes in flight / latency)
   const int nwords = h * ww;
-  constexpr int U = 16;
+  constexpr int U = sizeof(T) == 4 ? 32 : 16;
+  // float32 planes: words with a pixel the float32 value cannot decide are noted here (the run tables, which nothing uses
+  // before the labelling starts, lend the space) and settled after the unrolled body by the exact recomputation
+  u64* und = reinterpret_cast<u64*>(L.parent) + (size_t)wv * U;
+  double* scratch = reinterpret_cast<double*>(reinterpret_cast<u64*>(L.parent) + (size_t)(kSrThreads / PL_WAVE) * U) +
+                    (size_t)wv * es_scratch_doubles(sizeof(T) == 4 ? ea.rad : 0);
   for (int q0 = wv * U; q0 < nwords; q0 += (kSrThreads / PL_WAVE) * U) {
     T v[U];
     bool inside[U];
@@ -270,21 +276,34 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
       inside[u] = (q0 + u < nwords) & (c < w);
       v[u] = src[(int64_t)r * w + (c < w ? c : w - 1)];
     }
+    bool any_und = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int q = q0 + u;
-      if (q >= nwords) break;                              // wave-uniform
-      bool fg = false;
+      if (q >= nwords) continue;                           // wave-uniform
+      bool fg;
       if constexpr (sizeof(T) == 4) {
-        // float32 plane: the float64 value it was rounded from lies between the value's two float32 neighbours
+        // the float64 value lies between the float32 value's two neighbours
         double vlo, vhi;
         es_f32_bracket(v[u], vlo, vhi);
         fg = inside[u] & (vlo > t);
-        unsigned long long todo = __ballot(inside[u] & !(vlo > t) & (vhi > t));
-        if (todo) {                                        // a handful of pixels per thousand slices
-          // scratch of the exact recomputation: the run tables, which nothing uses before the labelling starts
-          double* scratch = reinterpret_cast<double*>(L.parent) + (size_t)wv * es_scratch_doubles(ea.rad);
-          const int r = q / ww, j = q - r * ww;
+        const u64 todo = __ballot(inside[u] & !(vlo > t) & (vhi > t));
+        if (lane == 0) und[u] = todo;
+        any_und |= todo != 0;
+      } else {
+        fg = inside[u] & (thr ? ((double)v[u] > t) : (v[u] != (T)0));
+      }
+      const u64 m = __ballot(fg);
+      if (lane == 0) L.plane[q] = m;
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (any_und) {                                       // a handful of pixels per thousand slices
+        es_wave_sync();
+#pragma unroll 1
+        for (int u = 0; u < U && q0 + u < nwords; ++u) {
+          u64 todo = und[u];
+          const int q = q0 + u, r = q / ww, j = q - r * ww;
+          u64 add = 0;
           while (todo) {
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1;
@@ -292,14 +311,12 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
             const double ev = ea.raw_is_signed
                                   ? es_exact_wave(static_cast<const short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch)
                                   : es_exact_wave(static_cast<const unsigned short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch);
-            if (lane == l) fg = ev > t;
+            if (ev > t) add |= 1ull << l;
           }
+          if (lane == 0 && add) L.plane[q] |= add;
         }
-      } else {
-        fg = inside[u] & (thr ? ((double)v[u] > t) : (v[u] != (T)0));
+        es_wave_sync();
       }
-      const u64 m = __ballot(fg);
-      if (lane == 0) L.plane[q] = m;
     }
   }
   __syncthreads();
@@ -486,8 +503,8 @@ extern "C" int pl_edge_regions(const float* d_plane, const void* in_raw, int dty
   PL_REQUIRE(pl_mask_regions_fits(h, w, max_labels), "frame or label table too large for the LDS form (pl_mask_regions_fits)");
   if (n == 0) return PL_OK;
   const size_t lds = sr_lds_bytes(h, w);
-  static_assert((kSrThreads / PL_WAVE) * ((2 * 8 + 1) * (2 * 8 + 1) + 2 * 8 + 1) * sizeof(double) <= (size_t)kSrMaxRuns * 12,
-                "the exact recomputation's scratch (radius 8, every wave) must fit the run tables it borrows");
+  static_assert((kSrThreads / PL_WAVE) * (((2 * 8 + 1) * (2 * 8 + 1) + 2 * 8 + 1) * sizeof(double) + 32 * 8) <= (size_t)kSrMaxRuns * 12,
+                "the exact recomputation's scratch (radius 8, every wave) and the undecided-word notes must fit the run tables they borrow");
   static std::atomic<size_t> attr{0};
   if (lds > attr) {
     hipError_t e = hipFuncSetAttribute((const void*)mask_regions_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -171,17 +171,31 @@ def phantom_roi_batch(slices: torch.Tensor, mm_per_pixel: float, catphan_radius_
     plane as float32 + its exact extrema on the 110 mm disk), ``pl_edge_otsu`` (the disk histogram and its Otsu threshold)
     and ``pl_edge_regions`` (threshold, clear_border, fill_holes, label, regionprops and the choice of the phantom region,
     one workgroup per slice)."""
+    return _phantom_roi_finish(_phantom_roi_launch(slices, mm_per_pixel, catphan_radius_mm, max_labels))
+
+
+def _phantom_roi_launch(slices: torch.Tensor, mm_per_pixel: float, catphan_radius_mm: float = CATPHAN_RADIUS_MM,
+                        max_labels: int = 64):
+    """The device half of ``phantom_roi_batch``: queues the three launches and the transfer of the ROI table, returns at once."""
     x = ops._frames(slices)
     n, h, w = x.shape
     catphan_size = np.pi * catphan_radius_mm**2 / mm_per_pixel**2        # ct.py:2581-2584
+    args = (x, mm_per_pixel, catphan_size, max_labels)
     if not (x.dtype in (torch.int16, torch.uint16) and ops.mask_regions_fits(h, w, max_labels)):
-        return _phantom_roi_general(x, mm_per_pixel, catphan_size, max_labels)
+        return args, None
     spans = _disk_spans_on_device(h, w, mm_per_pixel, x.device)
     plane, raw_max, lo, hi = ops.edge_plane(x, 1, spans=spans)
     thr, _ = ops.edge_otsu(plane, lo, hi, frames=x, sigma=1, spans=spans, scale=0.8)
     reg = ops.edge_regions(plane, x, 1, thr, min(int(max(h, w) / 100), 3) + 1, True, max_labels, catphan_size=catphan_size,
                            rawmax=raw_max, want_table=False)
-    out = reg["roi"].cpu().numpy()                                       # the one synchronisation of the localisation
+    return args, ops.HostCopy(reg["roi"])
+
+
+def _phantom_roi_finish(pending) -> np.ndarray:
+    (x, mm_per_pixel, catphan_size, max_labels), copy = pending
+    if copy is None:
+        return _phantom_roi_general(x, mm_per_pixel, catphan_size, max_labels)
+    out = copy.numpy().copy()                                            # the one synchronisation of the localisation
     redo = np.flatnonzero(out[:, 0] == 5)                                # slices with more row runs than the LDS list holds
     if len(redo):
         sub = x[torch.from_numpy(redo).to(x.device)].contiguous()
@@ -424,40 +438,29 @@ def ctp528_mtf_batch(profiles: torch.Tensor, regions=CTP528_REGIONS):
     Michelson contrast, normalised to region 1.  A slice stops at the first region with the wrong number of peaks, like
     the reference's ``break``.  -> dict(rmtf float64 [M, 8] (NaN beyond the regions found; all NaN = the reference's
     "Did not find any spatial resolution pairs"), nregions int [M], maxs / mins float64 [M, 8])."""
+    return _ctp528_mtf_finish(_ctp528_mtf_launch(profiles, regions))
+
+
+def _ctp528_mtf_launch(profiles: torch.Tensor, regions=CTP528_REGIONS):
     p = profiles.contiguous()
     m, length = p.shape
     # ONE launch for the sixteen searches of a profile (a wave per (profile, region) pair: the peaks, then the valleys inside
-    # the span of THAT profile's peaks) and ONE transfer: counts, peak heights and valley values of the eight regions
-    pc, ph, vc, vv = ops.peak_valley_regions(
+    # the span of THAT profile's peaks, then the two means) and ONE transfer of 16 doubles per profile
+    _, _, _, _, means = ops.peak_valley_regions(
         p, [dict(threshold=0.3, peak_separation=sp, max_number=npk, search_region=(st, en)) for st, en, npk, _, sp, _ in regions],
         [dict(threshold=0.3, peak_separation=sp, max_number=nval) for _, _, _, nval, sp, _ in regions])
-    nr = len(regions)
-    packed = torch.cat([pc.to(torch.float64), vc.to(torch.float64), ph.reshape(m, -1), vv.reshape(m, -1)], dim=1).cpu().numpy()
-    cnts = packed[:, :nr].astype(np.int64)                                                # [M, R]
-    vcnts = packed[:, nr:2 * nr].astype(np.int64)
-    hts = packed[:, 2 * nr:2 * nr + nr * ph.shape[2]].reshape(m, nr, ph.shape[2])
-    vls = packed[:, 2 * nr + nr * ph.shape[2]:].reshape(m, nr, vv.shape[2])
-    heights = [hts[:, k, :] for k in range(nr)]                                           # peak_heights, [M, cap] each
-    vvalues = [vls[:, k, :] for k in range(nr)]
-    maxs = np.full((m, len(regions)), np.nan)
-    mins = np.full((m, len(regions)), np.nan)
-    alive = np.ones(m, dtype=bool)
-    nreg = np.zeros(m, dtype=np.int64)
-    rows = np.arange(m)
-    for k, (start, end, npk, nval, spacing, _) in enumerate(regions):
-        alive = alive & (cnts[:, k] == npk)                              # the reference's `break` at the first miss
-        if not alive.any():
-            break
-        maxs[alive, k] = heights[k][alive, :npk].mean(axis=1)
-        vals, vc = vvalues[k], vcnts[:, k]
-        vals = np.where(np.arange(vals.shape[1])[None, :] < vc[:, None], vals, np.nan)
-        with np.errstate(invalid="ignore"), warnings.catch_warnings():
-            warnings.simplefilter("ignore", RuntimeWarning)
-            vmean = np.nansum(vals, axis=1) / np.maximum(vc, 1)
-        vmean = np.where(vc > 0, vmean, np.nan)                        # np.mean of an empty selection
-        # np.mean sums sequentially for short arrays: nansum over <= 4 entries is the same left-to-right sum
-        mins[alive, k] = vmean[alive]
-        nreg[alive] = k + 1
+    return m, len(regions), ops.HostCopy(means.reshape(m, 2 * len(regions)))
+
+
+def _ctp528_mtf_finish(pending):
+    m, nr, copy = pending
+    mh = copy.numpy().reshape(m, nr, 2)
+    # a region counts while every region before it held its number of peaks (the reference's `break`): the peak mean is NaN
+    # exactly where the count was wrong
+    alive = np.logical_and.accumulate(~np.isnan(mh[:, :, 0]), axis=1)
+    maxs = np.where(alive, mh[:, :, 0], np.nan)
+    mins = np.where(alive, mh[:, :, 1], np.nan)
+    nreg = alive.sum(axis=1)
     with np.errstate(invalid="ignore", divide="ignore"):
         mtf = (maxs - mins) / (maxs + mins)                             # michelson: (max - min) / (max + min)
         rmtf = mtf / mtf[:, :1]
@@ -465,7 +468,7 @@ def ctp528_mtf_batch(profiles: torch.Tensor, regions=CTP528_REGIONS):
 
 
 def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=None, slices=None, roll_deg: float = 0.0,
-                 **kw):
+                 chunk_volumes: int | None = None, **kw):
     """Config #5's per-slice record for resident CatPhan volumes: one volume [S, H, W] or several
     [V, S, H, W] in ONE batch (the phantom ROI of every slice, then per volume the reference's axis fits, then the circle
     profile and relative MTF of every requested slice; volumes never mix: the +-3-slice window and the fits stay inside a
@@ -474,16 +477,57 @@ def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=
     ROI table, fit_zx / fit_zy [V, 2])."""
     x = volume if volume.dim() == 4 else volume[None]
     nv, spv = x.shape[0], x.shape[1]
-    flat = x.reshape(nv * spv, x.shape[2], x.shape[3])
-    roi = None
-    if fit_zx is None or fit_zy is None:
-        roi = phantom_roi_batch(flat, mm_per_pixel)
-        fit_zx, fit_zy = find_phantom_axes_batch(roi, nv)
-    prof, idx = ctp528_profiles_batch(flat, mm_per_pixel, fit_zx, fit_zy, slices=slices, roll_deg=roll_deg,
-                                      slices_per_volume=spv, **kw)
-    out = ctp528_mtf_batch(prof)
-    fzx, fzy = np.atleast_2d(np.asarray(fit_zx, dtype=np.float64)), np.atleast_2d(np.asarray(fit_zy, dtype=np.float64))
+    hh, ww = x.shape[2], x.shape[3]
+    # Volumes go through in CHUNKS so that the host's share of a chunk (the two polynomial fits per volume, the small
+    # per-profile arithmetic, queueing launches) overlaps the device's work on the next one: every chunk's localisation is
+    # queued first, each transfer is an event the host waits for only when it needs those numbers.
+    chunk = int(chunk_volumes) if chunk_volumes else max(1, -(-nv // 4))
+    bounds = [(a, min(a + chunk, nv)) for a in range(0, nv, chunk)]
+    given = fit_zx is not None and fit_zy is not None
+    sl = None if slices is None else np.asarray(slices, dtype=np.int64)
+    flats = [x[a:b].reshape((b - a) * spv, hh, ww) for a, b in bounds]
+    rois = [None if given else _phantom_roi_launch(f, mm_per_pixel) for f in flats]
+    gz = (np.atleast_2d(np.asarray(fit_zx, dtype=np.float64)), np.atleast_2d(np.asarray(fit_zy, dtype=np.float64))) if given else None
+    second, where = [], []
+    for (a, b), f, pend in zip(bounds, flats, rois):
+        if given:
+            roi, fzx, fzy = None, gz[0][a:b], gz[1][a:b]
+        else:
+            roi = _phantom_roi_finish(pend)
+            fzx, fzy = find_phantom_axes_batch(roi, b - a)
+        if sl is None:
+            local = None
+        else:
+            pos = np.flatnonzero((sl >= a * spv) & (sl < b * spv))
+            where.append(pos)
+            local = sl[pos] - a * spv
+        if local is not None and len(local) == 0:
+            second.append(None)
+            continue
+        prof, idx = ctp528_profiles_batch(f, mm_per_pixel, fzx, fzy, slices=local, roll_deg=roll_deg, slices_per_volume=spv, **kw)
+        second.append((roi, np.atleast_2d(fzx), np.atleast_2d(fzy), prof, idx + a * spv, _ctp528_mtf_launch(prof)))
+    parts = []
+    for item in second:
+        if item is None:
+            continue
+        roi, fzx, fzy, prof, idx, pend = item
+        parts.append((roi, fzx, fzy, prof, idx, _ctp528_mtf_finish(pend)))
+    if not parts:
+        raise ValueError("no slices selected")
+    idx = np.concatenate([p[4] for p in parts])
+    fzx, fzy = np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
+    if given:
+        fzx, fzy = gz
     v, z = idx // spv, idx % spv
+    out = {k: np.concatenate([p[5][k] for p in parts]) for k in ("rmtf", "nregions", "maxs", "mins")}
+    prof = parts[0][3] if len(parts) == 1 else torch.cat([p[3] for p in parts])
+    if sl is not None:                                     # back into the order the caller listed the slices in
+        back = np.argsort(np.concatenate(where), kind="stable")
+        if not np.array_equal(back, np.arange(len(back))):
+            idx, v, z = idx[back], v[back], z[back]
+            out = {k: a[back] for k, a in out.items()}
+            prof = prof[torch.from_numpy(back).to(prof.device)]
+    roi = None if given else np.concatenate([p[0] for p in parts])
     out.update(center=np.stack([fzx[v, 0] * z + fzx[v, 1], fzy[v, 0] * z + fzy[v, 1]], axis=1), profiles=prof, slices=idx,
                roi=roi, fit_zx=fzx if volume.dim() == 4 else fzx[0], fit_zy=fzy if volume.dim() == 4 else fzy[0])
     return out

@@ -26,6 +26,28 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class HostCopy:
+    """A device-to-host copy that does not stop the host: the tensor is copied into pinned memory on the current stream and
+    an event marks its arrival; ``numpy()`` waits for that event only.  Lets a caller queue the next batch's kernels while
+    an earlier batch's scalars are on their way (ct.ctp528_batch)."""
+
+    def __init__(self, t: torch.Tensor):
+        if t.device.type == "cuda":
+            self._host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._host.copy_(t, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record(torch.cuda.current_stream())
+        else:                                   # (CPU tensors only reach this under the test suite's emulated device)
+            self._host = t.clone()
+            self._event = None
+
+    def numpy(self) -> np.ndarray:
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+        return self._host.numpy()
+
+
 def _dt(t: torch.Tensor) -> int:
     try:
         return _DTYPES[t.dtype]
@@ -500,7 +522,8 @@ def peak_valley_regions(profiles: torch.Tensor, peak_kwargs: list, valley_kwargs
     (``pl_peak_valley_regions``; CTP528CP504.mtf, pylinac/ct.py:1511-1544).  ``peak_kwargs[k]`` / ``valley_kwargs[k]``: the
     keyword arguments of ``find_peaks_batch`` for region k (``max_number`` required; the valleys' search region is set per
     profile by the peaks).  -> (peak counts int32 [N, R], peak heights float64 [N, R, cap_p], valley counts int32 [N, R],
-    profile values at the valleys float64 [N, R, cap_v]); NaN beyond a count."""
+    profile values at the valleys float64 [N, R, cap_v], means float64 [N, R, 2] = np.mean of the peak heights (NaN unless
+    the region held exactly ``max_number`` peaks) and of the valley values (NaN when none)); NaN beyond a count."""
     x = profiles
     if x.dim() == 1:
         x = x.unsqueeze(0)
@@ -520,9 +543,11 @@ def peak_valley_regions(profiles: torch.Tensor, peak_kwargs: list, valley_kwargs
     ph = torch.empty((n, r, cap_p), dtype=torch.float64, device=dev)
     vc = torch.empty((n, r), dtype=torch.int32, device=dev)
     vv = torch.empty((n, r, cap_v), dtype=torch.float64, device=dev)
+    means = torch.empty((n, r, 2), dtype=torch.float64, device=dev)
     check(_lib.load().pl_peak_valley_regions(x.data_ptr(), n, length, x.stride(0), pk, vl, r, cap_p, cap_v, pc.data_ptr(),
-                                             ph.data_ptr(), vc.data_ptr(), vv.data_ptr(), _stream()), "pl_peak_valley_regions")
-    return pc, ph, vc, vv
+                                             ph.data_ptr(), vc.data_ptr(), vv.data_ptr(), means.data_ptr(), _stream()),
+          "pl_peak_valley_regions")
+    return pc, ph, vc, vv, means
 
 
 def fwxm_record(res: PeakBatch, out=None) -> torch.Tensor:
