@@ -369,6 +369,7 @@ def main():
             "value": round(value, 1),
             "unit": "images/s",
             "n_gpus": world,
+            "rccl_ranks": (dist.get_world_size() if dist is not None else 0),   # ranks of the initialised process group
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),

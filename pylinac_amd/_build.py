@@ -6,6 +6,7 @@ the GPU box by gpurun).
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -59,16 +60,21 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
-    BUILD.mkdir(parents=True, exist_ok=True)
+    extra = os.environ.get("PL_EXTRA_HIPCC_FLAGS", "").split()
+    # a variant build (e.g. -DPL_OTSU_VARIANT=1 compiles a stopwatch kernel that gives WRONG thresholds) must never leave
+    # objects a later plain build would reuse: its objects go to their own directory and the link is forced
+    build_dir = BUILD if not extra else BUILD.parent / ("hip_" + hashlib.sha256(" ".join(extra).encode()).hexdigest()[:12])
+    stamp = BUILD.parent / "last_flags"
+    flags_changed = (stamp.read_text() if stamp.exists() else "") != " ".join(extra)
+    build_dir.mkdir(parents=True, exist_ok=True)
     headers = list(CSRC.glob("*.h")) + [PKG.parent / "include" / "pylinac_hip.h", Path(__file__)]
     jobs = []
     objs = []
     for src in sources():
-        obj = BUILD / (src.stem + ".o")
+        obj = build_dir / (src.stem + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([cc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src.name, []), *os.environ.get("PL_EXTRA_HIPCC_FLAGS", "").split(),
-                         "-c", str(src), "-o", str(obj)])
+            jobs.append([cc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src.name, []), *extra, "-c", str(src), "-o", str(obj)])
 
     def run(cmd):
         if verbose:
@@ -81,8 +87,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
+    if force or jobs or flags_changed or _stale(LIB, objs):
         run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)])
+        stamp.write_text(" ".join(extra))
     return LIB
 
 

@@ -130,13 +130,19 @@ def ground(array, value: float = 0):
     s = _Staged(array)
     t = s.t
     if not t.dtype.is_floating_point and isinstance(value, (float, np.floating)):
-        t = ops.normalize(t, 1.0)                                        # exact conversion to float64
-        out = s.out(ops.ground(t, float(value)))
-        if isinstance(value, np.floating) and not isinstance(out, torch.Tensor):
-            want = np.result_type(np.asarray(array).dtype, value)        # e.g. uint8 + float32 scalar -> float32
-            if want != out.dtype:
-                out = out.astype(want)
-        return out
+        if isinstance(value, np.floating) and value.dtype.itemsize < 8:
+            # numpy subtracts in the INTEGER dtype (wrapping like `array - array.min()` does) and adds the narrow scalar in
+            # the promoted narrow float type: a float64 detour would round twice and never wrap.  The device grounds in the
+            # integer dtype (exact, wrapping); the one narrow add is numpy's own on the host.
+            grounded = s.out(ops.ground(t, 0))
+            if isinstance(grounded, torch.Tensor):
+                raise TypeError("ground(): a numpy floating scalar narrower than float64 is supported for numpy input only")
+            return grounded + value
+        # numpy grounds in the INTEGER dtype first (`array - array.min()`, wrapping where the range exceeds the dtype: int16
+        # frames spanning more than 32767 levels), THEN promotes for the float addition
+        g = ops.normalize(ops.ground(t, 0), 1.0)                         # exact conversion of the grounded integers to float64
+        return s.out(ops.ground(g, float(value), mn=torch.zeros(g.shape[0] if g.dim() == 3 else 1, dtype=torch.float64,
+                                                                device=g.device)))
     return s.out(ops.ground(t, value))
 
 

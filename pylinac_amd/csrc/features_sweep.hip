@@ -213,7 +213,9 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #endif
   for (int level = 0; level < prm.nlevels; ++level) {
-    if (level > 0 && !((level_used >> level) & 1ull)) continue;
+    // (with min_separation == 0 the reference's duplicate test -- distance STRICTLY below the separation -- never fires, and a
+    // repeated mask appends the same centroids again until max_number is reached: every level runs then)
+    if (level > 0 && prm.min_sep_px > 0 && !((level_used >> level) & 1ull)) continue;
     SW_STAMP(7);
     // ---- A. the row's foreground as a 160-bit mask (lane = row): four level-map bytes per LDS read, "byte > level" for all
     // four at once (bytes <= 64: adding 127 - level sets bit 7 exactly where the byte exceeds the level), the four flags

@@ -233,12 +233,38 @@ def _polyfit1_stack(xs: np.ndarray, ys: np.ndarray):
     numpy/lib/_polynomial_impl.py) with the solver's stacked form -- the gufunc behind ``np.linalg.lstsq`` solves every
     leading-dimension item on its own with a single right-hand side, exactly like a separate call.  -> [G, 2] or None when
     that gufunc is not there (the caller then loops)."""
-    try:
-        from numpy.linalg import _umath_linalg as _ul
-
-        gufunc = _ul.lstsq
-    except (ImportError, AttributeError):
+    if not _polyfit_stack_usable():
         return None
+    try:
+        return _polyfit1_stack_raw(xs, ys)
+    except Exception:                                        # a numpy whose private gufunc differs: the caller loops
+        return None
+
+
+_POLYFIT_STACK_OK: bool | None = None
+
+
+def _polyfit_stack_usable() -> bool:
+    """The stacked solver goes through a PRIVATE numpy gufunc with a hard-coded signature and mirrors np.polyfit's internal
+    steps; it is trusted only after it has reproduced np.polyfit bit for bit on a small sample in this process (once)."""
+    global _POLYFIT_STACK_OK
+    if _POLYFIT_STACK_OK is None:
+        try:
+            rng = np.random.default_rng(12345)
+            xs = np.sort(rng.uniform(0, 80, (6, 17)), axis=1)
+            ys = 255.5 + 0.01 * xs + rng.normal(0, 0.3, xs.shape)
+            got = _polyfit1_stack_raw(xs, ys)
+            want = np.stack([np.polyfit(x, y, deg=1, rcond=0.00001) for x, y in zip(xs, ys)])
+            _POLYFIT_STACK_OK = got is not None and np.array_equal(got, want)
+        except Exception:
+            _POLYFIT_STACK_OK = False
+    return _POLYFIT_STACK_OK
+
+
+def _polyfit1_stack_raw(xs: np.ndarray, ys: np.ndarray):
+    from numpy.linalg import _umath_linalg as _ul
+
+    gufunc = _ul.lstsq
     lhs = np.stack([xs, np.ones_like(xs)], axis=2).astype(np.float64)          # np.vander(x, 2)
     scale = np.sqrt((lhs * lhs).sum(axis=1))
     lhs = lhs / scale[:, None, :]
@@ -478,10 +504,13 @@ def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=
     x = volume if volume.dim() == 4 else volume[None]
     nv, spv = x.shape[0], x.shape[1]
     hh, ww = x.shape[2], x.shape[3]
-    # Volumes go through in CHUNKS so that the host's share of a chunk (the two polynomial fits per volume, the small
-    # per-profile arithmetic, queueing launches) overlaps the device's work on the next one: every chunk's localisation is
-    # queued first, each transfer is an event the host waits for only when it needs those numbers.
-    chunk = int(chunk_volumes) if chunk_volumes else max(1, -(-nv // 4))
+    # ``chunk_volumes`` volumes at a time (default: all at once): every chunk's localisation is queued before the host waits
+    # for the first ROI table, each transfer is an event the host waits for only when it needs those numbers, so the host's
+    # share of a chunk (two polynomial fits per volume, queueing launches) overlaps the device's work on the next.  Measured
+    # on 25 volumes (scripts/run_ct_pass.py): one chunk 4.88 ms, two 4.95 ms, four 6.2 ms -- the per-slice workgroups of
+    # pl_edge_regions fill the chip in whole rounds of 512 slices, which smaller launches waste; chunks are for bounding the
+    # 1 MiB-per-slice edge plane, not for speed.
+    chunk = int(chunk_volumes) if chunk_volumes else nv
     bounds = [(a, min(a + chunk, nv)) for a in range(0, nv, chunk)]
     given = fit_zx is not None and fit_zy is not None
     sl = None if slices is None else np.asarray(slices, dtype=np.int64)

@@ -35,13 +35,19 @@ def all_gather_records(local: torch.Tensor, n_total: int | None = None, pending:
         return local
     world = dist.get_world_size()
     k = local.shape[1:]
-    if n_total is not None and n_total % world == 0 and local.shape[0] == n_total // world:
+    if n_total is not None and n_total % world == 0:
+        # the branch is taken from rank-independent information only: every rank must issue the same collective
+        if local.shape[0] != n_total // world:
+            raise ValueError(f"all_gather_records: n_total = {n_total} divides evenly over {world} ranks, so every rank must hold "
+                             f"{n_total // world} records (shard_range's split); this rank holds {local.shape[0]}")
         out = torch.empty((n_total, *k), dtype=local.dtype, device=local.device)
         if pending is not None:
             pending.append(dist.all_gather_into_tensor(out, local.contiguous(), async_op=True))
         else:
             dist.all_gather_into_tensor(out, local.contiguous())
         return out
+    if pending is not None:
+        raise ValueError("all_gather_records: the asynchronous form needs even shards (n_total divisible by the world size)")
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local)

@@ -1077,6 +1077,23 @@ def check_scharr_gaussian(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.ui
             assert none is None and torch.equal(rm5, rm) and torch.equal(lo5, lo4) and torch.equal(hi5, hi4)
 
 
+def check_ground_promotion():
+    """array_utils.ground == ``array - array.min() + value`` in numpy's dtype AND numpy's arithmetic for every kind of value:
+    a narrow numpy float scalar is added in the narrow float type (no float64 detour), and the integer subtraction
+    wraps like numpy's before the promotion (an int16 frame spanning more than 32 767 levels)."""
+    from pylinac_amd import array_utils as au
+
+    arrays = (np.array([[5, 9, 7], [6, 5, 8]], dtype=np.uint16), np.array([[5, 9, 7], [6, 65535, 8]], dtype=np.uint16),
+              np.array([[-32768, 32767, 5]], dtype=np.int16), np.array([[3, 250]], dtype=np.uint8))
+    for a in arrays:
+        for value in (0, 3, 0.0, 1.0, 2.5, 0.1, np.float64(1.0), np.float64(0.1), np.float32(1.5), np.float32(0.1), np.float16(0.3),
+                      float("inf")):
+            with np.errstate(over="ignore"):
+                want = a - a.min() + value
+            got = au.ground(a, value)
+            assert got.dtype == want.dtype and np.array_equal(got, want), (a.dtype, value, got.dtype, want.dtype)
+
+
 def check_edge_otsu(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.uint16), (1, 100, 9, np.uint16), (2, 64, 200, np.int16)),
                     sigmas=(1, 2)):
     """pl_edge_otsu (one launch; float32 plane with exact recomputation of the undecided pixels, and float64 plane) ==

@@ -65,3 +65,34 @@ def test_all_gather_records_world2(n_total):
 def test_all_gather_is_identity_without_process_group():
     x = torch.arange(12, dtype=torch.float64).reshape(4, 3)
     assert pdist.all_gather_records(x) is x
+
+
+def test_bench_launch_path_two_ranks_dry_run():
+    """`bench.py --gpus 2` the way the driver launches it (python -m torch.distributed.run --nproc-per-node 2, env
+    rendezvous on 127.0.0.1), on the emulated device (tests/bench_dryrun.py): rank 0 prints ONE JSON line with n_gpus = 2,
+    rccl_ranks = 2, weak scaling (frames_total = 2 x frames per GPU) and a positive value.  Proves the plumbing of the
+    N > 1 bench, not its speed."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "bench_dryrun.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--frames", "2", "--height", "96", "--width", "128", "--no-cpu-baseline", "--no-configs",
+           "--no-parity"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["frames_per_gpu"] == 2 and line["config"]["frames_total"] == 4
+    for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert key in line

@@ -828,6 +828,12 @@ def test_emulated_scharr_gaussian_bit_identical(emulated):
     checks.check_scharr_gaussian(emulated)
 
 
+def test_emulated_ground_promotion(emulated):
+    import next_row_checks as checks
+
+    checks.check_ground_promotion()
+
+
 def test_emulated_edge_otsu_one_launch(emulated):
     import next_row_checks as checks
 
