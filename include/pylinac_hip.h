@@ -618,6 +618,28 @@ int pl_pf_windows_rows(const uint16_t* in, int64_t n, int h, int w, const double
 int pl_pf_positions(const int32_t* d_status, const double* d_fwxm, const double* d_offset, int64_t m,
                     double* d_pos, void* stream);
 
+/* The window kernel with the FWXM search fused in, for either orientation (pylinac/picketfence.py:746-749, 847-886,
+ * 1605-1628): per (frame, leaf, picket slot) d_rec float64 [n*nleaves*cap][3] = centre, left edge, right edge of the window
+ * profile's FWXM peak, each + max(approx_idx - spacing/2, 0) -- `position` for separate_leaves False (centre) and True (left,
+ * right); NaN where d_status != 0 (codes as pl_pf_windows) or the profile has no peak.  orientation 0 = UP_DOWN (d_leaf_lo /
+ * d_leaf_hi are window ROWS, pickets run along the columns), 1 = LEFT_RIGHT (they are window COLUMNS, pickets run along the
+ * rows; np.std over axis 0 and np.median over axis 1 of the window, i.e. the transposed computation with numpy's summation
+ * order for a non-contiguous axis).  fwxm_params: pl_find_peaks parameters of FWXMProfile.field_edge_idx (fwxm_height,
+ * max_number = 1).  d_prof (optional, float64 [n*nleaves*cap][lmax >= 128]) receives the window profiles.  max_rows: the
+ * widest leaf in pixels, 1..48 (10 mm leaves on the finest supported EPID at isocentre scale are 45 pixels). */
+int pl_pf_measure(const uint16_t* in, int64_t n, int h, int w, int orientation, const double* d_sub, const double* d_div,
+                  const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap, const double* d_spacing,
+                  const int32_t* d_leaf_lo, const int32_t* d_leaf_hi, int nleaves, int max_rows, double height_threshold,
+                  double edge_threshold, const pl_peak_params* fwxm_params, double* d_rec, int32_t* d_status, double* d_prof,
+                  int lmax, void* stream);
+/* np.mean(q, 1) -> d_out float64 [n][h] (the leaf profile of LEFT_RIGHT pickets, picketfence.py:749) in numpy's PAIRWISE
+ * summation order for the contiguous axis.  The summation tree of a row of w values is laid out by the caller
+ * (ops.pairwise_plan): d_leaf_start / d_leaf_len int32 [nleaves] = the leaf blocks (<= 128 values each), d_program int32
+ * [2 * nleaves - 1] = postfix order of the recursion (k >= 0: leaf k's sum, -1: add the two sums on top). */
+int pl_scaled_rowmean(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                      const int32_t* d_leaf_start, const int32_t* d_leaf_len, int nleaves, const int32_t* d_program, int nprog,
+                      double* d_out, void* stream);
+
 /* FWXMProfile.field_edge_idx/center_idx/field_width_px (pylinac/core/profile.py:602-611, 322-344)
  * from a pl_find_peaks result obtained with max_number = 1:
  * d_out float64 [n][8] = n_peaks, peak_idx, height, prominence, left, right, centre, width

@@ -848,11 +848,12 @@ def pf_leaves_in_view(shape, dpmm, leaves, centers, widths, analysis_width=0.4):
 
 def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=None, leaf_analysis_width_ratio=0.4,
                picket_spacing=None, height_threshold=0.5, edge_threshold=1.5, peak_sort="peak_heights",
-               required_prominence=0.2, fwxm=50):
-    """The per-image measurement loop of PicketFence.analyze for UP_DOWN pickets
-    (picketfence.py:745-803): returns dict(peak_idxs, peak_vals, spacing, leaves [(num, center, width)],
-    position [n_leaves, P] float64 (NaN where the window failed _is_mlc_peak_in_window))."""
-    leaf_prof = np.mean(image, 0)                                        # :747
+               required_prominence=0.2, fwxm=50, orientation="UP_DOWN", separate_leaves=False):
+    """The per-image measurement loop of PicketFence.analyze (picketfence.py:745-803) for either orientation: returns
+    dict(peak_idxs, peak_vals, spacing, leaves [(num, center, width)], position [n_leaves, P] float64 (NaN where the window
+    failed _is_mlc_peak_in_window)[, left, right: the two leaf-end positions of separate_leaves, :1616-1623])."""
+    ud = orientation == "UP_DOWN"
+    leaf_prof = np.mean(image, 0) if ud else np.mean(image, 1)           # :746-749
     leaf_prof = normalize(leaf_prof)                                     # MultiProfile.normalize :752
     peak_idxs, peak_vals = multiprofile_find_fwxm_peaks(                 # :753-759
         leaf_prof, min_distance=0.02, threshold=height_threshold, max_number=num_pickets,
@@ -862,27 +863,36 @@ def pf_measure(image: np.ndarray, dpmm: float, mlc="MILLENNIUM", num_pickets=Non
     if picket_spacing is None:
         picket_spacing = np.median(np.diff(np.sort(peak_idxs)))          # :766-767
     leaves, centers, widths = mlc_arrangement(MLC_ARRANGEMENTS[mlc])
-    in_view = pf_leaves_in_view(image.shape, dpmm, leaves, centers, widths, leaf_analysis_width_ratio)
+    across = image.shape[0] if ud else image.shape[1]                     # the axis the leaves are stacked along
+    pixel_range = across / 2                                             # _leaves_in_view :888-912
+    pixel_range -= max(widths[0] * leaf_analysis_width_ratio, widths[-1] * leaf_analysis_width_ratio) * dpmm
+    in_view = [(n, c, w) for n, c, w in zip(leaves, centers, widths) if abs(c) < pixel_range / dpmm]
     pos = np.full((len(in_view), len(peak_idxs)), np.nan)
+    left_pos, right_pos = pos.copy(), pos.copy()
     for li, (leaf_num, center, width) in enumerate(in_view):
         leaf_width_px = width * dpmm                                     # _get_mlc_window :859-886
-        leaf_center_px = center * dpmm + image.shape[0] / 2
-        top = max(int(leaf_center_px - leaf_width_px / 2), 0)
-        bottom = min(int(leaf_center_px + leaf_width_px / 2), image.shape[0])
+        leaf_center_px = center * dpmm + across / 2
+        lo = max(int(leaf_center_px - leaf_width_px / 2), 0)
+        hi = min(int(leaf_center_px + leaf_width_px / 2), across)
         for pi, (approx_idx, peak_val) in enumerate(zip(peak_idxs, peak_vals)):
-            left = max(int(approx_idx - picket_spacing / 2), 0)
-            right = min(int(approx_idx + picket_spacing / 2), image.shape[1])
-            window = image[top:bottom, left:right]
-            std = np.std(window, axis=1)                                 # _is_mlc_peak_in_window :847-857
+            t0 = max(int(approx_idx - picket_spacing / 2), 0)
+            t1 = min(int(approx_idx + picket_spacing / 2), image.shape[1] if ud else image.shape[0])
+            window = image[lo:hi, t0:t1] if ud else image[t0:t1, lo:hi]
+            std = np.std(window, axis=1 if ud else 0)                    # _is_mlc_peak_in_window :847-857
             if not (np.max(window) > height_threshold * peak_val and max(std) < edge_threshold * np.median(std)):
                 continue
-            pix_vals = np.median(window, axis=0)                         # MLCValue.get_peak_positions :1605-1628
+            pix_vals = np.median(window, axis=0 if ud else 1)            # MLCValue.get_peak_positions :1605-1628
             vals = ground(pix_vals)                                      # FWXMProfilePhysical(ground=True,
             vals = normalize(vals)                                       #   normalization=MAX)
-            _, _, centre, _ = fwxm_edges(vals, fwxm)
-            pos[li, pi] = centre + max(approx_idx - picket_spacing / 2, 0)
-    return dict(peak_idxs=np.asarray(peak_idxs), peak_vals=np.asarray(peak_vals), spacing=float(picket_spacing),
-                leaves=in_view, position=pos)
+            le, re, centre, _ = fwxm_edges(vals, fwxm)
+            off = max(approx_idx - picket_spacing / 2, 0)
+            pos[li, pi] = centre + off
+            left_pos[li, pi], right_pos[li, pi] = le + off, re + off     # separate_leaves :1616-1623
+    out = dict(peak_idxs=np.asarray(peak_idxs), peak_vals=np.asarray(peak_vals), spacing=float(picket_spacing),
+               leaves=in_view, position=pos)
+    if separate_leaves:
+        out.update(left=left_pos, right=right_pos)
+    return out
 
 
 # --------------------------------------------------------------------------------------

@@ -6,14 +6,6 @@
 
 namespace {
 
-// LDS written by some lanes of a wave, read by others: the hardware runs a wave's LDS operations in order, the fences keep the
-// compiler from reordering them (wavefront scope: no wait instruction is generated)
-__device__ __forceinline__ void es_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __device__ __forceinline__ int es_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // skimage's Scharr magnitude sqrt(s0^2 + s1^2) / sqrt(2) from the integer responses S0 = 16 s0, S1 = 16 s1 (|S| <= 16 * 65535):
@@ -71,17 +63,17 @@ __device__ double es_exact_wave(const T* __restrict__ src, int h, int w, int r, 
     }
     scratch[g] = es_edge(S0, S1);
   }
-  es_wave_sync();
+  pl_wave_sync();
   if (lane < win) {
     double acc = scratch[rad * win + lane] * wts[rad];
     for (int k = rad; k >= 1; --k) acc = acc + (scratch[(rad - k) * win + lane] + scratch[(rad + k) * win + lane]) * wts[rad - k];
     scratch[win * win + lane] = acc;
   }
-  es_wave_sync();
+  pl_wave_sync();
   const double* v = scratch + win * win;
   double acc = v[rad] * wts[rad];
   for (int k = rad; k >= 1; --k) acc = acc + (v[rad - k] + v[rad + k]) * wts[rad - k];
-  es_wave_sync();                       // the scratch may be reused at once
+  pl_wave_sync();                       // the scratch may be reused at once
   return acc;
 }
 

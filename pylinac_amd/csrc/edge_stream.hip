@@ -143,11 +143,11 @@ edge_stream_kernel(const T* __restrict__ in, int h, int w, int strips, int segs,
         for (int k = RAD; k >= 1; --k)
           a0 = a0 + (E[(i + 2 * WIN - RAD - k) % WIN] + E[(i + WIN - RAD + k) % WIN]) * tw[RAD - k];
         vb[lane + RAD] = a0;
-        es_wave_sync();
+        pl_wave_sync();
         double a1 = a0 * tw[RAD];
 #pragma unroll
         for (int k = RAD; k >= 1; --k) a1 = a1 + (vb[lane + RAD - k] + vb[lane + RAD + k]) * tw[RAD - k];
-        es_wave_sync();                                    // (orders the next step's write behind these reads)
+        pl_wave_sync();                                    // (orders the next step's write behind these reads)
         bool sel = out_lane;
         if (has_spans) {
           sel = sel & (vc >= srow[0]) & (vc < srow[1]);

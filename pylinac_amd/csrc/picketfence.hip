@@ -18,6 +18,7 @@
 //   pl_pf_positions     centre + max(approx_idx - spacing/2, 0)    picketfence.py:1624-1627
 // One wave per window; the window's integer pixels are staged in LDS once.
 #include "pl_common.h"
+#include "peaks_device.h"
 
 namespace {
 
@@ -79,6 +80,65 @@ scaled_colmean4_kernel(const unsigned short* __restrict__ in, int h, int w, int6
   o[1] = a1 / (double)h;
   o[2] = a2 / (double)h;
   o[3] = a3 / (double)h;
+}
+
+// np.mean(image, 1) of the normalised frame (LEFT_RIGHT pickets, picketfence.py:749): along the CONTIGUOUS axis numpy sums
+// pairwise (numpy/_core/src/umath/loops_utils.h.src): a row of more than 128 values is halved recursively (first half rounded
+// down to a multiple of 8) into leaf blocks of at most 128, each summed with eight running partial sums combined as a tree,
+// and the leaves are added up along the recursion tree.  The tree depends on the row length only, so the HOST lays it out
+// once (leaf starts / lengths and a postfix program: k >= 0 pushes leaf k's sum, -1 adds the two on top); a wave stages its
+// row in LDS, eight lanes sum each leaf (lane j = partial sum j), one lane runs the program.
+constexpr int kRmMaxLeaves = 256;
+
+__global__ void __launch_bounds__(kThreads)
+scaled_rowmean_kernel(const unsigned short* __restrict__ in, int h, int w, int64_t total_rows, const double* __restrict__ sub,
+                      const double* __restrict__ div, const int32_t* __restrict__ leaf_start, const int32_t* __restrict__ leaf_len,
+                      int nleaves, const int32_t* __restrict__ program, int nprog, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rm_lds[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * (kThreads / PL_WAVE) + wv;
+  if (row >= total_rows) return;
+  const size_t wave_bytes = (((size_t)w * 2 + 15) & ~(size_t)15) + (size_t)(kRmMaxLeaves + 16) * sizeof(double);
+  unsigned short* srow = reinterpret_cast<unsigned short*>(rm_lds + (size_t)wv * wave_bytes);
+  double* ssum = reinterpret_cast<double*>(rm_lds + (size_t)wv * wave_bytes + (((size_t)w * 2 + 15) & ~(size_t)15));
+  const int64_t frame = row / h;
+  const unsigned short* p = in + row * (int64_t)w;
+  for (int c = lane; c < w; c += PL_WAVE) srow[c] = p[c];
+  pl_wave_sync();
+  const PlQuot k = pl_quot_make(sub[frame], div[frame]);
+  auto at = [&](int c) { return pl_quot(k, (double)srow[c]); };
+  const int j = lane & 7, g = lane >> 3;
+  for (int k0 = 0; k0 < nleaves; k0 += 8) {                  // wave-uniform trip count
+    const int kk = k0 + g;
+    const bool act = kk < nleaves;
+    const int s0 = act ? leaf_start[kk] : 0, len = act ? leaf_len[kk] : 8;
+    double res;
+    if (len < 8) {                                           // only rows shorter than eight pixels
+      res = 0.0;
+      if (j == 0) for (int i = 0; i < len; ++i) res = res + at(s0 + i);
+    } else {
+      const int nmain = len - (len % 8);
+      double acc = at(s0 + j);
+      for (int i = 8; i < nmain; i += 8) acc = acc + at(s0 + i + j);
+      acc = acc + __shfl_xor(acc, 1, 64);
+      acc = acc + __shfl_xor(acc, 2, 64);
+      acc = acc + __shfl_xor(acc, 4, 64);
+      res = acc;
+      if (j == 0) for (int i = nmain; i < len; ++i) res = res + at(s0 + i);
+    }
+    if (act && j == 0) ssum[kk] = res;
+  }
+  pl_wave_sync();
+  if (lane == 0) {
+    double* stack = ssum + kRmMaxLeaves;                     // 16 entries: the recursion is log2(w / 64) + 1 deep
+    int sp = 0;
+    for (int i = 0; i < nprog; ++i) {
+      const int op = program[i];
+      if (op >= 0) stack[sp++] = ssum[op];
+      else { --sp; stack[sp - 1] = stack[sp - 1] + stack[sp]; }
+    }
+    out[row] = stack[0] / (double)w;
+  }
 }
 
 __global__ void pf_pickets_kernel(const int32_t* __restrict__ count, const double* __restrict__ props, int cap,
@@ -172,15 +232,25 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
                   const double* __restrict__ spacing, const int32_t* __restrict__ leaf_top,
                   const int32_t* __restrict__ leaf_bottom, int nleaves, double height_threshold,
                   double edge_threshold, int lmax, double* __restrict__ prof_out, int32_t* __restrict__ len_out,
-                  double* __restrict__ offset_out, int32_t* __restrict__ status_out, int64_t total_windows, int rows_cap) {
+                  double* __restrict__ offset_out, int32_t* __restrict__ status_out, int64_t total_windows, int rows_cap,
+                  int lr, int wave_bytes, pl_peak_params fw, double* __restrict__ rec_out) {
   // dynamic LDS: per wave `rows_cap` x 128 window pixels, then `rows_cap` row deviations.  rows_cap is the tallest leaf window
   // the CALLER will ask for (the leaf geometry is host knowledge): the fixed 48-row capacity of rounds 1-3 kept three
   // workgroups on a CU where a 26-row bank leaves room for five -- the kernel is one long dependent chain per wave and
   // lives on the number of waves that hide it
   extern __shared__ __attribute__((aligned(16))) unsigned char pf_lds[];
-  double* const s_std_all = reinterpret_cast<double*>(pf_lds);
-  unsigned short* const s_win_all = reinterpret_cast<unsigned short*>(pf_lds + (size_t)(kThreads / PL_WAVE) * rows_cap * sizeof(double));
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // per wave: [rows_cap row deviations][rows_cap x 128 window pixels]; once the column medians are in registers the same
+  // bytes hold the FWXM search (rec_out): [128 profile samples][find_peaks tables]
+  unsigned char* const wave_lds = pf_lds + (size_t)wv * wave_bytes;
+  double* const s_std_w_ = reinterpret_cast<double*>(wave_lds);
+  unsigned short* const sw_ = reinterpret_cast<unsigned short*>(wave_lds + (size_t)rows_cap * sizeof(double));
+  __shared__ Scan pk_scan[kThreads / PL_WAVE];
+  __shared__ double pk_red[kThreads / PL_WAVE][2 * (kThreads / PL_WAVE)];
+  __shared__ int pk_cnt[kThreads / PL_WAVE];
+  __shared__ int32_t o_cnt[kThreads / PL_WAVE], o_st[kThreads / PL_WAVE], o_idx[kThreads / PL_WAVE], o_lb[kThreads / PL_WAVE],
+      o_rb[kThreads / PL_WAVE];
+  __shared__ double o_p[kThreads / PL_WAVE][6];
   // window index in 32 bits (the launcher refuses more: the profiles of 2^31 windows would be 2 TB), wave-uniform: scalar
   const unsigned win = blockIdx.x * (unsigned)(kThreads / PL_WAVE) + (unsigned)wv;
   if ((int64_t)win >= total_windows) return;
@@ -188,9 +258,18 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   const int li = (int)((win / (unsigned)cap) % (unsigned)nleaves);
   const int64_t frame = win / ((unsigned)cap * (unsigned)nleaves);
   int status = 0;   // 0 valid, 1 no such picket, 2 failed _is_mlc_peak_in_window, 3 window too large / empty
-  double* pout = prof_out + (size_t)win * lmax;
+  double* pout = prof_out ? prof_out + (size_t)win * lmax : nullptr;
+  const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+  auto leave = [&](int code, double off_) {                // no measurement for this window
+    if (lane == 0) {
+      status_out[win] = code;
+      if (len_out) len_out[win] = 0;
+      if (offset_out) offset_out[win] = off_;
+      if (rec_out) { rec_out[(size_t)win * 3] = qnan; rec_out[(size_t)win * 3 + 1] = qnan; rec_out[(size_t)win * 3 + 2] = qnan; }
+    }
+  };
   if (pi >= pk_count[frame]) {
-    if (lane == 0) { status_out[win] = 1; len_out[win] = 0; offset_out[win] = 0.0; }
+    leave(1, 0.0);
     return;
   }
   const double approx = (double)pk_idx[frame * cap + pi];
@@ -199,18 +278,19 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   int left = (int)(approx - sp / 2);            // python int(): truncation toward zero
   if (left < 0) left = 0;
   int right = (int)(approx + sp / 2);
-  if (right > w) right = w;
+  const int travel_len = lr ? h : w;               // LEFT_RIGHT: the pickets run along the rows (picketfence.py:877-884)
+  if (right > travel_len) right = travel_len;
   left = __builtin_amdgcn_readfirstlane(left);     // the window geometry is the wave's: keep it in scalar registers
   right = __builtin_amdgcn_readfirstlane(right);
   const int nrows = bottom - top, ncols = right - left;
   const double off = (approx - sp / 2 > 0.0) ? (approx - sp / 2) : 0.0;   // max(approx_idx - spacing/2, 0)
   if (nrows <= 0 || ncols <= 2 || nrows > rows_cap || ncols > kMaxCols || !(sp == sp)) {
-    if (lane == 0) { status_out[win] = 3; len_out[win] = 0; offset_out[win] = off; }
+    leave(3, off);
     return;
   }
   const unsigned short* f = in + frame * (size_t)h * w;
-  unsigned short* sw = s_win_all + (size_t)wv * rows_cap * kMaxCols;
-  double* const s_std_w = s_std_all + (size_t)wv * rows_cap;
+  unsigned short* sw = sw_;
+  double* const s_std_w = s_std_w_;
   // the window into LDS, its maximum on the way (element e = lane, lane + 64, ..: row / column advance by carry, no division).
   // EIGHT loads are issued before the first of them is consumed: one load per trip made the wave pay the full memory
   // latency for every 64 pixels (eight dependent round trips for a 12 x 38 window)
@@ -225,7 +305,10 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const bool in_win = e0 + k * PL_WAVE < total;
-        v[k] = in_win ? f[(size_t)(top + rr) * w + left + cc] : (unsigned short)0;
+        // window element (rr, cc) = (position across the leaf, position along the leaf's travel): UP_DOWN reads image row
+        // top + rr, LEFT_RIGHT image column top + rr -- the LDS copy is the TRANSPOSED window then, and everything below
+        // (max, column median = np.median(window, axis=1), the FWXM profile) is the UP_DOWN code
+        v[k] = in_win ? (lr ? f[(size_t)(left + cc) * w + top + rr] : f[(size_t)(top + rr) * w + left + cc]) : (unsigned short)0;
         rr += dr;
         cc += dc;
         if (cc >= ncols) { cc -= ncols; ++rr; }
@@ -255,6 +338,18 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   // share a row: lane j of the group owns chain r[j], the tree is three xor-shuffles (float addition commutes, so both
   // partners hold the same sum), one lane adds the tail.  Same operations in the same order as one lane doing it all,
   // at an eighth of the float64 divisions per lane (round 1: one lane per row, 12 of 64 lanes busy).
+  if (lr) {
+    // LEFT_RIGHT: np.std(window, axis=0) reduces over the window's ROWS (the travel direction), which numpy adds up one row
+    // after the other -- no pairwise blocks on a non-contiguous reduction axis: a plain left-to-right sum per leaf pixel
+    for (int a = lane; a < nrows; a += PL_WAVE) {
+      double sum = 0.0;
+      for (int b = 0; b < ncols; ++b) sum = sum + q(a, b);
+      const double mean = sum / (double)ncols;
+      double ss = 0.0;
+      for (int b = 0; b < ncols; ++b) { const double x = q(a, b) - mean; ss = ss + x * x; }
+      s_std_w[a] = sqrt(ss / (double)ncols);
+    }
+  } else
   {
     const int j = lane & 7, gr = lane >> 3;                 // chain index, row inside the pass of 8 rows
     const int nmain = ncols - (ncols % 8);
@@ -348,9 +443,40 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   if (has0) { const double g = pvr[0] - mn; mx = g > mx ? g : mx; }
   if (has1) { const double g = pvr[1] - mn; mx = g > mx ? g : mx; }
   mx = pl_wave_reduce(mx, [](double a, double b) { return a > b ? a : b; });
-  if (has0) pout[lane] = (pvr[0] - mn) / mx;
-  if (has1) pout[lane + PL_WAVE] = (pvr[1] - mn) / mx;
-  if (lane == 0) { status_out[win] = status; len_out[win] = ncols; offset_out[win] = off; }
+  const double p0 = (pvr[0] - mn) / mx, p1 = (pvr[1] - mn) / mx;
+  if (prof_out) {
+    if (has0) pout[lane] = p0;
+    if (has1) pout[lane + PL_WAVE] = p1;
+  }
+  if (lane == 0) {
+    status_out[win] = status;
+    if (len_out) len_out[win] = ncols;
+    if (offset_out) offset_out[win] = off;
+  }
+  if (!rec_out) return;
+  // ---- the FWXM search on the profile just built (FWXMProfilePhysical.field_edge_idx / center_idx, profile.py:602-611,
+  // 322-327: find_peaks(fwxm_height, max_number = 1), left_ips / right_ips of the most prominent peak) -- rounds 1-3 wrote the
+  // profile to a [windows][128] float64 table (0.5 GB per 512 frames) for a second launch to read
+  double c_pos = qnan, l_pos = qnan, r_pos = qnan;
+  if (status == 0) {                                       // wave-uniform
+    pl_wave_sync();                                        // every lane is done with the window pixels: the bytes change hands
+    double* s_prof = reinterpret_cast<double*>(wave_lds);
+    if (has0) s_prof[lane] = p0;
+    if (has1) s_prof[lane + PL_WAVE] = p1;
+    pl_wave_sync();
+    constexpr int kMaxc = kMaxCols / 2 + 1;
+    const PeakLds L{wave_lds + kMaxCols * sizeof(double), &pk_scan[wv], pk_red[wv], &pk_cnt[wv]};
+    find_peaks_profile<true, PL_WAVE>(s_prof, ncols, fw.region_lo, fw.region_hi, fw, 1, kMaxc, L, lane, &o_cnt[wv], &o_idx[wv],
+                                      &o_lb[wv], &o_rb[wv], o_p[wv], &o_st[wv]);
+    pl_wave_sync();
+    if (o_cnt[wv] > 0) {
+      const double l = o_p[wv][4], r = o_p[wv][5];
+      c_pos = (fabs(r - l) / 2 + l) + off;                 // center_idx + max(approx_idx - spacing / 2, 0)
+      l_pos = l + off;
+      r_pos = r + off;
+    }
+  }
+  if (lane == 0) { rec_out[(size_t)win * 3] = c_pos; rec_out[(size_t)win * 3 + 1] = l_pos; rec_out[(size_t)win * 3 + 2] = r_pos; }
 }
 
 __global__ void pf_positions_kernel(const int32_t* __restrict__ status, const double* __restrict__ fwxm /*[M][8]*/,
@@ -406,6 +532,17 @@ extern "C" int pl_pf_windows(const uint16_t* in, int64_t n, int h, int w, const 
                             nleaves, kMaxRows, height_threshold, edge_threshold, lmax, d_prof, d_len, d_offset, d_status, stream);
 }
 
+// per-wave LDS of pf_windows_kernel: the window block, or (fused FWXM search) the profile + find_peaks tables, whichever is larger
+static size_t pf_wave_bytes(int rows_cap, bool fused) {
+  size_t wb = (size_t)rows_cap * (sizeof(double) + (size_t)kMaxCols * sizeof(unsigned short));
+  if (fused) {
+    constexpr int maxc = kMaxCols / 2 + 1;
+    size_t sb = (size_t)kMaxCols * sizeof(double) + (((size_t)maxc * (8 + 8 + 4 * 4) + 8 + (size_t)kMaxCols * 8 + 15) & ~(size_t)15);
+    if (sb > wb) wb = sb;
+  }
+  return (wb + 15) & ~(size_t)15;
+}
+
 // max_rows: the tallest leaf window (bottom - top) of the call, 1 .. 48 -- windows taller than that get status 3
 extern "C" int pl_pf_windows_rows(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
                                   const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap,
@@ -421,11 +558,37 @@ extern "C" int pl_pf_windows_rows(const uint16_t* in, int64_t n, int h, int w, c
   const int64_t blocks = pl_cdiv(total, kThreads / PL_WAVE);
   PL_REQUIRE(total <= 0x7fffffffLL, "batch too large");
   const int rows_cap = (max_rows + 1) & ~1;          // even: the window planes stay 4-byte aligned behind the row deviations
-  const size_t lds = (size_t)(kThreads / PL_WAVE) * rows_cap * (sizeof(double) + (size_t)kMaxCols * sizeof(unsigned short));
-  hipLaunchKernelGGL(pf_windows_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, in, h, w,
+  const size_t wb = pf_wave_bytes(rows_cap, false);
+  hipLaunchKernelGGL(pf_windows_kernel, dim3((unsigned)blocks), dim3(kThreads), wb * (kThreads / PL_WAVE), (hipStream_t)stream, in, h, w,
                      d_sub, d_div, d_pk_count, d_pk_idx, d_pk_val, cap, d_spacing, d_leaf_top, d_leaf_bottom, nleaves,
-                     height_threshold, edge_threshold, lmax, d_prof, d_len, d_offset, d_status, total, rows_cap);
+                     height_threshold, edge_threshold, lmax, d_prof, d_len, d_offset, d_status, total, rows_cap, 0, (int)wb,
+                     pl_peak_params{}, nullptr);
   return pl_check_launch("pl_pf_windows");
+}
+
+/* windows + FWXM positions in one launch, either orientation: see pylinac_hip.h */
+extern "C" int pl_pf_measure(const uint16_t* in, int64_t n, int h, int w, int orientation, const double* d_sub, const double* d_div,
+                             const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap,
+                             const double* d_spacing, const int32_t* d_leaf_lo, const int32_t* d_leaf_hi, int nleaves,
+                             int max_rows, double height_threshold, double edge_threshold, const pl_peak_params* fwxm_params,
+                             double* d_rec, int32_t* d_status, double* d_prof, int lmax, void* stream) {
+  PL_REQUIRE(max_rows >= 1 && max_rows <= kMaxRows, "max_rows 1..48");
+  PL_REQUIRE(orientation == 0 || orientation == 1, "orientation 0 (UP_DOWN) or 1 (LEFT_RIGHT)");
+  PL_REQUIRE(in && d_sub && d_div && d_pk_count && d_pk_idx && d_pk_val && d_spacing && d_leaf_lo && d_leaf_hi && fwxm_params &&
+                 d_rec && d_status, "null pointer");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0 && cap > 0 && nleaves > 0 && (!d_prof || lmax >= kMaxCols), "bad shape (lmax >= 128)");
+  PL_REQUIRE(fwxm_params->distance >= 1, "distance must be >= 1");
+  if (n == 0) return PL_OK;
+  const int64_t total = n * (int64_t)nleaves * cap;
+  const int64_t blocks = pl_cdiv(total, kThreads / PL_WAVE);
+  PL_REQUIRE(total <= 0x7fffffffLL, "batch too large");
+  const int rows_cap = (max_rows + 1) & ~1;
+  const size_t wb = pf_wave_bytes(rows_cap, true);
+  hipLaunchKernelGGL(pf_windows_kernel, dim3((unsigned)blocks), dim3(kThreads), wb * (kThreads / PL_WAVE), (hipStream_t)stream, in, h, w,
+                     d_sub, d_div, d_pk_count, d_pk_idx, d_pk_val, cap, d_spacing, d_leaf_lo, d_leaf_hi, nleaves,
+                     height_threshold, edge_threshold, lmax, d_prof, (int32_t*)nullptr, (double*)nullptr, d_status, total, rows_cap,
+                     orientation, (int)wb, *fwxm_params, d_rec);
+  return pl_check_launch("pl_pf_measure");
 }
 
 extern "C" int pl_pf_positions(const int32_t* d_status, const double* d_fwxm, const double* d_offset, int64_t m,
@@ -436,4 +599,28 @@ extern "C" int pl_pf_positions(const int32_t* d_status, const double* d_fwxm, co
   hipLaunchKernelGGL(pf_positions_kernel, dim3((unsigned)pl_cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, d_status,
                      d_fwxm, d_offset, m, d_pos);
   return pl_check_launch("pl_pf_positions");
+}
+
+/* np.mean(q, 1) -> d_out float64 [n][h] in numpy's pairwise order; the summation tree (leaves, postfix program) of a row of
+ * w values is laid out by the caller: see scaled_rowmean_kernel */
+extern "C" int pl_scaled_rowmean(const uint16_t* in, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                                 const int32_t* d_leaf_start, const int32_t* d_leaf_len, int nleaves, const int32_t* d_program,
+                                 int nprog, double* d_out, void* stream) {
+  PL_REQUIRE(in && d_sub && d_div && d_leaf_start && d_leaf_len && d_program && d_out, "null pointer");
+  PL_REQUIRE(n >= 0 && h > 0 && w > 0 && w <= 16384, "bad shape (rows of at most 16384 pixels)");
+  PL_REQUIRE(nleaves >= 1 && nleaves <= kRmMaxLeaves && nprog == 2 * nleaves - 1, "a summation tree of 1..256 leaves");
+  if (n == 0) return PL_OK;
+  const int64_t rows = n * (int64_t)h;
+  PL_REQUIRE(pl_cdiv(rows, kThreads / PL_WAVE) <= 0x7fffffffLL, "batch too large");
+  const size_t wave_bytes = (((size_t)w * 2 + 15) & ~(size_t)15) + (size_t)(kRmMaxLeaves + 16) * sizeof(double);
+  const size_t lds = wave_bytes * (kThreads / PL_WAVE);
+  static std::atomic<size_t> attr{0};
+  if (lds > 64 * 1024 && lds > attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)scaled_rowmean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { pl_set_error("pl_scaled_rowmean: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+    attr = lds;
+  }
+  hipLaunchKernelGGL(scaled_rowmean_kernel, dim3((unsigned)pl_cdiv(rows, kThreads / PL_WAVE)), dim3(kThreads), lds, (hipStream_t)stream,
+                     in, h, w, rows, d_sub, d_div, d_leaf_start, d_leaf_len, nleaves, d_program, nprog, d_out);
+  return pl_check_launch("pl_scaled_rowmean");
 }

@@ -181,6 +181,14 @@ __device__ __forceinline__ const PL_CONSTANT_AS T* pl_constant_ptr(const T* p) {
   return (const PL_CONSTANT_AS T*)p;
 }
 
+// LDS written by some lanes of a wave and read by others: the hardware runs a wave's LDS operations in order, the fences keep
+// the COMPILER from reordering them (wavefront scope: no wait instruction is generated)
+__device__ __forceinline__ void pl_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // the float64 of lane `l` (wave-uniform) in every lane, on the scalar path (two v_readlane_b32; __shfl would go through the
 // LDS crossbar)
 __device__ __forceinline__ double pl_readlane_f64(double v, int l) {

@@ -298,7 +298,7 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
     }
     if constexpr (sizeof(T) == 4) {
       if (any_und) {                                       // a handful of pixels per thousand slices
-        es_wave_sync();
+        pl_wave_sync();
 #pragma unroll 1
         for (int u = 0; u < U && q0 + u < nwords; ++u) {
           u64 todo = und[u];
@@ -315,7 +315,7 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
           }
           if (lane == 0 && add) L.plane[q] |= add;
         }
-        es_wave_sync();
+        pl_wave_sync();
       }
     }
   }

@@ -1077,6 +1077,62 @@ def check_scharr_gaussian(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.ui
             assert none is None and torch.equal(rm5, rm) and torch.equal(lo5, lo4) and torch.equal(hi5, hi4)
 
 
+PF_ORIENT_CASES = (("lr", "lr", "LEFT_RIGHT", False), ("lr_sep", "lr", "LEFT_RIGHT", True), ("ud_sep", "ud_sep", "UP_DOWN", True))
+
+
+def check_pf_orientation_oracle(g):
+    """oracle.pf_measure(orientation=, separate_leaves=) against the reference's OWN PicketFence.analyze() on a LEFT_RIGHT
+    frame, the same frame with separate_leaves, and an UP_DOWN frame with separate_leaves
+    (tests/golden/make_pf_orient_golden.py): spacing, picket indices and every position the reference kept, bit for bit."""
+    from oracle import pylinac_oracle as o
+
+    for name, frame_key, orient, sep in PF_ORIENT_CASES:
+        raw, dpmm = g[f"{frame_key}.cropped"], float(g[f"{frame_key}.dpmm"])
+        r = o.pf_measure(o.normalize(o.ground(raw)), dpmm, orientation=orient, separate_leaves=sep)
+        assert r["spacing"] == float(g[f"{name}.spacing"])
+        idx = {n: i for i, (n, c, w) in enumerate(r["leaves"])}
+        meas = g[f"{name}.meas"]
+        assert len(meas) > 400
+        for row in meas:
+            leaf, picket, approx = int(row[0]), int(row[1]), row[2]
+            assert r["peak_idxs"][picket] == approx
+            if sep:
+                assert (r["left"][idx[leaf], picket], r["right"][idx[leaf], picket]) == (row[3], row[4])
+            else:
+                assert r["position"][idx[leaf], picket] == row[3]
+
+
+def check_pf_orientation_device(g, dev):
+    """picketfence.analyze_batch(orientation=, separate_leaves=) == the oracle on every window (NaN pattern included) and ==
+    the reference's own analyze() on every window it kept."""
+    import torch
+
+    from oracle import pylinac_oracle as o
+    from pylinac_amd import picketfence as ppf
+
+    for name, frame_key, orient, sep in PF_ORIENT_CASES:
+        raw, dpmm = g[f"{frame_key}.cropped"], float(g[f"{frame_key}.dpmm"])
+        res = ppf.analyze_batch(torch.from_numpy(np.ascontiguousarray(raw)[None]).to(dev), dpmm, orientation=orient,
+                                separate_leaves=sep)
+        ref = o.pf_measure(o.normalize(o.ground(raw)), dpmm, orientation=orient, separate_leaves=sep)
+        P = len(ref["peak_idxs"])
+        assert int(res.picket_count[0]) == P and float(res.spacing[0]) == ref["spacing"] == float(g[f"{name}.spacing"])
+        assert np.array_equal(res.picket_idx[0, :P].cpu().numpy(), ref["peak_idxs"])
+        assert res.leaf_nums == [n for n, _, _ in ref["leaves"]]
+        pairs = [(res.position, ref["position"])] + ([(res.left, ref["left"]), (res.right, ref["right"])] if sep else [])
+        for got_t, want in pairs:
+            got = got_t[0, :, :P].cpu().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(want)), name
+            assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(got)]), name
+        idx = {n: i for i, n in enumerate(res.leaf_nums)}
+        for row in g[f"{name}.meas"]:                      # what the reference itself measured
+            leaf, picket = int(row[0]), int(row[1])
+            if sep:
+                assert (float(res.left[0, idx[leaf], picket]), float(res.right[0, idx[leaf], picket])) == (row[3], row[4])
+            else:
+                assert float(res.position[0, idx[leaf], picket]) == row[3]
+
+
 def check_ground_promotion():
     """array_utils.ground == ``array - array.min() + value`` in numpy's dtype AND numpy's arithmetic for every kind of value:
     a narrow numpy float scalar is added in the narrow float type (no float64 detour), and the integer subtraction

@@ -828,6 +828,12 @@ def test_emulated_scharr_gaussian_bit_identical(emulated):
     checks.check_scharr_gaussian(emulated)
 
 
+def test_emulated_picket_fence_left_right_and_separate_leaves(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_pf_orientation_device(golden("picketfence_orient"), emulated)
+
+
 def test_emulated_ground_promotion(emulated):
     import next_row_checks as checks
 

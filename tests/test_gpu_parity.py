@@ -806,6 +806,12 @@ def test_picket_fence_batch_vs_reference_analyze(golden, dev):
         assert (st[:, P:] == 1).all() and set(np.unique(st[:, :P])) <= {0, 2}
 
 
+def test_picket_fence_left_right_and_separate_leaves(golden, dev):
+    import next_row_checks as checks
+
+    checks.check_pf_orientation_device(golden("picketfence_orient"), dev)
+
+
 def test_picket_fence_batch_of_frames(dev):
     from pylinac_amd import picketfence as ppf
     from tests.golden.make_golden import pf_frame

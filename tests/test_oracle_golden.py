@@ -296,6 +296,12 @@ def test_picket_fence_measurement_matches_reference_analyze(golden):
         assert np.isnan(r["position"]).sum() > 0     # the jaw-blocked rows were rejected
 
 
+def test_picket_fence_orientation_and_separate_leaves_match_reference_analyze(golden):
+    import next_row_checks as checks
+
+    checks.check_pf_orientation_oracle(golden("picketfence_orient"))
+
+
 def test_bb_finder_restatement_matches_reference_find_features(golden):
     """oracle.find_features_restated / region_props_like_skimage against the reference's own
     find_features + scikit-image 0.18.3 regionprops (py3.9 helper): every region the sweep saw
