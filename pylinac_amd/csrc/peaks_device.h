@@ -118,12 +118,10 @@ __device__ __forceinline__ void prominence_side(const double* xs, int pk, int m,
     if (lane < first && v < mn) { mn = v; step = t; }
     if (b) break;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ov = __shfl_xor(mn, o, 64);
-    const int os = __shfl_xor(step, o, 64);
-    if (ov < mn || (ov == mn && os < step)) { mn = ov; step = os; }
-  }
+  // the smallest value and, among equal values, the earliest step: two idempotent reductions on the DPP path
+  const double best = pl_wave_reduce_idem(mn, [](double a, double b) { return a < b ? a : b; });
+  step = pl_wave_reduce_idem(mn == best ? step : 0x7fffffff, [](int a, int b) { return a < b ? a : b; });
+  mn = best;
   out_min = mn;
   out_base = pk + DIR * step;
 }
@@ -178,8 +176,8 @@ __device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xf
       mn = v < mn ? v : mn;
       mx = v > mx ? v : mx;
     }
-    mn = pl_wave_reduce(mn, [](double a, double b) { return a < b ? a : b; });
-    mx = pl_wave_reduce(mx, [](double a, double b) { return a > b ? a : b; });
+    mn = pl_wave_reduce_idem(mn, [](double a, double b) { return a < b ? a : b; });
+    mx = pl_wave_reduce_idem(mx, [](double a, double b) { return a > b ? a : b; });
     if ((tid & 63) == 0) { s_red[tid >> 6] = mn; s_red[4 + (tid >> 6)] = mx; }
     group_sync<NT>();
     for (int k = 0; k < NT / PL_WAVE; ++k) {

@@ -330,7 +330,7 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   auto q = [&](int r, int c) { return pl_quot(kq, (double)sw[r * ncols + c]); };
 
   // np.max(window) > height_threshold * picket_peak_val   (q is monotone in the integer pixel)
-  vmax = pl_wave_reduce(vmax, [](int a, int b) { return a > b ? a : b; });
+  vmax = pl_wave_reduce_idem(vmax, [](int a, int b) { return a > b ? a : b; });
   const bool above = pl_quot(kq, (double)vmax) > height_threshold * pk_val[frame * cap + pi];
 
   // np.std(window, axis=1) with numpy's pairwise summation order (one block of ncols <= 128 values: eight running sums
@@ -385,7 +385,7 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   {
     const bool act = lane < nrows;
     const double va = act ? s_std_w[lane] : 0.0;
-    smax = pl_wave_reduce(act ? va : -1.0, [](double x, double y) { return x > y ? x : y; });   // std >= 0
+    smax = pl_wave_reduce_idem(act ? va : -1.0, [](double x, double y) { return x > y ? x : y; });   // std >= 0
     int rank = 0;
     for (int b2 = 0; b2 < nrows; ++b2) {
       const double vb = s_std_w[b2];
@@ -438,11 +438,11 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   double mn = __longlong_as_double(0x7ff0000000000000LL);
   if (has0) mn = pvr[0] < mn ? pvr[0] : mn;
   if (has1) mn = pvr[1] < mn ? pvr[1] : mn;
-  mn = pl_wave_reduce(mn, [](double a, double b) { return a < b ? a : b; });
+  mn = pl_wave_reduce_idem(mn, [](double a, double b) { return a < b ? a : b; });
   double mx = __longlong_as_double((long long)0xfff0000000000000ULL);
   if (has0) { const double g = pvr[0] - mn; mx = g > mx ? g : mx; }
   if (has1) { const double g = pvr[1] - mn; mx = g > mx ? g : mx; }
-  mx = pl_wave_reduce(mx, [](double a, double b) { return a > b ? a : b; });
+  mx = pl_wave_reduce_idem(mx, [](double a, double b) { return a > b ? a : b; });
   const double p0 = (pvr[0] - mn) / mx, p1 = (pvr[1] - mn) / mx;
   if (prof_out) {
     if (has0) pout[lane] = p0;

@@ -205,6 +205,40 @@ __device__ __forceinline__ T pl_wave_reduce(T v, F f) {
   return v;
 }
 
+// Wave-wide reductions of IDEMPOTENT operations (min, max: f(v, v) = v) on the VALU's data-parallel path: four row_shr steps
+// leave each row's result in its lane 15, row_bcast:15 / row_bcast:31 carry it across the rows, v_readlane hands lane 63's
+// total to every lane -- about twenty vector instructions.  The xor butterflies of pl_wave_reduce compile to ds_bpermute_b32
+// (two per step for a float64), an LDS round trip each: ~1 400 cycles per float64 reduction, and the per-window / per-peak
+// kernels are chains of those.  Not for sums: the order of a floating-point sum is part of the results.
+template <int CTRL, int RM>
+__device__ __forceinline__ int pl_dpp_keep(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xf, false); }
+
+template <typename F>
+__device__ __forceinline__ int pl_wave_reduce_idem(int v, F f) {
+  v = f(v, pl_dpp_keep<0x111, 0xf>(v));
+  v = f(v, pl_dpp_keep<0x112, 0xf>(v));
+  v = f(v, pl_dpp_keep<0x114, 0xf>(v));
+  v = f(v, pl_dpp_keep<0x118, 0xf>(v));
+  v = f(v, pl_dpp_keep<0x142, 0xa>(v));
+  v = f(v, pl_dpp_keep<0x143, 0xc>(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+template <typename F>
+__device__ __forceinline__ double pl_wave_reduce_idem(double v, F f) {
+  auto step = [&](auto tag_lo, auto tag_hi) {
+    const long long b = __double_as_longlong(v);
+    const int lo = tag_lo((int)b), hi = tag_hi((int)(b >> 32));
+    v = f(v, __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo)));
+  };
+  step([](int x) { return pl_dpp_keep<0x111, 0xf>(x); }, [](int x) { return pl_dpp_keep<0x111, 0xf>(x); });
+  step([](int x) { return pl_dpp_keep<0x112, 0xf>(x); }, [](int x) { return pl_dpp_keep<0x112, 0xf>(x); });
+  step([](int x) { return pl_dpp_keep<0x114, 0xf>(x); }, [](int x) { return pl_dpp_keep<0x114, 0xf>(x); });
+  step([](int x) { return pl_dpp_keep<0x118, 0xf>(x); }, [](int x) { return pl_dpp_keep<0x118, 0xf>(x); });
+  step([](int x) { return pl_dpp_keep<0x142, 0xa>(x); }, [](int x) { return pl_dpp_keep<0x142, 0xa>(x); });
+  step([](int x) { return pl_dpp_keep<0x143, 0xc>(x); }, [](int x) { return pl_dpp_keep<0x143, 0xc>(x); });
+  return pl_readlane_f64(v, 63);
+}
+
 // dispatch a dtype enum onto a template parameter
 #define PL_DISPATCH_DTYPE(dtype, T, ...)                         \
   switch (dtype) {                                               \

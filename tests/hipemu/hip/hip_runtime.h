@@ -220,15 +220,26 @@ inline T readfirstlane(T v) {
   return from_bits<T>(all[__builtin_ctzll(act)]);
 }
 }  // namespace hipemu
-// DPP wave_shr:1 (0x138: lane i <- lane i - 1) / wave_shl:1 (0x130: lane i <- lane i + 1); a lane without a source keeps `old`
-inline int hipemu_update_dpp(int old, int src, int ctrl) {
+// DPP controls the kernels use: wave_shr:1 (0x138: lane i <- lane i - 1) / wave_shl:1 (0x130: lane i <- lane i + 1),
+// row_shr:n (0x110 + n: lane i <- lane i - n inside its row of 16), row_bcast:15 (0x142: lane 15 of each row to the next
+// row), row_bcast:31 (0x143: lane 31 to rows 2 and 3).  A lane without a source, or whose row / bank the masks disable,
+// keeps `old` (bound_ctrl: 0 instead, for a missing source).
+inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   uint64_t all[64], act;
   hipemu::wave_exchange(hipemu::to_bits(src), all, &act);
-  const int from = hipemu::lane_id() + (ctrl == 0x138 ? -1 : ctrl == 0x130 ? 1 : 64);
-  if (from < 0 || from > 63 || !((act >> from) & 1ull)) return old;
+  const int lane = hipemu::lane_id();
+  const int row = lane >> 4, in_row = lane & 15;
+  if (!((row_mask >> row) & 1) || !((bank_mask >> (in_row >> 2)) & 1)) return old;
+  int from = -1;
+  if (ctrl == 0x138) from = lane - 1;
+  else if (ctrl == 0x130) from = lane + 1 < 64 ? lane + 1 : -1;
+  else if (ctrl > 0x110 && ctrl <= 0x11f) from = in_row >= (ctrl & 15) ? lane - (ctrl & 15) : -1;
+  else if (ctrl == 0x142) from = row >= 1 ? 16 * row - 1 : -1;
+  else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
+  if (from < 0 || from > 63 || !((act >> from) & 1ull)) return bound_ctrl ? 0 : old;
   return hipemu::from_bits<int>(all[from]);
 }
-#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_readlane(v, l) (hipemu::shfl_from((v), (l)))
 template <typename T>
 inline T __shfl(T v, int src, int width = 64) { (void)width; return hipemu::shfl_from(v, src); }
