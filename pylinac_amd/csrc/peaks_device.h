@@ -279,11 +279,16 @@ __device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xf
     prominence_side<+1>(xs, pk, m, right_min, rb);
     const double prom = xp - (left_min > right_min ? left_min : right_min);
     int keep = (!prm.has_prominence || prom >= prm.prominence_min) ? 1 : 0;
-    const Widths wd = peak_width(xs, pk, lb, rb, prom, prm.rel_height);
-    keep = keep && (wd.width >= prm.width_min);
+    // the width of every candidate is only needed for a width filter or a ranking by width; the peaks that are reported get
+    // theirs in stage H anyway (FWXM searches -- max_number = 1 by prominence, no width limit -- skip this walk)
+    double width = 0.0;
+    if (prm.width_min > 0.0 || (prm.max_number > 0 && prm.sort_key == PL_SORT_WIDTHS)) {
+      width = peak_width(xs, pk, lb, rb, prom, prm.rel_height).width;
+      keep = keep && (width >= prm.width_min);
+    }
     if ((tid & (PL_WAVE - 1)) == 0) {
       s_prom[p] = prom;
-      s_width[p] = wd.width;
+      s_width[p] = width;
       s_lb[p] = lb;
       s_rb[p] = rb;
       s_keep[p] = keep;
