@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0          # measured float4 copy (same guide): the ceiling a streaming kernel can reach
 ALG_BYTES_PER_FRAME = 4_194_304  # read u16 frame + write u16 frame
-ALG_BYTES = {"#3": 1_572_864, "#4": 2_097_152, "#5": 524_288}   # read-once roofline per frame / slice
+ALG_BYTES = {"#2": 4_194_304, "#3": 1_572_864, "#4": 2_097_152, "#5": 524_288}   # read-once roofline per frame / slice
 
 
 def parse():
@@ -156,6 +156,33 @@ def bench_configs(dev, world=8):
                     "value": round(rate, 1), "algorithmic_GBs": round(gbs, 2),
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "frac_of_measured_copy": round(gbs / HBM_COPY_GBS, 5),
                     "inputs": inputs, "parity_sample": parity}
+
+    # ---- "#2w": the headline step on frames stretched to the full 16-bit range (field plateau - background = 64 500 grey
+    # levels: a 16-bit-normalised EPID).  Their FILTERED range exceeds the 38 912-bin LDS window of the one-pass Otsu kernel,
+    # so every frame takes that stage's full-range kernel (65 536 packed 16-bit counters); the other stages are unchanged.
+    from pylinac_amd.pipeline import EpidPipeline
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    nw = 256
+    fr = epid_open_field_frames(nw, 1024, 1024, seed0=1000, device=dev)
+    q = torch.quantile(fr[0].to(torch.float32).flatten()[::16], torch.tensor([0.01, 0.99], device=dev))
+    lo_q, hi_q = float(q[0]), float(q[1])
+    wide = torch.empty_like(fr)
+    for a in range(0, nw, 32):                            # (in blocks: the float32 detour of 256 frames would be 1 GiB more)
+        blk = ((fr[a:a + 32].to(torch.float32) - lo_q) * (64500.0 / (hi_q - lo_q)) + 500.0).round().clamp(0, 65535)
+        wide.view(torch.int16)[a:a + 32] = blk.to(torch.int32).bitwise_and_(0xFFFF).to(torch.int16)
+    del fr, blk
+    pipe_w = EpidPipeline(nw, 1024, 1024, dev)
+    ev = {}
+    dt, rw = timed_passes(lambda: pipe_w.run(wide, ev), iters=20)
+    entry("#2w", "headline step (configs[1]) on 256 x 1024^2 uint16 frames stretched to the full 16-bit range: the median + Otsu "
+                 "stage runs its full-range kernel for every frame", nw, "images/s", dt,
+          "synthetic.epid_open_field_frames seed 1000+i, (x - q01) * 64500 / (q99 - q01) + 500, rounded, clipped",
+          parity_epid(rw, wide))
+    out["#2w"]["flagged_frames"] = int(pipe_w.flag.sum())
+    out["#2w"]["stage_ms"] = {k: round(sum(a.elapsed_time(b) for a, b in v) / len(v), 4) for k, v in ev.items()}
+    del wide, rw, pipe_w, ev
+    torch.cuda.empty_cache()
 
     n3 = 512
     f3 = pf_frames(n3, device=dev)

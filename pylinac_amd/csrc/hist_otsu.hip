@@ -509,6 +509,145 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
   }
 }
 
+// ---- single-pass Otsu for frames the 38 912-bin window cannot hold: ALL 65 536 bins in LDS as packed 16-bit counters -------
+// (a frame stretched to the full 16-bit range fell off a cliff -- gated median plane + two-part histogram + scan,
+// 0.226 -> 0.489 ms per 256 frames; three one-read alternatives built on 32-bit bins were slower still.)
+// 65 536 counters of 16 bits are 128 KiB: two per dword, added with ONE returning LDS atomic (1 << 0 or 1 << 16).  A counter
+// uses 15 bits; bit 15 is a GUARD: the add that finds the field at 0x7fff sets the guard (no carry can reach the neighbouring
+// field: that would take 32 768 further adds before the fix below), and exactly that lane -- it alone saw 0x7fff come back --
+// subtracts 0x8000 again and notes the key in a short LDS list: every entry stands for 32 768 pixels of that value.  Adds
+// that land between the two steps are preserved (the fix is a subtraction, not a store).  The Otsu scan reads the fields
+// and adds the noted multiples of 32 768: same integer prefix sums, float64 expression and first-index arg-max as otsu_kernel.
+// One workgroup per frame, gated by the window kernel's flag; medians on the fly like the window kernel (MED3).
+constexpr int kFullEvents = 2048;                            // overflow notes: frames of up to 2^26 pixels
+struct FullScratch {
+  Pair wave_tot[kHistThreads / 64];
+  double s_var[kHistThreads / 64];
+  int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64], s_idx[kHistThreads / 64];
+  int n_events;
+  unsigned short event_key[kFullEvents];
+};
+constexpr int kFullBinsBytes = 65536 * 2;
+constexpr size_t kFullLds = kFullBinsBytes + sizeof(FullScratch);
+
+template <typename T, bool MED3>
+__global__ void __launch_bounds__(kHistThreads)
+otsu16_full_kernel(const unsigned short* __restrict__ in, int64_t count, int h, int w, unsigned flip, int bias,
+                   int32_t* __restrict__ thr, int32_t* __restrict__ vmin, int32_t* __restrict__ vmax,
+                   int32_t* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // 32 768 dwords = 65 536 fields, then FullScratch
+  FullScratch& scr = *reinterpret_cast<FullScratch*>(reinterpret_cast<unsigned char*>(bins) + kFullBinsBytes);
+  const int64_t frame = blockIdx.x;
+  if (flag[frame] == 0) return;                              // the window kernel finished this frame
+  const unsigned short* src = in + frame * count;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 32768; i += kHistThreads) bins[i] = 0;
+  if (threadIdx.x == 0) scr.n_events = 0;
+  __syncthreads();
+  // key = value in the biased domain (0 .. 65535), n = how many pixels of it (1, or a whole wave's worth <= 512: the guard
+  // bit leaves room for 32 767 more before a carry, far more than every wave's bulk add landing between the two steps)
+  auto tally_n = [&](unsigned key, unsigned n) {
+    const unsigned sh = (key & 1u) << 4;
+    const unsigned old = atomicAdd(&bins[key >> 1], n << sh);
+    const unsigned f = (old >> sh) & 0xffffu;
+    if (f < 0x8000u && f + n >= 0x8000u) {                   // this add took the field across the guard: fold 32 768 away
+      atomicSub(&bins[key >> 1], 0x8000u << sh);
+      const int slot = atomicAdd(&scr.n_events, 1);
+      if (slot < kFullEvents) scr.event_key[slot] = (unsigned short)key;
+    }
+  };
+  auto tally = [&](unsigned key) { tally_n(key, 1u); };
+  if (MED3) {
+    constexpr int kRows = 32;
+    constexpr int kSBias = ((T)-1 < (T)0) ? 32768 : 0;
+    const int col_waves = (w / 8 + PL_WAVE - 1) / PL_WAVE, row_groups = (h + kRows - 1) / kRows;
+    for (int item = __builtin_amdgcn_readfirstlane(wv); item < col_waves * row_groups; item += kHistThreads / 64) {
+      const int c0 = ((item % col_waves) * PL_WAVE + lane) * 8;
+      const bool on = c0 < w;
+      const unsigned long long act = __ballot(on);
+      if (act == 0ull) continue;
+      const int first_on = __builtin_ctzll(act);
+      pl_median3_rows<T, kRows, PL_OTSU_AHEAD>(reinterpret_cast<const T*>(src), h, w, c0, lane, (item / col_waves) * kRows,
+                             [&](int, const int (&m)[8]) {
+        // one value in the whole wave (saturated / constant neighbourhoods): one add of the wave's count
+        unsigned spread = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) spread |= (unsigned)(m[k] ^ m[0]);
+        const int wave_first = __builtin_amdgcn_readlane(m[0], first_on);
+        if (__ballot(on && (spread | (unsigned)(m[0] ^ wave_first)) != 0u) == 0ull) {
+          if (lane == first_on) tally_n((unsigned)(wave_first + kSBias), 8u * (unsigned)__popcll(act));
+          return;
+        }
+        if (!on) return;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tally((unsigned)(m[k] + kSBias));
+      });
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < count; i += kHistThreads) tally((unsigned)src[i] ^ flip);
+  }
+  __syncthreads();
+  const int n_events = scr.n_events < kFullEvents ? scr.n_events : kFullEvents;   // (more: a frame beyond 2^26 pixels, refused by the launcher)
+
+  // ---- Otsu on the 65 536 bins: lane t owns bins [64 t, 64 t + 64)
+  const int b0 = threadIdx.x * 64;
+  // this lane's overflow notes, as extra counts per bin: rare, so a lane without any skips the lookup
+  int my_events = 0;
+  for (int e = 0; e < n_events; ++e) my_events += ((int)scr.event_key[e] >> 6) == (int)threadIdx.x ? 1 : 0;
+  auto count_of = [&](int b) {
+    unsigned c = (bins[b >> 1] >> ((b & 1) << 4)) & 0xffffu;
+    if (my_events)
+      for (int e = 0; e < n_events; ++e) c += (int)scr.event_key[e] == b ? 32768u : 0u;
+    return c;
+  };
+  Pair mine = {0, 0};
+  int lo = 1 << 30, hi = -1;
+  for (int b = b0; b < b0 + 64; ++b) {
+    const unsigned c = count_of(b);
+    mine.c += c;
+    mine.s += (long long)c * (long long)(b - bias);
+    if (c) { if (lo == (1 << 30)) lo = b; hi = b; }
+  }
+  lo = pl_wave_reduce(lo, [](int a, int b) { return a < b ? a : b; });
+  hi = pl_wave_reduce(hi, [](int a, int b) { return a > b ? a : b; });
+  if (lane == 0) { scr.s_lo[wv] = lo; scr.s_hi[wv] = hi; }
+  Pair total;
+  Pair ex = block_exclusive_scan(mine, &total, scr.wave_tot);  // contains __syncthreads
+  for (int k = 0; k < kHistThreads / 64; ++k) { lo = scr.s_lo[k] < lo ? scr.s_lo[k] : lo; hi = scr.s_hi[k] > hi ? scr.s_hi[k] : hi; }
+  double best = -1.0;
+  int best_k = 1 << 30;
+  unsigned long long w1 = ex.c;
+  long long s1 = ex.s;
+  for (int b = b0; b < b0 + 64; ++b) {
+    const unsigned c = count_of(b);
+    w1 += c;
+    s1 += (long long)c * (long long)(b - bias);
+    if (c != 0u && b >= lo && b < hi) {           // empty bins: see otsu_kernel
+      const double dw1 = (double)w1, dw2 = (double)(total.c - w1);
+      const double m1 = (double)s1 / dw1;
+      const double m2 = (double)(total.s - s1) / dw2;
+      const double d = m1 - m2;
+      const double var = (dw1 * dw2) * (d * d);
+      if (var > best) { best = var; best_k = b; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(best, o, 64);
+    int ok = __shfl_xor(best_k, o, 64);
+    if (ov > best || (ov == best && ok < best_k)) { best = ov; best_k = ok; }
+  }
+  if (lane == 0) { scr.s_var[wv] = best; scr.s_idx[wv] = best_k; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kHistThreads / 64; ++k)
+      if (scr.s_var[k] > best || (scr.s_var[k] == best && scr.s_idx[k] < best_k)) { best = scr.s_var[k]; best_k = scr.s_idx[k]; }
+    thr[frame] = (lo == hi) ? (lo - bias) : (best_k - bias);
+    if (vmin) vmin[frame] = lo - bias;
+    if (vmax) vmax[frame] = hi - bias;
+  }
+}
+
 __global__ void __launch_bounds__(kHistThreads)
 order_stats_kernel(const uint32_t* __restrict__ hist, int bias, const int64_t* __restrict__ ranks,
                    int nranks, int32_t* __restrict__ out) {
@@ -783,8 +922,23 @@ int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t c
   }
   hipLaunchKernelGGL((otsu16_window_kernel<T, MED3>), dim3((unsigned)n), dim3(kHistThreads), lds, st, (const unsigned short*)in,
                      count, h, w, flip, bias, d_lo, d_hi, d_thr, d_min, d_max, d_flag);
-  // frames too wide for the window: the two-kernel path, every workgroup gated by d_flag -- on the median plane, which is
-  // materialised for exactly those frames when the one-pass kernel computed its medians on the fly
+  // frames too wide for the window: the full-range kernel (packed 16-bit counters), every workgroup gated by d_flag; the
+  // medians are computed on the fly again for exactly those frames.  (Round 3: gated median plane + two-part histogram +
+  // scan, 2.2 x the window kernel's time on a stretched batch.)  Frames beyond 2^26 pixels keep the table path.
+  if (count <= (int64_t)kFullEvents * 32768) {
+    static std::atomic<bool> attr2{false};
+    if (!attr2) {
+      if (hipFuncSetAttribute((const void*)otsu16_full_kernel<T, MED3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFullLds) !=
+          hipSuccess) {
+        pl_set_error("%s: LDS attribute: %s", who, hipGetErrorString(hipGetLastError()));
+        return PL_ERR_HIP;
+      }
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((otsu16_full_kernel<T, MED3>), dim3((unsigned)n), dim3(kHistThreads), kFullLds, st, (const unsigned short*)in,
+                       count, h, w, flip, bias, d_thr, d_min, d_max, d_flag);
+    return pl_check_launch(who);
+  }
   const unsigned short* plane = (const unsigned short*)in;
   if (MED3) {
     if (pl_median3_gated(in, scratch, dtype == PL_I16, n, h, w, d_flag, st) != 0) {

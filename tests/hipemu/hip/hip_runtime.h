@@ -286,6 +286,8 @@ inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 template <typename T, typename U>
 inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
 template <typename T, typename U>
+inline T atomicSub(T* p, U v) { T o = *p; *p = (T)(o - (T)v); return o; }
+template <typename T, typename U>
 inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
 template <typename T, typename U>
 inline T atomicAnd(T* p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }

@@ -256,7 +256,7 @@ def test_emu_median_consumed_on_the_fly(emu):
     """pl_median3_otsu16 / pl_median3_threshold_colsum_u16 (median3_rows.h inside the Otsu window kernel and inside the
     threshold + column-sum kernel: the median plane is never written): tiny and ragged geometries (2 rows, one 8-column
     block, widths that leave the last wave partly idle, heights off the 16 / 32 row groups), a full-range frame that does not
-    fit the one-pass window (flagged: gated median into scratch + two-kernel histogram), int16."""
+    fit the one-pass window (flagged: the full-range kernel with packed 16-bit counters takes it), int16."""
     from scipy import ndimage
 
     rng = np.random.default_rng(5)
@@ -275,8 +275,7 @@ def test_emu_median_consumed_on_the_fly(emu):
             np.testing.assert_array_equal(mn, med.reshape(n, -1).min(1))
             np.testing.assert_array_equal(mx, med.reshape(n, -1).max(1))
             if h * w >= 1000:
-                assert flag[-1] == 1, (shape, flag)                        # the full-range frame went the two-kernel way
-                np.testing.assert_array_equal(scratch[-1], med[-1])        # ... on its materialised median plane
+                assert flag[-1] == 1, (shape, flag)                        # the full-range frame went to the full-range kernel
             if dt == np.uint16:
                 cut = np.array([int(np.percentile(f, 40)) for f in med], np.int32)
                 out, cs = np.zeros_like(a), np.zeros((n, w), np.uint64)
@@ -284,6 +283,41 @@ def test_emu_median_consumed_on_the_fly(emu):
                 want = np.where(med.astype(np.int64) >= cut[:, None, None], med, 0).astype(np.uint16)
                 np.testing.assert_array_equal(out, want, err_msg=str(shape))
                 np.testing.assert_array_equal(cs.astype(np.int64), want.astype(np.int64).sum(1))
+
+
+def test_emu_full_range_otsu_counter_overflow(emu):
+    """otsu16_full_kernel (the fallback of pl_otsu16 / pl_median3_otsu16 for frames wider than the 38 912-bin window): 65 536
+    packed 16-bit counters whose guard bit folds 32 768 counts away at a time.  Frames of > 32 768 pixels with one value
+    holding most of them, scattered (every add is a lane's own: the guard is crossed by single adds) and as flat areas (the
+    wave-uniform bulk add crosses it), twice over (two folds of one key), next to full-range noise; plain and median paths."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(9)
+    h, w = 96, 1032                                                     # 99 072 pixels
+    for dt, code in ((np.uint16, PL_U16), (np.int16, PL_I16)):
+        off = 32768 if dt == np.int16 else 0
+        noise = rng.integers(0, 65536, (3, h, w))
+        a = noise.copy()
+        a[0][rng.random((h, w)) < 0.75] = 777                           # scattered: ~74 000 single adds to one bin (two folds)
+        a[1][:, : w // 2] = 40000                                       # flat half: wave-uniform bulk adds
+        a[1][rng.random((h, w)) < 0.3] = 40001                          # ... broken up by a second heavy value
+        a[2] = np.where(rng.random((h, w)) < 0.5, 12, 65535)            # two values only, at the ends of the range
+        a = (a - off).astype(dt)
+        n = a.shape[0]
+        thr, mn, mx, flag = (np.zeros(n, np.int32) for _ in range(4))
+        hist = np.zeros((n, 65536), np.uint32)
+        _ok(emu, emu.pl_otsu16(_p(a), code, n, h * w, None, None, _p(thr), _p(mn), _p(mx), _p(flag), _p(hist), None))
+        assert flag.all()
+        np.testing.assert_array_equal(thr, [orc.threshold_otsu(f) for f in a], err_msg=dt.__name__)
+        np.testing.assert_array_equal(mn, a.reshape(n, -1).min(1))
+        np.testing.assert_array_equal(mx, a.reshape(n, -1).max(1))
+        med = np.stack([ndimage.median_filter(f, size=3) for f in a])
+        scratch = np.zeros_like(a)
+        _ok(emu, emu.pl_median3_otsu16(_p(a), _p(scratch), code, n, h, w, None, None, _p(thr), _p(mn), _p(mx), _p(flag), _p(hist), None))
+        assert flag.all()
+        np.testing.assert_array_equal(thr, [orc.threshold_otsu(f) for f in med], err_msg=dt.__name__ + " median")
+        np.testing.assert_array_equal(mn, med.reshape(n, -1).min(1))
+        np.testing.assert_array_equal(mx, med.reshape(n, -1).max(1))
 
 
 def test_emu_median3_packed_kernels(emu):

@@ -960,7 +960,7 @@ def test_median_consumed_on_the_fly_vs_scipy_and_oracle(dev):
     """pl_median3_otsu16 / pl_median3_threshold_colsum_u16 (the EPID pipeline's stages after the Gaussian: the 3x3 median is
     computed inside the Otsu histogram kernel and again inside the threshold + column-sum kernel, the median plane is never
     written) against scipy's median_filter + the oracle's Otsu + numpy: EPID-like frames, a frame with full-range noise (does
-    not fit the one-pass window: flagged, goes through the materialised plane), a constant frame, widths that leave the last
+    not fit the one-pass window: flagged, taken by the full-range kernel), a constant frame, widths that leave the last
     wave partly idle, a height that is not a multiple of 16, int16."""
     from scipy import ndimage
 
@@ -970,7 +970,7 @@ def test_median_consumed_on_the_fly_vs_scipy_and_oracle(dev):
     for shape in ((3, 200, 264), (2, 37, 1040), (4, 130, 64), (1, 16, 8)):
         for dt in (np.uint16, np.int16):
             a = (rng.integers(2000, 2600, shape) + (np.arange(shape[2]) > shape[2] // 2) * 9000).astype(np.int64)
-            a[-1] = rng.integers(0, 65536, shape[1:])                # full range: two-kernel path on the scratch plane
+            a[-1] = rng.integers(0, 65536, shape[1:])                # full range: the packed-counter kernel
             if shape[0] > 2:
                 a[1] = 12345                                          # constant frame
             a = (a - (32768 if dt == np.int16 else 0)).astype(dt)
@@ -987,6 +987,42 @@ def test_median_consumed_on_the_fly_vs_scipy_and_oracle(dev):
                 want = np.where(med.astype(np.int64) >= cut.cpu().numpy()[:, None, None], med, 0).astype(np.uint16)
                 assert np.array_equal(out.cpu().numpy(), want), shape
                 assert np.array_equal(cs.cpu().numpy(), want.astype(np.int64).sum(1)), shape
+
+
+def test_full_range_otsu_counter_overflow_1024(dev):
+    """The full-range Otsu kernel (65 536 packed 16-bit counters, guard bit, 32 768-count folds) under REAL concurrency: 1024 x
+    1024 frames whose histogram has bins far beyond 32 767 -- one value on 75 % of the pixels scattered among full-range noise
+    (single adds cross the guard ~24 times for one key while 1 024 threads race), flat halves (wave-uniform bulk adds), two
+    values at the ends of the range, an EPID frame stretched to the full range -- against the oracle's Otsu on scipy's median;
+    plain frames (pl_otsu16) too.  uint16 and int16."""
+    from scipy import ndimage
+
+    from pylinac_amd import ops
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    rng = np.random.default_rng(19)
+    h = w = 1024
+    epid = epid_open_field_frames(1, h, w, seed0=7100).numpy()[0].astype(np.float64)
+    lo, hi = np.quantile(epid[::16], [0.01, 0.99])
+    stretched = np.clip(np.round((epid - lo) * (64500.0 / (hi - lo)) + 500.0), 0, 65535)
+    for dt in (np.uint16, np.int16):
+        off = 32768 if dt == np.int16 else 0
+        a = rng.integers(0, 65536, (4, h, w))
+        a[0][rng.random((h, w)) < 0.75] = 777
+        a[1][:, : w // 2] = 40000
+        a[1][rng.random((h, w)) < 0.3] = 40001
+        a[2] = np.where(rng.random((h, w)) < 0.5, 12, 65535)
+        a[3] = stretched
+        a = (a - off).astype(dt)
+        t = torch.from_numpy(a).to(dev)
+        thr, mn, mx = ops.otsu16(t)
+        assert np.array_equal(thr.cpu().numpy(), np.array([o.threshold_otsu(f) for f in a])), dt
+        assert np.array_equal(mn.cpu().numpy(), a.reshape(4, -1).min(1)) and np.array_equal(mx.cpu().numpy(), a.reshape(4, -1).max(1))
+        med = np.stack([ndimage.median_filter(f, size=3) for f in a])
+        thr, mn, mx, flag = ops.median3_otsu16(t)
+        assert flag.cpu().numpy().all()
+        assert np.array_equal(thr.cpu().numpy(), np.array([o.threshold_otsu(f) for f in med])), dt
+        assert np.array_equal(mn.cpu().numpy(), med.reshape(4, -1).min(1)) and np.array_equal(mx.cpu().numpy(), med.reshape(4, -1).max(1))
 
 
 def test_pipeline_fused_stages_equal_separate_ops_at_baseline_size(dev):
