@@ -52,7 +52,7 @@ for _ in range(3): fn()
 torch.cuda.synchronize()
 print(which, "ms per pass", (time.perf_counter() - t0) / 3 * 1e3, flush=True)
 PY
-for which in ${@:-wl wln pf ctp}; do
+for which in ${@:-wl wln pf ctp25}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$which -o p -- python /tmp/run_cfg.py $which > $OUT/$which.log 2>&1
   grep "ms per pass" $OUT/$which.log
   python - "$OUT/$which" <<'PY'

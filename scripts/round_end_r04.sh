@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 3: one gpurun call that refreshes every piece of evidence the round is judged on.
-#   gpurun --timeout 1800 -- 'bash scripts/round_end_r03.sh r03z'
-TAG=${1:-r03z}
+# Round 4: one gpurun call that refreshes every piece of evidence the round is judged on.
+#   gpurun --timeout 1800 -- 'bash scripts/round_end_r04.sh r04z'
+TAG=${1:-r04z}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -32,6 +32,12 @@ bash scripts/pmc_write_pipeline.sh > $OUT/pmc_pipeline_traffic.txt 2>&1
 cp gpurun_out/pmc_pipe/pmc_traffic.json $OUT/pmc_traffic.json
 cat $OUT/pmc_traffic.json | tee -a $OUT/summary.txt
 bash scripts/gpu_pmc_bench.sh > $OUT/pmc_sq_pipeline_kernels.txt 2>&1
-scripts/ubench/g2d_v0 256 1 2000 5 > $OUT/dvfs_ramp.txt 2>&1
 bash scripts/profile_configs.sh > $OUT/configs_kernel_stats.txt 2>&1
-tail -3 $OUT/dvfs_ramp.txt | cut -c1-400 | tee -a $OUT/summary.txt
+# SQ counters of the config #5 / #3 kernels (two --pmc passes each, kernel trace only beside them)
+bash scripts/pmc_kernels.sh ct edge_otsu_kernel,edge_stream_kernel,mask_regions_kernel,circle_profile_combined,peak_valley_kernel -- python scripts/run_ct_pass.py 25 2 > /dev/null 2>&1
+cp gpurun_out/pmc_ct/summary.txt $OUT/pmc_sq_ct_kernels.txt
+bash scripts/pmc_kernels.sh pf pf_windows_kernel,scaled_colmean4,minmax_kernel -- python scripts/run_pf_pass.py 512 2 > /dev/null 2>&1
+cp gpurun_out/pmc_pf/summary.txt $OUT/pmc_sq_pf_kernels.txt
+python scripts/run_ct_pass.py 25 8 | tee -a $OUT/summary.txt
+python scripts/run_pf_pass.py 512 8 | tee -a $OUT/summary.txt
+python scripts/time_wide_range.py 2>&1 | tail -2 | tee $OUT/wide_range.txt

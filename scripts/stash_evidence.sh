@@ -5,7 +5,8 @@ set -e
 cd "$(dirname "$0")/.."
 TAG=$1; SRC=gpurun_out/$TAG
 for f in summary.txt pytest_gpu_full.log bench_line_full.json bench_line_under_rocprof.json bench_three_runs.txt rocprofv3_summary.txt \
-         pmc_pipeline_traffic.txt pmc_sq_pipeline_kernels.txt configs_kernel_stats.txt dvfs_ramp.txt pmc_traffic.json; do
+         pmc_pipeline_traffic.txt pmc_sq_pipeline_kernels.txt configs_kernel_stats.txt dvfs_ramp.txt pmc_traffic.json \
+         pmc_sq_ct_kernels.txt pmc_sq_pf_kernels.txt wide_range.txt; do
   [ -s $SRC/$f ] && cp $SRC/$f profiles/${TAG}_$f
 done
 python3 - $TAG <<'PY'
@@ -13,7 +14,7 @@ import json, subprocess, sys
 tag = sys.argv[1]
 d = json.load(open(f"gpurun_out/{tag}/pmc_traffic.json"))
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-d["_measured_at"] = f"commit {commit} (round 3, run {tag}: profiles/{tag}_pmc_pipeline_traffic.txt)"
+d["_measured_at"] = f"commit {commit} (round 4, run {tag}: profiles/{tag}_pmc_pipeline_traffic.txt)"
 json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(d)
 PY
