@@ -280,7 +280,8 @@ template <typename T, bool MED3>
 __global__ void __launch_bounds__(kHistThreads)
 otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h, int w, unsigned flip, int bias,
                      const int32_t* __restrict__ lo_hint, const int32_t* __restrict__ hi_hint, int32_t* __restrict__ thr,
-                     int32_t* __restrict__ vmin, int32_t* __restrict__ vmax, int32_t* __restrict__ flag) {
+                     int32_t* __restrict__ vmin, int32_t* __restrict__ vmax, int32_t* __restrict__ flag, int parts,
+                     uint32_t* __restrict__ merge /* parts > 1: [n][65536] zeroed; flag zeroed too */) {
   // ALL of the kernel's LDS is the dynamic block: the bins start at LDS address 0, so a bin's byte offset IS its address
   // (with static arrays in front the compiler spent one add per pixel on the base), the reduction scratch sits behind them
   extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // kWinBins + 1, then OtsuScratch
@@ -290,7 +291,12 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
   int* const s_hi = scr.s_hi;
   double* const s_var = scr.s_var;
   int* const s_idx = scr.s_idx;
-  const int64_t frame = blockIdx.x;
+  // parts > 1 (small batches: one workgroup per frame would leave most of the chip idle): `parts` workgroups share a frame,
+  // each tallies a band of its rows into its own LDS window (placed identically: same hints / same sample), the windows are
+  // merged into the frame's table in global memory by returning device-scope atomics, and the part that arrives last runs the
+  // scan on the merged counts.  No fences: every access to the table is a device-scope atomic or a device-coherent load.
+  const int64_t frame = blockIdx.x / (unsigned)parts;
+  const int part = (int)(blockIdx.x % (unsigned)parts);
   const unsigned short* src = in + frame * count;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int klo, khi;   // window = keys [klo, khi] (biased domain)
@@ -337,7 +343,7 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
   const int range = khi - klo + 1;
   // (MED3 addresses the bins by absolute LDS address: they must start the workgroup's LDS -- else the two-kernel path)
   if (range > kWinBins || range <= 0 || klo < 0 || khi > 65535 || (MED3 && pl_lds_base(bins) != 0u)) {
-    if (threadIdx.x == 0) flag[frame] = 1;
+    if (threadIdx.x == 0) flag[frame] = 1;                   // (every part of a frame decides the same)
     return;
   }
   for (int i = threadIdx.x; i <= range; i += kHistThreads) bins[i] = 0;      // + the spare bin at index `range`
@@ -360,7 +366,8 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     unsigned dummy = 0;
 #endif
     const int col_waves = (w / 8 + PL_WAVE - 1) / PL_WAVE, row_groups = (h + kRows - 1) / kRows;
-    for (int item = __builtin_amdgcn_readfirstlane(wv); item < col_waves * row_groups; item += kHistThreads / 64) {   // scalar
+    const int rg_lo = (int)((int64_t)row_groups * part / parts), rg_hi = (int)((int64_t)row_groups * (part + 1) / parts);
+    for (int item = rg_lo * col_waves + __builtin_amdgcn_readfirstlane(wv); item < col_waves * rg_hi; item += kHistThreads / 64) {   // scalar
       const int c0 = ((item % col_waves) * PL_WAVE + lane) * 8;
       const bool on = c0 < w;
       // per item: which lanes hold columns of the frame (all of them unless w / 8 is not a multiple of 64)
@@ -430,29 +437,52 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
         tally(wds[k] >> 16);
       }
     };
-    int64_t v = threadIdx.x;
+    const int64_t v_lo = nvec * part / parts, v_hi = nvec * (part + 1) / parts;      // this part's share of the vectors
+    int64_t v = v_lo + threadIdx.x;
     constexpr int U = 4;  // independent 16-byte loads in flight per lane
-    for (; v + (int64_t)(U - 1) * kHistThreads < nvec; v += (int64_t)U * kHistThreads) {
+    for (; v + (int64_t)(U - 1) * kHistThreads < v_hi; v += (int64_t)U * kHistThreads) {
       uint4 q[U];
 #pragma unroll
       for (int k = 0; k < U; ++k) q[k] = vsrc[v + (int64_t)k * kHistThreads];
 #pragma unroll
       for (int k = 0; k < U; ++k) tally4(q[k]);
     }
-    for (; v < nvec; v += kHistThreads) tally4(vsrc[v]);
-    for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally(src[i]);
+    for (; v < v_hi; v += kHistThreads) tally4(vsrc[v]);
+    if (part == parts - 1)
+      for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally(src[i]);
   } else {
-    for (int64_t i = threadIdx.x; i < count; i += kHistThreads) tally(src[i]);
+    const int64_t i_lo = count * part / parts, i_hi = count * (part + 1) / parts;
+    for (int64_t i = i_lo + threadIdx.x; i < i_hi; i += kHistThreads) tally(src[i]);
   }
   // a pixel fell outside the window (or outside the caller's bounds): two-kernel path.  (__syncthreads_or would bring 256
   // bytes of static LDS in front of the bins.)  The branch-free tally counts out-of-window pixels in the spare bin.
   if (outside) scr.any = 1;
   __syncthreads();
-  if (scr.any != 0 || (MED3 && bins[range] != 0u)) {   // the same for every thread
-    if (threadIdx.x == 0) flag[frame] = 1;
-    return;
+  const bool spilled = scr.any != 0 || (MED3 && bins[range] != 0u);   // the same for every thread
+  if (parts == 1) {
+    if (spilled) {
+      if (threadIdx.x == 0) flag[frame] = 1;
+      return;
+    }
+    if (threadIdx.x == 0) flag[frame] = 0;
+  } else {
+    uint32_t* table = merge + frame * 65536;
+    if (spilled && threadIdx.x == 0) atomicExch(&flag[frame], 1);
+    unsigned seen = 0;
+    if (!spilled)
+      for (int i = threadIdx.x; i < range; i += kHistThreads) {
+        const unsigned c = bins[i];
+        if (c) seen |= atomicAdd(&table[i], c) == 0xffffffffu ? 1u : 0u;   // RETURNING: the wave waits for its adds
+      }
+    const int never = __syncthreads_or((int)seen);           // (a count cannot reach 2^32 - 1)
+    if (threadIdx.x == 0) scr.any = atomicAdd(&table[65534], never ? 0u : 1u) == (unsigned)(parts - 1) ? 1 : 0;
+    __syncthreads();
+    if (scr.any == 0) return;                                // not the last part of this frame
+    if (__hip_atomic_load(&flag[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // a part spilled: fallback
+    for (int i = threadIdx.x; i < range; i += kHistThreads)
+      bins[i] = __hip_atomic_load(&table[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
   }
-  if (threadIdx.x == 0) flag[frame] = 0;
 
   // ---- Otsu on the window: lane t owns window bins [t*per, t*per + per); same integer prefix sums, float64 expression
   // and first-index arg-max as otsu_kernel
@@ -920,8 +950,19 @@ int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t c
     }
     attr = true;
   }
-  hipLaunchKernelGGL((otsu16_window_kernel<T, MED3>), dim3((unsigned)n), dim3(kHistThreads), lds, st, (const unsigned short*)in,
-                     count, h, w, flip, bias, d_lo, d_hi, d_thr, d_min, d_max, d_flag);
+  // small batches: several workgroups per frame (the table d_hist merges them; it and the flags start at zero)
+  int parts = 1;
+  const int cus = pl_cu_count();
+  while (parts < 8 && n * parts * 2 <= cus) parts *= 2;
+  if (MED3) { const int row_groups = (h + 31) / 32; while (parts > 1 && parts > row_groups) parts /= 2; }
+  if (count < 65536) parts = 1;
+  if (parts > 1) {
+    hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)n * 65536 * sizeof(uint32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, (size_t)n * sizeof(int32_t), st);
+    if (e != hipSuccess) { pl_set_error("%s: memset: %s", who, hipGetErrorString(e)); return PL_ERR_HIP; }
+  }
+  hipLaunchKernelGGL((otsu16_window_kernel<T, MED3>), dim3((unsigned)(n * parts)), dim3(kHistThreads), lds, st,
+                     (const unsigned short*)in, count, h, w, flip, bias, d_lo, d_hi, d_thr, d_min, d_max, d_flag, parts, d_hist);
   // frames too wide for the window: the full-range kernel (packed 16-bit counters), every workgroup gated by d_flag; the
   // medians are computed on the fly again for exactly those frames.  (Round 3: gated median plane + two-part histogram +
   // scan, 2.2 x the window kernel's time on a stretched batch.)  Frames beyond 2^26 pixels keep the table path.

@@ -285,6 +285,7 @@ inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 // ---- atomics (one OS thread: plain read-modify-write, returning the old value) -------------------------------
 template <typename T, typename U>
 inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
+#define __hip_atomic_load(p, order, scope) (*(p))           /* one OS thread: every store is visible at once */
 template <typename T, typename U>
 inline T atomicSub(T* p, U v) { T o = *p; *p = (T)(o - (T)v); return o; }
 template <typename T, typename U>

@@ -260,7 +260,9 @@ def test_emu_median_consumed_on_the_fly(emu):
     from scipy import ndimage
 
     rng = np.random.default_rng(5)
-    for shape in ((1, 2, 8), (2, 3, 16), (1, 5, 520), (2, 33, 24), (1, 40, 1032), (3, 17, 64)):
+    # (2, 70, 1040): 72 800 pixels per frame -- a batch this small gets EIGHT workgroups per frame, each tallying a band of
+    # rows into its own LDS window, merged through the frame's table; the second frame spills and goes to the full-range kernel
+    for shape in ((1, 2, 8), (2, 3, 16), (1, 5, 520), (2, 33, 24), (1, 40, 1032), (3, 17, 64), (2, 70, 1040)):
         for dt, code in ((np.uint16, PL_U16), (np.int16, PL_I16)):
             n, h, w = shape
             a = (rng.integers(1000, 1400, shape) + (np.arange(w) > w // 2) * 5000).astype(np.int64)
@@ -311,6 +313,15 @@ def test_emu_full_range_otsu_counter_overflow(emu):
         np.testing.assert_array_equal(thr, [orc.threshold_otsu(f) for f in a], err_msg=dt.__name__)
         np.testing.assert_array_equal(mn, a.reshape(n, -1).min(1))
         np.testing.assert_array_equal(mx, a.reshape(n, -1).max(1))
+        # (the window kernel's several-workgroups-per-frame form on frames that DO fit the window, plain path: 2 frames of
+        # 99 072 pixels get eight parts each, a ninth-of-a-vector tail included)
+        b = (rng.integers(3000, 9000, (2, h * w + 5)) - off).astype(dt)
+        t2, mn2, mx2, f2 = (np.zeros(2, np.int32) for _ in range(4))
+        _ok(emu, emu.pl_otsu16(_p(b), code, 2, h * w + 5, None, None, _p(t2), _p(mn2), _p(mx2), _p(f2), _p(hist), None))
+        assert not f2.any()
+        np.testing.assert_array_equal(t2, [orc.threshold_otsu(f) for f in b])
+        np.testing.assert_array_equal(mn2, b.min(1))
+        np.testing.assert_array_equal(mx2, b.max(1))
         med = np.stack([ndimage.median_filter(f, size=3) for f in a])
         scratch = np.zeros_like(a)
         _ok(emu, emu.pl_median3_otsu16(_p(a), _p(scratch), code, n, h, w, None, None, _p(thr), _p(mn), _p(mx), _p(flag), _p(hist), None))

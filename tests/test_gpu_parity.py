@@ -967,7 +967,8 @@ def test_median_consumed_on_the_fly_vs_scipy_and_oracle(dev):
     from pylinac_amd import ops
 
     rng = np.random.default_rng(77)
-    for shape in ((3, 200, 264), (2, 37, 1040), (4, 130, 64), (1, 16, 8)):
+    # (3, 512, 1024): a batch this small runs EIGHT workgroups per frame in the window kernel (bands of rows, merged table)
+    for shape in ((3, 200, 264), (2, 37, 1040), (4, 130, 64), (1, 16, 8), (3, 512, 1024)):
         for dt in (np.uint16, np.int16):
             a = (rng.integers(2000, 2600, shape) + (np.arange(shape[2]) > shape[2] // 2) * 9000).astype(np.int64)
             a[-1] = rng.integers(0, 65536, shape[1:])                # full range: the packed-counter kernel
