@@ -431,6 +431,7 @@ def main():
                                "peak_tops": 5000.0, "frac": round(n * (h // 16) * (w // 256) * 35 * 9 * 32768 / dom_s / 1e12 / 5000.0, 4)}
                               if dominant == "gauss2d" and h % 16 == 0 and w % 256 == 0 else None),
                 "pipeline_frac": round(value / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 4),
+                "otsu_full_range_frames": int(pipe.flag.sum()),   # frames the one-pass window could not hold (0 on this workload)
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             },
         }

@@ -474,8 +474,11 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
         const unsigned c = bins[i];
         if (c) seen |= atomicAdd(&table[i], c) == 0xffffffffu ? 1u : 0u;   // RETURNING: the wave waits for its adds
       }
-    const int never = __syncthreads_or((int)seen);           // (a count cannot reach 2^32 - 1)
-    if (threadIdx.x == 0) scr.any = atomicAdd(&table[65534], never ? 0u : 1u) == (unsigned)(parts - 1) ? 1 : 0;
+    // (a count cannot reach 2^32 - 1: `seen` stays 0; it exists so that the barrier below consumes the returned values.  Not
+    // __syncthreads_or: that brings static LDS in front of the bins, which must start at LDS address 0)
+    if (seen) scr.any = 2;
+    __syncthreads();
+    if (threadIdx.x == 0) scr.any = atomicAdd(&table[65534], scr.any == 2 ? 0u : 1u) == (unsigned)(parts - 1) ? 1 : 0;
     __syncthreads();
     if (scr.any == 0) return;                                // not the last part of this frame
     if (__hip_atomic_load(&flag[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // a part spilled: fallback

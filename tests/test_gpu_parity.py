@@ -982,6 +982,9 @@ def test_median_consumed_on_the_fly_vs_scipy_and_oracle(dev):
             assert np.array_equal(mn.cpu().numpy(), med.reshape(shape[0], -1).min(1)), (shape, dt)
             assert np.array_equal(mx.cpu().numpy(), med.reshape(shape[0], -1).max(1)), (shape, dt)
             assert int(flag[-1]) == 1 or shape[1] * shape[2] < 1000, (shape, dt, flag.cpu().tolist())
+            # the frames that fit the window must be finished by the window kernel itself (a silent trip through the
+            # full-range kernel gives the same numbers 50 % slower: round 4 lost a stage that way to a stray static LDS byte)
+            assert not flag[:-1].cpu().numpy().any(), (shape, dt, flag.cpu().tolist())
             if dt == np.uint16:
                 cut = torch.from_numpy(np.array([int(np.percentile(f, 40)) for f in med], dtype=np.int32)).to(dev)
                 out, cs = ops.median3_threshold_colsum_u16(t, cut)
