@@ -640,6 +640,16 @@ int pl_scaled_rowmean(const uint16_t* in, int64_t n, int h, int w, const double*
                       const int32_t* d_leaf_start, const int32_t* d_leaf_len, int nleaves, const int32_t* d_program, int nprog,
                       double* d_out, void* stream);
 
+/* Hill.fit (pylinac/core/hill.py:18-30: scipy.optimize.curve_fit(hill_func, x, y, p0 = (min(y), max(y), median(x), 0)) =
+ * MINPACK lmdif with scipy's defaults) for a batch of penumbra windows, one lane per fit (csrc/hill.hip restates the published
+ * Levenberg-Marquardt algorithm; SingleProfile.inflection_data fits two windows per profile, profile.py:1676-1708).
+ *   d_x / d_y float64 [n][stride] (fit i uses its first d_lens[i] samples; d_lens NULL = mmax for all), 4 <= samples <= mmax
+ *   <= 1024; d_work float64 [n][6 * mmax] scratch; d_params float64 [n][4] = a, b, c, d (NaN when the fit has fewer than four
+ *   samples); d_info int32 [n] = MINPACK's info (1-4 converged -- curve_fit accepts exactly these --, 5 maxfev, 6-8 tolerances
+ *   too small, -1 too few samples); d_nfev (optional) int32 [n] function evaluations. */
+int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
+                double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, void* stream);
+
 /* FWXMProfile.field_edge_idx/center_idx/field_width_px (pylinac/core/profile.py:602-611, 322-344)
  * from a pl_find_peaks result obtained with max_number = 1:
  * d_out float64 [n][8] = n_peaks, peak_idx, height, prominence, left, right, centre, width

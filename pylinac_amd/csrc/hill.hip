@@ -1,0 +1,431 @@
+// Batched four-parameter Hill fits (the Levenberg-Marquardt remainder).
+//
+// Replaces: pylinac.core.hill.Hill.fit (pylinac/core/hill.py:18-30) as SingleProfile.inflection_data calls it for both
+// penumbrae of a profile (pylinac/core/profile.py:1676-1708):
+//     curve_fit(hill_func, x_data, y_data, p0=(min(y), max(y), median(x), 0))
+// scipy.optimize.curve_fit without bounds or a Jacobian is scipy.optimize.leastsq = MINPACK's lmdif with ftol = xtol =
+// 1.49012e-8, gtol = 0, maxfev = 200 * (n + 1), epsfcn = machine epsilon, factor = 100, mode 1 (variables scaled by the
+// column norms of the Jacobian).  MINPACK is a third-party dependency of the reference (scipy >= 1.11, pyproject.toml:30-47),
+// absent from /root/reference; this file restates the PUBLISHED algorithm (More, "The Levenberg-Marquardt algorithm:
+// implementation and theory", 1978; the minpack routines lmdif, fdjac2, qrfac, lmpar, qrsolv, enorm): forward-difference
+// Jacobian, Householder QR with column pivoting, the trust-region parameter by More's iteration, the same acceptance and
+// termination tests -- so that the fit stops where scipy's stops.  Parity is anchored on the reference's own fitted
+// parameters and inflection points (tests/golden/hill.npz, produced by its SingleProfile / Hill through real scipy) at the
+// 1e-5 that row already uses downstream of a fit (the reference reproduces its OWN parameters only to ~1e-7 run to run:
+// numpy's vectorised pow is not bit-reproducible).
+//
+// One LANE per fit (n = 4 parameters, m <= 1024 samples): the batches this serves are thousands of penumbra windows of a few
+// dozen samples; the Jacobian (4 x m) and two m-vectors of a fit live in a caller-provided workspace in global memory.
+#include <math.h>
+
+#include "pl_common.h"
+
+namespace {
+
+constexpr int kHillN = 4;
+constexpr int kHillThreads = 64;
+
+__device__ __forceinline__ double hill_value(double x, const double* p) {
+  return p[0] + (p[1] - p[0]) / (1.0 + pow(p[2] / x, p[3]));       // hill_func, pylinac/core/hill.py:67-78
+}
+
+// minpack enorm: the Euclidean norm with separate accumulators for small, intermediate and large components
+__device__ double hill_enorm(int n, const double* x, int stride) {
+  const double rdwarf = 3.834e-20, rgiant = 1.304e19;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0, x1max = 0.0, x3max = 0.0;
+  const double agiant = rgiant / (double)n;
+  for (int i = 0; i < n; ++i) {
+    const double xabs = fabs(x[(size_t)i * stride]);
+    if (xabs > rdwarf && xabs < agiant) {
+      s2 += xabs * xabs;
+    } else if (xabs <= rdwarf) {
+      if (xabs > x3max) {
+        const double t = x3max / xabs;
+        s3 = 1.0 + s3 * (t * t);
+        x3max = xabs;
+      } else if (xabs != 0.0) {
+        const double t = xabs / x3max;
+        s3 += t * t;
+      }
+    } else {
+      if (xabs > x1max) {
+        const double t = x1max / xabs;
+        s1 = 1.0 + s1 * (t * t);
+        x1max = xabs;
+      } else {
+        const double t = xabs / x1max;
+        s1 += t * t;
+      }
+    }
+  }
+  if (s1 != 0.0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
+  if (s2 != 0.0) {
+    if (s2 >= x3max) return sqrt(s2 * (1.0 + (x3max / s2) * (x3max * s3)));
+    return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
+  }
+  return x3max * sqrt(s3);
+}
+
+// minpack qrsolv for n = 4: given the pivoted R (upper triangle of r, column-major r[j * 4 + i]; the strict lower triangle
+// is overwritten with the transposed strict upper triangle of S), solve for x with D x = 0 appended in the least squares
+// sense.  sdiag receives the diagonal of S.
+__device__ void hill_qrsolv(double* r, const int* ipvt, const double* diag, const double* qtb, double* x, double* sdiag,
+                            double* wa) {
+  constexpr int n = kHillN;
+  for (int j = 0; j < n; ++j) {
+    for (int i = j; i < n; ++i) r[j * n + i] = r[i * n + j];
+    x[j] = r[j * n + j];
+    wa[j] = qtb[j];
+  }
+  for (int j = 0; j < n; ++j) {
+    const int l = ipvt[j];
+    if (diag[l] != 0.0) {
+      for (int k = j; k < n; ++k) sdiag[k] = 0.0;
+      sdiag[j] = diag[l];
+      double qtbpj = 0.0;
+      for (int k = j; k < n; ++k) {
+        if (sdiag[k] == 0.0) continue;
+        double cs, sn;
+        if (fabs(r[k * n + k]) < fabs(sdiag[k])) {
+          const double cotan = r[k * n + k] / sdiag[k];
+          sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
+          cs = sn * cotan;
+        } else {
+          const double tn = sdiag[k] / r[k * n + k];
+          cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
+          sn = cs * tn;
+        }
+        r[k * n + k] = cs * r[k * n + k] + sn * sdiag[k];
+        const double temp = cs * wa[k] + sn * qtbpj;
+        qtbpj = -sn * wa[k] + cs * qtbpj;
+        wa[k] = temp;
+        for (int i = k + 1; i < n; ++i) {
+          const double t2 = cs * r[k * n + i] + sn * sdiag[i];
+          sdiag[i] = -sn * r[k * n + i] + cs * sdiag[i];
+          r[k * n + i] = t2;
+        }
+      }
+    }
+    sdiag[j] = r[j * n + j];
+    r[j * n + j] = x[j];
+  }
+  int nsing = n;
+  for (int j = 0; j < n; ++j) {
+    if (sdiag[j] == 0.0 && nsing == n) nsing = j;
+    if (nsing < n) wa[j] = 0.0;
+  }
+  for (int k = 0; k < nsing; ++k) {
+    const int j = nsing - 1 - k;
+    double sum = 0.0;
+    for (int i = j + 1; i < nsing; ++i) sum += r[j * n + i] * wa[i];
+    wa[j] = (wa[j] - sum) / sdiag[j];
+  }
+  for (int j = 0; j < n; ++j) x[ipvt[j]] = wa[j];
+}
+
+// minpack lmpar for n = 4: the Levenberg-Marquardt parameter par such that || D x || is within 10 % of delta
+__device__ void hill_lmpar(double* r, const int* ipvt, const double* diag, const double* qtb, double delta, double* par,
+                           double* x, double* sdiag, double* wa1, double* wa2) {
+  constexpr int n = kHillN;
+  const double dwarf = 2.2250738585072014e-308;
+  int nsing = n;
+  for (int j = 0; j < n; ++j) {
+    wa1[j] = qtb[j];
+    if (r[j * n + j] == 0.0 && nsing == n) nsing = j;
+    if (nsing < n) wa1[j] = 0.0;
+  }
+  for (int k = 0; k < nsing; ++k) {
+    const int j = nsing - 1 - k;
+    wa1[j] /= r[j * n + j];
+    const double temp = wa1[j];
+    for (int i = 0; i < j; ++i) wa1[i] -= r[j * n + i] * temp;
+  }
+  for (int j = 0; j < n; ++j) x[ipvt[j]] = wa1[j];
+  int iter = 0;
+  for (int j = 0; j < n; ++j) wa2[j] = diag[j] * x[j];
+  double dxnorm = hill_enorm(n, wa2, 1);
+  double fp = dxnorm - delta;
+  if (fp <= 0.1 * delta) {
+    if (iter == 0) *par = 0.0;
+    return;
+  }
+  double parl = 0.0;
+  if (nsing >= n) {
+    for (int j = 0; j < n; ++j) {
+      const int l = ipvt[j];
+      wa1[j] = diag[l] * (wa2[l] / dxnorm);
+    }
+    for (int j = 0; j < n; ++j) {
+      double sum = 0.0;
+      for (int i = 0; i < j; ++i) sum += r[j * n + i] * wa1[i];
+      wa1[j] = (wa1[j] - sum) / r[j * n + j];
+    }
+    const double temp = hill_enorm(n, wa1, 1);
+    parl = ((fp / delta) / temp) / temp;
+  }
+  for (int j = 0; j < n; ++j) {
+    double sum = 0.0;
+    for (int i = 0; i <= j; ++i) sum += r[j * n + i] * qtb[i];
+    wa1[j] = sum / diag[ipvt[j]];
+  }
+  const double gnorm = hill_enorm(n, wa1, 1);
+  double paru = gnorm / delta;
+  if (paru == 0.0) paru = dwarf / fmin(delta, 0.1);
+  *par = fmax(*par, parl);
+  *par = fmin(*par, paru);
+  if (*par == 0.0) *par = gnorm / dxnorm;
+  for (;;) {
+    ++iter;
+    if (*par == 0.0) *par = fmax(dwarf, 0.001 * paru);
+    const double temp = sqrt(*par);
+    for (int j = 0; j < n; ++j) wa1[j] = temp * diag[j];
+    hill_qrsolv(r, ipvt, wa1, qtb, x, sdiag, wa2);
+    for (int j = 0; j < n; ++j) wa2[j] = diag[j] * x[j];
+    dxnorm = hill_enorm(n, wa2, 1);
+    const double fp_old = fp;
+    fp = dxnorm - delta;
+    if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= fp_old && fp_old < 0.0) || iter == 10) return;
+    for (int j = 0; j < n; ++j) {
+      const int l = ipvt[j];
+      wa1[j] = diag[l] * (wa2[l] / dxnorm);
+    }
+    for (int j = 0; j < n; ++j) {
+      wa1[j] /= sdiag[j];
+      const double t2 = wa1[j];
+      for (int i = j + 1; i < n; ++i) wa1[i] -= r[j * n + i] * t2;
+    }
+    const double t3 = hill_enorm(n, wa1, 1);
+    const double parc = ((fp / delta) / t3) / t3;
+    if (fp > 0.0) parl = fmax(parl, *par);
+    if (fp < 0.0) paru = fmin(paru, *par);
+    *par = fmax(parl, *par + parc);
+  }
+}
+
+__global__ void __launch_bounds__(kHillThreads)
+hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, const int32_t* __restrict__ lens, int64_t nfits,
+                int mmax, int64_t stride, double* __restrict__ work /* [nfits][6 * mmax] */, double* __restrict__ params,
+                int32_t* __restrict__ info_out, int32_t* __restrict__ nfev_out) {
+  constexpr int n = kHillN;
+  const int64_t fit = (int64_t)blockIdx.x * kHillThreads + threadIdx.x;
+  if (fit >= nfits) return;
+  const int m = lens ? lens[fit] : mmax;
+  const double* xd = xs + fit * stride;
+  const double* yd = ys + fit * stride;
+  double* fjac = work + fit * 6 * (int64_t)mmax;          // column-major: fjac[j * mmax + i]
+  double* fvec = fjac + 4 * (int64_t)mmax;
+  double* wa4 = fvec + mmax;
+  double* out = params + fit * n;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  if (m < n || m > mmax) {                                  // curve_fit raises for fewer samples than parameters
+    for (int j = 0; j < n; ++j) out[j] = nan;
+    info_out[fit] = -1;
+    if (nfev_out) nfev_out[fit] = 0;
+    return;
+  }
+  // p0 = (min(y), max(y), np.median(x), 0): the median of the (sorted, as np.arange makes them) x values by selection
+  double x[n];
+  {
+    double mn = yd[0], mx = yd[0];
+    for (int i = 1; i < m; ++i) { mn = yd[i] < mn ? yd[i] : mn; mx = yd[i] > mx ? yd[i] : mx; }
+    // order statistics k_lo, k_hi of x by counting (m is a few dozen)
+    const int k_hi = m / 2, k_lo = (m & 1) ? k_hi : k_hi - 1;
+    double v_lo = 0.0, v_hi = 0.0;
+    for (int a = 0; a < m; ++a) {
+      const double va = xd[a];
+      int rank = 0;
+      for (int b = 0; b < m; ++b) rank += (xd[b] < va || (xd[b] == va && b < a)) ? 1 : 0;
+      if (rank == k_lo) v_lo = va;
+      if (rank == k_hi) v_hi = va;
+    }
+    x[0] = mn; x[1] = mx; x[2] = (m & 1) ? v_hi : (v_lo + v_hi) / 2.0; x[3] = 0.0;
+  }
+  const double epsmch = 2.220446049250313e-16;
+  const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
+  const int maxfev = 200 * (n + 1);
+  auto residuals = [&](const double* p, double* f) {        // curve_fit minimises func(x, *p) - y
+    for (int i = 0; i < m; ++i) f[i] = hill_value(xd[i], p) - yd[i];
+  };
+  double diag[n], qtf[n], wa1[n], wa2[n], wa3[n], r[n * n], sdiag[n];
+  int ipvt[n];
+  int info = 0, nfev = 1, iter = 1;
+  residuals(x, fvec);
+  double fnorm = hill_enorm(m, fvec, 1);
+  double par = 0.0, delta = 0.0, xnorm = 0.0;
+  bool done = false;
+  while (!done) {
+    // ---- fdjac2: forward differences
+    {
+      const double eps = sqrt(epsmch);                      // epsfcn = machine epsilon
+      for (int j = 0; j < n; ++j) {
+        const double temp = x[j];
+        double hstep = eps * fabs(temp);
+        if (hstep == 0.0) hstep = eps;
+        x[j] = temp + hstep;
+        residuals(x, wa4);
+        x[j] = temp;
+        for (int i = 0; i < m; ++i) fjac[(size_t)j * mmax + i] = (wa4[i] - fvec[i]) / hstep;
+      }
+      nfev += n;
+    }
+    // ---- qrfac with column pivoting (rdiag -> wa1, acnorm -> wa2, work -> wa3)
+    {
+      for (int j = 0; j < n; ++j) {
+        wa2[j] = hill_enorm(m, fjac + (size_t)j * mmax, 1);
+        wa1[j] = wa2[j];
+        wa3[j] = wa1[j];
+        ipvt[j] = j;
+      }
+      for (int j = 0; j < n; ++j) {
+        int kmax = j;
+        for (int k = j; k < n; ++k)
+          if (wa1[k] > wa1[kmax]) kmax = k;
+        if (kmax != j) {
+          for (int i = 0; i < m; ++i) {
+            const double t = fjac[(size_t)j * mmax + i];
+            fjac[(size_t)j * mmax + i] = fjac[(size_t)kmax * mmax + i];
+            fjac[(size_t)kmax * mmax + i] = t;
+          }
+          wa1[kmax] = wa1[j];
+          wa3[kmax] = wa3[j];
+          const int k = ipvt[j]; ipvt[j] = ipvt[kmax]; ipvt[kmax] = k;
+        }
+        double ajnorm = hill_enorm(m - j, fjac + (size_t)j * mmax + j, 1);
+        if (ajnorm != 0.0) {
+          if (fjac[(size_t)j * mmax + j] < 0.0) ajnorm = -ajnorm;
+          for (int i = j; i < m; ++i) fjac[(size_t)j * mmax + i] /= ajnorm;
+          fjac[(size_t)j * mmax + j] += 1.0;
+          for (int k = j + 1; k < n; ++k) {
+            double sum = 0.0;
+            for (int i = j; i < m; ++i) sum += fjac[(size_t)j * mmax + i] * fjac[(size_t)k * mmax + i];
+            const double temp = sum / fjac[(size_t)j * mmax + j];
+            for (int i = j; i < m; ++i) fjac[(size_t)k * mmax + i] -= temp * fjac[(size_t)j * mmax + i];
+            if (wa1[k] != 0.0) {
+              double t = fjac[(size_t)k * mmax + j] / wa1[k];
+              t = 1.0 - t * t;
+              wa1[k] *= sqrt(t > 0.0 ? t : 0.0);
+              const double q = wa1[k] / wa3[k];
+              if (0.05 * (q * q) <= epsmch) {
+                wa1[k] = hill_enorm(m - j - 1, fjac + (size_t)k * mmax + j + 1, 1);
+                wa3[k] = wa1[k];
+              }
+            }
+          }
+        }
+        wa1[j] = -ajnorm;
+      }
+    }
+    if (iter == 1) {
+      for (int j = 0; j < n; ++j) {
+        diag[j] = wa2[j];
+        if (wa2[j] == 0.0) diag[j] = 1.0;
+      }
+      for (int j = 0; j < n; ++j) wa3[j] = diag[j] * x[j];
+      xnorm = hill_enorm(n, wa3, 1);
+      delta = factor * xnorm;
+      if (delta == 0.0) delta = factor;
+    }
+    // ---- (q transpose) * fvec, first n components in qtf
+    for (int i = 0; i < m; ++i) wa4[i] = fvec[i];
+    for (int j = 0; j < n; ++j) {
+      if (fjac[(size_t)j * mmax + j] != 0.0) {
+        double sum = 0.0;
+        for (int i = j; i < m; ++i) sum += fjac[(size_t)j * mmax + i] * wa4[i];
+        const double temp = -sum / fjac[(size_t)j * mmax + j];
+        for (int i = j; i < m; ++i) wa4[i] += fjac[(size_t)j * mmax + i] * temp;
+      }
+      fjac[(size_t)j * mmax + j] = wa1[j];
+      qtf[j] = wa4[j];
+    }
+    // the n x n upper triangle R (column j, rows 0 .. j) in a register-sized copy: r[j * n + i]
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) r[j * n + i] = i <= j ? fjac[(size_t)j * mmax + i] : 0.0;
+    // ---- norm of the scaled gradient
+    double gnorm = 0.0;
+    if (fnorm != 0.0)
+      for (int j = 0; j < n; ++j) {
+        const int l = ipvt[j];
+        if (wa2[l] == 0.0) continue;
+        double sum = 0.0;
+        for (int i = 0; i <= j; ++i) sum += r[j * n + i] * (qtf[i] / fnorm);
+        gnorm = fmax(gnorm, fabs(sum / wa2[l]));
+      }
+    if (gnorm <= gtol) { info = 4; break; }
+    for (int j = 0; j < n; ++j) diag[j] = fmax(diag[j], wa2[j]);
+    // ---- inner loop: steps until one is accepted
+    for (;;) {
+      double rr[n * n];
+      for (int k = 0; k < n * n; ++k) rr[k] = r[k];       // lmpar / qrsolv scribble on the lower triangle
+      hill_lmpar(rr, ipvt, diag, qtf, delta, &par, wa1, sdiag, wa2, wa3);
+      double xnew[n];
+      for (int j = 0; j < n; ++j) {
+        wa1[j] = -wa1[j];
+        xnew[j] = x[j] + wa1[j];
+        wa3[j] = diag[j] * wa1[j];
+      }
+      const double pnorm = hill_enorm(n, wa3, 1);
+      if (iter == 1) delta = fmin(delta, pnorm);
+      residuals(xnew, wa4);
+      ++nfev;
+      const double fnorm1 = hill_enorm(m, wa4, 1);
+      double actred = -1.0;
+      if (0.1 * fnorm1 < fnorm) { const double t = fnorm1 / fnorm; actred = 1.0 - t * t; }
+      for (int j = 0; j < n; ++j) wa3[j] = 0.0;
+      for (int j = 0; j < n; ++j) {
+        const double temp = wa1[ipvt[j]];
+        for (int i = 0; i <= j; ++i) wa3[i] += r[j * n + i] * temp;
+      }
+      const double temp1 = hill_enorm(n, wa3, 1) / fnorm;
+      const double temp2 = (sqrt(par) * pnorm) / fnorm;
+      const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+      const double dirder = -(temp1 * temp1 + temp2 * temp2);
+      const double ratio = prered != 0.0 ? actred / prered : 0.0;
+      if (ratio <= 0.25) {
+        double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+        if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+        delta = temp * fmin(delta, pnorm / 0.1);
+        par /= temp;
+      } else if (par == 0.0 || ratio >= 0.75) {
+        delta = pnorm / 0.5;
+        par *= 0.5;
+      }
+      if (ratio >= 1.0e-4) {                                // successful iteration
+        for (int j = 0; j < n; ++j) {
+          x[j] = xnew[j];
+          wa2[j] = diag[j] * x[j];
+        }
+        for (int i = 0; i < m; ++i) fvec[i] = wa4[i];
+        xnorm = hill_enorm(n, wa2, 1);
+        fnorm = fnorm1;
+        ++iter;
+      }
+      const bool small_red = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
+      if (small_red) info = 1;
+      if (delta <= xtol * xnorm) info = 2;
+      if (small_red && info == 2) info = 3;
+      if (info != 0) { done = true; break; }
+      if (nfev >= maxfev) info = 5;
+      if (fabs(actred) <= epsmch && prered <= epsmch && 0.5 * ratio <= 1.0) info = 6;
+      if (delta <= epsmch * xnorm) info = 7;
+      if (gnorm <= epsmch) info = 8;
+      if (info != 0) { done = true; break; }
+      if (ratio >= 1.0e-4) break;                           // next outer iteration: a new Jacobian
+    }
+  }
+  for (int j = 0; j < n; ++j) out[j] = x[j];
+  info_out[fit] = info;
+  if (nfev_out) nfev_out[fit] = nfev;
+}
+
+}  // namespace
+
+extern "C" int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
+                           double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, void* stream) {
+  PL_REQUIRE(d_x && d_y && d_work && d_params && d_info, "null pointer");
+  PL_REQUIRE(n >= 0 && mmax >= 4 && mmax <= 1024 && stride >= mmax, "bad shape (4 .. 1024 samples per fit)");
+  if (n == 0) return PL_OK;
+  PL_REQUIRE(pl_cdiv(n, kHillThreads) <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(hill_fit_kernel, dim3((unsigned)pl_cdiv(n, kHillThreads)), dim3(kHillThreads), 0, (hipStream_t)stream, d_x, d_y,
+                     d_lens, n, mmax, stride, d_work, d_params, d_info, d_nfev);
+  return pl_check_launch("pl_hill_fit");
+}

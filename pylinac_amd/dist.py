@@ -30,7 +30,9 @@ def all_gather_records(local: torch.Tensor, n_total: int | None = None, pending:
     stopped the host from running ahead of the device, 60 us per step on one rank).  ``pending``: when a list is given and the
     shards are even, the collective is issued with ``async_op=True`` and its work handle appended; the returned tensor is
     complete once that handle's ``wait()`` has been called (or the device synchronised) -- the gather of step k then overlaps
-    the kernels of step k + 1 (RCCL runs on its own stream)."""
+    the kernels of step k + 1 (RCCL runs on its own stream).  With uneven shards the call is synchronous whatever ``pending``
+    is.  Which of the two paths runs is decided from ``n_total`` and the world size alone, so every rank issues the same
+    collective; a rank whose shard does not match an even split raises."""
     if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size()
@@ -46,8 +48,8 @@ def all_gather_records(local: torch.Tensor, n_total: int | None = None, pending:
         else:
             dist.all_gather_into_tensor(out, local.contiguous())
         return out
-    if pending is not None:
-        raise ValueError("all_gather_records: the asynchronous form needs even shards (n_total divisible by the world size)")
+    # uneven shards: the size exchange below needs the host anyway, so this path is synchronous -- `pending` receives
+    # nothing and the returned tensor is complete (callers that drain `pending` before reading stay correct)
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local)

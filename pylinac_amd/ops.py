@@ -550,6 +550,32 @@ def peak_valley_regions(profiles: torch.Tensor, peak_kwargs: list, valley_kwargs
     return pc, ph, vc, vv, means
 
 
+def hill_fit(x: torch.Tensor, y: torch.Tensor, lens: torch.Tensor | None = None):
+    """``Hill.fit`` (pylinac/core/hill.py:18-30 = ``scipy.optimize.curve_fit`` with the reference's start values) for a batch
+    of windows on the device (``pl_hill_fit``: MINPACK's Levenberg-Marquardt restated, one lane per fit).  ``x``, ``y``
+    float64 [N, M]; ``lens`` int32 [N] for ragged windows.  -> (params float64 [N, 4] = a, b, c, d; info int32 [N]: 1-4 =
+    converged, what ``curve_fit`` accepts; nfev int32 [N])."""
+    xs = x.to(torch.float64).contiguous()
+    ys = y.to(torch.float64).contiguous()
+    if xs.dim() != 2 or xs.shape != ys.shape:
+        raise ValueError("x and y must be [N, M] of the same shape")
+    if not xs.is_cuda:
+        raise ValueError("the windows must live on the GPU")
+    n, m = xs.shape
+    if not 4 <= m <= 1024:
+        raise ValueError("4 .. 1024 samples per fit")
+    dev = xs.device
+    work = torch.empty((n, 6 * m), dtype=torch.float64, device=dev)
+    params = torch.empty((n, 4), dtype=torch.float64, device=dev)
+    info = torch.empty(n, dtype=torch.int32, device=dev)
+    nfev = torch.empty(n, dtype=torch.int32, device=dev)
+    if lens is not None:
+        lens = lens.to(device=dev, dtype=torch.int32).contiguous()
+    check(_lib.load().pl_hill_fit(xs.data_ptr(), ys.data_ptr(), 0 if lens is None else lens.data_ptr(), n, m, xs.stride(0),
+                                  work.data_ptr(), params.data_ptr(), info.data_ptr(), nfev.data_ptr(), _stream()), "pl_hill_fit")
+    return params, info, nfev
+
+
 def fwxm_record(res: PeakBatch, out=None) -> torch.Tensor:
     """FWXMProfile edges / centre / width from a ``max_number=1`` peak batch -> float64 [N, 8]."""
     n = res.count.shape[0]
