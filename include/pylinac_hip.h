@@ -650,6 +650,28 @@ int pl_scaled_rowmean(const uint16_t* in, int64_t n, int h, int w, const double*
 int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
                 double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, void* stream);
 
+/* The two penumbra windows SingleProfile.inflection_data fits (pylinac/core/profile.py:1676-1700) for a batch of processed
+ * profiles sharing x_indices: left_idx / right_idx = _x_interp_to_original(first derivative peak / last valley),
+ * half = int(round(window_ratio * |right - left| / 2)), x = np.arange(idx - half, idx + half) filtered to x >= 0 (left) or
+ * x < s (right), y = _y_original_to_interp(x) (scipy's linear interp1d, extrapolating).
+ *   d_x_indices float64 [s]; d_values float64 [n][s]; peaks / valleys as pl_find_peaks_regions returns them (index order);
+ *   d_xw / d_yw float64 [2n][mmax] (fit 2i = left, 2i + 1 = right window of profile i); d_lens int32 [2n] (0 and NaN edges when
+ *   the derivative has no peak or valley -- the reference raises IndexError; negative = longer than mmax, nothing written);
+ *   d_edges float64 [n][2] = left_idx, right_idx (the INFLECTION_DERIVATIVE edges). */
+int pl_hill_windows(const double* d_x_indices, const double* d_values, int64_t n, int s, const int32_t* d_peak_count,
+                    const int32_t* d_peak_idx, int cap_peaks, const int32_t* d_valley_count, const int32_t* d_valley_idx,
+                    int cap_valleys, double window_ratio, int mmax, double* d_xw, double* d_yw, int32_t* d_lens, double* d_edges,
+                    void* stream);
+
+/* Hill.inflection_idx and Hill.y there (pylinac/core/hill.py:32-36, 56-65): d_params float64 [n][4] -> d_out float64 [n][2] =
+ * c * ((d - 1) / (d + 1)) ** (1 / d), and the curve's value at it. */
+int pl_hill_inflection(const double* d_params, int64_t n, double* d_out, void* stream);
+
+/* SingleProfile._y_original_to_interp (pylinac/core/profile.py:1227-1235) per profile: d_out[i][j] = scipy's linear interp1d
+ * (x_indices, values_i, extrapolating) at d_q[i][j].  d_x_indices float64 [s], d_values float64 [n][s], d_q / d_out [n][nq]. */
+int pl_profile_lookup(const double* d_x_indices, const double* d_values, int64_t n, int s, const double* d_q, int nq,
+                      double* d_out, void* stream);
+
 /* FWXMProfile.field_edge_idx/center_idx/field_width_px (pylinac/core/profile.py:602-611, 322-344)
  * from a pl_find_peaks result obtained with max_number = 1:
  * d_out float64 [n][8] = n_peaks, peak_idx, height, prominence, left, right, centre, width

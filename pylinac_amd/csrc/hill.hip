@@ -417,6 +417,105 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
   if (nfev_out) nfev_out[fit] = nfev;
 }
 
+// first index i in [0, n) with x[i] >= v (np.searchsorted side="left"), n if none
+__device__ __forceinline__ int hill_lower_bound(const double* __restrict__ x, int n, double v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (x[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// scipy's linear interp1d with extrapolation (SingleProfile._y_original_to_interp, profile.py:1227-1235)
+__device__ __forceinline__ double hill_lookup(const double* __restrict__ xi, const double* __restrict__ v, int S, double q) {
+  int hi = hill_lower_bound(xi, S, q);
+  hi = hi < 1 ? 1 : (hi > S - 1 ? S - 1 : hi);
+  const int lo = hi - 1;
+  const double slope = (v[hi] - v[lo]) / (xi[hi] - xi[lo]);
+  return slope * (q - xi[lo]) + v[lo];
+}
+
+// The two penumbra windows of SingleProfile.inflection_data (profile.py:1676-1700), one workgroup per profile:
+//   left_idx  = _x_interp_to_original(first peak of the derivative), right_idx = ...(last valley)
+//   half      = int(round(hill_window_ratio * abs(right_idx - left_idx) / 2))
+//   x_left    = [x for x in np.arange(left_idx - half, left_idx + half) if x >= 0]
+//   x_right   = [x for x in np.arange(right_idx - half, right_idx + half) if x < len(d1)]
+//   y         = _y_original_to_interp(x)
+// np.arange on floats: length = ceil(stop - start), element 0 = start, element 1 = start + 1.0, element i = start + i * delta
+// with delta = element 1 - element 0 (numpy's DOUBLE_fill) -- restated so that the windows are the reference's bit for bit.
+__global__ void __launch_bounds__(kHillThreads)
+hill_windows_kernel(const double* __restrict__ xi, const double* __restrict__ values, int S, const int32_t* __restrict__ pk_count,
+                    const int32_t* __restrict__ pk_idx, int cap_p, const int32_t* __restrict__ vl_count,
+                    const int32_t* __restrict__ vl_idx, int cap_v, double ratio, int mmax, double* __restrict__ xw,
+                    double* __restrict__ yw, int32_t* __restrict__ lens, double* __restrict__ edges) {
+  const int64_t p = blockIdx.x;
+  const double* v = values + p * (int64_t)S;
+  const int np_ = pk_count[p], nv = vl_count[p];
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  if (np_ <= 0 || nv <= 0) {                                // the reference indexes an empty list here (IndexError)
+    if (threadIdx.x == 0) {
+      lens[2 * p] = lens[2 * p + 1] = 0;
+      edges[2 * p] = edges[2 * p + 1] = nan;
+    }
+    return;
+  }
+  auto to_original = [&](int k) {                           // _x_interp_to_original: interp1d(arange(S), x_indices)(k)
+    int hi = k < 1 ? 1 : (k > S - 1 ? S - 1 : k);
+    const int lo = hi - 1;
+    const double slope = (xi[hi] - xi[lo]) / ((double)hi - (double)lo);
+    return slope * ((double)k - (double)lo) + xi[lo];
+  };
+  const double left = to_original(pk_idx[p * cap_p]);
+  const double right = to_original(vl_idx[p * cap_v + (nv < cap_v ? nv : cap_v) - 1]);
+  const double half = rint(ratio * fabs(right - left) / 2.0);          // python's round(): half to even
+  if (threadIdx.x == 0) { edges[2 * p] = left; edges[2 * p + 1] = right; }
+  for (int side = 0; side < 2; ++side) {
+    const double mid = side ? right : left;
+    const double start = mid - half, stop = mid + half;
+    const double span = ceil(stop - start);
+    int len = span > 0.0 ? (span > 1.0e9 ? 1000000000 : (int)span) : 0;
+    const double next = start + 1.0;
+    const double delta = next - start;
+    auto at = [&](int i) { return i == 0 ? start : (i == 1 ? next : start + (double)i * delta); };
+    // the filters keep a suffix (x >= 0) or a prefix (x < S) of the increasing sequence
+    int first = 0;
+    if (side == 0) {
+      while (first < len && !(at(first) >= 0.0)) ++first;
+    } else {
+      while (len > 0 && !(at(len - 1) < (double)S)) --len;
+    }
+    int m = len - first;
+    if (m > mmax) m = -m;                                   // cannot happen for the mmax the host sizes; reported, not truncated
+    const int64_t f = 2 * p + side;
+    if (threadIdx.x == 0) lens[f] = m;
+    for (int j = threadIdx.x; j < m; j += kHillThreads) {
+      const double x = at(first + j);
+      xw[f * mmax + j] = x;
+      yw[f * mmax + j] = hill_lookup(xi, v, S, x);
+    }
+  }
+}
+
+// Hill.inflection_idx and Hill.y at it (pylinac/core/hill.py:32-36, 56-65)
+__global__ void hill_inflection_kernel(const double* __restrict__ params, int64_t nfits, double* __restrict__ out) {
+  const int64_t f = (int64_t)blockIdx.x * kHillThreads + threadIdx.x;
+  if (f >= nfits) return;
+  const double* p = params + f * 4;
+  const double idx = p[2] * pow((p[3] - 1.0) / (p[3] + 1.0), 1.0 / p[3]);
+  out[2 * f] = idx;
+  out[2 * f + 1] = hill_value(idx, p);
+}
+
+// per-profile look-ups values_i(q_ij) through scipy's linear interp1d (SingleProfile._y_original_to_interp)
+__global__ void profile_lookup_kernel(const double* __restrict__ xi, const double* __restrict__ values, int S,
+                                      const double* __restrict__ q, int nq, int64_t total, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kHillThreads + threadIdx.x;
+  if (i >= total) return;
+  out[i] = hill_lookup(xi, values + (i / nq) * (int64_t)S, S, q[i]);
+}
+
 }  // namespace
 
 extern "C" int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
@@ -428,4 +527,41 @@ extern "C" int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* 
   hipLaunchKernelGGL(hill_fit_kernel, dim3((unsigned)pl_cdiv(n, kHillThreads)), dim3(kHillThreads), 0, (hipStream_t)stream, d_x, d_y,
                      d_lens, n, mmax, stride, d_work, d_params, d_info, d_nfev);
   return pl_check_launch("pl_hill_fit");
+}
+
+extern "C" int pl_hill_windows(const double* d_x_indices, const double* d_values, int64_t n, int s, const int32_t* d_peak_count,
+                               const int32_t* d_peak_idx, int cap_peaks, const int32_t* d_valley_count,
+                               const int32_t* d_valley_idx, int cap_valleys, double window_ratio, int mmax, double* d_xw,
+                               double* d_yw, int32_t* d_lens, double* d_edges, void* stream) {
+  PL_REQUIRE(d_x_indices && d_values && d_peak_count && d_peak_idx && d_valley_count && d_valley_idx && d_xw && d_yw && d_lens &&
+                 d_edges, "null pointer");
+  PL_REQUIRE(n >= 0 && s >= 2 && cap_peaks >= 1 && cap_valleys >= 1 && mmax >= 1, "bad shape");
+  if (n == 0) return PL_OK;
+  PL_REQUIRE(n <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(hill_windows_kernel, dim3((unsigned)n), dim3(kHillThreads), 0, (hipStream_t)stream, d_x_indices, d_values, s,
+                     d_peak_count, d_peak_idx, cap_peaks, d_valley_count, d_valley_idx, cap_valleys, window_ratio, mmax, d_xw, d_yw,
+                     d_lens, d_edges);
+  return pl_check_launch("pl_hill_windows");
+}
+
+extern "C" int pl_hill_inflection(const double* d_params, int64_t n, double* d_out, void* stream) {
+  PL_REQUIRE(d_params && d_out, "null pointer");
+  PL_REQUIRE(n >= 0, "bad shape");
+  if (n == 0) return PL_OK;
+  PL_REQUIRE(pl_cdiv(n, kHillThreads) <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(hill_inflection_kernel, dim3((unsigned)pl_cdiv(n, kHillThreads)), dim3(kHillThreads), 0, (hipStream_t)stream,
+                     d_params, n, d_out);
+  return pl_check_launch("pl_hill_inflection");
+}
+
+extern "C" int pl_profile_lookup(const double* d_x_indices, const double* d_values, int64_t n, int s, const double* d_q, int nq,
+                                 double* d_out, void* stream) {
+  PL_REQUIRE(d_x_indices && d_values && d_q && d_out, "null pointer");
+  PL_REQUIRE(n >= 0 && s >= 2 && nq >= 1, "bad shape");
+  if (n == 0) return PL_OK;
+  const int64_t total = n * nq;
+  PL_REQUIRE(pl_cdiv(total, kHillThreads) <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(profile_lookup_kernel, dim3((unsigned)pl_cdiv(total, kHillThreads)), dim3(kHillThreads), 0,
+                     (hipStream_t)stream, d_x_indices, d_values, s, d_q, nq, total, d_out);
+  return pl_check_launch("pl_profile_lookup");
 }

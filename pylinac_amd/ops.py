@@ -576,6 +576,48 @@ def hill_fit(x: torch.Tensor, y: torch.Tensor, lens: torch.Tensor | None = None)
     return params, info, nfev
 
 
+def hill_windows(x_indices: torch.Tensor, values: torch.Tensor, peaks: PeakBatch, valleys: PeakBatch, window_ratio: float,
+                 mmax: int):
+    """The penumbra windows of ``SingleProfile.inflection_data`` (pylinac/core/profile.py:1676-1700) for processed profiles
+    ``values`` float64 [N, S] sharing ``x_indices`` [S]; ``peaks`` / ``valleys`` = the derivative's extrema (index order).
+    -> (xw, yw float64 [2N, mmax], lens int32 [2N], edges float64 [N, 2] = left_idx, right_idx)."""
+    v = values.to(torch.float64).contiguous()
+    xi = x_indices.to(device=v.device, dtype=torch.float64).contiguous()
+    n, s = v.shape
+    if xi.numel() != s:
+        raise ValueError("x_indices and values must have the same length")
+    dev = v.device
+    xw = torch.zeros((2 * n, mmax), dtype=torch.float64, device=dev)
+    yw = torch.zeros((2 * n, mmax), dtype=torch.float64, device=dev)
+    lens = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    edges = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    check(_lib.load().pl_hill_windows(xi.data_ptr(), v.data_ptr(), n, s, peaks.count.data_ptr(), peaks.idx.data_ptr(),
+                                      peaks.idx.shape[1], valleys.count.data_ptr(), valleys.idx.data_ptr(), valleys.idx.shape[1],
+                                      float(window_ratio), int(mmax), xw.data_ptr(), yw.data_ptr(), lens.data_ptr(),
+                                      edges.data_ptr(), _stream()), "pl_hill_windows")
+    return xw, yw, lens, edges
+
+
+def hill_inflection(params: torch.Tensor) -> torch.Tensor:
+    """``Hill.inflection_idx`` and ``Hill.y`` there (pylinac/core/hill.py:32-36, 56-65): params [..., 4] -> [..., 2]."""
+    p = params.to(torch.float64).contiguous()
+    out = torch.empty(p.shape[:-1] + (2,), dtype=torch.float64, device=p.device)
+    check(_lib.load().pl_hill_inflection(p.data_ptr(), p.numel() // 4, out.data_ptr(), _stream()), "pl_hill_inflection")
+    return out
+
+
+def profile_lookup(x_indices: torch.Tensor, values: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    """``SingleProfile._y_original_to_interp`` per profile: values float64 [N, S], q float64 [N, Q] (or [N]) -> like q."""
+    v = values.to(torch.float64).contiguous()
+    xi = x_indices.to(device=v.device, dtype=torch.float64).contiguous()
+    n, s = v.shape
+    qq = q.to(torch.float64).reshape(n, -1).contiguous()
+    out = torch.empty_like(qq)
+    check(_lib.load().pl_profile_lookup(xi.data_ptr(), v.data_ptr(), n, s, qq.data_ptr(), qq.shape[1], out.data_ptr(),
+                                        _stream()), "pl_profile_lookup")
+    return out.reshape(q.shape)
+
+
 def fwxm_record(res: PeakBatch, out=None) -> torch.Tensor:
     """FWXMProfile edges / centre / width from a ``max_number=1`` peak batch -> float64 [N, 8]."""
     n = res.count.shape[0]

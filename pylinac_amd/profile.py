@@ -1106,6 +1106,133 @@ class SingleProfile:
             return fv.min()
 
 
+@dataclass
+class HillEdgesBatch:
+    """What ``SingleProfile(..., edge_detection_method=INFLECTION_HILL)`` holds and ``inflection_data()`` returns, for every
+    row of a batch (:func:`single_profile_hill_batch`); everything stays on the device."""
+
+    values: torch.Tensor            # float64 [N, S]   the processed profiles (SingleProfile.values)
+    x_indices: np.ndarray           # float64 [S]      SingleProfile.x_indices (shared)
+    dpmm: float | None
+    params: torch.Tensor            # float64 [N, 2, 4] "left / right Hill params"
+    index: torch.Tensor             # float64 [N, 2]   "left / right index (exact)": the Hill inflection points
+    value: torch.Tensor             # float64 [N, 2]   "left / right value (@exact)"
+    derivative_edges: torch.Tensor  # float64 [N, 2]   the windows' centres (the INFLECTION_DERIVATIVE edges)
+    info: torch.Tensor              # int32 [N, 2]     MINPACK info: 1-4 = converged (what curve_fit accepts); 5-8 = curve_fit
+                                    #                  raises RuntimeError; -1 = fewer than four samples in the window (TypeError);
+                                    #                  -2 = no derivative peak / valley (IndexError); -3 = more extrema than peak_cap
+    nfev: torch.Tensor              # int32 [N, 2]
+
+    def inflection_data(self, i: int) -> dict:
+        """The reference's dictionary (profile.py:1701-1721) for profile ``i`` -- a host copy of eight numbers."""
+        info = self.info[i].cpu().numpy()
+        for side, code in zip(("left", "right"), info):
+            if code == -3:
+                raise _lib_error(f"profile {i}: more derivative extrema than peak_cap; raise it")
+            if code == -2:
+                raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+            if code == -1:
+                raise TypeError("The number of func parameters=4 must not exceed the number of data points")
+            if not 1 <= code <= 4:
+                raise RuntimeError(f"Optimal parameters not found ({side} penumbra of profile {i}: MINPACK info {code})")
+        idx, val, prm = self.index[i].cpu().numpy(), self.value[i].cpu().numpy(), self.params[i].cpu().numpy()
+        return {
+            "left index (rounded)": int(round(float(idx[0]))),
+            "left index (exact)": float(idx[0]),
+            "right index (rounded)": int(round(float(idx[1]))),
+            "right index (exact)": float(idx[1]),
+            "left value (@exact)": float(val[0]),
+            "right value (@exact)": float(val[1]),
+            "left Hill params": prm[0],
+            "right Hill params": prm[1],
+        }
+
+
+def _lib_error(msg: str):
+    from ._lib import PylinacHipError
+
+    return PylinacHipError(msg)
+
+
+def _hill_edges_stage(vals: torch.Tensor, xi_dev: torch.Tensor, span: float, edge_smoothing_ratio: float, ratio: float,
+                      peak_cap: int):
+    """``SingleProfile.inflection_data`` (profile.py:1635-1721) for every row: seven launches, no host round trip."""
+    n, s = vals.shape
+    sm = ops.gaussian_filter1d(vals, edge_smoothing_ratio * s)
+    d1 = ops.gradient1d(sm)
+    cap = max(min(peak_cap, s // 2 + 1), 1)
+    pk = ops.find_peaks_batch(d1, cap=cap, threshold=0.8, peak_separation=0.05)      # MultiProfile(d1).find_peaks
+    vl = ops.find_peaks_batch(-d1, cap=cap, threshold=0.8, peak_separation=0.05)     # MultiProfile(d1).find_valleys
+    mmax = max(int(ratio * span) + 3, 4)
+    if mmax > 1024:
+        raise ValueError("hill_window_ratio x field width: more than 1024 samples per window")
+    xw, yw, lens, edges = ops.hill_windows(xi_dev, vals, pk, vl, ratio, mmax)
+    params, info, nfev = ops.hill_fit(xw, yw, lens)
+    infl = ops.hill_inflection(params)
+    no_edge = torch.isnan(edges).any(dim=1).repeat_interleave(2)
+    overflow = ((pk.status != 0) | (vl.status != 0)).repeat_interleave(2)
+    info = torch.where(no_edge, torch.full_like(info, -2), info)
+    info = torch.where(overflow, torch.full_like(info, -3), info)
+    return params.view(n, 2, 4), infl.view(n, 2, 2), edges, info.view(n, 2), nfev.view(n, 2)
+
+
+def single_profile_hill_batch(values, dpmm: float | None = None, interpolation=Interpolation.LINEAR, ground: bool = True,
+                              interpolation_resolution_mm: float = 0.1, interpolation_factor: float = 10,
+                              normalization_method=Normalization.BEAM_CENTER, edge_smoothing_ratio: float = 0.003,
+                              hill_window_ratio: float = 0.1, peak_cap: int = 32) -> HillEdgesBatch:
+    """``SingleProfile(values_i, ..., edge_detection_method=Edge.INFLECTION_HILL)`` followed by ``inflection_data()`` for every
+    row of ``values`` [N, L] (equal lengths, x = 0 .. L-1: the rows of an image, a detector array's frames) with no per-profile
+    host call: the constructor's resampling, grounding and normalisation (pylinac/core/profile.py:1165-1215), the smoothed
+    derivative and its extrema, both penumbra windows and both four-parameter fits (profile.py:1635-1721, hill.py:18-36) are
+    batched launches.  BEAM_CENTER normalisation runs the edge search twice, like the reference's constructor (the norm value is
+    the profile at the midpoint of the two Hill inflection points).  Rows whose search or fit fails are reported in ``info``
+    (their results are NaN), not raised."""
+    interp = _enum(interpolation, Interpolation)
+    norm = _enum(normalization_method, Normalization)
+    v = values if isinstance(values, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64))
+    if v.dim() != 2:
+        raise ValueError("values must be [N, L]")
+    if v.numel() == 0:
+        raise ValueError("Array must not be empty")
+    if not v.is_cuda:
+        v = v.to(au._device())
+    v = v.to(torch.float64).contiguous()
+    n, length = v.shape
+    x_values = np.arange(length)
+    if interp == Interpolation.NONE:
+        fitted, x_indices = v, x_values.astype(np.float64)
+    else:                                                   # SingleProfile._interpolate (profile.py:1306-1360)
+        if dpmm is not None:
+            samples = int(round(length / (dpmm * interpolation_resolution_mm)))
+        else:
+            samples = int(round(length * interpolation_factor))
+        offset = 0.5 - 1 / (2 * (samples / length))
+        x_indices = np.linspace(x_values[0] - offset, x_values[-1] + offset, num=samples)
+        xs = torch.from_numpy(x_values.astype(np.float64)).to(v.device)
+        fitted = ops.interp1d(xs, v, torch.from_numpy(x_indices).to(v.device),
+                              kind="linear" if interp == Interpolation.LINEAR else "cubic")
+    xi_dev = torch.from_numpy(np.ascontiguousarray(x_indices)).to(v.device)
+    span = float(x_indices[-1] - x_indices[0])
+    if ground:
+        fitted = ops.ground(fitted.unsqueeze(1)).squeeze(1)
+    if norm == Normalization.MAX:
+        fitted = ops.normalize(fitted.unsqueeze(1)).squeeze(1)
+    elif norm == Normalization.GEOMETRIC_CENTER:            # array_utils.geometric_center_value
+        s = fitted.shape[1]
+        gc = (fitted[:, s // 2] + fitted[:, s // 2 - 1]) / 2.0 if s % 2 == 0 else fitted[:, (s - 1) // 2]
+        fitted = ops.normalize(fitted.unsqueeze(1), gc.contiguous()).squeeze(1)
+    elif norm == Normalization.BEAM_CENTER:                 # beam_center() (profile.py:1390-1409) on the unnormalised profile
+        _, infl, _, _, _ = _hill_edges_stage(fitted, xi_dev, span, edge_smoothing_ratio, hill_window_ratio, peak_cap)
+        left, right = infl[:, 0, 0], infl[:, 1, 0]
+        mid = torch.round(left + (right - left) / 2)        # int(round(mid_point)): half to even, like python's
+        centre = ops.profile_lookup(xi_dev, fitted, mid.contiguous())
+        fitted = ops.normalize(fitted.unsqueeze(1), centre.contiguous()).squeeze(1)
+    fitted = fitted.contiguous()
+    params, infl, edges, info, nfev = _hill_edges_stage(fitted, xi_dev, span, edge_smoothing_ratio, hill_window_ratio, peak_cap)
+    return HillEdgesBatch(values=fitted, x_indices=x_indices, dpmm=dpmm,
+                          params=params, index=infl[..., 0], value=infl[..., 1], derivative_edges=edges, info=info, nfev=nfev)
+
+
 def _linregress(x, y):
     """slope / intercept of ``scipy.stats.linregress`` (ssxym / ssxm from the biased covariance matrix)."""
     x = np.asarray(x, dtype=float)

@@ -418,6 +418,131 @@ def check_hill_and_penumbra(g, make_profile, tol=1e-9, only=None, spline_tol=Non
     return n
 
 
+def check_hill_batch(g, run_batch, only=None):
+    """`run_batch(values [N, L], **constructor kwargs)` -> profile.HillEdgesBatch.  The INFLECTION_HILL profiles of hill.npz,
+    grouped by length and constructor arguments (a batch shares both), against the reference's own SingleProfile: the
+    processed values (1e-9: identical arithmetic upstream of the fit), the inflection dictionary and both parameter sets at the
+    1e-5 this row holds downstream of a fit; where the reference raised, `info` must report a failure.  A fit whose exponent
+    |d| exceeds 100 is a step inside one sample spacing (curve_fit warns that the covariance cannot be estimated): its
+    inflection INDEX is held to 1e-5 like the others, the curve's value there and d itself only to 1e-3 / not at all."""
+    groups = {}
+    for tag, values, edge, kw in hill_cases(g):
+        if edge != "hill" or (only is not None and not only(tag)):
+            continue
+        key = (len(values), tuple(sorted((k, str(v)) for k, v in kw.items())))
+        groups.setdefault(key, []).append((tag, values, kw))
+    n = 0
+    for items in groups.values():
+        res = run_batch(np.stack([v for _, v, _ in items]), **items[0][2])
+        info = res.info.cpu().numpy()
+        for i, (tag, _, _) in enumerate(items):
+            if f"{tag}.error" in g:
+                assert not ((info[i] >= 1) & (info[i] <= 4)).all(), (tag, "the reference raised", str(g[tag + ".error"]), info[i])
+                try:
+                    res.inflection_data(i)
+                except (ValueError, IndexError, RuntimeError, TypeError):
+                    n += 1
+                    continue
+                raise AssertionError(f"{tag}: inflection_data() did not raise")
+            assert ((info[i] >= 1) & (info[i] <= 4)).all(), (tag, info[i])
+            assert np.allclose(res.values[i].cpu().numpy(), g[f"{tag}.values"], rtol=1e-9, atol=1e-9), (tag, "values")
+            d = res.inflection_data(i)
+            want_p = g[f"{tag}.params"]
+            want = dict(zip([str(k) for k in g["hill_keys"]], g[f"{tag}.infl"]))
+            for side, wp in zip(("left", "right"), want_p):
+                step = abs(wp[3]) > 100
+                got_p = d[f"{side} Hill params"]
+                assert np.allclose(got_p[:3], wp[:3], rtol=1e-5, atol=1e-5), (tag, side, got_p, wp)
+                if not step:
+                    assert np.allclose(got_p[3], wp[3], rtol=1e-5, atol=1e-5), (tag, side, got_p, wp)
+                assert np.isclose(d[f"{side} index (exact)"], want[f"{side} index (exact)"], rtol=1e-5, atol=1e-5), (tag, side)
+                assert np.isclose(d[f"{side} value (@exact)"], want[f"{side} value (@exact)"], rtol=1e-3 if step else 1e-5,
+                                  atol=1e-5), (tag, side)
+            assert [d["left index (rounded)"], d["right index (rounded)"]] == list(g[f"{tag}.infl_rounded"]), tag
+            n += 1
+    return n
+
+
+def penumbra_windows(n, seed=0, mmax=64):
+    """`n` synthetic penumbra windows (rising and falling Hill curves with detector noise, 12-60 samples) -> x, y [n, mmax],
+    lens [n]"""
+    rng = np.random.default_rng(seed)
+    xs, ys, lens = np.zeros((n, mmax)), np.zeros((n, mmax)), np.zeros(n, np.int32)
+    for t in range(n):
+        m = int(rng.integers(12, min(60, mmax)))
+        c0 = rng.uniform(30, 400)
+        x = np.arange(int(c0) - m // 2, int(c0) - m // 2 + m).astype(float)
+        d = rng.uniform(8, 60) * (-1 if t % 2 == 0 else 1)
+        a, b = rng.uniform(0, 0.1), rng.uniform(0.8, 1.2)
+        xs[t, :m] = x
+        ys[t, :m] = a + (b - a) / (1.0 + (c0 / x) ** d) + rng.normal(0, 0.004, m)
+        lens[t] = m
+    return xs, ys, lens
+
+
+def check_hill_fit_vs_scipy(fit, n=60, seed=0):
+    """`fit(x [n, M], y, lens)` -> (params, info, nfev) numpy: the device Levenberg-Marquardt against scipy's (MINPACK lmdif
+    through leastsq, what curve_fit calls) on synthetic windows, through what the restatement promises: the same verdict
+    (converged or not), the same number of function evaluations for nearly every fit (the iteration follows MINPACK's path;
+    pow()'s last bit can move a stopping test by one iteration), the inflection point to 1e-5."""
+    import warnings
+
+    from scipy.optimize import leastsq
+
+    xs, ys, lens = penumbra_windows(n, seed)
+    params, info, nfev = fit(xs, ys, lens)
+    same_nfev = converged = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(n):
+            x, y = xs[i, :lens[i]], ys[i, :lens[i]]
+            ref, _, extra, _, ier = leastsq(lambda p: p[0] + (p[1] - p[0]) / (1.0 + (p[2] / x) ** p[3]) - y,
+                                            (y.min(), y.max(), np.median(x), 0), full_output=True)
+            ok_ref, ok_dev = ier in (1, 2, 3, 4), 1 <= info[i] <= 4
+            assert ok_ref == ok_dev, (i, ier, info[i])
+            if not ok_ref:
+                continue
+            converged += 1
+            same_nfev += int(extra["nfev"] == nfev[i])
+            infl = lambda q: q[2] * ((q[3] - 1) / (q[3] + 1)) ** (1 / q[3])
+            assert np.isclose(infl(params[i]), infl(ref), rtol=1e-5), (i, params[i], ref)
+            assert np.allclose(params[i], ref, rtol=2e-3, atol=1e-4), (i, params[i], ref)
+    assert converged >= 0.9 * n and same_nfev >= 0.9 * converged, (converged, same_nfev)
+    return converged
+
+
+def beam_profiles(n, length=200, seed=0):
+    """`n` synthetic open-field profiles of `length` detectors: two Hill penumbrae, a slightly domed top, detector noise"""
+    rng = np.random.default_rng(seed)
+    x = np.arange(length, dtype=float) + 1.0
+    out = np.empty((n, length))
+    for i in range(n):
+        left, right = rng.uniform(0.2, 0.3) * length, rng.uniform(0.7, 0.8) * length
+        steep = rng.uniform(15, 40)
+        rise = 1.0 / (1.0 + (left / x) ** steep)
+        fall = 1.0 / (1.0 + (x / right) ** (steep * right / left))
+        dome = 1.0 - rng.uniform(0, 0.05) * ((x - (left + right) / 2) / length) ** 2
+        out[i] = rng.uniform(50, 200) * rise * fall * dome + rng.uniform(0, 2) + rng.normal(0, 0.05, length)
+    return out
+
+
+def check_hill_batch_vs_single(run_batch, make_single, n=6, length=120, sample=None, **kw):
+    """The batched INFLECTION_HILL path against the per-profile SingleProfile mirror (scipy's curve_fit on the host) on the
+    same synthetic profiles: processed values bit for bit (same kernels), inflection data at 1e-5"""
+    profs = beam_profiles(n, length)
+    res = run_batch(profs, **kw)
+    info = res.info.cpu().numpy()
+    vals = res.values.cpu().numpy()
+    for i in (range(n) if sample is None else sample):
+        single = make_single(profs[i].copy(), **kw)
+        assert ((info[i] >= 1) & (info[i] <= 4)).all(), (i, info[i])
+        assert np.allclose(vals[i], single.values, rtol=1e-9, atol=1e-12), i
+        want, got = single.inflection_data(), res.inflection_data(i)
+        for k in ("left index (exact)", "right index (exact)", "left value (@exact)", "right value (@exact)"):
+            assert np.isclose(got[k], want[k], rtol=1e-5, atol=1e-5), (i, k, got[k], want[k])
+    return res
+
+
 # ---------------------------------------------------------------------------------------------- Starshot
 def starshot_cases(g):
     for name in g["names"]:

@@ -487,6 +487,35 @@ def test_emulated_single_profile_hill_and_penumbra(golden, emulated):
     assert n >= 20
 
 
+def test_emulated_hill_fit_matches_scipy(emulated):
+    """pl_hill_fit (MINPACK lmdif restated, one lane per fit) against scipy's leastsq on synthetic penumbra windows."""
+    import next_row_checks as checks
+    from pylinac_amd import ops
+
+    import torch
+
+    def fit(xs, ys, lens):
+        dev = torch.device("cuda:0")
+        p, info, nfev = ops.hill_fit(torch.from_numpy(xs).to(dev), torch.from_numpy(ys).to(dev), torch.from_numpy(lens).to(dev))
+        return p.cpu().numpy(), info.cpu().numpy(), nfev.cpu().numpy()
+
+    assert checks.check_hill_fit_vs_scipy(fit, n=40) >= 36
+
+
+def test_emulated_hill_batch(golden, emulated):
+    """single_profile_hill_batch (no per-profile host call) against the reference's SingleProfile numbers of hill.npz and
+    against the per-profile mirror."""
+    import next_row_checks as checks
+    from pylinac_amd import profile
+
+    n = checks.check_hill_batch(golden("hill"), profile.single_profile_hill_batch,
+                                only=lambda t: t.startswith(("fx0.", "fx2.", "fx3.", "fx6.", "fx8.", "epid.hill.dpmm", "fff1.")))
+    assert n >= 10
+    checks.check_hill_batch_vs_single(
+        profile.single_profile_hill_batch,
+        lambda v, **kw: profile.SingleProfile(v, edge_detection_method=profile.Edge.INFLECTION_HILL, **kw), n=3, length=90)
+
+
 def test_emulated_starshot(golden, emulated):
     """Starshot.analyze on the emulated device (one integer and the float32 frame; the full set runs with -m gpu)."""
     import next_row_checks as checks

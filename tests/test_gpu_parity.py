@@ -1941,3 +1941,45 @@ def test_canny_masked_vs_skimage_golden(golden, dev):
     import next_row_checks as checks
 
     checks.check_canny_masked(golden, dev)
+
+
+@pytest.mark.gpu
+def test_hill_fit_matches_scipy(dev):
+    """pl_hill_fit against scipy's leastsq (what the reference's Hill.fit calls) on 400 synthetic penumbra windows."""
+    import next_row_checks as checks
+    from pylinac_amd import ops
+
+    def fit(xs, ys, lens):
+        p, info, nfev = ops.hill_fit(T(xs, dev), T(ys, dev), T(lens, dev))
+        return p.cpu().numpy(), info.cpu().numpy(), nfev.cpu().numpy()
+
+    assert checks.check_hill_fit_vs_scipy(fit, n=400, seed=3) >= 360
+
+
+@pytest.mark.gpu
+def test_hill_batch_vs_reference_golden_and_single(golden, dev):
+    """single_profile_hill_batch: every INFLECTION_HILL profile of hill.npz against the reference's own numbers, then 2048
+    synthetic profiles in one batch against the per-profile mirror (scipy's curve_fit on the host) on a sample."""
+    import time
+    import warnings
+
+    import next_row_checks as checks
+    from pylinac_amd import profile
+
+    batch = profile.single_profile_hill_batch
+
+    assert checks.check_hill_batch(golden("hill"), batch) == 46
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = checks.check_hill_batch_vs_single(
+            batch, lambda v, **kw: profile.SingleProfile(v, edge_detection_method=profile.Edge.INFLECTION_HILL, **kw),
+            n=2048, length=200, sample=range(0, 2048, 256))
+    info = res.info.cpu().numpy()
+    assert ((info >= 1) & (info <= 4)).all()
+    profs = T(checks.beam_profiles(2048, 200), dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    profile.single_profile_hill_batch(profs)
+    torch.cuda.synchronize()
+    print(f"\nsingle_profile_hill_batch: 2048 profiles x 200 detectors (resampled x10), BEAM_CENTER normalisation: "
+          f"{(time.perf_counter() - t0) * 1e3:.2f} ms")
