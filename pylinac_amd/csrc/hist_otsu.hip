@@ -545,51 +545,80 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
 // ---- single-pass Otsu for frames the 38 912-bin window cannot hold: ALL 65 536 bins in LDS as packed 16-bit counters -------
 // (a frame stretched to the full 16-bit range fell off a cliff -- gated median plane + two-part histogram + scan,
 // 0.226 -> 0.489 ms per 256 frames; three one-read alternatives built on 32-bit bins were slower still.)
-// 65 536 counters of 16 bits are 128 KiB: two per dword, added with ONE returning LDS atomic (1 << 0 or 1 << 16).  A counter
-// uses 15 bits; bit 15 is a GUARD: the add that finds the field at 0x7fff sets the guard (no carry can reach the neighbouring
-// field: that would take 32 768 further adds before the fix below), and exactly that lane -- it alone saw 0x7fff come back --
-// subtracts 0x8000 again and notes the key in a short LDS list: every entry stands for 32 768 pixels of that value.  Adds
-// that land between the two steps are preserved (the fix is a subtraction, not a store).  The Otsu scan reads the fields
-// and adds the noted multiples of 32 768: same integer prefix sums, float64 expression and first-index arg-max as otsu_kernel.
+// 65 536 counters of 16 bits are 128 KiB: two per dword (values v and v + 32 768).  FIRST ATTEMPT (round 4, second half):
+// plain 16-bit fields and non-returning adds, exactness CHECKED afterwards through the decoded total (full_tally_pass below);
+// wave-wide flat neighbourhoods go to a small side list of 32-bit counts.  SECOND ATTEMPT, only for a frame whose total did
+// not add up: one returning LDS atomic per pixel on fields of 15 bits; bit 15 is a GUARD: the add that finds the field at
+// 0x7fff sets the guard (no carry can reach the neighbouring field: that would take 32 768 further adds before the fix
+// below), and exactly that lane -- it alone saw 0x7fff come back -- subtracts 0x8000 again and notes the key in a short LDS
+// list: every entry stands for 32 768 pixels of that value.  Adds that land between the two steps are preserved (the fix is
+// a subtraction, not a store).  The Otsu scan reads the fields and adds the noted counts: same integer prefix sums, float64
+// expression and first-index arg-max as otsu_kernel.
 // One workgroup per frame, gated by the window kernel's flag; medians on the fly like the window kernel (MED3).
+// Measured on 256 stretched 1024 x 1024 frames (profiles/r04_otsu_full_range_variants.txt): guard form 0.292-0.302 ms for the
+// stage (window attempt included) -> 0.245 with the unguarded first attempt -> 0.225 with the bank-conflict-free scan.
 constexpr int kFullEvents = 2048;                            // overflow notes: frames of up to 2^26 pixels
+constexpr int kFullBulk = 64;                                // values that whole waves hold (flat background / saturation)
 struct FullScratch {
   Pair wave_tot[kHistThreads / 64];
   double s_var[kHistThreads / 64];
   int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64], s_idx[kHistThreads / 64];
-  int n_events;
+  int n_events, n_bulk;
+  unsigned bulk_key[kFullBulk], bulk_cnt[kFullBulk];
   unsigned short event_key[kFullEvents];
 };
 constexpr int kFullBinsBytes = 65536 * 2;
 constexpr size_t kFullLds = kFullBinsBytes + sizeof(FullScratch);
 
-template <typename T, bool MED3>
-__global__ void __launch_bounds__(kHistThreads)
-otsu16_full_kernel(const unsigned short* __restrict__ in, int64_t count, int h, int w, unsigned flip, int bias,
-                   int32_t* __restrict__ thr, int32_t* __restrict__ vmin, int32_t* __restrict__ vmax,
-                   int32_t* __restrict__ flag) {
-  extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // 32 768 dwords = 65 536 fields, then FullScratch
-  FullScratch& scr = *reinterpret_cast<FullScratch*>(reinterpret_cast<unsigned char*>(bins) + kFullBinsBytes);
-  const int64_t frame = blockIdx.x;
-  if (flag[frame] == 0) return;                              // the window kernel finished this frame
-  const unsigned short* src = in + frame * count;
+// One pass over the frame into the packed fields.
+//   GUARD = false (first attempt): fields of 16 bits, NON-returning adds (the returning add of the guarded form and the test
+//     of what came back cost a third of the kernel), a wave's bulk count of a flat neighbourhood -- the one thing that
+//     routinely exceeds 65 535 per value -- into a 64-entry side list of 32-bit counts.  A field that overflows all the same
+//     carries into its neighbour or out of the dword; either way the decoded total comes out SMALLER than the pixel count
+//     (-65 535 or -65 536 per overflow, never compensated), which the caller tests: exactness is checked, not assumed.
+//   GUARD = true (the frame whose total did not add up: > 65 535 pixels of one value outside flat neighbourhoods): the
+//     15-bit fields with the guard bit described above.
+template <typename T, bool MED3, bool GUARD>
+__device__ __forceinline__ void full_tally_pass(const unsigned short* __restrict__ src, int64_t count, int h, int w, unsigned flip,
+                                                unsigned* __restrict__ bins, FullScratch& scr) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 32768; i += kHistThreads) bins[i] = 0;
-  if (threadIdx.x == 0) scr.n_events = 0;
-  __syncthreads();
   // key = value in the biased domain (0 .. 65535), n = how many pixels of it (1, or a whole wave's worth <= 512: the guard
   // bit leaves room for 32 767 more before a carry, far more than every wave's bulk add landing between the two steps)
   auto tally_n = [&](unsigned key, unsigned n) {
-    const unsigned sh = (key & 1u) << 4;
-    const unsigned old = atomicAdd(&bins[key >> 1], n << sh);
+    // values v and v + 32 768 share a dword (not v and v + 1: neighbouring pixels hold neighbouring values, and two lanes
+    // on one dword serialise in the LDS atomic unit)
+    const unsigned sh = (key >> 15) << 4, at = key & 0x7fffu;
+    if (!GUARD) {                // four vector instructions and the atomic; the bins start the workgroup's LDS (kernel's test)
+#if PL_OTSU_VARIANT & 1            // stopwatch only: everything but the LDS atomics
+      asm volatile("" ::"v"((key << 2) & 0x1fffcu), "v"(n * (1u + ((key >> 15) & 1u) * 0xffffu)));
+#else
+      pl_lds_add_abs((key << 2) & 0x1fffcu, n * (1u + ((key >> 15) & 1u) * 0xffffu));
+#endif
+      return;
+    }
+    const unsigned old = atomicAdd(&bins[at], n << sh);
     const unsigned f = (old >> sh) & 0xffffu;
     if (f < 0x8000u && f + n >= 0x8000u) {                   // this add took the field across the guard: fold 32 768 away
-      atomicSub(&bins[key >> 1], 0x8000u << sh);
+      atomicSub(&bins[at], 0x8000u << sh);
       const int slot = atomicAdd(&scr.n_events, 1);
       if (slot < kFullEvents) scr.event_key[slot] = (unsigned short)key;
     }
   };
   auto tally = [&](unsigned key) { tally_n(key, 1u); };
+  // a flat wave's count (called by the whole, converged wave; `key`, `n` wave-uniform)
+  auto tally_bulk = [&](unsigned key, unsigned n, int first_on) {
+    if (GUARD) {
+      if (lane == first_on) tally_n(key, n);
+      return;
+    }
+    const int have = scr.n_bulk < kFullBulk ? scr.n_bulk : kFullBulk;
+    const unsigned long long hit = __ballot(lane < have && scr.bulk_key[lane] == key);
+    if (lane != first_on) return;
+    if (hit) { atomicAdd(&scr.bulk_cnt[__builtin_ctzll(hit)], n); return; }
+    const int slot = atomicAdd(&scr.n_bulk, 1);              // (two waves may open the same value twice: both entries count)
+    if (slot < kFullBulk) { atomicAdd(&scr.bulk_cnt[slot], n); scr.bulk_key[slot] = key; }
+    else tally_n(key, n);                                    // list full: the field (an overflow there shows in the total)
+  };
   if (MED3) {
     constexpr int kRows = 32;
     constexpr int kSBias = ((T)-1 < (T)0) ? 32768 : 0;
@@ -608,7 +637,7 @@ otsu16_full_kernel(const unsigned short* __restrict__ in, int64_t count, int h, 
         for (int k = 1; k < 8; ++k) spread |= (unsigned)(m[k] ^ m[0]);
         const int wave_first = __builtin_amdgcn_readlane(m[0], first_on);
         if (__ballot(on && (spread | (unsigned)(m[0] ^ wave_first)) != 0u) == 0ull) {
-          if (lane == first_on) tally_n((unsigned)(wave_first + kSBias), 8u * (unsigned)__popcll(act));
+          tally_bulk((unsigned)(wave_first + kSBias), 8u * (unsigned)__popcll(act), first_on);
           return;
         }
         if (!on) return;
@@ -619,39 +648,94 @@ otsu16_full_kernel(const unsigned short* __restrict__ in, int64_t count, int h, 
   } else {
     for (int64_t i = threadIdx.x; i < count; i += kHistThreads) tally((unsigned)src[i] ^ flip);
   }
-  __syncthreads();
-  const int n_events = scr.n_events < kFullEvents ? scr.n_events : kFullEvents;   // (more: a frame beyond 2^26 pixels, refused by the launcher)
+}
+
+template <typename T, bool MED3>
+__global__ void __launch_bounds__(kHistThreads)
+otsu16_full_kernel(const unsigned short* __restrict__ in, int64_t count, int h, int w, unsigned flip, int bias,
+                   int32_t* __restrict__ thr, int32_t* __restrict__ vmin, int32_t* __restrict__ vmax,
+                   int32_t* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // 32 768 dwords = 65 536 fields, then FullScratch
+  FullScratch& scr = *reinterpret_cast<FullScratch*>(reinterpret_cast<unsigned char*>(bins) + kFullBinsBytes);
+  const int64_t frame = blockIdx.x;
+#ifndef PL_OTSU_FULL_ALWAYS
+  if (flag[frame] == 0) return;                              // the window kernel finished this frame
+#endif
+  const unsigned short* src = in + frame * count;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  auto clear = [&]() {
+    for (int i = threadIdx.x; i < 32768; i += kHistThreads) bins[i] = 0;
+    if (threadIdx.x < kFullBulk) { scr.bulk_key[threadIdx.x] = 0xffffffffu; scr.bulk_cnt[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { scr.n_events = 0; scr.n_bulk = 0; }
+    __syncthreads();
+  };
 
   // ---- Otsu on the 65 536 bins: lane t owns bins [64 t, 64 t + 64)
   const int b0 = threadIdx.x * 64;
-  // this lane's overflow notes, as extra counts per bin: rare, so a lane without any skips the lookup
-  int my_events = 0;
-  for (int e = 0; e < n_events; ++e) my_events += ((int)scr.event_key[e] >> 6) == (int)threadIdx.x ? 1 : 0;
+  int n_events = 0, n_bulk = 0, my_notes = 0;
   auto count_of = [&](int b) {
-    unsigned c = (bins[b >> 1] >> ((b & 1) << 4)) & 0xffffu;
-    if (my_events)
+    unsigned c = (bins[b & 0x7fff] >> ((b >> 15) << 4)) & 0xffffu;
+    if (my_notes) {                                          // rare, so a lane without any skips the lookups
       for (int e = 0; e < n_events; ++e) c += (int)scr.event_key[e] == b ? 32768u : 0u;
+      for (int e = 0; e < n_bulk; ++e) c += (int)scr.bulk_key[e] == b ? scr.bulk_cnt[e] : 0u;
+    }
     return c;
   };
-  Pair mine = {0, 0};
-  int lo = 1 << 30, hi = -1;
-  for (int b = b0; b < b0 + 64; ++b) {
-    const unsigned c = count_of(b);
-    mine.c += c;
-    mine.s += (long long)c * (long long)(b - bias);
-    if (c) { if (lo == (1 << 30)) lo = b; hi = b; }
+  // Lane t reads ITS 64 fields starting at the t-th (cyclically): at every step the 64 lanes of a wave are on 64 different
+  // banks.  In value order -- every lane at its first field -- they would all be on ONE bank (a lane's fields are 64 dwords
+  // apart): 2 x 64 reads of 64 cycles each per wave, a fifth of this kernel's time before round 4 noticed.  The sums do not
+  // care about the order; the running prefix of the second pass starts behind the wrapped part (`wrapped`) and is reset
+  // where the walk wraps.
+  Pair mine, total, ex, wrapped;
+  int lo, hi;
+  auto totals = [&]() {                                      // contains __syncthreads
+    n_events = scr.n_events < kFullEvents ? scr.n_events : kFullEvents;   // (more: a frame beyond 2^26 pixels, refused by the launcher)
+    n_bulk = scr.n_bulk < kFullBulk ? scr.n_bulk : kFullBulk;
+    my_notes = 0;
+    for (int e = 0; e < n_events; ++e) my_notes += ((int)scr.event_key[e] >> 6) == (int)threadIdx.x ? 1 : 0;
+    for (int e = 0; e < n_bulk; ++e) my_notes += (scr.bulk_key[e] >> 6) == threadIdx.x ? 1 : 0;
+    mine = {0, 0};
+    wrapped = {0, 0};
+    lo = 1 << 30, hi = -1;
+    for (int j = 0; j < 64; ++j) {
+      const int b = b0 + ((j + lane) & 63);
+      const unsigned c = count_of(b);
+      Pair& acc = j + lane < 64 ? mine : wrapped;
+      acc.c += c;
+      acc.s += (long long)c * (long long)(b - bias);
+      if (c) { lo = b < lo ? b : lo; hi = b > hi ? b : hi; }
+    }
+    mine.c += wrapped.c;
+    mine.s += wrapped.s;
+    lo = pl_wave_reduce(lo, [](int a, int b) { return a < b ? a : b; });
+    hi = pl_wave_reduce(hi, [](int a, int b) { return a > b ? a : b; });
+    if (lane == 0) { scr.s_lo[wv] = lo; scr.s_hi[wv] = hi; }
+    ex = block_exclusive_scan(mine, &total, scr.wave_tot);
+    for (int k = 0; k < kHistThreads / 64; ++k) { lo = scr.s_lo[k] < lo ? scr.s_lo[k] : lo; hi = scr.s_hi[k] > hi ? scr.s_hi[k] : hi; }
+  };
+
+  bool exact = false;
+  if (pl_lds_base(bins) == 0u) {                             // (the fast pass addresses the bins by absolute LDS address)
+    clear();
+    full_tally_pass<T, MED3, false>(src, count, h, w, flip, bins, scr);
+    __syncthreads();
+    totals();
+    exact = total.c == (unsigned long long)count;
+    __syncthreads();
   }
-  lo = pl_wave_reduce(lo, [](int a, int b) { return a < b ? a : b; });
-  hi = pl_wave_reduce(hi, [](int a, int b) { return a > b ? a : b; });
-  if (lane == 0) { scr.s_lo[wv] = lo; scr.s_hi[wv] = hi; }
-  Pair total;
-  Pair ex = block_exclusive_scan(mine, &total, scr.wave_tot);  // contains __syncthreads
-  for (int k = 0; k < kHistThreads / 64; ++k) { lo = scr.s_lo[k] < lo ? scr.s_lo[k] : lo; hi = scr.s_hi[k] > hi ? scr.s_hi[k] : hi; }
+  if (!exact) {                                              // a 16-bit field overflowed: once more with the guard bit
+    clear();
+    full_tally_pass<T, MED3, true>(src, count, h, w, flip, bins, scr);
+    __syncthreads();
+    totals();
+  }
   double best = -1.0;
   int best_k = 1 << 30;
-  unsigned long long w1 = ex.c;
-  long long s1 = ex.s;
-  for (int b = b0; b < b0 + 64; ++b) {
+  unsigned long long w1 = ex.c + wrapped.c;                  // the prefix in front of field `lane`, where the walk starts
+  long long s1 = ex.s + wrapped.s;
+  for (int j = 0; j < 64; ++j) {
+    if (j + lane == 64) { w1 = ex.c; s1 = ex.s; }            // wrapped to the lane's first field
+    const int b = b0 + ((j + lane) & 63);
     const unsigned c = count_of(b);
     w1 += c;
     s1 += (long long)c * (long long)(b - bias);
@@ -661,7 +745,7 @@ otsu16_full_kernel(const unsigned short* __restrict__ in, int64_t count, int h, 
       const double m2 = (double)(total.s - s1) / dw2;
       const double d = m1 - m2;
       const double var = (dw1 * dw2) * (d * d);
-      if (var > best) { best = var; best_k = b; }
+      if (var > best || (var == best && b < best_k)) { best = var; best_k = b; }   // first index of the maximum
     }
   }
 #pragma unroll
@@ -964,8 +1048,12 @@ int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t c
     if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, (size_t)n * sizeof(int32_t), st);
     if (e != hipSuccess) { pl_set_error("%s: memset: %s", who, hipGetErrorString(e)); return PL_ERR_HIP; }
   }
+#ifdef PL_OTSU_FULL_ALWAYS                                    // development variant: every frame through the full-range kernel
+  (void)hipMemsetAsync(d_flag, 0, (size_t)n * sizeof(int32_t), st);
+#else
   hipLaunchKernelGGL((otsu16_window_kernel<T, MED3>), dim3((unsigned)(n * parts)), dim3(kHistThreads), lds, st,
                      (const unsigned short*)in, count, h, w, flip, bias, d_lo, d_hi, d_thr, d_min, d_max, d_flag, parts, d_hist);
+#endif
   // frames too wide for the window: the full-range kernel (packed 16-bit counters), every workgroup gated by d_flag; the
   // medians are computed on the fly again for exactly those frames.  (Round 3: gated median plane + two-part histogram +
   // scan, 2.2 x the window kernel's time on a stretched batch.)  Frames beyond 2^26 pixels keep the table path.
