@@ -43,43 +43,62 @@ scaled_colmean_kernel(const unsigned short* __restrict__ in, int h, int w, int c
 // width % 4 == 0: a lane owns FOUR adjacent columns (one 8-byte load per row: 512 B per wave and row instead of 128) and
 // keeps sixteen rows of loads in flight; the four sums are independent chains, each still row by row like numpy's.
 // Round 1-3's one-column lanes reached 1 TB/s (a dependent float64 division per row and 128-byte wave loads).
+// COLS = 2 (round 4): twice the waves (256 frames x 1024 columns are 1024 waves at four columns per lane -- ONE per SIMD, which
+// then alternates between waiting for its loads and dividing) with twice the rows in flight.
+#ifndef PL_COLMEAN_COLS
+#define PL_COLMEAN_COLS 2
+#endif
+#ifndef PL_COLMEAN_ROWS
+#define PL_COLMEAN_ROWS 32
+#endif
+template <int COLS, int U>
 __global__ void __launch_bounds__(kThreads)
-scaled_colmean4_kernel(const unsigned short* __restrict__ in, int h, int w, int64_t total_quads,
+scaled_colmeanv_kernel(const unsigned short* __restrict__ in, int h, int w, int64_t total_groups,
                        const double* __restrict__ sub, const double* __restrict__ div, double* __restrict__ out) {
+  static_assert(COLS == 1 || COLS == 2 || COLS == 4, "one, two or four columns per lane");
   const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (g >= total_quads) return;
-  const int qpr = w >> 2;
-  const size_t frame = (size_t)(g / qpr);
-  const int c = (int)(g % qpr) * 4;
+  if (g >= total_groups) return;
+  const int gpr = w / COLS;
+  const size_t frame = (size_t)(g / gpr);
+  const int c = (int)(g % gpr) * COLS;
   const unsigned short* p = in + frame * (size_t)h * w + c;
   const PlQuot k = pl_quot_make(sub[frame], div[frame]);
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  constexpr int U = 16;
+  double a[COLS];
+#pragma unroll
+  for (int j = 0; j < COLS; ++j) a[j] = 0.0;
+  struct Px { unsigned w[COLS > 1 ? COLS / 2 : 1]; };
+  auto load = [&](int r) {
+    Px v;
+    if constexpr (COLS == 1) {
+      v.w[0] = p[(size_t)r * w];
+    } else if constexpr (COLS == 4) {
+      const uint2 q = *reinterpret_cast<const uint2*>(p + (size_t)r * w);
+      v.w[0] = q.x; v.w[1] = q.y;
+    } else {
+      v.w[0] = *reinterpret_cast<const unsigned*>(p + (size_t)r * w);
+    }
+    return v;
+  };
+  auto add = [&](const Px& v) {
+    if constexpr (COLS == 1) a[0] = a[0] + pl_quot(k, (double)v.w[0]);
+#pragma unroll
+    for (int j = 0; j < COLS / 2; ++j) {
+      a[2 * j] = a[2 * j] + pl_quot(k, (double)(v.w[j] & 0xffffu));
+      a[2 * j + 1] = a[2 * j + 1] + pl_quot(k, (double)(v.w[j] >> 16));
+    }
+  };
   int r = 0;
   for (; r + U <= h; r += U) {
-    uint2 v[U];
+    Px v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const uint2*>(p + (size_t)(r + u) * w);
+    for (int u = 0; u < U; ++u) v[u] = load(r + u);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      a0 = a0 + pl_quot(k, (double)(v[u].x & 0xffffu));
-      a1 = a1 + pl_quot(k, (double)(v[u].x >> 16));
-      a2 = a2 + pl_quot(k, (double)(v[u].y & 0xffffu));
-      a3 = a3 + pl_quot(k, (double)(v[u].y >> 16));
-    }
+    for (int u = 0; u < U; ++u) add(v[u]);
   }
-  for (; r < h; ++r) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p + (size_t)r * w);
-    a0 = a0 + pl_quot(k, (double)(v.x & 0xffffu));
-    a1 = a1 + pl_quot(k, (double)(v.x >> 16));
-    a2 = a2 + pl_quot(k, (double)(v.y & 0xffffu));
-    a3 = a3 + pl_quot(k, (double)(v.y >> 16));
-  }
+  for (; r < h; ++r) add(load(r));
   double* o = out + frame * (size_t)w + c;
-  o[0] = a0 / (double)h;
-  o[1] = a1 / (double)h;
-  o[2] = a2 / (double)h;
-  o[3] = a3 / (double)h;
+#pragma unroll
+  for (int j = 0; j < COLS; ++j) o[j] = a[j] / (double)h;
 }
 
 // np.mean(image, 1) of the normalised frame (LEFT_RIGHT pickets, picketfence.py:749): along the CONTIGUOUS axis numpy sums
@@ -497,9 +516,10 @@ extern "C" int pl_scaled_colmean(const uint16_t* in, int64_t n, int h, int w, co
   const int col_tiles = (int)pl_cdiv(w, kThreads);
   PL_REQUIRE(n * col_tiles <= 0x7fffffffLL, "batch too large");
   if ((w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 7) == 0) {
-    const int64_t quads = n * (int64_t)(w >> 2);
-    hipLaunchKernelGGL(scaled_colmean4_kernel, dim3((unsigned)pl_cdiv(quads, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
-                       in, h, w, quads, d_sub, d_div, d_out);
+    const int64_t groups = n * (int64_t)(w / PL_COLMEAN_COLS);
+    PL_REQUIRE(pl_cdiv(groups, kThreads) <= 0x7fffffffLL, "batch too large");
+    hipLaunchKernelGGL((scaled_colmeanv_kernel<PL_COLMEAN_COLS, PL_COLMEAN_ROWS>), dim3((unsigned)pl_cdiv(groups, kThreads)),
+                       dim3(kThreads), 0, (hipStream_t)stream, in, h, w, groups, d_sub, d_div, d_out);
     return pl_check_launch("pl_scaled_colmean");
   }
   hipLaunchKernelGGL(scaled_colmean_kernel, dim3((unsigned)(n * col_tiles)), dim3(kThreads), 0, (hipStream_t)stream,
