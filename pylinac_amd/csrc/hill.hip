@@ -15,7 +15,8 @@
 // numpy's vectorised pow is not bit-reproducible).
 //
 // One LANE per fit (n = 4 parameters, m <= 1024 samples): the batches this serves are thousands of penumbra windows of a few
-// dozen samples; the Jacobian (4 x m) and two m-vectors of a fit live in a caller-provided workspace in global memory.
+// dozen samples; the Jacobian (4 x m), two m-vectors and the samples of a fit live in a caller-provided workspace in global
+// memory, transposed so that the fits of a wave sit side by side (see the kernel).
 #include <math.h>
 
 #include "pl_common.h"
@@ -30,7 +31,7 @@ __device__ __forceinline__ double hill_value(double x, const double* p) {
 }
 
 // minpack enorm: the Euclidean norm with separate accumulators for small, intermediate and large components
-__device__ double hill_enorm(int n, const double* x, int stride) {
+__device__ double hill_enorm(int n, const double* x, int64_t stride) {
   const double rdwarf = 3.834e-20, rgiant = 1.304e19;
   double s1 = 0.0, s2 = 0.0, s3 = 0.0, x1max = 0.0, x3max = 0.0;
   const double agiant = rgiant / (double)n;
@@ -204,7 +205,7 @@ __device__ void hill_lmpar(double* r, const int* ipvt, const double* diag, const
 
 __global__ void __launch_bounds__(kHillThreads)
 hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, const int32_t* __restrict__ lens, int64_t nfits,
-                int mmax, int64_t stride, double* __restrict__ work /* [nfits][6 * mmax] */, double* __restrict__ params,
+                int mmax, int64_t stride, double* __restrict__ work /* [8 * mmax][nfits] */, double* __restrict__ params,
                 int32_t* __restrict__ info_out, int32_t* __restrict__ nfev_out) {
   constexpr int n = kHillN;
   const int64_t fit = (int64_t)blockIdx.x * kHillThreads + threadIdx.x;
@@ -212,9 +213,15 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
   const int m = lens ? lens[fit] : mmax;
   const double* xd = xs + fit * stride;
   const double* yd = ys + fit * stride;
-  double* fjac = work + fit * 6 * (int64_t)mmax;          // column-major: fjac[j * mmax + i]
-  double* fvec = fjac + 4 * (int64_t)mmax;
-  double* wa4 = fvec + mmax;
+  // The workspace is TRANSPOSED: element k of fit f at work[k * nfits + f], so that the 64 fits of a wave touch 64 consecutive
+  // doubles whenever they are at the same place in the algorithm (a per-fit slab made every access 64 cache lines: the
+  // kernel was bound by that latency, 2.3 ms for 8 192 ten-sample fits).  S = distance between a fit's consecutive elements.
+  const size_t S = (size_t)nfits;
+  double* fjac = work + fit;                                // column-major: fjac[(j * mmax + i) * S]
+  double* fvec = fjac + 4 * (size_t)mmax * S;
+  double* wa4 = fvec + (size_t)mmax * S;
+  double* xt = wa4 + (size_t)mmax * S;                      // the fit's own copy of its samples, same layout
+  double* yt = xt + (size_t)mmax * S;
   double* out = params + fit * n;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
   if (m < n || m > mmax) {                                  // curve_fit raises for fewer samples than parameters
@@ -226,15 +233,16 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
   // p0 = (min(y), max(y), np.median(x), 0): the median of the (sorted, as np.arange makes them) x values by selection
   double x[n];
   {
+    for (int i = 0; i < m; ++i) { xt[i * S] = xd[i]; yt[i * S] = yd[i]; }
     double mn = yd[0], mx = yd[0];
-    for (int i = 1; i < m; ++i) { mn = yd[i] < mn ? yd[i] : mn; mx = yd[i] > mx ? yd[i] : mx; }
+    for (int i = 1; i < m; ++i) { mn = yt[i * S] < mn ? yt[i * S] : mn; mx = yt[i * S] > mx ? yt[i * S] : mx; }
     // order statistics k_lo, k_hi of x by counting (m is a few dozen)
     const int k_hi = m / 2, k_lo = (m & 1) ? k_hi : k_hi - 1;
     double v_lo = 0.0, v_hi = 0.0;
     for (int a = 0; a < m; ++a) {
-      const double va = xd[a];
+      const double va = xt[a * S];
       int rank = 0;
-      for (int b = 0; b < m; ++b) rank += (xd[b] < va || (xd[b] == va && b < a)) ? 1 : 0;
+      for (int b = 0; b < m; ++b) rank += (xt[b * S] < va || (xt[b * S] == va && b < a)) ? 1 : 0;
       if (rank == k_lo) v_lo = va;
       if (rank == k_hi) v_hi = va;
     }
@@ -244,13 +252,13 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
   const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
   const int maxfev = 200 * (n + 1);
   auto residuals = [&](const double* p, double* f) {        // curve_fit minimises func(x, *p) - y
-    for (int i = 0; i < m; ++i) f[i] = hill_value(xd[i], p) - yd[i];
+    for (int i = 0; i < m; ++i) f[i * S] = hill_value(xt[i * S], p) - yt[i * S];
   };
   double diag[n], qtf[n], wa1[n], wa2[n], wa3[n], r[n * n], sdiag[n];
   int ipvt[n];
   int info = 0, nfev = 1, iter = 1;
   residuals(x, fvec);
-  double fnorm = hill_enorm(m, fvec, 1);
+  double fnorm = hill_enorm(m, fvec, (int64_t)S);
   double par = 0.0, delta = 0.0, xnorm = 0.0;
   bool done = false;
   while (!done) {
@@ -264,14 +272,14 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
         x[j] = temp + hstep;
         residuals(x, wa4);
         x[j] = temp;
-        for (int i = 0; i < m; ++i) fjac[(size_t)j * mmax + i] = (wa4[i] - fvec[i]) / hstep;
+        for (int i = 0; i < m; ++i) fjac[((size_t)j * mmax + i) * S] = (wa4[i * S] - fvec[i * S]) / hstep;
       }
       nfev += n;
     }
     // ---- qrfac with column pivoting (rdiag -> wa1, acnorm -> wa2, work -> wa3)
     {
       for (int j = 0; j < n; ++j) {
-        wa2[j] = hill_enorm(m, fjac + (size_t)j * mmax, 1);
+        wa2[j] = hill_enorm(m, fjac + (size_t)j * mmax * S, (int64_t)S);
         wa1[j] = wa2[j];
         wa3[j] = wa1[j];
         ipvt[j] = j;
@@ -282,31 +290,31 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
           if (wa1[k] > wa1[kmax]) kmax = k;
         if (kmax != j) {
           for (int i = 0; i < m; ++i) {
-            const double t = fjac[(size_t)j * mmax + i];
-            fjac[(size_t)j * mmax + i] = fjac[(size_t)kmax * mmax + i];
-            fjac[(size_t)kmax * mmax + i] = t;
+            const double t = fjac[((size_t)j * mmax + i) * S];
+            fjac[((size_t)j * mmax + i) * S] = fjac[((size_t)kmax * mmax + i) * S];
+            fjac[((size_t)kmax * mmax + i) * S] = t;
           }
           wa1[kmax] = wa1[j];
           wa3[kmax] = wa3[j];
           const int k = ipvt[j]; ipvt[j] = ipvt[kmax]; ipvt[kmax] = k;
         }
-        double ajnorm = hill_enorm(m - j, fjac + (size_t)j * mmax + j, 1);
+        double ajnorm = hill_enorm(m - j, fjac + ((size_t)j * mmax + j) * S, (int64_t)S);
         if (ajnorm != 0.0) {
-          if (fjac[(size_t)j * mmax + j] < 0.0) ajnorm = -ajnorm;
-          for (int i = j; i < m; ++i) fjac[(size_t)j * mmax + i] /= ajnorm;
-          fjac[(size_t)j * mmax + j] += 1.0;
+          if (fjac[((size_t)j * mmax + j) * S] < 0.0) ajnorm = -ajnorm;
+          for (int i = j; i < m; ++i) fjac[((size_t)j * mmax + i) * S] /= ajnorm;
+          fjac[((size_t)j * mmax + j) * S] += 1.0;
           for (int k = j + 1; k < n; ++k) {
             double sum = 0.0;
-            for (int i = j; i < m; ++i) sum += fjac[(size_t)j * mmax + i] * fjac[(size_t)k * mmax + i];
-            const double temp = sum / fjac[(size_t)j * mmax + j];
-            for (int i = j; i < m; ++i) fjac[(size_t)k * mmax + i] -= temp * fjac[(size_t)j * mmax + i];
+            for (int i = j; i < m; ++i) sum += fjac[((size_t)j * mmax + i) * S] * fjac[((size_t)k * mmax + i) * S];
+            const double temp = sum / fjac[((size_t)j * mmax + j) * S];
+            for (int i = j; i < m; ++i) fjac[((size_t)k * mmax + i) * S] -= temp * fjac[((size_t)j * mmax + i) * S];
             if (wa1[k] != 0.0) {
-              double t = fjac[(size_t)k * mmax + j] / wa1[k];
+              double t = fjac[((size_t)k * mmax + j) * S] / wa1[k];
               t = 1.0 - t * t;
               wa1[k] *= sqrt(t > 0.0 ? t : 0.0);
               const double q = wa1[k] / wa3[k];
               if (0.05 * (q * q) <= epsmch) {
-                wa1[k] = hill_enorm(m - j - 1, fjac + (size_t)k * mmax + j + 1, 1);
+                wa1[k] = hill_enorm(m - j - 1, fjac + ((size_t)k * mmax + j + 1) * S, (int64_t)S);
                 wa3[k] = wa1[k];
               }
             }
@@ -326,20 +334,20 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
       if (delta == 0.0) delta = factor;
     }
     // ---- (q transpose) * fvec, first n components in qtf
-    for (int i = 0; i < m; ++i) wa4[i] = fvec[i];
+    for (int i = 0; i < m; ++i) wa4[i * S] = fvec[i * S];
     for (int j = 0; j < n; ++j) {
-      if (fjac[(size_t)j * mmax + j] != 0.0) {
+      if (fjac[((size_t)j * mmax + j) * S] != 0.0) {
         double sum = 0.0;
-        for (int i = j; i < m; ++i) sum += fjac[(size_t)j * mmax + i] * wa4[i];
-        const double temp = -sum / fjac[(size_t)j * mmax + j];
-        for (int i = j; i < m; ++i) wa4[i] += fjac[(size_t)j * mmax + i] * temp;
+        for (int i = j; i < m; ++i) sum += fjac[((size_t)j * mmax + i) * S] * wa4[i * S];
+        const double temp = -sum / fjac[((size_t)j * mmax + j) * S];
+        for (int i = j; i < m; ++i) wa4[i * S] += fjac[((size_t)j * mmax + i) * S] * temp;
       }
-      fjac[(size_t)j * mmax + j] = wa1[j];
-      qtf[j] = wa4[j];
+      fjac[((size_t)j * mmax + j) * S] = wa1[j];
+      qtf[j] = wa4[j * S];
     }
     // the n x n upper triangle R (column j, rows 0 .. j) in a register-sized copy: r[j * n + i]
     for (int j = 0; j < n; ++j)
-      for (int i = 0; i < n; ++i) r[j * n + i] = i <= j ? fjac[(size_t)j * mmax + i] : 0.0;
+      for (int i = 0; i < n; ++i) r[j * n + i] = i <= j ? fjac[((size_t)j * mmax + i) * S] : 0.0;
     // ---- norm of the scaled gradient
     double gnorm = 0.0;
     if (fnorm != 0.0)
@@ -367,7 +375,7 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
       if (iter == 1) delta = fmin(delta, pnorm);
       residuals(xnew, wa4);
       ++nfev;
-      const double fnorm1 = hill_enorm(m, wa4, 1);
+      const double fnorm1 = hill_enorm(m, wa4, (int64_t)S);
       double actred = -1.0;
       if (0.1 * fnorm1 < fnorm) { const double t = fnorm1 / fnorm; actred = 1.0 - t * t; }
       for (int j = 0; j < n; ++j) wa3[j] = 0.0;
@@ -394,7 +402,7 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
           x[j] = xnew[j];
           wa2[j] = diag[j] * x[j];
         }
-        for (int i = 0; i < m; ++i) fvec[i] = wa4[i];
+        for (int i = 0; i < m; ++i) fvec[i * S] = wa4[i * S];
         xnorm = hill_enorm(n, wa2, 1);
         fnorm = fnorm1;
         ++iter;

@@ -565,7 +565,7 @@ def hill_fit(x: torch.Tensor, y: torch.Tensor, lens: torch.Tensor | None = None)
     if not 4 <= m <= 1024:
         raise ValueError("4 .. 1024 samples per fit")
     dev = xs.device
-    work = torch.empty((n, 6 * m), dtype=torch.float64, device=dev)
+    work = torch.empty((8 * m, n), dtype=torch.float64, device=dev)
     params = torch.empty((n, 4), dtype=torch.float64, device=dev)
     info = torch.empty(n, dtype=torch.int32, device=dev)
     nfev = torch.empty(n, dtype=torch.int32, device=dev)
