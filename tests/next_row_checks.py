@@ -516,6 +516,22 @@ def check_hill_fit_vs_scipy(fit, n=60, seed=0):
     return converged
 
 
+def check_hill_fit_kernels_agree(fit, n=40, seed=5):
+    """pl_hill_fit has two kernels: eight lanes per fit with the vectors in LDS (windows of up to 126 samples) and one lane per
+    fit on a global workspace (longer ones).  The same windows through both -- the second time padded to a 160-sample
+    capacity -- must give IDENTICAL parameters, info and function-evaluation counts: the group kernel's leader runs the same
+    operations in the same order and the model values do not depend on the lane that computes them."""
+    xs, ys, lens = penumbra_windows(n, seed)
+    lens[:3] = (3, 4, 5)                                     # fewer samples than parameters (info -1), and the smallest fits
+    pa, ia, na = fit(xs, ys, lens)
+    wide = lambda a: np.concatenate([a, np.zeros((n, 160 - a.shape[1]))], axis=1)
+    pb, ib, nb = fit(wide(xs), wide(ys), lens)
+    assert ia[0] == -1 and np.isnan(pa[0]).all()
+    assert np.array_equal(ia, ib) and np.array_equal(na, nb), (ia, ib, na, nb)
+    assert np.array_equal(pa, pb, equal_nan=True)
+    return int(((ia >= 1) & (ia <= 4)).sum())
+
+
 def beam_profiles(n, length=200, seed=0):
     """`n` synthetic open-field profiles of `length` detectors: two Hill penumbrae, a slightly domed top, detector noise"""
     rng = np.random.default_rng(seed)

@@ -500,6 +500,7 @@ def test_emulated_hill_fit_matches_scipy(emulated):
         return p.cpu().numpy(), info.cpu().numpy(), nfev.cpu().numpy()
 
     assert checks.check_hill_fit_vs_scipy(fit, n=40) >= 36
+    assert checks.check_hill_fit_kernels_agree(fit, n=24) >= 18
 
 
 def test_emulated_hill_batch(golden, emulated):

@@ -1954,6 +1954,7 @@ def test_hill_fit_matches_scipy(dev):
         return p.cpu().numpy(), info.cpu().numpy(), nfev.cpu().numpy()
 
     assert checks.check_hill_fit_vs_scipy(fit, n=400, seed=3) >= 360
+    assert checks.check_hill_fit_kernels_agree(fit, n=512) >= 460
 
 
 @pytest.mark.gpu
