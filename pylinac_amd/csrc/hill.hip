@@ -14,9 +14,11 @@
 // 1e-5 that row already uses downstream of a fit (the reference reproduces its OWN parameters only to ~1e-7 run to run:
 // numpy's vectorised pow is not bit-reproducible).
 //
-// One LANE per fit (n = 4 parameters, m <= 1024 samples): the batches this serves are thousands of penumbra windows of a few
-// dozen samples; the Jacobian (4 x m), two m-vectors and the samples of a fit live in a caller-provided workspace in global
-// memory, transposed so that the fits of a wave sit side by side (see the kernel).
+// Two kernels, identical results (n = 4 parameters, m <= 1024 samples): hill_fit_group_kernel -- EIGHT lanes per fit, the
+// fit's vectors in LDS, for the batches this mostly serves (thousands of penumbra windows of a few dozen samples) -- and
+// hill_fit_kernel -- one LANE per fit, the Jacobian (4 x m), two m-vectors and the samples in a caller-provided workspace in
+// global memory, transposed so that the fits of a wave sit side by side -- for longer windows and for batches that fill the chip
+// with one lane per fit.
 #include <math.h>
 
 #include "pl_common.h"
