@@ -564,6 +564,35 @@ def check_hill_batch_vs_single(run_batch, make_single, n=6, length=120, sample=N
     return res
 
 
+def check_hill_batch_options(run_batch, make_single, length=90):
+    """single_profile_hill_batch against the per-profile mirror for every normalisation / interpolation choice, with a row that
+    has no field at all (a ramp: the derivative never reaches 0.8 of its range on both sides -> the reference raises, the batch
+    reports it in `info` and keeps the other rows)."""
+    profs = beam_profiles(4, length, seed=11)
+    profs[2] = np.linspace(1.0, 2.0, length) ** 2           # monotone: no falling edge
+    n_ok = 0
+    for norm in (None, "Max", "Geometric center", "Beam center"):
+        for interp, kw in (("Linear", {}), (None, {}), ("Spline", dict(dpmm=2.0, interpolation_resolution_mm=0.1))):
+            opts = dict(normalization_method=norm, interpolation=interp, hill_window_ratio=0.3, **kw)
+            res = run_batch(profs, **opts)
+            info = res.info.cpu().numpy()
+            for i in range(len(profs)):
+                try:
+                    single = make_single(profs[i].copy(), **opts)
+                    want = single.inflection_data()
+                except (IndexError, ValueError, RuntimeError, TypeError):
+                    assert not ((info[i] >= 1) & (info[i] <= 4)).all(), (norm, interp, i, info[i])
+                    continue
+                assert ((info[i] >= 1) & (info[i] <= 4)).all(), (norm, interp, i, info[i])
+                tol = 1e-6 if interp == "Spline" else 1e-9           # the device spline agrees with scipy's to ~1e-13
+                assert np.allclose(res.values[i].cpu().numpy(), single.values, rtol=tol, atol=1e-12), (norm, interp, i)
+                got = res.inflection_data(i)
+                for k in ("left index (exact)", "right index (exact)", "left value (@exact)", "right value (@exact)"):
+                    assert np.isclose(got[k], want[k], rtol=1e-5, atol=1e-5), (norm, interp, i, k, got[k], want[k])
+                n_ok += 1
+    return n_ok
+
+
 # ---------------------------------------------------------------------------------------------- Starshot
 def starshot_cases(g):
     for name in g["names"]:

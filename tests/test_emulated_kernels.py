@@ -512,9 +512,9 @@ def test_emulated_hill_batch(golden, emulated):
     n = checks.check_hill_batch(golden("hill"), profile.single_profile_hill_batch,
                                 only=lambda t: t.startswith(("fx0.", "fx2.", "fx3.", "fx6.", "fx8.", "epid.hill.dpmm", "fff1.")))
     assert n >= 10
-    checks.check_hill_batch_vs_single(
-        profile.single_profile_hill_batch,
-        lambda v, **kw: profile.SingleProfile(v, edge_detection_method=profile.Edge.INFLECTION_HILL, **kw), n=3, length=90)
+    single = lambda v, **kw: profile.SingleProfile(v, edge_detection_method=profile.Edge.INFLECTION_HILL, **kw)
+    checks.check_hill_batch_vs_single(profile.single_profile_hill_batch, single, n=3, length=90)
+    assert checks.check_hill_batch_options(profile.single_profile_hill_batch, single) == 36
 
 
 def test_emulated_starshot(golden, emulated):

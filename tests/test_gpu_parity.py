@@ -1977,6 +1977,10 @@ def test_hill_batch_vs_reference_golden_and_single(golden, dev):
             n=2048, length=200, sample=range(0, 2048, 256))
     info = res.info.cpu().numpy()
     assert ((info >= 1) & (info <= 4)).all()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert checks.check_hill_batch_options(
+            batch, lambda v, **kw: profile.SingleProfile(v, edge_detection_method=profile.Edge.INFLECTION_HILL, **kw)) == 36
     profs = T(checks.beam_profiles(2048, 200), dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
