@@ -20,6 +20,12 @@ constexpr int kThreads = 256;
 constexpr int kChunkBytes = 64 * 1024;  // bytes of input one block streams (read + write kernels reach 5.3-5.6 TB/s with it on
                                         // 256 x 1024 x 1024 uint16; 256 KiB or 1 MiB blocks measured the same or slower; the pure
                                         // reduction pl_minmax is the exception, see kMinmaxChunkBytes)
+
+template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };
+template <typename T> struct is_floating { static constexpr bool value = false; };
+template <> struct is_floating<float> { static constexpr bool value = true; };
+template <> struct is_floating<double> { static constexpr bool value = true; };
+
 struct Plan { int64_t chunk; int bpf; };  // elements per block, blocks per frame
 
 template <typename T>
