@@ -36,8 +36,13 @@ bash scripts/profile_configs.sh > $OUT/configs_kernel_stats.txt 2>&1
 # SQ counters of the config #5 / #3 kernels (two --pmc passes each, kernel trace only beside them)
 bash scripts/pmc_kernels.sh ct edge_otsu_kernel,edge_stream_kernel,mask_regions_kernel,circle_profile_combined,peak_valley_kernel -- python scripts/run_ct_pass.py 25 2 > /dev/null 2>&1
 cp gpurun_out/pmc_ct/summary.txt $OUT/pmc_sq_ct_kernels.txt
-bash scripts/pmc_kernels.sh pf pf_windows_kernel,scaled_colmean4,minmax_kernel -- python scripts/run_pf_pass.py 512 2 > /dev/null 2>&1
+bash scripts/pmc_kernels.sh pf pf_windows_kernel,scaled_colmeanv,minmax_kernel -- python scripts/run_pf_pass.py 512 2 > /dev/null 2>&1
 cp gpurun_out/pmc_pf/summary.txt $OUT/pmc_sq_pf_kernels.txt
 python scripts/run_ct_pass.py 25 8 | tee -a $OUT/summary.txt
 python scripts/run_pf_pass.py 512 8 | tee -a $OUT/summary.txt
 python scripts/time_wide_range.py 2>&1 | tail -2 | tee $OUT/wide_range.txt
+python scripts/time_hill_batch.py 4096 200 2>&1 | grep -v amdgpu.ids | tee $OUT/hill_batch.txt
+python scripts/time_elementwise.py 2>&1 | grep -v amdgpu.ids | tee $OUT/elementwise.txt
+for f in 256 64 32 8; do timeout 120 python bench.py --gpus 1 --frames $f --steps 30 --warmup 10 --no-cpu-baseline --no-configs 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('frames', $f, 'ms/step', d['ms_per_step'], 'us/frame', round(d['ms_per_step']*1e3/$f, 3), d['roofline']['stage_ms'])"; done | tee $OUT/small_batch_sweep.txt
