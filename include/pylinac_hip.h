@@ -667,6 +667,13 @@ int pl_hill_windows(const double* d_x_indices, const double* d_values, int64_t n
  * c * ((d - 1) / (d + 1)) ** (1 / d), and the curve's value at it. */
 int pl_hill_inflection(const double* d_params, int64_t n, double* d_out, void* stream);
 
+/* SingleProfile.penumbra for the Hill edge method (pylinac/core/profile.py:1852-1898; Hill.x / Hill.gradient_at,
+ * pylinac/core/hill.py:38-54): d_params float64 [n][4], d_inflection float64 [n][2] (pl_hill_inflection's output) ->
+ * d_out float64 [n][6] = index where the curve takes lower / 50 of its inflection value, that value, the same for upper, the
+ * distance of the two indices, the curve's gradient at the inflection point. */
+int pl_hill_penumbra(const double* d_params, const double* d_inflection, int64_t n, double lower, double upper, double* d_out,
+                     void* stream);
+
 /* SingleProfile._y_original_to_interp (pylinac/core/profile.py:1227-1235) per profile: d_out[i][j] = scipy's linear interp1d
  * (x_indices, values_i, extrapolating) at d_q[i][j].  d_x_indices float64 [s], d_values float64 [n][s], d_q / d_out [n][nq]. */
 int pl_profile_lookup(const double* d_x_indices, const double* d_values, int64_t n, int s, const double* d_q, int nq,

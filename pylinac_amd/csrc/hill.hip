@@ -811,6 +811,29 @@ __global__ void hill_inflection_kernel(const double* __restrict__ params, int64_
   out[2 * f + 1] = hill_value(idx, p);
 }
 
+// SingleProfile.penumbra for the Hill edge method (pylinac/core/profile.py:1852-1898): the positions where the fitted curve
+// takes lower / 50 and upper / 50 of its value at the inflection point (Hill.x, hill.py:48-54), their distance, and the
+// curve's gradient at the inflection point (Hill.gradient_at, hill.py:38-46).  out[f] = lower index, lower value, upper
+// index, upper value, |upper index - lower index|, gradient.
+__global__ void hill_penumbra_kernel(const double* __restrict__ params, const double* __restrict__ infl, int64_t nfits,
+                                     double lower, double upper, double* __restrict__ out) {
+  const int64_t f = (int64_t)blockIdx.x * kHillThreads + threadIdx.x;
+  if (f >= nfits) return;
+  const double a = params[f * 4], b = params[f * 4 + 1], c = params[f * 4 + 2], d = params[f * 4 + 3];
+  const double x0 = infl[2 * f], y0 = infl[2 * f + 1];
+  const double lo_v = y0 * lower / 50.0, hi_v = y0 * upper / 50.0;
+  auto x_at = [&](double y) { return c * pow((y - a) / (b - y), 1.0 / d); };
+  const double lo_i = x_at(lo_v), hi_i = x_at(hi_v);
+  const double cxd = pow(c / x0, d);
+  double* o = out + f * 6;
+  o[0] = lo_i;
+  o[1] = lo_v;
+  o[2] = hi_i;
+  o[3] = hi_v;
+  o[4] = fabs(hi_i - lo_i);
+  o[5] = (b - a) * d * cxd / (((cxd + 1.0) * (cxd + 1.0)) * x0);
+}
+
 // per-profile look-ups values_i(q_ij) through scipy's linear interp1d (SingleProfile._y_original_to_interp)
 __global__ void profile_lookup_kernel(const double* __restrict__ xi, const double* __restrict__ values, int S,
                                       const double* __restrict__ q, int nq, int64_t total, double* __restrict__ out) {
@@ -878,4 +901,15 @@ extern "C" int pl_profile_lookup(const double* d_x_indices, const double* d_valu
   hipLaunchKernelGGL(profile_lookup_kernel, dim3((unsigned)pl_cdiv(total, kHillThreads)), dim3(kHillThreads), 0,
                      (hipStream_t)stream, d_x_indices, d_values, s, d_q, nq, total, d_out);
   return pl_check_launch("pl_profile_lookup");
+}
+
+extern "C" int pl_hill_penumbra(const double* d_params, const double* d_inflection, int64_t n, double lower, double upper,
+                                double* d_out, void* stream) {
+  PL_REQUIRE(d_params && d_inflection && d_out, "null pointer");
+  PL_REQUIRE(n >= 0 && lower <= upper, "bad arguments (lower <= upper)");
+  if (n == 0) return PL_OK;
+  PL_REQUIRE(pl_cdiv(n, kHillThreads) <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(hill_penumbra_kernel, dim3((unsigned)pl_cdiv(n, kHillThreads)), dim3(kHillThreads), 0, (hipStream_t)stream,
+                     d_params, d_inflection, n, lower, upper, d_out);
+  return pl_check_launch("pl_hill_penumbra");
 }

@@ -606,6 +606,18 @@ def hill_inflection(params: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def hill_penumbra(params: torch.Tensor, inflection: torch.Tensor, lower: float, upper: float) -> torch.Tensor:
+    """The Hill-method part of ``SingleProfile.penumbra`` (pylinac/core/profile.py:1852-1898): params [..., 4], inflection
+    [..., 2] (index, value: :func:`hill_inflection`) -> [..., 6] = lower index, lower value, upper index, upper value, width,
+    gradient at the inflection point."""
+    p = params.to(torch.float64).contiguous()
+    q = inflection.to(torch.float64).contiguous()
+    out = torch.empty(p.shape[:-1] + (6,), dtype=torch.float64, device=p.device)
+    check(_lib.load().pl_hill_penumbra(p.data_ptr(), q.data_ptr(), p.numel() // 4, float(lower), float(upper), out.data_ptr(),
+                                       _stream()), "pl_hill_penumbra")
+    return out
+
+
 def profile_lookup(x_indices: torch.Tensor, values: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
     """``SingleProfile._y_original_to_interp`` per profile: values float64 [N, S], q float64 [N, Q] (or [N]) -> like q."""
     v = values.to(torch.float64).contiguous()

@@ -1148,6 +1148,27 @@ class HillEdgesBatch:
         }
 
 
+    def penumbra(self, lower: int = 20, upper: int = 80) -> dict:
+        """``SingleProfile.penumbra`` for the Hill method (profile.py:1852-1908) for every row: the reference's keys, each a
+        float64 [N] tensor on the device ("left values" / "right values" are ragged slices of ``values`` between the rounded
+        indices and are left to the caller).  Rows whose fit failed hold NaN."""
+        if lower > upper:
+            raise ValueError("Upper penumbra value must be larger than the lower penumbra value")
+        rec = ops.hill_penumbra(self.params, torch.stack([self.index, self.value], dim=-1), lower, upper)   # [N, 2, 6]
+        data = {}
+        for s, side in enumerate(("left", "right")):
+            data[f"{side} {lower}% index (exact)"] = rec[:, s, 0]
+            data[f"{side} {lower}% value (exact)"] = rec[:, s, 1]
+            data[f"{side} {upper}% index (exact)"] = rec[:, s, 2]
+            data[f"{side} {upper}% value (exact)"] = rec[:, s, 3]
+            data[f"{side} penumbra width (exact)"] = rec[:, s, 4]
+            data[f"{side} gradient (exact)"] = rec[:, s, 5]
+            if self.dpmm:
+                data[f"{side} gradient (exact) %/mm"] = rec[:, s, 5] * self.dpmm * 100
+                data[f"{side} penumbra width (exact) mm"] = rec[:, s, 4] / self.dpmm
+        return data
+
+
 def _lib_error(msg: str):
     from ._lib import PylinacHipError
 

@@ -589,6 +589,12 @@ def check_hill_batch_options(run_batch, make_single, length=90):
                 got = res.inflection_data(i)
                 for k in ("left index (exact)", "right index (exact)", "left value (@exact)", "right value (@exact)"):
                     assert np.isclose(got[k], want[k], rtol=1e-5, atol=1e-5), (norm, interp, i, k, got[k], want[k])
+                for lower, upper in ((20, 80), (10, 90)):        # penumbra(): every key but the ragged value slices
+                    pen_want, pen_got = single.penumbra(lower, upper), res.penumbra(lower, upper)
+                    keys = [k for k in pen_want if not k.endswith("values")]
+                    assert sorted(keys) == sorted(pen_got), (sorted(keys), sorted(pen_got))
+                    for k in keys:
+                        assert np.isclose(float(pen_got[k][i]), pen_want[k], rtol=1e-5, atol=1e-5), (norm, interp, i, k)
                 n_ok += 1
     return n_ok
 
