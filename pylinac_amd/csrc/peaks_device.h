@@ -269,6 +269,60 @@ __device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xf
     group_sync<NT>();
   }
 
+  // ---- the FWXM search (FWXMProfile.field_edge_idx: max_number = 1 by prominence, no prominence / width / distance filter):
+  // the one peak that survives stage G is the most prominent candidate -- among equals the LAST (np.argsort(kind="stable")
+  // [::-1][:1]) -- so the candidate tables, the O(P^2) ranking and the two ordered scans of stages G / H are skipped: every
+  // wave keeps the best of its candidates in registers and the wave that holds the overall best measures its width.
+  if (prm.max_number == 1 && prm.sort_key == PL_SORT_PROMINENCES && !prm.has_prominence && !(prm.width_min > 0.0)) {
+    double best_prom = -1.0;                               // prominences are >= 0
+    int best_p = -1, best_lb = 0, best_rb = 0;
+    for (int p = tid / PL_WAVE; p < P; p += NT / PL_WAVE) {
+      const int pk = s_idx[p];
+      double left_min, right_min;
+      int lb, rb;
+      prominence_side<-1>(xs, pk, m, left_min, lb);
+      prominence_side<+1>(xs, pk, m, right_min, rb);
+      const double prom = xs[pk] - (left_min > right_min ? left_min : right_min);
+      if (prom >= best_prom) { best_prom = prom; best_p = p; best_lb = lb; best_rb = rb; }   // p ascends: the last of equals
+    }
+    // the waves' bests meet in s_red (stage A is done with it): [prominence x 4][candidate index x 4]; the wave that owns the
+    // winner still has its bases in registers and reports
+    int win_p = best_p;
+    if constexpr (NT > PL_WAVE) {
+      const int wv = tid >> 6;
+      group_sync<NT>();
+      if ((tid & 63) == 0) { s_red[wv] = best_prom; s_red[4 + wv] = (double)best_p; }
+      group_sync<NT>();
+      double win_prom = -1.0;
+      win_p = -1;
+      for (int k = 0; k < NT / PL_WAVE; ++k) {
+        const double pr = s_red[k];
+        const int pp = (int)s_red[4 + k];
+        if (pp >= 0 && (win_p < 0 || pr > win_prom || (pr == win_prom && pp > win_p))) { win_prom = pr; win_p = pp; }
+      }
+    }
+    if (best_p >= 0 && best_p == win_p) {                  // wave-uniform: the winner's wave
+      const int pk = s_idx[best_p];
+      const Widths wd = peak_width(xs, pk, best_lb, best_rb, best_prom, prm.rel_height);
+      if ((tid & (PL_WAVE - 1)) == 0) {
+        o_idx[0] = pk + lo;
+        o_lb[0] = best_lb;
+        o_rb[0] = best_rb;
+        o_p[0 * cap] = xs[pk];
+        o_p[1 * cap] = best_prom;
+        o_p[2 * cap] = wd.width;
+        o_p[3 * cap] = wd.height;
+        o_p[4 * cap] = wd.lip;
+        o_p[5 * cap] = wd.rip;
+      }
+    }
+    if (tid == 0) {
+      *o_count = win_p >= 0 ? 1 : 0;
+      *o_status = overflow ? 2 : 0;
+    }
+    return;
+  }
+
   // ---- D/E/F: prominences, bases, widths, filters (one wave per peak, see the walk helpers) -------
   for (int p = tid / PL_WAVE; p < P; p += NT / PL_WAVE) {
     const int pk = s_idx[p];

@@ -625,6 +625,18 @@ def test_emulated_find_peaks_sweep(emulated):
                 np.testing.assert_array_equal(props[k], wprops[k], err_msg=f"{k} {len(v)} {kw}")
             checked += 1
     assert checked > 150
+    # the FWXM search (max_number = 1 by prominence, no filter) takes a short cut through the search; with a prominence bound of
+    # zero -- which no peak fails -- the same call takes the general path: same peak, exact ties on the prominence included
+    same = 0
+    for v in profs:
+        for kw in (dict(max_number=1), dict(max_number=1, fwxm_height=0.3, peak_separation=2)):
+            a_idx, a = profile.find_peaks(v, **kw)
+            b_idx, b = profile.find_peaks(v, required_prominence=0.0, **kw)
+            np.testing.assert_array_equal(a_idx, b_idx, err_msg=f"{len(v)} {kw}")
+            for k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} {len(v)} {kw}")
+            same += len(a_idx)
+    assert same > 80
 
 
 def test_emulated_thickness_roi(golden, emulated):
