@@ -53,13 +53,16 @@ class EpidPipeline:
     fwxm_height: float = 50
     # True: per-band column sums + ONE launch for profile -> peaks -> record (pl_colparts_profile_fwxm) instead of memset +
     # 64-bit atomics + three small launches.  Same results; measured on 256 x 1024^2 (scripts/time_epid_tail.py): 0.7675 ms
-    # per step against 0.760 -- back-to-back launches on one stream cost next to nothing, so the default stays False
-    fused_tail: bool = False
+    # per step against 0.760 -- back-to-back launches on one stream cost next to nothing at that size, so the default (None)
+    # turns it on for small batches only, where three launch latencies are a tenth of the step
+    fused_tail: bool | None = None
     timings: dict = field(default_factory=dict)
 
     def __post_init__(self):
         dev = self.device
         n, h, w = self.n, self.h, self.w
+        if self.fused_tail is None:
+            self.fused_tail = n <= 64
         u16 = dict(dtype=torch.uint16, device=dev)
         self.buf_a = torch.empty((n, h, w), **u16)
         self.buf_b = torch.empty((n, h, w), **u16)
