@@ -646,7 +646,7 @@ int pl_scaled_rowmean(const uint16_t* in, int64_t n, int h, int w, const double*
  *   d_x / d_y float64 [n][stride] (fit i uses its first d_lens[i] samples; d_lens NULL = mmax for all), 4 <= samples <= mmax
  *   <= 1024; d_work float64 [8 * mmax][n] scratch (transposed: the fits of a wave side by side); d_params float64 [n][4] = a, b, c, d (NaN when the fit has fewer than four
  *   samples); d_info int32 [n] = MINPACK's info (1-4 converged -- curve_fit accepts exactly these --, 5 maxfev, 6-8 tolerances
- *   too small, -1 too few samples); d_nfev (optional) int32 [n] function evaluations. */
+ *   too small, -1 too few samples, -4 a NaN or infinity among the samples: curve_fit raises ValueError); d_nfev (optional) int32 [n] function evaluations. */
 int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
                 double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, void* stream);
 

@@ -243,7 +243,18 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
   // p0 = (min(y), max(y), np.median(x), 0): the median of the (sorted, as np.arange makes them) x values by selection
   double x[n];
   {
-    for (int i = 0; i < m; ++i) { xt[i * S] = xd[i]; yt[i * S] = yd[i]; }
+    bool finite = true;                                     // curve_fit(check_finite=True) raises ValueError for NaN / inf
+    for (int i = 0; i < m; ++i) {
+      xt[i * S] = xd[i];
+      yt[i * S] = yd[i];
+      finite = finite && fabs(xd[i]) <= 1.7976931348623157e308 && fabs(yd[i]) <= 1.7976931348623157e308;
+    }
+    if (!finite) {
+      for (int j = 0; j < n; ++j) out[j] = nan;
+      info_out[fit] = -4;
+      if (nfev_out) nfev_out[fit] = 0;
+      return;
+    }
     double mn = yd[0], mx = yd[0];
     for (int i = 1; i < m; ++i) { mn = yt[i * S] < mn ? yt[i * S] : mn; mx = yt[i * S] > mx ? yt[i * S] : mx; }
     // order statistics k_lo, k_hi of x by counting (m is a few dozen)
@@ -483,7 +494,24 @@ hill_fit_group_kernel(const double* __restrict__ xs, const double* __restrict__ 
   } else {
     const double* xd = xs + fit * stride;
     const double* yd = ys + fit * stride;
-    for (int i = sub; i < m; i += G) { xt[i] = xd[i]; yt[i] = yd[i]; }
+    if (leader) comm[12] = 0.0;
+    pl_wave_sync();
+    bool finite = true;                                      // curve_fit(check_finite=True) raises ValueError for NaN / inf
+    for (int i = sub; i < m; i += G) {
+      xt[i] = xd[i];
+      yt[i] = yd[i];
+      finite = finite && fabs(xd[i]) <= 1.7976931348623157e308 && fabs(yd[i]) <= 1.7976931348623157e308;
+    }
+    if (!finite) comm[12] = 1.0;                             // (any lane of the group: the same value)
+  }
+  pl_wave_sync();
+  if (phase != kHillDone && comm[12] != 0.0) {
+    if (leader) {
+      for (int j = 0; j < n; ++j) params[fit * n + j] = nan;
+      info_out[fit] = -4;
+      if (nfev_out) nfev_out[fit] = 0;
+    }
+    phase = kHillDone;
   }
   pl_wave_sync();
   // p0 = (min(y), max(y), np.median(x), 0): the order statistics of x by counting, the group's lanes sharing the candidates

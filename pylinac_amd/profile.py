@@ -1120,7 +1120,8 @@ class HillEdgesBatch:
     derivative_edges: torch.Tensor  # float64 [N, 2]   the windows' centres (the INFLECTION_DERIVATIVE edges)
     info: torch.Tensor              # int32 [N, 2]     MINPACK info: 1-4 = converged (what curve_fit accepts); 5-8 = curve_fit
                                     #                  raises RuntimeError; -1 = fewer than four samples in the window (TypeError);
-                                    #                  -2 = no derivative peak / valley (IndexError); -3 = more extrema than peak_cap
+                                    #                  -2 = no derivative peak / valley (IndexError); -3 = more extrema than peak_cap;
+                                    #                  -4 = NaN / infinity in a window (curve_fit's check_finite: ValueError)
     nfev: torch.Tensor              # int32 [N, 2]
 
     def inflection_data(self, i: int) -> dict:
@@ -1133,6 +1134,8 @@ class HillEdgesBatch:
                 raise IndexError("index 0 is out of bounds for axis 0 with size 0")
             if code == -1:
                 raise TypeError("The number of func parameters=4 must not exceed the number of data points")
+            if code == -4:
+                raise ValueError("array must not contain infs or NaNs")
             if not 1 <= code <= 4:
                 raise RuntimeError(f"Optimal parameters not found ({side} penumbra of profile {i}: MINPACK info {code})")
         idx, val, prm = self.index[i].cpu().numpy(), self.value[i].cpu().numpy(), self.params[i].cpu().numpy()

@@ -532,6 +532,35 @@ def check_hill_fit_kernels_agree(fit, n=40, seed=5):
     return int(((ia >= 1) & (ia <= 4)).sum())
 
 
+def check_hill_fit_pathological(fit):
+    """Windows no fit should be asked about -- constant, NaN, infinity, 1e300, 1e-300, pure noise, a step, a zero abscissa
+    (c / x = inf): both kernels of pl_hill_fit must TERMINATE, agree bit for bit, report NaN / inf as info -4 (curve_fit's
+    check_finite raises ValueError there) and leave the well-posed row alone."""
+    m = 24
+    x = np.arange(100, 100 + m, dtype=float)
+    good = 1 / (1 + (110 / x) ** 20)
+    rows = [np.full(m, 0.5), np.where(np.arange(m) == 5, np.nan, good), np.where(np.arange(m) == 7, np.inf, good), 1e300 * good,
+            1e-300 * good, np.random.default_rng(0).random(m), (x > 111).astype(float), good]
+    ys = np.stack(rows)
+    lens = np.full(len(rows), m, np.int32)
+    for zero_x in (False, True):
+        xs = np.stack([x] * len(rows))
+        if zero_x:
+            xs[:, 0] = 0.0
+        outs = []
+        for pad in (0, 140):                                 # the group kernel / the one-lane kernel
+            grow = lambda a: np.concatenate([a, np.zeros((len(a), pad))], axis=1)
+            outs.append(fit(grow(xs), grow(ys), lens))
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b, equal_nan=True)
+        params, info, nfev = outs[0]
+        assert info[1] == -4 and info[2] == -4 and np.isnan(params[1]).all() and np.isnan(params[2]).all(), info
+        assert (nfev <= 1005).all()
+        if not zero_x:
+            assert 1 <= info[-1] <= 4 and abs(params[-1][2] - 110) < 1e-6 and abs(params[-1][3] - 20) < 1e-5, (info, params[-1])
+    return True
+
+
 def beam_profiles(n, length=200, seed=0):
     """`n` synthetic open-field profiles of `length` detectors: two Hill penumbrae, a slightly domed top, detector noise"""
     rng = np.random.default_rng(seed)

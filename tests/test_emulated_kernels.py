@@ -501,6 +501,7 @@ def test_emulated_hill_fit_matches_scipy(emulated):
 
     assert checks.check_hill_fit_vs_scipy(fit, n=40) >= 36
     assert checks.check_hill_fit_kernels_agree(fit, n=24) >= 18
+    assert checks.check_hill_fit_pathological(fit)
 
 
 def test_emulated_hill_batch(golden, emulated):
