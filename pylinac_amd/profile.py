@@ -1200,19 +1200,11 @@ def _hill_edges_stage(vals: torch.Tensor, xi_dev: torch.Tensor, span: float, edg
     return params.view(n, 2, 4), infl.view(n, 2, 2), edges, info.view(n, 2), nfev.view(n, 2)
 
 
-def single_profile_hill_batch(values, dpmm: float | None = None, interpolation=Interpolation.LINEAR, ground: bool = True,
-                              interpolation_resolution_mm: float = 0.1, interpolation_factor: float = 10,
-                              normalization_method=Normalization.BEAM_CENTER, edge_smoothing_ratio: float = 0.003,
-                              hill_window_ratio: float = 0.1, peak_cap: int = 32) -> HillEdgesBatch:
-    """``SingleProfile(values_i, ..., edge_detection_method=Edge.INFLECTION_HILL)`` followed by ``inflection_data()`` for every
-    row of ``values`` [N, L] (equal lengths, x = 0 .. L-1: the rows of an image, a detector array's frames) with no per-profile
-    host call: the constructor's resampling, grounding and normalisation (pylinac/core/profile.py:1165-1215), the smoothed
-    derivative and its extrema, both penumbra windows and both four-parameter fits (profile.py:1635-1721, hill.py:18-36) are
-    batched launches.  BEAM_CENTER normalisation runs the edge search twice, like the reference's constructor (the norm value is
-    the profile at the midpoint of the two Hill inflection points).  Rows whose search or fit fails are reported in ``info``
-    (their results are NaN), not raised."""
+def _batch_constructor(values, dpmm, interpolation, ground, interpolation_resolution_mm, interpolation_factor):
+    """``SingleProfile.__init__`` up to the normalisation (pylinac/core/profile.py:1182-1205) for every row of ``values`` [N, L]
+    (x = 0 .. L-1): resampling and grounding -> (fitted float64 [N, S] on the device, x_indices numpy [S], x_indices on the
+    device)."""
     interp = _enum(interpolation, Interpolation)
-    norm = _enum(normalization_method, Normalization)
     v = values if isinstance(values, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64))
     if v.dim() != 2:
         raise ValueError("values must be [N, L]")
@@ -1236,25 +1228,127 @@ def single_profile_hill_batch(values, dpmm: float | None = None, interpolation=I
         fitted = ops.interp1d(xs, v, torch.from_numpy(x_indices).to(v.device),
                               kind="linear" if interp == Interpolation.LINEAR else "cubic")
     xi_dev = torch.from_numpy(np.ascontiguousarray(x_indices)).to(v.device)
-    span = float(x_indices[-1] - x_indices[0])
     if ground:
         fitted = ops.ground(fitted.unsqueeze(1)).squeeze(1)
+    return fitted.contiguous(), x_indices, xi_dev
+
+
+def _batch_normalize(fitted: torch.Tensor, norm: Normalization, beam_center_value):
+    """``SingleProfile._normalize`` (profile.py:1362-1371) per row; ``beam_center_value(fitted)`` -> float64 [N] is the edge
+    method's ``beam_center()["value (@rounded)"]`` on the unnormalised profiles."""
     if norm == Normalization.MAX:
-        fitted = ops.normalize(fitted.unsqueeze(1)).squeeze(1)
-    elif norm == Normalization.GEOMETRIC_CENTER:            # array_utils.geometric_center_value
+        return ops.normalize(fitted.unsqueeze(1)).squeeze(1).contiguous()
+    if norm == Normalization.GEOMETRIC_CENTER:              # array_utils.geometric_center_value
         s = fitted.shape[1]
         gc = (fitted[:, s // 2] + fitted[:, s // 2 - 1]) / 2.0 if s % 2 == 0 else fitted[:, (s - 1) // 2]
-        fitted = ops.normalize(fitted.unsqueeze(1), gc.contiguous()).squeeze(1)
-    elif norm == Normalization.BEAM_CENTER:                 # beam_center() (profile.py:1390-1409) on the unnormalised profile
-        _, infl, _, _, _ = _hill_edges_stage(fitted, xi_dev, span, edge_smoothing_ratio, hill_window_ratio, peak_cap)
+        return ops.normalize(fitted.unsqueeze(1), gc.contiguous()).squeeze(1).contiguous()
+    if norm == Normalization.BEAM_CENTER:
+        return ops.normalize(fitted.unsqueeze(1), beam_center_value(fitted).contiguous()).squeeze(1).contiguous()
+    return fitted
+
+
+def single_profile_hill_batch(values, dpmm: float | None = None, interpolation=Interpolation.LINEAR, ground: bool = True,
+                              interpolation_resolution_mm: float = 0.1, interpolation_factor: float = 10,
+                              normalization_method=Normalization.BEAM_CENTER, edge_smoothing_ratio: float = 0.003,
+                              hill_window_ratio: float = 0.1, peak_cap: int = 32) -> HillEdgesBatch:
+    """``SingleProfile(values_i, ..., edge_detection_method=Edge.INFLECTION_HILL)`` followed by ``inflection_data()`` for every
+    row of ``values`` [N, L] (equal lengths, x = 0 .. L-1: the rows of an image, a detector array's frames) with no per-profile
+    host call: the constructor's resampling, grounding and normalisation (pylinac/core/profile.py:1165-1215), the smoothed
+    derivative and its extrema, both penumbra windows and both four-parameter fits (profile.py:1635-1721, hill.py:18-36) are
+    batched launches.  BEAM_CENTER normalisation runs the edge search twice, like the reference's constructor (the norm value is
+    the profile at the midpoint of the two Hill inflection points).  Rows whose search or fit fails are reported in ``info``
+    (their results are NaN), not raised."""
+    norm = _enum(normalization_method, Normalization)
+    fitted, x_indices, xi_dev = _batch_constructor(values, dpmm, interpolation, ground, interpolation_resolution_mm,
+                                                   interpolation_factor)
+    span = float(x_indices[-1] - x_indices[0])
+
+    def beam_center_value(unnormalised):                    # beam_center() (profile.py:1390-1409) on the unnormalised profile
+        _, infl, _, _, _ = _hill_edges_stage(unnormalised, xi_dev, span, edge_smoothing_ratio, hill_window_ratio, peak_cap)
         left, right = infl[:, 0, 0], infl[:, 1, 0]
         mid = torch.round(left + (right - left) / 2)        # int(round(mid_point)): half to even, like python's
-        centre = ops.profile_lookup(xi_dev, fitted, mid.contiguous())
-        fitted = ops.normalize(fitted.unsqueeze(1), centre.contiguous()).squeeze(1)
-    fitted = fitted.contiguous()
+        return ops.profile_lookup(xi_dev, unnormalised, mid.contiguous())
+
+    fitted = _batch_normalize(fitted, norm, beam_center_value)
     params, infl, edges, info, nfev = _hill_edges_stage(fitted, xi_dev, span, edge_smoothing_ratio, hill_window_ratio, peak_cap)
     return HillEdgesBatch(values=fitted, x_indices=x_indices, dpmm=dpmm,
                           params=params, index=infl[..., 0], value=infl[..., 1], derivative_edges=edges, info=info, nfev=nfev)
+
+
+@dataclass
+class FWXMEdgesBatch:
+    """What ``SingleProfile(..., edge_detection_method=FWHM)`` holds, for every row of a batch (:func:`single_profile_fwhm_batch`);
+    ``fwxm_data(x)`` returns the reference's keys as float64 [N] tensors on the device."""
+
+    values: torch.Tensor            # float64 [N, S]   the processed profiles (SingleProfile.values)
+    x_indices: np.ndarray           # float64 [S]
+    dpmm: float | None
+
+    def _edges(self, x: float, values: torch.Tensor | None = None):
+        """left / right FWXM edges in ORIGINAL coordinates and the peak count per row (0: the reference raises IndexError)"""
+        v = self.values if values is None else values
+        res = ops.find_peaks_batch(v, cap=1, fwxm_height=x / 100, max_number=1)
+        s = v.shape[1]
+        dev = v.device
+        grid = torch.arange(s, dtype=torch.float64, device=dev)
+        xi = torch.from_numpy(np.ascontiguousarray(self.x_indices)).to(dev)
+        ips = torch.stack([res.props[:, 4, 0], res.props[:, 5, 0]], dim=0).reshape(1, -1)      # left_ips, right_ips
+        ips = torch.where(res.count.repeat(2).reshape(1, -1) > 0, ips, torch.zeros_like(ips))
+        orig = ops.profile_lookup(grid, xi.reshape(1, -1), ips.contiguous()).reshape(2, -1)    # _x_interp_to_original
+        nan = torch.full_like(orig[0], float("nan"))
+        ok = res.count > 0
+        return torch.where(ok, orig[0], nan), torch.where(ok, orig[1], nan), res.count, xi
+
+    def fwxm_data(self, x: int = 50) -> dict:
+        """``SingleProfile.fwxm_data`` (profile.py:1411-1461) for every row; rows without a peak hold NaN ("peaks" is 0 there).
+        "field values" (a ragged slice) and "peak_props" are left out."""
+        if not 0 <= x <= 100:
+            raise ValueError("x must be within (0, 100)")
+        left, right, count, xi = self._edges(x)
+        width = right - left
+        centre = (right - left) / 2 + left
+        at = lambda idx: ops.profile_lookup(xi, self.values, torch.nan_to_num(torch.round(idx)).contiguous())
+        bad = count <= 0
+        mask = lambda t: torch.where(bad, torch.full_like(t, float("nan")), t)
+        data = {
+            "peaks": count,
+            "width (exact)": width,
+            "width (rounded)": torch.round(width),
+            "center index (rounded)": torch.round(centre),
+            "center index (exact)": centre,
+            "center value (@rounded)": mask(at(centre)),
+            "left index (exact)": left,
+            "left index (rounded)": torch.round(left),
+            "left value (@rounded)": mask(at(left)),
+            "right index (exact)": right,
+            "right index (rounded)": torch.round(right),
+            "right value (@rounded)": mask(at(right)),
+        }
+        if self.dpmm:
+            data["width (exact) mm"] = width / self.dpmm
+            data["left distance (exact) mm"] = torch.abs(centre - left) / self.dpmm
+            data["right distance (exact) mm"] = torch.abs(right - centre) / self.dpmm
+        return data
+
+    def beam_center(self) -> dict:
+        """``SingleProfile.beam_center`` for the FWHM method (profile.py:1390-1399)."""
+        d = self.fwxm_data(50)
+        return {"index (rounded)": d["center index (rounded)"], "index (exact)": d["center index (exact)"],
+                "value (@rounded)": d["center value (@rounded)"]}
+
+
+def single_profile_fwhm_batch(values, dpmm: float | None = None, interpolation=Interpolation.LINEAR, ground: bool = True,
+                              interpolation_resolution_mm: float = 0.1, interpolation_factor: float = 10,
+                              normalization_method=Normalization.BEAM_CENTER) -> FWXMEdgesBatch:
+    """``SingleProfile(values_i, ...)`` with the default FWHM edge method for every row of ``values`` [N, L] (equal lengths) in
+    batched launches: resampling, grounding, the beam-centre (or maximum / geometric-centre) normalisation
+    (pylinac/core/profile.py:1165-1215, 1362-1409); ``fwxm_data(x)`` / ``beam_center()`` of the result answer for all rows."""
+    norm = _enum(normalization_method, Normalization)
+    fitted, x_indices, _ = _batch_constructor(values, dpmm, interpolation, ground, interpolation_resolution_mm,
+                                              interpolation_factor)
+    fitted = _batch_normalize(fitted, norm, lambda unnormalised: FWXMEdgesBatch(unnormalised, x_indices, dpmm)
+                              .fwxm_data(50)["center value (@rounded)"])
+    return FWXMEdgesBatch(values=fitted, x_indices=x_indices, dpmm=dpmm)
 
 
 def _linregress(x, y):

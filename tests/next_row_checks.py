@@ -628,6 +628,36 @@ def check_hill_batch_options(run_batch, make_single, length=90):
     return n_ok
 
 
+def check_fwhm_batch(run_batch, make_single, length=90):
+    """single_profile_fwhm_batch against the per-profile mirror (default FWHM edge method) for every normalisation /
+    interpolation choice: processed values and every scalar key of fwxm_data(x) for x = 50, 20, 80; a row without a peak (a
+    ramp) holds NaN where the reference raises IndexError."""
+    profs = beam_profiles(4, length, seed=13)
+    profs[1] = np.linspace(1.0, 2.0, length)                # monotone: find_peaks finds nothing
+    n_ok = 0
+    for norm in (None, "Max", "Geometric center", "Beam center"):
+        for interp, kw in (("Linear", {}), (None, {}), ("Spline", dict(dpmm=2.0, interpolation_resolution_mm=0.1))):
+            opts = dict(normalization_method=norm, interpolation=interp, **kw)
+            res = run_batch(profs, **opts)
+            for x in (50, 20, 80):
+                got = {k: v.cpu().numpy() for k, v in res.fwxm_data(x).items()}
+                for i in range(len(profs)):
+                    try:
+                        single = make_single(profs[i].copy(), **opts)
+                        want = single.fwxm_data(x)
+                    except IndexError:
+                        assert got["peaks"][i] == 0 or np.isnan(res.values[i].cpu().numpy()).any(), (norm, interp, x, i)
+                        continue
+                    tol = 1e-6 if interp == "Spline" else 1e-9
+                    assert np.allclose(res.values[i].cpu().numpy(), single.values, rtol=tol, atol=1e-12), (norm, interp, i)
+                    keys = [k for k in want if k not in ("field values", "peak_props")]
+                    assert sorted(keys) == sorted(k for k in got if k != "peaks"), (sorted(keys), sorted(got))
+                    for k in keys:
+                        assert np.isclose(got[k][i], want[k], rtol=tol, atol=1e-9), (norm, interp, x, i, k, got[k][i], want[k])
+                    n_ok += 1
+    return n_ok
+
+
 # ---------------------------------------------------------------------------------------------- Starshot
 def starshot_cases(g):
     for name in g["names"]:

@@ -518,6 +518,14 @@ def test_emulated_hill_batch(golden, emulated):
     assert checks.check_hill_batch_options(profile.single_profile_hill_batch, single) == 36
 
 
+def test_emulated_fwhm_batch(emulated):
+    """single_profile_fwhm_batch (the default edge method for every row of a batch) against the per-profile SingleProfile."""
+    import next_row_checks as checks
+    from pylinac_amd import profile
+
+    assert checks.check_fwhm_batch(profile.single_profile_fwhm_batch, lambda v, **kw: profile.SingleProfile(v, **kw)) == 108
+
+
 def test_emulated_starshot(golden, emulated):
     """Starshot.analyze on the emulated device (one integer and the float32 frame; the full set runs with -m gpu)."""
     import next_row_checks as checks

@@ -1989,3 +1989,21 @@ def test_hill_batch_vs_reference_golden_and_single(golden, dev):
     torch.cuda.synchronize()
     print(f"\nsingle_profile_hill_batch: 2048 profiles x 200 detectors (resampled x10), BEAM_CENTER normalisation: "
           f"{(time.perf_counter() - t0) * 1e3:.2f} ms")
+
+
+@pytest.mark.gpu
+def test_fwhm_batch_vs_single(dev):
+    """single_profile_fwhm_batch against the per-profile SingleProfile for every normalisation / interpolation choice, then 4096
+    profiles in one batch: a sample against the mirror, all rows with a peak."""
+    import next_row_checks as checks
+    from pylinac_amd import profile
+
+    assert checks.check_fwhm_batch(profile.single_profile_fwhm_batch, lambda v, **kw: profile.SingleProfile(v, **kw)) == 108
+    profs = checks.beam_profiles(4096, 200, seed=3)
+    res = profile.single_profile_fwhm_batch(T(profs, dev))
+    d = {k: v.cpu().numpy() for k, v in res.fwxm_data(50).items()}
+    assert (d["peaks"] == 1).all()
+    for i in range(0, 4096, 512):
+        want = profile.SingleProfile(profs[i].copy()).fwxm_data(50)
+        for k in ("left index (exact)", "right index (exact)", "center value (@rounded)", "width (exact)"):
+            assert np.isclose(d[k][i], want[k], rtol=1e-9, atol=1e-9), (i, k)
