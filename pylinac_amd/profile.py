@@ -1351,6 +1351,69 @@ def single_profile_fwhm_batch(values, dpmm: float | None = None, interpolation=I
     return FWXMEdgesBatch(values=fitted, x_indices=x_indices, dpmm=dpmm)
 
 
+@dataclass
+class InflectionEdgesBatch:
+    """``SingleProfile(..., edge_detection_method=INFLECTION_DERIVATIVE)`` and its ``inflection_data()`` (profile.py:1635-1674,
+    1711-1721) for every row of a batch (:func:`single_profile_inflection_batch`): float64 [N] tensors under the reference's
+    keys; rows whose derivative has no peak or valley (the reference raises IndexError) hold NaN."""
+
+    values: torch.Tensor            # float64 [N, S]
+    x_indices: np.ndarray           # float64 [S]
+    dpmm: float | None
+    edges: torch.Tensor             # float64 [N, 2]   left / right index (exact)
+    status: torch.Tensor            # int32 [N]        0 ok, 2 no derivative peak / valley, 3 more extrema than peak_cap
+
+    def inflection_data(self) -> dict:
+        xi = torch.from_numpy(np.ascontiguousarray(self.x_indices)).to(self.values.device)
+        left, right = self.edges[:, 0].contiguous(), self.edges[:, 1].contiguous()
+        at = lambda q: torch.where(torch.isnan(q), q, ops.profile_lookup(xi, self.values, torch.nan_to_num(q).contiguous()))
+        return {
+            "left index (rounded)": torch.round(left),
+            "left index (exact)": left,
+            "right index (rounded)": torch.round(right),
+            "right index (exact)": right,
+            "left value (@rounded)": at(torch.round(left)),
+            "left value (@exact)": at(left),
+            "right value (@rounded)": at(torch.round(right)),
+            "right value (@exact)": at(right),
+        }
+
+
+def _inflection_edges_stage(vals: torch.Tensor, xi_dev: torch.Tensor, edge_smoothing_ratio: float, peak_cap: int):
+    """the outermost extrema of the smoothed derivative in original coordinates (profile.py:1660-1674) -> ([N, 2], status)"""
+    n, s = vals.shape
+    sm = ops.gaussian_filter1d(vals, edge_smoothing_ratio * s)
+    d1 = ops.gradient1d(sm)
+    cap = max(min(peak_cap, s // 2 + 1), 1)
+    pk = ops.find_peaks_batch(d1, cap=cap, threshold=0.8, peak_separation=0.05)
+    vl = ops.find_peaks_batch(-d1, cap=cap, threshold=0.8, peak_separation=0.05)
+    _, _, _, edges = ops.hill_windows(xi_dev, vals, pk, vl, 0.0, 4)     # (the windows themselves are not needed here)
+    status = torch.where(torch.isnan(edges).any(dim=1), 2, 0).to(torch.int32)
+    status = torch.where((pk.status != 0) | (vl.status != 0), torch.full_like(status, 3), status)
+    return edges, status
+
+
+def single_profile_inflection_batch(values, dpmm: float | None = None, interpolation=Interpolation.LINEAR, ground: bool = True,
+                                    interpolation_resolution_mm: float = 0.1, interpolation_factor: float = 10,
+                                    normalization_method=Normalization.BEAM_CENTER, edge_smoothing_ratio: float = 0.003,
+                                    peak_cap: int = 32) -> InflectionEdgesBatch:
+    """``SingleProfile(values_i, ..., edge_detection_method=Edge.INFLECTION_DERIVATIVE)`` for every row of ``values`` [N, L] in
+    batched launches (the constructor of :func:`single_profile_hill_batch` without the fits: the beam centre is the midpoint of
+    the derivative's outermost extrema, profile.py:1400-1409)."""
+    norm = _enum(normalization_method, Normalization)
+    fitted, x_indices, xi_dev = _batch_constructor(values, dpmm, interpolation, ground, interpolation_resolution_mm,
+                                                   interpolation_factor)
+
+    def beam_center_value(unnormalised):
+        e, _ = _inflection_edges_stage(unnormalised, xi_dev, edge_smoothing_ratio, peak_cap)
+        mid = torch.round(e[:, 0] + (e[:, 1] - e[:, 0]) / 2)
+        return torch.where(torch.isnan(mid), mid, ops.profile_lookup(xi_dev, unnormalised, torch.nan_to_num(mid).contiguous()))
+
+    fitted = _batch_normalize(fitted, norm, beam_center_value)
+    edges, status = _inflection_edges_stage(fitted, xi_dev, edge_smoothing_ratio, peak_cap)
+    return InflectionEdgesBatch(values=fitted, x_indices=x_indices, dpmm=dpmm, edges=edges, status=status)
+
+
 def _linregress(x, y):
     """slope / intercept of ``scipy.stats.linregress`` (ssxym / ssxm from the biased covariance matrix)."""
     x = np.asarray(x, dtype=float)

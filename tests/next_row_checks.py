@@ -658,6 +658,35 @@ def check_fwhm_batch(run_batch, make_single, length=90):
     return n_ok
 
 
+def check_inflection_batch(run_batch, make_single, length=90):
+    """single_profile_inflection_batch against the per-profile mirror (INFLECTION_DERIVATIVE) for every normalisation /
+    interpolation choice, a row without a falling edge included (NaN + status 2 where the reference raises)."""
+    profs = beam_profiles(4, length, seed=17)
+    profs[3] = np.linspace(1.0, 2.0, length) ** 2
+    n_ok = 0
+    for norm in (None, "Max", "Geometric center", "Beam center"):
+        for interp, kw in (("Linear", {}), (None, {}), ("Spline", dict(dpmm=2.0, interpolation_resolution_mm=0.1))):
+            opts = dict(normalization_method=norm, interpolation=interp, **kw)
+            res = run_batch(profs, **opts)
+            got = {k: v.cpu().numpy() for k, v in res.inflection_data().items()}
+            status = res.status.cpu().numpy()
+            for i in range(len(profs)):
+                try:
+                    single = make_single(profs[i].copy(), **opts)
+                    want = single.inflection_data()
+                except (IndexError, ValueError):
+                    assert status[i] != 0 and np.isnan(got["left index (exact)"][i]), (norm, interp, i)
+                    continue
+                tol = 1e-6 if interp == "Spline" else 1e-9
+                assert status[i] == 0
+                assert np.allclose(res.values[i].cpu().numpy(), single.values, rtol=tol, atol=1e-12), (norm, interp, i)
+                assert sorted(want) == sorted(got)
+                for k in want:
+                    assert np.isclose(got[k][i], want[k], rtol=tol, atol=1e-9), (norm, interp, i, k, got[k][i], want[k])
+                n_ok += 1
+    return n_ok
+
+
 # ---------------------------------------------------------------------------------------------- Starshot
 def starshot_cases(g):
     for name in g["names"]:

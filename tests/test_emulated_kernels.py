@@ -524,6 +524,9 @@ def test_emulated_fwhm_batch(emulated):
     from pylinac_amd import profile
 
     assert checks.check_fwhm_batch(profile.single_profile_fwhm_batch, lambda v, **kw: profile.SingleProfile(v, **kw)) == 108
+    assert checks.check_inflection_batch(
+        profile.single_profile_inflection_batch,
+        lambda v, **kw: profile.SingleProfile(v, edge_detection_method=profile.Edge.INFLECTION_DERIVATIVE, **kw)) == 36
 
 
 def test_emulated_starshot(golden, emulated):

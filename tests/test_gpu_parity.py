@@ -1999,6 +1999,9 @@ def test_fwhm_batch_vs_single(dev):
     from pylinac_amd import profile
 
     assert checks.check_fwhm_batch(profile.single_profile_fwhm_batch, lambda v, **kw: profile.SingleProfile(v, **kw)) == 108
+    assert checks.check_inflection_batch(
+        profile.single_profile_inflection_batch,
+        lambda v, **kw: profile.SingleProfile(v, edge_detection_method=profile.Edge.INFLECTION_DERIVATIVE, **kw)) == 36
     profs = checks.beam_profiles(4096, 200, seed=3)
     res = profile.single_profile_fwhm_batch(T(profs, dev))
     d = {k: v.cpu().numpy() for k, v in res.fwxm_data(50).items()}
