@@ -1330,6 +1330,23 @@ class FWXMEdgesBatch:
             data["right distance (exact) mm"] = torch.abs(right - centre) / self.dpmm
         return data
 
+    def penumbra(self, lower: int = 20, upper: int = 80) -> dict:
+        """``SingleProfile.penumbra`` for the FWHM method (profile.py:1759-1790) for every row: the FWXM edges at ``lower`` and
+        ``upper`` per cent ("left values" / "right values", ragged slices, are left out)."""
+        if lower > upper:
+            raise ValueError("Upper penumbra value must be larger than the lower penumbra value")
+        lo, up = self.fwxm_data(lower), self.fwxm_data(upper)
+        data = {}
+        for side in ("left", "right"):
+            data[f"{side} {lower}% index (exact)"] = lo[f"{side} index (exact)"]
+            data[f"{side} {lower}% value (@rounded)"] = lo[f"{side} value (@rounded)"]
+            data[f"{side} {upper}% index (exact)"] = up[f"{side} index (exact)"]
+            data[f"{side} {upper}% value (@rounded)"] = up[f"{side} value (@rounded)"]
+            data[f"{side} penumbra width (exact)"] = torch.abs(up[f"{side} index (exact)"] - lo[f"{side} index (exact)"])
+            if self.dpmm:
+                data[f"{side} penumbra width (exact) mm"] = data[f"{side} penumbra width (exact)"] / self.dpmm
+        return data
+
     def beam_center(self) -> dict:
         """``SingleProfile.beam_center`` for the FWHM method (profile.py:1390-1399)."""
         d = self.fwxm_data(50)

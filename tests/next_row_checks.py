@@ -655,6 +655,13 @@ def check_fwhm_batch(run_batch, make_single, length=90):
                     for k in keys:
                         assert np.isclose(got[k][i], want[k], rtol=tol, atol=1e-9), (norm, interp, x, i, k, got[k][i], want[k])
                     n_ok += 1
+            pen = {k: v.cpu().numpy() for k, v in res.penumbra(20, 80).items()}
+            for i in (0, 2, 3):                             # (row 1 has no peak)
+                want = make_single(profs[i].copy(), **opts).penumbra(20, 80)
+                keys = [k for k in want if not k.endswith("values")]
+                assert sorted(keys) == sorted(pen), (sorted(keys), sorted(pen))
+                for k in keys:
+                    assert np.isclose(pen[k][i], want[k], rtol=1e-6 if interp == "Spline" else 1e-9, atol=1e-9), (norm, interp, i, k)
     return n_ok
 
 
