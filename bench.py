@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0          # measured float4 copy (same guide): the ceiling a streaming kernel can reach
 ALG_BYTES_PER_FRAME = 4_194_304  # read u16 frame + write u16 frame
-ALG_BYTES = {"#2": 4_194_304, "#3": 1_572_864, "#4": 2_097_152, "#5": 524_288}   # read-once roofline per frame / slice
+ALG_BYTES = {"#2": 4_194_304, "#3": 1_572_864, "#4": 2_097_152, "#5": 524_288,     # read-once roofline per frame / slice
+             "f4": 1_600}                                                             # row f4: one 200-detector float64 profile
 
 
 def parse():
@@ -222,7 +223,47 @@ def bench_configs(dev, world=8):
                 "ROI (scharr, gaussian, Otsu, clear_border, fill, label, regionprops) -> axis fits -> +-3-slice max -> "
                 "collapsed circle profile -> 8-region peak/valley rMTF", nv * 80, "slices/s", dt,
           "synthetic.catphan_volume seed 4000+v", parity_ct(r5, vols, 0.5))
+    try:                                                    # (an extra row must not take the bench line down)
+        hill_entry(dev, entry, out)
+    except Exception as exc:
+        out["f4h"] = {"error": repr(exc)}
     return out, vols
+
+
+def hill_entry(dev, entry, out, n=4096):
+    """SURVEY row f4 (not a BASELINE configuration): SingleProfile(edge_detection_method=INFLECTION_HILL) + inflection_data() for
+    4 096 open-field detector profiles in one batch -- resampling, grounding, beam-centre normalisation (= the edge search and
+    both Hill fits twice), no per-profile host call; compute-bound (MINPACK's Levenberg-Marquardt per penumbra), so `frac` is
+    only there for uniformity.  Parity sample: the oracle's restated SingleProfile (scipy curve_fit) at the row's 1e-5."""
+    import numpy as np
+    import torch
+
+    from oracle import pylinac_oracle as o
+    from pylinac_amd import profile
+
+    length = 200
+    rng = np.random.default_rng(4100)
+    x = np.arange(length, dtype=float) + 1.0
+    profs = np.empty((n, length))
+    for i in range(n):
+        left, right, steep = rng.uniform(0.2, 0.3) * length, rng.uniform(0.7, 0.8) * length, rng.uniform(15, 40)
+        dome = 1.0 - rng.uniform(0, 0.05) * ((x - (left + right) / 2) / length) ** 2
+        profs[i] = (rng.uniform(50, 200) / (1.0 + (left / x) ** steep) / (1.0 + (x / right) ** (steep * right / left)) * dome
+                    + rng.uniform(0, 2) + rng.normal(0, 0.05, length))
+    d = torch.from_numpy(profs).to(dev)
+    dt, res = timed_passes(lambda: profile.single_profile_hill_batch(d), iters=5)
+    info = res.info.cpu().numpy()
+    ok = bool(((info >= 1) & (info <= 4)).all())
+    idx, val = res.index.cpu().numpy(), res.value.cpu().numpy()
+    for i in (0, n // 2, n - 1):
+        want = o.SingleProfileRestated(profs[i], edge_detection_method="Inflection Hill").inflection_data()
+        got = [idx[i, 0], idx[i, 1], val[i, 0], val[i, 1]]
+        ref = [want["left index (exact)"], want["right index (exact)"], want["left value (@exact)"], want["right value (@exact)"]]
+        ok &= bool(np.allclose(got, ref, rtol=1e-5, atol=1e-5))
+    entry("f4h", "SingleProfile(INFLECTION_HILL) constructor + inflection_data() for 4096 profiles x 200 detectors (x10 linear "
+                 "resampling, BEAM_CENTER normalisation: 16 384 four-parameter Hill fits)", n, "profiles/s", dt,
+          "two Hill penumbrae + dome + N(0, 0.05), numpy default_rng(4100)", {"units": 3, "ok": ok})
+    out["f4h"]["nfev_mean"] = round(float(res.nfev.float().mean()), 1)
 
 
 def _median_rate(fn, warmup=3, repeats=5):

@@ -628,18 +628,18 @@ def check_hill_batch_options(run_batch, make_single, length=90):
     return n_ok
 
 
-def check_fwhm_batch(run_batch, make_single, length=90):
+def check_fwhm_batch(run_batch, make_single, length=90, xs=(50, 20, 80), norms=(None, "Max", "Geometric center", "Beam center")):
     """single_profile_fwhm_batch against the per-profile mirror (default FWHM edge method) for every normalisation /
     interpolation choice: processed values and every scalar key of fwxm_data(x) for x = 50, 20, 80; a row without a peak (a
     ramp) holds NaN where the reference raises IndexError."""
     profs = beam_profiles(4, length, seed=13)
     profs[1] = np.linspace(1.0, 2.0, length)                # monotone: find_peaks finds nothing
     n_ok = 0
-    for norm in (None, "Max", "Geometric center", "Beam center"):
+    for norm in norms:
         for interp, kw in (("Linear", {}), (None, {}), ("Spline", dict(dpmm=2.0, interpolation_resolution_mm=0.1))):
             opts = dict(normalization_method=norm, interpolation=interp, **kw)
             res = run_batch(profs, **opts)
-            for x in (50, 20, 80):
+            for x in xs:
                 got = {k: v.cpu().numpy() for k, v in res.fwxm_data(x).items()}
                 for i in range(len(profs)):
                     try:
@@ -665,13 +665,13 @@ def check_fwhm_batch(run_batch, make_single, length=90):
     return n_ok
 
 
-def check_inflection_batch(run_batch, make_single, length=90):
+def check_inflection_batch(run_batch, make_single, length=90, norms=(None, "Max", "Geometric center", "Beam center")):
     """single_profile_inflection_batch against the per-profile mirror (INFLECTION_DERIVATIVE) for every normalisation /
     interpolation choice, a row without a falling edge included (NaN + status 2 where the reference raises)."""
     profs = beam_profiles(4, length, seed=17)
     profs[3] = np.linspace(1.0, 2.0, length) ** 2
     n_ok = 0
-    for norm in (None, "Max", "Geometric center", "Beam center"):
+    for norm in norms:
         for interp, kw in (("Linear", {}), (None, {}), ("Spline", dict(dpmm=2.0, interpolation_resolution_mm=0.1))):
             opts = dict(normalization_method=norm, interpolation=interp, **kw)
             res = run_batch(profs, **opts)
