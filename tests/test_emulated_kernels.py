@@ -777,7 +777,7 @@ def test_emulated_bb_finder_random_windows(emulated):
     rng = np.random.default_rng(77)
     dpmm = 2.98
     wins, specs = [], []
-    for k in range(7):          # k = 1, 4: a second BB; k = 2, 6: a rod (the emulator runs a window in ~10 s)
+    for k in range(5):          # k = 1, 4: a second BB; k = 2: a rod (the emulator runs a window in ~10 s; -m gpu runs hundreds)
         n = int(rng.integers(90, 150))
         yy, xx = np.mgrid[0:n, 0:n].astype(float)
         img = np.full((n, n), 0.2)
@@ -811,7 +811,7 @@ def test_emulated_bb_finder_random_windows(emulated):
                                     min_separation_mm=minsep, level_by_level=True)
         assert int(lv["count"][0]) == int(res["count"][0]) and int(lv["level"][0]) == int(res["level"][0])
         assert np.array_equal(lv["xy"][0, : len(ref_pts)].cpu().numpy(), res["xy"][0, : len(ref_pts)].cpu().numpy())
-    assert checked >= 4
+    assert checked >= 3
 
 
 def test_emulated_picket_fence_random_frames(emulated):
