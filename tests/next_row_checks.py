@@ -694,6 +694,42 @@ def check_inflection_batch(run_batch, make_single, length=90, norms=(None, "Max"
     return n_ok
 
 
+def check_fwhm_batch_golden(g, run_batch, only_lengths=None):
+    """single_profile_fwhm_batch against the REFERENCE's own SingleProfile numbers (tests/golden/single_profile.npz: its 20 frozen
+    detector profiles without abscissae x 3 resampling modes, grouped by length -- a batch shares length and arguments -- and
+    the EPID profile with dpmm / factor / normalisation options): x_indices and processed values (bit-identical for NONE /
+    LINEAR, 1e-10 for SPLINE) and the seven scalars of fwxm_data(50 / 25 / 80) at 1e-9."""
+    wkeys = [str(k) for k in g["fwxm_keys"]]
+    n = 0
+    groups = {}
+    for i in range(20):
+        groups.setdefault(len(g[f"fx{i}.y"]), []).append(i)
+    cases = []
+    for length, idxs in groups.items():
+        if only_lengths is not None and length not in only_lengths:
+            continue
+        for mode, interp in (("none_nox", None), ("linear_nox", "Linear"), ("spline_nox", "Spline")):
+            cases.append(([f"fx{i}.{mode}" for i in idxs], np.stack([g[f"fx{i}.y"] for i in idxs]), dict(interpolation=interp)))
+    epid = {"dpmm": dict(dpmm=1 / 0.336), "dpmm_spline": dict(dpmm=1 / 0.336, interpolation="Spline", interpolation_resolution_mm=0.05),
+            "factor3": dict(interpolation_factor=3), "max": dict(normalization_method="Max"),
+            "geo": dict(normalization_method="Geometric center"), "raw": dict(normalization_method=None, ground=False, interpolation=None)}
+    if only_lengths is None:
+        for name, kw in epid.items():
+            cases.append(([f"epid.{name}"], g["epid.y"][None].copy(), kw))
+    for tags, values, kw in cases:
+        res = run_batch(values, **kw)
+        vtol = 1e-10 if kw.get("interpolation") == "Spline" else 0
+        got = {h: {k: v.cpu().numpy() for k, v in res.fwxm_data(h).items()} for h in (50, 25, 80)}
+        vals = res.values.cpu().numpy()
+        for r, tag in enumerate(tags):
+            assert np.array_equal(np.asarray(res.x_indices, float), g[f"{tag}.x_indices"]), tag
+            assert np.allclose(vals[r], g[f"{tag}.values"], rtol=vtol, atol=vtol), tag
+            for h in (50, 25, 80):
+                assert np.allclose([got[h][k][r] for k in wkeys], g[f"{tag}.fwxm{h}"], rtol=1e-9, atol=1e-9), (tag, h)
+            n += 1
+    return n
+
+
 # ---------------------------------------------------------------------------------------------- Starshot
 def starshot_cases(g):
     for name in g["names"]:

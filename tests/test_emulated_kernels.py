@@ -518,10 +518,13 @@ def test_emulated_hill_batch(golden, emulated):
     assert checks.check_hill_batch_options(profile.single_profile_hill_batch, single) == 36
 
 
-def test_emulated_fwhm_batch(emulated):
-    """single_profile_fwhm_batch (the default edge method for every row of a batch) against the per-profile SingleProfile."""
+def test_emulated_fwhm_batch(golden, emulated):
+    """single_profile_fwhm_batch (the default edge method for every row of a batch) against the reference's own SingleProfile
+    numbers (its frozen 63- and 65-detector profiles) and against the per-profile SingleProfile."""
     import next_row_checks as checks
     from pylinac_amd import profile
+
+    assert checks.check_fwhm_batch_golden(golden("single_profile"), profile.single_profile_fwhm_batch, only_lengths={63, 65}) == 21
 
     assert checks.check_fwhm_batch(profile.single_profile_fwhm_batch, lambda v, **kw: profile.SingleProfile(v, **kw),
                                    xs=(50, 20), norms=("Geometric center", "Beam center")) == 36

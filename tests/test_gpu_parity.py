@@ -1992,11 +1992,14 @@ def test_hill_batch_vs_reference_golden_and_single(golden, dev):
 
 
 @pytest.mark.gpu
-def test_fwhm_batch_vs_single(dev):
-    """single_profile_fwhm_batch against the per-profile SingleProfile for every normalisation / interpolation choice, then 4096
-    profiles in one batch: a sample against the mirror, all rows with a peak."""
+def test_fwhm_batch_vs_single(golden, dev):
+    """single_profile_fwhm_batch against the reference's own SingleProfile numbers (20 frozen profiles x 3 resampling modes + the
+    EPID options of single_profile.npz), against the per-profile SingleProfile for every normalisation / interpolation choice,
+    then 4096 profiles in one batch: a sample against the mirror, all rows with a peak."""
     import next_row_checks as checks
     from pylinac_amd import profile
+
+    assert checks.check_fwhm_batch_golden(golden("single_profile"), profile.single_profile_fwhm_batch) == 66
 
     assert checks.check_fwhm_batch(profile.single_profile_fwhm_batch, lambda v, **kw: profile.SingleProfile(v, **kw)) == 108
     assert checks.check_inflection_batch(
