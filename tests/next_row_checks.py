@@ -730,6 +730,45 @@ def check_fwhm_batch_golden(g, run_batch, only_lengths=None):
     return n
 
 
+def check_profile_batch_golden(g, batch_fns):
+    """The three batched SingleProfile paths against the REFERENCE's own SingleProfile (tests/golden/profile_batch.npz, made by
+    tests/golden/make_profile_batch_golden.py: its frozen 63-detector profiles and synthetic open-field profiles, three
+    constructor option sets): `batch_fns` = dict(infl=, fwhm=, hill=) -> the batch objects.  inflection_data() and the
+    processed values of the derivative method, penumbra(20, 80) of the FWHM and Hill methods; 1e-9 (1e-5 downstream of a Hill
+    fit); where the reference raised, the batch must flag the row."""
+    opts = {"default": {}, "none": dict(interpolation=None), "max_dpmm": dict(normalization_method="Max", dpmm=2.0)}
+    ikeys, fkeys, hkeys = ([str(k) for k in g[n]] for n in ("infl_keys", "fwhm_pen_keys", "hill_pen_keys"))
+    n = 0
+    for sname in g["sets"]:
+        rows = g[f"{sname}.rows"]
+        for oname, kw in opts.items():
+            infl = batch_fns["infl"](rows, **kw)
+            idata = {k: v.cpu().numpy() for k, v in infl.inflection_data().items()}
+            ivals, istat = infl.values.cpu().numpy(), infl.status.cpu().numpy()
+            fpen = {k: v.cpu().numpy() for k, v in batch_fns["fwhm"](rows, **kw).penumbra(20, 80).items()}
+            hill = batch_fns["hill"](rows, **kw)
+            hpen = {k: v.cpu().numpy() for k, v in hill.penumbra(20, 80).items()}
+            hinfo = hill.info.cpu().numpy()
+            for r in range(len(rows)):
+                tag = f"{sname}.{oname}.{r}"
+                if f"{tag}.infl.error" in g:
+                    assert istat[r] != 0, tag
+                else:
+                    assert istat[r] == 0, tag
+                    assert np.allclose(ivals[r], g[f"{tag}.infl_values"], rtol=1e-9, atol=1e-12), tag
+                    assert np.allclose([idata[k][r] for k in ikeys], g[f"{tag}.infl"], rtol=1e-9, atol=1e-9), tag
+                if f"{tag}.fwhm.error" not in g:
+                    assert np.allclose([fpen[k][r] for k in fkeys], g[f"{tag}.fwhm_pen"], rtol=1e-9, atol=1e-9), tag
+                if f"{tag}.hill.error" in g:
+                    assert not ((hinfo[r] >= 1) & (hinfo[r] <= 4)).all() or np.isnan([hpen[k][r] for k in hkeys]).any(), tag
+                else:
+                    assert ((hinfo[r] >= 1) & (hinfo[r] <= 4)).all(), (tag, hinfo[r])
+                    got, want = np.array([hpen[k][r] for k in hkeys]), g[f"{tag}.hill_pen"]
+                    assert np.allclose(got, want, rtol=1e-5, atol=1e-5), (tag, got, want)
+                n += 1
+    return n
+
+
 # ---------------------------------------------------------------------------------------------- Starshot
 def starshot_cases(g):
     for name in g["names"]:

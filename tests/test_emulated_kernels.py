@@ -525,6 +525,9 @@ def test_emulated_fwhm_batch(golden, emulated):
     from pylinac_amd import profile
 
     assert checks.check_fwhm_batch_golden(golden("single_profile"), profile.single_profile_fwhm_batch, only_lengths={63, 65}) == 21
+    fns = dict(infl=profile.single_profile_inflection_batch, fwhm=profile.single_profile_fwhm_batch,
+               hill=profile.single_profile_hill_batch)
+    assert checks.check_profile_batch_golden(golden("profile_batch"), fns) == 33
 
     assert checks.check_fwhm_batch(profile.single_profile_fwhm_batch, lambda v, **kw: profile.SingleProfile(v, **kw),
                                    xs=(50, 20), norms=("Geometric center", "Beam center")) == 36

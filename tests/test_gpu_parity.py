@@ -2000,6 +2000,9 @@ def test_fwhm_batch_vs_single(golden, dev):
     from pylinac_amd import profile
 
     assert checks.check_fwhm_batch_golden(golden("single_profile"), profile.single_profile_fwhm_batch) == 66
+    fns = dict(infl=profile.single_profile_inflection_batch, fwhm=profile.single_profile_fwhm_batch,
+               hill=profile.single_profile_hill_batch)
+    assert checks.check_profile_batch_golden(golden("profile_batch"), fns) == 33      # the reference's own numbers, three methods
 
     assert checks.check_fwhm_batch(profile.single_profile_fwhm_batch, lambda v, **kw: profile.SingleProfile(v, **kw)) == 108
     assert checks.check_inflection_batch(
