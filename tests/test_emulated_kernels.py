@@ -504,6 +504,25 @@ def test_emulated_hill_fit_matches_scipy(emulated):
     assert checks.check_hill_fit_pathological(fit)
 
 
+def test_emu_hill_entry_points_reject_bad_arguments(emu):
+    """The Hill entry points' own argument checks (C ABI: PL_REQUIRE -> non-zero code + pl_last_error), no launch."""
+    d = np.zeros(64)
+    i32 = np.zeros(16, np.int32)
+    f = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    emu.pl_hill_fit.argtypes, emu.pl_hill_fit.restype = f, C.c_int
+    assert emu.pl_hill_fit(_p(d), _p(d), None, 1, 3, 3, _p(d), _p(d), _p(i32), None, None) != 0          # fewer than 4 samples of room
+    assert b"4 .. 1024" in emu.pl_last_error()
+    assert emu.pl_hill_fit(_p(d), _p(d), None, 1, 8, 4, _p(d), _p(d), _p(i32), None, None) != 0          # stride < mmax
+    assert emu.pl_hill_fit(None, _p(d), None, 1, 8, 8, _p(d), _p(d), _p(i32), None, None) != 0           # null pointer
+    assert emu.pl_hill_fit(_p(d), _p(d), None, 0, 8, 8, _p(d), _p(d), _p(i32), None, None) == 0          # empty batch: nothing to do
+    emu.pl_hill_penumbra.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    emu.pl_hill_penumbra.restype = C.c_int
+    assert emu.pl_hill_penumbra(_p(d), _p(d), 1, 80.0, 20.0, _p(d), None) != 0                           # lower > upper
+    emu.pl_profile_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    emu.pl_profile_lookup.restype = C.c_int
+    assert emu.pl_profile_lookup(_p(d), _p(d), 1, 1, _p(d), 1, _p(d), None) != 0                         # one sample: no interval
+
+
 def test_emulated_hill_batch(golden, emulated):
     """single_profile_hill_batch (no per-profile host call) against the reference's SingleProfile numbers of hill.npz and
     against the per-profile mirror."""
