@@ -123,8 +123,8 @@ minmax_kernel(const T* __restrict__ in, int64_t count, int64_t chunk, int bpf, d
   if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const int64_t nvec = len / N;
     const uint4* vsrc = reinterpret_cast<const uint4*>(src);
-    // FOUR 16-byte loads per lane in flight (a streaming kernel's rate is its bytes in flight over the loaded latency: one
-    // load per lane and iteration reached 3.4 TB/s on 256 x 768 x 1024 uint16); 16-bit integers through the packed min / max
+    // kMinmaxLoads 16-byte loads per lane in flight (a streaming kernel's rate is its bytes in flight over the loaded latency:
+    // one load per lane and iteration reached 3.4 TB/s on 256 x 768 x 1024 uint16); 16-bit integers through the packed min / max
     if constexpr (sizeof(T) == 2 && !is_floating<T>::value) {
       typedef T T2 __attribute__((ext_vector_type(2)));
       T2 lo2 = {lo, lo}, hi2 = {hi, hi};
