@@ -679,6 +679,10 @@ int pl_hill_penumbra(const double* d_params, const double* d_inflection, int64_t
 int pl_profile_lookup(const double* d_x_indices, const double* d_values, int64_t n, int s, const double* d_q, int nq,
                       double* d_out, void* stream);
 
+/* SingleProfile._x_interp_to_original (pylinac/core/profile.py:1204, 1217-1226): interp1d(range(s), x_indices) without
+ * extrapolation = numpy's compiled np.interp (the grid value itself on a grid point).  d_q / d_out float64 [total]. */
+int pl_index_to_original(const double* d_x_indices, int s, const double* d_q, int64_t total, double* d_out, void* stream);
+
 /* FWXMProfile.field_edge_idx/center_idx/field_width_px (pylinac/core/profile.py:602-611, 322-344)
  * from a pl_find_peaks result obtained with max_number = 1:
  * d_out float64 [n][8] = n_peaks, peak_idx, height, prominence, left, right, centre, width

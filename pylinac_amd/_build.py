@@ -61,11 +61,12 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 def build(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
     extra = os.environ.get("PL_EXTRA_HIPCC_FLAGS", "").split()
-    # a variant build (e.g. -DPL_OTSU_VARIANT=1 compiles a stopwatch kernel that gives WRONG thresholds) must never leave
-    # objects a later plain build would reuse: its objects go to their own directory and the link is forced
-    build_dir = BUILD if not extra else BUILD.parent / ("hip_" + hashlib.sha256(" ".join(extra).encode()).hexdigest()[:12])
-    stamp = BUILD.parent / "last_flags"
-    flags_changed = (stamp.read_text() if stamp.exists() else "") != " ".join(extra)
+    # a variant build (e.g. -DPL_OTSU_VARIANT=1 compiles a stopwatch kernel that gives WRONG thresholds) never touches the
+    # product library or its objects: objects and the linked library go to build/variants/<hash>/, and only a process that
+    # sets PYLINAC_HIP_LIB to that path (see _lib.lib_path) loads it
+    tag = hashlib.sha256(" ".join(extra).encode()).hexdigest()[:12] if extra else ""
+    build_dir = BUILD if not extra else BUILD.parent / "variants" / tag
+    target = LIB if not extra else build_dir / "libpylinac_hip.so"
     build_dir.mkdir(parents=True, exist_ok=True)
     headers = list(CSRC.glob("*.h")) + [PKG.parent / "include" / "pylinac_hip.h", Path(__file__)]
     jobs = []
@@ -87,10 +88,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or flags_changed or _stale(LIB, objs):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)])
-        stamp.write_text(" ".join(extra))
-    return LIB
+    if force or jobs or _stale(target, objs):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(target), *map(str, objs)])
+    return target
 
 
 if __name__ == "__main__":

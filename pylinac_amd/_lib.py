@@ -106,6 +106,7 @@ SIGNATURES = {
     "pl_hill_inflection": ([_p, _l, _p, _p], C.c_int),
     "pl_hill_penumbra": ([_p, _p, _l, _d, _d, _p, _p], C.c_int),
     "pl_profile_lookup": ([_p, _p, _l, _i, _p, _i, _p, _p], C.c_int),
+    "pl_index_to_original": ([_p, _i, _p, _l, _p, _p], C.c_int),
     "pl_edge_plane": ([_p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p], C.c_int),
     "pl_mask_regions_fits": ([_i, _i, _i], C.c_int),
     "pl_mask_regions": ([_p, _i, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p], C.c_int),

@@ -775,7 +775,7 @@ __device__ __forceinline__ double hill_lookup(const double* __restrict__ xi, con
 //   x_right   = [x for x in np.arange(right_idx - half, right_idx + half) if x < len(d1)]
 //   y         = _y_original_to_interp(x)
 // np.arange on floats: length = ceil(stop - start), element 0 = start, element 1 = start + 1.0, element i = start + i * delta
-// with delta = element 1 - element 0 (numpy's DOUBLE_fill) -- restated so that the windows are the reference's bit for bit.
+// with delta = element 1 - element 0 (numpy's DOUBLE_fill); the edges come from np.interp's grid-point rule (to_original below).
 __global__ void __launch_bounds__(kHillThreads)
 hill_windows_kernel(const double* __restrict__ xi, const double* __restrict__ values, int S, const int32_t* __restrict__ pk_count,
                     const int32_t* __restrict__ pk_idx, int cap_p, const int32_t* __restrict__ vl_count,
@@ -792,12 +792,9 @@ hill_windows_kernel(const double* __restrict__ xi, const double* __restrict__ va
     }
     return;
   }
-  auto to_original = [&](int k) {                           // _x_interp_to_original: interp1d(arange(S), x_indices)(k)
-    int hi = k < 1 ? 1 : (k > S - 1 ? S - 1 : k);
-    const int lo = hi - 1;
-    const double slope = (xi[hi] - xi[lo]) / ((double)hi - (double)lo);
-    return slope * ((double)k - (double)lo) + xi[lo];
-  };
+  // _x_interp_to_original: interp1d(arange(S), x_indices) does not extrapolate, so scipy hands it to np.interp, which returns
+  // x_indices[k] itself on a grid point (no slope arithmetic: no last-bit difference on resampled grids)
+  auto to_original = [&](int k) { return xi[k < 0 ? 0 : (k > S - 1 ? S - 1 : k)]; };
   const double left = to_original(pk_idx[p * cap_p]);
   const double right = to_original(vl_idx[p * cap_v + (nv < cap_v ? nv : cap_v) - 1]);
   const double half = rint(ratio * fabs(right - left) / 2.0);          // python's round(): half to even
@@ -870,7 +867,41 @@ __global__ void profile_lookup_kernel(const double* __restrict__ xi, const doubl
   out[i] = hill_lookup(xi, values + (i / nq) * (int64_t)S, S, q[i]);
 }
 
+// SingleProfile._x_interp_to_original for fractional positions: np.interp(q, arange(S), x_indices) (numpy's compiled interp:
+// j = the interval with j <= q < j + 1, the grid value itself when q == j, else slope * (q - j) + x_indices[j] with
+// slope = (x_indices[j + 1] - x_indices[j]) / ((j + 1) - j); positions outside [0, S - 1] take the end values)
+__global__ void index_to_original_kernel(const double* __restrict__ xi, int S, const double* __restrict__ q, int64_t total,
+                                         double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kHillThreads + threadIdx.x;
+  if (i >= total) return;
+  const double x = q[i];
+  double r;
+  if (x != x) r = x;
+  else if (x <= 0.0) r = xi[0];
+  else if (x >= (double)(S - 1)) r = xi[S - 1];
+  else {
+    const int j = (int)floor(x);
+    if (x == (double)j) r = xi[j];
+    else {
+      const double slope = (xi[j + 1] - xi[j]) / ((double)(j + 1) - (double)j);
+      r = slope * (x - (double)j) + xi[j];
+    }
+  }
+  out[i] = r;
+}
+
 }  // namespace
+
+extern "C" int pl_index_to_original(const double* d_x_indices, int s, const double* d_q, int64_t total, double* d_out,
+                                    void* stream) {
+  PL_REQUIRE(d_x_indices && d_q && d_out, "null pointer");
+  PL_REQUIRE(s >= 2 && total >= 0, "bad shape");
+  if (total == 0) return PL_OK;
+  PL_REQUIRE(pl_cdiv(total, kHillThreads) <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(index_to_original_kernel, dim3((unsigned)pl_cdiv(total, kHillThreads)), dim3(kHillThreads), 0,
+                     (hipStream_t)stream, d_x_indices, s, d_q, total, d_out);
+  return pl_check_launch("pl_index_to_original");
+}
 
 extern "C" int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
                            double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, void* stream) {

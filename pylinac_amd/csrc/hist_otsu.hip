@@ -467,8 +467,10 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     if (threadIdx.x == 0) flag[frame] = 0;
   } else {
     uint32_t* table = merge + frame * 65536;
-    if (spilled && threadIdx.x == 0) atomicExch(&flag[frame], 1);
     unsigned seen = 0;
+    // RETURNING exchange, its value folded into `seen`: the wave waits for the flag write to be performed before it reaches
+    // the barrier and thread 0 takes the arrival ticket, so the last part cannot read a stale 0
+    if (spilled && threadIdx.x == 0) seen |= atomicExch(&flag[frame], 1) == 0x7fffffff ? 1u : 0u;
     if (!spilled)
       for (int i = threadIdx.x; i < range; i += kHistThreads) {
         const unsigned c = bins[i];

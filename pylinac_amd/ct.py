@@ -517,13 +517,16 @@ def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=
     flats = [x[a:b].reshape((b - a) * spv, hh, ww) for a, b in bounds]
     rois = [None if given else _phantom_roi_launch(f, mm_per_pixel) for f in flats]
     gz = (np.atleast_2d(np.asarray(fit_zx, dtype=np.float64)), np.atleast_2d(np.asarray(fit_zy, dtype=np.float64))) if given else None
-    second, where = [], []
+    second, where, per_chunk = [], [], []
     for (a, b), f, pend in zip(bounds, flats, rois):
         if given:
             roi, fzx, fzy = None, gz[0][a:b], gz[1][a:b]
         else:
             roi = _phantom_roi_finish(pend)
             fzx, fzy = find_phantom_axes_batch(roi, b - a)
+        # every chunk keeps its ROI table and fits -- also one that holds none of the requested slices -- so that the
+        # [V, 2] fit tables are indexed by the GLOBAL volume number below
+        per_chunk.append((roi, np.atleast_2d(fzx), np.atleast_2d(fzy)))
         if sl is None:
             local = None
         else:
@@ -531,32 +534,27 @@ def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=
             where.append(pos)
             local = sl[pos] - a * spv
         if local is not None and len(local) == 0:
-            second.append(None)
             continue
         prof, idx = ctp528_profiles_batch(f, mm_per_pixel, fzx, fzy, slices=local, roll_deg=roll_deg, slices_per_volume=spv, **kw)
-        second.append((roi, np.atleast_2d(fzx), np.atleast_2d(fzy), prof, idx + a * spv, _ctp528_mtf_launch(prof)))
-    parts = []
-    for item in second:
-        if item is None:
-            continue
-        roi, fzx, fzy, prof, idx, pend = item
-        parts.append((roi, fzx, fzy, prof, idx, _ctp528_mtf_finish(pend)))
+        second.append((prof, idx + a * spv, _ctp528_mtf_launch(prof)))
+    parts = [(prof, idx, _ctp528_mtf_finish(pend)) for prof, idx, pend in second]
     if not parts:
         raise ValueError("no slices selected")
-    idx = np.concatenate([p[4] for p in parts])
-    fzx, fzy = np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
+    idx = np.concatenate([p[1] for p in parts])
     if given:
         fzx, fzy = gz
+    else:
+        fzx, fzy = np.concatenate([c[1] for c in per_chunk]), np.concatenate([c[2] for c in per_chunk])
     v, z = idx // spv, idx % spv
-    out = {k: np.concatenate([p[5][k] for p in parts]) for k in ("rmtf", "nregions", "maxs", "mins")}
-    prof = parts[0][3] if len(parts) == 1 else torch.cat([p[3] for p in parts])
+    out = {k: np.concatenate([p[2][k] for p in parts]) for k in ("rmtf", "nregions", "maxs", "mins")}
+    prof = parts[0][0] if len(parts) == 1 else torch.cat([p[0] for p in parts])
     if sl is not None:                                     # back into the order the caller listed the slices in
         back = np.argsort(np.concatenate(where), kind="stable")
         if not np.array_equal(back, np.arange(len(back))):
             idx, v, z = idx[back], v[back], z[back]
             out = {k: a[back] for k, a in out.items()}
             prof = prof[torch.from_numpy(back).to(prof.device)]
-    roi = None if given else np.concatenate([p[0] for p in parts])
+    roi = None if given else np.concatenate([c[0] for c in per_chunk])
     out.update(center=np.stack([fzx[v, 0] * z + fzx[v, 1], fzy[v, 0] * z + fzy[v, 1]], axis=1), profiles=prof, slices=idx,
                roi=roi, fit_zx=fzx if volume.dim() == 4 else fzx[0], fit_zy=fzy if volume.dim() == 4 else fzy[0])
     return out

@@ -630,6 +630,17 @@ def profile_lookup(x_indices: torch.Tensor, values: torch.Tensor, q: torch.Tenso
     return out.reshape(q.shape)
 
 
+def index_to_original(x_indices: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    """``SingleProfile._x_interp_to_original``: ``np.interp(q, arange(S), x_indices)`` (what scipy's non-extrapolating linear
+    ``interp1d`` delegates to) for positions q (any shape, float64) in sample coordinates."""
+    xi = x_indices.to(torch.float64).contiguous()
+    qq = q.to(device=xi.device, dtype=torch.float64).contiguous()
+    out = torch.empty_like(qq)
+    check(_lib.load().pl_index_to_original(xi.data_ptr(), xi.numel(), qq.data_ptr(), qq.numel(), out.data_ptr(), _stream()),
+          "pl_index_to_original")
+    return out
+
+
 def fwxm_record(res: PeakBatch, out=None) -> torch.Tensor:
     """FWXMProfile edges / centre / width from a ``max_number=1`` peak batch -> float64 [N, 8]."""
     n = res.count.shape[0]

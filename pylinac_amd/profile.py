@@ -674,7 +674,7 @@ def _enum(value, cls):
 
 class _Linear1d:
     """``scipy.interpolate.interp1d(x, y)`` (linear) for the scalar look-ups SingleProfile makes on the host:
-    scipy's slope form ``(y_hi - y_lo) / (x_hi - x_lo) * (x_new - x_lo) + y_lo`` with
+    ``np.interp`` when not extrapolating (what scipy itself dispatches to), otherwise scipy's slope form ``(y_hi - y_lo) / (x_hi - x_lo) * (x_new - x_lo) + y_lo`` with
     ``hi = clip(searchsorted(x, x_new), 1, len - 1)``; out of range -> ValueError unless ``extrapolate``."""
 
     def __init__(self, x, y, extrapolate: bool):
@@ -689,6 +689,9 @@ class _Linear1d:
                 raise ValueError(f"A value ({xn.min()}) in x_new is below the interpolation range's minimum value ({self.x[0]}).")
             if (xn > self.x[-1]).any():
                 raise ValueError(f"A value ({xn.max()}) in x_new is above the interpolation range's maximum value ({self.x[-1]}).")
+            # scipy hands a non-extrapolating linear interp1d over float64 / int data to np.interp (interp1d.__init__:
+            # ``_call_linear_np``), whose result on a grid point is the sample itself
+            return np.interp(xn, self.x, self.y)
         hi = np.clip(np.searchsorted(self.x, xn), 1, len(self.x) - 1).astype(int)
         lo = hi - 1
         slope = (self.y[hi] - self.y[lo]) / (self.x[hi] - self.x[lo])
@@ -1263,14 +1266,22 @@ def single_profile_hill_batch(values, dpmm: float | None = None, interpolation=I
                                                    interpolation_factor)
     span = float(x_indices[-1] - x_indices[0])
 
+    first_info = []
+
     def beam_center_value(unnormalised):                    # beam_center() (profile.py:1390-1409) on the unnormalised profile
-        _, infl, _, _, _ = _hill_edges_stage(unnormalised, xi_dev, span, edge_smoothing_ratio, hill_window_ratio, peak_cap)
+        _, infl, _, info0, _ = _hill_edges_stage(unnormalised, xi_dev, span, edge_smoothing_ratio, hill_window_ratio, peak_cap)
+        first_info.append(info0)
         left, right = infl[:, 0, 0], infl[:, 1, 0]
         mid = torch.round(left + (right - left) / 2)        # int(round(mid_point)): half to even, like python's
         return ops.profile_lookup(xi_dev, unnormalised, mid.contiguous())
 
     fitted = _batch_normalize(fitted, norm, beam_center_value)
     params, infl, edges, info, nfev = _hill_edges_stage(fitted, xi_dev, span, edge_smoothing_ratio, hill_window_ratio, peak_cap)
+    if first_info:
+        # a fit the constructor's own beam_center() could not make (MINPACK info outside 1..4: curve_fit raises RuntimeError
+        # in the reference's __init__) normalised this row by a value at a non-converged midpoint: the row keeps THAT code
+        bad = (first_info[0] < 1) | (first_info[0] > 4)
+        info = torch.where(bad, first_info[0], info)
     return HillEdgesBatch(values=fitted, x_indices=x_indices, dpmm=dpmm,
                           params=params, index=infl[..., 0], value=infl[..., 1], derivative_edges=edges, info=info, nfev=nfev)
 
@@ -1290,11 +1301,10 @@ class FWXMEdgesBatch:
         res = ops.find_peaks_batch(v, cap=1, fwxm_height=x / 100, max_number=1)
         s = v.shape[1]
         dev = v.device
-        grid = torch.arange(s, dtype=torch.float64, device=dev)
         xi = torch.from_numpy(np.ascontiguousarray(self.x_indices)).to(dev)
         ips = torch.stack([res.props[:, 4, 0], res.props[:, 5, 0]], dim=0).reshape(1, -1)      # left_ips, right_ips
         ips = torch.where(res.count.repeat(2).reshape(1, -1) > 0, ips, torch.zeros_like(ips))
-        orig = ops.profile_lookup(grid, xi.reshape(1, -1), ips.contiguous()).reshape(2, -1)    # _x_interp_to_original
+        orig = ops.index_to_original(xi, ips.contiguous()).reshape(2, -1)                      # _x_interp_to_original
         nan = torch.full_like(orig[0], float("nan"))
         ok = res.count > 0
         return torch.where(ok, orig[0], nan), torch.where(ok, orig[1], nan), res.count, xi

@@ -278,6 +278,14 @@ def check_ctp528_batch(golden, dev, whole=True):
         # (the last three slices of every volume hold NaN profiles: their +-3 window passes the end of the stack)
         assert torch.equal(torch.nan_to_num(both["profiles"][s_:], nan=-1.0), torch.nan_to_num(one["profiles"], nan=-1.0))
         assert bool(torch.isnan(one["profiles"][-3:]).all()) and not bool(torch.isnan(one["profiles"][:-3]).any())
+        # one volume per chunk, slices confined to the LAST volume: chunks without a requested slice still
+        # contribute their fits and ROI rows, and the centres come from the right volume's fit
+        pick = np.array([s_ + int(sl[0]), s_ + int(sl[-1])])
+        late = ct.ctp528_batch(torch.stack([vol, v2]), mmpp, slices=pick, chunk_volumes=1)
+        assert np.array_equal(late["slices"], pick) and late["fit_zx"].shape == (2, 2) and len(late["roi"]) == 2 * s_
+        assert np.array_equal(late["fit_zx"], both["fit_zx"]) and np.array_equal(late["fit_zy"], both["fit_zy"])
+        assert np.array_equal(late["rmtf"], both["rmtf"][pick], equal_nan=True)
+        assert np.array_equal(late["center"], both["center"][pick])
 
 
 def check_rectangle_roi(golden, dev):
