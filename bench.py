@@ -5,6 +5,8 @@
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no launcher: starts the N ranks itself through the line above; a WORLD_SIZE that
+                                       contradicts --gpus is an error, never a silent one-GPU run)
 
 A "step" is one pass of the hot path (Gaussian(5) -> median(3) -> Otsu -> threshold -> column
 profile -> FWXM peak) over one batch of 256 synthetic 1024x1024 uint16 frames PER GPU
@@ -343,15 +345,45 @@ def cpu_baselines(frames_host, args, with_configs):
     return head, per_cfg
 
 
+def ensure_ranks(args):
+    """`--gpus N` decides the job.  Under a launcher (WORLD_SIZE set) the two must agree -- a mismatch exits non-zero rather
+    than timing a different job than the one asked for.  Without a launcher and N > 1 (plain `python bench.py --gpus 8`) this
+    process starts the N ranks itself, exactly the way the driver's own command line does, and returns their exit code."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"[bench] --gpus {args.gpus} contradicts WORLD_SIZE={env_world}: refusing to time a different "
+                             f"job than the one asked for")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0]), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's only working mode on this host driver
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
+    args = parse()
+    ensure_ranks(args)
+
     import torch
 
-    args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"[bench] rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -360,8 +392,8 @@ def main():
         import torch.distributed as dist  # noqa: F811
 
         dist.init_process_group(backend="nccl", device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"[bench] process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
     from pylinac_amd import dist as pdist
     from pylinac_amd.pipeline import EpidPipeline
@@ -409,8 +441,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = torch.empty(dist.get_world_size(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, t)              # each rank's own clock: a straggler GPU shows up by rank
+        per_rank_ms = [round(float(x) / args.steps * 1e3, 4) for x in every.cpu()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -441,6 +477,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,

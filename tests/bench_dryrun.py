@@ -47,7 +47,8 @@ def main():
         return real_init(backend="gloo", **kw)
 
     with emulated_device(), mock.patch.object(dist, "init_process_group", init_gloo), \
-            mock.patch.object(torch.cuda, "Event", _Event), mock.patch.object(torch.cuda, "set_device", lambda d: None):
+            mock.patch.object(torch.cuda, "Event", _Event), mock.patch.object(torch.cuda, "set_device", lambda d: None), \
+            mock.patch.object(torch.cuda, "device_count", lambda: int(os.environ.get("WORLD_SIZE", "1"))):
         bench.main()
 
 

@@ -67,6 +67,35 @@ def test_all_gather_is_identity_without_process_group():
     assert pdist.all_gather_records(x) is x
 
 
+def _dry_run_args(gpus):
+    return ["--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--frames", "2", "--height", "96", "--width", "128",
+            "--no-cpu-baseline", "--no-configs", "--no-parity"]
+
+
+def test_bench_plain_python_form_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the form the driver's recorded command line has)
+    starts two ranks itself and prints ONE line with n_gpus = rccl_ranks = 2; a WORLD_SIZE that contradicts --gpus exits
+    non-zero instead of timing one GPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    script = os.path.join(root, "tests", "bench_dryrun.py")
+    r = subprocess.run([sys.executable, script, *_dry_run_args(2)], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["frames_total"] == 4
+    assert len(line["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in line["per_rank_ms_per_step"])
+    bad = subprocess.run([sys.executable, script, *_dry_run_args(8)], capture_output=True, text=True, timeout=300, cwd=root,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "contradicts WORLD_SIZE" in bad.stderr and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_launch_path_two_ranks_dry_run():
     """`bench.py --gpus 2` the way the driver launches it (python -m torch.distributed.run --nproc-per-node 2, env
     rendezvous on 127.0.0.1), on the emulated device (tests/bench_dryrun.py): rank 0 prints ONE JSON line with n_gpus = 2,
