@@ -470,6 +470,14 @@ int pl_bakai_mask(const double* d_ref, const double* d_frame_cut, int64_t n, int
 int pl_bakai_gamma(const double* d_ref_masked, const double* d_comp, const float* d_grad_x, const float* d_grad_y,
                    float dose_term, float dist_term, int64_t total, double* d_out, void* stream);
 
+/* pylinac/core/gamma.py:105-227 gamma_geometric (the simplex-distance 1-D gamma PhysicalProfileMixin.gamma calls,
+ * pylinac/core/profile.py:822-874): d_ref / d_ref_x float64 [n_ref], d_eval / d_eval_x float64 [n_eval] (n_eval >= 2);
+ * dose_denominator = max(reference) * dose_to_agreement, threshold_normalized = dose_threshold / dose_to_agreement,
+ * eval_x_decreasing = the evaluation coordinates run high -> low.  d_gamma float64 [n_ref] (fill_value below the threshold). */
+int pl_gamma_geometric(const double* d_ref, const double* d_ref_x, int n_ref, const double* d_eval, const double* d_eval_x,
+                       int n_eval, double dose_denominator, double distance_to_agreement, double threshold_normalized,
+                       int eval_x_decreasing, double gamma_cap, double fill_value, double* d_gamma, void* stream);
+
 /* ---- f4 ("next" row, gamma part): pylinac.core.gamma.gamma_2d (pylinac/core/gamma.py:229-330) --------------
  * d_reference / d_evaluation float64 [n][h][w]; dose_fraction = dose_to_agreement / 100; global_dose != 0:
  * dose_ta = dose_fraction * d_ref_max[frame] (reference.max()), else dose_fraction * reference (elementwise).

@@ -1205,6 +1205,45 @@ def gamma_1d(reference, evaluation, reference_coordinates=None, evaluation_coord
     return np.asarray(gamma), np.asarray(vals), np.asarray(xs)
 
 
+def gamma_geometric(reference, evaluation, reference_coordinates=None, evaluation_coordinates=None, dose_to_agreement=1,
+                    distance_to_agreement=1, gamma_cap_value=2, dose_threshold=5, fill_value=np.nan):
+    """pylinac/core/gamma.py:105-227 (+ _construct_matrices / _calculate_weights / _compute_distance :16-102; validation
+    omitted): per reference point the smallest distance to the segments of the normalised evaluation curve between the
+    samples nearest (x - DTA) and (x + DTA), projection weights through the 1 x 1 pseudo-inverse."""
+    if reference_coordinates is None:
+        reference_coordinates = np.arange(len(reference), dtype=float)
+    if evaluation_coordinates is None:
+        evaluation_coordinates = np.arange(len(evaluation), dtype=float)
+    threshold = float(dose_threshold) / float(dose_to_agreement)
+    nref = reference.astype(float) * 100 / (reference.max() * dose_to_agreement)
+    nev = evaluation.astype(float) * 100 / (reference.max() * dose_to_agreement)
+    nrx = np.asarray(reference_coordinates) / distance_to_agreement
+    nex = np.asarray(evaluation_coordinates) / distance_to_agreement
+    decreasing = bool(np.all(np.diff(nex) < 0))
+    gamma = np.full(len(reference), fill_value)
+    for idx, (rx, rp) in enumerate(zip(nrx, nref)):
+        if rp < threshold:
+            continue
+        left_d, right_d = np.abs(nex - (rx - distance_to_agreement)), np.abs(nex - (rx + distance_to_agreement))
+        if decreasing:
+            left_d, right_d = right_d, left_d
+        lo = max(np.argmin(left_d) - 1, 0)
+        hi = min(np.argmin(right_d) + 1, len(nev) - 1)
+        p = np.array([rx, rp])
+        dists = []
+        for j in range(lo, hi):
+            v1, v2 = np.array([nex[j], nev[j]]), np.array([nex[j + 1], nev[j + 1]])
+            V, P = (v1 - v2)[:, None], p - v2                  # V: 2 x 1
+            w = np.dot(np.linalg.pinv(np.dot(V.T, V)), np.dot(V.T, P))
+            weights = np.append(w, 1 - np.sum(w))
+            if np.any(weights < 0):
+                dists.append(min(math.dist(p, v1), math.dist(p, v2)))
+            else:
+                dists.append(np.linalg.norm(p - np.sum(weights[:, None] * np.array([v1, v2]), axis=0)))
+        gamma[idx] = min(min(dists), gamma_cap_value)
+    return gamma
+
+
 # --------------------------------------------------------------------------------------
 # f3: DiskROI statistics (skimage.draw.disk restated by disk_mask_like_skimage)
 # --------------------------------------------------------------------------------------

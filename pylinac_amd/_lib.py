@@ -132,6 +132,7 @@ SIGNATURES = {
     "pl_bakai_mask": ([_p, _p, _l, _l, _p, _p, _p], C.c_int),
     "pl_bakai_gamma": ([_p, _p, _p, _p, C.c_float, C.c_float, _l, _p, _p], C.c_int),
     "pl_gamma1d": ([_p, _p, _i, _p, _p, _i, _d, _d, _i, _d, _d, _d, _i, _d, _d, _p, _p, _p, _p, _p], C.c_int),
+    "pl_gamma_geometric": ([_p, _p, _i, _p, _p, _i, _d, _d, _d, _i, _d, _d, _p, _p], C.c_int),
     "pl_gamma2d": ([_p, _p, _l, _i, _i, _d, _i, _p, _p, _p, _p, _i, _d, _d, _d, _p, _p, _p], C.c_int),
     "pl_cast_wrap": ([_p, _p, _i, _l, _p], C.c_int),
     "pl_zoom1d_cubic": ([_p, _l, _i, _i, _i, _p, _p, _p], C.c_int),

@@ -101,6 +101,66 @@ __global__ void gamma1d_kernel(const double* __restrict__ ref, const double* __r
   gamma[i] = cap < best ? cap : best;
 }
 
+// pylinac/core/gamma.py:105-227, gamma_geometric (Ju et al. 2008: distance from each reference point to the piecewise-linear
+// evaluation curve in (x / DTA, dose / dose-to-agreement) space), one lane per reference point:
+//   nr = ref * 100 / (max(ref) * dose_ta)      ne = ev * 100 / (max(ref) * dose_ta)      nrx = ref_x / dta      nex = ev_x / dta
+//   vertices: from  max(argmin|nex - (nrx - dta)| - 1, 0)  to  min(argmin|nex - (nrx + dta)| + 1, m - 1)   (first arg-min; the
+//   reference subtracts the UN-normalised dta from normalised positions, restated as is; the two searches swap for a
+//   decreasing nex), and over consecutive vertex pairs (v1, v2) the distance of p = (nrx, nr) to the segment:
+//     V = v1 - v2, P = p - v2, w = pinv([V.V]) * (V.P)   (1 x 1 pseudo-inverse: the reciprocal, 0 for a zero matrix),
+//     w < 0 or 1 - w < 0 -> the nearer vertex;  else |p - (w v1 + (1 - w) v2)|
+//   gamma = min(min over pairs, cap); points with nr < dose_threshold / dose_ta keep `fill`.
+// Float64 in the reference's operation order; BLAS dot products / math.dist may differ in the last bit.
+__global__ void gamma_geometric_kernel(const double* __restrict__ ref, const double* __restrict__ ref_x, int n_ref,
+                                       const double* __restrict__ ev, const double* __restrict__ ev_x, int n_ev, double denom,
+                                       double dta, double threshold, int decreasing, double cap, double fill,
+                                       double* __restrict__ gamma) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_ref) return;
+  const double py = ref[i] * 100.0 / denom;
+  const double px = ref_x[i] / dta;
+  if (py < threshold) {
+    gamma[i] = fill;
+    return;
+  }
+  const double lo_t = px - dta, hi_t = px + dta;
+  int a_lo = 0, a_hi = 0;
+  double b_lo = 0.0, b_hi = 0.0;
+  for (int j = 0; j < n_ev; ++j) {
+    const double x = ev_x[j] / dta;
+    const double dl = fabs(x - lo_t), dh = fabs(x - hi_t);
+    if (j == 0 || dl < b_lo) { b_lo = dl; a_lo = j; }
+    if (j == 0 || dh < b_hi) { b_hi = dh; a_hi = j; }
+  }
+  if (decreasing) { const int t = a_lo; a_lo = a_hi; a_hi = t; }
+  const int left = a_lo - 1 > 0 ? a_lo - 1 : 0;
+  const int right = a_hi + 1 < n_ev - 1 ? a_hi + 1 : n_ev - 1;
+  double best = 0.0;
+  bool any = false;
+  for (int j = left; j < right; ++j) {
+    const double v1x = ev_x[j] / dta, v1y = ev[j] * 100.0 / denom;
+    const double v2x = ev_x[j + 1] / dta, v2y = ev[j + 1] * 100.0 / denom;
+    const double Vx = v1x - v2x, Vy = v1y - v2y, Px = px - v2x, Py = py - v2y;
+    const double vtv = Vx * Vx + Vy * Vy;
+    const double inv = vtv != 0.0 ? 1.0 / vtv : 0.0;
+    const double w = inv * (Vx * Px + Vy * Py);
+    const double w2 = 1.0 - w;
+    double d;
+    if (w < 0.0 || w2 < 0.0) {
+      const double d1 = sqrt((px - v1x) * (px - v1x) + (py - v1y) * (py - v1y));
+      const double d2 = sqrt(Px * Px + Py * Py);
+      d = d2 < d1 ? d2 : d1;
+    } else {
+      const double qx = px - (w * v1x + w2 * v2x), qy = py - (w * v1y + w2 * v2y);
+      d = sqrt(qx * qx + qy * qy);
+    }
+    if (!any || d < best) best = d;
+    any = true;
+  }
+  // (no pair: n_ev >= 2 makes right > left always)
+  gamma[i] = cap < best ? cap : best;
+}
+
 // BaseImage.gamma (Bakai et al. eq. 6; pylinac/core/image.py:994-1016), in numpy's own mixed precision:
 //   ref[ref < threshold * max(ref)] = nan                          (float64)
 //   img_x, img_y = sobel(ref.astype(float32), 1 / 0)               (float32: pl_sobel on the array written here)
@@ -167,6 +227,20 @@ extern "C" int pl_gamma1d(const double* d_ref, const double* d_ref_x, int n_ref,
                      threshold, dose_ta_global, dose_fraction, global_dose, gamma_cap, fill_value, d_gamma,
                      d_eval_vals, d_eval_xs, d_computed);
   return pl_check_launch("pl_gamma1d");
+}
+
+extern "C" int pl_gamma_geometric(const double* d_ref, const double* d_ref_x, int n_ref, const double* d_eval,
+                                  const double* d_eval_x, int n_eval, double dose_denominator, double distance_to_agreement,
+                                  double threshold_normalized, int eval_x_decreasing, double gamma_cap, double fill_value,
+                                  double* d_gamma, void* stream) {
+  PL_REQUIRE(d_ref && d_ref_x && d_eval && d_eval_x && d_gamma, "null pointer");
+  PL_REQUIRE(n_ref >= 0 && n_eval >= 2, "bad shape (the evaluation profile needs two samples)");
+  PL_REQUIRE(distance_to_agreement > 0.0, "distance to agreement must be greater than 0");
+  if (n_ref == 0) return PL_OK;
+  hipLaunchKernelGGL(gamma_geometric_kernel, dim3((unsigned)pl_cdiv(n_ref, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                     d_ref, d_ref_x, n_ref, d_eval, d_eval_x, n_eval, dose_denominator, distance_to_agreement,
+                     threshold_normalized, eval_x_decreasing, gamma_cap, fill_value, d_gamma);
+  return pl_check_launch("pl_gamma_geometric");
 }
 
 extern "C" int pl_gamma2d(const double* d_reference, const double* d_evaluation, int64_t n, int h, int w,

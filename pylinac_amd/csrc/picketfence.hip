@@ -22,6 +22,9 @@
 
 namespace {
 
+#ifndef PL_PF_VARIANT
+#define PL_PF_VARIANT 0         // 1 / 2 / 3: stopwatch builds that skip a stage of pf_windows_kernel (WRONG results; scripts/)
+#endif
 constexpr int kThreads = 256;
 constexpr int kMaxRows = 48;    // window rows  (leaf width in pixels)
 constexpr int kMaxCols = 128;   // window cols  (picket spacing in pixels); numpy pairwise-sum single block
@@ -357,6 +360,9 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   // share a row: lane j of the group owns chain r[j], the tree is three xor-shuffles (float addition commutes, so both
   // partners hold the same sum), one lane adds the tail.  Same operations in the same order as one lane doing it all,
   // at an eighth of the float64 divisions per lane (round 1: one lane per row, 12 of 64 lanes busy).
+#if PL_PF_VARIANT == 1                                     // stopwatch: no deviation stage (wrong edge test)
+  if (lane < nrows) s_std_w[lane] = 1.0;
+#else
   if (lr) {
     // LEFT_RIGHT: np.std(window, axis=0) reduces over the window's ROWS (the travel direction), which numpy adds up one row
     // after the other -- no pairwise blocks on a non-contiguous reduction axis: a plain left-to-right sum per leaf pixel
@@ -397,6 +403,7 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
       if (act && j == 0) s_std_w[r] = sqrt(ss / (double)ncols);
     }
   }
+#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
   // max(std) < edge_threshold * np.median(std): lane a ranks std[a] (nrows <= 48 <= 64 lanes)
@@ -429,6 +436,9 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
     if (c >= ncols) continue;
     const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
     int v_lo = 0, v_hi = 0;
+#if PL_PF_VARIANT == 2                                     // stopwatch: no column median (row 0 instead)
+    v_lo = v_hi = sw[c];
+#else
     if (nrows <= 32) {                               // wave-uniform; every leaf of the Millennium / HD / Agility banks at EPID scale
       // A sorting network on the column in registers.  The column is padded to N values with floor((N - n) / 2) values below
       // every pixel and the rest above: the middle order statistics then sit at the FIXED positions N/2 - 1 and N/2 (n even)
@@ -449,6 +459,7 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
         if (rank == k_hi) v_hi = va;
       }
     }
+#endif
     const double qh = pl_quot(kq, (double)v_hi);
     pvr[slot] = (nrows & 1) ? qh : (pl_quot(kq, (double)v_lo) + qh) / 2.0;
   }
@@ -477,7 +488,12 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   // 322-327: find_peaks(fwxm_height, max_number = 1), left_ips / right_ips of the most prominent peak) -- rounds 1-3 wrote the
   // profile to a [windows][128] float64 table (0.5 GB per 512 frames) for a second launch to read
   double c_pos = qnan, l_pos = qnan, r_pos = qnan;
+#if PL_PF_VARIANT == 3                                     // stopwatch: no FWXM search
+  if (status == 0) c_pos = l_pos = r_pos = p0 + p1;
+  if (false) {
+#else
   if (status == 0) {                                       // wave-uniform
+#endif
     pl_wave_sync();                                        // every lane is done with the window pixels: the bytes change hands
     double* s_prof = reinterpret_cast<double*>(wave_lds);
     if (has0) s_prof[lane] = p0;

@@ -118,3 +118,51 @@ def gamma_1d(reference, evaluation, reference_coordinates=None, evaluation_coord
           "pl_gamma1d")
     keep = computed.bool().cpu().numpy()
     return gamma.cpu().numpy(), vals.cpu().numpy()[keep].ravel(), xs.cpu().numpy()[keep].ravel()
+
+
+def gamma_geometric(reference, evaluation, reference_coordinates=None, evaluation_coordinates=None,
+                    dose_to_agreement: float = 1, distance_to_agreement: float = 1, gamma_cap_value: float = 2,
+                    dose_threshold: float = 5, fill_value: float = np.nan, device=None) -> np.ndarray:
+    """pylinac/core/gamma.py:105-227: the geometric (simplex-distance) 1-D gamma of Ju et al. -- for every reference point the
+    distance to the piecewise-linear evaluation curve in normalised (position, dose) space; same arguments, validation and
+    messages as the reference, one lane per reference point on the device (``pl_gamma_geometric``)."""
+    reference, evaluation = np.asarray(reference), np.asarray(evaluation)
+    if reference.ndim != 1 or evaluation.ndim != 1:
+        raise ValueError(f"Reference and evaluation arrays must be 1D. Got reference: {reference.ndim} and evaluation: {evaluation.ndim}")
+    if distance_to_agreement <= 0:
+        raise ValueError("Dose to agreement must be greater than 0")          # (the reference swaps the two messages)
+    if dose_to_agreement <= 0:
+        raise ValueError("Distance to agreement must be greater than 0")
+
+    def monotonic(x):
+        d = np.diff(x)
+        return bool(np.all(d > 0) or np.all(d < 0))
+
+    if reference_coordinates is None:
+        reference_coordinates = np.arange(len(reference), dtype=float)
+    reference_coordinates = np.asarray(reference_coordinates)
+    if not monotonic(reference_coordinates):
+        raise ValueError("Reference x-values must be monotonically increasing or decreasing")
+    if len(reference) != len(reference_coordinates):
+        raise ValueError(f"Reference and reference_x_values must be the same length. Got reference: {len(reference)} and reference_x_values: {len(reference_coordinates)}")
+    if evaluation_coordinates is None:
+        evaluation_coordinates = np.arange(len(evaluation), dtype=float)
+    evaluation_coordinates = np.asarray(evaluation_coordinates)
+    if not monotonic(evaluation_coordinates):
+        raise ValueError("Evaluation x-values must be monotonically increasing or decreasing")
+    if len(evaluation) != len(evaluation_coordinates):
+        raise ValueError(f"Evaluation and evaluation_x_values must be the same length. Got evaluation: {len(evaluation)} and evaluation_x_values: {len(evaluation_coordinates)}")
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+    d_ref, d_rx, d_ev, d_ex = up(reference), up(reference_coordinates), up(evaluation), up(evaluation_coordinates)
+    out = torch.empty(len(reference), dtype=torch.float64, device=dev)
+    decreasing = bool(np.all(np.diff(evaluation_coordinates / distance_to_agreement) < 0))
+    check(_lib.load().pl_gamma_geometric(d_ref.data_ptr(), d_rx.data_ptr(), len(reference), d_ev.data_ptr(), d_ex.data_ptr(),
+                                         len(evaluation), float(reference.max() * dose_to_agreement), float(distance_to_agreement),
+                                         float(dose_threshold) / float(dose_to_agreement), 1 if decreasing else 0,
+                                         float(gamma_cap_value), float(fill_value), out.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream), "pl_gamma_geometric")
+    return out.cpu().numpy()

@@ -110,35 +110,28 @@ class _MutatorMixin:
         self.array = au.normalize(self.array, value=norm_val)
 
 
-class ArrayImage(_MutatorMixin):
-    """An image constructed solely from a numpy array (image.py:1815-1869), GPU-computed."""
+class BaseImage(_MutatorMixin):
+    """The array-level members of ``pylinac.core.image.BaseImage`` (image.py:433-1102) that analyzers call on an image;
+    subclasses provide ``array`` / ``dpi`` / ``dpmm`` / ``sid``.  File and plotting members (``date_created``,
+    ``truncated_path``, ``as_dicom``, ``plot*``, ``from_multiples``) belong to the loaders and the UI: out of scope."""
 
-    def __init__(self, array, *, dpi: float = None, sid: float = None, dtype=None):
-        if dtype is not None:
-            self.array = np.array(array, dtype=dtype)
-        else:
-            self.array = np.asarray(array)
-        self._dpi = dpi
-        self.sid = sid
-        self.metrics = []
-        self.metric_values = {}
-
-    # -- geometry / numpy protocol (image.py:1062-1102, 1851-1866)
-    @property
-    def dpi(self):
-        dpi = None
-        if self._dpi is not None:
-            dpi = self._dpi
-            if self.sid is not None:
-                dpi *= self.sid / 1000
-        return dpi
+    metrics: list
+    metric_values: dict
 
     @property
-    def dpmm(self):
-        try:
-            return self.dpi / MM_PER_INCH
-        except Exception:
-            return None
+    def physical_shape(self):
+        """image.py:535-538: (rows, columns) in mm"""
+        return self.shape[0] / self.dpmm, self.shape[1] / self.dpmm
+
+    def dist2edge_min(self, point) -> float:
+        """image.py:817-837: distance from ``point`` (a point or an (x, y) tuple) to the closest image edge"""
+        x, y = (point[0], point[1]) if isinstance(point, tuple) else (point.x, point.y)
+        rows, cols = self.shape[0], self.shape[1]
+        return min(np.array([rows - y, cols - x, y, x], dtype=float))
+
+    @property
+    def flat(self):
+        return self.array.flat
 
     @property
     def shape(self):
@@ -170,9 +163,6 @@ class ArrayImage(_MutatorMixin):
 
     def __array__(self, dtype=None, copy=None):
         return np.asarray(self.array, dtype=dtype)
-
-    def __sub__(self, other):
-        return ArrayImage(self.array - other.array)
 
     # -- mutators with reference-specific return values
     def threshold(self, threshold: float, kind: str = "high") -> None:
@@ -232,7 +222,7 @@ class ArrayImage(_MutatorMixin):
     def center(self):
         """image.py:526-533: the centre of the array as a point (x, y); even lengths give the mid-point between the two
         central indices."""
-        from .profile import Point
+        from .geometry import Point
 
         return Point(x=(self.shape[1] / 2) - 0.5, y=(self.shape[0] / 2) - 0.5)
 
@@ -352,6 +342,40 @@ class ArrayImage(_MutatorMixin):
         if self.array.dtype == np.float32:
             return out.astype(np.float32)
         return out
+
+
+class ArrayImage(BaseImage):
+    """An image constructed solely from a numpy array (image.py:1815-1869), GPU-computed."""
+
+    def __init__(self, array, *, dpi: float = None, sid: float = None, dtype=None):
+        if dtype is not None:
+            self.array = np.array(array, dtype=dtype)
+        else:
+            self.array = np.asarray(array)
+        self._dpi = dpi
+        self.sid = sid
+        self.metrics = []
+        self.metric_values = {}
+
+    # image.py:1851-1866
+    @property
+    def dpi(self):
+        dpi = None
+        if self._dpi is not None:
+            dpi = self._dpi
+            if self.sid is not None:
+                dpi *= self.sid / 1000
+        return dpi
+
+    @property
+    def dpmm(self):
+        try:
+            return self.dpi / MM_PER_INCH
+        except Exception:
+            return None
+
+    def __sub__(self, other):
+        return ArrayImage(self.array - other.array)
 
 
 class ImageBatch:

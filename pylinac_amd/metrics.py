@@ -1,0 +1,203 @@
+"""The image-metric plug-ins the Winston-Lutz analyzers instantiate: the reference's
+``MetricBase`` protocol (pylinac/metrics/image.py:39-93), ``SizedDiskRegion`` / ``SizedDiskLocator`` (:402-700) and
+``GlobalSizedFieldLocator`` (:703-897) with the reference's constructors, alternate constructors and ``calculate()`` results,
+their search running in the device finders of :mod:`pylinac_amd.features` (``pl_features_sweep`` / ``pl_fields_level``) instead
+of ``skimage.measure`` loops.  ``BaseImage.compute(metric)`` takes these objects (pylinac/core/image.py:1022-1054), so
+``WLBaseImage.find_bb_centroids`` (pylinac/winston_lutz.py:788-806) runs unchanged with ``SizedDiskLocator`` bound to this class.
+
+The finders implement the detection conditions the reference's analyzers use: the five default disk conditions
+(``is_right_size_bb, is_round, is_right_circumference, is_symmetric, is_solid``; metrics/features.py:7-68) and the two field
+conditions (``is_right_area_square, is_right_square_perimeter``).  Another list of callables cannot be evaluated inside a
+kernel and is refused.  Plotting members are out of scope.
+"""
+from __future__ import annotations
+
+import math
+import weakref
+
+import numpy as np
+import torch
+
+from . import array_utils as au
+from . import features
+from .geometry import Point
+
+_DISK_CONDITIONS = ("is_right_size_bb", "is_round", "is_right_circumference", "is_symmetric", "is_solid")
+_FIELD_CONDITIONS = ("is_right_area_square", "is_right_square_perimeter")
+
+
+def _check_conditions(conditions, supported: tuple, what: str) -> None:
+    if conditions is None:
+        return
+    names = tuple(getattr(c, "__name__", str(c)) for c in conditions)
+    if sorted(names) != sorted(supported):                  # (a region must pass every condition: their order is immaterial)
+        raise NotImplementedError(f"{what} evaluates the conditions {supported} inside its kernel; got {names}")
+
+
+class MetricBase:
+    """metrics/image.py:39-93: ``inject_image`` (a weak proxy), ``context_calculate`` (the image must not change), ``calculate``"""
+
+    unit: str = ""
+    image_compatibility = None
+    name: str
+
+    def inject_image(self, image) -> None:
+        if self.image_compatibility is not None and not isinstance(image, tuple(self.image_compatibility)):
+            raise TypeError(f"Image must be one of {self.image_compatibility}")
+        self.image = weakref.proxy(image)
+
+    def context_calculate(self):
+        img_hash = hash(self.image.array.tobytes())
+        calculation = self.calculate()
+        if hash(self.image.array.tobytes()) != img_hash:
+            raise RuntimeError("A metric modified an image. This is not allowed as this could affect other, downstream metrics. "
+                               "Change the calculate method to not modify the underlying image.")
+        return calculation
+
+    def calculate(self):
+        raise NotImplementedError
+
+
+class DiskRegion:
+    """What ``SizedDiskRegion.calculate`` reports per disk: the intensity-weighted centroid (row, col) in window coordinates
+    and the threshold level that produced it (the reference returns scikit-image ``RegionProperties``; the members its
+    analyzers read are the centroid, through ``SizedDiskLocator``)."""
+
+    def __init__(self, row: float, col: float, level: int):
+        self.weighted_centroid = (row, col)
+        self.centroid_weighted = (row, col)
+        self.level = level
+
+
+class SizedDiskRegion(MetricBase):
+    """metrics/image.py:402-612: a disk / BB of known size near an expected position."""
+
+    def __init__(self, expected_position, search_window, radius: float, radius_tolerance: float, detection_conditions=None,
+                 invert: bool = True, name: str = "Disk Region", max_number: int = 1, min_number: int = 1,
+                 min_separation_pixels: float = 5):
+        _check_conditions(detection_conditions, _DISK_CONDITIONS, type(self).__name__)
+        self.expected_position = Point(expected_position)
+        self.radius = radius
+        self.radius_tolerance = radius_tolerance
+        self.search_window = search_window
+        self.detection_conditions = detection_conditions
+        self.name = name
+        self.invert = invert
+        self.is_from_center = False
+        self.is_from_physical = False
+        self.max_number = max_number
+        self.min_number = min_number
+        self.min_separation = min_separation_pixels
+
+    @classmethod
+    def _make(cls, physical: bool, center: bool, position, window, radius, tolerance, detection_conditions, invert, name,
+              max_number, min_number, separation):
+        inst = cls(expected_position=position, search_window=window, radius=radius, radius_tolerance=tolerance,
+                   detection_conditions=detection_conditions, name=name, invert=invert, max_number=max_number,
+                   min_number=min_number, min_separation_pixels=separation)
+        inst.is_from_physical, inst.is_from_center = physical, center
+        return inst
+
+    @classmethod
+    def from_physical(cls, expected_position_mm, search_window_mm, radius_mm: float, radius_tolerance_mm: float,
+                      detection_conditions=None, invert: bool = True, name="Disk Region", max_number: int = 1,
+                      min_number: int = 1, min_separation_mm: float = 5):
+        return cls._make(True, False, expected_position_mm, search_window_mm, radius_mm, radius_tolerance_mm,
+                         detection_conditions, invert, name, max_number, min_number, min_separation_mm)
+
+    @classmethod
+    def from_center(cls, expected_position, search_window, radius: float, radius_tolerance: float, detection_conditions=None,
+                    invert: bool = True, name="Disk Region", max_number: int = 1, min_number: int = 1,
+                    min_separation_pixels: float = 5):
+        return cls._make(False, True, expected_position, search_window, radius, radius_tolerance, detection_conditions, invert,
+                         name, max_number, min_number, min_separation_pixels)
+
+    @classmethod
+    def from_center_physical(cls, expected_position_mm, search_window_mm, radius_mm: float, radius_tolerance_mm: float = 0.25,
+                             detection_conditions=None, invert: bool = True, name="Disk Region", max_number: int = 1,
+                             min_number: int = 1, min_separation_mm: float = 5):
+        return cls._make(True, True, expected_position_mm, search_window_mm, radius_mm, radius_tolerance_mm,
+                         detection_conditions, invert, name, max_number, min_number, min_separation_mm)
+
+    def calculate(self):
+        """metrics/image.py:564-612 + metrics/utils.py:66-190: the window about the expected position (floor / ceil of centre
+        -+ half the window, clipped by numpy's slicing), ``invert``, then the threshold sweep over the stretched sample on the
+        device.  -> list of :class:`DiskRegion`; ``self.points`` = the centroids in image coordinates."""
+        dpmm = self.image.dpmm
+        if self.is_from_physical:
+            self.expected_position * dpmm                      # (scales the point in place, like the reference's statement)
+            self.search_window = np.asarray(self.search_window) * dpmm
+        else:
+            self.min_separation /= dpmm
+            self.radius /= dpmm
+            self.radius_tolerance /= dpmm
+        if self.is_from_center:
+            self.expected_position.x += self.image.shape[1] / 2
+            self.expected_position.y += self.image.shape[0] / 2
+        left = max(math.floor(self.expected_position.x - self.search_window[0] / 2), 0)
+        right = math.ceil(self.expected_position.x + self.search_window[0] / 2)
+        top = max(math.floor(self.expected_position.y - self.search_window[1] / 2), 0)
+        bottom = math.ceil(self.expected_position.y + self.search_window[1] / 2)
+        sample = np.asarray(self.image[top:bottom, left:right])
+        if self.invert:
+            sample = au.invert(sample)
+        if self.max_number > 8:
+            raise ValueError("at most 8 disks per window are reported")
+        dev_sample = torch.from_numpy(np.ascontiguousarray(sample, dtype=np.float64)).to(au._device())[None]
+        res = features.find_features_batch(dev_sample, dpmm, self.radius, self.radius_tolerance, max_number=self.max_number,
+                                           min_separation_mm=self.min_separation)
+        count = int(res["count"][0])
+        if int(res["status"][0]) not in (0, 1):
+            raise RuntimeError(f"the disk finder could not process this window (status {int(res['status'][0])})")
+        if count < self.min_number:
+            raise ValueError(f"Couldn't find the minimum number of disks in the image. Found {count}; required: {self.min_number}")
+        xy = res["xy"][0, :count].cpu().numpy()
+        self.x_offset, self.y_offset = left, top
+        self.boundaries = []                                   # (plotting aid in the reference: not produced)
+        self.points = [Point(float(x) + left, float(y) + top) for x, y in xy]
+        return [DiskRegion(float(y), float(x), int(res["level"][0])) for x, y in xy]
+
+
+class SizedDiskLocator(SizedDiskRegion):
+    """metrics/image.py:663-700: the weighted centroids as points (x, y) in image coordinates"""
+
+    def calculate(self):
+        super().calculate()
+        return self.points
+
+
+class GlobalSizedFieldLocator(MetricBase):
+    """metrics/image.py:703-897: square / rectangular radiation fields of a given size anywhere in the image (the multi-target
+    Winston-Lutz field finder, pylinac/winston_lutz.py:2734-2766): 8-connected regions per threshold level, a 3-pixel border
+    band, area and perimeter conditions, UNWEIGHTED centroids."""
+
+    def __init__(self, field_width_px: float, field_height_px: float, field_tolerance_px: float, min_number: int = 1,
+                 max_number: int | None = None, name: str = "Field Finder", detection_conditions=None):
+        _check_conditions(detection_conditions, _FIELD_CONDITIONS, type(self).__name__)
+        self.field_width_mm, self.field_height_mm, self.field_tolerance_mm = field_width_px, field_height_px, field_tolerance_px
+        self.min_number = min_number
+        self.max_number = max_number or 1e6
+        self.name = name
+        self.detection_conditions = detection_conditions
+        self.is_from_physical = False
+
+    @classmethod
+    def from_physical(cls, field_width_mm: float, field_height_mm: float, field_tolerance_mm: float, min_number: int = 1,
+                      max_number: int | None = None, name: str = "Field Finder", detection_conditions=None):
+        inst = cls(field_width_px=field_width_mm, field_height_px=field_height_mm, field_tolerance_px=field_tolerance_mm,
+                   min_number=min_number, max_number=max_number, name=name, detection_conditions=detection_conditions)
+        inst.is_from_physical = True
+        return inst
+
+    def calculate(self):
+        frame = np.asarray(self.image.array)
+        dev = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.float64)).to(au._device())[None]
+        cap = None if self.max_number == 1e6 else int(self.max_number)
+        res = features.find_fields_batch(dev, self.image.dpmm, self.field_width_mm, self.field_height_mm, self.field_tolerance_mm,
+                                         max_number=cap, is_from_physical=self.is_from_physical)
+        count = int(res["count"][0])
+        if count < self.min_number:
+            raise ValueError(f"Couldn't find the minimum number of fields in the image. Found {count}; required: {self.min_number}")
+        self.boundaries = []
+        self.fields = [Point(float(x), float(y)) for x, y in res["xy"][0, :count].cpu().numpy()]
+        return self.fields

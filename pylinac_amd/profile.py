@@ -12,13 +12,16 @@ from __future__ import annotations
 
 import enum
 import math
+import warnings
 from dataclasses import dataclass
+from functools import cached_property
 
 import numpy as np
 import torch
 
 from . import array_utils as au
 from . import ops
+from .geometry import Circle, Point  # noqa: F401  (Point is re-exported: analyzers import it from here)
 
 LEFT = "left"
 RIGHT = "right"
@@ -31,17 +34,6 @@ class Normalization(enum.Enum):
     GEOMETRIC_CENTER = "Geometric center"
     BEAM_CENTER = "Beam center"
     MAX = "Max"
-
-
-@dataclass
-class Point:
-    """The two fields of ``pylinac.core.geometry.Point`` that the profile classes use."""
-
-    idx: int | None = None
-    value: float | None = None
-    x: float = 0
-    y: float = 0
-    z: float = 0
 
 
 def _to_device_profile(values) -> torch.Tensor:
@@ -92,22 +84,36 @@ def find_peaks(
     return res.to_host(0)
 
 
-class MultiProfile:
-    """pylinac/core/profile.py:2002-2176."""
+def stretch(array, min: int = 0, max: int = 1, fill_dtype=None):
+    """pylinac/core/profile.py:40-83, the deprecated profile-module ``stretch``: (array - min) / range scaled to ``max`` (or to
+    ``fill_dtype``'s maximum, then cast); the new minimum is NOT applied (the reference's line is commented out)."""
+    warnings.warn("Using stretch from the profile module is deprecated. Use 'stretch' from the pylinac.core.array_utils module",
+                  DeprecationWarning)
+    new_max = max
+    if fill_dtype is not None:
+        new_max = (np.iinfo(fill_dtype) if np.issubdtype(fill_dtype, np.integer) else np.finfo(fill_dtype)).max
+    out = au.stretch(np.asarray(array), min=0, max=1) * new_max          # ground / range on the device, then the scale
+    return out.astype(fill_dtype) if fill_dtype else out
 
-    def __init__(self, values):
-        self.values = values
-        self.peaks = []
-        self.valleys = []
 
-    def __len__(self):
-        return len(self.values)
+class ProfileMixin:
+    """pylinac/core/profile.py:86-153: in-place manipulations of a profile's ``values`` through ``array_utils`` (device
+    kernels); every 1-D profile class carries them."""
 
-    def __getitem__(self, items):
-        return self.values[items]
+    def invert(self) -> None:
+        self.values = au.invert(np.asarray(self.values))
+
+    def bit_invert(self) -> None:
+        self.values = au.bit_invert(np.asarray(self.values))
 
     def normalize(self, norm_val=None) -> None:
-        self.values = au.normalize(np.asarray(self.values), value=None if norm_val == "max" else norm_val)
+        self.values = au.normalize(np.asarray(self.values), value=None if isinstance(norm_val, str) and norm_val == "max" else norm_val)
+
+    def stretch(self, min: float = 0, max: float = 1) -> None:
+        self.values = au.stretch(np.asarray(self.values), min=min, max=max)
+
+    def convert_to_dtype(self, dtype) -> None:
+        self.values = au.convert_to_dtype(np.asarray(self.values), dtype=dtype)
 
     def ground(self) -> float:
         v = np.asarray(self.values)
@@ -115,8 +121,23 @@ class MultiProfile:
         self.values = au.ground(v)
         return mn
 
-    def filter(self, size=0.05, kind: str = "median") -> None:
+    def filter(self, size: float = 0.05, kind: str = "median") -> None:
         self.values = au.filter(np.asarray(self.values), size=size, kind=kind)
+
+    def __len__(self):
+        return len(self.values)
+
+    def __getitem__(self, items):
+        return self.values[items]
+
+
+class MultiProfile(ProfileMixin):
+    """pylinac/core/profile.py:2002-2176."""
+
+    def __init__(self, values):
+        self.values = values
+        self.peaks = []
+        self.valleys = []
 
     def find_peaks(self, threshold=0.3, min_distance=0.05, max_number=None,
                    search_region=(0.0, 1.0), peak_sort="prominences"):
@@ -163,15 +184,22 @@ def _linear_at(xp: np.ndarray, fp: np.ndarray, x):
     return fp[i] + t * (fp[i + 1] - fp[i])
 
 
-class _ProfileBase:
-    """pylinac/core/profile.py:195-344 (``ProfileBase``): sorting by x, grounding / normalisation, index <-> position
+class ProfileBase(ProfileMixin):
+    """pylinac/core/profile.py:195-576 (``ProfileBase``): sorting by x, grounding / normalisation, index <-> position
     look-ups (a k=1, s=0 ``UnivariateSpline`` is piecewise-linear interpolation), centre / width from the subclass's
-    ``field_edge_idx``."""
+    ``field_edge_idx``, the metric plug-in protocol (``compute``)."""
 
-    def __init__(self, values, x_values=None, ground: bool = False, normalization=Normalization.NONE):
+    def __init__(self, values, x_values=None, ground: bool = False, normalization=Normalization.NONE,
+                 interpolation_order: int = 1):
         values = np.asarray(values)
         if values.ndim > 1:
             raise ValueError(f"Array was multidimensional. Must pass 1D array; found {values.ndim}")
+        if interpolation_order != 1:
+            raise NotImplementedError("index <-> position look-ups are built for interpolation_order=1 (the reference's default; "
+                                      "no analyzer passes another)")
+        self.metrics = []
+        self.metric_values = {}
+        self._interp_order = interpolation_order
         if x_values is None:
             x_values = np.arange(len(values))
         x_values = np.asarray(x_values)
@@ -180,12 +208,11 @@ class _ProfileBase:
             raise ValueError("X values must be monotonically increasing or decreasing")
         sort_idxs = np.argsort(x_values)
         self.x_values = x_values[sort_idxs]
-        self.values = values[sort_idxs]
         self._cache = {}
+        self.values = values[sort_idxs]
         if ground:
             self.values = au.ground(self.values)
-        if isinstance(normalization, str):
-            normalization = Normalization(normalization)
+        normalization = _enum(normalization, Normalization)
         if normalization == Normalization.MAX:
             self.normalize()
         elif normalization == Normalization.GEOMETRIC_CENTER:
@@ -193,15 +220,40 @@ class _ProfileBase:
         elif normalization == Normalization.BEAM_CENTER:
             self.normalize(self.y_at_x(self.center_idx))
 
-    def __len__(self):
-        return len(self.values)
+    # ``values`` is a plain attribute in the reference and every mutator rebinds it; here the rebinding also drops what was
+    # derived from the old samples (the edge search, the smoothed derivative): ``field_edge_idx`` searches the current
+    # values on every call like the reference's, while ``center_idx`` & co. stay what they were at first use
+    # (``cached_property`` there and here)
+    @property
+    def values(self):
+        return self._values
 
-    def __getitem__(self, items):
-        return self.values[items]
-
-    def normalize(self, norm_val=None) -> None:
-        self.values = au.normalize(self.values, value=norm_val)
+    @values.setter
+    def values(self, v) -> None:
+        self._values = v
         self._cache.clear()
+
+    def x_at_x(self, x):
+        """profile.py:242-247: deprecated alias"""
+        warnings.warn("x_at_x is deprecated. Use x_at_x_idx instead", DeprecationWarning)
+        return self.x_at_x_idx(x)
+
+    def compute(self, metrics):
+        """profile.py:531-575: the profile-metric plug-in protocol.  ``metrics``: one object or an iterable of objects with
+        ``inject_profile(profile)``, ``calculate()`` and ``full_name`` -- the reference's own ``ProfileMetric`` subclasses
+        (pylinac/metrics/profile.py) run unchanged on these profiles.  One metric -> its value, several -> a dict."""
+        from .image import _uniquify
+
+        if hasattr(metrics, "calculate"):
+            metrics = [metrics]
+        values = {}
+        for metric in metrics:
+            metric.inject_profile(self)
+            self.metrics.append(metric)
+            key = _uniquify(list(values.keys()) + list(self.metric_values.keys()), metric.full_name)
+            values[key] = metric.calculate()
+        self.metric_values |= values
+        return values[key] if len(values) == 1 else values
 
     def x_at_x_idx(self, x):
         r = _linear_at(np.arange(len(self.x_values), dtype=float), self.x_values.astype(float), x)
@@ -278,7 +330,7 @@ class _ProfileBase:
         return type(self)(values=new_y, x_values=new_x, ground=False, normalization=Normalization.NONE,
                           **self._resample_kwargs())
 
-    def resample_to(self, target_profile: "_ProfileBase"):
+    def resample_to(self, target_profile: "ProfileBase"):
         """profile.py:392-431: this profile's values linearly interpolated at the target's x-values (no
         extrapolation), as a new profile of this class."""
         target_x = np.asarray(target_profile.x_values, dtype=float)
@@ -293,30 +345,35 @@ class _ProfileBase:
                                 kind="linear").reshape(-1).cpu().numpy()
         return type(self)(values=target_y, x_values=target_x)
 
-    @property
+    @cached_property
     def center_idx(self) -> float:
+        """profile.py:322-327 (a ``cached_property`` there too: fixed at first use)"""
         left = self.field_edge_idx(LEFT)
         right = self.field_edge_idx(RIGHT)
         return abs(right - left) / 2 + left
 
-    @property
+    @cached_property
     def geometric_center_idx(self) -> float:
         """profile.py:329-332"""
         return self.x_at_x_idx(au.geometric_center_idx(self.values))
 
-    @property
+    @cached_property
     def cax_index(self) -> float:
         """profile.py:334-337"""
         return self.x_at_x_idx((len(self.x_values) - 1) / 2)
 
-    @property
+    @cached_property
     def field_width_px(self) -> float:
+        """profile.py:339-344"""
         left = self.field_edge_idx(LEFT)
         right = self.field_edge_idx(RIGHT)
         return max(right, left) - min(right, left)
 
 
-class FWXMProfile(_ProfileBase):
+_ProfileBase = ProfileBase          # (the name earlier rounds used)
+
+
+class FWXMProfile(ProfileBase):
     """pylinac/core/profile.py:578-611: a profile with one large signal whose edges are the FWXM intersections of its
     most prominent peak."""
 
@@ -363,7 +420,7 @@ class _CubicOnHost:
         return out if np.ndim(xq) else out.reshape(())
 
 
-class InflectionDerivativeProfile(_ProfileBase):
+class InflectionDerivativeProfile(ProfileBase):
     """pylinac/core/profile.py:612-680: field edges = the extrema of the derivative of the Gaussian-smoothed profile,
     refined on its cubic interpolant.  Smoothing, gradient and the spline solve run on the device; the two
     one-dimensional BFGS refinements are the reference's own ``scipy.optimize.minimize`` calls on the host (SURVEY.md
@@ -447,6 +504,26 @@ class PhysicalProfileMixin:
     def field_width_mm(self) -> float:
         return self.field_width_px / self.implicit_dpmm
 
+    def gamma(self, evaluation_profile, dose_to_agreement: float = 3, distance_to_agreement: float = 3,
+              gamma_cap_value: float = 2, dose_threshold: float = 5, fill_value: float = np.nan, return_profiles: bool = False):
+        """profile.py:822-874: geometric gamma of this (reference) profile against ``evaluation_profile``, both shifted so that
+        their geometric centres sit at 0, on their physical x-values (``gamma.gamma_geometric`` -> ``pl_gamma_geometric``).
+        ``return_profiles`` -> (gamma, the shifted copy of self, the shifted copy of the evaluation profile)."""
+        import copy
+
+        from .gamma import gamma_geometric
+
+        if not isinstance(evaluation_profile, PhysicalProfileMixin):
+            raise ValueError("The evaluation profile must also be a physical profile.")
+        reference, evaluation = copy.deepcopy(self), copy.deepcopy(evaluation_profile)
+        reference.x_values = reference.x_values - reference.geometric_center_idx
+        evaluation.x_values = evaluation.x_values - evaluation.geometric_center_idx
+        g = gamma_geometric(reference=np.asarray(reference.values), reference_coordinates=reference.physical_x_values,
+                            evaluation=np.asarray(evaluation.values), evaluation_coordinates=evaluation.physical_x_values,
+                            dose_to_agreement=dose_to_agreement, distance_to_agreement=distance_to_agreement,
+                            gamma_cap_value=gamma_cap_value, dose_threshold=dose_threshold, fill_value=fill_value)
+        return (g, reference, evaluation) if return_profiles else g
+
     def as_simple_profile(self):
         """profile.py:936-948: the non-physical class over the physical x-values"""
         return type(self).__bases__[-1](values=self.values, x_values=self.physical_x_values)
@@ -509,14 +586,13 @@ class HillProfilePhysical(PhysicalProfileMixin, HillProfile):
         self._init_physical(dpmm)
 
 
-class CircleProfile(MultiProfile):
+class CircleProfile(MultiProfile, Circle):
     """pylinac/core/profile.py:2179-2402: a profile sampled along a circle
-    (``ndimage.map_coordinates(image, [y, x], order=0)``)."""
+    (``ndimage.map_coordinates(image, [y, x], order=0)``); a ``Circle`` too (``center``, ``radius``, ``diameter``, ``area``)."""
 
     def __init__(self, center, radius: float, image_array, start_angle=0, ccw: bool = True,
                  sampling_ratio: float = 1.0):
-        self.center = center if hasattr(center, "x") else Point(x=center[0], y=center[1])
-        self.radius = radius
+        Circle.__init__(self, center, radius)
         image_array = np.asarray(image_array)
         self._ensure_array_size(image_array, self.radius + self.center.x, self.radius + self.center.y)
         self.image_array = image_array
@@ -668,8 +744,11 @@ class Centering(enum.Enum):
 
 
 def _enum(value, cls):
-    """pylinac.core.utilities.convert_to_enum."""
-    return value if isinstance(value, cls) else cls(value)
+    """pylinac.core.utilities.convert_to_enum; a member of the HOST package's enum of the same name (``pylinac.Edge.FWHM`` handed
+    to these classes by the reference's analyzers) converts through its value."""
+    if isinstance(value, cls):
+        return value
+    return cls(value.value if isinstance(value, enum.Enum) else value)
 
 
 class _Linear1d:
@@ -736,7 +815,7 @@ class Hill:
         return self.params[0] + (self.params[1] - self.params[0]) / (1 + (self.params[2] / x) ** self.params[3])
 
 
-class SingleProfile:
+class SingleProfile(ProfileMixin):
     """pylinac/core/profile.py:1118-1633: a profile with one large signal (a beam profile).
 
     Same constructor arguments, dictionary keys and error behaviour as the reference for the FWHM,
@@ -774,8 +853,42 @@ class SingleProfile:
 
     def _set_values(self, t: torch.Tensor) -> None:
         self.values_device = t
-        self.values = t.cpu().numpy()
-        self._y_interp1d = _Linear1d(self.x_indices, self.values, extrapolate=True)
+        self._values = t.cpu().numpy()
+        self._y_interp1d = _Linear1d(self.x_indices, self._values, extrapolate=True)
+
+    # ``values`` is what the reference's users read and what the ProfileMixin methods rebind (invert, stretch, filter ...);
+    # a rebinding refreshes the resident copy the searches run on.  Like the reference, it does NOT rebuild ``_y_interp1d``
+    # (the look-up function of the constructor's values, profile.py:1213-1215).
+    @property
+    def values(self):
+        return self._values
+
+    @values.setter
+    def values(self, v) -> None:
+        self._values = np.asarray(v)
+        self.values_device = _to_device_profile(self._values)
+
+    def resample(self, interpolation_factor: int = 10, interpolation_resolution_mm: float = 0.1) -> "SingleProfile":
+        """profile.py:1283-1304: a new profile of the current values at another resolution"""
+        return SingleProfile(values=self.values, x_values=self.x_indices, dpmm=(1 / self._interpolation_res) if self.dpmm else None,
+                             interpolation=self._interp_method, ground=self._ground,
+                             interpolation_resolution_mm=interpolation_resolution_mm, interpolation_factor=interpolation_factor,
+                             normalization_method=self._norm_method, edge_detection_method=self._edge_method,
+                             edge_smoothing_ratio=self._edge_smoothing_ratio, hill_window_ratio=self._hill_window_ratio)
+
+    def gamma(self, evaluation_profile: "SingleProfile", distance_to_agreement: int = 1, dose_to_agreement: float = 1,
+              gamma_cap_value: float = 2, dose_threshold: float = 5, global_dose: bool = True, fill_value: float = np.nan):
+        """profile.py:1939-1993: 1-D gamma of this (reference) profile against ``evaluation_profile`` on their physical
+        x-indices (``pl_gamma1d``)."""
+        from .gamma import gamma_1d
+
+        if not self.dpmm or not evaluation_profile.dpmm:
+            raise ValueError("At least one profile does not have the dpmm attribute. Physical spacing cannot be determined. "
+                             "Set it before performing gamma analysis.")
+        return gamma_1d(reference=self.values, evaluation=evaluation_profile.values, reference_coordinates=self.x_indices,
+                        evaluation_coordinates=evaluation_profile.x_indices, dose_to_agreement=dose_to_agreement,
+                        distance_to_agreement=distance_to_agreement, gamma_cap_value=gamma_cap_value, global_dose=global_dose,
+                        dose_threshold=dose_threshold, fill_value=fill_value)[0]
 
     # --- interpolation (profile.py:1306-1360)
     @staticmethod

@@ -3,6 +3,7 @@ emulated-device tests (tests/emu_backend.py, CPU).  Each takes the golden loader
 from __future__ import annotations
 
 import numpy as np
+import pytest
 import torch
 
 
@@ -1730,3 +1731,48 @@ def check_fused_tail_vs_separate(dev, shapes=((3, 200, 520), (2, 128, 64), (2, 1
             assert np.array_equal(a[k].cpu().numpy()[c > 0], b[k].cpu().numpy()[c > 0]), (n, h, w, k)
         assert np.array_equal(a["props"].cpu().numpy()[c > 0], b["props"].cpu().numpy()[c > 0]), (n, h, w)
     return len(shapes)
+
+
+def _gamma_geometric_cases(g):
+    import json
+
+    for k in range(int(g["count"])):
+        kw = json.loads(str(g[f"kw{k}"]))
+        for name in ("reference", "evaluation", "reference_coordinates", "evaluation_coordinates"):
+            if f"{name}{k}" in g.files:
+                kw[name] = g[f"{name}{k}"]
+        yield k, kw, g[f"gamma{k}"]
+
+
+def check_gamma_geometric(golden, dev):
+    """pl_gamma_geometric against the reference's own gamma_geometric (its known-answer inputs from
+    tests_basic/core/test_gamma.py:304-372; dose-like profile pairs incl. coarser, reversed and integer evaluation samples) and
+    PhysicalProfileMixin.gamma against the reference's own method (tests/golden/gamma_geometric.npz): NaN / fill positions
+    identical, gamma to 1e-12 (float64 in the reference's operation order; only BLAS ``dot`` / ``math.dist`` may round the last
+    bit differently); the reference's ValueErrors."""
+    from pylinac_amd import gamma as pg
+    from pylinac_amd import profile as pp
+
+    g = golden("gamma_geometric")
+    for k, kw, want in _gamma_geometric_cases(g):
+        got = pg.gamma_geometric(device=dev, **kw)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), k
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-13, equal_nan=True), (k, np.nanmax(np.abs(got - want)))
+    for bad in (dict(reference=np.ones((2, 2)), evaluation=np.ones(4)), dict(reference=np.ones(5), evaluation=np.ones(5), distance_to_agreement=0),
+                dict(reference=np.ones(5), evaluation=np.ones(5), dose_to_agreement=-1),
+                dict(reference=np.ones(5), evaluation=np.ones(5), reference_coordinates=np.arange(6)),
+                dict(reference=np.ones(5), evaluation=np.ones(5), evaluation_coordinates=np.array([0.0, 1, 3, 2, 4]))):
+        with pytest.raises(ValueError):
+            pg.gamma_geometric(device=dev, **bad)
+    # the profile method: both profiles re-centred on their geometric centres, physical x-values
+    r1, e1 = pp.FWXMProfilePhysical(g["p.ref"], dpmm=2.0), pp.FWXMProfilePhysical(g["p.ev"], dpmm=2.0)
+    g1, rr, ee = r1.gamma(e1, dose_to_agreement=1, distance_to_agreement=1, return_profiles=True)
+    assert np.allclose(g1, g["p.gamma1"], rtol=1e-12, atol=1e-13, equal_nan=True)
+    assert np.array_equal(rr.x_values, g["p.ref_x1"]) and np.array_equal(ee.x_values, g["p.ev_x1"])
+    assert np.array_equal(r1.x_values, np.arange(len(g["p.ref"])))                       # the originals are untouched
+    r2 = pp.FWXMProfilePhysical(g["p.ref"], dpmm=2.0)
+    e2 = pp.FWXMProfilePhysical(g["p.ev2"], x_values=g["p.xs2"] + 0.3, dpmm=None)
+    g2 = r2.gamma(e2, dose_to_agreement=2, distance_to_agreement=2, gamma_cap_value=3, dose_threshold=8, fill_value=-1.0)
+    assert np.allclose(g2, g["p.gamma2"], rtol=1e-12, atol=1e-13)
+    with pytest.raises(ValueError, match="must also be a physical profile"):
+        r1.gamma(pp.FWXMProfile(g["p.ev"]))

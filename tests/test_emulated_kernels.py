@@ -1002,3 +1002,9 @@ def test_emulated_canny_masked(golden, emulated):
     import next_row_checks as checks
 
     checks.check_canny_masked(golden, emulated)
+
+
+def test_emulated_gamma_geometric(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_gamma_geometric(golden, emulated)

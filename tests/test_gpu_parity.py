@@ -1476,6 +1476,12 @@ def test_gamma_1d_vs_reference_golden(golden, dev):
         pg.gamma_1d(np.ones(5), np.ones(5), reference_coordinates=np.arange(5.0) + 10, device=dev)
 
 
+def test_gamma_geometric_vs_reference_golden(golden, dev):
+    import next_row_checks as checks
+
+    checks.check_gamma_geometric(golden, dev)
+
+
 def test_median3_eight_columns_per_lane_shapes(dev):
     """median3_oct_kernel (width % 8 == 0, 16-byte aligned frames): one lane, partial waves, several waves per row
     (neighbour columns fetched across a wave boundary), heights that are not a multiple of the 16-row group, uint16

@@ -596,6 +596,18 @@ def test_gamma_1d_restatement_matches_reference(golden):
     assert abs(g["gamma3"][0] - 3) < 0.01 and g["gamma6"].max() == 2
 
 
+def test_gamma_geometric_restatement_matches_reference(golden):
+    """f4 (gamma): oracle.gamma_geometric against the reference's own gamma_geometric (tests/golden/gamma_geometric.npz,
+    make_gamma_geometric_golden.py): identical fill positions, gamma to 1e-13, and the reference's known answers."""
+    from next_row_checks import _gamma_geometric_cases
+
+    g = golden("gamma_geometric")
+    for k, kw, want in _gamma_geometric_cases(g):
+        got = o.gamma_geometric(**kw)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.allclose(got, want, rtol=1e-13, atol=1e-14, equal_nan=True), k
+    assert g["gamma0"].max() == 0 and abs(g["gamma1"].max() - 1) < 1e-3 and abs(g["gamma3"].min() - 0.5) < 1e-3 and g["gamma4"].max() == 2
+
+
 def _xim_split(file_bytes: np.ndarray):
     """(width, height, bytes_per_pixel, lookup table, pixel buffer) of a compressed .xim file image."""
     import struct
