@@ -1776,3 +1776,48 @@ def check_gamma_geometric(golden, dev):
     assert np.allclose(g2, g["p.gamma2"], rtol=1e-12, atol=1e-13)
     with pytest.raises(ValueError, match="must also be a physical profile"):
         r1.gamma(pp.FWXMProfile(g["p.ev"]))
+
+
+def _pf_mlc_cases(g):
+    for name, mlc, tr in zip(g["names"], g["mlcs"], g["transposed"]):
+        yield str(name), str(mlc), ("LEFT_RIGHT" if bool(tr) else "UP_DOWN")
+
+
+def check_pf_mlc_oracle(g):
+    """oracle.pf_measure(mlc=) against the reference's OWN PicketFence.analyze(mlc=MLC.X) on the HD Millennium, Agility,
+    Halcyon-distal and B-mod banks (tests/golden/make_pf_mlc_golden.py): spacing, picket indices, and every position the
+    reference kept, bit for bit."""
+    from oracle import pylinac_oracle as o
+
+    for name, mlc, orient in _pf_mlc_cases(g):
+        raw, dpmm = g[f"{name}.cropped"], float(g[f"{name}.dpmm"])
+        r = o.pf_measure(o.normalize(o.ground(raw)), dpmm, mlc=mlc, orientation=orient)
+        assert r["spacing"] == float(g[f"{name}.spacing"]), name
+        idx = {n: i for i, (n, c, w) in enumerate(r["leaves"])}
+        meas = g[f"{name}.meas"]
+        assert len(meas) > 150
+        for row in meas:
+            leaf, picket = int(row[0]), int(row[1])
+            assert r["peak_idxs"][picket] == row[2] and r["position"][idx[leaf], picket] == row[3], (name, leaf, picket)
+
+
+def check_pf_mlc_device(g, dev):
+    """picketfence.analyze_batch(mlc=) == the oracle on every window (NaN pattern included) and == the reference's own
+    analyze() on every window it kept, for the leaf banks other than the Millennium 120."""
+    from oracle import pylinac_oracle as o
+    from pylinac_amd import picketfence as ppf
+
+    for name, mlc, orient in _pf_mlc_cases(g):
+        raw, dpmm = g[f"{name}.cropped"], float(g[f"{name}.dpmm"])
+        res = ppf.analyze_batch(torch.from_numpy(np.ascontiguousarray(raw)[None]).to(dev), dpmm, mlc=mlc, orientation=orient)
+        ref = o.pf_measure(o.normalize(o.ground(raw)), dpmm, mlc=mlc, orientation=orient)
+        P = len(ref["peak_idxs"])
+        assert int(res.picket_count[0]) == P and float(res.spacing[0]) == ref["spacing"] == float(g[f"{name}.spacing"]), name
+        assert np.array_equal(res.picket_idx[0, :P].cpu().numpy(), ref["peak_idxs"]) and res.leaf_nums == [n for n, _, _ in ref["leaves"]]
+        got = res.position[0, :, :P].cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref["position"])), name
+        assert np.array_equal(got[~np.isnan(got)], ref["position"][~np.isnan(got)]), name
+        assert not (res.status[0, :, :P] == 3).any(), name                 # no window was refused as too tall
+        idx = {n: i for i, n in enumerate(res.leaf_nums)}
+        for row in g[f"{name}.meas"]:
+            assert float(res.position[0, idx[int(row[0])], int(row[1])]) == row[3], (name, row[:2])

@@ -1008,3 +1008,9 @@ def test_emulated_gamma_geometric(golden, emulated):
     import next_row_checks as checks
 
     checks.check_gamma_geometric(golden, emulated)
+
+
+def test_emulated_picket_fence_other_leaf_banks(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_pf_mlc_device(golden("picketfence_mlc"), emulated)

@@ -1476,6 +1476,13 @@ def test_gamma_1d_vs_reference_golden(golden, dev):
         pg.gamma_1d(np.ones(5), np.ones(5), reference_coordinates=np.arange(5.0) + 10, device=dev)
 
 
+def test_picket_fence_other_leaf_banks_vs_reference_golden(golden, dev):
+    """HD_MILLENNIUM / AGILITY / HALCYON_DISTAL / BMOD banks (and AGILITY LEFT_RIGHT) against the reference's own analyze()"""
+    import next_row_checks as checks
+
+    checks.check_pf_mlc_device(golden("picketfence_mlc"), dev)
+
+
 def test_gamma_geometric_vs_reference_golden(golden, dev):
     import next_row_checks as checks
 

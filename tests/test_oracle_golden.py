@@ -596,6 +596,12 @@ def test_gamma_1d_restatement_matches_reference(golden):
     assert abs(g["gamma3"][0] - 3) < 0.01 and g["gamma6"].max() == 2
 
 
+def test_picket_fence_other_leaf_banks_match_reference(golden):
+    import next_row_checks as checks
+
+    checks.check_pf_mlc_oracle(golden("picketfence_mlc"))
+
+
 def test_gamma_geometric_restatement_matches_reference(golden):
     """f4 (gamma): oracle.gamma_geometric against the reference's own gamma_geometric (tests/golden/gamma_geometric.npz,
     make_gamma_geometric_golden.py): identical fill positions, gamma to 1e-13, and the reference's known answers."""
