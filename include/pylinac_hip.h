@@ -98,6 +98,13 @@ int pl_bit_invert(const void* in, void* out, int dtype, int64_t total, void* str
 int pl_warp_affine(const void* in, void* out, int dtype, int64_t n, int64_t h, int64_t w, int order, const double* h_matrix,
                    const double* d_min, const double* d_max, void* stream);
 
+/* The per-unit record table an analyzer's batch returns (e.g. WLBaseImage.analyze's field centre / BB centroid / status per
+ * image, pylinac/winston_lutz.py:709-762): d_out float64 [n][k], out[i][j] = (double)col_j[i * strides[j] + offsets[j]] +
+ * adds[j]; d_cols = k device pointers (HOST array of pointers) to float64 (is_int32[j] = 0) or int32 (1) arrays; strides /
+ * offsets in elements; 1 <= k <= 16. */
+int pl_pack_columns(const void* const* d_cols, const int* is_int32, const int64_t* strides, const int64_t* offsets,
+                    const double* adds, int k, int64_t n, double* d_out, void* stream);
+
 /* out = a * factor   (same dtype; the multiply inside stretch(), array_utils.py:168) */
 int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,
              void* stream);
@@ -118,6 +125,11 @@ int pl_as_binary(const void* in, uint8_t* out, int dtype, int64_t n, int64_t cou
  * hist: uint32 [n][65536]; bin b counts value b (PL_U16) or value b-32768 (PL_I16).  Every bin
  * is written (no zero-fill needed). */
 int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, void* stream);
+/* The same pass, which also leaves the largest KEY (value for PL_U16, value + 32768 for PL_I16) of every 512-pixel tile
+ * [512 t, 512 t + 512) of every frame in d_tile_max uint16 [n][ceil(count / 512)] -- 0xffff for a tile the kernel did not
+ * look at as one unit (frames below 2^18 pixels, unaligned frames, a ragged tail): "look inside".  pl_field_cax_tiles uses
+ * it to visit only the tiles that can hold a pixel above the field threshold (pylinac/winston_lutz.py:775-779). */
+int pl_hist16_tiles(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, uint16_t* d_tile_max, void* stream);
 /* skimage.filters.threshold_otsu on an integer image (pylinac/ct.py:3323,3338; acr.py:1409):
  * one bin per integer in [min,max], float64 class statistics, first argmax.  Outputs int32[n]. */
 int pl_otsu_from_hist(const uint32_t* d_hist, int dtype, int64_t n, int32_t* d_thr,
@@ -222,6 +234,12 @@ int pl_scaled_binary(const void* in, int dtype, int64_t n, int64_t count, const 
  * pl_binary_centroid for that frame. */
 int pl_field_cax(const void* in, int dtype, int64_t n, int h, int w, const double* d_sub, const double* d_div,
                  const double* d_thr, unsigned long long* d_acc, double* d_out, int32_t* d_status, void* stream);
+/* The same with the streaming pass driven by pl_hist16_tiles' d_tile_max (uint16 [n][h * w / 512]): only tiles whose largest
+ * value can pass the threshold are read.  Same results; frames that are not 16-bit, not a whole number of 512-pixel tiles,
+ * not 8-pixel aligned, take pl_field_cax's full pass. */
+int pl_field_cax_tiles(const void* in, int dtype, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                       const double* d_thr, const uint16_t* d_tile_max, unsigned long long* d_acc, double* d_out,
+                       int32_t* d_status, void* stream);
 /* min / max over the four `window`-pixel-wide edge strips of every 16-bit frame (int32[n] each): the edge test of
  * WLBaseImage._clean_edges (pylinac/winston_lutz.py:1109-1133). */
 int pl_edge_minmax(const void* in, int dtype, int64_t n, int h, int w, int window, int32_t* d_min, int32_t* d_max,
@@ -634,12 +652,15 @@ int pl_pf_positions(const int32_t* d_status, const double* d_fwxm, const double*
  * rows; np.std over axis 0 and np.median over axis 1 of the window, i.e. the transposed computation with numpy's summation
  * order for a non-contiguous axis).  fwxm_params: pl_find_peaks parameters of FWXMProfile.field_edge_idx (fwxm_height,
  * max_number = 1).  d_prof (optional, float64 [n*nleaves*cap][lmax >= 128]) receives the window profiles.  max_rows: the
- * widest leaf in pixels, 1..48 (10 mm leaves on the finest supported EPID at isocentre scale are 45 pixels). */
+ * widest leaf in pixels, 1..48 (10 mm leaves on the finest supported EPID at isocentre scale are 45 pixels).
+ * exact_deviation: 0 = the edge test max(std) < edge_threshold * median(std) (:855) is decided from exact integer row moments
+ * whenever it holds or fails by more than numpy's rounding could move it (1e-7 relative), and numpy's float64 sequence only
+ * runs for a window inside that margin; 1 = always evaluate numpy's sequence.  Same results either way. */
 int pl_pf_measure(const uint16_t* in, int64_t n, int h, int w, int orientation, const double* d_sub, const double* d_div,
                   const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap, const double* d_spacing,
                   const int32_t* d_leaf_lo, const int32_t* d_leaf_hi, int nleaves, int max_rows, double height_threshold,
-                  double edge_threshold, const pl_peak_params* fwxm_params, double* d_rec, int32_t* d_status, double* d_prof,
-                  int lmax, void* stream);
+                  double edge_threshold, int exact_deviation, const pl_peak_params* fwxm_params, double* d_rec, int32_t* d_status,
+                  double* d_prof, int lmax, void* stream);
 /* np.mean(q, 1) -> d_out float64 [n][h] (the leaf profile of LEFT_RIGHT pickets, picketfence.py:749) in numpy's PAIRWISE
  * summation order for the contiguous axis.  The summation tree of a row of w values is laid out by the caller
  * (ops.pairwise_plan): d_leaf_start / d_leaf_len int32 [nleaves] = the leaf blocks (<= 128 values each), d_program int32

@@ -64,6 +64,7 @@ SIGNATURES = {
     "pl_threshold": ([_p, _p, _i, _l, _l, _p, _i, _i, _p], C.c_int),
     "pl_as_binary": ([_p, _p, _i, _l, _l, _p, _i, _p], C.c_int),
     "pl_hist16": ([_p, _i, _l, _l, _p, _p], C.c_int),
+    "pl_hist16_tiles": ([_p, _i, _l, _l, _p, _p, _p], C.c_int),
     "pl_otsu_from_hist": ([_p, _i, _l, _p, _p, _p, _p], C.c_int),
     "pl_otsu16": ([_p, _i, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_median3_otsu16": ([_p, _p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "pl_binary_centroid": ([_p, _l, _i, _i, _p, _p, _p], C.c_int),
     "pl_scaled_binary": ([_p, _i, _l, _l, _p, _p, _p, _p, _p], C.c_int),
     "pl_field_cax": ([_p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p], C.c_int),
+    "pl_field_cax_tiles": ([_p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_edge_minmax": ([_p, _i, _l, _i, _i, _i, _p, _p, _p], C.c_int),
     "pl_wl_decisions": ([_p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_scharr": ([_p, _p, _i, _l, _i, _i, _p], C.c_int),
@@ -99,7 +101,7 @@ SIGNATURES = {
     "pl_edge_otsu": ([_p, _i, _p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p, _p], C.c_int),
     "pl_edge_regions": ([_p, _p, _i, _p, _i, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _d, _p, _p, _p], C.c_int),
     "pl_peak_valley_regions": ([_p, _l, _i, _l, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
-    "pl_pf_measure": ([_p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _d, _d, _p, _p, _p, _p, _i, _p], C.c_int),
+    "pl_pf_measure": ([_p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _d, _d, _i, _p, _p, _p, _p, _i, _p], C.c_int),
     "pl_scaled_rowmean": ([_p, _l, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p], C.c_int),
     "pl_hill_fit": ([_p, _p, _p, _l, _i, _l, _p, _p, _p, _p, _p], C.c_int),
     "pl_hill_windows": ([_p, _p, _l, _i, _p, _p, _i, _p, _p, _i, _d, _i, _p, _p, _p, _p, _p], C.c_int),
@@ -107,6 +109,7 @@ SIGNATURES = {
     "pl_hill_penumbra": ([_p, _p, _l, _d, _d, _p, _p], C.c_int),
     "pl_profile_lookup": ([_p, _p, _l, _i, _p, _i, _p, _p], C.c_int),
     "pl_index_to_original": ([_p, _i, _p, _l, _p, _p], C.c_int),
+    "pl_pack_columns": ([_p, _p, _p, _p, _p, _i, _l, _p, _p], C.c_int),
     "pl_edge_plane": ([_p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p], C.c_int),
     "pl_mask_regions_fits": ([_i, _i, _i], C.c_int),
     "pl_mask_regions": ([_p, _i, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p], C.c_int),

@@ -438,6 +438,83 @@ cax_reduce_kernel(const T* __restrict__ in, int h, int w, int bpf, const double*
   }
 }
 
+// The same reduction driven by the 512-pixel tile maxima pl_hist16_tiles left behind: a tile whose largest key is below the
+// integer threshold cannot hold a foreground pixel and is never read -- a 20 x 20 mm field on a 1024^2 panel is a few dozen of
+// the frame's 2 048 tiles, so the second full read of the batch (r04z: 0.20 ms per 512 frames) becomes a 4 KiB table scan
+// per frame.  16-bit frames of a whole number of tiles with 16-byte aligned rows of 8-pixel vectors; exact integer
+// moments like cax_reduce_kernel (the sums are order-independent).  A frame whose divisor is not positive keeps the float64
+// test and looks at every tile.
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+cax_reduce_tiles_kernel(const T* __restrict__ in, int h, int w, int wpf /* workgroups per frame */, const double* __restrict__ sub,
+                        const double* __restrict__ div, const double* __restrict__ thr, const unsigned short* __restrict__ tile_max,
+                        unsigned long long* __restrict__ acc) {
+  const int64_t frame = blockIdx.x / wpf;
+  const int part = blockIdx.x % wpf;
+  const int64_t per_frame = (int64_t)h * w;
+  const int ntiles = (int)(per_frame >> 9);
+  const T* f = in + frame * per_frame;
+  const unsigned short* tm = tile_max + frame * ntiles;
+  const double s = sub[frame], d = div[frame], t = thr[frame];
+  const bool use_int = d > 0.0;
+  const int ithr = use_int ? cax_int_threshold<T>(s, d, t) : 0;
+  constexpr unsigned flip = (T)-1 < (T)0 ? 0x8000u : 0u;
+  // key(v) >= key(ithr) <=> v >= ithr; an ithr beyond the type's range (nothing passes) maps beyond every 16-bit key
+  const unsigned kthr = use_int ? (unsigned)(ithr + (int)flip) : 0u;
+  unsigned long long cnt = 0, sr = 0, sc = 0;
+  unsigned rmin = 0xffffffffu, rmax = 0, cmin = 0xffffffffu, cmax = 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = part * (kThreads / 64) + (int)(threadIdx.x >> 6), nwaves = wpf * (kThreads / 64);
+  const uint4* vf = reinterpret_cast<const uint4*>(f);
+  for (int t0 = wave * 64; t0 < ntiles; t0 += nwaves * 64) {          // 64 tiles' maxima per wave and step, one per lane
+    const int ti = t0 + lane;
+    const bool want = ti < ntiles && (unsigned)tm[ti < ntiles ? ti : 0] >= kthr;
+    unsigned long long todo = __ballot(want);
+    while (todo) {                                                    // wave-uniform: the tiles that may hold foreground
+      const int tile = t0 + __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int64_t v = (int64_t)tile * 64 + lane;
+      const uint4 q = vf[v];
+      const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+      const int64_t i = v * 8;
+      const unsigned r = (unsigned)(i / w), c0 = (unsigned)(i % w);
+      unsigned m = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int a0 = (int)(T)(wd[k] & 0xffffu), a1 = (int)(T)(wd[k] >> 16);
+        const bool p0 = use_int ? a0 >= ithr : ((double)a0 - s) / d >= t;
+        const bool p1 = use_int ? a1 >= ithr : ((double)a1 - s) / d >= t;
+        m |= (p0 ? 1u : 0u) << (2 * k);
+        m |= (p1 ? 1u : 0u) << (2 * k + 1);
+      }
+      if (m) {
+        const unsigned n = (unsigned)__popc(m);
+        unsigned csum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) csum += ((m >> k) & 1u) * (c0 + (unsigned)k);
+        cnt += n; sr += (unsigned long long)r * n; sc += csum;
+        rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax;
+        const unsigned cl = c0 + (unsigned)__builtin_ctz(m), ch = c0 + 31u - (unsigned)__builtin_clz(m);
+        cmin = cl < cmin ? cl : cmin; cmax = ch > cmax ? ch : cmax;
+      }
+    }
+  }
+  auto add = [](unsigned long long a, unsigned long long b) { return a + b; };
+  auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
+  auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+  cnt = pl_wave_reduce(cnt, add);
+  if (cnt == 0) return;                                               // wave-uniform: most waves saw no foreground at all
+  sr = pl_wave_reduce(sr, add); sc = pl_wave_reduce(sc, add);
+  rmin = pl_wave_reduce(rmin, mn); rmax = pl_wave_reduce(rmax, mx);
+  cmin = pl_wave_reduce(cmin, mn); cmax = pl_wave_reduce(cmax, mx);
+  if (lane == 0) {
+    unsigned long long* a = acc + frame * 8;
+    atomicAdd(&a[0], cnt); atomicAdd(&a[1], sr); atomicAdd(&a[2], sc);
+    atomicMin(&a[3], (unsigned long long)rmin); atomicMax(&a[4], (unsigned long long)rmax);
+    atomicMin(&a[5], (unsigned long long)cmin); atomicMax(&a[6], (unsigned long long)cmax);
+  }
+}
+
 __global__ void cax_init_kernel(unsigned long long* __restrict__ acc, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
@@ -514,9 +591,28 @@ cax_window_kernel(const T* __restrict__ in, int h, int w, const double* __restri
  * without materialising the mask: d_out float64[n][3] = (row, col, filled pixel count); d_acc uint64[n][8] scratch;
  * d_status int32[n]: 0 done, 1 = the foreground's bounding box exceeds the 384 x 384 LDS window (use pl_scaled_binary ->
  * pl_fill_holes -> pl_binary_centroid for that frame). */
+static int field_cax_impl(const void* in, int dtype, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                          const double* d_thr, const uint16_t* d_tile_max, unsigned long long* d_acc, double* d_out,
+                          int32_t* d_status, void* stream);
+
 extern "C" int pl_field_cax(const void* in, int dtype, int64_t n, int h, int w, const double* d_sub,
                             const double* d_div, const double* d_thr, unsigned long long* d_acc, double* d_out,
                             int32_t* d_status, void* stream) {
+  return field_cax_impl(in, dtype, n, h, w, d_sub, d_div, d_thr, nullptr, d_acc, d_out, d_status, stream);
+}
+
+/* pl_field_cax with the streaming pass driven by pl_hist16_tiles' tile maxima (see cax_reduce_tiles_kernel).  16-bit frames
+ * whose pixel count is a multiple of 512, width a multiple of 8 and base 16-byte aligned; anything else takes the full pass. */
+extern "C" int pl_field_cax_tiles(const void* in, int dtype, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                                  const double* d_thr, const uint16_t* d_tile_max, unsigned long long* d_acc, double* d_out,
+                                  int32_t* d_status, void* stream) {
+  PL_REQUIRE(d_tile_max, "null pointer");
+  return field_cax_impl(in, dtype, n, h, w, d_sub, d_div, d_thr, d_tile_max, d_acc, d_out, d_status, stream);
+}
+
+static int field_cax_impl(const void* in, int dtype, int64_t n, int h, int w, const double* d_sub, const double* d_div,
+                          const double* d_thr, const uint16_t* d_tile_max, unsigned long long* d_acc, double* d_out,
+                          int32_t* d_status, void* stream) {
   PL_REQUIRE(in && d_sub && d_div && d_thr && d_acc && d_out && d_status, "null pointer");
   PL_CCL_CHECK_SHAPE();
   hipStream_t st = (hipStream_t)stream;
@@ -536,8 +632,19 @@ extern "C" int pl_field_cax(const void* in, int dtype, int64_t n, int h, int w, 
       (void)hipFuncSetAttribute((const void*)cax_window_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, kCaxMaxWindow);
       attr = true;
     }
-    hipLaunchKernelGGL(cax_reduce_kernel<T>, dim3((unsigned)(n * bpf)), dim3(kThreads), 0, st, (const T*)in, h, w, bpf,
-                       d_sub, d_div, d_thr, d_acc);
+    bool tiled = false;
+    if constexpr (sizeof(T) == 2) {
+      if (d_tile_max && (((int64_t)h * w) & 511) == 0 && (w & 7) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        // two workgroups per frame scan the 4 KiB of maxima; the tiles they keep are a few dozen
+        const int wpf = 2;
+        hipLaunchKernelGGL(cax_reduce_tiles_kernel<T>, dim3((unsigned)(n * wpf)), dim3(kThreads), 0, st, (const T*)in, h, w, wpf,
+                           d_sub, d_div, d_thr, d_tile_max, d_acc);
+        tiled = true;
+      }
+    }
+    if (!tiled)
+      hipLaunchKernelGGL(cax_reduce_kernel<T>, dim3((unsigned)(n * bpf)), dim3(kThreads), 0, st, (const T*)in, h, w, bpf,
+                         d_sub, d_div, d_thr, d_acc);
     hipLaunchKernelGGL(cax_window_kernel<T>, dim3((unsigned)n), dim3(kThreads), kCaxMaxWindow, st, (const T*)in, h, w,
                        d_sub, d_div, d_thr, d_acc, d_out, d_status);
   });

@@ -389,6 +389,43 @@ extern "C" int pl_cast_wrap(const double* in, void* out, int dtype, int64_t coun
   return pl_check_launch("pl_cast_wrap");
 }
 
+// Per-unit result records: out[i][j] = (double)column_j[i * stride_j + offset_j] + add_j for up to 16 columns of float64 or
+// int32 device arrays -- the ONE table an analyzer's batch sends to the host (the Winston-Lutz record: field centre, BB
+// centroid + window offset, counts, status words, decision flags), assembled in one launch instead of a dozen framework
+// kernels of a few microseconds each (r04z: 0.2 of the 1.07 ms of a 512-frame Winston-Lutz pass).
+struct PackCols {
+  const void* ptr[16];
+  int64_t stride[16], offset[16];
+  double add[16];
+  int is_i32[16];
+};
+
+__global__ void pack_columns_kernel(PackCols c, int k, int64_t n, double* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (t >= n * k) return;
+  const int64_t i = t / k;
+  const int j = (int)(t - i * k);
+  const int64_t at = i * c.stride[j] + c.offset[j];
+  const double v = c.is_i32[j] ? (double)static_cast<const int32_t*>(c.ptr[j])[at] : static_cast<const double*>(c.ptr[j])[at];
+  out[t] = v + c.add[j];
+}
+
+extern "C" int pl_pack_columns(const void* const* d_cols, const int* is_int32, const int64_t* strides, const int64_t* offsets,
+                               const double* adds, int k, int64_t n, double* d_out, void* stream) {
+  PL_REQUIRE(d_cols && is_int32 && strides && offsets && adds && d_out, "null pointer");
+  PL_REQUIRE(k >= 1 && k <= 16 && n >= 0, "1..16 columns");
+  if (n == 0) return PL_OK;
+  PackCols c{};
+  for (int j = 0; j < k; ++j) {
+    PL_REQUIRE(d_cols[j] != nullptr, "null column");
+    c.ptr[j] = d_cols[j]; c.stride[j] = strides[j]; c.offset[j] = offsets[j]; c.add[j] = adds[j]; c.is_i32[j] = is_int32[j];
+  }
+  PL_REQUIRE(pl_cdiv(n * k, kThreads) <= 0x7fffffffLL, "batch too large");
+  hipLaunchKernelGGL(pack_columns_kernel, dim3((unsigned)pl_cdiv(n * k, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, c, k, n,
+                     d_out);
+  return pl_check_launch("pl_pack_columns");
+}
+
 extern "C" int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,
                         void* stream) {
   PL_EW_PROLOGUE("pl_scale");

@@ -810,7 +810,8 @@ constexpr int kTwScratchAt = (2 * kTwBins + 1 + PL_WAVE + 3) / 4 * 16;   // two 
 constexpr size_t kTwLds = kTwScratchAt + sizeof(TwScratch);
 
 __global__ void __launch_bounds__(kHistThreads)
-hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, unsigned flip, uint32_t* __restrict__ hist) {
+hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, unsigned flip, uint32_t* __restrict__ hist,
+                         unsigned short* __restrict__ tile_max /* optional [n][ceil(count / 512)] */) {
   extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // 2 * kTwBins, then TwScratch
   TwScratch& scr = *reinterpret_cast<TwScratch*>(reinterpret_cast<unsigned char*>(bins) + kTwScratchAt);
   const int64_t frame = blockIdx.x;
@@ -822,6 +823,13 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   const uint4* vsrc = reinterpret_cast<const uint4*>(src);
 
   for (int i = threadIdx.x; i < 2 * kTwBins; i += kHistThreads) bins[i] = 0;
+  // tile maxima (pl_hist16_tiles): tile t = pixels [512 t, 512 t + 512) = the 64 vectors ONE wave load of the main loop
+  // fetches; its largest key (biased domain) lets a later pass skip every tile that cannot hold a pixel above its
+  // threshold (pl_field_cax_tiles).  Tiles the main loop does not cover keep 0xffff ("look inside").
+  const int64_t ntiles = (count + 511) / 512;
+  unsigned short* const tmax = tile_max ? tile_max + frame * ntiles : nullptr;
+  if (tmax)
+    for (int64_t i = threadIdx.x; i < ntiles; i += kHistThreads) tmax[i] = (unsigned short)0xffffu;
   // extrema of a 1/16 sample (blocks of 1024 pixels, every 16th block), as otsu16_window_kernel
   int mn = 1 << 30, mx = -1;
   auto see = [&](unsigned key) {
@@ -936,6 +944,21 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
     uint4 q[U];
 #pragma unroll
     for (int k = 0; k < U; ++k) q[k] = vsrc[v + (int64_t)k * kHistThreads];
+    if (tmax) {                                                     // wave-uniform
+      const unsigned f2 = flip | (flip << 16);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        auto pmax = [](unsigned a, unsigned b) {
+          const us2 r = __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
+          return __builtin_bit_cast(unsigned, r);
+        };
+        const unsigned m2 = pmax(pmax(q[k].x ^ f2, q[k].y ^ f2), pmax(q[k].z ^ f2, q[k].w ^ f2));
+        int m = (int)((m2 & 0xffffu) > (m2 >> 16) ? (m2 & 0xffffu) : (m2 >> 16));
+        m = pl_wave_reduce_idem(m, [](int a, int b) { return a > b ? a : b; });
+        if (lane == 0) tmax[(v - lane + (int64_t)k * kHistThreads) >> 6] = (unsigned short)m;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < U; ++k) tally4(q[k]);
     // 64 pixels per lane later: keep a guess that attracted >= 1/16 of them, else try the first lane's latest pixel
@@ -960,8 +983,20 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
 
 }  // namespace
 
-extern "C" int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist,
-                         void* stream) {
+static int hist16_impl(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, uint16_t* d_tile_max, void* stream);
+
+extern "C" int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, void* stream) {
+  return hist16_impl(in, dtype, n, count, d_hist, nullptr, stream);
+}
+
+extern "C" int pl_hist16_tiles(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, uint16_t* d_tile_max,
+                               void* stream) {
+  PL_REQUIRE(d_tile_max, "null pointer");
+  return hist16_impl(in, dtype, n, count, d_hist, d_tile_max, stream);
+}
+
+static int hist16_impl(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, uint16_t* d_tile_max,
+                       void* stream) {
   PL_REQUIRE(in && d_hist, "null pointer");
   PL_REQUIRE(n >= 0 && count > 0, "bad shape");
   PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
@@ -983,8 +1018,14 @@ extern "C" int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, ui
     two_window = ok ? 1 : -1;
   }
   if (two_window == 1 && count >= 262144) {
-    hipLaunchKernelGGL(hist16_two_window_kernel, dim3((unsigned)n), dim3(kHistThreads), kTwLds, st, src, count, flip, d_hist);
+    hipLaunchKernelGGL(hist16_two_window_kernel, dim3((unsigned)n), dim3(kHistThreads), kTwLds, st, src, count, flip, d_hist,
+                       d_tile_max);
     return pl_check_launch("pl_hist16");
+  }
+  // (the multi-part kernels keep no tile maxima: every tile says "look inside")
+  if (d_tile_max && hipMemsetAsync(d_tile_max, 0xff, (size_t)n * (size_t)((count + 511) / 512) * sizeof(uint16_t), st) != hipSuccess) {
+    pl_set_error("pl_hist16_tiles: memset failed");
+    return PL_ERR_HIP;
   }
   int rc = launch_hist16<2, false>(src, n, count, flip, d_hist, st);
   if (rc != 0) rc = launch_hist16<4, false>(src, n, count, flip, d_hist, st);   // 64 KiB LDS needs no opt-in

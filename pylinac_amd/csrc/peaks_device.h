@@ -273,6 +273,10 @@ __device__ __forceinline__ void find_peaks_profile(const double* __restrict__ xf
   // the one peak that survives stage G is the most prominent candidate -- among equals the LAST (np.argsort(kind="stable")
   // [::-1][:1]) -- so the candidate tables, the O(P^2) ranking and the two ordered scans of stages G / H are skipped: every
   // wave keeps the best of its candidates in registers and the wave that holds the overall best measures its width.
+  // (Round 5 tried to go further for one-wave profiles of <= 64 samples -- lane i holds sample i; if exactly one candidate holds
+  // the global maximum M its bases are the side minima and any other candidate's prominence is bounded by h' - min(profile),
+  // so five wave reductions replace the walks -- bit-identical on every exit, and NOT faster: a picket-fence window has two
+  // or three candidates, whose walks cost the same five reductions.  profiles/r05b_pf_window_variants.txt; not kept.)
   if (prm.max_number == 1 && prm.sort_key == PL_SORT_PROMINENCES && !prm.has_prominence && !(prm.width_min > 0.0)) {
     double best_prom = -1.0;                               // prominences are >= 0
     int best_p = -1, best_lb = 0, best_rb = 0;

@@ -255,7 +255,7 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
                   const int32_t* __restrict__ leaf_bottom, int nleaves, double height_threshold,
                   double edge_threshold, int lmax, double* __restrict__ prof_out, int32_t* __restrict__ len_out,
                   double* __restrict__ offset_out, int32_t* __restrict__ status_out, int64_t total_windows, int rows_cap,
-                  int lr, int wave_bytes, pl_peak_params fw, double* __restrict__ rec_out) {
+                  int lr, int wave_bytes, pl_peak_params fw, double* __restrict__ rec_out, int exact_std) {
   // dynamic LDS: per wave `rows_cap` x 128 window pixels, then `rows_cap` row deviations.  rows_cap is the tallest leaf window
   // the CALLER will ask for (the leaf geometry is host knowledge): the fixed 48-row capacity of rounds 1-3 kept three
   // workgroups on a CU where a 26-row bank leaves room for five -- the kernel is one long dependent chain per wave and
@@ -360,6 +360,58 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   // share a row: lane j of the group owns chain r[j], the tree is three xor-shuffles (float addition commutes, so both
   // partners hold the same sum), one lane adds the tail.  Same operations in the same order as one lane doing it all,
   // at an eighth of the float64 divisions per lane (round 1: one lane per row, 12 of 64 lanes busy).
+  // ---- is_not_at_edge = max(std) < edge_threshold * np.median(std), std = np.std(window, axis) per leaf pixel row.
+  // The DECISION does not need numpy's float64 deviations: std(q) = std(a) / div for the integer pixels a, and with
+  // V_r = n * sum(a^2) - (sum a)^2 (an exact integer below 2^47) the test reads  max_r sqrt(V_r) < thr * median_r sqrt(V_r)
+  // -- n and div cancel.  numpy's values (pairwise or sequential sums of rounded quotients, two-pass deviations) differ from
+  // the exact ones by far less than 1e-7 relative + 1e-11 * div * n absolute in these units (a row that is not constant has
+  // sqrt(V) >= 1.4), so the test is taken from the integer moments whenever it holds or fails by more than that margin, and
+  // only a window inside the margin (or with `exact_std`) evaluates numpy's sequence below.  r05a stopwatch: the float64
+  // stage was 180 of the kernel's 485 us.
+  bool decided = false, not_edge = false;
+  if (!exact_std) {
+    const int j = lane & 7, gr = lane >> 3;
+    for (int row0 = 0; row0 < nrows; row0 += 8) {           // wave-uniform trip count
+      const int r = row0 + gr;
+      const bool act = r < nrows;
+      const unsigned short* rowp = sw + (act ? r : 0) * ncols;
+      unsigned s1 = 0;
+      unsigned long long s2 = 0;
+      for (int c = j; c < ncols; c += 8) {
+        const unsigned a = rowp[c];
+        s1 += a;
+        s2 += (unsigned long long)(a * a);                   // a < 2^16: the product fits 32 bits
+      }
+      s1 = pl_group8_sum(s1);
+      s2 = pl_group8_sum(s2);
+      if (act && j == 0) {
+        const unsigned long long v = (unsigned long long)ncols * s2 - (unsigned long long)s1 * (unsigned long long)s1;
+        s_std_w[r] = sqrt((double)v);                        // V < 2^47: the conversion is exact
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const bool act = lane < nrows;
+    const double va = act ? s_std_w[lane] : 0.0;
+    const double smax_i = pl_wave_reduce_idem(act ? va : -1.0, [](double x, double y) { return x > y ? x : y; });
+    int rank = 0;
+    for (int b2 = 0; b2 < nrows; ++b2) {
+      const double vb = s_std_w[b2];
+      rank += (vb < va || (vb == va && b2 < lane)) ? 1 : 0;
+    }
+    const int k_hi = nrows / 2, k_lo = (nrows & 1) ? k_hi : k_hi - 1;
+    const unsigned long long m_lo = __ballot(act && rank == k_lo), m_hi = __ballot(act && rank == k_hi);
+    const double v_lo = __shfl(va, __builtin_ctzll(m_lo | (1ull << 63)), 64);
+    const double v_hi = __shfl(va, __builtin_ctzll(m_hi | (1ull << 63)), 64);
+    const double med_i = (nrows & 1) ? v_hi : (v_lo + v_hi) / 2.0;
+    const double tau = 1.0e-11 * div[frame] * (double)ncols, eta = 1.0e-7;
+    const double max_hi = smax_i * (1.0 + eta) + tau, max_lo = smax_i * (1.0 - eta) - tau;
+    const double med_hi = med_i * (1.0 + eta) + tau, med_lo = med_i * (1.0 - eta) - tau;
+    if (max_hi < edge_threshold * med_lo) { decided = true; not_edge = true; }
+    else if (max_lo >= edge_threshold * med_hi) { decided = true; not_edge = false; }
+    __builtin_amdgcn_wave_barrier();                         // (the exact stage below rewrites s_std_w)
+  }
+  if (!decided) {
 #if PL_PF_VARIANT == 1                                     // stopwatch: no deviation stage (wrong edge test)
   if (lane < nrows) s_std_w[lane] = 1.0;
 #else
@@ -423,7 +475,8 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
     const double v_hi = __shfl(va, __builtin_ctzll(m_hi | (1ull << 63)), 64);
     med = (nrows & 1) ? v_hi : (v_lo + v_hi) / 2.0;
   }
-  const bool not_edge = smax < edge_threshold * med;
+  not_edge = smax < edge_threshold * med;
+  }
   if (!(above && not_edge)) status = 2;
 
   // np.median(window, axis=0): lane c (and c+64) selects the middle order statistic(s) of its column; the profile stays in
@@ -598,7 +651,7 @@ extern "C" int pl_pf_windows_rows(const uint16_t* in, int64_t n, int h, int w, c
   hipLaunchKernelGGL(pf_windows_kernel, dim3((unsigned)blocks), dim3(kThreads), wb * (kThreads / PL_WAVE), (hipStream_t)stream, in, h, w,
                      d_sub, d_div, d_pk_count, d_pk_idx, d_pk_val, cap, d_spacing, d_leaf_top, d_leaf_bottom, nleaves,
                      height_threshold, edge_threshold, lmax, d_prof, d_len, d_offset, d_status, total, rows_cap, 0, (int)wb,
-                     pl_peak_params{}, nullptr);
+                     pl_peak_params{}, nullptr, 0);
   return pl_check_launch("pl_pf_windows");
 }
 
@@ -606,8 +659,9 @@ extern "C" int pl_pf_windows_rows(const uint16_t* in, int64_t n, int h, int w, c
 extern "C" int pl_pf_measure(const uint16_t* in, int64_t n, int h, int w, int orientation, const double* d_sub, const double* d_div,
                              const int32_t* d_pk_count, const int32_t* d_pk_idx, const double* d_pk_val, int cap,
                              const double* d_spacing, const int32_t* d_leaf_lo, const int32_t* d_leaf_hi, int nleaves,
-                             int max_rows, double height_threshold, double edge_threshold, const pl_peak_params* fwxm_params,
-                             double* d_rec, int32_t* d_status, double* d_prof, int lmax, void* stream) {
+                             int max_rows, double height_threshold, double edge_threshold, int exact_deviation,
+                             const pl_peak_params* fwxm_params, double* d_rec, int32_t* d_status, double* d_prof, int lmax,
+                             void* stream) {
   PL_REQUIRE(max_rows >= 1 && max_rows <= kMaxRows, "max_rows 1..48");
   PL_REQUIRE(orientation == 0 || orientation == 1, "orientation 0 (UP_DOWN) or 1 (LEFT_RIGHT)");
   PL_REQUIRE(in && d_sub && d_div && d_pk_count && d_pk_idx && d_pk_val && d_spacing && d_leaf_lo && d_leaf_hi && fwxm_params &&
@@ -623,7 +677,7 @@ extern "C" int pl_pf_measure(const uint16_t* in, int64_t n, int h, int w, int or
   hipLaunchKernelGGL(pf_windows_kernel, dim3((unsigned)blocks), dim3(kThreads), wb * (kThreads / PL_WAVE), (hipStream_t)stream, in, h, w,
                      d_sub, d_div, d_pk_count, d_pk_idx, d_pk_val, cap, d_spacing, d_leaf_lo, d_leaf_hi, nleaves,
                      height_threshold, edge_threshold, lmax, d_prof, (int32_t*)nullptr, (double*)nullptr, d_status, total, rows_cap,
-                     orientation, (int)wb, *fwxm_params, d_rec);
+                     orientation, (int)wb, *fwxm_params, d_rec, exact_deviation ? 1 : 0);
   return pl_check_launch("pl_pf_measure");
 }
 

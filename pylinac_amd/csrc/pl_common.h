@@ -239,6 +239,25 @@ __device__ __forceinline__ double pl_wave_reduce_idem(double v, F f) {
   return pl_readlane_f64(v, 63);
 }
 
+// Sums over the EIGHT lanes of a lane's aligned group (lanes 8k .. 8k + 7), every lane gets the total: two quad permutes and a
+// half-row mirror on the DPP path (one vector move per 32-bit word and step) where __shfl_xor is an LDS round trip each.
+// Integer sums only (any order is exact).
+__device__ __forceinline__ unsigned pl_group8_sum(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1, 0, 3, 2]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2, 3, 0, 1]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);    // row_half_mirror: lane i <- lane 7 - i
+  return v;
+}
+__device__ __forceinline__ unsigned long long pl_group8_sum(unsigned long long v) {
+  auto from = [](unsigned long long x, auto mv) {
+    return ((unsigned long long)(unsigned)mv((int)(x >> 32)) << 32) | (unsigned long long)(unsigned)mv((int)x);
+  };
+  v += from(v, [](int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true); });
+  v += from(v, [](int x) { return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true); });
+  v += from(v, [](int x) { return __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true); });
+  return v;
+}
+
 // dispatch a dtype enum onto a template parameter
 #define PL_DISPATCH_DTYPE(dtype, T, ...)                         \
   switch (dtype) {                                               \

@@ -107,11 +107,11 @@ def _find_features_levels(s: torch.Tensor, dpmm: float, radius_mm: float, radius
 
 def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float, low_density: bool = False,
                        bb_tolerance_mm: float | None = None, vmin: torch.Tensor | None = None,
-                       vmax: torch.Tensor | None = None, defer: bool = False):
+                       vmax: torch.Tensor | None = None, defer: bool = False, shift: bool = True):
     """``WLBaseImage.find_bb_centroids`` (pylinac/winston_lutz.py:788-806) for uint16 frames:
     SizedDiskLocator.from_center_physical(expected (0, 0) mm, window (40 + d) mm, radius d/2,
     invert = not low_density) on the ground()/normalize()d frame.  Returns the find_features result
-    with ``xy`` shifted to frame coordinates."""
+    with ``xy`` shifted to frame coordinates (``shift=False``: left in window coordinates, the offsets in ``window``)."""
     x = ops._frames(frames)
     if x.dtype != torch.uint16:
         raise TypeError("bb_centroids_batch needs uint16 frames")
@@ -155,9 +155,10 @@ def bb_centroids_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float,
     else:
         sample = _bb_sample(x, top, bottom, left, right, vmin, vmax, low_density)
         res = find_features_batch(sample, dpmm, bb_diameter_mm / 2, bb_tolerance_mm, defer=defer)
-    res["xy"][..., 0] += float(left)                     # (scalar adds: no host-to-device copy, no synchronisation)
-    res["xy"][..., 1] += float(top)
-    res["window"] = (top, bottom, left, right)
+    if shift:                                            # (scalar adds: no host-to-device copy, no synchronisation)
+        res["xy"][..., 0] += float(left)
+        res["xy"][..., 1] += float(top)
+    res["window"] = (top, bottom, left, right)           # shift=False: ``xy`` stays in window coordinates, the caller adds these
     return res
 
 

@@ -250,16 +250,23 @@ def as_binary(frames: torch.Tensor, thr) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------- histogram / Otsu / percentile
-def histogram16(frames: torch.Tensor, out=None) -> torch.Tensor:
+def histogram16(frames: torch.Tensor, out=None, tiles: bool = False):
     """Exact per-frame histogram of a 16-bit integer batch: uint32 [N, 65536] (stored in an int32
-    tensor; bin b = value b for uint16, value b-32768 for int16)."""
+    tensor; bin b = value b for uint16, value b-32768 for int16).  ``tiles=True`` -> (histogram, tile maxima): the same pass
+    also leaves the largest key of every 512-pixel tile of every frame (uint16 [N, ceil(pixels / 512)], stored in an int16
+    tensor; 0xffff = "look inside"), which :func:`field_cax` uses to skip the tiles that cannot hold foreground."""
     x = _frames(frames)
     if x.dtype not in (torch.uint16, torch.int16):
         raise TypeError("histogram16 needs uint16 or int16 frames")
     n = x.shape[0]
     out = torch.empty((n, 65536), dtype=torch.int32, device=x.device) if out is None else out
-    check(_lib.load().pl_hist16(x.data_ptr(), _dt(x), n, x[0].numel(), out.data_ptr(), _stream()), "pl_hist16")
-    return out
+    if not tiles:
+        check(_lib.load().pl_hist16(x.data_ptr(), _dt(x), n, x[0].numel(), out.data_ptr(), _stream()), "pl_hist16")
+        return out
+    tmax = torch.empty((n, (x[0].numel() + 511) // 512), dtype=torch.int16, device=x.device)
+    check(_lib.load().pl_hist16_tiles(x.data_ptr(), _dt(x), n, x[0].numel(), out.data_ptr(), tmax.data_ptr(), _stream()),
+          "pl_hist16_tiles")
+    return out, tmax
 
 
 def otsu_from_hist(hist: torch.Tensor, dtype: torch.dtype):
@@ -780,11 +787,12 @@ def binary_centroid(mask: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def field_cax(frames: torch.Tensor, sub, div, thr, defer: bool = False):
+def field_cax(frames: torch.Tensor, sub, div, thr, defer: bool = False, tile_max: torch.Tensor | None = None):
     """``center_of_mass(binary_fill_holes(((a - sub) / div) >= thr))`` per frame -> float64 [N,3] = (row, col, count):
     the fused window path (``pl_field_cax``), the general mask -> fill -> centroid path for frames whose foreground
     bounding box does not fit the LDS window.  ``defer=True`` returns ``(out, status)`` without looking at the status on
-    the host (no synchronisation): the caller redoes the frames whose status is non-zero."""
+    the host (no synchronisation): the caller redoes the frames whose status is non-zero.  ``tile_max``: see
+    :func:`histogram16` -- same results, without a second full read of the frames."""
     x = _frames(frames)
     n, h, w = x.shape
     dev = x.device
@@ -793,8 +801,15 @@ def field_cax(frames: torch.Tensor, sub, div, thr, defer: bool = False):
     acc = torch.empty((n, 8), dtype=torch.int64, device=dev)
     out = torch.empty((n, 3), dtype=torch.float64, device=dev)
     status = torch.empty(n, dtype=torch.int32, device=dev)
-    check(_lib.load().pl_field_cax(x.data_ptr(), _dt(x), n, h, w, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
-                                   acc.data_ptr(), out.data_ptr(), status.data_ptr(), _stream()), "pl_field_cax")
+    if tile_max is not None:          # histogram16(..., tiles=True)'s maxima: only tiles that can hold foreground are read
+        if tile_max.shape != (n, (h * w + 511) // 512) or tile_max.dtype != torch.int16:
+            raise ValueError("tile_max must be histogram16(frames, tiles=True)[1] of the same frames")
+        check(_lib.load().pl_field_cax_tiles(x.data_ptr(), _dt(x), n, h, w, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                             tile_max.contiguous().data_ptr(), acc.data_ptr(), out.data_ptr(), status.data_ptr(),
+                                             _stream()), "pl_field_cax_tiles")
+    else:
+        check(_lib.load().pl_field_cax(x.data_ptr(), _dt(x), n, h, w, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                       acc.data_ptr(), out.data_ptr(), status.data_ptr(), _stream()), "pl_field_cax")
     if defer:
         return out, status
     redo = torch.nonzero(status).flatten()
@@ -802,6 +817,34 @@ def field_cax(frames: torch.Tensor, sub, div, thr, defer: bool = False):
         sel = x.view(torch.int16)[redo].view(torch.uint16) if x.dtype == torch.uint16 else x[redo]
         binary = scaled_binary(sel, a[0][redo], a[1][redo], a[2][redo])
         out[redo] = binary_centroid(fill_holes(binary, connectivity_bg=4))
+    return out
+
+
+def pack_columns(columns, n: int) -> torch.Tensor:
+    """One float64 [n, K] table from K per-unit device columns in ONE launch (``pl_pack_columns``).  ``columns``: a list of
+    ``tensor`` or ``(tensor, offset, add)`` -- the tensor float64 or int32, of shape [n] or [n, ...] (the column is
+    ``tensor.reshape(n, -1)[:, offset] + add``)."""
+    import ctypes as C
+
+    k = len(columns)
+    if not 1 <= k <= 16:
+        raise ValueError("1..16 columns")
+    ptrs, is32 = (C.c_void_p * k)(), (C.c_int * k)()
+    strides, offsets, adds = (C.c_int64 * k)(), (C.c_int64 * k)(), (C.c_double * k)()
+    keep, dev = [], None
+    for j, col in enumerate(columns):
+        t, off, add = (col, 0, 0.0) if isinstance(col, torch.Tensor) else col
+        if t.dtype not in (torch.float64, torch.int32):
+            raise TypeError("pack_columns takes float64 or int32 columns")
+        t = t.contiguous()
+        if t.shape[0] != n:
+            raise ValueError("every column needs n rows")
+        keep.append(t)
+        dev = t.device
+        ptrs[j], is32[j] = t.data_ptr(), 1 if t.dtype == torch.int32 else 0
+        strides[j], offsets[j], adds[j] = (t.numel() // n if n else 1), int(off), float(add)
+    out = torch.empty((n, k), dtype=torch.float64, device=dev)
+    check(_lib.load().pl_pack_columns(ptrs, is32, strides, offsets, adds, k, n, out.data_ptr(), _stream()), "pl_pack_columns")
     return out
 
 

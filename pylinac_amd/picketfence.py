@@ -96,13 +96,15 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, mlc: str = "MILLENNIUM", nu
                   leaf_analysis_width_ratio: float = 0.4, height_threshold: float = 0.5,
                   edge_threshold: float = 1.5, peak_sort: str = "peak_heights",
                   required_prominence: float = 0.2, fwxm: int = 50, cap: int | None = None,
-                  orientation: str = "UP_DOWN", separate_leaves: bool = False) -> PFBatchResult:
+                  orientation: str = "UP_DOWN", separate_leaves: bool = False, exact_deviation: bool = False) -> PFBatchResult:
     """The per-image measurement of ``PicketFence.analyze`` (picketfence.py:745-803, 1605-1628) for a resident batch, in five
     launches: min / max (ground + normalize folded into every later read), leaf profile, picket peaks, picket table, and ONE
     kernel for all leaf x picket windows (window test, median profile, FWXM search, position).  ``orientation``: "UP_DOWN"
     (pickets run up-down: the leaf profile is ``np.mean(image, 0)``) or "LEFT_RIGHT" (``np.mean(image, 1)``, windows
     transposed).  ``separate_leaves``: also return both leaf-end positions per window.  ``cap`` = picket slots per frame
-    (default ``num_pickets`` when given, else 16)."""
+    (default ``num_pickets`` when given, else 16).  ``exact_deviation=True`` makes every window evaluate numpy's float64
+    ``np.std`` sequence for the edge test instead of deciding it from exact integer row moments where the margin allows
+    (identical results; a test knob)."""
     x = ops._frames(frames)
     if x.dtype != torch.uint16:
         raise TypeError("analyze_batch needs uint16 frames (the reference's int16 ground() overflows)")
@@ -165,7 +167,8 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, mlc: str = "MILLENNIUM", nu
     import ctypes as C
     check(lib.pl_pf_measure(x.data_ptr(), n, h, w, 1 if lr else 0, vmin.data_ptr(), gmax.data_ptr(), peaks.count.data_ptr(),
                             pk_idx.data_ptr(), pk_val.data_ptr(), cap, spacing.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(), nl,
-                            max_rows, float(height_threshold), float(edge_threshold), C.byref(fw), rec.data_ptr(),
+                            max_rows, float(height_threshold), float(edge_threshold), 1 if exact_deviation else 0, C.byref(fw),
+                            rec.data_ptr(),
                             status.data_ptr(), 0, 0, st), "pl_pf_measure")
     rec = rec.view(n, nl, cap, 3)
     return PFBatchResult([v[0] for v in view], pk_idx, peaks.count, spacing, rec[..., 0], status.view(n, nl, cap),

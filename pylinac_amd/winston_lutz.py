@@ -84,7 +84,7 @@ def field_centroids_batch(frames: torch.Tensor, stats: _FrameStats | None = None
 
 
 def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0, low_density: bool = False,
-                  clean_edges: bool = True):
+                  clean_edges: bool = True, tile_maxima: bool = True):
     """The per-image part of ``WLBaseImage.analyze`` (pylinac/winston_lutz.py:709-725) for a batch of uint16 frames
     resident on the GPU:
 
@@ -115,17 +115,22 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0
     cnt = h * w
     qs = _FIELD_Q + _INVERSION_Q + _EDGE_Q
     _, lo, hi, frac = ops._percentile_plan(cnt, list(qs))
-    hist = ops.histogram16(x)
+    # the histogram pass also notes the largest value of every 512-pixel tile: the field CAX then reads only the tiles that
+    # can hold a pixel above the field threshold instead of the whole batch a second time (``tile_maxima=False``: the full
+    # pass; same results -- an A/B knob)
+    hist, tmax = ops.histogram16(x, tiles=True) if tile_maxima else (ops.histogram16(x), None)
     st = ops.order_stats(x, np.concatenate([[0, cnt - 1], lo, hi]), hist=hist)          # int32 [N, 16], on the device
     del hist
     emin, emax = ops.edge_minmax(x, 2)
     dec = ops.wl_decisions(st, emin, emax, frac)
-    cen, cax_status = ops.field_cax(x, dec["vmin"], dec["gmax"], dec["thr"], defer=True)   # (row, col, count)
+    cen, cax_status = ops.field_cax(x, dec["vmin"], dec["gmax"], dec["thr"], defer=True, tile_max=tmax)   # (row, col, count)
     bb = features.bb_centroids_batch(x, dpmm, bb_diameter_mm, low_density=low_density, vmin=dec["vmin"], vmax=dec["vmax"],
-                                     defer=True)
-    f64 = lambda t: t.to(torch.float64)
-    table = torch.stack([cen[:, 1], cen[:, 0], bb["xy"][:, 0, 0], bb["xy"][:, 0, 1], f64(bb["count"]), f64(bb["status"]),
-                         f64(cax_status), f64(dec["inverted"]), f64(dec["noisy"])], dim=1).cpu().numpy()   # the one sync
+                                     defer=True, shift=False)
+    top, _, left, _ = bb["window"]
+    # the record table in ONE launch (field x / y, BB x / y moved from window to frame coordinates, count, the status words,
+    # the two decision flags) and the one synchronisation of the pass
+    table = ops.pack_columns([(cen, 1, 0.0), (cen, 0, 0.0), (bb["xy"], 0, float(left)), (bb["xy"], 1, float(top)), bb["count"],
+                              bb["status"], cax_status, dec["inverted"], dec["noisy"]], n).cpu().numpy()
     cntb = table[:, 4]
     record = np.concatenate([table[:, :2], np.where(cntb[:, None] > 0, table[:, 2:4], np.nan)], axis=1)
     status = (cntb == 0).astype(np.int32)

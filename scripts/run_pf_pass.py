@@ -1,5 +1,5 @@
 """Driver for profiling BASELINE config #3: `passes` x picketfence.analyze_batch over `n` resident 768 x 1024 frames.
-    python scripts/run_pf_pass.py [n=512] [passes=3]"""
+    python scripts/run_pf_pass.py [n=512] [passes=3] [exact]      ("exact": every window evaluates numpy's float64 np.std sequence)"""
 import sys
 import time
 
@@ -13,7 +13,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda:0")
 fr = pf_frames(n, device=dev)
-fn = lambda: picketfence.analyze_batch(fr, 1 / 0.390625, num_pickets=10)
+exact = len(sys.argv) > 3 and sys.argv[3] == "exact"
+fn = lambda: picketfence.analyze_batch(fr, 1 / 0.390625, num_pickets=10, exact_deviation=exact)
 fn()
 torch.cuda.synchronize()
 t0 = time.perf_counter()

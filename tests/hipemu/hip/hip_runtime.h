@@ -221,6 +221,7 @@ inline T readfirstlane(T v) {
 }
 }  // namespace hipemu
 // DPP controls the kernels use: wave_shr:1 (0x138: lane i <- lane i - 1) / wave_shl:1 (0x130: lane i <- lane i + 1),
+// quad_perm (0x00 - 0xff: two selector bits per lane of a quad), row_half_mirror (0x141) / row_mirror (0x140),
 // row_shr:n (0x110 + n: lane i <- lane i - n inside its row of 16), row_bcast:15 (0x142: lane 15 of each row to the next
 // row), row_bcast:31 (0x143: lane 31 to rows 2 and 3).  A lane without a source, or whose row / bank the masks disable,
 // keeps `old` (bound_ctrl: 0 instead, for a missing source).
@@ -231,7 +232,10 @@ inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_
   const int row = lane >> 4, in_row = lane & 15;
   if (!((row_mask >> row) & 1) || !((bank_mask >> (in_row >> 2)) & 1)) return old;
   int from = -1;
-  if (ctrl == 0x138) from = lane - 1;
+  if (ctrl >= 0 && ctrl <= 0xff) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);   // quad_perm
+  else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));                            // row_half_mirror
+  else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));                         // row_mirror
+  else if (ctrl == 0x138) from = lane - 1;
   else if (ctrl == 0x130) from = lane + 1 < 64 ? lane + 1 : -1;
   else if (ctrl > 0x110 && ctrl <= 0x11f) from = in_row >= (ctrl & 15) ? lane - (ctrl & 15) : -1;
   else if (ctrl == 0x142) from = row >= 1 ? 16 * row - 1 : -1;

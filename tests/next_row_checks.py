@@ -1807,6 +1807,7 @@ def check_pf_mlc_device(g, dev):
     from oracle import pylinac_oracle as o
     from pylinac_amd import picketfence as ppf
 
+    rejected = 0
     for name, mlc, orient in _pf_mlc_cases(g):
         raw, dpmm = g[f"{name}.cropped"], float(g[f"{name}.dpmm"])
         res = ppf.analyze_batch(torch.from_numpy(np.ascontiguousarray(raw)[None]).to(dev), dpmm, mlc=mlc, orientation=orient)
@@ -1818,6 +1819,132 @@ def check_pf_mlc_device(g, dev):
         assert np.array_equal(np.isnan(got), np.isnan(ref["position"])), name
         assert np.array_equal(got[~np.isnan(got)], ref["position"][~np.isnan(got)]), name
         assert not (res.status[0, :, :P] == 3).any(), name                 # no window was refused as too tall
+        # the edge test decided from integer row moments (default) == numpy's float64 deviations evaluated for every window
+        ex = ppf.analyze_batch(torch.from_numpy(np.ascontiguousarray(raw)[None]).to(dev), dpmm, mlc=mlc, orientation=orient,
+                               exact_deviation=True)
+        assert torch.equal(ex.status, res.status) and torch.equal(torch.nan_to_num(ex.position, nan=-1.0), torch.nan_to_num(res.position, nan=-1.0)), name
+        rejected += int((res.status[0, :, :P] == 2).sum())
         idx = {n: i for i, n in enumerate(res.leaf_nums)}
         for row in g[f"{name}.meas"]:
             assert float(res.position[0, idx[int(row[0])], int(row[1])]) == row[3], (name, row[:2])
+    assert rejected > 0                                                     # (jaw-blocked rows: windows that fail the test)
+    # a window ON the decision boundary: edge_threshold := numpy's own max(std) / median(std) of one window, so that the integer
+    # moments cannot decide it (inside the 1e-7 margin) and numpy's float64 sequence must -- the oracle says how it comes out
+    name, mlc, orient = next(iter(_pf_mlc_cases(g)))
+    raw, dpmm = g[f"{name}.cropped"], float(g[f"{name}.dpmm"])
+    img = o.normalize(o.ground(raw))
+    base = o.pf_measure(img, dpmm, mlc=mlc, orientation=orient)
+    ratios = []
+    sp, peaks = base["spacing"], base["peak_idxs"]
+    for num, center, width in base["leaves"]:                 # _get_mlc_window (picketfence.py:859-886), UP_DOWN
+        c_px, w_px = center * dpmm + raw.shape[0] / 2, width * dpmm
+        lo, hi = max(int(c_px - w_px / 2), 0), min(int(c_px + w_px / 2), raw.shape[0])
+        for pk in peaks[:3]:
+            t0, t1 = max(int(pk - sp / 2), 0), min(int(pk + sp / 2), raw.shape[1])
+            std = np.std(img[lo:hi, t0:t1], axis=1)
+            if len(std) and np.median(std) > 0:
+                ratios.append(max(std) / np.median(std))
+    for thr in sorted(ratios)[len(ratios) // 2 - 1:len(ratios) // 2 + 2]:
+        want = o.pf_measure(img, dpmm, mlc=mlc, orientation=orient, edge_threshold=float(thr))
+        got = ppf.analyze_batch(torch.from_numpy(np.ascontiguousarray(raw)[None]).to(dev), dpmm, mlc=mlc, orientation=orient,
+                                edge_threshold=float(thr)).position[0, :, :len(peaks)].cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want["position"])), thr
+        assert 0 < int(np.isnan(want["position"]).sum()) < want["position"].size       # the threshold splits the windows
+
+
+def check_fwxm_short_profiles(dev, trials=600):
+    """The FWXM search (max_number = 1 by prominence) on short one-wave profiles (the picket-fence windows' case:
+    peaks_device.h) against scipy through the oracle, on profiles built for its corner cases: smooth humps, the global
+    maximum on an edge sample or shared by two peaks, plateaus, a side peak more prominent than the highest one, monotone and
+    constant profiles.  Indices, bases, prominence, width, width height and both interpolated positions bit for bit."""
+    from oracle import pylinac_oracle as o
+    from pylinac_amd import ops
+    from scipy.signal import find_peaks as sp_find_peaks
+
+    rng = np.random.default_rng(31)
+    found = skipped = 0
+    for t in range(trials):
+        L = int(rng.integers(3, 65))
+        kind = t % 6
+        xx = np.arange(L, dtype=float)
+        if kind == 0:                                         # one hump + noise (a picket-fence window)
+            x = np.exp(-0.5 * ((xx - rng.uniform(0.2, 0.8) * L) / rng.uniform(1.5, 6)) ** 2) + rng.normal(0, 0.01, L)
+        elif kind == 1:                                       # integers: plateaus, equal maxima
+            x = rng.integers(0, 5, L).astype(float)
+        elif kind == 2:                                       # the highest sample sits on an edge
+            x = np.abs(rng.normal(size=L)).cumsum() * (1 if rng.random() < 0.5 else -1)
+            x = x - x.min()
+            x[rng.integers(1, L - 1) if L > 2 else 0] += 0.3
+        elif kind == 3:                                       # a low side peak next to a deep valley beats the high peak on a shoulder
+            x = np.concatenate([[0.0, 5.0, 0.0], np.linspace(5.5, 6.0, max(L - 5, 1)), [5.9, 5.95]])[:L] + rng.normal(0, 1e-3, min(L, max(L - 5, 1) + 5))
+        elif kind == 4:
+            x = rng.random(L)
+        else:
+            x = np.full(L, 2.0) if t % 12 == 5 else np.sort(rng.random(L))
+        x = np.ascontiguousarray(x[:L] if len(x) >= L else np.pad(x, (0, L - len(x))))
+        h = float(rng.choice([0.5, 0.2, 0.8]))
+        pk, props = sp_find_peaks(x, prominence=0)
+        if len(pk) > 1:
+            pr = np.sort(props["prominences"])
+            if pr[-1] == pr[-2]:                              # an exact tie for the first place: platform-defined in the reference
+                skipped += 1
+                continue
+        i1, p1 = o.find_peaks(x, fwxm_height=h, max_number=1)
+        i2, p2 = ops.find_peaks_batch(torch.from_numpy(x).to(dev), fwxm_height=h, max_number=1).to_host(0)
+        assert np.array_equal(i1, i2), (t, kind, x.tolist())
+        for k in p1:
+            assert np.array_equal(p1[k], p2[k]), (t, kind, k, x.tolist())
+        found += len(i1)
+    assert found > 0.6 * (trials - skipped) and skipped < trials // 4, (found, skipped)
+
+
+def check_field_cax_tile_maxima(dev, big=False):
+    """pl_hist16_tiles + pl_field_cax_tiles against pl_hist16 + pl_field_cax: identical histograms, tile maxima that are the
+    true maxima of their 512-pixel tiles (or 0xffff), identical field CAX records -- uint16 and int16 frames, thresholds below
+    every pixel / above every pixel / inside the noise, a frame with holes, and frames the tiled pass must refuse (pixel count
+    not a multiple of 512: the full pass runs, same results)."""
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(77)
+    h, w = (1024, 1024) if big else (512, 512)              # >= 2^18 pixels: the two-window histogram kernel with tile maxima
+    base = rng.integers(900, 1100, (4, h, w)).astype(np.int64)
+    base[0, 200:260, 300:380] += 30000                      # a field
+    base[1, 100:400, 50:450] += 20000
+    base[1, 200:230, 200:260] -= 20000                      # ... with a hole
+    base[2, 5:9, 7:11] += 40000                             # a tiny one, touching nothing
+    frames = np.clip(base, 0, 65535).astype(np.uint16)
+    done = 0
+    for dtype, arr in ((torch.uint16, frames), (torch.int16, (frames.astype(np.int64) - 20000).astype(np.int16))):
+        x = torch.from_numpy(arr).to(dev)
+        hist0 = ops.histogram16(x)
+        hist1, tmax = ops.histogram16(x, tiles=True)
+        assert torch.equal(hist0, hist1)
+        keys = arr.astype(np.int64) + (32768 if dtype == torch.int16 else 0)
+        true_max = keys.reshape(4, -1, 512).max(axis=2)
+        got = tmax.cpu().numpy().astype(np.int64) & 0xFFFF
+        assert ((got == true_max) | (got == 0xFFFF)).all() and (got == true_max).mean() > 0.99
+        vmin = torch.from_numpy(arr.reshape(4, -1).min(axis=1).astype(np.float64)).to(dev)
+        vmax = torch.from_numpy(arr.reshape(4, -1).max(axis=1).astype(np.float64)).to(dev)
+        for thr in (0.5, 0.0, 1.5, 0.002, 0.9999):            # mid-level, everything, nothing, inside the noise, only the peak
+            t = torch.full((4,), thr, dtype=torch.float64, device=dev)
+            a, sa = ops.field_cax(x, vmin, vmax - vmin, t, defer=True)
+            b, sb = ops.field_cax(x, vmin, vmax - vmin, t, defer=True, tile_max=tmax)
+            ok = sa == 0                                     # (status 1 = window too large: the record is not written)
+            assert torch.equal(sa, sb) and torch.equal(torch.nan_to_num(a[ok], nan=-1.0), torch.nan_to_num(b[ok], nan=-1.0)), (str(dtype), thr)
+            done += int(ok.sum())
+        if dtype == torch.uint16:                            # a divisor that is not positive keeps the float64 test on every tile
+            t = torch.full((4,), 0.5, dtype=torch.float64, device=dev)
+            a, sa = ops.field_cax(x, vmin, -(vmax - vmin), t, defer=True)
+            b, sb = ops.field_cax(x, vmin, -(vmax - vmin), t, defer=True, tile_max=tmax)
+            ok = sa == 0
+            assert torch.equal(sa, sb) and torch.equal(torch.nan_to_num(a[ok], nan=-1.0), torch.nan_to_num(b[ok], nan=-1.0))
+    assert done >= 20
+    # 513 x 520: two-window kernel (>= 2^18 pixels), but 266 760 pixels are not a whole number of tiles -> full pass, same record
+    odd = np.clip(rng.integers(900, 1100, (2, 513, 520)), 0, 65535).astype(np.uint16)
+    odd[:, 100:180, 90:200] += 30000
+    x = torch.from_numpy(odd).to(dev)
+    _, tmax = ops.histogram16(x, tiles=True)
+    vmin = torch.from_numpy(odd.reshape(2, -1).min(axis=1).astype(np.float64)).to(dev)
+    rng_ = torch.from_numpy((odd.reshape(2, -1).max(axis=1) - odd.reshape(2, -1).min(axis=1)).astype(np.float64)).to(dev)
+    t = torch.full((2,), 0.5, dtype=torch.float64, device=dev)
+    assert torch.equal(ops.field_cax(x, vmin, rng_, t), ops.field_cax(x, vmin, rng_, t, tile_max=tmax))

@@ -1014,3 +1014,15 @@ def test_emulated_picket_fence_other_leaf_banks(golden, emulated):
     import next_row_checks as checks
 
     checks.check_pf_mlc_device(golden("picketfence_mlc"), emulated)
+
+
+def test_emulated_fwxm_short_profiles(emulated):
+    import next_row_checks as checks
+
+    checks.check_fwxm_short_profiles(emulated, trials=240)
+
+
+def test_emulated_field_cax_tile_maxima(emulated):
+    import next_row_checks as checks
+
+    checks.check_field_cax_tile_maxima(emulated)

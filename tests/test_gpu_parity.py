@@ -413,6 +413,18 @@ def test_find_peaks_vs_oracle_random(dev):
     assert n_peaks > 1000
 
 
+def test_field_cax_driven_by_tile_maxima_equals_the_full_pass(dev):
+    import next_row_checks as checks
+
+    checks.check_field_cax_tile_maxima(dev, big=True)
+
+
+def test_fwxm_search_short_profiles_corner_cases(dev):
+    import next_row_checks as checks
+
+    checks.check_fwxm_short_profiles(dev)
+
+
 def test_find_peaks_batch_rows_are_independent(dev):
     from pylinac_amd import ops
 
