@@ -320,17 +320,21 @@ pf_windows_kernel(const unsigned short* __restrict__ in, int h, int w, const dou
   {
     int r = lane / ncols, c = lane - r * ncols;
     const int dr = PL_WAVE / ncols, dc = PL_WAVE - dr * ncols;
+    const unsigned stride_across = lr ? 1u : (unsigned)w, stride_along = lr ? (unsigned)w : 1u;   // scalars: no branch per load
     const int total = nrows * ncols;
     for (int e0 = lane; e0 < total + lane; e0 += 8 * PL_WAVE) {      // wave-uniform trip count
       unsigned short v[8];
       int rr = r, cc = c;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const bool in_win = e0 + k * PL_WAVE < total;
         // window element (rr, cc) = (position across the leaf, position along the leaf's travel): UP_DOWN reads image row
         // top + rr, LEFT_RIGHT image column top + rr -- the LDS copy is the TRANSPOSED window then, and everything below
-        // (max, column median = np.median(window, axis=1), the FWXM profile) is the UP_DOWN code
-        v[k] = in_win ? (lr ? f[(size_t)(left + cc) * w + top + rr] : f[(size_t)(top + rr) * w + left + cc]) : (unsigned short)0;
+        // (max, column median = np.median(window, axis=1), the FWXM profile) is the UP_DOWN code.  The load is UNCONDITIONAL
+        // (an element past the window's end re-reads its last row; only the LDS store below looks at the bound): behind a
+        // per-lane branch every load cost twenty instructions of exec-mask bookkeeping and 64-bit address arithmetic
+        // (r05c ISA); here it is a 32-bit element offset from the frame's scalar base
+        const int rrc = rr < nrows ? rr : nrows - 1;
+        v[k] = f[(unsigned)(top + rrc) * stride_across + (unsigned)(left + cc) * stride_along];
         rr += dr;
         cc += dc;
         if (cc >= ncols) { cc -= ncols; ++rr; }
