@@ -678,6 +678,12 @@ int pl_scaled_rowmean(const uint16_t* in, int64_t n, int h, int w, const double*
  *   too small, -1 too few samples, -4 a NaN or infinity among the samples: curve_fit raises ValueError); d_nfev (optional) int32 [n] function evaluations. */
 int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
                 double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, void* stream);
+/* The same fit, which also reports d_last_step float64 [n]: the length of the LAST ACCEPTED Levenberg-Marquardt step relative
+ * to the parameter vector (MINPACK's scaled variables).  MINPACK stops on the reduction of the sum of squares; in a flat valley
+ * that happens while the parameters still move, and where it happens depends on the last bit of pow(): such a fit (last step
+ * above ~1e-6) is reproduced by scipy to 1e-3, not to 1e-5.  NaN where no fit was attempted. */
+int pl_hill_fit_ex(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
+                   double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, double* d_last_step, void* stream);
 
 /* The two penumbra windows SingleProfile.inflection_data fits (pylinac/core/profile.py:1676-1700) for a batch of processed
  * profiles sharing x_indices: left_idx / right_idx = _x_interp_to_original(first derivative peak / last valley),

@@ -104,6 +104,7 @@ SIGNATURES = {
     "pl_pf_measure": ([_p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _d, _d, _i, _p, _p, _p, _p, _i, _p], C.c_int),
     "pl_scaled_rowmean": ([_p, _l, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p], C.c_int),
     "pl_hill_fit": ([_p, _p, _p, _l, _i, _l, _p, _p, _p, _p, _p], C.c_int),
+    "pl_hill_fit_ex": ([_p, _p, _p, _l, _i, _l, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_hill_windows": ([_p, _p, _l, _i, _p, _p, _i, _p, _p, _i, _d, _i, _p, _p, _p, _p, _p], C.c_int),
     "pl_hill_inflection": ([_p, _l, _p, _p], C.c_int),
     "pl_hill_penumbra": ([_p, _p, _l, _d, _d, _p, _p], C.c_int),

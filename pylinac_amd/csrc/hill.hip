@@ -216,7 +216,7 @@ __device__ void hill_lmpar(double* r, const int* ipvt, const double* diag, const
 __global__ void __launch_bounds__(kHillThreads)
 hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, const int32_t* __restrict__ lens, int64_t nfits,
                 int mmax, int64_t stride, double* __restrict__ work /* [8 * mmax][nfits] */, double* __restrict__ params,
-                int32_t* __restrict__ info_out, int32_t* __restrict__ nfev_out) {
+                int32_t* __restrict__ info_out, int32_t* __restrict__ nfev_out, double* __restrict__ step_out) {
   constexpr int n = kHillN;
   const int64_t fit = (int64_t)blockIdx.x * kHillThreads + threadIdx.x;
   if (fit >= nfits) return;
@@ -238,6 +238,7 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
     for (int j = 0; j < n; ++j) out[j] = nan;
     info_out[fit] = -1;
     if (nfev_out) nfev_out[fit] = 0;
+    if (step_out) step_out[fit] = nan;
     return;
   }
   // p0 = (min(y), max(y), np.median(x), 0): the median of the (sorted, as np.arange makes them) x values by selection
@@ -253,6 +254,7 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
       for (int j = 0; j < n; ++j) out[j] = nan;
       info_out[fit] = -4;
       if (nfev_out) nfev_out[fit] = 0;
+      if (step_out) step_out[fit] = nan;
       return;
     }
     double mn = yd[0], mx = yd[0];
@@ -281,6 +283,7 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
   residuals(x, fvec);
   double fnorm = hill_enorm_vec(m, fvec, (int64_t)S);
   double par = 0.0, delta = 0.0, xnorm = 0.0;
+  double last_step = 0.0;                                   // |last accepted step| / |x| in the scaled variables (step_out)
   bool done = false;
   while (!done) {
     // ---- fdjac2: forward differences
@@ -426,6 +429,7 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
         for (int i = 0; i < m; ++i) fvec[i * S] = wa4[i * S];
         xnorm = hill_enorm(n, wa2, 1);
         fnorm = fnorm1;
+        last_step = pnorm / xnorm;
         ++iter;
       }
       const bool small_red = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
@@ -444,6 +448,7 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
   for (int j = 0; j < n; ++j) out[j] = x[j];
   info_out[fit] = info;
   if (nfev_out) nfev_out[fit] = nfev;
+  if (step_out) step_out[fit] = last_step;
 }
 
 // ---- the same fit by a GROUP of eight lanes -----------------------------------------------------------------------------
@@ -464,7 +469,7 @@ __host__ __device__ constexpr size_t hill_group_doubles(int mmax) { return 8 * (
 __global__ void __launch_bounds__(PL_WAVE)
 hill_fit_group_kernel(const double* __restrict__ xs, const double* __restrict__ ys, const int32_t* __restrict__ lens, int64_t nfits,
                       int mmax, int64_t stride, double* __restrict__ params, int32_t* __restrict__ info_out,
-                      int32_t* __restrict__ nfev_out) {
+                      int32_t* __restrict__ nfev_out, double* __restrict__ step_out) {
   constexpr int n = kHillN, G = kHillGroup;
   extern __shared__ __attribute__((aligned(16))) unsigned char hill_lds[];
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
@@ -530,7 +535,7 @@ hill_fit_group_kernel(const double* __restrict__ xs, const double* __restrict__ 
   double x[n], xnew[n], diag[n], qtf[n], wa1[n], wa2[n], wa3[n], r[n * n], sdiag[n];
   int ipvt[n];
   int info = 0, nfev = 0, iter = 1;
-  double fnorm = 0.0, par = 0.0, delta = 0.0, xnorm = 0.0, gnorm = 0.0, pnorm = 0.0;
+  double fnorm = 0.0, par = 0.0, delta = 0.0, xnorm = 0.0, gnorm = 0.0, pnorm = 0.0, last_step = 0.0;
   if (leader && phase != kHillDone) {
     double mn = yt[0], mx = yt[0];
     for (int i = 1; i < m; ++i) { mn = yt[i] < mn ? yt[i] : mn; mx = yt[i] > mx ? yt[i] : mx; }
@@ -566,6 +571,7 @@ hill_fit_group_kernel(const double* __restrict__ xs, const double* __restrict__ 
     for (int j = 0; j < n; ++j) params[fit * n + j] = x[j];
     info_out[fit] = info;
     if (nfev_out) nfev_out[fit] = nfev;
+    if (step_out) step_out[fit] = last_step;
   };
 
   while (__ballot(phase != kHillDone) != 0ull) {
@@ -717,6 +723,7 @@ hill_fit_group_kernel(const double* __restrict__ xs, const double* __restrict__ 
           for (int i = 0; i < m; ++i) fvec[i] = wa4[i];
           xnorm = hill_enorm(n, wa2, 1);
           fnorm = fnorm1;
+          last_step = pnorm / xnorm;
           ++iter;
         }
         const bool small_red = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
@@ -903,8 +910,8 @@ extern "C" int pl_index_to_original(const double* d_x_indices, int s, const doub
   return pl_check_launch("pl_index_to_original");
 }
 
-extern "C" int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
-                           double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, void* stream) {
+static int hill_fit_impl(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
+                         double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, double* d_last_step, void* stream) {
   PL_REQUIRE(d_x && d_y && d_work && d_params && d_info, "null pointer");
   PL_REQUIRE(n >= 0 && mmax >= 4 && mmax <= 1024 && stride >= mmax, "bad shape (4 .. 1024 samples per fit)");
   if (n == 0) return PL_OK;
@@ -916,13 +923,28 @@ extern "C" int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* 
     const int64_t blocks = pl_cdiv(n, PL_WAVE / kHillGroup);
     PL_REQUIRE(blocks <= 0x7fffffffLL, "batch too large");
     hipLaunchKernelGGL(hill_fit_group_kernel, dim3((unsigned)blocks), dim3(PL_WAVE), lds, (hipStream_t)stream, d_x, d_y, d_lens, n,
-                       mmax, stride, d_params, d_info, d_nfev);
+                       mmax, stride, d_params, d_info, d_nfev, d_last_step);
     return pl_check_launch("pl_hill_fit");
   }
   PL_REQUIRE(pl_cdiv(n, kHillThreads) <= 0x7fffffffLL, "batch too large");
   hipLaunchKernelGGL(hill_fit_kernel, dim3((unsigned)pl_cdiv(n, kHillThreads)), dim3(kHillThreads), 0, (hipStream_t)stream, d_x, d_y,
-                     d_lens, n, mmax, stride, d_work, d_params, d_info, d_nfev);
+                     d_lens, n, mmax, stride, d_work, d_params, d_info, d_nfev, d_last_step);
   return pl_check_launch("pl_hill_fit");
+}
+
+extern "C" int pl_hill_fit(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
+                           double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, void* stream) {
+  return hill_fit_impl(d_x, d_y, d_lens, n, mmax, stride, d_work, d_params, d_info, d_nfev, nullptr, stream);
+}
+
+/* pl_hill_fit + d_last_step float64 [n]: the length of the LAST ACCEPTED Levenberg-Marquardt step relative to the parameter
+ * vector (both in MINPACK's scaled variables).  MINPACK stops on the REDUCTION of the sum of squares (ftol); in a flat valley
+ * that happens while the parameters are still moving, and where exactly it happens depends on the last bit of pow(): a fit
+ * whose last step is above ~1e-6 reports a point that scipy reproduces to 1e-3, not 1e-5 (NaN: no fit was attempted). */
+extern "C" int pl_hill_fit_ex(const double* d_x, const double* d_y, const int32_t* d_lens, int64_t n, int mmax, int64_t stride,
+                              double* d_work, double* d_params, int32_t* d_info, int32_t* d_nfev, double* d_last_step, void* stream) {
+  PL_REQUIRE(d_last_step, "null pointer");
+  return hill_fit_impl(d_x, d_y, d_lens, n, mmax, stride, d_work, d_params, d_info, d_nfev, d_last_step, stream);
 }
 
 extern "C" int pl_hill_windows(const double* d_x_indices, const double* d_values, int64_t n, int s, const int32_t* d_peak_count,

@@ -557,7 +557,7 @@ def peak_valley_regions(profiles: torch.Tensor, peak_kwargs: list, valley_kwargs
     return pc, ph, vc, vv, means
 
 
-def hill_fit(x: torch.Tensor, y: torch.Tensor, lens: torch.Tensor | None = None):
+def hill_fit(x: torch.Tensor, y: torch.Tensor, lens: torch.Tensor | None = None, last_step: bool = False):
     """``Hill.fit`` (pylinac/core/hill.py:18-30 = ``scipy.optimize.curve_fit`` with the reference's start values) for a batch
     of windows on the device (``pl_hill_fit``: MINPACK's Levenberg-Marquardt restated, one lane per fit).  ``x``, ``y``
     float64 [N, M]; ``lens`` int32 [N] for ragged windows.  -> (params float64 [N, 4] = a, b, c, d; info int32 [N]: 1-4 =
@@ -578,6 +578,12 @@ def hill_fit(x: torch.Tensor, y: torch.Tensor, lens: torch.Tensor | None = None)
     nfev = torch.empty(n, dtype=torch.int32, device=dev)
     if lens is not None:
         lens = lens.to(device=dev, dtype=torch.int32).contiguous()
+    if last_step:           # + the relative length of the last accepted step (pl_hill_fit_ex): > ~1e-6 = stopped in a flat valley
+        step = torch.empty(n, dtype=torch.float64, device=dev)
+        check(_lib.load().pl_hill_fit_ex(xs.data_ptr(), ys.data_ptr(), 0 if lens is None else lens.data_ptr(), n, m, xs.stride(0),
+                                         work.data_ptr(), params.data_ptr(), info.data_ptr(), nfev.data_ptr(), step.data_ptr(),
+                                         _stream()), "pl_hill_fit_ex")
+        return params, info, nfev, step
     check(_lib.load().pl_hill_fit(xs.data_ptr(), ys.data_ptr(), 0 if lens is None else lens.data_ptr(), n, m, xs.stride(0),
                                   work.data_ptr(), params.data_ptr(), info.data_ptr(), nfev.data_ptr(), _stream()), "pl_hill_fit")
     return params, info, nfev

@@ -16,8 +16,8 @@ for _ in range(3):
     pipe.run(fr)
 torch.cuda.synchronize()
 PY
-for c in WRITE_SIZE FETCH_SIZE; do
-  timeout 80 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- python /tmp/run_pipe.py > $OUT/$c.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout ${PMC_TIMEOUT:-200} rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- python /tmp/run_pipe.py > $OUT/$c.log 2>&1
   echo "$c rc=$?"
 done
 python3 - <<'PY' | tee gpurun_out/pmc_pipe/summary.txt

@@ -496,14 +496,18 @@ def check_hill_fit_vs_scipy(fit, n=60, seed=0):
     function evaluations for at least 90 % of the fits (the iteration follows MINPACK's path; pow()'s last bit can move a
     stopping test) and the inflection point to 1e-5 for at least 95 % of them -- the rest are windows that miss a plateau: a
     flat valley in parameter space where the stopping point (not the quality of the fit) depends on the last bit of pow();
-    those are held to 2e-3.  The reference's real windows are held to 1e-5 one by one in check_hill_batch."""
+    those are held to 2e-3.  When `fit` also returns pl_hill_fit_ex's last-step length, EVERY fit whose last accepted step
+    is at most 1e-6 of the parameter vector ("settled", what HillEdgesBatch.settled reports) must meet 1e-5, and at least 90 %
+    of the converged fits must be settled.  The reference's real windows are held to 1e-5 one by one in check_hill_batch."""
     import warnings
 
     from scipy.optimize import leastsq
 
     xs, ys, lens = penumbra_windows(n, seed)
-    params, info, nfev = fit(xs, ys, lens)
-    same_nfev = converged = tight = 0
+    got = fit(xs, ys, lens)
+    params, info, nfev = got[:3]
+    step = got[3] if len(got) > 3 else None                 # pl_hill_fit_ex: the relative length of the last accepted step
+    same_nfev = converged = tight = settled = settled_tight = 0
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for i in range(n):
@@ -520,8 +524,15 @@ def check_hill_fit_vs_scipy(fit, n=60, seed=0):
             ssq_dev, ssq_ref = (resid(params[i]) ** 2).sum(), (resid(ref) ** 2).sum()
             assert abs(ssq_dev - ssq_ref) <= 1e-4 * ssq_ref, (i, ssq_dev, ssq_ref)
             assert np.isclose(infl(params[i]), infl(ref), rtol=2e-3), (i, params[i], ref)
-            tight += int(np.isclose(infl(params[i]), infl(ref), rtol=1e-5))
+            is_tight = bool(np.isclose(infl(params[i]), infl(ref), rtol=1e-5))
+            tight += int(is_tight)
+            if step is not None and step[i] <= 1.0e-6:       # HillEdgesBatch.settled: EVERY such fit is held to 1e-5
+                settled += 1
+                settled_tight += int(is_tight)
+                assert is_tight, (i, step[i], infl(params[i]), infl(ref), extra["nfev"], nfev[i])
     assert converged >= 0.9 * n and same_nfev >= 0.9 * converged and tight >= 0.95 * converged, (converged, same_nfev, tight)
+    if step is not None:                                      # the flag is not an excuse: at least nine fits in ten are settled
+        assert settled >= 0.9 * converged and settled_tight == settled, (converged, settled, settled_tight)
     return converged
 
 

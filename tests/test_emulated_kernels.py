@@ -499,7 +499,13 @@ def test_emulated_hill_fit_matches_scipy(emulated):
         p, info, nfev = ops.hill_fit(torch.from_numpy(xs).to(dev), torch.from_numpy(ys).to(dev), torch.from_numpy(lens).to(dev))
         return p.cpu().numpy(), info.cpu().numpy(), nfev.cpu().numpy()
 
-    assert checks.check_hill_fit_vs_scipy(fit, n=40) >= 36
+    def fit_ex(xs, ys, lens):
+        dev = torch.device("cuda:0")
+        p, info, nfev, step = ops.hill_fit(torch.from_numpy(xs).to(dev), torch.from_numpy(ys).to(dev), torch.from_numpy(lens).to(dev),
+                                           last_step=True)
+        return p.cpu().numpy(), info.cpu().numpy(), nfev.cpu().numpy(), step.cpu().numpy()
+
+    assert checks.check_hill_fit_vs_scipy(fit_ex, n=40) >= 36
     assert checks.check_hill_fit_kernels_agree(fit, n=24) >= 18
     assert checks.check_hill_fit_pathological(fit)
 
