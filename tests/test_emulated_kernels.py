@@ -1032,3 +1032,23 @@ def test_emulated_field_cax_tile_maxima(emulated):
     import next_row_checks as checks
 
     checks.check_field_cax_tile_maxima(emulated)
+
+
+def test_emulated_pack_columns(emulated):
+    """pl_pack_columns: float64 / int32 columns, strided sources with offsets and additive constants -> one float64 table."""
+    import torch
+
+    from pylinac_amd import ops
+
+    n = 37
+    a = torch.arange(n * 3, dtype=torch.float64, device=emulated).reshape(n, 3) * 0.5
+    b = torch.arange(n * 8 * 2, dtype=torch.float64, device=emulated).reshape(n, 8, 2) - 7.25
+    c = torch.arange(n, dtype=torch.int32, device=emulated) * -3
+    got = ops.pack_columns([(a, 1, 0.0), (a, 0, 2.5), (b, 0, 10.0), (b, 1, -1.0), c, (c, 0, 0.5)], n).cpu().numpy()
+    want = np.stack([a[:, 1].numpy(), a[:, 0].numpy() + 2.5, b[:, 0, 0].numpy() + 10.0, b[:, 0, 1].numpy() - 1.0,
+                     c.numpy().astype(float), c.numpy() + 0.5], axis=1)
+    assert np.array_equal(got, want)
+    with pytest.raises(TypeError):
+        ops.pack_columns([torch.zeros(n, dtype=torch.float32, device=emulated)], n)
+    with pytest.raises(ValueError):
+        ops.pack_columns([a] * 17, n)
