@@ -130,6 +130,13 @@ int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_h
  * look at as one unit (frames below 2^18 pixels, unaligned frames, a ragged tail): "look inside".  pl_field_cax_tiles uses
  * it to visit only the tiles that can hold a pixel above the field threshold (pylinac/winston_lutz.py:775-779). */
 int pl_hist16_tiles(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, uint16_t* d_tile_max, void* stream);
+/* pl_hist16_tiles and pl_edge_minmax (min / max over the four edge_window-wide edge strips, int32 [n] each) in one launch:
+ * everything the per-image half of WLBaseImage.analyze asks of a frame before its scalar decisions
+ * (pylinac/winston_lutz.py:709-712, 775, 1109-1133).  d_ranks / d_order_stats (both or neither; as pl_order_stats_from_hist):
+ * the order statistics of the np.percentile calls are selected in the same launch from the histogram while it is still in
+ * LDS -- d_hist is then SCRATCH (it only receives the bins outside the kernel's LDS windows). */
+int pl_hist16_wl(const void* in, int dtype, int64_t n, int h, int w, uint32_t* d_hist, uint16_t* d_tile_max, int edge_window,
+                 int32_t* d_edge_min, int32_t* d_edge_max, const int64_t* d_ranks, int nranks, int32_t* d_order_stats, void* stream);
 /* skimage.filters.threshold_otsu on an integer image (pylinac/ct.py:3323,3338; acr.py:1409):
  * one bin per integer in [min,max], float64 class statistics, first argmax.  Outputs int32[n]. */
 int pl_otsu_from_hist(const uint32_t* d_hist, int dtype, int64_t n, int32_t* d_thr,

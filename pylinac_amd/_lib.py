@@ -65,6 +65,7 @@ SIGNATURES = {
     "pl_as_binary": ([_p, _p, _i, _l, _l, _p, _i, _p], C.c_int),
     "pl_hist16": ([_p, _i, _l, _l, _p, _p], C.c_int),
     "pl_hist16_tiles": ([_p, _i, _l, _l, _p, _p, _p], C.c_int),
+    "pl_hist16_wl": ([_p, _i, _l, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p], C.c_int),
     "pl_otsu_from_hist": ([_p, _i, _l, _p, _p, _p, _p], C.c_int),
     "pl_otsu16": ([_p, _i, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_median3_otsu16": ([_p, _p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),

@@ -517,19 +517,30 @@ cax_reduce_tiles_kernel(const T* __restrict__ in, int h, int w, const double* __
     }
     __syncthreads();                                                  // (the list is rebuilt in the next round)
   }
+  // the frame's accumulator row is WRITTEN by this workgroup (its only one): no initialisation launch, no global atomics
   auto add = [](unsigned long long a, unsigned long long b) { return a + b; };
   auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
   auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
-  cnt = pl_wave_reduce(cnt, add);
-  if (cnt == 0) return;                                               // wave-uniform
-  sr = pl_wave_reduce(sr, add); sc = pl_wave_reduce(sc, add);
+  __shared__ unsigned long long s_sum[kThreads / 64][3];
+  __shared__ unsigned s_box[kThreads / 64][4];
+  cnt = pl_wave_reduce(cnt, add); sr = pl_wave_reduce(sr, add); sc = pl_wave_reduce(sc, add);
   rmin = pl_wave_reduce(rmin, mn); rmax = pl_wave_reduce(rmax, mx);
   cmin = pl_wave_reduce(cmin, mn); cmax = pl_wave_reduce(cmax, mx);
   if (lane == 0) {
-    unsigned long long* a = acc + frame * 8;
-    atomicAdd(&a[0], cnt); atomicAdd(&a[1], sr); atomicAdd(&a[2], sc);
-    atomicMin(&a[3], (unsigned long long)rmin); atomicMax(&a[4], (unsigned long long)rmax);
-    atomicMin(&a[5], (unsigned long long)cmin); atomicMax(&a[6], (unsigned long long)cmax);
+    s_sum[wv][0] = cnt; s_sum[wv][1] = sr; s_sum[wv][2] = sc;
+    s_box[wv][0] = rmin; s_box[wv][1] = rmax; s_box[wv][2] = cmin; s_box[wv][3] = cmax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kThreads / 64; ++k) {
+      cnt += s_sum[k][0]; sr += s_sum[k][1]; sc += s_sum[k][2];
+      rmin = mn(rmin, s_box[k][0]); rmax = mx(rmax, s_box[k][1]); cmin = mn(cmin, s_box[k][2]); cmax = mx(cmax, s_box[k][3]);
+    }
+    unsigned long long* a = acc + frame * 8;                          // cax_init_kernel's values where nothing was found
+    a[0] = cnt; a[1] = sr; a[2] = sc;
+    a[3] = cnt ? (unsigned long long)rmin : ~0ull; a[4] = cnt ? (unsigned long long)rmax : 0ull;
+    a[5] = cnt ? (unsigned long long)cmin : ~0ull; a[6] = cnt ? (unsigned long long)cmax : 0ull;
+    a[7] = 0;
   }
 }
 
@@ -637,7 +648,9 @@ static int field_cax_impl(const void* in, int dtype, int64_t n, int h, int w, co
   const int bpf = (int)pl_cdiv((int64_t)h * w, 65536);
   PL_REQUIRE(n * bpf <= 0x7fffffffLL, "batch too large");
   static std::atomic<bool> attr{false};
-  hipLaunchKernelGGL(cax_init_kernel, dim3((unsigned)pl_cdiv(n, kThreads)), dim3(kThreads), 0, st, d_acc, n);
+  const bool tiles_ok = d_tile_max && (dtype == PL_U16 || dtype == PL_I16) && (((int64_t)h * w) & 511) == 0 && (w & 7) == 0 &&
+                        (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+  if (!tiles_ok) hipLaunchKernelGGL(cax_init_kernel, dim3((unsigned)pl_cdiv(n, kThreads)), dim3(kThreads), 0, st, d_acc, n);
   PL_DISPATCH_DTYPE(dtype, T, {
     if (!attr) {
       // every instantiation that can be launched gets the opt-in (cheap; done once per process)
@@ -652,7 +665,7 @@ static int field_cax_impl(const void* in, int dtype, int64_t n, int h, int w, co
     }
     bool tiled = false;
     if constexpr (sizeof(T) == 2) {
-      if (d_tile_max && (((int64_t)h * w) & 511) == 0 && (w & 7) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+      if (tiles_ok) {
         hipLaunchKernelGGL(cax_reduce_tiles_kernel<T>, dim3((unsigned)n), dim3(kThreads), 0, st, (const T*)in, h, w, d_sub, d_div,
                            d_thr, d_tile_max, d_acc);
         tiled = true;

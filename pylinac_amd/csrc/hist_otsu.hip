@@ -811,7 +811,9 @@ constexpr size_t kTwLds = kTwScratchAt + sizeof(TwScratch);
 
 __global__ void __launch_bounds__(kHistThreads)
 hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, unsigned flip, uint32_t* __restrict__ hist,
-                         unsigned short* __restrict__ tile_max /* optional [n][ceil(count / 512)] */) {
+                         unsigned short* __restrict__ tile_max /* optional [n][ceil(count / 512)] */, int eh, int ew, int ews,
+                         int32_t* __restrict__ edge_min, int32_t* __restrict__ edge_max /* optional: pl_hist16_wl */,
+                         const int64_t* __restrict__ ranks, int nranks, int32_t* __restrict__ stats /* optional: pl_hist16_wl */) {
   extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // 2 * kTwBins, then TwScratch
   TwScratch& scr = *reinterpret_cast<TwScratch*>(reinterpret_cast<unsigned char*>(bins) + kTwScratchAt);
   const int64_t frame = blockIdx.x;
@@ -823,6 +825,50 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   const uint4* vsrc = reinterpret_cast<const uint4*>(src);
 
   for (int i = threadIdx.x; i < 2 * kTwBins; i += kHistThreads) bins[i] = 0;
+  if (edge_min) {
+    // min / max over the four `ews`-wide edge strips of the eh x ew frame (WLBaseImage._clean_edges' edge test,
+    // pylinac/winston_lutz.py:1109-1133; pl_edge_minmax's loops): a few scattered loads per thread, all issued before the
+    // first is looked at -- as a kernel of its own (one 256-thread workgroup per frame walking them sixteen deep) this was
+    // 30 us per 512 frames of pure latency (r05z)
+    int mn = 0x7fffffff, mx = -0x7fffffff - 1;
+    auto value = [&](unsigned short raw) { return flip ? (int)(short)raw : (int)raw; };
+    auto see = [&](int v) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; };
+    const int band = ews < eh ? ews : eh, cb = ews < ew ? ews : ew;
+    constexpr int E = 4;
+    for (int e0 = threadIdx.x; e0 < band * ew; e0 += E * kHistThreads) {        // top and bottom strips
+      unsigned short a[E], b[E];
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        const int e = e0 + k * kHistThreads < band * ew ? e0 + k * kHistThreads : e0;
+        a[k] = src[e];
+        b[k] = src[(int64_t)(eh - band) * ew + e];
+      }
+#pragma unroll
+      for (int k = 0; k < E; ++k) { see(value(a[k])); see(value(b[k])); }
+    }
+    for (int e0 = threadIdx.x; e0 < eh * cb; e0 += E * kHistThreads) {          // left and right strips
+      unsigned short a[E], b[E];
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        const int e = e0 + k * kHistThreads < eh * cb ? e0 + k * kHistThreads : e0;
+        const int r = e / cb, c = e - r * cb;
+        a[k] = src[(int64_t)r * ew + c];
+        b[k] = src[(int64_t)r * ew + (ew - cb) + c];
+      }
+#pragma unroll
+      for (int k = 0; k < E; ++k) { see(value(a[k])); see(value(b[k])); }
+    }
+    mn = pl_wave_reduce(mn, [](int a, int b) { return a < b ? a : b; });
+    mx = pl_wave_reduce(mx, [](int a, int b) { return a > b ? a : b; });
+    if (lane == 0) { scr.s_lo[wv] = mn; scr.s_hi[wv] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 0; k < kHistThreads / 64; ++k) { mn = scr.s_lo[k] < mn ? scr.s_lo[k] : mn; mx = scr.s_hi[k] > mx ? scr.s_hi[k] : mx; }
+      edge_min[frame] = mn;
+      edge_max[frame] = mx;
+    }
+    __syncthreads();                                                  // (the scratch is used again for the sample's extrema)
+  }
   // tile maxima (pl_hist16_tiles): tile t = pixels [512 t, 512 t + 512) = the 64 vectors ONE wave load of the main loop
   // fetches; its largest key (biased domain) lets a later pass skip every tile that cannot hold a pixel above its
   // threshold (pl_field_cax_tiles).  Tiles the main loop does not cover keep 0xffff ("look inside").
@@ -974,6 +1020,40 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally1(src[i]);
   flush();
   __syncthreads();
+  if (ranks) {
+    // pl_hist16_wl: the order statistics are taken HERE, from the windows while they are still in LDS (order_stats_kernel's
+    // selection: thread t owns bins [64 t, 64 t + 64), exclusive scan of the counts, the bin where the running count passes
+    // the rank) -- the windows are never stored and no second launch reads the 256 KiB table back (r05z: 55 us per 512
+    // frames).  Bins outside the windows come from the frame's table (zeros + what the global atomics added: device-coherent
+    // loads).  The lanes of a wave start at different bins of their 64 (the sum does not care): a common start is a 64-way
+    // bank conflict on every read.
+    __shared__ Pair wave_tot[kHistThreads / 64];
+    const int b0 = threadIdx.x * 64;
+    auto bin = [&](int b) -> unsigned {
+      const unsigned d0 = (unsigned)b - uw0, d1 = (unsigned)b - uw1;
+      if (d0 < (unsigned)kTwBins) return bins[d0];
+      if (d1 < (unsigned)kTwBins) return bins[kTwBins + d1];
+      return __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    Pair mine = {0, 0};
+    for (int k = 0; k < 64; ++k) mine.c += bin(b0 + ((k + lane) & 63));
+    Pair total;
+    const Pair ex = block_exclusive_scan(mine, &total, wave_tot);
+    const int bias = (int)flip;                                       // 0x8000 for int16 keys
+    for (int q = 0; q < nranks; ++q) {
+      long long r = ranks[q];
+      if (r < 0) r = 0;
+      if ((unsigned long long)r >= total.c) r = (long long)total.c - 1;
+      if ((unsigned long long)r >= ex.c && (unsigned long long)r < ex.c + mine.c) {
+        unsigned long long acc = ex.c;
+        for (int k = 0; k < 64; ++k) {
+          acc += bin(b0 + k);
+          if ((unsigned long long)r < acc) { stats[frame * nranks + q] = b0 + k - bias; break; }
+        }
+      }
+    }
+    return;
+  }
   // the windows go out with plain stores: no global atomic ever touched a bin inside a window
   for (int i = threadIdx.x; i < kTwBins; i += kHistThreads) {
     row[w0 + i] = bins[i];
@@ -983,20 +1063,40 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
 
 }  // namespace
 
-static int hist16_impl(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, uint16_t* d_tile_max, void* stream);
+struct HistEdges { int h, w, window; int32_t *d_min, *d_max; const int64_t* d_ranks; int nranks; int32_t* d_stats; };
+static int hist16_impl(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, uint16_t* d_tile_max,
+                       HistEdges edges, void* stream);
 
 extern "C" int pl_hist16(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, void* stream) {
-  return hist16_impl(in, dtype, n, count, d_hist, nullptr, stream);
+  return hist16_impl(in, dtype, n, count, d_hist, nullptr, HistEdges{0, 0, 0, nullptr, nullptr, nullptr, 0, nullptr}, stream);
 }
 
 extern "C" int pl_hist16_tiles(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, uint16_t* d_tile_max,
                                void* stream) {
   PL_REQUIRE(d_tile_max, "null pointer");
-  return hist16_impl(in, dtype, n, count, d_hist, d_tile_max, stream);
+  return hist16_impl(in, dtype, n, count, d_hist, d_tile_max, HistEdges{0, 0, 0, nullptr, nullptr, nullptr, 0, nullptr}, stream);
+}
+
+extern "C" int pl_edge_minmax(const void* in, int dtype, int64_t n, int h, int w, int window, int32_t* d_min, int32_t* d_max,
+                              void* stream);
+
+/* pl_hist16_tiles + pl_edge_minmax in the one launch (what the per-image half of WLBaseImage.analyze asks of a frame before
+ * its decisions: pylinac/winston_lutz.py:709-712, 775, 1109-1133) */
+extern "C" int pl_order_stats_from_hist(const uint32_t* d_hist, int dtype, int64_t n, const int64_t* d_ranks, int nranks,
+                                        int32_t* d_out, void* stream);
+
+extern "C" int pl_hist16_wl(const void* in, int dtype, int64_t n, int h, int w, uint32_t* d_hist, uint16_t* d_tile_max,
+                            int edge_window, int32_t* d_edge_min, int32_t* d_edge_max, const int64_t* d_ranks, int nranks,
+                            int32_t* d_order_stats, void* stream) {
+  PL_REQUIRE(d_tile_max && d_edge_min && d_edge_max, "null pointer");
+  PL_REQUIRE(h > 0 && w > 0 && edge_window > 0, "bad shape");
+  PL_REQUIRE((d_ranks == nullptr) == (d_order_stats == nullptr) && (!d_ranks || nranks > 0), "ranks and their output go together");
+  return hist16_impl(in, dtype, n, (int64_t)h * w, d_hist, d_tile_max,
+                     HistEdges{h, w, edge_window, d_edge_min, d_edge_max, d_ranks, nranks, d_order_stats}, stream);
 }
 
 static int hist16_impl(const void* in, int dtype, int64_t n, int64_t count, uint32_t* d_hist, uint16_t* d_tile_max,
-                       void* stream) {
+                       HistEdges edges, void* stream) {
   PL_REQUIRE(in && d_hist, "null pointer");
   PL_REQUIRE(n >= 0 && count > 0, "bad shape");
   PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
@@ -1019,8 +1119,13 @@ static int hist16_impl(const void* in, int dtype, int64_t n, int64_t count, uint
   }
   if (two_window == 1 && count >= 262144) {
     hipLaunchKernelGGL(hist16_two_window_kernel, dim3((unsigned)n), dim3(kHistThreads), kTwLds, st, src, count, flip, d_hist,
-                       d_tile_max);
+                       d_tile_max, edges.h, edges.w, edges.window, edges.d_min, edges.d_max, edges.d_ranks, edges.nranks, edges.d_stats);
     return pl_check_launch("pl_hist16");
+  }
+  // (the multi-part kernels know nothing of edges: the stand-alone kernel)
+  if (edges.d_min) {
+    const int rc0 = pl_edge_minmax(in, dtype, n, edges.h, edges.w, edges.window, edges.d_min, edges.d_max, stream);
+    if (rc0 != PL_OK) return rc0;
   }
   // (the multi-part kernels keep no tile maxima: every tile says "look inside")
   if (d_tile_max && hipMemsetAsync(d_tile_max, 0xff, (size_t)n * (size_t)((count + 511) / 512) * sizeof(uint16_t), st) != hipSuccess) {
@@ -1030,6 +1135,7 @@ static int hist16_impl(const void* in, int dtype, int64_t n, int64_t count, uint
   int rc = launch_hist16<2, false>(src, n, count, flip, d_hist, st);
   if (rc != 0) rc = launch_hist16<4, false>(src, n, count, flip, d_hist, st);   // 64 KiB LDS needs no opt-in
   PL_REQUIRE(rc == 0, "launch configuration rejected");
+  if (edges.d_ranks) return pl_order_stats_from_hist(d_hist, dtype, n, edges.d_ranks, edges.nranks, edges.d_stats, stream);
   return pl_check_launch("pl_hist16");
 }
 

@@ -106,7 +106,7 @@ __device__ __forceinline__ void prominence_side(const double* xs, int pk, int m,
   const int lane = threadIdx.x & (PL_WAVE - 1);
   const double xp = xs[pk];
   double mn = xp;
-  int step = 0;
+  int step = 0, rounds = 0;
   for (int t0 = 0;; t0 += PL_WAVE) {
     const int t = t0 + lane;
     const int j = pk + DIR * t;
@@ -116,11 +116,20 @@ __device__ __forceinline__ void prominence_side(const double* xs, int pk, int m,
     const unsigned long long b = __ballot(fail);
     const int first = b ? __builtin_ctzll(b) : PL_WAVE;
     if (lane < first && v < mn) { mn = v; step = t; }
+    ++rounds;
     if (b) break;
   }
-  // the smallest value and, among equal values, the earliest step: two idempotent reductions on the DPP path
+  // the smallest value and, among equal values, the earliest step
   const double best = pl_wave_reduce_idem(mn, [](double a, double b) { return a < b ? a : b; });
-  step = pl_wave_reduce_idem(mn == best ? step : 0x7fffffff, [](int a, int b) { return a < b ? a : b; });
+  if (rounds == 1) {
+    // one round (the walk ended within 64 samples -- every picket-fence window): a lane's step is its own index, so the
+    // earliest step is the lowest lane that holds the minimum -- a ballot instead of a second reduction; a minimum equal to the
+    // peak itself was never "updated": step 0
+    const unsigned long long at = __ballot(mn == best);
+    step = best == xp ? 0 : __builtin_ctzll(at);
+  } else {
+    step = pl_wave_reduce_idem(mn == best ? step : 0x7fffffff, [](int a, int b) { return a < b ? a : b; });
+  }
   mn = best;
   out_min = mn;
   out_base = pk + DIR * step;

@@ -250,11 +250,14 @@ def as_binary(frames: torch.Tensor, thr) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------- histogram / Otsu / percentile
-def histogram16(frames: torch.Tensor, out=None, tiles: bool = False):
+def histogram16(frames: torch.Tensor, out=None, tiles: bool = False, edge_window: int | None = None, ranks=None):
     """Exact per-frame histogram of a 16-bit integer batch: uint32 [N, 65536] (stored in an int32
     tensor; bin b = value b for uint16, value b-32768 for int16).  ``tiles=True`` -> (histogram, tile maxima): the same pass
     also leaves the largest key of every 512-pixel tile of every frame (uint16 [N, ceil(pixels / 512)], stored in an int16
-    tensor; 0xffff = "look inside"), which :func:`field_cax` uses to skip the tiles that cannot hold foreground."""
+    tensor; 0xffff = "look inside"), which :func:`field_cax` uses to skip the tiles that cannot hold foreground;
+    ``edge_window=k`` (with ``tiles``) -> (histogram, tile maxima, edge min, edge max): :func:`edge_minmax` in the same launch;
+    with ``ranks`` too -> (None, tile maxima, edge min, edge max, order statistics int32 [N, len(ranks)]): :func:`order_stats`
+    selected inside the histogram launch -- the table itself is scratch then."""
     x = _frames(frames)
     if x.dtype not in (torch.uint16, torch.int16):
         raise TypeError("histogram16 needs uint16 or int16 frames")
@@ -264,6 +267,19 @@ def histogram16(frames: torch.Tensor, out=None, tiles: bool = False):
         check(_lib.load().pl_hist16(x.data_ptr(), _dt(x), n, x[0].numel(), out.data_ptr(), _stream()), "pl_hist16")
         return out
     tmax = torch.empty((n, (x[0].numel() + 511) // 512), dtype=torch.int16, device=x.device)
+    if edge_window is not None:       # + edge_minmax(frames, edge_window) in the same launch -> (hist, tiles, edge min, edge max)
+        emin = torch.empty(n, dtype=torch.int32, device=x.device)
+        emax = torch.empty_like(emin)
+        if ranks is not None:         # + order_stats(frames, ranks) from the same launch; the histogram table is then scratch
+            r = _device_ranks(ranks, x.device)
+            st = torch.empty((n, r.numel()), dtype=torch.int32, device=x.device)
+            check(_lib.load().pl_hist16_wl(x.data_ptr(), _dt(x), n, x.shape[1], x.shape[2], out.data_ptr(), tmax.data_ptr(),
+                                           int(edge_window), emin.data_ptr(), emax.data_ptr(), r.data_ptr(), r.numel(), st.data_ptr(),
+                                           _stream()), "pl_hist16_wl")
+            return None, tmax, emin, emax, st
+        check(_lib.load().pl_hist16_wl(x.data_ptr(), _dt(x), n, x.shape[1], x.shape[2], out.data_ptr(), tmax.data_ptr(), int(edge_window),
+                                       emin.data_ptr(), emax.data_ptr(), 0, 0, 0, _stream()), "pl_hist16_wl")
+        return out, tmax, emin, emax
     check(_lib.load().pl_hist16_tiles(x.data_ptr(), _dt(x), n, x[0].numel(), out.data_ptr(), tmax.data_ptr(), _stream()),
           "pl_hist16_tiles")
     return out, tmax

@@ -118,10 +118,16 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0
     # the histogram pass also notes the largest value of every 512-pixel tile: the field CAX then reads only the tiles that
     # can hold a pixel above the field threshold instead of the whole batch a second time (``tile_maxima=False``: the full
     # pass; same results -- an A/B knob)
-    hist, tmax = ops.histogram16(x, tiles=True) if tile_maxima else (ops.histogram16(x), None)
-    st = ops.order_stats(x, np.concatenate([[0, cnt - 1], lo, hi]), hist=hist)          # int32 [N, 16], on the device
-    del hist
-    emin, emax = ops.edge_minmax(x, 2)
+    # ... and the min / max of the 2-pixel edge strips (``_clean_edges``' test) come out of the same launch
+    # and so do the order statistics of every percentile the sequence asks for (selected from the histogram while it is in LDS)
+    ranks = np.concatenate([[0, cnt - 1], lo, hi])
+    if tile_maxima:
+        _, tmax, emin, emax, st = ops.histogram16(x, tiles=True, edge_window=2, ranks=ranks)     # st: int32 [N, 16], on the device
+    else:
+        hist, tmax = ops.histogram16(x), None
+        emin, emax = ops.edge_minmax(x, 2)
+        st = ops.order_stats(x, ranks, hist=hist)
+        del hist
     dec = ops.wl_decisions(st, emin, emax, frac)
     cen, cax_status = ops.field_cax(x, dec["vmin"], dec["gmax"], dec["thr"], defer=True, tile_max=tmax)   # (row, col, count)
     bb = features.bb_centroids_batch(x, dpmm, bb_diameter_mm, low_density=low_density, vmin=dec["vmin"], vmax=dec["vmax"],

@@ -1930,6 +1930,21 @@ def check_field_cax_tile_maxima(dev, big=False):
         hist0 = ops.histogram16(x)
         hist1, tmax = ops.histogram16(x, tiles=True)
         assert torch.equal(hist0, hist1)
+        for win in (1, 2, 5):                                  # pl_hist16_wl: the edge strips' extrema from the same launch
+            h2, t2, emin, emax = ops.histogram16(x, tiles=True, edge_window=win)
+            e0, e1 = ops.edge_minmax(x, win)
+            assert torch.equal(h2, hist0) and torch.equal(t2, tmax) and torch.equal(emin, e0) and torch.equal(emax, e1), (str(dtype), win)
+            a = arr.astype(np.int64)
+            strips = [np.concatenate([a[k, :win].ravel(), a[k, -win:].ravel(), a[k, :, :win].ravel(), a[k, :, -win:].ravel()]) for k in range(4)]
+            assert emin.cpu().tolist() == [int(v.min()) for v in strips] and emax.cpu().tolist() == [int(v.max()) for v in strips]
+        # ... and the order statistics selected inside the same launch == pl_order_stats_from_hist == numpy's sort
+        cnt = arr[0].size
+        ranks = np.array([0, cnt - 1, 1, cnt // 2, cnt // 2 + 1, int(0.999 * cnt), 12345, cnt - 2, 7 * cnt // 10, -5, cnt + 9], dtype=np.int64)
+        _, t3, emin3, emax3, st = ops.histogram16(x, tiles=True, edge_window=2, ranks=ranks)
+        want = ops.order_stats(x, ranks, hist=hist0)
+        assert torch.equal(st, want) and torch.equal(t3, tmax)
+        srt = np.sort(arr.reshape(4, -1).astype(np.int64), axis=1)
+        assert np.array_equal(st.cpu().numpy(), srt[:, np.clip(ranks, 0, cnt - 1)])
         keys = arr.astype(np.int64) + (32768 if dtype == torch.int16 else 0)
         true_max = keys.reshape(4, -1, 512).max(axis=2)
         got = tmax.cpu().numpy().astype(np.int64) & 0xFFFF
@@ -1955,6 +1970,16 @@ def check_field_cax_tile_maxima(dev, big=False):
     odd[:, 100:180, 90:200] += 30000
     x = torch.from_numpy(odd).to(dev)
     _, tmax = ops.histogram16(x, tiles=True)
+    _, _, emin, emax = ops.histogram16(x, tiles=True, edge_window=2)
+    e0, e1 = ops.edge_minmax(x, 2)
+    assert torch.equal(emin, e0) and torch.equal(emax, e1)
+    small = torch.from_numpy(odd[:, :100, :120].copy()).to(dev)            # below 2^18 pixels: the multi-part histogram + the stand-alone edge kernel
+    _, ts, emin, emax = ops.histogram16(small, tiles=True, edge_window=2)
+    e0, e1 = ops.edge_minmax(small, 2)
+    assert torch.equal(emin, e0) and torch.equal(emax, e1) and bool(((ts.to(torch.int32) & 0xFFFF) == 0xFFFF).all())
+    rk = np.array([0, 11999, 6000, 3], dtype=np.int64)
+    st = ops.histogram16(small, tiles=True, edge_window=2, ranks=rk)[4]    # ... + the stand-alone order-statistics kernel
+    assert np.array_equal(st.cpu().numpy(), np.sort(odd[:, :100, :120].reshape(2, -1).astype(np.int64), axis=1)[:, rk])
     vmin = torch.from_numpy(odd.reshape(2, -1).min(axis=1).astype(np.float64)).to(dev)
     rng_ = torch.from_numpy((odd.reshape(2, -1).max(axis=1) - odd.reshape(2, -1).min(axis=1)).astype(np.float64)).to(dev)
     t = torch.full((2,), 0.5, dtype=torch.float64, device=dev)
