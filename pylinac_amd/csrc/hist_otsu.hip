@@ -1029,27 +1029,91 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
     // bank conflict on every read.
     __shared__ Pair wave_tot[kHistThreads / 64];
     const int b0 = threadIdx.x * 64;
-    auto bin = [&](int b) -> unsigned {
-      const unsigned d0 = (unsigned)b - uw0, d1 = (unsigned)b - uw1;
-      if (d0 < (unsigned)kTwBins) return bins[d0];
-      if (d1 < (unsigned)kTwBins) return bins[kTwBins + d1];
-      return __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned d0 = (unsigned)b0 - uw0, d1 = (unsigned)b0 - uw1;
+    const bool all0 = d0 < (unsigned)kTwBins && d0 + 63u < (unsigned)kTwBins;
+    const bool all1 = d1 < (unsigned)kTwBins && d1 + 63u < (unsigned)kTwBins;
+    // the table's bins were written by this workgroup's own stores and L2 atomics (complete at the barrier above); the
+    // invalidate makes the plain vector loads below see L2, not a line of this CU's L1
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // half of a thread's 64 counts, in bin order, in registers.  Threads whose bins lie in a window read LDS; the others take
+    // the table's bytes with eight loads issued together (r05f walked them one dependent load at a time, and the bins outside
+    // the windows are 40 % of the table: +140 us per 512 frames) and patch in whatever part of a window they straddle
+    auto counts = [&](int half, unsigned (&val)[32]) {
+      if (all0 || all1) {
+        const unsigned* p = (all0 ? bins + d0 : bins + kTwBins + d1) + 32 * half;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) val[k] = p[k];
+      } else {
+        const uint4* g = reinterpret_cast<const uint4*>(row + b0 + 32 * half);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint4 q = g[j];
+          val[4 * j] = q.x; val[4 * j + 1] = q.y; val[4 * j + 2] = q.z; val[4 * j + 3] = q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const unsigned e0 = d0 + (unsigned)(32 * half + k), e1 = d1 + (unsigned)(32 * half + k);
+          if (e0 < (unsigned)kTwBins) val[k] = bins[e0];
+          else if (e1 < (unsigned)kTwBins) val[k] = bins[kTwBins + e1];
+        }
+      }
     };
-    Pair mine = {0, 0};
-    for (int k = 0; k < 64; ++k) mine.c += bin(b0 + ((k + lane) & 63));
+    unsigned both = 0;
+    if (all0 || all1) {
+      // the sum does not care about the order: lanes start at different bins of their 64 (a common start is a 64-way bank
+      // conflict on every read)
+      const unsigned* p = all0 ? bins + d0 : bins + kTwBins + d1;
+      for (int k = 0; k < 64; ++k) both += p[(k + lane) & 63];
+    } else {
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        unsigned val[32];
+        counts(half, val);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) both += val[k];
+      }
+    }
+    Pair mine = {both, 0};
     Pair total;
     const Pair ex = block_exclusive_scan(mine, &total, wave_tot);
     const int bias = (int)flip;                                       // 0x8000 for int16 keys
-    for (int q = 0; q < nranks; ++q) {
+    auto clamped = [&](int q) {
       long long r = ranks[q];
       if (r < 0) r = 0;
       if ((unsigned long long)r >= total.c) r = (long long)total.c - 1;
-      if ((unsigned long long)r >= ex.c && (unsigned long long)r < ex.c + mine.c) {
-        unsigned long long acc = ex.c;
-        for (int k = 0; k < 64; ++k) {
-          acc += bin(b0 + k);
-          if ((unsigned long long)r < acc) { stats[frame * nranks + q] = b0 + k - bias; break; }
+      return (unsigned long long)r;
+    };
+    bool owner = false;
+    for (int q = 0; q < nranks; ++q) {
+      const unsigned long long r = clamped(q);
+      owner = owner || (r >= ex.c && r < ex.c + mine.c);
+    }
+    if (owner) {                                                      // a handful of threads of the workgroup
+      unsigned before = 0;                                            // the counts of this thread's bins in front of the half
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        unsigned val[32];
+        counts(half, val);
+        unsigned here = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) here += val[k];
+        const unsigned long long lo = ex.c + before, hi = lo + here;
+        for (int q = 0; q < nranks; ++q) {
+          const unsigned long long r = clamped(q);
+          if (r >= lo && r < hi) {
+            unsigned acc = 0;                                         // < 2^32: bins of one frame
+            const unsigned want = (unsigned)(r - lo);
+            int at = 31;
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+              acc += val[k];
+              if (!found && want < acc) { at = k; found = true; }
+            }
+            stats[frame * nranks + q] = b0 + 32 * half + at - bias;
+          }
         }
+        before += here;
       }
     }
     return;
@@ -1091,6 +1155,7 @@ extern "C" int pl_hist16_wl(const void* in, int dtype, int64_t n, int h, int w, 
   PL_REQUIRE(d_tile_max && d_edge_min && d_edge_max, "null pointer");
   PL_REQUIRE(h > 0 && w > 0 && edge_window > 0, "bad shape");
   PL_REQUIRE((d_ranks == nullptr) == (d_order_stats == nullptr) && (!d_ranks || nranks > 0), "ranks and their output go together");
+  PL_REQUIRE(!d_ranks || (reinterpret_cast<uintptr_t>(d_hist) & 15) == 0, "the table must be 16-byte aligned");
   return hist16_impl(in, dtype, n, (int64_t)h * w, d_hist, d_tile_max,
                      HistEdges{h, w, edge_window, d_edge_min, d_edge_max, d_ranks, nranks, d_order_stats}, stream);
 }

@@ -1918,7 +1918,9 @@ def check_field_cax_tile_maxima(dev, big=False):
 
     rng = np.random.default_rng(77)
     h, w = (1024, 1024) if big else (512, 512)              # >= 2^18 pixels: the two-window histogram kernel with tile maxima
-    base = rng.integers(900, 1100, (4, h, w)).astype(np.int64)
+    base = rng.integers(900, 1100, (5, h, w)).astype(np.int64)
+    base[4] = rng.integers(0, 65536, (h, w))                # every value of the range: most order statistics sit BETWEEN the
+    #                                                         histogram kernel's two LDS windows (the table's own bins)
     base[0, 200:260, 300:380] += 30000                      # a field
     base[1, 100:400, 50:450] += 20000
     base[1, 200:230, 200:260] -= 20000                      # ... with a hole
@@ -1935,7 +1937,7 @@ def check_field_cax_tile_maxima(dev, big=False):
             e0, e1 = ops.edge_minmax(x, win)
             assert torch.equal(h2, hist0) and torch.equal(t2, tmax) and torch.equal(emin, e0) and torch.equal(emax, e1), (str(dtype), win)
             a = arr.astype(np.int64)
-            strips = [np.concatenate([a[k, :win].ravel(), a[k, -win:].ravel(), a[k, :, :win].ravel(), a[k, :, -win:].ravel()]) for k in range(4)]
+            strips = [np.concatenate([a[k, :win].ravel(), a[k, -win:].ravel(), a[k, :, :win].ravel(), a[k, :, -win:].ravel()]) for k in range(len(a))]
             assert emin.cpu().tolist() == [int(v.min()) for v in strips] and emax.cpu().tolist() == [int(v.max()) for v in strips]
         # ... and the order statistics selected inside the same launch == pl_order_stats_from_hist == numpy's sort
         cnt = arr[0].size
@@ -1943,23 +1945,23 @@ def check_field_cax_tile_maxima(dev, big=False):
         _, t3, emin3, emax3, st = ops.histogram16(x, tiles=True, edge_window=2, ranks=ranks)
         want = ops.order_stats(x, ranks, hist=hist0)
         assert torch.equal(st, want) and torch.equal(t3, tmax)
-        srt = np.sort(arr.reshape(4, -1).astype(np.int64), axis=1)
+        srt = np.sort(arr.reshape(len(arr), -1).astype(np.int64), axis=1)
         assert np.array_equal(st.cpu().numpy(), srt[:, np.clip(ranks, 0, cnt - 1)])
         keys = arr.astype(np.int64) + (32768 if dtype == torch.int16 else 0)
-        true_max = keys.reshape(4, -1, 512).max(axis=2)
+        true_max = keys.reshape(len(arr), -1, 512).max(axis=2)
         got = tmax.cpu().numpy().astype(np.int64) & 0xFFFF
         assert ((got == true_max) | (got == 0xFFFF)).all() and (got == true_max).mean() > 0.99
-        vmin = torch.from_numpy(arr.reshape(4, -1).min(axis=1).astype(np.float64)).to(dev)
-        vmax = torch.from_numpy(arr.reshape(4, -1).max(axis=1).astype(np.float64)).to(dev)
+        vmin = torch.from_numpy(arr.reshape(len(arr), -1).min(axis=1).astype(np.float64)).to(dev)
+        vmax = torch.from_numpy(arr.reshape(len(arr), -1).max(axis=1).astype(np.float64)).to(dev)
         for thr in (0.5, 0.0, 1.5, 0.002, 0.9999):            # mid-level, everything, nothing, inside the noise, only the peak
-            t = torch.full((4,), thr, dtype=torch.float64, device=dev)
+            t = torch.full((len(arr),), thr, dtype=torch.float64, device=dev)
             a, sa = ops.field_cax(x, vmin, vmax - vmin, t, defer=True)
             b, sb = ops.field_cax(x, vmin, vmax - vmin, t, defer=True, tile_max=tmax)
             ok = sa == 0                                     # (status 1 = window too large: the record is not written)
             assert torch.equal(sa, sb) and torch.equal(torch.nan_to_num(a[ok], nan=-1.0), torch.nan_to_num(b[ok], nan=-1.0)), (str(dtype), thr)
             done += int(ok.sum())
         if dtype == torch.uint16:                            # a divisor that is not positive keeps the float64 test on every tile
-            t = torch.full((4,), 0.5, dtype=torch.float64, device=dev)
+            t = torch.full((len(arr),), 0.5, dtype=torch.float64, device=dev)
             a, sa = ops.field_cax(x, vmin, -(vmax - vmin), t, defer=True)
             b, sb = ops.field_cax(x, vmin, -(vmax - vmin), t, defer=True, tile_max=tmax)
             ok = sa == 0
