@@ -290,6 +290,8 @@ inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 template <typename T, typename U>
 inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
 #define __hip_atomic_load(p, order, scope) (*(p))           /* one OS thread: every store is visible at once */
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+#define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
 template <typename T, typename U>
 inline T atomicSub(T* p, U v) { T o = *p; *p = (T)(o - (T)v); return o; }
 template <typename T, typename U>

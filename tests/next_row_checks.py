@@ -1975,6 +1975,18 @@ def check_field_cax_tile_maxima(dev, big=False):
     _, _, emin, emax = ops.histogram16(x, tiles=True, edge_window=2)
     e0, e1 = ops.edge_minmax(x, 2)
     assert torch.equal(emin, e0) and torch.equal(emax, e1)
+    # rows of 100 vectors (not a power of two, the stream ends in tail vectors): the strips come out of the histogram's own
+    # loads for windows up to a vector wide, out of its prologue beyond that -- int16 too
+    for dt in (np.uint16, np.int16):
+        wide = rng.integers(0, 65536, (2, 330, 800)).astype(np.uint16).view(dt) if dt == np.int16 else rng.integers(0, 65536, (2, 330, 800)).astype(dt)
+        wide[0, 3:-3, 3:-3] = np.clip(wide[0, 3:-3, 3:-3].astype(np.int64), -20000, 20000).astype(dt)   # extrema only in the strips
+        xw = torch.from_numpy(wide).to(dev)
+        for win in (1, 2, 3, 8, 9):
+            hw, tw, emin, emax = ops.histogram16(xw, tiles=True, edge_window=win)
+            a = wide.astype(np.int64)
+            strips = [np.concatenate([a[k, :win].ravel(), a[k, -win:].ravel(), a[k, :, :win].ravel(), a[k, :, -win:].ravel()]) for k in range(2)]
+            assert emin.cpu().tolist() == [int(v.min()) for v in strips] and emax.cpu().tolist() == [int(v.max()) for v in strips], (dt.__name__, win)
+            assert torch.equal(hw, ops.histogram16(xw))
     small = torch.from_numpy(odd[:, :100, :120].copy()).to(dev)            # below 2^18 pixels: the multi-part histogram + the stand-alone edge kernel
     _, ts, emin, emax = ops.histogram16(small, tiles=True, edge_window=2)
     e0, e1 = ops.edge_minmax(small, 2)
