@@ -467,37 +467,25 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     if (threadIdx.x == 0) flag[frame] = 0;
   } else {
     uint32_t* table = merge + frame * 65536;
-    // The window's non-empty bins go to the table with plain (non-returning) device-scope adds, all of a thread's in flight
-    // together; the release fence in front of the barrier waits for them (and for the spill flag's store) to be performed at
-    // L2, and only then does thread 0 take the frame's arrival ticket (acq_rel).  Round 4 made every add a RETURNING one
-    // instead of fencing: up to 38 dependent L2 round trips per thread, the largest fixed cost of a small batch (r05z:
-    // 87 us for 8 frames, of which the tally itself is 21).
-    if (spilled) {
-      if (threadIdx.x == 0) __hip_atomic_store(&flag[frame], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
+    unsigned seen = 0;
+    // RETURNING exchange, its value folded into `seen`: the wave waits for the flag write to be performed before it reaches
+    // the barrier and thread 0 takes the arrival ticket, so the last part cannot read a stale 0
+    if (spilled && threadIdx.x == 0) seen |= atomicExch(&flag[frame], 1) == 0x7fffffff ? 1u : 0u;
+    if (!spilled)
       for (int i = threadIdx.x; i < range; i += kHistThreads) {
         const unsigned c = bins[i];
-        if (c) __hip_atomic_fetch_add(&table[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c) seen |= atomicAdd(&table[i], c) == 0xffffffffu ? 1u : 0u;   // RETURNING: the wave waits for its adds
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // (a count cannot reach 2^32 - 1: `seen` stays 0; it exists so that the barrier below consumes the returned values.  Not
+    // __syncthreads_or: that brings static LDS in front of the bins, which must start at LDS address 0)
+    if (seen) scr.any = 2;
     __syncthreads();
-    if (threadIdx.x == 0)
-      scr.any = __hip_atomic_fetch_add(&table[65534], spilled ? 0u : 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) ==
-                        (unsigned)(parts - 1) && !spilled ? 1 : 0;
+    if (threadIdx.x == 0) scr.any = atomicAdd(&table[65534], scr.any == 2 ? 0u : 1u) == (unsigned)(parts - 1) ? 1 : 0;
     __syncthreads();
-    if (scr.any == 0) return;                                // not the last part of this frame (or a spilled one: see below)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (scr.any == 0) return;                                // not the last part of this frame
     if (__hip_atomic_load(&flag[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // a part spilled: fallback
-    // (after the acquire: plain vector loads, several in flight.  Whole quads: the bins behind `range` hold zeros in the table
-    // and room in LDS -- kOtsuScratchAt leaves three spare words behind the spare bin)
-    {
-      const uint4* t4 = reinterpret_cast<const uint4*>(table);
-      uint4* b4 = reinterpret_cast<uint4*>(bins);
-      const int quads = (range + 3) / 4;
-#pragma unroll 5
-      for (int i = threadIdx.x; i < quads; i += kHistThreads) b4[i] = t4[i];
-    }
+    for (int i = threadIdx.x; i < range; i += kHistThreads)
+      bins[i] = __hip_atomic_load(&table[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
 
@@ -837,14 +825,7 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   const uint4* vsrc = reinterpret_cast<const uint4*>(src);
 
   for (int i = threadIdx.x; i < 2 * kTwBins; i += kHistThreads) bins[i] = 0;
-  // The edge strips' extrema (pl_hist16_wl) are taken from the main loop's own vectors where the geometry allows: rows of a
-  // whole number of vectors, at least one wave load long, strips no wider than a vector.  (A prologue that loads the strips
-  // by themselves -- the form below, kept for every other geometry -- touches one cache line per row and side ahead of the
-  // stream: 12 % more traffic for a kernel that runs at the memory system's pace, r05g.)
-  const int e_wv = ew / 8, e_band = ews < eh ? ews : eh, e_cb = ews < ew ? ews : ew;
-  const bool edge_loop = edge_min != nullptr && vec && (ew & 7) == 0 && e_wv >= PL_WAVE && e_cb <= 8 && (int64_t)eh * ew == count;
-  int e_mn = 0x7fffffff, e_mx = -0x7fffffff - 1;
-  if (edge_min && !edge_loop) {
+  if (edge_min) {
     // min / max over the four `ews`-wide edge strips of the eh x ew frame (WLBaseImage._clean_edges' edge test,
     // pylinac/winston_lutz.py:1109-1133; pl_edge_minmax's loops): a few scattered loads per thread, all issued before the
     // first is looked at -- as a kernel of its own (one 256-thread workgroup per frame walking them sixteen deep) this was
@@ -1004,41 +985,11 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   };
   int64_t v = threadIdx.x;
   constexpr int U = 8;  // independent 16-byte loads in flight per lane (one workgroup per CU: 128 KiB in flight)
-  // edge strips from the stream: vector j holds row j / e_wv, columns 8 (j % e_wv) .. + 7.  e_rem = (the wave's first vector)
-  // % e_wv, wave-uniform, advanced by kHistThreads % e_wv per load; a wave load meets the left strip where that remainder
-  // wraps, the right strip one vector earlier, the top / bottom strips by its vector number alone
-  const int64_t e_top = (int64_t)e_band * e_wv, e_bot = (int64_t)(eh - e_band) * e_wv;
-  const int e_step = edge_loop ? kHistThreads % e_wv : 0;
-  int e_rem = edge_loop ? __builtin_amdgcn_readfirstlane((int)((threadIdx.x - lane) % (unsigned)e_wv)) : 0;
-  auto edge_see = [&](uint4 q, int64_t vk, int c) {                 // c = vk % e_wv (+ e_wv)
-    if (c >= e_wv) c -= e_wv;
-    const bool rows = vk < e_top || vk >= e_bot;
-    unsigned mask = rows ? 0xffu : 0u;
-    if (c == 0) mask |= (1u << e_cb) - 1u;
-    if (c == e_wv - 1) mask |= (0xffu << (8 - e_cb)) & 0xffu;
-    if (mask == 0u) return;
-    const unsigned wds[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned raw = (j & 1) ? wds[j >> 1] >> 16 : wds[j >> 1] & 0xffffu;
-      const int val = flip ? (int)(short)raw : (int)raw;
-      if (mask >> j & 1u) { e_mn = val < e_mn ? val : e_mn; e_mx = val > e_mx ? val : e_mx; }
-    }
-  };
   // the trip count is the WAVE's (its last lane decides): the wave-level steps inside never run under divergence
   for (; v - lane + (PL_WAVE - 1) + (int64_t)(U - 1) * kHistThreads < nvec; v += (int64_t)U * kHistThreads) {
     uint4 q[U];
 #pragma unroll
     for (int k = 0; k < U; ++k) q[k] = vsrc[v + (int64_t)k * kHistThreads];
-    if (edge_loop) {                                                // wave-uniform
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const int64_t vb = v - lane + (int64_t)k * kHistThreads;      // the wave's first vector of this load
-        if (e_rem == 0 || e_rem + PL_WAVE >= e_wv || vb < e_top || vb + PL_WAVE > e_bot) edge_see(q[k], vb + lane, e_rem + lane);
-        e_rem += e_step;
-        if (e_rem >= e_wv) e_rem -= e_wv;
-      }
-    }
     if (tmax) {                                                     // wave-uniform
       const unsigned f2 = flip | (flip << 16);
 #pragma unroll
@@ -1062,7 +1013,6 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   }
   for (; v < nvec; v += kHistThreads) {              // fewer than 8192 vectors are left: no wave-level steps under divergence
     const uint4 q = vsrc[v];
-    if (edge_loop) edge_see(q, v, (int)(v % e_wv));
     const unsigned wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) { tally1(wds[k] & 0xffffu); tally1(wds[k] >> 16); }
@@ -1070,17 +1020,6 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally1(src[i]);
   flush();
   __syncthreads();
-  if (edge_loop) {
-    e_mn = pl_wave_reduce(e_mn, [](int a, int b) { return a < b ? a : b; });
-    e_mx = pl_wave_reduce(e_mx, [](int a, int b) { return a > b ? a : b; });
-    if (lane == 0) { scr.s_lo[wv] = e_mn; scr.s_hi[wv] = e_mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int k = 0; k < kHistThreads / 64; ++k) { e_mn = scr.s_lo[k] < e_mn ? scr.s_lo[k] : e_mn; e_mx = scr.s_hi[k] > e_mx ? scr.s_hi[k] : e_mx; }
-      edge_min[frame] = e_mn;
-      edge_max[frame] = e_mx;
-    }
-  }
   if (ranks) {
     // pl_hist16_wl: the order statistics are taken HERE, from the windows while they are still in LDS (order_stats_kernel's
     // selection: thread t owns bins [64 t, 64 t + 64), exclusive scan of the counts, the bin where the running count passes
@@ -1317,7 +1256,7 @@ int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t c
   const int cus = pl_cu_count();
   while (parts < 8 && n * parts * 2 <= cus) parts *= 2;
   if (MED3) { const int row_groups = (h + 31) / 32; while (parts > 1 && parts > row_groups) parts /= 2; }
-  if (count < 65536 || (reinterpret_cast<uintptr_t>(d_hist) & 15) != 0) parts = 1;   // (the merged table is read back in quads)
+  if (count < 65536) parts = 1;
   if (parts > 1) {
     hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)n * 65536 * sizeof(uint32_t), st);
     if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, (size_t)n * sizeof(int32_t), st);
