@@ -59,15 +59,8 @@ __global__ void __launch_bounds__(kThreads)
 scaled_colmeanv_kernel(const unsigned short* __restrict__ in, int h, int w, int64_t total_groups,
                        const double* __restrict__ sub, const double* __restrict__ div, double* __restrict__ out) {
   static_assert(COLS == 1 || COLS == 2 || COLS == 4, "one, two or four columns per lane");
-  // The LAST frames first: this is the second whole read of the batch (the extrema pass in front of it walked it first to
-  // last), and what a 0.4 GB batch leaves in the 256 MB memory-side cache is its tail; the window kernel behind this one walks
-  // first to last again and meets this pass's tail.  (PL_COLMEAN_REVERSE=0: the A/B build.)
-#ifndef PL_COLMEAN_REVERSE
-#define PL_COLMEAN_REVERSE 1
-#endif
-  const int64_t g0 = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (g0 >= total_groups) return;
-  const int64_t g = PL_COLMEAN_REVERSE ? total_groups - 1 - g0 : g0;
+  const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (g >= total_groups) return;
   const int gpr = w / COLS;
   const size_t frame = (size_t)(g / gpr);
   const int c = (int)(g % gpr) * COLS;
