@@ -134,7 +134,7 @@ int pl_hist16_tiles(const void* in, int dtype, int64_t n, int64_t count, uint32_
  * everything the per-image half of WLBaseImage.analyze asks of a frame before its scalar decisions
  * (pylinac/winston_lutz.py:709-712, 775, 1109-1133).  d_ranks / d_order_stats (both or neither; as pl_order_stats_from_hist):
  * the order statistics of the np.percentile calls are selected in the same launch from the histogram while it is still in
- * LDS -- d_hist is then SCRATCH (it only receives the bins outside the kernel's LDS windows). */
+ * LDS -- d_hist is then SCRATCH (it only receives the bins outside the kernel's LDS windows) and must be 16-byte aligned. */
 int pl_hist16_wl(const void* in, int dtype, int64_t n, int h, int w, uint32_t* d_hist, uint16_t* d_tile_max, int edge_window,
                  int32_t* d_edge_min, int32_t* d_edge_max, const int64_t* d_ranks, int nranks, int32_t* d_order_stats, void* stream);
 /* skimage.filters.threshold_otsu on an integer image (pylinac/ct.py:3323,3338; acr.py:1409):

@@ -69,6 +69,13 @@ def test_argument_validation_without_launch(lib):
     assert lib.pl_hist16(p, 3, 1, 16, p, None) == 1  # float dtype refused
     assert lib.pl_reduce_axis(p, 0, 1, 4, 4, 2, 0, p, None) == 1  # bad axis
     assert lib.pl_threshold(p, p, 0, 1, 16, None, 0, 0, None) == 1
+    # pl_hist16_wl: ranks and their output go together; the scratch table of the order-statistics form is read back in quads
+    big = (C.c_uint32 * 32)()
+    base = C.addressof(big)
+    aligned, odd = C.c_void_p((base + 15) & ~15), C.c_void_p(((base + 15) & ~15) + 4)
+    assert lib.pl_hist16_wl(p, 0, 1, 4, 4, aligned, p, 2, p, p, p, 0, None, None) == 1 and b"go together" in lib.pl_last_error()
+    assert lib.pl_hist16_wl(p, 0, 1, 4, 4, odd, p, 2, p, p, p, 1, p, None) == 1 and b"16-byte" in lib.pl_last_error()
+    assert lib.pl_hist16_wl(p, 0, 1, 4, 4, aligned, p, 0, p, p, None, 0, None, None) == 1   # an edge window of zero pixels
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
