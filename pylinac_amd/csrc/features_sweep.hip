@@ -41,8 +41,9 @@ namespace {
 constexpr int kSwThreads = 256;
 constexpr int kSwMaxSide = 160;          // window side limit (coordinates are packed in 8 bits)
 constexpr int kSwMaxRuns = 4096;         // row runs of one level: the large table (second pass)
-constexpr int kSwFirstRuns = 1536;       // ... the first pass's table: 74 KB of LDS per workgroup, two workgroups per CU
+constexpr int kSwMidRuns = 1536;         // ... the second pass's: 67 KB of LDS per workgroup, two workgroups per CU
 constexpr int kSwMaxCrop = 64;           // candidate bbox side limit for the crop analysis
+constexpr int kSwThirdLds = 52224;       // LDS budget (static + dynamic) of the FIRST pass: three workgroups per CU (160 KB)
 constexpr int kSwMaxHullPts = 8 * kSwMaxCrop;
 constexpr int kSwMaxOut = 8;
 constexpr int kSwMaxLevels = 64;
@@ -108,10 +109,10 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
                 int32_t* __restrict__ out_count, double* __restrict__ out_xy, int32_t* __restrict__ out_level,
                 int32_t* __restrict__ status, int max_runs, int redo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // Two passes share this kernel.  The first runs every frame with a table of kSwFirstRuns row runs: 74 KB of LDS, TWO
-  // workgroups per CU (the 4096-run table of rounds 1-3 left ONE: four waves on a CU for a kernel that is all latency).  A
-  // level with more runs (speckle) ends the frame with status 5; the second pass (redo != 0) takes exactly those frames again
-  // with the large table -- a workgroup whose frame is not marked leaves at once.
+  // Up to three passes share this kernel (sweep_launch): the first runs every frame with the run table that keeps the
+  // workgroup within a third of a CU's LDS (the 4096-run table of rounds 1-3 left ONE workgroup per CU: four waves on a CU
+  // for a kernel that is all latency).  A level with more runs (speckle) ends the frame with status 5; the later passes
+  // (redo != 0) take exactly those frames again with larger tables -- a workgroup whose frame is not marked leaves at once.
   if (redo && status[blockIdx.x] != 5) return;
   // ---- dynamic LDS carve-up
   const int npx = h * w;
@@ -121,14 +122,15 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
   int* t_r1 = t_area + max_runs;
   int* t_c0 = t_r1 + max_runs;
   int* t_c1 = t_c0 + max_runs;
-  int* s_hx = t_c1 + max_runs;
-  int* s_hy = s_hx + kSwMaxHullPts;
-  int* s_hull_x = s_hy + kSwMaxHullPts;
-  int* s_hull_y = s_hull_x + kSwMaxHullPts + 1;
-  unsigned char* m = reinterpret_cast<unsigned char*>(s_hull_y + kSwMaxHullPts + 1);   // crop mask
-  unsigned char* reach = m + kSwMaxCrop * kSwMaxCrop;
-  unsigned char* bord = reach + kSwMaxCrop * kSwMaxCrop;
-  unsigned char* L = bord + kSwMaxCrop * kSwMaxCrop;                      // level map [npx]
+  short* s_hx = reinterpret_cast<short*>(t_c1 + max_runs);               // hull work tables: doubled crop coordinates (< 130)
+  short* s_hy = s_hx + kSwMaxHullPts;
+  short* s_hull_x = s_hy + kSwMaxHullPts;
+  short* s_hull_y = s_hull_x + kSwMaxHullPts + 2;
+  // crop planes, one byte per crop pixel: bit 0 region mask, bit 1 reached from the crop border, bit 2 region border pixel.
+  // A thread only ever rewrites the byte of its OWN pixel (and never bit 0 after the mask is built), neighbours read single
+  // bits of it: the same monotone races as three separate planes, a third of the LDS
+  unsigned char* crop = reinterpret_cast<unsigned char*>(s_hull_y + kSwMaxHullPts + 2);
+  unsigned char* L = crop + kSwMaxCrop * kSwMaxCrop;                      // level map [npx]
   __shared__ int row_cnt[kSwMaxSide + 1];                                  // runs per row, then exclusive prefix
   __shared__ int s_cand[32];
   __shared__ int s_ncand, s_nh, s_inside, s_nruns;
@@ -175,6 +177,8 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
     const double g = (sv - c_smin) + 0.0;
     return (((g / c_mg) * 1.0) - c_mn2) + 0.0;
   };
+  auto M = [&](int e) { return (crop[e] & 1) != 0; };          // crop planes (see the carve-up)
+  auto REACH = [&](int e) { return (crop[e] & 2) != 0; };
   const double dp2 = prm.dpmm * prm.dpmm;
   const double pi = 3.141592653589793;
   const double larger = pi * ((prm.radius_mm + prm.tol_mm) * (prm.radius_mm + prm.tol_mm));
@@ -350,14 +354,14 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
       if (ch > kSwMaxCrop || cw > kSwMaxCrop) { if (tid == 0) s_status = 3; continue; }
       const int cpx = ch * cw;
       // region mask of the crop from the runs of its rows
-      for (int e = tid; e < cpx; e += kSwThreads) m[e] = 0;
+      for (int e = tid; e < cpx; e += kSwThreads) crop[e] = 0;
       __syncthreads();
       for (int rr = tid; rr < ch; rr += kSwThreads) {
         for (int id = row_cnt[r0 + rr]; id < row_cnt[r0 + rr + 1]; ++id) {
           if (parent[id] != (unsigned)k) continue;
           const unsigned info = run_info[id];
           const int s = info & 255, e = (info >> 8) & 255;
-          for (int c = s; c <= e; ++c) m[rr * cw + (c - c0)] = 1;
+          for (int c = s; c <= e; ++c) crop[rr * cw + (c - c0)] = 1;
         }
       }
       __syncthreads();
@@ -366,25 +370,25 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
       for (int e = tid; e < cpx; e += kSwThreads) {
         const int r = e / cw, c = e % cw;
         const bool edge = (r == 0 || c == 0 || r == ch - 1 || c == cw - 1);
-        reach[e] = (!m[e] && edge) ? 1 : 0;
+        const bool me = M(e);
         bool b = false;
-        if (m[e]) b = (r == 0 || !m[e - cw]) || (r == ch - 1 || !m[e + cw]) || (c == 0 || !m[e - 1]) || (c == cw - 1 || !m[e + 1]);
-        bord[e] = b ? 1 : 0;
+        if (me) b = (r == 0 || !M(e - cw)) || (r == ch - 1 || !M(e + cw)) || (c == 0 || !M(e - 1)) || (c == cw - 1 || !M(e + 1));
+        crop[e] = (unsigned char)((me ? 1 : 0) | ((!me && edge) ? 2 : 0) | (b ? 4 : 0));
       }
       __syncthreads();
       for (;;) {
         int changed = 0;
         for (int e = tid; e < cpx; e += kSwThreads) {
-          if (m[e] || reach[e]) continue;
+          if (crop[e] & 3) continue;
           const int r = e / cw, c = e % cw;
           bool hit = false;
           for (int dr = -1; dr <= 1 && !hit; ++dr)
             for (int dc = -1; dc <= 1; ++dc) {
               const int rr = r + dr, cc = c + dc;
               if ((dr | dc) == 0 || rr < 0 || cc < 0 || rr >= ch || cc >= cw) continue;
-              if (reach[rr * cw + cc]) { hit = true; break; }
+              if (REACH(rr * cw + cc)) { hit = true; break; }
             }
-          if (hit) { reach[e] = 1; changed = 1; }
+          if (hit) { crop[e] = 2; changed = 1; }
         }
         if (!__syncthreads_or(changed)) break;
       }
@@ -396,16 +400,16 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
       double w0 = 0.0, wr = 0.0, wc = 0.0;
       for (int e = tid; e < cpx; e += kSwThreads) {
         const int r = e / cw, c = e % cw;
-        if (!m[e] && !reach[e]) ++holes;
-        if (bord[e]) {
-          auto B = [&](int rr, int cc) { return (rr < 0 || cc < 0 || rr >= ch || cc >= cw) ? 0 : (int)bord[rr * cw + cc]; };
+        if (!(crop[e] & 3)) ++holes;
+        if (crop[e] & 4) {
+          auto B = [&](int rr, int cc) { return (rr < 0 || cc < 0 || rr >= ch || cc >= cw) ? 0 : (int)((crop[rr * cw + cc] >> 2) & 1); };
           const int code = 1 + 2 * (B(r - 1, c) + B(r + 1, c) + B(r, c - 1) + B(r, c + 1)) +
                            10 * (B(r - 1, c - 1) + B(r - 1, c + 1) + B(r + 1, c - 1) + B(r + 1, c + 1));
           if (code == 5 || code == 7 || code == 15 || code == 17 || code == 25 || code == 27) ++n1;
           else if (code == 21 || code == 33) ++n2;
           else if (code == 13 || code == 23) ++n3;
         }
-        if (m[e]) {
+        if (M(e)) {
           const double v = value_at(r0 + r, c0 + c);
           w0 += v; wr += v * (double)r; wc += v * (double)c;
         }
@@ -431,8 +435,8 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
       if (nx <= 63) {                                       // wave-uniform: the usual BB blob (ch <= 31 rows)
         for (int r = tid; r < ch; r += kSwThreads) {
           int cl = -1, cr = -1;
-          for (int c = 0; c < cw; ++c) if (m[r * cw + c]) { if (cl < 0) cl = c; cr = c; }
-          s_hx[r] = cl; s_hy[r] = cr;                       // (a connected region has a pixel in every row of its bbox)
+          for (int c = 0; c < cw; ++c) if (M(r * cw + c)) { if (cl < 0) cl = c; cr = c; }
+          s_hx[r] = (short)cl; s_hy[r] = (short)cr;         // (a connected region has a pixel in every row of its bbox)
         }
         __syncthreads();
         if (wv == 0) {
@@ -476,7 +480,7 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
             const unsigned long long keep = alive & ~(1ull << (npts - 1));
             if ((keep >> lane) & 1ull) {
               const int at = nh + __popcll(keep & ((1ull << lane) - 1ull));
-              s_hull_x[at] = X; s_hull_y[at] = Y;
+              s_hull_x[at] = (short)X; s_hull_y[at] = (short)Y;
             }
             nh += __popcll(keep);
           }
@@ -486,17 +490,17 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
       // tall crops: the sequential form (eight points per row, sorted, Andrew's chains on one lane)
       for (int r = tid; r < ch; r += kSwThreads) {
         int cl = -1, cr = -1;
-        for (int c = 0; c < cw; ++c) if (m[r * cw + c]) { if (cl < 0) cl = c; cr = c; }
-        int* px = s_hx + r * 8; int* py = s_hy + r * 8;
-        for (int q = 0; q < 8; ++q) { px[q] = 0x7fffffff; py[q] = 0; }
+        for (int c = 0; c < cw; ++c) if (M(r * cw + c)) { if (cl < 0) cl = c; cr = c; }
+        short* px = s_hx + r * 8; short* py = s_hy + r * 8;
+        for (int q = 0; q < 8; ++q) { px[q] = 0x7fff; py[q] = 0; }
         if (cl >= 0) {
           const int xs[2] = {cl, cr};
           for (int q = 0; q < 2; ++q) {
             const int X = 2 * r, Y = 2 * xs[q];
-            px[4 * q + 0] = X;     py[4 * q + 0] = Y - 1;
-            px[4 * q + 1] = X;     py[4 * q + 1] = Y + 1;
-            px[4 * q + 2] = X - 1; py[4 * q + 2] = Y;
-            px[4 * q + 3] = X + 1; py[4 * q + 3] = Y;
+            px[4 * q + 0] = (short)X;       py[4 * q + 0] = (short)(Y - 1);
+            px[4 * q + 1] = (short)X;       py[4 * q + 1] = (short)(Y + 1);
+            px[4 * q + 2] = (short)(X - 1); py[4 * q + 2] = (short)Y;
+            px[4 * q + 3] = (short)(X + 1); py[4 * q + 3] = (short)Y;
           }
         }
       }
@@ -504,13 +508,13 @@ bb_sweep_kernel(const double* __restrict__ sample, const SweepSrc src, int h, in
       if (tid == 0) {
         const int np = ch * 8;
         for (int a = 1; a < np; ++a) {
-          const int vx = s_hx[a], vy = s_hy[a];
+          const short vx = s_hx[a], vy = s_hy[a];
           int b = a - 1;
           while (b >= 0 && (s_hx[b] > vx || (s_hx[b] == vx && s_hy[b] > vy))) { s_hx[b + 1] = s_hx[b]; s_hy[b + 1] = s_hy[b]; --b; }
           s_hx[b + 1] = vx; s_hy[b + 1] = vy;
         }
         int n = 0;
-        while (n < np && s_hx[n] != 0x7fffffff) ++n;
+        while (n < np && s_hx[n] != 0x7fff) ++n;
         int u = 0;
         for (int a = 0; a < n; ++a) if (a == 0 || s_hx[a] != s_hx[a - 1] || s_hy[a] != s_hy[a - 1]) { s_hx[u] = s_hx[a]; s_hy[u] = s_hy[a]; ++u; }
         n = u;
@@ -619,21 +623,39 @@ int sweep_launch(const double* d_sample, const SweepSrc& src, int64_t n, int h, 
   for (int k = 0; k < kSwMaxLevels; ++k) prm.cut[k] = k < nlevels ? h_cutoffs[k] : 0.0;
   for (int k = 1; k < nlevels; ++k)
     if (!(h_cutoffs[k] > h_cutoffs[k - 1])) { pl_set_error("%s: cutoffs must increase", who); return PL_ERR_INVALID_ARG; }
-  const size_t fixed = ((size_t)2 * kSwMaxHullPts + 2 * (kSwMaxHullPts + 1)) * 4 + (size_t)3 * kSwMaxCrop * kSwMaxCrop +
+  const size_t fixed = ((size_t)2 * kSwMaxHullPts + 2 * (kSwMaxHullPts + 2)) * sizeof(short) + (size_t)kSwMaxCrop * kSwMaxCrop +
                        (size_t)h * ((w + 3) & ~3);
-  const size_t lds = (size_t)kSwMaxRuns * 6 * 4 + fixed, lds_first = (size_t)kSwFirstRuns * 6 * 4 + fixed;
+  auto lds_for = [&](int runs) { return (size_t)runs * 6 * 4 + fixed; };
   static std::atomic<size_t> attr_lds{0};
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)bb_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { pl_set_error("%s: LDS attribute: %s", who, hipGetErrorString(e)); return PL_ERR_HIP; }
-    attr_lds = lds;
+  static std::atomic<int> static_lds{-1};
+  if (static_lds < 0) {
+    hipFuncAttributes fa;
+    static_lds = hipFuncGetAttributes(&fa, (const void*)bb_sweep_kernel) == hipSuccess ? (int)fa.sharedSizeBytes : 2048;
+    (void)hipGetLastError();
   }
-  // measured on 512 Winston-Lutz frames (scripts/time_wl_variants.py, analyze_batch per pass): this pair 0.956 ms clean / 1.157 ms
-  // noisy; one pass with the large table 1.080 / 1.319; 512 threads per workgroup instead of 256: 0.985 / 1.21
-  hipLaunchKernelGGL(bb_sweep_kernel, dim3((unsigned)n), dim3(kSwThreads), lds_first, (hipStream_t)stream, d_sample, src, h, w, prm,
-                     d_count, d_xy, d_level, d_status, kSwFirstRuns, 0);
-  hipLaunchKernelGGL(bb_sweep_kernel, dim3((unsigned)n), dim3(kSwThreads), lds, (hipStream_t)stream, d_sample, src, h, w, prm,
-                     d_count, d_xy, d_level, d_status, kSwMaxRuns, 1);
+  if (lds_for(kSwMaxRuns) > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)bb_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_for(kSwMaxRuns));
+    if (e != hipSuccess) { pl_set_error("%s: LDS attribute: %s", who, hipGetErrorString(e)); return PL_ERR_HIP; }
+    attr_lds = lds_for(kSwMaxRuns);
+  }
+  // Up to three passes over the batch, each taking only the frames the one before left with status 5 (a level with more row
+  // runs than its table holds; a workgroup whose frame is not marked leaves at once: 4 us per empty pass):
+  //   1. the largest run table that keeps the workgroup within a THIRD of a CU's LDS (896 runs for a 144 x 144 window) --
+  //      the kernel is all latency, four waves per workgroup: 1 250 Winston-Lutz frames are 1.6 rounds of 768 slots instead
+  //      of 2.4 rounds of 512 (profiles/r05j_wl_sweep_occupancy_ab.txt: 544 -> 442 us with a timing-only build);
+  //   2. 1 536 runs, two workgroups per CU (rounds 3-5's first pass);   3. 4 096 runs, one per CU.
+  // Measured on 512 frames (round 3, scripts/time_wl_variants.py): 1 536 + 4 096: 0.956 ms clean / 1.157 noisy; 4 096 alone 1.080 / 1.319.
+  int first = (int)(((long long)kSwThirdLds - static_lds - (long long)fixed) / 24) & ~63;
+  if (first > kSwMidRuns) first = kSwMidRuns;
+  if (first < 256) first = kSwMidRuns;                                  // a window too large for three per CU: rounds 3-5's pair
+  const int tiers[3] = {first, first < kSwMidRuns ? kSwMidRuns : 0, kSwMaxRuns};
+  int redo = 0;
+  for (int t = 0; t < 3; ++t) {
+    if (tiers[t] == 0) continue;
+    hipLaunchKernelGGL(bb_sweep_kernel, dim3((unsigned)n), dim3(kSwThreads), lds_for(tiers[t]), (hipStream_t)stream, d_sample, src, h, w,
+                       prm, d_count, d_xy, d_level, d_status, tiers[t], redo);
+    redo = 1;
+  }
   return pl_check_launch(who);
 }
 }  // namespace

@@ -107,6 +107,8 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 template <typename F>
 inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+struct hipFuncAttributes { size_t sharedSizeBytes; };
+inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { a->sharedSizeBytes = 2048; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };

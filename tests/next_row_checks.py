@@ -1998,3 +1998,34 @@ def check_field_cax_tile_maxima(dev, big=False):
     rng_ = torch.from_numpy((odd.reshape(2, -1).max(axis=1) - odd.reshape(2, -1).min(axis=1)).astype(np.float64)).to(dev)
     t = torch.full((2,), 0.5, dtype=torch.float64, device=dev)
     assert torch.equal(ops.field_cax(x, vmin, rng_, t), ops.field_cax(x, vmin, rng_, t, tile_max=tmax))
+
+
+def check_bb_sweep_run_table_tiers(dev):
+    """pl_features_sweep's passes: windows whose speckle needs more row runs at a level than the first pass's table holds (896
+    at this window size: three workgroups per CU), more than the second's (1 536), more than the third's (4 096: status 5, the
+    caller's level-by-level path) -- every one gives the features of the level-by-level path, and the sweep alone
+    (``defer=True``) reports status 0 for the first three."""
+    from pylinac_amd import features as pf
+
+    rng = np.random.default_rng(5)
+    dpmm, n = 2.98, 140
+    yy, xx = np.mgrid[0:n, 0:n].astype(float)
+    wins = []
+    for frac in (0.0, 0.06, 0.2, 0.5):
+        img = np.full((n, n), 0.2) + rng.normal(0, 1e-4, (n, n))
+        cy, cx = 70.3, 66.8
+        far = np.hypot(yy - cy, xx - cx) > 16
+        img[far & (rng.random((n, n)) < frac)] = 0.6
+        img[np.hypot(yy - cy, xx - cx) < 2.5 * dpmm] = 1.0
+        wins.append(img)
+        runs = int(((img[:, 1:] > 0.3) & ~(img[:, :-1] > 0.3)).sum() + (img[:, 0] > 0.3).sum())
+        assert {0.0: runs < 896, 0.06: 896 < runs <= 1536, 0.2: 1536 < runs <= 4096, 0.5: runs > 4096}[frac], (frac, runs)
+    x = torch.from_numpy(np.stack(wins)).to(dev)
+    alone = pf.find_features_batch(x, dpmm, 2.5, 0.5, defer=True)
+    assert alone["status"].cpu().tolist() == [0, 0, 0, 5]
+    res = pf.find_features_batch(x, dpmm, 2.5, 0.5)
+    lv = pf.find_features_batch(x, dpmm, 2.5, 0.5, level_by_level=True)
+    assert res["count"].cpu().tolist() == [1, 1, 1, 1] == lv["count"].cpu().tolist()
+    assert torch.equal(res["level"], lv["level"]) and torch.equal(res["xy"][:, 0], lv["xy"][:, 0])
+    assert torch.equal(alone["xy"][:3, 0], lv["xy"][:3, 0])
+    return 4

@@ -1034,6 +1034,12 @@ def test_emulated_field_cax_tile_maxima(emulated):
     checks.check_field_cax_tile_maxima(emulated)
 
 
+def test_emulated_bb_sweep_run_table_tiers(emulated):
+    import next_row_checks as checks
+
+    assert checks.check_bb_sweep_run_table_tiers(emulated) == 4
+
+
 def test_emulated_pack_columns(emulated):
     """pl_pack_columns: float64 / int32 columns, strided sources with offsets and additive constants -> one float64 table."""
     import torch

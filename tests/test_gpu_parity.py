@@ -419,6 +419,14 @@ def test_field_cax_driven_by_tile_maxima_equals_the_full_pass(dev):
     checks.check_field_cax_tile_maxima(dev, big=True)
 
 
+@pytest.mark.gpu
+def test_bb_sweep_run_table_tiers(dev):
+    """the sweep's three run-table sizes (three / two / one workgroup per CU) hand frames on by status 5"""
+    import next_row_checks as checks
+
+    assert checks.check_bb_sweep_run_table_tiers(dev) == 4
+
+
 def test_fwxm_search_short_profiles_corner_cases(dev):
     import next_row_checks as checks
 
