@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5: one gpurun call that refreshes every piece of evidence the round is judged on; EVERY step under its own time-out
 # (r04's final PMC pass sat until gpurun's limit).
-#   gpurun --timeout 2400 -- 'bash scripts/round_end_r05b.sh r05y'
+#   gpurun --timeout 2400 -- 'bash scripts/round_end_r05b.sh r05x'
 TAG=${1:-r05x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
