@@ -2000,7 +2000,7 @@ def check_field_cax_tile_maxima(dev, big=False):
     assert torch.equal(ops.field_cax(x, vmin, rng_, t), ops.field_cax(x, vmin, rng_, t, tile_max=tmax))
 
 
-def check_bb_sweep_run_table_tiers(dev):
+def check_bb_sweep_run_table_tiers(dev, full=True):
     """pl_features_sweep's passes: windows whose speckle needs more row runs at a level than the first pass's table holds (896
     at this window size: three workgroups per CU), more than the second's (1 536), more than the third's (4 096: status 5, the
     caller's level-by-level path) -- every one gives the features of the level-by-level path, and the sweep alone
@@ -2023,6 +2023,11 @@ def check_bb_sweep_run_table_tiers(dev):
     x = torch.from_numpy(np.stack(wins)).to(dev)
     alone = pf.find_features_batch(x, dpmm, 2.5, 0.5, defer=True)
     assert alone["status"].cpu().tolist() == [0, 0, 0, 5]
+    assert alone["count"].cpu().tolist()[:3] == [1, 1, 1]
+    if not full:                                             # (the CPU emulator: the two windows that were handed on, once)
+        lv = pf.find_features_batch(x[1:3], dpmm, 2.5, 0.5, level_by_level=True)
+        assert torch.equal(alone["level"][1:3], lv["level"]) and torch.equal(alone["xy"][1:3, 0], lv["xy"][:, 0])
+        return 2
     res = pf.find_features_batch(x, dpmm, 2.5, 0.5)
     lv = pf.find_features_batch(x, dpmm, 2.5, 0.5, level_by_level=True)
     assert res["count"].cpu().tolist() == [1, 1, 1, 1] == lv["count"].cpu().tolist()
