@@ -2,7 +2,7 @@
 # Round 5, call h: suite; the small-batch sweep of the headline step and the kernel list of a 32-frame step (the window
 # Otsu kernel's merge no longer waits for one L2 round trip per bin); the Winston-Lutz pass with the edge strips taken
 # from the histogram's own stream; the bench line.
-TAG=${1:-r05h}
+TAG=${1:-r05l}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
