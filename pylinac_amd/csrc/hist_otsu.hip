@@ -469,11 +469,11 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     }
     if (threadIdx.x == 0) flag[frame] = 0;
   } else if (slabs) {
-    // Slab merge (pl_*_ex with a workspace): every part PUBLISHES the populated stretch of its window with plain 16-byte
-    // stores into a slab of its own, one agent-scope release fence, one arrival ticket; the part that arrives last adds the
-    // other slabs to the window it still holds in LDS and runs the scan.  The table form below sends every non-empty bin of
-    // every part through a device-scope atomic, and those execute at the memory side (the XCDs' L2s are not coherent): 2 x 10^6
-    // of them per 32-frame step, 0.07 ms of the stage's 0.09 (r05h: returning or not, fenced or not).
+    // Slab merge (pl_*_ex with a workspace): every part PUBLISHES the populated stretch of its window with 16-byte
+    // write-through stores into a slab of its own, waits for them, and takes an arrival ticket; the part that arrives last
+    // adds the other slabs to the window it still holds in LDS and runs the scan.  The table form below sends every non-empty
+    // bin of every part through a device-scope atomic, and those execute at the memory side (the XCDs' L2s are not coherent):
+    // 2 x 10^6 of them per 32-frame step, 0.07 ms of the stage's 0.09 (r05h: returning or not, fenced or not).
     // The stretch: the bins between the sample's extrema +- 256, whole quads -- identical in every part of a frame (same
     // sample); a part that holds a count outside it (the sample missed a value by more than that) declares the frame spilled.
     int q_lo = (seen_lo - 256 - klo) >> 2, q_hi = (seen_hi + 257 - klo + 3) >> 2;
@@ -489,19 +489,21 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     uint32_t* const tickets = slabs + (size_t)gridDim.x * kWinBins;         // gridDim.x = frames x parts
     const uint4* b4 = reinterpret_cast<const uint4*>(bins);
     if (spill2) {
-      if (threadIdx.x == 0) __hip_atomic_store(&flag[frame], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) __hip_atomic_store(&flag[frame], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an sc1 store)
     } else {
       uint4* mine4 = reinterpret_cast<uint4*>(slabs + ((size_t)frame * parts + part) * kWinBins);
-      for (int q = q_lo + threadIdx.x; q < q_hi; q += kHistThreads) mine4[q] = b4[q];
+      for (int q = q_lo + threadIdx.x; q < q_hi; q += kHistThreads) pl_store_through_u4(mine4 + q, b4[q]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the slab (or the flag) is performed before the ticket is taken
+    // every thread waits until ITS stores have been performed; behind the barrier the whole slab (or the flag) is at the
+    // memory side, and only then is the ticket taken (a relaxed device-scope add: nothing is left for a release to order)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0)
-      scr.any = (__hip_atomic_fetch_add(&tickets[frame], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1) &&
+      scr.any = (__hip_atomic_fetch_add(&tickets[frame], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1) &&
                  !spill2) ? 1 : 0;
     __syncthreads();
     if (scr.any == 0) return;                                // not the last part of this frame (or a spilled one: fallback)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the last arriver: nothing this CU holds of the slabs is reused
     if (__hip_atomic_load(&flag[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // another part spilled
     const uint4* all4 = reinterpret_cast<const uint4*>(slabs + (size_t)frame * parts * kWinBins);
     uint4* w4 = reinterpret_cast<uint4*>(bins);

@@ -2080,6 +2080,19 @@ def check_otsu16_workspace_forms(dev):
             assert np.array_equal(out[form, kind][1], src.reshape(n, -1).min(1)) and np.array_equal(out[form, kind][2], src.reshape(n, -1).max(1))
             assert out[form, kind][3][4] == 1 and out[form, kind][3][0] == 0 and out[form, kind][3][2] == 0
     assert out["slabs", "plain"][3][3] == 1                               # the stray value: that frame's parts spill
+    # the SAME workspace over changing batches (what a pipeline does step after step): nothing of an earlier step's slabs may
+    # be read again -- the last arriver of a frame reads what the other parts wrote through to memory in THIS launch
+    for it in range(12):
+        lo = int(rng.integers(500, 20000))
+        b = rng.integers(lo, lo + int(rng.integers(300, 9000)), (n, h, w)).astype(np.uint16)
+        b[it % n, 100:300, 50:400] += 3000
+        xb = torch.from_numpy(b).to(dev)
+        thr, mn, mx, flag = (torch.full((n,), -9, dtype=torch.int32, device=dev) for _ in range(4))
+        rc = lib.pl_otsu16_ex(xb.data_ptr(), 0, n, h * w, None, None, thr.data_ptr(), mn.data_ptr(), mx.data_ptr(),
+                              flag.data_ptr(), hist.data_ptr(), ws.data_ptr(), need, st)
+        assert rc == 0, lib.pl_last_error()
+        assert not flag.cpu().numpy().any() and np.array_equal(thr.cpu().numpy(), [orc.threshold_otsu(f) for f in b]), it
+        assert np.array_equal(mn.cpu().numpy(), b.reshape(n, -1).min(1)) and np.array_equal(mx.cpu().numpy(), b.reshape(n, -1).max(1))
     for kind in ("plain", "median"):
         assert all(np.array_equal(u, v) for u, v in zip(out["slabs", kind][:3], out["atomics", kind][:3]))
     return 4
