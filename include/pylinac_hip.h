@@ -156,18 +156,6 @@ int pl_otsu16(const void* in, int dtype, int64_t n, int64_t count, const int32_t
 int pl_median3_otsu16(const void* in, void* scratch, int dtype, int64_t n, int h, int w, const int32_t* d_lo,
                       const int32_t* d_hi, int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag,
                       uint32_t* d_hist, void* stream);
-/* The same two entry points with a WORKSPACE for small batches.  When one workgroup per frame would leave most of the chip
- * idle (n * 2 <= CUs) several workgroups share a frame and their partial histograms have to be merged: through d_ws (per-part
- * slabs written with plain stores, one fence and one arrival ticket per workgroup) when it is given, 16-byte aligned and at
- * least pl_otsu16_workspace_bytes(n, count, h) long (h = 0 for pl_otsu16_ex) -- else through device-scope atomics on d_hist,
- * which cost 0.07 ms per step at 32 frames (profiles/r05h_small_batch_kernels.txt).  The query returns 0 when the batch is
- * large enough for one workgroup per frame; d_ws may then be NULL.  Results are identical either way. */
-int64_t pl_otsu16_workspace_bytes(int64_t n, int64_t count, int h);
-int pl_otsu16_ex(const void* in, int dtype, int64_t n, int64_t count, const int32_t* d_lo, const int32_t* d_hi, int32_t* d_thr,
-                 int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist, void* d_ws, int64_t ws_bytes, void* stream);
-int pl_median3_otsu16_ex(const void* in, void* scratch, int dtype, int64_t n, int h, int w, const int32_t* d_lo,
-                         const int32_t* d_hi, int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist,
-                         void* d_ws, int64_t ws_bytes, void* stream);
 /* exact order statistics: out[i][k] = value with 0-based rank d_ranks[k] in frame i
  * (np.percentile call sites: pylinac/core/image.py:899-926, picketfence.py:229-238). */
 int pl_order_stats_from_hist(const uint32_t* d_hist, int dtype, int64_t n, const int64_t* d_ranks,

@@ -69,9 +69,6 @@ SIGNATURES = {
     "pl_otsu_from_hist": ([_p, _i, _l, _p, _p, _p, _p], C.c_int),
     "pl_otsu16": ([_p, _i, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_median3_otsu16": ([_p, _p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
-    "pl_otsu16_workspace_bytes": ([_l, _l, _i], C.c_int64),
-    "pl_otsu16_ex": ([_p, _i, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p], C.c_int),
-    "pl_median3_otsu16_ex": ([_p, _p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p], C.c_int),
     "pl_order_stats_from_hist": ([_p, _i, _l, _p, _i, _p, _p], C.c_int),
     "pl_reduce_axis": ([_p, _i, _l, _i, _i, _i, _i, _p, _p], C.c_int),
     "pl_threshold_colsum_u16": ([_p, _p, _l, _i, _i, _p, _p, _p], C.c_int),

@@ -281,8 +281,7 @@ __global__ void __launch_bounds__(kHistThreads)
 otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h, int w, unsigned flip, int bias,
                      const int32_t* __restrict__ lo_hint, const int32_t* __restrict__ hi_hint, int32_t* __restrict__ thr,
                      int32_t* __restrict__ vmin, int32_t* __restrict__ vmax, int32_t* __restrict__ flag, int parts,
-                     uint32_t* __restrict__ merge /* parts > 1: [n][65536] zeroed; flag zeroed too */,
-                     uint32_t* __restrict__ slabs /* parts > 1, optional: [n][parts][kWinBins], then the tickets [n] zeroed */) {
+                     uint32_t* __restrict__ merge /* parts > 1: [n][65536] zeroed; flag zeroed too */) {
   // ALL of the kernel's LDS is the dynamic block: the bins start at LDS address 0, so a bin's byte offset IS its address
   // (with static arrays in front the compiler spent one add per pixel on the base), the reduction scratch sits behind them
   extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // kWinBins + 1, then OtsuScratch
@@ -301,7 +300,6 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
   const unsigned short* src = in + frame * count;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int klo, khi;   // window = keys [klo, khi] (biased domain)
-  int seen_lo = 0, seen_hi = 65535;   // keys the sample saw (the slab merge publishes only the bins around them)
   if (lo_hint) {
     klo = lo_hint[frame] + bias;
     khi = hi_hint[frame] + bias;
@@ -316,11 +314,18 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && count >= 8) {
       const int64_t nvec = count / 8;
       const uint4* vsrc = reinterpret_cast<const uint4*>(src);
-      for (int64_t blk = threadIdx.x >> 7; blk * 2048 < nvec; blk += kHistThreads >> 7) {
-        const int64_t idx = blk * 2048 + (threadIdx.x & 127);
-        if (idx < nvec) {
-          const uint4 q = vsrc[idx];
-          const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+      // eight of a thread's sample vectors are in flight together (one load per trip made every workgroup wait out eight
+      // memory round trips before it could place its window: 8.5 us, profiles/r05n_otsu_phases.txt)
+      for (int64_t blk0 = threadIdx.x >> 7; blk0 * 2048 < nvec; blk0 += 8 * (kHistThreads >> 7)) {
+        uint4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t idx = (blk0 + u * (kHistThreads >> 7)) * 2048 + (threadIdx.x & 127);
+          q[u] = vsrc[idx < nvec ? idx : 0];                            // (a vector of the frame either way)
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const unsigned wds[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) { see(wds[k] & 0xffffu); see(wds[k] >> 16); }
         }
@@ -335,7 +340,6 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     for (int k = 0; k < kHistThreads / 64; ++k) { mn = s_lo[k] < mn ? s_lo[k] : mn; mx = s_hi[k] > mx ? s_hi[k] : mx; }
     __syncthreads();
     if (mx < mn) { mn = 0; mx = 0; }
-    seen_lo = mn; seen_hi = mx;
     const int slack = kWinBins - (mx - mn + 1);
     klo = mn - (slack > 0 ? slack / 2 : 0);
     if (klo < 0) klo = 0;
@@ -468,56 +472,6 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
       return;
     }
     if (threadIdx.x == 0) flag[frame] = 0;
-  } else if (slabs) {
-    // Slab merge (pl_*_ex with a workspace): every part PUBLISHES the populated stretch of its window with 16-byte
-    // write-through stores into a slab of its own, waits for them, and takes an arrival ticket; the part that arrives last
-    // adds the other slabs to the window it still holds in LDS and runs the scan.  The table form below sends every non-empty
-    // bin of every part through a device-scope atomic, and those execute at the memory side (the XCDs' L2s are not coherent):
-    // 2 x 10^6 of them per 32-frame step, 0.07 ms of the stage's 0.09 (r05h: returning or not, fenced or not).
-    // The stretch: the bins between the sample's extrema +- 256, whole quads -- identical in every part of a frame (same
-    // sample); a part that holds a count outside it (the sample missed a value by more than that) declares the frame spilled.
-    int q_lo = (seen_lo - 256 - klo) >> 2, q_hi = (seen_hi + 257 - klo + 3) >> 2;
-    q_lo = q_lo < 0 ? 0 : q_lo;
-    q_hi = q_hi > (range + 3) >> 2 ? (range + 3) >> 2 : q_hi;
-    int stray = 0;
-    for (int i = threadIdx.x; i < range; i += kHistThreads)
-      if ((i < 4 * q_lo || i >= 4 * q_hi) && bins[i] != 0u) stray = 1;
-    __syncthreads();                                         // (every thread has read scr.any for `spilled`)
-    if (stray) scr.any = 1;
-    __syncthreads();
-    const bool spill2 = spilled || scr.any != 0;
-    uint32_t* const tickets = slabs + (size_t)gridDim.x * kWinBins;         // gridDim.x = frames x parts
-    const uint4* b4 = reinterpret_cast<const uint4*>(bins);
-    if (spill2) {
-      if (threadIdx.x == 0) __hip_atomic_store(&flag[frame], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an sc1 store)
-    } else {
-      uint4* mine4 = reinterpret_cast<uint4*>(slabs + ((size_t)frame * parts + part) * kWinBins);
-      for (int q = q_lo + threadIdx.x; q < q_hi; q += kHistThreads) pl_store_through_u4(mine4 + q, b4[q]);
-    }
-    // every thread waits until ITS stores have been performed; behind the barrier the whole slab (or the flag) is at the
-    // memory side, and only then is the ticket taken (a relaxed device-scope add: nothing is left for a release to order)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0)
-      scr.any = (__hip_atomic_fetch_add(&tickets[frame], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1) &&
-                 !spill2) ? 1 : 0;
-    __syncthreads();
-    if (scr.any == 0) return;                                // not the last part of this frame (or a spilled one: fallback)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the last arriver: nothing this CU holds of the slabs is reused
-    if (__hip_atomic_load(&flag[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // another part spilled
-    const uint4* all4 = reinterpret_cast<const uint4*>(slabs + (size_t)frame * parts * kWinBins);
-    uint4* w4 = reinterpret_cast<uint4*>(bins);
-    for (int q = q_lo + threadIdx.x; q < q_hi; q += kHistThreads) {
-      uint4 v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = all4[(size_t)(k < parts ? k : part) * (kWinBins / 4) + q];   // (parts <= 8)
-      uint4 acc = w4[q];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (k < parts && k != part) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
-      w4[q] = acc;
-    }
-    __syncthreads();
   } else {
     uint32_t* table = merge + frame * 65536;
     unsigned seen = 0;
@@ -937,11 +891,16 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
     mx = k > mx ? k : mx;
   };
   if (vec) {
-    for (int64_t blk = threadIdx.x >> 7; blk * 2048 < nvec; blk += kHistThreads >> 7) {
-      const int64_t idx = blk * 2048 + (threadIdx.x & 127);
-      if (idx < nvec) {
-        const uint4 q = vsrc[idx];
-        const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+    for (int64_t blk0 = threadIdx.x >> 7; blk0 * 2048 < nvec; blk0 += 8 * (kHistThreads >> 7)) {   // eight loads in flight (as otsu16_window_kernel)
+      uint4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t idx = (blk0 + u * (kHistThreads >> 7)) * 2048 + (threadIdx.x & 127);
+        q[u] = vsrc[idx < nvec ? idx : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned wds[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) { see(wds[k] & 0xffffu); see(wds[k] >> 16); }
       }
@@ -1288,23 +1247,10 @@ extern "C" int pl_order_stats_from_hist(const uint32_t* d_hist, int dtype, int64
 int pl_median3_gated(const void* in, void* out, int is_signed, int64_t n, int h, int w, const int32_t* d_gate, hipStream_t st);
 
 namespace {
-// how many workgroups share a frame of a small batch (one per frame would leave most of the chip idle)
-int otsu16_parts(int64_t n, int64_t count, int h, bool med3) {
-  int parts = 1;
-  const int cus = pl_cu_count();
-  while (parts < 8 && n * parts * 2 <= cus) parts *= 2;
-  if (med3) { const int row_groups = (h + 31) / 32; while (parts > 1 && parts > row_groups) parts /= 2; }
-  if (count < 65536) parts = 1;
-  return parts;
-}
-size_t otsu16_ws_bytes(int64_t n, int parts) {
-  return parts > 1 ? ((size_t)n * parts * kWinBins + (size_t)n) * sizeof(uint32_t) : 0;
-}
-
 template <typename T, bool MED3>
 int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t count, int h, int w, const int32_t* d_lo,
                   const int32_t* d_hi, int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist,
-                  void* d_ws, int64_t ws_bytes, hipStream_t st, const char* who) {
+                  hipStream_t st, const char* who) {
   const unsigned flip = dtype == PL_I16 ? 0x8000u : 0u;
   const int bias = dtype == PL_I16 ? 32768 : 0;
   const size_t lds = kOtsuLds;                                  // bins + the spare bin of the branch-free tally + scratch
@@ -1317,25 +1263,22 @@ int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t c
     }
     attr = true;
   }
-  // small batches: several workgroups per frame, merged through per-part slabs in the caller's workspace (pl_*_ex) or, without
-  // one, through device-scope atomics on the table d_hist (which then starts at zero, like the flags)
-  int parts = otsu16_parts(n, count, h, MED3);
-  uint32_t* slabs = nullptr;
+  // small batches: several workgroups per frame (the table d_hist merges them; it and the flags start at zero)
+  int parts = 1;
+  const int cus = pl_cu_count();
+  while (parts < 8 && n * parts * 2 <= cus) parts *= 2;
+  if (MED3) { const int row_groups = (h + 31) / 32; while (parts > 1 && parts > row_groups) parts /= 2; }
+  if (count < 65536) parts = 1;
   if (parts > 1) {
-    hipError_t e = hipMemsetAsync(d_flag, 0, (size_t)n * sizeof(int32_t), st);
-    if (d_ws && (reinterpret_cast<uintptr_t>(d_ws) & 15) == 0 && ws_bytes >= (int64_t)otsu16_ws_bytes(n, parts)) {
-      slabs = static_cast<uint32_t*>(d_ws);
-      if (e == hipSuccess) e = hipMemsetAsync(slabs + (size_t)n * parts * kWinBins, 0, (size_t)n * sizeof(uint32_t), st);   // the tickets
-    } else if (e == hipSuccess) {
-      e = hipMemsetAsync(d_hist, 0, (size_t)n * 65536 * sizeof(uint32_t), st);
-    }
+    hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)n * 65536 * sizeof(uint32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, (size_t)n * sizeof(int32_t), st);
     if (e != hipSuccess) { pl_set_error("%s: memset: %s", who, hipGetErrorString(e)); return PL_ERR_HIP; }
   }
 #ifdef PL_OTSU_FULL_ALWAYS                                    // development variant: every frame through the full-range kernel
   (void)hipMemsetAsync(d_flag, 0, (size_t)n * sizeof(int32_t), st);
 #else
   hipLaunchKernelGGL((otsu16_window_kernel<T, MED3>), dim3((unsigned)(n * parts)), dim3(kHistThreads), lds, st,
-                     (const unsigned short*)in, count, h, w, flip, bias, d_lo, d_hi, d_thr, d_min, d_max, d_flag, parts, d_hist, slabs);
+                     (const unsigned short*)in, count, h, w, flip, bias, d_lo, d_hi, d_thr, d_min, d_max, d_flag, parts, d_hist);
 #endif
   // frames too wide for the window: the full-range kernel (packed 16-bit counters), every workgroup gated by d_flag; the
   // medians are computed on the fly again for exactly those frames.  (Round 3: gated median plane + two-part histogram +
@@ -1374,33 +1317,21 @@ int otsu16_launch(const void* in, void* scratch, int dtype, int64_t n, int64_t c
 }
 }  // namespace
 
-extern "C" int64_t pl_otsu16_workspace_bytes(int64_t n, int64_t count, int h) {
-  if (n <= 0 || count <= 0) return 0;
-  return (int64_t)otsu16_ws_bytes(n, otsu16_parts(n, count, h > 0 ? h : 0, h > 0));
-}
-
-extern "C" int pl_otsu16_ex(const void* in, int dtype, int64_t n, int64_t count, const int32_t* d_lo, const int32_t* d_hi,
-                            int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist, void* d_ws,
-                            int64_t ws_bytes, void* stream) {
+extern "C" int pl_otsu16(const void* in, int dtype, int64_t n, int64_t count, const int32_t* d_lo, const int32_t* d_hi,
+                         int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist,
+                         void* stream) {
   PL_REQUIRE(in && d_thr && d_flag && d_hist, "null pointer");
   PL_REQUIRE((d_lo == nullptr) == (d_hi == nullptr), "give both bounds or neither");
   PL_REQUIRE(n >= 0 && n <= 0x7fffffffLL / 8 && count > 0, "bad shape");
   PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
-  PL_REQUIRE(ws_bytes >= 0 && (d_ws != nullptr || ws_bytes == 0), "workspace pointer and size go together");
   if (n == 0) return PL_OK;
   return otsu16_launch<unsigned short, false>(in, nullptr, dtype, n, count, 0, 0, d_lo, d_hi, d_thr, d_min, d_max, d_flag, d_hist,
-                                              d_ws, ws_bytes, (hipStream_t)stream, "pl_otsu16");
+                                              (hipStream_t)stream, "pl_otsu16");
 }
 
-extern "C" int pl_otsu16(const void* in, int dtype, int64_t n, int64_t count, const int32_t* d_lo, const int32_t* d_hi,
-                         int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag, uint32_t* d_hist,
-                         void* stream) {
-  return pl_otsu16_ex(in, dtype, n, count, d_lo, d_hi, d_thr, d_min, d_max, d_flag, d_hist, nullptr, 0, stream);
-}
-
-extern "C" int pl_median3_otsu16_ex(const void* in, void* scratch, int dtype, int64_t n, int h, int w, const int32_t* d_lo,
-                                    const int32_t* d_hi, int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag,
-                                    uint32_t* d_hist, void* d_ws, int64_t ws_bytes, void* stream) {
+extern "C" int pl_median3_otsu16(const void* in, void* scratch, int dtype, int64_t n, int h, int w, const int32_t* d_lo,
+                                 const int32_t* d_hi, int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag,
+                                 uint32_t* d_hist, void* stream) {
   PL_REQUIRE(in && scratch && d_thr && d_flag && d_hist, "null pointer");
   PL_REQUIRE(in != scratch, "scratch must be a distinct buffer");
   PL_REQUIRE((d_lo == nullptr) == (d_hi == nullptr), "give both bounds or neither");
@@ -1408,18 +1339,11 @@ extern "C" int pl_median3_otsu16_ex(const void* in, void* scratch, int dtype, in
   PL_REQUIRE(dtype == PL_U16 || dtype == PL_I16, "16-bit integer frames only");
   PL_REQUIRE(pl_median3_rows_covers(in, h, w) && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0,
              "needs h > 1, width % 8 == 0 and 16-byte aligned frames (run pl_median2d + pl_otsu16 otherwise)");
-  PL_REQUIRE(ws_bytes >= 0 && (d_ws != nullptr || ws_bytes == 0), "workspace pointer and size go together");
   if (n == 0) return PL_OK;
   const int64_t count = (int64_t)h * w;
   return dtype == PL_I16
              ? otsu16_launch<short, true>(in, scratch, dtype, n, count, h, w, d_lo, d_hi, d_thr, d_min, d_max, d_flag, d_hist,
-                                          d_ws, ws_bytes, (hipStream_t)stream, "pl_median3_otsu16")
+                                          (hipStream_t)stream, "pl_median3_otsu16")
              : otsu16_launch<unsigned short, true>(in, scratch, dtype, n, count, h, w, d_lo, d_hi, d_thr, d_min, d_max, d_flag,
-                                                   d_hist, d_ws, ws_bytes, (hipStream_t)stream, "pl_median3_otsu16");
-}
-
-extern "C" int pl_median3_otsu16(const void* in, void* scratch, int dtype, int64_t n, int h, int w, const int32_t* d_lo,
-                                 const int32_t* d_hi, int32_t* d_thr, int32_t* d_min, int32_t* d_max, int32_t* d_flag,
-                                 uint32_t* d_hist, void* stream) {
-  return pl_median3_otsu16_ex(in, scratch, dtype, n, h, w, d_lo, d_hi, d_thr, d_min, d_max, d_flag, d_hist, nullptr, 0, stream);
+                                                   d_hist, (hipStream_t)stream, "pl_median3_otsu16");
 }

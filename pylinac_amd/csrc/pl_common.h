@@ -172,21 +172,6 @@ __device__ __forceinline__ void pl_lds_add_abs(unsigned byte_addr, unsigned v) {
 }
 __device__ __forceinline__ unsigned pl_lds_base(const void* lds_ptr) { return (unsigned)reinterpret_cast<uintptr_t>(lds_ptr); }
 
-// A 16-byte WRITE-THROUGH store (sc0 sc1): performed at the memory side, the line dropped from this XCD's L2.  What one
-// workgroup publishes for a workgroup on another XCD goes out this way and is waited for with s_waitcnt vmcnt(0) before the
-// arrival ticket is taken: plain stores need an agent-scope release fence instead, which writes back EVERY dirty line of the
-// XCD's L2 -- once per publishing workgroup (MI355X_MICROARCH.md, "publish-large": 3.0 against 8.2 us for 64 KB; the Otsu
-// slabs, 32 workgroups per XCD publishing 60-150 KB each: 94 -> 188 us per 32-frame stage with the fence, r05l).
-__device__ __forceinline__ void pl_store_through_u4(uint4* p, uint4 v) {
-#ifdef PL_HIPEMU
-  *p = v;
-#else
-  typedef unsigned pl_u4 __attribute__((ext_vector_type(4)));
-  const pl_u4 x = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
-#endif
-}
-
 // A pointer into memory the kernel never writes, read at wave-uniform addresses: through the CONSTANT address space the
 // compiler uses scalar loads (s_load: no vector memory instruction, no place in the in-order vmcnt queue).  A plain
 // `const T* __restrict__` read inside a loop that also stores came out as a vector load followed by s_waitcnt vmcnt(0).

@@ -307,21 +307,10 @@ def otsu16(frames: torch.Tensor, lo: torch.Tensor | None = None, hi: torch.Tenso
     thr = torch.empty(n, dtype=torch.int32, device=dev)
     mn, mx, flag = torch.empty_like(thr), torch.empty_like(thr), torch.empty_like(thr)
     hist = torch.empty((n, 65536), dtype=torch.int32, device=dev) if hist is None else hist
-    ws, ws_ptr, ws_bytes = otsu16_workspace(n, x[0].numel(), 0, dev)
-    check(_lib.load().pl_otsu16_ex(x.data_ptr(), _dt(x), n, x[0].numel(), None if lo is None else lo.data_ptr(),
-                                   None if hi is None else hi.data_ptr(), thr.data_ptr(), mn.data_ptr(), mx.data_ptr(),
-                                   flag.data_ptr(), hist.data_ptr(), ws_ptr, ws_bytes, _stream()), "pl_otsu16_ex")
+    check(_lib.load().pl_otsu16(x.data_ptr(), _dt(x), n, x[0].numel(), None if lo is None else lo.data_ptr(),
+                                None if hi is None else hi.data_ptr(), thr.data_ptr(),
+                                mn.data_ptr(), mx.data_ptr(), flag.data_ptr(), hist.data_ptr(), _stream()), "pl_otsu16")
     return thr, mn, mx
-
-
-def otsu16_workspace(n: int, count: int, h: int, device):
-    """The small-batch workspace of ``pl_otsu16_ex`` / ``pl_median3_otsu16_ex`` (``h = 0`` for the former) ->
-    (tensor or None, pointer or None, bytes): nothing for batches with one workgroup per frame."""
-    need = int(_lib.load().pl_otsu16_workspace_bytes(n, count, h))
-    if need <= 0:
-        return None, None, 0
-    ws = torch.empty(need, dtype=torch.uint8, device=device)
-    return ws, ws.data_ptr(), need
 
 
 def median3_otsu16(frames: torch.Tensor, hist: torch.Tensor | None = None, scratch: torch.Tensor | None = None):
@@ -338,10 +327,9 @@ def median3_otsu16(frames: torch.Tensor, hist: torch.Tensor | None = None, scrat
     mn, mx, flag = torch.empty_like(thr), torch.empty_like(thr), torch.empty_like(thr)
     hist = torch.empty((n, 65536), dtype=torch.int32, device=dev) if hist is None else hist
     scratch = torch.empty_like(x) if scratch is None else scratch
-    ws, ws_ptr, ws_bytes = otsu16_workspace(n, h * w, h, dev)
-    check(_lib.load().pl_median3_otsu16_ex(x.data_ptr(), scratch.data_ptr(), _dt(x), n, h, w, None, None, thr.data_ptr(),
-                                           mn.data_ptr(), mx.data_ptr(), flag.data_ptr(), hist.data_ptr(), ws_ptr, ws_bytes,
-                                           _stream()), "pl_median3_otsu16_ex")
+    check(_lib.load().pl_median3_otsu16(x.data_ptr(), scratch.data_ptr(), _dt(x), n, h, w, None, None, thr.data_ptr(),
+                                        mn.data_ptr(), mx.data_ptr(), flag.data_ptr(), hist.data_ptr(), _stream()),
+          "pl_median3_otsu16")
     return thr, mn, mx, flag
 
 

@@ -86,18 +86,8 @@ class EpidPipeline:
             props=torch.empty((n, 6, 1), dtype=torch.float64, device=dev),
             status=torch.empty(n, dtype=torch.int32, device=dev),
         )
-        self._ws = {}                                          # small-batch workspaces of the Otsu stage, by (frames, pixels, rows)
         self.wts, self.host_wts, self.radius = ops._device_weights(self.sigma, dev)
         self.prm = ops.make_peak_params(w, fwxm_height=self.fwxm_height / 100, max_number=1)
-
-    def _otsu_ws(self, m: int, count: int, h: int):
-        """(pointer, bytes) of the workspace pl_otsu16_ex / pl_median3_otsu16_ex merge a small batch's partial histograms
-        through (allocated once per batch shape; (None, 0) when every frame has a workgroup of its own)"""
-        key = (m, count, h)
-        if key not in self._ws:
-            self._ws[key] = ops.otsu16_workspace(m, count, h, self.device)
-        _, ptr, nbytes = self._ws[key]
-        return ptr, nbytes
 
     def run(self, frames: torch.Tensor, events: dict | None = None) -> EpidResult:
         """One pass over a resident batch.  ``events``: optional {stage: [(start, stop), ...]} sink;
@@ -159,10 +149,9 @@ class EpidPipeline:
                 # Image.filter(3, "median") is never materialised: the Otsu histogram and the threshold + column sums each
                 # compute the 3x3 medians of the Gaussian plane on the fly (two reads of that plane instead of median write +
                 # two reads of the median plane); buf_a is scratch for frames the one-pass Otsu window cannot hold
-                stage("median3_otsu16", lambda: lib.pl_median3_otsu16_ex(bp + o, ap + o, U16, m, h, w, None, None, thr + lo * 4,
-                                                                         vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
-                                                                         hist + lo * 65536 * 4, *self._otsu_ws(m, h * w, h), st),
-                      stream)
+                stage("median3_otsu16", lambda: lib.pl_median3_otsu16(bp + o, ap + o, U16, m, h, w, None, None, thr + lo * 4,
+                                                                      vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
+                                                                      hist + lo * 65536 * 4, st), stream)
                 if not self.fused_tail:
                     stage("median3_threshold_colsum", lambda: lib.pl_median3_threshold_colsum_u16(
                         bp + o, op + o, m, h, w, thr + lo * 4, colsum + lo * w * 8, st), stream)
@@ -178,9 +167,9 @@ class EpidPipeline:
                 return
             stage("median3", lambda: lib.pl_median2d(bp + o, ap + o, U16, m, h, w, self.median_size, st), stream)
             med = ap + o
-            stage("otsu16", lambda: lib.pl_otsu16_ex(med, U16, m, h * w, None, None, thr + lo * 4,
-                                                     vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
-                                                     hist + lo * 65536 * 4, *self._otsu_ws(m, h * w, 0), st), stream)
+            stage("otsu16", lambda: lib.pl_otsu16(med, U16, m, h * w, None, None, thr + lo * 4,
+                                                  vmin + lo * 4, vmax + lo * 4, flag + lo * 4,
+                                                  hist + lo * 65536 * 4, st), stream)
             stage("threshold_colsum", lambda: lib.pl_threshold_colsum_u16(med, op + o, m, h, w, thr + lo * 4,
                                                                           colsum + lo * w * 8, st), stream)
             separate_tail()

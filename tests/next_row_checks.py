@@ -2035,64 +2035,3 @@ def check_bb_sweep_run_table_tiers(dev, full=True):
     assert torch.equal(res["level"], lv["level"]) and torch.equal(res["xy"][:, 0], lv["xy"][:, 0])
     assert torch.equal(alone["xy"][:3, 0], lv["xy"][:3, 0])
     return 4
-
-
-def check_otsu16_workspace_forms(dev):
-    """pl_otsu16_ex / pl_median3_otsu16_ex on a small batch (several workgroups per frame): the slab merge through the
-    workspace == the atomics merge without one == skimage's threshold; a frame with a stray value outside the published
-    stretch and a full-range frame take the fallback in both forms."""
-    from scipy import ndimage
-
-    from pylinac_amd import _lib, ops
-    from oracle import pylinac_oracle as orc
-
-    lib = _lib.load()
-    rng = np.random.default_rng(21)
-    n, h, w = 6, 512, 512
-    a = rng.integers(4000, 9000, (n, h, w)).astype(np.uint16)
-    yy, xx = np.mgrid[0:h, 0:w]
-    a[1] = (6000 + 2500 * np.exp(-((yy - 250) ** 2 + (xx - 260) ** 2) / 9000.0) + rng.integers(0, 30, (h, w))).astype(np.uint16)
-    a[2] = np.where(rng.random((h, w)) < 0.4, 500, 500 + 38000)         # two values a whole window apart
-    a[3, 3, 700 % w] = 30000                                             # a stray value, in a block the sample skips
-    a[4] = rng.integers(0, 65536, (h, w))                                # full range: the packed-counter kernel
-    x = torch.from_numpy(a).to(dev)
-    st = torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else None
-    need = int(lib.pl_otsu16_workspace_bytes(n, h * w, 0))
-    assert need > 0 and int(lib.pl_otsu16_workspace_bytes(n, h * w, h)) == need
-    ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    hist = torch.empty((n, 65536), dtype=torch.int32, device=dev)
-    scratch = torch.empty_like(x)
-    med = np.stack([ndimage.median_filter(f, size=3) for f in a])
-    out = {}
-    for form, (p, nb) in (("slabs", (ws.data_ptr(), need)), ("atomics", (None, 0))):
-        for kind in ("plain", "median"):
-            thr, mn, mx, flag = (torch.full((n,), -9, dtype=torch.int32, device=dev) for _ in range(4))
-            if kind == "plain":
-                rc = lib.pl_otsu16_ex(x.data_ptr(), 0, n, h * w, None, None, thr.data_ptr(), mn.data_ptr(), mx.data_ptr(),
-                                      flag.data_ptr(), hist.data_ptr(), p, nb, st)
-            else:
-                rc = lib.pl_median3_otsu16_ex(x.data_ptr(), scratch.data_ptr(), 0, n, h, w, None, None, thr.data_ptr(), mn.data_ptr(),
-                                              mx.data_ptr(), flag.data_ptr(), hist.data_ptr(), p, nb, st)
-            assert rc == 0, lib.pl_last_error()
-            out[form, kind] = tuple(t.cpu().numpy() for t in (thr, mn, mx, flag))
-            src = a if kind == "plain" else med
-            assert np.array_equal(out[form, kind][0], [orc.threshold_otsu(f) for f in src]), (form, kind)
-            assert np.array_equal(out[form, kind][1], src.reshape(n, -1).min(1)) and np.array_equal(out[form, kind][2], src.reshape(n, -1).max(1))
-            assert out[form, kind][3][4] == 1 and out[form, kind][3][0] == 0 and out[form, kind][3][2] == 0
-    assert out["slabs", "plain"][3][3] == 1                               # the stray value: that frame's parts spill
-    # the SAME workspace over changing batches (what a pipeline does step after step): nothing of an earlier step's slabs may
-    # be read again -- the last arriver of a frame reads what the other parts wrote through to memory in THIS launch
-    for it in range(12):
-        lo = int(rng.integers(500, 20000))
-        b = rng.integers(lo, lo + int(rng.integers(300, 9000)), (n, h, w)).astype(np.uint16)
-        b[it % n, 100:300, 50:400] += 3000
-        xb = torch.from_numpy(b).to(dev)
-        thr, mn, mx, flag = (torch.full((n,), -9, dtype=torch.int32, device=dev) for _ in range(4))
-        rc = lib.pl_otsu16_ex(xb.data_ptr(), 0, n, h * w, None, None, thr.data_ptr(), mn.data_ptr(), mx.data_ptr(),
-                              flag.data_ptr(), hist.data_ptr(), ws.data_ptr(), need, st)
-        assert rc == 0, lib.pl_last_error()
-        assert not flag.cpu().numpy().any() and np.array_equal(thr.cpu().numpy(), [orc.threshold_otsu(f) for f in b]), it
-        assert np.array_equal(mn.cpu().numpy(), b.reshape(n, -1).min(1)) and np.array_equal(mx.cpu().numpy(), b.reshape(n, -1).max(1))
-    for kind in ("plain", "median"):
-        assert all(np.array_equal(u, v) for u, v in zip(out["slabs", kind][:3], out["atomics", kind][:3]))
-    return 4

@@ -322,44 +322,6 @@ def test_emu_full_range_otsu_counter_overflow(emu):
         np.testing.assert_array_equal(t2, [orc.threshold_otsu(f) for f in b])
         np.testing.assert_array_equal(mn2, b.min(1))
         np.testing.assert_array_equal(mx2, b.max(1))
-        # ... and the same frames through the WORKSPACE forms (pl_*_ex: per-part slabs + arrival tickets instead of device-scope
-        # atomics on the table): plain and median, a frame with two values a whole window apart (every part's counts lie in
-        # the stretch around the sample's extrema), and the full-range frames above (every part spills: the fallback)
-        need = emu.pl_otsu16_workspace_bytes(2, h * w + 5, 0)
-        assert need == (2 * 8 * 38912 + 2) * 4 and emu.pl_otsu16_workspace_bytes(1000, h * w, 0) == 0
-        raw = np.zeros(need + 16, np.uint8)
-        ws = C.c_void_p((raw.ctypes.data + 15) & ~15)
-        t3, mn3, mx3, f3 = (np.full(2, -7, np.int32) for _ in range(4))
-        _ok(emu, emu.pl_otsu16_ex(_p(b), code, 2, h * w + 5, None, None, _p(t3), _p(mn3), _p(mx3), _p(f3), _p(hist), ws, need, None))
-        assert not f3.any() and np.array_equal(t3, t2) and np.array_equal(mn3, mn2) and np.array_equal(mx3, mx2)
-        b2 = b.copy()
-        b2[0, 1500] = 15000 - off          # inside the LDS window, outside the published stretch, in a block the sample skips
-        _ok(emu, emu.pl_otsu16_ex(_p(b2), code, 2, h * w + 5, None, None, _p(t3), _p(mn3), _p(mx3), _p(f3), _p(hist), ws, need, None))
-        assert f3.tolist() == [1, 0]                                                # that frame took the fallback
-        np.testing.assert_array_equal(t3, [orc.threshold_otsu(f) for f in b2])
-        np.testing.assert_array_equal(mx3, b2.max(1))
-        bm = np.ascontiguousarray(b[:, : h * w].reshape(2, h, w))
-        bm[1] = np.where(rng.random((h, w)) < 0.5, 3000, 3000 + 38000) - off       # two values, 38 000 apart
-        medb = np.stack([ndimage.median_filter(f, size=3) for f in bm])
-        needm = emu.pl_otsu16_workspace_bytes(2, h * w, h)
-        assert 0 < needm <= need
-        sc2 = np.zeros_like(bm)
-        for give in (True, False):                                                  # with the workspace / without (atomics)
-            t4, mn4, mx4, f4 = (np.full(2, -7, np.int32) for _ in range(4))
-            _ok(emu, emu.pl_median3_otsu16_ex(_p(bm), _p(sc2), code, 2, h, w, None, None, _p(t4), _p(mn4), _p(mx4), _p(f4), _p(hist),
-                                              ws if give else None, needm if give else 0, None))
-            assert not f4.any()
-            np.testing.assert_array_equal(t4, [orc.threshold_otsu(f) for f in medb])
-            np.testing.assert_array_equal(mn4, medb.reshape(2, -1).min(1))
-            np.testing.assert_array_equal(mx4, medb.reshape(2, -1).max(1))
-        needa = emu.pl_otsu16_workspace_bytes(n, h * w, 0)
-        rawa = np.zeros(needa + 16, np.uint8)
-        thr5, mn5, mx5, flag5 = (np.zeros(n, np.int32) for _ in range(4))
-        _ok(emu, emu.pl_otsu16_ex(_p(a), code, n, h * w, None, None, _p(thr5), _p(mn5), _p(mx5), _p(flag5), _p(hist),
-                                  C.c_void_p((rawa.ctypes.data + 15) & ~15), needa, None))
-        assert flag5.all()
-        np.testing.assert_array_equal(thr5, [orc.threshold_otsu(f) for f in a])
-        assert emu.pl_otsu16_ex(_p(a), code, n, h * w, None, None, _p(thr5), _p(mn5), _p(mx5), _p(flag5), _p(hist), None, 64, None) == 1
         med = np.stack([ndimage.median_filter(f, size=3) for f in a])
         scratch = np.zeros_like(a)
         _ok(emu, emu.pl_median3_otsu16(_p(a), _p(scratch), code, n, h, w, None, None, _p(thr), _p(mn), _p(mx), _p(flag), _p(hist), None))
@@ -1076,12 +1038,6 @@ def test_emulated_bb_sweep_run_table_tiers(emulated):
     import next_row_checks as checks
 
     assert checks.check_bb_sweep_run_table_tiers(emulated, full=False) == 2
-
-
-def test_emulated_otsu16_workspace_forms(emulated):
-    import next_row_checks as checks
-
-    assert checks.check_otsu16_workspace_forms(emulated) == 4
 
 
 def test_emulated_pack_columns(emulated):

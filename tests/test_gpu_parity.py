@@ -2053,11 +2053,3 @@ def test_fwhm_batch_vs_single(golden, dev):
         want = profile.SingleProfile(profs[i].copy()).fwxm_data(50)
         for k in ("left index (exact)", "right index (exact)", "center value (@rounded)", "width (exact)"):
             assert np.isclose(d[k][i], want[k], rtol=1e-9, atol=1e-9), (i, k)
-
-
-@pytest.mark.gpu
-def test_otsu16_workspace_forms(dev):
-    """small batches: the slab merge (workspace) and the atomics merge give skimage's thresholds, spills included"""
-    import next_row_checks as checks
-
-    assert checks.check_otsu16_workspace_forms(dev) == 4
