@@ -314,18 +314,11 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && count >= 8) {
       const int64_t nvec = count / 8;
       const uint4* vsrc = reinterpret_cast<const uint4*>(src);
-      // eight of a thread's sample vectors are in flight together (one load per trip made every workgroup wait out eight
-      // memory round trips before it could place its window: 8.5 us, profiles/r05n_otsu_phases.txt)
-      for (int64_t blk0 = threadIdx.x >> 7; blk0 * 2048 < nvec; blk0 += 8 * (kHistThreads >> 7)) {
-        uint4 q[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int64_t idx = (blk0 + u * (kHistThreads >> 7)) * 2048 + (threadIdx.x & 127);
-          q[u] = vsrc[idx < nvec ? idx : 0];                            // (a vector of the frame either way)
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const unsigned wds[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+      for (int64_t blk = threadIdx.x >> 7; blk * 2048 < nvec; blk += kHistThreads >> 7) {
+        const int64_t idx = blk * 2048 + (threadIdx.x & 127);
+        if (idx < nvec) {
+          const uint4 q = vsrc[idx];
+          const unsigned wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) { see(wds[k] & 0xffffu); see(wds[k] >> 16); }
         }
@@ -891,16 +884,11 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
     mx = k > mx ? k : mx;
   };
   if (vec) {
-    for (int64_t blk0 = threadIdx.x >> 7; blk0 * 2048 < nvec; blk0 += 8 * (kHistThreads >> 7)) {   // eight loads in flight (as otsu16_window_kernel)
-      uint4 q[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t idx = (blk0 + u * (kHistThreads >> 7)) * 2048 + (threadIdx.x & 127);
-        q[u] = vsrc[idx < nvec ? idx : 0];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const unsigned wds[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+    for (int64_t blk = threadIdx.x >> 7; blk * 2048 < nvec; blk += kHistThreads >> 7) {
+      const int64_t idx = blk * 2048 + (threadIdx.x & 127);
+      if (idx < nvec) {
+        const uint4 q = vsrc[idx];
+        const unsigned wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) { see(wds[k] & 0xffffu); see(wds[k] >> 16); }
       }
