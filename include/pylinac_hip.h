@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_ABI_VERSION 2
+#define PL_ABI_VERSION 3
 
 typedef enum pl_status {
   PL_OK = 0,

@@ -40,6 +40,8 @@ PL_U16, PL_I16, PL_F32, PL_F64, PL_U8, PL_I32, PL_I64 = 0, 1, 2, 3, 4, 5, 6
 PL_SUM, PL_MEAN, PL_MAX, PL_MIN = 0, 1, 2, 3
 PL_SORT = {"prominences": 0, "peak_heights": 1, "widths": 2}
 
+ABI_VERSION = 3   # include/pylinac_hip.h: PL_ABI_VERSION (3: pl_pf_measure gained exact_deviation; six round-5 entry points)
+
 _p = C.c_void_p
 _i = C.c_int
 _l = C.c_int64
@@ -196,8 +198,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.pl_abi_version() != 2:
-        raise PylinacHipError(f"ABI version mismatch: library reports {lib.pl_abi_version()}")
+    if lib.pl_abi_version() != ABI_VERSION:
+        raise PylinacHipError(f"ABI version mismatch: library reports {lib.pl_abi_version()}, this package binds {ABI_VERSION}")
     _lib = lib
     return lib
 

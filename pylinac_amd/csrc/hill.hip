@@ -429,7 +429,7 @@ hill_fit_kernel(const double* __restrict__ xs, const double* __restrict__ ys, co
         for (int i = 0; i < m; ++i) fvec[i * S] = wa4[i * S];
         xnorm = hill_enorm(n, wa2, 1);
         fnorm = fnorm1;
-        last_step = pnorm / xnorm;
+        last_step = xnorm > 0.0 ? pnorm / xnorm : (pnorm == 0.0 ? 0.0 : __longlong_as_double(0x7ff0000000000000LL));   // all scaled parameters zero: never NaN
         ++iter;
       }
       const bool small_red = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
@@ -723,7 +723,7 @@ hill_fit_group_kernel(const double* __restrict__ xs, const double* __restrict__ 
           for (int i = 0; i < m; ++i) fvec[i] = wa4[i];
           xnorm = hill_enorm(n, wa2, 1);
           fnorm = fnorm1;
-          last_step = pnorm / xnorm;
+          last_step = xnorm > 0.0 ? pnorm / xnorm : (pnorm == 0.0 ? 0.0 : __longlong_as_double(0x7ff0000000000000LL));   // all scaled parameters zero: never NaN
           ++iter;
         }
         const bool small_red = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;

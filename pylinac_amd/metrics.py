@@ -26,12 +26,39 @@ _DISK_CONDITIONS = ("is_right_size_bb", "is_round", "is_right_circumference", "i
 _FIELD_CONDITIONS = ("is_right_area_square", "is_right_square_perimeter")
 
 
+_CONDITION_MODULES = ("pylinac.metrics.features", __name__)
+
+
+def _condition_stub(name: str):
+    def stub(region, *args, **kwargs):
+        raise NotImplementedError(f"{name} is evaluated inside the threshold-sweep kernel; it is passed by identity only")
+
+    stub.__name__ = stub.__qualname__ = name
+    stub.__doc__ = f"pylinac/metrics/features.py ``{name}``: marker for ``detection_conditions`` (the kernel evaluates it)"
+    return stub
+
+
+# markers a caller may list in ``detection_conditions`` where the reference's own functions are not importable
+is_right_size_bb, is_round, is_right_circumference, is_symmetric, is_solid = (_condition_stub(n) for n in _DISK_CONDITIONS)
+is_right_area_square, is_right_square_perimeter = (_condition_stub(n) for n in _FIELD_CONDITIONS)
+
+
 def _check_conditions(conditions, supported: tuple, what: str) -> None:
+    """The kernels evaluate exactly the reference's default predicates (metrics/features.py:7-68).  A condition is accepted by
+    IDENTITY -- defined in the reference's ``pylinac.metrics.features`` or one of this module's markers, under its own name --
+    so a user callable that merely shares a default's name (a stricter custom ``is_round``), a lambda or a ``partial`` is
+    refused instead of being silently replaced by the built-in."""
     if conditions is None:
         return
-    names = tuple(getattr(c, "__name__", str(c)) for c in conditions)
+    names = []
+    for c in conditions:
+        name = getattr(c, "__qualname__", None)
+        if getattr(c, "__module__", None) not in _CONDITION_MODULES or name not in supported:
+            raise NotImplementedError(f"{what} evaluates the reference's own conditions {supported} inside its kernel; "
+                                      f"{c!r} is not one of them (custom conditions are not supported)")
+        names.append(name)
     if sorted(names) != sorted(supported):                  # (a region must pass every condition: their order is immaterial)
-        raise NotImplementedError(f"{what} evaluates the conditions {supported} inside its kernel; got {names}")
+        raise NotImplementedError(f"{what} evaluates the conditions {supported} inside its kernel; got {tuple(names)}")
 
 
 class MetricBase:

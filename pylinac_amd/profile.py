@@ -207,8 +207,8 @@ class ProfileBase(ProfileMixin):
         if x_diff.max() > 0 > x_diff.min():
             raise ValueError("X values must be monotonically increasing or decreasing")
         sort_idxs = np.argsort(x_values)
-        self.x_values = x_values[sort_idxs]
         self._cache = {}
+        self.x_values = x_values[sort_idxs]
         self.values = values[sort_idxs]
         if ground:
             self.values = au.ground(self.values)
@@ -231,6 +231,18 @@ class ProfileBase(ProfileMixin):
     @values.setter
     def values(self, v) -> None:
         self._values = v
+        self._cache.clear()
+
+    # the same for ``x_values``: ``PhysicalProfileMixin.gamma`` shifts the x-values of deep copies (profile.py:861-866), and what
+    # the edge search derived from the old coordinates (the cubic through the smoothed derivative) must not answer for the new.
+    # An IN-PLACE edit of either array is invisible to this: rebind the attribute, as every mutator of the reference does.
+    @property
+    def x_values(self):
+        return self._x_values
+
+    @x_values.setter
+    def x_values(self, v) -> None:
+        self._x_values = v
         self._cache.clear()
 
     def x_at_x(self, x):

@@ -552,7 +552,7 @@ def check_hill_fit_kernels_agree(fit, n=40, seed=5):
     return int(((ia >= 1) & (ia <= 4)).sum())
 
 
-def check_hill_fit_pathological(fit):
+def check_hill_fit_pathological(fit, fit_ex=None):
     """Windows no fit should be asked about -- constant, NaN, infinity, 1e300, 1e-300, pure noise, a step, a zero abscissa
     (c / x = inf): both kernels of pl_hill_fit must TERMINATE, agree bit for bit, report NaN / inf as info -4 (curve_fit's
     check_finite raises ValueError there) and leave the well-posed row alone."""
@@ -578,6 +578,16 @@ def check_hill_fit_pathological(fit):
         assert (nfev <= 1005).all()
         if not zero_x:
             assert 1 <= info[-1] <= 4 and abs(params[-1][2] - 110) < 1e-6 and abs(params[-1][3] - 20) < 1e-5, (info, params[-1])
+        if fit_ex is not None:
+            # the last accepted step of a degenerate window (all scaled parameters zero) is 0 or +inf, never NaN;
+            # NaN marks only the windows that were refused (info -4), and the well-posed row is settled
+            for pad in (0, 140):
+                grow = lambda a: np.concatenate([a, np.zeros((len(a), pad))], axis=1)
+                _, info_e, _, step = fit_ex(grow(xs), grow(ys), lens)
+                ok = info_e != -4
+                assert not np.isnan(step[ok]).any() and (step[ok] >= 0).all(), (step, info_e)
+                if not zero_x:
+                    assert step[-1] < 1e-6, step
     return True
 
 

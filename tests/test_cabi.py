@@ -52,7 +52,9 @@ def test_library_contains_gfx950_code_object():
 
 
 def test_status_strings_and_version(lib):
-    assert lib.pl_abi_version() == 2
+    from pylinac_amd import _lib
+
+    assert lib.pl_abi_version() == _lib.ABI_VERSION == 3
     assert lib.pl_status_string(0) == b"ok"
     assert b"invalid" in lib.pl_status_string(1)
 

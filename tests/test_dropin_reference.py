@@ -21,6 +21,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import pylinac_oracle as oracle  # noqa: E402  (checker only)
 from oracle import ref_loader  # noqa: E402
 
 pytestmark = pytest.mark.skipif(not ref_loader.reference_available(), reason="needs /root/reference (build container)")
@@ -167,6 +168,67 @@ def test_find_peaks_exact_ties_vs_the_reference():
                     assert np.array_equal(ri, gi), (npk, key, k)
                 differing += int(not np.array_equal(ri, gi))
     print(f"exact-tie cases where the stable order departs from numpy's argsort: {differing} of {total}")
+
+
+def test_find_peaks_distance_ties_vs_the_reference():
+    """The SECOND exact-tie site: scipy's ``_select_by_peak_distance`` walks the candidates in
+    ``np.argsort(priority)`` order (default kind: x86-simd-sort on this CPU, unstable), reached through
+    ``peak_separation > 0`` (pylinac/core/profile.py:2605-2612).  Integer-valued / plateaued profiles -- ``np.max`` of a uint16
+    image along an axis (pylinac/starshot.py:216-217), medians of integer windows -- tie exactly, and two tied candidates
+    closer than ``distance`` suppress each other in whichever order the sort left them.  The device walks them in the
+    STABLE order (later index first among equals, csrc/peaks_device.h distance filter).  Held here on 360 calls:
+      * device == scipy's algorithm with ``argsort(kind="stable")`` (oracle ``impl="restated"``) in every call;
+      * device == the live reference whenever no two tied candidates lie within ``distance`` of each other (tied
+        candidates further apart commute, so the sort's order cannot matter);
+      * otherwise BOTH results are valid outcomes of scipy's rule: kept peaks at least ``distance`` apart, every dropped
+        candidate has a kept peak at least as high within ``distance``, and a candidate strictly higher than every
+        other candidate within ``distance`` is kept by both.  (The kept heights' multiset may differ: a different winner
+        of a tie suppresses different neighbours.)"""
+    from emu_backend import emulated_device
+
+    prof = ref_loader.ref("core.profile")
+    rng = np.random.default_rng(11)
+    differing = total = 0
+    for trial in range(40):
+        n = int(rng.integers(60, 400))
+        if trial % 3 == 0:
+            x = rng.integers(0, 6, n).astype(float)
+        elif trial % 3 == 1:
+            x = np.repeat(rng.integers(0, 5, n // 3 + 1), 3)[:n].astype(float)        # plateaus
+        else:
+            x = np.round(np.abs(rng.normal(size=n).cumsum()))
+        for thr in (0, 0.1, 0.3):
+            for sep in (0.02, 0.05, 0.2):
+                kw = dict(threshold=thr, peak_separation=sep)
+                ri, rp = prof.find_peaks(x.copy(), **kw)
+                si, sp = oracle.find_peaks(x.copy(), impl="restated", **kw)
+                with emulated_device():
+                    from pylinac_amd import profile as shim
+
+                    gi, gp = shim.find_peaks(x.copy(), **kw)
+                total += 1
+                assert np.array_equal(gi, si), (trial, kw)
+                for k in sp:
+                    assert np.array_equal(gp[k], sp[k]), (trial, kw, k)
+                # the candidates of the distance filter: every local maximum at or above the height threshold
+                ci, cp = prof.find_peaks(x.copy(), threshold=thr, peak_separation=0)
+                ch = cp["peak_heights"]
+                dist = max(int(sep * n), 1)
+                near = np.abs(ci[:, None] - ci[None, :]) < dist
+                np.fill_diagonal(near, False)
+                tied_near = bool((near & (ch[:, None] == ch[None, :])).any())
+                if not tied_near:
+                    assert np.array_equal(gi, ri), (trial, kw)
+                differing += int(not np.array_equal(gi, ri))
+                dominant = ci[~(near & (ch[None, :] >= ch[:, None])).any(axis=1)]
+                for kept in (ri, gi):
+                    assert len(kept) < 2 or np.diff(kept).min() >= dist
+                    assert set(dominant) <= set(kept)
+                    kh = x[kept]
+                    for c, hc in zip(ci, ch):
+                        if c not in kept:
+                            assert (kh[np.abs(kept - c) < dist] >= hc).any(), (trial, kw, c)
+    print(f"distance-filter tie cases where the stable order departs from numpy's argsort: {differing} of {total}")
 
 
 # ------------------------------------------------------------------------------------------------------------------------

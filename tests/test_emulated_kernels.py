@@ -507,7 +507,7 @@ def test_emulated_hill_fit_matches_scipy(emulated):
 
     assert checks.check_hill_fit_vs_scipy(fit_ex, n=40) >= 36
     assert checks.check_hill_fit_kernels_agree(fit, n=24) >= 18
-    assert checks.check_hill_fit_pathological(fit)
+    assert checks.check_hill_fit_pathological(fit, fit_ex)
 
 
 def test_emu_hill_entry_points_reject_bad_arguments(emu):

@@ -1992,7 +1992,7 @@ def test_hill_fit_matches_scipy(dev):
 
     assert checks.check_hill_fit_vs_scipy(fit_ex, n=400, seed=3) >= 360
     assert checks.check_hill_fit_kernels_agree(fit, n=512) >= 460
-    assert checks.check_hill_fit_pathological(fit)
+    assert checks.check_hill_fit_pathological(fit, fit_ex)
 
 
 @pytest.mark.gpu

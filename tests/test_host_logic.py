@@ -143,3 +143,42 @@ def test_fma_quotient_identity_exhaustive(tmp_path):
     subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_detection_conditions_are_accepted_by_identity_only():
+    """a user callable that shares a default predicate's NAME must not be silently replaced by the built-in."""
+    import functools
+
+    from pylinac_amd import metrics as m
+
+    disk = [m.is_right_size_bb, m.is_round, m.is_right_circumference, m.is_symmetric, m.is_solid]
+    m.SizedDiskLocator((0, 0), (10, 10), 2, 1, detection_conditions=disk[::-1])            # order is immaterial
+
+    def is_round(region, *a, **k):                                                            # a stricter user version
+        return False
+
+    for bad in ([is_round] + disk[:1] + disk[2:], disk[:-1] + [lambda r: True], disk[:-1] + [functools.partial(disk[-1])],
+                disk[:-1]):
+        with pytest.raises(NotImplementedError):
+            m.SizedDiskLocator((0, 0), (10, 10), 2, 1, detection_conditions=bad)
+    m.GlobalSizedFieldLocator(10, 10, 1, detection_conditions=[m.is_right_square_perimeter, m.is_right_area_square])
+    with pytest.raises(NotImplementedError):
+        m.GlobalSizedFieldLocator(10, 10, 1, detection_conditions=disk)
+
+
+def test_profile_cache_follows_x_values_rebinding():
+    """what the edge search derived from the old coordinates must not answer after ``x_values`` is rebound
+    (PhysicalProfileMixin.gamma does that to deep copies, pylinac/core/profile.py:861-866)."""
+    import copy
+
+    from pylinac_amd import profile as p
+
+    prof = p.ProfileBase(np.array([0, 1, 2, 3, 2, 1, 0.0]))
+    prof._cache["probe"] = 1
+    clone = copy.deepcopy(prof)
+    assert clone._cache == {"probe": 1}
+    clone.x_values = clone.x_values - 3
+    assert clone._cache == {} and prof._cache == {"probe": 1}
+    assert np.array_equal(clone.x_values, np.arange(7) - 3)
+    prof.values = prof.values * 2
+    assert prof._cache == {}
