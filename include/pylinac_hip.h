@@ -208,6 +208,26 @@ int pl_circle_profile_combined(const void* stack, int dtype, int64_t n_stack, in
                                const double* d_sin, int nsamp, const double* d_radii, int nr, const double* d_cx,
                                const double* d_cy, double divisor, double* d_out, void* stream);
 
+/* pl_circle_profile_combined + d_margin float64 [m] (may be NULL; the caller presets it to +inf): per profile the smallest
+ * distance of any tap's coordinate + 0.5 to an integer (the nearest-pixel choice of map_coordinates(order=0)) or of a
+ * coordinate to 0 / n - 1 (its bounds test) -- how far the centre may move before any sample of the profile changes.  Lets
+ * ct.ctp528_batch place the profiles about a centre fitted on the device (pl_phantom_axis_fit) and prove afterwards that
+ * the reference's np.polyfit centre (pylinac/ct.py:2440-2445) selects the same pixels. */
+int pl_circle_profile_combined_ex(const void* stack, int dtype, int64_t n_stack, int h, int w,
+                                  const int64_t* d_slice_index, int64_t m, int64_t slices_per_volume, int plusminus,
+                                  const double* d_cos, const double* d_sin, int nsamp, const double* d_radii, int nr,
+                                  const double* d_cx, const double* d_cy, double divisor, double* d_out,
+                                  double* d_margin, void* stream);
+
+/* CatPhanBase.find_phantom_axis (pylinac/ct.py:2398-2446) for the phantom-ROI tables d_roi [n_volumes * spv][8] of
+ * pl_edge_regions, one volume after the other: slices with status 0, np.median of their centres, the np.isclose(median, c,
+ * atol=3, rtol=0.01) screen on both axes (both exact), then a closed-form first-order least-squares fit of centre against
+ * slice number -- a PLACEMENT aid, not the reported fit (the host's np.polyfit is; see pl_circle_profile_combined_ex).
+ * d_fit [n_volumes][4] = zx slope, zx intercept, zy slope, zy intercept; d_centers [n_volumes * spv][2] = (x, y) of the fitted
+ * line at every slice; d_flag int32 [n_volumes]: 0 ok, 1 no slice shows the phantom, 2 fewer than two slices pass. */
+int pl_phantom_axis_fit(const double* d_roi, int64_t n_volumes, int slices_per_volume, double x_adjustment,
+                        double y_adjustment, double* d_fit, double* d_centers, int32_t* d_flag, void* stream);
+
 /* ---- a15: ndimage.sobel(image, axis) (pylinac/core/image.py:1006-1007): [-1,0,1] along `axis`
  * then [1,2,1] along the other axis, mode='reflect', each pass cast into the image dtype. */
 int pl_sobel(const void* in, void* out, int dtype, int64_t n, int h, int w, int axis, void* stream);
@@ -426,6 +446,26 @@ int64_t pl_xim_work_bytes(int width, int height);
 int pl_xim_decode(const unsigned char* d_lookup, int64_t lookup_bytes, const unsigned char* d_stream,
                   int64_t stream_bytes, int width, int height, int bytes_per_pixel, void* d_out,
                   unsigned char* d_work, void* stream);
+
+/* ---- f1 ("next" row), the DICOM half: native (uncompressed) Pixel Data -> typed frames -------------------------
+ * Replaces `self.metadata.pixel_array` [+ `.astype(dtype)`] [+ `pixels.apply_rescale`] of DicomImage.__init__
+ * (pylinac/core/image.py:1431-1444, 363-389) and the per-file loop of the DICOM stacks (image.py:2155-2160, 2234-2243)
+ * for a batch: pydicom's numpy handler (pydicom>=2.0,<3, pyproject.toml:40; pixel_data_handlers/numpy_handler.py
+ * get_pixeldata + util.pixel_dtype) = np.frombuffer(PixelData, '<' or '>', 'u' or 'i', BitsAllocated / 8 bytes).
+ *   d_bytes [nbytes]: a device copy of the file(s) or of a Pixel Data value, 4-byte-aligned start; d_offsets int64 [n]:
+ *   the byte at which each frame's first sample lies (any alignment: (7FE0,0010) values start wherever the header ends);
+ *   rows x cols samples per frame, SamplesPerPixel 1; bits_allocated 8 / 16 / 32; pixel_representation 0 / 1;
+ *   big_endian: Explicit VR Big Endian (1.2.840.10008.1.2.2);
+ *   unused_bits 0 = the container value as stored (pydicom 2.x, the reference's pin), 1 = low bits_stored bits kept /
+ *   sign-extended from bit bits_stored - 1 (pydicom >= 3 `correct_unused_bits`);
+ *   d_out [n][rows][cols], out_dtype = the container dtype (PL_U8 for 8-bit, PL_U16 / PL_I16, PL_I32 for 32-bit: wider
+ *   unsigned and int8 travel as same-width bits), PL_F32 (`astype(float32)`) or PL_F64 (`astype(float64)`, and with
+ *   rescale != 0: `* slope` then `+ intercept`, two roundings = apply_modality_lut);
+ *   d_status int32 [n]: 1 = the frame does not lie inside the buffer (pydicom raises ValueError), frame left untouched. */
+int pl_dicom_decode(const unsigned char* d_bytes, int64_t nbytes, const int64_t* d_offsets, int64_t n, int rows, int cols,
+                    int bits_allocated, int bits_stored, int pixel_representation, int big_endian, int unused_bits,
+                    void* d_out, int out_dtype, int rescale, double slope, double intercept, int32_t* d_status,
+                    void* stream);
 
 /* ---- f2 ("next" row, first half): skimage.feature.canny as called at pylinac/planar_imaging.py:574-588 -------
  * float64 images, mask=None.  The caller composes: G = pl_gaussian2d_mode(mode 2) of the image and of an all-ones

@@ -2135,3 +2135,118 @@ def ctp528_slice(volume: np.ndarray, s: int, center_xy, mm_per_pixel: float, rol
         mtf = [(a - b) / (a + b) for a, b in zip(maxs, mins)]
         rmtf[: len(mtf)] = np.array(mtf) / mtf[0]
     return prof, rmtf
+
+
+# --------------------------------------------------------------------------------------
+# f1, the DICOM half: `DicomImage.__init__` (pylinac/core/image.py:1431-1444) = pydicom's `pixel_array` [+ astype] +
+# `_rescale_dicom_values` (:363-389).  PARITY UNPINNED against pydicom itself: pydicom (pyproject.toml:40, >=2.0,<3) is
+# in no environment this build reaches and its source is not under /root/reference.  Restated from its published native
+# path (pixel_data_handlers/numpy_handler.py `get_pixeldata`, util.py `pixel_dtype` / `get_expected_length` /
+# `reshape_pixel_array`, `apply_modality_lut`) and pinned to (a) the layout the reference's OWN writer states
+# (pylinac/core/array_utils.py:291-297: `PixelData = array.tobytes()`, BitsAllocated = itemsize * 8, Explicit VR Little
+# Endian) through the fixtures of tests/golden/make_dicom_golden.py, (b) the identities the reference's tests state for
+# `_rescale_dicom_values` (tests_basic/core/test_image.py:131-200).  The Part-10 walk below is written independently of
+# pylinac_amd/dicom.py (a generator over raw elements; tags by number).
+# --------------------------------------------------------------------------------------
+def _dicom_elements(buf: bytes):
+    """(group, element, VR or None, value bytes or None for a skipped undefined-length value, value offset)"""
+    import struct
+
+    n, pos = len(buf), 0
+    if n >= 132 and buf[128:132] == b"DICM":
+        pos = 132
+    syntax, explicit, big = None, pos != 0, False
+    long_vrs = (b"OB", b"OD", b"OF", b"OL", b"OV", b"OW", b"SQ", b"UC", b"UN", b"UR", b"UT", b"SV", b"UV")
+
+    def read_at(p, expl, be):
+        e = ">" if be else "<"
+        g, el = struct.unpack_from(e + "HH", buf, p)
+        vr = None
+        if expl and g != 0xFFFE:
+            vr = buf[p + 4:p + 6]
+            if vr in long_vrs:
+                ln, p = struct.unpack_from(e + "I", buf, p + 8)[0], p + 12
+            else:
+                ln, p = struct.unpack_from(e + "H", buf, p + 6)[0], p + 8
+        else:
+            ln, p = struct.unpack_from(e + "I", buf, p + 4)[0], p + 8
+        return g, el, vr, ln, p
+
+    def skip_items(p, expl, be):                            # PS3.5 section 7.5
+        while True:
+            g, el, _, ln, p = read_at(p, expl, be)
+            if (g, el) == (0xFFFE, 0xE0DD):
+                return p
+            if ln != 0xFFFFFFFF:
+                p += ln
+                continue
+            while True:
+                g2, el2, _, ln2, q = read_at(p, expl, be)
+                if (g2, el2) == (0xFFFE, 0xE00D):
+                    p = q
+                    break
+                p = skip_items(q, expl, be) if ln2 == 0xFFFFFFFF else q + ln2
+
+    in_meta = pos != 0
+    while pos + 8 <= n:
+        if in_meta and struct.unpack_from("<H", buf, pos)[0] != 0x0002:
+            in_meta = False
+            explicit = syntax != "1.2.840.10008.1.2"
+            big = syntax == "1.2.840.10008.1.2.2"
+        g, el, vr, ln, start = read_at(pos, True if in_meta else explicit, False if in_meta else big)
+        if ln == 0xFFFFFFFF:
+            pos = skip_items(start, explicit, big)
+            yield g, el, vr, None, start, big
+            continue
+        val = buf[start:start + ln]
+        if (g, el) == (0x0002, 0x0010):
+            syntax = val.decode().rstrip(" \x00")
+        yield g, el, vr, val, start, (False if in_meta else big)
+        pos = start + ln
+
+
+def dicom_pixel_array(file_bytes, correct_unused_bits: bool = False):
+    """pydicom 2.x `Dataset.pixel_array` for native Pixel Data -> (array, dict of the numeric tags used, value offset).
+    numpy_handler.get_pixeldata: `np.frombuffer(PixelData[:expected_len], pixel_dtype)`; util.pixel_dtype: byte order by
+    transfer syntax, 'u' / 'i' by PixelRepresentation, BitsAllocated // 8 bytes; reshape_pixel_array: (frames, rows, cols)
+    for NumberOfFrames > 1, else (rows, cols).  ``correct_unused_bits`` = pydicom >= 3's default for native data."""
+    import struct
+
+    buf = bytes(np.asarray(file_bytes, dtype=np.uint8).tobytes())
+    tags, pixel = {}, None
+    for g, el, vr, val, start, big in _dicom_elements(buf):
+        e = ">" if big else "<"
+        if val is None:
+            continue
+        if (g, el) == (0x7FE0, 0x0010):
+            pixel = (val, start, big)
+        elif g == 0x0028 and el in (0x0002, 0x0010, 0x0011, 0x0100, 0x0101, 0x0102, 0x0103):
+            tags[el] = struct.unpack(e + "H", val[:2])[0]
+        elif (g, el) == (0x0028, 0x1041):
+            tags[el] = struct.unpack(e + "h", val[:2])[0]
+        elif (g, el) in ((0x0028, 0x0008), (0x0028, 0x1052), (0x0028, 0x1053)):
+            tags[el] = float(val.decode().strip(" \x00"))
+    rows, cols, bits, rep = tags[0x0010], tags[0x0011], tags[0x0100], tags[0x0103]
+    frames = int(tags.get(0x0008, 1))
+    val, start, big = pixel
+    dt = np.dtype((">" if big else "<") + ("i" if rep else "u") + str(bits // 8))
+    expected = rows * cols * frames * (bits // 8)
+    if len(val) < expected:
+        raise ValueError("The length of the pixel data in the dataset doesn't match the expected length")
+    arr = np.frombuffer(val[:expected], dtype=dt).astype(dt.newbyteorder("="))
+    stored = tags.get(0x0101, bits)
+    if correct_unused_bits and stored < bits:
+        if rep:
+            sh = bits - stored
+            arr = np.right_shift(np.left_shift(arr, sh), sh)          # arithmetic shift on a signed dtype
+        else:
+            arr = arr & arr.dtype.type((1 << stored) - 1)
+    arr = arr.reshape((frames, rows, cols) if frames > 1 else (rows, cols))
+    return arr, tags, start
+
+
+def dicom_image_array(file_bytes, dtype=None, raw_pixels: bool = False, invert_pixels=None):
+    """`DicomImage.__init__`'s array (image.py:1431-1444)"""
+    arr, tags, _ = dicom_pixel_array(file_bytes)
+    arr = arr.astype(dtype) if dtype is not None else arr.copy()
+    return rescale_dicom_values(arr, tags.get(0x1053), tags.get(0x1052), tags.get(0x1041), raw_pixels, invert_pixels)

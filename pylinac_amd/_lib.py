@@ -80,6 +80,8 @@ SIGNATURES = {
     "pl_colparts_profile_fwxm": ([_p, _l, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_circle_profile": ([_p, _i, _l, _i, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p], C.c_int),
     "pl_circle_profile_combined": ([_p, _i, _l, _i, _i, _p, _l, _l, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p], C.c_int),
+    "pl_circle_profile_combined_ex": ([_p, _i, _l, _i, _i, _p, _l, _l, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p, _p], C.c_int),
+    "pl_phantom_axis_fit": ([_p, _l, _i, _d, _d, _p, _p, _p, _p], C.c_int),
     "pl_sobel": ([_p, _p, _i, _l, _i, _i, _i, _p], C.c_int),
     "pl_label": ([_p, _l, _i, _i, _i, _p, _p, _p, _p], C.c_int),
     "pl_fill_holes": ([_p, _p, _l, _i, _i, _i, _p, _p, _p], C.c_int),
@@ -149,6 +151,7 @@ SIGNATURES = {
     "pl_nps2d_work_doubles": ([_l, _i], C.c_int64),
     "pl_radial_average": ([_p, _i, _i, _i, _p, _p], C.c_int),
     "pl_esf_mtf": ([_p, _p, _p, _i, _i, _i, _p, _p, _p, _p], C.c_int),
+    "pl_dicom_decode": ([_p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _d, _d, _p, _p], C.c_int),
     "pl_colsum_to_mean": ([_p, _l, _i, _i, _p, _p], C.c_int),
     "pl_find_peaks_var": (
         [_p, _l, _i, _p, _l, C.POINTER(PeakParams), _i, _p, _p, _p, _p, _p, _p, _p],

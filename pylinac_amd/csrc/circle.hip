@@ -67,7 +67,7 @@ circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const 
                                int64_t per_volume, int k_pm, const double* __restrict__ cosv,
                                const double* __restrict__ sinv, int nsamp, const double* __restrict__ radii, int nr,
                                const double* __restrict__ cx, const double* __restrict__ cy, double divisor,
-                               double* __restrict__ out) {
+                               double* __restrict__ out, double* __restrict__ margin) {
   const int rl = threadIdx.x & (kCpRadLanes - 1);
   const int s_raw = blockIdx.x * kCpSamples + (threadIdx.x / kCpRadLanes);
   const bool live = s_raw < nsamp;
@@ -86,12 +86,25 @@ circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const 
     return stack + (size_t)(v0 + q) * per_frame;
   };
   const double* rad = radii + frame * nr;
+  // `margin` (optional, [frames], preset to +inf): how far the centre may move before ANY decision of this profile changes --
+  // the smallest distance of a coordinate + 0.5 to an integer (the nearest-pixel choice) or of a coordinate to 0 / n - 1 (the
+  // inside test).  ct.ctp528_batch samples about a centre fitted on the DEVICE and accepts the profile only if the exact
+  // host fit (np.polyfit, bit for bit the reference's) lies closer than this margin: then every tap is the same pixel.
+  double mrg = __longlong_as_double(0x7ff0000000000000LL);
+  const bool want_margin = margin != nullptr;
   auto tap = [&](double r, unsigned& off) {                  // -> inside?, offset of the nearest pixel
     const double x = c * r + x0;
     const double y = sn * r + y0;
     const bool in = x >= 0.0 && x <= (double)(w - 1) && y >= 0.0 && y <= (double)(h - 1);
-    const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
+    const double fx = floor(x + 0.5), fy = floor(y + 0.5);
+    const int xi = (int)fx, yi = (int)fy;
     off = in ? (unsigned)yi * (unsigned)w + (unsigned)xi : 0u;
+    if (want_margin) {
+      const double dx = (x + 0.5) - fx, dy = (y + 0.5) - fy;
+      double m = fmin(fmin(dx, 1.0 - dx), fmin(dy, 1.0 - dy));
+      m = fmin(m, fmin(fmin(fabs(x), fabs(x - (double)(w - 1))), fmin(fabs(y), fabs(y - (double)(h - 1)))));
+      mrg = m < mrg ? m : mrg;                               // (a NaN coordinate never lowers it: the caller tests NaN centres)
+    }
     return in;
   };
   double acc = 0.0;                                          // integers: exact whatever the order
@@ -126,15 +139,20 @@ circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const 
 #pragma unroll
   for (int o = 1; o < kCpRadLanes; o <<= 1) acc = acc + __shfl_xor(acc, o, 64);
   if (live && rl == 0) out[frame * (size_t)nsamp + s] = (divisor == 1.0) ? acc : acc / divisor;
+  if (want_margin) {
+    mrg = pl_wave_reduce(mrg, [](double a, double b) { return a < b ? a : b; });
+    // non-negative doubles order like their bit patterns
+    if ((threadIdx.x & 63) == 0) atomicMin(reinterpret_cast<long long*>(margin + frame), __double_as_longlong(mrg));
+  }
 }
 
 }  // namespace
 
-extern "C" int pl_circle_profile_combined(const void* stack, int dtype, int64_t n_stack, int h, int w,
-                                          const int64_t* d_slice_index, int64_t m, int64_t slices_per_volume, int plusminus,
-                                          const double* d_cos, const double* d_sin, int nsamp, const double* d_radii, int nr,
-                                          const double* d_cx, const double* d_cy, double divisor, double* d_out,
-                                          void* stream) {
+extern "C" int pl_circle_profile_combined_ex(const void* stack, int dtype, int64_t n_stack, int h, int w,
+                                             const int64_t* d_slice_index, int64_t m, int64_t slices_per_volume, int plusminus,
+                                             const double* d_cos, const double* d_sin, int nsamp, const double* d_radii, int nr,
+                                             const double* d_cx, const double* d_cy, double divisor, double* d_out,
+                                             double* d_margin, void* stream) {
   PL_REQUIRE(stack && d_cos && d_sin && d_radii && d_cx && d_cy && d_out, "null pointer");
   PL_REQUIRE(m >= 0 && m <= 65535 && h > 0 && w > 0 && nsamp > 0 && nr > 0 && plusminus >= 0, "bad shape");
   PL_REQUIRE(slices_per_volume > 0 && n_stack > 0 && n_stack % slices_per_volume == 0, "the stack must hold whole volumes");
@@ -146,7 +164,8 @@ extern "C" int pl_circle_profile_combined(const void* stack, int dtype, int64_t 
   PL_REQUIRE((int64_t)h * w <= 0xffffffffLL, "frame too large");
 #define CPC_LAUNCH(K)                                                                                                       \
   hipLaunchKernelGGL((circle_profile_combined_kernel<T, K>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)stack, h, w, \
-                     d_slice_index, slices_per_volume, plusminus, d_cos, d_sin, nsamp, d_radii, nr, d_cx, d_cy, divisor, d_out)
+                     d_slice_index, slices_per_volume, plusminus, d_cos, d_sin, nsamp, d_radii, nr, d_cx, d_cy, divisor, d_out, \
+                     d_margin)
   PL_DISPATCH_DTYPE(dtype, T, {
     switch (plusminus) {
       case 0: CPC_LAUNCH(0); break;
@@ -158,6 +177,15 @@ extern "C" int pl_circle_profile_combined(const void* stack, int dtype, int64_t 
   });
 #undef CPC_LAUNCH
   return pl_check_launch("pl_circle_profile_combined");
+}
+
+extern "C" int pl_circle_profile_combined(const void* stack, int dtype, int64_t n_stack, int h, int w,
+                                          const int64_t* d_slice_index, int64_t m, int64_t slices_per_volume, int plusminus,
+                                          const double* d_cos, const double* d_sin, int nsamp, const double* d_radii, int nr,
+                                          const double* d_cx, const double* d_cy, double divisor, double* d_out,
+                                          void* stream) {
+  return pl_circle_profile_combined_ex(stack, dtype, n_stack, h, w, d_slice_index, m, slices_per_volume, plusminus, d_cos, d_sin,
+                                       nsamp, d_radii, nr, d_cx, d_cy, divisor, d_out, nullptr, stream);
 }
 
 extern "C" int pl_circle_profile(const void* img, int dtype, int64_t n, int h, int w, const double* d_cos,

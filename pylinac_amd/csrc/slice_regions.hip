@@ -21,6 +21,24 @@
 #include "pl_common.h"
 #include "edge_exact.h"
 
+// Phase stopwatch (-DPL_SR_TIMING, development builds only: scripts/r06_sr_phases.sh): s_memtime totals per phase, summed over
+// the workgroups of every launch since the last read (pl_debug_sr_timing).  0 plane build, 1-3 the three labellings
+// (unused), 4 flag + paint passes, 5 region table + results; inside the labellings (clear_border 8-13, fill_holes 14-19,
+// final 20-25): runs per row, prefix, run extraction, first-above links, pointer jumping, unions + final flattening.
+#ifndef PL_SR_TIMING
+#define PL_SR_TIMING 0
+#endif
+#if PL_SR_TIMING
+__device__ unsigned long long pl_sr_dbg[32];
+#define SR_STAMP(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); sr_tacc[k] += t_ - sr_tlast; sr_tlast = t_; } } while (0)
+#define SR_TIMING_ARGS , long long* sr_tacc, long long& sr_tlast, int sr_base
+#define SR_TIMING_PASS(b) , sr_tacc, sr_tlast, b
+#else
+#define SR_STAMP(k) do { } while (0)
+#define SR_TIMING_ARGS
+#define SR_TIMING_PASS(b)
+#endif
+
 namespace {
 
 constexpr int kSrThreads = 512;
@@ -69,7 +87,7 @@ struct SrLds {
 
 // Runs of the plane (inverted inside the frame when `invert`), numbered in raster order; 4- or 8-connected components over
 // them; afterwards parent[id] is the root (smallest run id) of id's component.  -> number of runs, or -1 when they do not fit.
-__device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, bool conn8, int* s_total) {
+__device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, bool conn8, int* s_total SR_TIMING_ARGS) {
   const int tid = threadIdx.x;
   const u64 tail = (w & 63) ? ((1ull << (w & 63)) - 1ull) : ~0ull;
   auto word = [&](int r, int j) -> u64 {
@@ -90,6 +108,7 @@ __device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, 
   }
   if (tid == 0) L.row_off[0] = 0;
   __syncthreads();
+  SR_STAMP(sr_base + 8);
   // inclusive prefix over row_off[1 .. h] by the first wave, 64 rows at a time
   if (tid < PL_WAVE) {
     int base = 0;
@@ -108,6 +127,7 @@ __device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, 
   }
   __syncthreads();
   const int nruns = *s_total;
+  SR_STAMP(sr_base + 9);
   if (nruns > kSrMaxRuns) return -1;
   // the runs themselves: the k-th start and the k-th end of a row belong together
   for (int r = tid; r < h; r += kSrThreads) {
@@ -137,6 +157,7 @@ __device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, 
     }
   }
   __syncthreads();
+  SR_STAMP(sr_base + 10);
   // ---- components over the runs.  Rounds 1-3 united every run with every overlapping run of the row above through an
   // atomic union-find whose links point to the smaller id: a tall component (the phantom's outline is 450 rows of one or two
   // runs) became a 450-deep chain that every find walked link by link, three labellings per slice.  Now:
@@ -168,6 +189,7 @@ __device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, 
     L.aux[id] = more ? 1 : 0;
   }
   __syncthreads();
+  SR_STAMP(sr_base + 11);
   for (;;) {
     int changed = 0;
     for (int id = tid; id < nruns; id += kSrThreads) {
@@ -177,6 +199,7 @@ __device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, 
     }
     if (!__syncthreads_or(changed)) break;
   }
+  SR_STAMP(sr_base + 12);
   for (int id = tid; id < nruns; id += kSrThreads) {
     if (!L.aux[id]) continue;
     const int r = L.run_r[id];
@@ -199,6 +222,7 @@ __device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, 
     L.aux[id] = 0;
   }
   __syncthreads();
+  SR_STAMP(sr_base + 13);
   return nruns;
 }
 
@@ -253,6 +277,9 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if PL_SR_TIMING
+  long long sr_tacc[32] = {0}, sr_tlast = clock64();
+#endif
   const T* src = in + f * (int64_t)h * w;
   const double t = thr ? thr[f] : 0.0;
   // ---- the bit plane: a wave turns 64 consecutive pixels of a row into one word; thirty-two words' loads are in flight per
@@ -320,10 +347,11 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
     }
   }
   __syncthreads();
+  SR_STAMP(0);
   int st = 0;
   // ---- clear_border: 8-connected components with a pixel in the border band
   if (clear_ext > 0) {
-    const int nr = sr_label_runs(L, h, w, ww, false, true, &s_total);
+    const int nr = sr_label_runs(L, h, w, ww, false, true, &s_total SR_TIMING_PASS(0));
     if (nr < 0) st = 1;
     else {
       for (int id = tid; id < nr; id += kSrThreads) {
@@ -335,10 +363,11 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
         if (L.aux[L.parent[id]]) sr_paint(L, ww, id, false);
       __syncthreads();
     }
+    SR_STAMP(4);
   }
   // ---- binary_fill_holes: 4-connected background components away from the frame border
   if (fill && st == 0) {
-    const int nr = sr_label_runs(L, h, w, ww, true, false, &s_total);
+    const int nr = sr_label_runs(L, h, w, ww, true, false, &s_total SR_TIMING_PASS(6));
     if (nr < 0) st = 1;
     else {
       for (int id = tid; id < nr; id += kSrThreads) {
@@ -350,11 +379,12 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
         if (!L.aux[L.parent[id]]) sr_paint(L, ww, id, true);
       __syncthreads();
     }
+    SR_STAMP(4);
   }
   // ---- label (8-connected) + region table
   int nlab = 0;
   if (st == 0) {
-    const int nr = sr_label_runs(L, h, w, ww, false, true, &s_total);
+    const int nr = sr_label_runs(L, h, w, ww, false, true, &s_total SR_TIMING_PASS(12));
     if (nr < 0) st = 1;
     else {
       for (int k = tid; k < kSrMaxLabels; k += kSrThreads) {
@@ -440,6 +470,10 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
       o[7] = ok ? (double)(t_r1[best] + 1) : nan;
     }
   }
+#if PL_SR_TIMING
+  SR_STAMP(5);
+  if (tid == 0) for (int k = 0; k < 32; ++k) atomicAdd(&pl_sr_dbg[k], (unsigned long long)sr_tacc[k]);
+#endif
   if (out_mask && st == 0) {
     uint8_t* om = out_mask + f * (int64_t)h * w;
     for (int q = wv; q < nwords; q += kSrThreads / PL_WAVE) {
@@ -516,3 +550,11 @@ extern "C" int pl_edge_regions(const float* d_plane, const void* in_raw, int dty
                      clear_border_ext, fill_holes, max_labels, d_table, d_count, d_status, d_out_mask, ea);
   return pl_check_launch("pl_edge_regions");
 }
+
+#if PL_SR_TIMING
+extern "C" int pl_debug_sr_timing(unsigned long long* h_out) {
+  if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(pl_sr_dbg), sizeof(pl_sr_dbg)) != hipSuccess) return 1;
+  unsigned long long zero[32] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(pl_sr_dbg), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -188,7 +188,9 @@ def _phantom_roi_launch(slices: torch.Tensor, mm_per_pixel: float, catphan_radiu
     thr, _ = ops.edge_otsu(plane, lo, hi, frames=x, sigma=1, spans=spans, scale=0.8)
     reg = ops.edge_regions(plane, x, 1, thr, min(int(max(h, w) / 100), 3) + 1, True, max_labels, catphan_size=catphan_size,
                            rawmax=raw_max, want_table=False)
-    return args, ops.HostCopy(reg["roi"])
+    copy = ops.HostCopy(reg["roi"])
+    copy.device_table = reg["roi"]                                       # (ctp528_batch goes on from it without waiting)
+    return args, copy
 
 
 def _phantom_roi_finish(pending) -> np.ndarray:
@@ -409,34 +411,49 @@ CTP528_REGIONS = (
 )
 
 
+_BEYOND_CACHE: dict = {}
+
+
 def ctp528_profiles_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx, fit_zy, slices=None, roll_deg: float = 0.0,
                           radius2linepairs_mm: float = 47, scaling_factor: float = 1.0, roi_size_factor: float = 1.0,
                           start_angle: float = np.pi, ccw: bool = True, slices_plusminus: int = 3,
-                          slices_per_volume: int | None = None):
+                          slices_per_volume: int | None = None, device_centers: torch.Tensor | None = None):
     """``CTP528CP504.circle_profile`` (pylinac/ct.py:1559-1580) for the chosen slices of resident volumes: a stack
     [S, H, W] of one volume, or of several volumes of ``slices_per_volume`` slices each (``fit_zx`` / ``fit_zy`` are then
     [V, 2] coefficient tables and ``slices`` indexes the stack).  ``combine_surrounding_slices(+-3, "max")`` (module
     attributes ``combine_method = "max"``, ``num_slices = 3``, ct.py:1415-1416) inside each slice's own volume, a
     CollapsedCircleProfile of 20 radii within +-4 % of the line-pair radius at 2x sampling about the phantom centre
     ``(fit_zx(z), fit_zy(z))``, ``filter(0.001, "gaussian")``, ``ground()``.
-    -> (float64 [M, L] profiles on the device, the slice indices into the stack)."""
+    -> (float64 [M, L] profiles on the device, the slice indices into the stack).
+    ``device_centers`` (float64 [S, 2] on the device, ``ops.phantom_axis_fit``) instead of the fits: nothing comes from or
+    goes to the host, the array-size test is left to the caller, and the result is (profiles, indices, margin [M])."""
     from .array_utils import resolve_filter_size
 
     x = ops._frames(volume)
     n, h, w = x.shape
     spv = int(slices_per_volume or n)
     idx = np.arange(n) if slices is None else np.asarray(slices, dtype=np.int64)
-    fzx, fzy = np.atleast_2d(np.asarray(fit_zx, dtype=np.float64)), np.atleast_2d(np.asarray(fit_zy, dtype=np.float64))
     v, z = idx // spv, idx % spv                                               # volume and slice number inside it
-    cx = fzx[v, 0] * z + fzx[v, 1]                                             # np.poly1d(fit)(z), ct.py:434-439
-    cy = fzy[v, 0] * z + fzy[v, 1]
     radius = radius2linepairs_mm * scaling_factor / mm_per_pixel               # ct.py:1546-1549
-    if (w < radius + cx).any() or (h < radius + cy).any():                     # CircleProfile._ensure_array_size
-        raise ValueError("Array size not large enough to compute profile")
+    margin = None
+    if device_centers is None:
+        fzx, fzy = np.atleast_2d(np.asarray(fit_zx, dtype=np.float64)), np.atleast_2d(np.asarray(fit_zy, dtype=np.float64))
+        cx = fzx[v, 0] * z + fzx[v, 1]                                         # np.poly1d(fit)(z), ct.py:434-439
+        cy = fzy[v, 0] * z + fzy[v, 1]
+        if (w < radius + cx).any() or (h < radius + cy).any():                 # CircleProfile._ensure_array_size
+            raise ValueError("Array size not large enough to compute profile")
+    else:
+        cen = device_centers if slices is None else device_centers[_device_index(idx, x.device)]
+        cx, cy = cen[:, 0].contiguous(), cen[:, 1].contiguous()
     width_ratio, num_profiles, sampling_ratio = 0.04 * roi_size_factor, 20, 2
     radii = np.linspace(radius * (1 - width_ratio), radius * (1 + width_ratio), num_profiles)   # profile.py:2448-2452
     size = np.pi * radii.max() * 2 * sampling_ratio
-    if x.dtype in (torch.int16, torch.uint16, torch.int32, torch.uint8) and len(idx) <= 65535:
+    if device_centers is not None:
+        if not (x.dtype in (torch.int16, torch.uint16, torch.int32, torch.uint8) and len(idx) <= 65535):
+            raise TypeError("device centres: integer slices, at most 65535 profiles")
+        prof, margin = ops.circle_profile(x, cx, cy, radii, size, start_angle + np.deg2rad(roll_deg), ccw, float(num_profiles),
+                                          combine=(idx, spv, slices_plusminus), want_margin=True)
+    elif x.dtype in (torch.int16, torch.uint16, torch.int32, torch.uint8) and len(idx) <= 65535:
         # the +-3-slice maximum is taken per tap of the ring: the combined slices are never built
         prof = ops.circle_profile(x, cx, cy, radii, size, start_angle + np.deg2rad(roll_deg), ccw, float(num_profiles),
                                   combine=(idx, spv, slices_plusminus))
@@ -451,10 +468,28 @@ def ctp528_profiles_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx, fit
     # combine_surrounding_slices indexes dicomstack[z - k .. z + k] (ct.py:3375-3378): negative indices wrap around to the end
     # of the stack (reproduced by pl_combine_slices), indices past the last slice raise IndexError in the reference -- those
     # slices get a NaN profile here (-> no regions, NaN rMTF downstream)
-    beyond = torch.from_numpy(z + slices_plusminus >= spv).to(prof.device)
     if bool((z + slices_plusminus >= spv).any()):
-        prof = torch.where(beyond[:, None], torch.full_like(prof, float("nan")), prof)
-    return prof, idx
+        key = ((z + slices_plusminus >= spv).tobytes(), str(prof.device))     # (the same mask pass after pass: no upload mid-pass)
+        beyond = _BEYOND_CACHE.get(key)
+        if beyond is None:
+            if len(_BEYOND_CACHE) > 16:
+                _BEYOND_CACHE.clear()
+            beyond = _BEYOND_CACHE[key] = torch.from_numpy(z + slices_plusminus >= spv).to(prof.device)
+        prof = prof.masked_fill(beyond[:, None], float("nan"))
+    return (prof, idx) if device_centers is None else (prof, idx, margin)
+
+
+_INDEX_CACHE: dict = {}
+
+
+def _device_index(idx: np.ndarray, dev) -> torch.Tensor:
+    key = (idx.tobytes(), str(dev))
+    hit = _INDEX_CACHE.get(key)
+    if hit is None:
+        if len(_INDEX_CACHE) > 16:
+            _INDEX_CACHE.clear()
+        hit = _INDEX_CACHE[key] = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(dev)
+    return hit
 
 
 def ctp528_mtf_batch(profiles: torch.Tensor, regions=CTP528_REGIONS):
@@ -493,6 +528,28 @@ def _ctp528_mtf_finish(pending):
     return dict(rmtf=rmtf, nregions=nreg, maxs=maxs, mins=mins)
 
 
+def _device_centres_disagree(aux: np.ndarray, idx: np.ndarray, spv: int, fzx: np.ndarray, fzy: np.ndarray, h: int, w: int,
+                             mm_per_pixel: float, kw: dict, rerun: bool):
+    """Pass one sampled the profiles ``idx`` about the DEVICE's centres; the reference's are ``np.poly1d(np.polyfit(...))``.
+    -> None when every profile provably holds the samples the exact centre selects (|difference| + 1e-9 below the profile's
+    decision margin: the coordinates of every tap are sums of the same terms, so they move by at most the difference plus a
+    rounding), else the positions in ``idx`` to sample again (all of them when the ROI table itself changed on the host)."""
+    m = len(idx)
+    nflag = len(aux) - 3 * m
+    cen, margin, flag = aux[:2 * m].reshape(m, 2), aux[2 * m:3 * m], aux[3 * m:3 * m + nflag]
+    v, z = idx // spv, idx % spv
+    cx = fzx[v, 0] * z + fzx[v, 1]                                             # np.poly1d(fit)(z), ct.py:434-439
+    cy = fzy[v, 0] * z + fzy[v, 1]
+    radius = kw.get("radius2linepairs_mm", 47) * kw.get("scaling_factor", 1.0) / mm_per_pixel
+    if (w < radius + cx).any() or (h < radius + cy).any():                     # CircleProfile._ensure_array_size
+        raise ValueError("Array size not large enough to compute profile")
+    if rerun or flag.any():
+        return np.arange(m)
+    with np.errstate(invalid="ignore"):
+        ok = np.maximum(np.abs(cen[:, 0] - cx), np.abs(cen[:, 1] - cy)) + 1e-9 < margin
+    return None if ok.all() else np.flatnonzero(~ok)
+
+
 def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=None, slices=None, roll_deg: float = 0.0,
                  chunk_volumes: int | None = None, **kw):
     """Config #5's per-slice record for resident CatPhan volumes: one volume [S, H, W] or several
@@ -515,26 +572,57 @@ def ctp528_batch(volume: torch.Tensor, mm_per_pixel: float, fit_zx=None, fit_zy=
     given = fit_zx is not None and fit_zy is not None
     sl = None if slices is None else np.asarray(slices, dtype=np.int64)
     flats = [x[a:b].reshape((b - a) * spv, hh, ww) for a, b in bounds]
-    rois = [None if given else _phantom_roi_launch(f, mm_per_pixel) for f in flats]
     gz = (np.atleast_2d(np.asarray(fit_zx, dtype=np.float64)), np.atleast_2d(np.asarray(fit_zy, dtype=np.float64))) if given else None
+    # Pass one, queued without a single wait: the localisation of every chunk, and -- where the ROI table stays on the device
+    # (16-bit slices) -- the placement fit (pl_phantom_axis_fit), the circle profiles about ITS centres and the MTF searches.
+    # Round 5 stopped the device here for the ROI table, fitted on the host and only then queued the second half: 0.8 ms of
+    # a 4.85 ms pass with nothing running.
+    queued = []
+    for (a, b), f in zip(bounds, flats):
+        if sl is None:
+            pos, local = None, None
+        else:
+            pos = np.flatnonzero((sl >= a * spv) & (sl < b * spv))
+            local = sl[pos] - a * spv
+        q = dict(a=a, b=b, f=f, pos=pos, local=local, roi=None if given else _phantom_roi_launch(f, mm_per_pixel), dev=None)
+        table = getattr(q["roi"][1], "device_table", None) if q["roi"] is not None else None
+        if table is not None and (local is None or len(local)):
+            _, cen, flag = ops.phantom_axis_fit(table, b - a)
+            prof, idx, margin = ctp528_profiles_batch(f, mm_per_pixel, None, None, slices=local, roll_deg=roll_deg,
+                                                      slices_per_volume=spv, device_centers=cen, **kw)
+            sel = cen if local is None else cen[_device_index(idx, cen.device)]
+            aux = ops.HostCopy(torch.cat([sel.reshape(-1), margin, flag.to(torch.float64)]))
+            q["dev"] = (prof, idx, _ctp528_mtf_launch(prof), aux)
+        queued.append(q)
     second, where, per_chunk = [], [], []
-    for (a, b), f, pend in zip(bounds, flats, rois):
+    for q in queued:
+        a, b, f, local = q["a"], q["b"], q["f"], q["local"]
         if given:
             roi, fzx, fzy = None, gz[0][a:b], gz[1][a:b]
         else:
-            roi = _phantom_roi_finish(pend)
-            fzx, fzy = find_phantom_axes_batch(roi, b - a)
+            roi = _phantom_roi_finish(q["roi"])
+            fzx, fzy = find_phantom_axes_batch(roi, b - a)                 # the reference's np.polyfit, bit for bit
         # every chunk keeps its ROI table and fits -- also one that holds none of the requested slices -- so that the
         # [V, 2] fit tables are indexed by the GLOBAL volume number below
         per_chunk.append((roi, np.atleast_2d(fzx), np.atleast_2d(fzy)))
-        if sl is None:
-            local = None
-        else:
-            pos = np.flatnonzero((sl >= a * spv) & (sl < b * spv))
-            where.append(pos)
-            local = sl[pos] - a * spv
+        if q["pos"] is not None:
+            where.append(q["pos"])
         if local is not None and len(local) == 0:
             continue
+        if q["dev"] is not None:
+            prof, idx, mtf_pending, aux = q["dev"]
+            redo = _device_centres_disagree(aux.numpy(), idx, spv, np.atleast_2d(fzx), np.atleast_2d(fzy), hh, ww, mm_per_pixel,
+                                            kw, rerun=bool((q["roi"][1].numpy()[:, 0] == 5).any()))
+            if redo is None:
+                second.append((prof, idx + a * spv, mtf_pending))
+                continue
+            if len(redo) < len(idx):                                       # (never observed: a tap within 1e-9 of a decision)
+                fix, _ = ctp528_profiles_batch(f, mm_per_pixel, fzx, fzy, slices=idx[redo], roll_deg=roll_deg,
+                                               slices_per_volume=spv, **kw)
+                prof = prof.clone()
+                prof[_device_index(redo, prof.device)] = fix
+                second.append((prof, idx + a * spv, _ctp528_mtf_launch(prof)))
+                continue
         prof, idx = ctp528_profiles_batch(f, mm_per_pixel, fzx, fzy, slices=local, roll_deg=roll_deg, slices_per_volume=spv, **kw)
         second.append((prof, idx + a * spv, _ctp528_mtf_launch(prof)))
     parts = [(prof, idx, _ctp528_mtf_finish(pend)) for prof, idx, pend in second]

@@ -706,14 +706,39 @@ def circle_radians(size: float, start_angle: float = 0, ccw: bool = True) -> np.
     return rads
 
 
+_ring_cache: dict = {}
+
+
+def _ring_args(sidx, radii: np.ndarray, n: int, dev):
+    """Slice index [n] (int64) and radii [n, nr] on the device, cached: for a CatPhan pass they are the same numbers batch after
+    batch, and a pageable host-to-device copy in the middle of a pass waits for everything queued before it."""
+    r = np.ascontiguousarray(radii, dtype=np.float64)
+    key = (None if sidx is None else sidx.tobytes(), r.tobytes(), r.shape, n, str(dev))
+    hit = _ring_cache.get(key)
+    if hit is None:
+        if r.ndim == 1:
+            r = np.broadcast_to(r[None, :], (n, r.shape[0]))
+        pack = np.empty(n * (r.shape[1] + 1), dtype=np.float64)
+        pack[:n].view(np.int64)[:] = sidx if sidx is not None else 0
+        pack[n:] = r.reshape(-1)
+        d = torch.from_numpy(pack).to(dev)
+        if len(_ring_cache) > 16:
+            _ring_cache.clear()
+        hit = _ring_cache[key] = (d[:n].view(torch.int64), d[n:].view(n, r.shape[1]))
+    return hit
+
+
 def circle_profile(frames: torch.Tensor, cx, cy, radii, size: float, start_angle: float = 0,
-                   ccw: bool = True, divisor: float = 1.0, combine=None) -> torch.Tensor:
+                   ccw: bool = True, divisor: float = 1.0, combine=None, want_margin: bool = False):
     """``ndimage.map_coordinates(order=0)`` along circles, summed over ``radii`` and divided by
-    ``divisor`` (pylinac/core/profile.py:2279-2283, 2473-2483).  ``cx, cy``: scalar or [N];
-    ``radii``: [nr] or [N, nr]; ``size`` = pi * r_max * 2 * sampling_ratio.  -> float64 [N, nsamp].
+    ``divisor`` (pylinac/core/profile.py:2279-2283, 2473-2483).  ``cx, cy``: scalar or [N] (numpy / python numbers, or
+    float64 DEVICE tensors [N]: nothing is uploaded then); ``radii``: [nr] or [N, nr]; ``size`` = pi * r_max * 2 *
+    sampling_ratio.  -> float64 [N, nsamp].
     ``combine=(slice_index, slices_per_volume, plusminus)``: ``frames`` is a stack of whole volumes and profile i is taken
     on ``combine_surrounding_slices(slice_index[i] +- plusminus, "max")`` of its own volume (pylinac/ct.py:3351-3386) --
-    the maximum is formed per tap, the combined slices are never built; N is then ``len(slice_index)``."""
+    the maximum is formed per tap, the combined slices are never built; N is then ``len(slice_index)``.
+    ``want_margin`` (with ``combine``) -> (profiles, margin float64 [N]): how far each profile's centre may move before any
+    of its samples changes (``pl_circle_profile_combined_ex``)."""
     x = _frames(frames)
     n_stack, h, w = x.shape
     dev = x.device
@@ -725,33 +750,62 @@ def circle_profile(frames: torch.Tensor, cx, cy, radii, size: float, start_angle
         sidx = None
         n = n_stack
     d_cos, d_sin, nsamp = _circle_tables(size, start_angle, ccw, dev)
-    # ONE host-to-device copy for the per-profile arguments (slice index, radii, centres): five separate pageable copies
-    # were five synchronisations per call
-    r = np.asarray(radii, dtype=np.float64)
-    if r.ndim == 1:
-        r = np.broadcast_to(r[None, :], (n, r.shape[0]))
-    nr = r.shape[1]
-    pack = np.empty(n * (nr + 3), dtype=np.float64)
-    pack[:n].view(np.int64)[:] = sidx if sidx is not None else 0
-    pack[n:n + n * nr] = r.reshape(-1)
-    pack[n + n * nr:2 * n + n * nr] = np.broadcast_to(np.asarray(cx, dtype=np.float64), (n,))
-    pack[2 * n + n * nr:] = np.broadcast_to(np.asarray(cy, dtype=np.float64), (n,))
-    d_pack = torch.from_numpy(pack).to(dev)
-    d_sidx = d_pack[:n].view(torch.int64)
-    r = d_pack[n:n + n * nr].view(n, nr)
-    cxs = d_pack[n + n * nr:2 * n + n * nr]
-    cys = d_pack[2 * n + n * nr:]
+    r_host = np.asarray(radii, dtype=np.float64)
+    if isinstance(cx, torch.Tensor) and isinstance(cy, torch.Tensor):
+        d_sidx, r = _ring_args(sidx, r_host, n, dev)
+        cxs, cys = cx.to(torch.float64).contiguous(), cy.to(torch.float64).contiguous()
+        if cxs.numel() != n or cys.numel() != n or cxs.device != dev:
+            raise ValueError("device centres: one (x, y) per profile, on the frames' device")
+    else:
+        # ONE host-to-device copy for the per-profile arguments (slice index, radii, centres): five separate pageable copies
+        # were five synchronisations per call
+        r = r_host
+        if r.ndim == 1:
+            r = np.broadcast_to(r[None, :], (n, r.shape[0]))
+        nr = r.shape[1]
+        pack = np.empty(n * (nr + 3), dtype=np.float64)
+        pack[:n].view(np.int64)[:] = sidx if sidx is not None else 0
+        pack[n:n + n * nr] = r.reshape(-1)
+        pack[n + n * nr:2 * n + n * nr] = np.broadcast_to(np.asarray(cx, dtype=np.float64), (n,))
+        pack[2 * n + n * nr:] = np.broadcast_to(np.asarray(cy, dtype=np.float64), (n,))
+        d_pack = torch.from_numpy(pack).to(dev)
+        d_sidx = d_pack[:n].view(torch.int64)
+        r = d_pack[n:n + n * nr].view(n, nr)
+        cxs = d_pack[n + n * nr:2 * n + n * nr]
+        cys = d_pack[2 * n + n * nr:]
     out = torch.empty((n, nsamp), dtype=torch.float64, device=dev)
     if combine is not None:
-        check(_lib.load().pl_circle_profile_combined(x.data_ptr(), _dt(x), n_stack, h, w, d_sidx.data_ptr(), n, int(spv),
-                                                     int(pm), d_cos.data_ptr(), d_sin.data_ptr(), nsamp, r.data_ptr(),
-                                                     r.shape[1], cxs.data_ptr(), cys.data_ptr(), float(divisor),
-                                                     out.data_ptr(), _stream()), "pl_circle_profile_combined")
-        return out
+        margin = torch.full((n,), float("inf"), dtype=torch.float64, device=dev) if want_margin else None
+        check(_lib.load().pl_circle_profile_combined_ex(x.data_ptr(), _dt(x), n_stack, h, w, d_sidx.data_ptr(), n, int(spv),
+                                                        int(pm), d_cos.data_ptr(), d_sin.data_ptr(), nsamp, r.data_ptr(),
+                                                        r.shape[1], cxs.data_ptr(), cys.data_ptr(), float(divisor),
+                                                        out.data_ptr(), 0 if margin is None else margin.data_ptr(),
+                                                        _stream()), "pl_circle_profile_combined_ex")
+        return (out, margin) if want_margin else out
+    if want_margin:
+        raise ValueError("want_margin needs combine=")
     check(_lib.load().pl_circle_profile(x.data_ptr(), _dt(x), n, h, w, d_cos.data_ptr(), d_sin.data_ptr(),
                                         nsamp, r.data_ptr(), r.shape[1], cxs.data_ptr(), cys.data_ptr(),
                                         float(divisor), out.data_ptr(), _stream()), "pl_circle_profile")
     return out
+
+
+def phantom_axis_fit(roi: torch.Tensor, n_volumes: int, x_adjustment: float = 0.0, y_adjustment: float = 0.0):
+    """``pl_phantom_axis_fit``: the device's placement fit of ``CatPhanBase.find_phantom_axis`` (pylinac/ct.py:2398-2446) over
+    the ROI tables [n_volumes * spv, 8] of ``edge_regions``.  -> (fit float64 [V, 4] = zx slope, zx intercept, zy slope, zy
+    intercept; centres float64 [V * spv, 2] = (x, y); flag int32 [V])."""
+    t = roi.contiguous()
+    n = t.shape[0]
+    if t.dim() != 2 or t.shape[1] != 8 or t.dtype != torch.float64 or n % int(n_volumes):
+        raise ValueError("roi: float64 [n_volumes * slices_per_volume, 8]")
+    spv = n // int(n_volumes)
+    dev = t.device
+    fit = torch.empty((int(n_volumes), 4), dtype=torch.float64, device=dev)
+    centers = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    flag = torch.empty(int(n_volumes), dtype=torch.int32, device=dev)
+    check(_lib.load().pl_phantom_axis_fit(t.data_ptr(), int(n_volumes), spv, float(x_adjustment), float(y_adjustment),
+                                          fit.data_ptr(), centers.data_ptr(), flag.data_ptr(), _stream()), "pl_phantom_axis_fit")
+    return fit, centers, flag
 
 
 def sobel(frames: torch.Tensor, axis: int) -> torch.Tensor:

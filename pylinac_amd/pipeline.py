@@ -89,9 +89,10 @@ class EpidPipeline:
         self.wts, self.host_wts, self.radius = ops._device_weights(self.sigma, dev)
         self.prm = ops.make_peak_params(w, fwxm_height=self.fwxm_height / 100, max_number=1)
 
-    def run(self, frames: torch.Tensor, events: dict | None = None) -> EpidResult:
+    def run(self, frames: torch.Tensor, events: dict | None = None, chunks=None) -> EpidResult:
         """One pass over a resident batch.  ``events``: optional {stage: [(start, stop), ...]} sink;
-        when given, every stage is bracketed by HIP events on the launch stream."""
+        when given, every stage is bracketed by HIP events on the launch stream.  ``chunks``: ``run_from_host``'s plan
+        [((first frame, count), copy-done event), ...]; None = the whole batch at once."""
         if frames.dtype != torch.uint16 or tuple(frames.shape) != (self.n, self.h, self.w):
             raise ValueError(f"expected uint16 [{self.n},{self.h},{self.w}] frames")
         if not frames.is_cuda:
@@ -174,6 +175,43 @@ class EpidPipeline:
                                                                           colsum + lo * w * 8, st), stream)
             separate_tail()
 
-        filters(0, self.n, main)
-        rest(0, self.n, main)
+        if chunks is None:
+            filters(0, self.n, main)
+            rest(0, self.n, main)
+        else:
+            # run_from_host: chunk k's kernels wait for chunk k's copy only; the copy engine streams chunk k + 1 meanwhile
+            for (lo, m), ready in chunks:
+                main.wait_event(ready)
+                filters(lo, m, main)
+                done = torch.cuda.Event()
+                done.record(main)
+                self._stage_free.append(done)              # the staging rows may be overwritten once the Gaussian has read them
+                rest(lo, m, main)
         return EpidResult(self.out, self.profile, self.thr, self.fwxm, self.peaks.status)
+
+    def run_from_host(self, host_frames: torch.Tensor, chunks: int = 8, events: dict | None = None) -> EpidResult:
+        """The step for frames that arrive in (pinned) HOST memory -- what a loader hands over.
+        The batch is cut into ``chunks`` pieces; a copy stream moves piece k + 1 over PCIe while the launch stream runs the
+        whole pipeline on piece k, so the pass costs the copy plus ONE piece's kernels instead of copy + all kernels
+        (scripts/time_pcie_inclusive.py).  Results are those of ``run`` on the same frames (every stage is per frame)."""
+        if host_frames.dtype != torch.uint16 or tuple(host_frames.shape) != (self.n, self.h, self.w):
+            raise ValueError(f"expected uint16 [{self.n},{self.h},{self.w}] frames")
+        if not hasattr(self, "_stage"):
+            self._stage = torch.empty((self.n, self.h, self.w), dtype=torch.uint16, device=self.device)
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._stage_free = []
+        chunks = max(1, min(int(chunks), self.n))
+        per = -(-self.n // chunks)
+        cs = self._copy_stream
+        for ev in self._stage_free:                            # the previous pass's Gaussians have read the staging buffer
+            cs.wait_event(ev)
+        self._stage_free = []
+        plan = []
+        for lo in range(0, self.n, per):
+            m = min(per, self.n - lo)
+            with torch.cuda.stream(cs):
+                self._stage[lo:lo + m].copy_(host_frames[lo:lo + m], non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(cs)
+            plan.append(((lo, m), ready))
+        return self.run(self._stage, events=events, chunks=plan)

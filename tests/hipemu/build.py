@@ -26,7 +26,7 @@ CXX = str(_CLANG) if _CLANG.exists() else "g++"
 
 SOURCES = ["runtime.hip", "interp.hip", "gamma.hip", "roi.hip", "canny.hip", "elementwise.hip", "reduce.hip",
            "edge.hip", "circle.hip", "spectral.hip", "xim.hip", "planar.hip", "ccl.hip", "ct.hip", "features.hip", "peaks.hip",
-           "hist_otsu.hip", "picketfence.hip", "median.hip", "gaussian.hip", "features_sweep.hip", "slice_regions.hip", "edge_stream.hip", "hill.hip"]
+           "hist_otsu.hip", "picketfence.hip", "median.hip", "gaussian.hip", "features_sweep.hip", "slice_regions.hip", "edge_stream.hip", "hill.hip", "dicom.hip", "ct_axis.hip"]
 if CXX != "g++":
     SOURCES += ["gaussian_rw.hip", "gaussian_mm.hip"]
 

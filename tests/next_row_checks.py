@@ -2045,3 +2045,197 @@ def check_bb_sweep_run_table_tiers(dev, full=True):
     assert torch.equal(res["level"], lv["level"]) and torch.equal(res["xy"][:, 0], lv["xy"][:, 0])
     assert torch.equal(alone["xy"][:3, 0], lv["xy"][:3, 0])
     return 4
+
+
+# ---- f1, the DICOM half ------------------------------------------------------------------------------------------------
+def _dicom_cases(golden):
+    g = golden("dicom")
+    return {k[len("file__"):]: (g[k], g["expect__" + k[len("file__"):]]) for k in g.files if k.startswith("file__")}
+
+
+def check_dicom_golden(golden, dev):
+    """pylinac_amd.dicom (Part-10 walk on the host, pl_dicom_decode on the device) against the fixtures of
+    tests/golden/make_dicom_golden.py: `pixel_array` of every case bit for bit (container dtype, pydicom 2.x semantics), the
+    pydicom >= 3 unused-bit correction where BitsStored < BitsAllocated, `astype`, the rescaled / inverted float64 array of
+    `DicomImage.__init__` (pylinac/core/image.py:1431-1444) against the oracle's restatement, and the metadata-driven
+    properties (image.py:1491-1578)."""
+    from oracle import pylinac_oracle as orc
+    from pylinac_amd import dicom
+
+    cases = _dicom_cases(golden)
+    assert len(cases) >= 16
+    for name, (blob, expect) in cases.items():
+        meta, data = dicom.read_part10(blob.tobytes())
+        want, tags, start = orc.dicom_pixel_array(blob)
+        assert np.array_equal(want, expect) and want.dtype == expect.dtype, name      # the oracle against the encoded array
+        assert meta.PixelData[0] == start, name
+        frames, _ = dicom.load_frames([blob.tobytes()], raw_pixels=True, device=dev)
+        got = dicom._to_numpy(frames)
+        assert got.dtype == expect.dtype and np.array_equal(got.reshape(expect.shape), expect), name
+        # DicomImage: rescale + inversion as the tags say
+        img = dicom.DicomImage(blob.tobytes())
+        ref = orc.dicom_image_array(blob)
+        assert img.array.dtype == ref.dtype and np.array_equal(img.array, ref), name
+        for dt in (np.float32, np.float64, np.int32, np.uint8):
+            a = dicom.DicomImage(blob.tobytes(), dtype=dt, raw_pixels=True).array
+            r = orc.dicom_image_array(blob, dtype=dt, raw_pixels=True)
+            assert a.dtype == r.dtype and np.array_equal(a, r), (name, dt)
+        for inv in (True, False):
+            if inv and expect.dtype in (np.int8, np.uint32):
+                with pytest.raises(NotImplementedError):
+                    dicom.DicomImage(blob.tobytes(), invert_pixels=True)
+                continue
+            a = dicom.DicomImage(blob.tobytes(), invert_pixels=inv).array
+            assert np.array_equal(a, orc.dicom_image_array(blob, invert_pixels=inv)), (name, inv)
+        if "stored12" in name:
+            fixed, _ = dicom.load_frames([blob.tobytes()], raw_pixels=True, correct_unused_bits=True, device=dev)
+            w3, _, _ = orc.dicom_pixel_array(blob, correct_unused_bits=True)
+            assert np.array_equal(dicom._to_numpy(fixed)[0], w3), name
+            assert not np.array_equal(w3, expect)                                      # the fixture's unused bits are dirty
+            lim = 4096 if expect.dtype == np.uint16 else 2048
+            assert w3.max() < lim and w3.min() >= (0 if expect.dtype == np.uint16 else -2048)
+    # the tags the image properties read
+    img = dicom.DicomImage(cases["u16_epid_tags"][0].tobytes())
+    assert img.sid == 1500.0 and img.sad == 1000.0
+    assert abs(img.dpmm - (1 / 0.336) * 1.5) < 1e-12 and abs(img.dpi - img.dpmm * 25.4) < 1e-9
+    cx, cy = img.center.x, img.center.y
+    assert abs(img.cax.x - (cx - 1.5 * img.dpmm / 1.5)) < 1e-12 and abs(img.cax.y - (cy + -2.25 * img.dpmm / 1.5)) < 1e-12
+    assert img.metadata.GantryAngle == 90.0 and img.metadata.get("RescaleSlope") is None
+    plain = dicom.DicomImage(cases["u16_explicit"][0].tobytes(), dpi=100, sid=1200)
+    assert plain.sid == 1200 and plain.dpi == 100 and abs(plain.dpmm - 100 / 25.4) < 1e-12 and plain.cax.x == plain.center.x
+    # a CT-like stack: several files -> one batch, the fused rescale
+    ct = cases["i16_ct"][0].tobytes()
+    stack, metas = dicom.load_frames([ct, ct, ct], device=dev)
+    assert stack.shape[0] == 3 and stack.dtype == torch.float64
+    assert np.array_equal(stack[1].cpu().numpy(), orc.dicom_image_array(cases["i16_ct"][0]))
+    # truncated Pixel Data: pydicom raises ValueError
+    short = cases["u16_explicit"][0][:-200].tobytes()
+    with pytest.raises((ValueError, struct_error())):
+        dicom.load_frames([short], device=dev)
+
+
+def struct_error():
+    import struct
+
+    return struct.error
+
+
+def check_dicom_decode_fuzz(dev, frame_shapes=((9, 14), (16, 16)), n=3):
+    """pl_dicom_decode on random byte buffers: every container width, both representations, both byte orders, each of the
+    four alignments of the first frame, with / without the unused-bit correction, the three output forms -- against
+    np.frombuffer (+ numpy's own shifts / casts), bit for bit."""
+    from pylinac_amd import dicom
+
+    rng = np.random.default_rng(77)
+    for rows, cols in frame_shapes:
+        for bits in (8, 16, 32):
+            ib = bits // 8
+            for rep in (0, 1):
+                for big in (False, True):
+                    for shift in range(4):
+                        stored = int(rng.integers(max(2, bits - 7), bits + 1))
+                        gap = int(rng.integers(0, 5)) * ib + (0 if ib == 1 else 0)
+                        frame_bytes = rows * cols * ib
+                        buf = rng.integers(0, 256, shift + n * (frame_bytes + gap) + 8, dtype=np.uint8)
+                        offs = [shift + k * (frame_bytes + gap) for k in range(n)]
+                        dt = np.dtype((">" if big else "<") + ("i" if rep else "u") + str(ib))
+                        want = np.stack([np.frombuffer(buf[o:o + frame_bytes].tobytes(), dt).reshape(rows, cols) for o in offs])
+                        want = want.astype(dt.newbyteorder("="))
+                        fixed = want
+                        if stored < bits:
+                            fixed = (np.right_shift(np.left_shift(want, bits - stored), bits - stored) if rep
+                                     else want & want.dtype.type((1 << stored) - 1))
+                        for fix, ref in ((False, want), (True, fixed)):
+                            if ib * rows * cols % 4 and n > 1:
+                                continue
+                            kw = dict(rows=rows, cols=cols, bits_allocated=bits, bits_stored=stored, pixel_representation=rep,
+                                      big_endian=big, correct_unused_bits=fix, device=dev)
+                            got = dicom._to_numpy(dicom._check_status(dicom.decode_frames(buf, offs, out="container", **kw)))
+                            assert got.dtype == ref.dtype and np.array_equal(got, ref), (rows, cols, bits, rep, big, shift, fix)
+                            g32 = dicom.decode_frames(buf, offs, out="float32", **kw).cpu().numpy()
+                            assert np.array_equal(g32, ref.astype(np.float32))
+                            g64 = dicom.decode_frames(buf, offs, out="float64", rescale=(1.25, -1000.5), **kw).cpu().numpy()
+                            r64 = ref.astype(np.float64) * 1.25
+                            r64 += -1000.5
+                            assert np.array_equal(g64, r64)
+    # a frame that pokes out of the buffer is reported, the others are decoded
+    buf = rng.integers(0, 256, 1000, dtype=np.uint8)
+    x = dicom.decode_frames(buf, [0, 900], rows=10, cols=10, bits_allocated=16, bits_stored=16, pixel_representation=0, device=dev)
+    assert x._pl_status.cpu().tolist() == [0, 1]
+    with pytest.raises(ValueError):
+        dicom._check_status(x)
+    assert np.array_equal(dicom._to_numpy(x)[0], np.frombuffer(buf[:200].tobytes(), "<u2").reshape(10, 10))
+
+
+def check_ctp528_device_axis_path(dev, n_slices=8, size=256, mmpp=0.98):
+    """Round 6: ct.ctp528_batch places the circle profiles about the centre line fitted ON THE DEVICE (pl_phantom_axis_fit)
+    and reports the host's np.polyfit.  Held here: (1) the result equals the classic path's (the same call with the reported
+    fits handed in: host centres, no device fit) bit for bit; (2) the device's placement fit agrees with np.polyfit to 1e-9
+    and its median / np.isclose screen drops the same outlier slices; (3) when the margin test refuses some profiles
+    (forced), those are sampled again about the exact centres and the result does not change; (4) a slice that does not
+    show the phantom is left out of the fit exactly like the reference's `is_phantom_in_view` screen."""
+    from unittest import mock
+
+    from pylinac_amd import ct, ops
+    from pylinac_amd.synthetic import catphan_volume
+
+    vols = np.stack([catphan_volume(4000 + v, n_slices=n_slices, size=size, mm_per_pixel=mmpp) for v in range(2)])
+    vols[1, 2] = vols[1, 2, 0, 0]                       # one slice of air: no phantom in view (status != 0)
+    vols[1, 5] = np.roll(vols[1, 5], 9, axis=1)         # one slice shifted by 9 px: fails the isclose screen (atol 3)
+    x = torch.from_numpy(vols).to(dev)
+    res = ct.ctp528_batch(x, mmpp)
+    classic = ct.ctp528_batch(x, mmpp, fit_zx=res["fit_zx"], fit_zy=res["fit_zy"])
+    for k in ("rmtf", "maxs", "mins", "nregions", "center", "slices"):
+        assert np.array_equal(res[k], classic[k], equal_nan=True), k
+    assert torch.equal(torch.nan_to_num(res["profiles"], nan=-1.0), torch.nan_to_num(classic["profiles"], nan=-1.0))
+    assert res["roi"][n_slices + 2, 0] != 0 and (res["roi"][:n_slices, 0] == 0).all()
+    # the placement fit against the exact one
+    roi_dev = torch.from_numpy(res["roi"]).to(dev)
+    fit, cen, flag = ops.phantom_axis_fit(roi_dev, 2)
+    fit, cen, flag = fit.cpu().numpy(), cen.cpu().numpy(), flag.cpu().numpy()
+    assert (flag == 0).all()
+    assert np.allclose(fit[:, :2], res["fit_zx"], rtol=1e-9, atol=1e-9) and np.allclose(fit[:, 2:], res["fit_zy"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(cen, res["center"], rtol=0, atol=1e-9)
+    # (the shifted slice moved the fit if it had been kept: the exact fit without the screen differs)
+    z = np.arange(n_slices)
+    keep = np.ones(n_slices, bool)
+    keep[2] = False
+    loose = np.polyfit(z[keep], res["roi"][n_slices:, 4][keep], 1)
+    assert abs(loose[1] - res["fit_zx"][1][1]) > 0.1
+    # no phantom anywhere / one usable slice -> flags
+    empty = res["roi"].copy()
+    empty[:n_slices, 0] = 2
+    single = res["roi"].copy()
+    single[1:n_slices, 0] = 2
+    f1 = ops.phantom_axis_fit(torch.from_numpy(empty).to(dev), 2)[2].cpu().numpy()
+    f2 = ops.phantom_axis_fit(torch.from_numpy(single).to(dev), 2)[2].cpu().numpy()
+    assert f1.tolist() == [1, 0] and f2.tolist() == [2, 0]
+    # forced refusal of three profiles: sampled again about the exact centres, same answer
+    real = ct._device_centres_disagree
+    calls = []
+
+    def refuse(*a, **k):
+        assert real(*a, **k) is None
+        calls.append(1)
+        return np.array([0, 3, n_slices + 1])
+
+    with mock.patch.object(ct, "_device_centres_disagree", refuse):
+        again = ct.ctp528_batch(x, mmpp)
+    assert calls
+    for k in ("rmtf", "maxs", "mins", "nregions", "center"):
+        assert np.array_equal(res[k], again[k], equal_nan=True), k
+    assert torch.equal(torch.nan_to_num(res["profiles"], nan=-1.0), torch.nan_to_num(again["profiles"], nan=-1.0))
+    # a subset of slices, one volume per chunk
+    pick = np.array([1, n_slices + 3, n_slices + 4])
+    part = ct.ctp528_batch(x, mmpp, slices=pick, chunk_volumes=1)
+    assert np.array_equal(part["rmtf"], res["rmtf"][pick], equal_nan=True) and np.array_equal(part["center"], res["center"][pick])
+    # the margin really is the distance to the nearest decision: moving a centre by less keeps every sample
+    prof, idx, margin = ct.ctp528_profiles_batch(x[0], mmpp, None, None, slices_per_volume=n_slices,
+                                                 device_centers=torch.from_numpy(res["center"][:n_slices]).to(dev))
+    m = margin.cpu().numpy()
+    assert (m > 0).all() and (m <= 0.5).all()
+    for sign in (-1.0, 1.0):
+        moved = res["center"][:n_slices] + sign * 0.5 * m[:, None]
+        p2, _, _ = ct.ctp528_profiles_batch(x[0], mmpp, None, None, slices_per_volume=n_slices,
+                                            device_centers=torch.from_numpy(moved).to(dev))
+        assert torch.equal(torch.nan_to_num(p2, nan=-1.0), torch.nan_to_num(prof, nan=-1.0))

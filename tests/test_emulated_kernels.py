@@ -1058,3 +1058,17 @@ def test_emulated_pack_columns(emulated):
         ops.pack_columns([torch.zeros(n, dtype=torch.float32, device=emulated)], n)
     with pytest.raises(ValueError):
         ops.pack_columns([a] * 17, n)
+
+
+def test_emulated_dicom_decode(golden, emulated):
+    """f1, the DICOM half: the Part-10 walk + pl_dicom_decode on the emulated device against the fixtures and np.frombuffer."""
+    import next_row_checks as checks
+
+    checks.check_dicom_golden(golden, emulated)
+    checks.check_dicom_decode_fuzz(emulated, frame_shapes=((6, 10),), n=2)
+
+
+def test_emulated_ctp528_device_axis_path(emulated):
+    import next_row_checks as checks
+
+    checks.check_ctp528_device_axis_path(emulated)

@@ -2053,3 +2053,57 @@ def test_fwhm_batch_vs_single(golden, dev):
         want = profile.SingleProfile(profs[i].copy()).fwxm_data(50)
         for k in ("left index (exact)", "right index (exact)", "center value (@rounded)", "width (exact)"):
             assert np.isclose(d[k][i], want[k], rtol=1e-9, atol=1e-9), (i, k)
+
+
+@pytest.mark.gpu
+def test_dicom_decode_vs_fixtures_and_frombuffer(golden, dev):
+    """f1, the DICOM half (pylinac/core/image.py:1431-1444): Part-10 fixtures (tests/golden/make_dicom_golden.py), every
+    container format / byte order / alignment against np.frombuffer, and a batch at the bench's frame size: 64 files of one
+    1024 x 1024 uint16 frame each, file bytes uploaded as they are, one launch -> the frames that were encoded."""
+    import importlib.util
+
+    import next_row_checks as checks
+    from pylinac_amd import dicom
+
+    checks.check_dicom_golden(golden, dev)
+    checks.check_dicom_decode_fuzz(dev, frame_shapes=((9, 14), (16, 16), (61, 67)), n=3)
+    spec = importlib.util.spec_from_file_location("make_dicom_golden", os.path.join(os.path.dirname(__file__), "golden", "make_dicom_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rng = np.random.default_rng(5)
+    arrays = [rng.integers(0, 65536, (1024, 1024), dtype=np.uint16) for _ in range(64)]
+    files = [gen.part10(a, pad_text="x" * (2 * (k % 3))) for k, a in enumerate(arrays)]     # Pixel Data at varying alignments
+    frames, metas = dicom.load_frames(files, device=dev)
+    assert frames.shape == (64, 1024, 1024) and frames.dtype == torch.uint16
+    assert np.array_equal(dicom._to_numpy(frames), np.stack(arrays))
+    assert len({m.PixelData[0] % 4 for m in metas}) == 2
+
+
+@pytest.mark.gpu
+def test_epid_run_from_host_equals_run(dev):
+    """EpidPipeline.run_from_host (pinned host frames, copy of piece k + 1 under the kernels of piece k) returns exactly what
+    run() returns on the same frames, for every chunking, pass after pass (the staging buffer is reused)."""
+    from pylinac_amd.pipeline import EpidPipeline
+    from pylinac_amd.synthetic import epid_open_field_frames
+
+    n, h, w = 12, 256, 320
+    frames = epid_open_field_frames(n, h, w, seed0=21, device=dev, field_mm=40.0)
+    host = frames.cpu().pin_memory()
+    pipe = EpidPipeline(n, h, w, dev)
+    ref = pipe.run(frames)
+    want = (ref.frames.clone(), ref.profile.clone(), ref.record().clone())
+    for chunks in (1, 2, 5, 12, 40):
+        for _ in range(2):
+            res = pipe.run_from_host(host, chunks)
+            torch.cuda.synchronize()
+            assert torch.equal(res.frames, want[0]) and torch.equal(res.profile, want[1])
+            assert torch.equal(torch.nan_to_num(res.record()), torch.nan_to_num(want[2]))
+
+
+@pytest.mark.gpu
+def test_ctp528_device_axis_path(dev):
+    """Round 6: the circle profiles of ct.ctp528_batch are placed by a fit made on the device and verified against the
+    reference's np.polyfit through each profile's decision margin (tests/next_row_checks.py)."""
+    import next_row_checks as checks
+
+    checks.check_ctp528_device_axis_path(dev, n_slices=12, size=512, mmpp=0.5)

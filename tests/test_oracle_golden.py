@@ -780,3 +780,25 @@ def test_oracle_ctp528_slice_vs_reference_golden(golden):
         prof, rmtf = o.ctp528_slice(g["volume"], int(s), c, float(g["mmpp"]))
         assert np.allclose(prof, g["profiles"][j], rtol=0, atol=1e-9), s
         assert np.allclose(rmtf, g["rmtf"][j], rtol=1e-9, atol=1e-9, equal_nan=True), s
+
+
+def test_dicom_restatement_vs_fixtures(golden):
+    """f1, the DICOM half: the oracle's restatement of pydicom's native `pixel_array` on the Part-10 fixtures (the arrays
+    that were encoded; tests/golden/make_dicom_golden.py) and the identities the reference's own tests state for
+    `_rescale_dicom_values` (tests_basic/core/test_image.py:131-200)."""
+    g = golden("dicom")
+    names = [k[len("file__"):] for k in g.files if k.startswith("file__")]
+    assert len(names) >= 16
+    for name in names:
+        arr, tags, start = o.dicom_pixel_array(g["file__" + name])
+        want = g["expect__" + name]
+        assert arr.dtype == want.dtype and np.array_equal(arr, want), name
+        assert start % 2 == 0
+    ct = g["file__i16_ct"]
+    px, tags, _ = o.dicom_pixel_array(ct)
+    assert np.array_equal(o.dicom_image_array(ct), 1.5 * px + -1024)                      # RescaleSlope * pixel_array + RescaleIntercept
+    assert np.array_equal(o.dicom_image_array(ct, raw_pixels=True), px)                   # raw pixels: untouched
+    inv = o.dicom_image_array(g["file__u16_inverted_sign"])                               # PixelIntensityRelationshipSign = -1
+    px, _, _ = o.dicom_pixel_array(g["file__u16_inverted_sign"])
+    assert np.array_equal(inv, px.astype(float).max() - px.astype(float) + px.astype(float).min())
+    assert np.array_equal(o.dicom_image_array(g["file__u16_inverted_sign"], invert_pixels=False), px.astype(float))
