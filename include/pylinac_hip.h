@@ -105,6 +105,15 @@ int pl_warp_affine(const void* in, void* out, int dtype, int64_t n, int64_t h, i
 int pl_pack_columns(const void* const* d_cols, const int* is_int32, const int64_t* strides, const int64_t* offsets,
                     const double* adds, int k, int64_t n, double* d_out, void* stream);
 
+/* frame - frame.min() as uint16 where that is exact (every value an integer, no difference beyond max_range <= 65535):
+ * the bridge from what the reference's loader may produce -- int16 frames, float64 frames holding integers -- to the
+ * uint16 analyzers, whose ground() / normalize() (pylinac/picketfence.py:322-323, pylinac/winston_lutz.py:711-712) only ever
+ * see a - min.  dtype PL_I16 / PL_I32 / PL_F64; d_min [n] = the frames' minima (pl_minmax); d_flag int32 [n]: 1 = the frame
+ * does not qualify (non-integer value or range beyond max_range; its output is unspecified).  max_range 32767 for int16
+ * reproduces where the reference's own int16 ground() stops being exact (array_utils.py:102). */
+int pl_to_u16_exact(const void* in, int dtype, int64_t n, int64_t count, const double* d_min, double max_range,
+                    uint16_t* out, int32_t* d_flag, void* stream);
+
 /* out = a * factor   (same dtype; the multiply inside stretch(), array_utils.py:168) */
 int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,
              void* stream);

@@ -151,6 +151,7 @@ SIGNATURES = {
     "pl_nps2d_work_doubles": ([_l, _i], C.c_int64),
     "pl_radial_average": ([_p, _i, _i, _i, _p, _p], C.c_int),
     "pl_esf_mtf": ([_p, _p, _p, _i, _i, _i, _p, _p, _p, _p], C.c_int),
+    "pl_to_u16_exact": ([_p, _i, _l, _l, _p, _d, _p, _p, _p], C.c_int),
     "pl_dicom_decode": ([_p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _d, _d, _p, _p], C.c_int),
     "pl_colsum_to_mean": ([_p, _l, _i, _i, _p, _p], C.c_int),
     "pl_find_peaks_var": (

@@ -48,6 +48,25 @@ __device__ __forceinline__ void es_atomic_min(double* addr, double v) {
   atomicMin(reinterpret_cast<long long*>(addr), __double_as_longlong(v));
 }
 
+// v_min_f64 / v_max_f64 return the other operand when one is a NaN: a lane is taken out of a running minimum / maximum by
+// replacing the HIGH dword of its value with a NaN pattern -- one v_cndmask instead of a compare and two selects per
+// extremum (round 6: the extrema and selects were a quarter of the kernel's vector instructions outside the float64 sums)
+__device__ __forceinline__ double es_nan_unless(double v, bool keep) {
+  const long long b = __double_as_longlong(v);
+  const unsigned hi = keep ? (unsigned)((unsigned long long)b >> 32) : 0x7ff80000u;
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | ((unsigned long long)b & 0xffffffffull)));
+}
+__device__ __forceinline__ double es_min_num(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double es_max_num(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __global__ void es_init_kernel(double* __restrict__ rawmax, double* __restrict__ mn, double* __restrict__ mx, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * kEsThreads + threadIdx.x;
   if (i >= n) return;
@@ -133,8 +152,11 @@ edge_stream_kernel(const T* __restrict__ in, int h, int w, int strips, int segs,
       pending = ldo(noff);                                 // in flight for a whole step
       const double en = edge_row(ra, rb, rc);
       // rows below the frame (last segment only) repeat the last edge row: a register copy on the rare side of a branch
-      if (vr <= hm1) E[i] = en;
-      else E[i] = E[(i + WIN - 1) % WIN];
+      E[i] = en;
+      if (__builtin_expect(vr > hm1, 0)) {                 // (wave-uniform: a branch around two moves, not a select per row)
+        E[i] = E[(i + WIN - 1) % WIN];
+        asm volatile("" : "+v"(E[i]));
+      }
       const int ro = vr - RAD;
       if (ro >= r0 && ro < r1) {
         const double ctr = E[(i + WIN - RAD) % WIN];
@@ -156,11 +178,10 @@ edge_stream_kernel(const T* __restrict__ in, int h, int w, int strips, int segs,
           sel = sel & (mrow[cc] != 0);                     // every lane reads inside the frame (clamped column)
           mrow += w;
         }
-        if (out_lane) rmax = ctr > rmax ? ctr : rmax;
-        if (sel) {
-          lo = a1 < lo ? a1 : lo;
-          hi = a1 > hi ? a1 : hi;
-        }
+        rmax = es_max_num(rmax, es_nan_unless(ctr, out_lane));
+        const double a1s = es_nan_unless(a1, sel);
+        lo = es_min_num(lo, a1s);
+        hi = es_max_num(hi, a1s);
         if (has_out) {
           if (out_lane) orow[vc] = (OutT)a1;
           orow += w;

@@ -259,6 +259,24 @@ scale_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int64
   });
 }
 
+// frame - frame.min() as uint16, where that is EXACT: every value an integer, no difference beyond `max_range`.  Lets the
+// uint16 analyzers take what the reference's loader may hand over instead -- int16 frames of a signed panel, float64 frames
+// that hold integers (`dtype=float`, or rescale tags with an integer slope and intercept) -- with identical results:
+// ground() / normalize() only ever see a - min (picketfence.py:322-323, winston_lutz.py:711-712).  flag[frame] = 1 marks a
+// frame that does not qualify (its output is unspecified).
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+to_u16_exact_kernel(const T* __restrict__ in, unsigned short* __restrict__ out, int64_t count, int64_t chunk, int bpf,
+                    const double* __restrict__ mn, double max_range, int32_t* __restrict__ flag) {
+  bool bad = false;
+  stream_chunk<T, unsigned short>(in, out, count, chunk, bpf, [&](T a, int64_t fr) -> unsigned short {
+    const double d = (double)a - mn[fr];                   // exact for integers below 2^53
+    bad |= !(d >= 0.0 && d <= max_range) || d != floor(d);
+    return (unsigned short)(unsigned)(d >= 0.0 && d <= 65535.0 ? d : 0.0);
+  });
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&flag[blockIdx.x / bpf], 1);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 threshold_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t count, int64_t chunk, int bpf,
@@ -424,6 +442,23 @@ extern "C" int pl_pack_columns(const void* const* d_cols, const int* is_int32, c
   hipLaunchKernelGGL(pack_columns_kernel, dim3((unsigned)pl_cdiv(n * k, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, c, k, n,
                      d_out);
   return pl_check_launch("pl_pack_columns");
+}
+
+extern "C" int pl_to_u16_exact(const void* in, int dtype, int64_t n, int64_t count, const double* d_min, double max_range,
+                               uint16_t* out, int32_t* d_flag, void* stream) {
+  PL_EW_PROLOGUE("pl_to_u16_exact");
+  PL_REQUIRE(d_min && d_flag, "null pointer");
+  PL_REQUIRE(dtype == PL_I16 || dtype == PL_F64 || dtype == PL_I32, "int16, int32 or float64 frames");
+  PL_REQUIRE(max_range >= 0.0 && max_range <= 65535.0, "max_range in [0, 65535]");
+  hipError_t e = hipMemsetAsync(d_flag, 0, (size_t)n * sizeof(int32_t), st);
+  if (e != hipSuccess) { pl_set_error("pl_to_u16_exact: memset: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
+  PL_DISPATCH_DTYPE(dtype, T, {
+    Plan p = make_plan<T>(count);
+    if (int rc = check_grid(n, p.bpf, "pl_to_u16_exact")) return rc;
+    hipLaunchKernelGGL(to_u16_exact_kernel<T>, dim3((unsigned)(n * p.bpf)), dim3(kThreads), 0, st, (const T*)in, out, count,
+                       p.chunk, p.bpf, d_min, max_range, d_flag);
+  });
+  return pl_check_launch("pl_to_u16_exact");
 }
 
 extern "C" int pl_scale(const void* in, void* out, int dtype, int64_t n, int64_t count, double factor,

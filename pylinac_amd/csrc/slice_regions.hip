@@ -292,35 +292,56 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
   u64* und = reinterpret_cast<u64*>(L.parent) + (size_t)wv * U;
   double* scratch = reinterpret_cast<double*>(reinterpret_cast<u64*>(L.parent) + (size_t)(kSrThreads / PL_WAVE) * U) +
                     (size_t)wv * es_scratch_doubles(sizeof(T) == 4 ? ea.rad : 0);
+  // Round 6 (phase stopwatch, profiles/r06b_sr_phases.txt: the build was 78 % of this kernel, and vector-instruction bound:
+  // two float32 -> float64 conversions, two float64 compares and an integer division per pixel word).  A float32 plane is
+  // now compared in its BIT domain.  The exact value lies between the two float32 neighbours of the stored value v (edge
+  // values are >= 0, bit patterns order like the values): with a = the largest float32 <= t,
+  //     prev(v) > t  <=>  bits(v) >= bits(a) + 2        -> foreground, decided
+  //     next(v) > t >= prev(v)  <=>  bits(v) - bits(a) in {0, 1}   (v != 0: a stored 0 is an exact 0)   -> undecided
+  // one v_cmp per mask, whose result IS the wave's ballot.  t < 0: everything is foreground; t NaN / beyond FLT_MAX: nothing.
+  unsigned fa = 0xffffffffu, f2 = 0xffffffffu;            // bits(a), bits(a) + 2: "nothing is foreground, nothing undecided"
+  if constexpr (sizeof(T) == 4) {
+    if (t < 0.0) { fa = 0u; f2 = 0u; }
+    else if (t < 3.0e38) {
+      float a = (float)t;                                  // RN; step down when it rounded up
+      if ((double)a > t) a = __uint_as_float(__float_as_uint(a) - 1u);
+      fa = __float_as_uint(a);
+      f2 = fa + 2u;
+    }
+  }
+  const unsigned zero_und = (sizeof(T) == 4 && t < 0.0) ? 1u : 0u;      // (t < 0: fa = f2 = 0 must not flag anything)
   for (int q0 = wv * U; q0 < nwords; q0 += (kSrThreads / PL_WAVE) * U) {
     T v[U];
     bool inside[U];
+    // (row, word) of the first word by ONE scalar division; the unrolled body steps them
+    int r = __builtin_amdgcn_readfirstlane(q0 / ww), j = __builtin_amdgcn_readfirstlane(q0 - (q0 / ww) * ww);
+    {
+      int rr = r, jj = j;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int q = min(q0 + u, nwords - 1);
-      const int r = q / ww, j = q - r * ww;
-      const int c = j * 64 + lane;
-      inside[u] = (q0 + u < nwords) & (c < w);
-      v[u] = src[(int64_t)r * w + (c < w ? c : w - 1)];
+      for (int u = 0; u < U; ++u) {
+        const bool live = q0 + u < nwords;                 // wave-uniform
+        const int c = jj * 64 + lane;
+        inside[u] = live & (c < w);
+        const int rl = live ? rr : h - 1, cl = c < w ? c : w - 1;
+        v[u] = src[(unsigned)rl * (unsigned)w + (unsigned)cl];
+        if (++jj == ww) { jj = 0; ++rr; }
+      }
     }
     bool any_und = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int q = q0 + u;
       if (q >= nwords) continue;                           // wave-uniform
-      bool fg;
+      u64 m;
       if constexpr (sizeof(T) == 4) {
-        // the float64 value lies between the float32 value's two neighbours
-        double vlo, vhi;
-        es_f32_bracket(v[u], vlo, vhi);
-        fg = inside[u] & (vlo > t);
-        const u64 todo = __ballot(inside[u] & !(vlo > t) & (vhi > t));
+        const unsigned vb = __float_as_uint(v[u]);
+        m = __ballot(inside[u] & (vb >= f2));
+        const u64 todo = zero_und ? 0ull : __ballot(inside[u] & ((vb - fa) < 2u) & (vb != 0u));
         if (lane == 0) und[u] = todo;
         any_und |= todo != 0;
       } else {
-        fg = inside[u] & (thr ? ((double)v[u] > t) : (v[u] != (T)0));
+        m = __ballot(inside[u] & (thr ? ((double)v[u] > t) : (v[u] != (T)0)));
       }
-      const u64 m = __ballot(fg);
       if (lane == 0) L.plane[q] = m;
     }
     if constexpr (sizeof(T) == 4) {

@@ -531,9 +531,9 @@ def _ctp528_mtf_finish(pending):
 def _device_centres_disagree(aux: np.ndarray, idx: np.ndarray, spv: int, fzx: np.ndarray, fzy: np.ndarray, h: int, w: int,
                              mm_per_pixel: float, kw: dict, rerun: bool):
     """Pass one sampled the profiles ``idx`` about the DEVICE's centres; the reference's are ``np.poly1d(np.polyfit(...))``.
-    -> None when every profile provably holds the samples the exact centre selects (|difference| + 1e-9 below the profile's
-    decision margin: the coordinates of every tap are sums of the same terms, so they move by at most the difference plus a
-    rounding), else the positions in ``idx`` to sample again (all of them when the ROI table itself changed on the host)."""
+    -> None when every profile provably holds the samples the exact centre selects (|difference| + a few roundings below the
+    profile's decision margin), else the positions in ``idx`` to sample again (all of them when the ROI table itself changed
+    on the host)."""
     m = len(idx)
     nflag = len(aux) - 3 * m
     cen, margin, flag = aux[:2 * m].reshape(m, 2), aux[2 * m:3 * m], aux[3 * m:3 * m + nflag]
@@ -545,8 +545,12 @@ def _device_centres_disagree(aux: np.ndarray, idx: np.ndarray, spv: int, fzx: np
         raise ValueError("Array size not large enough to compute profile")
     if rerun or flag.any():
         return np.arange(m)
+    # a tap's coordinate is fl(fl(cos * r) + centre) and the decision reads fl(coordinate + 0.5): the product is the same
+    # number on both sides, each of the two sums rounds by at most half an ulp of a coordinate (< max(h, w)) -- four
+    # roundings in all between the two evaluations, covered sixteen times over by the slack
+    slack = 16 * np.finfo(np.float64).eps * max(h, w)
     with np.errstate(invalid="ignore"):
-        ok = np.maximum(np.abs(cen[:, 0] - cx), np.abs(cen[:, 1] - cy)) + 1e-9 < margin
+        ok = np.maximum(np.abs(cen[:, 0] - cx), np.abs(cen[:, 1] - cy)) + slack < margin
     return None if ok.all() else np.flatnonzero(~ok)
 
 

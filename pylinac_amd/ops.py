@@ -214,6 +214,24 @@ def invert(frames: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def to_u16_exact(frames: torch.Tensor, max_range: float | None = None):
+    """``frame - frame.min()`` as uint16 where that is exact (``pl_to_u16_exact``): int16 / int32 / float64 frames whose
+    values are integers spanning at most ``max_range`` (default: 32767 for int16 -- beyond it the reference's own int16
+    ``ground()`` wraps around --, 65535 otherwise).  -> (uint16 frames, flag int32 [N]: 1 = frame does not qualify)."""
+    x = _frames(frames)
+    if x.dtype not in (torch.int16, torch.int32, torch.float64):
+        raise TypeError("to_u16_exact: int16, int32 or float64 frames")
+    n = x.shape[0]
+    if max_range is None:
+        max_range = 32767.0 if x.dtype == torch.int16 else 65535.0
+    mn, _ = minmax(x)
+    out = torch.empty(x.shape, dtype=torch.uint16, device=x.device)
+    flag = torch.empty(n, dtype=torch.int32, device=x.device)
+    check(_lib.load().pl_to_u16_exact(x.data_ptr(), _dt(x), n, x[0].numel(), mn.data_ptr(), float(max_range), out.data_ptr(),
+                                      flag.data_ptr(), _stream()), "pl_to_u16_exact")
+    return out, flag
+
+
 def scale(frames: torch.Tensor, factor: float) -> torch.Tensor:
     """``array * scalar`` in the array's dtype (the multiply inside ``stretch``)."""
     x = _frames(frames)

@@ -106,8 +106,15 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, mlc: str = "MILLENNIUM", nu
     ``np.std`` sequence for the edge test instead of deciding it from exact integer row moments where the margin allows
     (identical results; a test knob)."""
     x = ops._frames(frames)
-    if x.dtype != torch.uint16:
-        raise TypeError("analyze_batch needs uint16 frames (the reference's int16 ground() overflows)")
+    unfit = None
+    if x.dtype in (torch.int16, torch.float64):
+        # what the reference's loader may hand over instead of uint16: a signed panel's int16, or float64 holding integers
+        # (``dtype=float``; rescale tags with an integer slope and intercept).  ground() / normalize() (picketfence.py:322-323)
+        # only see a - min, which pl_to_u16_exact forms exactly; frames it cannot represent -- non-integer float64 values,
+        # an int16 range beyond 32767 where the reference's own ground() wraps -- come back with status 3 in every window
+        x, unfit = ops.to_u16_exact(x)
+    elif x.dtype != torch.uint16:
+        raise TypeError("analyze_batch takes uint16 frames, int16 frames, or float64 frames holding integers")
     if orientation not in ("UP_DOWN", "LEFT_RIGHT"):
         raise ValueError("orientation must be 'UP_DOWN' or 'LEFT_RIGHT'")
     lr = orientation == "LEFT_RIGHT"
@@ -171,5 +178,9 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, mlc: str = "MILLENNIUM", nu
                             rec.data_ptr(),
                             status.data_ptr(), 0, 0, st), "pl_pf_measure")
     rec = rec.view(n, nl, cap, 3)
+    if unfit is not None:                                   # (device-side selects: no synchronisation)
+        bad = (unfit != 0).view(n, 1, 1)
+        status = torch.where(bad.expand(n, nl, cap).reshape(-1), torch.full_like(status, 3), status)
+        rec = torch.where(bad.unsqueeze(-1), torch.full_like(rec, float("nan")), rec)
     return PFBatchResult([v[0] for v in view], pk_idx, peaks.count, spacing, rec[..., 0], status.view(n, nl, cap),
                          rec[..., 1] if separate_leaves else None, rec[..., 2] if separate_leaves else None)

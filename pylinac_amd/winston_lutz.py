@@ -20,6 +20,8 @@ bb_y)`` record per frame.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 import torch
 
@@ -86,7 +88,7 @@ def field_centroids_batch(frames: torch.Tensor, stats: _FrameStats | None = None
 def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0, low_density: bool = False,
                   clean_edges: bool = True, tile_maxima: bool = True):
     """The per-image part of ``WLBaseImage.analyze`` (pylinac/winston_lutz.py:709-725) for a batch of uint16 frames
-    resident on the GPU:
+    resident on the GPU (float64 and int16 frames: see the first lines of the body):
 
         check_inversion_by_histogram((0.01, 50, 99.99))   image.py:899-926
         _clean_edges()                                     winston_lutz.py:1109-1133
@@ -107,8 +109,14 @@ def analyze_batch(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0
     from . import features
 
     x = ops._frames(frames)
+    if x.dtype in (torch.float64, torch.int16):
+        # what the reference's loader hands over once RescaleSlope / RescaleIntercept exist (float64: pydicom's
+        # apply_rescale, pylinac/core/image.py:375-389) or for a signed panel: the same sequence on the float
+        # kernels (``_analyze_batch_general``) -- several passes per frame instead of one and a bit, but resident and exact
+        return _analyze_batch_general(x, dpmm, bb_diameter_mm, low_density, clean_edges)
     if x.dtype != torch.uint16:
-        raise TypeError("analyze_batch needs uint16 frames")
+        raise TypeError("analyze_batch takes uint16, int16 or float64 frames (float32 never leaves the reference's loader: "
+                        "apply_rescale widens to float64)")
     n, h, w = x.shape
     if n == 0:
         return dict(record=np.zeros((0, 4)), status=np.zeros(0, np.int32), inverted=np.zeros(0, bool), crop=np.zeros(0, np.int32))
@@ -219,5 +227,107 @@ def _analyze_batch_host(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float
         cnt = bb["count"].cpu().numpy()
         rec = np.concatenate([fld[:, :2], np.where(cnt[:, None] > 0, bxy, np.nan)], axis=1)
         record[keep] = rec
+        status[keep] = (cnt == 0).astype(np.int32)
+    return dict(record=record, status=status, inverted=inverted, crop=crop)
+
+
+def _percentiles_f64(x: torch.Tensor, qs) -> np.ndarray:
+    """``np.percentile(frame, qs)`` per float64 frame -> float64 [N, len(qs)] on the host (exact order statistics by key
+    bisection, ``pl_order_stats_f64``; numpy's ``_lerp``)."""
+    from .canny import _percentile_f64
+
+    return np.stack([_percentile_f64(x, float(q)).cpu().numpy() for q in qs], axis=1)
+
+
+def _edge_strip_extrema(x: torch.Tensor, ws: int = 2):
+    """min / max over the four ``ws``-wide edge strips of every float64 frame (``_clean_edges``, winston_lutz.py:1121-1127)"""
+    from .roi import rectangle_stats_batch
+
+    n, h, w = x.shape
+    strips = np.array([[0, ws, 0, w], [0, h, 0, ws], [h - ws, h, 0, w], [0, h, w - ws, w]], dtype=np.float64)
+    s = rectangle_stats_batch(x, strips)[0].cpu().numpy()          # [N, 4, (count, mean, std, min, max, ...)]
+    return s[:, :, 3].min(axis=1), s[:, :, 4].max(axis=1)
+
+
+def _analyze_batch_general(frames: torch.Tensor, dpmm: float, bb_diameter_mm: float = 5.0, low_density: bool = False,
+                           clean_edges: bool = True, check_inversion: bool = True):
+    """``analyze_batch`` for float64 frames (and int16 frames, widened exactly): every step of ``WLBaseImage.analyze``
+    (winston_lutz.py:709-725) as the reference performs it on such an array -- ``np.percentile`` on the float values,
+    ``-a + max + min``, ``a - min``, ``a / max``, ``as_binary``, ``binary_fill_holes`` + ``center_of_mass``,
+    ``SizedDiskLocator`` on the float window -- with the general float kernels; the frames stay on the device.  Same result
+    dictionary as ``analyze_batch``.
+
+    int16: the reference's own ``ground()`` (``array - array.min()`` IN int16, array_utils.py:102) wraps around for a frame
+    whose range exceeds 32767 and everything after it is an overflow artefact; such a frame raises ``ValueError`` here.  Below
+    that the integer steps are exact in float64 (``invert`` wraps in int16 too, but its result lies inside [min, max])."""
+    from . import features
+
+    x = ops._frames(frames)
+    n, h, w = x.shape
+    if n == 0:
+        return dict(record=np.zeros((0, 4)), status=np.zeros(0, np.int32), inverted=np.zeros(0, bool), crop=np.zeros(0, np.int32))
+    if x.dtype == torch.int16:
+        mn, mx = ops.minmax(x)
+        if bool(((mx - mn) > 32767).any()):
+            raise ValueError("int16 frame with a range beyond 32767: the reference's ground() overflows int16 there "
+                             "(array_utils.py:102) and its result is an artefact; widen the frames first")
+        x = ops.normalize(x, 1.0)                                   # exact conversion to float64
+    dev = x.device
+    # ---- check_inversion_by_histogram((0.01, 50, 99.99)), image.py:899-926
+    inverted = np.zeros(n, dtype=bool)
+    if check_inversion:
+        p = _percentiles_f64(x, _INVERSION_Q)
+        inverted = np.abs(p[:, 1] - p[:, 0]) > np.abs(p[:, 1] - p[:, 2])
+    if inverted.any():
+        idx = torch.from_numpy(np.nonzero(inverted)[0]).to(dev)
+        x = x.clone()
+        x[idx] = ops.invert(x[idx].contiguous())
+    crop = np.zeros(n, dtype=np.int32)
+    record = np.full((n, 4), np.nan, dtype=np.float64)
+    status = np.zeros(n, dtype=np.int32)
+    keep = np.ones(n, dtype=bool)
+    # ---- _clean_edges, winston_lutz.py:1109-1133: frames that need cropping change shape and are finished on their own
+    if clean_edges:
+        pe = _percentiles_f64(x, _EDGE_Q)
+        emin, emax = _edge_strip_extrema(x, 2)
+        rng = pe[:, 1] - pe[:, 0]
+        noisy = (emin < pe[:, 0] - rng / 10) | (emax > pe[:, 1] + rng / 10)
+        for i in np.nonzero(noisy)[0]:
+            f = x[i]
+            safety_stop = min(f.shape) / 10
+            while safety_stop > 0:
+                f = f[2:-2, 2:-2].contiguous()                     # BaseImage.crop(window_size)
+                safety_stop -= 1
+                q = _percentiles_f64(f[None], _EDGE_Q)[0]
+                lo_, hi_ = _edge_strip_extrema(f[None], 2)
+                r_ = q[1] - q[0]
+                if not (lo_[0] < q[0] - r_ / 10 or hi_[0] > q[1] + r_ / 10):
+                    break
+            crop[i] = (h - f.shape[0]) // 2
+            # (the inversion test belongs to the uncropped frame and has been applied: winston_lutz.py:709-710 precede :711)
+            one = _analyze_batch_general(f[None], dpmm, bb_diameter_mm, low_density, clean_edges=False, check_inversion=False)
+            record[i], status[i] = one["record"][0], one["status"][0]
+            keep[i] = False
+    if keep.any():
+        sel = x if keep.all() else x[torch.from_numpy(np.nonzero(keep)[0]).to(dev)].contiguous()
+        nrm = ops.normalize(ops.ground(sel))                        # ground(); normalize(), winston_lutz.py:711-712
+        # ---- find_field_centroids, winston_lutz.py:764-780
+        fp = _percentiles_f64(nrm, _FIELD_Q)
+        thr = torch.from_numpy(np.ascontiguousarray((fp[:, 1] - fp[:, 0]) / 2 + fp[:, 0])).to(dev)
+        cen = ops.binary_centroid(ops.fill_holes(ops.as_binary(nrm, thr), 4)).cpu().numpy()      # (row, col, count)
+        # ---- find_bb_centroids, winston_lutz.py:788-806 (SizedDiskLocator.from_center_physical about the image centre)
+        tol = float(np.interp(bb_diameter_mm, (1.5, 30), (2, 4)))
+        hh, ww = sel.shape[1], sel.shape[2]
+        win = (40 + bb_diameter_mm) * dpmm
+        ex, ey = ww / 2, hh / 2
+        left, right = max(math.floor(ex - win / 2), 0), min(math.ceil(ex + win / 2), ww)
+        top, bottom = max(math.floor(ey - win / 2), 0), min(math.ceil(ey + win / 2), hh)
+        sample = nrm[:, top:bottom, left:right].contiguous()
+        if not low_density:
+            sample = ops.invert(sample)
+        bb = features.find_features_batch(sample, dpmm, bb_diameter_mm / 2, tol)
+        bxy = bb["xy"][:, 0, :].cpu().numpy() + np.array([left, top], dtype=np.float64)
+        cnt = bb["count"].cpu().numpy()
+        record[keep] = np.concatenate([cen[:, [1, 0]], np.where(cnt[:, None] > 0, bxy, np.nan)], axis=1)
         status[keep] = (cnt == 0).astype(np.int32)
     return dict(record=record, status=status, inverted=inverted, crop=crop)

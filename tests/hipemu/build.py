@@ -35,6 +35,8 @@ _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)
 
 _WAITCNT = re.compile(r'asm\s+volatile\s*\(\s*"s_waitcnt[^;]*;')
 _MED3 = re.compile(r'asm\("v_med3_[ui]32[^;]*;')
+_MINF64 = re.compile(r'asm\("v_min_f64[^;]*;')                           # operands a, b -> r: the NaN-ignoring minimum = fmin
+_MAXF64 = re.compile(r'asm\("v_max_f64[^;]*;')
 _PIN = re.compile(r'asm\s+volatile\s*\(\s*""[^;]*;')                      # empty asm: a register-allocation hint
 _LDSABS = re.compile(r'__hip_atomic_fetch_add\(\(pl_lds_u32\*\)\(uintptr_t\)byte_addr[^;]*;')   # absolute LDS address -> offset into the emulator's block
 _LDSBASE = re.compile(r'return \(unsigned\)reinterpret_cast<uintptr_t>\(lds_ptr\);')
@@ -53,6 +55,8 @@ def _rewrite(text: str) -> str:
     text = _LDSBASE.sub("return (unsigned)(static_cast<const unsigned char*>(lds_ptr) - static_cast<const unsigned char*>(hipemu::dyn_lds()));", text)
     text = _LDSTYPE.sub("", text)
     text = _MED3.sub("r = std::max(std::min(a, b), std::min(std::max(a, b), c));", text)
+    text = _MINF64.sub("r = std::fmin(a, b);", text)
+    text = _MAXF64.sub("r = std::fmax(a, b);", text)
     # `extern __shared__ T name[];`  ->  a pointer to the emulator's dynamic-LDS buffer
     return _DYN.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(hipemu::dyn_lds());", text)
 

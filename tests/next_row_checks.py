@@ -201,6 +201,42 @@ def check_wl_analyze_batch(golden, dev, frames=None):
         assert np.array_equal(r2["record"], res["record"][sub]) and np.array_equal(r2["inverted"], g["inverted"][sub])
 
 
+def check_wl_analyze_batch_other_dtypes(golden, dev, frames=(0, 6, 7)):
+    """winston_lutz.analyze_batch on what the reference's loader produces -- float64 frames (stored value
+    * RescaleSlope + RescaleIntercept, pydicom's apply_rescale) and int16 frames -- against the oracle's restatement of the
+    per-image sequence run on exactly those arrays (field CAX exact, BB 1e-9), and against the uint16 result of the same
+    pixels (an affine map with a positive slope moves nothing: same CAX, BB within 1e-9); plus the refused cases."""
+    from oracle import pylinac_oracle as orc
+    from pylinac_amd import winston_lutz as wl
+
+    g = golden("wl")
+    sel = list(frames)
+    dpmm, bb_mm = 1 / float(g["pixel_mm"]), float(g["bb_mm"])
+    u16 = g["frames"][sel]
+    base = wl.analyze_batch(torch.from_numpy(u16).to(dev), dpmm, bb_mm)
+    scaled = u16.astype(np.float64) * 4.315e-5
+    scaled += -0.25
+    i16 = (u16.astype(np.int32) // 2 - 16384).astype(np.int16)                     # range < 32768: the reference's int16 path is exact
+    for arr in (scaled, i16):
+        res = wl.analyze_batch(torch.from_numpy(arr).to(dev), dpmm, bb_mm)
+        for k, f in enumerate(arr):
+            fx, fy, bx, by, inv, crop = orc.wl_analyze_frame(f, dpmm, bb_mm)
+            assert res["record"][k, 0] == fx and res["record"][k, 1] == fy, (arr.dtype, k)
+            assert np.allclose(res["record"][k, 2:], [bx, by], rtol=0, atol=1e-9), (arr.dtype, k)
+            assert bool(res["inverted"][k]) == bool(inv) and int(res["crop"][k]) == int(crop), (arr.dtype, k)
+        assert np.array_equal(res["status"], base["status"]) and np.array_equal(res["crop"], base["crop"])
+        if arr.dtype == np.float64:
+            assert np.array_equal(res["record"][:, :2], base["record"][:, :2])
+            assert np.allclose(res["record"][:, 2:], base["record"][:, 2:], rtol=0, atol=1e-9)
+    wide = np.zeros((1, 64, 64), np.int16)
+    wide[0, :8] = -30000
+    wide[0, 8:] = 30000
+    with pytest.raises(ValueError):
+        wl.analyze_batch(torch.from_numpy(wide).to(dev), dpmm, bb_mm)
+    with pytest.raises(TypeError):
+        wl.analyze_batch(torch.from_numpy(u16.astype(np.float32)).to(dev), dpmm, bb_mm)
+
+
 def check_field_cax(dev):
     """ops.field_cax (pl_field_cax: one streaming reduction + an LDS window flood fill) against scipy's
     binary_fill_holes + center_of_mass on masks with holes, nested holes, shapes touching the frame border (a hole that
@@ -1561,8 +1597,13 @@ def check_edge_otsu(dev, shapes=((2, 70, 130, np.int16), (1, 33, 65, np.uint16),
             p32 = e64.to(torch.float32)
             for plane, kw in ((p32, dict(frames=x, sigma=sigma)), (e64, {})):
                 for sel in (dict(spans=spans), dict(mask=mt)):
-                    thr, raw = ops.edge_otsu(plane, lo, hi, scale=0.8, **kw, **sel)
+                    thr, raw, work = ops.edge_otsu(plane, lo, hi, scale=0.8, return_work=True, **kw, **sel)
                     assert torch.equal(raw, want_raw) and torch.equal(thr, want_thr), (n, h, w, sigma, plane.dtype, list(sel))
+                    # round 6 (float32 planes are binned in the bit domain): all 256 counts, not only the threshold they give
+                    lin0 = torch.empty((n, 257), dtype=torch.float64, device=e64.device)
+                    from pylinac_amd import _lib as _l
+                    ops.check(_l.load().pl_linspace_edges(lo.data_ptr(), hi.data_ptr(), 256, n, lin0.data_ptr(), ops._stream()), "edges")
+                    assert torch.equal(work[:, :256], ops.hist_uniform(e64, lin0, mt)), (n, h, w, sigma, plane.dtype, list(sel))
             # a NARROW range (np.histogram drops what lies outside): the bins shrink to a few float32 steps, so the float32
             # plane cannot decide most pixels inside and the exact recomputation carries the histogram
             sel_vals = e64[0][mt.bool()]
@@ -1664,6 +1705,18 @@ def check_phantom_roi_fused_vs_separate(dev, slices=(0, 24, 44, 79)):
     tt = e64.reshape(n, -1).sort(dim=1).values[:, -500].contiguous()     # high: a mask of few runs
     q = ops.edge_regions(p32, x, 1, tt, 0, False, 64, return_mask=True, want_table=False)
     assert not q["status"].any() and torch.equal(q["mask"], (e64 > tt[:, None, None]).to(torch.uint8))
+    # round 6: the comparison runs in the float32 BIT domain (bits(v) against bits(a), a = the largest float32 <= t): every
+    # position of t relative to the float32 grid, the ends of the range, and thresholds nothing can pass
+    f32 = tt.to(torch.float32)
+    up = torch.nextafter(f32, torch.full_like(f32, float("inf"))).to(torch.float64)
+    dn = torch.nextafter(f32, torch.full_like(f32, float("-inf"))).to(torch.float64)
+    variants = [f32.to(torch.float64), up, dn, (up + f32.to(torch.float64)) / 2, torch.nextafter(tt, torch.full_like(tt, float("inf"))),
+                torch.nextafter(tt, torch.full_like(tt, float("-inf"))), torch.zeros_like(tt), torch.full_like(tt, -1.0),
+                torch.full_like(tt, 1e-300), torch.full_like(tt, 1e-45), torch.full_like(tt, 3.5e38), torch.full_like(tt, 1e300),
+                torch.full_like(tt, float("nan")), e64.reshape(n, -1).min(dim=1).values, e64.reshape(n, -1).max(dim=1).values]
+    for k, tv in enumerate(variants):
+        q = ops.edge_regions(p32, x, 1, tv.contiguous(), 0, False, 64, return_mask=True, want_table=False)
+        assert torch.equal(q["mask"], (e64 > tv[:, None, None]).to(torch.uint8)), k
     return new
 
 
@@ -1871,6 +1924,48 @@ def check_pf_mlc_device(g, dev):
                                 edge_threshold=float(thr)).position[0, :, :len(peaks)].cpu().numpy()
         assert np.array_equal(np.isnan(got), np.isnan(want["position"])), thr
         assert 0 < int(np.isnan(want["position"]).sum()) < want["position"].size       # the threshold splits the windows
+
+
+def check_pf_other_dtypes(g, dev):
+    """picketfence.analyze_batch on int16 frames and on float64 frames holding integers -- what the
+    reference's loader produces for a signed panel, for ``dtype=float`` and for integer rescale tags -- against the oracle run
+    on exactly those arrays (``normalize(ground(a))``: positions bit for bit, same NaN pattern) and against the uint16 result
+    of the same pixels; frames that cannot be bridged exactly (non-integer values, an int16 range beyond 32767 where the
+    reference's own ground() wraps) come back refused: status 3, NaN positions."""
+    from oracle import pylinac_oracle as o
+    from pylinac_amd import picketfence as ppf
+
+    name, mlc, orient = next(iter(_pf_mlc_cases(g)))
+    raw, dpmm = np.ascontiguousarray(g[f"{name}.cropped"]), float(g[f"{name}.dpmm"])
+    base = ppf.analyze_batch(torch.from_numpy(raw[None]).to(dev), dpmm, mlc=mlc, orientation=orient)
+    half = (raw.astype(np.int32) // 2).astype(np.uint16)                    # fits int16 after the shift below
+    variants = {
+        "float64": raw.astype(np.float64),
+        "float64 + intercept": raw.astype(np.float64) - 1024.0,
+        "int16": (half.astype(np.int32) - 20000).astype(np.int16),
+    }
+    for tag, arr in variants.items():
+        res = ppf.analyze_batch(torch.from_numpy(arr[None]).to(dev), dpmm, mlc=mlc, orientation=orient)
+        ref = o.pf_measure(o.normalize(o.ground(arr)), dpmm, mlc=mlc, orientation=orient)
+        P = len(ref["peak_idxs"])
+        got = res.position[0, :, :P].cpu().numpy()
+        assert int(res.picket_count[0]) == P and float(res.spacing[0]) == ref["spacing"], tag
+        assert np.array_equal(np.isnan(got), np.isnan(ref["position"])), tag
+        assert np.array_equal(got[~np.isnan(got)], ref["position"][~np.isnan(got)]), tag
+        if tag.startswith("float64"):
+            assert torch.equal(torch.nan_to_num(res.position, nan=-1.0), torch.nan_to_num(base.position, nan=-1.0)), tag
+            assert torch.equal(res.status, base.status)
+    # refused frames inside a batch: the others are measured as usual
+    frac = raw.astype(np.float64)
+    frac[3, 5] += 0.5
+    batch = np.stack([raw.astype(np.float64), frac])
+    res = ppf.analyze_batch(torch.from_numpy(batch).to(dev), dpmm, mlc=mlc, orientation=orient)
+    assert torch.equal(res.status[0], base.status[0]) and bool((res.status[1] == 3).all()) and bool(torch.isnan(res.position[1]).all())
+    wide = np.where(raw > raw.mean(), 30000, -30000).astype(np.int16)
+    res = ppf.analyze_batch(torch.from_numpy(wide[None]).to(dev), dpmm, mlc=mlc, orientation=orient)
+    assert bool((res.status == 3).all())
+    with pytest.raises(TypeError):
+        ppf.analyze_batch(torch.from_numpy(raw.astype(np.float32)[None]).to(dev), dpmm, mlc=mlc, orientation=orient)
 
 
 def check_fwxm_short_profiles(dev, trials=600):

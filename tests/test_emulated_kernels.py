@@ -1072,3 +1072,15 @@ def test_emulated_ctp528_device_axis_path(emulated):
     import next_row_checks as checks
 
     checks.check_ctp528_device_axis_path(emulated)
+
+
+def test_emulated_wl_analyze_batch_other_dtypes(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_wl_analyze_batch_other_dtypes(golden, emulated, frames=(0, 7))
+
+
+def test_emulated_pf_other_dtypes(golden, emulated):
+    import next_row_checks as checks
+
+    checks.check_pf_other_dtypes(golden("picketfence_mlc"), emulated)

@@ -2107,3 +2107,30 @@ def test_ctp528_device_axis_path(dev):
     import next_row_checks as checks
 
     checks.check_ctp528_device_axis_path(dev, n_slices=12, size=512, mmpp=0.5)
+
+
+@pytest.mark.gpu
+def test_analyze_batch_takes_what_the_loader_produces(golden, dev):
+    """the batched Winston-Lutz and picket-fence analyzers on int16 and float64 frames (post
+    apply_rescale), against the oracle on exactly those arrays and against the uint16 result; 1024 x 1024 frames included."""
+    import next_row_checks as checks
+    from pylinac_amd import picketfence as ppf
+    from pylinac_amd import winston_lutz as wl
+    from pylinac_amd.synthetic import pf_frames, wl_frames
+
+    checks.check_wl_analyze_batch_other_dtypes(golden, dev, frames=(0, 6, 7))
+    checks.check_pf_other_dtypes(golden("picketfence_mlc"), dev)
+    # BASELINE's frame sizes: 1024 x 1024 Winston-Lutz frames as rescaled float64, 768 x 1024 picket fences as float64 / int16
+    fr = torch.from_numpy(wl_frames(6)).to(dev)
+    base = wl.analyze_batch(fr, 1 / 0.336, 5.0)
+    scaled = fr.to(torch.float64) * 4.315e-5 - 0.25
+    res = wl.analyze_batch(scaled, 1 / 0.336, 5.0)
+    assert np.array_equal(res["record"][:, :2], base["record"][:, :2]) and np.array_equal(res["status"], base["status"])
+    assert np.allclose(res["record"][:, 2:], base["record"][:, 2:], rtol=0, atol=1e-9)
+    pf = pf_frames(4, device=dev)
+    b = ppf.analyze_batch(pf, 1 / 0.390625, num_pickets=10)
+    for other in (pf.to(torch.float64) - 300.0, (pf.to(torch.int32) - 32768).to(torch.int16)):
+        r = ppf.analyze_batch(other, 1 / 0.390625, num_pickets=10)
+        if other.dtype == torch.int16 and bool((r.status == 3).all()):
+            continue                                            # (a range beyond 32767 is refused like the reference's overflow)
+        assert torch.equal(r.status, b.status) and torch.equal(torch.nan_to_num(r.position, nan=-1.0), torch.nan_to_num(b.position, nan=-1.0))
