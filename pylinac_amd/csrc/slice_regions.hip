@@ -254,6 +254,41 @@ struct SrEdgeArgs {
   double* roi;                // [n][8] or NULL
 };
 
+// The float32 plane -> bit plane for frames whose rows are WW whole 64-pixel words (w = 64 WW: 256, 512 and 1024 wide CT
+// slices): a wave takes 32 / WW consecutive rows per trip, and every one of its 32 loads is `scalar row base + lane + a
+// compile-time offset` -- no vector address arithmetic between the loads (r06e: the generic loop below spent seventeen
+// instructions, one of them a quarter-rate multiply, between two loads, so a wave's 32 loads trickled out over a memory
+// latency instead of being in flight together; the build ran at 3 TB/s on 16 waves per CU).  Marks undecided words in `und`
+// exactly like the generic loop; -> whether any was seen.
+template <int WW>
+__device__ __forceinline__ bool sr_build_rows(const float* __restrict__ src, int h, int r0, unsigned f2, unsigned fa, bool zero_und,
+                                              u64* __restrict__ plane, u64* __restrict__ und, int lane) {
+  constexpr int R = 32 / WW, W = 64 * WW;
+  float v[32];
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int rr = u / WW, jj = u % WW;
+    const int rl = r0 + rr < h ? r0 + rr : h - 1;          // wave-uniform: rows past the frame re-read its last row
+    v[u] = src[(unsigned)rl * (unsigned)W + (unsigned)(jj * 64) + (unsigned)lane];
+  }
+  bool any_und = false;
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int rr = u / WW, jj = u % WW;
+    if (r0 + rr >= h) continue;                            // wave-uniform
+    const unsigned vb = __float_as_uint(v[u]);
+    const u64 m = __ballot(vb >= f2);
+    const u64 todo = zero_und ? 0ull : __ballot(((vb - fa) < 2u) & (vb != 0u));
+    if (lane == 0) {
+      plane[(r0 + rr) * WW + jj] = m;
+      und[u] = todo;
+    }
+    any_und |= todo != 0;
+  }
+  (void)R;
+  return any_und;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kSrThreads)
 mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, int h, int w, int clear_ext, int fill,
@@ -310,7 +345,41 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
     }
   }
   const unsigned zero_und = (sizeof(T) == 4 && t < 0.0) ? 1u : 0u;      // (t < 0: fa = f2 = 0 must not flag anything)
-  for (int q0 = wv * U; q0 < nwords; q0 += (kSrThreads / PL_WAVE) * U) {
+  bool rows_done = false;
+  if constexpr (sizeof(T) == 4) {
+    if (w == ww * 64 && (ww == 4 || ww == 8 || ww == 16)) {
+      rows_done = true;
+      const int rows_per = 32 / ww;
+      for (int r0 = wv * rows_per; r0 < h; r0 += (kSrThreads / PL_WAVE) * rows_per) {
+        const float* fsrc = reinterpret_cast<const float*>(src);
+        const bool any_und = ww == 8 ? sr_build_rows<8>(fsrc, h, r0, f2, fa, zero_und != 0u, L.plane, und, lane)
+                             : (ww == 4 ? sr_build_rows<4>(fsrc, h, r0, f2, fa, zero_und != 0u, L.plane, und, lane)
+                                        : sr_build_rows<16>(fsrc, h, r0, f2, fa, zero_und != 0u, L.plane, und, lane));
+        if (any_und) {                                     // a handful of pixels per thousand slices
+          pl_wave_sync();
+          const int q0 = r0 * ww;
+#pragma unroll 1
+          for (int u = 0; u < U && q0 + u < nwords; ++u) {
+            u64 todo = und[u];
+            const int q = q0 + u, r = q / ww, j = q - r * ww;
+            u64 add = 0;
+            while (todo) {
+              const int l = __builtin_ctzll(todo);
+              todo &= todo - 1;
+              const int64_t off = f * (int64_t)h * w;
+              const double ev = ea.raw_is_signed
+                                    ? es_exact_wave(static_cast<const short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch)
+                                    : es_exact_wave(static_cast<const unsigned short*>(ea.raw) + off, h, w, r, j * 64 + l, ea.wts, ea.rad, scratch);
+              if (ev > t) add |= 1ull << l;
+            }
+            if (lane == 0 && add) L.plane[q] |= add;
+          }
+          pl_wave_sync();
+        }
+      }
+    }
+  }
+  for (int q0 = wv * U; q0 < nwords && !rows_done; q0 += (kSrThreads / PL_WAVE) * U) {
     T v[U];
     bool inside[U];
     // (row, word) of the first word by ONE scalar division; the unrolled body steps them

@@ -201,7 +201,7 @@ def check_wl_analyze_batch(golden, dev, frames=None):
         assert np.array_equal(r2["record"], res["record"][sub]) and np.array_equal(r2["inverted"], g["inverted"][sub])
 
 
-def check_wl_analyze_batch_other_dtypes(golden, dev, frames=(0, 6, 7)):
+def check_wl_analyze_batch_other_dtypes(golden, dev, frames=(0, 6, 7), int16_frames=None):
     """winston_lutz.analyze_batch on what the reference's loader produces -- float64 frames (stored value
     * RescaleSlope + RescaleIntercept, pydicom's apply_rescale) and int16 frames -- against the oracle's restatement of the
     per-image sequence run on exactly those arrays (field CAX exact, BB 1e-9), and against the uint16 result of the same
@@ -217,7 +217,10 @@ def check_wl_analyze_batch_other_dtypes(golden, dev, frames=(0, 6, 7)):
     scaled = u16.astype(np.float64) * 4.315e-5
     scaled += -0.25
     i16 = (u16.astype(np.int32) // 2 - 16384).astype(np.int16)                     # range < 32768: the reference's int16 path is exact
+    keep16 = list(range(len(sel))) if int16_frames is None else [sel.index(f) for f in int16_frames]
     for arr in (scaled, i16):
+        if arr.dtype == np.int16 and len(keep16) < len(sel):     # (the emulated suite runs the int16 form on fewer frames)
+            arr, base = arr[keep16], {k: v[keep16] for k, v in base.items()}
         res = wl.analyze_batch(torch.from_numpy(arr).to(dev), dpmm, bb_mm)
         for k, f in enumerate(arr):
             fx, fy, bx, by, inv, crop = orc.wl_analyze_frame(f, dpmm, bb_mm)
@@ -2262,7 +2265,7 @@ def check_dicom_decode_fuzz(dev, frame_shapes=((9, 14), (16, 16)), n=3):
     assert np.array_equal(dicom._to_numpy(x)[0], np.frombuffer(buf[:200].tobytes(), "<u2").reshape(10, 10))
 
 
-def check_ctp528_device_axis_path(dev, n_slices=8, size=256, mmpp=0.98):
+def check_ctp528_device_axis_path(dev, n_slices=8, size=256, mmpp=0.98, light=False):
     """Round 6: ct.ctp528_batch places the circle profiles about the centre line fitted ON THE DEVICE (pl_phantom_axis_fit)
     and reports the host's np.polyfit.  Held here: (1) the result equals the classic path's (the same call with the reported
     fits handed in: host centres, no device fit) bit for bit; (2) the device's placement fit agrees with np.polyfit to 1e-9
@@ -2321,9 +2324,10 @@ def check_ctp528_device_axis_path(dev, n_slices=8, size=256, mmpp=0.98):
         assert np.array_equal(res[k], again[k], equal_nan=True), k
     assert torch.equal(torch.nan_to_num(res["profiles"], nan=-1.0), torch.nan_to_num(again["profiles"], nan=-1.0))
     # a subset of slices, one volume per chunk
-    pick = np.array([1, n_slices + 3, n_slices + 4])
-    part = ct.ctp528_batch(x, mmpp, slices=pick, chunk_volumes=1)
-    assert np.array_equal(part["rmtf"], res["rmtf"][pick], equal_nan=True) and np.array_equal(part["center"], res["center"][pick])
+    if not light:
+        pick = np.array([1, n_slices + 3, n_slices + 4])
+        part = ct.ctp528_batch(x, mmpp, slices=pick, chunk_volumes=1)
+        assert np.array_equal(part["rmtf"], res["rmtf"][pick], equal_nan=True) and np.array_equal(part["center"], res["center"][pick])
     # the margin really is the distance to the nearest decision: moving a centre by less keeps every sample
     prof, idx, margin = ct.ctp528_profiles_batch(x[0], mmpp, None, None, slices_per_volume=n_slices,
                                                  device_centers=torch.from_numpy(res["center"][:n_slices]).to(dev))

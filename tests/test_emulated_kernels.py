@@ -1071,13 +1071,13 @@ def test_emulated_dicom_decode(golden, emulated):
 def test_emulated_ctp528_device_axis_path(emulated):
     import next_row_checks as checks
 
-    checks.check_ctp528_device_axis_path(emulated)
+    checks.check_ctp528_device_axis_path(emulated, n_slices=6, light=True)
 
 
 def test_emulated_wl_analyze_batch_other_dtypes(golden, emulated):
     import next_row_checks as checks
 
-    checks.check_wl_analyze_batch_other_dtypes(golden, emulated, frames=(0, 7))
+    checks.check_wl_analyze_batch_other_dtypes(golden, emulated, frames=(0, 7), int16_frames=(0,))
 
 
 def test_emulated_pf_other_dtypes(golden, emulated):
