@@ -92,6 +92,14 @@ circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const 
   // host fit (np.polyfit, bit for bit the reference's) lies closer than this margin: then every tap is the same pixel.
   double mrg = __longlong_as_double(0x7ff0000000000000LL);
   const bool want_margin = margin != nullptr;
+  // a ring that stays a pixel clear of the frame on every side cannot meet a bounds decision: the inside test's margin is
+  // then dropped from every tap (wave-uniform; the radii are sorted neither way, so the largest is looked up once)
+  bool near_border = true;
+  if (want_margin) {
+    double rmax = 0.0;
+    for (int k = 0; k < nr; ++k) rmax = fmax(rmax, fabs(rad[k]));
+    near_border = !(x0 - rmax > 1.0 && x0 + rmax < (double)(w - 2) && y0 - rmax > 1.0 && y0 + rmax < (double)(h - 2));
+  }
   auto tap = [&](double r, unsigned& off) {                  // -> inside?, offset of the nearest pixel
     const double x = c * r + x0;
     const double y = sn * r + y0;
@@ -100,10 +108,12 @@ circle_profile_combined_kernel(const T* __restrict__ stack, int h, int w, const 
     const int xi = (int)fx, yi = (int)fy;
     off = in ? (unsigned)yi * (unsigned)w + (unsigned)xi : 0u;
     if (want_margin) {
-      const double dx = (x + 0.5) - fx, dy = (y + 0.5) - fy;
-      double m = fmin(fmin(dx, 1.0 - dx), fmin(dy, 1.0 - dy));
-      m = fmin(m, fmin(fmin(fabs(x), fabs(x - (double)(w - 1))), fmin(fabs(y), fabs(y - (double)(h - 1)))));
-      mrg = m < mrg ? m : mrg;                               // (a NaN coordinate never lowers it: the caller tests NaN centres)
+      // distance of c + 0.5 to the nearest integer = 0.5 - |frac - 0.5|; both coordinates, then the running minimum
+      const double dx = ((x + 0.5) - fx) - 0.5, dy = ((y + 0.5) - fy) - 0.5;
+      double m = 0.5 - fmax(fabs(dx), fabs(dy));
+      if (near_border)                                       // |min(c, n - 1 - c)| = the distance to the nearer bound
+        m = fmin(m, fmin(fabs(fmin(x, (double)(w - 1) - x)), fabs(fmin(y, (double)(h - 1) - y))));
+      mrg = fmin(mrg, m);                                    // (a NaN coordinate never lowers it: the caller tests NaN centres)
     }
     return in;
   };

@@ -71,39 +71,50 @@ phantom_axis_fit_kernel(const double* __restrict__ roi, int spv, double x_adj, d
     if (ry == rb) s_med[3] = yi;
   }
   __syncthreads();
+  // np.mean of the one or two middle elements: (a + a) / 2 == a exactly
+  const double medx = (s_med[0] + s_med[1]) / 2.0, medy = (s_med[2] + s_med[3]) / 2.0;
+  // the np.isclose screen (exact, per slice) and the sums of the fit.  The sums are formed in whatever order the block
+  // reduction takes: this line only PLACES the profiles (its centres are verified against np.polyfit through the margins),
+  // so its last bits are free -- a serial loop on one lane was 40 us of the pass
+  __shared__ double s_red[4][4];
+  auto block_sum4 = [&](double (&v)[4]) {                    // -> the four sums in every thread
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = pl_wave_reduce(v[q], [](double a, double b) { return a + b; });
+    __syncthreads();
+    if ((tid & 63) == 0)
+      for (int q = 0; q < 4; ++q) s_red[tid >> 6][q] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]);
+  };
+  double a1[4] = {0.0, 0.0, 0.0, 0.0};                       // count, sum z, sum x, sum y
+  for (int z = tid; z < spv; z += 256) {
+    // np.isclose(a = median, b = c): |a - b| <= atol + rtol * |b|
+    const bool ok = seen[z] && fabs(medx - cx[z]) <= 3.0 + 0.01 * fabs(cx[z]) && fabs(medy - cy[z]) <= 3.0 + 0.01 * fabs(cy[z]);
+    seen[z] = ok ? 1 : 0;                                    // (each slice is read and written by its own thread only)
+    if (ok) { a1[0] += 1.0; a1[1] += (double)z; a1[2] += cx[z]; a1[3] += cy[z]; }
+  }
+  block_sum4(a1);
+  const int k = (int)a1[0];
+  const int code = k < 2 ? 2 : 0;
+  double f[4] = {nan, nan, nan, nan};
+  if (code == 0) {                                           // (block-uniform)
+    const double zb = a1[1] / k, xb = a1[2] / k, yb = a1[3] / k;
+    double a2[4] = {0.0, 0.0, 0.0, 0.0};                     // szz, szx, szy
+    for (int z = tid; z < spv; z += 256) {
+      if (!seen[z]) continue;
+      const double dz = (double)z - zb;
+      a2[0] += dz * dz;
+      a2[1] += dz * (cx[z] - xb);
+      a2[2] += dz * (cy[z] - yb);
+    }
+    block_sum4(a2);
+    f[0] = a2[1] / a2[0];
+    f[1] = xb - f[0] * zb;
+    f[2] = a2[2] / a2[0];
+    f[3] = yb - f[2] * zb;
+  }
   if (tid == 0) {
-    // np.mean of the one or two middle elements: (a + a) / 2 == a exactly
-    const double medx = (s_med[0] + s_med[1]) / 2.0, medy = (s_med[2] + s_med[3]) / 2.0;
-    int k = 0;
-    double sz = 0.0, sx = 0.0, sy = 0.0;
-    for (int z = 0; z < spv; ++z) {
-      // np.isclose(a = median, b = c): |a - b| <= atol + rtol * |b|
-      const bool ok = seen[z] && fabs(medx - cx[z]) <= 3.0 + 0.01 * fabs(cx[z]) && fabs(medy - cy[z]) <= 3.0 + 0.01 * fabs(cy[z]);
-      seen[z] = ok ? 1 : 0;
-      if (ok) {
-        ++k;
-        sz += (double)z;
-        sx += cx[z];
-        sy += cy[z];
-      }
-    }
-    const int code = k < 2 ? 2 : 0;
-    double f[4] = {nan, nan, nan, nan};
-    if (code == 0) {
-      const double zb = sz / k, xb = sx / k, yb = sy / k;
-      double szz = 0.0, szx = 0.0, szy = 0.0;
-      for (int z = 0; z < spv; ++z) {
-        if (!seen[z]) continue;
-        const double dz = (double)z - zb;
-        szz += dz * dz;
-        szx += dz * (cx[z] - xb);
-        szy += dz * (cy[z] - yb);
-      }
-      f[0] = szx / szz;
-      f[1] = xb - f[0] * zb;
-      f[2] = szy / szz;
-      f[3] = yb - f[2] * zb;
-    }
     for (int q = 0; q < 4; ++q) {
       s_fit[q] = f[q];
       fit[v * 4 + q] = f[q];
