@@ -109,19 +109,31 @@ __device__ int sr_label_runs(const SrLds& L, int h, int w, int ww, bool invert, 
   if (tid == 0) L.row_off[0] = 0;
   __syncthreads();
   SR_STAMP(sr_base + 8);
-  // inclusive prefix over row_off[1 .. h] by the first wave, 64 rows at a time
-  if (tid < PL_WAVE) {
+  // inclusive prefix over row_off[1 .. h]: every wave scans 64 rows, the waves' totals chain through LDS (round 6; before,
+  // the first wave walked the rows 64 at a time while seven waves waited: a fifth of a labelling)
+  {
+    __shared__ int s_wtot[kSrThreads / PL_WAVE];
+    const int lane = tid & 63, wv = tid >> 6;
     int base = 0;
-    for (int r0 = 0; r0 < h; r0 += PL_WAVE) {
-      const int r = r0 + tid;
+    for (int c0 = 0; c0 < h; c0 += kSrThreads) {             // (block-uniform trip count)
+      const int r = c0 + tid;
       int v = r < h ? L.row_off[r + 1] : 0;
 #pragma unroll
       for (int o = 1; o < PL_WAVE; o <<= 1) {
         const int u = __shfl_up(v, o, PL_WAVE);
-        if (tid >= o) v += u;
+        if (lane >= o) v += u;
       }
-      if (r < h) L.row_off[r + 1] = base + v;
-      base += __shfl(v, PL_WAVE - 1, PL_WAVE);
+      if (lane == PL_WAVE - 1) s_wtot[wv] = v;
+      __syncthreads();
+      int add = base, tot = 0;
+#pragma unroll
+      for (int k = 0; k < kSrThreads / PL_WAVE; ++k) {
+        add += k < wv ? s_wtot[k] : 0;
+        tot += s_wtot[k];
+      }
+      if (r < h) L.row_off[r + 1] = add + v;
+      base += tot;
+      __syncthreads();
     }
     if (tid == 0) *s_total = base;
   }
@@ -439,8 +451,34 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
   __syncthreads();
   SR_STAMP(0);
   int st = 0;
-  // ---- clear_border: 8-connected components with a pixel in the border band
-  if (clear_ext > 0) {
+  // ---- clear_border: 8-connected components with a pixel in the border band.  A band without a single foreground pixel
+  // (the usual CT slice: air all around the phantom and the couch) has nothing to clear: the labelling that would find
+  // that out -- a third of this kernel's labelling work -- is skipped after one look at the band's words (round 6)
+  bool band_empty = false;
+  if (clear_ext > 0 && clear_ext <= 64 && w >= 2 * clear_ext) {
+    const u64 low = clear_ext == 64 ? ~0ull : ((1ull << clear_ext) - 1ull);
+    const int last_bits = w - (ww - 1) * 64;                 // valid bits of a row's last word (1 .. 64)
+    int hit = 0;
+    for (int r = tid; r < h; r += kSrThreads) {
+      const u64* row = L.plane + (size_t)r * ww;
+      if (r < clear_ext || r >= h - clear_ext) {
+        for (int j = 0; j < ww; ++j) hit |= row[j] != 0ull;
+      } else {
+        hit |= (row[0] & low) != 0ull;
+        // the last clear_ext columns: bits last_bits - clear_ext .. last_bits - 1 of the last word, and when they do not fit
+        // there, the top bits of the word before it
+        const int from = last_bits - clear_ext;
+        if (from >= 0) {
+          hit |= ((row[ww - 1] >> from) & low) != 0ull;
+        } else {
+          hit |= row[ww - 1] != 0ull;
+          hit |= (row[ww - 2] >> (64 + from)) != 0ull;
+        }
+      }
+    }
+    band_empty = __syncthreads_or(hit) == 0;
+  }
+  if (clear_ext > 0 && !band_empty) {
     const int nr = sr_label_runs(L, h, w, ww, false, true, &s_total SR_TIMING_PASS(0));
     if (nr < 0) st = 1;
     else {

@@ -1443,6 +1443,33 @@ def check_mask_regions(dev, shapes=((64, 64), (70, 130), (33, 65), (17, 5), (96,
                 assert np.array_equal(om[i], rbw), (h, w, ext, fill, i)
                 assert np.array_equal(tab[i], rt), (h, w, ext, fill, i)
                 checked += 1
+    # round 6: the clear_border labelling is skipped when the border band holds no foreground pixel -- an interior blob with
+    # an empty band, then one arm of it reaching exactly the first / last column and row inside and outside the band (the last
+    # columns of a row live in the top bits of its last word, or across two words when w % 64 < ext)
+    for h, w in ((40, 64), (70, 130), (33, 65), (96, 192), (48, 67)):
+        for ext in (1, 3, 4):
+            base = np.zeros((h, w), np.uint8)
+            base[h // 3:2 * h // 3, w // 3:2 * w // 3] = 1
+            base[h // 2 - 2:h // 2 + 2, w // 2 - 2:w // 2 + 2] = 0                    # a hole
+            cases = [base]
+            r, c = h // 2, w // 2
+            for lo_c in (0, ext - 1, ext):                                           # left arm ends inside / outside the band
+                m = base.copy(); m[r, lo_c:w // 3] = 1; cases.append(m)
+            for hi_c in (w - 1, w - ext, w - ext - 1):
+                m = base.copy(); m[r, 2 * w // 3:hi_c + 1] = 1; cases.append(m)
+            for lo_r in (0, ext - 1, ext):
+                m = base.copy(); m[lo_r:h // 3, c] = 1; cases.append(m)
+            for hi_r in (h - 1, h - ext, h - ext - 1):
+                m = base.copy(); m[2 * h // 3:hi_r + 1, c] = 1; cases.append(m)
+            m = base.copy(); m[0, 0] = 1; cases.append(m)                             # a lone corner pixel
+            m = base.copy(); m[h - 1, w - 1] = 1; cases.append(m)
+            arr = np.stack(cases)
+            tab, cnt, st, om = ops.mask_regions(torch.from_numpy(arr).to(dev), None, ext, True, 64, return_mask=True)
+            assert not st.any()
+            for i in range(len(cases)):
+                rt, rn, rbw = _regions_reference(arr[i], ext, True, 64)
+                assert int(cnt[i]) == rn and np.array_equal(om[i].cpu().numpy(), rbw) and np.array_equal(tab[i].cpu().numpy(), rt), (h, w, ext, i)
+                checked += 1
     # float64 frames with per-frame thresholds (strictly greater; NaN is background)
     e = rng.random((2, 50, 70))
     e[0, 3, 3] = np.nan
