@@ -503,7 +503,11 @@ def main():
                 "parallelism": f"{world} x independent frame shards + 1 all-gather of [N,9] f64 records",
             },
             "roofline": {
+                # "bound" names the roofline `achieved` / `peak` are priced on (BASELINE's metric: % of the HBM roofline, on
+                # the algorithmic 4 MiB per frame); "limiter" names what actually holds the dominant kernel
                 "bound": "hbm",
+                "limiter": ("mfma+valu issue (HBM traffic is 1.06x algorithmic: profiles/pmc_traffic.json; DESIGN.md 9.1)"
+                            if dominant == "gauss2d" else "hbm"),
                 "kernel": dominant,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,

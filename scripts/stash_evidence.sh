@@ -14,7 +14,7 @@ import json, subprocess, sys
 tag = sys.argv[1]
 d = json.load(open(f"gpurun_out/{tag}/pmc_traffic.json"))
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-d["_measured_at"] = f"commit {commit} (round 4, run {tag}: profiles/{tag}_pmc_pipeline_traffic.txt)"
+d["_measured_at"] = f"commit {commit} (run {tag}: profiles/{tag}_pmc_epid.txt)"
 json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(d)
 PY
