@@ -386,6 +386,33 @@ int pl_edge_regions(const float* d_plane, const void* in_raw, int dtype, const d
                     const double* d_thr, int64_t n, int h, int w, int clear_border_ext, int fill_holes, int max_labels,
                     double* d_table, int32_t* d_count, int32_t* d_status, uint8_t* d_out_mask, double catphan_size,
                     const double* d_rawmax, double* d_roi, void* stream);
+
+/* pl_edge_plane in PACKED FLOAT32 (round 6; csrc/edge_stream32.hip): the same smoothed Scharr plane (pylinac/ct.py:391,
+ * 3327-3328) at less than half the vector instructions.  d_out [n][h][w] float32 lies within pl_edge_plane32_bracket() bit
+ * patterns of the exact float64 value (a stored 0 is exact) -- for consumers that decide from it and recompute exactly what
+ * they cannot decide: pl_edge_otsu_ex / pl_edge_regions_ex with that bracket.  d_min / d_max [n]: the EXACT float64 extrema over
+ * the row spans (candidates within two brackets of the float32 extrema, recomputed from the slices in scipy's float64
+ * sequence); d_rawmax [n]: max of the raw Scharr magnitude, exact below 32 (it only feeds the "no edges" test < 0.1).
+ * d_status int32 [n]: 1 = the extrema of this slice could not be certified (two candidates in one lane, or a full list):
+ * the caller repeats the slice with pl_edge_plane.  Even widths; d_work: pl_edge_plane32_work_bytes(n) bytes, 16-byte aligned. */
+int pl_edge_plane32_bracket(void);
+int64_t pl_edge_plane32_work_bytes(int64_t n);
+int pl_edge_plane32(const void* in, int dtype, int64_t n, int h, int w, const double* d_weights, int radius,
+                    const int32_t* d_row_spans, float* d_out, unsigned char* d_work, double* d_rawmax, double* d_min,
+                    double* d_max, int32_t* d_status, void* stream);
+
+/* pl_edge_otsu / pl_edge_regions on a float32 plane that lies within `bracket` bit patterns of the exact value instead of being
+ * its correctly rounded image (bracket 1): the plane of pl_edge_plane32.  Every decision -- histogram bin, threshold -- is taken
+ * from the plane where the bracket allows and recomputed exactly from the slices otherwise, so the results are those of the
+ * exact plane. */
+int pl_edge_otsu_ex(const void* d_plane, int plane_dtype, const void* in_raw, int dtype, int64_t n, int h, int w,
+                    const double* d_weights, int radius, const int32_t* d_row_spans, const uint8_t* d_mask,
+                    const double* d_min, const double* d_max, double scale, uint32_t* d_work, double* d_thr,
+                    double* d_raw_otsu, int bracket, void* stream);
+int pl_edge_regions_ex(const float* d_plane, const void* in_raw, int dtype, const double* d_weights, int radius,
+                       const double* d_thr, int64_t n, int h, int w, int clear_border_ext, int fill_holes, int max_labels,
+                       double* d_table, int32_t* d_count, int32_t* d_status, uint8_t* d_out_mask, double catphan_size,
+                       const double* d_rawmax, double* d_roi, int bracket, void* stream);
 /* combine_surrounding_slices (pylinac/ct.py:3351-3386) for EVERY slice of a stack [n][count] made of whole volumes of
  * slices_per_volume slices: mode 0 = np.max (d_out has the input dtype), mode 1 = np.mean (d_out float64).  The window
  * z-k .. z+k indexes the slice's own volume the way the reference indexes its Python list: a negative index wraps around

@@ -105,6 +105,8 @@ SIGNATURES = {
     "pl_scharr_gaussian": ([_p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_edge_otsu": ([_p, _i, _p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p, _p], C.c_int),
     "pl_edge_regions": ([_p, _p, _i, _p, _i, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _d, _p, _p, _p], C.c_int),
+    "pl_edge_regions_ex": ([_p, _p, _i, _p, _i, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _d, _p, _p, _i, _p], C.c_int),
+    "pl_edge_otsu_ex": ([_p, _i, _p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _p, _d, _p, _p, _p, _i, _p], C.c_int),
     "pl_peak_valley_regions": ([_p, _l, _i, _l, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p], C.c_int),
     "pl_pf_measure": ([_p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _d, _d, _i, _p, _p, _p, _p, _i, _p], C.c_int),
     "pl_scaled_rowmean": ([_p, _l, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p], C.c_int),
@@ -117,6 +119,9 @@ SIGNATURES = {
     "pl_index_to_original": ([_p, _i, _p, _l, _p, _p], C.c_int),
     "pl_pack_columns": ([_p, _p, _p, _p, _p, _i, _l, _p, _p], C.c_int),
     "pl_edge_plane": ([_p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p], C.c_int),
+    "pl_edge_plane32": ([_p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p], C.c_int),
+    "pl_edge_plane32_bracket": ([], C.c_int),
+    "pl_edge_plane32_work_bytes": ([_l], C.c_int64),
     "pl_mask_regions_fits": ([_i, _i, _i], C.c_int),
     "pl_mask_regions": ([_p, _i, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p], C.c_int),
     "pl_combine_slices": ([_p, _p, _i, _l, _l, _i, _i, _l, _p], C.c_int),

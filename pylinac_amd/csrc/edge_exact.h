@@ -18,9 +18,13 @@ __device__ __forceinline__ int es_clamp(int v, int lo, int hi) { return v < lo ?
 //     r = RN(1 / c).  Correct rounding for EVERY float64 g is proven by enumeration (tests/test_exact_sequences.py): the exact
 //     value the last operation rounds lies within g / c * 4.001 * 2^-106 of g / c, only six mantissas g put g / c that close
 //     to a rounding boundary, and all six round correctly.
+__device__ __forceinline__ double es_edge_k(double x);
 __device__ __forceinline__ double es_edge(int S0, int S1) {
   const double a = (double)S0, b = (double)S1;
-  const double x = fma(a, a, b * b);                    // K, exact
+  return es_edge_k(fma(a, a, b * b));                   // K, exact
+}
+// the same from K = S0^2 + S1^2 itself (an exact integer below 2^43)
+__device__ __forceinline__ double es_edge_k(double x) {
   const long long xb = __double_as_longlong(x);
   const unsigned hi = max((unsigned)(xb >> 32), 0x3ff00000u);
   const double xs = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)(xb & 0xffffffffLL)));
@@ -86,6 +90,13 @@ __device__ __forceinline__ void es_f32_bracket(float v, double& vlo, double& vhi
   const unsigned b = __float_as_uint(v);
   vlo = b ? (double)__uint_as_float(b - 1u) : 0.0;
   vhi = b ? (double)__uint_as_float(b + 1u) : 0.0;
+}
+// the same with a radius of `n` bit patterns (n = 1: the plane holds RN32 of the exact value; the packed-float32 edge kernel's
+// plane is within kEs32Bracket patterns of it, edge_stream32.hip).  A stored 0 is an exact 0 in both planes.
+__device__ __forceinline__ void es_f32_bracket_n(float v, unsigned n, double& vlo, double& vhi) {
+  const unsigned b = __float_as_uint(v);
+  vlo = b > n ? (double)__uint_as_float(b - n) : 0.0;
+  vhi = b ? (double)__uint_as_float(b + n) : 0.0;
 }
 
 }  // namespace

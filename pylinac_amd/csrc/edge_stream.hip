@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(kEsThreads)
 edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, int h, int w, const double* __restrict__ wts, int rad,
                  const int* __restrict__ spans, const uint8_t* __restrict__ mask, const double* __restrict__ lo_all,
                  const double* __restrict__ hi_all, double scale, uint32_t* __restrict__ work /* [n][258], zeroed */,
-                 double* __restrict__ thr, double* __restrict__ otsu_raw) {
+                 double* __restrict__ thr, double* __restrict__ otsu_raw, unsigned bracket) {
   constexpr int NB = 256;
   constexpr int kCopies = 8, kStride = NB + 1;
   __shared__ double s_edge[NB + 1];
@@ -270,8 +270,9 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
   // Float32 planes, the common case in the BIT domain (round 6; r06e: the kernel issued 38 vector instructions per pixel, most of them
   // the float64 bracket: two conversions, subtract / multiply / convert, two 8-byte LDS reads, three compares).  The exact
   // value of a pixel lies between the float32 neighbours of its stored value v (non-negative: bit patterns order like values):
-  //     tab[k].x = bits(the smallest float32 >= edge k) + 1        prev(v) >= edge k      <=>  bits(v) >= tab[k].x
-  //     tab[k].y = how many bit patterns from there on satisfy     next(v) <  edge k + 1  (<= `last` for the last bin)
+  //     tab[k].x = bits(the smallest float32 >= edge k) + B        prev^B(v) >= edge k      <=>  bits(v) >= tab[k].x
+  //     tab[k].y = how many bit patterns from there on satisfy     next^B(v) <  edge k + 1  (<= `last` for the last bin)
+  // (B = `bracket`: 1 for a plane that stores RN32 of the exact value, kEs32Bracket for the packed-float32 kernel's plane)
   // so "certainly in bin k" is ONE unsigned compare (bits(v) - x < y) against one 8-byte entry, with the bin estimated in
   // float32.  Whatever that does not place -- a pixel next to an edge, a stored 0, an estimate one bin off -- takes the
   // float64 logic below unchanged, including the exact recomputation from the slice.  A/B on one box (profiles/r06g_*):
@@ -285,14 +286,14 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
         if (e0 > 0.0) {
           float c = (float)e0;                              // RN; step up when it rounded down
           if ((double)c < e0) c = __uint_as_float(__float_as_uint(c) + 1u);
-          lo_b = __float_as_uint(c) + 1u;
+          lo_b = __float_as_uint(c) + bracket;              // bits(v) - bracket >= bits(c)
         }
         if (e1 > 0.0) {
           float c = (float)e1;                              // the largest float32 < e1 (<= e1 for the closed last bin)
           const bool over = tid == NB - 1 ? ((double)c > e1) : ((double)c >= e1);
           unsigned cb = __float_as_uint(c);
           if (over) cb = cb ? cb - 1u : 0u;
-          hi_b = cb;                                        // next(v) <= that value  <=>  bits(v) < cb
+          hi_b = cb + 1u > bracket ? cb + 1u - bracket : 0u;   // bits(v) + bracket <= cb  <=>  bits(v) < cb + 1 - bracket
         }
       }
       s_tab[tid] = uint2{lo_b, hi_b > lo_b ? hi_b - lo_b : 0u};
@@ -362,7 +363,7 @@ edge_otsu_kernel(const PlaneT* __restrict__ plane, const T* __restrict__ raw, in
             vld = vld & !placed;                            // the wave's other pixels: the float64 logic
           }
           double vlo, vhi;
-          if constexpr (sizeof(PlaneT) == 4) es_f32_bracket(pvu, vlo, vhi);
+          if constexpr (sizeof(PlaneT) == 4) es_f32_bracket_n(pvu, bracket, vlo, vhi);
           else { vlo = (double)pvu; vhi = vlo; }
           // the bin of vlo as estimated, and whether the whole bracket provably lies in it
           int idx = (int)((vlo - first) * inv);
@@ -571,10 +572,11 @@ extern "C" int pl_scharr_gaussian(const void* in, int dtype, int64_t n, int h, i
 }
 
 /* np.histogram(plane[selection], 256) over [d_min, d_max] + skimage's threshold_otsu on it, per frame, one launch */
-extern "C" int pl_edge_otsu(const void* d_plane, int plane_dtype, const void* in_raw, int dtype, int64_t n, int h, int w,
-                            const double* d_weights, int radius, const int32_t* d_row_spans, const uint8_t* d_mask,
-                            const double* d_min, const double* d_max, double scale, uint32_t* d_work, double* d_thr,
-                            double* d_raw_otsu, void* stream) {
+extern "C" int pl_edge_otsu_ex(const void* d_plane, int plane_dtype, const void* in_raw, int dtype, int64_t n, int h, int w,
+                               const double* d_weights, int radius, const int32_t* d_row_spans, const uint8_t* d_mask,
+                               const double* d_min, const double* d_max, double scale, uint32_t* d_work, double* d_thr,
+                               double* d_raw_otsu, int bracket, void* stream) {
+  PL_REQUIRE(bracket >= 1 && bracket <= 4096, "bracket: 1 .. 4096 float32 bit patterns");
   PL_REQUIRE(d_plane && d_min && d_max && d_work && d_thr, "null pointer");
   PL_REQUIRE(n >= 0 && n <= 65535 && h > 0 && w > 0, "bad shape");
   PL_REQUIRE(plane_dtype == PL_F32 || plane_dtype == PL_F64, "float32 or float64 plane");
@@ -593,7 +595,7 @@ extern "C" int pl_edge_otsu(const void* d_plane, int plane_dtype, const void* in
   const dim3 grid((unsigned)parts, (unsigned)n);
 #define EO_LAUNCH(P, T)                                                                                                     \
   hipLaunchKernelGGL((edge_otsu_kernel<P, T>), grid, dim3(kEsThreads), 0, st, (const P*)d_plane, (const T*)in_raw, h, w,    \
-                     d_weights, radius, d_row_spans, d_mask, d_min, d_max, scale, d_work, d_thr, d_raw_otsu)
+                     d_weights, radius, d_row_spans, d_mask, d_min, d_max, scale, d_work, d_thr, d_raw_otsu, (unsigned)bracket)
   if (plane_dtype == PL_F32) {
     if (dtype == PL_I16) EO_LAUNCH(float, short);
     else EO_LAUNCH(float, unsigned short);
@@ -602,4 +604,12 @@ extern "C" int pl_edge_otsu(const void* d_plane, int plane_dtype, const void* in
   }
 #undef EO_LAUNCH
   return pl_check_launch("pl_edge_otsu");
+}
+
+extern "C" int pl_edge_otsu(const void* d_plane, int plane_dtype, const void* in_raw, int dtype, int64_t n, int h, int w,
+                            const double* d_weights, int radius, const int32_t* d_row_spans, const uint8_t* d_mask,
+                            const double* d_min, const double* d_max, double scale, uint32_t* d_work, double* d_thr,
+                            double* d_raw_otsu, void* stream) {
+  return pl_edge_otsu_ex(d_plane, plane_dtype, in_raw, dtype, n, h, w, d_weights, radius, d_row_spans, d_mask, d_min, d_max, scale,
+                         d_work, d_thr, d_raw_otsu, 1, stream);
 }

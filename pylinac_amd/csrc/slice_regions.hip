@@ -264,6 +264,7 @@ struct SrEdgeArgs {
   double catphan_size;        // > 0 with roi
   const double* rawmax;       // [n] max of the raw Scharr magnitude (the "no edges" test)
   double* roi;                // [n][8] or NULL
+  unsigned bracket;           // the plane lies within this many float32 bit patterns of the exact value (>= 1)
 };
 
 // The float32 plane -> bit plane for frames whose rows are WW whole 64-pixel words (w = 64 WW: 256, 512 and 1024 wide CT
@@ -273,7 +274,7 @@ struct SrEdgeArgs {
 // latency instead of being in flight together; the build ran at 3 TB/s on 16 waves per CU).  Marks undecided words in `und`
 // exactly like the generic loop; -> whether any was seen.
 template <int WW>
-__device__ __forceinline__ bool sr_build_rows(const float* __restrict__ src, int h, int r0, unsigned f2, unsigned fa, bool zero_und,
+__device__ __forceinline__ bool sr_build_rows(const float* __restrict__ src, int h, int r0, unsigned f2, unsigned lowb, unsigned span,
                                               u64* __restrict__ plane, u64* __restrict__ und, int lane) {
   constexpr int R = 32 / WW, W = 64 * WW;
   float v[32];
@@ -290,7 +291,7 @@ __device__ __forceinline__ bool sr_build_rows(const float* __restrict__ src, int
     if (r0 + rr >= h) continue;                            // wave-uniform
     const unsigned vb = __float_as_uint(v[u]);
     const u64 m = __ballot(vb >= f2);
-    const u64 todo = zero_und ? 0ull : __ballot(((vb - fa) < 2u) & (vb != 0u));
+    const u64 todo = __ballot(((vb - lowb) < span) & (vb != 0u));
     if (lane == 0) {
       plane[(r0 + rr) * WW + jj] = m;
       und[u] = todo;
@@ -346,17 +347,22 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
   //     prev(v) > t  <=>  bits(v) >= bits(a) + 2        -> foreground, decided
   //     next(v) > t >= prev(v)  <=>  bits(v) - bits(a) in {0, 1}   (v != 0: a stored 0 is an exact 0)   -> undecided
   // one v_cmp per mask, whose result IS the wave's ballot.  t < 0: everything is foreground; t NaN / beyond FLT_MAX: nothing.
-  unsigned fa = 0xffffffffu, f2 = 0xffffffffu;            // bits(a), bits(a) + 2: "nothing is foreground, nothing undecided"
+  // With a bracket of B patterns (ea.bracket; 1 = a plane that stores RN32 of the exact value):
+  //     foreground, decided:  bits(v) - B >= bits(a) + 1           <=>  bits(v) >= f2 = bits(a) + B + 1
+  //     undecided:            bits(v) + B >= bits(a) + 1 otherwise  <=>  lowb = bits(a) + 1 - B <= bits(v) < f2
+  unsigned f2 = 0xffffffffu, lowb = 0xffffffffu;          // "nothing is foreground, nothing undecided"
   if constexpr (sizeof(T) == 4) {
-    if (t < 0.0) { fa = 0u; f2 = 0u; }
+    const unsigned B = ea.bracket ? ea.bracket : 1u;
+    if (t < 0.0) { f2 = 0u; lowb = 0u; }                   // everything is foreground
     else if (t < 3.0e38) {
       float a = (float)t;                                  // RN; step down when it rounded up
       if ((double)a > t) a = __uint_as_float(__float_as_uint(a) - 1u);
-      fa = __float_as_uint(a);
-      f2 = fa + 2u;
+      const unsigned fa = __float_as_uint(a);
+      f2 = fa + B + 1u;
+      lowb = fa + 1u > B ? fa + 1u - B : 1u;
     }
   }
-  const unsigned zero_und = (sizeof(T) == 4 && t < 0.0) ? 1u : 0u;      // (t < 0: fa = f2 = 0 must not flag anything)
+  const unsigned span = f2 - lowb;
   bool rows_done = false;
   if constexpr (sizeof(T) == 4) {
     if (w == ww * 64 && (ww == 4 || ww == 8 || ww == 16)) {
@@ -364,9 +370,9 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
       const int rows_per = 32 / ww;
       for (int r0 = wv * rows_per; r0 < h; r0 += (kSrThreads / PL_WAVE) * rows_per) {
         const float* fsrc = reinterpret_cast<const float*>(src);
-        const bool any_und = ww == 8 ? sr_build_rows<8>(fsrc, h, r0, f2, fa, zero_und != 0u, L.plane, und, lane)
-                             : (ww == 4 ? sr_build_rows<4>(fsrc, h, r0, f2, fa, zero_und != 0u, L.plane, und, lane)
-                                        : sr_build_rows<16>(fsrc, h, r0, f2, fa, zero_und != 0u, L.plane, und, lane));
+        const bool any_und = ww == 8 ? sr_build_rows<8>(fsrc, h, r0, f2, lowb, span, L.plane, und, lane)
+                             : (ww == 4 ? sr_build_rows<4>(fsrc, h, r0, f2, lowb, span, L.plane, und, lane)
+                                        : sr_build_rows<16>(fsrc, h, r0, f2, lowb, span, L.plane, und, lane));
         if (any_und) {                                     // a handful of pixels per thousand slices
           pl_wave_sync();
           const int q0 = r0 * ww;
@@ -417,7 +423,7 @@ mask_regions_kernel(const T* __restrict__ in, const double* __restrict__ thr, in
       if constexpr (sizeof(T) == 4) {
         const unsigned vb = __float_as_uint(v[u]);
         m = __ballot(inside[u] & (vb >= f2));
-        const u64 todo = zero_und ? 0ull : __ballot(inside[u] & ((vb - fa) < 2u) & (vb != 0u));
+        const u64 todo = __ballot(inside[u] & ((vb - lowb) < span) & (vb != 0u));
         if (lane == 0) und[u] = todo;
         any_und |= todo != 0;
       } else {
@@ -653,10 +659,11 @@ extern "C" int pl_mask_regions(const void* in, int dtype, const double* d_thr, i
 }
 
 /* pl_mask_regions on the float32 plane of pl_edge_plane, with the phantom ROI chosen in the same launch */
-extern "C" int pl_edge_regions(const float* d_plane, const void* in_raw, int dtype, const double* d_weights, int radius,
-                               const double* d_thr, int64_t n, int h, int w, int clear_border_ext, int fill_holes, int max_labels,
-                               double* d_table, int32_t* d_count, int32_t* d_status, uint8_t* d_out_mask, double catphan_size,
-                               const double* d_rawmax, double* d_roi, void* stream) {
+extern "C" int pl_edge_regions_ex(const float* d_plane, const void* in_raw, int dtype, const double* d_weights, int radius,
+                                  const double* d_thr, int64_t n, int h, int w, int clear_border_ext, int fill_holes, int max_labels,
+                                  double* d_table, int32_t* d_count, int32_t* d_status, uint8_t* d_out_mask, double catphan_size,
+                                  const double* d_rawmax, double* d_roi, int bracket, void* stream) {
+  PL_REQUIRE(bracket >= 1 && bracket <= 4096, "bracket: 1 .. 4096 float32 bit patterns");
   PL_REQUIRE(d_plane && in_raw && d_weights && d_thr && d_count && d_status, "null pointer");
   PL_REQUIRE(dtype == PL_I16 || dtype == PL_U16, "int16 / uint16 slices");
   PL_REQUIRE(radius >= 1 && radius <= 8, "radius 1..8");
@@ -673,7 +680,7 @@ extern "C" int pl_edge_regions(const float* d_plane, const void* in_raw, int dty
     if (e != hipSuccess) { pl_set_error("pl_edge_regions: LDS attribute: %s", hipGetErrorString(e)); return PL_ERR_HIP; }
     attr = lds;
   }
-  SrEdgeArgs ea{in_raw, dtype == PL_I16, d_weights, radius, catphan_size, d_rawmax, d_roi};
+  SrEdgeArgs ea{in_raw, dtype == PL_I16, d_weights, radius, catphan_size, d_rawmax, d_roi, (unsigned)bracket};
   hipLaunchKernelGGL(mask_regions_kernel<float>, dim3((unsigned)n), dim3(kSrThreads), lds, (hipStream_t)stream, d_plane, d_thr, h, w,
                      clear_border_ext, fill_holes, max_labels, d_table, d_count, d_status, d_out_mask, ea);
   return pl_check_launch("pl_edge_regions");
@@ -686,3 +693,12 @@ extern "C" int pl_debug_sr_timing(unsigned long long* h_out) {
   return hipMemcpyToSymbol(HIP_SYMBOL(pl_sr_dbg), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
 }
 #endif
+
+/* pl_edge_regions_ex for a plane that stores RN32 of the exact value (bracket 1): pl_edge_plane's */
+extern "C" int pl_edge_regions(const float* d_plane, const void* in_raw, int dtype, const double* d_weights, int radius,
+                               const double* d_thr, int64_t n, int h, int w, int clear_border_ext, int fill_holes, int max_labels,
+                               double* d_table, int32_t* d_count, int32_t* d_status, uint8_t* d_out_mask, double catphan_size,
+                               const double* d_rawmax, double* d_roi, void* stream) {
+  return pl_edge_regions_ex(d_plane, in_raw, dtype, d_weights, radius, d_thr, n, h, w, clear_border_ext, fill_holes, max_labels,
+                            d_table, d_count, d_status, d_out_mask, catphan_size, d_rawmax, d_roi, 1, stream);
+}

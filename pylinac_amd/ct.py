@@ -22,6 +22,7 @@ against scikit-image on the golden slices.
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -30,6 +31,8 @@ import torch
 from . import ops, regionprops as _rp
 
 CATPHAN_RADIUS_MM = 101  # pylinac/ct.py: CatPhanBase.catphan_radius_mm
+EDGE_PLANE32 = os.environ.get("PL_EDGE_PLANE32", "1") != "0"   # the localisation's edge image from pl_edge_plane32 (0: the exact
+                                                             # float64 kernel -- an A/B knob; results are identical)
 
 
 def disk_mask(center_rc, radius: float, shape) -> np.ndarray:
@@ -184,10 +187,20 @@ def _phantom_roi_launch(slices: torch.Tensor, mm_per_pixel: float, catphan_radiu
     if not (x.dtype in (torch.int16, torch.uint16) and ops.mask_regions_fits(h, w, max_labels)):
         return args, None
     spans = _disk_spans_on_device(h, w, mm_per_pixel, x.device)
-    plane, raw_max, lo, hi = ops.edge_plane(x, 1, spans=spans)
-    thr, _ = ops.edge_otsu(plane, lo, hi, frames=x, sigma=1, spans=spans, scale=0.8)
+    if w % 2 == 0 and EDGE_PLANE32:
+        # round 6: the edge image in packed float32 (half the vector instructions of the exact kernel); the histogram and the
+        # threshold decide from it within its bracket and recompute exactly what they cannot decide, the extrema are exact.
+        # A slice whose extrema the kernel could not certify (status 1: two tied candidates in one lane) is marked 5 in the
+        # ROI table and repeated on the general path by _phantom_roi_finish, like a slice with too many row runs
+        plane, raw_max, lo, hi, unsure, bracket = ops.edge_plane32(x, 1, spans=spans)
+    else:
+        plane, raw_max, lo, hi = ops.edge_plane(x, 1, spans=spans)
+        unsure, bracket = None, 1
+    thr, _ = ops.edge_otsu(plane, lo, hi, frames=x, sigma=1, spans=spans, scale=0.8, bracket=bracket)
     reg = ops.edge_regions(plane, x, 1, thr, min(int(max(h, w) / 100), 3) + 1, True, max_labels, catphan_size=catphan_size,
-                           rawmax=raw_max, want_table=False)
+                           rawmax=raw_max, want_table=False, bracket=bracket)
+    if unsure is not None:
+        reg["roi"][:, 0] = torch.where(unsure != 0, torch.full_like(reg["roi"][:, 0], 5.0), reg["roi"][:, 0])
     copy = ops.HostCopy(reg["roi"])
     copy.device_table = reg["roi"]                                       # (ctp528_batch goes on from it without waiting)
     return args, copy

@@ -1100,8 +1100,37 @@ def edge_plane(frames: torch.Tensor, sigma: float, spans: torch.Tensor | None = 
     return out, rawmax, lo, hi
 
 
+def edge_plane32(frames: torch.Tensor, sigma: float, spans: torch.Tensor | None = None):
+    """``edge_plane`` in packed float32 (``pl_edge_plane32``): the plane lies within ``bracket`` float32 bit patterns of the
+    exact value instead of being its rounded image -- hand ``bracket`` to ``edge_otsu`` / ``edge_regions``, which then decide
+    from it exactly like from the exact plane.  The extrema are the EXACT float64 ones (recomputed from candidates).
+    -> (plane float32, raw maximum [N], min [N], max [N], status int32 [N] (1 = repeat the slice with ``edge_plane``), bracket)."""
+    x = _frames(frames)
+    n, h, w = x.shape
+    dev = x.device
+    if w % 2:
+        raise ValueError("edge_plane32 needs an even width")
+    wts, _, lw = _device_weights(sigma, dev)
+    lib = _lib.load()
+    out = torch.empty((n, h, w), dtype=torch.float32, device=dev)
+    work = torch.empty(int(lib.pl_edge_plane32_work_bytes(n)) + 16, dtype=torch.uint8, device=dev)
+    rawmax = torch.empty(n, dtype=torch.float64, device=dev)
+    lo = torch.empty(n, dtype=torch.float64, device=dev)
+    hi = torch.empty(n, dtype=torch.float64, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    if spans is not None:
+        spans = spans.to(torch.int32).contiguous()
+        if tuple(spans.shape) != (h, 2):
+            raise ValueError("spans must be [H, 2]")
+    check(lib.pl_edge_plane32(x.data_ptr(), _dt(x), n, h, w, wts.data_ptr(), lw, 0 if spans is None else spans.data_ptr(),
+                              out.data_ptr(), work.data_ptr(), rawmax.data_ptr(), lo.data_ptr(), hi.data_ptr(), status.data_ptr(),
+                              _stream()), "pl_edge_plane32")
+    return out, rawmax, lo, hi, status, int(lib.pl_edge_plane32_bracket())
+
+
 def edge_otsu(plane: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, frames: torch.Tensor | None = None, sigma: float = 1.0,
-              spans: torch.Tensor | None = None, mask: torch.Tensor | None = None, scale: float = 1.0, return_work: bool = False):
+              spans: torch.Tensor | None = None, mask: torch.Tensor | None = None, scale: float = 1.0, return_work: bool = False,
+              bracket: int = 1):
     """``threshold_otsu(plane[selection]) * scale`` for the plane of ``edge_plane`` in one launch (``pl_edge_otsu``;
     pylinac/ct.py:3334-3340).  ``lo`` / ``hi``: the selection's exact extrema (``edge_plane``'s); a float32 plane also needs the
     ``frames`` and ``sigma`` it was made from.  -> (threshold * scale, threshold) float64 [N][, int32 [N, 258]: the histogram,
@@ -1126,10 +1155,10 @@ def edge_otsu(plane: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, frames: t
     work = torch.empty((n, 258), dtype=torch.int32, device=dev)
     thr = torch.empty(n, dtype=torch.float64, device=dev)
     raw = torch.empty(n, dtype=torch.float64, device=dev)
-    check(_lib.load().pl_edge_otsu(p.data_ptr(), _dt(p), raw_ptr, raw_dt, n, h, w, wp, lw,
-                                   0 if spans is None else spans.data_ptr(), 0 if mask is None else mask.contiguous().data_ptr(),
-                                   lo.contiguous().data_ptr(), hi.contiguous().data_ptr(), float(scale), work.data_ptr(),
-                                   thr.data_ptr(), raw.data_ptr(), _stream()), "pl_edge_otsu")
+    check(_lib.load().pl_edge_otsu_ex(p.data_ptr(), _dt(p), raw_ptr, raw_dt, n, h, w, wp, lw,
+                                      0 if spans is None else spans.data_ptr(), 0 if mask is None else mask.contiguous().data_ptr(),
+                                      lo.contiguous().data_ptr(), hi.contiguous().data_ptr(), float(scale), work.data_ptr(),
+                                      thr.data_ptr(), raw.data_ptr(), int(bracket), _stream()), "pl_edge_otsu_ex")
     return (thr, raw, work) if return_work else (thr, raw)
 
 
@@ -1250,7 +1279,7 @@ def mask_regions(frames: torch.Tensor, thr=None, clear_border_ext: int = 0, fill
 
 def edge_regions(plane: torch.Tensor, frames: torch.Tensor, sigma: float, thr: torch.Tensor, clear_border_ext: int = 0,
                  fill_holes: bool = False, max_labels: int = 64, catphan_size: float | None = None,
-                 rawmax: torch.Tensor | None = None, want_table: bool = True, return_mask: bool = False):
+                 rawmax: torch.Tensor | None = None, want_table: bool = True, return_mask: bool = False, bracket: int = 1):
     """``mask_regions`` on the float32 plane of ``edge_plane`` (``pl_edge_regions``): pixels the float32 value cannot decide
     against the threshold are recomputed exactly from ``frames``.  With ``catphan_size`` and ``rawmax`` the phantom ROI of
     ``Slice.phantom_roi`` (pylinac/ct.py:381-425) is chosen in the same launch.
@@ -1274,12 +1303,12 @@ def edge_regions(plane: torch.Tensor, frames: torch.Tensor, sigma: float, thr: t
     if roi is not None and rawmax is None:
         raise ValueError("the ROI selection needs rawmax")
     om = torch.empty((n, h, w), dtype=torch.uint8, device=dev) if return_mask else None
-    check(_lib.load().pl_edge_regions(p.data_ptr(), x.data_ptr(), _dt(x), wts.data_ptr(), lw, t.data_ptr(), n, h, w,
-                                      int(clear_border_ext), int(bool(fill_holes)), int(max_labels),
-                                      0 if table is None else table.data_ptr(), count.data_ptr(), status.data_ptr(),
-                                      0 if om is None else om.data_ptr(), float(catphan_size or 0.0),
-                                      0 if rawmax is None else rawmax.contiguous().data_ptr(),
-                                      0 if roi is None else roi.data_ptr(), _stream()), "pl_edge_regions")
+    check(_lib.load().pl_edge_regions_ex(p.data_ptr(), x.data_ptr(), _dt(x), wts.data_ptr(), lw, t.data_ptr(), n, h, w,
+                                         int(clear_border_ext), int(bool(fill_holes)), int(max_labels),
+                                         0 if table is None else table.data_ptr(), count.data_ptr(), status.data_ptr(),
+                                         0 if om is None else om.data_ptr(), float(catphan_size or 0.0),
+                                         0 if rawmax is None else rawmax.contiguous().data_ptr(),
+                                         0 if roi is None else roi.data_ptr(), int(bracket), _stream()), "pl_edge_regions_ex")
     return dict(table=table, count=count, status=status, roi=roi, mask=om)
 
 

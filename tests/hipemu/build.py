@@ -28,7 +28,7 @@ SOURCES = ["runtime.hip", "interp.hip", "gamma.hip", "roi.hip", "canny.hip", "el
            "edge.hip", "circle.hip", "spectral.hip", "xim.hip", "planar.hip", "ccl.hip", "ct.hip", "features.hip", "peaks.hip",
            "hist_otsu.hip", "picketfence.hip", "median.hip", "gaussian.hip", "features_sweep.hip", "slice_regions.hip", "edge_stream.hip", "hill.hip", "dicom.hip", "ct_axis.hip"]
 if CXX != "g++":
-    SOURCES += ["gaussian_rw.hip", "gaussian_mm.hip"]
+    SOURCES += ["gaussian_rw.hip", "gaussian_mm.hip", "edge_stream32.hip"]
 
 _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([\w\s]+?)\s+(\w+)\[\];")
 

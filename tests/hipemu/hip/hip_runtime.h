@@ -125,6 +125,7 @@ inline int __syncthreads_or(int p) { return hipemu::block_barrier_or(p); }
 #define __builtin_amdgcn_fract(x) ((x) - floor(x))
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))   /* v_rsq_f64: a seed; the kernels refine it */
 #define __builtin_amdgcn_fractf(x) ((x) - floorf(x))
+#define __builtin_amdgcn_sqrtf(x) sqrtf(x)                   /* v_sqrt_f32 (1 ulp on the device; correctly rounded here) */
 // v_mfma_i32_16x16x64_i8: byte s of lane (m, g) of A meets byte s of lane (n, g) of B (m, n = lane & 15, g = lane >> 4);
 // D[m = 4 * (lane >> 4) + reg][n = lane & 15] (the layout scripts/ubench/mfma_i8.hip checks on the device).  All 64 lanes
 // must take part (the kernels call it wave-uniformly).
@@ -283,6 +284,8 @@ inline double __longlong_as_double(long long v) { return hipemu::from_bits<doubl
 inline long long __double_as_longlong(double v) { return (long long)hipemu::to_bits(v); }
 inline float __uint_as_float(unsigned v) { return hipemu::from_bits<float>(v); }
 inline unsigned __float_as_uint(float v) { return (unsigned)hipemu::to_bits(v); }
+inline int __float_as_int(float v) { return (int)hipemu::to_bits(v); }
+inline float __int_as_float(int v) { return hipemu::from_bits<float>((unsigned)v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }

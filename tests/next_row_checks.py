@@ -2365,3 +2365,78 @@ def check_ctp528_device_axis_path(dev, n_slices=8, size=256, mmpp=0.98, light=Fa
         p2, _, _ = ct.ctp528_profiles_batch(x[0], mmpp, None, None, slices_per_volume=n_slices,
                                             device_centers=torch.from_numpy(moved).to(dev))
         assert torch.equal(torch.nan_to_num(p2, nan=-1.0), torch.nan_to_num(prof, nan=-1.0))
+
+
+def check_edge_plane32(dev, shapes=((2, 70, 130, np.int16), (1, 40, 66, np.uint16), (2, 64, 256, np.int16), (1, 33, 300, np.uint16)),
+                       sigmas=(1,), catphan_slices=()):
+    """The packed-float32 edge plane (pl_edge_plane32) against the exact one (pl_edge_plane, pinned to scikit-image / scipy):
+      * every stored value within `bracket` float32 bit patterns of RN32(exact) -- measured, not assumed --, an exact 0 stored
+        as 0, and nothing else stored as 0;
+      * the extrema over row spans and the raw maximum EXACT (bit for bit the float64 values of the exact path) for every
+        slice whose status is 0, and status 0 for all but deliberately tied inputs;
+      * the consumers on that plane with the bracket: Otsu threshold, all 256 histogram counts, the thresholded mask for
+        thresholds ON plane values, the region table and the phantom ROI -- identical to the exact path's."""
+    import torch
+
+    from pylinac_amd import ct, ops
+
+    rng = np.random.default_rng(23)
+    worst = 0
+    cases = []
+    for n, h, w, dt in shapes:
+        a = rng.integers(-1000 if dt == np.int16 else 0, 3000, (n, h, w)).astype(dt)
+        a[:, h // 4:h // 2, w // 4:w // 2] += 700
+        a[0, : h // 8] = 5                                        # a flat band: edge value exactly 0 there
+        c0 = rng.integers(0, w // 2, h)
+        c1 = np.minimum(c0 + rng.integers(1, w, h), w)
+        cases.append((a, np.stack([c0, c1], 1).astype(np.int32)))
+    if len(catphan_slices):
+        from pylinac_amd.synthetic import catphan_volume
+
+        vol = catphan_volume(seed=4000, n_slices=80)
+        spans = ct._disk_spans_on_device(512, 512, 0.5, dev).cpu().numpy()
+        cases.append((np.ascontiguousarray(vol[list(catphan_slices)]), spans))
+    for a, spans_np in cases:
+        x = torch.from_numpy(a).to(dev)
+        spans = torch.from_numpy(spans_np).to(dev)
+        n, h, w = a.shape
+        for sigma in sigmas:
+            e64, rawmax64, lo64, hi64 = ops.edge_plane(x, sigma, spans=spans, dtype=torch.float64)
+            p32, rawmax, lo, hi, status, B = ops.edge_plane32(x, sigma, spans=spans)
+            assert B >= 1 and not bool(status.any()), (a.shape, status.cpu().tolist())
+            want32 = e64.to(torch.float32)
+            d = (p32.view(torch.int32).to(torch.int64) - want32.view(torch.int32).to(torch.int64)).abs()
+            worst = max(worst, int(d.max()))
+            assert int(d.max()) <= B, (a.shape, sigma, int(d.max()))
+            assert torch.equal(p32 == 0, e64 == 0)
+            assert torch.equal(lo, lo64) and torch.equal(hi, hi64), (a.shape, sigma)
+            small = rawmax64 < 32
+            assert torch.equal(rawmax[small], rawmax64[small]) and torch.allclose(rawmax, rawmax64, rtol=1e-6, atol=0)
+            # consumers
+            thr64, raw64, work64 = ops.edge_otsu(e64, lo64, hi64, spans=spans, scale=0.8, return_work=True)
+            thr, raw, work = ops.edge_otsu(p32, lo, hi, frames=x, sigma=sigma, spans=spans, scale=0.8, return_work=True, bracket=B)
+            assert torch.equal(thr, thr64) and torch.equal(raw, raw64) and torch.equal(work[:, :256], work64[:, :256]), (a.shape, sigma)
+            if ops.mask_regions_fits(h, w, 64) and min(h, w) >= 12:
+                # thresholds ON plane values (an exact float64 value; a float32 value): the pixels around them are undecided
+                # within the bracket and take the exact recomputation.  (High ones: a mask of few row runs fits the LDS list.)
+                k_hi = max(h * w // 500, 8)
+                for tv in (thr64, e64.reshape(n, -1).sort(dim=1).values[:, -k_hi].contiguous(),
+                           want32.reshape(n, -1).sort(dim=1).values[:, -2 * k_hi].to(torch.float64).contiguous(),
+                           torch.full_like(thr64, -1.0), torch.full_like(thr64, float("inf"))):
+                    q = ops.edge_regions(p32, x, sigma, tv.contiguous(), 0, False, 64, return_mask=True, want_table=False, bracket=B)
+                    ok = q["status"] == 0                                     # (status 1 = more row runs than the LDS list holds)
+                    assert bool(ok.any()), (a.shape, sigma)
+                    assert torch.equal(q["mask"][ok], (e64 > tv[:, None, None]).to(torch.uint8)[ok]), (a.shape, sigma)
+                r64 = ops.mask_regions(e64, thr64, 2, True, 64)
+                r32 = ops.edge_regions(p32, x, sigma, thr64, 2, True, 64, bracket=B)
+                assert torch.equal(r32["status"], r64[2]) and torch.equal(r32["count"], r64[1]) and torch.equal(r32["table"], r64[0])
+    # ties at the extremum: two pixels of the selection with the SAME smallest value in one lane's columns cannot be ranked
+    # by the float32 plane -- the slice must say so (status 1), not guess
+    t = np.zeros((1, 48, 64), np.int16)
+    t[0, :, 32:] = 1000                                            # a vertical step: every row has the same edge profile
+    x = torch.from_numpy(t).to(dev)
+    sp = torch.from_numpy(np.tile(np.array([[24, 40]], np.int32), (48, 1))).to(dev)
+    _, _, lo_t, hi_t, st_t, _ = ops.edge_plane32(x, 1, spans=sp)
+    _, _, lo_e, hi_e = ops.edge_plane(x, 1, spans=sp, dtype=torch.float64)
+    assert int(st_t[0]) == 1 or (torch.equal(lo_t, lo_e) and torch.equal(hi_t, hi_e))
+    return worst

@@ -1084,3 +1084,12 @@ def test_emulated_pf_other_dtypes(golden, emulated):
     import next_row_checks as checks
 
     checks.check_pf_other_dtypes(golden("picketfence_mlc"), emulated)
+
+
+def test_emulated_edge_plane32(emulated):
+    """The packed-float32 edge kernel and its bracketed consumers against the exact path (small frames; the GPU suite adds
+    CatPhan slices)."""
+    import next_row_checks as checks
+
+    worst = checks.check_edge_plane32(emulated, shapes=((2, 70, 130, np.int16), (1, 40, 66, np.uint16)))
+    assert worst <= 32

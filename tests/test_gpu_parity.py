@@ -2134,3 +2134,26 @@ def test_analyze_batch_takes_what_the_loader_produces(golden, dev):
         if other.dtype == torch.int16 and bool((r.status == 3).all()):
             continue                                            # (a range beyond 32767 is refused like the reference's overflow)
         assert torch.equal(r.status, b.status) and torch.equal(torch.nan_to_num(r.position, nan=-1.0), torch.nan_to_num(b.position, nan=-1.0))
+
+
+@pytest.mark.gpu
+def test_edge_plane32_vs_exact_path(dev):
+    """Round 6: the packed-float32 edge kernel (pl_edge_plane32) and the bracketed consumers against the exact float64 path on
+    random slices, ragged shapes and CatPhan slices: stored values within the bracket (the distance is measured), exact zeros,
+    exact extrema, identical histogram / threshold / mask / region table; then the whole localisation with the knob on and
+    off gives the same ROI table."""
+    import next_row_checks as checks
+    from pylinac_amd import ct
+    from pylinac_amd.synthetic import catphan_volume
+
+    worst = checks.check_edge_plane32(dev, catphan_slices=tuple(range(0, 80, 8)), sigmas=(1, 2))
+    assert worst <= 32
+    print("largest distance of a stored value from RN32(exact), in float32 bit patterns:", worst)
+    x = torch.from_numpy(catphan_volume(4001)).to(dev)
+    on = ct.phantom_roi_batch(x, 0.5)
+    try:
+        ct.EDGE_PLANE32 = False
+        off = ct.phantom_roi_batch(x, 0.5)
+    finally:
+        ct.EDGE_PLANE32 = True
+    assert np.array_equal(on, off, equal_nan=True)
