@@ -29,6 +29,10 @@
 #include "pl_common.h"
 #include "edge_exact.h"
 
+#ifndef PL_E32_WANT_FACTOR
+#define PL_E32_WANT_FACTOR 4
+#endif
+
 namespace {
 
 constexpr int kE32Threads = 256;
@@ -312,7 +316,7 @@ int e32_launch(const T* in, int64_t n, int h, int w, const double* wts, int radi
                unsigned char* work, double* rawmax, double* dmin, double* dmax, int32_t* status, hipStream_t st) {
   const int hl = (radius + 2) / 2, outw = 2 * (PL_WAVE - 2 * hl);
   const int strips = (int)pl_cdiv(w, outw);
-  const int64_t want = 4LL * pl_cu_count() * 32;
+  const int64_t want = (int64_t)PL_E32_WANT_FACTOR * pl_cu_count() * 32;   // waves the launch should at least have
   int segs = (int)pl_cdiv(want, n * strips);
   const int max_segs = (int)pl_cdiv(h, 32);
   if (segs > max_segs) segs = max_segs;
