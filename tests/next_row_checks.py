@@ -2439,4 +2439,14 @@ def check_edge_plane32(dev, shapes=((2, 70, 130, np.int16), (1, 40, 66, np.uint1
     _, _, lo_t, hi_t, st_t, _ = ops.edge_plane32(x, 1, spans=sp)
     _, _, lo_e, hi_e = ops.edge_plane(x, 1, spans=sp, dtype=torch.float64)
     assert int(st_t[0]) == 1 or (torch.equal(lo_t, lo_e) and torch.equal(hi_t, hi_e))
+    # ... and the localisation repeats such a slice on the exact path: the ROI table is the same with the knob on and off
+    both = np.concatenate([t, rng.integers(-1000, 1000, (1, 48, 64)).astype(np.int16)])
+    xb = torch.from_numpy(both).to(dev)
+    on = ct.phantom_roi_batch(xb, 4.0)
+    try:
+        ct.EDGE_PLANE32 = False
+        off = ct.phantom_roi_batch(xb, 4.0)
+    finally:
+        ct.EDGE_PLANE32 = True
+    assert np.array_equal(on, off, equal_nan=True), (on, off)
     return worst
