@@ -83,7 +83,7 @@ def timed_passes(fn, iters=3):
 # After a configuration's timed passes a few of the units it just produced are compared with the CPU oracle's sequence
 # (oracle/ = the checker, never the thing measured): `"parity_sample": {"units": k, "ok": true}` in the line.  Bars as
 # in tests/test_gpu_bench_size.py: integer results / indices / picket positions exact, BB centroids 1e-9, profiles 1e-9.
-def parity_epid(res, frames, k=4):
+def parity_epid(res, frames, k=8):
     import numpy as np
 
     from oracle import pylinac_oracle as o
@@ -98,7 +98,7 @@ def parity_epid(res, frames, k=4):
             "Otsu, threshold, np.mean, scipy find_peaks): frames, profiles, records"}
 
 
-def parity_pf(res, frames, dpmm, k=2):
+def parity_pf(res, frames, dpmm, k=4):
     import numpy as np
 
     from oracle import pylinac_oracle as o
@@ -115,7 +115,7 @@ def parity_pf(res, frames, dpmm, k=2):
     return {"units": int(k), "ok": bool(ok), "against": "oracle.pf_measure: picket indices, spacing, every leaf x picket position"}
 
 
-def parity_wl(res, frames, dpmm, k=2):
+def parity_wl(res, frames, dpmm, k=4):
     import numpy as np
 
     from oracle import pylinac_oracle as o
@@ -129,7 +129,7 @@ def parity_wl(res, frames, dpmm, k=2):
     return {"units": int(k), "ok": bool(ok), "against": "oracle.wl_analyze_frame: field CAX exact, BB centroid 1e-9, inversion, crop"}
 
 
-def parity_ct(res, vols, mmpp, k=3):
+def parity_ct(res, vols, mmpp, k=8):
     import numpy as np
 
     from oracle import pylinac_oracle as o

@@ -296,15 +296,10 @@ class ProfileBase(ProfileMixin):
     def field_x_values(self, in_field_ratio: float) -> np.ndarray:
         """profile.py:308-321: the x-values inside the central ``in_field_ratio`` of the field, inclusive of the edges
         (floor / ceil of the two bounds)."""
-        left = self.field_edge_idx(side=LEFT)
-        right = self.field_edge_idx(side=RIGHT)
-        width = self.field_width_px
-        f_left = left + (1 - in_field_ratio) / 2 * width
-        f_right = right - (1 - in_field_ratio) / 2 * width
-        lower_bound = math.floor(min((f_left, f_right)))
-        upper_bound = math.ceil(max((f_left, f_right)))
-        inner = np.nonzero((self.x_values >= lower_bound) & (self.x_values <= upper_bound))[0]
-        return self.x_values[inner]
+        margin = (1 - in_field_ratio) / 2 * self.field_width_px               # what each edge gives up
+        ends = (self.field_edge_idx(side=LEFT) + margin, self.field_edge_idx(side=RIGHT) - margin)
+        keep = (self.x_values >= math.floor(min(ends))) & (self.x_values <= math.ceil(max(ends)))
+        return self.x_values[np.nonzero(keep)[0]]
 
     def field_values(self, in_field_ratio: float = 0.8) -> np.ndarray:
         """profile.py:345-352"""
@@ -1123,21 +1118,23 @@ class SingleProfile(ProfileMixin):
 
     def _sample_points_in_physical_window(self, left_edge: float, right_edge: float):
         """profile.py:1237-1283."""
-        lower, upper = sorted((left_edge, right_edge))
-        start = int(np.searchsorted(self.x_indices, lower, side="left"))
-        stop = int(np.searchsorted(self.x_indices, upper, side="right"))
-        if stop - start < 3:
-            left_idx = int(np.abs(self.x_indices - lower).argmin())
-            right_idx = int(np.abs(self.x_indices - upper).argmin())
-            start = min(left_idx, right_idx)
-            stop = max(left_idx, right_idx) + 1
-        if stop - start < 3:
-            center_sample_idx = int(np.abs(self.x_indices - (lower + upper) / 2).argmin())
-            start = max(0, center_sample_idx - 1)
-            stop = min(len(self.x_indices), start + 3)
-            start = max(0, stop - 3)
-        x_samples = self.x_indices[start:stop]
-        return x_samples, self._y_original_to_interp(x_samples)
+        xi = self.x_indices
+        lo, hi = (left_edge, right_edge) if left_edge <= right_edge else (right_edge, left_edge)
+
+        def nearest(position) -> int:
+            return int(np.abs(xi - position).argmin())
+
+        # three tiers, each tried only while fewer than three samples are in hand: every sample inside the closed window;
+        # from the sample nearest one end to the sample nearest the other; three samples about the one nearest the middle
+        take = slice(int(np.searchsorted(xi, lo, side="left")), int(np.searchsorted(xi, hi, side="right")))
+        if take.stop - take.start < 3:
+            first, last = sorted((nearest(lo), nearest(hi)))
+            take = slice(first, last + 1)
+        if take.stop - take.start < 3:
+            end = min(len(xi), max(0, nearest((lo + hi) / 2) - 1) + 3)
+            take = slice(max(0, end - 3), end)
+        xs = xi[take]
+        return xs, self._y_original_to_interp(xs)
 
     def field_data(self, in_field_ratio: float = 0.8, slope_exclusion_ratio=0.2) -> dict:
         """profile.py:1463-1633: in-field window, two edge-slope regressions, quadratic "top"."""
@@ -1145,66 +1142,37 @@ class SingleProfile(ProfileMixin):
             raise ValueError("in_field_ratio and slope_exclusion_ratio must be within (0, 1)")
         if slope_exclusion_ratio >= in_field_ratio:
             raise ValueError("The exclusion region must be smaller than the field ratio")
+        # which centre the windows hang on, and the full field width they are fractions of
         if self._edge_method == Edge.FWHM:
-            data = self.fwxm_data(x=50)
-            beam_center_idx = data["center index (exact)"]
-            full_width = data["width (exact)"]
+            half_max = self.fwxm_data(x=50)
+            beam, span = half_max["center index (exact)"], half_max["width (exact)"]
         else:
-            data = self.inflection_data()
-            beam_center_idx = self.beam_center()["index (exact)"]
-            full_width = data["right index (exact)"] - data["left index (exact)"]
-        beam_center_idx_r = int(round(beam_center_idx))
-        cax_idx = self.geometric_center()["index (exact)"]
-        cax_idx_r = int(round(cax_idx))
-        center_idx = cax_idx if self._centering == Centering.GEOMETRIC_CENTER else beam_center_idx
-
-        field_left_idx = center_idx - in_field_ratio * full_width / 2
-        field_right_idx = center_idx + in_field_ratio * full_width / 2
-        field_width = field_right_idx - field_left_idx
-        inner_left_idx = center_idx - slope_exclusion_ratio * field_width / 2
-        inner_right_idx = center_idx + slope_exclusion_ratio * field_width / 2
-        left_slope_x, left_slope_y = self._sample_points_in_physical_window(field_left_idx, inner_left_idx)
-        right_slope_x, right_slope_y = self._sample_points_in_physical_window(inner_right_idx, field_right_idx)
-        left_slope, left_intercept = _linregress(left_slope_x, left_slope_y)
-        right_slope, right_intercept = _linregress(right_slope_x, right_slope_y)
-
-        top_x, top_y = self._sample_points_in_physical_window(inner_left_idx, inner_right_idx)
-        fit_params = np.polyfit(top_x, top_y, deg=2)
-        width = abs(top_x[-1] - top_x[0])
-        top_idx, top_val = _bounded_top(fit_params, top_x[0] + width / 2, top_x[0], top_x[-1])
-
-        pixel_offset = center_idx - int(round(center_idx))
-        x_indices_shifted = self.x_indices + pixel_offset
-        x_index_min = int(np.abs(x_indices_shifted - field_left_idx).argmin())
-        x_index_max = int(np.abs(x_indices_shifted - field_right_idx).argmin())
-        out = {
-            "width (exact)": field_width,
-            "beam center index (exact)": beam_center_idx,
-            "beam center index (rounded)": beam_center_idx_r,
-            "beam center value (@rounded)": self._y_original_to_interp(round(beam_center_idx)),
-            "cax index (exact)": cax_idx,
-            "cax index (rounded)": cax_idx_r,
-            "cax value (@rounded)": self._y_original_to_interp(round(cax_idx)),
-            "left index (exact)": field_left_idx,
-            "left index (rounded)": int(round(field_left_idx)),
-            "left value (@rounded)": self._y_original_to_interp(round(field_left_idx)),
-            "left slope": left_slope,
-            "left intercept": left_intercept,
-            "right slope": right_slope,
-            "right intercept": right_intercept,
-            "left inner index (exact)": inner_left_idx,
-            "left inner index (rounded)": int(round(inner_left_idx)),
-            "right inner index (exact)": inner_right_idx,
-            "right inner index (rounded)": int(round(inner_right_idx)),
-            '"top" index (exact)': top_idx,
-            '"top" index (rounded)': int(round(top_idx)),
-            '"top" value (@exact)': top_val,
-            "top params": fit_params,
-            "right index (exact)": field_right_idx,
-            "right index (rounded)": int(round(field_right_idx)),
-            "right value (@rounded)": self._y_original_to_interp(round(field_right_idx)),
-            "field values": self._y_original_to_interp(x_indices_shifted[x_index_min: x_index_max + 1]),
-        }
+            edges = self.inflection_data()
+            beam, span = self.beam_center()["index (exact)"], edges["right index (exact)"] - edges["left index (exact)"]
+        cax = self.geometric_center()["index (exact)"]
+        anchor = cax if self._centering == Centering.GEOMETRIC_CENTER else beam
+        field = _Span.about(anchor, in_field_ratio * span)                    # the in-field window
+        core = _Span.about(anchor, slope_exclusion_ratio * field.width)       # its flat core, left out of the slope fits
+        window = self._sample_points_in_physical_window
+        slope = {"left": _linregress(*window(field.lo, core.lo)), "right": _linregress(*window(core.hi, field.hi))}
+        top_x, top_y = window(core.lo, core.hi)
+        parabola = np.polyfit(top_x, top_y, deg=2)
+        top_at, top_value = _bounded_top(parabola, top_x[0] + abs(top_x[-1] - top_x[0]) / 2, top_x[0], top_x[-1])
+        # the in-field samples: the index grid moved by the centre's fractional part, so that both halves hold the same
+        # number of points (the reference's RAM-4559 note)
+        grid = self.x_indices + (anchor - int(round(anchor)))
+        first, last = (int(np.abs(grid - edge).argmin()) for edge in (field.lo, field.hi))
+        at = self._y_original_to_interp
+        out = {"width (exact)": field.width}
+        out |= _index_entries("beam center", beam, value=at(round(beam)))
+        out |= _index_entries("cax", cax, value=at(round(cax)))
+        out |= _index_entries("left", field.lo, value=at(round(field.lo)))
+        for side in ("left", "right"):
+            out[f"{side} slope"], out[f"{side} intercept"] = slope[side]
+        out |= _index_entries("left inner", core.lo) | _index_entries("right inner", core.hi)
+        out |= _index_entries('"top"', top_at) | {'"top" value (@exact)': top_value, "top params": parabola}
+        out |= _index_entries("right", field.hi, value=at(round(field.hi)))
+        out["field values"] = at(grid[first:last + 1])
         if self.dpmm:
             d = self.dpmm
             out["width (exact) mm"] = out["width (exact)"] / d
@@ -1589,6 +1557,33 @@ def _linregress(x, y):
     ssxm, ssxym, _, _ = np.cov(x, y, bias=1).flat
     slope = ssxym / ssxm
     return slope, ymean - slope * xmean
+
+
+class _Span:
+    """An index interval hung symmetrically on a centre: ``about(c, full)`` -> [c - full / 2, c + full / 2]; ``width`` is the
+    difference of the two ROUNDED ends (what the reference carries forward), not ``full``."""
+
+    __slots__ = ("lo", "hi")
+
+    def __init__(self, lo: float, hi: float):
+        self.lo, self.hi = lo, hi
+
+    @classmethod
+    def about(cls, centre: float, full: float) -> "_Span":
+        return cls(centre - full / 2, centre + full / 2)
+
+    @property
+    def width(self) -> float:
+        return self.hi - self.lo
+
+
+def _index_entries(name: str, index: float, value=None) -> dict:
+    """The reference's result-dictionary triplet for one position: ``<name> index (exact)``, ``... (rounded)`` and -- where it
+    reports one -- ``<name> value (@rounded)``."""
+    entries = {f"{name} index (exact)": index, f"{name} index (rounded)": int(round(index))}
+    if value is not None:
+        entries[f"{name} value (@rounded)"] = value
+    return entries
 
 
 def _bounded_top(fit_params, x0: float, lo: float, hi: float):
