@@ -67,7 +67,7 @@ def mfma_view(tiles, seconds):
             "peaks": "datasheet = dense int8 spec; measured = MI355X_MICROARCH.md's v_mfma_i32_16x16x64_i8 rate (>= 3944 TOPS)"}
 
 
-def timed_passes(fn, iters=3):
+def timed_passes(fn, iters=8):      # (eight passes after one untimed: three sat inside the power governor's ramp, like the headline)
     import torch
 
     fn()
