@@ -878,6 +878,66 @@ def check_starshot(g, make, only=None, tol=1e-9):
     return n
 
 
+def check_starshot_batch(g, dev, names=("four", "six_off", "inverted", "nofwhm"), variants=3):
+    """starshot.analyze_batch against (a) the reference's own Starshot.analyze() numbers for the golden frame that leads each
+    stack and (b) the class API, frame by frame, for shifted / histogram-inverted copies of it (other start points, so other
+    ring sizes and more than one gather group per pass)."""
+    from pylinac_amd import starshot
+
+    n_checked = 0
+    for name, frame, dpi, kw in starshot_cases(g):
+        if name not in names or frame.dtype != np.uint16:
+            continue
+        stack = [frame]
+        for k in range(1, variants):
+            v = np.roll(frame, (2 * k + 1, -3 * k), axis=(0, 1))
+            if k % 2 == 0:
+                v = (int(v.max()) + int(v.min()) - v.astype(np.int64)).astype(np.uint16)      # an inverted film
+            stack.append(v)
+        stack = np.stack(stack)
+        kw = dict(kw)
+        kw.pop("start_point", None)
+        res = starshot.analyze_batch(torch.from_numpy(stack).to(dev), dpi=dpi, sid=1000, **kw)
+        assert len(res) == len(stack) and (res.status == 0).all(), (name, res.status)
+        want = g[f"{name}.wobble"]
+        got = [res.wobble_center[0, 0], res.wobble_center[0, 1], res.wobble_radius[0], res.wobble_radius_mm[0],
+               res.wobble_diameter_mm[0]]
+        a0 = res.analyzers[0]
+        lines = np.array([[ln.point1.x, ln.point1.y, ln.point2.x, ln.point2.y] for ln in a0.lines.lines], dtype=float)
+        assert np.allclose(lines, g[f"{name}.lines"], rtol=1e-9, atol=1e-9), (name, "lines")
+        wtol = 1e-7 if np.array_equal(lines, g[f"{name}.lines"]) else 2e-3
+        assert np.allclose(got, want, rtol=wtol, atol=wtol), (name, got, want)
+        assert np.allclose(np.asarray(a0.circle_profile.values, float), g[f"{name}.profile"], rtol=1e-9, atol=1e-9), name
+        assert tuple(res.start_point[0]) == tuple(g[f"{name}.start"][:2]) and bool(res.passed[0]) == bool(g[f"{name}.passed"])
+        assert np.allclose(a0.angles, g[f"{name}.angles"], rtol=1e-9, atol=1e-9), name
+        for i in range(len(stack)):
+            s1 = starshot.Starshot(stack[i].copy(), dpi=dpi, sid=1000)
+            s1.analyze(**kw)
+            sp, lm = s1._get_reasonable_start_point()
+            assert (sp.x, sp.y) == tuple(res.start_point[i]) and lm == res.local_max[i], (name, i, "start")
+            assert np.array_equal(np.asarray(s1.circle_profile.values), np.asarray(res.analyzers[i].circle_profile.values)), (name, i)
+            assert [(q.idx, q.x, q.y) for q in s1.circle_profile.peaks] == \
+                   [(q.idx, q.x, q.y) for q in res.analyzers[i].circle_profile.peaks], (name, i, "peaks")
+            assert (s1.wobble.center.x, s1.wobble.center.y, s1.wobble.radius) == \
+                   (res.wobble_center[i, 0], res.wobble_center[i, 1], res.wobble_radius[i]), (name, i, "wobble")
+            assert s1.passed == bool(res.passed[i]) and len(s1.lines) == res.n_lines[i]
+            n_checked += 1
+    # the error cases come back as codes: a flat frame has no FW80M peak (IndexError in the class), a frame without spokes
+    # exhausts the sweep (RuntimeError in the class), and with recursive=False it fails at the first peak count
+    frame = g["four.frame"]
+    flat = np.full_like(frame, 1000)
+    rng = np.random.default_rng(5)
+    blob = (1000 + 20000 * np.exp(-(((np.arange(frame.shape[0])[:, None] - 300) ** 2 + (np.arange(frame.shape[1])[None, :] - 320) ** 2)
+                                    / (2 * 60.0 ** 2)))).astype(np.uint16)
+    blob += rng.integers(0, 3, blob.shape).astype(np.uint16)
+    res = starshot.analyze_batch(torch.from_numpy(np.stack([frame, flat, blob])).to(dev), dpi=100, sid=1000)
+    assert res.status.tolist() == [0, 3, 1], res.status
+    assert np.isnan(res.wobble_radius[1:]).all() and res.analyzers[1] is None and res.analyzers[2] is None
+    res = starshot.analyze_batch(torch.from_numpy(np.stack([frame, blob])).to(dev), dpi=100, sid=1000, recursive=False)
+    assert res.status.tolist() == [0, 2], res.status
+    return n_checked
+
+
 # ---------------------------------------------------------------------------------------------- contrast ROIs
 def check_contrast_rois(golden, dev):
     """LowContrastDiskROI / HighContrastDiskROI and the pylinac.core.contrast formulas against the reference's own

@@ -572,6 +572,14 @@ def test_emulated_starshot(golden, emulated):
     assert n == 2
 
 
+def test_emulated_starshot_batch(golden, emulated):
+    """starshot.analyze_batch on the emulated device: the golden "inverted" frame + one shifted copy against the reference's
+    numbers and the class API, and the status codes (the four-frame set runs with -m gpu)."""
+    import next_row_checks as checks
+
+    assert checks.check_starshot_batch(golden("starshot"), emulated, names=("inverted",), variants=2) == 2
+
+
 def test_emulated_contrast_rois(golden, emulated):
     import next_row_checks as checks
 

@@ -1691,6 +1691,15 @@ def test_starshot_vs_reference_golden(golden, dev):
         s.analyze(radius=0.1)
 
 
+@pytest.mark.gpu
+def test_starshot_analyze_batch(golden, dev):
+    """starshot.analyze_batch: four stacks (golden frame + shifted / inverted copies) against the reference's own numbers for
+    the leading frame and the class API for every frame; per-frame status codes for the cases the class raises on."""
+    import next_row_checks as checks
+
+    assert checks.check_starshot_batch(golden("starshot"), dev) == 12
+
+
 
 
 
