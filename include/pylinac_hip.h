@@ -228,6 +228,19 @@ int pl_circle_profile_combined_ex(const void* stack, int dtype, int64_t n_stack,
                                   const double* d_cx, const double* d_cy, double divisor, double* d_out,
                                   double* d_margin, void* stream);
 
+/* pl_circle_profile_combined_ex for a THIN ring (CTP528CP504.circle_profile, pylinac/ct.py:1559-1580: 20 radii within +-4 % of
+ * the line-pair radius): the caller promises r_lo <= |radius| <= r_hi for every radius of every profile.  One workgroup per
+ * profile copies the annulus of the ring's bounding box -- per row the one or two chords, the maximum over the
+ * 2 * plusminus + 1 slices formed on the way -- into LDS with row-contiguous loads and takes the taps from there: the 172 000
+ * scattered gathers of a CTP528 profile become 45 000 contiguous loads; consecutive profiles run on the same XCD, whose L2
+ * then serves the 2 * plusminus slices neighbours share.  Same samples, same margins.  A tap whose pixel is not inside a staged
+ * chord is fetched from the slices themselves (a wrong promise costs time, never a sample); a ring whose annulus exceeds 64 KB
+ * of LDS, or plusminus > 3, takes pl_circle_profile_combined_ex. */
+int pl_circle_profile_ring(const void* stack, int dtype, int64_t n_stack, int h, int w, const int64_t* d_slice_index,
+                           int64_t m, int64_t slices_per_volume, int plusminus, const double* d_cos, const double* d_sin,
+                           int nsamp, const double* d_radii, int nr, const double* d_cx, const double* d_cy, double divisor,
+                           double r_lo, double r_hi, double* d_out, double* d_margin, void* stream);
+
 /* CatPhanBase.find_phantom_axis (pylinac/ct.py:2398-2446) for the phantom-ROI tables d_roi [n_volumes * spv][8] of
  * pl_edge_regions, one volume after the other: slices with status 0, np.median of their centres, the np.isclose(median, c,
  * atol=3, rtol=0.01) screen on both axes (both exact), then a closed-form first-order least-squares fit of centre against

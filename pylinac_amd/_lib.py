@@ -81,6 +81,7 @@ SIGNATURES = {
     "pl_circle_profile": ([_p, _i, _l, _i, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p], C.c_int),
     "pl_circle_profile_combined": ([_p, _i, _l, _i, _i, _p, _l, _l, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p], C.c_int),
     "pl_circle_profile_combined_ex": ([_p, _i, _l, _i, _i, _p, _l, _l, _i, _p, _p, _i, _p, _i, _p, _p, _d, _p, _p, _p], C.c_int),
+    "pl_circle_profile_ring": ([_p, _i, _l, _i, _i, _p, _l, _l, _i, _p, _p, _i, _p, _i, _p, _p, _d, _d, _d, _p, _p, _p], C.c_int),
     "pl_phantom_axis_fit": ([_p, _l, _i, _d, _d, _p, _p, _p, _p], C.c_int),
     "pl_sobel": ([_p, _p, _i, _l, _i, _i, _i, _p], C.c_int),
     "pl_label": ([_p, _l, _i, _i, _i, _p, _p, _p, _p], C.c_int),

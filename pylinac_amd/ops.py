@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -700,6 +701,7 @@ def fwxm_record(res: PeakBatch, out=None) -> torch.Tensor:
 
 # ------------------------------------------------------------------------- circle profiles, Sobel
 _circle_cache: dict = {}
+CIRCLE_RING = os.environ.get("PL_CIRCLE_RING", "1") != "0"
 
 
 def _circle_tables(size: float, start_angle: float, ccw: bool, dev):
@@ -794,11 +796,16 @@ def circle_profile(frames: torch.Tensor, cx, cy, radii, size: float, start_angle
     out = torch.empty((n, nsamp), dtype=torch.float64, device=dev)
     if combine is not None:
         margin = torch.full((n,), float("inf"), dtype=torch.float64, device=dev) if want_margin else None
-        check(_lib.load().pl_circle_profile_combined_ex(x.data_ptr(), _dt(x), n_stack, h, w, d_sidx.data_ptr(), n, int(spv),
-                                                        int(pm), d_cos.data_ptr(), d_sin.data_ptr(), nsamp, r.data_ptr(),
-                                                        r.shape[1], cxs.data_ptr(), cys.data_ptr(), float(divisor),
-                                                        out.data_ptr(), 0 if margin is None else margin.data_ptr(),
-                                                        _stream()), "pl_circle_profile_combined_ex")
+        # the radii are host numbers: their range is the promise that lets a thin ring be staged in LDS (csrc/circle.hip)
+        r_abs = np.abs(r_host)
+        r_lo, r_hi = (float(r_abs.min()), float(r_abs.max())) if r_abs.size and np.isfinite(r_abs).all() else (0.0, np.inf)
+        if not CIRCLE_RING:                                  # A/B knob: an infinite promise forwards to the gather kernel
+            r_lo, r_hi = 0.0, np.inf
+        check(_lib.load().pl_circle_profile_ring(x.data_ptr(), _dt(x), n_stack, h, w, d_sidx.data_ptr(), n, int(spv),
+                                                 int(pm), d_cos.data_ptr(), d_sin.data_ptr(), nsamp, r.data_ptr(),
+                                                 r.shape[1], cxs.data_ptr(), cys.data_ptr(), float(divisor), r_lo, r_hi,
+                                                 out.data_ptr(), 0 if margin is None else margin.data_ptr(),
+                                                 _stream()), "pl_circle_profile_ring")
         return (out, margin) if want_margin else out
     if want_margin:
         raise ValueError("want_margin needs combine=")

@@ -50,6 +50,7 @@ HIPEMU_VEC(unsigned char, uchar)
 HIPEMU_VEC(unsigned long long, ulonglong)
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 inline double2 make_double2(double x, double y) { return double2{x, y}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 typedef struct ihipStream_t* hipStream_t;

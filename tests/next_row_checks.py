@@ -1744,6 +1744,59 @@ def check_circle_profile_combined(dev, n_volumes=2, spv=9, h=96, w=112):
         assert torch.equal(got, want[torch.from_numpy(sub).to(dev)]), k
 
 
+def check_circle_profile_ring(dev, n_volumes=2, spv=5, h=120, w=136, light=False):
+    """pl_circle_profile_ring (the annulus staged in LDS) against pl_circle_profile_combined_ex (scattered gathers), samples AND
+    margins bit for bit: rings inside the frame, cut by every border, centred outside it, a NaN centre; uint8 / int16 / uint16
+    / int32 slices; k = 0 .. 3; a promise about the radii that is too narrow on either side (the taps outside it must come
+    from the slices themselves) and one so wide that the box exceeds the LDS (the entry point forwards)."""
+    import ctypes as C
+
+    import torch
+
+    from pylinac_amd import _lib, ops
+
+    lib = _lib.load()
+    rng = np.random.default_rng(23)
+    n = n_volumes * spv
+    centres = np.stack([w / 2 + rng.uniform(-4, 4, n), h / 2 + rng.uniform(-4, 4, n)], 1)
+    centres[1] = (6.3, 50.2)               # cut by the left border
+    centres[2] = (w - 4.6, h - 3.1)        # the bottom-right corner
+    centres[3] = (-20.5, -11.25)           # outside the frame
+    centres[4] = (w / 2, 2.0)
+    centres[5] = (np.nan, 40.0)
+    n_checked = 0
+    cases = ((np.int16, -1000, 3000), (np.uint16, 0, 65535), (np.uint8, 0, 255), (np.int32, -70000, 70000))
+    for dtype, lo, hi in (cases[:2] if light else cases):
+        vol = torch.from_numpy(rng.integers(lo, hi, (n, h, w)).astype(dtype)).to(dev)
+        for radii in (np.linspace(30.0, 34.0, 7), np.linspace(3.0, 9.0, 20), np.array([0.0, 1.5, np.nan, 47.25])):
+            size = np.pi * np.nanmax(radii) * 2 * 2
+            d_cos, d_sin, nsamp = ops._circle_tables(size, np.pi, True, dev)
+            r = torch.from_numpy(np.broadcast_to(radii[None, :], (n, len(radii))).copy()).to(dev)
+            cx = torch.from_numpy(centres[:, 0].copy()).to(dev)
+            cy = torch.from_numpy(centres[:, 1].copy()).to(dev)
+            sidx = torch.arange(n, dtype=torch.int64, device=dev)
+            for k in (((1, 3) if light else (0, 1, 2, 3)) if dtype == np.int16 else (1,)):
+                def run(entry, *promise):
+                    out = torch.full((n, nsamp), -7.0, dtype=torch.float64, device=dev)
+                    mrg = torch.full((n,), float("inf"), dtype=torch.float64, device=dev)
+                    args = [vol.data_ptr(), ops._dt(vol), n, h, w, sidx.data_ptr(), n, spv, k, d_cos.data_ptr(), d_sin.data_ptr(),
+                            nsamp, r.data_ptr(), len(radii), cx.data_ptr(), cy.data_ptr(), float(len(radii))]
+                    rc = getattr(lib, entry)(*args, *promise, out.data_ptr(), mrg.data_ptr(), ops._stream())
+                    _lib.check(rc, entry)
+                    return out.cpu().numpy(), mrg.cpu().numpy()
+
+                want, want_m = run("pl_circle_profile_combined_ex")
+                r_min, r_max = float(np.nanmin(radii)), float(np.nanmax(radii))      # (a NaN radius: its taps read 0)
+                for promise in ((r_min, r_max),                                     # honest
+                                (r_min + 2.0, r_max - 2.0) if r_max - r_min > 4 and len(radii) > 4 else (0.0, 0.5),
+                                (0.0, 400.0)):                                      # box > 150 KB: forwarded
+                    got, got_m = run("pl_circle_profile_ring", *promise)
+                    assert np.array_equal(got, want, equal_nan=True), (dtype, radii[:2], k, promise)
+                    assert np.array_equal(got_m, want_m, equal_nan=True), (dtype, radii[:2], k, promise, got_m, want_m)
+                    n_checked += 1
+    return n_checked
+
+
 def check_phantom_roi_fused_vs_separate(dev, slices=(0, 24, 44, 79)):
     """ct.phantom_roi_batch (three launches: pl_edge_plane float32, pl_edge_otsu, pl_edge_regions with the ROI chosen on the
     device) == the same table built from the separate entry points (get_regions_batch + the host selection: the golden-pinned

@@ -572,6 +572,13 @@ def test_emulated_starshot(golden, emulated):
     assert n == 2
 
 
+def test_emulated_circle_profile_ring(emulated):
+    """pl_circle_profile_ring (LDS-staged annulus) == pl_circle_profile_combined_ex, samples and margins, on the emulated device."""
+    import next_row_checks as checks
+
+    assert checks.check_circle_profile_ring(emulated, light=True) == 27
+
+
 def test_emulated_starshot_batch(golden, emulated):
     """starshot.analyze_batch on the emulated device: the golden "inverted" frame + one shifted copy against the reference's
     numbers and the class API, and the status codes (the four-frame set runs with -m gpu)."""
@@ -816,7 +823,7 @@ def test_emulated_bb_finder_random_windows(emulated):
     rng = np.random.default_rng(77)
     dpmm = 2.98
     wins, specs = [], []
-    for k in range(5):          # k = 1, 4: a second BB; k = 2: a rod (the emulator runs a window in ~10 s; -m gpu runs hundreds)
+    for k in range(3):          # k = 1: a second BB; k = 2: a rod (the emulator runs a window in ~10 s; -m gpu runs hundreds)
         n = int(rng.integers(90, 150))
         yy, xx = np.mgrid[0:n, 0:n].astype(float)
         img = np.full((n, n), 0.2)
@@ -850,7 +857,7 @@ def test_emulated_bb_finder_random_windows(emulated):
                                     min_separation_mm=minsep, level_by_level=True)
         assert int(lv["count"][0]) == int(res["count"][0]) and int(lv["level"][0]) == int(res["level"][0])
         assert np.array_equal(lv["xy"][0, : len(ref_pts)].cpu().numpy(), res["xy"][0, : len(ref_pts)].cpu().numpy())
-    assert checked >= 3
+    assert checked >= 2
 
 
 def test_emulated_picket_fence_random_frames(emulated):
@@ -995,7 +1002,7 @@ def test_emulated_circle_profile_combined(emulated):
 def test_emulated_phantom_roi_fused_vs_separate(emulated):
     import next_row_checks as checks
 
-    checks.check_phantom_roi_fused_vs_separate(emulated, slices=(24, 44))
+    checks.check_phantom_roi_fused_vs_separate(emulated, slices=(44,))
 
 
 def test_emulated_histogram16_one_read(emulated):

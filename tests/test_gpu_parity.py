@@ -1692,6 +1692,15 @@ def test_starshot_vs_reference_golden(golden, dev):
 
 
 @pytest.mark.gpu
+def test_circle_profile_ring_vs_gathers(dev):
+    """pl_circle_profile_ring == pl_circle_profile_combined_ex bit for bit (samples, margins): borders, outside / NaN centres, four
+    dtypes, k = 0 .. 3, honest / too narrow / too wide promises about the radii."""
+    import next_row_checks as checks
+
+    assert checks.check_circle_profile_ring(dev) == 63
+
+
+@pytest.mark.gpu
 def test_starshot_analyze_batch(golden, dev):
     """starshot.analyze_batch: four stacks (golden frame + shifted / inverted copies) against the reference's own numbers for
     the leading frame and the class API for every frame; per-frame status codes for the cases the class raises on."""
