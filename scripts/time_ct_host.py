@@ -1,8 +1,9 @@
-"""Where a pass of ct.ctp528_batch spends its wall time (25 volumes): each phase bracketed by torch.cuda.synchronize()."""
+"""Development aid: where the HOST's time goes in one config #5 pass (ct.ctp528_batch over 25 resident volumes): wall-clock of the
+host-side steps (each includes the wait for the device results it needs), against the pass.
+    python scripts/time_ct_host.py [nv=25] [passes=8]"""
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, ".")
@@ -10,36 +11,44 @@ from pylinac_amd import ct  # noqa: E402
 from pylinac_amd.synthetic import catphan_volume  # noqa: E402
 
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+passes = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda:0")
 vols = torch.stack([torch.from_numpy(catphan_volume(4000 + v)) for v in range(nv)]).to(dev)
-flat = vols.reshape(nv * 80, 512, 512)
+acc, marks = {}, []
+
+
+def timed(name):
+    fn = getattr(ct, name)
+
+    def wrapper(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            t1 = time.perf_counter()
+            acc[name] = acc.get(name, 0.0) + (t1 - t)
+            marks.append((name, t, t1))
+    setattr(ct, name, wrapper)
+
+
+for name in ("_phantom_roi_launch", "ctp528_profiles_batch", "_ctp528_mtf_launch", "_phantom_roi_finish", "find_phantom_axes_batch",
+             "_device_centres_disagree", "_ctp528_mtf_finish"):
+    timed(name)
 ct.ctp528_batch(vols, 0.5)
 torch.cuda.synchronize()
-
-
-def lap(acc, name, t0):
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    acc[name] = acc.get(name, 0.0) + (t1 - t0)
-    return t1
-
-
-acc = {}
-reps = 5
-for _ in range(reps):
-    t = time.perf_counter()
-    roi = ct.phantom_roi_batch(flat, 0.5)
-    t = lap(acc, "phantom_roi_batch (3 launches + 1 D2H)", t)
-    fzx, fzy = ct.find_phantom_axes_batch(roi, nv)
-    t = lap(acc, "find_phantom_axes_batch (host)", t)
-    prof, idx = ct.ctp528_profiles_batch(flat, 0.5, fzx, fzy, slices_per_volume=80)
-    t = lap(acc, "ctp528_profiles_batch", t)
-    out = ct.ctp528_mtf_batch(prof)
-    t = lap(acc, "ctp528_mtf_batch", t)
-t0 = time.perf_counter()
-for _ in range(reps):
+acc.clear()
+total = 0.0
+for _ in range(passes):
+    marks.clear()
+    t0 = time.perf_counter()
     ct.ctp528_batch(vols, 0.5)
-torch.cuda.synchronize()
-print(f"whole pass: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms")
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    total += time.perf_counter() - t0
+print(f"pass {total / passes * 1e3:.3f} ms")
 for k, v in acc.items():
-    print(f"  {k:45s} {v / reps * 1e3:8.3f} ms")
+    print(f"  {k:28s} {v / passes * 1e6:8.1f} us")
+print("last pass, host timeline (us from the call):")
+for name, a, b in marks:
+    print(f"  {(a - t0) * 1e6:8.1f} .. {(b - t0) * 1e6:8.1f}  {name}")
+print(f"  returned at {(t1 - t0) * 1e6:8.1f}")
