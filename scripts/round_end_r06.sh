@@ -78,5 +78,5 @@ for f in 256 64 32 8; do timeout 120 python bench.py --gpus 1 --frames $f --step
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('frames', $f, 'ms/step', d['ms_per_step'], 'us/frame', round(d['ms_per_step']*1e3/$f, 3), d['roofline']['stage_ms'])"; done | tee $OUT/small_batch_sweep.txt
 # round 6 additions: config #5's SQ counters + HBM traffic on the final build
-timeout 500 bash scripts/pmc_kernels.sh ct mask_regions_kernel,edge_otsu_kernel,edge_stream32_kernel,circle_profile_combined -- python scripts/run_ct_pass.py 25 2 > /dev/null 2>&1
+timeout 500 bash scripts/pmc_kernels.sh ct mask_regions_kernel,edge_otsu_kernel,edge_stream32_kernel,circle_profile_combined,circle_ring_kernel -- python scripts/run_ct_pass.py 25 2 > /dev/null 2>&1
 cp gpurun_out/pmc_ct/summary.txt $OUT/pmc_sq_ct_kernels.txt
