@@ -1768,7 +1768,8 @@ def check_circle_profile_ring(dev, n_volumes=2, spv=5, h=120, w=136, light=False
     cases = ((np.int16, -1000, 3000), (np.uint16, 0, 65535), (np.uint8, 0, 255), (np.int32, -70000, 70000))
     for dtype, lo, hi in (cases[:2] if light else cases):
         vol = torch.from_numpy(rng.integers(lo, hi, (n, h, w)).astype(dtype)).to(dev)
-        for radii in (np.linspace(30.0, 34.0, 7), np.linspace(3.0, 9.0, 20), np.array([0.0, 1.5, np.nan, 47.25])):
+        for radii in (np.linspace(30.0, 34.0, 7), np.linspace(3.0, 9.0, 20), np.array([0.0, 1.5, np.nan, 47.25]),
+                      np.linspace(20.0, 26.0, 41)):      # (41 radii: beyond the 32 a lane group keeps in registers)
             size = np.pi * np.nanmax(radii) * 2 * 2
             d_cos, d_sin, nsamp = ops._circle_tables(size, np.pi, True, dev)
             r = torch.from_numpy(np.broadcast_to(radii[None, :], (n, len(radii))).copy()).to(dev)

@@ -576,7 +576,7 @@ def test_emulated_circle_profile_ring(emulated):
     """pl_circle_profile_ring (LDS-staged annulus) == pl_circle_profile_combined_ex, samples and margins, on the emulated device."""
     import next_row_checks as checks
 
-    assert checks.check_circle_profile_ring(emulated, light=True) == 27
+    assert checks.check_circle_profile_ring(emulated, light=True) == 36
 
 
 def test_emulated_starshot_batch(golden, emulated):

@@ -1697,7 +1697,7 @@ def test_circle_profile_ring_vs_gathers(dev):
     dtypes, k = 0 .. 3, honest / too narrow / too wide promises about the radii."""
     import next_row_checks as checks
 
-    assert checks.check_circle_profile_ring(dev) == 63
+    assert checks.check_circle_profile_ring(dev) == 84
 
 
 @pytest.mark.gpu
