@@ -211,25 +211,28 @@ otsu_kernel(const uint32_t* __restrict__ hist, int bias, int32_t* __restrict__ t
 
   double best = -1.0;
   int best_k = 1 << 30;
-  unsigned long long w1 = ex.c;
-  long long s1 = ex.s;
+  // (float64 running sums of integers below 2^53: exact, see otsu16_window_kernel)
+  double dw1 = (double)ex.c, ds1 = (double)ex.s;
+  const double dW = (double)total.c, dS = (double)total.s;
   for (int k4 = 0; k4 < 16; ++k4) {   // second sweep re-reads the 256 B from L2 (no spills)
     const uint4 q = p[k4];
     const uint32_t c[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int b = b0 + 4 * k4 + j;
-      w1 += c[j];
-      s1 += (long long)c[j] * (long long)(b - bias);
       // an empty bin leaves both classes as they were: its variance equals the previous non-empty bin's (>= lo, evaluated) and
       // can never be strictly greater -- skipped, with its two float64 divisions
-      if (c[j] != 0u && b >= lo && b < hi) {
-        const double dw1 = (double)w1, dw2 = (double)(total.c - w1);
-        const double m1 = (double)s1 / dw1;
-        const double m2 = (double)(total.s - s1) / dw2;
-        const double d = m1 - m2;
-        const double var = (dw1 * dw2) * (d * d);
-        if (var > best) { best = var; best_k = b; }
+      if (c[j] != 0u) {
+        dw1 += (double)c[j];
+        ds1 = fma((double)c[j], (double)(b - bias), ds1);
+        if (b >= lo && b < hi) {
+          const double dw2 = dW - dw1;
+          const double m1 = ds1 / dw1;
+          const double m2 = (dS - ds1) / dw2;
+          const double d = m1 - m2;
+          const double var = (dw1 * dw2) * (d * d);
+          if (var > best) { best = var; best_k = b; }
+        }
       }
     }
   }
@@ -491,7 +494,13 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
 
   // ---- Otsu on the window: lane t owns window bins [t*per, t*per + per); same integer prefix sums, float64 expression
   // and first-index arg-max as otsu_kernel
+  // an ODD number of bins per lane: lane t's j-th bin sits in bank (per * t + j) mod 32, and with the even 38 of a full window
+  // the 64 lanes of a read met in 16 banks (four-way conflicts on each of the 2 x 38 reads); 39 spreads them over all 32
+#ifdef PL_OTSU_EVEN_PER
   const int per = (range + kHistThreads - 1) / kHistThreads;
+#else
+  const int per = ((range + kHistThreads - 1) / kHistThreads) | 1;
+#endif
   const int b0 = threadIdx.x * per;
   const int b1 = b0 + per < range ? b0 + per : range;
   Pair mine = {0, 0};
@@ -511,19 +520,24 @@ otsu16_window_kernel(const unsigned short* __restrict__ in, int64_t count, int h
 
   double best = -1.0;
   int best_k = 1 << 30;
-  unsigned long long w1 = ex.c;
-  long long s1 = ex.s;
+  // the running class sums as float64: every value is an integer below 2^53 (a frame's pixel count and its sum of 16-bit
+  // keys), so `dw1 += c` and the fused `c * key + ds1` are EXACT and equal (double)w1 / (double)s1 of the integer prefix
+  // sums bit for bit -- without the 64-bit multiply-add and the four 64-bit integer -> float64 conversions per bin
+  double dw1 = (double)ex.c, ds1 = (double)ex.s;
+  const double dW = (double)total.c, dS = (double)total.s;
   for (int b = b0; b < b1; ++b) {
     const unsigned c = bins[b];
-    w1 += c;
-    s1 += (long long)c * (long long)(b + klo - bias);
-    if (c != 0u && b >= lo && b < hi) {           // empty bins: see otsu_kernel
-      const double dw1 = (double)w1, dw2 = (double)(total.c - w1);
-      const double m1 = (double)s1 / dw1;
-      const double m2 = (double)(total.s - s1) / dw2;
-      const double d = m1 - m2;
-      const double var = (dw1 * dw2) * (d * d);
-      if (var > best) { best = var; best_k = b; }
+    if (c != 0u) {                                // (an empty bin changes nothing)
+      dw1 += (double)c;
+      ds1 = fma((double)c, (double)(b + klo - bias), ds1);
+      if (b >= lo && b < hi) {                    // empty bins: see otsu_kernel
+        const double dw2 = dW - dw1;
+        const double m1 = ds1 / dw1;
+        const double m2 = (dS - ds1) / dw2;
+        const double d = m1 - m2;
+        const double var = (dw1 * dw2) * (d * d);
+        if (var > best) { best = var; best_k = b; }
+      }
     }
   }
 #pragma unroll
@@ -733,21 +747,25 @@ otsu16_full_kernel(const unsigned short* __restrict__ in, int64_t count, int h, 
   }
   double best = -1.0;
   int best_k = 1 << 30;
-  unsigned long long w1 = ex.c + wrapped.c;                  // the prefix in front of field `lane`, where the walk starts
-  long long s1 = ex.s + wrapped.s;
+  // (float64 running sums of integers below 2^53: exact, see otsu16_window_kernel)
+  double dw1 = (double)(ex.c + wrapped.c);                   // the prefix in front of field `lane`, where the walk starts
+  double ds1 = (double)(ex.s + wrapped.s);
+  const double dW = (double)total.c, dS = (double)total.s;
   for (int j = 0; j < 64; ++j) {
-    if (j + lane == 64) { w1 = ex.c; s1 = ex.s; }            // wrapped to the lane's first field
+    if (j + lane == 64) { dw1 = (double)ex.c; ds1 = (double)ex.s; }   // wrapped to the lane's first field
     const int b = b0 + ((j + lane) & 63);
     const unsigned c = count_of(b);
-    w1 += c;
-    s1 += (long long)c * (long long)(b - bias);
-    if (c != 0u && b >= lo && b < hi) {           // empty bins: see otsu_kernel
-      const double dw1 = (double)w1, dw2 = (double)(total.c - w1);
-      const double m1 = (double)s1 / dw1;
-      const double m2 = (double)(total.s - s1) / dw2;
-      const double d = m1 - m2;
-      const double var = (dw1 * dw2) * (d * d);
-      if (var > best || (var == best && b < best_k)) { best = var; best_k = b; }   // first index of the maximum
+    if (c != 0u) {
+      dw1 += (double)c;
+      ds1 = fma((double)c, (double)(b - bias), ds1);
+      if (b >= lo && b < hi) {                    // empty bins: see otsu_kernel
+        const double dw2 = dW - dw1;
+        const double m1 = ds1 / dw1;
+        const double m2 = (dS - ds1) / dw2;
+        const double d = m1 - m2;
+        const double var = (dw1 * dw2) * (d * d);
+        if (var > best || (var == best && b < best_k)) { best = var; best_k = b; }   // first index of the maximum
+      }
     }
   }
 #pragma unroll
