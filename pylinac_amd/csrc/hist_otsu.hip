@@ -822,18 +822,25 @@ order_stats_kernel(const uint32_t* __restrict__ hist, int bias, const int64_t* _
 // dark noise of a real detector puts half of the background on one value, 30-way same-address serialisation per atomic
 // instruction (the noisy Winston-Lutz frames: 0.90 ms per 256 frames with hist16_kernel<2> against 0.47 without noise).
 // The guess is replaced by the first lane's pixel whenever it attracted less than 1/16 of the last 64 pixels per lane.
-constexpr int kTwBins = 19456;                               // bins per window
+// Two instantiations.  19 456 bins per window (152 KiB: one workgroup per CU) for frames nobody knows anything about: two
+// windows then cover 59 % of the 16-bit range.  9 728 (76 KiB: TWO workgroups per CU, one's prologue / epilogue and atomic
+// stalls under the other's loads) for pl_hist16_wl, whose frames are Winston-Lutz images -- a flat background, a flat field
+// and a few thousand penumbra pixels: r06x2, 1 250 frames: with dark-current noise 2.14 -> 1.83 ms per pass, noise-free
+// unchanged (1.51); at 256 frames, one workgroup per CU either way, the small windows are 4 % slower: taken only for batches
+// of more frames than the chip has CUs.
+constexpr int kTwBinsWide = 19456, kTwBinsWl = 9728;
 struct TwScratch { int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64]; };
-constexpr int kTwScratchAt = (2 * kTwBins + 1 + PL_WAVE + 3) / 4 * 16;   // two windows, the spare bin, one dummy bin per lane
-constexpr size_t kTwLds = kTwScratchAt + sizeof(TwScratch);
+constexpr int tw_scratch_at(int bins) { return (2 * bins + 1 + PL_WAVE + 3) / 4 * 16; }   // two windows, the spare bin, one dummy bin per lane
+constexpr size_t tw_lds(int bins) { return tw_scratch_at(bins) + sizeof(TwScratch); }
 
-__global__ void __launch_bounds__(kHistThreads)
+template <int kTwBins, int WAVES_PER_EU>
+__global__ void __launch_bounds__(kHistThreads, WAVES_PER_EU)
 hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, unsigned flip, uint32_t* __restrict__ hist,
                          unsigned short* __restrict__ tile_max /* optional [n][ceil(count / 512)] */, int eh, int ew, int ews,
                          int32_t* __restrict__ edge_min, int32_t* __restrict__ edge_max /* optional: pl_hist16_wl */,
                          const int64_t* __restrict__ ranks, int nranks, int32_t* __restrict__ stats /* optional: pl_hist16_wl */) {
   extern __shared__ __attribute__((aligned(16))) unsigned bins[];  // 2 * kTwBins, then TwScratch
-  TwScratch& scr = *reinterpret_cast<TwScratch*>(reinterpret_cast<unsigned char*>(bins) + kTwScratchAt);
+  TwScratch& scr = *reinterpret_cast<TwScratch*>(reinterpret_cast<unsigned char*>(bins) + tw_scratch_at(kTwBins));
   const int64_t frame = blockIdx.x;
   const unsigned short* src = in + frame * count;
   uint32_t* row = hist + frame * 65536;
@@ -1195,14 +1202,22 @@ static int hist16_impl(const void* in, int dtype, int64_t n, int64_t count, uint
   // pixels in between); smaller frames, or no 152 KiB of LDS: the multi-part kernels
   static std::atomic<int> two_window{0};             // 0 untried, 1 available, -1 refused
   if (two_window == 0) {
-    const bool ok = hipFuncSetAttribute((const void*)hist16_two_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kTwLds) == hipSuccess;
+    bool ok = hipFuncSetAttribute((const void*)hist16_two_window_kernel<kTwBinsWide, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)tw_lds(kTwBinsWide)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)hist16_two_window_kernel<kTwBinsWl, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)tw_lds(kTwBinsWl)) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     two_window = ok ? 1 : -1;
   }
   if (two_window == 1 && count >= 262144) {
-    hipLaunchKernelGGL(hist16_two_window_kernel, dim3((unsigned)n), dim3(kHistThreads), kTwLds, st, src, count, flip, d_hist,
-                       d_tile_max, edges.h, edges.w, edges.window, edges.d_min, edges.d_max, edges.d_ranks, edges.nranks, edges.d_stats);
+    if (edges.d_stats && n > pl_cu_count())            // pl_hist16_wl: Winston-Lutz frames, and more of them than CUs
+      hipLaunchKernelGGL((hist16_two_window_kernel<kTwBinsWl, 8>), dim3((unsigned)n), dim3(kHistThreads), tw_lds(kTwBinsWl), st, src,
+                         count, flip, d_hist, d_tile_max, edges.h, edges.w, edges.window, edges.d_min, edges.d_max, edges.d_ranks,
+                         edges.nranks, edges.d_stats);
+    else
+      hipLaunchKernelGGL((hist16_two_window_kernel<kTwBinsWide, 4>), dim3((unsigned)n), dim3(kHistThreads), tw_lds(kTwBinsWide), st,
+                         src, count, flip, d_hist, d_tile_max, edges.h, edges.w, edges.window, edges.d_min, edges.d_max,
+                         edges.d_ranks, edges.nranks, edges.d_stats);
     return pl_check_launch("pl_hist16");
   }
   // (the multi-part kernels know nothing of edges: the stand-alone kernel)

@@ -15,6 +15,7 @@
 // lock-step without a barrier or wave intrinsic.  Floating point is IEEE double / float on both sides (g++ builds
 // with -ffp-contract=off like hipcc does for this library); libm functions may differ from ROCm's in the last ulp.
 #pragma once
+#include <cstdlib>
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -113,7 +114,11 @@ inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { a->s
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
-inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {   // HIPEMU_CU_COUNT: a smaller chip (launch policies that ask for it)
+  const char* e = getenv("HIPEMU_CU_COUNT");
+  *v = e && atoi(e) > 0 ? atoi(e) : 256;
+  return hipSuccess;
+}
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 
 // ---- barriers and wave intrinsics ------------------------------------------------------------------------

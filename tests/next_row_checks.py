@@ -1899,6 +1899,46 @@ def check_histogram16_one_read(dev, sizes=((512, 512), (513, 520), (600, 437), (
     return n_checked
 
 
+def check_hist16_wl_many_frames(dev, n=260, h=512, w=512):
+    """pl_hist16_wl on MORE frames than the chip has CUs (the launcher then takes the two-workgroups-per-CU instantiation with
+    9 728-bin windows) against the kernels that do the same work apart: pl_hist16 (19 456-bin windows), pl_order_stats,
+    pl_edge_minmax, and the true tile maxima -- Winston-Lutz-like frames (flat background, field, penumbra, clipped noise),
+    frames with every value of the range (most pixels BETWEEN the small windows: the global-atomic path), int16."""
+    import torch
+    from scipy import ndimage
+
+    from pylinac_amd import ops
+
+    rng = np.random.default_rng(83)
+    yy, xx = np.mgrid[:h, :w]
+    field = ndimage.gaussian_filter(((abs(yy - h / 2) < h / 6) & (abs(xx - w / 2) < w / 6)).astype(np.float64), 4)
+    kinds = [np.clip(field * 52000 + 3000, 0, 65535),                                      # noise-free
+             np.clip(field * 52000 + rng.normal(0, 65, (h, w)), 0, 65535),                  # clipped dark noise
+             rng.integers(0, 65536, (h, w)).astype(np.float64),                             # everything everywhere
+             np.clip(30000 + rng.normal(0, 4000, (h, w)), 0, 65535)]                        # one broad mode
+    base = np.stack(kinds).astype(np.uint16)
+    arr = np.empty((n, h, w), dtype=np.uint16)
+    for i in range(n):
+        arr[i] = np.roll(base[i % 4], (i, 3 * i), axis=(0, 1))
+    arr[1, 0, 0], arr[1, -1, -1] = 0, 65535
+    cnt = h * w
+    ranks = np.array([0, cnt - 1, cnt // 2, int(0.999 * cnt), 12345, 7 * cnt // 10, int(0.05 * cnt), 1, cnt - 2, int(0.3 * cnt),
+                      int(0.5001 * cnt), int(0.9 * cnt)], dtype=np.int64)
+    for a in (arr, (arr.astype(np.int32) - 32768).astype(np.int16)):
+        x = torch.from_numpy(a).to(dev)
+        _, tmax, emin, emax, st = ops.histogram16(x, tiles=True, edge_window=2, ranks=ranks)   # (the table is scratch in this form)
+        assert torch.equal(st, ops.order_stats(x, ranks, hist=ops.histogram16(x))), "order statistics"
+        srt = np.sort(a[:8].reshape(8, -1).astype(np.int64), axis=1) if n >= 8 else np.sort(a.reshape(n, -1).astype(np.int64), axis=1)
+        assert np.array_equal(st[:len(srt)].cpu().numpy(), srt[:, ranks]), "order statistics vs numpy"
+        e0, e1 = ops.edge_minmax(x, 2)
+        assert torch.equal(emin, e0) and torch.equal(emax, e1), "edge strips"
+        keys = a.astype(np.int64) + (32768 if a.dtype == np.int16 else 0)
+        true_max = keys.reshape(n, -1, 512).max(axis=2)
+        got = tmax.cpu().numpy().astype(np.int64) & 0xFFFF
+        assert ((got == true_max) | (got == 0xFFFF)).all() and (got == true_max).mean() > 0.99
+    return 2 * n
+
+
 def check_fused_tail_vs_separate(dev, shapes=((3, 200, 520), (2, 128, 64), (2, 130, 1032), (1, 2, 8))):
     """pl_median3_threshold_colparts_u16 + pl_colparts_profile_fwxm (the EPID pipeline's third stage and its one-launch tail)
     == pl_median3_threshold_colsum_u16 -> pl_colsum_to_mean -> pl_find_peaks -> pl_fwxm_record, bit for bit, on heights that

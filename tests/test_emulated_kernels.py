@@ -572,6 +572,22 @@ def test_emulated_starshot(golden, emulated):
     assert n == 2
 
 
+def test_emulated_hist16_wl_small_windows():
+    """The 9 728-bin instantiation of pl_hist16_wl on the emulated device: a process of its own whose emulated chip has two CUs
+    (HIPEMU_CU_COUNT), so that three frames are "more frames than CUs"."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from emu_backend import emulated_device\nimport next_row_checks as checks\n"
+            "with emulated_device():\n    print('checked', checks.check_hist16_wl_many_frames(torch.device('cuda:0'), n=3))\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, HIPEMU_CU_COUNT="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "checked 6" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_emulated_circle_profile_ring(emulated):
     """pl_circle_profile_ring (LDS-staged annulus) == pl_circle_profile_combined_ex, samples and margins, on the emulated device."""
     import next_row_checks as checks

@@ -1692,6 +1692,15 @@ def test_starshot_vs_reference_golden(golden, dev):
 
 
 @pytest.mark.gpu
+def test_hist16_wl_more_frames_than_cus(dev):
+    """pl_hist16_wl's two-workgroups-per-CU instantiation (9 728-bin windows; taken for batches of more frames than CUs) against
+    pl_hist16 / pl_order_stats / pl_edge_minmax and np.bincount: 260 frames 512 x 512, uint16 and int16."""
+    import next_row_checks as checks
+
+    assert checks.check_hist16_wl_many_frames(dev) == 520
+
+
+@pytest.mark.gpu
 def test_circle_profile_ring_vs_gathers(dev):
     """pl_circle_profile_ring == pl_circle_profile_combined_ex bit for bit (samples, margins): borders, outside / NaN centres, four
     dtypes, k = 0 .. 3, honest / too narrow / too wide promises about the radii."""
