@@ -829,6 +829,14 @@ order_stats_kernel(const uint32_t* __restrict__ hist, int bias, const int64_t* _
 // unchanged (1.51); at 256 frames, one workgroup per CU either way, the small windows are 4 % slower: taken only for batches
 // of more frames than the chip has CUs.
 constexpr int kTwBinsWide = 19456, kTwBinsWl = 9728;
+#ifndef PL_TW_TIMING
+#define PL_TW_TIMING 0   // 1: thread 0 leaves wall_clock64() stamps of the phases in bins 65520.. of the frame's table (timing builds only)
+#endif
+#if PL_TW_TIMING
+#define TW_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) tw_stamp[k] = wall_clock64(); } while (0)
+#else
+#define TW_STAMP(k) do { } while (0)
+#endif
 struct TwScratch { int s_lo[kHistThreads / 64], s_hi[kHistThreads / 64]; };
 constexpr int tw_scratch_at(int bins) { return (2 * bins + 1 + PL_WAVE + 3) / 4 * 16; }   // two windows, the spare bin, one dummy bin per lane
 constexpr size_t tw_lds(int bins) { return tw_scratch_at(bins) + sizeof(TwScratch); }
@@ -849,6 +857,10 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   const int64_t nvec = vec ? count / 8 : 0;
   const uint4* vsrc = reinterpret_cast<const uint4*>(src);
 
+#if PL_TW_TIMING
+  unsigned long long tw_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  TW_STAMP(0);
   for (int i = threadIdx.x; i < 2 * kTwBins; i += kHistThreads) bins[i] = 0;
   if (edge_min) {
     // min / max over the four `ews`-wide edge strips of the eh x ew frame (WLBaseImage._clean_edges' edge test,
@@ -894,6 +906,7 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
     }
     __syncthreads();                                                  // (the scratch is used again for the sample's extrema)
   }
+  TW_STAMP(1);
   // tile maxima (pl_hist16_tiles): tile t = pixels [512 t, 512 t + 512) = the 64 vectors ONE wave load of the main loop
   // fetches; its largest key (biased domain) lets a later pass skip every tile that cannot hold a pixel above its
   // threshold (pl_field_cax_tiles).  Tiles the main loop does not cover keep 0xffff ("look inside").
@@ -927,6 +940,7 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   __syncthreads();
   for (int k = 0; k < kHistThreads / 64; ++k) { mn = scr.s_lo[k] < mn ? scr.s_lo[k] : mn; mx = scr.s_hi[k] > mx ? scr.s_hi[k] : mx; }
   if (mx < mn) { mn = 0; mx = 0; }
+  TW_STAMP(2);
   // window bases (biased key domain): contiguous [w0, w0 + 2 W) around a narrow range, else one window at each end
   int w0, w1;
   if (mx - mn + 1 <= 2 * kTwBins) {
@@ -948,6 +962,7 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
     if (!inside) reinterpret_cast<uint4*>(row)[i] = uint4{0u, 0u, 0u, 0u};
   }
   __syncthreads();                                   // the zeroed table is in place before any global atomic
+  TW_STAMP(3);
 
   unsigned hot = 0;                                  // this lane's pixels that equalled the wave's guess since the last flush
   unsigned guess = 0xffffffffu;                      // wave-uniform key (biased domain), none yet
@@ -1045,6 +1060,7 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
   for (int64_t i = nvec * 8 + threadIdx.x; i < count; i += kHistThreads) tally1(src[i]);
   flush();
   __syncthreads();
+  TW_STAMP(4);
   if (ranks) {
     // pl_hist16_wl: the order statistics are taken HERE, from the windows while they are still in LDS (order_stats_kernel's
     // selection: thread t owns bins [64 t, 64 t + 64), exclusive scan of the counts, the bin where the running count passes
@@ -1098,9 +1114,11 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
         for (int k = 0; k < 32; ++k) both += val[k];
       }
     }
+    TW_STAMP(5);
     Pair mine = {both, 0};
     Pair total;
     const Pair ex = block_exclusive_scan(mine, &total, wave_tot);
+    TW_STAMP(6);
     const int bias = (int)flip;                                       // 0x8000 for int16 keys
     auto clamped = [&](int q) {
       long long r = ranks[q];
@@ -1141,6 +1159,11 @@ hist16_two_window_kernel(const unsigned short* __restrict__ in, int64_t count, u
         before += here;
       }
     }
+#if PL_TW_TIMING
+    TW_STAMP(7);
+    if (threadIdx.x == 0)
+      for (int k = 0; k < 8; ++k) row[65520 + k] = (uint32_t)(tw_stamp[k] - tw_stamp[0]);   // 10 ns units (100 MHz)
+#endif
     return;
   }
   // the windows go out with plain stores: no global atomic ever touched a bin inside a window
