@@ -29,6 +29,9 @@
 #include "pl_common.h"
 #include "edge_exact.h"
 
+#ifndef PL_E32_AHEAD
+#define PL_E32_AHEAD 4      // rows a wave has in flight ahead of the one it works on
+#endif
 #ifndef PL_E32_WANT_FACTOR
 #define PL_E32_WANT_FACTOR 4
 #endif
@@ -138,8 +141,14 @@ edge_stream32_kernel(const T* __restrict__ in, int h, int w, int strips, int seg
   f2 ra = unpack(ldo((unsigned)max(fr - 1, 0) * (unsigned)w)), rb = unpack(ldo((unsigned)fr * (unsigned)w));
   unsigned noff = min((unsigned)(fr + 1) * (unsigned)w, last_row);
   f2 rc = unpack(ldo(noff));
-  noff = min(noff + (unsigned)w, last_row);
-  unsigned pending = ldo(noff);
+  // PL_E32_AHEAD rows in flight per wave: with ONE (rounds up to r06z) a CU's 32 waves had 8 KB on their way, and the
+  // kernel's reads ran at what that buys against a microsecond and a half of latency (4.4 GB/s per CU: its 1.15 ms)
+  unsigned pend[PL_E32_AHEAD];
+#pragma unroll
+  for (int j = 0; j < PL_E32_AHEAD; ++j) {
+    noff = min(noff + (unsigned)w, last_row);
+    pend[j] = ldo(noff);
+  }
   f2 e0 = edge_row(ra, rb, rc);
   f2 E[WIN];
 #pragma unroll
@@ -178,9 +187,11 @@ edge_stream32_kernel(const T* __restrict__ in, int h, int w, int strips, int seg
 #pragma unroll
     for (int i = 0; i < WIN; ++i) {
       const int vr = base + i;
-      ra = rb; rb = rc; rc = unpack(pending);
+      ra = rb; rb = rc; rc = unpack(pend[0]);
+#pragma unroll
+      for (int j = 0; j + 1 < PL_E32_AHEAD; ++j) pend[j] = pend[j + 1];
       noff = min(noff + (unsigned)w, last_row);
-      pending = ldo(noff);                                 // in flight for a whole step
+      pend[PL_E32_AHEAD - 1] = ldo(noff);                  // in flight for PL_E32_AHEAD steps
       const f2 en = edge_row(ra, rb, rc);
       E[i] = en;
       if (__builtin_expect(vr > hm1, 0)) {                 // rows below the frame repeat the last edge row (wave-uniform)
