@@ -80,3 +80,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('frames', $f, 'ms
 # round 6 additions: config #5's SQ counters + HBM traffic on the final build
 timeout 500 bash scripts/pmc_kernels.sh ct mask_regions_kernel,edge_otsu_kernel,edge_stream32_kernel,circle_profile_combined,circle_ring_kernel -- python scripts/run_ct_pass.py 25 2 > /dev/null 2>&1
 cp gpurun_out/pmc_ct/summary.txt $OUT/pmc_sq_ct_kernels.txt
+# gpurun copies back at most 64 MiB: the raw profiler trees are scratch once their summaries sit in $OUT (r06zw: a timed-out PMC
+# pass left its traces behind and NOTHING came back)
+for d in gpurun_out/*/; do [ "$d" = "gpurun_out/$TAG/" ] || rm -rf "$d"; done
+du -sh gpurun_out | tee -a $OUT/summary.txt
